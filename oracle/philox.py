@@ -1,0 +1,96 @@
+"""TEST INFRASTRUCTURE ONLY (oracle/): CPU restatement of the dropout RNG.
+
+The reference draws dropout masks from TensorFlow's stateful RNG
+(`tf.nn.dropout`, e.g. /root/reference/models/modules.py:15,27,69 and the
+sites listed in SURVEY.md §8 a21).  TF's generator cannot be reproduced (TF is
+not installed, version unpinned), so the build defines its own counter-based
+generator - Philox4x32-10 (Salmon et al., SC'11) - and uses it on both sides:
+the HIP kernels (hual_amd/csrc/philox.h) and this numpy restatement.  With the
+same (seed, offset) the oracle and the kernels drop exactly the same elements,
+which makes parity tests with drop_rate > 0 exact instead of statistical.
+
+Counter layout (must match hual_amd/csrc/philox.h):
+    c0 = col >> 2      c1 = row      c2 = site id      c3 = offset (step)
+    key = (seed & 0xffffffff, seed >> 32)
+The four 32-bit outputs belong to columns 4*c0 + {0,1,2,3}.
+An element is KEPT iff  out < thresh,  thresh = floor((1 - rate) * 2**32)
+(clamped to 2**32-1) and kept elements are scaled by float32(1)/(float32(1)-float32(rate)).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import numpy as np
+
+PHILOX_M0 = np.uint64(0xD2511F53)
+PHILOX_M1 = np.uint64(0xCD9E8D57)
+PHILOX_W0 = 0x9E3779B9
+PHILOX_W1 = 0xBB67AE85
+MASK32 = np.uint64(0xFFFFFFFF)
+
+# ---- dropout call-site ids (mirrors include/hual_seqpan.h HUAL_SITE_*) -------------
+SITE_WORD = 0        # modules.py:15   word_emb        rows = b*L+l,        cols = word_dim
+SITE_CHAR = 1        # modules.py:27   char_emb        rows = (b*L+l)*C+c,  cols = char_dim
+SITE_VIDEO = 2       # model.py:47     video_inputs    rows = b*T+t,        cols = vdim
+SITE_CONV = 3        # +layer (0..3)   modules.py:69   shared conv_block, unified rows
+SITE_DA = 8          # +8*li + {0 self probs, 1 cross probs, 2 dense_1 out, 3 LN2 out, 4 dense_2 out}
+SITE_TRI = 24        # +{0 q2v.x1(v rows), 1 q2v.x2(q rows), 2 v2q.x1(q rows), 3 v2q.x2(v rows)}  ops.py:104
+SITE_FE = 32         # +16*pass + {0..3 conv layer, 4 LN1 out, 5 attn probs, 6 attn out, 7 LN2 out, 8 dense out}
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10.  All inputs broadcastable uint32-valued arrays."""
+    c0 = np.asarray(c0, dtype=np.uint64) & MASK32
+    c1 = np.asarray(c1, dtype=np.uint64) & MASK32
+    c2 = np.asarray(c2, dtype=np.uint64) & MASK32
+    c3 = np.asarray(c3, dtype=np.uint64) & MASK32
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = PHILOX_M0 * c0
+        p1 = PHILOX_M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK32
+        n0 = hi1 ^ c1 ^ np.uint64(k0)
+        n2 = hi0 ^ c3 ^ np.uint64(k1)
+        c0, c1, c2, c3 = n0, lo1, n2, lo0
+        k0 = (k0 + PHILOX_W0) & 0xFFFFFFFF
+        k1 = (k1 + PHILOX_W1) & 0xFFFFFFFF
+    return (c0.astype(np.uint32), c1.astype(np.uint32), c2.astype(np.uint32), c3.astype(np.uint32))
+
+
+def keep_threshold(rate):
+    """uint32 threshold: keep iff rnd < thresh.  Same double arithmetic as the C++ host code."""
+    r = float(np.float32(rate))
+    t = int(np.floor((1.0 - r) * 4294967296.0))
+    return max(0, min(t, 0xFFFFFFFF))
+
+
+def keep_scale(rate):
+    return np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
+
+
+class DropoutRNG:
+    """mask(site, rows, ncols) -> float32 array [len(rows), ncols] of {0, scale}."""
+
+    def __init__(self, seed, offset, rate):
+        self.seed = int(seed)
+        self.offset = int(offset)
+        self.rate = float(rate)
+        self.k0 = self.seed & 0xFFFFFFFF
+        self.k1 = (self.seed >> 32) & 0xFFFFFFFF
+        self.thresh = keep_threshold(rate)
+        self.scale = keep_scale(rate)
+
+    def bits(self, site, rows, ncols):
+        rows = np.asarray(rows, dtype=np.uint64).reshape(-1, 1)
+        nblk = (ncols + 3) // 4
+        c0 = np.arange(nblk, dtype=np.uint64).reshape(1, -1)
+        o = philox4x32_10(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
+        out = np.stack(o, axis=-1).reshape(rows.shape[0], nblk * 4)
+        return out[:, :ncols]
+
+    def mask(self, site, rows, ncols):
+        if self.rate == 0.0:
+            return np.ones((len(np.atleast_1d(rows)), ncols), dtype=np.float32)
+        b = self.bits(site, rows, ncols)
+        return np.where(b < np.uint32(self.thresh), self.scale, np.float32(0.0)).astype(np.float32)
