@@ -1,0 +1,63 @@
+"""Builds hual_amd/libhual_seqpan.so (HIP kernels + C ABI) in-tree with hipcc for gfx950."""
+import glob
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libhual_seqpan.so')
+OBJ = os.path.join(HERE, 'csrc', 'build')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
+
+
+def _stamp(src):
+    h = hashlib.sha1()
+    for f in [src] + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, '..', 'include', 'hual_seqpan.h')]:
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(verbose=False, force=False):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    os.makedirs(OBJ, exist_ok=True)
+    objs, rebuilt, procs = [], False, []
+    for src in _sources():
+        base = os.path.basename(src)
+        obj = os.path.join(OBJ, base + '.o')
+        stamp_file = obj + '.stamp'
+        stamp = _stamp(src)
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+            continue
+        cmd = [hipcc] + FLAGS + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), stamp_file, stamp, base))
+        rebuilt = True
+    for pr, stamp_file, stamp, base in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError('hipcc failed on %s' % base)
+        if verbose and out:
+            print(out.decode())
+        with open(stamp_file, 'w') as fh:
+            fh.write(stamp)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(verbose=True, force='--force' in sys.argv))

@@ -1,0 +1,34 @@
+// Multi-head scaled-dot attention with the reference's additive outer-product mask, softmax and dropout on the
+// probabilities: /root/reference/models/layers.py:80-96 (self + cross attention of dual_multihead_attention) and
+// /root/reference/models/modules.py:104-119 (top_self_attention).  Heads stay merged: head h = columns [16h,16h+16).
+#pragma once
+#include "common.h"
+
+namespace hual {
+
+// One attention problem = B clips; queries of clip b are rows qrow0 + b*Tq + [0,Tq) of Q/dO/O,
+// keys/values are rows krow0 + b*Tk + [0,Tk) of K/V.  Masks are indexed by the same absolute rows.
+struct AttnJob {
+  const float* Q; int ldq;
+  const float* K; const float* V; int ldkv;
+  float* O; int ldo;                       // forward output, merged heads [rows,128]
+  int B, Tq, Tk, qrow0, krow0;
+  const float* qmask; const float* kmask;  // [rows] floats
+  int drop_site; uint32_t drop_row0;       // Philox row = (drop_row0 + qrow) * 8 + head ; col = key index
+  // backward
+  const float* dO; int lddo;
+  float* dQ; int lddq;                     // written (not accumulated)
+  float* dK; float* dV; int lddkv;         // written (not accumulated)
+};
+
+#define HUAL_MAX_ATTN_JOBS 4
+struct AttnBatch {
+  AttnJob j[HUAL_MAX_ATTN_JOBS];
+};
+
+void attn_job_init(AttnJob& j);
+int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t s);
+// dQ, dK, dV.  `stats` = scratch of n * 3 * stat_n floats (stat_n >= max_j B*Tq*8): row max, 1/rowsum, delta
+int launch_attn_bwd_impl(const AttnJob* jobs, int n, const DropCfg& drop, float* stats, int stat_n, hipStream_t s);
+
+}  // namespace hual

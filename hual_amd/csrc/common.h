@@ -1,0 +1,88 @@
+// Shared device/host helpers for the SeqPAN HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/hual_seqpan.h"
+
+#define HUAL_D 128          // hidden size the kernels are specialised for (configs/*/SeqPAN.yaml model.dim)
+#define HUAL_H 8            // heads
+#define HUAL_DH 16          // head size
+#define HUAL_MASK_VALUE (-1e30f)   // models/ops.py:89
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace hual {
+
+// ---- error plumbing: no exception crosses the C ABI; message via hual_last_error() -------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define HUAL_CHECK_HIP(expr)                                                                   \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) return ::hual::fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+#define HUAL_REQUIRE(cond, msg)                                                                \
+  do {                                                                                         \
+    if (!(cond)) return ::hual::fail(-1, std::string("invalid argument: ") + (msg));           \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- dropout parameters shared by every kernel (derived from drop_rate on the host) -----------
+// The Philox key/offset live in DEVICE memory (state[0]=seed lo, [1]=seed hi, [2]=offset) so that a captured
+// hipGraph can be replayed with a fresh offset every step without re-capturing.
+struct DropCfg {
+  const uint32_t* state;  // device: {k0, k1, offset}
+  uint32_t thresh;        // keep iff rnd < thresh
+  float scale;            // 1/(1-rate)
+  int enabled;            // rate > 0
+};
+
+DropCfg make_dropcfg(const uint32_t* state, float rate);
+
+}  // namespace hual
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+__device__ __forceinline__ float wave_sum16(float v) {   // sum across the 16 lanes sharing lane>>4
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ float half_sum32(float v) {   // sum across the 32 lanes sharing lane>>5
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  return v;
+}
+__device__ __forceinline__ float half_max32(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1));
+  v = fmaxf(v, __shfl_xor(v, 2));
+  v = fmaxf(v, __shfl_xor(v, 4));
+  v = fmaxf(v, __shfl_xor(v, 8));
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+  v = half_sum32(v);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ float wave_max64(float v) {
+  v = half_max32(v);
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}

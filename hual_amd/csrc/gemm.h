@@ -1,0 +1,85 @@
+// Job-table GEMM family on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32 / 32x32x2_f32).
+// Every dense contraction of the SeqPAN graph - the 46 conv1d(kernel_size=1) weight sets of
+// /root/reference/models/layers.py:20-29 and their gradients - goes through these two kernels.
+#pragma once
+#include "common.h"
+
+namespace hual {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_SIGMOID_ROWMASK = 3 };
+enum MulMode { MUL_NONE = 0, MUL_TENSOR = 1, MUL_DRELU = 2, MUL_DSIGMOID = 3 };
+enum Comb { COMB_NONE = 0, COMB_GATE_VAL = 1, COMB_CROSSGATE = 2 };
+
+#define HUAL_MAX_PIECES 4
+#define HUAL_MAX_JOBS 6
+
+// Y[M,N] = epilogue( sum_p prologue(A[p])[M,kw[p]] . W[p] )   (N multiple of 64, kw multiple of 16)
+struct GemmJob {
+  // ---- A operand: up to 4 column pieces (concatenation along K), optional elementwise multiplier
+  const float* A[HUAL_MAX_PIECES];
+  const float* A2[HUAL_MAX_PIECES];
+  int lda[HUAL_MAX_PIECES];
+  int lda2[HUAL_MAX_PIECES];
+  int kw[HUAL_MAX_PIECES];
+  int npieces;
+  int a_drop_site;            // >=0: A = dropout(A) (tf.nn.dropout on the GEMM input, model.py:47)
+  uint32_t a_drop_row0;
+  // ---- B operand: one weight block per piece. transW=0: W[p][k][n] (ldw); transW=1: W[p][n][k] (used for dX)
+  const float* W[HUAL_MAX_PIECES];
+  int ldw;
+  int transW;
+  const float* bias;          // [N] or null
+  int M, N;
+  // ---- epilogue pipeline: +bias -> act -> save -> mul -> dropout -> +add -> *rowmask -> Y
+  int act;
+  const float* rowmask;       // [M] floats (0/1)
+  float* save; int ldsave;
+  int mulmode; const float* mul; int ldmul;
+  int drop_site; uint32_t drop_row0;
+  const float* add; int ldadd; int add_div;
+  int mask_out;
+  float* Y; int ldy;
+  // ---- dual mode (second accumulator): A_b pieces (null => same as A), W2/bias2, combine
+  const float* Ab[HUAL_MAX_PIECES];
+  int ldab[HUAL_MAX_PIECES];
+  const float* W2[HUAL_MAX_PIECES];
+  const float* bias2;
+  int comb;
+  float* save2; int ldsave2;
+  const float* aux1; const float* aux2; int ldaux;   // COMB_CROSSGATE: Y = sig1*aux1 + sig2*aux2
+};
+
+struct GemmBatch {
+  GemmJob j[HUAL_MAX_JOBS];
+};
+
+// dW[p][k][n] += sum_m prologue(A[p])[m][k] * dY[m][n] ;  db[n] += sum_m dY[m][n]     (N multiple of 64)
+struct DwJob {
+  const float* A[HUAL_MAX_PIECES];
+  const float* A2[HUAL_MAX_PIECES];
+  int lda[HUAL_MAX_PIECES];
+  int lda2[HUAL_MAX_PIECES];
+  int kw[HUAL_MAX_PIECES];
+  int npieces;
+  int a_drop_site;
+  uint32_t a_drop_row0;
+  float* dW[HUAL_MAX_PIECES];
+  int ldw;
+  const float* dY; int ldy;
+  int M, N;
+  float* db;
+};
+
+#define HUAL_MAX_DW_JOBS 12
+struct DwBatch {
+  DwJob j[HUAL_MAX_DW_JOBS];
+};
+
+void gemm_job_init(GemmJob& j);
+void dw_job_init(DwJob& j);
+// enqueue `n` jobs (n <= HUAL_MAX_JOBS) as ONE launch on `stream`
+int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
+// enqueue `n` gradient jobs (any n; split into launches of HUAL_MAX_DW_JOBS); rows_per_wave tunes split-M
+int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_wave, hipStream_t stream);
+
+}  // namespace hual

@@ -1,0 +1,63 @@
+// train_op of /root/reference/models/ops.py:119-204: clip_by_global_norm(1.0) + AdamWeightDecayOptimizer
+// (beta .9/.999, eps 1e-6, NO bias correction, decoupled weight decay 0.01 on every variable whose name does not
+// contain LayerNorm|layer_norm|bias) as two launches over the flat parameter / gradient buffers.
+#include "optim.h"
+
+using namespace hual;
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, size_t n, float prescale, float* out) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  const size_t n4 = n >> 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = ld4(g + 4 * i);
+    v = make_float4(v.x * prescale, v.y * prescale, v.z * prescale, v.w * prescale);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  s = wave_sum64(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, const float* decay,
+                                                    size_t n, const float* lr_dev, float clip_norm, float prescale,
+                                                    const float* sqnorm, float b1, float b2, float eps) {
+  const float lr = lr_dev[0];
+  const float gn = sqrtf(sqnorm[0]);
+  const float sc = prescale * (clip_norm / fmaxf(gn, clip_norm));     // tf.clip_by_global_norm
+  const size_t n4 = n >> 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 gg = ld4(g + 4 * i), mm = ld4(m + 4 * i), vv = ld4(v + 4 * i), pp = ld4(p + 4 * i), dd = ld4(decay + 4 * i);
+    float* gp = &gg.x; float* mp = &mm.x; float* vp = &vv.x; float* ppp = &pp.x; const float* dp = &dd.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = gp[k] * sc;
+      const float nm = b1 * mp[k] + (1.0f - b1) * gr;
+      const float nv = b2 * vp[k] + (1.0f - b2) * gr * gr;
+      float upd = nm / (sqrtf(nv) + eps);          // ops.py:166-168
+      upd += dp[k] * ppp[k];                       // ops.py:169-170 (decay[k] = 0 for excluded variables)
+      ppp[k] = ppp[k] - lr * upd;
+      mp[k] = nm;
+      vp[k] = nv;
+    }
+    st4(p + 4 * i, pp);
+    st4(m + 4 * i, mm);
+    st4(v + 4 * i, vv);
+  }
+}
+
+namespace hual {
+
+int launch_adamw(const AdamArgs& a, hipStream_t s) {
+  HUAL_REQUIRE(a.p && a.g && a.m && a.v && a.decay && a.lr_dev && a.sqnorm, "adamw: null pointer");
+  HUAL_REQUIRE((a.n % 4) == 0, "adamw: flat size must be a multiple of 4");
+  HUAL_CHECK_HIP(hipMemsetAsync(a.sqnorm, 0, sizeof(float), s));
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(256), dim3(256), 0, s, (const float*)a.g, a.n, a.prescale, a.sqnorm);
+  hipLaunchKernelGGL(adamw_kernel, dim3(512), dim3(256), 0, s, a.p, (const float*)a.g, a.m, a.v, a.decay, a.n, a.lr_dev,
+                     a.clip_norm, a.prescale, (const float*)a.sqnorm, 0.9f, 0.999f, 1e-6f);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace hual

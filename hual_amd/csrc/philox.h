@@ -1,0 +1,47 @@
+// Device Philox4x32-10: the dropout generator shared with oracle/philox.py (same counter layout).
+//   c0 = col >> 2, c1 = row, c2 = site, c3 = offset ; key = seed.  Output w belongs to column 4*c0 + w.
+// Replaces TensorFlow's stateful RNG behind tf.nn.dropout (/root/reference/models/modules.py:15,27,69,83-88,
+// 131-139; layers.py:86,91; ops.py:104; model.py:47) - see DESIGN.md "Dropout".
+#pragma once
+#include "common.h"
+
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+struct uint4_ { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint4_ philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                uint32_t k1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint32_t hi0 = __umulhi(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
+    uint32_t hi1 = __umulhi(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0;
+    uint32_t n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += PHILOX_W0;
+    k1 += PHILOX_W1;
+  }
+  uint4_ r = {c0, c1, c2, c3};
+  return r;
+}
+
+// multiplicative keep-mask {0, scale} for the 4 columns [4*c0, 4*c0+3] of `row` at call-site `site`
+__device__ __forceinline__ float4 drop_mask4(const hual::DropCfg& d, uint32_t site, uint32_t row, uint32_t col4) {
+  uint4_ r = philox4x32_10(col4, row, site, d.state[2], d.state[0], d.state[1]);
+  float4 m;
+  m.x = r.x < d.thresh ? d.scale : 0.f;
+  m.y = r.y < d.thresh ? d.scale : 0.f;
+  m.z = r.z < d.thresh ? d.scale : 0.f;
+  m.w = r.w < d.thresh ? d.scale : 0.f;
+  return m;
+}
+
+__device__ __forceinline__ float4 apply_drop4(const hual::DropCfg& d, uint32_t site, uint32_t row, uint32_t col4,
+                                              float4 v) {
+  float4 m = drop_mask4(d, site, row, col4);
+  v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+  return v;
+}

@@ -1,0 +1,78 @@
+// Row-wise (per activation row of 128 floats) kernels: layer norm, depthwise conv, position embeddings and the
+// small elementwise glue between the GEMMs.  Rows live in the "unified row space":
+//   rows [0, Nv)       = video rows  b*T + t
+//   rows [Nv, Nv + Nq) = query rows  Nv + b*L + l
+// so that blocks whose weights are shared between the video and the query side
+// (/root/reference/models/model.py:53-68: conv_block and dual_attn_block with reuse=True) run as ONE launch.
+#pragma once
+#include "common.h"
+
+namespace hual {
+
+struct RowSpace {
+  int B, T, L, Nv, Nq, R;
+  const float* rowmask;   // [R] 1.0 valid / 0.0 padded (v: t < video_seq_len[b]; q: word_ids != 0)
+};
+
+// y1 = LN(x; g1,b1) (+pos[t]) (dropout) ; y2 = LN(x; g2,b2)          models/layers.py:7-17
+struct LnFwd {
+  const float* x; int R;
+  const float* g1; const float* b1; float* y1;
+  const float* g2; const float* b2; float* y2;     // optional
+  float* mean; float* rstd;                        // optional [R]
+  const float* pos;                                // optional [max_vlen,128]: y1 += pos[t]   (modules.py:41-56)
+  int drop_site; uint32_t drop_row0;               // optional dropout on y1
+  int row0;                                        // unified row index of x's first row (pos / clip lookup)
+};
+int launch_ln_fwd(const LnFwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
+
+// dx = LNbwd(x; dy1,g1) + LNbwd(x; dy2,g2) + add1 + add2 ; dgamma/dbeta accumulated with atomics
+struct LnBwd {
+  const float* x; const float* mean; const float* rstd; int R;
+  const float* dy1; const float* g1; float* dg1; float* db1; int drop_site1; uint32_t drop_row0;
+  const float* dy2; const float* g2; float* dg2; float* db2;
+  const float* add1; const float* add2;
+  float* dx;
+};
+int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s);
+
+// c = depthwise_conv7(LN(x))  (SAME zero padding inside each clip, NO length mask)     layers.py:32-45, modules.py:59-70
+struct ConvFwd {
+  const float* x; const float* g; const float* b; const float* dw;   // dw [7,128]
+  float* c; float* mean; float* rstd;
+};
+int launch_ln_dwconv_fwd(const ConvFwd& a, const RowSpace& rs, hipStream_t s);
+
+struct ConvBwd {
+  const float* dc; const float* x; const float* mean; const float* rstd;
+  const float* g; const float* b; const float* dw;
+  const float* dres;            // gradient arriving through the residual connection (added to dx)
+  float* dx; float* dg; float* db; float* ddw;
+};
+int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, hipStream_t s);
+
+// dpos[t] += sum_b dx[b,t] over both sides (pos table shared by video and query, model.py:53,56)
+int launch_pos_bwd(const float* dx, float* dpos, const RowSpace& rs, int do_v, int do_q, hipStream_t s);
+
+// generic elementwise helpers on [R,128] tensors -----------------------------------------------------------
+enum EwOp {
+  EW_DROP_DRELU = 1,    // out = dropout(a, site) * (b > 0)                    (dZ of relu->dropout)
+  EW_DROP = 2,          // out = dropout(a, site)
+  EW_GATE_BWD = 3,      // cross gating backward, see rowops.hip
+  EW_BILINEAR_BWD = 4,  // out = d*val*gate*(1-gate) ; out2 = d*gate
+  EW_ADD = 5,           // out = a + b
+  EW_MASKROWS = 6,      // out = a * rowmask
+  EW_ADD_POS = 7,       // out = a + pos[row % T]                            (modules.py:41-56; a = video rows)
+  EW_DROP_ADD = 8       // out = dropout(a, site) + b
+};
+struct EwArgs {
+  int op; int R;
+  const float* a; const float* b; const float* c; const float* d; const float* e;
+  float* out; float* out2; float* out3; float* out4;
+  int drop_site; uint32_t drop_row0;
+  const float* rowmask;
+  const float* pos; int T;
+};
+int launch_ew(const EwArgs& a, const DropCfg& drop, hipStream_t s);
+
+}  // namespace hual

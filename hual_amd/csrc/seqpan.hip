@@ -1,0 +1,1138 @@
+// Whole-graph orchestration of the SeqPAN hot path: the launch sequence that replaces
+// `sess.run([...])` on /root/reference/models/model.py:29-122, plus its hand-derived backward pass.
+// Everything here only ENQUEUES kernels on the caller's stream (no allocation, no sync) so that a training step
+// can be captured into a hipGraph.  Buffers are carved out of the caller's workspace by a deterministic bump
+// allocator; a "dry" pass of the very same code computes the workspace size and the name table.
+#include "attn.h"
+#include "cq.h"
+#include "embed.h"
+#include "gemm.h"
+#include "heads.h"
+#include "optim.h"
+#include "params.h"
+#include "rowops.h"
+#include <string.h>
+#include <unordered_map>
+
+namespace hual {
+const char* last_error_cstr();
+}
+using namespace hual;
+
+// ------------------------------------------------------------------------------------------------------
+// small kernels that belong to no family
+__global__ void prep_masks_kernel(const int32_t* lens, const int32_t* word_ids, float* rowmask, int B, int T, int L) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Nv = B * T, Nq = B * L;
+  if (i < Nv) rowmask[i] = (i % T) < lens[i / T] ? 1.0f : 0.0f;           // tf.sequence_mask, model.py:31
+  else if (i < Nv + Nq) rowmask[i] = word_ids[i - Nv] != 0 ? 1.0f : 0.0f;   // model.py:32
+}
+__global__ void loss_finalize_kernel(const float* acc, float lambda, float* out) {
+  const float match = acc[LA_MATCH_SUM] / acc[LA_DENOM] + acc[LA_ORTHO];    // layers.py:173 + model.py:91
+  const float loc = acc[LA_LOC], align = acc[LA_ALIGN];
+  out[0] = loc + lambda * match + align;                                    // model.py:120
+  out[1] = loc;
+  out[2] = match;
+  out[3] = align;
+}
+
+namespace {
+
+struct WsEntry { std::string name; size_t off, rows, cols; };
+
+struct Ctx {
+  const hual_cfg* cfg = nullptr;
+  ParamMap pm;
+  int B = 0, T = 0, L = 0, C = 0;
+  RowSpace rs;      // unified rows (video + query)
+  RowSpace rsv;     // video rows only (predictor)
+  char* base = nullptr;
+  size_t cap = 0, used = 0;
+  bool dry = true;
+  hipStream_t stream = nullptr;
+  DropCfg drop;
+  const float* P = nullptr;   // flat params
+  float* G = nullptr;         // flat grads
+  const float* word_table = nullptr;
+  std::vector<WsEntry> entries;
+  std::unordered_map<std::string, size_t> index;
+  std::vector<DwJob> dwjobs;
+  int rc = 0;
+
+  float* buf(const std::string& name, size_t rows, size_t cols) {
+    auto it = index.find(name);
+    if (it != index.end()) return reinterpret_cast<float*>(base + entries[it->second].off);
+    WsEntry e{name, used, rows, cols};
+    size_t bytes = (rows * cols * sizeof(float) + 255) & ~(size_t)255;
+    used += bytes + 256;     // 256 B guard: clamped fragment loads never leave the workspace
+    index[name] = entries.size();
+    entries.push_back(e);
+    return reinterpret_cast<float*>(base + e.off);
+  }
+  float* act(const std::string& name) { return buf(name, (size_t)rs.R, HUAL_D); }     // [R,128]
+  float* actv(const std::string& name) { return buf(name, (size_t)rs.Nv, HUAL_D); }   // [Nv,128]
+  float* vec(const std::string& name) { return buf(name, (size_t)rs.R, 1); }
+  const float* p(size_t off) const { return P + off; }
+  float* g(size_t off) const { return G + off; }
+  bool ok() const { return rc == 0; }
+  void chk(int r) { if (rc == 0 && r != 0) rc = r; }
+
+  // ---- launch wrappers (skipped in the dry pass) ----
+  void gemm(const GemmJob* j, int n) { if (!dry && ok()) chk(launch_gemm(j, n, drop, stream)); }
+  void ln_fwd(const LnFwd& a, const RowSpace& r) { if (!dry && ok()) chk(launch_ln_fwd(a, r, drop, stream)); }
+  void ln_bwd(const LnBwd& a) { if (!dry && ok()) chk(launch_ln_bwd(a, drop, stream)); }
+  void ew(const EwArgs& a) { if (!dry && ok()) chk(launch_ew(a, drop, stream)); }
+  void attn_fwd(const AttnJob* j, int n) { if (!dry && ok()) chk(launch_attn_fwd(j, n, drop, stream)); }
+  void attn_bwd(const AttnJob* j, int n, float* stats, int stat_n) {
+    if (!dry && ok()) chk(launch_attn_bwd_impl(j, n, drop, stats, stat_n, stream));
+  }
+};
+
+GemmJob mkjob(const float* A, int lda, int M, int K, const float* W, const float* bias, float* Y, int ldy, int N = HUAL_D) {
+  GemmJob j;
+  gemm_job_init(j);
+  j.npieces = 1;
+  j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.W[0] = W; j.ldw = N; j.bias = bias;
+  j.M = M; j.N = N; j.Y = Y; j.ldy = ldy;
+  return j;
+}
+// dX = dY . W^T for W stored [K,N] (row stride N): output [M,K]
+GemmJob mkjob_dx(const float* dY, int lddy, int M, int N, const float* W, float* dX, int lddx, int K = HUAL_D) {
+  GemmJob j;
+  gemm_job_init(j);
+  j.npieces = 1;
+  j.A[0] = dY; j.lda[0] = lddy; j.kw[0] = N; j.W[0] = W; j.ldw = N; j.transW = 1;
+  j.M = M; j.N = K; j.Y = dX; j.ldy = lddx;
+  return j;
+}
+DwJob mkdw(const float* A, int lda, int K, const float* dY, int ldy, int M, float* dW, float* db, int N = HUAL_D) {
+  DwJob j;
+  dw_job_init(j);
+  j.npieces = 1;
+  j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.dW[0] = dW; j.ldw = N;
+  j.dY = dY; j.ldy = ldy; j.M = M; j.N = N; j.db = db;
+  return j;
+}
+
+int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
+  HUAL_REQUIRE(cfg != nullptr, "null cfg");
+  int rc = build_param_map(*cfg, c.pm);
+  if (rc) return rc;
+  HUAL_REQUIRE(B >= 1 && T >= 1 && L >= 1, "empty batch");
+  HUAL_REQUIRE(T <= cfg->max_vlen && L <= cfg->max_vlen, "sequence longer than max_vlen (assert_less_equal, modules.py:44)");
+  HUAL_REQUIRE(T <= 256 && L <= 256, "T, L <= 256");
+  HUAL_REQUIRE(C >= 4, "char_ids need C >= 4 (conv width 4, VALID)");
+  HUAL_REQUIRE((long long)B * (T + L) * 8 < (1ll << 28), "batch too large for 32-bit RNG row ids");
+  c.cfg = cfg; c.B = B; c.T = T; c.L = L; c.C = C;
+  c.rs.B = B; c.rs.T = T; c.rs.L = L; c.rs.Nv = B * T; c.rs.Nq = B * L; c.rs.R = B * (T + L); c.rs.rowmask = nullptr;
+  c.rsv = c.rs; c.rsv.Nq = 0; c.rsv.L = 0; c.rsv.R = c.rs.Nv;
+  return 0;
+}
+
+// ======================================================================================================
+// shared sub-graphs
+// ======================================================================================================
+
+// conv_block (modules.py:59-70) on rows described by `rs`; x0 -> returns x4.  tag prefixes the buffer names.
+float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP& cp, const RowSpace& rs, int site0) {
+  const int R = rs.R;
+  for (int i = 0; i < 4; ++i) {
+    const std::string is = std::to_string(i);
+    float* cbuf = c.buf(tag + ".c" + is, R, HUAL_D);
+    float* y = c.buf(tag + ".y" + is, R, HUAL_D);
+    float* xn = c.buf(tag + ".x" + std::to_string(i + 1), R, HUAL_D);
+    float* mean = c.buf(tag + ".mean" + is, R, 1);
+    float* rstd = c.buf(tag + ".rstd" + is, R, 1);
+    ConvFwd cf{x, c.p(cp.ln[i].g), c.p(cp.ln[i].b), c.p(cp.dw[i]), cbuf, mean, rstd};
+    if (!c.dry && c.ok()) c.chk(launch_ln_dwconv_fwd(cf, rs, c.stream));
+    GemmJob j = mkjob(cbuf, HUAL_D, R, HUAL_D, c.p(cp.pw[i]), c.p(cp.b[i]), xn, HUAL_D);
+    j.act = ACT_RELU;
+    j.save = y; j.ldsave = HUAL_D;
+    j.drop_site = site0 + i; j.drop_row0 = 0;
+    j.add = x; j.ldadd = HUAL_D;
+    c.gemm(&j, 1);
+    x = xn;
+  }
+  return x;
+}
+
+// backward of conv_block: d_out = gradient wrt x4 -> returns gradient wrt x0
+float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, const ConvBlockP& cp, const RowSpace& rs,
+                      int site0) {
+  const int R = rs.R;
+  for (int i = 3; i >= 0; --i) {
+    const std::string is = std::to_string(i);
+    float* xin = i == 0 ? x0 : c.buf(tag + ".x" + is, R, HUAL_D);
+    float* cbuf = c.buf(tag + ".c" + is, R, HUAL_D);
+    float* y = c.buf(tag + ".y" + is, R, HUAL_D);
+    float* mean = c.buf(tag + ".mean" + is, R, 1);
+    float* rstd = c.buf(tag + ".rstd" + is, R, 1);
+    float* dZ = c.buf("d." + tag + ".z" + is, R, HUAL_D);
+    float* dC = c.buf("d." + tag + ".c" + is, R, HUAL_D);
+    float* dxin = c.buf("d." + tag + ".x" + is, R, HUAL_D);
+    EwArgs e{};
+    e.op = EW_DROP_DRELU; e.R = R; e.a = dx; e.b = y; e.out = dZ; e.drop_site = site0 + i; e.drop_row0 = 0;
+    c.ew(e);
+    c.dwjobs.push_back(mkdw(cbuf, HUAL_D, HUAL_D, dZ, HUAL_D, R, c.g(cp.pw[i]), c.g(cp.b[i])));
+    GemmJob j = mkjob_dx(dZ, HUAL_D, R, HUAL_D, c.p(cp.pw[i]), dC, HUAL_D);
+    c.gemm(&j, 1);
+    ConvBwd cb{dC, xin, mean, rstd, c.p(cp.ln[i].g), c.p(cp.ln[i].b), c.p(cp.dw[i]), dx, dxin,
+               c.g(cp.ln[i].g), c.g(cp.ln[i].b), c.g(cp.dw[i])};
+    if (!c.dry && c.ok()) c.chk(launch_dwconv_ln_bwd(cb, rs, c.stream));
+    dx = dxin;
+  }
+  return dx;
+}
+
+// ======================================================================================================
+// forward
+// ======================================================================================================
+int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hual_outputs* out, const hual_run_opts* opt) {
+  const ParamMap& pm = c.pm;
+  const RowSpace& rs = c.rs;
+  const int Nv = rs.Nv, Nq = rs.Nq, R = rs.R, B = c.B, T = c.T, L = c.L;
+  const int D = HUAL_D;
+  const int catw = c.cfg->word_dim + 100;
+  float* rowmask = c.vec("rowmask");
+  c.rs.rowmask = rowmask;
+  c.rsv.rowmask = rowmask;
+  float* loss_acc = c.buf("loss_acc", 8, 1);
+  if (!c.dry) {
+    HUAL_CHECK_HIP(hipMemsetAsync(loss_acc, 0, 8 * sizeof(float), c.stream));
+    hipLaunchKernelGGL(prep_masks_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.stream, bt->video_seq_len, bt->word_ids,
+                       rowmask, B, T, L);
+  }
+  // ---------------- text encoder front: word + char embeddings (model.py:36-41)
+  float* cat = c.buf("cat", Nq, catw);
+  int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
+  EmbedArgs ea{};
+  if (!c.dry) {
+    ea.word_ids = bt->word_ids; ea.char_ids = bt->char_ids; ea.word_table = c.word_table; ea.unk = c.p(pm.unk);
+    ea.char_table = c.p(pm.char_table);
+    for (int i = 0; i < 4; ++i) { ea.filt[i] = c.p(pm.filt[i]); ea.fbias[i] = c.p(pm.fbias[i]); }
+    ea.cat = cat; ea.ldcat = catw; ea.char_arg = char_arg;
+    ea.word_dim = c.cfg->word_dim; ea.char_dim = c.cfg->char_dim; ea.C = c.C; ea.num_chars = c.cfg->num_chars;
+    if (c.ok()) c.chk(launch_embed_fwd(ea, Nq, c.drop, c.stream));
+  }
+  // ---------------- the two input projections (model.py:42,48) as one launch; LN + pos (model.py:43,49,53,56)
+  float* lin = c.act("lin");
+  {
+    GemmJob j[2];
+    j[0] = mkjob(c.dry ? nullptr : bt->video, c.cfg->vdim, Nv, c.cfg->vdim, c.p(pm.vconv.k), c.p(pm.vconv.b), lin, D);
+    j[0].a_drop_site = HUAL_SITE_VIDEO; j[0].a_drop_row0 = 0;
+    j[1] = mkjob(cat, catw, Nq, catw, c.p(pm.qconv.k), c.p(pm.qconv.b), lin + (size_t)Nv * D, D);
+    c.gemm(j, 2);
+  }
+  float* x = c.act("cb.x0");
+  float* lin_mean = c.vec("lin.mean");
+  float* lin_rstd = c.vec("lin.rstd");
+  {
+    LnFwd a{};
+    a.x = lin; a.R = Nv; a.g1 = c.p(pm.vln.g); a.b1 = c.p(pm.vln.b); a.y1 = x; a.mean = lin_mean; a.rstd = lin_rstd;
+    a.pos = c.p(pm.pos); a.drop_site = -1; a.row0 = 0;
+    c.ln_fwd(a, rs);
+    a.x = lin + (size_t)Nv * D; a.R = Nq; a.g1 = c.p(pm.qln.g); a.b1 = c.p(pm.qln.b); a.y1 = x + (size_t)Nv * D;
+    a.mean = lin_mean + Nv; a.rstd = lin_rstd + Nv; a.row0 = Nv;
+    c.ln_fwd(a, rs);
+  }
+  // ---------------- shared conv block (model.py:54-58)
+  x = conv_block_fwd(c, "cb", x, pm.cb, rs, HUAL_SITE_CONV);
+  // ---------------- dual attention layers (model.py:60-68)
+  for (int li = 0; li < c.cfg->attn_layer; ++li) {
+    const DualAttnP& d = pm.da[li];
+    const std::string t = "da" + std::to_string(li);
+    const int site = HUAL_SITE_DA + 8 * li;
+    float* ln1 = c.act(t + ".ln1");
+    float* lnt = c.act(t + ".lnt");
+    float* mean = c.vec(t + ".mean");
+    float* rstd = c.vec(t + ".rstd");
+    {
+      LnFwd a{};
+      a.x = x; a.R = R; a.g1 = c.p(d.ln1.g); a.b1 = c.p(d.ln1.b); a.y1 = ln1; a.g2 = c.p(d.lnt.g); a.b2 = c.p(d.lnt.b);
+      a.y2 = lnt; a.mean = mean; a.rstd = rstd; a.drop_site = -1;
+      c.ln_fwd(a, rs);
+    }
+    float* qkv = c.buf(t + ".qkv", R, 3 * D);
+    float* ktvt = c.buf(t + ".ktvt", R, 2 * D);
+    {
+      GemmJob j[5];
+      j[0] = mkjob(ln1, D, R, D, c.p(d.query.k), c.p(d.query.b), qkv, 3 * D);
+      j[1] = mkjob(ln1, D, R, D, c.p(d.f_key.k), c.p(d.f_key.b), qkv + D, 3 * D);
+      j[2] = mkjob(ln1, D, R, D, c.p(d.f_value.k), c.p(d.f_value.b), qkv + 2 * D, 3 * D);
+      j[3] = mkjob(lnt, D, R, D, c.p(d.t_key.k), c.p(d.t_key.b), ktvt, 2 * D);
+      j[4] = mkjob(lnt, D, R, D, c.p(d.t_value.k), c.p(d.t_value.b), ktvt + D, 2 * D);
+      c.gemm(j, 5);
+    }
+    float* s_att = c.act(t + ".s_att");
+    float* x_att = c.act(t + ".x_att");
+    {
+      AttnJob a[4];
+      for (int k = 0; k < 4; ++k) {
+        attn_job_init(a[k]);
+        a[k].Q = qkv; a[k].ldq = 3 * D; a[k].B = B; a[k].qmask = rowmask; a[k].kmask = rowmask; a[k].ldo = D;
+      }
+      // video side: self (keys = video) / cross (keys = query)
+      a[0].K = qkv + D; a[0].V = qkv + 2 * D; a[0].ldkv = 3 * D; a[0].Tq = T; a[0].Tk = T; a[0].qrow0 = 0; a[0].krow0 = 0;
+      a[0].O = s_att; a[0].drop_site = site + 0;
+      a[1].K = ktvt; a[1].V = ktvt + D; a[1].ldkv = 2 * D; a[1].Tq = T; a[1].Tk = L; a[1].qrow0 = 0; a[1].krow0 = Nv;
+      a[1].O = x_att; a[1].drop_site = site + 1;
+      // query side
+      a[2].K = qkv + D; a[2].V = qkv + 2 * D; a[2].ldkv = 3 * D; a[2].Tq = L; a[2].Tk = L; a[2].qrow0 = Nv; a[2].krow0 = Nv;
+      a[2].O = s_att; a[2].drop_site = site + 0;
+      a[3].K = ktvt; a[3].V = ktvt + D; a[3].ldkv = 2 * D; a[3].Tq = L; a[3].Tk = T; a[3].qrow0 = Nv; a[3].krow0 = 0;
+      a[3].O = x_att; a[3].drop_site = site + 1;
+      c.attn_fwd(a, 4);
+    }
+    float* sv = c.act(t + ".s");
+    float* xv = c.act(t + ".x");
+    {
+      GemmJob j[2];
+      j[0] = mkjob(s_att, D, R, D, c.p(d.s_dense.k), c.p(d.s_dense.b), sv, D);
+      j[1] = mkjob(x_att, D, R, D, c.p(d.x_dense.k), c.p(d.x_dense.b), xv, D);
+      c.gemm(j, 2);
+    }
+    float* sg = c.act(t + ".sg");
+    float* xg = c.act(t + ".xg");
+    float* o = c.act(t + ".o");
+    {
+      GemmJob j = mkjob(sv, D, R, D, c.p(d.s_gate.k), c.p(d.s_gate.b), o, D);
+      j.act = ACT_SIGMOID;
+      j.comb = COMB_CROSSGATE;
+      j.Ab[0] = xv; j.ldab[0] = D; j.W2[0] = c.p(d.x_gate.k); j.bias2 = c.p(d.x_gate.b);
+      j.save = sg; j.ldsave = D; j.save2 = xg; j.ldsave2 = D;
+      j.aux1 = xv; j.aux2 = sv; j.ldaux = D;      // o = sg * x + xg * s   (layers.py:101-103)
+      c.gemm(&j, 1);
+    }
+    float* gd = c.act(t + ".g");
+    {
+      GemmJob j = mkjob(o, D, R, D, c.p(d.guided.k), c.p(d.guided.b), gd, D);
+      c.gemm(&j, 1);
+    }
+    float* gate = c.act(t + ".gate");
+    float* val = c.act(t + ".val");
+    float* mha = c.act(t + ".mha");
+    {
+      GemmJob j = mkjob(ln1, D, R, D, c.p(d.bl1_d1), c.p(d.bl1_b), mha, D);
+      j.npieces = 2;
+      j.A[1] = gd; j.lda[1] = D; j.kw[1] = D; j.W[1] = c.p(d.bl1_d2);
+      j.act = ACT_SIGMOID_ROWMASK; j.rowmask = rowmask;
+      j.comb = COMB_GATE_VAL;
+      j.W2[0] = c.p(d.bl2_d1); j.W2[1] = c.p(d.bl2_d2); j.bias2 = c.p(d.bl2_b);
+      j.save = gate; j.ldsave = D; j.save2 = val; j.ldsave2 = D;
+      c.gemm(&j, 1);
+    }
+    float* res = c.act(t + ".res");
+    {
+      GemmJob j = mkjob(mha, D, R, D, c.p(d.dense1.k), c.p(d.dense1.b), res, D);
+      j.drop_site = site + 2; j.add = x; j.ldadd = D;
+      c.gemm(&j, 1);
+    }
+    float* l2 = c.act(t + ".l2");
+    float* mean2 = c.vec(t + ".mean2");
+    float* rstd2 = c.vec(t + ".rstd2");
+    {
+      LnFwd a{};
+      a.x = res; a.R = R; a.g1 = c.p(d.ln2.g); a.b1 = c.p(d.ln2.b); a.y1 = l2; a.mean = mean2; a.rstd = rstd2;
+      a.drop_site = site + 3; a.drop_row0 = 0;
+      c.ln_fwd(a, rs);
+    }
+    float* xo = c.act(t + ".out");
+    {
+      GemmJob j = mkjob(l2, D, R, D, c.p(d.dense2.k), c.p(d.dense2.b), xo, D);
+      j.drop_site = site + 4; j.add = res; j.ldadd = D;
+      c.gemm(&j, 1);
+    }
+    x = xo;
+  }
+  // ---------------- context-query attention in both directions (model.py:70-73)
+  CqBufs cq{};
+  cq.X = x;
+  cq.D1W = c.act("cq.d1w"); cq.D2 = c.act("cq.d2"); cq.S0 = c.vec("cq.s0"); cq.S1 = c.vec("cq.s1");
+  cq.C2Q = c.act("cq.c2q"); cq.Q2C = c.act("cq.q2c");
+  const size_t mat = cq_mat_elems_host(T, L);
+  cq.SR = c.buf("cq.sr", (size_t)2 * B, mat);
+  cq.SC = c.buf("cq.sc", (size_t)2 * B, mat);
+  cq.M2 = c.buf("cq.m2", (size_t)2 * B * cq_m2_rows_host(T, L), D);
+  CqParams cqp{};
+  for (int i = 0; i < 2; ++i) { cqp.w0[i] = c.p(pm.cq[i].w0); cqp.w1[i] = c.p(pm.cq[i].w1); cqp.wm[i] = c.p(pm.cq[i].wm); }
+  if (!c.dry && c.ok()) c.chk(launch_tri_prep(cq, cqp, c.rs, c.drop, c.stream));
+  if (!c.dry && c.ok()) c.chk(launch_cq_fwd(cq, c.rs, c.stream));
+  float* cqf = c.act("cq.feats");      // q2v_feats (video rows) | v2q_feats (query rows)
+  {
+    GemmJob j[2];
+    for (int s = 0; s < 2; ++s) {
+      const size_t ro = s == 0 ? 0 : (size_t)Nv * D;
+      const float* W = c.p(pm.cq[s].dense);
+      j[s] = mkjob(x + ro, D, s == 0 ? Nv : Nq, D, W, nullptr, cqf + ro, D);
+      j[s].npieces = 4;
+      const float* a1[4] = {x + ro, cq.C2Q + ro, x + ro, x + ro};
+      const float* a2[4] = {nullptr, nullptr, cq.C2Q + ro, cq.Q2C + ro};
+      for (int p = 0; p < 4; ++p) {
+        j[s].A[p] = a1[p]; j[s].A2[p] = a2[p]; j[s].lda[p] = D; j[s].lda2[p] = D; j[s].kw[p] = D;
+        j[s].W[p] = W + (size_t)p * D * D;
+      }
+    }
+    c.gemm(j, 2);
+  }
+  // ---------------- cq_concat (layers.py:145-154)
+  PoolArgs pa{};
+  pa.F2 = cqf; pa.wp = c.p(pm.pool_w); pa.Wbot = c.p(pm.cqcat.k) + (size_t)D * D;
+  pa.alpha = c.buf("pool.alpha", B, L); pa.pooled = c.buf("pool.pooled", B, D); pa.PW = c.buf("pool.pw", B, D);
+  if (!c.dry && c.ok()) c.chk(launch_pool_fwd(pa, c.rs, c.stream));
+  float* fuse = c.actv("fuse");
+  {
+    GemmJob j = mkjob(cqf, D, Nv, D, c.p(pm.cqcat.k), c.p(pm.cqcat.b), fuse, D);
+    j.add = pa.PW; j.ldadd = D; j.add_div = T;
+    c.gemm(&j, 1);
+  }
+  // ---------------- matching head + label embeddings (model.py:82-97)
+  float* outputs = c.actv("outputs");
+  MatchArgs ma{};
+  ma.fuse = fuse; ma.Wm = c.p(pm.match.k); ma.bm = c.p(pm.match.b); ma.E = c.p(pm.label_emb);
+  ma.labels = (lab && !c.dry) ? lab->match_labels : nullptr;
+  ma.probs = c.dry ? nullptr : out->match_scores; ma.outputs = outputs; ma.loss_acc = loss_acc;
+  if (!c.dry && c.ok()) c.chk(launch_match_fwd(ma, c.rs, c.stream));
+  // ---------------- alignment loss, per-sample part (model.py:76)
+  AlignPool ap{};
+  ap.F2 = cqf; ap.F1 = cqf; ap.inner = (lab && !c.dry) ? lab->inner_labels : nullptr;
+  ap.tpre = c.buf("align.tpre", B, D); ap.vpre = c.buf("align.vpre", B, D);
+  ap.that = c.buf("align.that", B, D); ap.vhat = c.buf("align.vhat", B, D);
+  float* d_that = c.buf("d.align.that", B, D);
+  float* d_vhat = c.buf("d.align.vhat", B, D);
+  float* align_scratch = c.buf("align.scratch", (size_t)2 * B, B);
+  if (lab && !c.dry && c.ok()) {
+    c.chk(launch_align_pool(ap, c.rs, c.stream));
+    if (!opt->align_external) {
+      AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, d_that, d_vhat, loss_acc, 1.0f};
+      if (c.ok()) c.chk(launch_align_sim(as, c.stream));
+    }
+  }
+  // ---------------- conditioned predictor (modules.py:143-160)
+  float* fin = outputs;
+  float* feo[2];
+  for (int ps = 0; ps < 2; ++ps) {
+    const std::string t = "fe" + std::to_string(ps);
+    const int site = HUAL_SITE_FE + 16 * ps;
+    float* x0 = c.actv(t + ".x0");
+    {
+      EwArgs e{};
+      e.op = EW_ADD_POS; e.R = Nv; e.a = fin; e.out = x0; e.pos = c.p(pm.fe_pos); e.T = T; e.drop_site = -1;
+      c.ew(e);
+    }
+    float* f = conv_block_fwd(c, t, x0, pm.fe_cb, c.rsv, site);
+    float* a1 = c.actv(t + ".a");
+    float* mean = c.buf(t + ".ln1.mean", Nv, 1);
+    float* rstd = c.buf(t + ".ln1.rstd", Nv, 1);
+    {
+      LnFwd a{};
+      a.x = f; a.R = Nv; a.g1 = c.p(pm.fe_ln1.g); a.b1 = c.p(pm.fe_ln1.b); a.y1 = a1; a.mean = mean; a.rstd = rstd;
+      a.drop_site = site + 4; a.drop_row0 = 0;
+      c.ln_fwd(a, c.rsv);
+    }
+    float* qkv = c.buf(t + ".qkv", Nv, 3 * D);
+    {
+      GemmJob j[3];
+      j[0] = mkjob(a1, D, Nv, D, c.p(pm.fe_q.k), c.p(pm.fe_q.b), qkv, 3 * D);
+      j[1] = mkjob(a1, D, Nv, D, c.p(pm.fe_k.k), c.p(pm.fe_k.b), qkv + D, 3 * D);
+      j[2] = mkjob(a1, D, Nv, D, c.p(pm.fe_v.k), c.p(pm.fe_v.b), qkv + 2 * D, 3 * D);
+      c.gemm(j, 3);
+    }
+    float* att = c.actv(t + ".att");
+    {
+      AttnJob a;
+      attn_job_init(a);
+      a.Q = qkv; a.ldq = 3 * D; a.K = qkv + D; a.V = qkv + 2 * D; a.ldkv = 3 * D; a.O = att; a.ldo = D;
+      a.B = B; a.Tq = T; a.Tk = T; a.qrow0 = 0; a.krow0 = 0; a.qmask = rowmask; a.kmask = rowmask;
+      a.drop_site = site + 5;
+      c.attn_fwd(&a, 1);
+    }
+    float* res = c.actv(t + ".res");
+    {
+      EwArgs e{};
+      e.op = EW_DROP_ADD; e.R = Nv; e.a = att; e.b = f; e.out = res; e.drop_site = site + 6; e.drop_row0 = 0;
+      c.ew(e);
+    }
+    float* l2 = c.actv(t + ".l2");
+    float* mean2 = c.buf(t + ".ln2.mean", Nv, 1);
+    float* rstd2 = c.buf(t + ".ln2.rstd", Nv, 1);
+    {
+      LnFwd a{};
+      a.x = res; a.R = Nv; a.g1 = c.p(pm.fe_ln2.g); a.b1 = c.p(pm.fe_ln2.b); a.y1 = l2; a.mean = mean2; a.rstd = rstd2;
+      a.drop_site = site + 7; a.drop_row0 = 0;
+      c.ln_fwd(a, c.rsv);
+    }
+    float* fo = c.actv(t + ".out");
+    {
+      GemmJob j = mkjob(l2, D, Nv, D, c.p(pm.fe_dense.k), c.p(pm.fe_dense.b), fo, D);
+      j.drop_site = site + 8; j.add = res; j.ldadd = D;
+      c.gemm(&j, 1);
+    }
+    feo[ps] = fo;
+    fin = fo;
+  }
+  float* sfn = c.actv("head.sfn");
+  float* efn = c.actv("head.efn");
+  float* hmean = c.buf("head.mean", (size_t)2 * Nv, 1);
+  float* hrstd = c.buf("head.rstd", (size_t)2 * Nv, 1);
+  {
+    LnFwd a{};
+    a.x = feo[0]; a.R = Nv; a.g1 = c.p(pm.sln.g); a.b1 = c.p(pm.sln.b); a.y1 = sfn; a.mean = hmean; a.rstd = hrstd;
+    a.drop_site = -1;
+    c.ln_fwd(a, c.rsv);
+    a.x = feo[1]; a.g1 = c.p(pm.eln.g); a.b1 = c.p(pm.eln.b); a.y1 = efn; a.mean = hmean + Nv; a.rstd = hrstd + Nv;
+    c.ln_fwd(a, c.rsv);
+  }
+  float* hs = c.actv("head.hs");
+  float* he = c.actv("head.he");
+  {
+    GemmJob j[2];
+    j[0] = mkjob(sfn, D, Nv, D, c.p(pm.shid.k), c.p(pm.shid.b), hs, D);
+    j[0].npieces = 2; j[0].A[1] = outputs; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.p(pm.shid.k) + (size_t)D * D;
+    j[0].act = ACT_RELU;
+    j[1] = mkjob(efn, D, Nv, D, c.p(pm.ehid.k), c.p(pm.ehid.b), he, D);
+    j[1].npieces = 2; j[1].A[1] = outputs; j[1].lda[1] = D; j[1].kw[1] = D; j[1].W[1] = c.p(pm.ehid.k) + (size_t)D * D;
+    j[1].act = ACT_RELU;
+    c.gemm(j, 2);
+  }
+  float* d_s = c.buf("d.s_logit", B, T);
+  float* d_e = c.buf("d.e_logit", B, T);
+  if (!c.dry && c.ok()) {
+    DotArgs da{};
+    da.h[0] = hs; da.h[1] = he; da.w[0] = c.p(pm.sdense.k); da.w[1] = c.p(pm.edense.k);
+    da.b[0] = c.p(pm.sdense.b); da.b[1] = c.p(pm.edense.b);
+    da.logit[0] = out->start_logits; da.logit[1] = out->end_logits; da.R = Nv;
+    c.chk(launch_rowdot_fwd(da, c.stream));
+    LocArgs la{};
+    la.s_logit = out->start_logits; la.e_logit = out->end_logits; la.vmask = rowmask;
+    la.y1 = lab ? lab->y1 : nullptr; la.y2 = lab ? lab->y2 : nullptr;
+    la.start_index = out->start_index; la.end_index = out->end_index;
+    la.ds = lab ? d_s : nullptr; la.de = lab ? d_e : nullptr; la.loss_acc = loss_acc; la.inv_batch = 1.0f / (float)B;
+    if (c.ok()) c.chk(launch_loc(la, B, T, c.stream));
+    if (lab && c.ok()) {
+      c.chk(launch_match_denominator(loss_acc, opt->match_denom_override, c.stream));
+      if (c.ok()) c.chk(launch_ortho(c.p(pm.label_emb), nullptr, loss_acc, c.cfg->match_lambda, c.stream));
+      if (out->loss_terms)
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, c.stream, (const float*)loss_acc, c.cfg->match_lambda,
+                           out->loss_terms);
+    }
+  }
+  return c.rc;
+}
+
+// ======================================================================================================
+// backward  (hand-derived; mirrors forward_graph bottom-up).  Parameter gradients of the dense layers are
+// queued as DwJobs and flushed at the very end as a few large launches.
+// ======================================================================================================
+int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hual_run_opts* opt) {
+  const ParamMap& pm = c.pm;
+  const int Nv = c.rs.Nv, Nq = c.rs.Nq, R = c.rs.R, B = c.B, T = c.T, L = c.L;
+  const int D = HUAL_D;
+  const int catw = c.cfg->word_dim + 100;
+  float* rowmask = c.vec("rowmask");
+  float* loss_acc = c.buf("loss_acc", 8, 1);
+  c.dwjobs.clear();
+  if (!c.dry) HUAL_CHECK_HIP(hipMemsetAsync(c.G, 0, pm.total * sizeof(float), c.stream));
+  float* outputs = c.actv("outputs");
+  // ---------------- heads
+  float* hs = c.actv("head.hs");
+  float* he = c.actv("head.he");
+  float* sfn = c.actv("head.sfn");
+  float* efn = c.actv("head.efn");
+  float* hmean = c.buf("head.mean", (size_t)2 * Nv, 1);
+  float* hrstd = c.buf("head.rstd", (size_t)2 * Nv, 1);
+  float* d_s = c.buf("d.s_logit", B, T);
+  float* d_e = c.buf("d.e_logit", B, T);
+  float* dz_hs = c.actv("d.head.zs");
+  float* dz_he = c.actv("d.head.ze");
+  if (!c.dry && c.ok()) {
+    DotArgs da{};
+    da.h[0] = hs; da.h[1] = he; da.w[0] = c.p(pm.sdense.k); da.w[1] = c.p(pm.edense.k); da.R = Nv;
+    DotBwd db{};
+    db.dlogit[0] = d_s; db.dlogit[1] = d_e; db.dZ[0] = dz_hs; db.dZ[1] = dz_he;
+    db.dw[0] = c.g(pm.sdense.k); db.dw[1] = c.g(pm.edense.k); db.db[0] = c.g(pm.sdense.b); db.db[1] = c.g(pm.edense.b);
+    c.chk(launch_rowdot_bwd(da, db, c.stream));
+  }
+  for (int h = 0; h < 2; ++h) {
+    const DenseP& hp = h == 0 ? pm.shid : pm.ehid;
+    DwJob j = mkdw(h == 0 ? sfn : efn, D, D, h == 0 ? dz_hs : dz_he, D, Nv, c.g(hp.k), c.g(hp.b));
+    j.npieces = 2; j.A[1] = outputs; j.lda[1] = D; j.kw[1] = D; j.dW[1] = c.g(hp.k) + (size_t)D * D;
+    c.dwjobs.push_back(j);
+  }
+  float* d_sfn = c.actv("d.head.sfn");
+  float* d_efn = c.actv("d.head.efn");
+  float* d_out_heads = c.actv("d.outputs.heads");
+  {
+    GemmJob j[3];
+    j[0] = mkjob_dx(dz_hs, D, Nv, D, c.p(pm.shid.k), d_sfn, D);
+    j[1] = mkjob_dx(dz_he, D, Nv, D, c.p(pm.ehid.k), d_efn, D);
+    j[2] = mkjob_dx(dz_hs, D, Nv, D, c.p(pm.shid.k) + (size_t)D * D, d_out_heads, D);
+    j[2].npieces = 2; j[2].A[1] = dz_he; j[2].lda[1] = D; j[2].kw[1] = D; j[2].W[1] = c.p(pm.ehid.k) + (size_t)D * D;
+    c.gemm(j, 3);
+  }
+  // ---------------- feature encoders, pass 1 then pass 0
+  float* d_feout = c.actv("d.fe1.out");
+  {
+    LnBwd a{};
+    a.x = c.actv("fe1.out"); a.mean = hmean + Nv; a.rstd = hrstd + Nv; a.R = Nv; a.dy1 = d_efn; a.g1 = c.p(pm.eln.g);
+    a.dg1 = c.g(pm.eln.g); a.db1 = c.g(pm.eln.b); a.drop_site1 = -1; a.dx = d_feout;
+    c.ln_bwd(a);
+  }
+  float* d_in = nullptr;
+  for (int ps = 1; ps >= 0; --ps) {
+    const std::string t = "fe" + std::to_string(ps);
+    const int site = HUAL_SITE_FE + 16 * ps;
+    float* x0 = c.actv(t + ".x0");
+    float* f = c.buf(t + ".x4", Nv, D);
+    float* a1 = c.actv(t + ".a");
+    float* mean = c.buf(t + ".ln1.mean", Nv, 1);
+    float* rstd = c.buf(t + ".ln1.rstd", Nv, 1);
+    float* qkv = c.buf(t + ".qkv", Nv, 3 * D);
+    float* res = c.actv(t + ".res");
+    float* l2 = c.actv(t + ".l2");
+    float* mean2 = c.buf(t + ".ln2.mean", Nv, 1);
+    float* rstd2 = c.buf(t + ".ln2.rstd", Nv, 1);
+    if (ps == 0) {
+      // gradient wrt fe0.out = start_layer_norm backward + what pass 1 sent back to its input
+      float* d0 = c.actv("d.fe0.out");
+      LnBwd a{};
+      a.x = c.actv("fe0.out"); a.mean = hmean; a.rstd = hrstd; a.R = Nv; a.dy1 = d_sfn; a.g1 = c.p(pm.sln.g);
+      a.dg1 = c.g(pm.sln.g); a.db1 = c.g(pm.sln.b); a.drop_site1 = -1; a.add1 = d_in; a.dx = d0;
+      c.ln_bwd(a);
+      d_feout = d0;
+    }
+    // out = dropout(l2 . Wd + b, s8) + res
+    float* dzd = c.actv("d." + t + ".zd");
+    {
+      EwArgs e{};
+      e.op = EW_DROP; e.R = Nv; e.a = d_feout; e.out = dzd; e.drop_site = site + 8; e.drop_row0 = 0;
+      c.ew(e);
+    }
+    c.dwjobs.push_back(mkdw(l2, D, D, dzd, D, Nv, c.g(pm.fe_dense.k), c.g(pm.fe_dense.b)));
+    float* d_l2 = c.actv("d." + t + ".l2");
+    {
+      GemmJob j = mkjob_dx(dzd, D, Nv, D, c.p(pm.fe_dense.k), d_l2, D);
+      c.gemm(&j, 1);
+    }
+    float* d_res = c.actv("d." + t + ".res");
+    {
+      LnBwd a{};
+      a.x = res; a.mean = mean2; a.rstd = rstd2; a.R = Nv; a.dy1 = d_l2; a.g1 = c.p(pm.fe_ln2.g);
+      a.dg1 = c.g(pm.fe_ln2.g); a.db1 = c.g(pm.fe_ln2.b); a.drop_site1 = site + 7; a.drop_row0 = 0; a.add1 = d_feout;
+      a.dx = d_res;
+      c.ln_bwd(a);
+    }
+    // res = dropout(att, s6) + f
+    float* d_att = c.actv("d." + t + ".att");
+    {
+      EwArgs e{};
+      e.op = EW_DROP; e.R = Nv; e.a = d_res; e.out = d_att; e.drop_site = site + 6; e.drop_row0 = 0;
+      c.ew(e);
+    }
+    float* d_qkv = c.buf("d." + t + ".qkv", Nv, 3 * D);
+    float* stats = c.buf("attn.stats", (size_t)4 * 3, (size_t)R * 8);
+    {
+      AttnJob a;
+      attn_job_init(a);
+      a.Q = qkv; a.ldq = 3 * D; a.K = qkv + D; a.V = qkv + 2 * D; a.ldkv = 3 * D;
+      a.B = B; a.Tq = T; a.Tk = T; a.qrow0 = 0; a.krow0 = 0; a.qmask = rowmask; a.kmask = rowmask;
+      a.drop_site = site + 5;
+      a.dO = d_att; a.lddo = D; a.dQ = d_qkv; a.lddq = 3 * D; a.dK = d_qkv + D; a.dV = d_qkv + 2 * D; a.lddkv = 3 * D;
+      c.attn_bwd(&a, 1, stats, R * 8);
+    }
+    c.dwjobs.push_back(mkdw(a1, D, D, d_qkv, 3 * D, Nv, c.g(pm.fe_q.k), c.g(pm.fe_q.b)));
+    c.dwjobs.push_back(mkdw(a1, D, D, d_qkv + D, 3 * D, Nv, c.g(pm.fe_k.k), c.g(pm.fe_k.b)));
+    c.dwjobs.push_back(mkdw(a1, D, D, d_qkv + 2 * D, 3 * D, Nv, c.g(pm.fe_v.k), c.g(pm.fe_v.b)));
+    float* d_a = c.actv("d." + t + ".a");
+    {
+      GemmJob j = mkjob_dx(d_qkv, 3 * D, Nv, D, c.p(pm.fe_q.k), d_a, D);
+      j.npieces = 3;
+      j.A[1] = d_qkv + D; j.lda[1] = 3 * D; j.kw[1] = D; j.W[1] = c.p(pm.fe_k.k);
+      j.A[2] = d_qkv + 2 * D; j.lda[2] = 3 * D; j.kw[2] = D; j.W[2] = c.p(pm.fe_v.k);
+      c.gemm(&j, 1);
+    }
+    float* d_f = c.actv("d." + t + ".x4");
+    {
+      LnBwd a{};
+      a.x = f; a.mean = mean; a.rstd = rstd; a.R = Nv; a.dy1 = d_a; a.g1 = c.p(pm.fe_ln1.g);
+      a.dg1 = c.g(pm.fe_ln1.g); a.db1 = c.g(pm.fe_ln1.b); a.drop_site1 = site + 4; a.drop_row0 = 0; a.add1 = d_res;
+      a.dx = d_f;
+      c.ln_bwd(a);
+    }
+    float* d_x0 = conv_block_bwd(c, t, x0, d_f, pm.fe_cb, c.rsv, site);
+    if (!c.dry && c.ok()) c.chk(launch_pos_bwd(d_x0, c.g(pm.fe_pos), c.rsv, 1, 0, c.stream));
+    d_in = d_x0;
+  }
+  // ---------------- gradient wrt `outputs`, matching head
+  float* d_outputs = c.actv("d.outputs");
+  {
+    EwArgs e{};
+    e.op = EW_ADD; e.R = Nv; e.a = d_in; e.b = d_out_heads; e.out = d_outputs; e.drop_site = -1;
+    c.ew(e);
+  }
+  float* fuse = c.actv("fuse");
+  float* d_fuse = c.actv("d.fuse");
+  if (!c.dry && c.ok()) {
+    MatchArgs ma{};
+    ma.fuse = fuse; ma.Wm = c.p(pm.match.k); ma.bm = c.p(pm.match.b); ma.E = c.p(pm.label_emb);
+    ma.labels = lab->match_labels; ma.probs = nullptr; ma.outputs = outputs; ma.loss_acc = loss_acc;
+    // probs were written to the caller's match_scores buffer; keep a private copy for backward
+    ma.probs = c.buf("match.probs", Nv, 4);
+    MatchBwd mb{};
+    mb.dOut = d_outputs; mb.dFuse = d_fuse; mb.dWm = c.g(pm.match.k); mb.dbm = c.g(pm.match.b); mb.dE = c.g(pm.label_emb);
+    mb.lambda = c.cfg->match_lambda;
+    c.chk(launch_match_bwd(ma, mb, c.rs, c.stream));
+    if (c.ok()) c.chk(launch_ortho(c.p(pm.label_emb), c.g(pm.label_emb), loss_acc, c.cfg->match_lambda, c.stream));
+  } else {
+    c.buf("match.probs", Nv, 4);
+  }
+  // ---------------- cq_concat
+  float* cqf = c.act("cq.feats");
+  float* d_cqf = c.act("d.cq.feats");
+  c.dwjobs.push_back(mkdw(cqf, D, D, d_fuse, D, Nv, c.g(pm.cqcat.k), c.g(pm.cqcat.b)));
+  {
+    GemmJob j = mkjob_dx(d_fuse, D, Nv, D, c.p(pm.cqcat.k), d_cqf, D);
+    c.gemm(&j, 1);
+  }
+  AlignPool ap{};
+  ap.F2 = cqf; ap.F1 = cqf; ap.inner = c.dry ? nullptr : lab->inner_labels;
+  ap.tpre = c.buf("align.tpre", B, D); ap.vpre = c.buf("align.vpre", B, D);
+  ap.that = c.buf("align.that", B, D); ap.vhat = c.buf("align.vhat", B, D);
+  float* d_that = c.buf("d.align.that", B, D);
+  float* d_vhat = c.buf("d.align.vhat", B, D);
+  if (!c.dry && c.ok()) {
+    AlignPoolBwd ab{d_that, d_vhat, d_cqf, d_cqf};
+    c.chk(launch_align_pool_bwd(ap, ab, c.rs, c.stream));      // writes the query rows, accumulates the video rows
+  }
+  PoolArgs pa{};
+  pa.F2 = cqf; pa.wp = c.p(pm.pool_w); pa.Wbot = c.p(pm.cqcat.k) + (size_t)D * D;
+  pa.alpha = c.buf("pool.alpha", B, L); pa.pooled = c.buf("pool.pooled", B, D); pa.PW = c.buf("pool.pw", B, D);
+  float* d_pw = c.buf("d.pool.pw", B, D);
+  if (!c.dry && c.ok()) {
+    PoolBwd pb{d_fuse, d_pw, d_cqf, c.g(pm.pool_w)};
+    c.chk(launch_pool_bwd(pa, pb, c.rs, c.stream));
+  }
+  c.dwjobs.push_back(mkdw(pa.pooled, D, D, d_pw, D, B, c.g(pm.cqcat.k) + (size_t)D * D, nullptr));
+  // ---------------- the two cq_attention dense layers
+  float* xf = c.cfg->attn_layer > 0 ? c.act("da" + std::to_string(c.cfg->attn_layer - 1) + ".out") : nullptr;
+  CqBufs cq{};
+  cq.X = xf;
+  cq.D1W = c.act("cq.d1w"); cq.D2 = c.act("cq.d2"); cq.S0 = c.vec("cq.s0"); cq.S1 = c.vec("cq.s1");
+  cq.C2Q = c.act("cq.c2q"); cq.Q2C = c.act("cq.q2c");
+  const size_t mat = cq_mat_elems_host(T, L);
+  cq.SR = c.buf("cq.sr", (size_t)2 * B, mat);
+  cq.SC = c.buf("cq.sc", (size_t)2 * B, mat);
+  cq.M2 = c.buf("cq.m2", (size_t)2 * B * cq_m2_rows_host(T, L), D);
+  for (int s = 0; s < 2; ++s) {
+    const size_t ro = s == 0 ? 0 : (size_t)Nv * D;
+    DwJob j = mkdw(xf + ro, D, D, d_cqf + ro, D, s == 0 ? Nv : Nq, c.g(pm.cq[s].dense), nullptr);
+    j.npieces = 4;
+    const float* a1[4] = {xf + ro, cq.C2Q + ro, xf + ro, xf + ro};
+    const float* a2[4] = {nullptr, nullptr, cq.C2Q + ro, cq.Q2C + ro};
+    for (int p = 0; p < 4; ++p) {
+      j.A[p] = a1[p]; j.A2[p] = a2[p]; j.lda[p] = D; j.lda2[p] = D; j.kw[p] = D;
+      j.dW[p] = c.g(pm.cq[s].dense) + (size_t)p * D * D;
+    }
+    c.dwjobs.push_back(j);
+  }
+  float* d_cat4 = c.buf("d.cq.cat", R, 4 * D);
+  {
+    GemmJob j[2];
+    j[0] = mkjob_dx(d_cqf, D, Nv, D, c.p(pm.cq[0].dense), d_cat4, 4 * D, 4 * D);
+    j[1] = mkjob_dx(d_cqf + (size_t)Nv * D, D, Nq, D, c.p(pm.cq[1].dense), d_cat4 + (size_t)Nv * 4 * D, 4 * D, 4 * D);
+    c.gemm(j, 2);
+  }
+  CqBwdBufs cg{};
+  cg.dCat = d_cat4; cg.ldcat = 4 * D;
+  cg.dC2Q = c.act("d.cq.c2q"); cg.dQ2C = c.act("d.cq.q2c"); cg.dX = c.act("d.cq.x");
+  cg.dD1W = c.act("d.cq.d1w"); cg.dD2 = c.act("d.cq.d2"); cg.dS0 = c.vec("d.cq.s0"); cg.dS1 = c.vec("d.cq.s1");
+  cg.dM2 = c.buf("d.cq.m2", (size_t)2 * B * cq_m2_rows_host(T, L), D);
+  float* dXa = c.act("d.cq.xa");
+  float* dXb = c.act("d.cq.xb");
+  CqParams cqp{};
+  CqGrads cqg{};
+  for (int i = 0; i < 2; ++i) {
+    cqp.w0[i] = c.p(pm.cq[i].w0); cqp.w1[i] = c.p(pm.cq[i].w1); cqp.wm[i] = c.p(pm.cq[i].wm);
+    cqg.w0[i] = c.g(pm.cq[i].w0); cqg.w1[i] = c.g(pm.cq[i].w1); cqg.wm[i] = c.g(pm.cq[i].wm);
+  }
+  if (!c.dry && c.ok()) {
+    c.chk(launch_cq_bwd_pre(cq, cg, c.rs, c.stream));
+    if (c.ok()) c.chk(launch_cq_bwd_impl(cq, cg, c.rs, dXa, dXb, c.stream));
+    if (c.ok()) c.chk(launch_tri_bwd_impl(cq, cg, cqp, cqg, c.rs, c.drop, dXa, dXb, c.stream));
+  }
+  float* dx = cg.dX;
+  // ---------------- dual attention layers, last to first
+  for (int li = c.cfg->attn_layer - 1; li >= 0; --li) {
+    const DualAttnP& d = pm.da[li];
+    const std::string t = "da" + std::to_string(li);
+    const int site = HUAL_SITE_DA + 8 * li;
+    float* xin = li == 0 ? c.act("cb.x4") : c.act("da" + std::to_string(li - 1) + ".out");
+    float* ln1 = c.act(t + ".ln1");
+    float* lnt = c.act(t + ".lnt");
+    float* mean = c.vec(t + ".mean");
+    float* rstd = c.vec(t + ".rstd");
+    float* qkv = c.buf(t + ".qkv", R, 3 * D);
+    float* ktvt = c.buf(t + ".ktvt", R, 2 * D);
+    float* s_att = c.act(t + ".s_att");
+    float* x_att = c.act(t + ".x_att");
+    float* sv = c.act(t + ".s");
+    float* xv = c.act(t + ".x");
+    float* sg = c.act(t + ".sg");
+    float* xg = c.act(t + ".xg");
+    float* o = c.act(t + ".o");
+    float* gd = c.act(t + ".g");
+    float* gate = c.act(t + ".gate");
+    float* val = c.act(t + ".val");
+    float* mha = c.act(t + ".mha");
+    float* res = c.act(t + ".res");
+    float* l2 = c.act(t + ".l2");
+    float* mean2 = c.vec(t + ".mean2");
+    float* rstd2 = c.vec(t + ".rstd2");
+    const std::string dt = "d." + t;
+    // out = dropout(l2 . Wd2 + b, s4) + res
+    float* dz2 = c.act(dt + ".z2");
+    {
+      EwArgs e{};
+      e.op = EW_DROP; e.R = R; e.a = dx; e.out = dz2; e.drop_site = site + 4; e.drop_row0 = 0;
+      c.ew(e);
+    }
+    c.dwjobs.push_back(mkdw(l2, D, D, dz2, D, R, c.g(d.dense2.k), c.g(d.dense2.b)));
+    float* d_l2 = c.act(dt + ".l2");
+    {
+      GemmJob j = mkjob_dx(dz2, D, R, D, c.p(d.dense2.k), d_l2, D);
+      c.gemm(&j, 1);
+    }
+    float* d_res = c.act(dt + ".res");
+    {
+      LnBwd a{};
+      a.x = res; a.mean = mean2; a.rstd = rstd2; a.R = R; a.dy1 = d_l2; a.g1 = c.p(d.ln2.g); a.dg1 = c.g(d.ln2.g);
+      a.db1 = c.g(d.ln2.b); a.drop_site1 = site + 3; a.drop_row0 = 0; a.add1 = dx; a.dx = d_res;
+      c.ln_bwd(a);
+    }
+    // res = dropout(mha . Wd1 + b, s2) + xin
+    float* dz1 = c.act(dt + ".z1");
+    {
+      EwArgs e{};
+      e.op = EW_DROP; e.R = R; e.a = d_res; e.out = dz1; e.drop_site = site + 2; e.drop_row0 = 0;
+      c.ew(e);
+    }
+    c.dwjobs.push_back(mkdw(mha, D, D, dz1, D, R, c.g(d.dense1.k), c.g(d.dense1.b)));
+    float* d_mha = c.act(dt + ".mha");
+    {
+      GemmJob j = mkjob_dx(dz1, D, R, D, c.p(d.dense1.k), d_mha, D);
+      c.gemm(&j, 1);
+    }
+    // mha = gate * val
+    float* d_sc = c.act(dt + ".sc");
+    float* d_val = c.act(dt + ".val");
+    {
+      EwArgs e{};
+      e.op = EW_BILINEAR_BWD; e.R = R; e.a = d_mha; e.b = gate; e.c = val; e.out = d_sc; e.out2 = d_val; e.drop_site = -1;
+      c.ew(e);
+    }
+    for (int k = 0; k < 2; ++k) {
+      DwJob j = mkdw(ln1, D, D, k == 0 ? d_sc : d_val, D, R, c.g(k == 0 ? d.bl1_d1 : d.bl2_d1), c.g(k == 0 ? d.bl1_b : d.bl2_b));
+      j.npieces = 2; j.A[1] = gd; j.lda[1] = D; j.kw[1] = D; j.dW[1] = c.g(k == 0 ? d.bl1_d2 : d.bl2_d2);
+      c.dwjobs.push_back(j);
+    }
+    float* d_ln1a = c.act(dt + ".ln1a");
+    float* d_g = c.act(dt + ".g");
+    {
+      GemmJob j[2];
+      j[0] = mkjob_dx(d_sc, D, R, D, c.p(d.bl1_d1), d_ln1a, D);
+      j[0].npieces = 2; j[0].A[1] = d_val; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.p(d.bl2_d1);
+      j[1] = mkjob_dx(d_sc, D, R, D, c.p(d.bl1_d2), d_g, D);
+      j[1].npieces = 2; j[1].A[1] = d_val; j[1].lda[1] = D; j[1].kw[1] = D; j[1].W[1] = c.p(d.bl2_d2);
+      c.gemm(j, 2);
+    }
+    // g = o . Wg + b
+    c.dwjobs.push_back(mkdw(o, D, D, d_g, D, R, c.g(d.guided.k), c.g(d.guided.b)));
+    float* d_o = c.act(dt + ".o");
+    {
+      GemmJob j = mkjob_dx(d_g, D, R, D, c.p(d.guided.k), d_o, D);
+      c.gemm(&j, 1);
+    }
+    // o = sg * x + xg * s
+    float* dz_sg = c.act(dt + ".zsg");
+    float* dz_xg = c.act(dt + ".zxg");
+    float* ds_part = c.act(dt + ".sp");
+    float* dx_part = c.act(dt + ".xp");
+    {
+      EwArgs e{};
+      e.op = EW_GATE_BWD; e.R = R; e.a = d_o; e.b = sg; e.c = xg; e.d = sv; e.e = xv;
+      e.out = dz_sg; e.out2 = dz_xg; e.out3 = ds_part; e.out4 = dx_part; e.drop_site = -1;
+      c.ew(e);
+    }
+    c.dwjobs.push_back(mkdw(sv, D, D, dz_sg, D, R, c.g(d.s_gate.k), c.g(d.s_gate.b)));
+    c.dwjobs.push_back(mkdw(xv, D, D, dz_xg, D, R, c.g(d.x_gate.k), c.g(d.x_gate.b)));
+    float* d_sv = c.act(dt + ".s");
+    float* d_xv = c.act(dt + ".x");
+    {
+      GemmJob j[2];
+      j[0] = mkjob_dx(dz_sg, D, R, D, c.p(d.s_gate.k), d_sv, D);
+      j[0].add = ds_part; j[0].ldadd = D;
+      j[1] = mkjob_dx(dz_xg, D, R, D, c.p(d.x_gate.k), d_xv, D);
+      j[1].add = dx_part; j[1].ldadd = D;
+      c.gemm(j, 2);
+    }
+    c.dwjobs.push_back(mkdw(s_att, D, D, d_sv, D, R, c.g(d.s_dense.k), c.g(d.s_dense.b)));
+    c.dwjobs.push_back(mkdw(x_att, D, D, d_xv, D, R, c.g(d.x_dense.k), c.g(d.x_dense.b)));
+    float* d_satt = c.act(dt + ".s_att");
+    float* d_xatt = c.act(dt + ".x_att");
+    {
+      GemmJob j[2];
+      j[0] = mkjob_dx(d_sv, D, R, D, c.p(d.s_dense.k), d_satt, D);
+      j[1] = mkjob_dx(d_xv, D, R, D, c.p(d.x_dense.k), d_xatt, D);
+      c.gemm(j, 2);
+    }
+    // the four attentions
+    float* dq_self = c.act(dt + ".q_self");
+    float* dq_cross = c.act(dt + ".q_cross");
+    float* d_qkv = c.buf(dt + ".qkv", R, 3 * D);     // only the Kf / Vf column blocks are used
+    float* d_ktvt = c.buf(dt + ".ktvt", R, 2 * D);
+    float* stats = c.buf("attn.stats", (size_t)4 * 3, (size_t)R * 8);
+    {
+      AttnJob a[4];
+      for (int k = 0; k < 4; ++k) {
+        attn_job_init(a[k]);
+        a[k].Q = qkv; a[k].ldq = 3 * D; a[k].B = B; a[k].qmask = rowmask; a[k].kmask = rowmask; a[k].lddo = D; a[k].lddq = D;
+      }
+      a[0].K = qkv + D; a[0].V = qkv + 2 * D; a[0].ldkv = 3 * D; a[0].Tq = T; a[0].Tk = T; a[0].qrow0 = 0; a[0].krow0 = 0;
+      a[0].dO = d_satt; a[0].dQ = dq_self; a[0].dK = d_qkv + D; a[0].dV = d_qkv + 2 * D; a[0].lddkv = 3 * D; a[0].drop_site = site + 0;
+      a[1].K = ktvt; a[1].V = ktvt + D; a[1].ldkv = 2 * D; a[1].Tq = T; a[1].Tk = L; a[1].qrow0 = 0; a[1].krow0 = Nv;
+      a[1].dO = d_xatt; a[1].dQ = dq_cross; a[1].dK = d_ktvt; a[1].dV = d_ktvt + D; a[1].lddkv = 2 * D; a[1].drop_site = site + 1;
+      a[2].K = qkv + D; a[2].V = qkv + 2 * D; a[2].ldkv = 3 * D; a[2].Tq = L; a[2].Tk = L; a[2].qrow0 = Nv; a[2].krow0 = Nv;
+      a[2].dO = d_satt; a[2].dQ = dq_self; a[2].dK = d_qkv + D; a[2].dV = d_qkv + 2 * D; a[2].lddkv = 3 * D; a[2].drop_site = site + 0;
+      a[3].K = ktvt; a[3].V = ktvt + D; a[3].ldkv = 2 * D; a[3].Tq = L; a[3].Tk = T; a[3].qrow0 = Nv; a[3].krow0 = 0;
+      a[3].dO = d_xatt; a[3].dQ = dq_cross; a[3].dK = d_ktvt; a[3].dV = d_ktvt + D; a[3].lddkv = 2 * D; a[3].drop_site = site + 1;
+      c.attn_bwd(a, 4, stats, R * 8);
+    }
+    c.dwjobs.push_back(mkdw(ln1, D, D, dq_self, D, R, c.g(d.query.k), c.g(d.query.b)));
+    c.dwjobs.push_back(mkdw(ln1, D, D, dq_cross, D, R, c.g(d.query.k), c.g(d.query.b)));
+    c.dwjobs.push_back(mkdw(ln1, D, D, d_qkv + D, 3 * D, R, c.g(d.f_key.k), c.g(d.f_key.b)));
+    c.dwjobs.push_back(mkdw(ln1, D, D, d_qkv + 2 * D, 3 * D, R, c.g(d.f_value.k), c.g(d.f_value.b)));
+    c.dwjobs.push_back(mkdw(lnt, D, D, d_ktvt, 2 * D, R, c.g(d.t_key.k), c.g(d.t_key.b)));
+    c.dwjobs.push_back(mkdw(lnt, D, D, d_ktvt + D, 2 * D, R, c.g(d.t_value.k), c.g(d.t_value.b)));
+    float* d_ln1 = c.act(dt + ".ln1");
+    float* d_lnt = c.act(dt + ".lnt");
+    {
+      GemmJob j[2];
+      j[0] = mkjob_dx(dq_self, D, R, D, c.p(d.query.k), d_ln1, D);
+      j[0].npieces = 4;
+      j[0].A[1] = dq_cross; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.p(d.query.k);
+      j[0].A[2] = d_qkv + D; j[0].lda[2] = 3 * D; j[0].kw[2] = D; j[0].W[2] = c.p(d.f_key.k);
+      j[0].A[3] = d_qkv + 2 * D; j[0].lda[3] = 3 * D; j[0].kw[3] = D; j[0].W[3] = c.p(d.f_value.k);
+      j[0].add = d_ln1a; j[0].ldadd = D;
+      j[1] = mkjob_dx(d_ktvt, 2 * D, R, D, c.p(d.t_key.k), d_lnt, D);
+      j[1].npieces = 2;
+      j[1].A[1] = d_ktvt + D; j[1].lda[1] = 2 * D; j[1].kw[1] = D; j[1].W[1] = c.p(d.t_value.k);
+      c.gemm(j, 2);
+    }
+    float* d_xin = c.act(dt + ".in");
+    {
+      LnBwd a{};
+      a.x = xin; a.mean = mean; a.rstd = rstd; a.R = R; a.dy1 = d_ln1; a.g1 = c.p(d.ln1.g); a.dg1 = c.g(d.ln1.g);
+      a.db1 = c.g(d.ln1.b); a.drop_site1 = -1; a.dy2 = d_lnt; a.g2 = c.p(d.lnt.g); a.dg2 = c.g(d.lnt.g); a.db2 = c.g(d.lnt.b);
+      a.add1 = d_res; a.dx = d_xin;
+      c.ln_bwd(a);
+    }
+    dx = d_xin;
+  }
+  // ---------------- shared conv block, position table, input layer norms, projections
+  float* x0 = c.act("cb.x0");
+  float* d_x0 = conv_block_bwd(c, "cb", x0, dx, pm.cb, c.rs, HUAL_SITE_CONV);
+  if (!c.dry && c.ok()) c.chk(launch_pos_bwd(d_x0, c.g(pm.pos), c.rs, 1, 1, c.stream));
+  float* lin = c.act("lin");
+  float* lin_mean = c.vec("lin.mean");
+  float* lin_rstd = c.vec("lin.rstd");
+  float* d_lin = c.act("d.lin");
+  {
+    LnBwd a{};
+    a.x = lin; a.mean = lin_mean; a.rstd = lin_rstd; a.R = Nv; a.dy1 = d_x0; a.g1 = c.p(pm.vln.g); a.dg1 = c.g(pm.vln.g);
+    a.db1 = c.g(pm.vln.b); a.drop_site1 = -1; a.dx = d_lin;
+    c.ln_bwd(a);
+    const size_t ro = (size_t)Nv * D;
+    a.x = lin + ro; a.mean = lin_mean + Nv; a.rstd = lin_rstd + Nv; a.R = Nq; a.dy1 = d_x0 + ro; a.g1 = c.p(pm.qln.g);
+    a.dg1 = c.g(pm.qln.g); a.db1 = c.g(pm.qln.b); a.dx = d_lin + ro;
+    c.ln_bwd(a);
+  }
+  float* cat = c.buf("cat", Nq, catw);
+  {
+    DwJob j = mkdw(c.dry ? nullptr : bt->video, c.cfg->vdim, c.cfg->vdim, d_lin, D, Nv, c.g(pm.vconv.k), c.g(pm.vconv.b));
+    j.a_drop_site = HUAL_SITE_VIDEO; j.a_drop_row0 = 0;
+    c.dwjobs.push_back(j);
+    c.dwjobs.push_back(mkdw(cat, catw, catw, d_lin + (size_t)Nv * D, D, Nq, c.g(pm.qconv.k), c.g(pm.qconv.b)));
+  }
+  float* d_cat = c.buf("d.cat", Nq, catw);
+  {
+    GemmJob j = mkjob_dx(d_lin + (size_t)Nv * D, D, Nq, D, c.p(pm.qconv.k), d_cat, catw, catw);
+    c.gemm(&j, 1);
+  }
+  int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
+  if (!c.dry && c.ok()) {
+    EmbedArgs ea{};
+    ea.word_ids = bt->word_ids; ea.char_ids = bt->char_ids; ea.word_table = c.word_table; ea.unk = c.p(pm.unk);
+    ea.char_table = c.p(pm.char_table);
+    for (int i = 0; i < 4; ++i) { ea.filt[i] = c.p(pm.filt[i]); ea.fbias[i] = c.p(pm.fbias[i]); }
+    ea.cat = cat; ea.ldcat = catw; ea.char_arg = char_arg;
+    ea.word_dim = c.cfg->word_dim; ea.char_dim = c.cfg->char_dim; ea.C = c.C; ea.num_chars = c.cfg->num_chars;
+    EmbedGrads eg{};
+    eg.dcat = d_cat; eg.lddcat = catw; eg.dunk = c.g(pm.unk); eg.dchar_table = c.g(pm.char_table);
+    for (int i = 0; i < 4; ++i) { eg.dfilt[i] = c.g(pm.filt[i]); eg.dfbias[i] = c.g(pm.fbias[i]); }
+    c.chk(launch_embed_bwd(ea, eg, Nq, c.drop, c.stream));
+  }
+  // ---------------- all dense-layer weight gradients, as a few big launches
+  if (!c.dry && c.ok()) c.chk(launch_dw(c.dwjobs.data(), (int)c.dwjobs.size(), c.drop, 256, c.stream));
+  (void)opt;
+  return c.rc;
+}
+
+int plan(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
+  int rc = setup_ctx(c, cfg, B, T, L, C);
+  if (rc) return rc;
+  c.dry = true;
+  c.base = nullptr;
+  hual_run_opts o{};
+  rc = forward_graph(c, nullptr, nullptr, nullptr, &o);
+  if (rc) return rc;
+  return backward_graph(c, nullptr, nullptr, &o);
+}
+
+}  // namespace
+
+// ======================================================================================================
+// C ABI
+// ======================================================================================================
+extern "C" {
+
+int hual_seqpan_validate(const hual_cfg* cfg) {
+  HUAL_REQUIRE(cfg != nullptr, "null cfg");
+  return validate_cfg(*cfg);
+}
+
+int hual_seqpan_param_count(const hual_cfg* cfg, uint64_t* padded_floats, uint64_t* count) {
+  HUAL_REQUIRE(cfg != nullptr, "null cfg");
+  ParamMap pm;
+  int rc = build_param_map(*cfg, pm);
+  if (rc) return rc;
+  if (padded_floats) *padded_floats = pm.total;
+  if (count) *count = pm.count;
+  return 0;
+}
+
+int hual_seqpan_param_table(const hual_cfg* cfg, hual_param_entry* out, int max_entries) {
+  HUAL_REQUIRE(cfg != nullptr, "null cfg");
+  ParamMap pm;
+  int rc = build_param_map(*cfg, pm);
+  if (rc) return rc;
+  const int n = (int)pm.entries.size();
+  for (int i = 0; i < n && i < max_entries && out; ++i) {
+    const ParamEntry& e = pm.entries[i];
+    memset(&out[i], 0, sizeof(out[i]));
+    strncpy(out[i].name, e.name.c_str(), sizeof(out[i].name) - 1);
+    out[i].offset = e.off; out[i].size = e.size; out[i].ndim = e.ndim; out[i].decay = e.decay;
+    for (int k = 0; k < 4; ++k) out[i].shape[k] = e.shape[k];
+  }
+  return n;
+}
+
+int hual_seqpan_query_workspace(const hual_cfg* cfg, int B, int T, int L, int C, uint64_t* bytes) {
+  HUAL_REQUIRE(bytes != nullptr, "null bytes");
+  Ctx c;
+  int rc = plan(c, cfg, B, T, L, C);
+  if (rc) return rc;
+  *bytes = c.used + 4096;
+  return 0;
+}
+
+int hual_seqpan_ws_table(const hual_cfg* cfg, int B, int T, int L, int C, hual_ws_entry* out, int max_entries) {
+  Ctx c;
+  int rc = plan(c, cfg, B, T, L, C);
+  if (rc) return rc;
+  const int n = (int)c.entries.size();
+  for (int i = 0; i < n && i < max_entries && out; ++i) {
+    memset(&out[i], 0, sizeof(out[i]));
+    strncpy(out[i].name, c.entries[i].name.c_str(), sizeof(out[i].name) - 1);
+    out[i].offset = c.entries[i].off; out[i].rows = c.entries[i].rows; out[i].cols = c.entries[i].cols;
+  }
+  return n;
+}
+
+static int check_common(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts,
+                        void* workspace) {
+  HUAL_REQUIRE(cfg && params && batch && opts && workspace, "null argument");
+  HUAL_REQUIRE(batch->video && batch->video_seq_len && batch->word_ids && batch->char_ids, "null batch tensor");
+  HUAL_REQUIRE(opts->drop_rate >= 0.f && opts->drop_rate < 1.f, "drop_rate in [0,1)");
+  HUAL_REQUIRE(opts->drop_rate == 0.f || opts->rng_state != nullptr, "rng_state required when drop_rate > 0");
+  HUAL_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)params & 15) == 0, "workspace/params alignment");
+  return 0;
+}
+
+int hual_seqpan_forward(const hual_cfg* cfg, const float* params, const float* word_table, const hual_batch* batch,
+                        const hual_labels* labels, const hual_outputs* out, const hual_run_opts* opts, void* workspace,
+                        uint64_t ws_bytes, void* stream) {
+  int rc = check_common(cfg, params, batch, opts, workspace);
+  if (rc) return rc;
+  HUAL_REQUIRE(word_table != nullptr, "null word_table");
+  HUAL_REQUIRE(out && out->start_logits && out->end_logits && out->match_scores && out->start_index && out->end_index,
+               "null output tensor");
+  if (labels) HUAL_REQUIRE(labels->y1 && labels->y2 && labels->match_labels && labels->inner_labels, "null label tensor");
+  Ctx c;
+  rc = plan(c, cfg, batch->B, batch->T, batch->L, batch->C);
+  if (rc) return rc;
+  if (c.used + 4096 > ws_bytes) return fail(HUAL_ERR_WORKSPACE, "workspace too small: call hual_seqpan_query_workspace");
+  c.dry = false;
+  c.base = (char*)workspace;
+  c.stream = (hipStream_t)stream;
+  c.P = params;
+  c.word_table = word_table;
+  c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
+  rc = forward_graph(c, batch, labels, out, opts);
+  if (rc) return rc;
+  if (labels) {
+    // keep the matching probabilities for backward (the caller owns match_scores and may overwrite it)
+    float* probs = c.buf("match.probs", c.rs.Nv, 4);
+    HUAL_CHECK_HIP(hipMemcpyAsync(probs, out->match_scores, (size_t)c.rs.Nv * 4 * sizeof(float), hipMemcpyDeviceToDevice,
+                                  c.stream));
+  }
+  return 0;
+}
+
+int hual_seqpan_backward(const hual_cfg* cfg, const float* params, const float* word_table, const hual_batch* batch,
+                         const hual_labels* labels, const hual_run_opts* opts, float* grads, void* workspace,
+                         uint64_t ws_bytes, void* stream) {
+  int rc = check_common(cfg, params, batch, opts, workspace);
+  if (rc) return rc;
+  HUAL_REQUIRE(grads != nullptr && ((uintptr_t)grads & 15) == 0, "null/unaligned grads");
+  HUAL_REQUIRE(labels && labels->y1 && labels->y2 && labels->match_labels && labels->inner_labels, "null label tensor");
+  Ctx c;
+  rc = plan(c, cfg, batch->B, batch->T, batch->L, batch->C);
+  if (rc) return rc;
+  if (c.used + 4096 > ws_bytes) return fail(HUAL_ERR_WORKSPACE, "workspace too small: call hual_seqpan_query_workspace");
+  c.dry = false;
+  c.base = (char*)workspace;
+  c.stream = (hipStream_t)stream;
+  c.P = params;
+  c.G = grads;
+  c.word_table = word_table;
+  c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
+  c.rs.rowmask = c.vec("rowmask");
+  c.rsv.rowmask = c.rs.rowmask;
+  return backward_graph(c, batch, labels, opts);
+}
+
+int hual_adamw_clip_step(float* params, const float* grads, float* adam_m, float* adam_v, const float* decay,
+                         uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
+                         void* stream) {
+  AdamArgs a{params, const_cast<float*>(grads), adam_m, adam_v, decay, (size_t)n_padded, lr, clip_norm, grad_prescale, sqnorm};
+  return launch_adamw(a, (hipStream_t)stream);
+}
+
+int hual_align_loss(const float* that, const float* vhat, int Bg, float* scratch, float* d_that, float* d_vhat,
+                    float* loss, float grad_scale, void* stream) {
+  HUAL_REQUIRE(that && vhat && scratch && d_that && d_vhat && loss, "hual_align_loss: null pointer");
+  // loss accumulates into loss[0]: present it as an accumulator array whose LA_ALIGN slot is loss[0]
+  AlignSim as{that, vhat, Bg, scratch, scratch + (size_t)Bg * Bg, d_that, d_vhat, loss - LA_ALIGN, grad_scale};
+  return launch_align_sim(as, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+/* libhual_seqpan.so - C ABI of the MI355X-native SeqPAN hot path of renjie-liang/HUAL.
+ *
+ * The reference has no FFI, plugin or operator registry: its hot path is a TensorFlow-1 graph
+ * (/root/reference/models/model.py:7-122) entered only through `sess.run(fetches, feed_dict)` at
+ *   /root/reference/utils/runner_utils.py:147   [train_op, loss, start_index, end_index]
+ *   /root/reference/utils/runner_utils.py:166   [start_index, end_index]
+ *   /root/reference/utils/runner_utils.py:75-81 match_scores / [start_logits, end_logits]
+ * This header is the boundary a binding for that path would sit on: the feeds of
+ * model.py:15-27 (`_add_placeholders`) are `hual_batch` + `hual_labels`, the fetches are `hual_outputs`,
+ * `train_op` (models/ops.py:119-132) is hual_seqpan_backward + hual_adamw_clip_step.
+ *
+ * Conventions
+ *  - extern "C", plain C structs, plain pointers and sizes; no torch / C++ types.
+ *  - EVERY pointer is DEVICE memory owned by the caller (parameters, inputs, outputs, workspace);
+ *    the library never allocates, frees or synchronises.  All work is enqueued on `stream`
+ *    (a hipStream_t passed as void*), so a whole step can be captured into a hipGraph.
+ *  - return 0 on success, negative on error; message via hual_last_error() (thread local).
+ *    No C++ exception crosses the ABI.
+ *  - re-entrant: no global mutable state; one stream per device/rank is safe.
+ *  - kernels are specialised for gfx950 and model.dim = 128, num_heads = 8 (the value in both
+ *    configs/<task>/SeqPAN.yaml); other values are rejected by hual_seqpan_validate().
+ */
+#ifndef HUAL_SEQPAN_H
+#define HUAL_SEQPAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HUAL_ABI_VERSION 1
+
+#define HUAL_OK 0
+#define HUAL_ERR_INVALID (-1)
+#define HUAL_ERR_HIP (-2)
+#define HUAL_ERR_UNSUPPORTED (-3)
+#define HUAL_ERR_WORKSPACE (-4)
+
+/* dropout call-site ids (Philox counter word c2); mirrors oracle/philox.py SITE_* and DESIGN.md */
+#define HUAL_SITE_WORD 0
+#define HUAL_SITE_CHAR 1
+#define HUAL_SITE_VIDEO 2
+#define HUAL_SITE_CONV 3
+#define HUAL_SITE_DA 8
+#define HUAL_SITE_TRI 24
+#define HUAL_SITE_FE 32
+
+/* keys of configs/<task>/SeqPAN.yaml read by models/model.py (model.py:17,36-43,61,83,101,122) */
+typedef struct hual_cfg {
+  int32_t vdim;        /* model.vdim      */
+  int32_t dim;         /* model.dim  (128) */
+  int32_t num_heads;   /* model.num_heads (8) */
+  int32_t word_dim;    /* model.word_dim  */
+  int32_t char_dim;    /* model.char_dim  */
+  int32_t max_vlen;    /* model.max_vlen = rows of both position tables */
+  int32_t attn_layer;  /* model.attn_layer */
+  int32_t num_chars;   /* configs.num_chars */
+  int32_t num_words;   /* rows of [zero; unk; word_table] */
+  int32_t no_gumbel;   /* loss.no_gumbel (must be 1; both YAMLs set true) */
+  float match_lambda;  /* loss.match_lambda */
+  float tau;           /* loss.tau (unused when no_gumbel) */
+  float clip_norm;     /* train.clip_norm */
+} hual_cfg;
+
+int hual_abi_version(void);
+const char* hual_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Parameters.  One flat fp32 device buffer in the layout reported by hual_seqpan_param_table():
+ * every trainable TF variable of models/model.py under its TF scope name and TF
+ * shape, each tensor 16-byte aligned.  Gradients and both Adam slots use the same layout.
+ * The frozen GloVe table `word_embs/word_table` [num_words-2, word_dim] (modules.py:10) is separate.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hual_param_entry {
+  char name[112];
+  uint64_t offset;       /* in floats */
+  uint64_t size;         /* in floats */
+  int32_t ndim;
+  int32_t shape[4];
+  int32_t decay;         /* 1: AdamWeightDecay applies weight decay (ops.py:123,176-184) */
+} hual_param_entry;
+
+int hual_seqpan_validate(const hual_cfg* cfg);
+/* *padded_floats = size of the flat buffer, *count = number of trainable scalars (1,186,508 for Charades) */
+int hual_seqpan_param_count(const hual_cfg* cfg, uint64_t* padded_floats, uint64_t* count);
+/* returns the number of entries (fills at most max_entries) or a negative error */
+int hual_seqpan_param_table(const hual_cfg* cfg, hual_param_entry* out, int max_entries);
+
+/* feeds of model.py:15-27 (`_add_placeholders`); all device pointers */
+typedef struct hual_batch {
+  const float* video;             /* video_inputs  f32 [B,T,vdim], rows beyond video_seq_len zero padded */
+  const int32_t* video_seq_len;   /* [B]; max must equal T (model.py:31) */
+  const int32_t* word_ids;        /* [B,L], 0 = PAD, 1 = unk */
+  const int32_t* char_ids;        /* [B,L,C], 0 = PAD, C >= 4 */
+  int32_t B, T, L, C;
+} hual_batch;
+
+typedef struct hual_labels {
+  const float* y1;                /* start_indexes f32 [B,T] (soft labels) */
+  const float* y2;                /* end_indexes   f32 [B,T] */
+  const int32_t* match_labels;    /* i32 [B,T] in 0..3 */
+  const float* inner_labels;      /* f32 [B,T] */
+} hual_labels;
+
+/* fetches used by runner_utils.py:75-81,147,166 */
+typedef struct hual_outputs {
+  float* start_logits;            /* f32 [B,T] raw (unmasked beyond v_len, as the reference) */
+  float* end_logits;              /* f32 [B,T] */
+  float* match_scores;            /* f32 [B,T,4] */
+  int64_t* start_index;           /* i64 [B] */
+  int64_t* end_index;             /* i64 [B] */
+  float* loss_terms;              /* f32 [4]: loss, loc_loss, match_loss, align_loss (written only with labels) */
+} hual_outputs;
+
+typedef struct hual_run_opts {
+  float drop_rate;                /* the `dropout_rate` placeholder (0 = inference) */
+  const uint32_t* rng_state;      /* device u32[3] = {seed lo, seed hi, offset}; may be NULL when drop_rate == 0 */
+  float match_denom_override;     /* > 0: denominator of the masked matching loss (exact data parallel) */
+  int32_t align_external;         /* 1: the [B,B] alignment loss is evaluated by the caller through
+                                        hual_align_loss() on gathered features (exact data parallel) */
+} hual_run_opts;
+
+/* bytes of workspace needed for one forward(+backward) of this shape */
+int hual_seqpan_query_workspace(const hual_cfg* cfg, int B, int T, int L, int C, uint64_t* bytes);
+
+/* named intermediate tensors inside the workspace (debugging / parity taps) */
+typedef struct hual_ws_entry {
+  char name[48];
+  uint64_t offset;       /* bytes */
+  uint64_t rows, cols;   /* fp32 elements */
+} hual_ws_entry;
+int hual_seqpan_ws_table(const hual_cfg* cfg, int B, int T, int L, int C, hual_ws_entry* out, int max_entries);
+
+/* the graph of model.py:29-118: all five fetch tensors in ONE pass (the reference runs five).  With `labels`
+ * it also evaluates model.py:76-120 (losses) and keeps what backward needs in the workspace. */
+int hual_seqpan_forward(const hual_cfg* cfg, const float* params, const float* word_table, const hual_batch* batch,
+                        const hual_labels* labels, const hual_outputs* out, const hual_run_opts* opts, void* workspace,
+                        uint64_t ws_bytes, void* stream);
+
+/* tf.gradients(loss, tvars) (ops.py:126): fills `grads` (flat layout, overwritten).  Must follow a forward with
+ * labels on the same workspace, batch and rng_state. */
+int hual_seqpan_backward(const hual_cfg* cfg, const float* params, const float* word_table, const hual_batch* batch,
+                         const hual_labels* labels, const hual_run_opts* opts, float* grads, void* workspace,
+                         uint64_t ws_bytes, void* stream);
+
+/* clip_by_global_norm + AdamWeightDecayOptimizer.apply_gradients (ops.py:127-132,149-174).
+ * decay: per-element weight decay rate in the flat layout; lr: device scalar; grad_prescale multiplies the
+ * gradient first (1/world after a sum all-reduce); sqnorm: device scalar scratch. */
+int hual_adamw_clip_step(float* params, const float* grads, float* adam_m, float* adam_v, const float* decay,
+                         uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
+                         void* stream);
+
+/* cross-sample part of lossfun_aligment (layers.py:232-247) on [Bg,128] l2-normalised features
+ * (all-gathered over ranks in exact data-parallel mode).  scratch: 2*Bg*Bg floats.
+ * Writes d_that / d_vhat [Bg,128] (scaled by grad_scale) and ADDS the loss to *loss (device scalar). */
+int hual_align_loss(const float* that, const float* vhat, int Bg, float* scratch, float* d_that, float* d_vhat,
+                    float* loss, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel entry points (unit parity tests call these through ctypes).
+ * ------------------------------------------------------------------------------------------ */
+
+/* conv1d(kernel_size=1) == dense  (models/layers.py:20-29):
+ *   Y[M,N] = act(A[M,K] . W + bias),  W is [K,N] (trans_w=0) or [N,K] read transposed (trans_w=1, = dX of a dense)
+ *   act: 0 none, 1 relu, 2 sigmoid.  K % 16 == 0, N % 64 == 0, leading dims % 4 == 0. */
+int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, int trans_w, const float* bias, float* Y,
+                    int ldy, int M, int K, int N, int act, void* stream);
+
+/* gradients of the dense above: dW[K,N] += A^T . dY ; db[N] += colsum(dY) (db may be NULL).
+ * Accumulates with float atomics: zero the destinations first. */
+int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
+                   int N, int rows_per_wave, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HUAL_SEQPAN_H */

@@ -1,0 +1,141 @@
+"""Shared helpers for the GPU parity tests: run the CPU oracle and the HIP path on the same seeded inputs and
+report per-tensor differences (outputs, named intermediates, losses, gradients)."""
+import collections
+
+import numpy as np
+import torch
+
+from oracle import seqpan_ref as R
+
+
+def make_case(B=3, T=20, L=6, C=5, seed=3, max_vlen=32, num_words=60, vdim=1024, char_dim=50, param_seed=1):
+    cfg = R.default_cfg(max_vlen=max_vlen, num_words=num_words, vdim=vdim, char_dim=char_dim)
+    p = R.init_params(cfg, seed=param_seed)
+    # biases / LN offsets start at exactly 0 / 1 in the reference; perturb them so their gradients and uses are tested
+    g = np.random.default_rng(param_seed + 100)
+    for k in p:
+        if k.endswith('bias') or 'bias_' in k or k.endswith('layer_norm_scale'):
+            p[k] = p[k] + torch.tensor(g.normal(0, 0.05, size=tuple(p[k].shape)), dtype=torch.float32)
+    # label_emb starts exactly orthogonal, where the gradient of ||offdiag(E E^T)||_F is pure rounding noise
+    p['label_emb'] = p['label_emb'] + torch.tensor(g.normal(0, 0.1, size=tuple(p['label_emb'].shape)), dtype=torch.float32)
+    wv = R.init_word_vectors(cfg)
+    b = R.synthetic_batch(cfg, B, T, L, C, seed=seed)
+    # make sure some spans are long enough to have inner (I-M) frames, otherwise v_hat == 0
+    lens = b['lens'].numpy()
+    for k in range(0, B, 2):
+        b['s_ind'][k] = 1
+        b['e_ind'][k] = int(lens[k]) - 2
+    from hual_amd import data
+    y1, y2, m, i = data.make_labels(b['s_ind'], b['e_ind'], b['lens'].numpy(), max_len=T)
+    labels = (torch.tensor(y1), torch.tensor(y2), torch.tensor(m), torch.tensor(i, dtype=torch.float32))
+    return cfg, p, wv, b, labels
+
+
+def unify(tap, name, B, T, L):
+    v = tap[name + '.v'].reshape(B * T, -1)
+    q = tap[name + '.q'].reshape(B * L, -1)
+    return torch.cat([v, q], dim=0)
+
+
+def oracle_run(cfg, p, wv, b, labels, drop_rate=0.0, seed=0, offset=0, dtype=torch.float32, with_grads=True):
+    pr = collections.OrderedDict((k, t.detach().clone().to(dtype).requires_grad_(with_grads)) for k, t in p.items())
+    out = R.forward(pr, cfg, wv.to(dtype), b['video'].to(dtype), b['lens'], b['word_ids'], b['char_ids'], drop_rate=drop_rate,
+                    seed=seed, offset=offset, labels=labels, want_tap=True)
+    grads = None
+    if with_grads:
+        names = list(pr.keys())
+        gl = torch.autograd.grad(out['loss'], [pr[k] for k in names], allow_unused=True)
+        grads = {k: (g if g is not None else torch.zeros_like(pr[k])).detach() for k, g in zip(names, gl)}
+    return out, grads
+
+
+def hip_model(cfg, p, wv, device='cuda:0'):
+    from hual_amd import lib
+    from hual_amd.model import SeqPAN
+    hc = lib.make_cfg(vdim=cfg.vdim, dim=cfg.dim, num_heads=cfg.num_heads, word_dim=cfg.word_dim, char_dim=cfg.char_dim,
+                      max_vlen=cfg.max_vlen, attn_layer=cfg.attn_layer, num_chars=cfg.num_chars, num_words=cfg.num_words,
+                      match_lambda=cfg.match_lambda, clip_norm=cfg.clip_norm)
+    m = SeqPAN(hc, wv.numpy(), device=device)
+    m.load_state_dict({k: v.detach().numpy() for k, v in p.items()})
+    return m
+
+
+def tap_pairs(o_tap, B, T, L, n_layers=2):
+    """(hip workspace name, oracle tensor flattened to [rows, cols])"""
+    pairs = []
+    Nv = B * T
+
+    def add_u(h, o):
+        pairs.append((h, unify(o_tap, o, B, T, L)))
+
+    pairs.append(('cat', o_tap['cat'].reshape(B * L, -1)))
+    pairs.append(('lin[v]', o_tap['vlin'].reshape(Nv, -1)))
+    add_u('cb.x0', 'cb.x0')
+    for i in range(4):
+        add_u('cb.c%d' % i, 'cb.c%d' % i)
+        add_u('cb.y%d' % i, 'cb.y%d' % i)
+        add_u('cb.x%d' % (i + 1), 'cb.x%d' % (i + 1))
+    for li in range(n_layers):
+        for n in ('s_att', 'x_att', 's', 'x', 'g', 'mha', 'res', 'out'):
+            add_u('da%d.%s' % (li, n), 'da%d.%s' % (li, n))
+    pairs.append(('cq.c2q', torch.cat([o_tap['q2v_attn.c2q'].reshape(Nv, -1), o_tap['v2q_attn.c2q'].reshape(B * L, -1)])))
+    pairs.append(('cq.q2c', torch.cat([o_tap['q2v_attn.q2c'].reshape(Nv, -1), o_tap['v2q_attn.q2c'].reshape(B * L, -1)])))
+    pairs.append(('cq.feats', torch.cat([o_tap['q2v'].reshape(Nv, -1), o_tap['v2q'].reshape(B * L, -1)])))
+    pairs.append(('fuse', o_tap['fuse'].reshape(Nv, -1)))
+    pairs.append(('outputs', o_tap['outputs'].reshape(Nv, -1)))
+    if 't_hat' in o_tap:
+        pairs.append(('align.that', o_tap['t_hat']))
+        pairs.append(('align.vhat', o_tap['v_hat']))
+    for ps in range(2):
+        for i in range(4):
+            pairs.append(('fe%d.c%d' % (ps, i), o_tap['fe%d.c%d' % (ps, i)].reshape(Nv, -1)))
+            pairs.append(('fe%d.x%d' % (ps, i + 1), o_tap['fe%d.x%d' % (ps, i + 1)].reshape(Nv, -1)))
+        pairs.append(('fe%d.res' % ps, o_tap['fe%d.res' % ps].reshape(Nv, -1)))
+        pairs.append(('fe%d.out' % ps, o_tap['fe%d.out' % ps].reshape(Nv, -1)))
+    return pairs
+
+
+def compare(cfg, p, wv, b, labels, drop_rate=0.0, seed=5, offset=7, with_grads=True, device='cuda:0'):
+    """returns (report rows [(kind, name, maxabs_diff, ref_maxabs)], oracle out, hip out)"""
+    B, T = b['video'].shape[:2]
+    L = b['word_ids'].shape[1]
+    o_out, o_grads = oracle_run(cfg, p, wv, b, labels, drop_rate, seed, offset, with_grads=with_grads)
+    m = hip_model(cfg, p, wv, device)
+    m.set_rng(seed, offset)
+    h_out = m.forward(b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(),
+                      drop_rate=drop_rate, labels=tuple(x.numpy() for x in labels))
+    torch.cuda.synchronize()
+    rows = []
+
+    def add(kind, name, hip, ref):
+        hip = hip.detach().double().cpu().reshape(-1)
+        ref = ref.detach().double().cpu().reshape(-1)
+        rows.append((kind, name, float((hip - ref).abs().max()), float(ref.abs().max())))
+
+    for hname, ref in tap_pairs(o_out['tap'], B, T, L, cfg.attn_layer):
+        if hname == 'lin[v]':
+            add('tap', hname, m.tap('lin')[:B * T], ref)
+        else:
+            add('tap', hname, m.tap(hname), ref)
+    for k in ('start_logits', 'end_logits', 'match_scores'):
+        add('out', k, h_out[k], o_out[k])
+    for k in ('loss', 'loc_loss', 'match_loss', 'align_loss'):
+        add('loss', k, h_out[k], o_out[k])
+    idx_equal = bool(torch.equal(h_out['start_index'].cpu(), o_out['start_index']) and
+                     torch.equal(h_out['end_index'].cpu(), o_out['end_index']))
+    if with_grads:
+        m.backward()
+        torch.cuda.synchronize()
+        hg = m.grads_dict()
+        for k, gref in o_grads.items():
+            add('grad', k, torch.from_numpy(hg[k]), gref)
+    return rows, idx_equal, o_out, h_out, m
+
+
+def format_report(rows):
+    lines = []
+    for kind, name, d, r in rows:
+        rel = d / max(r, 1e-30)
+        flag = '' if (d <= 1e-3 or rel <= 1e-3) else '   <<<<<<'
+        lines.append('%-5s %-70s diff %.3e  ref %.3e  rel %.2e%s' % (kind, name, d, r, rel, flag))
+    return '\n'.join(lines)

@@ -1,0 +1,31 @@
+"""End-to-end GPU parity: HIP SeqPAN (through the C ABI) vs the CPU oracle on identical seeded inputs.
+Tolerance 1e-3 (north_star), span argmax indices bit exact."""
+import pytest
+import torch
+
+import parity_util as pu
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _assert_rows(rows, kinds):
+    bad = [(k, n, d, r) for (k, n, d, r) in rows if k in kinds and not (d <= TOL or d <= TOL * r)]
+    assert not bad, 'parity failures:\n' + pu.format_report(bad)
+
+
+@pytest.mark.parametrize('drop', [0.0, 0.2])
+def test_forward_backward_parity_small(drop):
+    case = pu.make_case()
+    rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=drop)
+    _assert_rows(rows, ('tap', 'out', 'loss'))
+    assert idx_equal
+    _assert_rows(rows, ('grad',))
+
+
+def test_ragged_shapes_parity():
+    # T, L not multiples of 16; C = 4 (minimum); one clip of length 1-ish neighbours
+    case = pu.make_case(B=5, T=37, L=9, C=4, seed=11, max_vlen=40)
+    rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.1)
+    _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
+    assert idx_equal
