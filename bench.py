@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SeqPAN train clips/sec on MI355X (BASELINE.json metric).
+
+A "step" = one sess.run([train_op, loss, start_index, end_index]) of the reference
+(/root/reference/utils/runner_utils.py:147): forward + backward + clip_by_global_norm + AdamWeightDecay on one
+synthetic batch that is already resident in HBM, with the reference's training dropout (train.droprate 0.2).
+Workload at N=1: BASELINE.json configs[1]  (batch 64, T=128, vdim 1024, L=20, C=8, dim 128, 8 heads, 2 attention
+layers).  N>1: one process per GPU (torch.distributed, RCCL), weak scaling (64 clips per GPU), gradients averaged
+with one flat all-reduce per step.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     - dominant kernel family, measured live with HIP events through hual_prof_begin/end
+  cpu_baseline - the CPU oracle (oracle/seqpan_ref.py, "port") timed on this host on a bounded sample
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(B, T, L, C, vdim, num_words, num_chars, seed):
+    g = np.random.default_rng(seed)
+    lens = g.integers((T + 1) // 2, T + 1, size=B).astype(np.int32)
+    lens[g.integers(0, B)] = T
+    video = g.standard_normal((B, T, vdim)).astype(np.float32)
+    for b in range(B):
+        video[b, lens[b]:] = 0.0
+    qlens = g.integers(3, L + 1, size=B)
+    qlens[g.integers(0, B)] = L
+    word_ids = np.zeros((B, L), dtype=np.int32)
+    char_ids = np.zeros((B, L, C), dtype=np.int32)
+    for b in range(B):
+        word_ids[b, :qlens[b]] = g.integers(2, num_words, size=qlens[b])
+        for l in range(qlens[b]):
+            cl = g.integers(1, C + 1)
+            char_ids[b, l, :cl] = g.integers(1, num_chars, size=cl)
+    s = np.array([g.integers(0, lens[b] - 1) for b in range(B)])
+    e = np.array([g.integers(s[b] + 1, lens[b]) for b in range(B)])
+    from hual_amd import data
+    y1, y2, m, i = data.make_labels(s, e, lens, max_len=T)
+    return dict(video=video, lens=lens, word_ids=word_ids, char_ids=char_ids, y1=y1, y2=y2, match=m,
+                inner=i.astype(np.float32))
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """oracle train step (fwd + bwd + AdamWD) at BASELINE configs[0] shape: B16 T64 vdim1024 fp32."""
+    from oracle import seqpan_ref as R
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    torch.set_num_threads(max(1, min(ncores, 64)))
+    print('[bench] cpu baseline on %d threads (affinity %d, cpu_count %d)' % (torch.get_num_threads(), ncores, os.cpu_count()), file=sys.stderr, flush=True)
+    cfg = R.default_cfg(max_vlen=64, num_words=1000)
+    p = R.init_params(cfg, seed=12345)
+    wv = R.init_word_vectors(cfg)
+    b = synth_batch(16, 64, 20, 8, cfg.vdim, cfg.num_words, cfg.num_chars, 12345)
+    batch = (torch.tensor(b['video']), torch.tensor(b['lens']), torch.tensor(b['word_ids']), torch.tensor(b['char_ids']))
+    labels = (torch.tensor(b['y1']), torch.tensor(b['y2']), torch.tensor(b['match']), torch.tensor(b['inner']))
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    R.train_step(p, m, v, cfg, wv, batch, labels, 1e-4, 0.2, seed=1, offset=0)      # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        p, m, v, _ = R.train_step(p, m, v, cfg, wv, batch, labels, 1e-4, 0.2, seed=1, offset=n + 1)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget or n >= 200:
+            break
+    return dict(value=round(16 * n / dt, 2), unit='clips/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d train steps (fwd+bwd+AdamWD, dropout 0.2) of the PyTorch-CPU oracle at B16 T64 vdim1024 L20 fp32, %.1f s'
+                       % (n, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
+    ap.add_argument('--T', type=int, default=128)
+    ap.add_argument('--L', type=int, default=20)
+    ap.add_argument('--C', type=int, default=8)
+    ap.add_argument('--vdim', type=int, default=1024)
+    ap.add_argument('--drop', type=float, default=0.2)
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+    from hual_amd import lib
+    from hual_amd.model import SeqPAN
+    from hual_amd.train import Trainer
+
+    num_words, num_chars = 1000, 40
+    cfg = lib.make_cfg(vdim=args.vdim, max_vlen=max(args.T, args.L), num_words=num_words, num_chars=num_chars)
+    wv = np.random.default_rng(777).normal(0, 0.4, size=(num_words - 2, 300)).astype(np.float32)
+    model = SeqPAN(cfg, wv, device=dev, seed=12345, rng_seed=12345 + rank)
+    b = synth_batch(args.batch, args.T, args.L, args.C, args.vdim, num_words, num_chars, 12345 + rank)
+    trainer = Trainer(model, world=world, use_graph=not args.no_graph)
+    trainer.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'])
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(lr=1e-4, drop_rate=args.drop)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(lr=1e-4, drop_rate=args.drop)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(trainer.last_loss())
+    clips = args.batch * world * args.steps
+
+    roof = None
+    print('[bench] timed region done: %.3f ms/step' % (dt / args.steps * 1e3), file=sys.stderr, flush=True)
+    if rank == 0 and not args.no_roofline:
+        # roofline leg: same step, launched eagerly, every launch of every kernel family bracketed by HIP events
+        l = lib.load()
+        l.hual_prof_kind_name.restype = ctypes.c_char_p
+        n = 15
+        eager = Trainer(model, world=1, use_graph=False)
+        eager.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'])
+        eager.step(lr=1e-4, drop_rate=args.drop)
+        torch.cuda.synchronize()
+        l.hual_prof_begin()
+        psteps = 5
+        for _ in range(psteps):
+            eager.step(lr=1e-4, drop_rate=args.drop)
+        launches = (ctypes.c_int64 * n)()
+        usec = (ctypes.c_double * n)()
+        flops = (ctypes.c_double * n)()
+        byts = (ctypes.c_double * n)()
+        l.hual_prof_end(launches, usec, flops, byts, n)
+        fam = [dict(kernel=l.hual_prof_kind_name(i).decode(), launches=int(launches[i]), us=usec[i], flops=flops[i],
+                    bytes=byts[i]) for i in range(n) if launches[i] > 0]
+        fam.sort(key=lambda d: -d['us'])
+        total_us = sum(d['us'] for d in fam)
+        top = fam[0]
+        if top['flops'] > 0:
+            ach = top['flops'] / top['us'] / 1e6      # TFLOP/s
+            roof = dict(bound='mfma', kernel=top['kernel'], achieved=round(ach, 2), peak=PEAK_F32_MATRIX_TFLOPS,
+                        unit='TFLOP/s', frac=round(ach / PEAK_F32_MATRIX_TFLOPS, 4), traffic=None,
+                        avg_launch_us=round(top['us'] / top['launches'], 2), launches_per_step=top['launches'] // psteps,
+                        share_of_kernel_time=round(top['us'] / total_us, 3))
+        else:
+            ach = top['bytes'] / top['us'] / 1e3      # GB/s
+            roof = dict(bound='hbm', kernel=top['kernel'], achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                        frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, avg_launch_us=round(top['us'] / top['launches'], 2),
+                        launches_per_step=top['launches'] // psteps, share_of_kernel_time=round(top['us'] / total_us, 3))
+        roof['families'] = [dict(kernel=d['kernel'], launches_per_step=d['launches'] // psteps,
+                                 us_per_step=round(d['us'] / psteps, 1),
+                                 tflops=round(d['flops'] / d['us'] / 1e6, 2) if d['flops'] > 0 else None) for d in fam]
+    print('[bench] roofline leg done', file=sys.stderr, flush=True)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = dict(metric='train clips/sec', value=round(clips / dt, 2), unit='clips/s', n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
+                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload='Charades-STA SeqPAN train step (fwd+bwd+clip+AdamWD, dropout %.1f), batch %d/GPU, '
+                                        'T=%d, vdim=%d, L=%d, C=%d, dim=128, 8 heads, 2 attention layers, random init'
+                                        % (args.drop, args.batch, args.T, args.vdim, args.L, args.C),
+                               global_batch=args.batch * world, T=args.T, vdim=args.vdim, L=args.L,
+                               parallelism='dp%d' % world, launch='eager' if args.no_graph else 'hipGraph',
+                               final_loss=round(loss, 4)),
+                   roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

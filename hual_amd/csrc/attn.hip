@@ -9,6 +9,7 @@
 // The backward dK/dV kernel uses the mirrored orientation (S = Q.K^T, lane holds 4 queries x 1 key).
 #include "attn.h"
 #include "philox.h"
+#include "prof.h"
 #include <string.h>
 
 using namespace hual;
@@ -333,6 +334,9 @@ int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
   for (int i = 0; i < n; ++i) b.j[i] = jobs[i];
   dim3 grid(cdiv(cdiv(maxTq, 16), 4), maxB * 8, n), block(256);
   const int nkt = cdiv(maxTk, 16);
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) flops += 4.0 * jobs[i].B * 8.0 * jobs[i].Tq * jobs[i].Tk * 16.0;   // QK^T + PV
+  ProfScope ps(PK_ATTN_FWD, s, flops, 0.0);
   if (nkt <= 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, 0, s, b, drop);
   else if (nkt <= 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, 0, s, b, drop);
   else if (nkt <= 8) hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, block, 0, s, b, drop);
@@ -352,12 +356,18 @@ int launch_attn_bwd_impl(const AttnJob* jobs, int n, const DropCfg& drop, float*
   for (int i = 0; i < n; ++i) b.j[i] = jobs[i];
   dim3 grid(cdiv(cdiv(maxTq, 16), 4), maxB * 8, n), block(256);
   const int nkt = cdiv(maxTk, 16);
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) flops += 2.0 * jobs[i].B * 8.0 * jobs[i].Tq * jobs[i].Tk * 16.0;
+  {
+  ProfScope ps(PK_ATTN_BWD_DQ, s, 3.0 * flops, 0.0);   // S, dP, dQ
   if (nkt <= 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, block, 0, s, b, drop, stats, stat_n);
   else if (nkt <= 4) hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, block, 0, s, b, drop, stats, stat_n);
   else if (nkt <= 8) hipLaunchKernelGGL(attn_bwd_dq_kernel<8>, grid, block, 0, s, b, drop, stats, stat_n);
   else hipLaunchKernelGGL(attn_bwd_dq_kernel<16>, grid, block, 0, s, b, drop, stats, stat_n);
+  }
   HUAL_CHECK_HIP(hipGetLastError());
   dim3 grid2(cdiv(cdiv(maxTk, 16), 4), maxB * 8, n);
+  ProfScope ps2(PK_ATTN_BWD_DKV, s, 4.0 * flops, 0.0);   // S, dP, dK, dV
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid2, block, 0, s, b, drop, (const float*)stats, stat_n);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

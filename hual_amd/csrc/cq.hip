@@ -3,6 +3,7 @@
 // K-contiguous (float4 fragment loads) or K-strided (4 scalar loads) - same fragment maps as gemm.hip/attn.hip.
 #include "cq.h"
 #include "philox.h"
+#include "prof.h"
 
 using namespace hual;
 
@@ -420,6 +421,7 @@ int launch_cq_fwd(const CqBufs& b, const RowSpace& rs, hipStream_t s) {
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)cq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
+  ProfScope ps(PK_CQ, s, 2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0);
   hipLaunchKernelGGL(cq_fwd_kernel, dim3(rs.B, 2), dim3(256), bytes, s, b, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
@@ -442,6 +444,7 @@ int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, 
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)cq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
+  ProfScope ps(PK_CQ, s, 2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0);
   hipLaunchKernelGGL(cq_bwd_kernel, dim3(rs.B, 2), dim3(256), bytes, s, b, g, rs, dXa, dXb);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

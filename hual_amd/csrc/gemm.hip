@@ -15,6 +15,7 @@
 // atomic shape of MI355X_MICROARCH.md "Global float atomics").
 #include "gemm.h"
 #include "philox.h"
+#include "prof.h"
 #include <string.h>
 
 namespace hual {
@@ -371,6 +372,15 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
   for (int i = 0; i < n; ++i)
     HUAL_REQUIRE((jobs[i].comb != COMB_NONE) == dual, "launch_gemm: cannot mix dual and single jobs in one launch");
   dim3 grid(cdiv(maxM, 32), cdiv(maxN, 128), n), block(256);
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double kt = 0.0;
+    for (int p = 0; p < jobs[i].npieces; ++p) kt += jobs[i].kw[p];
+    const double mult = dual ? 2.0 : 1.0;
+    flops += 2.0 * jobs[i].M * kt * jobs[i].N * mult;
+    bytes += 4.0 * ((double)jobs[i].M * kt + kt * jobs[i].N * mult + (double)jobs[i].M * jobs[i].N);
+  }
+  ProfScope ps(dual ? PK_GEMM_DUAL : PK_GEMM, stream, flops, bytes);
   if (dual)
     hipLaunchKernelGGL(gemm_kernel<true>, grid, block, 0, stream, b, drop);
   else
@@ -402,6 +412,15 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_wave, 
       maxTiles = tiles > maxTiles ? tiles : maxTiles;
     }
     dim3 grid(cdiv(maxM, rows_per_wave * 4), maxTiles, cnt), block(256);
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < cnt; ++i) {
+      const DwJob& j = jobs[base + i];
+      double kt = 0.0;
+      for (int p = 0; p < j.npieces; ++p) kt += j.kw[p];
+      flops += 2.0 * j.M * kt * j.N;
+      bytes += 4.0 * ((double)j.M * kt + (double)j.M * j.N + kt * j.N);
+    }
+    ProfScope ps(PK_DW, stream, flops, bytes);
     hipLaunchKernelGGL(dw_kernel, grid, block, 4 * 4096 * sizeof(float), stream, b, drop, rows_per_wave);
     HUAL_CHECK_HIP(hipGetLastError());
   }

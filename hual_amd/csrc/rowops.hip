@@ -2,6 +2,7 @@
 // works on 8 rows at a time; row reductions are wave shuffles inside a 32-lane half (no LDS, no barrier).
 #include "rowops.h"
 #include "philox.h"
+#include "prof.h"
 
 using namespace hual;
 
@@ -293,6 +294,7 @@ static inline int row_grid(int R) {
 
 int launch_ln_fwd(const LnFwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.x && a.g1 && a.b1 && a.y1 && a.R > 0, "ln_fwd: null/empty");
+  ProfScope ps(PK_LN_FWD, s, 0.0, 8.0 * a.R * HUAL_D);
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(row_grid(a.R)), dim3(256), 0, s, a, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
@@ -302,6 +304,7 @@ int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.x && a.mean && a.rstd && a.dy1 && a.g1 && a.dx && a.R > 0, "ln_bwd: null/empty");
   int g = cdiv(a.R, 8);
   g = g < 512 ? g : 512;
+  ProfScope ps(PK_LN_BWD, s, 0.0, 12.0 * a.R * HUAL_D);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(256), 0, s, a, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
@@ -311,6 +314,7 @@ static int conv_blocks(const RowSpace& rs) { return rs.B * cdiv(rs.T, SEG) + (rs
 
 int launch_ln_dwconv_fwd(const ConvFwd& a, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(a.x && a.g && a.b && a.dw && a.c && a.mean && a.rstd, "ln_dwconv_fwd: null");
+  ProfScope ps(PK_CONV_FWD, s, 0.0, 8.0 * rs.R * HUAL_D);
   hipLaunchKernelGGL(ln_dwconv_fwd_kernel, dim3(conv_blocks(rs)), dim3(256), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
@@ -318,6 +322,7 @@ int launch_ln_dwconv_fwd(const ConvFwd& a, const RowSpace& rs, hipStream_t s) {
 
 int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(a.dc && a.x && a.mean && a.rstd && a.g && a.b && a.dw && a.dx && a.dg && a.db && a.ddw, "dwconv_ln_bwd: null");
+  ProfScope ps(PK_CONV_BWD, s, 0.0, 16.0 * rs.R * HUAL_D);
   hipLaunchKernelGGL(dwconv_ln_bwd_kernel, dim3(conv_blocks(rs)), dim3(256), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
@@ -335,6 +340,7 @@ int launch_pos_bwd(const float* dx, float* dpos, const RowSpace& rs, int do_v, i
 
 int launch_ew(const EwArgs& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.R > 0 && a.a && a.out, "ew: null/empty");
+  ProfScope ps(PK_EW, s, 0.0, 12.0 * a.R * HUAL_D);
   hipLaunchKernelGGL(ew_kernel, dim3(row_grid(a.R)), dim3(256), 0, s, a, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

@@ -1,0 +1,60 @@
+"""Data-parallel plumbing (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI on ROCm,
+"gloo" in the CPU tests).  The reference is single-process; data parallelism is the build's addition
+and is exact, i.e. N ranks x B clips reproduce the single-process gradient of the N*B-clip batch:
+
+  * gradients: ONE flat fp32 bucket (the whole parameter layout, ~4.75 MB) summed with all_reduce, then scaled by
+    1/world inside the fused clip+AdamWD kernel (grad_prescale);
+  * matching loss (layers.py:172-173) divides by the GLOBAL valid-frame count: every rank uses the denominator
+    n_global/world so that the rank average equals the global masked mean;
+  * alignment loss (layers.py:232-247) couples all samples of the batch through [B,B] softmaxes: the per-sample
+    l2-normalised features are all-gathered, every rank evaluates the global loss, keeps the gradient rows of its
+    own samples and scales them by `world` (they are averaged, not summed, afterwards).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def allreduce_sum_(flat):
+    """in-place sum of the flat gradient bucket over ranks"""
+    if world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def global_count(local_count, device):
+    """sum of a python/0-d count over ranks -> float"""
+    t = torch.tensor([float(local_count)], device=device, dtype=torch.float64)
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def match_denominator(local_valid_frames, device):
+    """denominator each rank must use for the masked matching loss (+1e-12 of layers.py:173 on the global count)"""
+    w = world_size()
+    return (global_count(local_valid_frames, device) + 1e-12) / w
+
+
+def gather_features(that, vhat):
+    """all_gather of the [B,128] alignment features -> ([W*B,128], [W*B,128]) in rank order (equal B per rank)"""
+    w = world_size()
+    if w == 1:
+        return that, vhat
+    both = torch.cat([that, vhat], dim=1).contiguous()
+    out = torch.empty((w * both.shape[0], both.shape[1]), dtype=both.dtype, device=both.device)
+    dist.all_gather_into_tensor(out, both)
+    d = that.shape[1]
+    return out[:, :d].contiguous(), out[:, d:].contiguous()
+
+
+def local_rows(t, batch):
+    r = rank()
+    return t[r * batch:(r + 1) * batch]

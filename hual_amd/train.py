@@ -1,0 +1,155 @@
+"""Training-step driver for the HIP SeqPAN path: static device buffers, the whole step
+(forward + backward + clip + AdamWD) enqueued through the C ABI and - single GPU - replayed as ONE hipGraph.
+
+Equivalent of the loop body of /root/reference/utils/runner_utils.py:144-147 (feed_dict upload + sess.run).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import dist as hdist
+from . import lib
+
+
+class Trainer:
+    def __init__(self, model, world=1, use_graph=True):
+        self.m = model
+        self.world = world
+        self.use_graph = use_graph and world == 1
+        self.graph = None
+        self.graph_drop = None
+        self.shape = None
+        self._lib = lib.load()
+
+    # ------------------------------------------------------------------ static batch buffers
+    def set_batch(self, video, lens, word_ids, char_ids, y1, y2, match_labels, inner_labels):
+        m, dev = self.m, self.m.device
+        B, T, V = np.shape(video)
+        L, C = np.shape(word_ids)[1], np.shape(char_ids)[2]
+        if int(np.max(lens)) != T:
+            raise ValueError('video T must equal max(video_seq_len) - model.py:31')
+        shape = (B, T, L, C)
+        if shape != self.shape:
+            self.shape = shape
+            self.graph = None
+            f32, i32 = torch.float32, torch.int32
+            self.video = torch.empty(B, T, V, device=dev, dtype=f32)
+            self.lens = torch.empty(B, device=dev, dtype=i32)
+            self.word_ids = torch.empty(B, L, device=dev, dtype=i32)
+            self.char_ids = torch.empty(B, L, C, device=dev, dtype=i32)
+            self.y1 = torch.empty(B, T, device=dev, dtype=f32)
+            self.y2 = torch.empty(B, T, device=dev, dtype=f32)
+            self.match = torch.empty(B, T, device=dev, dtype=i32)
+            self.inner = torch.empty(B, T, device=dev, dtype=f32)
+            self.start_logits = torch.empty(B, T, device=dev)
+            self.end_logits = torch.empty(B, T, device=dev)
+            self.match_scores = torch.empty(B, T, 4, device=dev)
+            self.start_index = torch.empty(B, device=dev, dtype=torch.int64)
+            self.end_index = torch.empty(B, device=dev, dtype=torch.int64)
+            self.loss_terms = torch.zeros(4, device=dev)
+            self.ws = m._workspace(B, T, L, C)
+            p = lib.ptr
+            self.bt = lib.hual_batch(p(self.video).value, p(self.lens).value, p(self.word_ids).value,
+                                     p(self.char_ids).value, B, T, L, C)
+            self.lab = lib.hual_labels(p(self.y1).value, p(self.y2).value, p(self.match).value, p(self.inner).value)
+            self.out = lib.hual_outputs(p(self.start_logits).value, p(self.end_logits).value, p(self.match_scores).value,
+                                        p(self.start_index).value, p(self.end_index).value, p(self.loss_terms).value)
+            if self.world > 1:
+                Bg = B * self.world
+                self.align_scratch = torch.empty(2 * Bg * Bg, device=dev)
+                self.d_that_all = torch.empty(Bg, 128, device=dev)
+                self.d_vhat_all = torch.empty(Bg, 128, device=dev)
+                self.align_loss = torch.zeros(1, device=dev)
+
+        def put(dst, src, dt):
+            dst.copy_(torch.as_tensor(np.ascontiguousarray(src), dtype=dt), non_blocking=False)
+        put(self.video, video, torch.float32)
+        put(self.lens, lens, torch.int32)
+        put(self.word_ids, word_ids, torch.int32)
+        put(self.char_ids, char_ids, torch.int32)
+        put(self.y1, y1, torch.float32)
+        put(self.y2, y2, torch.float32)
+        put(self.match, match_labels, torch.int32)
+        put(self.inner, inner_labels, torch.float32)
+        self.match_denom = 0.0
+        if self.world > 1:
+            self.match_denom = hdist.match_denominator(int(np.sum(np.asarray(lens))), dev)
+
+    # ------------------------------------------------------------------ one step
+    def _opts(self, drop_rate, align_external):
+        return lib.hual_run_opts(float(drop_rate), lib.ptr(self.m.rng_state).value, float(self.match_denom),
+                                 int(align_external))
+
+    def _forward(self, opts):
+        m = self.m
+        lib.check(self._lib.hual_seqpan_forward(
+            ctypes.byref(m.cfg), lib.ptr(m.params), lib.ptr(m.word_table), ctypes.byref(self.bt), ctypes.byref(self.lab),
+            ctypes.byref(self.out), ctypes.byref(opts), lib.ptr(self.ws), self.ws.numel(), lib.stream_ptr()))
+
+    def _backward(self, opts):
+        m = self.m
+        lib.check(self._lib.hual_seqpan_backward(
+            ctypes.byref(m.cfg), lib.ptr(m.params), lib.ptr(m.word_table), ctypes.byref(self.bt), ctypes.byref(self.lab),
+            ctypes.byref(opts), lib.ptr(m.grads), lib.ptr(self.ws), self.ws.numel(), lib.stream_ptr()))
+
+    def _adam(self, prescale):
+        m = self.m
+        lib.check(self._lib.hual_adamw_clip_step(
+            lib.ptr(m.params), lib.ptr(m.grads), lib.ptr(m.adam_m), lib.ptr(m.adam_v), lib.ptr(m.decay),
+            m.params.numel(), lib.ptr(m.lr), float(m.cfg.clip_norm), float(prescale), lib.ptr(m.sqnorm),
+            lib.stream_ptr()))
+
+    def _enqueue_single(self, drop_rate):
+        opts = self._opts(drop_rate, 0)
+        self._forward(opts)
+        self._backward(opts)
+        self._adam(1.0)
+        self.m.rng_state[2] += 1
+
+    def _enqueue_dp(self, drop_rate):
+        m, B = self.m, self.shape[0]
+        opts = self._opts(drop_rate, 1)
+        self._forward(opts)
+        that, vhat = hdist.gather_features(m.tap('align.that'), m.tap('align.vhat'))
+        self.align_loss.zero_()
+        lib.check(self._lib.hual_align_loss(lib.ptr(that), lib.ptr(vhat), that.shape[0], lib.ptr(self.align_scratch),
+                                            lib.ptr(self.d_that_all), lib.ptr(self.d_vhat_all), lib.ptr(self.align_loss),
+                                            float(self.world), lib.stream_ptr()))
+        m.tap('d.align.that').copy_(hdist.local_rows(self.d_that_all, B))
+        m.tap('d.align.vhat').copy_(hdist.local_rows(self.d_vhat_all, B))
+        self._backward(opts)
+        hdist.allreduce_sum_(m.grads)
+        self._adam(1.0 / self.world)
+        m.rng_state[2] += 1
+
+    def step(self, lr, drop_rate):
+        m = self.m
+        m.lr.fill_(float(lr))
+        if self.world > 1:
+            self._enqueue_dp(drop_rate)
+        elif not self.use_graph:
+            self._enqueue_single(drop_rate)
+        else:
+            if self.graph is None or self.graph_drop != drop_rate:
+                # warm-up outside capture (first-use hipFuncSetAttribute etc.) on a snapshot of the training state,
+                # then capture the whole step; the first replay below is the first real step
+                snap = [t.clone() for t in (m.params, m.adam_m, m.adam_v, m.rng_state)]
+                self._enqueue_single(drop_rate)
+                torch.cuda.synchronize()
+                for t, s in zip((m.params, m.adam_m, m.adam_v, m.rng_state), snap):
+                    t.copy_(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue_single(drop_rate)
+                self.graph, self.graph_drop = g, drop_rate
+            self.graph.replay()
+        m.global_step += 1
+
+    def last_loss(self):
+        """total loss of the last step (device sync).  DP: local loc/match terms + the global alignment loss."""
+        l = self.loss_terms[0]
+        if self.world > 1:
+            l = l + self.align_loss[0]
+        return l

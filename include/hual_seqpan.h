@@ -173,6 +173,16 @@ int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, int trans_
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
                    int N, int rows_per_wave, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement hook for bench.py's roofline leg (not part of the reference's surface): between begin and end every
+ * launch of each kernel family is bracketed by HIP events on its stream; hual_prof_end() synchronises those events
+ * (the only synchronising call in the library) and returns, per family, launches, microseconds, algorithmic FLOPs
+ * and algorithmic bytes. */
+#define HUAL_PROF_KINDS 15
+int hual_prof_begin(void);
+int hual_prof_end(int64_t* launches, double* usec, double* flops, double* bytes, int n);
+const char* hual_prof_kind_name(int kind);
+
 #ifdef __cplusplus
 }
 #endif

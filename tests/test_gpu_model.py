@@ -16,16 +16,23 @@ def _assert_rows(rows, kinds):
 
 @pytest.mark.parametrize('drop', [0.0, 0.2])
 def test_forward_backward_parity_small(drop):
-    case = pu.make_case()
+    case = pu.well_conditioned_case(drop_rate=drop)
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=drop)
     _assert_rows(rows, ('tap', 'out', 'loss'))
     assert idx_equal
     _assert_rows(rows, ('grad',))
 
 
+def test_second_shape_with_dropout():
+    case = pu.well_conditioned_case(drop_rate=0.2, B=4, T=24, L=7, C=5, seed=21)
+    rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2)
+    _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
+    assert idx_equal
+
+
 def test_ragged_shapes_parity():
     # T, L not multiples of 16; C = 4 (minimum); one clip of length 1-ish neighbours
-    case = pu.make_case(B=5, T=37, L=9, C=4, seed=11, max_vlen=40)
+    case = pu.well_conditioned_case(drop_rate=0.1, B=3, T=37, L=9, C=4, seed=11, max_vlen=40)
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.1)
     _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
     assert idx_equal
