@@ -35,78 +35,79 @@ __device__ __forceinline__ f32x4 dot16(const float4& a, const float4& b) {   // 
 
 #define ATT_SCALE 0.25f   // 1/sqrt(head_size=16)   layers.py:82
 
-// scores -> normalised probabilities in place; keys >= Tk get probability 0.  Returns nothing; p[] holds softmax.
+// ---- LDS staging ---------------------------------------------------------------------------------------
+// A block = 4 waves = 4 consecutive 16-row tiles of ONE (clip, head).  The per-head K/V (or Q/dO) panels of the
+// clip ([T,16] floats each, <= 16 KB at T = 256) are staged once per block with 16-byte loads and then read many
+// times from LDS: rows as float4 (A operand / transposed B operand), columns as scalars (B operand of P.V).
+__device__ __forceinline__ void stage_panel(float* dst, const float* src, int ld, int rows, int rows_padded) {
+  // dst[row][16] <- src[row*ld + 0..15], zero beyond `rows`
+  for (int idx = threadIdx.x; idx < rows_padded * 4; idx += 256) {
+    const int row = idx >> 2, c4 = idx & 3;
+    float4 v = f4zero();
+    if (row < rows) v = ld4(src + (size_t)row * ld + 4 * c4);
+    *reinterpret_cast<float4*>(dst + row * 16 + 4 * c4) = v;
+  }
+}
+
 template <int MAXKT>
-__device__ __forceinline__ void softmax_rows(f32x4 (&s)[MAXKT], int nkt, int Tk, int g, float mq, const float* kmask_clip) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, DropCfg drop) {
+  extern __shared__ float lds[];
+  const AttnJob& job = batch.j[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int Tq = job.Tq, Tk = job.Tk;
+  const int b = blockIdx.y >> 3, h = blockIdx.y & 7;
+  if (b >= job.B || blockIdx.x * 64 >= Tq) return;   // block-uniform
+  const int nkt = (Tk + 15) >> 4, Tkp = nkt * 16;
+  const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
+  float* Ks = lds;
+  float* Vs = lds + Tkp * 16;
+  float* Ms = Vs + Tkp * 16;
+  stage_panel(Ks, job.K + (size_t)kbase * job.ldkv + 16 * h, job.ldkv, Tk, Tkp);
+  stage_panel(Vs, job.V + (size_t)kbase * job.ldkv + 16 * h, job.ldkv, Tk, Tkp);
+  for (int k = threadIdx.x; k < Tkp; k += 256) Ms[k] = k < Tk ? job.kmask[kbase + k] : 0.f;
+  __syncthreads();
+  const int qt = blockIdx.x * 4 + wave;
+  if (qt * 16 >= Tq) return;   // wave-uniform, after the only barrier
+  const int q0 = qt * 16;
+  const int qrow = qbase + min(q0 + j, Tq - 1);
+  const float4 qb = ld4(job.Q + (size_t)qrow * job.ldq + 16 * h + 4 * g);
+  const float mq = job.qmask[qrow];
+  f32x4 s[MAXKT];
   float mx = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < MAXKT; ++kt) {
     if (kt < nkt) {
+      const float4 ka = *reinterpret_cast<const float4*>(Ks + (kt * 16 + j) * 16 + 4 * g);
+      f32x4 a = dot16(ka, qb);
+      const float4 mk4 = *reinterpret_cast<const float4*>(Ms + kt * 16 + 4 * g);
+      const float mk[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + 4 * g + r;
-        float v;
-        if (key < Tk) {
-          const float mk = kmask_clip[key];
-          v = s[kt][r] * ATT_SCALE + (1.0f - mq * mk) * HUAL_MASK_VALUE;   // layers.py:82-84
-        } else {
-          v = -INFINITY;
-        }
-        s[kt][r] = v;
+        const float v = key < Tk ? a[r] * ATT_SCALE + (1.0f - mq * mk[r]) * HUAL_MASK_VALUE : -INFINITY;   // layers.py:82-84
+        a[r] = v;
         mx = fmaxf(mx, v);
       }
+      s[kt] = a;
     }
   }
   mx = fmaxf(mx, __shfl_xor(mx, 16));
   mx = fmaxf(mx, __shfl_xor(mx, 32));
   float sum = 0.f;
 #pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt) {
+  for (int kt = 0; kt < MAXKT; ++kt)
     if (kt < nkt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float e = __expf(s[kt][r] - mx);
+        const float e = __expf(s[kt][r] - mx);
         s[kt][r] = e;
         sum += e;
       }
     }
-  }
   sum += __shfl_xor(sum, 16);
   sum += __shfl_xor(sum, 32);
   const float inv = 1.0f / sum;
-#pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt)
-    if (kt < nkt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
-    }
-}
-
-template <int MAXKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, DropCfg drop) {
-  const AttnJob& job = batch.j[blockIdx.z];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, g = lane >> 4;
-  const int Tq = job.Tq, Tk = job.Tk;
-  const int qt = blockIdx.x * 4 + wave;
-  const int b = blockIdx.y >> 3, h = blockIdx.y & 7;
-  if (b >= job.B || qt * 16 >= Tq) return;   // wave-uniform
-  const int q0 = qt * 16;
-  const int nkt = (Tk + 15) >> 4;
-  const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
-  const int qrow = qbase + min(q0 + j, Tq - 1);
-  const float4 qb = ld4(job.Q + (size_t)qrow * job.ldq + 16 * h + 4 * g);
-  const float mq = job.qmask[qrow];
-  f32x4 s[MAXKT];
-#pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt) {
-    if (kt < nkt) {
-      const int krow = kbase + min(kt * 16 + j, Tk - 1);
-      const float4 ka = ld4(job.K + (size_t)krow * job.ldkv + 16 * h + 4 * g);
-      s[kt] = dot16(ka, qb);
-    }
-  }
-  softmax_rows<MAXKT>(s, nkt, Tk, g, mq, job.kmask + kbase);
   const bool dodrop = job.drop_site >= 0 && drop.enabled;
   const uint32_t drow = (job.drop_row0 + (uint32_t)qrow) * 8u + (uint32_t)h;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -114,16 +115,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, DropCfg 
   for (int kt = 0; kt < MAXKT; ++kt) {
     if (kt < nkt) {
       f32x4 p = s[kt];
+      float4 m = make_float4(inv, inv, inv, inv);
       if (dodrop) {
-        float4 m = drop_mask4(drop, (uint32_t)job.drop_site, drow, (uint32_t)(kt * 4 + g));
-        p[0] *= m.x; p[1] *= m.y; p[2] *= m.z; p[3] *= m.w;
+        float4 dm = drop_mask4(drop, (uint32_t)job.drop_site, drow, (uint32_t)(kt * 4 + g));
+        m = make_float4(inv * dm.x, inv * dm.y, inv * dm.z, inv * dm.w);
       }
+      p[0] *= m.x; p[1] *= m.y; p[2] *= m.z; p[3] *= m.w;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int krow = kbase + min(kt * 16 + 4 * g + r, Tk - 1);
-        const float vb = job.V[(size_t)krow * job.ldkv + 16 * h + j];
-        o = mfma16_(p[r], vb, o);
-      }
+      for (int r = 0; r < 4; ++r) o = mfma16_(p[r], Vs[(kt * 16 + 4 * g + r) * 16 + j], o);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
@@ -137,46 +137,50 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, DropCfg 
 // delta = sum_k P*dP in `stats` for the dK/dV kernel.
 template <int MAXKT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBatch batch, DropCfg drop, float* stats, int stat_n) {
+  extern __shared__ float lds[];
   const AttnJob& job = batch.j[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
-  const int qt = blockIdx.x * 4 + wave;
   const int b = blockIdx.y >> 3, h = blockIdx.y & 7;
-  if (b >= job.B || qt * 16 >= Tq) return;
-  const int q0 = qt * 16;
-  const int nkt = (Tk + 15) >> 4;
+  if (b >= job.B || blockIdx.x * 64 >= Tq) return;
+  const int nkt = (Tk + 15) >> 4, Tkp = nkt * 16;
   const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
+  float* Ks = lds;
+  float* Vs = lds + Tkp * 16;
+  float* Ms = Vs + Tkp * 16;
+  stage_panel(Ks, job.K + (size_t)kbase * job.ldkv + 16 * h, job.ldkv, Tk, Tkp);
+  stage_panel(Vs, job.V + (size_t)kbase * job.ldkv + 16 * h, job.ldkv, Tk, Tkp);
+  for (int k = threadIdx.x; k < Tkp; k += 256) Ms[k] = k < Tk ? job.kmask[kbase + k] : 0.f;
+  __syncthreads();
+  const int qt = blockIdx.x * 4 + wave;
+  if (qt * 16 >= Tq) return;
+  const int q0 = qt * 16;
   const int qrow = qbase + min(q0 + j, Tq - 1);
   const float4 qb = ld4(job.Q + (size_t)qrow * job.ldq + 16 * h + 4 * g);
   const float4 dob = ld4(job.dO + (size_t)qrow * job.lddo + 16 * h + 4 * g);
   const float mq = job.qmask[qrow];
   f32x4 s[MAXKT], dp[MAXKT];
-  // raw scores; keep the row max / sum to hand them to the dK/dV kernel
+  float mx = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < MAXKT; ++kt) {
     if (kt < nkt) {
-      const int krow = kbase + min(kt * 16 + j, Tk - 1);
-      const float4 ka = ld4(job.K + (size_t)krow * job.ldkv + 16 * h + 4 * g);
-      const float4 va = ld4(job.V + (size_t)krow * job.ldkv + 16 * h + 4 * g);
-      s[kt] = dot16(ka, qb);
+      const float4 ka = *reinterpret_cast<const float4*>(Ks + (kt * 16 + j) * 16 + 4 * g);
+      const float4 va = *reinterpret_cast<const float4*>(Vs + (kt * 16 + j) * 16 + 4 * g);
+      f32x4 a = dot16(ka, qb);
       dp[kt] = dot16(va, dob);
-    }
-  }
-  float mx = -INFINITY;
-  const float* kmask_clip = job.kmask + kbase;
-#pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt)
-    if (kt < nkt) {
+      const float4 mk4 = *reinterpret_cast<const float4*>(Ms + kt * 16 + 4 * g);
+      const float mk[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + 4 * g + r;
-        float v = -INFINITY;
-        if (key < Tk) v = s[kt][r] * ATT_SCALE + (1.0f - mq * kmask_clip[key]) * HUAL_MASK_VALUE;
-        s[kt][r] = v;
+        const float v = key < Tk ? a[r] * ATT_SCALE + (1.0f - mq * mk[r]) * HUAL_MASK_VALUE : -INFINITY;
+        a[r] = v;
         mx = fmaxf(mx, v);
       }
+      s[kt] = a;
     }
+  }
   mx = fmaxf(mx, __shfl_xor(mx, 16));
   mx = fmaxf(mx, __shfl_xor(mx, 32));
   float sum = 0.f;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBatch batch, DropC
     if (kt < nkt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float e = __expf(s[kt][r] - mx);
+        const float e = __expf(s[kt][r] - mx);
         s[kt][r] = e;
         sum += e;
       }
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBatch batch, DropC
         s[kt][r] *= inv;
         delta = fmaf(s[kt][r], dp[kt][r], delta);
       }
+      __builtin_amdgcn_sched_barrier(0);   // keep the 8-16 unrolled Philox chains from being interleaved (VGPR blow-up)
     }
   delta += __shfl_xor(delta, 16);
   delta += __shfl_xor(delta, 32);
@@ -225,9 +230,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBatch batch, DropC
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float ds = s[kt][r] * (dp[kt][r] - delta) * ATT_SCALE;
-        const int krow = kbase + min(kt * 16 + 4 * g + r, Tk - 1);
-        const float kb = job.K[(size_t)krow * job.ldkv + 16 * h + j];
-        dq = mfma16_(ds, kb, dq);
+        dq = mfma16_(ds, Ks[(kt * 16 + 4 * g + r) * 16 + j], dq);
       }
     }
 #pragma unroll
@@ -237,64 +240,79 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBatch batch, DropC
   }
 }
 
-// dK, dV: a wave owns 16 keys of one (clip, head) and sweeps the query tiles.
+// dK, dV: a wave owns 16 keys of one (clip, head) and sweeps the query tiles; Q, dO and the per-query softmax
+// statistics of the clip are staged in LDS once per block.
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBatch batch, DropCfg drop, const float* stats, int stat_n) {
+  extern __shared__ float lds[];
   const AttnJob& job = batch.j[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
-  const int kt = blockIdx.x * 4 + wave;
   const int b = blockIdx.y >> 3, h = blockIdx.y & 7;
-  if (b >= job.B || kt * 16 >= Tk) return;
-  const int k0 = kt * 16;
-  const int nqt = (Tq + 15) >> 4;
+  if (b >= job.B || blockIdx.x * 64 >= Tk) return;
+  const int nqt = (Tq + 15) >> 4, Tqp = nqt * 16;
   const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
+  float* Qs = lds;
+  float* Ds = lds + Tqp * 16;
+  float* St = Ds + Tqp * 16;        // [4][Tqp]: row max, 1/rowsum, delta, query mask
+  stage_panel(Qs, job.Q + (size_t)qbase * job.ldq + 16 * h, job.ldq, Tq, Tqp);
+  stage_panel(Ds, job.dO + (size_t)qbase * job.lddo + 16 * h, job.lddo, Tq, Tqp);
+  const float* st = stats + (size_t)blockIdx.z * 3 * stat_n;
+  for (int q = threadIdx.x; q < Tqp; q += 256) {
+    const bool ok = q < Tq;
+    const int si = (b * Tq + (ok ? q : 0)) * 8 + h;
+    St[q] = ok ? st[si] : 0.f;
+    St[Tqp + q] = ok ? st[stat_n + si] : 0.f;          // 1/rowsum = 0 for padding queries -> p = 0
+    St[2 * Tqp + q] = ok ? st[2 * stat_n + si] : 0.f;
+    St[3 * Tqp + q] = ok ? job.qmask[qbase + q] : 0.f;
+  }
+  __syncthreads();
+  const int kt = blockIdx.x * 4 + wave;
+  if (kt * 16 >= Tk) return;
+  const int k0 = kt * 16;
   const int key = k0 + j;
   const bool keyok = key < Tk;
   const int krow = kbase + min(key, Tk - 1);
   const float4 kb = ld4(job.K + (size_t)krow * job.ldkv + 16 * h + 4 * g);
   const float4 vb = ld4(job.V + (size_t)krow * job.ldkv + 16 * h + 4 * g);
   const float mk = job.kmask[krow];
-  const float* st = stats + (size_t)blockIdx.z * 3 * stat_n;
   const bool dodrop = job.drop_site >= 0 && drop.enabled;
   f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * 16;
-    const int qrow_j = qbase + min(q0 + j, Tq - 1);
-    const float4 qa = ld4(job.Q + (size_t)qrow_j * job.ldq + 16 * h + 4 * g);
-    const float4 doa = ld4(job.dO + (size_t)qrow_j * job.lddo + 16 * h + 4 * g);
+    const float4 qa = *reinterpret_cast<const float4*>(Qs + (q0 + j) * 16 + 4 * g);
+    const float4 doa = *reinterpret_cast<const float4*>(Ds + (q0 + j) * 16 + 4 * g);
     f32x4 s = dot16(qa, kb);     // lane: S[query q0+4g+r][key k0+j]
     f32x4 dp = dot16(doa, vb);
-    float qv[4], dov[4];
+    const float4 m4 = *reinterpret_cast<const float4*>(St + q0 + 4 * g);
+    const float4 l4 = *reinterpret_cast<const float4*>(St + Tqp + q0 + 4 * g);
+    const float4 d4 = *reinterpret_cast<const float4*>(St + 2 * Tqp + q0 + 4 * g);
+    const float4 qm4 = *reinterpret_cast<const float4*>(St + 3 * Tqp + q0 + 4 * g);
+    const float mxv[4] = {m4.x, m4.y, m4.z, m4.w}, liv[4] = {l4.x, l4.y, l4.z, l4.w};
+    const float dlv[4] = {d4.x, d4.y, d4.z, d4.w}, qmv[4] = {qm4.x, qm4.y, qm4.z, qm4.w};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int q = q0 + 4 * g + r;
-      const bool qok = q < Tq;
-      const int qrow = qbase + min(q, Tq - 1);
-      const int si = (b * Tq + min(q, Tq - 1)) * 8 + h;
       float p = 0.f;
-      if (qok && keyok) {
-        const float mqv = job.qmask[qrow];
-        const float v = s[r] * ATT_SCALE + (1.0f - mqv * mk) * HUAL_MASK_VALUE;
-        p = __expf(v - st[si]) * st[stat_n + si];
+      if (keyok) {
+        const float v = s[r] * ATT_SCALE + (1.0f - qmv[r] * mk) * HUAL_MASK_VALUE;
+        p = __expf(v - mxv[r]) * liv[r];
       }
       float m = 1.0f;
       if (dodrop) {
-        const uint32_t drow = (job.drop_row0 + (uint32_t)qrow) * 8u + (uint32_t)h;
+        const uint32_t drow = (job.drop_row0 + (uint32_t)(qbase + min(q, Tq - 1))) * 8u + (uint32_t)h;
         float4 mm = drop_mask4(drop, (uint32_t)job.drop_site, drow, (uint32_t)(key >> 2));
         const int c = key & 3;
         m = c == 0 ? mm.x : (c == 1 ? mm.y : (c == 2 ? mm.z : mm.w));
       }
-      const float ds = p * (dp[r] * m - st[2 * stat_n + si]) * ATT_SCALE;
+      const float ds = p * (dp[r] * m - dlv[r]) * ATT_SCALE;
       s[r] = p * m;     // dropped probability (A operand of dV)
       dp[r] = ds;       // A operand of dK
-      qv[r] = job.Q[(size_t)qrow * job.ldq + 16 * h + j];
-      dov[r] = job.dO[(size_t)qrow * job.lddo + 16 * h + j];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      dv = mfma16_(s[r], dov[r], dv);
-      dk = mfma16_(dp[r], qv[r], dk);
+      dv = mfma16_(s[r], Ds[(q0 + 4 * g + r) * 16 + j], dv);
+      dk = mfma16_(dp[r], Qs[(q0 + 4 * g + r) * 16 + j], dk);
     }
   }
 #pragma unroll
@@ -337,10 +355,11 @@ int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
   double flops = 0.0;
   for (int i = 0; i < n; ++i) flops += 4.0 * jobs[i].B * 8.0 * jobs[i].Tq * jobs[i].Tk * 16.0;   // QK^T + PV
   ProfScope ps(PK_ATTN_FWD, s, flops, 0.0);
-  if (nkt <= 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, 0, s, b, drop);
-  else if (nkt <= 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, 0, s, b, drop);
-  else if (nkt <= 8) hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, block, 0, s, b, drop);
-  else hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, block, 0, s, b, drop);
+  const size_t lds = (size_t)nkt * 16 * 33 * sizeof(float);
+  if (nkt <= 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, lds, s, b, drop);
+  else if (nkt <= 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, lds, s, b, drop);
+  else if (nkt <= 8) hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, block, lds, s, b, drop);
+  else hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, block, lds, s, b, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -360,15 +379,17 @@ int launch_attn_bwd_impl(const AttnJob* jobs, int n, const DropCfg& drop, float*
   for (int i = 0; i < n; ++i) flops += 2.0 * jobs[i].B * 8.0 * jobs[i].Tq * jobs[i].Tk * 16.0;
   {
   ProfScope ps(PK_ATTN_BWD_DQ, s, 3.0 * flops, 0.0);   // S, dP, dQ
-  if (nkt <= 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, block, 0, s, b, drop, stats, stat_n);
-  else if (nkt <= 4) hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, block, 0, s, b, drop, stats, stat_n);
-  else if (nkt <= 8) hipLaunchKernelGGL(attn_bwd_dq_kernel<8>, grid, block, 0, s, b, drop, stats, stat_n);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<16>, grid, block, 0, s, b, drop, stats, stat_n);
+  const size_t lds = (size_t)nkt * 16 * 33 * sizeof(float);
+  if (nkt <= 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, block, lds, s, b, drop, stats, stat_n);
+  else if (nkt <= 4) hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, block, lds, s, b, drop, stats, stat_n);
+  // (the MAXKT=8 instantiation trips a register-allocation pathology in hipcc 7.2: 512 VGPRs; MAXKT=16 needs 162)
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<16>, grid, block, lds, s, b, drop, stats, stat_n);
   }
   HUAL_CHECK_HIP(hipGetLastError());
   dim3 grid2(cdiv(cdiv(maxTk, 16), 4), maxB * 8, n);
   ProfScope ps2(PK_ATTN_BWD_DKV, s, 4.0 * flops, 0.0);   // S, dP, dK, dV
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid2, block, 0, s, b, drop, (const float*)stats, stat_n);
+  const size_t lds2 = (size_t)cdiv(maxTq, 16) * 16 * 36 * sizeof(float);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid2, block, lds2, s, b, drop, (const float*)stats, stat_n);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

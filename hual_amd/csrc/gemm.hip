@@ -111,7 +111,7 @@ __device__ __forceinline__ void load_chunk(const GemmJob& job, int ch, int arow,
   }
 }
 
-#define HUAL_PD 4   // prefetch depth in 16-k chunks: the whole K=128 panel of a wave is in flight after 2 groups
+#define HUAL_PD 8   // prefetch depth in 16-k chunks: the whole K=128 panel of a wave is in flight after 2 groups
 
 template <bool DUAL>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, DropCfg drop) {
@@ -290,15 +290,16 @@ __global__ __launch_bounds__(256) void dw_kernel(DwBatch batch, DropCfg drop, in
     }
   };
 
-  float2 ca[4], na[4];
-  float cb0[4], cb1[4], nb0[4], nb1[4];
+  constexpr int GP = 8;     // row pairs per pipeline stage: 32 MFMAs (2048 cycles) cover the next stage's loads
+  float2 ca[GP], na[GP];
+  float cb0[GP], cb1[GP], nb0[GP], nb1[GP];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) load_pair(u, ca[u], cb0[u], cb1[u]);
-  for (int it = 0; it < npairs; it += 4) {
+  for (int u = 0; u < GP; ++u) load_pair(u, ca[u], cb0[u], cb1[u]);
+  for (int it = 0; it < npairs; it += GP) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load_pair(it + 4 + u, na[u], nb0[u], nb1[u]);
+    for (int u = 0; u < GP; ++u) load_pair(it + GP + u, na[u], nb0[u], nb1[u]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GP; ++u) {
       acc[0][0] = mfma32(ca[u].x, cb0[u], acc[0][0]);
       acc[0][1] = mfma32(ca[u].x, cb1[u], acc[0][1]);
       acc[1][0] = mfma32(ca[u].y, cb0[u], acc[1][0]);
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwBatch batch, DropCfg drop, in
       bsum1 += cb1[u];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GP; ++u) {
       ca[u] = na[u];
       cb0[u] = nb0[u];
       cb1[u] = nb1[u];
