@@ -32,16 +32,16 @@ int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, int trans_
 }
 
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
-                   int N, int rows_per_wave, void* stream) {
+                   int N, int rows_per_block, void* stream) {
   HUAL_REQUIRE(A && dY && dW, "hual_linear_dw: null pointer");
-  HUAL_REQUIRE(M > 0 && K % 16 == 0 && N % 64 == 0, "hual_linear_dw: K % 16 == 0 and N % 64 == 0 required");
+  HUAL_REQUIRE(M > 0 && K % 16 == 0 && N == 128, "hual_linear_dw: K % 16 == 0 and N == 128 required");
   DwJob j;
   dw_job_init(j);
   j.npieces = 1;
   j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.dW[0] = dW; j.ldw = ldw;
   j.dY = dY; j.ldy = ldy; j.M = M; j.N = N; j.db = db;
   DropCfg d = make_dropcfg(nullptr, 0.f);
-  return launch_dw(&j, 1, d, rows_per_wave > 0 ? rows_per_wave : 128, (hipStream_t)stream);
+  return launch_dw(&j, 1, d, rows_per_block > 0 ? rows_per_block : 1024, (hipStream_t)stream);
 }
 
 }  // extern "C"

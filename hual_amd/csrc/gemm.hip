@@ -111,7 +111,7 @@ __device__ __forceinline__ void load_chunk(const GemmJob& job, int ch, int arow,
   }
 }
 
-#define HUAL_PD 8   // prefetch depth in 16-k chunks: the whole K=128 panel of a wave is in flight after 2 groups
+#define HUAL_PD 4   // prefetch depth in 16-k chunks: the whole K=128 panel of a wave is in flight after 2 groups
 
 template <bool DUAL>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, DropCfg drop) {
@@ -216,38 +216,52 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, DropCfg drop
 }
 
 // ------------------------------------------------------------------------------------------------------
-// dW / db
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dw_kernel(DwBatch batch, DropCfg drop, int rows_per_wave) {
-  extern __shared__ float red[];   // [4 waves][64 acc regs][64 lanes]
-  const DwJob& job = batch.j[blockIdx.z];
+// dW / db.  A block owns one 128(k) x 128(n) gradient tile of one job over a chunk of rows_per_block rows; its four
+// waves own the four 64 x 64 quadrants.  Rows of A (with the job's prologue: elementwise product, dropout) and of dY
+// stream through LDS in 32-row tiles, loaded ONCE with coalesced 16-byte loads and double buffered, so every
+// activation / gradient element is read once per job from HBM.  The MFMA is v_mfma_f32_32x32x2_f32 with the row
+// index m as its k dimension; accumulators leave as float atomics whose wave-instructions are two contiguous
+// 128-byte row segments (the full-rate shape of MI355X_MICROARCH.md "Global float atomics").
+#define DW_TM 32            // rows per LDS tile
+#define DW_LD 132           // padded leading dimension (floats)
+// copies a slice of job descriptors (passed by value, so graph-capture safe) into the device-resident job table
+__global__ void dw_table_write_kernel(DwBatch part, DwJob* table, int base, int cnt) {
+  const int t = threadIdx.x;
+  if (t < cnt) table[base + t] = part.j[t];
+}
+
+template <bool FROM_TABLE>
+__global__ __launch_bounds__(256) void dw_kernel(DwBatch batch, const DwJob* __restrict__ table, DropCfg drop,
+                                                 int rows_per_block) {
+  extern __shared__ float lds[];     // As[2][DW_TM][DW_LD] | Ys[2][DW_TM][DW_LD]
+  const DwJob& job = FROM_TABLE ? table[blockIdx.z] : batch.j[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int M = job.M, N = job.N;
-  const int ntn = N >> 6;
-  // decode tile -> (piece, k-tile, n-tile)
-  int tile = blockIdx.y;
-  int p = 0, kt = 0;
-  {
-    int t = tile / ntn;
-    for (p = 0; p < job.npieces; ++p) {
-      int nk = (job.kw[p] + 63) >> 6;
-      if (t < nk) { kt = t; break; }
-      t -= nk;
-    }
-    if (p >= job.npieces) return;   // block-uniform
+  const int kq = wave >> 1, nq = wave & 1;
+  const int M = job.M;
+  // decode k-block -> (piece, offset inside the piece)
+  int p = 0, kb = blockIdx.y;
+  for (p = 0; p < job.npieces; ++p) {
+    const int nkb = (job.kw[p] + 127) >> 7;
+    if (kb < nkb) break;
+    kb -= nkb;
   }
-  const int nt = tile % ntn;
-  const int mblock = blockIdx.x * rows_per_wave * 4;
-  if (mblock >= M) return;          // block-uniform
-  const int kbase = kt * 64, nbase = nt * 64;
+  if (p >= job.npieces) return;                 // block-uniform
+  const int m_lo = blockIdx.x * rows_per_block;
+  if (m_lo >= M) return;                        // block-uniform
+  const int m_hi = min(m_lo + rows_per_block, M);
+  const int k0 = kb * 128;
   const int kw = job.kw[p];
   const float* Ap = job.A[p];
   const float* A2p = job.A2[p];
   const int lda = job.lda[p], lda2 = job.lda2[p];
+  const float* Yp = job.dY;
+  const int ldy = job.ldy;
   const bool adrop = job.a_drop_site >= 0 && drop.enabled;
-  const bool kok = (kbase + 2 * i) < kw;     // kw is a multiple of 16 => the float2 is all-in or all-out
-  const bool dob = (job.db != nullptr) && p == 0 && kt == 0;
+  const uint32_t asite = (uint32_t)job.a_drop_site;
+  const uint32_t arow0 = job.a_drop_row0;
+  float* As = lds;
+  float* Ys = lds + 2 * DW_TM * DW_LD;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -257,86 +271,80 @@ __global__ __launch_bounds__(256) void dw_kernel(DwBatch batch, DropCfg drop, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
   float bsum0 = 0.f, bsum1 = 0.f;
+  const bool dob = (job.db != nullptr) && p == 0 && kb == 0 && kq == 0;
 
-  const int m0 = mblock + wave * rows_per_wave;
-  const int mend = min(m0 + rows_per_wave, M);
-  const int npairs = (mend - m0 + 1) >> 1;        // wave-uniform trip count; lane half h takes row m0+2*it+h
-  const uint32_t asite = (uint32_t)job.a_drop_site;
-  const uint32_t arow0 = job.a_drop_row0;
-  const float* dYp = job.dY + nbase + i;
-  const int ldy = job.ldy;
-
-  auto load_pair = [&](int it, float2& a, float& b0, float& b1) {
-    const int m = m0 + 2 * it + h;
-    a = make_float2(0.f, 0.f);
-    b0 = 0.f;
-    b1 = 0.f;
-    if (it < npairs && m < mend) {
-      if (kok) {
-        a = *reinterpret_cast<const float2*>(Ap + (size_t)m * lda + kbase + 2 * i);
-        if (A2p) {
-          float2 a2 = *reinterpret_cast<const float2*>(A2p + (size_t)m * lda2 + kbase + 2 * i);
-          a.x *= a2.x; a.y *= a2.y;
+  // staging: 32 rows x 32 float4 per matrix = 1024 float4 -> 4 per thread per matrix
+  float4 ra[4], ry[4];
+  auto stage_load = [&](int mt) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = threadIdx.x + 256 * u;
+      const int row = idx >> 5, c4 = idx & 31;
+      const int m = mt + row;
+      float4 a = f4zero(), y = f4zero();
+      if (m < m_hi) {
+        const int k = k0 + 4 * c4;
+        if (k < kw) {
+          a = ld4(Ap + (size_t)m * lda + k);
+          if (A2p) a = f4mul(a, ld4(A2p + (size_t)m * lda2 + k));
+          if (adrop) a = apply_drop4(drop, asite, arow0 + (uint32_t)m, (uint32_t)(k >> 2), a);
         }
-        if (adrop) {
-          const int kcol = kbase + 2 * i;
-          float4 mk = drop_mask4(drop, asite, arow0 + (uint32_t)m, (uint32_t)(kcol >> 2));
-          if (kcol & 2) { a.x *= mk.z; a.y *= mk.w; } else { a.x *= mk.x; a.y *= mk.y; }
-        }
+        y = ld4(Yp + (size_t)m * ldy + 4 * c4);
       }
-      const float* yp = dYp + (size_t)m * ldy;
-      b0 = yp[0];
-      b1 = yp[32];
+      ra[u] = a;
+      ry[u] = y;
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = threadIdx.x + 256 * u;
+      const int row = idx >> 5, c4 = idx & 31;
+      *reinterpret_cast<float4*>(As + (buf * DW_TM + row) * DW_LD + 4 * c4) = ra[u];
+      *reinterpret_cast<float4*>(Ys + (buf * DW_TM + row) * DW_LD + 4 * c4) = ry[u];
     }
   };
 
-  constexpr int GP = 8;     // row pairs per pipeline stage: 32 MFMAs (2048 cycles) cover the next stage's loads
-  float2 ca[GP], na[GP];
-  float cb0[GP], cb1[GP], nb0[GP], nb1[GP];
-#pragma unroll
-  for (int u = 0; u < GP; ++u) load_pair(u, ca[u], cb0[u], cb1[u]);
-  for (int it = 0; it < npairs; it += GP) {
-#pragma unroll
-    for (int u = 0; u < GP; ++u) load_pair(it + GP + u, na[u], nb0[u], nb1[u]);
-#pragma unroll
-    for (int u = 0; u < GP; ++u) {
-      acc[0][0] = mfma32(ca[u].x, cb0[u], acc[0][0]);
-      acc[0][1] = mfma32(ca[u].x, cb1[u], acc[0][1]);
-      acc[1][0] = mfma32(ca[u].y, cb0[u], acc[1][0]);
-      acc[1][1] = mfma32(ca[u].y, cb1[u], acc[1][1]);
-      bsum0 += cb0[u];
-      bsum1 += cb1[u];
+  stage_load(m_lo);
+  stage_store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int mt = m_lo; mt < m_hi; mt += DW_TM) {
+    const bool more = (mt + DW_TM) < m_hi;
+    if (more) stage_load(mt + DW_TM);            // global loads in flight under the MFMAs below
+    const float* At = As + buf * DW_TM * DW_LD + kq * 64 + 2 * i;
+    const float* Yt = Ys + buf * DW_TM * DW_LD + nq * 64 + i;
+#pragma unroll 4
+    for (int r = 0; r < DW_TM; r += 2) {
+      const float2 a = *reinterpret_cast<const float2*>(At + (r + h) * DW_LD);
+      const float b0 = Yt[(r + h) * DW_LD];
+      const float b1 = Yt[(r + h) * DW_LD + 32];
+      acc[0][0] = mfma32(a.x, b0, acc[0][0]);
+      acc[0][1] = mfma32(a.x, b1, acc[0][1]);
+      acc[1][0] = mfma32(a.y, b0, acc[1][0]);
+      acc[1][1] = mfma32(a.y, b1, acc[1][1]);
+      bsum0 += b0;
+      bsum1 += b1;
     }
-#pragma unroll
-    for (int u = 0; u < GP; ++u) {
-      ca[u] = na[u];
-      cb0[u] = nb0[u];
-      cb1[u] = nb1[u];
-    }
+    if (more) stage_store(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
 
-  // ---- cross-wave reduction through LDS, then one set of atomics per block
-  float* mine = red + wave * 4096;
+  // each wave owns its quadrant: no cross-wave reduction, straight to global atomics
+  float* dWp = job.dW[p];
+  const int kbase = k0 + kq * 64, nbase = nq * 64;
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mine[((c * 2 + t) * 16 + r) * 64 + lane] = acc[c][t][r];
-  __syncthreads();
-  // wave w reduces the 16 (c,t,r) slots [16w, 16w+16)
-  float* dWp = job.dW[p];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const int slot = wave * 16 + s;
-    float v = red[slot * 64 + lane] + red[4096 + slot * 64 + lane] + red[8192 + slot * 64 + lane] +
-              red[12288 + slot * 64 + lane];
-    const int c = slot >> 5, t = (slot >> 4) & 1, r = slot & 15;
-    const int rowi = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int k = kbase + 2 * rowi + c;
-    const int n = nbase + 32 * t + i;
-    if (k < kw) atomicAdd(dWp + (size_t)k * job.ldw + n, v);
-  }
+      for (int r = 0; r < 16; ++r) {
+        const int rowi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int k = kbase + 2 * rowi + c;
+        const int n = nbase + 32 * t + i;
+        if (k < kw) atomicAdd(dWp + (size_t)k * job.ldw + n, acc[c][t][r]);
+      }
   if (dob) {
     bsum0 += __shfl_xor(bsum0, 32);
     bsum1 += __shfl_xor(bsum1, 32);
@@ -390,39 +398,74 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
   return 0;
 }
 
-int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_wave, hipStream_t stream) {
-  HUAL_REQUIRE(rows_per_wave >= 2 && (rows_per_wave % 2) == 0, "launch_dw: rows_per_wave must be even");
+static int dw_check(const DwJob& j, int& kbs, double& flops, double& bytes) {
+  HUAL_REQUIRE(j.M > 0 && j.N == 128, "launch_dw: N must be 128");
+  HUAL_REQUIRE(j.npieces >= 1 && j.npieces <= HUAL_MAX_PIECES, "launch_dw: pieces");
+  kbs = 0;
+  double kt = 0.0;
+  for (int p = 0; p < j.npieces; ++p) {
+    HUAL_REQUIRE(j.kw[p] > 0 && (j.kw[p] % 16) == 0, "launch_dw: piece width must be a multiple of 16");
+    HUAL_REQUIRE(j.A[p] && j.dW[p], "launch_dw: null operand");
+    HUAL_REQUIRE((j.lda[p] % 4) == 0 && (j.ldy % 4) == 0, "launch_dw: leading dims must be multiples of 4");
+    kbs += cdiv(j.kw[p], 128);
+    kt += j.kw[p];
+  }
+  flops += 2.0 * j.M * kt * j.N;
+  bytes += 4.0 * ((double)j.M * kt + (double)j.M * j.N + kt * j.N);
+  return 0;
+}
+
+// `table`: optional device buffer of n DwJob entries.  With it ALL jobs run as ONE launch (the descriptors are first
+// written to the table by tiny kernels that carry them by value); without it jobs go HUAL_MAX_DW_JOBS per launch.
+int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block, hipStream_t stream, DwJob* table) {
+  HUAL_REQUIRE(rows_per_block >= DW_TM && (rows_per_block % DW_TM) == 0, "launch_dw: rows_per_block must be a multiple of 32");
+  static bool attr = false;
+  if (!attr) {
+    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr = true;
+  }
+  const size_t lds = (size_t)4 * DW_TM * DW_LD * sizeof(float);
+  if (table != nullptr) {
+    int maxM = 0, maxKb = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int base = 0; base < n; base += HUAL_MAX_DW_JOBS) {
+      const int cnt = n - base < HUAL_MAX_DW_JOBS ? n - base : HUAL_MAX_DW_JOBS;
+      DwBatch b;
+      for (int i = 0; i < cnt; ++i) {
+        int kbs;
+        int rc = dw_check(jobs[base + i], kbs, flops, bytes);
+        if (rc) return rc;
+        b.j[i] = jobs[base + i];
+        maxM = jobs[base + i].M > maxM ? jobs[base + i].M : maxM;
+        maxKb = kbs > maxKb ? kbs : maxKb;
+      }
+      hipLaunchKernelGGL(dw_table_write_kernel, dim3(1), dim3(64), 0, stream, b, table, base, cnt);
+    }
+    DwBatch dummy;
+    dw_job_init(dummy.j[0]);
+    dim3 grid(cdiv(maxM, rows_per_block), maxKb, n), block(256);
+    ProfScope ps(PK_DW, stream, flops, bytes);
+    hipLaunchKernelGGL(dw_kernel<true>, grid, block, lds, stream, dummy, (const DwJob*)table, drop, rows_per_block);
+    HUAL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   for (int base = 0; base < n; base += HUAL_MAX_DW_JOBS) {
     int cnt = n - base < HUAL_MAX_DW_JOBS ? n - base : HUAL_MAX_DW_JOBS;
     DwBatch b;
-    int maxM = 0, maxTiles = 0;
-    for (int i = 0; i < cnt; ++i) {
-      const DwJob& j = jobs[base + i];
-      HUAL_REQUIRE(j.M > 0 && j.N > 0 && (j.N % 64) == 0, "launch_dw: N must be a positive multiple of 64");
-      HUAL_REQUIRE(j.npieces >= 1 && j.npieces <= HUAL_MAX_PIECES, "launch_dw: pieces");
-      int tiles = 0;
-      for (int p = 0; p < j.npieces; ++p) {
-        HUAL_REQUIRE(j.kw[p] > 0 && (j.kw[p] % 16) == 0, "launch_dw: piece width must be a multiple of 16");
-        HUAL_REQUIRE(j.A[p] && j.dW[p], "launch_dw: null operand");
-        HUAL_REQUIRE((j.lda[p] % 2) == 0, "launch_dw: lda must be even");
-        tiles += cdiv(j.kw[p], 64);
-      }
-      tiles *= j.N / 64;
-      b.j[i] = j;
-      maxM = j.M > maxM ? j.M : maxM;
-      maxTiles = tiles > maxTiles ? tiles : maxTiles;
-    }
-    dim3 grid(cdiv(maxM, rows_per_wave * 4), maxTiles, cnt), block(256);
+    int maxM = 0, maxKb = 0;
     double flops = 0.0, bytes = 0.0;
     for (int i = 0; i < cnt; ++i) {
-      const DwJob& j = jobs[base + i];
-      double kt = 0.0;
-      for (int p = 0; p < j.npieces; ++p) kt += j.kw[p];
-      flops += 2.0 * j.M * kt * j.N;
-      bytes += 4.0 * ((double)j.M * kt + (double)j.M * j.N + kt * j.N);
+      int kbs;
+      int rc = dw_check(jobs[base + i], kbs, flops, bytes);
+      if (rc) return rc;
+      b.j[i] = jobs[base + i];
+      maxM = jobs[base + i].M > maxM ? jobs[base + i].M : maxM;
+      maxKb = kbs > maxKb ? kbs : maxKb;
     }
+    dim3 grid(cdiv(maxM, rows_per_block), maxKb, cnt), block(256);
     ProfScope ps(PK_DW, stream, flops, bytes);
-    hipLaunchKernelGGL(dw_kernel, grid, block, 4 * 4096 * sizeof(float), stream, b, drop, rows_per_wave);
+    hipLaunchKernelGGL(dw_kernel<false>, grid, block, lds, stream, b, (const DwJob*)nullptr, drop, rows_per_block);
     HUAL_CHECK_HIP(hipGetLastError());
   }
   return 0;

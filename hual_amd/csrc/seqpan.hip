@@ -981,7 +981,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.chk(launch_embed_bwd(ea, eg, Nq, c.drop, c.stream));
   }
   // ---------------- all dense-layer weight gradients, as a few big launches
-  if (!c.dry && c.ok()) c.chk(launch_dw(c.dwjobs.data(), (int)c.dwjobs.size(), c.drop, 256, c.stream));
+  DwJob* dwtable = reinterpret_cast<DwJob*>(c.buf("dw.table", c.dwjobs.size(), (sizeof(DwJob) + 3) / 4));
+  if (!c.dry && c.ok()) c.chk(launch_dw(c.dwjobs.data(), (int)c.dwjobs.size(), c.drop, 512, c.stream, dwtable));
   (void)opt;
   return c.rc;
 }

@@ -153,8 +153,8 @@ def linear_fwd(A, W, bias=None, act=0, trans_w=False, out=None):
     return Y
 
 
-def linear_dw(A, dY, dW, db=None, rows_per_wave=128):
+def linear_dw(A, dY, dW, db=None, rows_per_block=1024):
     M, K = A.shape
     N = dY.shape[1]
     check(load().hual_linear_dw(ptr(A), A.stride(0), ptr(dY), dY.stride(0), ptr(dW), dW.stride(0), ptr(db), M, K, N,
-                                rows_per_wave, stream_ptr()))
+                                rows_per_block, stream_ptr()))

@@ -169,9 +169,10 @@ int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, int trans_
                     int ldy, int M, int K, int N, int act, void* stream);
 
 /* gradients of the dense above: dW[K,N] += A^T . dY ; db[N] += colsum(dY) (db may be NULL).
- * Accumulates with float atomics: zero the destinations first. */
+  * N must be 128 (every dense layer of the graph has 128 outputs); rows_per_block (multiple of 32, 0 = 1024) sets the
+ * split over M.  Accumulates with float atomics: zero the destinations first. */
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
-                   int N, int rows_per_wave, void* stream);
+                   int N, int rows_per_block, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hook for bench.py's roofline leg (not part of the reference's surface): between begin and end every

@@ -52,8 +52,8 @@ def test_linear_dx_transposed_weight(dev, M, K, N):
     assert torch.equal(out, dY @ W.t())
 
 
-@pytest.mark.parametrize('M,K,N,rpw', [(64, 64, 64, 8), (37, 128, 128, 16), (1000, 400, 128, 64), (9472, 128, 128, 128),
-                                       (4096, 1024, 128, 256), (513, 16, 64, 2)])
+@pytest.mark.parametrize('M,K,N,rpw', [(64, 64, 128, 32), (37, 128, 128, 32), (1000, 400, 128, 64), (9472, 128, 128, 1024),
+                                       (4096, 1024, 128, 256), (513, 16, 128, 96), (33, 272, 128, 1024)])
 def test_linear_dw(dev, M, K, N, rpw):
     from hual_amd import lib
     g = torch.Generator(device='cpu').manual_seed(M + K + N)
@@ -61,12 +61,12 @@ def test_linear_dw(dev, M, K, N, rpw):
     dY = torch.randint(-2, 3, (M, N), generator=g).float().to(dev)
     dW = torch.zeros(K, N, device=dev)
     db = torch.zeros(N, device=dev)
-    lib.linear_dw(A, dY, dW, db, rows_per_wave=rpw)
+    lib.linear_dw(A, dY, dW, db, rows_per_block=rpw)
     assert torch.equal(dW, A.t() @ dY)          # small integers: exact in fp32 regardless of summation order
     assert torch.equal(db, dY.sum(0))
     A = torch.randn(M, K, generator=g).to(dev)
     dY = torch.randn(M, N, generator=g).to(dev)
     dW.zero_(); db.zero_()
-    lib.linear_dw(A, dY, dW, db, rows_per_wave=rpw)
+    lib.linear_dw(A, dY, dW, db, rows_per_block=rpw)
     ref = A.double().t() @ dY.double()
     assert (dW.double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item()) * (M ** 0.5)
