@@ -19,7 +19,9 @@ struct EmbedArgs {
 struct EmbedGrads {
   const float* dcat; int lddcat;
   float* dunk; float* dchar_table; float* dfilt[4]; float* dfbias[4];
+  float* partial;               // scratch: embed_bwd_partial_floats() floats
 };
+size_t embed_bwd_partial_floats(int nrows, int word_dim, int char_dim, int num_chars);
 int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStream_t s);
 int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const DropCfg& drop, hipStream_t s);
 

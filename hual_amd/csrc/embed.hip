@@ -95,8 +95,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a, DropCfg dro
   }
 }
 
-// backward: LDS accumulators [dF | dB | dT | dU], two words in flight per block
-__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, EmbedGrads gr, DropCfg drop, int nrows) {
+// backward: LDS accumulators [dF | dB | dT | dU]; one word at a time per block, all 256 threads.
+// Thread <-> filter tap (kernel width k, tap dk, embedding column d): it owns that row of dF (plain LDS
+// read-modify-write, no conflicts) and walks the channels of width k; the char-embedding gradient goes through
+// ds_add_f32 (taps of different threads can meet on the same (char, d) only across waves).
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, EmbedGrads gr, DropCfg drop, int nrows,
+                                                        int words_per_block) {
   extern __shared__ float sm[];
   const int wd = a.word_dim, cd = a.char_dim, C = a.C;
   const int nfil = cd * (1 * 10 + 2 * 20 + 3 * 30 + 4 * 40);
@@ -105,80 +109,106 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, EmbedGrads 
   float* dB = dF + nfil;                 // [NCH]
   float* dT = dB + NCH;                  // [ntab]
   float* dU = dT + ntab;                 // [wd]
-  float* slot = dU + wd;                 // per half: emb[C*cd], demb[C*cd]
-  const int half = threadIdx.x >> 7, tid = threadIdx.x & 127;
-  float* emb = slot + half * 2 * C * cd;
-  float* demb = emb + C * cd;
+  float* emb = dU + wd;                  // [C*cd] dropped char embeddings of the current word
+  float* demb = emb + C * cd;            // [C*cd]
+  float* gch = demb + C * cd;            // [NCH] upstream gradient per channel (0 where relu clipped)
+  int* argc = reinterpret_cast<int*>(gch + NCH);   // [NCH]
+  const int tid = threadIdx.x;
   const int nacc = nfil + NCH + ntab + wd;
-  for (int i = threadIdx.x; i < nacc; i += 256) sm[i] = 0.f;
+  for (int i = tid; i < nacc; i += 256) sm[i] = 0.f;
   const int foff[4] = {0, cd * 10, cd * 10 + 2 * cd * 20, cd * 10 + 2 * cd * 20 + 3 * cd * 30};
-  for (int row0 = blockIdx.x * 2; row0 < nrows; row0 += gridDim.x * 2) {
-    const int row = row0 + half;
-    const bool act = row < nrows;
+  const int choff[4] = {0, 10, 30, 60};
+  const int ntap = 10 * cd;              // (1+2+3+4) * cd taps
+  const int row_lo = blockIdx.x * words_per_block;
+  const int row_hi = min(row_lo + words_per_block, nrows);
+  for (int row = row_lo; row < row_hi; ++row) {
     __syncthreads();
-    if (act) {
-      load_char_emb(a, drop, row, emb, tid, 128);
-      for (int idx = tid; idx < C * cd; idx += 128) demb[idx] = 0.f;
-      const float* dcat = gr.dcat + (size_t)row * gr.lddcat;
-      if (a.word_ids[row] == 1)
-        for (int c = tid; c < wd; c += 128) {
-          float g = dcat[c];
-          if (drop.enabled) g *= drop1(drop, HUAL_SITE_WORD, (uint32_t)row, c);
-          atomicAdd(&dU[c], g);
-        }
-    }
-    __syncthreads();
-    if (act && tid < NCH) {
+    load_char_emb(a, drop, row, emb, tid, 256);
+    for (int idx = tid; idx < C * cd; idx += 256) demb[idx] = 0.f;
+    const float* dcat = gr.dcat + (size_t)row * gr.lddcat;
+    if (tid < NCH) {
       const int arg = a.char_arg[(size_t)row * NCH + tid];
-      if (arg >= 0) {
-        int k, chk, nchk;
-        chan_to_kernel(tid, k, chk, nchk);
-        const float g = gr.dcat[(size_t)row * gr.lddcat + wd + tid];
-        atomicAdd(&dB[tid], g);
-        const float* F = a.filt[k - 1] + chk;
-        float* f = dF + foff[k - 1] + chk;
-        for (int dk = 0; dk < k; ++dk) {
-          const float* e = emb + (arg + dk) * cd;
-          float* de = demb + (arg + dk) * cd;
-          for (int d = 0; d < cd; ++d) {
-            const int fi = (dk * cd + d) * nchk;
-            atomicAdd(&f[fi], g * e[d]);            // filter gradient (LDS)
-            atomicAdd(&de[d], g * F[fi]);           // embedding gradient (LDS)
-          }
-        }
+      const float g = arg >= 0 ? dcat[wd + tid] : 0.f;
+      argc[tid] = arg;
+      gch[tid] = g;
+      dB[tid] += g;
+    }
+    if (a.word_ids[row] == 1)
+      for (int c = tid; c < wd; c += 256) {
+        float g = dcat[c];
+        if (drop.enabled) g *= drop1(drop, HUAL_SITE_WORD, (uint32_t)row, c);
+        dU[c] += g;
+      }
+    __syncthreads();
+    for (int tap = tid; tap < ntap; tap += 256) {
+      // taps are ordered [k=1: cd][k=2: 2cd][k=3: 3cd][k=4: 4cd]
+      int k, base;
+      if (tap < cd) { k = 1; base = 0; }
+      else if (tap < 3 * cd) { k = 2; base = cd; }
+      else if (tap < 6 * cd) { k = 3; base = 3 * cd; }
+      else { k = 4; base = 6 * cd; }
+      const int rel = tap - base;            // dk*cd + d
+      const int dk = rel / cd, d = rel - dk * cd;
+      const int nchk = 10 * k;
+      const float* F = a.filt[k - 1] + (size_t)rel * nchk;
+      float* f = dF + foff[k - 1] + rel * nchk;
+      const int c0 = choff[k - 1];
+      for (int ch = 0; ch < nchk; ++ch) {
+        const int arg = argc[c0 + ch];
+        if (arg < 0) continue;
+        const float g = gch[c0 + ch];
+        const int ei = (arg + dk) * cd + d;
+        f[ch] += g * emb[ei];
+        atomicAdd(&demb[ei], g * F[ch]);
       }
     }
     __syncthreads();
-    if (act) {
-      for (int idx = tid; idx < C * cd; idx += 128) {
-        const int c = idx / cd, d = idx - c * cd;
-        const int cid = a.char_ids[(size_t)row * C + c];
-        if (cid > 0) {
-          float g = demb[idx];
-          if (drop.enabled) g *= drop1(drop, HUAL_SITE_CHAR, (uint32_t)(row * C + c), d);
-          atomicAdd(&dT[(size_t)(cid - 1) * cd + d], g);
-        }
+    for (int idx = tid; idx < C * cd; idx += 256) {
+      const int c = idx / cd, d = idx - c * cd;
+      const int cid = a.char_ids[(size_t)row * C + c];
+      if (cid > 0) {
+        float g = demb[idx];
+        if (drop.enabled) g *= drop1(drop, HUAL_SITE_CHAR, (uint32_t)(row * C + c), d);
+        atomicAdd(&dT[(size_t)(cid - 1) * cd + d], g);
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nfil; i += 256) {
-    const int k = i < foff[1] ? 0 : (i < foff[2] ? 1 : (i < foff[3] ? 2 : 3));
-    const float v = dF[i];
-    if (v != 0.f) atomicAdd(gr.dfilt[k] + (i - foff[k]), v);
-  }
-  for (int i = threadIdx.x; i < NCH; i += 256) {
-    int k, chk, nchk;
-    chan_to_kernel(i, k, chk, nchk);
-    atomicAdd(gr.dfbias[k - 1] + chk, dB[i]);
-  }
-  for (int i = threadIdx.x; i < ntab; i += 256) {
-    const float v = dT[i];
-    if (v != 0.f) atomicAdd(gr.dchar_table + i, v);
-  }
-  for (int i = threadIdx.x; i < wd; i += 256) {
-    const float v = dU[i];
-    if (v != 0.f) atomicAdd(gr.dunk + i, v);
+  // this block's partial sums -> scratch (plain coalesced stores; summed over blocks by embed_reduce_kernel)
+  float* part = gr.partial + (size_t)blockIdx.x * nacc;
+  for (int i = tid; i < nacc; i += 256) part[i] = sm[i];
+}
+
+// sums the per-block partials [nblocks][nacc] and adds them to the parameter gradients (one owner per element).
+// 256 threads = 64 elements x 4 groups of blocks.
+__global__ __launch_bounds__(256) void embed_reduce_kernel(EmbedArgs a, EmbedGrads gr, int nblocks) {
+  __shared__ float part[4][64];
+  const int cd = a.char_dim, wd = a.word_dim;
+  const int nfil = cd * (1 * 10 + 2 * 20 + 3 * 30 + 4 * 40);
+  const int ntab = (a.num_chars - 1) * cd;
+  const int nacc = nfil + NCH + ntab + wd;
+  const int foff[4] = {0, cd * 10, cd * 10 + 2 * cd * 20, cd * 10 + 2 * cd * 20 + 3 * cd * 30};
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  float s = 0.f;
+  if (i < nacc)
+    for (int b = grp; b < nblocks; b += 4) s += gr.partial[(size_t)b * nacc + i];
+  part[grp][e] = s;
+  __syncthreads();
+  if (grp == 0 && i < nacc) {
+    s = part[0][e] + part[1][e] + part[2][e] + part[3][e];
+    if (i < nfil) {
+      const int k = i < foff[1] ? 0 : (i < foff[2] ? 1 : (i < foff[3] ? 2 : 3));
+      gr.dfilt[k][i - foff[k]] += s;
+    } else if (i < nfil + NCH) {
+      int k, chk, nchk;
+      chan_to_kernel(i - nfil, k, chk, nchk);
+      gr.dfbias[k - 1][chk] += s;
+    } else if (i < nfil + NCH + ntab) {
+      gr.dchar_table[i - nfil - NCH] += s;
+    } else {
+      gr.dunk[i - nfil - NCH - ntab] += s;
+    }
   }
 }
 
@@ -194,20 +224,29 @@ int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStre
   return 0;
 }
 
+#define EMBED_WPB 5                      // words per block of the backward kernel
+int embed_bwd_blocks(int nrows) { return cdiv(nrows, EMBED_WPB); }
+size_t embed_bwd_partial_floats(int nrows, int word_dim, int char_dim, int num_chars) {
+  const size_t nacc = (size_t)char_dim * 300 + NCH + (size_t)(num_chars - 1) * char_dim + word_dim;
+  return nacc * embed_bwd_blocks(nrows);
+}
+
 int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const DropCfg& drop, hipStream_t s) {
   const int cd = a.char_dim;
   const int nfil = cd * (10 + 40 + 90 + 160);
-  const size_t bytes = ((size_t)4 * a.C * cd + nfil + NCH + (size_t)(a.num_chars - 1) * cd + a.word_dim) * sizeof(float);
+  const size_t bytes = ((size_t)2 * a.C * cd + nfil + 3 * NCH + (size_t)(a.num_chars - 1) * cd + a.word_dim) * sizeof(float);
   HUAL_REQUIRE(bytes <= 160 * 1024, "embed_bwd: char filter gradients do not fit LDS");
   static bool attr = false;
   if (!attr) {
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)embed_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  int grid = cdiv(nrows, 8);           // >= 4 word pairs per block before its accumulators are flushed
-  grid = grid < 256 ? (grid > 0 ? grid : 1) : 256;
+  HUAL_REQUIRE(g.partial != nullptr, "embed_bwd: null partial-sum scratch");
+  const int grid = embed_bwd_blocks(nrows);
   ProfScope ps(PK_EMBED, s, 0.0, 0.0);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), bytes, s, a, g, drop, nrows);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), bytes, s, a, g, drop, nrows, EMBED_WPB);
+  const int nacc = nfil + NCH + (a.num_chars - 1) * cd + a.word_dim;
+  hipLaunchKernelGGL(embed_reduce_kernel, dim3(cdiv(nacc, 64)), dim3(256), 0, s, a, g, grid);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -75,6 +75,9 @@ struct DwBatch {
   DwJob j[HUAL_MAX_DW_JOBS];
 };
 
+// dst[off + n*K + k] = src[off + k*N + n] for n dense weights [K,N] inside the flat parameter buffer
+int launch_transpose_weights(const uint32_t* offs, const int* Ks, const int* Ns, int n, const float* src, float* dst,
+                             hipStream_t stream);
 void gemm_job_init(GemmJob& j);
 void dw_job_init(DwJob& j);
 // enqueue `n` jobs (n <= HUAL_MAX_JOBS) as ONE launch on `stream`

@@ -16,6 +16,7 @@
 #include "gemm.h"
 #include "philox.h"
 #include "prof.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace hual {
@@ -82,6 +83,64 @@ __device__ __forceinline__ void mma_frag(f32x4 (&acc)[4], const float4& a, const
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = mfma16(av, f4get(b[t], c), acc[t]);
     }
+  }
+}
+
+template <bool DUAL>
+__device__ __forceinline__ void gemm_epilogue(const GemmJob& job, const DropCfg& drop, f32x4 (&acc)[4], f32x4 (&acc2)[4],
+                                              int rowbase, int n0, int j, int g) {
+  const int M = job.M, N = job.N;
+  // ---------------- epilogue: lane owns rows rowbase+4g+r (r=0..3), columns n0+4j .. n0+4j+3 -------------
+  const int col = n0 + 4 * j;
+  float4 bias = (job.bias && col < N) ? ld4(job.bias + col) : f4zero();
+  float4 bias2 = f4zero();
+  if (DUAL && job.bias2 && col < N) bias2 = ld4(job.bias2 + col);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = rowbase + 4 * g + r;
+    if (row >= M || col >= N) continue;
+    float4 v = make_float4(acc[0][r] + bias.x, acc[1][r] + bias.y, acc[2][r] + bias.z, acc[3][r] + bias.w);
+    float rm = job.rowmask ? job.rowmask[row] : 1.0f;
+    if (job.act == ACT_RELU) {
+      v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    } else if (job.act == ACT_SIGMOID) {
+      v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+    } else if (job.act == ACT_SIGMOID_ROWMASK) {
+      // sigmoid(mask_logits(x, m)): m=1 -> sigmoid(x); m=0 -> sigmoid(-1e30) == 0   (layers.py:110)
+      v = rm != 0.f ? make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)) : f4zero();
+    }
+    if (DUAL) {
+      float4 v2 = make_float4(acc2[0][r] + bias2.x, acc2[1][r] + bias2.y, acc2[2][r] + bias2.z, acc2[3][r] + bias2.w);
+      if (job.comb == COMB_GATE_VAL) {
+        if (job.save) st4(job.save + (size_t)row * job.ldsave + col, v);
+        if (job.save2) st4(job.save2 + (size_t)row * job.ldsave2 + col, v2);
+        v = f4mul(v, v2);
+      } else if (job.comb == COMB_CROSSGATE) {
+        v2 = make_float4(sigmoidf_(v2.x), sigmoidf_(v2.y), sigmoidf_(v2.z), sigmoidf_(v2.w));
+        if (job.save) st4(job.save + (size_t)row * job.ldsave + col, v);
+        if (job.save2) st4(job.save2 + (size_t)row * job.ldsave2 + col, v2);
+        float4 x1 = ld4(job.aux1 + (size_t)row * job.ldaux + col);
+        float4 x2 = ld4(job.aux2 + (size_t)row * job.ldaux + col);
+        v = f4add(f4mul(v, x1), f4mul(v2, x2));
+      }
+    } else {
+      if (job.save) st4(job.save + (size_t)row * job.ldsave + col, v);
+    }
+    if (job.mulmode != MUL_NONE) {
+      float4 m = ld4(job.mul + (size_t)row * job.ldmul + col);
+      if (job.mulmode == MUL_TENSOR) {
+        v = f4mul(v, m);
+      } else if (job.mulmode == MUL_DRELU) {
+        v = make_float4(m.x > 0.f ? v.x : 0.f, m.y > 0.f ? v.y : 0.f, m.z > 0.f ? v.z : 0.f, m.w > 0.f ? v.w : 0.f);
+      } else {
+        v = make_float4(v.x * m.x * (1.f - m.x), v.y * m.y * (1.f - m.y), v.z * m.z * (1.f - m.z), v.w * m.w * (1.f - m.w));
+      }
+    }
+    if (job.drop_site >= 0 && drop.enabled)
+      v = apply_drop4(drop, (uint32_t)job.drop_site, job.drop_row0 + (uint32_t)row, (uint32_t)(col >> 2), v);
+    if (job.add) v = f4add(v, ld4(job.add + (size_t)(row / job.add_div) * job.ldadd + col));
+    if (job.mask_out) v = make_float4(v.x * rm, v.y * rm, v.z * rm, v.w * rm);
+    st4(job.Y + (size_t)row * job.ldy + col, v);
   }
 }
 
@@ -161,27 +220,66 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, DropCfg drop
     if (DUAL) mma_frag(acc2, fb[0].a, fb[0].b, transW);
   }
 
-  // ---------------- epilogue: lane owns rows rowbase+4g+r (r=0..3), columns n0+4j .. n0+4j+3 -------------
+  gemm_epilogue<DUAL>(job, drop, acc, acc2, rowbase, n0, j, g);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// gemm_lds_kernel: same job semantics and the same wave -> (16 rows x 64 cols) mapping as gemm_kernel, built to
+// expose ONE memory round trip per block instead of four (PMC on gemm_kernel: 61 % of wave cycles in s_waitcnt,
+// 26 k cycles of wave life for 4 k cycles of MFMA):
+//   * the weight panel (all 128 output columns x 64 K rows per stage, 32 KB) goes global -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers), once per BLOCK, shared by the four waves; two stages (= a
+//     whole K=128 layer) are requested in the prologue, later stages are requested as soon as a buffer is free;
+//   * each wave requests the A fragments of those stages and its epilogue operands (bias, residual rows) in the
+//     same prologue, so they are in registers when the MFMAs / the epilogue need them;
+//   * the panel image is the plain [64][128] row-major tile: for the B-fragment ds_read_b128 (lane (j,g) reads 16 B
+//     at row 4g+c, column 4j) the hardware's 16-lane groups then cover disjoint bank ranges - conflict free.
+// Weights must be stored [K,N] (transW = 0); dX jobs use the transposed copy made by transpose_weights_kernel.
+#define GL_KS 64            // K rows per stage
+#define GL_STAGE (GL_KS * 128)   // floats per staged panel
+
+struct EpiRegs {
+  float4 bias, bias2;
+  float4 add[4];
+  float rm[4];
+};
+
+template <bool DUAL>
+__device__ __forceinline__ void epi_prefetch(const GemmJob& job, EpiRegs& e, int rowbase, int n0, int j, int g) {
+  const int M = job.M, N = job.N;
   const int col = n0 + 4 * j;
-  float4 bias = (job.bias && col < N) ? ld4(job.bias + col) : f4zero();
-  float4 bias2 = f4zero();
-  if (DUAL && job.bias2 && col < N) bias2 = ld4(job.bias2 + col);
+  const bool cok = col < N;
+  e.bias = (job.bias && cok) ? ld4(job.bias + col) : f4zero();
+  e.bias2 = (DUAL && job.bias2 && cok) ? ld4(job.bias2 + col) : f4zero();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = min(rowbase + 4 * g + r, M - 1);
+    e.rm[r] = job.rowmask ? job.rowmask[row] : 1.0f;
+    e.add[r] = (job.add && cok) ? ld4(job.add + (size_t)(row / job.add_div) * job.ldadd + col) : f4zero();
+  }
+}
+
+template <bool DUAL>
+__device__ __forceinline__ void epi_apply(const GemmJob& job, const DropCfg& drop, const EpiRegs& e, f32x4 (&acc)[4],
+                                          f32x4 (&acc2)[4], int rowbase, int n0, int j, int g) {
+  const int M = job.M, N = job.N;
+  const int col = n0 + 4 * j;
+  if (col >= N) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = rowbase + 4 * g + r;
-    if (row >= M || col >= N) continue;
-    float4 v = make_float4(acc[0][r] + bias.x, acc[1][r] + bias.y, acc[2][r] + bias.z, acc[3][r] + bias.w);
-    float rm = job.rowmask ? job.rowmask[row] : 1.0f;
+    if (row >= M) continue;
+    float4 v = make_float4(acc[0][r] + e.bias.x, acc[1][r] + e.bias.y, acc[2][r] + e.bias.z, acc[3][r] + e.bias.w);
+    const float rm = e.rm[r];
     if (job.act == ACT_RELU) {
       v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     } else if (job.act == ACT_SIGMOID) {
       v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
     } else if (job.act == ACT_SIGMOID_ROWMASK) {
-      // sigmoid(mask_logits(x, m)): m=1 -> sigmoid(x); m=0 -> sigmoid(-1e30) == 0   (layers.py:110)
       v = rm != 0.f ? make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)) : f4zero();
     }
     if (DUAL) {
-      float4 v2 = make_float4(acc2[0][r] + bias2.x, acc2[1][r] + bias2.y, acc2[2][r] + bias2.z, acc2[3][r] + bias2.w);
+      float4 v2 = make_float4(acc2[0][r] + e.bias2.x, acc2[1][r] + e.bias2.y, acc2[2][r] + e.bias2.z, acc2[3][r] + e.bias2.w);
       if (job.comb == COMB_GATE_VAL) {
         if (job.save) st4(job.save + (size_t)row * job.ldsave + col, v);
         if (job.save2) st4(job.save2 + (size_t)row * job.ldsave2 + col, v2);
@@ -198,7 +296,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, DropCfg drop
       if (job.save) st4(job.save + (size_t)row * job.ldsave + col, v);
     }
     if (job.mulmode != MUL_NONE) {
-      float4 m = ld4(job.mul + (size_t)row * job.ldmul + col);
+      const float4 m = ld4(job.mul + (size_t)row * job.ldmul + col);
       if (job.mulmode == MUL_TENSOR) {
         v = f4mul(v, m);
       } else if (job.mulmode == MUL_DRELU) {
@@ -209,9 +307,162 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, DropCfg drop
     }
     if (job.drop_site >= 0 && drop.enabled)
       v = apply_drop4(drop, (uint32_t)job.drop_site, job.drop_row0 + (uint32_t)row, (uint32_t)(col >> 2), v);
-    if (job.add) v = f4add(v, ld4(job.add + (size_t)(row / job.add_div) * job.ldadd + col));
+    if (job.add) v = f4add(v, e.add[r]);
     if (job.mask_out) v = make_float4(v.x * rm, v.y * rm, v.z * rm, v.w * rm);
     st4(job.Y + (size_t)row * job.ldy + col, v);
+  }
+}
+
+// stage index (64 K rows each, over the concatenated pieces) -> piece and K offset inside it (block-uniform)
+__device__ __forceinline__ void stage_to_piece(const GemmJob& job, int st, int& p, int& k0) {
+  p = 0;
+  while (p + 1 < job.npieces) {
+    const int n = (job.kw[p] + GL_KS - 1) / GL_KS;
+    if (st < n) break;
+    st -= n;
+    ++p;
+  }
+  k0 = st * GL_KS;
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void gemm_lds_kernel(GemmBatch batch, DropCfg drop) {
+  extern __shared__ float lds[];     // Ws[2][GL_STAGE] (+ W2s[2][GL_STAGE] when DUAL)
+  const GemmJob& job = batch.j[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int M = job.M, N = job.N;
+  const int blockrow = blockIdx.x * 32;
+  const int nblk = blockIdx.y * 128;
+  if (blockrow >= M || nblk >= N) return;          // block-uniform
+  const int rowbase = blockrow + (wave >> 1) * 16;
+  const int n0 = nblk + (wave & 1) * 64;
+  const bool wave_on = rowbase < M && n0 < N;       // idle waves still take part in staging and barriers
+  const int arow = min(rowbase + j, M - 1);
+  const int ldw = job.ldw;
+  const bool adrop = job.a_drop_site >= 0 && drop.enabled;
+  const uint32_t asite = (uint32_t)job.a_drop_site;
+  const uint32_t adrow = job.a_drop_row0 + (uint32_t)arow;
+  float* Ws = lds;
+  float* W2s = lds + 2 * GL_STAGE;
+  int nstages = 0;
+  for (int p = 0; p < job.npieces; ++p) nstages += (job.kw[p] + GL_KS - 1) / GL_KS;
+
+  f32x4 acc[4], acc2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // LDS-DMA of one stage: 32 pieces of 1 KB (2 panel rows each), 8 per wave; lane l -> row 2*pc + (l>>5), 16 B at
+  // column 4*(l&31).  Out-of-range rows / columns are clamped to valid memory (never multiplied / never stored).
+  auto dma_stage = [&](const float* Wp, int k0, int kw, float* dst) {
+    const int c4 = lane & 31, rr = lane >> 5;
+    const int n = min(nblk + 4 * c4, N - 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int pc = wave * 8 + u;
+      const int kk = min(k0 + 2 * pc + rr, kw - 1);
+      const float* src = Wp + (size_t)kk * ldw + n;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+    }
+  };
+  auto a_load = [&](const float* Ap, const float* A2p, int k0, int kw, float4 (&a)[4]) {
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const int kk = k0 + kc * 16;
+      float4 v = f4zero();
+      if (kk < kw) {
+        v = ld4(Ap + kk + 4 * g);
+        if (A2p) v = f4mul(v, ld4(A2p + kk + 4 * g));
+        if (adrop) v = apply_drop4(drop, asite, adrow, (uint32_t)((kk + 4 * g) >> 2), v);
+      }
+      a[kc] = v;
+    }
+  };
+  // request stage s: weight panel(s) by DMA into buffer (s & 1), A fragments into the given register slot
+  auto issue = [&](int s, float4 (&a)[4], float4 (&a2)[4], int& kw_out, int& k0_out) {
+    int p, k0;
+    stage_to_piece(job, s, p, k0);
+    const int kw = job.kw[p];
+    dma_stage(job.W[p], k0, kw, Ws + (s & 1) * GL_STAGE);
+    if (DUAL) dma_stage(job.W2[p], k0, kw, W2s + (s & 1) * GL_STAGE);
+    const float* Ap = job.A[p] + (size_t)arow * job.lda[p];
+    const float* A2p = job.A2[p] ? job.A2[p] + (size_t)arow * job.lda2[p] : nullptr;
+    a_load(Ap, A2p, k0, kw, a);
+    if (DUAL) {
+      if (job.Ab[p]) a_load(job.Ab[p] + (size_t)arow * job.ldab[p], nullptr, k0, kw, a2);
+      else {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) a2[kc] = a[kc];
+      }
+    }
+    kw_out = kw;
+    k0_out = k0;
+  };
+  auto compute = [&](int bufi, int k0, int kw, const float4 (&a)[4], const float4 (&a2)[4]) {
+    const float* wsb = Ws + bufi * GL_STAGE + (wave & 1) * 64 + 4 * j;
+    const float* w2b = W2s + bufi * GL_STAGE + (wave & 1) * 64 + 4 * j;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      if (k0 + kc * 16 < kw) {
+        float4 b[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(wsb + (kc * 16 + 4 * g + c) * 128);
+        mma_frag(acc, a[kc], b, 0);
+        if (DUAL) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(w2b + (kc * 16 + 4 * g + c) * 128);
+          mma_frag(acc2, a2[kc], b, 0);
+        }
+      }
+    }
+  };
+
+  float4 a0[4], a1[4], c0[4], c1[4];
+  int kw0 = 0, kw1 = 0, k00 = 0, k01 = 0;
+  EpiRegs epi;
+  // prologue: the first TWO stages (a whole K=128 layer) + everything the epilogue will read
+  issue(0, a0, c0, kw0, k00);
+  if (nstages > 1) issue(1, a1, c1, kw1, k01);
+  epi_prefetch<DUAL>(job, epi, rowbase, n0, j, g);
+  for (int s = 0; s < nstages; s += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // DMA of the resident stages has landed (this wave's part)
+    __syncthreads();                                      // ... and everybody else's
+    if (wave_on) compute(0, k00, kw0, a0, c0);
+    if (s + 1 < nstages && wave_on) compute(1, k01, kw1, a1, c1);
+    if (s + 2 < nstages) {
+      __syncthreads();                                    // both buffers consumed by every wave
+      issue(s + 2, a0, c0, kw0, k00);
+      if (s + 3 < nstages) issue(s + 3, a1, c1, kw1, k01);
+    }
+  }
+  if (!wave_on) return;
+  epi_apply<DUAL>(job, drop, epi, acc, acc2, rowbase, n0, j, g);
+}
+
+// WT[n][k] = W[k][n] for a table of dense weights inside the flat parameter buffer (same offsets in `dst`).
+struct TrJob { uint32_t off; int K, N; };
+#define HUAL_MAX_TR 96
+struct TrBatch { TrJob j[HUAL_MAX_TR]; };
+__global__ __launch_bounds__(256) void transpose_weights_kernel(TrBatch b, const float* src, float* dst) {
+  __shared__ float tile[32][33];
+  const TrJob job = b.j[blockIdx.z];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  if (k0 >= job.K || n0 >= job.N) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* W = src + job.off;
+  float* WT = dst + job.off;
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, n = n0 + tx;
+    tile[r][tx] = (k < job.K && n < job.N) ? W[(size_t)k * job.N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, k = k0 + tx;
+    if (n < job.N && k < job.K) WT[(size_t)n * job.K + k] = tile[tx][r];
   }
 }
 
@@ -357,6 +608,21 @@ __global__ __launch_bounds__(256) void dw_kernel(DwBatch batch, const DwJob* __r
 
 namespace hual {
 
+int launch_transpose_weights(const uint32_t* offs, const int* Ks, const int* Ns, int n, const float* src, float* dst, hipStream_t stream) {
+  HUAL_REQUIRE(n >= 0 && n <= HUAL_MAX_TR, "transpose: too many weights");
+  if (n == 0) return 0;
+  TrBatch b;
+  int maxK = 0, maxN = 0;
+  for (int i = 0; i < n; ++i) {
+    b.j[i].off = offs[i]; b.j[i].K = Ks[i]; b.j[i].N = Ns[i];
+    maxK = Ks[i] > maxK ? Ks[i] : maxK;
+    maxN = Ns[i] > maxN ? Ns[i] : maxN;
+  }
+  hipLaunchKernelGGL(transpose_weights_kernel, dim3(cdiv(maxK, 32), cdiv(maxN, 32), n), dim3(256), 0, stream, b, src, dst);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream) {
   HUAL_REQUIRE(n >= 1 && n <= HUAL_MAX_JOBS, "launch_gemm: job count");
   GemmBatch b;
@@ -390,10 +656,27 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
     bytes += 4.0 * ((double)jobs[i].M * kt + kt * jobs[i].N * mult + (double)jobs[i].M * jobs[i].N);
   }
   ProfScope ps(dual ? PK_GEMM_DUAL : PK_GEMM, stream, flops, bytes);
-  if (dual)
-    hipLaunchKernelGGL(gemm_kernel<true>, grid, block, 0, stream, b, drop);
-  else
-    hipLaunchKernelGGL(gemm_kernel<false>, grid, block, 0, stream, b, drop);
+  static const int impl = []() { const char* e = getenv("HUAL_GEMM_IMPL"); return e ? atoi(e) : 1; }();
+  bool anytrans = false;
+  for (int i = 0; i < n; ++i) anytrans = anytrans || jobs[i].transW != 0;
+  if (impl == 0 || anytrans) {   // the LDS-DMA kernel needs [K,N] weights; transposed reads fall back to gemm_kernel
+    if (dual)
+      hipLaunchKernelGGL(gemm_kernel<true>, grid, block, 0, stream, b, drop);
+    else
+      hipLaunchKernelGGL(gemm_kernel<false>, grid, block, 0, stream, b, drop);
+  } else {
+    const size_t lds = (size_t)(dual ? 4 : 2) * GL_STAGE * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    if (dual)
+      hipLaunchKernelGGL(gemm_lds_kernel<true>, grid, block, lds, stream, b, drop);
+    else
+      hipLaunchKernelGGL(gemm_lds_kernel<false>, grid, block, lds, stream, b, drop);
+  }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

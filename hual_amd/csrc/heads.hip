@@ -11,7 +11,7 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {   // blockDim m
   __syncthreads();
   float s = 0.f;
   for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sm[i];
-  return s;
+  return s;   // sm must hold blockDim.x/64 floats
 }
 __device__ __forceinline__ float block_max(float v, float* sm) {
   v = wave_max64(v);
@@ -59,18 +59,26 @@ __global__ __launch_bounds__(128) void pool_fwd_kernel(PoolArgs a, RowSpace rs) 
   a.PW[b * HUAL_D + c] = o;
 }
 
+// stage 1 (512 threads): dPW[b] = sum_t dFuse[b,t,:]   (4 row groups, then LDS)
+__global__ __launch_bounds__(512) void pool_dpw_kernel(PoolBwd g, RowSpace rs) {
+  __shared__ float part[4][HUAL_D];
+  const int b = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
+  const int T = rs.T;
+  float s = 0.f;
+  const float* dfu = g.dFuse + (size_t)b * T * HUAL_D;
+  for (int t = grp; t < T; t += 4) s += dfu[(size_t)t * HUAL_D + c];
+  part[grp][c] = s;
+  __syncthreads();
+  if (grp == 0) g.dPW[b * HUAL_D + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+}
+
 __global__ __launch_bounds__(128) void pool_bwd_kernel(PoolArgs a, PoolBwd g, RowSpace rs) {
   __shared__ float dpw[HUAL_D];
   __shared__ float da[256];
   __shared__ float sm[4];
   const int b = blockIdx.x, c = threadIdx.x;
-  const int L = rs.L, T = rs.T;
-  // dPW = sum_t dFuse[b,t,:]
-  float s = 0.f;
-  const float* dfu = g.dFuse + (size_t)b * T * HUAL_D;
-  for (int t = 0; t < T; ++t) s += dfu[(size_t)t * HUAL_D + c];
-  dpw[c] = s;
-  g.dPW[b * HUAL_D + c] = s;
+  const int L = rs.L;
+  dpw[c] = g.dPW[b * HUAL_D + c];
   __syncthreads();
   // dpooled[c] = sum_n dPW[n] * Wbot[c][n]
   float dp = 0.f;
@@ -364,25 +372,31 @@ __global__ __launch_bounds__(256) void loc_kernel(LocArgs a, int T) {
 // ------------------------------------------------------------------------------------------------------
 // alignment loss
 #define L2_EPS 1e-12f
-__global__ __launch_bounds__(128) void align_pool_kernel(AlignPool a, RowSpace rs) {
-  __shared__ float sm[4];
-  const int b = blockIdx.x, c = threadIdx.x;
+__global__ __launch_bounds__(512) void align_pool_kernel(AlignPool a, RowSpace rs) {
+  __shared__ float sm[8];
+  __shared__ float part[2][4][HUAL_D];
+  const int b = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
   const int L = rs.L, T = rs.T;
-  float ts = 0.f, tc = 0.f;
-  for (int l = 0; l < L; ++l) {
-    ts += a.F2[(size_t)(rs.Nv + b * L + l) * HUAL_D + c];     // padded words included (layers.py:214)
-    tc += rs.rowmask[rs.Nv + b * L + l];
-  }
-  const float tp = ts / tc;
-  float vs = 0.f, vc = 0.f;
+  float tc = 0.f, vc = 0.f;
+  for (int l = 0; l < L; ++l) tc += rs.rowmask[rs.Nv + b * L + l];
   for (int t = 0; t < T; ++t) vc += rs.rowmask[b * T + t];
-  for (int t = 0; t < T; ++t) vs += a.F1[(size_t)(b * T + t) * HUAL_D + c] * (a.inner[b * T + t] / vc);
-  const float tn = block_sum(tp * tp, sm);
-  const float vn = block_sum(vs * vs, sm);
-  a.tpre[b * HUAL_D + c] = tp;
-  a.vpre[b * HUAL_D + c] = vs;
-  a.that[b * HUAL_D + c] = tp * rsqrtf(fmaxf(tn, L2_EPS));
-  a.vhat[b * HUAL_D + c] = vs * rsqrtf(fmaxf(vn, L2_EPS));
+  float ts = 0.f, vs = 0.f;
+  for (int l = grp; l < L; l += 4) ts += a.F2[(size_t)(rs.Nv + b * L + l) * HUAL_D + c];     // padded words included (layers.py:214)
+  for (int t = grp; t < T; t += 4) vs += a.F1[(size_t)(b * T + t) * HUAL_D + c] * (a.inner[b * T + t] / vc);
+  part[0][grp][c] = ts;
+  part[1][grp][c] = vs;
+  __syncthreads();
+  ts = part[0][0][c] + part[0][1][c] + part[0][2][c] + part[0][3][c];
+  vs = part[1][0][c] + part[1][1][c] + part[1][2][c] + part[1][3][c];
+  const float tp = ts / tc;
+  const float tn = block_sum(grp == 0 ? tp * tp : 0.f, sm);
+  const float vn = block_sum(grp == 0 ? vs * vs : 0.f, sm);
+  if (grp == 0) {
+    a.tpre[b * HUAL_D + c] = tp;
+    a.vpre[b * HUAL_D + c] = vs;
+    a.that[b * HUAL_D + c] = tp * rsqrtf(fmaxf(tn, L2_EPS));
+    a.vhat[b * HUAL_D + c] = vs * rsqrtf(fmaxf(vn, L2_EPS));
+  }
 }
 
 // row i of the [Bg,Bg] similarity matrices; one block (256 threads) per row, Bg <= 1024
@@ -453,16 +467,17 @@ __global__ __launch_bounds__(128) void align_sim_cols_kernel(AlignSim a) {
   a.dvhat[j * HUAL_D + c] += s;
 }
 
-__global__ __launch_bounds__(128) void align_pool_bwd_kernel(AlignPool a, AlignPoolBwd g, RowSpace rs) {
-  __shared__ float sm[4];
-  const int b = blockIdx.x, c = threadIdx.x;
+__global__ __launch_bounds__(512) void align_pool_bwd_kernel(AlignPool a, AlignPoolBwd g, RowSpace rs) {
+  __shared__ float sm[8];
+  const int b = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
   const int L = rs.L, T = rs.T;
   // l2_normalize backward: x_hat = x * r, r = rsqrt(max(|x|^2, eps)); dx = r * (dxh - x_hat * (x_hat . dxh)) when |x|^2 > eps
   const float tp = a.tpre[b * HUAL_D + c], vp = a.vpre[b * HUAL_D + c];
   const float th = a.that[b * HUAL_D + c], vh = a.vhat[b * HUAL_D + c];
   const float dth = g.dthat[b * HUAL_D + c], dvh = g.dvhat[b * HUAL_D + c];
-  const float tn = block_sum(tp * tp, sm), vn = block_sum(vp * vp, sm);
-  const float tdot = block_sum(th * dth, sm), vdot = block_sum(vh * dvh, sm);
+  const float w0 = grp == 0 ? 1.f : 0.f;     // every group holds the same 128 values: count them once
+  const float tn = block_sum(w0 * tp * tp, sm), vn = block_sum(w0 * vp * vp, sm);
+  const float tdot = block_sum(w0 * th * dth, sm), vdot = block_sum(w0 * vh * dvh, sm);
   const float rt = rsqrtf(fmaxf(tn, L2_EPS)), rv = rsqrtf(fmaxf(vn, L2_EPS));
   const float dtp = tn > L2_EPS ? rt * (dth - th * tdot) : rt * dth;
   const float dvp = vn > L2_EPS ? rv * (dvh - vh * vdot) : rv * dvh;
@@ -470,8 +485,8 @@ __global__ __launch_bounds__(128) void align_pool_bwd_kernel(AlignPool a, AlignP
   for (int l = 0; l < L; ++l) tc += rs.rowmask[rs.Nv + b * L + l];
   for (int t = 0; t < T; ++t) vc += rs.rowmask[b * T + t];
   const float dts = dtp / tc;
-  for (int l = 0; l < L; ++l) g.dF2[(size_t)(rs.Nv + b * L + l) * HUAL_D + c] = dts;
-  for (int t = 0; t < T; ++t) g.dF1[(size_t)(b * T + t) * HUAL_D + c] += dvp * (a.inner[b * T + t] / vc);
+  for (int l = grp; l < L; l += 4) g.dF2[(size_t)(rs.Nv + b * L + l) * HUAL_D + c] = dts;
+  for (int t = grp; t < T; t += 4) g.dF1[(size_t)(b * T + t) * HUAL_D + c] += dvp * (a.inner[b * T + t] / vc);
 }
 
 namespace hual {
@@ -483,6 +498,7 @@ int launch_pool_fwd(const PoolArgs& a, const RowSpace& rs, hipStream_t s) {
   return 0;
 }
 int launch_pool_bwd(const PoolArgs& a, const PoolBwd& g, const RowSpace& rs, hipStream_t s) {
+  hipLaunchKernelGGL(pool_dpw_kernel, dim3(rs.B), dim3(512), 0, s, g, rs);
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(rs.B), dim3(128), 0, s, a, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
@@ -528,7 +544,7 @@ int launch_loc(const LocArgs& a, int B, int T, hipStream_t s) {
   return 0;
 }
 int launch_align_pool(const AlignPool& a, const RowSpace& rs, hipStream_t s) {
-  hipLaunchKernelGGL(align_pool_kernel, dim3(rs.B), dim3(128), 0, s, a, rs);
+  hipLaunchKernelGGL(align_pool_kernel, dim3(rs.B), dim3(512), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -540,7 +556,7 @@ int launch_align_sim(const AlignSim& a, hipStream_t s) {
   return 0;
 }
 int launch_align_pool_bwd(const AlignPool& a, const AlignPoolBwd& g, const RowSpace& rs, hipStream_t s) {
-  hipLaunchKernelGGL(align_pool_bwd_kernel, dim3(rs.B), dim3(128), 0, s, a, g, rs);
+  hipLaunchKernelGGL(align_pool_bwd_kernel, dim3(rs.B), dim3(512), 0, s, a, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -222,14 +222,17 @@ __global__ __launch_bounds__(256) void dwconv_ln_bwd_kernel(ConvBwd a, RowSpace 
 }
 
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void pos_bwd_kernel(const float* dx, float* dpos, RowSpace rs, int do_v, int do_q) {
-  const int t = blockIdx.x, c = threadIdx.x;
+__global__ __launch_bounds__(512) void pos_bwd_kernel(const float* dx, float* dpos, RowSpace rs, int do_v, int do_q) {
+  __shared__ float part[4][HUAL_D];
+  const int t = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
   float s = 0.f;
   if (do_v && t < rs.T)
-    for (int b = 0; b < rs.B; ++b) s += dx[(size_t)(b * rs.T + t) * HUAL_D + c];
+    for (int b = grp; b < rs.B; b += 4) s += dx[(size_t)(b * rs.T + t) * HUAL_D + c];
   if (do_q && t < rs.L)
-    for (int b = 0; b < rs.B; ++b) s += dx[(size_t)(rs.Nv + b * rs.L + t) * HUAL_D + c];
-  dpos[(size_t)t * HUAL_D + c] += s;
+    for (int b = grp; b < rs.B; b += 4) s += dx[(size_t)(rs.Nv + b * rs.L + t) * HUAL_D + c];
+  part[grp][c] = s;
+  __syncthreads();
+  if (grp == 0) dpos[(size_t)t * HUAL_D + c] += part[0][c] + part[1][c] + part[2][c] + part[3][c];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -339,7 +342,7 @@ int launch_pos_bwd(const float* dx, float* dpos, const RowSpace& rs, int do_v, i
   if (do_v) n = rs.T;
   if (do_q && rs.L > n) n = rs.L;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(pos_bwd_kernel, dim3(n), dim3(128), 0, s, dx, dpos, rs, do_v, do_q);
+  hipLaunchKernelGGL(pos_bwd_kernel, dim3(n), dim3(512), 0, s, dx, dpos, rs, do_v, do_q);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

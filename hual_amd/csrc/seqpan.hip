@@ -12,7 +12,9 @@
 #include "params.h"
 #include "rowops.h"
 #include <string.h>
+#include <algorithm>
 #include <unordered_map>
+#include <vector>
 
 namespace hual {
 const char* last_error_cstr();
@@ -72,7 +74,9 @@ struct Ctx {
   float* act(const std::string& name) { return buf(name, (size_t)rs.R, HUAL_D); }     // [R,128]
   float* actv(const std::string& name) { return buf(name, (size_t)rs.Nv, HUAL_D); }   // [Nv,128]
   float* vec(const std::string& name) { return buf(name, (size_t)rs.R, 1); }
+  const float* PT = nullptr;  // transposed copies of the dense weights (same offsets), made at the start of backward
   const float* p(size_t off) const { return P + off; }
+  const float* pt(size_t off) const { return PT + off; }
   float* g(size_t off) const { return G + off; }
   bool ok() const { return rc == 0; }
   void chk(int r) { if (rc == 0 && r != 0) rc = r; }
@@ -96,12 +100,13 @@ GemmJob mkjob(const float* A, int lda, int M, int K, const float* W, const float
   j.M = M; j.N = N; j.Y = Y; j.ldy = ldy;
   return j;
 }
-// dX = dY . W^T for W stored [K,N] (row stride N): output [M,K]
-GemmJob mkjob_dx(const float* dY, int lddy, int M, int N, const float* W, float* dX, int lddx, int K = HUAL_D) {
+// dX[M,K] = dY[M,N] . W^T through the transposed copy WT[N, Ktot] (row stride ldwt = rows of the original weight);
+// WT points at column 0 of the K block wanted.
+GemmJob mkjob_dx(const float* dY, int lddy, int M, int N, const float* WT, int ldwt, float* dX, int lddx, int K = HUAL_D) {
   GemmJob j;
   gemm_job_init(j);
   j.npieces = 1;
-  j.A[0] = dY; j.lda[0] = lddy; j.kw[0] = N; j.W[0] = W; j.ldw = N; j.transW = 1;
+  j.A[0] = dY; j.lda[0] = lddy; j.kw[0] = N; j.W[0] = WT; j.ldw = ldwt; j.transW = 0;
   j.M = M; j.N = K; j.Y = dX; j.ldy = lddx;
   return j;
 }
@@ -174,7 +179,7 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
     e.op = EW_DROP_DRELU; e.R = R; e.a = dx; e.b = y; e.out = dZ; e.drop_site = site0 + i; e.drop_row0 = 0;
     c.ew(e);
     c.dwjobs.push_back(mkdw(cbuf, HUAL_D, HUAL_D, dZ, HUAL_D, R, c.g(cp.pw[i]), c.g(cp.b[i])));
-    GemmJob j = mkjob_dx(dZ, HUAL_D, R, HUAL_D, c.p(cp.pw[i]), dC, HUAL_D);
+    GemmJob j = mkjob_dx(dZ, HUAL_D, R, HUAL_D, c.pt(cp.pw[i]), HUAL_D, dC, HUAL_D);
     c.gemm(&j, 1);
     ConvBwd cb{dC, xin, mean, rstd, c.p(cp.ln[i].g), c.p(cp.ln[i].b), c.p(cp.dw[i]), dx, dxin,
                c.g(cp.ln[i].g), c.g(cp.ln[i].b), c.g(cp.dw[i])};
@@ -532,6 +537,29 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* loss_acc = c.buf("loss_acc", 8, 1);
   c.dwjobs.clear();
   if (!c.dry) HUAL_CHECK_HIP(hipMemsetAsync(c.G, 0, pm.total * sizeof(float), c.stream));
+  // transposed copies of every dense weight that a dX product reads (weights are constant within a step)
+  float* PT = c.buf("params.T", pm.total, 1);
+  c.PT = PT;
+  if (!c.dry && c.ok()) {
+    std::vector<uint32_t> offs;
+    std::vector<int> Ks, Ns;
+    auto add = [&](size_t off, int K, int N) { offs.push_back((uint32_t)off); Ks.push_back(K); Ns.push_back(N); };
+    add(pm.shid.k, 2 * D, D); add(pm.ehid.k, 2 * D, D);
+    add(pm.fe_dense.k, D, D); add(pm.fe_q.k, D, D); add(pm.fe_k.k, D, D); add(pm.fe_v.k, D, D);
+    for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D, D); add(pm.cb.pw[i], D, D); }
+    add(pm.cqcat.k, 2 * D, D); add(pm.cq[0].dense, 4 * D, D); add(pm.cq[1].dense, 4 * D, D);
+    add(pm.qconv.k, catw, D);
+    for (int li = 0; li < c.cfg->attn_layer; ++li) {
+      const DualAttnP& d = pm.da[li];
+      const size_t w[] = {d.dense1.k, d.dense2.k, d.bl1_d1, d.bl1_d2, d.bl2_d1, d.bl2_d2, d.guided.k, d.s_gate.k, d.x_gate.k,
+                          d.s_dense.k, d.x_dense.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
+      for (size_t o : w) add(o, D, D);
+    }
+    for (size_t base = 0; base < offs.size() && c.ok(); base += 96) {
+      const int cnt = (int)std::min<size_t>(96, offs.size() - base);
+      c.chk(launch_transpose_weights(offs.data() + base, Ks.data() + base, Ns.data() + base, cnt, c.P, PT, c.stream));
+    }
+  }
   float* outputs = c.actv("outputs");
   // ---------------- heads
   float* hs = c.actv("head.hs");
@@ -563,10 +591,10 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* d_out_heads = c.actv("d.outputs.heads");
   {
     GemmJob j[3];
-    j[0] = mkjob_dx(dz_hs, D, Nv, D, c.p(pm.shid.k), d_sfn, D);
-    j[1] = mkjob_dx(dz_he, D, Nv, D, c.p(pm.ehid.k), d_efn, D);
-    j[2] = mkjob_dx(dz_hs, D, Nv, D, c.p(pm.shid.k) + (size_t)D * D, d_out_heads, D);
-    j[2].npieces = 2; j[2].A[1] = dz_he; j[2].lda[1] = D; j[2].kw[1] = D; j[2].W[1] = c.p(pm.ehid.k) + (size_t)D * D;
+    j[0] = mkjob_dx(dz_hs, D, Nv, D, c.pt(pm.shid.k), 2 * D, d_sfn, D);
+    j[1] = mkjob_dx(dz_he, D, Nv, D, c.pt(pm.ehid.k), 2 * D, d_efn, D);
+    j[2] = mkjob_dx(dz_hs, D, Nv, D, c.pt(pm.shid.k) + D, 2 * D, d_out_heads, D);
+    j[2].npieces = 2; j[2].A[1] = dz_he; j[2].lda[1] = D; j[2].kw[1] = D; j[2].W[1] = c.pt(pm.ehid.k) + D;
     c.gemm(j, 3);
   }
   // ---------------- feature encoders, pass 1 then pass 0
@@ -610,7 +638,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.dwjobs.push_back(mkdw(l2, D, D, dzd, D, Nv, c.g(pm.fe_dense.k), c.g(pm.fe_dense.b)));
     float* d_l2 = c.actv("d." + t + ".l2");
     {
-      GemmJob j = mkjob_dx(dzd, D, Nv, D, c.p(pm.fe_dense.k), d_l2, D);
+      GemmJob j = mkjob_dx(dzd, D, Nv, D, c.pt(pm.fe_dense.k), D, d_l2, D);
       c.gemm(&j, 1);
     }
     float* d_res = c.actv("d." + t + ".res");
@@ -644,10 +672,10 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.dwjobs.push_back(mkdw(a1, D, D, d_qkv + 2 * D, 3 * D, Nv, c.g(pm.fe_v.k), c.g(pm.fe_v.b)));
     float* d_a = c.actv("d." + t + ".a");
     {
-      GemmJob j = mkjob_dx(d_qkv, 3 * D, Nv, D, c.p(pm.fe_q.k), d_a, D);
+      GemmJob j = mkjob_dx(d_qkv, 3 * D, Nv, D, c.pt(pm.fe_q.k), D, d_a, D);
       j.npieces = 3;
-      j.A[1] = d_qkv + D; j.lda[1] = 3 * D; j.kw[1] = D; j.W[1] = c.p(pm.fe_k.k);
-      j.A[2] = d_qkv + 2 * D; j.lda[2] = 3 * D; j.kw[2] = D; j.W[2] = c.p(pm.fe_v.k);
+      j.A[1] = d_qkv + D; j.lda[1] = 3 * D; j.kw[1] = D; j.W[1] = c.pt(pm.fe_k.k);
+      j.A[2] = d_qkv + 2 * D; j.lda[2] = 3 * D; j.kw[2] = D; j.W[2] = c.pt(pm.fe_v.k);
       c.gemm(&j, 1);
     }
     float* d_f = c.actv("d." + t + ".x4");
@@ -690,7 +718,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* d_cqf = c.act("d.cq.feats");
   c.dwjobs.push_back(mkdw(cqf, D, D, d_fuse, D, Nv, c.g(pm.cqcat.k), c.g(pm.cqcat.b)));
   {
-    GemmJob j = mkjob_dx(d_fuse, D, Nv, D, c.p(pm.cqcat.k), d_cqf, D);
+    GemmJob j = mkjob_dx(d_fuse, D, Nv, D, c.pt(pm.cqcat.k), 2 * D, d_cqf, D);
     c.gemm(&j, 1);
   }
   AlignPool ap{};
@@ -737,8 +765,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* d_cat4 = c.buf("d.cq.cat", R, 4 * D);
   {
     GemmJob j[2];
-    j[0] = mkjob_dx(d_cqf, D, Nv, D, c.p(pm.cq[0].dense), d_cat4, 4 * D, 4 * D);
-    j[1] = mkjob_dx(d_cqf + (size_t)Nv * D, D, Nq, D, c.p(pm.cq[1].dense), d_cat4 + (size_t)Nv * 4 * D, 4 * D, 4 * D);
+    j[0] = mkjob_dx(d_cqf, D, Nv, D, c.pt(pm.cq[0].dense), 4 * D, d_cat4, 4 * D, 4 * D);
+    j[1] = mkjob_dx(d_cqf + (size_t)Nv * D, D, Nq, D, c.pt(pm.cq[1].dense), 4 * D, d_cat4 + (size_t)Nv * 4 * D, 4 * D, 4 * D);
     c.gemm(j, 2);
   }
   CqBwdBufs cg{};
@@ -798,7 +826,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.dwjobs.push_back(mkdw(l2, D, D, dz2, D, R, c.g(d.dense2.k), c.g(d.dense2.b)));
     float* d_l2 = c.act(dt + ".l2");
     {
-      GemmJob j = mkjob_dx(dz2, D, R, D, c.p(d.dense2.k), d_l2, D);
+      GemmJob j = mkjob_dx(dz2, D, R, D, c.pt(d.dense2.k), D, d_l2, D);
       c.gemm(&j, 1);
     }
     float* d_res = c.act(dt + ".res");
@@ -818,7 +846,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.dwjobs.push_back(mkdw(mha, D, D, dz1, D, R, c.g(d.dense1.k), c.g(d.dense1.b)));
     float* d_mha = c.act(dt + ".mha");
     {
-      GemmJob j = mkjob_dx(dz1, D, R, D, c.p(d.dense1.k), d_mha, D);
+      GemmJob j = mkjob_dx(dz1, D, R, D, c.pt(d.dense1.k), D, d_mha, D);
       c.gemm(&j, 1);
     }
     // mha = gate * val
@@ -838,17 +866,17 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* d_g = c.act(dt + ".g");
     {
       GemmJob j[2];
-      j[0] = mkjob_dx(d_sc, D, R, D, c.p(d.bl1_d1), d_ln1a, D);
-      j[0].npieces = 2; j[0].A[1] = d_val; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.p(d.bl2_d1);
-      j[1] = mkjob_dx(d_sc, D, R, D, c.p(d.bl1_d2), d_g, D);
-      j[1].npieces = 2; j[1].A[1] = d_val; j[1].lda[1] = D; j[1].kw[1] = D; j[1].W[1] = c.p(d.bl2_d2);
+      j[0] = mkjob_dx(d_sc, D, R, D, c.pt(d.bl1_d1), D, d_ln1a, D);
+      j[0].npieces = 2; j[0].A[1] = d_val; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.pt(d.bl2_d1);
+      j[1] = mkjob_dx(d_sc, D, R, D, c.pt(d.bl1_d2), D, d_g, D);
+      j[1].npieces = 2; j[1].A[1] = d_val; j[1].lda[1] = D; j[1].kw[1] = D; j[1].W[1] = c.pt(d.bl2_d2);
       c.gemm(j, 2);
     }
     // g = o . Wg + b
     c.dwjobs.push_back(mkdw(o, D, D, d_g, D, R, c.g(d.guided.k), c.g(d.guided.b)));
     float* d_o = c.act(dt + ".o");
     {
-      GemmJob j = mkjob_dx(d_g, D, R, D, c.p(d.guided.k), d_o, D);
+      GemmJob j = mkjob_dx(d_g, D, R, D, c.pt(d.guided.k), D, d_o, D);
       c.gemm(&j, 1);
     }
     // o = sg * x + xg * s
@@ -868,9 +896,9 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* d_xv = c.act(dt + ".x");
     {
       GemmJob j[2];
-      j[0] = mkjob_dx(dz_sg, D, R, D, c.p(d.s_gate.k), d_sv, D);
+      j[0] = mkjob_dx(dz_sg, D, R, D, c.pt(d.s_gate.k), D, d_sv, D);
       j[0].add = ds_part; j[0].ldadd = D;
-      j[1] = mkjob_dx(dz_xg, D, R, D, c.p(d.x_gate.k), d_xv, D);
+      j[1] = mkjob_dx(dz_xg, D, R, D, c.pt(d.x_gate.k), D, d_xv, D);
       j[1].add = dx_part; j[1].ldadd = D;
       c.gemm(j, 2);
     }
@@ -880,8 +908,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* d_xatt = c.act(dt + ".x_att");
     {
       GemmJob j[2];
-      j[0] = mkjob_dx(d_sv, D, R, D, c.p(d.s_dense.k), d_satt, D);
-      j[1] = mkjob_dx(d_xv, D, R, D, c.p(d.x_dense.k), d_xatt, D);
+      j[0] = mkjob_dx(d_sv, D, R, D, c.pt(d.s_dense.k), D, d_satt, D);
+      j[1] = mkjob_dx(d_xv, D, R, D, c.pt(d.x_dense.k), D, d_xatt, D);
       c.gemm(j, 2);
     }
     // the four attentions
@@ -916,15 +944,15 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* d_lnt = c.act(dt + ".lnt");
     {
       GemmJob j[2];
-      j[0] = mkjob_dx(dq_self, D, R, D, c.p(d.query.k), d_ln1, D);
+      j[0] = mkjob_dx(dq_self, D, R, D, c.pt(d.query.k), D, d_ln1, D);
       j[0].npieces = 4;
-      j[0].A[1] = dq_cross; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.p(d.query.k);
-      j[0].A[2] = d_qkv + D; j[0].lda[2] = 3 * D; j[0].kw[2] = D; j[0].W[2] = c.p(d.f_key.k);
-      j[0].A[3] = d_qkv + 2 * D; j[0].lda[3] = 3 * D; j[0].kw[3] = D; j[0].W[3] = c.p(d.f_value.k);
+      j[0].A[1] = dq_cross; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.pt(d.query.k);
+      j[0].A[2] = d_qkv + D; j[0].lda[2] = 3 * D; j[0].kw[2] = D; j[0].W[2] = c.pt(d.f_key.k);
+      j[0].A[3] = d_qkv + 2 * D; j[0].lda[3] = 3 * D; j[0].kw[3] = D; j[0].W[3] = c.pt(d.f_value.k);
       j[0].add = d_ln1a; j[0].ldadd = D;
-      j[1] = mkjob_dx(d_ktvt, 2 * D, R, D, c.p(d.t_key.k), d_lnt, D);
+      j[1] = mkjob_dx(d_ktvt, 2 * D, R, D, c.pt(d.t_key.k), D, d_lnt, D);
       j[1].npieces = 2;
-      j[1].A[1] = d_ktvt + D; j[1].lda[1] = 2 * D; j[1].kw[1] = D; j[1].W[1] = c.p(d.t_value.k);
+      j[1].A[1] = d_ktvt + D; j[1].lda[1] = 2 * D; j[1].kw[1] = D; j[1].W[1] = c.pt(d.t_value.k);
       c.gemm(j, 2);
     }
     float* d_xin = c.act(dt + ".in");
@@ -964,10 +992,11 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   }
   float* d_cat = c.buf("d.cat", Nq, catw);
   {
-    GemmJob j = mkjob_dx(d_lin + (size_t)Nv * D, D, Nq, D, c.p(pm.qconv.k), d_cat, catw, catw);
+    GemmJob j = mkjob_dx(d_lin + (size_t)Nv * D, D, Nq, D, c.pt(pm.qconv.k), catw, d_cat, catw, catw);
     c.gemm(&j, 1);
   }
   int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
+  float* embed_partial = c.buf("d.embed.partial", embed_bwd_partial_floats(Nq, c.cfg->word_dim, c.cfg->char_dim, c.cfg->num_chars), 1);
   if (!c.dry && c.ok()) {
     EmbedArgs ea{};
     ea.word_ids = bt->word_ids; ea.char_ids = bt->char_ids; ea.word_table = c.word_table; ea.unk = c.p(pm.unk);
@@ -978,6 +1007,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     EmbedGrads eg{};
     eg.dcat = d_cat; eg.lddcat = catw; eg.dunk = c.g(pm.unk); eg.dchar_table = c.g(pm.char_table);
     for (int i = 0; i < 4; ++i) { eg.dfilt[i] = c.g(pm.filt[i]); eg.dfbias[i] = c.g(pm.fbias[i]); }
+    eg.partial = embed_partial;
     c.chk(launch_embed_bwd(ea, eg, Nq, c.drop, c.stream));
   }
   // ---------------- all dense-layer weight gradients, as a few big launches
