@@ -325,14 +325,17 @@ __device__ __forceinline__ void stage_to_piece(const GemmJob& job, int st, int& 
   k0 = st * GL_KS;
 }
 
-template <bool DUAL>
-__global__ __launch_bounds__(256) void gemm_lds_kernel(GemmBatch batch, DropCfg drop) {
+// RT = 16-row tiles per block (block = 2*RT waves = RT row tiles x 2 column halves).  RT = 3 (48 rows, 384 threads)
+// is picked when it brings a launch down to one block per CU: the kernel is bound by what each CU can pull through
+// its vector-memory path (64 KB of weights per block + the activations), so fewer, taller blocks win.
+template <bool DUAL, int RT>
+__global__ __launch_bounds__(RT * 128) void gemm_lds_kernel(GemmBatch batch, DropCfg drop) {
   extern __shared__ float lds[];     // Ws[2][GL_STAGE] (+ W2s[2][GL_STAGE] when DUAL)
   const GemmJob& job = batch.j[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int M = job.M, N = job.N;
-  const int blockrow = blockIdx.x * 32;
+  const int blockrow = blockIdx.x * (16 * RT);
   const int nblk = blockIdx.y * 128;
   if (blockrow >= M || nblk >= N) return;          // block-uniform
   const int rowbase = blockrow + (wave >> 1) * 16;
@@ -360,9 +363,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmBatch batch, DropCfg 
   auto dma_stage = [&](const float* Wp, int k0, int kw, float* dst) {
     const int c4 = lane & 31, rr = lane >> 5;
     const int n = min(nblk + 4 * c4, N - 4);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int pc = wave * 8 + u;
+    for (int pc = wave; pc < 32; pc += 2 * RT) {
       const int kk = min(k0 + 2 * pc + rr, kw - 1);
       const float* src = Wp + (size_t)kk * ldw + n;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -668,14 +669,28 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
     const size_t lds = (size_t)(dual ? 4 : 2) * GL_STAGE * sizeof(float);
     static bool attr = false;
     if (!attr) {
-      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr = true;
     }
-    if (dual)
-      hipLaunchKernelGGL(gemm_lds_kernel<true>, grid, block, lds, stream, b, drop);
-    else
-      hipLaunchKernelGGL(gemm_lds_kernel<false>, grid, block, lds, stream, b, drop);
+    static const int rt_env = []() { const char* e = getenv("HUAL_GEMM_RT"); return e ? atoi(e) : 0; }();
+    const int ncol = cdiv(maxN, 128);
+    int rt = (cdiv(maxM, 32) * ncol * n > 256 && maxM > 48) ? 3 : 2;
+    if (rt_env == 2 || rt_env == 3) rt = rt_env;
+    if (rt == 3) {
+      dim3 g3(cdiv(maxM, 48), ncol, n), b3(384);
+      if (dual)
+        hipLaunchKernelGGL((gemm_lds_kernel<true, 3>), g3, b3, lds, stream, b, drop);
+      else
+        hipLaunchKernelGGL((gemm_lds_kernel<false, 3>), g3, b3, lds, stream, b, drop);
+    } else {
+      if (dual)
+        hipLaunchKernelGGL((gemm_lds_kernel<true, 2>), grid, block, lds, stream, b, drop);
+      else
+        hipLaunchKernelGGL((gemm_lds_kernel<false, 2>), grid, block, lds, stream, b, drop);
+    }
   }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
