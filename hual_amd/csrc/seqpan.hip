@@ -11,6 +11,7 @@
 #include "optim.h"
 #include "params.h"
 #include "rowops.h"
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <unordered_map>
@@ -59,6 +60,9 @@ struct Ctx {
   std::vector<WsEntry> entries;
   std::unordered_map<std::string, size_t> index;
   std::vector<DwJob> dwjobs;
+  size_t dw_flushed = 0;
+  int dw_flushes = 0;
+  const hual_aux* aux = nullptr;
   int rc = 0;
 
   float* buf(const std::string& name, size_t rows, size_t cols) {
@@ -117,6 +121,35 @@ DwJob mkdw(const float* A, int lda, int K, const float* dY, int ldy, int M, floa
   j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.dW[0] = dW; j.ldw = N;
   j.dY = dY; j.ldy = ldy; j.M = M; j.N = N; j.db = db;
   return j;
+}
+
+// Launch the weight-gradient jobs queued since the last flush.  With an aux stream they run there, forked from the
+// main stream at this point (their operands are complete) and overlapping the dX chain that continues on main.
+void flush_dw(Ctx& c, bool last = false) {
+  // measured: early flushes (dW overlapping the dX chain) cost more than they hide - the two compete for the same CUs;
+  // only the last launch is forked, so that it overlaps the embedding backward.  HUAL_DW_EARLY=1 restores early flushes.
+  static const int early = []() { const char* e = getenv("HUAL_DW_EARLY"); return e ? atoi(e) : 0; }();
+  if (!last && !early) return;
+  const size_t n = c.dwjobs.size() - c.dw_flushed;
+  if (n == 0) return;
+  DwJob* table = reinterpret_cast<DwJob*>(c.buf("dw.table." + std::to_string(c.dw_flushes), n, (sizeof(DwJob) + 3) / 4));
+  if (!c.dry && c.ok()) {
+    hipStream_t s = c.stream;
+    if (c.aux && c.aux->stream) {
+      s = (hipStream_t)c.aux->stream;
+      hipEventRecord((hipEvent_t)c.aux->ev_fork, c.stream);
+      hipStreamWaitEvent(s, (hipEvent_t)c.aux->ev_fork, 0);
+    }
+    c.chk(launch_dw(c.dwjobs.data() + c.dw_flushed, (int)n, c.drop, 512, s, table));
+  }
+  c.dw_flushed = c.dwjobs.size();
+  c.dw_flushes++;
+}
+void join_aux(Ctx& c) {
+  if (!c.dry && c.aux && c.aux->stream) {
+    hipEventRecord((hipEvent_t)c.aux->ev_join, (hipStream_t)c.aux->stream);
+    hipStreamWaitEvent(c.stream, (hipEvent_t)c.aux->ev_join, 0);
+  }
 }
 
 int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
@@ -536,6 +569,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* rowmask = c.vec("rowmask");
   float* loss_acc = c.buf("loss_acc", 8, 1);
   c.dwjobs.clear();
+  c.dw_flushed = 0;
+  c.dw_flushes = 0;
   if (!c.dry) HUAL_CHECK_HIP(hipMemsetAsync(c.G, 0, pm.total * sizeof(float), c.stream));
   // transposed copies of every dense weight that a dX product reads (weights are constant within a step)
   float* PT = c.buf("params.T", pm.total, 1);
@@ -690,6 +725,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     if (!c.dry && c.ok()) c.chk(launch_pos_bwd(d_x0, c.g(pm.fe_pos), c.rsv, 1, 0, c.stream));
     d_in = d_x0;
   }
+  flush_dw(c);
   // ---------------- gradient wrt `outputs`, matching head
   float* d_outputs = c.actv("d.outputs");
   {
@@ -787,6 +823,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     if (c.ok()) c.chk(launch_cq_bwd_impl(cq, cg, c.rs, dXa, dXb, c.stream));
     if (c.ok()) c.chk(launch_tri_bwd_impl(cq, cg, cqp, cqg, c.rs, c.drop, dXa, dXb, c.stream));
   }
+  flush_dw(c);
   float* dx = cg.dX;
   // ---------------- dual attention layers, last to first
   for (int li = c.cfg->attn_layer - 1; li >= 0; --li) {
@@ -964,6 +1001,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       c.ln_bwd(a);
     }
     dx = d_xin;
+    flush_dw(c);
   }
   // ---------------- shared conv block, position table, input layer norms, projections
   float* x0 = c.act("cb.x0");
@@ -995,6 +1033,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     GemmJob j = mkjob_dx(d_lin + (size_t)Nv * D, D, Nq, D, c.pt(pm.qconv.k), catw, d_cat, catw, catw);
     c.gemm(&j, 1);
   }
+  flush_dw(c, true);      // the weight-gradient launch (aux stream) overlaps the embedding backward below
   int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
   float* embed_partial = c.buf("d.embed.partial", embed_bwd_partial_floats(Nq, c.cfg->word_dim, c.cfg->char_dim, c.cfg->num_chars), 1);
   if (!c.dry && c.ok()) {
@@ -1010,9 +1049,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     eg.partial = embed_partial;
     c.chk(launch_embed_bwd(ea, eg, Nq, c.drop, c.stream));
   }
-  // ---------------- all dense-layer weight gradients, as a few big launches
-  DwJob* dwtable = reinterpret_cast<DwJob*>(c.buf("dw.table", c.dwjobs.size(), (sizeof(DwJob) + 3) / 4));
-  if (!c.dry && c.ok()) c.chk(launch_dw(c.dwjobs.data(), (int)c.dwjobs.size(), c.drop, 512, c.stream, dwtable));
+  join_aux(c);
   (void)opt;
   return c.rc;
 }
@@ -1144,11 +1181,32 @@ int hual_seqpan_backward(const hual_cfg* cfg, const float* params, const float* 
   c.stream = (hipStream_t)stream;
   c.P = params;
   c.G = grads;
+  c.aux = opts->aux;
   c.word_table = word_table;
   c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
   c.rs.rowmask = c.vec("rowmask");
   c.rsv.rowmask = c.rs.rowmask;
   return backward_graph(c, batch, labels, opts);
+}
+
+int hual_aux_create(hual_aux* aux) {
+  HUAL_REQUIRE(aux != nullptr, "hual_aux_create: null");
+  hipStream_t st;
+  hipEvent_t e1, e2;
+  HUAL_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  HUAL_CHECK_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+  HUAL_CHECK_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+  aux->stream = st; aux->ev_fork = e1; aux->ev_join = e2;
+  return 0;
+}
+
+int hual_aux_destroy(hual_aux* aux) {
+  if (!aux) return 0;
+  if (aux->ev_fork) hipEventDestroy((hipEvent_t)aux->ev_fork);
+  if (aux->ev_join) hipEventDestroy((hipEvent_t)aux->ev_join);
+  if (aux->stream) hipStreamDestroy((hipStream_t)aux->stream);
+  aux->stream = aux->ev_fork = aux->ev_join = nullptr;
+  return 0;
 }
 
 int hual_adamw_clip_step(float* params, const float* grads, float* adam_m, float* adam_v, const float* decay,

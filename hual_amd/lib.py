@@ -43,9 +43,13 @@ class hual_outputs(ctypes.Structure):
                 ('start_index', ctypes.c_void_p), ('end_index', ctypes.c_void_p), ('loss_terms', ctypes.c_void_p)]
 
 
+class hual_aux(ctypes.Structure):
+    _fields_ = [('stream', ctypes.c_void_p), ('ev_fork', ctypes.c_void_p), ('ev_join', ctypes.c_void_p)]
+
+
 class hual_run_opts(ctypes.Structure):
     _fields_ = [('drop_rate', ctypes.c_float), ('rng_state', ctypes.c_void_p), ('match_denom_override', ctypes.c_float),
-                ('align_external', ctypes.c_int32)]
+                ('align_external', ctypes.c_int32), ('aux', ctypes.POINTER(hual_aux))]
 
 
 class hual_ws_entry(ctypes.Structure):
@@ -78,6 +82,8 @@ def load():
                                          u64, vp]
     lib.hual_adamw_clip_step.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp]
     lib.hual_align_loss.argtypes = [vp, vp, i32, vp, vp, vp, vp, f32, vp]
+    lib.hual_aux_create.argtypes = [P(hual_aux)]
+    lib.hual_aux_destroy.argtypes = [P(hual_aux)]
     lib.hual_linear_fwd.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.hual_linear_dw.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]
     _lib = lib

@@ -13,14 +13,21 @@ from . import lib
 
 
 class Trainer:
-    def __init__(self, model, world=1, use_graph=True):
+    def __init__(self, model, world=1, use_graph=True, force_dp=False, use_aux=False):
         self.m = model
         self.world = world
-        self.use_graph = use_graph and world == 1
+        self.dp = world > 1 or force_dp          # force_dp: run the data-parallel code path on one rank (tests)
+        self.use_graph = use_graph and not self.dp
         self.graph = None
         self.graph_drop = None
         self.shape = None
         self._lib = lib.load()
+        # optional second stream + fork/join events (hual_run_opts.aux).  Measured on MI355X: overlapping the
+        # weight-gradient launch with the rest of backward does not pay (3.55 vs 3.50 ms/step), so it is off by default.
+        self.aux = None
+        if use_aux:
+            self.aux = lib.hual_aux()
+            lib.check(self._lib.hual_aux_create(ctypes.byref(self.aux)))
 
     # ------------------------------------------------------------------ static batch buffers
     def set_batch(self, video, lens, word_ids, char_ids, y1, y2, match_labels, inner_labels):
@@ -55,7 +62,7 @@ class Trainer:
             self.lab = lib.hual_labels(p(self.y1).value, p(self.y2).value, p(self.match).value, p(self.inner).value)
             self.out = lib.hual_outputs(p(self.start_logits).value, p(self.end_logits).value, p(self.match_scores).value,
                                         p(self.start_index).value, p(self.end_index).value, p(self.loss_terms).value)
-            if self.world > 1:
+            if self.dp:
                 Bg = B * self.world
                 self.align_scratch = torch.empty(2 * Bg * Bg, device=dev)
                 self.d_that_all = torch.empty(Bg, 128, device=dev)
@@ -73,13 +80,13 @@ class Trainer:
         put(self.match, match_labels, torch.int32)
         put(self.inner, inner_labels, torch.float32)
         self.match_denom = 0.0
-        if self.world > 1:
+        if self.dp:
             self.match_denom = hdist.match_denominator(int(np.sum(np.asarray(lens))), dev)
 
     # ------------------------------------------------------------------ one step
     def _opts(self, drop_rate, align_external):
         return lib.hual_run_opts(float(drop_rate), lib.ptr(self.m.rng_state).value, float(self.match_denom),
-                                 int(align_external))
+                                 int(align_external), ctypes.pointer(self.aux) if self.aux is not None else None)
 
     def _forward(self, opts):
         m = self.m
@@ -126,7 +133,7 @@ class Trainer:
     def step(self, lr, drop_rate):
         m = self.m
         m.lr.fill_(float(lr))
-        if self.world > 1:
+        if self.dp:
             self._enqueue_dp(drop_rate)
         elif not self.use_graph:
             self._enqueue_single(drop_rate)
@@ -150,6 +157,6 @@ class Trainer:
     def last_loss(self):
         """total loss of the last step (device sync).  DP: local loc/match terms + the global alignment loss."""
         l = self.loss_terms[0]
-        if self.world > 1:
+        if self.dp:
             l = l + self.align_loss[0]
         return l

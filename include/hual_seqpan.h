@@ -114,12 +114,24 @@ typedef struct hual_outputs {
   float* loss_terms;              /* f32 [4]: loss, loc_loss, match_loss, align_loss (written only with labels) */
 } hual_outputs;
 
+/* Optional second stream for work that is independent of the critical path (the weight-gradient GEMMs of
+ * backward run there while the dX chain continues on the main stream).  Caller-owned handles created with
+ * hual_aux_create(); fork/join use the two events, so the pair can be captured into one hipGraph. */
+typedef struct hual_aux {
+  void* stream;                   /* hipStream_t */
+  void* ev_fork;                  /* hipEvent_t  */
+  void* ev_join;                  /* hipEvent_t  */
+} hual_aux;
+int hual_aux_create(hual_aux* aux);
+int hual_aux_destroy(hual_aux* aux);
+
 typedef struct hual_run_opts {
   float drop_rate;                /* the `dropout_rate` placeholder (0 = inference) */
   const uint32_t* rng_state;      /* device u32[3] = {seed lo, seed hi, offset}; may be NULL when drop_rate == 0 */
   float match_denom_override;     /* > 0: denominator of the masked matching loss (exact data parallel) */
   int32_t align_external;         /* 1: the [B,B] alignment loss is evaluated by the caller through
                                         hual_align_loss() on gathered features (exact data parallel) */
+  const hual_aux* aux;            /* NULL: everything on `stream` */
 } hual_run_opts;
 
 /* bytes of workspace needed for one forward(+backward) of this shape */
