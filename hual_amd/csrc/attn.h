@@ -11,10 +11,15 @@ namespace hual {
 struct AttnJob {
   const float* Q; int ldq;
   const float* K; const float* V; int ldkv;
-  float* O; int ldo;                       // forward output, merged heads [rows,128]
+  float* O; int ldo;                       // forward output, merged heads [rows,128] (an input of the backward)
+  float* stats;                            // [2][B*Tq*8]: row max, 1/rowsum per (query, head); written by the forward
+                                           // when non-null, required by the backward
   int B, Tq, Tk, qrow0, krow0;
   const float* qmask; const float* kmask;  // [rows] floats
   int drop_site; uint32_t drop_row0;       // Philox row = (drop_row0 + qrow) * 8 + head ; col = key index
+  // keep bits of the dropout on the probabilities, one byte per Philox call (4 keys): byte [((b*Tq + q)*8 + h)*ldm + key/4].
+  // Written by the forward when non-null, read by both backward kernels (null: they redo the Philox draws).
+  uint8_t* dmask; int ldm;                 // ldm >= 4*ceil(Tk/16), multiple of 4
   // backward
   const float* dO; int lddo;
   float* dQ; int lddq;                     // written (not accumulated)
@@ -28,7 +33,7 @@ struct AttnBatch {
 
 void attn_job_init(AttnJob& j);
 int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t s);
-// dQ, dK, dV.  `stats` = scratch of n * 3 * stat_n floats (stat_n >= max_j B*Tq*8): row max, 1/rowsum, delta
-int launch_attn_bwd_impl(const AttnJob* jobs, int n, const DropCfg& drop, float* stats, int stat_n, hipStream_t s);
+// dQ, dK, dV in one launch (needs O and stats of the forward)
+int launch_attn_bwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t s);
 
 }  // namespace hual

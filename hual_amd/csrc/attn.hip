@@ -18,6 +18,7 @@ namespace hual {
 void attn_job_init(AttnJob& j) {
   ::memset((void*)&j, 0, sizeof(j));
   j.drop_site = -1;
+  j.dmask = nullptr;
 }
 }  // namespace hual
 
@@ -108,8 +109,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, DropCfg 
   sum += __shfl_xor(sum, 16);
   sum += __shfl_xor(sum, 32);
   const float inv = 1.0f / sum;
+  if (job.stats && g == 0 && (q0 + j) < Tq) {
+    const int si = (b * Tq + q0 + j) * 8 + h;
+    job.stats[si] = mx;
+    job.stats[job.B * Tq * 8 + si] = inv;
+  }
   const bool dodrop = job.drop_site >= 0 && drop.enabled;
   const uint32_t drow = (job.drop_row0 + (uint32_t)qrow) * 8u + (uint32_t)h;
+  uint8_t* mrow = (job.dmask && dodrop && (q0 + j) < Tq) ? job.dmask + ((size_t)(b * Tq + q0 + j) * 8 + h) * job.ldm : nullptr;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kt = 0; kt < MAXKT; ++kt) {
@@ -117,8 +124,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, DropCfg 
       f32x4 p = s[kt];
       float4 m = make_float4(inv, inv, inv, inv);
       if (dodrop) {
-        float4 dm = drop_mask4(drop, (uint32_t)job.drop_site, drow, (uint32_t)(kt * 4 + g));
-        m = make_float4(inv * dm.x, inv * dm.y, inv * dm.z, inv * dm.w);
+        const uint32_t bits = drop_bits4(drop, (uint32_t)job.drop_site, drow, (uint32_t)(kt * 4 + g));
+        if (mrow) mrow[kt * 4 + g] = (uint8_t)bits;
+        m = mask_from_bits4(bits, inv * drop.scale);
       }
       p[0] *= m.x; p[1] *= m.y; p[2] *= m.z; p[3] *= m.w;
 #pragma unroll
@@ -133,17 +141,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, DropCfg 
   }
 }
 
-// dQ: same decomposition as the forward; also leaves the softmax statistics (row max, 1/rowsum) and
-// delta = sum_k P*dP in `stats` for the dK/dV kernel.
-template <int MAXKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBatch batch, DropCfg drop, float* stats, int stat_n) {
-  extern __shared__ float lds[];
-  const AttnJob& job = batch.j[blockIdx.z];
+// ---- backward -------------------------------------------------------------------------------------------
+// The forward leaves the softmax statistics (row max, 1/rowsum) per (query, head); delta = sum_k P~.dP~ = dO . O
+// (row of the head's 16 output columns), so neither half needs a pass over the keys before its main loop and the
+// two halves are independent: ONE launch, blockIdx.z = 2*job + half.
+//   half 0 (dQ):      a wave owns 16 queries and sweeps the key tiles      (S^T orientation, like the forward)
+//   half 1 (dK, dV):  a wave owns 16 keys and sweeps the query tiles       (S orientation)
+__device__ __forceinline__ void attn_bwd_dq_part(const AttnJob& job, const DropCfg& drop, float* lds, int bx, int b, int h) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
-  const int b = blockIdx.y >> 3, h = blockIdx.y & 7;
-  if (b >= job.B || blockIdx.x * 64 >= Tq) return;
+  if (bx * 64 >= Tq) return;
   const int nkt = (Tk + 15) >> 4, Tkp = nkt * 16;
   const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
   float* Ks = lds;
@@ -153,86 +161,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBatch batch, DropC
   stage_panel(Vs, job.V + (size_t)kbase * job.ldkv + 16 * h, job.ldkv, Tk, Tkp);
   for (int k = threadIdx.x; k < Tkp; k += 256) Ms[k] = k < Tk ? job.kmask[kbase + k] : 0.f;
   __syncthreads();
-  const int qt = blockIdx.x * 4 + wave;
+  const int qt = bx * 4 + wave;
   if (qt * 16 >= Tq) return;
   const int q0 = qt * 16;
+  const int ql = b * Tq + min(q0 + j, Tq - 1);       // job-local query index
   const int qrow = qbase + min(q0 + j, Tq - 1);
   const float4 qb = ld4(job.Q + (size_t)qrow * job.ldq + 16 * h + 4 * g);
   const float4 dob = ld4(job.dO + (size_t)qrow * job.lddo + 16 * h + 4 * g);
+  const float4 ob = ld4(job.O + (size_t)qrow * job.ldo + 16 * h + 4 * g);
   const float mq = job.qmask[qrow];
-  f32x4 s[MAXKT], dp[MAXKT];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt) {
-    if (kt < nkt) {
-      const float4 ka = *reinterpret_cast<const float4*>(Ks + (kt * 16 + j) * 16 + 4 * g);
-      const float4 va = *reinterpret_cast<const float4*>(Vs + (kt * 16 + j) * 16 + 4 * g);
-      f32x4 a = dot16(ka, qb);
-      dp[kt] = dot16(va, dob);
-      const float4 mk4 = *reinterpret_cast<const float4*>(Ms + kt * 16 + 4 * g);
-      const float mk[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        const float v = key < Tk ? a[r] * ATT_SCALE + (1.0f - mq * mk[r]) * HUAL_MASK_VALUE : -INFINITY;
-        a[r] = v;
-        mx = fmaxf(mx, v);
-      }
-      s[kt] = a;
-    }
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float sum = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt)
-    if (kt < nkt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(s[kt][r] - mx);
-        s[kt][r] = e;
-        sum += e;
-      }
-    }
-  sum += __shfl_xor(sum, 16);
-  sum += __shfl_xor(sum, 32);
-  const float inv = 1.0f / sum;
-  const bool dodrop = job.drop_site >= 0 && drop.enabled;
-  const uint32_t drow = (job.drop_row0 + (uint32_t)qrow) * 8u + (uint32_t)h;
-  float delta = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt)
-    if (kt < nkt) {
-      if (dodrop) {
-        float4 m = drop_mask4(drop, (uint32_t)job.drop_site, drow, (uint32_t)(kt * 4 + g));
-        dp[kt][0] *= m.x; dp[kt][1] *= m.y; dp[kt][2] *= m.z; dp[kt][3] *= m.w;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[kt][r] *= inv;
-        delta = fmaf(s[kt][r], dp[kt][r], delta);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the 8-16 unrolled Philox chains from being interleaved (VGPR blow-up)
-    }
+  const int stat_n = job.B * Tq * 8;
+  const float mx = job.stats[ql * 8 + h], inv = job.stats[stat_n + ql * 8 + h];
+  float delta = (dob.x * ob.x + dob.y * ob.y) + (dob.z * ob.z + dob.w * ob.w);
   delta += __shfl_xor(delta, 16);
   delta += __shfl_xor(delta, 32);
-  if (g == 0 && (q0 + j) < Tq) {
-    const int si = (b * Tq + q0 + j) * 8 + h;
-    float* st = stats + (size_t)blockIdx.z * 3 * stat_n;
-    st[si] = mx;
-    st[stat_n + si] = inv;
-    st[2 * stat_n + si] = delta;
-  }
+  const bool dodrop = job.drop_site >= 0 && drop.enabled;
+  const uint32_t drow = (job.drop_row0 + (uint32_t)qrow) * 8u + (uint32_t)h;
+  const uint8_t* mrow = job.dmask ? job.dmask + ((size_t)ql * 8 + h) * job.ldm : nullptr;
   f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < nkt; ++kt) {
+    const float4 ka = *reinterpret_cast<const float4*>(Ks + (kt * 16 + j) * 16 + 4 * g);
+    const float4 va = *reinterpret_cast<const float4*>(Vs + (kt * 16 + j) * 16 + 4 * g);
+    f32x4 a = dot16(ka, qb);          // S^T[key 4g+r][query j]
+    f32x4 dp = dot16(va, dob);
+    const float4 mk4 = *reinterpret_cast<const float4*>(Ms + kt * 16 + 4 * g);
+    const float mk[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
+    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (dodrop)
+      m = mrow ? mask_from_bits4(mrow[kt * 4 + g], drop.scale)
+               : drop_mask4(drop, (uint32_t)job.drop_site, drow, (uint32_t)(kt * 4 + g));
+    const float mm[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
-  for (int kt = 0; kt < MAXKT; ++kt)
-    if (kt < nkt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ds = s[kt][r] * (dp[kt][r] - delta) * ATT_SCALE;
-        dq = mfma16_(ds, Ks[(kt * 16 + 4 * g + r) * 16 + j], dq);
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      float p = 0.f;
+      if (key < Tk) p = __expf(a[r] * ATT_SCALE + (1.0f - mq * mk[r]) * HUAL_MASK_VALUE - mx) * inv;
+      const float ds = p * (dp[r] * mm[r] - delta) * ATT_SCALE;
+      dq = mfma16_(ds, Ks[(kt * 16 + 4 * g + r) * 16 + j], dq);
     }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int q = q0 + 4 * g + r;
@@ -240,34 +207,50 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBatch batch, DropC
   }
 }
 
-// dK, dV: a wave owns 16 keys of one (clip, head) and sweeps the query tiles; Q, dO and the per-query softmax
-// statistics of the clip are staged in LDS once per block.
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBatch batch, DropCfg drop, const float* stats, int stat_n) {
-  extern __shared__ float lds[];
-  const AttnJob& job = batch.j[blockIdx.z];
+__device__ __forceinline__ void attn_bwd_dkv_part(const AttnJob& job, const DropCfg& drop, float* lds, int bx, int b, int h) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
-  const int b = blockIdx.y >> 3, h = blockIdx.y & 7;
-  if (b >= job.B || blockIdx.x * 64 >= Tk) return;
+  if (bx * 64 >= Tk) return;
   const int nqt = (Tq + 15) >> 4, Tqp = nqt * 16;
   const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
   float* Qs = lds;
   float* Ds = lds + Tqp * 16;
   float* St = Ds + Tqp * 16;        // [4][Tqp]: row max, 1/rowsum, delta, query mask
+  uint32_t* Mb = reinterpret_cast<uint32_t*>(St + 4 * Tqp);     // [Tqp][4] words = the keep bytes of this block's 64 keys
   stage_panel(Qs, job.Q + (size_t)qbase * job.ldq + 16 * h, job.ldq, Tq, Tqp);
-  stage_panel(Ds, job.dO + (size_t)qbase * job.lddo + 16 * h, job.lddo, Tq, Tqp);
-  const float* st = stats + (size_t)blockIdx.z * 3 * stat_n;
-  for (int q = threadIdx.x; q < Tqp; q += 256) {
-    const bool ok = q < Tq;
-    const int si = (b * Tq + (ok ? q : 0)) * 8 + h;
-    St[q] = ok ? st[si] : 0.f;
-    St[Tqp + q] = ok ? st[stat_n + si] : 0.f;          // 1/rowsum = 0 for padding queries -> p = 0
-    St[2 * Tqp + q] = ok ? st[2 * stat_n + si] : 0.f;
-    St[3 * Tqp + q] = ok ? job.qmask[qbase + q] : 0.f;
+  const bool dodrop = job.drop_site >= 0 && drop.enabled;
+  const bool usemask = dodrop && job.dmask != nullptr;
+  const int stat_n = job.B * Tq * 8;
+  // dO panel + delta = dO . O: 4 consecutive threads hold the 16 columns of one query
+  for (int idx = threadIdx.x; idx < Tqp * 4; idx += 256) {
+    const int q = idx >> 2, c4 = idx & 3;
+    float4 v = f4zero();
+    float part = 0.f;
+    uint32_t w = 0;
+    if (q < Tq) {
+      v = ld4(job.dO + (size_t)(qbase + q) * job.lddo + 16 * h + 4 * c4);
+      const float4 o = ld4(job.O + (size_t)(qbase + q) * job.ldo + 16 * h + 4 * c4);
+      part = (v.x * o.x + v.y * o.y) + (v.z * o.z + v.w * o.w);
+      const int byte0 = bx * 16 + 4 * c4;
+      if (usemask && byte0 < job.ldm)
+        w = *reinterpret_cast<const uint32_t*>(job.dmask + ((size_t)(b * Tq + q) * 8 + h) * job.ldm + byte0);
+    }
+    *reinterpret_cast<float4*>(Ds + q * 16 + 4 * c4) = v;
+    Mb[idx] = w;
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    if (c4 == 0) {
+      const bool ok = q < Tq;
+      const int si = (b * Tq + (ok ? q : 0)) * 8 + h;
+      St[q] = ok ? job.stats[si] : 0.f;
+      St[Tqp + q] = ok ? job.stats[stat_n + si] : 0.f;          // 1/rowsum = 0 for padding queries -> p = 0
+      St[2 * Tqp + q] = part;
+      St[3 * Tqp + q] = ok ? job.qmask[qbase + q] : 0.f;
+    }
   }
   __syncthreads();
-  const int kt = blockIdx.x * 4 + wave;
+  const int kt = bx * 4 + wave;
   if (kt * 16 >= Tk) return;
   const int k0 = kt * 16;
   const int key = k0 + j;
@@ -276,7 +259,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBatch batch, Drop
   const float4 kb = ld4(job.K + (size_t)krow * job.ldkv + 16 * h + 4 * g);
   const float4 vb = ld4(job.V + (size_t)krow * job.ldkv + 16 * h + 4 * g);
   const float mk = job.kmask[krow];
-  const bool dodrop = job.drop_site >= 0 && drop.enabled;
   f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * 16;
@@ -299,7 +281,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBatch batch, Drop
         p = __expf(v - mxv[r]) * liv[r];
       }
       float m = 1.0f;
-      if (dodrop) {
+      if (usemask) {
+        const uint32_t byte = (Mb[q * 4 + wave] >> (8 * (j >> 2))) & 0xFFu;
+        m = ((byte >> (j & 3)) & 1u) ? drop.scale : 0.f;
+      } else if (dodrop) {
         const uint32_t drow = (job.drop_row0 + (uint32_t)(qbase + min(q, Tq - 1))) * 8u + (uint32_t)h;
         float4 mm = drop_mask4(drop, (uint32_t)job.drop_site, drow, (uint32_t)(key >> 2));
         const int c = key & 3;
@@ -325,6 +310,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBatch batch, Drop
   }
 }
 
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBatch batch, DropCfg drop) {
+  extern __shared__ float lds[];
+  const AttnJob& job = batch.j[blockIdx.z >> 1];
+  const int b = blockIdx.y >> 3, h = blockIdx.y & 7;
+  if (b >= job.B) return;   // block-uniform
+  if (blockIdx.z & 1) attn_bwd_dkv_part(job, drop, lds, blockIdx.x, b, h);
+  else attn_bwd_dq_part(job, drop, lds, blockIdx.x, b, h);
+}
+
 namespace hual {
 
 static int check_jobs(const AttnJob* jobs, int n, bool bwd, int& maxTq, int& maxTk, int& maxB) {
@@ -335,7 +329,10 @@ static int check_jobs(const AttnJob* jobs, int n, bool bwd, int& maxTq, int& max
     HUAL_REQUIRE(j.Q && j.K && j.V && j.qmask && j.kmask, "attn: null operand");
     HUAL_REQUIRE(j.B > 0 && j.Tq > 0 && j.Tk > 0 && j.Tk <= 256, "attn: need 0 < Tk <= 256, Tq > 0");
     HUAL_REQUIRE((j.ldq % 4) == 0 && (j.ldkv % 4) == 0, "attn: leading dims must be multiples of 4");
-    if (bwd) HUAL_REQUIRE(j.dO && j.dQ && j.dK && j.dV && (j.lddo % 4) == 0, "attn bwd: null gradient buffer");
+    HUAL_REQUIRE(!j.dmask || ((j.ldm % 4) == 0 && j.ldm >= 4 * cdiv(j.Tk, 16) && (reinterpret_cast<uintptr_t>(j.dmask) & 3) == 0),
+                 "attn: dropout keep-byte rows need ldm >= 4*ceil(Tk/16), multiple of 4");
+    if (bwd) HUAL_REQUIRE(j.dO && j.dQ && j.dK && j.dV && j.O && j.stats && (j.lddo % 4) == 0 && (j.ldo % 4) == 0,
+                          "attn bwd: needs dO, dQ, dK, dV, the forward output O and the forward softmax statistics");
     else HUAL_REQUIRE(j.O != nullptr, "attn fwd: null output");
     maxTq = j.Tq > maxTq ? j.Tq : maxTq;
     maxTk = j.Tk > maxTk ? j.Tk : maxTk;
@@ -364,32 +361,19 @@ int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
   return 0;
 }
 
-// `stats` scratch: n jobs x 3 x stat_n floats, stat_n >= max_j(B*Tq*8)
-int launch_attn_bwd_impl(const AttnJob* jobs, int n, const DropCfg& drop, float* stats, int stat_n, hipStream_t s) {
+int launch_attn_bwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t s) {
   int maxTq, maxTk, maxB;
   int rc = check_jobs(jobs, n, true, maxTq, maxTk, maxB);
   if (rc) return rc;
-  HUAL_REQUIRE(stats != nullptr, "attn bwd: null stats scratch");
-  for (int i = 0; i < n; ++i) HUAL_REQUIRE(jobs[i].B * jobs[i].Tq * 8 <= stat_n, "attn bwd: stats scratch too small");
   AttnBatch b;
   for (int i = 0; i < n; ++i) b.j[i] = jobs[i];
-  dim3 grid(cdiv(cdiv(maxTq, 16), 4), maxB * 8, n), block(256);
-  const int nkt = cdiv(maxTk, 16);
+  const int nqt = cdiv(maxTq, 16), nkt = cdiv(maxTk, 16);
+  dim3 grid(cdiv(nqt > nkt ? nqt : nkt, 4), maxB * 8, 2 * n), block(256);
   double flops = 0.0;
   for (int i = 0; i < n; ++i) flops += 2.0 * jobs[i].B * 8.0 * jobs[i].Tq * jobs[i].Tk * 16.0;
-  {
-  ProfScope ps(PK_ATTN_BWD_DQ, s, 3.0 * flops, 0.0);   // S, dP, dQ
-  const size_t lds = (size_t)nkt * 16 * 33 * sizeof(float);
-  if (nkt <= 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, block, lds, s, b, drop, stats, stat_n);
-  else if (nkt <= 4) hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, block, lds, s, b, drop, stats, stat_n);
-  // (the MAXKT=8 instantiation trips a register-allocation pathology in hipcc 7.2: 512 VGPRs; MAXKT=16 needs 162)
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<16>, grid, block, lds, s, b, drop, stats, stat_n);
-  }
-  HUAL_CHECK_HIP(hipGetLastError());
-  dim3 grid2(cdiv(cdiv(maxTk, 16), 4), maxB * 8, n);
-  ProfScope ps2(PK_ATTN_BWD_DKV, s, 4.0 * flops, 0.0);   // S, dP, dK, dV
-  const size_t lds2 = (size_t)cdiv(maxTq, 16) * 16 * 36 * sizeof(float);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid2, block, lds2, s, b, drop, (const float*)stats, stat_n);
+  ProfScope ps(PK_ATTN_BWD_DQ, s, 7.0 * flops, 0.0);   // dQ half: S, dP, dQ ; dK/dV half: S, dP, dK, dV
+  const size_t lds_dq = (size_t)nkt * 16 * 33 * sizeof(float), lds_dkv = (size_t)nqt * 16 * 40 * sizeof(float);
+  hipLaunchKernelGGL(attn_bwd_kernel, grid, block, lds_dq > lds_dkv ? lds_dq : lds_dkv, s, b, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -22,8 +22,13 @@ struct GemmJob {
   int lda2[HUAL_MAX_PIECES];
   int kw[HUAL_MAX_PIECES];
   int npieces;
+  // prologue extras on piece 0, applied in this order after the A2 product (gemm_lds_kernel only):
+  const float* ln_g; const float* ln_b;    // layer norm over the 128 columns of piece 0 (kw[0] must be 128)
+  float* ln_mean; float* ln_rstd;          // optional per-row statistics out
   int a_drop_site;            // >=0: A = dropout(A) (tf.nn.dropout on the GEMM input, model.py:47)
   uint32_t a_drop_row0;
+  const float* a_relu; int lda_relu;       // A *= (a_relu > 0)          (relu' of a saved activation)
+  float* a_save; int lda_save;             // store the transformed operand (LN output / dZ) for later kernels
   // ---- B operand: one weight block per piece. transW=0: W[p][k][n] (ldw); transW=1: W[p][n][k] (used for dX)
   const float* W[HUAL_MAX_PIECES];
   int ldw;

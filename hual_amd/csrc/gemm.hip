@@ -444,6 +444,177 @@ __global__ __launch_bounds__(RT * 128) void gemm_lds_kernel(GemmBatch batch, Dro
   epi_apply<DUAL>(job, drop, epi, acc, acc2, rowbase, n0, j, g);
 }
 
+// Variant of gemm_lds_kernel with the extended A prologue (only launched for jobs that use it: the extra operand
+// registers and the longer dependency chain cost every launch about 1.5 us).
+//
+// A-operand prologue (what the MFMA consumes is f(A)), in this order:
+//   A2 product -> layer norm over the 128 columns of piece 0 (ln_g) -> dropout (a_drop_site) -> relu mask (a_relu > 0)
+//   -> optional store of the transformed operand (a_save: the dZ / LN output that later kernels need).
+// This is how the elementwise kernels around the dense layers (LN, dropout, relu') disappear from the step.
+template <bool DUAL, int RT>
+__global__ __launch_bounds__(RT * 128) void gemm_lds_px_kernel(GemmBatch batch, DropCfg drop) {
+  extern __shared__ float lds[];     // Ws[2][GL_STAGE] (+ W2s[2][GL_STAGE] when DUAL)
+  const GemmJob& job = batch.j[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int M = job.M, N = job.N;
+  const int blockrow = blockIdx.x * (16 * RT);
+  const int nblk = blockIdx.y * 128;
+  if (blockrow >= M || nblk >= N) return;          // block-uniform
+  const int rowbase = blockrow + (wave >> 1) * 16;
+  const int n0 = nblk + (wave & 1) * 64;
+  const bool wave_on = rowbase < M && n0 < N;       // idle waves still take part in staging and barriers
+  const int arow = min(rowbase + j, M - 1);
+  const bool arow_ok = (rowbase + j) < M;
+  const int ldw = job.ldw;
+  const bool adrop = job.a_drop_site >= 0 && drop.enabled;
+  const uint32_t asite = (uint32_t)job.a_drop_site;
+  const uint32_t adrow = job.a_drop_row0 + (uint32_t)arow;
+  const bool saver = job.a_save != nullptr && (wave & 1) == 0 && blockIdx.y == 0 && arow_ok;
+  float* Ws = lds;
+  float* W2s = lds + 2 * GL_STAGE;
+  int nstages = 0;
+  for (int p = 0; p < job.npieces; ++p) nstages += (job.kw[p] + GL_KS - 1) / GL_KS;
+
+  f32x4 acc[4], acc2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // LDS-DMA of one stage: 32 pieces of 1 KB (2 panel rows each); lane l -> row 2*pc + (l>>5), 16 B at column 4*(l&31).
+  // Out-of-range rows / columns are clamped to valid memory (never multiplied / never stored).
+  auto dma_stage = [&](const float* Wp, int k0, int kw, float* dst) {
+    const int c4 = lane & 31, rr = lane >> 5;
+    const int n = min(nblk + 4 * c4, N - 4);
+    for (int pc = wave; pc < 32; pc += 2 * RT) {
+      const int kk = min(k0 + 2 * pc + rr, kw - 1);
+      const float* src = Wp + (size_t)kk * ldw + n;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+    }
+  };
+  struct Stage { int p, k0, kw; };
+  // request stage s: weight panel(s) by DMA into buffer (s & 1); raw A fragments (+ the multiplier / mask operand)
+  auto issue = [&](int s, float4 (&a)[4], float4 (&x)[4], float4 (&a2)[4], Stage& st) {
+    stage_to_piece(job, s, st.p, st.k0);
+    const int p = st.p, k0 = st.k0;
+    const int kw = job.kw[p];
+    st.kw = kw;
+    dma_stage(job.W[p], k0, kw, Ws + (s & 1) * GL_STAGE);
+    if (DUAL) dma_stage(job.W2[p], k0, kw, W2s + (s & 1) * GL_STAGE);
+    const float* Ap = job.A[p] + (size_t)arow * job.lda[p];
+    const float* Xp = job.A2[p] ? job.A2[p] + (size_t)arow * job.lda2[p]
+                                : ((p == 0 && job.a_relu) ? job.a_relu + (size_t)arow * job.lda_relu : nullptr);
+    const float* Abp = (DUAL && job.Ab[p]) ? job.Ab[p] + (size_t)arow * job.ldab[p] : nullptr;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const int kk = k0 + kc * 16;
+      const bool ok = kk < kw;
+      a[kc] = ok ? ld4(Ap + kk + 4 * g) : f4zero();
+      x[kc] = (ok && Xp) ? ld4(Xp + kk + 4 * g) : f4zero();
+      if (DUAL) a2[kc] = (ok && Abp) ? ld4(Abp + kk + 4 * g) : f4zero();
+    }
+  };
+  // everything of the prologue except the layer norm, for one stage of fragments
+  auto finish = [&](float4 (&a)[4], const float4 (&x)[4], float4 (&a2)[4], const Stage& st) {
+    const int p = st.p;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const int kk = st.k0 + kc * 16;
+      if (kk >= st.kw) continue;
+      float4 v = a[kc];
+      if (job.A2[p]) v = f4mul(v, x[kc]);
+      if (adrop) v = apply_drop4(drop, asite, adrow, (uint32_t)((kk + 4 * g) >> 2), v);
+      if (p == 0 && job.a_relu) {
+        const float4 y = x[kc];
+        v = make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
+      }
+      if (p == 0 && saver) st4(job.a_save + (size_t)arow * job.lda_save + kk + 4 * g, v);
+      a[kc] = v;
+      if (DUAL && !job.Ab[p]) a2[kc] = v;
+    }
+  };
+  auto compute = [&](int bufi, const Stage& st, const float4 (&a)[4], const float4 (&a2)[4]) {
+    const float* wsb = Ws + bufi * GL_STAGE + (wave & 1) * 64 + 4 * j;
+    const float* w2b = W2s + bufi * GL_STAGE + (wave & 1) * 64 + 4 * j;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      if (st.k0 + kc * 16 < st.kw) {
+        float4 b[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(wsb + (kc * 16 + 4 * g + c) * 128);
+        mma_frag(acc, a[kc], b, 0);
+        if (DUAL) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(w2b + (kc * 16 + 4 * g + c) * 128);
+          mma_frag(acc2, a2[kc], b, 0);
+        }
+      }
+    }
+  };
+
+  float4 a0[4], a1[4], x0[4], x1[4], c0[4], c1[4];
+  Stage s0{0, 0, 0}, s1{0, 0, 0};
+  EpiRegs epi;
+  // prologue: the first TWO stages (a whole K=128 layer) + everything the epilogue will read
+  issue(0, a0, x0, c0, s0);
+  if (nstages > 1) issue(1, a1, x1, c1, s1);
+  epi_prefetch<DUAL>(job, epi, rowbase, n0, j, g);
+  if (job.ln_g) {
+    // layer norm of piece 0 (kw[0] == 128 => exactly stages 0 and 1).  Row j of the tile is spread over the 4 lanes
+    // (j, g = 0..3): in-lane sums + two shuffles give mean / biased variance (models/layers.py:13-15).
+    float sum = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) sum += (a0[kc].x + a0[kc].y) + (a0[kc].z + a0[kc].w) + (a1[kc].x + a1[kc].y) + (a1[kc].z + a1[kc].w);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / 128.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      float4 d = make_float4(a0[kc].x - mean, a0[kc].y - mean, a0[kc].z - mean, a0[kc].w - mean);
+      sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+      d = make_float4(a1[kc].x - mean, a1[kc].y - mean, a1[kc].z - mean, a1[kc].w - mean);
+      sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    const float rstd = rsqrtf(sq * (1.0f / 128.0f) + 1e-6f);
+    if (job.ln_mean && g == 0 && (wave & 1) == 0 && blockIdx.y == 0 && arow_ok) {
+      job.ln_mean[arow] = mean;
+      job.ln_rstd[arow] = rstd;
+    }
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const float4 g0 = ld4(job.ln_g + kc * 16 + 4 * g), b0 = ld4(job.ln_b + kc * 16 + 4 * g);
+      const float4 g1 = ld4(job.ln_g + 64 + kc * 16 + 4 * g), b1 = ld4(job.ln_b + 64 + kc * 16 + 4 * g);
+      a0[kc] = make_float4((a0[kc].x - mean) * rstd * g0.x + b0.x, (a0[kc].y - mean) * rstd * g0.y + b0.y,
+                           (a0[kc].z - mean) * rstd * g0.z + b0.z, (a0[kc].w - mean) * rstd * g0.w + b0.w);
+      a1[kc] = make_float4((a1[kc].x - mean) * rstd * g1.x + b1.x, (a1[kc].y - mean) * rstd * g1.y + b1.y,
+                           (a1[kc].z - mean) * rstd * g1.z + b1.z, (a1[kc].w - mean) * rstd * g1.w + b1.w);
+    }
+  }
+  finish(a0, x0, c0, s0);
+  if (nstages > 1) finish(a1, x1, c1, s1);
+  for (int s = 0; s < nstages; s += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // DMA of the resident stages has landed (this wave's part)
+    __syncthreads();                                      // ... and everybody else's
+    if (wave_on) compute(0, s0, a0, c0);
+    if (s + 1 < nstages && wave_on) compute(1, s1, a1, c1);
+    if (s + 2 < nstages) {
+      __syncthreads();                                    // both buffers consumed by every wave
+      issue(s + 2, a0, x0, c0, s0);
+      if (s + 3 < nstages) issue(s + 3, a1, x1, c1, s1);
+      finish(a0, x0, c0, s0);
+      if (s + 3 < nstages) finish(a1, x1, c1, s1);
+    }
+  }
+  if (!wave_on) return;
+  epi_apply<DUAL>(job, drop, epi, acc, acc2, rowbase, n0, j, g);
+}
+
 // WT[n][k] = W[k][n] for a table of dense weights inside the flat parameter buffer (same offsets in `dst`).
 struct TrJob { uint32_t off; int K, N; };
 #define HUAL_MAX_TR 96
@@ -640,6 +811,9 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
     }
     HUAL_REQUIRE(j.Y != nullptr, "launch_gemm: null output");
     HUAL_REQUIRE(j.add_div >= 1, "launch_gemm: add_div");
+    HUAL_REQUIRE(!j.ln_g || (j.ln_b && j.kw[0] == 128 && !j.A2[0]), "launch_gemm: LN prologue needs kw[0] == 128");
+    HUAL_REQUIRE(!(j.ln_g || j.a_relu || j.a_save) || j.transW == 0, "launch_gemm: A prologue extras need [K,N] weights");
+    HUAL_REQUIRE(!(j.a_relu && j.A2[0]), "launch_gemm: a_relu and A2[0] are exclusive");
     if (j.comb != COMB_NONE) dual = true;
     b.j[i] = j;
     maxM = j.M > maxM ? j.M : maxM;
@@ -660,7 +834,10 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
   static const int impl = []() { const char* e = getenv("HUAL_GEMM_IMPL"); return e ? atoi(e) : 1; }();
   bool anytrans = false;
   for (int i = 0; i < n; ++i) anytrans = anytrans || jobs[i].transW != 0;
-  if (impl == 0 || anytrans) {   // the LDS-DMA kernel needs [K,N] weights; transposed reads fall back to gemm_kernel
+  bool extras = false;
+  for (int i = 0; i < n; ++i) extras = extras || jobs[i].ln_g || jobs[i].a_relu || jobs[i].a_save;
+  HUAL_REQUIRE(!(extras && anytrans), "launch_gemm: A prologue extras need [K,N] weights");
+  if ((impl == 0 && !extras) || anytrans) {   // the LDS-DMA kernel needs [K,N] weights; transposed reads fall back to gemm_kernel
     if (dual)
       hipLaunchKernelGGL(gemm_kernel<true>, grid, block, 0, stream, b, drop);
     else
@@ -669,28 +846,31 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
     const size_t lds = (size_t)(dual ? 4 : 2) * GL_STAGE * sizeof(float);
     static bool attr = false;
     if (!attr) {
-      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lds_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      const void* fns[] = {(const void*)gemm_lds_kernel<true, 2>,     (const void*)gemm_lds_kernel<false, 2>,
+                           (const void*)gemm_lds_kernel<true, 3>,     (const void*)gemm_lds_kernel<false, 3>,
+                           (const void*)gemm_lds_px_kernel<true, 2>,  (const void*)gemm_lds_px_kernel<false, 2>,
+                           (const void*)gemm_lds_px_kernel<true, 3>,  (const void*)gemm_lds_px_kernel<false, 3>};
+      for (const void* f : fns) HUAL_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr = true;
     }
     static const int rt_env = []() { const char* e = getenv("HUAL_GEMM_RT"); return e ? atoi(e) : 0; }();
     const int ncol = cdiv(maxN, 128);
     int rt = (cdiv(maxM, 32) * ncol * n > 256 && maxM > 48) ? 3 : 2;
     if (rt_env == 2 || rt_env == 3) rt = rt_env;
-    if (rt == 3) {
-      dim3 g3(cdiv(maxM, 48), ncol, n), b3(384);
-      if (dual)
-        hipLaunchKernelGGL((gemm_lds_kernel<true, 3>), g3, b3, lds, stream, b, drop);
-      else
-        hipLaunchKernelGGL((gemm_lds_kernel<false, 3>), g3, b3, lds, stream, b, drop);
-    } else {
-      if (dual)
-        hipLaunchKernelGGL((gemm_lds_kernel<true, 2>), grid, block, lds, stream, b, drop);
-      else
-        hipLaunchKernelGGL((gemm_lds_kernel<false, 2>), grid, block, lds, stream, b, drop);
-    }
+    const dim3 g(cdiv(maxM, 16 * rt), ncol, n), blk(128 * rt);
+#define HUAL_LAUNCH_LDS(KERN)                                                                      \
+  do {                                                                                             \
+    if (rt == 3) {                                                                                 \
+      if (dual) hipLaunchKernelGGL((KERN<true, 3>), g, blk, lds, stream, b, drop);                 \
+      else hipLaunchKernelGGL((KERN<false, 3>), g, blk, lds, stream, b, drop);                     \
+    } else {                                                                                       \
+      if (dual) hipLaunchKernelGGL((KERN<true, 2>), g, blk, lds, stream, b, drop);                 \
+      else hipLaunchKernelGGL((KERN<false, 2>), g, blk, lds, stream, b, drop);                     \
+    }                                                                                              \
+  } while (0)
+    if (extras) HUAL_LAUNCH_LDS(gemm_lds_px_kernel);
+    else HUAL_LAUNCH_LDS(gemm_lds_kernel);
+#undef HUAL_LAUNCH_LDS
   }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

@@ -16,8 +16,11 @@ __device__ __forceinline__ uint4_ philox4x32_10(uint32_t c0, uint32_t c1, uint32
                                                 uint32_t k1) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    uint32_t hi0 = __umulhi(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
-    uint32_t hi1 = __umulhi(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
+    // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: integer
+    // multiplies are quarter rate on CDNA4 and dominate the cost of the generator
+    const uint64_t p0 = (uint64_t)PHILOX_M0 * c0, p1 = (uint64_t)PHILOX_M1 * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0;
     uint32_t n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -37,6 +40,16 @@ __device__ __forceinline__ float4 drop_mask4(const hual::DropCfg& d, uint32_t si
   m.z = r.z < d.thresh ? d.scale : 0.f;
   m.w = r.w < d.thresh ? d.scale : 0.f;
   return m;
+}
+
+// the same draw as 4 keep bits (bit c = column 4*col4 + c is kept).  Forward kernels store this byte so that backward
+// kernels do not have to repeat the Philox rounds (40 quarter-rate integer multiplies per call on CDNA4).
+__device__ __forceinline__ uint32_t drop_bits4(const hual::DropCfg& d, uint32_t site, uint32_t row, uint32_t col4) {
+  uint4_ r = philox4x32_10(col4, row, site, d.state[2], d.state[0], d.state[1]);
+  return (r.x < d.thresh ? 1u : 0u) | (r.y < d.thresh ? 2u : 0u) | (r.z < d.thresh ? 4u : 0u) | (r.w < d.thresh ? 8u : 0u);
+}
+__device__ __forceinline__ float4 mask_from_bits4(uint32_t bits, float scale) {
+  return make_float4((bits & 1u) ? scale : 0.f, (bits & 2u) ? scale : 0.f, (bits & 4u) ? scale : 0.f, (bits & 8u) ? scale : 0.f);
 }
 
 __device__ __forceinline__ float4 apply_drop4(const hual::DropCfg& d, uint32_t site, uint32_t row, uint32_t col4,

@@ -63,7 +63,7 @@ int hual_prof_end(int64_t* launches, double* usec, double* flops, double* bytes,
 
 const char* hual_prof_kind_name(int k) {
   static const char* names[] = {"gemm_kernel<false>", "gemm_kernel<true>", "dw_kernel", "attn_fwd_kernel",
-                                "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel", "ln_fwd_kernel", "ln_bwd_kernel",
+                                "attn_bwd_kernel", "(unused)", "ln_fwd_kernel", "ln_bwd_kernel",
                                 "ln_dwconv_fwd_kernel", "dwconv_ln_bwd_kernel", "ew_kernel", "cq_kernels",
                                 "embed_kernels", "head_kernels", "optim_kernels"};
   return (k >= 0 && k < hual::PK_COUNT) ? names[k] : "";

@@ -64,6 +64,12 @@ struct Ctx {
   int dw_flushes = 0;
   const hual_aux* aux = nullptr;
   int rc = 0;
+  // kernel-fusion switches (environment, read per call so that tests can run both settings):
+  //   HUAL_FUSE_LN=1   layer norms that feed dense layers run in the GEMM A prologue instead of ln_fwd launches
+  //   HUAL_FUSE_BWD=1  dropout' / relu' in front of dX GEMMs run in the GEMM A prologue instead of ew launches
+  // Measured on MI355X (DESIGN.md "Fusion experiments"): both lengthen the latency-bound GEMMs by more than the
+  // launches they remove, so they default to off.
+  bool fuse_ln = false, fuse_bwd = false;
 
   float* buf(const std::string& name, size_t rows, size_t cols) {
     auto it = index.find(name);
@@ -91,8 +97,8 @@ struct Ctx {
   void ln_bwd(const LnBwd& a) { if (!dry && ok()) chk(launch_ln_bwd(a, drop, stream)); }
   void ew(const EwArgs& a) { if (!dry && ok()) chk(launch_ew(a, drop, stream)); }
   void attn_fwd(const AttnJob* j, int n) { if (!dry && ok()) chk(launch_attn_fwd(j, n, drop, stream)); }
-  void attn_bwd(const AttnJob* j, int n, float* stats, int stat_n) {
-    if (!dry && ok()) chk(launch_attn_bwd_impl(j, n, drop, stats, stat_n, stream));
+  void attn_bwd(const AttnJob* j, int n) {
+    if (!dry && ok()) chk(launch_attn_bwd(j, n, drop, stream));
   }
 };
 
@@ -113,6 +119,48 @@ GemmJob mkjob_dx(const float* dY, int lddy, int M, int N, const float* WT, int l
   j.A[0] = dY; j.lda[0] = lddy; j.kw[0] = N; j.W[0] = WT; j.ldw = ldwt; j.transW = 0;
   j.M = M; j.N = K; j.Y = dX; j.ldy = lddx;
   return j;
+}
+// A-prologue layer norm of piece 0: the GEMM consumes dropout(LN(A[0])); `save` receives that operand, mean / rstd the
+// row statistics (both optional - only one job of a group that shares the input needs to write them).
+void set_ln(GemmJob& j, const float* g, const float* b, float* mean, float* rstd, float* save, int drop_site) {
+  j.ln_g = g; j.ln_b = b; j.ln_mean = mean; j.ln_rstd = rstd;
+  j.a_save = save; j.lda_save = HUAL_D;
+  j.a_drop_site = drop_site; j.a_drop_row0 = 0;
+}
+// y = dropout(LN(x)) feeding `njobs` dense jobs that read x as piece 0.  Fused (c.fuse_ln): every job normalises in its
+// A prologue and job 0 keeps y + statistics.  Otherwise one ln_fwd launch and the jobs read y.
+void ln_into_jobs(Ctx& c, GemmJob* j, int njobs, const float* x, int M, const RowSpace& rs, const float* g, const float* b,
+                  float* mean, float* rstd, float* y, int drop_site) {
+  if (c.fuse_ln) {
+    for (int k = 0; k < njobs; ++k) set_ln(j[k], g, b, k == 0 ? mean : nullptr, k == 0 ? rstd : nullptr, k == 0 ? y : nullptr, drop_site);
+    return;
+  }
+  LnFwd a{};
+  a.x = x; a.R = M; a.g1 = g; a.b1 = b; a.y1 = y; a.mean = mean; a.rstd = rstd; a.drop_site = drop_site; a.drop_row0 = 0;
+  c.ln_fwd(a, rs);
+  for (int k = 0; k < njobs; ++k) j[k].A[0] = y;
+}
+// keep-byte buffer of an attention job's probability dropout (attn.h): B*Tq*8 rows of ldm bytes
+// + the softmax statistics the forward leaves for the backward
+void set_dmask(Ctx& c, AttnJob& a, const std::string& name) {
+  a.ldm = 4 * cdiv(a.Tk, 16);
+  a.dmask = reinterpret_cast<uint8_t*>(c.buf(name, (size_t)a.B * a.Tq * 8, a.ldm / 4));
+  a.stats = c.buf(name + ".st", (size_t)2 * a.B * a.Tq * 8, 1);
+}
+// dX = dropout'(dY, site) . W^T with dZ = dropout'(dY) kept for the weight-gradient job: one elementwise launch +
+// plain GEMM, or the GEMM's A prologue (c.fuse_bwd)
+void dx_after_dropout(Ctx& c, const float* dY, float* dZ, int M, int site, const float* WT, float* dX) {
+  if (c.fuse_bwd) {
+    GemmJob j = mkjob_dx(dY, HUAL_D, M, HUAL_D, WT, HUAL_D, dX, HUAL_D);
+    j.a_drop_site = site; j.a_drop_row0 = 0; j.a_save = dZ; j.lda_save = HUAL_D;
+    c.gemm(&j, 1);
+  } else {
+    EwArgs e{};
+    e.op = EW_DROP; e.R = M; e.a = dY; e.out = dZ; e.drop_site = site; e.drop_row0 = 0;
+    c.ew(e);
+    GemmJob j = mkjob_dx(dZ, HUAL_D, M, HUAL_D, WT, HUAL_D, dX, HUAL_D);
+    c.gemm(&j, 1);
+  }
 }
 DwJob mkdw(const float* A, int lda, int K, const float* dY, int ldy, int M, float* dW, float* db, int N = HUAL_D) {
   DwJob j;
@@ -162,6 +210,8 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
   HUAL_REQUIRE(C >= 4, "char_ids need C >= 4 (conv width 4, VALID)");
   HUAL_REQUIRE((long long)B * (T + L) * 8 < (1ll << 28), "batch too large for 32-bit RNG row ids");
   c.cfg = cfg; c.B = B; c.T = T; c.L = L; c.C = C;
+  { const char* e = getenv("HUAL_FUSE_LN"); c.fuse_ln = e && atoi(e) != 0; }
+  { const char* e = getenv("HUAL_FUSE_BWD"); c.fuse_bwd = e && atoi(e) != 0; }
   c.rs.B = B; c.rs.T = T; c.rs.L = L; c.rs.Nv = B * T; c.rs.Nq = B * L; c.rs.R = B * (T + L); c.rs.rowmask = nullptr;
   c.rsv = c.rs; c.rsv.Nq = 0; c.rsv.L = 0; c.rsv.R = c.rs.Nv;
   return 0;
@@ -208,12 +258,21 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
     float* dZ = c.buf("d." + tag + ".z" + is, R, HUAL_D);
     float* dC = c.buf("d." + tag + ".c" + is, R, HUAL_D);
     float* dxin = c.buf("d." + tag + ".x" + is, R, HUAL_D);
-    EwArgs e{};
-    e.op = EW_DROP_DRELU; e.R = R; e.a = dx; e.b = y; e.out = dZ; e.drop_site = site0 + i; e.drop_row0 = 0;
-    c.ew(e);
+    // dZ = dropout'(dx) * relu'(y): its own elementwise launch, or formed in the GEMM's A prologue (c.fuse_bwd)
     c.dwjobs.push_back(mkdw(cbuf, HUAL_D, HUAL_D, dZ, HUAL_D, R, c.g(cp.pw[i]), c.g(cp.b[i])));
-    GemmJob j = mkjob_dx(dZ, HUAL_D, R, HUAL_D, c.pt(cp.pw[i]), HUAL_D, dC, HUAL_D);
-    c.gemm(&j, 1);
+    if (c.fuse_bwd) {
+      GemmJob j = mkjob_dx(dx, HUAL_D, R, HUAL_D, c.pt(cp.pw[i]), HUAL_D, dC, HUAL_D);
+      j.a_drop_site = site0 + i; j.a_drop_row0 = 0;
+      j.a_relu = y; j.lda_relu = HUAL_D;
+      j.a_save = dZ; j.lda_save = HUAL_D;
+      c.gemm(&j, 1);
+    } else {
+      EwArgs e{};
+      e.op = EW_DROP_DRELU; e.R = R; e.a = dx; e.b = y; e.out = dZ; e.drop_site = site0 + i; e.drop_row0 = 0;
+      c.ew(e);
+      GemmJob j = mkjob_dx(dZ, HUAL_D, R, HUAL_D, c.pt(cp.pw[i]), HUAL_D, dC, HUAL_D);
+      c.gemm(&j, 1);
+    }
     ConvBwd cb{dC, xin, mean, rstd, c.p(cp.ln[i].g), c.p(cp.ln[i].b), c.p(cp.dw[i]), dx, dxin,
                c.g(cp.ln[i].g), c.g(cp.ln[i].b), c.g(cp.dw[i])};
     if (!c.dry && c.ok()) c.chk(launch_dwconv_ln_bwd(cb, rs, c.stream));
@@ -284,21 +343,26 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* lnt = c.act(t + ".lnt");
     float* mean = c.vec(t + ".mean");
     float* rstd = c.vec(t + ".rstd");
-    {
-      LnFwd a{};
-      a.x = x; a.R = R; a.g1 = c.p(d.ln1.g); a.b1 = c.p(d.ln1.b); a.y1 = ln1; a.g2 = c.p(d.lnt.g); a.b2 = c.p(d.lnt.b);
-      a.y2 = lnt; a.mean = mean; a.rstd = rstd; a.drop_site = -1;
-      c.ln_fwd(a, rs);
-    }
     float* qkv = c.buf(t + ".qkv", R, 3 * D);
     float* ktvt = c.buf(t + ".ktvt", R, 2 * D);
     {
       GemmJob j[5];
-      j[0] = mkjob(ln1, D, R, D, c.p(d.query.k), c.p(d.query.b), qkv, 3 * D);
-      j[1] = mkjob(ln1, D, R, D, c.p(d.f_key.k), c.p(d.f_key.b), qkv + D, 3 * D);
-      j[2] = mkjob(ln1, D, R, D, c.p(d.f_value.k), c.p(d.f_value.b), qkv + 2 * D, 3 * D);
-      j[3] = mkjob(lnt, D, R, D, c.p(d.t_key.k), c.p(d.t_key.b), ktvt, 2 * D);
-      j[4] = mkjob(lnt, D, R, D, c.p(d.t_value.k), c.p(d.t_value.b), ktvt + D, 2 * D);
+      // both layer norms of x (layers.py:73-74) run in the projections' A prologue; job 0 / 3 keep ln1 / lnt + statistics
+      j[0] = mkjob(x, D, R, D, c.p(d.query.k), c.p(d.query.b), qkv, 3 * D);
+      j[1] = mkjob(x, D, R, D, c.p(d.f_key.k), c.p(d.f_key.b), qkv + D, 3 * D);
+      j[2] = mkjob(x, D, R, D, c.p(d.f_value.k), c.p(d.f_value.b), qkv + 2 * D, 3 * D);
+      j[3] = mkjob(x, D, R, D, c.p(d.t_key.k), c.p(d.t_key.b), ktvt, 2 * D);
+      j[4] = mkjob(x, D, R, D, c.p(d.t_value.k), c.p(d.t_value.b), ktvt + D, 2 * D);
+      if (c.fuse_ln) {
+        for (int k = 0; k < 3; ++k) set_ln(j[k], c.p(d.ln1.g), c.p(d.ln1.b), k == 0 ? mean : nullptr, k == 0 ? rstd : nullptr, k == 0 ? ln1 : nullptr, -1);
+        for (int k = 3; k < 5; ++k) set_ln(j[k], c.p(d.lnt.g), c.p(d.lnt.b), nullptr, nullptr, k == 3 ? lnt : nullptr, -1);
+      } else {
+        LnFwd a{};
+        a.x = x; a.R = R; a.g1 = c.p(d.ln1.g); a.b1 = c.p(d.ln1.b); a.y1 = ln1; a.g2 = c.p(d.lnt.g); a.b2 = c.p(d.lnt.b);
+        a.y2 = lnt; a.mean = mean; a.rstd = rstd; a.drop_site = -1;
+        c.ln_fwd(a, rs);
+        for (int k = 0; k < 5; ++k) j[k].A[0] = k < 3 ? ln1 : lnt;
+      }
       c.gemm(j, 5);
     }
     float* s_att = c.act(t + ".s_att");
@@ -319,6 +383,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       a[2].O = s_att; a[2].drop_site = site + 0;
       a[3].K = ktvt; a[3].V = ktvt + D; a[3].ldkv = 2 * D; a[3].Tq = L; a[3].Tk = T; a[3].qrow0 = Nv; a[3].krow0 = 0;
       a[3].O = x_att; a[3].drop_site = site + 1;
+      for (int k = 0; k < 4; ++k) set_dmask(c, a[k], t + ".dm" + std::to_string(k));
       c.attn_fwd(a, 4);
     }
     float* sv = c.act(t + ".s");
@@ -368,15 +433,10 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* l2 = c.act(t + ".l2");
     float* mean2 = c.vec(t + ".mean2");
     float* rstd2 = c.vec(t + ".rstd2");
-    {
-      LnFwd a{};
-      a.x = res; a.R = R; a.g1 = c.p(d.ln2.g); a.b1 = c.p(d.ln2.b); a.y1 = l2; a.mean = mean2; a.rstd = rstd2;
-      a.drop_site = site + 3; a.drop_row0 = 0;
-      c.ln_fwd(a, rs);
-    }
     float* xo = c.act(t + ".out");
     {
-      GemmJob j = mkjob(l2, D, R, D, c.p(d.dense2.k), c.p(d.dense2.b), xo, D);
+      GemmJob j = mkjob(res, D, R, D, c.p(d.dense2.k), c.p(d.dense2.b), xo, D);
+      ln_into_jobs(c, &j, 1, res, R, rs, c.p(d.ln2.g), c.p(d.ln2.b), mean2, rstd2, l2, site + 3);
       j.drop_site = site + 4; j.add = res; j.ldadd = D;
       c.gemm(&j, 1);
     }
@@ -461,18 +521,13 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* a1 = c.actv(t + ".a");
     float* mean = c.buf(t + ".ln1.mean", Nv, 1);
     float* rstd = c.buf(t + ".ln1.rstd", Nv, 1);
-    {
-      LnFwd a{};
-      a.x = f; a.R = Nv; a.g1 = c.p(pm.fe_ln1.g); a.b1 = c.p(pm.fe_ln1.b); a.y1 = a1; a.mean = mean; a.rstd = rstd;
-      a.drop_site = site + 4; a.drop_row0 = 0;
-      c.ln_fwd(a, c.rsv);
-    }
     float* qkv = c.buf(t + ".qkv", Nv, 3 * D);
     {
       GemmJob j[3];
-      j[0] = mkjob(a1, D, Nv, D, c.p(pm.fe_q.k), c.p(pm.fe_q.b), qkv, 3 * D);
-      j[1] = mkjob(a1, D, Nv, D, c.p(pm.fe_k.k), c.p(pm.fe_k.b), qkv + D, 3 * D);
-      j[2] = mkjob(a1, D, Nv, D, c.p(pm.fe_v.k), c.p(pm.fe_v.b), qkv + 2 * D, 3 * D);
+      j[0] = mkjob(f, D, Nv, D, c.p(pm.fe_q.k), c.p(pm.fe_q.b), qkv, 3 * D);
+      j[1] = mkjob(f, D, Nv, D, c.p(pm.fe_k.k), c.p(pm.fe_k.b), qkv + D, 3 * D);
+      j[2] = mkjob(f, D, Nv, D, c.p(pm.fe_v.k), c.p(pm.fe_v.b), qkv + 2 * D, 3 * D);
+      ln_into_jobs(c, j, 3, f, Nv, c.rsv, c.p(pm.fe_ln1.g), c.p(pm.fe_ln1.b), mean, rstd, a1, site + 4);
       c.gemm(j, 3);
     }
     float* att = c.actv(t + ".att");
@@ -482,6 +537,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       a.Q = qkv; a.ldq = 3 * D; a.K = qkv + D; a.V = qkv + 2 * D; a.ldkv = 3 * D; a.O = att; a.ldo = D;
       a.B = B; a.Tq = T; a.Tk = T; a.qrow0 = 0; a.krow0 = 0; a.qmask = rowmask; a.kmask = rowmask;
       a.drop_site = site + 5;
+      set_dmask(c, a, t + ".dm");
       c.attn_fwd(&a, 1);
     }
     float* res = c.actv(t + ".res");
@@ -493,15 +549,10 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* l2 = c.actv(t + ".l2");
     float* mean2 = c.buf(t + ".ln2.mean", Nv, 1);
     float* rstd2 = c.buf(t + ".ln2.rstd", Nv, 1);
-    {
-      LnFwd a{};
-      a.x = res; a.R = Nv; a.g1 = c.p(pm.fe_ln2.g); a.b1 = c.p(pm.fe_ln2.b); a.y1 = l2; a.mean = mean2; a.rstd = rstd2;
-      a.drop_site = site + 7; a.drop_row0 = 0;
-      c.ln_fwd(a, c.rsv);
-    }
     float* fo = c.actv(t + ".out");
     {
-      GemmJob j = mkjob(l2, D, Nv, D, c.p(pm.fe_dense.k), c.p(pm.fe_dense.b), fo, D);
+      GemmJob j = mkjob(res, D, Nv, D, c.p(pm.fe_dense.k), c.p(pm.fe_dense.b), fo, D);
+      ln_into_jobs(c, &j, 1, res, Nv, c.rsv, c.p(pm.fe_ln2.g), c.p(pm.fe_ln2.b), mean2, rstd2, l2, site + 7);
       j.drop_site = site + 8; j.add = res; j.ldadd = D;
       c.gemm(&j, 1);
     }
@@ -512,22 +563,17 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* efn = c.actv("head.efn");
   float* hmean = c.buf("head.mean", (size_t)2 * Nv, 1);
   float* hrstd = c.buf("head.rstd", (size_t)2 * Nv, 1);
-  {
-    LnFwd a{};
-    a.x = feo[0]; a.R = Nv; a.g1 = c.p(pm.sln.g); a.b1 = c.p(pm.sln.b); a.y1 = sfn; a.mean = hmean; a.rstd = hrstd;
-    a.drop_site = -1;
-    c.ln_fwd(a, c.rsv);
-    a.x = feo[1]; a.g1 = c.p(pm.eln.g); a.b1 = c.p(pm.eln.b); a.y1 = efn; a.mean = hmean + Nv; a.rstd = hrstd + Nv;
-    c.ln_fwd(a, c.rsv);
-  }
   float* hs = c.actv("head.hs");
   float* he = c.actv("head.he");
   {
     GemmJob j[2];
-    j[0] = mkjob(sfn, D, Nv, D, c.p(pm.shid.k), c.p(pm.shid.b), hs, D);
+    // start / end layer norms (modules.py:152-153) in the A prologue
+    j[0] = mkjob(feo[0], D, Nv, D, c.p(pm.shid.k), c.p(pm.shid.b), hs, D);
+    ln_into_jobs(c, &j[0], 1, feo[0], Nv, c.rsv, c.p(pm.sln.g), c.p(pm.sln.b), hmean, hrstd, sfn, -1);
     j[0].npieces = 2; j[0].A[1] = outputs; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.p(pm.shid.k) + (size_t)D * D;
     j[0].act = ACT_RELU;
-    j[1] = mkjob(efn, D, Nv, D, c.p(pm.ehid.k), c.p(pm.ehid.b), he, D);
+    j[1] = mkjob(feo[1], D, Nv, D, c.p(pm.ehid.k), c.p(pm.ehid.b), he, D);
+    ln_into_jobs(c, &j[1], 1, feo[1], Nv, c.rsv, c.p(pm.eln.g), c.p(pm.eln.b), hmean + Nv, hrstd + Nv, efn, -1);
     j[1].npieces = 2; j[1].A[1] = outputs; j[1].lda[1] = D; j[1].kw[1] = D; j[1].W[1] = c.p(pm.ehid.k) + (size_t)D * D;
     j[1].act = ACT_RELU;
     c.gemm(j, 2);
@@ -665,17 +711,9 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     }
     // out = dropout(l2 . Wd + b, s8) + res
     float* dzd = c.actv("d." + t + ".zd");
-    {
-      EwArgs e{};
-      e.op = EW_DROP; e.R = Nv; e.a = d_feout; e.out = dzd; e.drop_site = site + 8; e.drop_row0 = 0;
-      c.ew(e);
-    }
     c.dwjobs.push_back(mkdw(l2, D, D, dzd, D, Nv, c.g(pm.fe_dense.k), c.g(pm.fe_dense.b)));
     float* d_l2 = c.actv("d." + t + ".l2");
-    {
-      GemmJob j = mkjob_dx(dzd, D, Nv, D, c.pt(pm.fe_dense.k), D, d_l2, D);
-      c.gemm(&j, 1);
-    }
+    dx_after_dropout(c, d_feout, dzd, Nv, site + 8, c.pt(pm.fe_dense.k), d_l2);
     float* d_res = c.actv("d." + t + ".res");
     {
       LnBwd a{};
@@ -692,15 +730,16 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       c.ew(e);
     }
     float* d_qkv = c.buf("d." + t + ".qkv", Nv, 3 * D);
-    float* stats = c.buf("attn.stats", (size_t)4 * 3, (size_t)R * 8);
     {
       AttnJob a;
       attn_job_init(a);
       a.Q = qkv; a.ldq = 3 * D; a.K = qkv + D; a.V = qkv + 2 * D; a.ldkv = 3 * D;
       a.B = B; a.Tq = T; a.Tk = T; a.qrow0 = 0; a.krow0 = 0; a.qmask = rowmask; a.kmask = rowmask;
       a.drop_site = site + 5;
+      a.O = c.actv(t + ".att"); a.ldo = D;
       a.dO = d_att; a.lddo = D; a.dQ = d_qkv; a.lddq = 3 * D; a.dK = d_qkv + D; a.dV = d_qkv + 2 * D; a.lddkv = 3 * D;
-      c.attn_bwd(&a, 1, stats, R * 8);
+      set_dmask(c, a, t + ".dm");
+      c.attn_bwd(&a, 1);
     }
     c.dwjobs.push_back(mkdw(a1, D, D, d_qkv, 3 * D, Nv, c.g(pm.fe_q.k), c.g(pm.fe_q.b)));
     c.dwjobs.push_back(mkdw(a1, D, D, d_qkv + D, 3 * D, Nv, c.g(pm.fe_k.k), c.g(pm.fe_k.b)));
@@ -855,17 +894,9 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     const std::string dt = "d." + t;
     // out = dropout(l2 . Wd2 + b, s4) + res
     float* dz2 = c.act(dt + ".z2");
-    {
-      EwArgs e{};
-      e.op = EW_DROP; e.R = R; e.a = dx; e.out = dz2; e.drop_site = site + 4; e.drop_row0 = 0;
-      c.ew(e);
-    }
     c.dwjobs.push_back(mkdw(l2, D, D, dz2, D, R, c.g(d.dense2.k), c.g(d.dense2.b)));
     float* d_l2 = c.act(dt + ".l2");
-    {
-      GemmJob j = mkjob_dx(dz2, D, R, D, c.pt(d.dense2.k), D, d_l2, D);
-      c.gemm(&j, 1);
-    }
+    dx_after_dropout(c, dx, dz2, R, site + 4, c.pt(d.dense2.k), d_l2);
     float* d_res = c.act(dt + ".res");
     {
       LnBwd a{};
@@ -875,17 +906,9 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     }
     // res = dropout(mha . Wd1 + b, s2) + xin
     float* dz1 = c.act(dt + ".z1");
-    {
-      EwArgs e{};
-      e.op = EW_DROP; e.R = R; e.a = d_res; e.out = dz1; e.drop_site = site + 2; e.drop_row0 = 0;
-      c.ew(e);
-    }
     c.dwjobs.push_back(mkdw(mha, D, D, dz1, D, R, c.g(d.dense1.k), c.g(d.dense1.b)));
     float* d_mha = c.act(dt + ".mha");
-    {
-      GemmJob j = mkjob_dx(dz1, D, R, D, c.pt(d.dense1.k), D, d_mha, D);
-      c.gemm(&j, 1);
-    }
+    dx_after_dropout(c, d_res, dz1, R, site + 2, c.pt(d.dense1.k), d_mha);
     // mha = gate * val
     float* d_sc = c.act(dt + ".sc");
     float* d_val = c.act(dt + ".val");
@@ -954,12 +977,12 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* dq_cross = c.act(dt + ".q_cross");
     float* d_qkv = c.buf(dt + ".qkv", R, 3 * D);     // only the Kf / Vf column blocks are used
     float* d_ktvt = c.buf(dt + ".ktvt", R, 2 * D);
-    float* stats = c.buf("attn.stats", (size_t)4 * 3, (size_t)R * 8);
     {
       AttnJob a[4];
       for (int k = 0; k < 4; ++k) {
         attn_job_init(a[k]);
         a[k].Q = qkv; a[k].ldq = 3 * D; a[k].B = B; a[k].qmask = rowmask; a[k].kmask = rowmask; a[k].lddo = D; a[k].lddq = D;
+        a[k].O = (k & 1) ? x_att : s_att; a[k].ldo = D;
       }
       a[0].K = qkv + D; a[0].V = qkv + 2 * D; a[0].ldkv = 3 * D; a[0].Tq = T; a[0].Tk = T; a[0].qrow0 = 0; a[0].krow0 = 0;
       a[0].dO = d_satt; a[0].dQ = dq_self; a[0].dK = d_qkv + D; a[0].dV = d_qkv + 2 * D; a[0].lddkv = 3 * D; a[0].drop_site = site + 0;
@@ -969,7 +992,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       a[2].dO = d_satt; a[2].dQ = dq_self; a[2].dK = d_qkv + D; a[2].dV = d_qkv + 2 * D; a[2].lddkv = 3 * D; a[2].drop_site = site + 0;
       a[3].K = ktvt; a[3].V = ktvt + D; a[3].ldkv = 2 * D; a[3].Tq = L; a[3].Tk = T; a[3].qrow0 = Nv; a[3].krow0 = 0;
       a[3].dO = d_xatt; a[3].dQ = dq_cross; a[3].dK = d_ktvt; a[3].dV = d_ktvt + D; a[3].lddkv = 2 * D; a[3].drop_site = site + 1;
-      c.attn_bwd(a, 4, stats, R * 8);
+      for (int k = 0; k < 4; ++k) set_dmask(c, a[k], t + ".dm" + std::to_string(k));
+      c.attn_bwd(a, 4);
     }
     c.dwjobs.push_back(mkdw(ln1, D, D, dq_self, D, R, c.g(d.query.k), c.g(d.query.b)));
     c.dwjobs.push_back(mkdw(ln1, D, D, dq_cross, D, R, c.g(d.query.k), c.g(d.query.b)));

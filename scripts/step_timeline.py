@@ -1,0 +1,65 @@
+"""Per-kernel timeline of ONE training step from a rocprofv3 --kernel-trace CSV.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace -d gpurun_out/tl -o tl --output-format csv -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline
+    python scripts/step_timeline.py gpurun_out/tl/*kernel_trace.csv [--steps 20] [--group]
+
+A step starts at every `prep_masks_kernel`; the last --steps complete steps are averaged position by position
+(duration and the idle gap in front of the kernel).
+"""
+import argparse
+import csv
+import glob
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'\(.*$', '', name)
+    name = re.sub(r'^void ', '', name)
+    name = name.replace('hual::', '').replace('(anonymous namespace)::', '')
+    return name[:48]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('csv')
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--group', action='store_true', help='only the per-kernel-name totals')
+    a = ap.parse_args()
+    paths = glob.glob(a.csv)
+    rows = []
+    for p in paths:
+        with open(p) as f:
+            for r in csv.DictReader(f):
+                rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+    rows.sort()
+    starts = [i for i, r in enumerate(rows) if 'prep_masks_kernel' in r[2]]
+    if len(starts) < 3:
+        sys.exit('no steps found')
+    steps = [rows[starts[i]:starts[i + 1]] for i in range(len(starts) - 1)]
+    n = max(set(len(s) for s in steps), key=[len(s) for s in steps].count)
+    steps = [s for s in steps if len(s) == n][-a.steps:]
+    print('%d kernels per step, averaging %d steps' % (n, len(steps)))
+    tot = defaultdict(lambda: [0, 0.0, 0.0])
+    t_sum = g_sum = 0.0
+    for k in range(n):
+        dur = sum(s[k][1] - s[k][0] for s in steps) / len(steps) / 1e3
+        gap = sum((s[k][0] - s[k - 1][1]) for s in steps) / len(steps) / 1e3 if k else 0.0
+        nm = short(steps[0][k][2])
+        tot[nm][0] += 1
+        tot[nm][1] += dur
+        tot[nm][2] += gap
+        t_sum += dur
+        g_sum += gap
+        if not a.group:
+            print('%4d %-50s %8.2f us  gap %6.2f' % (k, nm, dur, gap))
+    span = sum(s[-1][1] - s[0][0] for s in steps) / len(steps) / 1e3
+    print('--- totals: kernel time %.1f us, gaps %.1f us, first-to-last span %.1f us' % (t_sum, g_sum, span))
+    for nm, (cnt, d, g) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+        print('%-50s x%-3d %9.1f us  (avg %6.2f)  gaps %7.1f' % (nm, cnt, d, d / cnt, g))
+
+
+if __name__ == '__main__':
+    main()

@@ -36,3 +36,15 @@ def test_ragged_shapes_parity():
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.1)
     _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
     assert idx_equal
+
+
+@pytest.mark.parametrize('flags', [('1', '0'), ('0', '1'), ('1', '1')])
+def test_fused_prologue_variants_parity(flags, monkeypatch):
+    """HUAL_FUSE_LN / HUAL_FUSE_BWD move layer norms and dropout'/relu' into the GEMM A prologue
+    (gemm_lds_px_kernel); same numbers either way."""
+    monkeypatch.setenv('HUAL_FUSE_LN', flags[0])
+    monkeypatch.setenv('HUAL_FUSE_BWD', flags[1])
+    case = pu.well_conditioned_case(drop_rate=0.2, B=3, T=37, L=9, C=4, seed=11, max_vlen=40)
+    rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2)
+    _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
+    assert idx_equal
