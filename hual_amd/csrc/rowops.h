@@ -33,7 +33,11 @@ struct LnBwd {
   const float* dy2; const float* g2; float* dg2; float* db2;
   const float* add1; const float* add2;
   float* dx;
+  // optional [ln_bwd_blocks(R)][4][128] scratch: per-block column sums (dg1, db1, dg2, db2) are written there with plain
+  // stores instead of atomics on dg/db, so the launch can use every CU; launch_colsum() folds them into the gradients
+  float* part;
 };
+int ln_bwd_blocks(int R);
 int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s);
 
 // c = depthwise_conv7(LN(x))  (SAME zero padding inside each clip, NO length mask)     layers.py:32-45, modules.py:59-70
@@ -48,8 +52,20 @@ struct ConvBwd {
   const float* g; const float* b; const float* dw;
   const float* dres;            // gradient arriving through the residual connection (added to dx)
   float* dx; float* dg; float* db; float* ddw;
+  float* part;                  // optional [dwconv_bwd_blocks(rs)][9][128] scratch (ddw[0..6], dg, db), as in LnBwd
 };
+int dwconv_bwd_blocks(const RowSpace& rs);
 int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, hipStream_t s);
+
+// dst[v][c] += sum_blk src[(blk*nvec + v)*128 + c] for the per-block partial sums left by the two kernels above.
+// All jobs of a backward pass go into ONE launch at its end.
+#define HUAL_COLSUM_MAX_VEC 9
+#define HUAL_COLSUM_MAX_JOBS 40
+struct ColsumJob {
+  const float* src; int nblk; int nvec;
+  float* dst[HUAL_COLSUM_MAX_VEC];     // null entries are skipped
+};
+int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s);
 
 // dpos[t] += sum_b dx[b,t] over both sides (pos table shared by video and query, model.py:53,56)
 int launch_pos_bwd(const float* dx, float* dpos, const RowSpace& rs, int do_v, int do_q, hipStream_t s);

@@ -1,5 +1,6 @@
 // Row-wise kernels (see rowops.h).  One activation row = 128 floats = 32 lanes x float4; a 256-thread block
 // works on 8 rows at a time; row reductions are wave shuffles inside a 32-lane half (no LDS, no barrier).
+#include <string.h>
 #include "rowops.h"
 #include "philox.h"
 #include "prof.h"
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += reinterpret_cast<const float*>(&red[vec][k][c >> 2])[c & 3];
+    if (a.part) {
+      a.part[((size_t)blockIdx.x * 4 + vec) * HUAL_D + c] = s;
+      continue;
+    }
     float* dst = vec == 0 ? a.dg1 : (vec == 1 ? a.db1 : (vec == 2 ? a.dg2 : a.db2));
     if (dst) atomicAdd(dst + c, s);
   }
@@ -216,9 +221,29 @@ __global__ __launch_bounds__(256) void dwconv_ln_bwd_kernel(ConvBwd a, RowSpace 
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += reinterpret_cast<const float*>(&red[vec][k][c >> 2])[c & 3];
+    if (a.part) {
+      a.part[((size_t)blockIdx.x * 9 + vec) * HUAL_D + c] = s;
+      continue;
+    }
     float* dst = vec < 7 ? a.ddw + vec * HUAL_D : (vec == 7 ? a.dg : a.db);
     atomicAdd(dst + c, s);
   }
+}
+
+// ------------------------------------------------------------------------------------------------------
+struct ColsumBatch { ColsumJob j[HUAL_COLSUM_MAX_JOBS]; };
+#define COLSUM_SPLIT 4
+__global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch batch) {
+  __shared__ float part[HUAL_D];
+  const ColsumJob& job = batch.j[blockIdx.x];
+  const int vec = blockIdx.y;
+  if (vec >= job.nvec || job.dst[vec] == nullptr) return;     // block-uniform
+  const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+  float s = 0.f;
+  for (int r = blockIdx.z * 2 + half; r < job.nblk; r += 2 * COLSUM_SPLIT) s += job.src[((size_t)r * job.nvec + vec) * HUAL_D + c];
+  if (half) part[c] = s;
+  __syncthreads();
+  if (!half) atomicAdd(job.dst[vec] + c, s + part[c]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -307,10 +332,13 @@ int launch_ln_fwd(const LnFwd& a, const RowSpace& rs, const DropCfg& drop, hipSt
   return 0;
 }
 
+int ln_bwd_blocks(int R) { return cdiv(R, 32); }     // 4 rows per 32-lane group
+
 int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.x && a.mean && a.rstd && a.dy1 && a.g1 && a.dx && a.R > 0, "ln_bwd: null/empty");
   int g = cdiv(a.R, 8);
   g = g < 128 ? g : 128;     // every block ends with 256-512 same-address float atomics: keep the count low
+  if (a.part) g = ln_bwd_blocks(a.R);
   ProfScope ps(PK_LN_BWD, s, 0.0, 12.0 * a.R * HUAL_D);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(256), 0, s, a, drop);
   HUAL_CHECK_HIP(hipGetLastError());
@@ -332,7 +360,26 @@ int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, hipStream_t s) {
   ProfScope ps(PK_CONV_BWD, s, 0.0, 16.0 * rs.R * HUAL_D);
   int grid = conv_blocks(rs);
   grid = grid < 128 ? grid : 128;      // each block ends with 9x128 same-address float atomics
+  if (a.part) grid = conv_blocks(rs);
   hipLaunchKernelGGL(dwconv_ln_bwd_kernel, dim3(grid), dim3(256), 0, s, a, rs);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int dwconv_bwd_blocks(const RowSpace& rs) { return conv_blocks(rs); }
+
+int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s) {
+  if (n == 0) return 0;
+  HUAL_REQUIRE(n > 0 && n <= HUAL_COLSUM_MAX_JOBS, "colsum: job count");
+  ColsumBatch b;
+  ::memset((void*)&b, 0, sizeof(b));
+  int maxvec = 0;
+  for (int i = 0; i < n; ++i) {
+    HUAL_REQUIRE(jobs[i].src && jobs[i].nblk > 0 && jobs[i].nvec >= 1 && jobs[i].nvec <= HUAL_COLSUM_MAX_VEC, "colsum: bad job");
+    b.j[i] = jobs[i];
+    maxvec = jobs[i].nvec > maxvec ? jobs[i].nvec : maxvec;
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3(n, maxvec, COLSUM_SPLIT), dim3(256), 0, s, b);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -60,6 +60,7 @@ struct Ctx {
   std::vector<WsEntry> entries;
   std::unordered_map<std::string, size_t> index;
   std::vector<DwJob> dwjobs;
+  std::vector<ColsumJob> colsum;
   size_t dw_flushed = 0;
   int dw_flushes = 0;
   const hual_aux* aux = nullptr;
@@ -94,7 +95,33 @@ struct Ctx {
   // ---- launch wrappers (skipped in the dry pass) ----
   void gemm(const GemmJob* j, int n) { if (!dry && ok()) chk(launch_gemm(j, n, drop, stream)); }
   void ln_fwd(const LnFwd& a, const RowSpace& r) { if (!dry && ok()) chk(launch_ln_fwd(a, r, drop, stream)); }
-  void ln_bwd(const LnBwd& a) { if (!dry && ok()) chk(launch_ln_bwd(a, drop, stream)); }
+  // layer-norm backward; the per-block dgamma / dbeta sums go to scratch and are folded in by flush_colsum()
+  void ln_bwd(const LnBwd& a0) {
+    LnBwd a = a0;
+    const int nblk = ln_bwd_blocks(a.R);
+    a.part = buf("part." + std::to_string(colsum.size()), (size_t)nblk * 4, HUAL_D);
+    ColsumJob cj{};
+    cj.src = a.part; cj.nblk = nblk; cj.nvec = 4;      // scratch layout [blk][4][128]; null dst = unused vector
+    cj.dst[0] = a.dg1; cj.dst[1] = a.db1; cj.dst[2] = a.dg2; cj.dst[3] = a.db2;
+    colsum.push_back(cj);
+    if (!dry && ok()) chk(launch_ln_bwd(a, drop, stream));
+  }
+  void dwconv_ln_bwd(const ConvBwd& a0, const RowSpace& r) {
+    ConvBwd a = a0;
+    const int nblk = dwconv_bwd_blocks(r);
+    a.part = buf("part." + std::to_string(colsum.size()), (size_t)nblk * 9, HUAL_D);
+    ColsumJob cj{};
+    cj.src = a.part; cj.nblk = nblk; cj.nvec = 9;
+    for (int k = 0; k < 7; ++k) cj.dst[k] = a.ddw + k * HUAL_D;
+    cj.dst[7] = a.dg; cj.dst[8] = a.db;
+    colsum.push_back(cj);
+    if (!dry && ok()) chk(launch_dwconv_ln_bwd(a, r, stream));
+  }
+  void flush_colsum() {
+    for (size_t i = 0; i < colsum.size() && !dry && ok(); i += HUAL_COLSUM_MAX_JOBS)
+      chk(launch_colsum(colsum.data() + i, (int)std::min<size_t>(HUAL_COLSUM_MAX_JOBS, colsum.size() - i), stream));
+    colsum.clear();
+  }
   void ew(const EwArgs& a) { if (!dry && ok()) chk(launch_ew(a, drop, stream)); }
   void attn_fwd(const AttnJob* j, int n) { if (!dry && ok()) chk(launch_attn_fwd(j, n, drop, stream)); }
   void attn_bwd(const AttnJob* j, int n) {
@@ -275,7 +302,7 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
     }
     ConvBwd cb{dC, xin, mean, rstd, c.p(cp.ln[i].g), c.p(cp.ln[i].b), c.p(cp.dw[i]), dx, dxin,
                c.g(cp.ln[i].g), c.g(cp.ln[i].b), c.g(cp.dw[i])};
-    if (!c.dry && c.ok()) c.chk(launch_dwconv_ln_bwd(cb, rs, c.stream));
+    c.dwconv_ln_bwd(cb, rs);
     dx = dxin;
   }
   return dx;
@@ -615,6 +642,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* rowmask = c.vec("rowmask");
   float* loss_acc = c.buf("loss_acc", 8, 1);
   c.dwjobs.clear();
+  c.colsum.clear();
   c.dw_flushed = 0;
   c.dw_flushes = 0;
   if (!c.dry) HUAL_CHECK_HIP(hipMemsetAsync(c.G, 0, pm.total * sizeof(float), c.stream));
@@ -1057,6 +1085,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     GemmJob j = mkjob_dx(d_lin + (size_t)Nv * D, D, Nq, D, c.pt(pm.qconv.k), catw, d_cat, catw, catw);
     c.gemm(&j, 1);
   }
+  c.flush_colsum();       // layer-norm / depthwise-conv parameter gradients: one reduction of the per-block partial sums
   flush_dw(c, true);      // the weight-gradient launch (aux stream) overlaps the embedding backward below
   int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
   float* embed_partial = c.buf("d.embed.partial", embed_bwd_partial_floats(Nq, c.cfg->word_dim, c.cfg->char_dim, c.cfg->num_chars), 1);
