@@ -36,6 +36,9 @@ struct LnBwd {
   // optional [ln_bwd_blocks(R)][4][128] scratch: per-block column sums (dg1, db1, dg2, db2) are written there with plain
   // stores instead of atomics on dg/db, so the launch can use every CU; launch_colsum() folds them into the gradients
   float* part;
+  // optional second output for the consumer of dx: dz = dropout'(dx, dz_site) * (dz_relu > 0)   (site < 0: no dropout,
+  // dz_relu null: no mask) - saves the elementwise launch in front of the next dX GEMM
+  float* dz; int dz_site; uint32_t dz_row0; const float* dz_relu;
 };
 int ln_bwd_blocks(int R);
 int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s);
@@ -53,9 +56,10 @@ struct ConvBwd {
   const float* dres;            // gradient arriving through the residual connection (added to dx)
   float* dx; float* dg; float* db; float* ddw;
   float* part;                  // optional [dwconv_bwd_blocks(rs)][9][128] scratch (ddw[0..6], dg, db), as in LnBwd
+  float* dz; int dz_site; uint32_t dz_row0; const float* dz_relu;     // optional second output, as in LnBwd
 };
 int dwconv_bwd_blocks(const RowSpace& rs);
-int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, hipStream_t s);
+int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
 
 // dst[v][c] += sum_blk src[(blk*nvec + v)*128 + c] for the per-block partial sums left by the two kernels above.
 // All jobs of a backward pass go into ONE launch at its end.

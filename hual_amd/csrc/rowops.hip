@@ -26,6 +26,17 @@ __device__ __forceinline__ void row_stats(float4 v, float& mean, float& rstd) {
   rstd = rsqrtf(var + LN_EPS);
 }
 
+// dz = dropout'(dx, site) * (relu > 0): the operand of the next dX GEMM, written next to dx
+__device__ __forceinline__ void store_dz(float* dz, int site, uint32_t row, const float* relu, size_t off, int l32, float4 dx,
+                                         const hual::DropCfg& drop) {
+  if (site >= 0 && drop.enabled) dx = apply_drop4(drop, (uint32_t)site, row, (uint32_t)l32, dx);
+  if (relu) {
+    const float4 y = ld4(relu + off);
+    dx = make_float4(y.x > 0.f ? dx.x : 0.f, y.y > 0.f ? dx.y : 0.f, y.z > 0.f ? dx.z : 0.f, y.w > 0.f ? dx.w : 0.f);
+  }
+  st4(dz + off, dx);
+}
+
 __device__ __forceinline__ void row_to_clip(int row, int Nv, int T, int L, int& t, int& n, int& base) {
   if (row < Nv) { int b = row / T; t = row - b * T; n = T; base = b * T; }
   else { int r = row - Nv; int b = r / L; t = r - b * L; n = L; base = Nv + b * L; }
@@ -87,6 +98,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) {
     if (a.add1) dx = f4add_(dx, ld4(a.add1 + off));
     if (a.add2) dx = f4add_(dx, ld4(a.add2 + off));
     st4(a.dx + off, dx);
+    if (a.dz) store_dz(a.dz, a.dz_site, a.dz_row0 + (uint32_t)row, a.dz_relu, off, l32, dx, drop);
   }
   red[0][grp][l32] = sg1; red[1][grp][l32] = sb1; red[2][grp][l32] = sg2; red[3][grp][l32] = sb2;
   __syncthreads();
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(ConvFwd a, RowSpace 
 }
 
 // backward of the front half:  dh = dwconv^T(dc) ; ddw ; LN backward ; + residual gradient
-__global__ __launch_bounds__(256) void dwconv_ln_bwd_kernel(ConvBwd a, RowSpace rs) {
+__global__ __launch_bounds__(256) void dwconv_ln_bwd_kernel(ConvBwd a, RowSpace rs, DropCfg drop) {
   __shared__ float4 hbuf[SEG + 2 * HALO][32];
   __shared__ float4 dbuf[SEG + 2 * HALO][32];
   __shared__ float4 red[9][8][32];
@@ -209,6 +221,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_bwd_kernel(ConvBwd a, RowSpace 
                             rstd * (gv.z - m1 - xh.z * m2), rstd * (gv.w - m1 - xh.w * m2));
     if (a.dres) dx = f4add_(dx, ld4(a.dres + off));
     st4(a.dx + off, dx);
+    if (a.dz) store_dz(a.dz, a.dz_site, a.dz_row0 + (uint32_t)row, a.dz_relu, off, l32, dx, drop);
   }
   }   // segment loop
 #pragma unroll
@@ -355,13 +368,13 @@ int launch_ln_dwconv_fwd(const ConvFwd& a, const RowSpace& rs, hipStream_t s) {
   return 0;
 }
 
-int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, hipStream_t s) {
+int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.dc && a.x && a.mean && a.rstd && a.g && a.b && a.dw && a.dx && a.dg && a.db && a.ddw, "dwconv_ln_bwd: null");
   ProfScope ps(PK_CONV_BWD, s, 0.0, 16.0 * rs.R * HUAL_D);
   int grid = conv_blocks(rs);
   grid = grid < 128 ? grid : 128;      // each block ends with 9x128 same-address float atomics
   if (a.part) grid = conv_blocks(rs);
-  hipLaunchKernelGGL(dwconv_ln_bwd_kernel, dim3(grid), dim3(256), 0, s, a, rs);
+  hipLaunchKernelGGL(dwconv_ln_bwd_kernel, dim3(grid), dim3(256), 0, s, a, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

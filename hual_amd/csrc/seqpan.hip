@@ -71,6 +71,9 @@ struct Ctx {
   // Measured on MI355X (DESIGN.md "Fusion experiments"): both lengthen the latency-bound GEMMs by more than the
   // launches they remove, so they default to off.
   bool fuse_ln = false, fuse_bwd = false;
+  //   HUAL_FUSE_ROW=0  (default on) the row kernel that produces a gradient also writes dropout'(.) * relu'(.) of it for
+  //                    the next dX GEMM, instead of an elementwise launch in between
+  bool fuse_row = true;
 
   float* buf(const std::string& name, size_t rows, size_t cols) {
     auto it = index.find(name);
@@ -115,7 +118,7 @@ struct Ctx {
     for (int k = 0; k < 7; ++k) cj.dst[k] = a.ddw + k * HUAL_D;
     cj.dst[7] = a.dg; cj.dst[8] = a.db;
     colsum.push_back(cj);
-    if (!dry && ok()) chk(launch_dwconv_ln_bwd(a, r, stream));
+    if (!dry && ok()) chk(launch_dwconv_ln_bwd(a, r, drop, stream));
   }
   void flush_colsum() {
     for (size_t i = 0; i < colsum.size() && !dry && ok(); i += HUAL_COLSUM_MAX_JOBS)
@@ -176,8 +179,11 @@ void set_dmask(Ctx& c, AttnJob& a, const std::string& name) {
 }
 // dX = dropout'(dY, site) . W^T with dZ = dropout'(dY) kept for the weight-gradient job: one elementwise launch +
 // plain GEMM, or the GEMM's A prologue (c.fuse_bwd)
-void dx_after_dropout(Ctx& c, const float* dY, float* dZ, int M, int site, const float* WT, float* dX) {
-  if (c.fuse_bwd) {
+void dx_after_dropout(Ctx& c, const float* dY, float* dZ, int M, int site, const float* WT, float* dX, bool dz_ready) {
+  if (dz_ready) {      // the kernel that produced dY already wrote dZ (Ctx::fuse_row)
+    GemmJob j = mkjob_dx(dZ, HUAL_D, M, HUAL_D, WT, HUAL_D, dX, HUAL_D);
+    c.gemm(&j, 1);
+  } else if (c.fuse_bwd) {
     GemmJob j = mkjob_dx(dY, HUAL_D, M, HUAL_D, WT, HUAL_D, dX, HUAL_D);
     j.a_drop_site = site; j.a_drop_row0 = 0; j.a_save = dZ; j.lda_save = HUAL_D;
     c.gemm(&j, 1);
@@ -239,6 +245,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
   c.cfg = cfg; c.B = B; c.T = T; c.L = L; c.C = C;
   { const char* e = getenv("HUAL_FUSE_LN"); c.fuse_ln = e && atoi(e) != 0; }
   { const char* e = getenv("HUAL_FUSE_BWD"); c.fuse_bwd = e && atoi(e) != 0; }
+  { const char* e = getenv("HUAL_FUSE_ROW"); c.fuse_row = !c.fuse_bwd && !(e && atoi(e) == 0); }
   c.rs.B = B; c.rs.T = T; c.rs.L = L; c.rs.Nv = B * T; c.rs.Nq = B * L; c.rs.R = B * (T + L); c.rs.rowmask = nullptr;
   c.rsv = c.rs; c.rsv.Nq = 0; c.rsv.L = 0; c.rsv.R = c.rs.Nv;
   return 0;
@@ -272,8 +279,9 @@ float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP
 }
 
 // backward of conv_block: d_out = gradient wrt x4 -> returns gradient wrt x0
+// dz3_ready: the producer of dx already left dropout'(dx) * relu'(y3) in "d.<tag>.z3" (Ctx::fuse_row)
 float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, const ConvBlockP& cp, const RowSpace& rs,
-                      int site0) {
+                      int site0, bool dz3_ready) {
   const int R = rs.R;
   for (int i = 3; i >= 0; --i) {
     const std::string is = std::to_string(i);
@@ -287,7 +295,11 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
     float* dxin = c.buf("d." + tag + ".x" + is, R, HUAL_D);
     // dZ = dropout'(dx) * relu'(y): its own elementwise launch, or formed in the GEMM's A prologue (c.fuse_bwd)
     c.dwjobs.push_back(mkdw(cbuf, HUAL_D, HUAL_D, dZ, HUAL_D, R, c.g(cp.pw[i]), c.g(cp.b[i])));
-    if (c.fuse_bwd) {
+    const bool dz_ready = i == 3 ? dz3_ready : c.fuse_row;
+    if (dz_ready) {
+      GemmJob j = mkjob_dx(dZ, HUAL_D, R, HUAL_D, c.pt(cp.pw[i]), HUAL_D, dC, HUAL_D);
+      c.gemm(&j, 1);
+    } else if (c.fuse_bwd) {
       GemmJob j = mkjob_dx(dx, HUAL_D, R, HUAL_D, c.pt(cp.pw[i]), HUAL_D, dC, HUAL_D);
       j.a_drop_site = site0 + i; j.a_drop_row0 = 0;
       j.a_relu = y; j.lda_relu = HUAL_D;
@@ -302,6 +314,11 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
     }
     ConvBwd cb{dC, xin, mean, rstd, c.p(cp.ln[i].g), c.p(cp.ln[i].b), c.p(cp.dw[i]), dx, dxin,
                c.g(cp.ln[i].g), c.g(cp.ln[i].b), c.g(cp.dw[i])};
+    if (c.fuse_row && i > 0) {
+      cb.dz = c.buf("d." + tag + ".z" + std::to_string(i - 1), R, HUAL_D);
+      cb.dz_site = site0 + i - 1; cb.dz_row0 = 0;
+      cb.dz_relu = c.buf(tag + ".y" + std::to_string(i - 1), R, HUAL_D);
+    }
     c.dwconv_ln_bwd(cb, rs);
     dx = dxin;
   }
@@ -712,6 +729,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     LnBwd a{};
     a.x = c.actv("fe1.out"); a.mean = hmean + Nv; a.rstd = hrstd + Nv; a.R = Nv; a.dy1 = d_efn; a.g1 = c.p(pm.eln.g);
     a.dg1 = c.g(pm.eln.g); a.db1 = c.g(pm.eln.b); a.drop_site1 = -1; a.dx = d_feout;
+    if (c.fuse_row) { a.dz = c.actv("d.fe1.zd"); a.dz_site = HUAL_SITE_FE + 16 + 8; }
     c.ln_bwd(a);
   }
   float* d_in = nullptr;
@@ -734,6 +752,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       LnBwd a{};
       a.x = c.actv("fe0.out"); a.mean = hmean; a.rstd = hrstd; a.R = Nv; a.dy1 = d_sfn; a.g1 = c.p(pm.sln.g);
       a.dg1 = c.g(pm.sln.g); a.db1 = c.g(pm.sln.b); a.drop_site1 = -1; a.add1 = d_in; a.dx = d0;
+      if (c.fuse_row) { a.dz = c.actv("d.fe0.zd"); a.dz_site = HUAL_SITE_FE + 8; }
       c.ln_bwd(a);
       d_feout = d0;
     }
@@ -741,18 +760,19 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* dzd = c.actv("d." + t + ".zd");
     c.dwjobs.push_back(mkdw(l2, D, D, dzd, D, Nv, c.g(pm.fe_dense.k), c.g(pm.fe_dense.b)));
     float* d_l2 = c.actv("d." + t + ".l2");
-    dx_after_dropout(c, d_feout, dzd, Nv, site + 8, c.pt(pm.fe_dense.k), d_l2);
+    dx_after_dropout(c, d_feout, dzd, Nv, site + 8, c.pt(pm.fe_dense.k), d_l2, c.fuse_row);
     float* d_res = c.actv("d." + t + ".res");
     {
       LnBwd a{};
       a.x = res; a.mean = mean2; a.rstd = rstd2; a.R = Nv; a.dy1 = d_l2; a.g1 = c.p(pm.fe_ln2.g);
       a.dg1 = c.g(pm.fe_ln2.g); a.db1 = c.g(pm.fe_ln2.b); a.drop_site1 = site + 7; a.drop_row0 = 0; a.add1 = d_feout;
       a.dx = d_res;
+      if (c.fuse_row) { a.dz = c.actv("d." + t + ".att"); a.dz_site = site + 6; }
       c.ln_bwd(a);
     }
     // res = dropout(att, s6) + f
     float* d_att = c.actv("d." + t + ".att");
-    {
+    if (!c.fuse_row) {
       EwArgs e{};
       e.op = EW_DROP; e.R = Nv; e.a = d_res; e.out = d_att; e.drop_site = site + 6; e.drop_row0 = 0;
       c.ew(e);
@@ -786,9 +806,10 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       a.x = f; a.mean = mean; a.rstd = rstd; a.R = Nv; a.dy1 = d_a; a.g1 = c.p(pm.fe_ln1.g);
       a.dg1 = c.g(pm.fe_ln1.g); a.db1 = c.g(pm.fe_ln1.b); a.drop_site1 = site + 4; a.drop_row0 = 0; a.add1 = d_res;
       a.dx = d_f;
+      if (c.fuse_row) { a.dz = c.actv("d." + t + ".z3"); a.dz_site = site + 3; a.dz_relu = c.actv(t + ".y3"); }
       c.ln_bwd(a);
     }
-    float* d_x0 = conv_block_bwd(c, t, x0, d_f, pm.fe_cb, c.rsv, site);
+    float* d_x0 = conv_block_bwd(c, t, x0, d_f, pm.fe_cb, c.rsv, site, c.fuse_row);
     if (!c.dry && c.ok()) c.chk(launch_pos_bwd(d_x0, c.g(pm.fe_pos), c.rsv, 1, 0, c.stream));
     d_in = d_x0;
   }
@@ -924,19 +945,20 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* dz2 = c.act(dt + ".z2");
     c.dwjobs.push_back(mkdw(l2, D, D, dz2, D, R, c.g(d.dense2.k), c.g(d.dense2.b)));
     float* d_l2 = c.act(dt + ".l2");
-    dx_after_dropout(c, dx, dz2, R, site + 4, c.pt(d.dense2.k), d_l2);
+    dx_after_dropout(c, dx, dz2, R, site + 4, c.pt(d.dense2.k), d_l2, c.fuse_row && li < c.cfg->attn_layer - 1);
     float* d_res = c.act(dt + ".res");
     {
       LnBwd a{};
       a.x = res; a.mean = mean2; a.rstd = rstd2; a.R = R; a.dy1 = d_l2; a.g1 = c.p(d.ln2.g); a.dg1 = c.g(d.ln2.g);
       a.db1 = c.g(d.ln2.b); a.drop_site1 = site + 3; a.drop_row0 = 0; a.add1 = dx; a.dx = d_res;
+      if (c.fuse_row) { a.dz = c.act(dt + ".z1"); a.dz_site = site + 2; }
       c.ln_bwd(a);
     }
     // res = dropout(mha . Wd1 + b, s2) + xin
     float* dz1 = c.act(dt + ".z1");
     c.dwjobs.push_back(mkdw(mha, D, D, dz1, D, R, c.g(d.dense1.k), c.g(d.dense1.b)));
     float* d_mha = c.act(dt + ".mha");
-    dx_after_dropout(c, d_res, dz1, R, site + 2, c.pt(d.dense1.k), d_mha);
+    dx_after_dropout(c, d_res, dz1, R, site + 2, c.pt(d.dense1.k), d_mha, c.fuse_row);
     // mha = gate * val
     float* d_sc = c.act(dt + ".sc");
     float* d_val = c.act(dt + ".val");
@@ -1050,6 +1072,10 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       a.x = xin; a.mean = mean; a.rstd = rstd; a.R = R; a.dy1 = d_ln1; a.g1 = c.p(d.ln1.g); a.dg1 = c.g(d.ln1.g);
       a.db1 = c.g(d.ln1.b); a.drop_site1 = -1; a.dy2 = d_lnt; a.g2 = c.p(d.lnt.g); a.dg2 = c.g(d.lnt.g); a.db2 = c.g(d.lnt.b);
       a.add1 = d_res; a.dx = d_xin;
+      if (c.fuse_row) {      // operand of the next dX GEMM down the stack: previous layer's dense_2, or the conv block's layer 3
+        if (li > 0) { a.dz = c.act("d.da" + std::to_string(li - 1) + ".z2"); a.dz_site = HUAL_SITE_DA + 8 * (li - 1) + 4; }
+        else { a.dz = c.act("d.cb.z3"); a.dz_site = HUAL_SITE_CONV + 3; a.dz_relu = c.act("cb.y3"); }
+      }
       c.ln_bwd(a);
     }
     dx = d_xin;
@@ -1057,7 +1083,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   }
   // ---------------- shared conv block, position table, input layer norms, projections
   float* x0 = c.act("cb.x0");
-  float* d_x0 = conv_block_bwd(c, "cb", x0, dx, pm.cb, c.rs, HUAL_SITE_CONV);
+  float* d_x0 = conv_block_bwd(c, "cb", x0, dx, pm.cb, c.rs, HUAL_SITE_CONV, c.fuse_row && c.cfg->attn_layer > 0);
   if (!c.dry && c.ok()) c.chk(launch_pos_bwd(d_x0, c.g(pm.pos), c.rs, 1, 1, c.stream));
   float* lin = c.act("lin");
   float* lin_mean = c.vec("lin.mean");
