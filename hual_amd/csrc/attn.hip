@@ -351,12 +351,11 @@ int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
   const int nkt = cdiv(maxTk, 16);
   double flops = 0.0;
   for (int i = 0; i < n; ++i) flops += 4.0 * jobs[i].B * 8.0 * jobs[i].Tq * jobs[i].Tk * 16.0;   // QK^T + PV
-  ProfScope ps(PK_ATTN_FWD, s, flops, 0.0);
   const size_t lds = (size_t)nkt * 16 * 33 * sizeof(float);
-  if (nkt <= 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, lds, s, b, drop);
-  else if (nkt <= 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, lds, s, b, drop);
-  else if (nkt <= 8) hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, block, lds, s, b, drop);
-  else hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, block, lds, s, b, drop);
+  if (nkt <= 2) HUAL_LAUNCH(flops, 0.0, attn_fwd_kernel<2>, grid, block, lds, s, b, drop);
+  else if (nkt <= 4) HUAL_LAUNCH(flops, 0.0, attn_fwd_kernel<4>, grid, block, lds, s, b, drop);
+  else if (nkt <= 8) HUAL_LAUNCH(flops, 0.0, attn_fwd_kernel<8>, grid, block, lds, s, b, drop);
+  else HUAL_LAUNCH(flops, 0.0, attn_fwd_kernel<16>, grid, block, lds, s, b, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -371,9 +370,9 @@ int launch_attn_bwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
   dim3 grid(cdiv(nqt > nkt ? nqt : nkt, 4), maxB * 8, 2 * n), block(256);
   double flops = 0.0;
   for (int i = 0; i < n; ++i) flops += 2.0 * jobs[i].B * 8.0 * jobs[i].Tq * jobs[i].Tk * 16.0;
-  ProfScope ps(PK_ATTN_BWD_DQ, s, 7.0 * flops, 0.0);   // dQ half: S, dP, dQ ; dK/dV half: S, dP, dK, dV
+  // dQ half: S, dP, dQ ; dK/dV half: S, dP, dK, dV
   const size_t lds_dq = (size_t)nkt * 16 * 33 * sizeof(float), lds_dkv = (size_t)nqt * 16 * 40 * sizeof(float);
-  hipLaunchKernelGGL(attn_bwd_kernel, grid, block, lds_dq > lds_dkv ? lds_dq : lds_dkv, s, b, drop);
+  HUAL_LAUNCH(7.0 * flops, 0.0, attn_bwd_kernel, grid, block, lds_dq > lds_dkv ? lds_dq : lds_dkv, s, b, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -408,7 +408,7 @@ static int cq_lds_bytes(const RowSpace& rs, int nmats) { return (int)(cq_mat_ele
 int launch_tri_prep(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   int g = cdiv(rs.R, 8);
   g = g < 2048 ? g : 2048;
-  hipLaunchKernelGGL(tri_prep_kernel, dim3(g), dim3(256), 0, s, b, p, rs, drop);
+  HUAL_LAUNCH(0.0, 0.0, tri_prep_kernel, dim3(g), dim3(256), 0, s, b, p, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -421,8 +421,7 @@ int launch_cq_fwd(const CqBufs& b, const RowSpace& rs, hipStream_t s) {
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)cq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  ProfScope ps(PK_CQ, s, 2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0);
-  hipLaunchKernelGGL(cq_fwd_kernel, dim3(rs.B, 2), dim3(256), bytes, s, b, rs);
+  HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_kernel, dim3(rs.B, 2), dim3(256), bytes, s, b, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -430,7 +429,7 @@ int launch_cq_fwd(const CqBufs& b, const RowSpace& rs, hipStream_t s) {
 int launch_cq_bwd_pre(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, hipStream_t s) {
   int n = cdiv(rs.R, 8);
   n = n < 2048 ? n : 2048;
-  hipLaunchKernelGGL(cq_bwd_pre_kernel, dim3(n), dim3(256), 0, s, b, g, rs);
+  HUAL_LAUNCH(0.0, 0.0, cq_bwd_pre_kernel, dim3(n), dim3(256), 0, s, b, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -444,8 +443,7 @@ int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, 
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)cq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  ProfScope ps(PK_CQ, s, 2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0);
-  hipLaunchKernelGGL(cq_bwd_kernel, dim3(rs.B, 2), dim3(256), bytes, s, b, g, rs, dXa, dXb);
+  HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_kernel, dim3(rs.B, 2), dim3(256), bytes, s, b, g, rs, dXa, dXb);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -454,10 +452,10 @@ int launch_tri_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const CqParams& p, 
                         const DropCfg& drop, const float* dXa, const float* dXb, hipStream_t s) {
   int n = cdiv(rs.Nv, 8);
   n = n < 512 ? n : 512;
-  hipLaunchKernelGGL(tri_bwd_kernel, dim3(n), dim3(256), 0, s, b, g, p, pg, rs, drop, dXa, dXb, 0, rs.Nv);
+  HUAL_LAUNCH(0.0, 0.0, tri_bwd_kernel, dim3(n), dim3(256), 0, s, b, g, p, pg, rs, drop, dXa, dXb, 0, rs.Nv);
   n = cdiv(rs.Nq, 8);
   n = n < 512 ? n : 512;
-  hipLaunchKernelGGL(tri_bwd_kernel, dim3(n), dim3(256), 0, s, b, g, p, pg, rs, drop, dXa, dXb, rs.Nv, rs.R);
+  HUAL_LAUNCH(0.0, 0.0, tri_bwd_kernel, dim3(n), dim3(256), 0, s, b, g, p, pg, rs, drop, dXa, dXb, rs.Nv, rs.R);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -218,8 +218,7 @@ int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStre
   HUAL_REQUIRE(a.C >= 4, "char_ids need at least 4 chars per word (conv width 4, VALID) - modules.py:33");
   int grid = cdiv(nrows, 2);
   grid = grid < 1024 ? grid : 1024;
-  ProfScope ps(PK_EMBED, s, 0.0, 0.0);
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid), dim3(256), (size_t)2 * a.C * a.char_dim * sizeof(float), s, a, drop, nrows);
+  HUAL_LAUNCH(0.0, 0.0, embed_fwd_kernel, dim3(grid), dim3(256), (size_t)2 * a.C * a.char_dim * sizeof(float), s, a, drop, nrows);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -243,10 +242,9 @@ int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const D
   }
   HUAL_REQUIRE(g.partial != nullptr, "embed_bwd: null partial-sum scratch");
   const int grid = embed_bwd_blocks(nrows);
-  ProfScope ps(PK_EMBED, s, 0.0, 0.0);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), bytes, s, a, g, drop, nrows, EMBED_WPB);
+  HUAL_LAUNCH(0.0, 0.0, embed_bwd_kernel, dim3(grid), dim3(256), bytes, s, a, g, drop, nrows, EMBED_WPB);
   const int nacc = nfil + NCH + (a.num_chars - 1) * cd + a.word_dim;
-  hipLaunchKernelGGL(embed_reduce_kernel, dim3(cdiv(nacc, 64)), dim3(256), 0, s, a, g, grid);
+  HUAL_LAUNCH(0.0, 0.0, embed_reduce_kernel, dim3(cdiv(nacc, 64)), dim3(256), 0, s, a, g, grid);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -790,7 +790,7 @@ int launch_transpose_weights(const uint32_t* offs, const int* Ks, const int* Ns,
     maxK = Ks[i] > maxK ? Ks[i] : maxK;
     maxN = Ns[i] > maxN ? Ns[i] : maxN;
   }
-  hipLaunchKernelGGL(transpose_weights_kernel, dim3(cdiv(maxK, 32), cdiv(maxN, 32), n), dim3(256), 0, stream, b, src, dst);
+  HUAL_LAUNCH(0.0, 0.0, transpose_weights_kernel, dim3(cdiv(maxK, 32), cdiv(maxN, 32), n), dim3(256), 0, stream, b, src, dst);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -830,7 +830,6 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
     flops += 2.0 * jobs[i].M * kt * jobs[i].N * mult;
     bytes += 4.0 * ((double)jobs[i].M * kt + kt * jobs[i].N * mult + (double)jobs[i].M * jobs[i].N);
   }
-  ProfScope ps(dual ? PK_GEMM_DUAL : PK_GEMM, stream, flops, bytes);
   static const int impl = []() { const char* e = getenv("HUAL_GEMM_IMPL"); return e ? atoi(e) : 1; }();
   bool anytrans = false;
   for (int i = 0; i < n; ++i) anytrans = anytrans || jobs[i].transW != 0;
@@ -839,9 +838,9 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
   HUAL_REQUIRE(!(extras && anytrans), "launch_gemm: A prologue extras need [K,N] weights");
   if ((impl == 0 && !extras) || anytrans) {   // the LDS-DMA kernel needs [K,N] weights; transposed reads fall back to gemm_kernel
     if (dual)
-      hipLaunchKernelGGL(gemm_kernel<true>, grid, block, 0, stream, b, drop);
+      HUAL_LAUNCH(flops, bytes, gemm_kernel<true>, grid, block, 0, stream, b, drop);
     else
-      hipLaunchKernelGGL(gemm_kernel<false>, grid, block, 0, stream, b, drop);
+      HUAL_LAUNCH(flops, bytes, gemm_kernel<false>, grid, block, 0, stream, b, drop);
   } else {
     const size_t lds = (size_t)(dual ? 4 : 2) * GL_STAGE * sizeof(float);
     static bool attr = false;
@@ -861,11 +860,11 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
 #define HUAL_LAUNCH_LDS(KERN)                                                                      \
   do {                                                                                             \
     if (rt == 3) {                                                                                 \
-      if (dual) hipLaunchKernelGGL((KERN<true, 3>), g, blk, lds, stream, b, drop);                 \
-      else hipLaunchKernelGGL((KERN<false, 3>), g, blk, lds, stream, b, drop);                     \
+      if (dual) HUAL_LAUNCH(flops, bytes, (KERN<true, 3>), g, blk, lds, stream, b, drop);                 \
+      else HUAL_LAUNCH(flops, bytes, (KERN<false, 3>), g, blk, lds, stream, b, drop);                     \
     } else {                                                                                       \
-      if (dual) hipLaunchKernelGGL((KERN<true, 2>), g, blk, lds, stream, b, drop);                 \
-      else hipLaunchKernelGGL((KERN<false, 2>), g, blk, lds, stream, b, drop);                     \
+      if (dual) HUAL_LAUNCH(flops, bytes, (KERN<true, 2>), g, blk, lds, stream, b, drop);                 \
+      else HUAL_LAUNCH(flops, bytes, (KERN<false, 2>), g, blk, lds, stream, b, drop);                     \
     }                                                                                              \
   } while (0)
     if (extras) HUAL_LAUNCH_LDS(gemm_lds_px_kernel);
@@ -918,13 +917,12 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
         maxM = jobs[base + i].M > maxM ? jobs[base + i].M : maxM;
         maxKb = kbs > maxKb ? kbs : maxKb;
       }
-      hipLaunchKernelGGL(dw_table_write_kernel, dim3(1), dim3(64), 0, stream, b, table, base, cnt);
+      HUAL_LAUNCH(0.0, 0.0, dw_table_write_kernel, dim3(1), dim3(64), 0, stream, b, table, base, cnt);
     }
     DwBatch dummy;
     dw_job_init(dummy.j[0]);
     dim3 grid(cdiv(maxM, rows_per_block), maxKb, n), block(256);
-    ProfScope ps(PK_DW, stream, flops, bytes);
-    hipLaunchKernelGGL(dw_kernel<true>, grid, block, lds, stream, dummy, (const DwJob*)table, drop, rows_per_block);
+    HUAL_LAUNCH(flops, bytes, dw_kernel<true>, grid, block, lds, stream, dummy, (const DwJob*)table, drop, rows_per_block);
     HUAL_CHECK_HIP(hipGetLastError());
     return 0;
   }
@@ -942,8 +940,7 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
       maxKb = kbs > maxKb ? kbs : maxKb;
     }
     dim3 grid(cdiv(maxM, rows_per_block), maxKb, cnt), block(256);
-    ProfScope ps(PK_DW, stream, flops, bytes);
-    hipLaunchKernelGGL(dw_kernel<false>, grid, block, lds, stream, b, (const DwJob*)nullptr, drop, rows_per_block);
+    HUAL_LAUNCH(flops, bytes, dw_kernel<false>, grid, block, lds, stream, b, (const DwJob*)nullptr, drop, rows_per_block);
     HUAL_CHECK_HIP(hipGetLastError());
   }
   return 0;

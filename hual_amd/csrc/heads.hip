@@ -1,5 +1,6 @@
 // Heads, losses and span argmax (see heads.h).  These are tiny, HBM/latency-bound row kernels.
 #include "heads.h"
+#include "prof.h"
 
 using namespace hual;
 
@@ -493,13 +494,13 @@ namespace hual {
 
 int launch_pool_fwd(const PoolArgs& a, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(rs.L <= 256, "pool: L <= 256");
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(rs.B), dim3(128), 0, s, a, rs);
+  HUAL_LAUNCH(0.0, 0.0, pool_fwd_kernel, dim3(rs.B), dim3(128), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_pool_bwd(const PoolArgs& a, const PoolBwd& g, const RowSpace& rs, hipStream_t s) {
-  hipLaunchKernelGGL(pool_dpw_kernel, dim3(rs.B), dim3(512), 0, s, g, rs);
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(rs.B), dim3(128), 0, s, a, g, rs);
+  HUAL_LAUNCH(0.0, 0.0, pool_dpw_kernel, dim3(rs.B), dim3(512), 0, s, g, rs);
+  HUAL_LAUNCH(0.0, 0.0, pool_bwd_kernel, dim3(rs.B), dim3(128), 0, s, a, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -508,55 +509,55 @@ static int rowgrid(int R, int cap) {
   return g < cap ? (g > 0 ? g : 1) : cap;
 }
 int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, hipStream_t s) {
-  hipLaunchKernelGGL(match_fwd_kernel, dim3(rowgrid(rs.Nv, 1024)), dim3(256), 0, s, a, rs);
+  HUAL_LAUNCH(0.0, 0.0, match_fwd_kernel, dim3(rowgrid(rs.Nv, 1024)), dim3(256), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_match_denominator(float* loss_acc, float override_denom, hipStream_t s) {
-  hipLaunchKernelGGL(match_denominator_kernel, dim3(1), dim3(1), 0, s, loss_acc, override_denom);
+  HUAL_LAUNCH(0.0, 0.0, match_denominator_kernel, dim3(1), dim3(1), 0, s, loss_acc, override_denom);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, hipStream_t s) {
-  hipLaunchKernelGGL(match_bwd_kernel, dim3(rowgrid(rs.Nv, 256)), dim3(256), 0, s, a, g, rs);
+  HUAL_LAUNCH(0.0, 0.0, match_bwd_kernel, dim3(rowgrid(rs.Nv, 256)), dim3(256), 0, s, a, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_ortho(const float* E, float* dE, float* loss_acc, float lambda, hipStream_t s) {
-  hipLaunchKernelGGL(ortho_kernel, dim3(1), dim3(128), 0, s, E, dE, loss_acc, lambda);
+  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, dE, loss_acc, lambda);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_rowdot_fwd(const DotArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(rowgrid(a.R, 1024), 2), dim3(256), 0, s, a);
+  HUAL_LAUNCH(0.0, 0.0, rowdot_fwd_kernel, dim3(rowgrid(a.R, 1024), 2), dim3(256), 0, s, a);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_rowdot_bwd(const DotArgs& a, const DotBwd& g, hipStream_t s) {
-  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(rowgrid(a.R, 256), 2), dim3(256), 0, s, a, g);
+  HUAL_LAUNCH(0.0, 0.0, rowdot_bwd_kernel, dim3(rowgrid(a.R, 256), 2), dim3(256), 0, s, a, g);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_loc(const LocArgs& a, int B, int T, hipStream_t s) {
   HUAL_REQUIRE(T <= 256, "loc: T <= 256");
-  hipLaunchKernelGGL(loc_kernel, dim3(B), dim3(256), 0, s, a, T);
+  HUAL_LAUNCH(0.0, 0.0, loc_kernel, dim3(B), dim3(256), 0, s, a, T);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_align_pool(const AlignPool& a, const RowSpace& rs, hipStream_t s) {
-  hipLaunchKernelGGL(align_pool_kernel, dim3(rs.B), dim3(512), 0, s, a, rs);
+  HUAL_LAUNCH(0.0, 0.0, align_pool_kernel, dim3(rs.B), dim3(512), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_align_sim(const AlignSim& a, hipStream_t s) {
   HUAL_REQUIRE(a.Bg >= 1 && a.Bg <= 1024, "align: global batch <= 1024");
-  hipLaunchKernelGGL(align_sim_rows_kernel, dim3(a.Bg), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(align_sim_cols_kernel, dim3(a.Bg), dim3(128), 0, s, a);
+  HUAL_LAUNCH(0.0, 0.0, align_sim_rows_kernel, dim3(a.Bg), dim3(256), 0, s, a);
+  HUAL_LAUNCH(0.0, 0.0, align_sim_cols_kernel, dim3(a.Bg), dim3(128), 0, s, a);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_align_pool_bwd(const AlignPool& a, const AlignPoolBwd& g, const RowSpace& rs, hipStream_t s) {
-  hipLaunchKernelGGL(align_pool_bwd_kernel, dim3(rs.B), dim3(512), 0, s, a, g, rs);
+  HUAL_LAUNCH(0.0, 0.0, align_pool_bwd_kernel, dim3(rs.B), dim3(512), 0, s, a, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

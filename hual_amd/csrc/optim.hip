@@ -54,9 +54,8 @@ int launch_adamw(const AdamArgs& a, hipStream_t s) {
   HUAL_REQUIRE(a.p && a.g && a.m && a.v && a.decay && a.lr_dev && a.sqnorm, "adamw: null pointer");
   HUAL_REQUIRE((a.n % 4) == 0, "adamw: flat size must be a multiple of 4");
   HUAL_CHECK_HIP(hipMemsetAsync(a.sqnorm, 0, sizeof(float), s));
-  ProfScope ps(PK_OPTIM, s, 0.0, 36.0 * a.n);
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(256), dim3(256), 0, s, (const float*)a.g, a.n, a.prescale, a.sqnorm);
-  hipLaunchKernelGGL(adamw_kernel, dim3(512), dim3(256), 0, s, a.p, (const float*)a.g, a.m, a.v, a.decay, a.n, a.lr_dev,
+  HUAL_LAUNCH(0.0, 4.0 * a.n, sqnorm_kernel, dim3(256), dim3(256), 0, s, (const float*)a.g, a.n, a.prescale, a.sqnorm);
+  HUAL_LAUNCH(0.0, 32.0 * a.n, adamw_kernel, dim3(512), dim3(256), 0, s, a.p, (const float*)a.g, a.m, a.v, a.decay, a.n, a.lr_dev,
                      a.clip_norm, a.prescale, (const float*)a.sqnorm, 0.9f, 0.999f, 1e-6f);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

@@ -1,35 +1,41 @@
 #include "prof.h"
+#include <map>
+#include <string>
 #include <vector>
+#include <string.h>
+#include "../../include/hual_seqpan.h"
 
 namespace hual {
 
 namespace {
-struct Rec { int kind; hipEvent_t a, b; double flops, bytes; };
+struct Rec { std::string name; hipEvent_t a, b; double flops, bytes; };
+struct Agg { std::string name; int64_t launches = 0; double usec = 0.0, flops = 0.0, bytes = 0.0; };
 struct State {
   bool on = false;
   std::vector<Rec> recs;
-  hipEvent_t pending = nullptr;
+  std::vector<Agg> aggs;
 };
 thread_local State g_prof;
+
+// "(gemm_lds_kernel<false, 3>)" -> "gemm_lds_kernel<false, 3>"
+std::string clean(const char* s) {
+  std::string n(s);
+  while (!n.empty() && (n.front() == '(' || n.front() == ' ')) n.erase(n.begin());
+  while (!n.empty() && (n.back() == ')' || n.back() == ' ')) n.pop_back();
+  return n;
+}
 }  // namespace
 
 bool prof_on() { return g_prof.on; }
 
-void prof_start(int kind, hipStream_t s) {
-  (void)kind;
-  hipEvent_t e;
-  if (hipEventCreate(&e) != hipSuccess) return;
-  hipEventRecord(e, s);
-  g_prof.pending = e;
-}
-
-void prof_stop(int kind, hipStream_t s, double flops, double bytes) {
-  if (!g_prof.pending) return;
-  hipEvent_t e;
-  if (hipEventCreate(&e) != hipSuccess) return;
-  hipEventRecord(e, s);
-  g_prof.recs.push_back(Rec{kind, g_prof.pending, e, flops, bytes});
-  g_prof.pending = nullptr;
+void prof_events(const char* name, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop) {
+  *start = *stop = nullptr;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess) return;
+  if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return; }
+  g_prof.recs.push_back(Rec{clean(name), a, b, flops, bytes});
+  *start = a;
+  *stop = b;
 }
 
 }  // namespace hual
@@ -39,34 +45,44 @@ extern "C" {
 int hual_prof_begin(void) {
   hual::g_prof.on = true;
   hual::g_prof.recs.clear();
+  hual::g_prof.aggs.clear();
   return 0;
 }
 
-// out arrays of length HUAL_PROF_KINDS: launches, microseconds, flops, bytes.  Synchronises the recorded events.
-int hual_prof_end(int64_t* launches, double* usec, double* flops, double* bytes, int n) {
+int hual_prof_end(void) {
   using namespace hual;
   g_prof.on = false;
-  for (int i = 0; i < n; ++i) { launches[i] = 0; usec[i] = 0.0; flops[i] = 0.0; bytes[i] = 0.0; }
+  std::map<std::string, size_t> idx;
+  g_prof.aggs.clear();
   for (auto& r : g_prof.recs) {
     hipEventSynchronize(r.b);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, r.a, r.b);
-    if (r.kind < n) {
-      launches[r.kind] += 1; usec[r.kind] += (double)ms * 1e3; flops[r.kind] += r.flops; bytes[r.kind] += r.bytes;
+    const bool ok = hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess;
+    auto it = idx.find(r.name);
+    if (it == idx.end()) {
+      it = idx.emplace(r.name, g_prof.aggs.size()).first;
+      g_prof.aggs.push_back(Agg{r.name});
     }
+    Agg& a = g_prof.aggs[it->second];
+    if (ok) { a.launches += 1; a.usec += (double)ms * 1e3; a.flops += r.flops; a.bytes += r.bytes; }
     hipEventDestroy(r.a);
     hipEventDestroy(r.b);
   }
   g_prof.recs.clear();
-  return 0;
+  return (int)g_prof.aggs.size();
 }
 
-const char* hual_prof_kind_name(int k) {
-  static const char* names[] = {"gemm_kernel<false>", "gemm_kernel<true>", "dw_kernel", "attn_fwd_kernel",
-                                "attn_bwd_kernel", "(unused)", "ln_fwd_kernel", "ln_bwd_kernel",
-                                "ln_dwconv_fwd_kernel", "dwconv_ln_bwd_kernel", "ew_kernel", "cq_kernels",
-                                "embed_kernels", "head_kernels", "optim_kernels"};
-  return (k >= 0 && k < hual::PK_COUNT) ? names[k] : "";
+int hual_prof_get(int i, char* name, int name_cap, int64_t* launches, double* usec, double* flops, double* bytes) {
+  using namespace hual;
+  if (i < 0 || i >= (int)g_prof.aggs.size() || !name || name_cap < 1) return HUAL_ERR_INVALID;
+  const Agg& a = g_prof.aggs[i];
+  strncpy(name, a.name.c_str(), (size_t)name_cap - 1);
+  name[name_cap - 1] = 0;
+  if (launches) *launches = a.launches;
+  if (usec) *usec = a.usec;
+  if (flops) *flops = a.flops;
+  if (bytes) *bytes = a.bytes;
+  return 0;
 }
 
 }  // extern "C"

@@ -1,28 +1,30 @@
-// Optional per-kernel-family timing with HIP events, used only by bench.py's roofline leg.
-// Off by default: hual_prof_begin() arms it for the calling thread, hual_prof_end() synchronises the recorded
-// events (the ONLY place the library ever synchronises) and reports launches / microseconds / algorithmic FLOPs
-// and bytes per family.
+// Optional per-kernel timing, used only by bench.py's roofline leg.
+// Off by default: hual_prof_begin() arms it for the calling thread; while armed every launch goes through
+// hipExtLaunchKernelGGL with its own start / stop events, which take the begin / end timestamps of that kernel's own
+// dispatch (the numbers rocprofv3 --kernel-trace reports), not the time between two markers on the stream.
+// hual_prof_end() synchronises the recorded events (the ONLY place the library ever synchronises) and aggregates
+// launches / microseconds / algorithmic FLOPs and bytes per kernel symbol.
 #pragma once
+#include <hip/hip_ext.h>
 #include "common.h"
 
 namespace hual {
 
-enum ProfKind {
-  PK_GEMM = 0, PK_GEMM_DUAL, PK_DW, PK_ATTN_FWD, PK_ATTN_BWD_DQ, PK_ATTN_BWD_DKV, PK_LN_FWD, PK_LN_BWD, PK_CONV_FWD,
-  PK_CONV_BWD, PK_EW, PK_CQ, PK_EMBED, PK_HEADS, PK_OPTIM, PK_COUNT
-};
-
 bool prof_on();
-// bracket one launch: call before and after the hipLaunchKernelGGL
-void prof_start(int kind, hipStream_t s);
-void prof_stop(int kind, hipStream_t s, double flops, double bytes);
-
-struct ProfScope {
-  int kind; hipStream_t s; double flops, bytes; bool on;
-  ProfScope(int k, hipStream_t st, double f = 0.0, double b = 0.0) : kind(k), s(st), flops(f), bytes(b), on(prof_on()) {
-    if (on) prof_start(kind, s);
-  }
-  ~ProfScope() { if (on) prof_stop(kind, s, flops, bytes); }
-};
+// a fresh event pair for one launch of kernel `name` (the stringified kernel expression)
+void prof_events(const char* name, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop);
 
 }  // namespace hual
+
+// Launch KERN (parenthesise template instantiations that contain commas).  FLOPS / BYTES = algorithmic work of this
+// launch for the roofline report (0.0 when not meaningful).
+#define HUAL_LAUNCH(FLOPS, BYTES, KERN, GRID, BLOCK, LDS, STREAM, ...)                              \
+  do {                                                                                              \
+    if (hual::prof_on()) {                                                                          \
+      hipEvent_t hual_e0_ = nullptr, hual_e1_ = nullptr;                                            \
+      hual::prof_events(#KERN, (FLOPS), (BYTES), &hual_e0_, &hual_e1_);                             \
+      hipExtLaunchKernelGGL(KERN, GRID, BLOCK, LDS, STREAM, hual_e0_, hual_e1_, 0, __VA_ARGS__);    \
+    } else {                                                                                        \
+      hipLaunchKernelGGL(KERN, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                              \
+    }                                                                                               \
+  } while (0)

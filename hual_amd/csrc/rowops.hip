@@ -339,8 +339,7 @@ static inline int row_grid(int R) {
 
 int launch_ln_fwd(const LnFwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.x && a.g1 && a.b1 && a.y1 && a.R > 0, "ln_fwd: null/empty");
-  ProfScope ps(PK_LN_FWD, s, 0.0, 8.0 * a.R * HUAL_D);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(row_grid(a.R)), dim3(256), 0, s, a, rs, drop);
+  HUAL_LAUNCH(0.0, 8.0 * a.R * HUAL_D, ln_fwd_kernel, dim3(row_grid(a.R)), dim3(256), 0, s, a, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -352,8 +351,7 @@ int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s) {
   int g = cdiv(a.R, 8);
   g = g < 128 ? g : 128;     // every block ends with 256-512 same-address float atomics: keep the count low
   if (a.part) g = ln_bwd_blocks(a.R);
-  ProfScope ps(PK_LN_BWD, s, 0.0, 12.0 * a.R * HUAL_D);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(256), 0, s, a, drop);
+  HUAL_LAUNCH(0.0, 12.0 * a.R * HUAL_D, ln_bwd_kernel, dim3(g), dim3(256), 0, s, a, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -362,19 +360,17 @@ static int conv_blocks(const RowSpace& rs) { return rs.B * cdiv(rs.T, SEG) + (rs
 
 int launch_ln_dwconv_fwd(const ConvFwd& a, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(a.x && a.g && a.b && a.dw && a.c && a.mean && a.rstd, "ln_dwconv_fwd: null");
-  ProfScope ps(PK_CONV_FWD, s, 0.0, 8.0 * rs.R * HUAL_D);
-  hipLaunchKernelGGL(ln_dwconv_fwd_kernel, dim3(conv_blocks(rs)), dim3(256), 0, s, a, rs);
+  HUAL_LAUNCH(0.0, 8.0 * rs.R * HUAL_D, ln_dwconv_fwd_kernel, dim3(conv_blocks(rs)), dim3(256), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.dc && a.x && a.mean && a.rstd && a.g && a.b && a.dw && a.dx && a.dg && a.db && a.ddw, "dwconv_ln_bwd: null");
-  ProfScope ps(PK_CONV_BWD, s, 0.0, 16.0 * rs.R * HUAL_D);
   int grid = conv_blocks(rs);
   grid = grid < 128 ? grid : 128;      // each block ends with 9x128 same-address float atomics
   if (a.part) grid = conv_blocks(rs);
-  hipLaunchKernelGGL(dwconv_ln_bwd_kernel, dim3(grid), dim3(256), 0, s, a, rs, drop);
+  HUAL_LAUNCH(0.0, 16.0 * rs.R * HUAL_D, dwconv_ln_bwd_kernel, dim3(grid), dim3(256), 0, s, a, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -392,7 +388,7 @@ int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s) {
     b.j[i] = jobs[i];
     maxvec = jobs[i].nvec > maxvec ? jobs[i].nvec : maxvec;
   }
-  hipLaunchKernelGGL(colsum_kernel, dim3(n, maxvec, COLSUM_SPLIT), dim3(256), 0, s, b);
+  HUAL_LAUNCH(0.0, 0.0, colsum_kernel, dim3(n, maxvec, COLSUM_SPLIT), dim3(256), 0, s, b);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -402,15 +398,14 @@ int launch_pos_bwd(const float* dx, float* dpos, const RowSpace& rs, int do_v, i
   if (do_v) n = rs.T;
   if (do_q && rs.L > n) n = rs.L;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(pos_bwd_kernel, dim3(n), dim3(512), 0, s, dx, dpos, rs, do_v, do_q);
+  HUAL_LAUNCH(0.0, 0.0, pos_bwd_kernel, dim3(n), dim3(512), 0, s, dx, dpos, rs, do_v, do_q);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_ew(const EwArgs& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.R > 0 && a.a && a.out, "ew: null/empty");
-  ProfScope ps(PK_EW, s, 0.0, 12.0 * a.R * HUAL_D);
-  hipLaunchKernelGGL(ew_kernel, dim3(row_grid(a.R)), dim3(256), 0, s, a, drop);
+  HUAL_LAUNCH(0.0, 12.0 * a.R * HUAL_D, ew_kernel, dim3(row_grid(a.R)), dim3(256), 0, s, a, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -4,6 +4,7 @@
 // can be captured into a hipGraph.  Buffers are carved out of the caller's workspace by a deterministic bump
 // allocator; a "dry" pass of the very same code computes the workspace size and the name table.
 #include "attn.h"
+#include "prof.h"
 #include "cq.h"
 #include "embed.h"
 #include "gemm.h"
@@ -340,7 +341,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* loss_acc = c.buf("loss_acc", 8, 1);
   if (!c.dry) {
     HUAL_CHECK_HIP(hipMemsetAsync(loss_acc, 0, 8 * sizeof(float), c.stream));
-    hipLaunchKernelGGL(prep_masks_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.stream, bt->video_seq_len, bt->word_ids,
+    HUAL_LAUNCH(0.0, 0.0, prep_masks_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.stream, bt->video_seq_len, bt->word_ids,
                        rowmask, B, T, L);
   }
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
@@ -640,7 +641,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       c.chk(launch_match_denominator(loss_acc, opt->match_denom_override, c.stream));
       if (c.ok()) c.chk(launch_ortho(c.p(pm.label_emb), nullptr, loss_acc, c.cfg->match_lambda, c.stream));
       if (out->loss_terms)
-        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, c.stream, (const float*)loss_acc, c.cfg->match_lambda,
+        HUAL_LAUNCH(0.0, 0.0, loss_finalize_kernel, dim3(1), dim3(1), 0, c.stream, (const float*)loss_acc, c.cfg->match_lambda,
                            out->loss_terms);
     }
   }

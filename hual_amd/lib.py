@@ -82,6 +82,8 @@ def load():
                                          u64, vp]
     lib.hual_adamw_clip_step.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp]
     lib.hual_align_loss.argtypes = [vp, vp, i32, vp, vp, vp, vp, f32, vp]
+    lib.hual_prof_get.argtypes = [i32, ctypes.c_char_p, i32, P(ctypes.c_int64), P(ctypes.c_double), P(ctypes.c_double),
+                                  P(ctypes.c_double)]
     lib.hual_aux_create.argtypes = [P(hual_aux)]
     lib.hual_aux_destroy.argtypes = [P(hual_aux)]
     lib.hual_linear_fwd.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]

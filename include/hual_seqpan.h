@@ -188,13 +188,13 @@ int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW,
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hook for bench.py's roofline leg (not part of the reference's surface): between begin and end every
- * launch of each kernel family is bracketed by HIP events on its stream; hual_prof_end() synchronises those events
- * (the only synchronising call in the library) and returns, per family, launches, microseconds, algorithmic FLOPs
- * and algorithmic bytes. */
-#define HUAL_PROF_KINDS 15
+ * kernel launch carries its own start / stop events (hipExtLaunchKernelGGL: the begin / end timestamps of that
+ * kernel's dispatch, the quantity rocprofv3 --kernel-trace reports).  hual_prof_end() synchronises those events (the
+ * only synchronising call in the library), aggregates per kernel symbol and returns the number of distinct kernels;
+ * hual_prof_get(i, ...) reads entry i: kernel name, launches, microseconds, algorithmic FLOPs and bytes. */
 int hual_prof_begin(void);
-int hual_prof_end(int64_t* launches, double* usec, double* flops, double* bytes, int n);
-const char* hual_prof_kind_name(int kind);
+int hual_prof_end(void);
+int hual_prof_get(int i, char* name, int name_cap, int64_t* launches, double* usec, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }
