@@ -4,11 +4,20 @@
 //              (widths 1..4 -> 10/20/30/40 channels) + bias -> relu -> max over chars (padding not masked)
 // Output row = [word_emb(300) | char features(100)] (model.py:41), consumed by the query_conv1d GEMM.
 //
-// Work decomposition: a 256-thread block handles TWO words at a time (threads 0-127 / 128-255); inside a word
-// thread c < 100 owns output channel c.  Filter taps are read from global memory with consecutive channels on
-// consecutive lanes (coalesced, L2 resident: 60-120 KB), the word's char embeddings sit in LDS and are read as
-// broadcasts.  The backward pass keeps ALL parameter gradients of the front end in LDS accumulators (ds_add_f32)
-// while a block walks its words and flushes them with one set of global atomics per block.
+// The four convolutions are ONE dense product on the right layout.  cemb holds the (dropped) char embeddings, one row
+// of CP floats (char_dim padded with zeros to a multiple of 16) per char slot, rows in (word, slot) order.  The window
+// that starts at slot row r and is 4 slots wide is then simply the row of length 4*CP at cemb + r*CP (leading dimension
+// CP: overlapping rows), and with
+//     Wall[dk*CP + d][off_k + n] = filter_k[dk][d][n]   (zero for dk >= k, for the padding columns and d >= char_dim)
+// Yall = windows . Wall + ball gives every channel of every width at every start position in one [M x 128] GEMM
+// (M = words * C).  Windows that run past a word's last slot are computed and ignored.
+//   forward : embed_gather_kernel (lookups, dropout, Wall / Wall^T / ball) -> launch_gemm -> char_pool_kernel
+//             (relu, max over the valid start positions, arg-max)
+//   backward: char_pool_bwd_kernel scatters the channel gradients to the arg-max rows of dYall [M x 128];
+//             d filters / d bias = windows^T . dYall is one more job of the step's weight-gradient launch (dw_kernel),
+//             into the packed scratch dFall which embed_unpack_kernel adds to the real gradients;
+//             d windows = dYall . Wall^T (launch_gemm) and embed_finish_kernel folds the overlapping windows back to
+//             char slots, applies the dropout mask and accumulates char-table rows (LDS, then global atomics).
 #include "embed.h"
 #include "philox.h"
 #include "prof.h"
@@ -16,235 +25,276 @@
 using namespace hual;
 
 #define NCH 100          // 10+20+30+40 channels
-#define MAXPOS 16        // conv positions kept in registers at once
-__device__ __forceinline__ void chan_to_kernel(int ch, int& k, int& chk, int& nchk) {
-  if (ch < 10) { k = 1; chk = ch; nchk = 10; }
-  else if (ch < 30) { k = 2; chk = ch - 10; nchk = 20; }
-  else if (ch < 60) { k = 3; chk = ch - 30; nchk = 30; }
-  else { k = 4; chk = ch - 60; nchk = 40; }
+#define NALL 128         // padded channel count = GEMM N
+__device__ __host__ __forceinline__ int bank_off(int k) { return k == 1 ? 0 : (k == 2 ? 10 : (k == 3 ? 30 : 60)); }
+__device__ __forceinline__ void chan_to_kernel(int ch, int& k, int& chk) {
+  if (ch < 10) { k = 1; chk = ch; }
+  else if (ch < 30) { k = 2; chk = ch - 10; }
+  else if (ch < 60) { k = 3; chk = ch - 30; }
+  else { k = 4; chk = ch - 60; }
 }
 
-__device__ __forceinline__ float drop1(const DropCfg& d, uint32_t site, uint32_t row, int col) {
-  float4 m = drop_mask4(d, site, row, (uint32_t)(col >> 2));
-  const int c = col & 3;
-  return c == 0 ? m.x : (c == 1 ? m.y : (c == 2 ? m.z : m.w));
+namespace hual {
+static inline int cpad(int char_dim) { return (char_dim + 15) / 16 * 16; }
+EmbedLayout embed_layout(int nrows, int C, int char_dim) {
+  EmbedLayout l;
+  const int CP = cpad(char_dim);
+  const size_t M = (size_t)nrows * C;
+  l.CP = CP;
+  size_t off = 0;
+  l.cemb = off; off += (M + 4) * CP;
+  l.wall = off; off += (size_t)4 * CP * NALL;
+  l.wallt = off; off += (size_t)NALL * 4 * CP;
+  l.ball = off; off += NALL;
+  l.yall = off; off += M * NALL;
+  l.dxall = off; off += M * 4 * CP;
+  l.dfall = off; off += (size_t)4 * CP * NALL + NALL;
+  l.total = off;
+  return l;
 }
+}  // namespace hual
 
-// stage the (dropped) char embeddings of `row` into emb[C*cd]; threads tid..(+=nthr)
-__device__ __forceinline__ void load_char_emb(const EmbedArgs& a, const DropCfg& drop, int row, float* emb, int tid, int nthr) {
-  const int cd = a.char_dim, C = a.C;
-  for (int idx = tid; idx < C * cd; idx += nthr) {
-    const int c = idx / cd, d = idx - c * cd;
-    const int cid = a.char_ids[(size_t)row * C + c];
-    float v = cid > 0 ? a.char_table[(size_t)(cid - 1) * cd + d] : 0.f;
-    if (drop.enabled) v *= drop1(drop, HUAL_SITE_CHAR, (uint32_t)(row * C + c), d);
-    emb[idx] = v;
-  }
-}
-
-__global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedArgs a, DropCfg drop, int nrows) {
-  extern __shared__ float sm[];    // [2][C*cd]
-  const int half = threadIdx.x >> 7, tid = threadIdx.x & 127;
+// ------------------------------------------------------------------------------------------------------
+// one task = 4 consecutive columns of a word row or of a char slot row; tail tasks build Wall / Wall^T / ball
+__global__ __launch_bounds__(256) void embed_gather_kernel(EmbedArgs a, DropCfg drop, int nrows, int CP, int ntask_words) {
   const int wd = a.word_dim, cd = a.char_dim, C = a.C;
-  float* emb = sm + half * C * cd;
-  for (int row0 = blockIdx.x * 2; row0 < nrows; row0 += gridDim.x * 2) {
-    const int row = row0 + half;
-    const bool act = row < nrows;
-    __syncthreads();
-    if (act) {
-      float* out = a.cat + (size_t)row * a.ldcat;
+  const int ngw = wd >> 2, ngc = CP >> 2;
+  const int per_word = ngw + C * ngc;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid < ntask_words) {
+    const int row = gid / per_word, t = gid - row * per_word;
+    if (t < ngw) {
       const int wid = a.word_ids[row];
-      for (int c = tid; c < wd; c += 128) {
-        float v = 0.f;
-        if (wid == 1) v = a.unk[c];
-        else if (wid >= 2) v = a.word_table[(size_t)(wid - 2) * wd + c];
-        if (drop.enabled) v *= drop1(drop, HUAL_SITE_WORD, (uint32_t)row, c);
-        out[c] = v;
-      }
-      load_char_emb(a, drop, row, emb, tid, 128);
-    }
-    __syncthreads();
-    if (act && tid < NCH) {
-      int k, chk, nchk;
-      chan_to_kernel(tid, k, chk, nchk);
-      const float* F = a.filt[k - 1] + chk;          // [k][cd][nchk]
-      const float bias = a.fbias[k - 1][chk];
-      const int npos = C - k + 1;
-      float best = 0.f;                              // relu floor: max_c relu(o_c) = max(0, max_c o_c)
-      int arg = -1;
-      for (int p0 = 0; p0 < npos; p0 += MAXPOS) {
-        float acc[MAXPOS];
-#pragma unroll
-        for (int p = 0; p < MAXPOS; ++p) acc[p] = bias;
-        for (int dk = 0; dk < k; ++dk) {
-          for (int d = 0; d < cd; ++d) {
-            const float f = F[(size_t)(dk * cd + d) * nchk];
-            const float* e = emb + (p0 + dk) * cd + d;
-#pragma unroll
-            for (int p = 0; p < MAXPOS; ++p)
-              if (p0 + p < npos) acc[p] = fmaf(e[p * cd], f, acc[p]);
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < MAXPOS; ++p)
-          if (p0 + p < npos && acc[p] > best) { best = acc[p]; arg = p0 + p; }
-      }
-      a.cat[(size_t)row * a.ldcat + wd + tid] = best;
-      a.char_arg[(size_t)row * NCH + tid] = arg;
-    }
-  }
-}
-
-// backward: LDS accumulators [dF | dB | dT | dU]; one word at a time per block, all 256 threads.
-// Thread <-> filter tap (kernel width k, tap dk, embedding column d): it owns that row of dF (plain LDS
-// read-modify-write, no conflicts) and walks the channels of width k; the char-embedding gradient goes through
-// ds_add_f32 (taps of different threads can meet on the same (char, d) only across waves).
-__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedArgs a, EmbedGrads gr, DropCfg drop, int nrows,
-                                                        int words_per_block) {
-  extern __shared__ float sm[];
-  const int wd = a.word_dim, cd = a.char_dim, C = a.C;
-  const int nfil = cd * (1 * 10 + 2 * 20 + 3 * 30 + 4 * 40);
-  const int ntab = (a.num_chars - 1) * cd;
-  float* dF = sm;                        // [nfil]
-  float* dB = dF + nfil;                 // [NCH]
-  float* dT = dB + NCH;                  // [ntab]
-  float* dU = dT + ntab;                 // [wd]
-  float* emb = dU + wd;                  // [C*cd] dropped char embeddings of the current word
-  float* demb = emb + C * cd;            // [C*cd]
-  float* gch = demb + C * cd;            // [NCH] upstream gradient per channel (0 where relu clipped)
-  int* argc = reinterpret_cast<int*>(gch + NCH);   // [NCH]
-  const int tid = threadIdx.x;
-  const int nacc = nfil + NCH + ntab + wd;
-  for (int i = tid; i < nacc; i += 256) sm[i] = 0.f;
-  const int foff[4] = {0, cd * 10, cd * 10 + 2 * cd * 20, cd * 10 + 2 * cd * 20 + 3 * cd * 30};
-  const int choff[4] = {0, 10, 30, 60};
-  const int ntap = 10 * cd;              // (1+2+3+4) * cd taps
-  const int row_lo = blockIdx.x * words_per_block;
-  const int row_hi = min(row_lo + words_per_block, nrows);
-  for (int row = row_lo; row < row_hi; ++row) {
-    __syncthreads();
-    load_char_emb(a, drop, row, emb, tid, 256);
-    for (int idx = tid; idx < C * cd; idx += 256) demb[idx] = 0.f;
-    const float* dcat = gr.dcat + (size_t)row * gr.lddcat;
-    if (tid < NCH) {
-      const int arg = a.char_arg[(size_t)row * NCH + tid];
-      const float g = arg >= 0 ? dcat[wd + tid] : 0.f;
-      argc[tid] = arg;
-      gch[tid] = g;
-      dB[tid] += g;
-    }
-    if (a.word_ids[row] == 1)
-      for (int c = tid; c < wd; c += 256) {
-        float g = dcat[c];
-        if (drop.enabled) g *= drop1(drop, HUAL_SITE_WORD, (uint32_t)row, c);
-        dU[c] += g;
-      }
-    __syncthreads();
-    for (int tap = tid; tap < ntap; tap += 256) {
-      // taps are ordered [k=1: cd][k=2: 2cd][k=3: 3cd][k=4: 4cd]
-      int k, base;
-      if (tap < cd) { k = 1; base = 0; }
-      else if (tap < 3 * cd) { k = 2; base = cd; }
-      else if (tap < 6 * cd) { k = 3; base = 3 * cd; }
-      else { k = 4; base = 6 * cd; }
-      const int rel = tap - base;            // dk*cd + d
-      const int dk = rel / cd, d = rel - dk * cd;
-      const int nchk = 10 * k;
-      const float* F = a.filt[k - 1] + (size_t)rel * nchk;
-      float* f = dF + foff[k - 1] + rel * nchk;
-      const int c0 = choff[k - 1];
-      for (int ch = 0; ch < nchk; ++ch) {
-        const int arg = argc[c0 + ch];
-        if (arg < 0) continue;
-        const float g = gch[c0 + ch];
-        const int ei = (arg + dk) * cd + d;
-        f[ch] += g * emb[ei];
-        atomicAdd(&demb[ei], g * F[ch]);
-      }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < C * cd; idx += 256) {
-      const int c = idx / cd, d = idx - c * cd;
-      const int cid = a.char_ids[(size_t)row * C + c];
-      if (cid > 0) {
-        float g = demb[idx];
-        if (drop.enabled) g *= drop1(drop, HUAL_SITE_CHAR, (uint32_t)(row * C + c), d);
-        atomicAdd(&dT[(size_t)(cid - 1) * cd + d], g);
-      }
-    }
-  }
-  __syncthreads();
-  // this block's partial sums -> scratch (plain coalesced stores; summed over blocks by embed_reduce_kernel)
-  float* part = gr.partial + (size_t)blockIdx.x * nacc;
-  for (int i = tid; i < nacc; i += 256) part[i] = sm[i];
-}
-
-// sums the per-block partials [nblocks][nacc] and adds them to the parameter gradients (one owner per element).
-// 256 threads = 64 elements x 4 groups of blocks.
-__global__ __launch_bounds__(256) void embed_reduce_kernel(EmbedArgs a, EmbedGrads gr, int nblocks) {
-  __shared__ float part[4][64];
-  const int cd = a.char_dim, wd = a.word_dim;
-  const int nfil = cd * (1 * 10 + 2 * 20 + 3 * 30 + 4 * 40);
-  const int ntab = (a.num_chars - 1) * cd;
-  const int nacc = nfil + NCH + ntab + wd;
-  const int foff[4] = {0, cd * 10, cd * 10 + 2 * cd * 20, cd * 10 + 2 * cd * 20 + 3 * cd * 30};
-  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + e;
-  float s = 0.f;
-  if (i < nacc)
-    for (int b = grp; b < nblocks; b += 4) s += gr.partial[(size_t)b * nacc + i];
-  part[grp][e] = s;
-  __syncthreads();
-  if (grp == 0 && i < nacc) {
-    s = part[0][e] + part[1][e] + part[2][e] + part[3][e];
-    if (i < nfil) {
-      const int k = i < foff[1] ? 0 : (i < foff[2] ? 1 : (i < foff[3] ? 2 : 3));
-      gr.dfilt[k][i - foff[k]] += s;
-    } else if (i < nfil + NCH) {
-      int k, chk, nchk;
-      chan_to_kernel(i - nfil, k, chk, nchk);
-      gr.dfbias[k - 1][chk] += s;
-    } else if (i < nfil + NCH + ntab) {
-      gr.dchar_table[i - nfil - NCH] += s;
+      float4 v = f4zero();
+      if (wid == 1) v = ld4(a.unk + 4 * t);
+      else if (wid >= 2) v = ld4(a.word_table + (size_t)(wid - 2) * wd + 4 * t);
+      if (drop.enabled) v = apply_drop4(drop, HUAL_SITE_WORD, (uint32_t)row, (uint32_t)t, v);
+      st4(a.cat + (size_t)row * a.ldcat + 4 * t, v);
     } else {
-      gr.dunk[i - nfil - NCH - ntab] += s;
+      const int u = t - ngw, c = u / ngc, g4 = u - c * ngc;
+      const int cid = a.char_ids[(size_t)row * C + c];
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      if (cid > 0) {
+        const float* src = a.char_table + (size_t)(cid - 1) * cd;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * g4 + q < cd) e[q] = src[4 * g4 + q];
+      }
+      float4 v = make_float4(e[0], e[1], e[2], e[3]);
+      if (drop.enabled && 4 * g4 < cd) v = apply_drop4(drop, HUAL_SITE_CHAR, (uint32_t)(row * C + c), (uint32_t)g4, v);
+      st4(a.cemb + ((size_t)row * C + c) * CP + 4 * g4, v);
     }
+    return;
+  }
+  int x = gid - ntask_words;
+  if (x < 4 * CP) { a.cemb[(size_t)nrows * C * CP + x] = 0.f; return; }      // guard rows behind the last window
+  x -= 4 * CP;
+  if (x < 4 * CP * NALL) {
+    const int r = x / NALL, n = x - r * NALL;       // Wall[r][n]
+    const int dk = r / CP, d = r - dk * CP;
+    float v = 0.f;
+    if (n < NCH && d < cd) {
+      int k, chk;
+      chan_to_kernel(n, k, chk);
+      if (dk < k) v = a.filt[k - 1][(size_t)(dk * cd + d) * (10 * k) + chk];
+    }
+    a.wall[x] = v;
+    a.wallt[(size_t)n * 4 * CP + r] = v;
+    return;
+  }
+  x -= 4 * CP * NALL;
+  if (x < NALL) {
+    float v = 0.f;
+    if (x < NCH) {
+      int k, chk;
+      chan_to_kernel(x, k, chk);
+      v = a.fbias[k - 1][chk];
+    }
+    a.ball[x] = v;
+  }
+}
+
+// relu + max over the C - k + 1 valid window starts; thread = (word, channel)
+__global__ __launch_bounds__(256) void char_pool_kernel(EmbedArgs a, int nrows) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= nrows * NCH) return;
+  const int row = gid / NCH, ch = gid - row * NCH;
+  int k, chk;
+  chan_to_kernel(ch, k, chk);
+  const float* y = a.yall + (size_t)row * a.C * NALL + ch;
+  float best = 0.f;                              // relu floor: max_p relu(o_p) = max(0, max_p o_p)
+  int arg = -1;
+  for (int p = 0; p + k <= a.C; ++p) {
+    const float v = y[(size_t)p * NALL];
+    if (v > best) { best = v; arg = p; }
+  }
+  a.cat[(size_t)row * a.ldcat + a.word_dim + ch] = best;
+  a.char_arg[(size_t)row * NCH + ch] = arg;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward 1: dYall (in place of Yall): channel gradient at the arg-max start row, zero elsewhere;
+//             the unk row gradient; zero the packed filter-gradient scratch.
+__global__ __launch_bounds__(256) void char_pool_bwd_kernel(EmbedArgs a, EmbedGrads gr, DropCfg drop, int nrows, int CP,
+                                                            int ntask_pool) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int C = a.C, wd = a.word_dim;
+  if (gid < ntask_pool) {            // (word, column of dYall)
+    const int row = gid / NALL, col = gid - row * NALL;
+    int arg = -1;
+    float g = 0.f;
+    if (col < NCH) {
+      arg = a.char_arg[(size_t)row * NCH + col];
+      if (arg >= 0) g = gr.dcat[(size_t)row * gr.lddcat + wd + col];
+    }
+    float* y = a.yall + (size_t)row * C * NALL + col;
+    for (int p = 0; p < C; ++p) y[(size_t)p * NALL] = p == arg ? g : 0.f;
+    return;
+  }
+  int x = gid - ntask_pool;
+  const int ngw = wd >> 2;
+  if (x < nrows * ngw) {             // unk row: d unk += dropout'(dcat[:, :wd]) over the words that ARE unk
+    const int row = x / ngw, c4 = x - row * ngw;
+    if (a.word_ids[row] == 1) {
+      float4 g = ld4(gr.dcat + (size_t)row * gr.lddcat + 4 * c4);
+      if (drop.enabled) g = apply_drop4(drop, HUAL_SITE_WORD, (uint32_t)row, (uint32_t)c4, g);
+      atomicAdd(gr.dunk + 4 * c4, g.x); atomicAdd(gr.dunk + 4 * c4 + 1, g.y);
+      atomicAdd(gr.dunk + 4 * c4 + 2, g.z); atomicAdd(gr.dunk + 4 * c4 + 3, g.w);
+    }
+    return;
+  }
+  x -= nrows * ngw;
+  if (x < 4 * CP * NALL + NALL) a.dfall[x] = 0.f;
+}
+
+// backward 2: fold the window gradients back to char slots:  d cemb[r][d] = sum_dk dXall[r - dk][dk*CP + d]  (same
+// word only), through the dropout mask, accumulated per char id.  Block = 64 slot rows, LDS accumulator per table row.
+#define EF_ROWS 64
+__global__ __launch_bounds__(256) void embed_finish_kernel(EmbedArgs a, EmbedGrads gr, DropCfg drop, int nrows, int CP) {
+  extern __shared__ float dT[];      // [(num_chars-1) * cd]
+  const int cd = a.char_dim, C = a.C;
+  const int ntab = (a.num_chars - 1) * cd;
+  for (int i = threadIdx.x; i < ntab; i += 256) dT[i] = 0.f;
+  __syncthreads();
+  const int ngc = (cd + 3) >> 2;
+  const int M = nrows * C;
+  const int r0 = blockIdx.x * EF_ROWS;
+  for (int t = threadIdx.x; t < EF_ROWS * ngc; t += 256) {
+    const int r = r0 + t / ngc, g4 = t % ngc;
+    if (r >= M) break;
+    const int cid = a.char_ids[r];
+    if (cid <= 0) continue;
+    const int c = r % C;
+    float4 s = f4zero();
+    for (int dk = 0; dk < 4 && dk <= c; ++dk) {
+      const float4 v = ld4(a.dxall + (size_t)(r - dk) * 4 * CP + dk * CP + 4 * g4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (drop.enabled) s = apply_drop4(drop, HUAL_SITE_CHAR, (uint32_t)r, (uint32_t)g4, s);
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (4 * g4 + q < cd) atomicAdd(&dT[(size_t)(cid - 1) * cd + 4 * g4 + q], sv[q]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ntab; i += 256) {
+    const float v = dT[i];
+    if (v != 0.f) atomicAdd(gr.dchar_table + i, v);
+  }
+}
+
+// backward 3 (after the weight-gradient launch): packed dFall / dball -> filter and bias gradients
+__global__ __launch_bounds__(256) void embed_unpack_kernel(EmbedArgs a, EmbedGrads gr, int CP) {
+  const int cd = a.char_dim;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int nfil = cd * (10 + 40 + 90 + 160);
+  if (gid < nfil) {
+    const int foff[4] = {0, cd * 10, cd * 10 + 2 * cd * 20, cd * 10 + 2 * cd * 20 + 3 * cd * 30};
+    const int k = gid < foff[1] ? 1 : (gid < foff[2] ? 2 : (gid < foff[3] ? 3 : 4));
+    const int rel = gid - foff[k - 1];             // (dk*cd + d) * 10k + n
+    const int n = rel % (10 * k), tap = rel / (10 * k);
+    const int dk = tap / cd, d = tap - dk * cd;
+    gr.dfilt[k - 1][rel] += a.dfall[(size_t)(dk * CP + d) * NALL + bank_off(k) + n];
+  } else if (gid < nfil + NCH) {
+    const int ch = gid - nfil;
+    int k, chk;
+    chan_to_kernel(ch, k, chk);
+    gr.dfbias[k - 1][chk] += a.dfall[(size_t)4 * CP * NALL + ch];
   }
 }
 
 namespace hual {
 
-int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStream_t s) {
+static int check_args(const EmbedArgs& a) {
   HUAL_REQUIRE(a.C >= 4, "char_ids need at least 4 chars per word (conv width 4, VALID) - modules.py:33");
-  int grid = cdiv(nrows, 2);
-  grid = grid < 1024 ? grid : 1024;
-  HUAL_LAUNCH(0.0, 0.0, embed_fwd_kernel, dim3(grid), dim3(256), (size_t)2 * a.C * a.char_dim * sizeof(float), s, a, drop, nrows);
+  HUAL_REQUIRE((a.word_dim % 4) == 0 && a.char_dim >= 1, "embed: word_dim must be a multiple of 4");
+  HUAL_REQUIRE(a.cemb && a.wall && a.wallt && a.ball && a.yall && a.dxall && a.dfall, "embed: null scratch");
+  return 0;
+}
+
+int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStream_t s) {
+  int rc = check_args(a);
+  if (rc) return rc;
+  const int CP = cpad(a.char_dim);
+  const int per_word = a.word_dim / 4 + a.C * (CP / 4);
+  const int ntask_words = nrows * per_word;
+  const int ntail = 4 * CP + 4 * CP * NALL + NALL;
+  HUAL_LAUNCH(0.0, 0.0, embed_gather_kernel, dim3(cdiv(ntask_words + ntail, 256)), dim3(256), 0, s, a, drop, nrows, CP,
+              ntask_words);
+  HUAL_CHECK_HIP(hipGetLastError());
+  GemmJob g;
+  gemm_job_init(g);
+  g.npieces = 1;
+  g.A[0] = a.cemb; g.lda[0] = CP; g.kw[0] = 4 * CP;          // overlapping rows: window r = slot rows r .. r+3
+  g.W[0] = a.wall; g.ldw = NALL; g.bias = a.ball;
+  g.M = nrows * a.C; g.N = NALL; g.Y = a.yall; g.ldy = NALL;
+  rc = launch_gemm(&g, 1, drop, s);
+  if (rc) return rc;
+  HUAL_LAUNCH(0.0, 0.0, char_pool_kernel, dim3(cdiv(nrows * NCH, 256)), dim3(256), 0, s, a, nrows);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-#define EMBED_WPB 5                      // words per block of the backward kernel
-int embed_bwd_blocks(int nrows) { return cdiv(nrows, EMBED_WPB); }
-size_t embed_bwd_partial_floats(int nrows, int word_dim, int char_dim, int num_chars) {
-  const size_t nacc = (size_t)char_dim * 300 + NCH + (size_t)(num_chars - 1) * char_dim + word_dim;
-  return nacc * embed_bwd_blocks(nrows);
+int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const DropCfg& drop, hipStream_t s, DwJob* dwjob) {
+  int rc = check_args(a);
+  if (rc) return rc;
+  HUAL_REQUIRE(dwjob != nullptr, "embed_bwd: null weight-gradient job");
+  const int cd = a.char_dim, CP = cpad(cd), M = nrows * a.C;
+  const int ntask_pool = nrows * NALL;
+  const int ntail = nrows * (a.word_dim / 4) + 4 * CP * NALL + NALL;
+  HUAL_LAUNCH(0.0, 0.0, char_pool_bwd_kernel, dim3(cdiv(ntask_pool + ntail, 256)), dim3(256), 0, s, a, g, drop, nrows, CP,
+              ntask_pool);
+  HUAL_CHECK_HIP(hipGetLastError());
+  // d filters / d bias: one more job for the step's weight-gradient launch
+  embed_dw_job(a, nrows, dwjob);
+  // d windows = dYall . Wall^T
+  GemmJob j;
+  gemm_job_init(j);
+  j.npieces = 1;
+  j.A[0] = a.yall; j.lda[0] = NALL; j.kw[0] = NALL; j.W[0] = a.wallt; j.ldw = 4 * CP;
+  j.M = M; j.N = 4 * CP; j.Y = a.dxall; j.ldy = 4 * CP;
+  rc = launch_gemm(&j, 1, drop, s);
+  if (rc) return rc;
+  const size_t lds = (size_t)(a.num_chars - 1) * cd * sizeof(float);
+  HUAL_REQUIRE(lds <= 64 * 1024, "embed_bwd: char table too large for the LDS accumulator");
+  HUAL_LAUNCH(0.0, 0.0, embed_finish_kernel, dim3(cdiv(M, EF_ROWS)), dim3(256), lds, s, a, g, drop, nrows, CP);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
-int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const DropCfg& drop, hipStream_t s) {
+void embed_dw_job(const EmbedArgs& a, int nrows, DwJob* dwjob) {
+  const int CP = cpad(a.char_dim);
+  dw_job_init(*dwjob);
+  dwjob->npieces = 1;
+  dwjob->A[0] = a.cemb; dwjob->lda[0] = CP; dwjob->kw[0] = 4 * CP; dwjob->dW[0] = a.dfall; dwjob->ldw = NALL;
+  dwjob->dY = a.yall; dwjob->ldy = NALL; dwjob->M = nrows * a.C; dwjob->N = NALL;
+  dwjob->db = a.dfall + (size_t)4 * CP * NALL;
+}
+
+int launch_embed_unpack(const EmbedArgs& a, const EmbedGrads& g, hipStream_t s) {
   const int cd = a.char_dim;
-  const int nfil = cd * (10 + 40 + 90 + 160);
-  const size_t bytes = ((size_t)2 * a.C * cd + nfil + 3 * NCH + (size_t)(a.num_chars - 1) * cd + a.word_dim) * sizeof(float);
-  HUAL_REQUIRE(bytes <= 160 * 1024, "embed_bwd: char filter gradients do not fit LDS");
-  static bool attr = false;
-  if (!attr) {
-    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)embed_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
-  HUAL_REQUIRE(g.partial != nullptr, "embed_bwd: null partial-sum scratch");
-  const int grid = embed_bwd_blocks(nrows);
-  HUAL_LAUNCH(0.0, 0.0, embed_bwd_kernel, dim3(grid), dim3(256), bytes, s, a, g, drop, nrows, EMBED_WPB);
-  const int nacc = nfil + NCH + (a.num_chars - 1) * cd + a.word_dim;
-  HUAL_LAUNCH(0.0, 0.0, embed_reduce_kernel, dim3(cdiv(nacc, 64)), dim3(256), 0, s, a, g, grid);
+  const int n = cd * 300 + NCH;
+  HUAL_LAUNCH(0.0, 0.0, embed_unpack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, g, cpad(cd));
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -17,6 +17,7 @@
 #include "philox.h"
 #include "prof.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 namespace hual {
@@ -847,6 +848,8 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
     if (!attr) {
       const void* fns[] = {(const void*)gemm_lds_kernel<true, 2>,     (const void*)gemm_lds_kernel<false, 2>,
                            (const void*)gemm_lds_kernel<true, 3>,     (const void*)gemm_lds_kernel<false, 3>,
+                           (const void*)gemm_lds_kernel<true, 4>,     (const void*)gemm_lds_kernel<false, 4>,
+                           (const void*)gemm_lds_kernel<true, 6>,     (const void*)gemm_lds_kernel<false, 6>,
                            (const void*)gemm_lds_px_kernel<true, 2>,  (const void*)gemm_lds_px_kernel<false, 2>,
                            (const void*)gemm_lds_px_kernel<true, 3>,  (const void*)gemm_lds_px_kernel<false, 3>};
       for (const void* f : fns) HUAL_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -856,19 +859,30 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
     const int ncol = cdiv(maxN, 128);
     int rt = (cdiv(maxM, 32) * ncol * n > 256 && maxM > 48) ? 3 : 2;
     if (rt_env == 2 || rt_env == 3) rt = rt_env;
+    // launches with many blocks per CU (several jobs / column blocks): bigger blocks share one weight panel among more
+    // row tiles (HUAL_GEMM_RTBIG = 4 or 6; experiment)
+    static const int rt_big = []() { const char* e = getenv("HUAL_GEMM_RTBIG"); return e ? atoi(e) : 0; }();
+    static const int big_min = []() { const char* e = getenv("HUAL_GEMM_BIGMIN"); return e ? atoi(e) : 512; }();
+    if (!extras && (rt_big == 4 || rt_big == 6) && cdiv(maxM, 48) * ncol * n >= big_min) rt = rt_big;
     const dim3 g(cdiv(maxM, 16 * rt), ncol, n), blk(128 * rt);
 #define HUAL_LAUNCH_LDS(KERN)                                                                      \
   do {                                                                                             \
     if (rt == 3) {                                                                                 \
-      if (dual) HUAL_LAUNCH(flops, bytes, (KERN<true, 3>), g, blk, lds, stream, b, drop);                 \
-      else HUAL_LAUNCH(flops, bytes, (KERN<false, 3>), g, blk, lds, stream, b, drop);                     \
+      if (dual) HUAL_LAUNCH(flops, bytes, (KERN<true, 3>), g, blk, lds, stream, b, drop);          \
+      else HUAL_LAUNCH(flops, bytes, (KERN<false, 3>), g, blk, lds, stream, b, drop);              \
     } else {                                                                                       \
-      if (dual) HUAL_LAUNCH(flops, bytes, (KERN<true, 2>), g, blk, lds, stream, b, drop);                 \
-      else HUAL_LAUNCH(flops, bytes, (KERN<false, 2>), g, blk, lds, stream, b, drop);                     \
+      if (dual) HUAL_LAUNCH(flops, bytes, (KERN<true, 2>), g, blk, lds, stream, b, drop);          \
+      else HUAL_LAUNCH(flops, bytes, (KERN<false, 2>), g, blk, lds, stream, b, drop);              \
     }                                                                                              \
   } while (0)
     if (extras) HUAL_LAUNCH_LDS(gemm_lds_px_kernel);
-    else HUAL_LAUNCH_LDS(gemm_lds_kernel);
+    else if (rt == 4) {
+      if (dual) HUAL_LAUNCH(flops, bytes, (gemm_lds_kernel<true, 4>), g, blk, lds, stream, b, drop);
+      else HUAL_LAUNCH(flops, bytes, (gemm_lds_kernel<false, 4>), g, blk, lds, stream, b, drop);
+    } else if (rt == 6) {
+      if (dual) HUAL_LAUNCH(flops, bytes, (gemm_lds_kernel<true, 6>), g, blk, lds, stream, b, drop);
+      else HUAL_LAUNCH(flops, bytes, (gemm_lds_kernel<false, 6>), g, blk, lds, stream, b, drop);
+    } else HUAL_LAUNCH_LDS(gemm_lds_kernel);
 #undef HUAL_LAUNCH_LDS
   }
   HUAL_CHECK_HIP(hipGetLastError());
@@ -894,7 +908,31 @@ static int dw_check(const DwJob& j, int& kbs, double& flops, double& bytes) {
 
 // `table`: optional device buffer of n DwJob entries.  With it ALL jobs run as ONE launch (the descriptors are first
 // written to the table by tiny kernels that carry them by value); without it jobs go HUAL_MAX_DW_JOBS per launch.
+// rows_per_block = 0: pick the split of M that minimises (rounds of co-resident blocks) x (block length).  Every block
+// of the launch runs about equally long (rows + a fixed prologue / atomics epilogue) and 2 blocks fit a CU, so the launch
+// time is quantised in rounds of 512 blocks; a fixed split can sit just past a round boundary (measured: 389 us at
+// 512 rows, 311 us at 384 rows for the same 62 jobs).
+static int dw_auto_rows(const DwJob* jobs, int n) {
+  static const int dbg = []() { const char* e = getenv("HUAL_DEBUG_DW"); return e ? atoi(e) : 0; }();
+  int best = 512;
+  double best_cost = 1e30;
+  for (int r = 192; r <= 1024; r += 32) {
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+      int kbs = 0;
+      for (int p = 0; p < jobs[i].npieces; ++p) kbs += (jobs[i].kw[p] + 127) / 128;
+      blocks += (long)kbs * cdiv(jobs[i].M, r);
+    }
+    const long rounds = (blocks + 511) / 512;
+    const double cost = (double)rounds * (r + 64.0);
+    if (dbg) fprintf(stderr, "[dw] rows %4d blocks %5ld rounds %2ld cost %.0f\n", r, blocks, rounds, cost);
+    if (cost < best_cost) { best_cost = cost; best = r; }
+  }
+  return best;
+}
+
 int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block, hipStream_t stream, DwJob* table) {
+  if (rows_per_block == 0) rows_per_block = dw_auto_rows(jobs, n);
   HUAL_REQUIRE(rows_per_block >= DW_TM && (rows_per_block % DW_TM) == 0, "launch_dw: rows_per_block must be a multiple of 32");
   static bool attr = false;
   if (!attr) {

@@ -171,6 +171,11 @@ void ln_into_jobs(Ctx& c, GemmJob* j, int njobs, const float* x, int M, const Ro
   c.ln_fwd(a, rs);
   for (int k = 0; k < njobs; ++k) j[k].A[0] = y;
 }
+void set_embed_scratch(EmbedArgs& ea, float* base, int Nq, int C, int char_dim) {
+  const EmbedLayout el = embed_layout(Nq, C, char_dim);
+  ea.cemb = base + el.cemb; ea.wall = base + el.wall; ea.wallt = base + el.wallt; ea.ball = base + el.ball;
+  ea.yall = base + el.yall; ea.dxall = base + el.dxall; ea.dfall = base + el.dfall;
+}
 // keep-byte buffer of an attention job's probability dropout (attn.h): B*Tq*8 rows of ldm bytes
 // + the softmax statistics the forward leaves for the backward
 void set_dmask(Ctx& c, AttnJob& a, const std::string& name) {
@@ -214,6 +219,8 @@ void flush_dw(Ctx& c, bool last = false) {
   if (!last && !early) return;
   const size_t n = c.dwjobs.size() - c.dw_flushed;
   if (n == 0) return;
+  // blocks are dispatched in job order: long-row jobs first, so that the launch ends on the short ones (tail)
+  std::stable_sort(c.dwjobs.begin() + c.dw_flushed, c.dwjobs.end(), [](const DwJob& a, const DwJob& b) { return a.M > b.M; });
   DwJob* table = reinterpret_cast<DwJob*>(c.buf("dw.table." + std::to_string(c.dw_flushes), n, (sizeof(DwJob) + 3) / 4));
   if (!c.dry && c.ok()) {
     hipStream_t s = c.stream;
@@ -222,7 +229,8 @@ void flush_dw(Ctx& c, bool last = false) {
       hipEventRecord((hipEvent_t)c.aux->ev_fork, c.stream);
       hipStreamWaitEvent(s, (hipEvent_t)c.aux->ev_fork, 0);
     }
-    c.chk(launch_dw(c.dwjobs.data() + c.dw_flushed, (int)n, c.drop, 512, s, table));
+    static const int rows = []() { const char* e = getenv("HUAL_DW_ROWS"); return e ? atoi(e) : 0; }();      // 0 = automatic split
+    c.chk(launch_dw(c.dwjobs.data() + c.dw_flushed, (int)n, c.drop, rows, s, table));
   }
   c.dw_flushed = c.dwjobs.size();
   c.dw_flushes++;
@@ -347,12 +355,14 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
   float* cat = c.buf("cat", Nq, catw);
   int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
+  float* embed_scratch = c.buf("embed.scratch", embed_layout(Nq, c.C, c.cfg->char_dim).total, 1);
   EmbedArgs ea{};
   if (!c.dry) {
     ea.word_ids = bt->word_ids; ea.char_ids = bt->char_ids; ea.word_table = c.word_table; ea.unk = c.p(pm.unk);
     ea.char_table = c.p(pm.char_table);
     for (int i = 0; i < 4; ++i) { ea.filt[i] = c.p(pm.filt[i]); ea.fbias[i] = c.p(pm.fbias[i]); }
     ea.cat = cat; ea.ldcat = catw; ea.char_arg = char_arg;
+    set_embed_scratch(ea, embed_scratch, Nq, c.C, c.cfg->char_dim);
     ea.word_dim = c.cfg->word_dim; ea.char_dim = c.cfg->char_dim; ea.C = c.C; ea.num_chars = c.cfg->num_chars;
     if (c.ok()) c.chk(launch_embed_fwd(ea, Nq, c.drop, c.stream));
   }
@@ -1112,24 +1122,29 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     GemmJob j = mkjob_dx(d_lin + (size_t)Nv * D, D, Nq, D, c.pt(pm.qconv.k), catw, d_cat, catw, catw);
     c.gemm(&j, 1);
   }
-  c.flush_colsum();       // layer-norm / depthwise-conv parameter gradients: one reduction of the per-block partial sums
-  flush_dw(c, true);      // the weight-gradient launch (aux stream) overlaps the embedding backward below
+  // ---------------- text encoder front end (embed.hip); its filter gradients ride in the weight-gradient launch
   int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
-  float* embed_partial = c.buf("d.embed.partial", embed_bwd_partial_floats(Nq, c.cfg->word_dim, c.cfg->char_dim, c.cfg->num_chars), 1);
+  float* embed_scratch = c.buf("embed.scratch", embed_layout(Nq, c.C, c.cfg->char_dim).total, 1);
+  EmbedArgs ea{};
+  EmbedGrads eg{};
+  set_embed_scratch(ea, embed_scratch, Nq, c.C, c.cfg->char_dim);
+  ea.word_dim = c.cfg->word_dim; ea.char_dim = c.cfg->char_dim; ea.C = c.C; ea.num_chars = c.cfg->num_chars;
+  DwJob embed_dw;
+  embed_dw_job(ea, Nq, &embed_dw);
   if (!c.dry && c.ok()) {
-    EmbedArgs ea{};
     ea.word_ids = bt->word_ids; ea.char_ids = bt->char_ids; ea.word_table = c.word_table; ea.unk = c.p(pm.unk);
     ea.char_table = c.p(pm.char_table);
     for (int i = 0; i < 4; ++i) { ea.filt[i] = c.p(pm.filt[i]); ea.fbias[i] = c.p(pm.fbias[i]); }
     ea.cat = cat; ea.ldcat = catw; ea.char_arg = char_arg;
-    ea.word_dim = c.cfg->word_dim; ea.char_dim = c.cfg->char_dim; ea.C = c.C; ea.num_chars = c.cfg->num_chars;
-    EmbedGrads eg{};
     eg.dcat = d_cat; eg.lddcat = catw; eg.dunk = c.g(pm.unk); eg.dchar_table = c.g(pm.char_table);
     for (int i = 0; i < 4; ++i) { eg.dfilt[i] = c.g(pm.filt[i]); eg.dfbias[i] = c.g(pm.fbias[i]); }
-    eg.partial = embed_partial;
-    c.chk(launch_embed_bwd(ea, eg, Nq, c.drop, c.stream));
+    c.chk(launch_embed_bwd(ea, eg, Nq, c.drop, c.stream, &embed_dw));
   }
+  c.dwjobs.push_back(embed_dw);
+  c.flush_colsum();       // layer-norm / depthwise-conv parameter gradients: one reduction of the per-block partial sums
+  flush_dw(c, true);      // every dense / conv weight gradient of the step: one launch
   join_aux(c);
+  if (!c.dry && c.ok()) c.chk(launch_embed_unpack(ea, eg, c.stream));
   (void)opt;
   return c.rc;
 }
