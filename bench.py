@@ -94,6 +94,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--aux', action='store_true', help='second stream for the weight-gradient launches (experiment)')
     ap.add_argument('--prewarm', type=int, default=400, help='untimed steps before the warm-up steps (clock ramp)')
     args = ap.parse_args()
 
@@ -116,7 +117,7 @@ def main():
     wv = np.random.default_rng(777).normal(0, 0.4, size=(num_words - 2, 300)).astype(np.float32)
     model = SeqPAN(cfg, wv, device=dev, seed=12345, rng_seed=12345 + rank)
     b = synth_batch(args.batch, args.T, args.L, args.C, args.vdim, num_words, num_chars, 12345 + rank)
-    trainer = Trainer(model, world=world, use_graph=not args.no_graph)
+    trainer = Trainer(model, world=world, use_graph=not args.no_graph, use_aux=args.aux)
     trainer.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'])
 
     def barrier():

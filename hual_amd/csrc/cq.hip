@@ -1,6 +1,7 @@
 // Context-query attention kernels (see cq.h).  All small matrix products of one clip run on
 // v_mfma_f32_16x16x4_f32 through one device helper (tile_mma) whose operands may sit in LDS or global memory,
 // K-contiguous (float4 fragment loads) or K-strided (4 scalar loads) - same fragment maps as gemm.hip/attn.hip.
+#include <stdlib.h>
 #include "cq.h"
 #include "philox.h"
 #include "prof.h"
@@ -47,6 +48,10 @@ __device__ __forceinline__ f32x4 tile_mma(const float* A, int lda, int imax, con
   return acc;
 }
 
+// per-clip kernels: one block = one (clip, direction); 16 waves share the tiles / rows of every phase
+#define CQ_MAX_THREADS 1024
+#define CQ_THREADS ((int)blockDim.x)
+#define CQ_WAVES ((int)blockDim.x >> 6)
 struct ClipGeom {
   int N1, N2, N1p, N2p, ld, x1base, x2base;
 };
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void tri_prep_kernel(CqBufs b, CqParams p, Row
 }
 
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cq_fwd_kernel(CqBufs b, RowSpace rs) {
+__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpace rs) {
   extern __shared__ float lds[];
   const int clip = blockIdx.x, dir = blockIdx.y;
   const ClipGeom c = clip_geom(rs, clip, dir);
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void cq_fwd_kernel(CqBufs b, RowSpace rs) {
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   // ---- score = d1w . d2^T + s0 + s1
   const int nj = c.N2p >> 4, ni = c.N1p >> 4;
-  for (int tile = wave; tile < ni * nj; tile += 4) {
+  for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
     f32x4 acc = tile_mma<true, true>(b.D1W + (size_t)c.x1base * HUAL_D, HUAL_D, c.N1, b.D2 + (size_t)c.x2base * HUAL_D,
                                      HUAL_D, c.N2, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void cq_fwd_kernel(CqBufs b, RowSpace rs) {
   }
   __syncthreads();
   // ---- row softmax over j with mask2 (layers.py:122-123) ; zero outside the valid block
-  for (int i = wave; i < c.N1p; i += 4) {
+  for (int i = wave; i < c.N1p; i += CQ_WAVES) {
     float mx = -INFINITY;
     if (i < c.N1)
       for (int jj = lane; jj < c.N2; jj += 64) {
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void cq_fwd_kernel(CqBufs b, RowSpace rs) {
     }
   }
   // ---- column softmax over i with mask1 (layers.py:124-125)
-  for (int jj = wave; jj < c.N2p; jj += 4) {
+  for (int jj = wave; jj < c.N2p; jj += CQ_WAVES) {
     float mx = -INFINITY;
     if (jj < c.N2)
       for (int i = lane; i < c.N1; i += 64) {
@@ -183,10 +188,10 @@ __global__ __launch_bounds__(256) void cq_fwd_kernel(CqBufs b, RowSpace rs) {
   const size_t mat = cq_mat_elems(rs.T, rs.L);
   float* gSr = b.SR + ((size_t)dir * rs.B + clip) * mat;
   float* gSc = b.SC + ((size_t)dir * rs.B + clip) * mat;
-  for (int idx = threadIdx.x; idx < msz; idx += 256) { gSr[idx] = Sr[idx]; gSc[idx] = Sc[idx]; }
+  for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { gSr[idx] = Sr[idx]; gSc[idx] = Sc[idx]; }
   // ---- c2q = Sr . x2   and   M2 = Sc^T . x1
   float* M2 = b.M2 + ((size_t)dir * rs.B + clip) * cq_m2_rows(rs.T, rs.L) * HUAL_D;
-  for (int tile = wave; tile < ni * 8; tile += 4) {
+  for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
     f32x4 acc = tile_mma<true, false>(Sr, c.ld, c.N1p, X2, HUAL_D, HUAL_D, c.N2p, c.N2p, c.N2, i0, n0, j, g, zero);
 #pragma unroll
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void cq_fwd_kernel(CqBufs b, RowSpace rs) {
       if (i < c.N1) b.C2Q[(size_t)(c.x1base + i) * HUAL_D + n0 + j] = acc[r];
     }
   }
-  for (int tile = wave; tile < nj * 8; tile += 4) {
+  for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;   // rows of M2 = index j of the score
     f32x4 acc = tile_mma<false, false>(Sc, c.ld, c.N2p, X1, HUAL_D, HUAL_D, c.N1p, c.N1p, c.N1, i0, n0, j, g, zero);
 #pragma unroll
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void cq_fwd_kernel(CqBufs b, RowSpace rs) {
   }
   __syncthreads();
   // ---- q2c = Sr . M2          (= (Sr.Sc^T).x1 of layers.py:127, re-associated)
-  for (int tile = wave; tile < ni * 8; tile += 4) {
+  for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
     f32x4 acc = tile_mma<true, false>(Sr, c.ld, c.N1p, M2, HUAL_D, HUAL_D, c.N2p, c.N2p, c.N2p, i0, n0, j, g, zero);
 #pragma unroll
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void cq_bwd_pre_kernel(CqBufs b, CqBwdBufs gb,
 //   dXa (x1-role rows, via M2)  is ADDED into gb.dX rows of x1;  dXb (x2-role rows, via c2q) goes to dD2's
 //   companion buffer - to stay race free between the two directions of a clip it is folded into dD2 itself is
 //   not possible (different dropout), so it is written to gb.dC2Q rows?  -> see below: uses dedicated slices.
-__global__ __launch_bounds__(256) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb) {
+__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb) {
   extern __shared__ float lds[];
   const int clip = blockIdx.x, dir = blockIdx.y;
   const ClipGeom c = clip_geom(rs, clip, dir);
@@ -260,10 +265,10 @@ __global__ __launch_bounds__(256) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, Row
   float* dM2 = gb.dM2 + m2off;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const int nj = c.N2p >> 4, ni = c.N1p >> 4;
-  for (int idx = threadIdx.x; idx < msz; idx += 256) { Sr[idx] = gSr[idx]; Sc[idx] = gSc[idx]; dSr[idx] = 0.f; dSc[idx] = 0.f; }
+  for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { Sr[idx] = gSr[idx]; Sc[idx] = gSc[idx]; dSr[idx] = 0.f; dSc[idx] = 0.f; }
   __syncthreads();
   // dSr = dc2q . x2^T + dq2c . M2^T
-  for (int tile = wave; tile < ni * nj; tile += 4) {
+  for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
     f32x4 acc = tile_mma<true, true>(dC2Q, HUAL_D, c.N1, X2, HUAL_D, c.N2, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
     acc = tile_mma<true, true>(dQ2C, HUAL_D, c.N1, M2, HUAL_D, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, acc);
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, Row
     for (int r = 0; r < 4; ++r) dSr[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
   }
   // dM2 = Sr^T . dq2c ;  dXb (x2 rows) = Sr^T . dc2q
-  for (int tile = wave; tile < nj * 8; tile += 4) {
+  for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
     f32x4 acc = tile_mma<false, false>(Sr, c.ld, c.N2p, dQ2C, HUAL_D, HUAL_D, c.N1p, c.N1p, c.N1, i0, n0, j, g, zero);
     f32x4 acc2 = tile_mma<false, false>(Sr, c.ld, c.N2p, dC2Q, HUAL_D, HUAL_D, c.N1p, c.N1p, c.N1, i0, n0, j, g, zero);
@@ -284,13 +289,13 @@ __global__ __launch_bounds__(256) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, Row
   }
   __syncthreads();
   // dSc = x1 . dM2^T ;  dXa (x1 rows) = Sc . dM2
-  for (int tile = wave; tile < ni * nj; tile += 4) {
+  for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
     f32x4 acc = tile_mma<true, true>(X1, HUAL_D, c.N1, dM2, HUAL_D, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) dSc[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
   }
-  for (int tile = wave; tile < ni * 8; tile += 4) {
+  for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
     f32x4 acc = tile_mma<true, false>(Sc, c.ld, c.N1p, dM2, HUAL_D, HUAL_D, c.N2p, c.N2p, c.N2p, i0, n0, j, g, zero);
 #pragma unroll
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, Row
   }
   __syncthreads();
   // softmax backward -> dscore (in dSr).  mask_logits is multiplicative, so its derivative is the mask.
-  for (int i = wave; i < c.N1; i += 4) {
+  for (int i = wave; i < c.N1; i += CQ_WAVES) {
     float dot = 0.f;
     for (int jj = lane; jj < c.N2; jj += 64) dot += Sr[i * c.ld + jj] * dSr[i * c.ld + jj];
     dot = wave_sum64(dot);
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, Row
       dSr[i * c.ld + jj] = Sr[i * c.ld + jj] * (dSr[i * c.ld + jj] - dot) * m2[jj];
   }
   __syncthreads();
-  for (int jj = wave; jj < c.N2; jj += 4) {
+  for (int jj = wave; jj < c.N2; jj += CQ_WAVES) {
     float dot = 0.f;
     for (int i = lane; i < c.N1; i += 64) dot += Sc[i * c.ld + jj] * dSc[i * c.ld + jj];
     dot = wave_sum64(dot);
@@ -323,14 +328,14 @@ __global__ __launch_bounds__(256) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, Row
     if (lane == 0) gb.dS1[c.x2base + jj] = colsum;
   }
   __syncthreads();
-  for (int i = wave; i < c.N1; i += 4) {
+  for (int i = wave; i < c.N1; i += CQ_WAVES) {
     float rowsum = 0.f;
     for (int jj = lane; jj < c.N2; jj += 64) rowsum += dSr[i * c.ld + jj];
     rowsum = wave_sum64(rowsum);
     if (lane == 0) gb.dS0[c.x1base + i] = rowsum;
   }
   // dD1W = dscore . d2 ;  dD2 = dscore^T . d1w
-  for (int tile = wave; tile < ni * 8; tile += 4) {
+  for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
     f32x4 acc = tile_mma<true, false>(dSr, c.ld, c.N1p, b.D2 + (size_t)c.x2base * HUAL_D, HUAL_D, HUAL_D, c.N2p, c.N2p, c.N2,
                                       i0, n0, j, g, zero);
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, Row
       if (i < c.N1) gb.dD1W[(size_t)(c.x1base + i) * HUAL_D + n0 + j] = acc[r];
     }
   }
-  for (int tile = wave; tile < nj * 8; tile += 4) {
+  for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
     f32x4 acc = tile_mma<false, false>(dSr, c.ld, c.N2p, b.D1W + (size_t)c.x1base * HUAL_D, HUAL_D, HUAL_D, c.N1p,
                                        c.N1p, c.N1, i0, n0, j, g, zero);
@@ -403,6 +408,10 @@ __global__ __launch_bounds__(256) void tri_bwd_kernel(CqBufs b, CqBwdBufs gb, Cq
 
 namespace hual {
 
+static int cq_threads() {
+  static const int t = []() { const char* e = getenv("HUAL_CQ_THREADS"); int v = e ? atoi(e) : 1024; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
+  return t;
+}
 static int cq_lds_bytes(const RowSpace& rs, int nmats) { return (int)(cq_mat_elems(rs.T, rs.L) * nmats * sizeof(float)); }
 
 int launch_tri_prep(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
@@ -421,7 +430,7 @@ int launch_cq_fwd(const CqBufs& b, const RowSpace& rs, hipStream_t s) {
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)cq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_kernel, dim3(rs.B, 2), dim3(256), bytes, s, b, rs);
+  HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_kernel, dim3(rs.B, 2), dim3(cq_threads()), bytes, s, b, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -443,7 +452,7 @@ int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, 
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)cq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_kernel, dim3(rs.B, 2), dim3(256), bytes, s, b, g, rs, dXa, dXb);
+  HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_kernel, dim3(rs.B, 2), dim3(cq_threads()), bytes, s, b, g, rs, dXa, dXb);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

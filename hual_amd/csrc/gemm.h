@@ -88,7 +88,9 @@ void dw_job_init(DwJob& j);
 // enqueue `n` jobs (n <= HUAL_MAX_JOBS) as ONE launch on `stream`
 int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
 // enqueue `n` gradient jobs (any n; split into launches of HUAL_MAX_DW_JOBS); rows_per_block tunes split-M
+// table != null: jobs are read from that device-resident table (any job count, one launch); write_table = false skips
+// filling it (the caller vouches that it still holds exactly these jobs)
 int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block, hipStream_t stream,
-              DwJob* table = nullptr);   // table: device buffer of n entries -> all jobs in ONE launch
+              DwJob* table = nullptr, bool write_table = true);   // table: device buffer of n entries -> all jobs in ONE launch
 
 }  // namespace hual

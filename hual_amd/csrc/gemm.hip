@@ -923,7 +923,8 @@ static int dw_auto_rows(const DwJob* jobs, int n) {
       for (int p = 0; p < jobs[i].npieces; ++p) kbs += (jobs[i].kw[p] + 127) / 128;
       blocks += (long)kbs * cdiv(jobs[i].M, r);
     }
-    const long rounds = (blocks + 511) / 512;
+    static const int slots = []() { const char* e = getenv("HUAL_DW_SLOTS"); return e ? atoi(e) : 512; }();
+    const long rounds = (blocks + slots - 1) / slots;
     const double cost = (double)rounds * (r + 64.0);
     if (dbg) fprintf(stderr, "[dw] rows %4d blocks %5ld rounds %2ld cost %.0f\n", r, blocks, rounds, cost);
     if (cost < best_cost) { best_cost = cost; best = r; }
@@ -931,7 +932,8 @@ static int dw_auto_rows(const DwJob* jobs, int n) {
   return best;
 }
 
-int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block, hipStream_t stream, DwJob* table) {
+int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block, hipStream_t stream, DwJob* table,
+              bool write_table) {
   if (rows_per_block == 0) rows_per_block = dw_auto_rows(jobs, n);
   HUAL_REQUIRE(rows_per_block >= DW_TM && (rows_per_block % DW_TM) == 0, "launch_dw: rows_per_block must be a multiple of 32");
   static bool attr = false;
@@ -940,7 +942,11 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr = true;
   }
-  const size_t lds = (size_t)4 * DW_TM * DW_LD * sizeof(float);
+  size_t lds = (size_t)4 * DW_TM * DW_LD * sizeof(float);
+  // HUAL_DW_LDS_KB pads the LDS request: above 80 KB only ONE block fits a CU, which leaves room for the blocks of
+  // other kernels when the launch runs on a side stream under the dX chain (experiment)
+  static const int lds_kb = []() { const char* e = getenv("HUAL_DW_LDS_KB"); return e ? atoi(e) : 0; }();
+  if ((size_t)lds_kb * 1024 > lds && lds_kb <= 96) lds = (size_t)lds_kb * 1024;
   if (table != nullptr) {
     int maxM = 0, maxKb = 0;
     double flops = 0.0, bytes = 0.0;
@@ -955,7 +961,7 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
         maxM = jobs[base + i].M > maxM ? jobs[base + i].M : maxM;
         maxKb = kbs > maxKb ? kbs : maxKb;
       }
-      HUAL_LAUNCH(0.0, 0.0, dw_table_write_kernel, dim3(1), dim3(64), 0, stream, b, table, base, cnt);
+      if (write_table) HUAL_LAUNCH(0.0, 0.0, dw_table_write_kernel, dim3(1), dim3(64), 0, stream, b, table, base, cnt);
     }
     DwBatch dummy;
     dw_job_init(dummy.j[0]);

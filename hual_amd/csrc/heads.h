@@ -35,6 +35,7 @@ struct MatchArgs {
   const float* E;         // label_emb [4,128]
   const int32_t* labels;  // [Nv] or null (inference)
   float* probs;           // [Nv,4]  == match_scores
+  float* probs2;          // optional second copy (kept in the workspace for the backward pass)
   float* outputs;         // [Nv,128]
   float* loss_acc;        // accumulators (LA_*), may be null when labels is null
 };
@@ -50,6 +51,8 @@ int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, 
 int launch_match_denominator(float* loss_acc, float override_denom, hipStream_t s);
 // ortho term ||(E E^T) * (1-I)||_F (model.py:88-91): loss_acc[LA_ORTHO] = norm ; dE += lambda * d norm / dE
 int launch_ortho(const float* E, float* dE, float* loss_acc, float lambda, hipStream_t s);
+// forward: ortho term + match denominator + the reported loss terms (loss_out[4], may be null) in one launch
+int launch_loss_tail(const float* E, float* loss_acc, float lambda, float override_denom, float* loss_out, hipStream_t s);
 
 // ---- start/end logit heads: logit = h . w + b  (predictor/{start,end}_dense, modules.py:155-156)
 struct DotArgs {

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void match_fwd_kernel(MatchArgs a, RowSpace rs
     const float mk = rs.rowmask[row];
     if (l32 == 0) {
       *reinterpret_cast<float4*>(a.probs + (size_t)row * 4) = make_float4(p0, p1, p2, p3);
+      if (a.probs2) *reinterpret_cast<float4*>(a.probs2 + (size_t)row * 4) = make_float4(p0, p1, p2, p3);
       if (a.labels) {
         const int lab = a.labels[row];
         const float ll = lab == 0 ? l0 : (lab == 1 ? l1 : (lab == 2 ? l2 : l3));
@@ -230,7 +231,9 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
 }
 
 // ortho: one block of 128 threads
-__global__ __launch_bounds__(128) void ortho_kernel(const float* E, float* dE, float* loss_acc, float lambda) {
+// forward use (tail != 0) also closes the loss: match denominator (layers.py:173) and the four reported loss terms
+__global__ __launch_bounds__(128) void ortho_kernel(const float* E, float* dE, float* loss_acc, float lambda, int tail,
+                                                    float override_denom, float* loss_out) {
   __shared__ float M[16];
   __shared__ float sm[4];
   const int c = threadIdx.x;
@@ -245,7 +248,21 @@ __global__ __launch_bounds__(128) void ortho_kernel(const float* E, float* dE, f
   float ss = 0.f;
   for (int i = 0; i < 16; ++i) ss += M[i] * M[i];
   const float nrm = sqrtf(ss);
-  if (c == 0) loss_acc[LA_ORTHO] = nrm;
+  if (c == 0) {
+    loss_acc[LA_ORTHO] = nrm;
+    if (tail) {
+      const float denom = override_denom > 0.f ? override_denom : loss_acc[LA_MASK_SUM] + 1e-12f;
+      loss_acc[LA_DENOM] = denom;
+      if (loss_out) {
+        const float match = loss_acc[LA_MATCH_SUM] / denom + nrm;             // layers.py:173 + model.py:91
+        const float loc = loss_acc[LA_LOC], align = loss_acc[LA_ALIGN];
+        loss_out[0] = loc + lambda * match + align;                           // model.py:120
+        loss_out[1] = loc;
+        loss_out[2] = match;
+        loss_out[3] = align;
+      }
+    }
+  }
   if (dE && nrm > 0.f) {
     for (int i = 0; i < 4; ++i) {
       float s = 0.f;
@@ -524,7 +541,12 @@ int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, 
   return 0;
 }
 int launch_ortho(const float* E, float* dE, float* loss_acc, float lambda, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, dE, loss_acc, lambda);
+  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, dE, loss_acc, lambda, 0, 0.f, (float*)nullptr);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int launch_loss_tail(const float* E, float* loss_acc, float lambda, float override_denom, float* loss_out, hipStream_t s) {
+  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, (float*)nullptr, loss_acc, lambda, 1, override_denom, loss_out);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

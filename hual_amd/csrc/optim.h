@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+#define HUAL_SQNORM_SLOTS 256
+
 namespace hual {
 
 struct AdamArgs {
@@ -11,8 +13,10 @@ struct AdamArgs {
   const float* lr_dev;    // device scalar: learning rate of this step (fed per step, main.py:61)
   float clip_norm;
   float prescale;         // multiplies the gradient first (1/world after a sum all-reduce)
-  float* sqnorm;          // device scalar scratch: squared global norm of prescale*g
+  float* sqnorm;          // device scratch, HUAL_SQNORM_SLOTS floats: per-block partial sums of |prescale*g|^2
 };
 int launch_adamw(const AdamArgs& a, hipStream_t s);
+// p[0..n) = 0 with a kernel (no memset node inside captured graphs)
+int launch_zero(float* p, size_t n, hipStream_t s);
 
 }  // namespace hual

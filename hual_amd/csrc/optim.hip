@@ -18,14 +18,23 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, size_t n, f
   s = wave_sum64(s);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+  if (threadIdx.x == 0) out[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];     // per-block partial: no zeroing, no atomics
+}
+
+__global__ __launch_bounds__(256) void zero_kernel(float* p, size_t n) {
+  const size_t n4 = n >> 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    st4(p + 4 * i, f4zero());
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[4 * n4 + threadIdx.x] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, const float* decay,
                                                     size_t n, const float* lr_dev, float clip_norm, float prescale,
                                                     const float* sqnorm, float b1, float b2, float eps) {
   const float lr = lr_dev[0];
-  const float gn = sqrtf(sqnorm[0]);
+  float part = 0.f;
+  for (int i = threadIdx.x & 63; i < HUAL_SQNORM_SLOTS; i += 64) part += sqnorm[i];     // same order in every wave
+  const float gn = sqrtf(wave_sum64(part));
   const float sc = prescale * (clip_norm / fmaxf(gn, clip_norm));     // tf.clip_by_global_norm
   const size_t n4 = n >> 2;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -53,10 +62,18 @@ namespace hual {
 int launch_adamw(const AdamArgs& a, hipStream_t s) {
   HUAL_REQUIRE(a.p && a.g && a.m && a.v && a.decay && a.lr_dev && a.sqnorm, "adamw: null pointer");
   HUAL_REQUIRE((a.n % 4) == 0, "adamw: flat size must be a multiple of 4");
-  HUAL_CHECK_HIP(hipMemsetAsync(a.sqnorm, 0, sizeof(float), s));
-  HUAL_LAUNCH(0.0, 4.0 * a.n, sqnorm_kernel, dim3(256), dim3(256), 0, s, (const float*)a.g, a.n, a.prescale, a.sqnorm);
+  HUAL_LAUNCH(0.0, 4.0 * a.n, sqnorm_kernel, dim3(HUAL_SQNORM_SLOTS), dim3(256), 0, s, (const float*)a.g, a.n, a.prescale, a.sqnorm);
   HUAL_LAUNCH(0.0, 32.0 * a.n, adamw_kernel, dim3(512), dim3(256), 0, s, a.p, (const float*)a.g, a.m, a.v, a.decay, a.n, a.lr_dev,
                      a.clip_norm, a.prescale, (const float*)a.sqnorm, 0.9f, 0.999f, 1e-6f);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_zero(float* p, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  size_t g = (n / 4 + 255) / 256;
+  g = g < 2048 ? (g > 0 ? g : 1) : 2048;
+  HUAL_LAUNCH(0.0, 4.0 * n, zero_kernel, dim3((unsigned)g), dim3(256), 0, s, p, n);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

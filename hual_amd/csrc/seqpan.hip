@@ -25,21 +25,14 @@ using namespace hual;
 
 // ------------------------------------------------------------------------------------------------------
 // small kernels that belong to no family
-__global__ void prep_masks_kernel(const int32_t* lens, const int32_t* word_ids, float* rowmask, int B, int T, int L) {
+__global__ void prep_masks_kernel(const int32_t* lens, const int32_t* word_ids, float* rowmask, int B, int T, int L,
+                                  float* loss_acc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 8) loss_acc[i] = 0.f;
   const int Nv = B * T, Nq = B * L;
   if (i < Nv) rowmask[i] = (i % T) < lens[i / T] ? 1.0f : 0.0f;           // tf.sequence_mask, model.py:31
   else if (i < Nv + Nq) rowmask[i] = word_ids[i - Nv] != 0 ? 1.0f : 0.0f;   // model.py:32
 }
-__global__ void loss_finalize_kernel(const float* acc, float lambda, float* out) {
-  const float match = acc[LA_MATCH_SUM] / acc[LA_DENOM] + acc[LA_ORTHO];    // layers.py:173 + model.py:91
-  const float loc = acc[LA_LOC], align = acc[LA_ALIGN];
-  out[0] = loc + lambda * match + align;                                    // model.py:120
-  out[1] = loc;
-  out[2] = match;
-  out[3] = align;
-}
-
 namespace {
 
 struct WsEntry { std::string name; size_t off, rows, cols; };
@@ -75,6 +68,7 @@ struct Ctx {
   //   HUAL_FUSE_ROW=0  (default on) the row kernel that produces a gradient also writes dropout'(.) * relu'(.) of it for
   //                    the next dX GEMM, instead of an elementwise launch in between
   bool fuse_row = true;
+  bool static_tables = false;   // hual_run_opts.static_tables
 
   float* buf(const std::string& name, size_t rows, size_t cols) {
     auto it = index.find(name);
@@ -220,7 +214,9 @@ void flush_dw(Ctx& c, bool last = false) {
   const size_t n = c.dwjobs.size() - c.dw_flushed;
   if (n == 0) return;
   // blocks are dispatched in job order: long-row jobs first, so that the launch ends on the short ones (tail)
-  std::stable_sort(c.dwjobs.begin() + c.dw_flushed, c.dwjobs.end(), [](const DwJob& a, const DwJob& b) { return a.M > b.M; });
+  static const int nosort = []() { const char* e = getenv("HUAL_DW_NOSORT"); return e ? atoi(e) : 0; }();
+  if (!nosort)
+    std::stable_sort(c.dwjobs.begin() + c.dw_flushed, c.dwjobs.end(), [](const DwJob& a, const DwJob& b) { return a.M > b.M; });
   DwJob* table = reinterpret_cast<DwJob*>(c.buf("dw.table." + std::to_string(c.dw_flushes), n, (sizeof(DwJob) + 3) / 4));
   if (!c.dry && c.ok()) {
     hipStream_t s = c.stream;
@@ -230,7 +226,7 @@ void flush_dw(Ctx& c, bool last = false) {
       hipStreamWaitEvent(s, (hipEvent_t)c.aux->ev_fork, 0);
     }
     static const int rows = []() { const char* e = getenv("HUAL_DW_ROWS"); return e ? atoi(e) : 0; }();      // 0 = automatic split
-    c.chk(launch_dw(c.dwjobs.data() + c.dw_flushed, (int)n, c.drop, rows, s, table));
+    c.chk(launch_dw(c.dwjobs.data() + c.dw_flushed, (int)n, c.drop, rows, s, table, !c.static_tables));
   }
   c.dw_flushed = c.dwjobs.size();
   c.dw_flushes++;
@@ -348,9 +344,8 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   c.rsv.rowmask = rowmask;
   float* loss_acc = c.buf("loss_acc", 8, 1);
   if (!c.dry) {
-    HUAL_CHECK_HIP(hipMemsetAsync(loss_acc, 0, 8 * sizeof(float), c.stream));
     HUAL_LAUNCH(0.0, 0.0, prep_masks_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.stream, bt->video_seq_len, bt->word_ids,
-                       rowmask, B, T, L);
+                rowmask, B, T, L, loss_acc);
   }
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
   float* cat = c.buf("cat", Nq, catw);
@@ -544,6 +539,9 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   ma.fuse = fuse; ma.Wm = c.p(pm.match.k); ma.bm = c.p(pm.match.b); ma.E = c.p(pm.label_emb);
   ma.labels = (lab && !c.dry) ? lab->match_labels : nullptr;
   ma.probs = c.dry ? nullptr : out->match_scores; ma.outputs = outputs; ma.loss_acc = loss_acc;
+  // private copy for the backward pass (the caller owns match_scores and may overwrite it)
+  float* probs_keep = c.buf("match.probs", Nv, 4);
+  ma.probs2 = (lab && !c.dry) ? probs_keep : nullptr;
   if (!c.dry && c.ok()) c.chk(launch_match_fwd(ma, c.rs, c.stream));
   // ---------------- alignment loss, per-sample part (model.py:76)
   AlignPool ap{};
@@ -648,11 +646,8 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     la.ds = lab ? d_s : nullptr; la.de = lab ? d_e : nullptr; la.loss_acc = loss_acc; la.inv_batch = 1.0f / (float)B;
     if (c.ok()) c.chk(launch_loc(la, B, T, c.stream));
     if (lab && c.ok()) {
-      c.chk(launch_match_denominator(loss_acc, opt->match_denom_override, c.stream));
-      if (c.ok()) c.chk(launch_ortho(c.p(pm.label_emb), nullptr, loss_acc, c.cfg->match_lambda, c.stream));
-      if (out->loss_terms)
-        HUAL_LAUNCH(0.0, 0.0, loss_finalize_kernel, dim3(1), dim3(1), 0, c.stream, (const float*)loss_acc, c.cfg->match_lambda,
-                           out->loss_terms);
+      c.chk(launch_loss_tail(c.p(pm.label_emb), loss_acc, c.cfg->match_lambda, opt->match_denom_override, out->loss_terms,
+                             c.stream));
     }
   }
   return c.rc;
@@ -673,7 +668,9 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   c.colsum.clear();
   c.dw_flushed = 0;
   c.dw_flushes = 0;
-  if (!c.dry) HUAL_CHECK_HIP(hipMemsetAsync(c.G, 0, pm.total * sizeof(float), c.stream));
+  // (a kernel, not hipMemsetAsync: memset nodes of a captured graph were seen to pick up the fill pattern of later eager
+  //  memsets on this ROCm - every 4th gradient came back as the caller's learning rate)
+  if (!c.dry && c.ok()) c.chk(launch_zero(c.G, pm.total, c.stream));
   // transposed copies of every dense weight that a dX product reads (weights are constant within a step)
   float* PT = c.buf("params.T", pm.total, 1);
   c.PT = PT;
@@ -1251,12 +1248,6 @@ int hual_seqpan_forward(const hual_cfg* cfg, const float* params, const float* w
   c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
   rc = forward_graph(c, batch, labels, out, opts);
   if (rc) return rc;
-  if (labels) {
-    // keep the matching probabilities for backward (the caller owns match_scores and may overwrite it)
-    float* probs = c.buf("match.probs", c.rs.Nv, 4);
-    HUAL_CHECK_HIP(hipMemcpyAsync(probs, out->match_scores, (size_t)c.rs.Nv * 4 * sizeof(float), hipMemcpyDeviceToDevice,
-                                  c.stream));
-  }
   return 0;
 }
 
@@ -1277,6 +1268,7 @@ int hual_seqpan_backward(const hual_cfg* cfg, const float* params, const float* 
   c.P = params;
   c.G = grads;
   c.aux = opts->aux;
+  c.static_tables = opts->static_tables != 0;
   c.word_table = word_table;
   c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
   c.rs.rowmask = c.vec("rowmask");

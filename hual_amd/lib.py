@@ -49,7 +49,7 @@ class hual_aux(ctypes.Structure):
 
 class hual_run_opts(ctypes.Structure):
     _fields_ = [('drop_rate', ctypes.c_float), ('rng_state', ctypes.c_void_p), ('match_denom_override', ctypes.c_float),
-                ('align_external', ctypes.c_int32), ('aux', ctypes.POINTER(hual_aux))]
+                ('align_external', ctypes.c_int32), ('aux', ctypes.POINTER(hual_aux)), ('static_tables', ctypes.c_int32)]
 
 
 class hual_ws_entry(ctypes.Structure):

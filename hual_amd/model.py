@@ -69,7 +69,7 @@ class SeqPAN:
         self.adam_v = torch.zeros_like(self.params)
         self.decay = torch.from_numpy(self.table.decay_flat(0.01)).to(self.device)
         self.lr = torch.zeros(1, device=self.device)
-        self.sqnorm = torch.zeros(1, device=self.device)
+        self.sqnorm = torch.zeros(256, device=self.device)       # hual_adamw_clip_step scratch
         # Philox state {seed lo, seed hi, offset}; offset advances once per train step (on device, graph friendly)
         st = np.array([rng_seed & 0xFFFFFFFF, (rng_seed >> 32) & 0xFFFFFFFF, 0], dtype=np.uint32).view(np.int32)
         self.rng_state = torch.from_numpy(st.copy()).to(self.device)
@@ -152,7 +152,7 @@ class SeqPAN:
 
     def _opts(self, drop_rate, match_denom=0.0, align_external=0):
         return lib.hual_run_opts(float(drop_rate), lib.ptr(self.rng_state).value, float(match_denom), int(align_external),
-                                 None)
+                                 None, 0)
 
     # ------------------------------------------------------------------ fetches
     def forward(self, video_inputs, video_seq_len, word_ids, char_ids, drop_rate=0.0, labels=None, _opts=None):

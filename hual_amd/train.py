@@ -4,6 +4,7 @@
 Equivalent of the loop body of /root/reference/utils/runner_utils.py:144-147 (feed_dict upload + sess.run).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -21,6 +22,7 @@ class Trainer:
         self.graph = None
         self.graph_drop = None
         self.shape = None
+        self._tables_ready = False
         self._lib = lib.load()
         # optional second stream + fork/join events (hual_run_opts.aux).  Measured on MI355X: overlapping the
         # weight-gradient launch with the rest of backward does not pay (3.55 vs 3.50 ms/step), so it is off by default.
@@ -40,6 +42,7 @@ class Trainer:
         if shape != self.shape:
             self.shape = shape
             self.graph = None
+            self._tables_ready = False
             f32, i32 = torch.float32, torch.int32
             self.video = torch.empty(B, T, V, device=dev, dtype=f32)
             self.lens = torch.empty(B, device=dev, dtype=i32)
@@ -85,8 +88,11 @@ class Trainer:
 
     # ------------------------------------------------------------------ one step
     def _opts(self, drop_rate, align_external):
+        # static_tables: all buffers of this trainer are static per shape, so after one backward on them the job tables
+        # in the workspace stay valid (hual_run_opts.static_tables)
         return lib.hual_run_opts(float(drop_rate), lib.ptr(self.m.rng_state).value, float(self.match_denom),
-                                 int(align_external), ctypes.pointer(self.aux) if self.aux is not None else None)
+                                 int(align_external), ctypes.pointer(self.aux) if self.aux is not None else None,
+                                 1 if (self._tables_ready and not os.environ.get('HUAL_NO_STATIC_TABLES')) else 0)
 
     def _forward(self, opts):
         m = self.m
@@ -96,6 +102,7 @@ class Trainer:
 
     def _backward(self, opts):
         m = self.m
+        self._tables_ready = True
         lib.check(self._lib.hual_seqpan_backward(
             ctypes.byref(m.cfg), lib.ptr(m.params), lib.ptr(m.word_table), ctypes.byref(self.bt), ctypes.byref(self.lab),
             ctypes.byref(opts), lib.ptr(m.grads), lib.ptr(self.ws), self.ws.numel(), lib.stream_ptr()))

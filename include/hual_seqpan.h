@@ -132,6 +132,10 @@ typedef struct hual_run_opts {
   int32_t align_external;         /* 1: the [B,B] alignment loss is evaluated by the caller through
                                         hual_align_loss() on gathered features (exact data parallel) */
   const hual_aux* aux;            /* NULL: everything on `stream` */
+  int32_t static_tables;          /* 1: the caller guarantees that a previous hual_seqpan_backward ran with the SAME
+                                        cfg, shapes, params / grads / workspace / batch pointers, so the device-resident
+                                        job tables it left in the workspace are still valid and are not rewritten
+                                        (saves six tiny launches per step inside a replayed hipGraph) */
 } hual_run_opts;
 
 /* bytes of workspace needed for one forward(+backward) of this shape */
@@ -159,7 +163,7 @@ int hual_seqpan_backward(const hual_cfg* cfg, const float* params, const float* 
 
 /* clip_by_global_norm + AdamWeightDecayOptimizer.apply_gradients (ops.py:127-132,149-174).
  * decay: per-element weight decay rate in the flat layout; lr: device scalar; grad_prescale multiplies the
- * gradient first (1/world after a sum all-reduce); sqnorm: device scalar scratch. */
+ * gradient first (1/world after a sum all-reduce); sqnorm: device scratch of 256 floats. */
 int hual_adamw_clip_step(float* params, const float* grads, float* adam_m, float* adam_v, const float* decay,
                          uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
                          void* stream);
