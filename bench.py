@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_FILE = 'r1c_pmc_traffic.json'     # per-kernel HBM bytes per launch from the PMC passes of this round
 
 
 def synth_batch(B, T, L, C, vdim, num_words, num_chars, seed):
@@ -183,6 +184,18 @@ def main():
             roof = dict(bound='hbm', kernel=top['kernel'], achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                         frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, avg_launch_us=round(top['us'] / top['launches'], 2),
                         launches_per_step=top['launches'] // psteps, share_of_kernel_time=round(top['us'] / total_us, 3))
+        # HBM traffic of that kernel: rocprofv3 PMC passes cannot run inside this process, so the per-launch figure is
+        # read from the committed summary of the separate FETCH_SIZE / WRITE_SIZE passes (scripts/pmc_traffic.py,
+        # gfx950 correction applied there); null when the file does not cover the kernel.
+        try:
+            tr_tab = json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)))
+            if top['kernel'] in tr_tab:
+                roof['traffic'] = tr_tab[top['kernel']]['hbm_bytes_per_launch']
+                roof['traffic_unit'] = 'bytes/launch'
+                roof['traffic_source'] = 'profiles/' + TRAFFIC_FILE
+                roof['algorithmic_bytes_per_launch'] = round(top['bytes'] / top['launches'])
+        except (OSError, ValueError):
+            pass
         roof['families'] = [dict(kernel=d['kernel'], launches_per_step=d['launches'] // psteps,
                                  us_per_step=round(d['us'] / psteps, 1),
                                  tflops=round(d['flops'] / d['us'] / 1e6, 2) if d['flops'] > 0 else None) for d in fam]
