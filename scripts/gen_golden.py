@@ -10,6 +10,9 @@ Pins:
                    overlapping +-2 extensions, vlen < max_len
   * timeidx.npz  - utils/data_utils.py:110-128 time_to_index / index_to_time and :70-85 visual_feature_sampling
   * uncert.npz   - utils/utils_hual.py:144-170 get_uncert_model / infer_idx(start_prob, end_prob) (the active-learning scoring)
+  * al.npz       - update_label.py: renew_label :85-123 on seeded cases (both branches), get_uncert_rank :125-169 and two
+                   consecutive main() rounds :173-208 on a synthetic 24-sample train set (files in a temp dir), with the
+                   F_renew coefficient tables :11-37 of both tasks; utils_hual.get_distance_score / center_width_gauss
 """
 import os
 import sys
@@ -19,6 +22,143 @@ import numpy as np
 
 REF = '/root/reference'
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+
+
+class _EasyDict(dict):
+    """stand-in for easydict.EasyDict (absent from this image): nested attribute access, nothing else is used"""
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = _EasyDict(v) if isinstance(v, dict) else v
+    __getattr__ = dict.__getitem__
+
+
+def _rand_ap(g, vlen, gt, npts):
+    """active points the way update_label.append_AP builds them: each observed frame is pos iff inside the GT span"""
+    pos, neg = [], []
+    for p in g.choice(vlen, size=min(npts, vlen), replace=False):
+        (pos if gt[0] <= int(p) <= gt[1] else neg).append(int(p))
+    return pos, neg
+
+
+def _pad_lists(lists, width):
+    out = np.full((len(lists), width), -1, dtype=np.int64)
+    for i, l in enumerate(lists):
+        out[i, :len(l)] = l
+    return out
+
+
+def gen_al(g, utils_hual):
+    import json
+    import pickle
+    import tempfile
+    ed = types.ModuleType('easydict')
+    ed.EasyDict = _EasyDict
+    sys.modules.setdefault('easydict', ed)
+    import update_label as U   # noqa: E402
+    a = {}
+    # ---------------- center_width_gauss / get_distance_score -----------------------------
+    rows = []
+    for k, (c, w, vlen, mv) in enumerate([(3.0, 7, 20, 32), (10.5, 4, 12, 12), (0.0, 1, 5, 16), (30.0, 19.2, 64, 64)]):
+        a['cwg%d_in' % k] = np.array([c, w, vlen, mv], dtype=np.float64)
+        a['cwg%d_out' % k] = np.asarray(utils_hual.center_width_gauss(c, w, vlen, mv))
+    for k, (pos, neg, vlen, mv) in enumerate([([], [], 10, 16), ([4, 6], [1, 9], 12, 16), ([], [3, 8], 12, 12),
+                                              ([0], [], 7, 8), ([5], [6, 2], 9, 9)]):
+        a['dist%d_pos' % k] = np.array(pos, dtype=np.int64)
+        a['dist%d_neg' % k] = np.array(neg, dtype=np.int64)
+        a['dist%d_dims' % k] = np.array([vlen, mv])
+        a['dist%d_out' % k] = np.asarray(utils_hual.get_distance_score(list(pos), list(neg), vlen, mv), dtype=np.float64)
+        s_, e_ = utils_hual.get_distance_score_shift(list(pos), list(neg), vlen, mv, -0.3 if pos else 0.9)
+        a['dist%d_shift_s' % k], a['dist%d_shift_e' % k] = np.asarray(s_, np.float64), np.asarray(e_, np.float64)
+    a['n_dist'] = np.array(5)
+    # ---------------- renew_label ---------------------------------------------------------
+    K, TM = 40, 48
+    rn = dict(old=[], pos=[], neg=[], sp=np.zeros((K, TM), np.float32), ep=np.zeros((K, TM), np.float32), dims=[],
+              coff=[], out=[])
+    for k in range(K):
+        mv = int(g.integers(8, TM + 1))
+        vlen = int(g.integers(4, mv + 1))
+        gs = int(g.integers(0, vlen - 1)); ge = int(g.integers(gs, vlen))
+        pos, neg = _rand_ap(g, vlen, (gs, ge), int(g.integers(1, 5)))
+        if k % 3 == 0:
+            pos = []                      # force the negative-only branch regularly
+            if not neg:
+                neg = [int(g.integers(0, vlen))]
+        os_ = int(g.integers(0, vlen)); oe = int(g.integers(os_, vlen))
+        sp = U.sigmoid(g.standard_normal(mv).astype(np.float32) * 2)
+        ep = U.sigmoid(g.standard_normal(mv).astype(np.float32) * 2)
+        task, I = ('charades', 'anet')[k % 2], 1 + (k // 2) % 3
+        coff = U.get_coff(U.F_renew, task, I)
+        res = U.renew_label([os_, oe], {'pos_idx': list(pos), 'neg_idx': list(neg)}, sp.copy(), ep.copy(), vlen, mv, coff)
+        rn['old'].append([os_, oe]); rn['pos'].append(pos); rn['neg'].append(neg)
+        rn['sp'][k, :mv] = sp; rn['ep'][k, :mv] = ep
+        rn['dims'].append([vlen, mv])
+        rn['coff'].append([coff.pos.distance, coff.pos.model, coff.pos.old, coff.neg.distance, coff.neg.model, coff.neg.old,
+                           coff.uncert])
+        rn['out'].append([int(res[0]), int(res[1])])
+    a['renew_old'] = np.array(rn['old']); a['renew_pos'] = _pad_lists(rn['pos'], 8); a['renew_neg'] = _pad_lists(rn['neg'], 8)
+    a['renew_sprob'], a['renew_eprob'] = rn['sp'], rn['ep']
+    a['renew_dims'] = np.array(rn['dims']); a['renew_coff'] = np.array(rn['coff'], dtype=np.float64)
+    a['renew_out'] = np.array(rn['out'])
+    # ---------------- get_uncert_rank + main(): two consecutive rounds ---------------------
+    N, TMAX = 24, 40
+    dur = np.round(g.uniform(8.0, 60.0, size=N), 2)
+    vlen = g.integers(6, 33, size=N)
+    tm = np.array([int(g.integers(v, TMAX + 1)) for v in vlen])      # padded length of the batch the sample was in
+    gt = np.zeros((N, 2)); old = np.zeros((N, 2))
+    for i in range(N):
+        s_ = g.uniform(0, dur[i] * 0.7); gt[i] = [round(s_, 2), round(g.uniform(s_ + 0.5, dur[i]), 2)]
+        s_ = g.uniform(0, dur[i] * 0.7); old[i] = [round(s_, 2), round(g.uniform(s_ + 0.5, dur[i]), 2)]
+    a['al_dur'], a['al_vlen'], a['al_tm'], a['al_gt'], a['al_old0'] = dur, vlen, tm, gt, old
+    tmp = tempfile.mkdtemp()
+    data_gt = [['v%d' % i, float(dur[i]), [float(gt[i, 0]), float(gt[i, 1])], 'q %d' % i] for i in range(N)]
+    data_old = [['v%d' % i, float(dur[i]), [float(old[i, 0]), float(old[i, 1])], 'q %d' % i] for i in range(N)]
+    gt_path = os.path.join(tmp, 'gt.json')
+    json.dump(data_gt, open(gt_path, 'w'))
+    U.GT_PATH = gt_path
+    cur_path = os.path.join(tmp, 're0.json')
+    json.dump(data_old, open(cur_path, 'w'))
+    for rnd, task in ((1, 'charades'), (2, 'anet')):
+        logits = np.zeros((N, 3, 2, TMAX), np.float32)
+        prop = []
+        for i in range(N):
+            lg = g.standard_normal((3, 2, tm[i])).astype(np.float32) * 1.5
+            lg[1] = lg[0] + 0.3 * g.standard_normal((2, tm[i])).astype(np.float32)   # MC-dropout passes near the base pass
+            lg[2] = lg[0] + 0.3 * g.standard_normal((2, tm[i])).astype(np.float32)
+            logits[i, :, :, :tm[i]] = lg
+            prop.append({'vid': 'v%d' % i, 'v_len': int(vlen[i]), 'prop_logits': [lg[0, 0], lg[0, 1]],
+                         'prop_logits1': [lg[1, 0], lg[1, 1]], 'prop_logits2': [lg[2, 0], lg[2, 1]]})
+        a['al_r%d_logits' % rnd] = logits
+        coff = U.get_coff(U.F_renew, task, rnd)
+        a['al_r%d_coff' % rnd] = np.array([coff.pos.distance, coff.pos.model, coff.pos.old, coff.neg.distance,
+                                            coff.neg.model, coff.neg.old, coff.uncert], dtype=np.float64)
+        prop_path = os.path.join(tmp, 'prop%d.pkl' % rnd)
+        pickle.dump(prop, open(prop_path, 'wb'))
+        # ranking as main() sees it (a fresh load: main() mutates its own copy)
+        d0 = json.load(open(cur_path))
+        if len(d0[0]) == 4:
+            for r in d0:
+                r.append({'pos_idx': [], 'neg_idx': []})
+        rank = U.get_uncert_rank(d0, data_gt, prop, coff)
+        a['al_r%d_rank_idx' % rnd] = np.array([r['idx'] for r in rank])
+        uf = np.zeros((N, TMAX), np.float64)
+        for r in rank:
+            uf[r['idx'], :r['max_vlen']] = r['uncert_frame']
+        a['al_r%d_uncert_frame' % rnd] = uf
+        uv = np.zeros(N, np.float64)
+        for r in rank:
+            uv[r['idx']] = r['uncert_video']
+        a['al_r%d_uncert_video' % rnd] = uv
+        a['al_r%d_gt_idx' % rnd] = np.array([r['gt_idx'] for r in sorted(rank, key=lambda r: r['idx'])])
+        a['al_r%d_old_idx' % rnd] = np.array([r['old_idx'] for r in sorted(rank, key=lambda r: r['idx'])])
+        new_path = os.path.join(tmp, 're%d.json' % rnd)
+        U.main(cur_path, new_path, prop_path, coff)
+        new = json.load(open(new_path))
+        a['al_r%d_new_time' % rnd] = np.array([r[2] for r in new], dtype=np.float64)
+        a['al_r%d_new_pos' % rnd] = _pad_lists([r[4]['pos_idx'] for r in new], 8)
+        a['al_r%d_new_neg' % rnd] = _pad_lists([r[4]['neg_idx'] for r in new], 8)
+        cur_path = new_path
+    np.savez_compressed(os.path.join(OUT, 'al.npz'), **a)
 
 
 def main():
@@ -101,6 +241,7 @@ def main():
         u['u%d_sprob' % k], u['u%d_eprob' % k] = sp, ep
         u['u%d_idx' % k] = np.asarray(utils_hual.infer_idx(sp, ep), dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, 'uncert.npz'), **u)
+    gen_al(g, utils_hual)
     print('wrote', sorted(os.listdir(OUT)))
 
 
