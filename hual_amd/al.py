@@ -1,0 +1,205 @@
+"""Active-learning round pieces around the SeqPAN hot path, MI355X side.
+
+    reference                                                    here
+    ---------------------------------------------------------    -------------------------------------------------
+    runner_utils.eval_test_save (utils/runner_utils.py:69-110)   infer_trainset(model, batches): ONE deterministic
+      five sess.run per batch + results/<task>/<suffix>.pkl        forward (all five fetches) + two stochastic forwards
+    update_label.main (update_label.py:173-208)                  update_labels(data_old, data_gt, last_prop, coff):
+      python loop over samples, sorted() inside the loop           two launches over the whole training set
+    update_label.get_coff / F_renew (update_label.py:11-37,212)  get_coff / F_RENEW
+
+The scoring and the pseudo-label re-derivation run in libhual_seqpan.so (csrc/al.hip, through hual_al_score /
+hual_al_renew); ranking, ground-truth lookup (the "annotator") and time<->index conversion are a few numpy lines on the
+host.  There is no CPU fallback: without the library or a GPU this module raises.
+
+Reference quirk kept selectable: eval-mode get_feed_dict (runner_utils.py:61-65) drops drop_rate, so the
+reference's two "dropout 0.5" passes run WITHOUT dropout and prop_logits1 == prop_logits2 == prop_logits;
+mc_dropout=None reproduces that, mc_dropout=0.5 is what the code intends.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import lib
+
+# update_label.py:11-37 (index = active-learning round I; entry 0 unused)
+F_RENEW = {
+    'charades': {'pos': {'old': [None, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], 'model': [None, 0.8, 0.8, 0.8, 0.8, 0.8, 0.8],
+                         'distance': [None, 4.0, 0.2, 0.2, 0.2, 0.2, 0.2]},
+                 'neg': {'old': [None, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], 'model': [None, 2.4, 0.2, 0.2, 0.2, 0.2, 0.2],
+                         'distance': [None, 2.0, 0.2, 0.2, 0.2, 0.2, 0.2]},
+                 'uncert': [None, 0.25, 0.25, 0.25, 0.25, 0.25, 0.25]},
+    'anet': {'pos': {'old': [None, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], 'model': [None, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0],
+                     'distance': [None, 2.0, 1.8, 1.6, 1.5, 1.5, 1.5]},
+             'neg': {'old': [None, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], 'model': [None, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0],
+                     'distance': [None, 2.0, 1.8, 1.6, 1.5, 1.5, 1.5]},
+             'uncert': [None, 0.25, 0.25, 0.25, 0.25, 0.25, 0.25]},
+}
+
+
+def get_coff(task, I):
+    """(pos.distance, pos.model, pos.old, neg.distance, neg.model, neg.old, uncert) of round I (update_label.py:212-218)"""
+    t = F_RENEW[task]
+    return (t['pos']['distance'][I], t['pos']['model'][I], t['pos']['old'][I],
+            t['neg']['distance'][I], t['neg']['model'][I], t['neg']['old'][I], t['uncert'][I])
+
+
+# ---------------------------------------------------------------- infer_trainset ----------------
+def infer_trainset(model, batches, mc_dropout=None):
+    """eval_test_save (runner_utils.py:69-110) without the file write: returns (records, ious).
+
+    batches: iterable of (raw_records, video, video_seq_len, word_ids, char_ids) as TestLoader.test_iter yields them
+    (data_loader.py:131-143).  Each record of the result has the keys of runner_utils.py:90-100; logits are the raw
+    [T_b] rows of the batch (unmasked beyond v_len), m_score is [T_b, 4].
+    """
+    from . import data
+    records, ious = [], []
+    for raw, video, lens, word_ids, char_ids in batches:
+        o = model.forward(video, lens, word_ids, char_ids, drop_rate=0.0)
+        s0, e0 = o['start_logits'].cpu().numpy(), o['end_logits'].cpu().numpy()
+        ms = o['match_scores'].cpu().numpy()
+        si, ei = o['start_index'].cpu().numpy(), o['end_index'].cpu().numpy()
+        if mc_dropout is None:
+            s1, e1, s2, e2 = s0, e0, s0, e0                     # as written: drop_rate never reaches the graph (F8)
+        else:
+            o1 = model.forward(video, lens, word_ids, char_ids, drop_rate=mc_dropout)
+            s1, e1 = o1['start_logits'].cpu().numpy(), o1['end_logits'].cpu().numpy()
+            model.rng_state[2] += 1                              # a fresh Philox offset for the second stochastic pass
+            o2 = model.forward(video, lens, word_ids, char_ids, drop_rate=mc_dropout)
+            s2, e2 = o2['start_logits'].cpu().numpy(), o2['end_logits'].cpu().numpy()
+            model.rng_state[2] += 1
+        for i, r in enumerate(raw):
+            st, et = data.index_to_time([int(si[i]), int(ei[i])], r['v_len'], r['duration'])
+            gs, ge = data.index_to_time([r['s_ind'], r['e_ind']], r['v_len'], r['duration'])
+            ious.append(calculate_iou([st, et], [gs, ge]))
+            records.append({'vid': r['vid'], 'duration': r['duration'], 'psuedo_idx': [r['s_ind'], r['e_ind']],
+                            'sentence': ' '.join(r['words']), 'v_len': int(r['v_len']),
+                            'prop_idx': [int(si[i]), int(ei[i])], 'prop_logits': [s0[i], e0[i]],
+                            'prop_logits1': [s1[i], e1[i]], 'prop_logits2': [s2[i], e2[i]], 'm_score': ms[i]})
+    return records, ious
+
+
+def calculate_iou(i0, i1):
+    """runner_utils.py:34-38"""
+    union = (min(i0[0], i1[0]), max(i0[1], i1[1]))
+    inter = (max(i0[0], i1[0]), min(i0[1], i1[1]))
+    return max(0.0, 1.0 * (inter[1] - inter[0]) / (union[1] - union[0]))
+
+
+def iou_metrics(ious):
+    """R@1 IoU={0.3,0.5,0.7} and mIoU in percent (runner_utils.py:25-31,106-109)"""
+    a = np.asarray(ious, dtype=np.float64)
+    return tuple(float(np.mean(a >= t) * 100.0) for t in (0.3, 0.5, 0.7)) + (float(np.mean(a) * 100.0),)
+
+
+# ---------------------------------------------------------------- label update -------------------
+def _round_half_even_index(t, duration, vlen):
+    """time_to_index_v2 (update_label.py:41-48): python round() of t / duration * (vlen - 1)"""
+    return round(t / duration * (vlen - 1))
+
+
+class LabelUpdater:
+    """Device-side state of one update_label round: the logits of the results pkl as [N, ld] matrices, the active
+    points as CSR.  score() and renew() are one launch each."""
+
+    def __init__(self, last_prop, aps, device='cuda:0'):
+        if not torch.cuda.is_available():
+            raise lib.HualError('LabelUpdater needs a GPU: the HIP path has no CPU fallback')
+        self._lib = lib.load()
+        self.dev = torch.device(device)
+        N = len(last_prop)
+        tlen = np.array([len(p['prop_logits'][0]) for p in last_prop], dtype=np.int32)
+        vlen = np.array([p['v_len'] for p in last_prop], dtype=np.int32)
+        ld = int(tlen.max())
+        if int(tlen.min()) < 2 or ld > 1024 or (vlen < 1).any() or (vlen > tlen).any():
+            raise ValueError('need 2 <= len(logits) <= 1024 and 1 <= v_len <= len(logits)')
+        lg = np.zeros((6, N, ld), dtype=np.float32)
+        for n, p in enumerate(last_prop):
+            for k, key in enumerate(('prop_logits', 'prop_logits1', 'prop_logits2')):
+                lg[2 * k, n, :tlen[n]] = p[key][0]
+                lg[2 * k + 1, n, :tlen[n]] = p[key][1]
+        self.N, self.ld = N, ld
+        self.tlen_h, self.vlen_h = tlen, vlen
+        self.logits = torch.from_numpy(lg).to(self.dev)
+        self.tlen = torch.from_numpy(tlen).to(self.dev)
+        self.vlen = torch.from_numpy(vlen).to(self.dev)
+        self.sprob = torch.zeros(N, ld, device=self.dev)
+        self.eprob = torch.zeros(N, ld, device=self.dev)
+        self.uncert_frame = torch.zeros(N, ld, device=self.dev, dtype=torch.float64)
+        self.uncert_video = torch.zeros(N, device=self.dev)
+        self.observe = torch.zeros(N, device=self.dev, dtype=torch.int32)
+        self.set_active_points(aps)
+
+    def set_active_points(self, aps):
+        """aps: per sample (list of (frame, is_pos)) in annotation order"""
+        off = np.zeros(self.N + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(a) for a in aps])
+        idx = np.array([f for a in aps for f, _ in a] + [0], dtype=np.int32)      # never empty: a valid pointer
+        pos = np.array([1 if p else 0 for a in aps for _, p in a] + [0], dtype=np.int8)
+        self.ap_off = torch.from_numpy(off).to(self.dev)
+        self.ap_idx = torch.from_numpy(idx).to(self.dev)
+        self.ap_pos = torch.from_numpy(pos).to(self.dev)
+        p = lib.ptr
+        self.set = lib.hual_al_set(self.N, self.ld, p(self.vlen).value, p(self.tlen).value, p(self.ap_off).value,
+                                   p(self.ap_idx).value, p(self.ap_pos).value)
+
+    def score(self, coff_uncert):
+        p, lg = lib.ptr, self.logits
+        lib.check(self._lib.hual_al_score(ctypes.byref(self.set), p(lg[0]), p(lg[1]), p(lg[2]), p(lg[3]), p(lg[4]), p(lg[5]),
+                                          float(coff_uncert), p(self.sprob), p(self.eprob), p(self.uncert_frame),
+                                          p(self.uncert_video), p(self.observe), lib.stream_ptr()))
+
+    def renew(self, sel, old_idx, coff):
+        """sel: sample ids (numpy); old_idx: int [N,2]; returns new_idx int32 [N,2] (valid for the selected rows)"""
+        sel_d = torch.from_numpy(np.ascontiguousarray(sel, dtype=np.int32)).to(self.dev)
+        old_d = torch.from_numpy(np.ascontiguousarray(old_idx, dtype=np.int32)).to(self.dev)
+        new_d = torch.full((self.N, 2), -1, device=self.dev, dtype=torch.int32)
+        c6 = (ctypes.c_double * 6)(*[float(x) for x in coff[:6]])
+        lib.check(self._lib.hual_al_renew(ctypes.byref(self.set), lib.ptr(sel_d), int(len(sel)), lib.ptr(self.sprob),
+                                          lib.ptr(self.eprob), lib.ptr(old_d), c6, lib.ptr(new_d), lib.stream_ptr()))
+        return new_d.cpu().numpy()
+
+
+def update_labels(data_old, data_gt, last_prop, coff, device='cuda:0', return_debug=False):
+    """update_label.main (update_label.py:173-208) without the file IO.
+
+    data_old / data_gt: lists [vid, duration, [start_time, end_time], sentence(, active points)] as in
+    data/<task>_re<I>/train.json; last_prop: the records of results/<task>/re<I-1>.pkl; coff: get_coff(task, I).
+    Mutates and returns data_old exactly as the reference writes it to data/<task>_re<I>/train.json.
+    """
+    if len(data_old[0]) == 4:
+        for r in data_old:
+            r.append({'pos_idx': [], 'neg_idx': []})
+    N = len(data_old)
+    for i in range(N):
+        assert data_old[i][0] == last_prop[i]['vid'] and data_old[i][0] == data_gt[i][0]
+    # active points in one list per sample; the reference keeps two lists and only ever asks for min / max / membership
+    # of each, so the relative order between the two kinds does not matter
+    aps = [[(f, True) for f in r[4]['pos_idx']] + [(f, False) for f in r[4]['neg_idx']] for r in data_old]
+    up = LabelUpdater(last_prop, aps, device=device)
+    up.score(coff[6])
+    uv = up.uncert_video.cpu().numpy()
+    observe = up.observe.cpu().numpy()
+    order = np.argsort(uv, kind='stable')                       # sorted(key=uncert_video), ties in sample order
+    sel = order[:math.ceil(N / 2)]
+    vlen = up.vlen_h
+    gt_idx = np.array([[_round_half_even_index(t, data_gt[i][1], int(vlen[i])) for t in data_gt[i][2]] for i in range(N)])
+    old_idx = np.array([[_round_half_even_index(t, data_old[i][1], int(vlen[i])) for t in data_old[i][2]] for i in range(N)])
+    # append_AP (utils_hual.py:133-139): the annotator answers "is the observed frame inside the ground-truth span?"
+    for i in sel:
+        p = int(observe[i])
+        is_pos = gt_idx[i, 0] <= p <= gt_idx[i, 1]
+        data_old[i][4]['pos_idx' if is_pos else 'neg_idx'].append(p)
+        aps[i].append((p, bool(is_pos)))
+    up.set_active_points(aps)
+    new_idx = up.renew(sel, old_idx, coff)
+    for i in sel:
+        dur, vl = data_old[i][1], int(vlen[i])
+        data_old[i][2] = [round(int(t) / (vl - 1) * dur, 2) for t in new_idx[i]]          # index_to_time, update_label.py:50-57
+    if return_debug:
+        return data_old, dict(order=order, uncert_video=uv, observe=observe, uncert_frame=up.uncert_frame.cpu().numpy(),
+                              sprob=up.sprob.cpu().numpy(), eprob=up.eprob.cpu().numpy(), new_idx=new_idx, gt_idx=gt_idx,
+                              old_idx=old_idx, updater=up)
+    return data_old

@@ -52,6 +52,18 @@ class hual_run_opts(ctypes.Structure):
                 ('align_external', ctypes.c_int32), ('aux', ctypes.POINTER(hual_aux)), ('static_tables', ctypes.c_int32)]
 
 
+class hual_al_set(ctypes.Structure):
+    _fields_ = [('N', ctypes.c_int32), ('ld', ctypes.c_int32), ('vlen', ctypes.c_void_p), ('tlen', ctypes.c_void_p),
+                ('ap_off', ctypes.c_void_p), ('ap_idx', ctypes.c_void_p), ('ap_pos', ctypes.c_void_p)]
+
+
+class hual_dataset(ctypes.Structure):
+    _fields_ = [('feat_bank', ctypes.c_void_p), ('feat_off', ctypes.c_void_p), ('vdim', ctypes.c_int32),
+                ('sample_vid', ctypes.c_void_p), ('word_off', ctypes.c_void_p), ('word_bank', ctypes.c_void_p),
+                ('char_off', ctypes.c_void_p), ('char_bank', ctypes.c_void_p), ('s_ind', ctypes.c_void_p),
+                ('e_ind', ctypes.c_void_p)]
+
+
 class hual_ws_entry(ctypes.Structure):
     _fields_ = [('name', ctypes.c_char * 48), ('offset', ctypes.c_uint64), ('rows', ctypes.c_uint64),
                 ('cols', ctypes.c_uint64)]
@@ -88,6 +100,9 @@ def load():
     lib.hual_aux_destroy.argtypes = [P(hual_aux)]
     lib.hual_linear_fwd.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.hual_linear_dw.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]
+    lib.hual_al_score.argtypes = [P(hual_al_set), vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]
+    lib.hual_al_renew.argtypes = [P(hual_al_set), vp, i32, vp, vp, vp, P(ctypes.c_double), vp, vp]
+    lib.hual_assemble_batch.argtypes = [P(hual_dataset), vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 

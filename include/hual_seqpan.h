@@ -191,6 +191,68 @@ int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW,
                    int N, int rows_per_block, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Device-side batch assembly: TrainLoader.process_batch / TestLoader.process_batch
+ * (/root/reference/utils/data_loader.py:30-98,145-164) from a training set that stays resident in HBM.
+ * All arrays are device memory owned by the caller.  Videos: rows feat_off[v] .. feat_off[v+1] of feat_bank
+ * [total_frames, vdim] (already down-sampled to <= max_vlen by visual_feature_sampling, data_utils.py:70-85).
+ * Samples: video id, word ids word_bank[word_off[s] .. word_off[s+1]), chars of word w (global word index)
+ * char_bank[char_off[w] .. char_off[w+1]), pseudo-label frame indices s_ind / e_ind (NULL for test sets).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hual_dataset {
+  const float* feat_bank;
+  const int64_t* feat_off;     /* [n_videos + 1] */
+  int32_t vdim;
+  const int32_t* sample_vid;   /* [n_samples] */
+  const int32_t* word_off;     /* [n_samples + 1] */
+  const int32_t* word_bank;
+  const int32_t* char_off;     /* [n_words_total + 1] */
+  const int32_t* char_bank;
+  const int32_t* s_ind;        /* [n_samples] */
+  const int32_t* e_ind;        /* [n_samples] */
+} hual_dataset;
+
+/* sel: i32 [B] sample ids of the batch.  T / L / C must be the maxima of the batch's video / word / char lengths
+ * (the caller knows the lengths; C >= 4 for the model).  Writes the feeds of model.py:16-27: video f32 [B,T,vdim] zero
+ * padded, video_seq_len i32 [B], word_ids i32 [B,L], char_ids i32 [B,L,C] and - unless y1 is NULL - the soft start/end
+ * labels f32 [B,T], match_labels i32 [B,T], inner_labels f32 [B,T] exactly as data_loader.py:55-94 computes them. */
+int hual_assemble_batch(const hual_dataset* ds, const int32_t* sel, int B, int T, int L, int C, float* video,
+                        int32_t* video_seq_len, int32_t* word_ids, int32_t* char_ids, float* y1, float* y2,
+                        int32_t* match_labels, float* inner_labels, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Active-learning label update (BASELINE.json configs[4]): what /root/reference/update_label.py does
+ * per training sample between two training rounds, for the whole training set in two launches.
+ *   hual_al_score  = the loop body of get_uncert_rank (update_label.py:125-169): sigmoid of the deterministic logits,
+ *                    get_uncert_model (utils/utils_hual.py:144-161) of the two stochastic passes, get_distance_score
+ *                    (:92-103) of the sample's active points, uncert_frame, uncert_video and the frame to annotate
+ *                    (argmax of uncert_frame, update_label.py:194)
+ *   hual_al_renew  = renew_label (update_label.py:85-123) for the selected samples, after the caller appended the
+ *                    annotated frame to their active points (append_AP, utils_hual.py:133-139)
+ * The ranking by uncert_video, the ground-truth lookup and the JSON/pickle files stay on the host (hual_amd/al.py).
+ * A sample's logits occupy the first tlen[n] entries of its row (tlen = padded length of the batch the record came
+ * from, `max_vlen = len(sprob)` in the reference); 2 <= tlen <= ld <= 1024, 1 <= vlen <= tlen.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hual_al_set {
+  int32_t N, ld;
+  const int32_t* vlen;     /* [N]   record['v_len'] */
+  const int32_t* tlen;     /* [N]   len(prop_logits[0]) */
+  const int32_t* ap_off;   /* [N+1] CSR offsets into ap_idx / ap_pos */
+  const int32_t* ap_idx;   /* active points: frame index, in annotation order */
+  const int8_t* ap_pos;    /* 1 = 'pos_idx' entry, 0 = 'neg_idx' entry */
+} hual_al_set;
+
+/* s0/e0: prop_logits, s1/e1: prop_logits1, s2/e2: prop_logits2, each f32 [N, ld].  Outputs: sprob, eprob f32 [N, ld];
+ * uncert_frame f64 [N, ld]; uncert_video f32 [N]; observe_point i32 [N]. */
+int hual_al_score(const hual_al_set* set, const float* s0, const float* e0, const float* s1, const float* e1,
+                  const float* s2, const float* e2, float coff_uncert, float* sprob, float* eprob, double* uncert_frame,
+                  float* uncert_video, int32_t* observe_point, void* stream);
+
+/* sel: i32 [nsel] sample ids (NULL = all N); old_idx i32 [N,2]; coff6 (HOST pointer) = pos.{distance,model,old},
+ * neg.{distance,model,old} of F_renew (update_label.py:11-37); new_idx i32 [N,2], written for the selected rows only. */
+int hual_al_renew(const hual_al_set* set, const int32_t* sel, int nsel, const float* sprob, const float* eprob,
+                  const int32_t* old_idx, const double* coff6, int32_t* new_idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement hook for bench.py's roofline leg (not part of the reference's surface): between begin and end every
  * kernel launch carries its own start / stop events (hipExtLaunchKernelGGL: the begin / end timestamps of that
  * kernel's dispatch, the quantity rocprofv3 --kernel-trace reports).  hual_prof_end() synchronises those events (the
