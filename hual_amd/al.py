@@ -203,3 +203,66 @@ def update_labels(data_old, data_gt, last_prop, coff, device='cuda:0', return_de
                               sprob=up.sprob.cpu().numpy(), eprob=up.eprob.cpu().numpy(), new_idx=new_idx, gt_idx=gt_idx,
                               old_idx=old_idx, updater=up)
     return data_old
+
+
+# ---------------------------------------------------------------- one whole round ----------------
+def labels_from_times(data, vlens):
+    """pseudo-label frame indices of train.json entries: dataset_gen's time_to_index (utils/data_gen.py:98-125 ->
+    data_utils.py:110-118) on every [vid, duration, [start, end], ...] record"""
+    from . import data as hdata
+    s, e = [], []
+    for r, n in zip(data, vlens):
+        a, b = hdata.time_to_index(r[2][0], r[2][1], int(n), r[1])
+        s.append(a)
+        e.append(b)
+    return np.array(s, dtype=np.int32), np.array(e, dtype=np.int32)
+
+
+def run_round(model, dataset, data_old, data_gt, last_prop, task, I, epochs, batch_size, lr, drop_rate, mc_dropout=0.5,
+              shuffle_seed=0, log=None):
+    """One active-learning round of run_charades.py:9-41 on device-resident data:
+         update_label.py <task> I   ->  main.py --mode train (epochs)   ->  main.py --mode infer_trainset
+    dataset: DeviceDataset over the training records in the SAME order as data_old / data_gt / last_prop.
+    Returns (new train list, new results records, metrics dict)."""
+    import time
+    from .train import Trainer
+    t0 = time.perf_counter()
+    new_data = update_labels(data_old, data_gt, last_prop, get_coff(task, I), device=model.device)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    s_ind, e_ind = labels_from_times(new_data, dataset.vlen_h)
+    dataset.set_labels(s_ind, e_ind)
+    for r, a, b in zip(dataset.records, s_ind, e_ind):
+        r['s_ind'], r['e_ind'] = int(a), int(b)
+    N = len(dataset)
+    tr = Trainer(model, world=1, use_graph=False)
+    rng = np.random.default_rng(shuffle_seed)
+    feeds, steps = None, 0
+    for ep in range(epochs):
+        cur_lr = lr * (1.0 - ep / epochs)                       # main.py:61
+        order = rng.permutation(N)                              # random.shuffle(self.dataset), data_loader.py:24
+        for lo in range(0, N, batch_size):
+            sel = order[lo:lo + batch_size]
+            feeds = dataset.assemble(sel, out=feeds, min_chars=4)
+            tr.set_batch_device(feeds)
+            tr.step(lr=cur_lr, drop_rate=drop_rate)
+            steps += 1
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+
+    def batches():
+        f = None
+        for lo in range(0, N, batch_size):
+            sel = np.arange(lo, min(N, lo + batch_size))
+            f = dataset.assemble(sel, out=None, labels=False, min_chars=4)
+            yield [dataset.records[i] for i in sel], f['video'], f['video_seq_len'], f['word_ids'], f['char_ids']
+    records, ious = infer_trainset(model, batches(), mc_dropout=mc_dropout)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    r3, r5, r7, mi = iou_metrics(ious)
+    m = dict(update_s=t1 - t0, train_s=t2 - t1, infer_s=t3 - t2, train_steps=steps, clips_per_s=N * epochs / max(t2 - t1, 1e-9),
+             r1i3=r3, r1i5=r5, r1i7=r7, miou=mi)
+    if log:
+        log('round %d: update_label %.3f s | train %d steps %.3f s (%.0f clips/s) | infer_trainset %.3f s | pseudo-label '
+            'R1@0.5 %.2f mIoU %.2f' % (I, m['update_s'], steps, m['train_s'], m['clips_per_s'], m['infer_s'], r5, mi))
+    return new_data, records, m

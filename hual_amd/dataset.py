@@ -1,0 +1,98 @@
+"""Training set resident in HBM + device-side batch assembly (csrc/assemble.hip through hual_assemble_batch).
+
+Replaces the per-step numpy work of the reference's loaders (TrainLoader.process_batch / TestLoader.process_batch,
+/root/reference/utils/data_loader.py:30-98,145-164) and the feed_dict upload of runner_utils.py:145-147: the features
+of every video (Charades: 3.2 GB fp32, ActivityNet at max_vlen 100: ~6 GB - small against 288 GB) are uploaded once,
+each step only sends the B sample ids.  Pseudo labels (s_ind / e_ind) are re-uploaded once per active-learning round.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib
+
+
+class DeviceDataset:
+    def __init__(self, records, visual_feats, device='cuda:0'):
+        """records: dicts with vid, w_ids, c_ids (and s_ind, e_ind for training sets), as produced by the reference's
+        dataset_gen (utils/data_gen.py:98-125); visual_feats: {vid: float32 [n_clips, vdim]} (data_utils.py:56-67)."""
+        if not torch.cuda.is_available():
+            raise lib.HualError('DeviceDataset needs a GPU: the HIP path has no CPU fallback')
+        self._lib = lib.load()
+        self.dev = torch.device(device)
+        self.records = records
+        vids = sorted({r['vid'] for r in records})
+        vid_id = {v: i for i, v in enumerate(vids)}
+        nclips = np.array([visual_feats[v].shape[0] for v in vids], dtype=np.int64)
+        self.vdim = int(visual_feats[vids[0]].shape[1])
+        feat_off = np.zeros(len(vids) + 1, dtype=np.int64)
+        feat_off[1:] = np.cumsum(nclips)
+        bank = torch.empty(int(feat_off[-1]), self.vdim, dtype=torch.float32, device=self.dev)
+        for i, v in enumerate(vids):
+            bank[int(feat_off[i]):int(feat_off[i + 1])] = torch.from_numpy(np.ascontiguousarray(visual_feats[v], dtype=np.float32))
+        self.feat_bank = bank
+        self.sample_vid_h = np.array([vid_id[r['vid']] for r in records], dtype=np.int32)
+        self.vlen_h = nclips[self.sample_vid_h].astype(np.int32)
+        self.nwords_h = np.array([len(r['w_ids']) for r in records], dtype=np.int32)
+        word_off = np.zeros(len(records) + 1, dtype=np.int32)
+        word_off[1:] = np.cumsum(self.nwords_h)
+        word_bank = np.array([w for r in records for w in r['w_ids']] + [0], dtype=np.int32)
+        nchars = np.array([len(c) for r in records for c in r['c_ids']], dtype=np.int32)
+        char_off = np.zeros(len(nchars) + 1, dtype=np.int32)
+        char_off[1:] = np.cumsum(nchars)
+        char_bank = np.array([x for r in records for c in r['c_ids'] for x in c] + [0], dtype=np.int32)
+        # longest word of each sample: the batch's C is the maximum over its samples (pad_char_seq, data_utils.py:143-155)
+        self.maxchars_h = np.array([max(len(c) for c in r['c_ids']) for r in records], dtype=np.int32)
+        up = lambda a: torch.from_numpy(a).to(self.dev)
+        self.feat_off, self.sample_vid = up(feat_off), up(self.sample_vid_h)
+        self.word_off, self.word_bank, self.char_off, self.char_bank = up(word_off), up(word_bank), up(char_off), up(char_bank)
+        self.s_ind = self.e_ind = None
+        if 's_ind' in records[0]:
+            self.set_labels([r['s_ind'] for r in records], [r['e_ind'] for r in records])
+        else:
+            self._struct()
+
+    def __len__(self):
+        return len(self.records)
+
+    def set_labels(self, s_ind, e_ind):
+        """new pseudo labels (frame indices) after an update_label round"""
+        self.s_ind = torch.from_numpy(np.ascontiguousarray(s_ind, dtype=np.int32)).to(self.dev)
+        self.e_ind = torch.from_numpy(np.ascontiguousarray(e_ind, dtype=np.int32)).to(self.dev)
+        self._struct()
+
+    def _struct(self):
+        p = lambda t: None if t is None else lib.ptr(t).value
+        self.ds = lib.hual_dataset(p(self.feat_bank), p(self.feat_off), self.vdim, p(self.sample_vid), p(self.word_off),
+                                   p(self.word_bank), p(self.char_off), p(self.char_bank), p(self.s_ind), p(self.e_ind))
+
+    def batch_shape(self, sel):
+        """(T, L, C) of the batch: maxima of its lengths, as the reference's padding produces them"""
+        sel = np.asarray(sel)
+        return int(self.vlen_h[sel].max()), int(self.nwords_h[sel].max()), int(self.maxchars_h[sel].max())
+
+    def assemble(self, sel, out=None, labels=True, min_chars=None):
+        """Gather the batch `sel` (sample ids) on the device.  Returns a dict of device tensors named like the feeds of
+        model.py:16-27.  out: a dict from a previous call with the same shape to write into (static buffers)."""
+        sel = np.ascontiguousarray(sel, dtype=np.int32)
+        B = len(sel)
+        T, L, C = self.batch_shape(sel)
+        if min_chars:
+            C = max(C, min_chars)
+        labels = labels and self.s_ind is not None
+        if out is None or out['video'].shape != (B, T, self.vdim) or out['char_ids'].shape != (B, L, C):
+            f32, i32, d = torch.float32, torch.int32, self.dev
+            out = dict(video=torch.empty(B, T, self.vdim, dtype=f32, device=d), video_seq_len=torch.empty(B, dtype=i32, device=d),
+                       word_ids=torch.empty(B, L, dtype=i32, device=d), char_ids=torch.empty(B, L, C, dtype=i32, device=d),
+                       sel=torch.empty(B, dtype=i32, device=d))
+            if labels:
+                out.update(y1=torch.empty(B, T, dtype=f32, device=d), y2=torch.empty(B, T, dtype=f32, device=d),
+                           match_labels=torch.empty(B, T, dtype=i32, device=d), inner_labels=torch.empty(B, T, dtype=f32, device=d))
+        out['sel'].copy_(torch.from_numpy(sel))
+        p = lib.ptr
+        lib.check(self._lib.hual_assemble_batch(
+            ctypes.byref(self.ds), p(out['sel']), B, T, L, C, p(out['video']), p(out['video_seq_len']), p(out['word_ids']),
+            p(out['char_ids']), p(out['y1']) if labels else None, p(out['y2']) if labels else None,
+            p(out['match_labels']) if labels else None, p(out['inner_labels']) if labels else None, lib.stream_ptr()))
+        return out

@@ -86,6 +86,41 @@ class Trainer:
         if self.dp:
             self.match_denom = hdist.match_denominator(int(np.sum(np.asarray(lens))), dev)
 
+    def set_batch_device(self, feeds):
+        """Point the step at feeds that already live on the device (DeviceDataset.assemble): no host copy, no upload.
+        Shapes may change from batch to batch (T = longest video of the batch), so this path launches eagerly."""
+        m, dev = self.m, self.m.device
+        B, T, V = feeds['video'].shape
+        L, C = feeds['word_ids'].shape[1], feeds['char_ids'].shape[2]
+        self.use_graph, self.graph = False, None
+        self._tables_ready = False
+        self.video, self.lens, self.word_ids, self.char_ids = (feeds[k] for k in ('video', 'video_seq_len', 'word_ids', 'char_ids'))
+        self.y1, self.y2, self.match, self.inner = (feeds[k] for k in ('y1', 'y2', 'match_labels', 'inner_labels'))
+        if (B, T, L, C) != self.shape:
+            self.shape = (B, T, L, C)
+            self.start_logits = torch.empty(B, T, device=dev)
+            self.end_logits = torch.empty(B, T, device=dev)
+            self.match_scores = torch.empty(B, T, 4, device=dev)
+            self.start_index = torch.empty(B, device=dev, dtype=torch.int64)
+            self.end_index = torch.empty(B, device=dev, dtype=torch.int64)
+            self.loss_terms = torch.zeros(4, device=dev)
+            if self.dp:
+                Bg = B * self.world
+                self.align_scratch = torch.empty(2 * Bg * Bg, device=dev)
+                self.d_that_all = torch.empty(Bg, 128, device=dev)
+                self.d_vhat_all = torch.empty(Bg, 128, device=dev)
+                self.align_loss = torch.zeros(1, device=dev)
+        self.ws = m._workspace(B, T, L, C)
+        p = lib.ptr
+        self.bt = lib.hual_batch(p(self.video).value, p(self.lens).value, p(self.word_ids).value, p(self.char_ids).value,
+                                 B, T, L, C)
+        self.lab = lib.hual_labels(p(self.y1).value, p(self.y2).value, p(self.match).value, p(self.inner).value)
+        self.out = lib.hual_outputs(p(self.start_logits).value, p(self.end_logits).value, p(self.match_scores).value,
+                                    p(self.start_index).value, p(self.end_index).value, p(self.loss_terms).value)
+        self.match_denom = 0.0
+        if self.dp:
+            self.match_denom = hdist.match_denominator(int(feeds['video_seq_len'].sum().item()), dev)
+
     # ------------------------------------------------------------------ one step
     def _opts(self, drop_rate, align_external):
         # static_tables: all buffers of this trainer are static per shape, so after one backward on them the job tables
