@@ -1,0 +1,47 @@
+// fp32 products on the bf16 matrix cores: x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (both round-to-nearest), and
+//   a * b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi            (three v_mfma_*_bf16, fp32 accumulate)
+// The dropped terms are <= 2^-16 |a b| per product (lo*lo and the rounding of lo), unbiased; sums over K = 128..9472
+// land within ~1e-6 relative of the fp32 result.  One v_mfma_f32_32x32x16_bf16 does the work of 8 v_mfma_f32_32x32x2_f32
+// in half their time, so the three passes cost 3/16 of the fp32 matrix-core time.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// (x0, x1) -> packed bf16 pairs {lo16 = element 0, hi16 = element 1}: the high parts and the residuals
+__device__ __forceinline__ void bf16_split_pair(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  const bf16x2_t h = __builtin_convertvector((f32x2_t){x0, x1}, bf16x2_t);        // v_cvt_pk_bf16_f32 (RNE)
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float h0 = __builtin_bit_cast(float, hi << 16);
+  const float h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+  const bf16x2_t l = __builtin_convertvector((f32x2_t){x0 - h0, x1 - h1}, bf16x2_t);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ void bf16_split4(const float4& x, uint2& hi, uint2& lo) {
+  bf16_split_pair(x.x, x.y, hi.x, lo.x);
+  bf16_split_pair(x.z, x.w, hi.y, lo.y);
+}
+
+// Byte offset of 16-byte chunk `ch` (0..15) of row `row` in a [rows][128 x bf16] LDS tile with plain 256-byte rows and the
+// XOR swizzle that keeps BOTH ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads conflict free
+// (cdna_hip_programming.md T10, image (b)).
+__device__ __forceinline__ int tile256_off(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+// ds_read_b64_tr_b16: per group of 16 lanes, a block of 4 rows x 16 columns of 16-bit elements is delivered column-major:
+// lane 4q+p of the group supplies the address of row q, columns 4p..4p+3; lane i receives column i, rows 0..3.
+// EXEC must be all ones.
+__device__ __forceinline__ s16x4 lds_read_tr16(const char* lds_base, int byte_off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_base + byte_off));
+}
+__device__ __forceinline__ bf16x8 join_tr(s16x4 a, s16x4 b) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}

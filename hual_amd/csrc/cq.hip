@@ -459,11 +459,13 @@ int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, 
 
 int launch_tri_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const CqParams& p, const CqGrads& pg, const RowSpace& rs,
                         const DropCfg& drop, const float* dXa, const float* dXb, hipStream_t s) {
+  // every block ends in 384 float atomics on the same 384 addresses (~30 ns each when queued on one address): cap the
+  // grid and let the blocks stride over the rows
   int n = cdiv(rs.Nv, 8);
-  n = n < 512 ? n : 512;
+  n = n < 128 ? n : 128;
   HUAL_LAUNCH(0.0, 0.0, tri_bwd_kernel, dim3(n), dim3(256), 0, s, b, g, p, pg, rs, drop, dXa, dXb, 0, rs.Nv);
   n = cdiv(rs.Nq, 8);
-  n = n < 512 ? n : 512;
+  n = n < 64 ? n : 64;
   HUAL_LAUNCH(0.0, 0.0, tri_bwd_kernel, dim3(n), dim3(256), 0, s, b, g, p, pg, rs, drop, dXa, dXb, rs.Nv, rs.R);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

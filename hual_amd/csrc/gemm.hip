@@ -15,6 +15,7 @@
 // atomic shape of MI355X_MICROARCH.md "Global float atomics").
 #include "gemm.h"
 #include "philox.h"
+#include "bf16x3.h"
 #include "prof.h"
 #include <stdlib.h>
 #include <stdio.h>
@@ -779,6 +780,164 @@ __global__ __launch_bounds__(256) void dw_kernel(DwBatch batch, const DwJob* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// dw_bf16_kernel: the same job semantics, tiling (128 x 128 gradient tile per block over a chunk of rows, one 64 x 64
+// quadrant per wave) and atomics epilogue as dw_kernel, with the products on the bf16 matrix cores as three passes of
+// split operands (bf16x3.h).  The reduction index of dW = A^T.dY is the ROW index m, which is the strided direction of
+// both operands in memory: the 32-row tiles are staged row-major as bf16 (hi and lo planes, 256-byte rows, XOR swizzled)
+// and read back with ds_read_b64_tr_b16, the LDS transpose read, so each lane receives 8 consecutive rows of its column.
+// Per 32-row tile and wave: 24 MFMAs (768 cycles) instead of 64 (4096 cycles); the kernel is then bound by streaming
+// the operands from HBM (every job reads its A and dY once).
+#define DWB_PLANE (DW_TM * 256)          // bytes of one [32][128] bf16 plane
+template <bool FROM_TABLE>
+__global__ __launch_bounds__(256) void dw_bf16_kernel(DwBatch batch, const DwJob* __restrict__ table, DropCfg drop,
+                                                      int rows_per_block) {
+  extern __shared__ float lds[];     // 2 buffers x {A_hi, A_lo, Y_hi, Y_lo} planes
+  __shared__ float4 bred[8][32];
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const DwJob& job = FROM_TABLE ? table[blockIdx.z] : batch.j[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int kq = wave >> 1, nq = wave & 1;
+  const int M = job.M;
+  int p = 0, kb = blockIdx.y;
+  for (p = 0; p < job.npieces; ++p) {
+    const int nkb = (job.kw[p] + 127) >> 7;
+    if (kb < nkb) break;
+    kb -= nkb;
+  }
+  if (p >= job.npieces) return;                 // block-uniform
+  const int m_lo = blockIdx.x * rows_per_block;
+  if (m_lo >= M) return;                        // block-uniform
+  const int m_hi = min(m_lo + rows_per_block, M);
+  const int k0 = kb * 128;
+  const int kw = job.kw[p];
+  const float* Ap = job.A[p];
+  const float* A2p = job.A2[p];
+  const int lda = job.lda[p], lda2 = job.lda2[p];
+  const float* Yp = job.dY;
+  const int ldy = job.ldy;
+  const bool adrop = job.a_drop_site >= 0 && drop.enabled;
+  const uint32_t asite = (uint32_t)job.a_drop_site;
+  const uint32_t arow0 = job.a_drop_row0;
+  const bool dob = (job.db != nullptr) && p == 0 && kb == 0;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+  float4 bsum = f4zero();
+
+  // staging: thread -> rows (tid>>5) + 8u, columns 4*(tid&31)..+3 of both tiles
+  const int srow = threadIdx.x >> 5, c4 = threadIdx.x & 31;
+  float4 ra[4], ry[4];
+  auto stage_load = [&](int mt) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = mt + srow + 8 * u;
+      float4 a = f4zero(), y = f4zero();
+      if (m < m_hi) {
+        const int k = k0 + 4 * c4;
+        if (k < kw) {
+          a = ld4(Ap + (size_t)m * lda + k);
+          if (A2p) a = f4mul(a, ld4(A2p + (size_t)m * lda2 + k));
+          if (adrop) a = apply_drop4(drop, asite, arow0 + (uint32_t)m, (uint32_t)(k >> 2), a);
+        }
+        y = ld4(Yp + (size_t)m * ldy + 4 * c4);
+      }
+      ra[u] = a;
+      ry[u] = y;
+    }
+  };
+  auto stage_store = [&](int buf) {
+    char* base = ldsb + buf * 4 * DWB_PLANE;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = srow + 8 * u;
+      const int off = tile256_off(row, c4 >> 1) + 8 * (c4 & 1);
+      uint2 hi, lo;
+      bf16_split4(ra[u], hi, lo);
+      *reinterpret_cast<uint2*>(base + off) = hi;
+      *reinterpret_cast<uint2*>(base + DWB_PLANE + off) = lo;
+      bf16_split4(ry[u], hi, lo);
+      *reinterpret_cast<uint2*>(base + 2 * DWB_PLANE + off) = hi;
+      *reinterpret_cast<uint2*>(base + 3 * DWB_PLANE + off) = lo;
+      bsum = f4add(bsum, ry[u]);
+    }
+  };
+  // transposed-read addressing: 16-lane group g' = lane>>4 takes the 4-row x 16-column block of columns
+  // colbase + 16*(g'&1), rows 16*ks + 8*(g'>>1) + 4*rr; lane 4q+pp of the group supplies row q, columns 4pp..4pp+3
+  const int gq = (lane >> 2) & 3, gp = lane & 3, ghalf = (lane >> 4) & 1, gh = lane >> 5;
+  auto tr_off = [&](int colbase, int ks, int rr) {
+    const int row = 16 * ks + 8 * gh + 4 * rr + gq;
+    const int ch = ((colbase + 16 * ghalf) >> 3) + (gp >> 1);
+    return tile256_off(row, ch) + 8 * (gp & 1);
+  };
+
+  stage_load(m_lo);
+  stage_store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int mt = m_lo; mt < m_hi; mt += DW_TM) {
+    const bool more = (mt + DW_TM) < m_hi;
+    if (more) stage_load(mt + DW_TM);            // global loads in flight under the MFMAs below
+    const char* base = ldsb + buf * 4 * DWB_PLANE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], al[2], yh[2], yl[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int o0 = tr_off(kq * 64 + 32 * c, ks, 0), o1 = tr_off(kq * 64 + 32 * c, ks, 1);
+        ah[c] = join_tr(lds_read_tr16(base, o0), lds_read_tr16(base, o1));
+        al[c] = join_tr(lds_read_tr16(base + DWB_PLANE, o0), lds_read_tr16(base + DWB_PLANE, o1));
+        const int y0 = tr_off(nq * 64 + 32 * c, ks, 0), y1 = tr_off(nq * 64 + 32 * c, ks, 1);
+        yh[c] = join_tr(lds_read_tr16(base + 2 * DWB_PLANE, y0), lds_read_tr16(base + 2 * DWB_PLANE, y1));
+        yl[c] = join_tr(lds_read_tr16(base + 3 * DWB_PLANE, y0), lds_read_tr16(base + 3 * DWB_PLANE, y1));
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], yh[t], acc[c][t], 0, 0, 0);
+          acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], yl[t], acc[c][t], 0, 0, 0);
+          acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c], yh[t], acc[c][t], 0, 0, 0);
+        }
+    }
+    if (more) stage_store(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // each wave owns its quadrant: no cross-wave reduction, straight to global atomics.  Accumulator register r of lane
+  // (i, h) is gradient row 32c + (r&3) + 8*(r>>2) + 4h, column 32t + i of the quadrant.
+  float* dWp = job.dW[p];
+  const int kbase = k0 + kq * 64, nbase = nq * 64;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = kbase + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int n = nbase + 32 * t + i;
+        if (k < kw) atomicAdd(dWp + (size_t)k * job.ldw + n, acc[c][t][r]);
+      }
+  if (dob) {                                   // block-uniform
+    bred[srow][c4] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int cc = threadIdx.x;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += reinterpret_cast<const float*>(&bred[k][cc >> 2])[cc & 3];
+      atomicAdd(job.db + cc, s);
+    }
+  }
+}
+
 namespace hual {
 
 int launch_transpose_weights(const uint32_t* offs, const int* Ks, const int* Ns, int n, const float* src, float* dst, hipStream_t stream) {
@@ -925,7 +1084,8 @@ static int dw_auto_rows(const DwJob* jobs, int n) {
     }
     static const int slots = []() { const char* e = getenv("HUAL_DW_SLOTS"); return e ? atoi(e) : 512; }();
     const long rounds = (blocks + slots - 1) / slots;
-    const double cost = (double)rounds * (r + 64.0);
+    static const double fixed = []() { const char* e = getenv("HUAL_DW_FIXED"); return e ? atof(e) : 64.0; }();
+    const double cost = (double)rounds * (r + fixed);
     if (dbg) fprintf(stderr, "[dw] rows %4d blocks %5ld rounds %2ld cost %.0f\n", r, blocks, rounds, cost);
     if (cost < best_cost) { best_cost = cost; best = r; }
   }
@@ -934,15 +1094,23 @@ static int dw_auto_rows(const DwJob* jobs, int n) {
 
 int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block, hipStream_t stream, DwJob* table,
               bool write_table) {
-  if (rows_per_block == 0) rows_per_block = dw_auto_rows(jobs, n);
+  static const int rows_env = []() { const char* e = getenv("HUAL_DW_ROWS"); return e ? atoi(e) : 0; }();
+  if (rows_per_block == 0) rows_per_block = rows_env > 0 ? rows_env : dw_auto_rows(jobs, n);
   HUAL_REQUIRE(rows_per_block >= DW_TM && (rows_per_block % DW_TM) == 0, "launch_dw: rows_per_block must be a multiple of 32");
-  static bool attr = false;
+  static bool attr = false, attr2 = false;
   if (!attr) {
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr = true;
   }
-  size_t lds = (size_t)4 * DW_TM * DW_LD * sizeof(float);
+  // HUAL_DW_IMPL=0: fp32 MFMA kernel (dw_kernel); default: split-bf16 kernel (dw_bf16_kernel)
+  static const int dw_impl = []() { const char* e = getenv("HUAL_DW_IMPL"); return e ? atoi(e) : 1; }();
+  if (!attr2) {
+    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr2 = true;
+  }
+  size_t lds = dw_impl ? (size_t)8 * DWB_PLANE : (size_t)4 * DW_TM * DW_LD * sizeof(float);
   // HUAL_DW_LDS_KB pads the LDS request: above 80 KB only ONE block fits a CU, which leaves room for the blocks of
   // other kernels when the launch runs on a side stream under the dX chain (experiment)
   static const int lds_kb = []() { const char* e = getenv("HUAL_DW_LDS_KB"); return e ? atoi(e) : 0; }();
@@ -966,7 +1134,8 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
     DwBatch dummy;
     dw_job_init(dummy.j[0]);
     dim3 grid(cdiv(maxM, rows_per_block), maxKb, n), block(256);
-    HUAL_LAUNCH(flops, bytes, dw_kernel<true>, grid, block, lds, stream, dummy, (const DwJob*)table, drop, rows_per_block);
+    if (dw_impl) HUAL_LAUNCH(flops, bytes, dw_bf16_kernel<true>, grid, block, lds, stream, dummy, (const DwJob*)table, drop, rows_per_block);
+    else HUAL_LAUNCH(flops, bytes, dw_kernel<true>, grid, block, lds, stream, dummy, (const DwJob*)table, drop, rows_per_block);
     HUAL_CHECK_HIP(hipGetLastError());
     return 0;
   }
@@ -984,7 +1153,8 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
       maxKb = kbs > maxKb ? kbs : maxKb;
     }
     dim3 grid(cdiv(maxM, rows_per_block), maxKb, cnt), block(256);
-    HUAL_LAUNCH(flops, bytes, dw_kernel<false>, grid, block, lds, stream, b, (const DwJob*)nullptr, drop, rows_per_block);
+    if (dw_impl) HUAL_LAUNCH(flops, bytes, dw_bf16_kernel<false>, grid, block, lds, stream, b, (const DwJob*)nullptr, drop, rows_per_block);
+    else HUAL_LAUNCH(flops, bytes, dw_kernel<false>, grid, block, lds, stream, b, (const DwJob*)nullptr, drop, rows_per_block);
     HUAL_CHECK_HIP(hipGetLastError());
   }
   return 0;

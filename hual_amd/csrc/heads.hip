@@ -26,19 +26,22 @@ __device__ __forceinline__ float block_max(float v, float* sm) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// weighted pooling + pooled half of cq_cat/dense.  One block (128 threads = columns) per clip.
-__global__ __launch_bounds__(128) void pool_fwd_kernel(PoolArgs a, RowSpace rs) {
+// weighted pooling + pooled half of cq_cat/dense.  One block of 256 threads per clip: the L row dots are spread over
+// 8 groups of 32 lanes (float4 per lane, shuffle reduction) instead of L block-wide reductions in sequence.
+__global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs a, RowSpace rs) {
   __shared__ float al[256];
   __shared__ float pooled[HUAL_D];
-  __shared__ float sm[4];
-  const int b = blockIdx.x, c = threadIdx.x;
+  __shared__ float part[HUAL_D];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int l32 = tid & 31, grp = tid >> 5;
   const int L = rs.L;
   const float* F = a.F2 + (size_t)(rs.Nv + b * L) * HUAL_D;
   const float* m = rs.rowmask + rs.Nv + b * L;
-  const float w = a.wp[c];
-  for (int l = 0; l < L; ++l) {
-    float d = block_sum(F[(size_t)l * HUAL_D + c] * w, sm);
-    if (c == 0) al[l] = d * m[l] + HUAL_MASK_VALUE * (1.0f - m[l]);   // mask_logits, layers.py:139
+  const float4 w4 = ld4(a.wp + 4 * l32);
+  for (int l = grp; l < L; l += 8) {
+    const float4 f = ld4(F + (size_t)l * HUAL_D + 4 * l32);
+    const float d = half_sum32(f.x * w4.x + f.y * w4.y + f.z * w4.z + f.w * w4.w);
+    if (l32 == 0) al[l] = d * m[l] + HUAL_MASK_VALUE * (1.0f - m[l]);   // mask_logits, layers.py:139
   }
   __syncthreads();
   float mx = -INFINITY;
@@ -46,18 +49,24 @@ __global__ __launch_bounds__(128) void pool_fwd_kernel(PoolArgs a, RowSpace rs) 
   float sum = 0.f;
   for (int l = 0; l < L; ++l) sum += __expf(al[l] - mx);
   const float inv = 1.0f / sum;
-  float p = 0.f;
-  for (int l = 0; l < L; ++l) {
-    const float alpha = __expf(al[l] - mx) * inv;
-    if (c == 0) a.alpha[b * L + l] = alpha;
-    p = fmaf(alpha, F[(size_t)l * HUAL_D + c], p);
+  const int c = tid & 127, half = tid >> 7;
+  if (half == 0) {
+    float p = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const float alpha = __expf(al[l] - mx) * inv;
+      if (c == 0) a.alpha[b * L + l] = alpha;
+      p = fmaf(alpha, F[(size_t)l * HUAL_D + c], p);
+    }
+    pooled[c] = p;
+    a.pooled[b * HUAL_D + c] = p;
   }
-  pooled[c] = p;
-  a.pooled[b * HUAL_D + c] = p;
   __syncthreads();
   float o = 0.f;
-  for (int k = 0; k < HUAL_D; ++k) o = fmaf(pooled[k], a.Wbot[(size_t)k * HUAL_D + c], o);
-  a.PW[b * HUAL_D + c] = o;
+#pragma unroll 8
+  for (int k = half * 64; k < half * 64 + 64; ++k) o = fmaf(pooled[k], a.Wbot[(size_t)k * HUAL_D + c], o);
+  if (half) part[c] = o;
+  __syncthreads();
+  if (!half) a.PW[b * HUAL_D + c] = o + part[c];
 }
 
 // stage 1 (512 threads): dPW[b] = sum_t dFuse[b,t,:]   (4 row groups, then LDS)
@@ -73,27 +82,44 @@ __global__ __launch_bounds__(512) void pool_dpw_kernel(PoolBwd g, RowSpace rs) {
   if (grp == 0) g.dPW[b * HUAL_D + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
 }
 
-__global__ __launch_bounds__(128) void pool_bwd_kernel(PoolArgs a, PoolBwd g, RowSpace rs) {
+__global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs a, PoolBwd g, RowSpace rs) {
   __shared__ float dpw[HUAL_D];
+  __shared__ float dps[HUAL_D];
+  __shared__ float part[HUAL_D];
   __shared__ float da[256];
-  __shared__ float sm[4];
-  const int b = blockIdx.x, c = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int c = tid & 127, half = tid >> 7;
+  const int l32 = tid & 31, grp = tid >> 5;
   const int L = rs.L;
-  dpw[c] = g.dPW[b * HUAL_D + c];
+  if (tid < HUAL_D) dpw[tid] = g.dPW[b * HUAL_D + tid];
   __syncthreads();
-  // dpooled[c] = sum_n dPW[n] * Wbot[c][n]
+  // dpooled[c] = sum_n dPW[n] * Wbot[c][n]   (two halves of n, float4 loads along the row of Wbot)
   float dp = 0.f;
-  for (int n = 0; n < HUAL_D; ++n) dp = fmaf(dpw[n], a.Wbot[(size_t)c * HUAL_D + n], dp);
+  const float* wrow = a.Wbot + (size_t)c * HUAL_D + half * 64;
+#pragma unroll 4
+  for (int n = 0; n < 64; n += 4) {
+    const float4 w = ld4(wrow + n);
+    const float* d = dpw + half * 64 + n;
+    dp += d[0] * w.x + d[1] * w.y + d[2] * w.z + d[3] * w.w;
+  }
+  if (half) part[c] = dp;
+  __syncthreads();
+  if (!half) dps[c] = dp + part[c];
+  __syncthreads();
   const float* F = a.F2 + (size_t)(rs.Nv + b * L) * HUAL_D;
   const float* m = rs.rowmask + rs.Nv + b * L;
   // dalpha[l] = dpooled . F[l]
-  float dot_acc = 0.f;
-  for (int l = 0; l < L; ++l) {
-    float d = block_sum(dp * F[(size_t)l * HUAL_D + c], sm);
-    if (c == 0) da[l] = d;
-    dot_acc += a.alpha[b * L + l] * d;     // identical in every thread
+  const float4 dp4 = *reinterpret_cast<const float4*>(dps + 4 * l32);
+  for (int l = grp; l < L; l += 8) {
+    const float4 f = ld4(F + (size_t)l * HUAL_D + 4 * l32);
+    const float d = half_sum32(f.x * dp4.x + f.y * dp4.y + f.z * dp4.z + f.w * dp4.w);
+    if (l32 == 0) da[l] = d;
   }
   __syncthreads();
+  float dot_acc = 0.f;
+  for (int l = 0; l < L; ++l) dot_acc += a.alpha[b * L + l] * da[l];     // identical in every thread
+  if (half) return;
+  dp = dps[c];
   const float w = a.wp[c];
   float dw = 0.f;
   float* dF = g.dF2 + (size_t)(rs.Nv + b * L) * HUAL_D;
@@ -396,8 +422,10 @@ __global__ __launch_bounds__(512) void align_pool_kernel(AlignPool a, RowSpace r
   const int b = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
   const int L = rs.L, T = rs.T;
   float tc = 0.f, vc = 0.f;
-  for (int l = 0; l < L; ++l) tc += rs.rowmask[rs.Nv + b * L + l];
-  for (int t = 0; t < T; ++t) vc += rs.rowmask[b * T + t];
+  for (int l = threadIdx.x; l < L; l += 512) tc += rs.rowmask[rs.Nv + b * L + l];
+  for (int t = threadIdx.x; t < T; t += 512) vc += rs.rowmask[b * T + t];
+  tc = block_sum(tc, sm);       // exact: the mask is 0/1
+  vc = block_sum(vc, sm);
   float ts = 0.f, vs = 0.f;
   for (int l = grp; l < L; l += 4) ts += a.F2[(size_t)(rs.Nv + b * L + l) * HUAL_D + c];     // padded words included (layers.py:214)
   for (int t = grp; t < T; t += 4) vs += a.F1[(size_t)(b * T + t) * HUAL_D + c] * (a.inner[b * T + t] / vc);
@@ -477,12 +505,19 @@ __global__ __launch_bounds__(256) void align_sim_rows_kernel(AlignSim a) {
   }
 }
 // column part: dvhat_j += sum_i dq[i][j] that_i + da[i][j] vhat_i
-__global__ __launch_bounds__(128) void align_sim_cols_kernel(AlignSim a) {
-  const int j = blockIdx.x, c = threadIdx.x, Bg = a.Bg;
+__global__ __launch_bounds__(256) void align_sim_cols_kernel(AlignSim a) {
+  __shared__ float cq[1024], ca[1024];
+  __shared__ float part[HUAL_D];
+  const int j = blockIdx.x, c = threadIdx.x & 127, half = threadIdx.x >> 7, Bg = a.Bg;
+  for (int i = threadIdx.x; i < Bg; i += 256) { cq[i] = a.dq[(size_t)i * Bg + j]; ca[i] = a.da[(size_t)i * Bg + j]; }
+  __syncthreads();
   float s = 0.f;
-  for (int i = 0; i < Bg; ++i)
-    s += a.dq[(size_t)i * Bg + j] * a.that[(size_t)i * HUAL_D + c] + a.da[(size_t)i * Bg + j] * a.vhat[(size_t)i * HUAL_D + c];
-  a.dvhat[j * HUAL_D + c] += s;
+#pragma unroll 4
+  for (int i = half; i < Bg; i += 2)
+    s += cq[i] * a.that[(size_t)i * HUAL_D + c] + ca[i] * a.vhat[(size_t)i * HUAL_D + c];
+  if (half) part[c] = s;
+  __syncthreads();
+  if (!half) a.dvhat[j * HUAL_D + c] += s + part[c];
 }
 
 __global__ __launch_bounds__(512) void align_pool_bwd_kernel(AlignPool a, AlignPoolBwd g, RowSpace rs) {
@@ -500,8 +535,10 @@ __global__ __launch_bounds__(512) void align_pool_bwd_kernel(AlignPool a, AlignP
   const float dtp = tn > L2_EPS ? rt * (dth - th * tdot) : rt * dth;
   const float dvp = vn > L2_EPS ? rv * (dvh - vh * vdot) : rv * dvh;
   float tc = 0.f, vc = 0.f;
-  for (int l = 0; l < L; ++l) tc += rs.rowmask[rs.Nv + b * L + l];
-  for (int t = 0; t < T; ++t) vc += rs.rowmask[b * T + t];
+  for (int l = threadIdx.x; l < L; l += 512) tc += rs.rowmask[rs.Nv + b * L + l];
+  for (int t = threadIdx.x; t < T; t += 512) vc += rs.rowmask[b * T + t];
+  tc = block_sum(tc, sm);
+  vc = block_sum(vc, sm);
   const float dts = dtp / tc;
   for (int l = grp; l < L; l += 4) g.dF2[(size_t)(rs.Nv + b * L + l) * HUAL_D + c] = dts;
   for (int t = grp; t < T; t += 4) g.dF1[(size_t)(b * T + t) * HUAL_D + c] += dvp * (a.inner[b * T + t] / vc);
@@ -511,22 +548,25 @@ namespace hual {
 
 int launch_pool_fwd(const PoolArgs& a, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(rs.L <= 256, "pool: L <= 256");
-  HUAL_LAUNCH(0.0, 0.0, pool_fwd_kernel, dim3(rs.B), dim3(128), 0, s, a, rs);
+  HUAL_LAUNCH(0.0, 0.0, pool_fwd_kernel, dim3(rs.B), dim3(256), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_pool_bwd(const PoolArgs& a, const PoolBwd& g, const RowSpace& rs, hipStream_t s) {
   HUAL_LAUNCH(0.0, 0.0, pool_dpw_kernel, dim3(rs.B), dim3(512), 0, s, g, rs);
-  HUAL_LAUNCH(0.0, 0.0, pool_bwd_kernel, dim3(rs.B), dim3(128), 0, s, a, g, rs);
+  HUAL_LAUNCH(0.0, 0.0, pool_bwd_kernel, dim3(rs.B), dim3(256), 0, s, a, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
+// Grid caps of the kernels below that end in atomics on a handful of addresses: float atomics queued on ONE address
+// retire at ~30 ns each on MI355X (match_fwd with 1024 blocks spent 30 us on 2 x 1024 of them), so those kernels use
+// few blocks with a grid-stride loop over the rows.
 static int rowgrid(int R, int cap) {
   int g = cdiv(R, 8);
   return g < cap ? (g > 0 ? g : 1) : cap;
 }
 int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, match_fwd_kernel, dim3(rowgrid(rs.Nv, 1024)), dim3(256), 0, s, a, rs);
+  HUAL_LAUNCH(0.0, 0.0, match_fwd_kernel, dim3(rowgrid(rs.Nv, 128)), dim3(256), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -536,7 +576,7 @@ int launch_match_denominator(float* loss_acc, float override_denom, hipStream_t 
   return 0;
 }
 int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, match_bwd_kernel, dim3(rowgrid(rs.Nv, 256)), dim3(256), 0, s, a, g, rs);
+  HUAL_LAUNCH(0.0, 0.0, match_bwd_kernel, dim3(rowgrid(rs.Nv, 64)), dim3(256), 0, s, a, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -556,7 +596,7 @@ int launch_rowdot_fwd(const DotArgs& a, hipStream_t s) {
   return 0;
 }
 int launch_rowdot_bwd(const DotArgs& a, const DotBwd& g, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, rowdot_bwd_kernel, dim3(rowgrid(a.R, 256), 2), dim3(256), 0, s, a, g);
+  HUAL_LAUNCH(0.0, 0.0, rowdot_bwd_kernel, dim3(rowgrid(a.R, 64), 2), dim3(256), 0, s, a, g);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -574,7 +614,7 @@ int launch_align_pool(const AlignPool& a, const RowSpace& rs, hipStream_t s) {
 int launch_align_sim(const AlignSim& a, hipStream_t s) {
   HUAL_REQUIRE(a.Bg >= 1 && a.Bg <= 1024, "align: global batch <= 1024");
   HUAL_LAUNCH(0.0, 0.0, align_sim_rows_kernel, dim3(a.Bg), dim3(256), 0, s, a);
-  HUAL_LAUNCH(0.0, 0.0, align_sim_cols_kernel, dim3(a.Bg), dim3(128), 0, s, a);
+  HUAL_LAUNCH(0.0, 0.0, align_sim_cols_kernel, dim3(a.Bg), dim3(256), 0, s, a);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
