@@ -44,4 +44,30 @@ int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW,
   return launch_dw(&j, 1, d, rows_per_block > 0 ? rows_per_block : 1024, (hipStream_t)stream);
 }
 
+int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, const float* bias, float* Y, int ldy, int M,
+                       int K, int N, int act, void* scratch, uint64_t scratch_bytes, void* stream) {
+  HUAL_REQUIRE(A && W && Y && scratch, "hual_linear_bf16x3: null pointer");
+  HUAL_REQUIRE(M > 0 && K > 0 && N > 0 && act >= 0 && act <= 2, "hual_linear_bf16x3: bad shape / act");
+  GemmJob j;
+  gemm_job_init(j);
+  j.npieces = 1;
+  j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.ldw = 128; j.bias = bias;
+  j.M = M; j.N = N; j.act = act; j.Y = Y; j.ldy = ldy;
+  j.W[0] = reinterpret_cast<const float*>(scratch);
+  const uint32_t off = 0, boff = 0;
+  if (!trans_w) {        // Y = act(A[M,K] . W[K,128] + bias)
+    HUAL_REQUIRE(N == 128 && K % 8 == 0, "hual_linear_bf16x3: W must be [K,128] with K % 8 == 0");
+    HUAL_REQUIRE(scratch_bytes >= (uint64_t)K * 512, "hual_linear_bf16x3: scratch too small (K * 512 bytes)");
+    int rc = launch_pack_weights(&off, &K, nullptr, 1, W, (char*)scratch, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+  } else {               // Y[M,N] = A[M,128] . W^T, W stored [N,128]  (dX of a dense layer with weight W)
+    HUAL_REQUIRE(K == 128 && N % 8 == 0, "hual_linear_bf16x3: transposed use needs K == 128 and N % 8 == 0");
+    HUAL_REQUIRE(scratch_bytes >= (uint64_t)((N + 127) / 128) * HUAL_PACK_BLOCK_BYTES, "hual_linear_bf16x3: scratch too small");
+    int rc = launch_pack_weights(&off, &N, &boff, 1, W, nullptr, (char*)scratch, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  DropCfg d = make_dropcfg(nullptr, 0.f);
+  return launch_gemm_bf16(&j, 1, d, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -83,6 +83,14 @@ struct DwBatch {
 // dst[off + n*K + k] = src[off + k*N + n] for n dense weights [K,N] inside the flat parameter buffer
 int launch_transpose_weights(const uint32_t* offs, const int* Ks, const int* Ns, int n, const float* src, float* dst,
                              hipStream_t stream);
+// Split-bf16 path (gemm_bf16_kernel, bf16x3.h).  launch_pack_weights writes, for n dense weights [K,128] at float offsets
+// offs[] of P, the forward image at fwd + 4*off and the image of the transposed weight (for dX) at bwd + boffs[]
+// (ceil(K/128) blocks of 64 KB); either destination may be null.  launch_gemm_bf16 takes jobs whose W[p] / W2[p] point at
+// such images (reinterpreted) - N > 128 walks the 64 KB column blocks of a backward image.
+#define HUAL_PACK_BLOCK_BYTES (128 * 512)
+int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
+                        hipStream_t stream);
+int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
 void gemm_job_init(GemmJob& j);
 void dw_job_init(DwJob& j);
 // enqueue `n` jobs (n <= HUAL_MAX_JOBS) as ONE launch on `stream`

@@ -446,6 +446,216 @@ __global__ __launch_bounds__(RT * 128) void gemm_lds_kernel(GemmBatch batch, Dro
   epi_apply<DUAL>(job, drop, epi, acc, acc2, rowbase, n0, j, g);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Split-bf16 dense kernel.  Same jobs, same wave -> (16 rows x 64 columns) mapping, same two-stage LDS-DMA pipeline and
+// the same epilogue as gemm_lds_kernel; the products run as three v_mfma_f32_16x16x32_bf16 passes on split operands
+// (bf16x3.h): 48 MFMAs x 16 cycles per 128-deep layer and wave instead of 128 x 32.
+//   * weights come pre-split from pack_weights_kernel: per K row 256 B of bf16 high parts then 256 B of residuals, the
+//     128 columns stored in the order that makes the transposed LDS read hand lane j of tile t column 4j + t (the
+//     accumulator -> column map of the epilogue).  A stage (64 K rows) is two [64][256 B] tiles (hi, lo) in the
+//     XOR-swizzled dual-use layout of bf16x3.h; the swizzle is applied on the GLOBAL side of the LDS-DMA (lane l of a
+//     1 KB piece fetches chunk (l&15) ^ sw(row) of its row), the LDS side of global_load_lds being lane-linear.
+//   * B fragments: ds_read_b64_tr_b16 (k is the strided direction of a [k][n] image), 2 reads per tile and plane;
+//   * A fragments: lane (j, g) loads 8 consecutive k of row j as two float4 and splits them right before the MFMAs.
+// dX = dY.W^T uses the same kernel on the image of the transposed weight (pack_weights_kernel writes both).
+#define GB_TILE (GL_KS * 256)            // bytes of one [64][128 x bf16] tile
+#define GB_STAGE (2 * GB_TILE)           // hi + lo
+#define GB_COLBLOCK (128 * 512)          // bytes between the images of consecutive 128-column blocks (dX with N > 128)
+
+template <bool DUAL, int RT>
+__global__ __launch_bounds__(RT * 128) void gemm_bf16_kernel(GemmBatch batch, DropCfg drop) {
+  extern __shared__ float lds[];     // Ws[2][GB_STAGE] (+ W2s[2][GB_STAGE] when DUAL)
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const GemmJob& job = batch.j[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int M = job.M, N = job.N;
+  const int blockrow = blockIdx.x * (16 * RT);
+  const int nblk = blockIdx.y * 128;
+  if (blockrow >= M || nblk >= N) return;          // block-uniform
+  const int rowbase = blockrow + (wave >> 1) * 16;
+  const int n0 = nblk + (wave & 1) * 64;
+  const bool wave_on = rowbase < M && n0 < N;       // idle waves still take part in staging, barriers and LDS reads
+  const int arow = min(rowbase + j, M - 1);
+  const bool adrop = job.a_drop_site >= 0 && drop.enabled;
+  const uint32_t asite = (uint32_t)job.a_drop_site;
+  const uint32_t adrow = job.a_drop_row0 + (uint32_t)arow;
+  char* Ws = ldsb;
+  char* W2s = ldsb + 2 * GB_STAGE;
+  int nstages = 0;
+  for (int p = 0; p < job.npieces; ++p) nstages += (job.kw[p] + GL_KS - 1) / GL_KS;
+
+  f32x4 acc[4], acc2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // LDS-DMA of one stage: 32 pieces of 1 KB = 4 tile rows each (pieces 0-15: hi tile, 16-31: lo tile)
+  auto dma_stage = [&](const float* Wimg, int k0, int kw, char* dst) {
+    const char* img = reinterpret_cast<const char*>(Wimg) + (size_t)blockIdx.y * GB_COLBLOCK;
+    const int chp = lane & 15, rr = lane >> 4;
+    for (int pc = wave; pc < 32; pc += 2 * RT) {
+      const int r = 4 * (pc & 15) + rr;
+      const int kk = min(k0 + r, kw - 1);
+      const int ch = chp ^ (((r & 3) << 2) | ((r >> 2) & 3));
+      const char* src = img + (size_t)kk * 512 + (pc >> 4) * 256 + 16 * ch;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+    }
+  };
+  // raw A fragments of one stage: a[2*ks + half] = row arow, k = k0 + 32 ks + 8 g + 4 half .. +3
+  auto a_load = [&](const float* Ap, const float* A2p, int k0, int kw, float4 (&a)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kk = k0 + 32 * (u >> 1) + 8 * g + 4 * (u & 1);
+      float4 v = f4zero();
+      if (kk < kw) {
+        v = ld4(Ap + kk);
+        if (A2p) v = f4mul(v, ld4(A2p + kk));
+        if (adrop) v = apply_drop4(drop, asite, adrow, (uint32_t)(kk >> 2), v);
+      }
+      a[u] = v;
+    }
+  };
+  auto issue = [&](int s, float4 (&a)[4], float4 (&a2)[4], int& kw_out, int& k0_out) {
+    int p, k0;
+    stage_to_piece(job, s, p, k0);
+    const int kw = job.kw[p];
+    dma_stage(job.W[p], k0, kw, Ws + (s & 1) * GB_STAGE);
+    if (DUAL) dma_stage(job.W2[p], k0, kw, W2s + (s & 1) * GB_STAGE);
+    const float* Ap = job.A[p] + (size_t)arow * job.lda[p];
+    const float* A2p = job.A2[p] ? job.A2[p] + (size_t)arow * job.lda2[p] : nullptr;
+    a_load(Ap, A2p, k0, kw, a);
+    if (DUAL) {
+      if (job.Ab[p]) a_load(job.Ab[p] + (size_t)arow * job.ldab[p], nullptr, k0, kw, a2);
+      else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a2[u] = a[u];
+      }
+    }
+    kw_out = kw;
+    k0_out = k0;
+  };
+  // transposed-read addressing: 16-lane group g takes rows 32 ks + 8 g + 4 rr + q, lane 4q+pp supplies stored columns
+  // 64 (wave&1) + 16 t + 4 pp .. +3
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
+  auto compute = [&](int bufi, int k0, int kw, const float4 (&a)[4], const float4 (&a2)[4]) {
+    const char* hi = Ws + bufi * GB_STAGE;
+    const char* hi2 = W2s + bufi * GB_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (k0 + 32 * ks < kw) {             // block-uniform
+        uint2 h0, l0, h1, l1;
+        bf16_split4(a[2 * ks], h0, l0);
+        bf16_split4(a[2 * ks + 1], h1, l1);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
+        const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
+        bf16x8 bh, bl, ch, cl;
+        if (DUAL) {
+          bf16_split4(a2[2 * ks], h0, l0);
+          bf16_split4(a2[2 * ks + 1], h1, l1);
+          bh = __builtin_bit_cast(bf16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
+          bl = __builtin_bit_cast(bf16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
+        }
+        const int r0 = 32 * ks + 8 * g + tq, r1 = r0 + 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int chunk = 8 * (wave & 1) + 2 * t + (tp >> 1);
+          const int o0 = tile256_off(r0, chunk) + 8 * (tp & 1), o1 = tile256_off(r1, chunk) + 8 * (tp & 1);
+          const bf16x8 wh = join_tr(lds_read_tr16(hi, o0), lds_read_tr16(hi, o1));
+          const bf16x8 wl = join_tr(lds_read_tr16(hi + GB_TILE, o0), lds_read_tr16(hi + GB_TILE, o1));
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, acc[t], 0, 0, 0);
+          if (DUAL) {
+            ch = join_tr(lds_read_tr16(hi2, o0), lds_read_tr16(hi2, o1));
+            cl = join_tr(lds_read_tr16(hi2 + GB_TILE, o0), lds_read_tr16(hi2 + GB_TILE, o1));
+            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ch, acc2[t], 0, 0, 0);
+            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, cl, acc2[t], 0, 0, 0);
+            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ch, acc2[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  float4 a0[4], a1[4], c0[4], c1[4];
+  int kw0 = 0, kw1 = 0, k00 = 0, k01 = 0;
+  EpiRegs epi;
+  issue(0, a0, c0, kw0, k00);
+  if (nstages > 1) issue(1, a1, c1, kw1, k01);
+  epi_prefetch<DUAL>(job, epi, rowbase, n0, j, g);
+  for (int s = 0; s < nstages; s += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // DMA of the resident stages has landed (this wave's part)
+    __syncthreads();                                      // ... and everybody else's
+    compute(0, k00, kw0, a0, c0);                         // every wave: the transposed reads need EXEC all ones
+    if (s + 1 < nstages) compute(1, k01, kw1, a1, c1);
+    if (s + 2 < nstages) {
+      __syncthreads();                                    // both buffers consumed by every wave
+      issue(s + 2, a0, c0, kw0, k00);
+      if (s + 3 < nstages) issue(s + 3, a1, c1, kw1, k01);
+    }
+  }
+  if (!wave_on) return;
+  epi_apply<DUAL>(job, drop, epi, acc, acc2, rowbase, n0, j, g);
+}
+
+// Pre-split weight images for gemm_bf16_kernel, made once per step (the weights are constant within a step).
+// For every dense weight W [K,128] at float offset `off` of the flat parameter buffer:
+//   forward image  at fwd + 4*off:  row k (512 B) = bf16 hi of W[k][perm(s)], s = 0..127 | the same for the residuals
+//   backward image at bwd + boff:   block b (64 KB) = the forward-style image of the 128 x 128 matrix W[128b + c][kk]^T
+//                                   (rows kk, columns c; zero where 128b + c >= K)
+// perm(s) = 64 (s>>6) + 4 (s&15) + ((s>>4)&3): stored column 16 t + i of a 64-column half is original column 4 i + t.
+struct PackJob { uint32_t off; int K; uint32_t boff; };
+#define HUAL_MAX_PACK 96
+struct PackBatch { PackJob j[HUAL_MAX_PACK]; };
+__device__ __forceinline__ int pack_perm(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* bwd) {
+  __shared__ float tile[16][129];
+  const PackJob job = b.j[blockIdx.y];
+  const int k0 = blockIdx.x * 16;
+  if (k0 >= ((job.K + 127) & ~127)) return;          // block-uniform
+  const float* W = P + job.off;
+  for (int idx = threadIdx.x; idx < 16 * 128; idx += 256) {
+    const int r = idx >> 7, n = idx & 127;
+    tile[r][n] = (k0 + r) < job.K ? W[(size_t)(k0 + r) * 128 + n] : 0.f;
+  }
+  __syncthreads();
+  // forward image: 16 rows x 64 column pairs
+  if (fwd) {
+    char* img = fwd + (size_t)job.off * 4;
+    for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+      const int r = idx >> 6, sp = idx & 63;
+      if (k0 + r < job.K) {
+        uint32_t hi, lo;
+        bf16_split_pair(tile[r][pack_perm(2 * sp)], tile[r][pack_perm(2 * sp + 1)], hi, lo);
+        *reinterpret_cast<uint32_t*>(img + (size_t)(k0 + r) * 512 + 4 * sp) = hi;
+        *reinterpret_cast<uint32_t*>(img + (size_t)(k0 + r) * 512 + 256 + 4 * sp) = lo;
+      }
+    }
+  }
+  // backward image: the 16 original rows k0..k0+15 are columns c = k0 % 128 + (0..15) of block k0 / 128; for every kk
+  // they sit at stored columns s with perm(s) = c, i.e. s = 64 (c>>6) + 16 t + i with 4 i + t = c & 63
+  if (bwd) {
+    char* img = bwd + job.boff + (size_t)(k0 >> 7) * GB_COLBLOCK;
+    const int cbase = k0 & 127;
+    for (int idx = threadIdx.x; idx < 128 * 8; idx += 256) {
+      const int kk = idx >> 3, pr = idx & 7;          // pair pr: local rows r = 2*? -> stored columns come in pairs (s, s+1)
+      // stored pair (s, s+1) with s even: perm(s) = c, perm(s+1) = c + 4  ->  local rows r and r + 4
+      const int t = pr & 3, ii = pr >> 2;             // r = 4*(2*ii') ...: enumerate r in {0..15} with (r>>2)&1 == 0
+      const int r = t + 8 * ii;                       // r in {0,1,2,3, 8,9,10,11}; partner r + 4
+      const int c = cbase + r;
+      const int s = 64 * (c >> 6) + 16 * (c & 3) + ((c & 63) >> 2);
+      uint32_t hi, lo;
+      bf16_split_pair(tile[r][kk], tile[r + 4][kk], hi, lo);
+      *reinterpret_cast<uint32_t*>(img + (size_t)kk * 512 + 2 * s) = hi;
+      *reinterpret_cast<uint32_t*>(img + (size_t)kk * 512 + 256 + 2 * s) = lo;
+    }
+  }
+}
+
 // Variant of gemm_lds_kernel with the extended A prologue (only launched for jobs that use it: the extra operand
 // registers and the longer dependency chain cost every launch about 1.5 us).
 //
@@ -1043,6 +1253,81 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
       else HUAL_LAUNCH(flops, bytes, (gemm_lds_kernel<false, 6>), g, blk, lds, stream, b, drop);
     } else HUAL_LAUNCH_LDS(gemm_lds_kernel);
 #undef HUAL_LAUNCH_LDS
+  }
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
+                        hipStream_t stream) {
+  for (int base = 0; base < n; base += HUAL_MAX_PACK) {
+    const int cnt = n - base < HUAL_MAX_PACK ? n - base : HUAL_MAX_PACK;
+    PackBatch b;
+    int maxK = 0;
+    double elems = 0.0;
+    for (int i = 0; i < cnt; ++i) {
+      HUAL_REQUIRE(Ks[base + i] > 0 && (Ks[base + i] % 8) == 0, "pack: K must be a positive multiple of 8");
+      b.j[i].off = offs[base + i]; b.j[i].K = Ks[base + i]; b.j[i].boff = boffs ? boffs[base + i] : 0;
+      const int kp = (Ks[base + i] + 127) & ~127;
+      maxK = kp > maxK ? kp : maxK;
+      elems += (double)Ks[base + i] * 128;
+    }
+    HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(maxK / 16, cnt), dim3(256), 0,
+                stream, b, P, fwd, bwd);
+  }
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// jobs whose W[p] / W2[p] already point at packed images (pack_weights_kernel); N multiple of 128 column blocks of the image
+int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream) {
+  HUAL_REQUIRE(n >= 1 && n <= HUAL_MAX_JOBS, "launch_gemm_bf16: job count");
+  GemmBatch b;
+  int maxM = 0, maxN = 0;
+  bool dual = false;
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const GemmJob& j = jobs[i];
+    HUAL_REQUIRE(j.M > 0 && j.N >= 4 && (j.N % 4) == 0, "launch_gemm_bf16: N must be a positive multiple of 4");
+    HUAL_REQUIRE(j.npieces >= 1 && j.npieces <= HUAL_MAX_PIECES, "launch_gemm_bf16: pieces");
+    double kt = 0.0;
+    for (int p = 0; p < j.npieces; ++p) {
+      HUAL_REQUIRE(j.kw[p] > 0 && (j.kw[p] % 8) == 0, "launch_gemm_bf16: piece width must be a multiple of 8");
+      HUAL_REQUIRE(j.A[p] && j.W[p], "launch_gemm_bf16: null operand");
+      HUAL_REQUIRE((j.lda[p] % 4) == 0, "launch_gemm_bf16: leading dims must be multiples of 4");
+      kt += j.kw[p];
+    }
+    HUAL_REQUIRE(j.Y != nullptr && j.add_div >= 1, "launch_gemm_bf16: output");
+    HUAL_REQUIRE(!j.ln_g && !j.a_relu && !j.a_save && !j.transW, "launch_gemm_bf16: A prologue extras / transW are not supported");
+    if (j.comb != COMB_NONE) dual = true;
+    b.j[i] = j;
+    maxM = j.M > maxM ? j.M : maxM;
+    maxN = j.N > maxN ? j.N : maxN;
+    const double mult = j.comb != COMB_NONE ? 2.0 : 1.0;
+    flops += 2.0 * j.M * kt * j.N * mult;
+    bytes += 4.0 * ((double)j.M * kt + kt * j.N * mult + (double)j.M * j.N);
+  }
+  for (int i = 0; i < n; ++i)
+    HUAL_REQUIRE((jobs[i].comb != COMB_NONE) == dual, "launch_gemm_bf16: cannot mix dual and single jobs in one launch");
+  static bool attr = false;
+  if (!attr) {
+    const void* fns[] = {(const void*)gemm_bf16_kernel<true, 2>, (const void*)gemm_bf16_kernel<false, 2>,
+                         (const void*)gemm_bf16_kernel<true, 3>, (const void*)gemm_bf16_kernel<false, 3>};
+    for (const void* f : fns) HUAL_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  const size_t lds = (size_t)(dual ? 4 : 2) * GB_STAGE;
+  static const int rt_env = []() { const char* e = getenv("HUAL_GEMM_RT"); return e ? atoi(e) : 0; }();
+  const int ncol = cdiv(maxN, 128);
+  int rt = (cdiv(maxM, 32) * ncol * n > 256 && maxM > 48) ? 3 : 2;
+  if (rt_env == 2 || rt_env == 3) rt = rt_env;
+  const dim3 g(cdiv(maxM, 16 * rt), ncol, n), blk(128 * rt);
+  if (rt == 3) {
+    if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 3>), g, blk, lds, stream, b, drop);
+    else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 3>), g, blk, lds, stream, b, drop);
+  } else {
+    if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 2>), g, blk, lds, stream, b, drop);
+    else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 2>), g, blk, lds, stream, b, drop);
   }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

@@ -69,6 +69,13 @@ struct Ctx {
   //                    the next dX GEMM, instead of an elementwise launch in between
   bool fuse_row = true;
   bool static_tables = false;   // hual_run_opts.static_tables
+  //   HUAL_GEMM_BF16=0  dense layers on the fp32 matrix cores (gemm_lds_kernel) instead of the split-bf16 kernel
+  bool use_bf16 = true;
+  struct DenseW { size_t off; int K; size_t boff; };
+  std::vector<DenseW> dense;          // every [K,128] weight of the graph, sorted by offset
+  char* PKF = nullptr;                // pre-split images (gemm.h launch_pack_weights): forward ...
+  char* PKB = nullptr;                // ... and of the transposed weights, for dX
+  size_t pk_bytes = 0;
 
   float* buf(const std::string& name, size_t rows, size_t cols) {
     auto it = index.find(name);
@@ -91,7 +98,63 @@ struct Ctx {
   void chk(int r) { if (rc == 0 && r != 0) rc = r; }
 
   // ---- launch wrappers (skipped in the dry pass) ----
-  void gemm(const GemmJob* j, int n) { if (!dry && ok()) chk(launch_gemm(j, n, drop, stream)); }
+  const DenseW* find_dense(size_t x) const {      // the weight whose [off, off + K*128) holds float offset x
+    size_t lo = 0, hi = dense.size();
+    while (lo < hi) {
+      const size_t mid = (lo + hi) / 2;
+      if (dense[mid].off <= x) lo = mid + 1; else hi = mid;
+    }
+    if (lo == 0) return nullptr;
+    const DenseW& d = dense[lo - 1];
+    return x < d.off + (size_t)d.K * HUAL_D ? &d : nullptr;
+  }
+  // W pointer of a job piece -> pointer into the pre-split images, or null when the piece cannot take the bf16 kernel
+  const float* packed_ptr(const float* w, int ldw, int N) const {
+    if (w >= P && w < P + pm.total) {                       // forward use: rows k0.. of a [K,128] weight
+      const size_t x = (size_t)(w - P);
+      const DenseW* d = find_dense(x);
+      if (!d || ldw != HUAL_D || N != HUAL_D || ((x - d->off) % HUAL_D) != 0) return nullptr;
+      return reinterpret_cast<const float*>(PKF + x * 4);
+    }
+    if (PT && w >= PT && w < PT + pm.total) {               // dX: the transposed copy [128, K], column block col0
+      const size_t x = (size_t)(w - PT);
+      const DenseW* d = find_dense(x);
+      if (!d) return nullptr;
+      const size_t col0 = x - d->off;
+      if (col0 >= (size_t)d->K || (col0 % 128) != 0 || ldw != d->K || (size_t)N > (size_t)((d->K + 127) & ~127) - col0) return nullptr;
+      return reinterpret_cast<const float*>(PKB + d->boff + (col0 / 128) * HUAL_PACK_BLOCK_BYTES);
+    }
+    return nullptr;
+  }
+  bool to_packed(GemmJob& j) const {
+    if (j.ln_g || j.a_relu || j.a_save || j.transW) return false;
+    for (int p = 0; p < j.npieces; ++p) {
+      if (j.kw[p] % 8) return false;
+      const float* w = packed_ptr(j.W[p], j.ldw, j.N);
+      if (!w) return false;
+      j.W[p] = w;
+      if (j.comb != COMB_NONE) {
+        const float* w2 = packed_ptr(j.W2[p], j.ldw, j.N);
+        if (!w2) return false;
+        j.W2[p] = w2;
+      }
+    }
+    return true;
+  }
+  void gemm(const GemmJob* j, int n) {
+    if (dry || !ok()) return;
+    if (use_bf16 && n <= HUAL_MAX_JOBS) {
+      GemmJob pk[HUAL_MAX_JOBS];
+      bool all = true;
+      for (int i = 0; i < n && all; ++i) { pk[i] = j[i]; all = to_packed(pk[i]); }
+      if (all) { chk(launch_gemm_bf16(pk, n, drop, stream)); return; }
+      for (int i = 0; i < n; ++i)
+        for (int p = 0; p < j[i].npieces; ++p)
+          if (pt_skipped && PT && j[i].W[p] >= PT && j[i].W[p] < PT + pm.total) { chk(fail(-1, "dX job outside the packed path while the transposed copies are skipped")); return; }
+    }
+    chk(launch_gemm(j, n, drop, stream));
+  }
+  bool pt_skipped = false;
   void ln_fwd(const LnFwd& a, const RowSpace& r) { if (!dry && ok()) chk(launch_ln_fwd(a, r, drop, stream)); }
   // layer-norm backward; the per-block dgamma / dbeta sums go to scratch and are folded in by flush_colsum()
   void ln_bwd(const LnBwd& a0) {
@@ -251,6 +314,32 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
   { const char* e = getenv("HUAL_FUSE_LN"); c.fuse_ln = e && atoi(e) != 0; }
   { const char* e = getenv("HUAL_FUSE_BWD"); c.fuse_bwd = e && atoi(e) != 0; }
   { const char* e = getenv("HUAL_FUSE_ROW"); c.fuse_row = !c.fuse_bwd && !(e && atoi(e) == 0); }
+  { const char* e = getenv("HUAL_GEMM_BF16"); c.use_bf16 = !(e && atoi(e) == 0); }
+  {
+    const ParamMap& pm = c.pm;
+    const int D = HUAL_D, catw = cfg->word_dim + 100;
+    c.dense.clear();
+    auto add = [&](size_t off, int K) { if (K % 8 == 0) c.dense.push_back({off, K, off * 4}); };
+    add(pm.vconv.k, cfg->vdim); add(pm.qconv.k, catw);
+    add(pm.shid.k, 2 * D); add(pm.ehid.k, 2 * D);
+    add(pm.fe_dense.k, D); add(pm.fe_q.k, D); add(pm.fe_k.k, D); add(pm.fe_v.k, D);
+    for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D); add(pm.cb.pw[i], D); }
+    add(pm.cqcat.k, 2 * D); add(pm.cq[0].dense, 4 * D); add(pm.cq[1].dense, 4 * D);
+    for (int li = 0; li < cfg->attn_layer; ++li) {
+      const DualAttnP& d = pm.da[li];
+      const size_t w[] = {d.dense1.k, d.dense2.k, d.bl1_d1, d.bl1_d2, d.bl2_d1, d.bl2_d2, d.guided.k, d.s_gate.k, d.x_gate.k,
+                          d.s_dense.k, d.x_dense.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
+      for (size_t o : w) add(o, D);
+    }
+    std::sort(c.dense.begin(), c.dense.end(), [](const Ctx::DenseW& a, const Ctx::DenseW& b) { return a.off < b.off; });
+    // the image of a transposed weight takes ceil(K/128) blocks of 64 KB: it fits the weight's own byte range when K is a
+    // multiple of 128; the others (query_conv1d, K = word_dim + 100) go behind the end of the parameter range
+    size_t extra = pm.total * 4;
+    extra = (extra + 255) & ~(size_t)255;
+    for (auto& d : c.dense)
+      if (d.K % 128) { d.boff = extra; extra += (size_t)((d.K + 127) / 128) * HUAL_PACK_BLOCK_BYTES; }
+    c.pk_bytes = extra;
+  }
   c.rs.B = B; c.rs.T = T; c.rs.L = L; c.rs.Nv = B * T; c.rs.Nq = B * L; c.rs.R = B * (T + L); c.rs.rowmask = nullptr;
   c.rsv = c.rs; c.rsv.Nq = 0; c.rsv.L = 0; c.rsv.R = c.rs.Nv;
   return 0;
@@ -346,6 +435,16 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   if (!c.dry) {
     HUAL_LAUNCH(0.0, 0.0, prep_masks_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.stream, bt->video_seq_len, bt->word_ids,
                 rowmask, B, T, L, loss_acc);
+  }
+  // ---------------- pre-split images of every dense weight for the bf16 kernels (weights are constant within a step)
+  c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
+  c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
+  c.PT = c.buf("params.T", pm.total, 1);
+  if (!c.dry && c.ok() && c.use_bf16) {
+    std::vector<uint32_t> offs, boffs;
+    std::vector<int> Ks;
+    for (const auto& d : c.dense) { offs.push_back((uint32_t)d.off); Ks.push_back(d.K); boffs.push_back((uint32_t)d.boff); }
+    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, lab ? c.PKB : nullptr, c.stream));
   }
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
   float* cat = c.buf("cat", Nq, catw);
@@ -674,7 +773,12 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   // transposed copies of every dense weight that a dX product reads (weights are constant within a step)
   float* PT = c.buf("params.T", pm.total, 1);
   c.PT = PT;
-  if (!c.dry && c.ok()) {
+  c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
+  c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
+  // with the split-bf16 kernel every dX product reads the image of the transposed weight that forward's pack launch left
+  // in the workspace; the fp32 transposed copies are only made for the fp32 kernels / the A-prologue fusion experiments
+  c.pt_skipped = c.use_bf16 && !c.fuse_ln && !c.fuse_bwd;
+  if (!c.dry && c.ok() && !c.pt_skipped) {
     std::vector<uint32_t> offs;
     std::vector<int> Ks, Ns;
     auto add = [&](size_t off, int K, int N) { offs.push_back((uint32_t)off); Ks.push_back(K); Ns.push_back(N); };

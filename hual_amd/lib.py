@@ -99,6 +99,7 @@ def load():
     lib.hual_aux_create.argtypes = [P(hual_aux)]
     lib.hual_aux_destroy.argtypes = [P(hual_aux)]
     lib.hual_linear_fwd.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.hual_linear_bf16x3.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, u64, vp]
     lib.hual_linear_dw.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]
     lib.hual_al_score.argtypes = [P(hual_al_set), vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]
     lib.hual_al_renew.argtypes = [P(hual_al_set), vp, i32, vp, vp, vp, P(ctypes.c_double), vp, vp]
@@ -173,6 +174,19 @@ def linear_fwd(A, W, bias=None, act=0, trans_w=False, out=None):
     Y = torch.empty(M, N, device=A.device, dtype=torch.float32) if out is None else out
     check(load().hual_linear_fwd(ptr(A), A.stride(0), ptr(W), W.stride(0), int(trans_w), ptr(bias), ptr(Y),
                                  Y.stride(0), M, K, N, act, stream_ptr()))
+    return Y
+
+
+def linear_bf16x3(A, W, bias=None, act=0, trans_w=False):
+    """split-bf16 dense: W [K,128] (trans_w False) or [N,128] used transposed (dX)"""
+    import torch
+    M, K = A.shape
+    N = W.shape[0] if trans_w else W.shape[1]
+    Y = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    nbytes = ((N + 127) // 128) * 65536 if trans_w else K * 512
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=A.device)
+    check(load().hual_linear_bf16x3(ptr(A), A.stride(0), ptr(W), int(trans_w), ptr(bias), ptr(Y), Y.stride(0), M, K, N, act,
+                                    ptr(scratch), nbytes, stream_ptr()))
     return Y
 
 

@@ -184,6 +184,15 @@ int hual_align_loss(const float* that, const float* vhat, int Bg, float* scratch
 int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, int trans_w, const float* bias, float* Y,
                     int ldy, int M, int K, int N, int act, void* stream);
 
+/* The same dense layer on the bf16 matrix cores with split operands (x = hi + lo, three MFMA passes, fp32 accumulate;
+ * ~1e-6 relative to the fp32 product) - the kernel the model path uses for every [K,128] weight.
+ *   trans_w = 0: Y[M,128] = act(A[M,K] . W[K,128] + bias), K % 8 == 0; scratch >= K * 512 bytes
+ *   trans_w = 1: Y[M,N]   = A[M,128] . W^T with W stored [N,128] (dX of a dense layer), N % 8 == 0;
+ *                scratch >= ceil(N/128) * 65536 bytes
+ * scratch (device) receives the pre-split weight image. */
+int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, const float* bias, float* Y, int ldy, int M,
+                       int K, int N, int act, void* scratch, uint64_t scratch_bytes, void* stream);
+
 /* gradients of the dense above: dW[K,N] += A^T . dY ; db[N] += colsum(dY) (db may be NULL).
   * N must be 128 (every dense layer of the graph has 128 outputs); rows_per_block (multiple of 32, 0 = 1024) sets the
  * split over M.  Accumulates with float atomics: zero the destinations first. */

@@ -70,3 +70,36 @@ def test_linear_dw(dev, M, K, N, rpw):
     lib.linear_dw(A, dY, dW, db, rows_per_block=rpw)
     ref = A.double().t() @ dY.double()
     assert (dW.double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item()) * (M ** 0.5)
+
+
+@pytest.mark.parametrize('M,K', [(16, 64), (37, 128), (1000, 400), (2048, 1024), (9472, 128), (100, 256), (48, 8)])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_linear_bf16x3_forward(dev, M, K, act):
+    """split-bf16 dense (three MFMA passes on hi/lo operands): exact on small integers, ~1e-6 relative on random data"""
+    from hual_amd import lib
+    g = torch.Generator(device='cpu').manual_seed(M * 3 + K + act)
+    Ai = torch.randint(-3, 4, (M, K), generator=g).float().to(dev)
+    Wi = torch.randint(-3, 4, (K, 128), generator=g).float().to(dev)
+    assert torch.equal(lib.linear_bf16x3(Ai, Wi), Ai @ Wi)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(K, 128, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(128, generator=g).to(dev)
+    Y = lib.linear_bf16x3(A, W, b, act=act)
+    ref = _ref(A, W, b, act)
+    err = (Y.double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize('M,N', [(37, 128), (500, 256), (9472, 128), (100, 512), (300, 400), (64, 1024)])
+def test_linear_bf16x3_transposed(dev, M, N):
+    """dX[M,N] = dY[M,128] . W^T with W stored [N,128], through the image of the transposed weight"""
+    from hual_amd import lib
+    g = torch.Generator(device='cpu').manual_seed(M + N)
+    dY = torch.randint(-3, 4, (M, 128), generator=g).float().to(dev)
+    W = torch.randint(-3, 4, (N, 128), generator=g).float().to(dev)
+    assert torch.equal(lib.linear_bf16x3(dY, W, trans_w=True), dY @ W.t())
+    dY = torch.randn(M, 128, generator=g).to(dev)
+    W = torch.randn(N, 128, generator=g).to(dev) / 11.0
+    out = lib.linear_bf16x3(dY, W, trans_w=True)
+    ref = dY.double() @ W.double().t()
+    assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
