@@ -91,6 +91,8 @@ int launch_transpose_weights(const uint32_t* offs, const int* Ks, const int* Ns,
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
                         hipStream_t stream);
 int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
+// the same jobs executed one after the other inside each block (row-local dependent layers; same M, N = 128)
+int launch_gemm_chain(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
 void gemm_job_init(GemmJob& j);
 void dw_job_init(DwJob& j);
 // enqueue `n` jobs (n <= HUAL_MAX_JOBS) as ONE launch on `stream`

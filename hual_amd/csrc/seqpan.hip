@@ -155,6 +155,25 @@ struct Ctx {
     chk(launch_gemm(j, n, drop, stream));
   }
   bool pt_skipped = false;
+  //   HUAL_CHAIN=0  launch the dense layers of a row-local chain one by one instead of as one chained launch
+  bool use_chain = true;
+  // `ngroups` consecutive groups of jobs (group g has gsz[g] jobs) where every group only reads, of the outputs of the
+  // earlier groups, rows of its own row block: one chained launch (gemm_chain_kernel) or, as fallback, one launch per group
+  void gemm_chain(const GemmJob* j, const int* gsz, int ngroups) {
+    if (dry || !ok()) return;
+    int n = 0;
+    for (int g = 0; g < ngroups; ++g) n += gsz[g];
+    if (use_bf16 && use_chain && n <= HUAL_MAX_JOBS) {
+      GemmJob pk[HUAL_MAX_JOBS];
+      bool all = true;
+      for (int i = 0; i < n && all; ++i) {
+        pk[i] = j[i];
+        all = to_packed(pk[i]) && pk[i].M == j[0].M && pk[i].N == HUAL_D;
+      }
+      if (all) { chk(launch_gemm_chain(pk, n, drop, stream)); return; }
+    }
+    for (int g = 0, i = 0; g < ngroups; i += gsz[g], ++g) gemm(j + i, gsz[g]);
+  }
   void ln_fwd(const LnFwd& a, const RowSpace& r) { if (!dry && ok()) chk(launch_ln_fwd(a, r, drop, stream)); }
   // layer-norm backward; the per-block dgamma / dbeta sums go to scratch and are folded in by flush_colsum()
   void ln_bwd(const LnBwd& a0) {
@@ -315,6 +334,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
   { const char* e = getenv("HUAL_FUSE_BWD"); c.fuse_bwd = e && atoi(e) != 0; }
   { const char* e = getenv("HUAL_FUSE_ROW"); c.fuse_row = !c.fuse_bwd && !(e && atoi(e) == 0); }
   { const char* e = getenv("HUAL_GEMM_BF16"); c.use_bf16 = !(e && atoi(e) == 0); }
+  { const char* e = getenv("HUAL_CHAIN"); c.use_chain = !(e && atoi(e) == 0); }
   {
     const ParamMap& pm = c.pm;
     const int D = HUAL_D, catw = cfg->word_dim + 100;
@@ -535,49 +555,40 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       for (int k = 0; k < 4; ++k) set_dmask(c, a[k], t + ".dm" + std::to_string(k));
       c.attn_fwd(a, 4);
     }
+    // s / x projections -> cross gating -> guided dense -> bilinear gate.value -> dense_1 + residual: six dense jobs that
+    // only ever touch their own rows - one chained launch (layers.py:93-111, modules.py:82-83)
     float* sv = c.act(t + ".s");
     float* xv = c.act(t + ".x");
-    {
-      GemmJob j[2];
-      j[0] = mkjob(s_att, D, R, D, c.p(d.s_dense.k), c.p(d.s_dense.b), sv, D);
-      j[1] = mkjob(x_att, D, R, D, c.p(d.x_dense.k), c.p(d.x_dense.b), xv, D);
-      c.gemm(j, 2);
-    }
     float* sg = c.act(t + ".sg");
     float* xg = c.act(t + ".xg");
     float* o = c.act(t + ".o");
-    {
-      GemmJob j = mkjob(sv, D, R, D, c.p(d.s_gate.k), c.p(d.s_gate.b), o, D);
-      j.act = ACT_SIGMOID;
-      j.comb = COMB_CROSSGATE;
-      j.Ab[0] = xv; j.ldab[0] = D; j.W2[0] = c.p(d.x_gate.k); j.bias2 = c.p(d.x_gate.b);
-      j.save = sg; j.ldsave = D; j.save2 = xg; j.ldsave2 = D;
-      j.aux1 = xv; j.aux2 = sv; j.ldaux = D;      // o = sg * x + xg * s   (layers.py:101-103)
-      c.gemm(&j, 1);
-    }
     float* gd = c.act(t + ".g");
-    {
-      GemmJob j = mkjob(o, D, R, D, c.p(d.guided.k), c.p(d.guided.b), gd, D);
-      c.gemm(&j, 1);
-    }
     float* gate = c.act(t + ".gate");
     float* val = c.act(t + ".val");
     float* mha = c.act(t + ".mha");
-    {
-      GemmJob j = mkjob(ln1, D, R, D, c.p(d.bl1_d1), c.p(d.bl1_b), mha, D);
-      j.npieces = 2;
-      j.A[1] = gd; j.lda[1] = D; j.kw[1] = D; j.W[1] = c.p(d.bl1_d2);
-      j.act = ACT_SIGMOID_ROWMASK; j.rowmask = rowmask;
-      j.comb = COMB_GATE_VAL;
-      j.W2[0] = c.p(d.bl2_d1); j.W2[1] = c.p(d.bl2_d2); j.bias2 = c.p(d.bl2_b);
-      j.save = gate; j.ldsave = D; j.save2 = val; j.ldsave2 = D;
-      c.gemm(&j, 1);
-    }
     float* res = c.act(t + ".res");
     {
-      GemmJob j = mkjob(mha, D, R, D, c.p(d.dense1.k), c.p(d.dense1.b), res, D);
-      j.drop_site = site + 2; j.add = x; j.ldadd = D;
-      c.gemm(&j, 1);
+      GemmJob j[6];
+      j[0] = mkjob(s_att, D, R, D, c.p(d.s_dense.k), c.p(d.s_dense.b), sv, D);
+      j[1] = mkjob(x_att, D, R, D, c.p(d.x_dense.k), c.p(d.x_dense.b), xv, D);
+      j[2] = mkjob(sv, D, R, D, c.p(d.s_gate.k), c.p(d.s_gate.b), o, D);
+      j[2].act = ACT_SIGMOID;
+      j[2].comb = COMB_CROSSGATE;
+      j[2].Ab[0] = xv; j[2].ldab[0] = D; j[2].W2[0] = c.p(d.x_gate.k); j[2].bias2 = c.p(d.x_gate.b);
+      j[2].save = sg; j[2].ldsave = D; j[2].save2 = xg; j[2].ldsave2 = D;
+      j[2].aux1 = xv; j[2].aux2 = sv; j[2].ldaux = D;      // o = sg * x + xg * s   (layers.py:101-103)
+      j[3] = mkjob(o, D, R, D, c.p(d.guided.k), c.p(d.guided.b), gd, D);
+      j[4] = mkjob(ln1, D, R, D, c.p(d.bl1_d1), c.p(d.bl1_b), mha, D);
+      j[4].npieces = 2;
+      j[4].A[1] = gd; j[4].lda[1] = D; j[4].kw[1] = D; j[4].W[1] = c.p(d.bl1_d2);
+      j[4].act = ACT_SIGMOID_ROWMASK; j[4].rowmask = rowmask;
+      j[4].comb = COMB_GATE_VAL;
+      j[4].W2[0] = c.p(d.bl2_d1); j[4].W2[1] = c.p(d.bl2_d2); j[4].bias2 = c.p(d.bl2_b);
+      j[4].save = gate; j[4].ldsave = D; j[4].save2 = val; j[4].ldsave2 = D;
+      j[5] = mkjob(mha, D, R, D, c.p(d.dense1.k), c.p(d.dense1.b), res, D);
+      j[5].drop_site = site + 2; j[5].add = x; j[5].ldadd = D;
+      const int gsz[5] = {2, 1, 1, 1, 1};
+      c.gemm_chain(j, gsz, 5);
     }
     float* l2 = c.act(t + ".l2");
     float* mean2 = c.vec(t + ".mean2");
