@@ -26,8 +26,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
+PEAK_BF16_MATRIX_TFLOPS = 2516.8  # MI355X_MICROARCH.md: bf16 MFMA = 16 x the fp32 matrix rate (~2.5 PF dense)
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILE = 'r1c_pmc_traffic.json'     # per-kernel HBM bytes per launch from the PMC passes of this round
+TRAFFIC_FILE = 'r1e_pmc_traffic.json'     # per-kernel HBM bytes per launch from the PMC passes of this round
+FEATURE_LOAD_KERNEL = 'feature_load_gemm_kernel<2>'
+
+
+def mfma_peak(kernel):
+    """(peak TFLOP/s of the matrix pipe the kernel runs on, MFMA passes per algorithmic product)"""
+    if 'bf16' in kernel or kernel.startswith('feature_load') or kernel.startswith('gemm_chain'):
+        return PEAK_BF16_MATRIX_TFLOPS, 3      # split-bf16: hi*hi + hi*lo + lo*hi (csrc/bf16x3.h)
+    return PEAK_F32_MATRIX_TFLOPS, 1
 
 
 def synth_batch(B, T, L, C, vdim, num_words, num_chars, seed):
@@ -173,17 +182,28 @@ def main():
         fam.sort(key=lambda d: -d['us'])
         total_us = sum(d['us'] for d in fam)
         top = fam[0]
-        if top['flops'] > 0:
-            ach = top['flops'] / top['us'] / 1e6      # TFLOP/s
-            roof = dict(bound='mfma', kernel=top['kernel'], achieved=round(ach, 2), peak=PEAK_F32_MATRIX_TFLOPS,
-                        unit='TFLOP/s', frac=round(ach / PEAK_F32_MATRIX_TFLOPS, 4), traffic=None,
-                        avg_launch_us=round(top['us'] / top['launches'], 2), launches_per_step=top['launches'] // psteps,
-                        share_of_kernel_time=round(top['us'] / total_us, 3))
+        # which roof bounds the dominant kernel: arithmetic intensity of its launches (algorithmic FLOPs / algorithmic bytes,
+        # both summed by the launch wrappers) against the ridge of the pipe it runs on.  A [M,128]x[128,128] fp32-in/out
+        # layer has 32 FLOP/B: above the fp32-matrix ridge (157.3 TF / 8 TB/s = 20 FLOP/B) but below the split-bf16 ridge
+        # (2516.8 / 3 passes / 8 TB/s = 105 FLOP/B), so with the split-bf16 kernels the dense layers are HBM-bound.
+        tflops = top['flops'] / top['us'] / 1e6 if top['flops'] > 0 else 0.0      # algorithmic TFLOP/s
+        gbs = top['bytes'] / top['us'] / 1e3                                       # algorithmic GB/s
+        peak, passes = mfma_peak(top['kernel'])
+        ai = top['flops'] / top['bytes'] if top['bytes'] > 0 else float('inf')
+        ridge = (peak / passes) * 1e3 / PEAK_HBM_GBS
+        common = dict(kernel=top['kernel'], avg_launch_us=round(top['us'] / top['launches'], 2),
+                      launches_per_step=top['launches'] // psteps, share_of_kernel_time=round(top['us'] / total_us, 3),
+                      arithmetic_intensity_flop_per_byte=round(ai, 1), ridge_flop_per_byte=round(ridge, 1))
+        if top['flops'] > 0 and ai >= ridge:
+            roof = dict(bound='mfma', achieved=round(tflops, 2), peak=peak, unit='TFLOP/s', frac=round(tflops / peak, 4),
+                        traffic=None, **common)
         else:
-            ach = top['bytes'] / top['us'] / 1e3      # GB/s
-            roof = dict(bound='hbm', kernel=top['kernel'], achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                        frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, avg_launch_us=round(top['us'] / top['launches'], 2),
-                        launches_per_step=top['launches'] // psteps, share_of_kernel_time=round(top['us'] / total_us, 3))
+            roof = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
+                        traffic=None, **common)
+        if top['flops'] > 0:
+            roof.update(algorithmic_tflops=round(tflops, 2), mfma_pipe_peak_tflops=peak, mfma_passes=passes,
+                        mfma_issue_frac=round(passes * tflops / peak, 4),
+                        frac_of_fp32_matrix_peak=round(tflops / PEAK_F32_MATRIX_TFLOPS, 4))
         # HBM traffic of that kernel: rocprofv3 PMC passes cannot run inside this process, so the per-launch figure is
         # read from the committed summary of the separate FETCH_SIZE / WRITE_SIZE passes (scripts/pmc_traffic.py,
         # gfx950 correction applied there); null when the file does not cover the kernel.
@@ -196,9 +216,23 @@ def main():
                 roof['algorithmic_bytes_per_launch'] = round(top['bytes'] / top['launches'])
         except (OSError, ValueError):
             pass
+        # the feature-load phase (video_conv1d + query_conv1d: streams the [B,T,vdim] clip features once) against HBM
+        for d in fam:
+            if d['kernel'] == FEATURE_LOAD_KERNEL and d['bytes'] > 0:
+                gbs = d['bytes'] / d['us'] / 1e3
+                roof['feature_load'] = dict(bound='hbm', kernel=d['kernel'], achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                                            frac=round(gbs / PEAK_HBM_GBS, 4), avg_launch_us=round(d['us'] / d['launches'], 2),
+                                            algorithmic_bytes_per_launch=round(d['bytes'] / d['launches']),
+                                            tflops=round(d['flops'] / d['us'] / 1e6, 2))
+                try:
+                    if d['kernel'] in tr_tab:
+                        roof['feature_load']['traffic'] = tr_tab[d['kernel']]['hbm_bytes_per_launch']
+                except NameError:
+                    pass
         roof['families'] = [dict(kernel=d['kernel'], launches_per_step=d['launches'] // psteps,
                                  us_per_step=round(d['us'] / psteps, 1),
-                                 tflops=round(d['flops'] / d['us'] / 1e6, 2) if d['flops'] > 0 else None) for d in fam]
+                                 tflops=round(d['flops'] / d['us'] / 1e6, 2) if d['flops'] > 0 else None,
+                                 gbs=round(d['bytes'] / d['us'] / 1e3, 1) if d['bytes'] > 0 else None) for d in fam]
     print('[bench] roofline leg done', file=sys.stderr, flush=True)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -207,7 +241,7 @@ def main():
     if rank == 0:
         out = dict(metric='train clips/sec', value=round(clips / dt, 2), unit='clips/s', n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
-                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   scaling='weak', vs_baseline=None, dtype='f32 (3xbf16 split MFMA, fp32 accumulate)', data='synthetic',
                    config=dict(workload='Charades-STA SeqPAN train step (fwd+bwd+clip+AdamWD, dropout %.1f), batch %d/GPU, '
                                         'T=%d, vdim=%d, L=%d, C=%d, dim=128, 8 heads, 2 attention layers, random init'
                                         % (args.drop, args.batch, args.T, args.vdim, args.L, args.C),

@@ -612,6 +612,15 @@ __global__ __launch_bounds__(RT * 128) void gemm_bf16_kernel(GemmBatch batch, Dr
   gemm_bf16_body<DUAL ? 1 : 0, RT>(batch.j[blockIdx.z], drop, reinterpret_cast<char*>(lds));
 }
 
+// The same kernel under its own symbol for the deep-K launch of a step - video_conv1d (+ query_conv1d), model.py:42,48: the
+// FEATURE-LOAD phase that streams the [B,T,vdim] clip features from HBM - so that rocprofv3 and bench.py's per-kernel
+// table show that phase separately from the 128-deep layers.
+template <int RT>
+__global__ __launch_bounds__(RT * 128) void feature_load_gemm_kernel(GemmBatch batch, DropCfg drop) {
+  extern __shared__ float lds[];
+  gemm_bf16_body<0, RT>(batch.j[blockIdx.z], drop, reinterpret_cast<char*>(lds));
+}
+
 // Chained launch: the jobs of the batch run ONE AFTER THE OTHER inside every block, on the block's own 16*RT rows.
 // Valid when each job reads, of the tensors written earlier in the chain, only the rows of its own block (dense layers
 // are row local), every job has the same M and N = 128: then a workgroup barrier between jobs is all the ordering
@@ -1350,9 +1359,21 @@ int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_
   static const int rt_env = []() { const char* e = getenv("HUAL_GEMM_RT"); return e ? atoi(e) : 0; }();
   const int ncol = cdiv(maxN, 128);
   int rt = (cdiv(maxM, 32) * ncol * n > 256 && maxM > 48) ? 3 : 2;
+  // deep-K jobs (video_conv1d: K = vdim, with Philox dropout on its A operand) are bound by per-wave VALU / MFMA work, not by
+  // the per-block weight traffic: four waves per block spread evenly over the four SIMDs, six do not
+  int kmax = 0;
+  for (int i = 0; i < n; ++i) { int kt = 0; for (int p = 0; p < jobs[i].npieces; ++p) kt += jobs[i].kw[p]; kmax = kt > kmax ? kt : kmax; }
+  if (kmax >= 768) rt = 2;
   if (rt_env == 2 || rt_env == 3) rt = rt_env;
   const dim3 g(cdiv(maxM, 16 * rt), ncol, n), blk(128 * rt);
-  if (rt == 3) {
+  if (kmax >= 768 && !dual && rt == 2) {
+    static bool fattr = false;
+    if (!fattr) {
+      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)feature_load_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      fattr = true;
+    }
+    HUAL_LAUNCH(flops, bytes, feature_load_gemm_kernel<2>, g, blk, lds, stream, b, drop);
+  } else if (rt == 3) {
     if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 3>), g, blk, lds, stream, b, drop);
     else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 3>), g, blk, lds, stream, b, drop);
   } else {

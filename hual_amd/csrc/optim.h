@@ -14,6 +14,7 @@ struct AdamArgs {
   float clip_norm;
   float prescale;         // multiplies the gradient first (1/world after a sum all-reduce)
   float* sqnorm;          // device scratch, HUAL_SQNORM_SLOTS floats: per-block partial sums of |prescale*g|^2
+  uint32_t* rng_state;    // optional: Philox state {k0, k1, offset}; offset += 1 after the update (next step's dropout)
 };
 int launch_adamw(const AdamArgs& a, hipStream_t s);
 // p[0..n) = 0 with a kernel (no memset node inside captured graphs)

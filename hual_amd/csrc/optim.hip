@@ -30,8 +30,9 @@ __global__ __launch_bounds__(256) void zero_kernel(float* p, size_t n) {
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, const float* decay,
                                                     size_t n, const float* lr_dev, float clip_norm, float prescale,
-                                                    const float* sqnorm, float b1, float b2, float eps) {
+                                                    const float* sqnorm, float b1, float b2, float eps, uint32_t* rng_state) {
   const float lr = lr_dev[0];
+  if (rng_state && blockIdx.x == 0 && threadIdx.x == 0) rng_state[2] += 1u;     // nothing in this launch reads it
   float part = 0.f;
   for (int i = threadIdx.x & 63; i < HUAL_SQNORM_SLOTS; i += 64) part += sqnorm[i];     // same order in every wave
   const float gn = sqrtf(wave_sum64(part));
@@ -64,7 +65,7 @@ int launch_adamw(const AdamArgs& a, hipStream_t s) {
   HUAL_REQUIRE((a.n % 4) == 0, "adamw: flat size must be a multiple of 4");
   HUAL_LAUNCH(0.0, 4.0 * a.n, sqnorm_kernel, dim3(HUAL_SQNORM_SLOTS), dim3(256), 0, s, (const float*)a.g, a.n, a.prescale, a.sqnorm);
   HUAL_LAUNCH(0.0, 32.0 * a.n, adamw_kernel, dim3(512), dim3(256), 0, s, a.p, (const float*)a.g, a.m, a.v, a.decay, a.n, a.lr_dev,
-                     a.clip_norm, a.prescale, (const float*)a.sqnorm, 0.9f, 0.999f, 1e-6f);
+                     a.clip_norm, a.prescale, (const float*)a.sqnorm, 0.9f, 0.999f, 1e-6f, a.rng_state);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -1414,7 +1414,16 @@ int hual_aux_destroy(hual_aux* aux) {
 int hual_adamw_clip_step(float* params, const float* grads, float* adam_m, float* adam_v, const float* decay,
                          uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
                          void* stream) {
-  AdamArgs a{params, const_cast<float*>(grads), adam_m, adam_v, decay, (size_t)n_padded, lr, clip_norm, grad_prescale, sqnorm};
+  AdamArgs a{params, const_cast<float*>(grads), adam_m, adam_v, decay, (size_t)n_padded, lr, clip_norm, grad_prescale, sqnorm,
+             nullptr};
+  return launch_adamw(a, (hipStream_t)stream);
+}
+
+int hual_adamw_clip_step_rng(float* params, const float* grads, float* adam_m, float* adam_v, const float* decay,
+                             uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
+                             uint32_t* rng_state, void* stream) {
+  AdamArgs a{params, const_cast<float*>(grads), adam_m, adam_v, decay, (size_t)n_padded, lr, clip_norm, grad_prescale, sqnorm,
+             rng_state};
   return launch_adamw(a, (hipStream_t)stream);
 }
 

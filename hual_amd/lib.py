@@ -93,6 +93,7 @@ def load():
     lib.hual_seqpan_backward.argtypes = [P(hual_cfg), vp, vp, P(hual_batch), P(hual_labels), P(hual_run_opts), vp, vp,
                                          u64, vp]
     lib.hual_adamw_clip_step.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp]
+    lib.hual_adamw_clip_step_rng.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp, vp]
     lib.hual_align_loss.argtypes = [vp, vp, i32, vp, vp, vp, vp, f32, vp]
     lib.hual_prof_get.argtypes = [i32, ctypes.c_char_p, i32, P(ctypes.c_int64), P(ctypes.c_double), P(ctypes.c_double),
                                   P(ctypes.c_double)]

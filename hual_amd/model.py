@@ -69,6 +69,7 @@ class SeqPAN:
         self.adam_v = torch.zeros_like(self.params)
         self.decay = torch.from_numpy(self.table.decay_flat(0.01)).to(self.device)
         self.lr = torch.zeros(1, device=self.device)
+        self.lr_value = 0.0                                       # host copy of self.lr (skips redundant fills)
         self.sqnorm = torch.zeros(256, device=self.device)       # hual_adamw_clip_step scratch
         # Philox state {seed lo, seed hi, offset}; offset advances once per train step (on device, graph friendly)
         st = np.array([rng_seed & 0xFFFFFFFF, (rng_seed >> 32) & 0xFFFFFFFF, 0], dtype=np.uint32).view(np.int32)
@@ -186,8 +187,10 @@ class SeqPAN:
         """clip_by_global_norm + AdamWeightDecay (ops.py:119-132); lr is the fed scalar of main.py:61."""
         if isinstance(lr, torch.Tensor):
             self.lr.copy_(lr.reshape(1))
-        else:
+            self.lr_value = None
+        elif self.lr_value != float(lr):
             self.lr.fill_(float(lr))
+            self.lr_value = float(lr)
         lib.check(lib.load().hual_adamw_clip_step(
             lib.ptr(self.params), lib.ptr(self.grads), lib.ptr(self.adam_m), lib.ptr(self.adam_v), lib.ptr(self.decay),
             self.params.numel(), lib.ptr(self.lr), float(self.cfg.clip_norm), float(grad_prescale), lib.ptr(self.sqnorm),

@@ -144,17 +144,17 @@ class Trainer:
 
     def _adam(self, prescale):
         m = self.m
-        lib.check(self._lib.hual_adamw_clip_step(
+        # the Philox offset of the dropout stream advances in the same launch (rng_state[2] += 1)
+        lib.check(self._lib.hual_adamw_clip_step_rng(
             lib.ptr(m.params), lib.ptr(m.grads), lib.ptr(m.adam_m), lib.ptr(m.adam_v), lib.ptr(m.decay),
             m.params.numel(), lib.ptr(m.lr), float(m.cfg.clip_norm), float(prescale), lib.ptr(m.sqnorm),
-            lib.stream_ptr()))
+            lib.ptr(m.rng_state), lib.stream_ptr()))
 
     def _enqueue_single(self, drop_rate):
         opts = self._opts(drop_rate, 0)
         self._forward(opts)
         self._backward(opts)
         self._adam(1.0)
-        self.m.rng_state[2] += 1
 
     def _enqueue_dp(self, drop_rate):
         m, B = self.m, self.shape[0]
@@ -170,11 +170,12 @@ class Trainer:
         self._backward(opts)
         hdist.allreduce_sum_(m.grads)
         self._adam(1.0 / self.world)
-        m.rng_state[2] += 1
 
     def step(self, lr, drop_rate):
         m = self.m
-        m.lr.fill_(float(lr))
+        if m.lr_value != float(lr):               # the fed scalar changes once per epoch (main.py:61): no fill launch otherwise
+            m.lr.fill_(float(lr))
+            m.lr_value = float(lr)
         if self.dp:
             self._enqueue_dp(drop_rate)
         elif not self.use_graph:

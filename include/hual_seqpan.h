@@ -168,6 +168,12 @@ int hual_adamw_clip_step(float* params, const float* grads, float* adam_m, float
                          uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
                          void* stream);
 
+/* the same, and the Philox offset rng_state[2] of the training loop is advanced by one in the same launch (the step
+ * counter of the dropout stream: one launch fewer per captured step than a separate increment) */
+int hual_adamw_clip_step_rng(float* params, const float* grads, float* adam_m, float* adam_v, const float* decay,
+                             uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
+                             uint32_t* rng_state, void* stream);
+
 /* cross-sample part of lossfun_aligment (layers.py:232-247) on [Bg,128] l2-normalised features
  * (all-gathered over ranks in exact data-parallel mode).  scratch: 2*Bg*Bg floats.
  * Writes d_that / d_vhat [Bg,128] (scaled by grad_scale) and ADDS the loss to *loss (device scalar). */
