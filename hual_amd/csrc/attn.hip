@@ -34,6 +34,17 @@ __device__ __forceinline__ f32x4 dot16(const float4& a, const float4& b) {   // 
   return acc;
 }
 
+// XCD-aware block order (cdna_hip_programming.md T1, bijective form).  The dispatcher deals consecutive linear block ids
+// round-robin over the 8 XCDs, each with a private L2; the 16+ blocks of one clip (8 heads x query tiles x halves) all read
+// that clip's Q/K/V/dO rows, so in launch order every XCD fetched every clip (PMC: 222 MB of HBM traffic per backward
+// launch against ~50 MB of operands).  The remap hands each XCD a contiguous run of logical ids, i.e. whole clips.
+__device__ __forceinline__ int xcd_logical_id() {
+  const int nwg = gridDim.x * gridDim.y * gridDim.z;
+  const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 #define ATT_SCALE 0.25f   // 1/sqrt(head_size=16)   layers.py:82
 
 // ---- LDS staging ---------------------------------------------------------------------------------------
@@ -53,12 +64,16 @@ __device__ __forceinline__ void stage_panel(float* dst, const float* src, int ld
 template <int MAXKT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, DropCfg drop) {
   extern __shared__ float lds[];
-  const AttnJob& job = batch.j[blockIdx.z];
+  int lid = xcd_logical_id();
+  const int bx = lid % (int)gridDim.x; lid /= (int)gridDim.x;
+  const int h = lid & 7; lid >>= 3;
+  const int njobs = (int)gridDim.z;
+  const AttnJob& job = batch.j[lid % njobs];       // clip-major: an XCD gets whole clips with ALL their jobs (balanced)
+  const int b = lid / njobs;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
-  const int b = blockIdx.y >> 3, h = blockIdx.y & 7;
-  if (b >= job.B || blockIdx.x * 64 >= Tq) return;   // block-uniform
+  if (b >= job.B || bx * 64 >= Tq) return;   // block-uniform
   const int nkt = (Tk + 15) >> 4, Tkp = nkt * 16;
   const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
   float* Ks = lds;
@@ -68,7 +83,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, DropCfg 
   stage_panel(Vs, job.V + (size_t)kbase * job.ldkv + 16 * h, job.ldkv, Tk, Tkp);
   for (int k = threadIdx.x; k < Tkp; k += 256) Ms[k] = k < Tk ? job.kmask[kbase + k] : 0.f;
   __syncthreads();
-  const int qt = blockIdx.x * 4 + wave;
+  const int qt = bx * 4 + wave;
   if (qt * 16 >= Tq) return;   // wave-uniform, after the only barrier
   const int q0 = qt * 16;
   const int qrow = qbase + min(q0 + j, Tq - 1);
@@ -312,11 +327,17 @@ __device__ __forceinline__ void attn_bwd_dkv_part(const AttnJob& job, const Drop
 
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBatch batch, DropCfg drop) {
   extern __shared__ float lds[];
-  const AttnJob& job = batch.j[blockIdx.z >> 1];
-  const int b = blockIdx.y >> 3, h = blockIdx.y & 7;
+  // logical order: tile, half (dQ | dK/dV), head, job fastest, clip slowest - all blocks of one clip are neighbours
+  int lid = xcd_logical_id();
+  const int bx = lid % (int)gridDim.x; lid /= (int)gridDim.x;
+  const int half = lid & 1; lid >>= 1;
+  const int h = lid & 7; lid >>= 3;
+  const int njobs = (int)gridDim.z >> 1;
+  const AttnJob& job = batch.j[lid % njobs];       // clip-major: an XCD gets whole clips with ALL their jobs (balanced)
+  const int b = lid / njobs;
   if (b >= job.B) return;   // block-uniform
-  if (blockIdx.z & 1) attn_bwd_dkv_part(job, drop, lds, blockIdx.x, b, h);
-  else attn_bwd_dq_part(job, drop, lds, blockIdx.x, b, h);
+  if (half) attn_bwd_dkv_part(job, drop, lds, bx, b, h);
+  else attn_bwd_dq_part(job, drop, lds, bx, b, h);
 }
 
 namespace hual {
