@@ -29,12 +29,12 @@ PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 
 PEAK_BF16_MATRIX_TFLOPS = 2516.8  # MI355X_MICROARCH.md: bf16 MFMA = 16 x the fp32 matrix rate (~2.5 PF dense)
 PEAK_HBM_GBS = 8000.0
 TRAFFIC_FILE = 'r1e_pmc_traffic.json'     # per-kernel HBM bytes per launch from the PMC passes of this round
-FEATURE_LOAD_KERNEL = 'feature_load_gemm_kernel<2>'
+FEATURE_LOAD_KERNEL = 'feature_ksplit_kernel'
 
 
 def mfma_peak(kernel):
     """(peak TFLOP/s of the matrix pipe the kernel runs on, MFMA passes per algorithmic product)"""
-    if 'bf16' in kernel or kernel.startswith('feature_load') or kernel.startswith('gemm_chain'):
+    if 'bf16' in kernel or kernel.startswith('feature_') or kernel.startswith('gemm_chain'):
         return PEAK_BF16_MATRIX_TFLOPS, 3      # split-bf16: hi*hi + hi*lo + lo*hi (csrc/bf16x3.h)
     return PEAK_F32_MATRIX_TFLOPS, 1
 
@@ -246,7 +246,8 @@ def main():
                 roof['algorithmic_bytes_per_launch'] = round(top['bytes'] / top['launches'])
         except (OSError, ValueError):
             pass
-        # the feature-load phase (video_conv1d + query_conv1d: streams the [B,T,vdim] clip features once) against HBM
+        # the feature-load phase (video_conv1d + query_conv1d: streams the [B,T,vdim] clip features once, writes the four
+        # K-quarter partial slabs) against HBM
         for d in fam:
             if d['kernel'] == FEATURE_LOAD_KERNEL and d['bytes'] > 0:
                 gbs = d['bytes'] / d['us'] / 1e3

@@ -93,6 +93,17 @@ int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* bof
 int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
 // the same jobs executed one after the other inside each block (row-local dependent layers; same M, N = 128)
 int launch_gemm_chain(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
+// Feature-load kernel: part[q][M][128] = dropout(A)[M, q*KS .. q*KS+KS) . W[q*KS .., :] for the four K-quarters q (Wimg =
+// forward image of the [K,128] weight, K <= 4*KS); the sum over q (+ bias) is taken by the consumer (ln_fwd_kernel's `part`).
+struct FkJob {
+  const float* A; int lda; int M; int K; int KS;
+  const float* Wimg;
+  float* part; size_t part_stride;
+  int drop_site; uint32_t drop_row0;
+};
+#define HUAL_MAX_FK_JOBS 2
+struct FkBatch { FkJob j[HUAL_MAX_FK_JOBS]; };
+int launch_feature_ksplit(const FkJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
 void gemm_job_init(GemmJob& j);
 void dw_job_init(DwJob& j);
 // enqueue `n` jobs (n <= HUAL_MAX_JOBS) as ONE launch on `stream`

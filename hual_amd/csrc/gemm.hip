@@ -621,6 +621,99 @@ __global__ __launch_bounds__(RT * 128) void feature_load_gemm_kernel(GemmBatch b
   gemm_bf16_body<0, RT>(batch.j[blockIdx.z], drop, reinterpret_cast<char*>(lds));
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Feature-load kernel: partial products of video_conv1d (model.py:47-48), Y_q[rows, 128] = dropout(video)[rows, Kq] . W[Kq, :]
+// for the K-quarter q = blockIdx.y.  The deep-K launch above is bound by what one CU pulls in (the whole 512 KB weight
+// image next to 128 KB of clip features) and both column-half waves draw the same dropout decisions.  Here a block owns
+// 128 rows x ONE quarter of K: its quarter of the weight image (KS <= 256 rows = 128 KB) is DMA'd into LDS once and stays
+// there, every clip-feature element is loaded, dropped and split exactly once (a wave owns 16 rows x all 128 columns), and
+// the four partial sums go to a [4][rows][128] slab that the layer-norm launch behind it adds up (ln_fwd_kernel, `part`).
+// Per CU: 128 KB of features + 128 KB of weights in, 64 KB out - against 640 KB in for the same rows before.
+#define FK_ROWS 128
+__global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, DropCfg drop) {
+  extern __shared__ float lds[];     // KS/64 stages of {hi tile, lo tile}
+  char* ldsb = reinterpret_cast<char*>(lds);
+  const FkJob& job = batch.j[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int q = blockIdx.y;
+  const int M = job.M, K = job.K, KS = job.KS;
+  if ((int)blockIdx.x * FK_ROWS >= M) return;          // block-uniform
+  const int rowbase = blockIdx.x * FK_ROWS + wave * 16;
+  const int arow = min(rowbase + j, M - 1);
+  const bool adrop = job.drop_site >= 0 && drop.enabled;
+  const uint32_t adrow = job.drop_row0 + (uint32_t)arow;
+  const int nst = KS / 64;
+  // the block's weight quarter: rows q*KS .. of the forward image (clamped to the last real row: the operand is zero
+  // there), 32 one-KB pieces per stage
+  {
+    const char* img = reinterpret_cast<const char*>(job.Wimg);
+    const int chp = lane & 15, rr = lane >> 4;
+    for (int pc = wave; pc < 32 * nst; pc += 8) {
+      const int st = pc >> 5, pl = pc & 31;
+      const int r = 4 * (pl & 15) + rr;
+      const int ch = chp ^ (((r & 3) << 2) | ((r >> 2) & 3));
+      const int kk = min(q * KS + 64 * st + r, K - 1);
+      const char* src = img + (size_t)kk * 512 + (pl >> 4) * 256 + 16 * ch;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(ldsb + st * GB_STAGE + pl * 1024), 16, 0, 0);
+    }
+  }
+  f32x4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* Ap = job.A + (size_t)arow * job.lda;
+  const int nks = KS / 32;
+  auto a_fetch = [&](int ks, float4& x0, float4& x1) {
+    const int kk = q * KS + 32 * ks + 8 * g;
+    x0 = kk < K ? ld4(Ap + kk) : f4zero();              // K is a multiple of 8: a lane's 8 values are in or out together
+    x1 = kk < K ? ld4(Ap + kk + 4) : f4zero();
+  };
+  float4 c0, c1, n0 = f4zero(), n1 = f4zero();
+  a_fetch(0, c0, c1);
+  if (nks > 1) a_fetch(1, n0, n1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
+  for (int ks = 0; ks < nks; ++ks) {
+    float4 f0 = f4zero(), f1 = f4zero();
+    if (ks + 2 < nks) a_fetch(ks + 2, f0, f1);       // two k-steps ahead
+    if (adrop) {
+      const uint32_t cg = (uint32_t)((q * KS + 32 * ks + 8 * g) >> 2);
+      c0 = apply_drop4(drop, (uint32_t)job.drop_site, adrow, cg, c0);
+      c1 = apply_drop4(drop, (uint32_t)job.drop_site, adrow, cg + 1u, c1);
+    }
+    uint2 h0, l0, h1, l1;
+    bf16_split4(c0, h0, l0);
+    bf16_split4(c1, h1, l1);
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
+    const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
+    const char* hi = ldsb + (ks >> 1) * GB_STAGE;
+    const int r0 = 32 * (ks & 1) + 8 * g + tq, r1 = r0 + 4;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int chunk = 2 * t + (tp >> 1);
+      const int o0 = tile256_off(r0, chunk) + 8 * (tp & 1), o1 = tile256_off(r1, chunk) + 8 * (tp & 1);
+      const bf16x8 wh = join_tr(lds_read_tr16(hi, o0), lds_read_tr16(hi, o1));
+      const bf16x8 wl = join_tr(lds_read_tr16(hi + GB_TILE, o0), lds_read_tr16(hi + GB_TILE, o1));
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, acc[t], 0, 0, 0);
+    }
+    c0 = n0; c1 = n1; n0 = f0; n1 = f1;
+  }
+  // accumulator tile t, lane (j, g), register r = row 4g + r, column 64 (t>>2) + 4j + (t&3)
+  float* out = job.part + (size_t)q * job.part_stride;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = rowbase + 4 * g + r;
+    if (row < M) {
+      st4(out + (size_t)row * 128 + 4 * j, make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]));
+      st4(out + (size_t)row * 128 + 64 + 4 * j, make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]));
+    }
+  }
+}
+
 // Chained launch: the jobs of the batch run ONE AFTER THE OTHER inside every block, on the block's own 16*RT rows.
 // Valid when each job reads, of the tensors written earlier in the chain, only the rows of its own block (dense layers
 // are row local), every job has the same M and N = 128: then a workgroup barrier between jobs is all the ordering
@@ -1380,6 +1473,33 @@ int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_
     if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 2>), g, blk, lds, stream, b, drop);
     else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 2>), g, blk, lds, stream, b, drop);
   }
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_feature_ksplit(const FkJob* jobs, int n, const DropCfg& drop, hipStream_t stream) {
+  HUAL_REQUIRE(n >= 1 && n <= HUAL_MAX_FK_JOBS, "feature_ksplit: job count");
+  FkBatch b;
+  int maxM = 0, maxKS = 0;
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const FkJob& j = jobs[i];
+    HUAL_REQUIRE(j.A && j.Wimg && j.part && j.M > 0, "feature_ksplit: null / empty");
+    HUAL_REQUIRE(j.K > 0 && (j.K % 8) == 0 && (j.KS % 64) == 0 && j.KS >= 64 && j.KS <= 256 && 4 * j.KS >= j.K && (j.lda % 4) == 0,
+                 "feature_ksplit: need K % 8 == 0 and a quarter size KS (multiple of 64, <= 256) with 4*KS >= K");
+    b.j[i] = j;
+    maxM = j.M > maxM ? j.M : maxM;
+    maxKS = j.KS > maxKS ? j.KS : maxKS;
+    flops += 2.0 * j.M * (double)j.K * 128.0;
+    bytes += 4.0 * ((double)j.M * j.K + (double)j.K * 128 + 4.0 * j.M * 128);      // features + weights in, 4 partial slabs out
+  }
+  static bool attr = false;
+  if (!attr) {
+    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)feature_ksplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  const size_t lds = (size_t)(maxKS / 64) * GB_STAGE;
+  HUAL_LAUNCH(flops, bytes, feature_ksplit_kernel, dim3(cdiv(maxM, FK_ROWS), 4, n), dim3(512), lds, stream, b, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

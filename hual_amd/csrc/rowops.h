@@ -23,6 +23,9 @@ struct LnFwd {
   const float* pos;                                // optional [max_vlen,128]: y1 += pos[t]   (modules.py:41-56)
   int drop_site; uint32_t drop_row0;               // optional dropout on y1
   int row0;                                        // unified row index of x's first row (pos / clip lookup)
+  // optional: x is not given ready but as nparts partial sums (feature_ksplit_kernel): x = sum_q part[q*part_stride + ...]
+  // + part_bias; the sum is also written to x_out (the pre-LN tensor backward needs)
+  const float* part; int nparts; size_t part_stride; const float* part_bias; float* x_out;
 };
 int launch_ln_fwd(const LnFwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
 

@@ -47,7 +47,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd a, RowSpace rs, DropC
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   for (int row = blockIdx.x * 8 + grp; row < a.R; row += gridDim.x * 8) {
-    float4 v = ld4(a.x + (size_t)row * HUAL_D + col);
+    float4 v;
+    if (a.part) {       // K-split partial sums of the producing dense layer (+ its bias)
+      v = ld4(a.part_bias + col);
+      for (int q = 0; q < a.nparts; ++q) v = f4add_(v, ld4(a.part + (size_t)q * a.part_stride + (size_t)row * HUAL_D + col));
+      st4(a.x_out + (size_t)row * HUAL_D + col, v);
+    } else {
+      v = ld4(a.x + (size_t)row * HUAL_D + col);
+    }
     float mean, rstd;
     row_stats(v, mean, rstd);
     float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
@@ -338,8 +345,8 @@ static inline int row_grid(int R) {
 }
 
 int launch_ln_fwd(const LnFwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
-  HUAL_REQUIRE(a.x && a.g1 && a.b1 && a.y1 && a.R > 0, "ln_fwd: null/empty");
-  HUAL_LAUNCH(0.0, 8.0 * a.R * HUAL_D, ln_fwd_kernel, dim3(row_grid(a.R)), dim3(256), 0, s, a, rs, drop);
+  HUAL_REQUIRE((a.x || (a.part && a.part_bias && a.x_out && a.nparts > 0)) && a.g1 && a.b1 && a.y1 && a.R > 0, "ln_fwd: null/empty");
+  HUAL_LAUNCH(0.0, (8.0 + (a.part ? 4.0 * a.nparts + 4.0 : 0.0)) * a.R * HUAL_D, ln_fwd_kernel, dim3(row_grid(a.R)), dim3(256), 0, s, a, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

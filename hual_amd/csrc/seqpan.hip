@@ -482,7 +482,22 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   }
   // ---------------- the two input projections (model.py:42,48) as one launch; LN + pos (model.py:43,49,53,56)
   float* lin = c.act("lin");
-  {
+  // feature-load path: K-split kernel with LDS-resident weight quarters (gemm.h launch_feature_ksplit); its four partial
+  // slabs are summed by the layer-norm launch.  HUAL_FEATURE_KSPLIT=0 or an unsupported vdim: the generic dense launch.
+  static const int ksplit_env = []() { const char* e = getenv("HUAL_FEATURE_KSPLIT"); return e ? atoi(e) : 1; }();
+  const int qks = ((catw + 3) / 4 + 63) & ~63;                   // quarter size of query_conv1d's K (multiple of 64)
+  const bool ksplit = c.use_bf16 && ksplit_env && (c.cfg->vdim % 256) == 0 && c.cfg->vdim <= 1024 && (catw % 8) == 0 && qks <= 256;
+  float* vpart = c.buf("lin.part", (size_t)4 * R, D);
+  if (ksplit) {
+    if (!c.dry && c.ok()) {
+      FkJob fj[2];
+      fj[0] = FkJob{bt->video, c.cfg->vdim, Nv, c.cfg->vdim, c.cfg->vdim / 4, reinterpret_cast<const float*>(c.PKF + pm.vconv.k * 4),
+                    vpart, (size_t)R * D, HUAL_SITE_VIDEO, 0};
+      fj[1] = FkJob{cat, catw, Nq, catw, qks, reinterpret_cast<const float*>(c.PKF + pm.qconv.k * 4),
+                    vpart + (size_t)Nv * D, (size_t)R * D, -1, 0};
+      c.chk(launch_feature_ksplit(fj, 2, c.drop, c.stream));
+    }
+  } else {
     GemmJob j[2];
     j[0] = mkjob(c.dry ? nullptr : bt->video, c.cfg->vdim, Nv, c.cfg->vdim, c.p(pm.vconv.k), c.p(pm.vconv.b), lin, D);
     j[0].a_drop_site = HUAL_SITE_VIDEO; j[0].a_drop_row0 = 0;
@@ -496,9 +511,11 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     LnFwd a{};
     a.x = lin; a.R = Nv; a.g1 = c.p(pm.vln.g); a.b1 = c.p(pm.vln.b); a.y1 = x; a.mean = lin_mean; a.rstd = lin_rstd;
     a.pos = c.p(pm.pos); a.drop_site = -1; a.row0 = 0;
+    if (ksplit) { a.x = nullptr; a.part = vpart; a.nparts = 4; a.part_stride = (size_t)R * D; a.part_bias = c.p(pm.vconv.b); a.x_out = lin; }
     c.ln_fwd(a, rs);
     a.x = lin + (size_t)Nv * D; a.R = Nq; a.g1 = c.p(pm.qln.g); a.b1 = c.p(pm.qln.b); a.y1 = x + (size_t)Nv * D;
     a.mean = lin_mean + Nv; a.rstd = lin_rstd + Nv; a.row0 = Nv;
+    if (ksplit) { a.x = nullptr; a.part = vpart + (size_t)Nv * D; a.part_bias = c.p(pm.qconv.b); a.x_out = lin + (size_t)Nv * D; }
     c.ln_fwd(a, rs);
   }
   // ---------------- shared conv block (model.py:54-58)
