@@ -1598,7 +1598,7 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
     attr = true;
   }
   // HUAL_DW_IMPL=0: fp32 MFMA kernel (dw_kernel); default: split-bf16 kernel (dw_bf16_kernel)
-  static const int dw_impl = []() { const char* e = getenv("HUAL_DW_IMPL"); return e ? atoi(e) : 1; }();
+  const int dw_impl = []() { const char* e = getenv("HUAL_DW_IMPL"); return e ? atoi(e) : 1; }();     // read per call (tests)
   if (!attr2) {
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

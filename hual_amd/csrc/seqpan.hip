@@ -484,7 +484,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* lin = c.act("lin");
   // feature-load path: K-split kernel with LDS-resident weight quarters (gemm.h launch_feature_ksplit); its four partial
   // slabs are summed by the layer-norm launch.  HUAL_FEATURE_KSPLIT=0 or an unsupported vdim: the generic dense launch.
-  static const int ksplit_env = []() { const char* e = getenv("HUAL_FEATURE_KSPLIT"); return e ? atoi(e) : 1; }();
+  const int ksplit_env = []() { const char* e = getenv("HUAL_FEATURE_KSPLIT"); return e ? atoi(e) : 1; }();     // per call (tests)
   const int qks = ((catw + 3) / 4 + 63) & ~63;                   // quarter size of query_conv1d's K (multiple of 64)
   const bool ksplit = c.use_bf16 && ksplit_env && (c.cfg->vdim % 256) == 0 && c.cfg->vdim <= 1024 && (catw % 8) == 0 && qks <= 256;
   float* vpart = c.buf("lin.part", (size_t)4 * R, D);

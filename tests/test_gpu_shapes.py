@@ -17,16 +17,16 @@ def _check(rows, idx_equal, kinds=('tap', 'out', 'loss', 'grad')):
     assert idx_equal
 
 
-def _check_large(rows, idx_equal):
+def _check_large(rows, idx_equal, max_miss=0.05, far=5e-2):
     """Shapes with ~10^5 ReLU inputs always have some within float32 rounding of 0, where relu'(z) - and with it whole
     gradient rows - is decided by rounding ("ReLU conditioning"): forward tensors and losses are held to
     1e-3 like everywhere; of the 170 gradient tensors at most 5 % may miss 1e-3 and none may miss 5e-2."""
     _check(rows, idx_equal, kinds=('tap', 'out', 'loss'))
     grads = [(k, n, d, r) for (k, n, d, r) in rows if k == 'grad']
     miss = [g for g in grads if not (g[2] <= TOL or g[2] <= TOL * g[3])]
-    far = [g for g in grads if not (g[2] <= 5e-2 or g[2] <= 5e-2 * g[3])]
-    assert not far, pu.format_report(far)
-    assert len(miss) <= 0.05 * len(grads), pu.format_report(miss)
+    beyond = [g for g in grads if not (g[2] <= far or g[2] <= far * g[3])]
+    assert not beyond, pu.format_report(beyond)
+    assert len(miss) <= max_miss * len(grads), pu.format_report(miss)
 
 
 def test_activitynet_dims():
@@ -66,3 +66,27 @@ def test_tiny_clips_and_one_word_queries():
     # gradients: compared too, but ReLU decisions within rounding of 0 may flip on this unconditioned batch
     bad = [(k, n, d, r) for (k, n, d, r) in rows if k == 'grad' and not (d <= 2e-2 or d <= 2e-2 * r)]
     assert not bad, pu.format_report(bad)
+
+
+@pytest.mark.parametrize('vdim', [512, 320, 2048])
+def test_other_feature_widths(vdim):
+    """vdim 512 (BASELINE configs[0], K-split feature kernel with 128-row quarters), 320 (generic dense launch: not a
+    multiple of 256) and 2048 (generic deep-K launch: above the K-split kernel's LDS budget)"""
+    case = pu.well_conditioned_case(drop_rate=0.2, B=3, T=21, L=6, C=5, seed=81, max_vlen=24, vdim=vdim)
+    rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2)
+    # forward strict; gradients with the ReLU-flip allowance: the split-bf16 products carry ~1e-6 relative error, so a ReLU
+    # input a few 1e-6 from 0 (inside the conditioning band of the oracle's float32 noise model) can still flip and change
+    # the ~10 gradient tensors upstream of that layer by a few percent (seen at vdim 512: conv_block layer 0)
+    _check_large(rows, idx_equal, max_miss=0.10, far=0.10)
+
+
+def test_generic_feature_path_switch(monkeypatch):
+    """HUAL_FEATURE_KSPLIT=0 / HUAL_GEMM_BF16=0 / HUAL_CHAIN=0: the generic and the fp32-MFMA paths give the same numbers"""
+    for env in ({'HUAL_FEATURE_KSPLIT': '0'}, {'HUAL_GEMM_BF16': '0', 'HUAL_DW_IMPL': '0'}, {'HUAL_CHAIN': '0'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        case = pu.well_conditioned_case(drop_rate=0.2, B=3, T=37, L=9, C=4, seed=11, max_vlen=40)
+        rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2)
+        _check(rows, idx_equal)
+        for k in env:
+            monkeypatch.delenv(k)
