@@ -1,0 +1,149 @@
+"""Thin driver with the loop contract of /root/reference/main.py:50-111 and utils/runner_utils.py:139-176 on the HIP path.
+
+    reference                                               here
+    ----------------------------------------------------    -------------------------------------------------------
+    main.py --mode train   (epochs, lr decay :61, best       Runner.train(epochs) -> per-epoch "TRAIN:\\t..\\nTEST:\\t.."
+      R1@0.7 checkpoint :71-75)                               lines, best checkpoint = <ckpt_dir>/best_SeqPAN.npz
+    main.py --mode test                                      Runner.test()
+    main.py --mode infer_trainset -> results/<task>/<suffix>.pkl   Runner.infer_trainset(path)
+    runner_utils.train_epoch / test_epoch (IoU bookkeeping)  Runner.train_epoch / Runner.test_epoch
+    tf.train.Saver                                           numpy .npz keyed by the TF variable names
+
+Data: the records the reference's dataset_gen leaves (utils/data_gen.py:98-125: vid, duration, v_len, words, w_ids, c_ids,
+s_ind, e_ind) + {vid: float32 [n, vdim]} features; both go to HBM once (hual_amd/dataset.py).  Python `random` is seeded here
+(the reference leaves the epoch order unseeded).  There is no CPU fallback.
+"""
+import logging
+import os
+import pickle
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import al, data, lib
+from .dataset import DeviceDataset
+from .model import SeqPAN
+from .train import Trainer
+
+
+class Runner:
+    def __init__(self, configs, word_vectors, train_records, test_records, visual_feats, device='cuda:0', seed=12345,
+                 ckpt_dir=None, logger=None):
+        """configs: dict with the keys of configs/<task>/SeqPAN.yaml (+ num_chars, num_words like main.py:35-36)."""
+        self.configs = configs
+        self.model = SeqPAN(configs, word_vectors, device=device, seed=seed, rng_seed=seed)
+        self.train_set = DeviceDataset(train_records, visual_feats, device=device)
+        self.test_set = DeviceDataset(test_records, visual_feats, device=device) if test_records else None
+        self.batch_size = int(configs['train']['batch_size'])
+        self.droprate = float(configs['train']['droprate'])
+        self.lr = float(configs['train']['lr'])
+        self.ckpt_dir = ckpt_dir or os.path.join('ckpt', '%s_' % configs.get('task', 'task'))      # main.py:42 (sic)
+        self.log = logger or logging.getLogger('hual_amd')
+        self.rand = random.Random(seed)
+        self.trainer = Trainer(self.model, world=1, use_graph=False)
+        self.clips_per_s = 0.0
+
+    # ------------------------------------------------------------------ runner_utils.train_epoch (:139-159)
+    @staticmethod
+    def _ious(records, sidx, eidx):
+        out = []
+        for r, s, e in zip(records, sidx, eidx):
+            st, et = data.index_to_time([int(s), int(e)], r['v_len'], r['duration'])
+            gs, ge = data.index_to_time([r['s_ind'], r['e_ind']], r['v_len'], r['duration'])
+            out.append(al.calculate_iou([st, et], [gs, ge]))
+        return out
+
+    def train_epoch(self, cur_lr):
+        ds, N = self.train_set, len(self.train_set)
+        order = list(range(N))
+        self.rand.shuffle(order)                                   # data_loader.py:24
+        ious, feeds, pending = [], None, None
+        t0 = time.perf_counter()
+        for lo in range(0, N, self.batch_size):
+            sel = order[lo:lo + self.batch_size]
+            feeds = ds.assemble(sel, out=None, min_chars=4)
+            self.trainer.set_batch_device(feeds)
+            self.trainer.step(lr=cur_lr, drop_rate=self.droprate)
+            # the spans of the previous batch are fetched while this one runs (one step of latency hiding)
+            if pending is not None:
+                ious += self._ious(pending[0], pending[1].cpu().numpy(), pending[2].cpu().numpy())
+            pending = ([ds.records[i] for i in sel], self.trainer.start_index.clone(), self.trainer.end_index.clone())
+        if pending is not None:
+            ious += self._ious(pending[0], pending[1].cpu().numpy(), pending[2].cpu().numpy())
+        torch.cuda.synchronize()
+        self.clips_per_s = N / max(time.perf_counter() - t0, 1e-9)
+        return al.iou_metrics(ious)
+
+    # ------------------------------------------------------------------ runner_utils.test_epoch (:161-176)
+    def test_epoch(self, dataset=None):
+        ds = dataset or self.test_set
+        ious = []
+        for lo in range(0, len(ds), self.batch_size):
+            sel = np.arange(lo, min(len(ds), lo + self.batch_size))
+            f = ds.assemble(sel, labels=False, min_chars=4)
+            o = self.model.forward(f['video'], f['video_seq_len'], f['word_ids'], f['char_ids'], drop_rate=0.0)
+            ious += self._ious([ds.records[i] for i in sel], o['start_index'].cpu().numpy(), o['end_index'].cpu().numpy())
+        return al.iou_metrics(ious)
+
+    # ------------------------------------------------------------------ main.py --mode train (:50-78)
+    def train(self, epochs=None):
+        epochs = int(epochs if epochs is not None else self.configs['train']['epochs'])
+        best, best_lines = -1.0, None
+        for epoch in range(epochs):
+            self.log.info('Epoch {}|{}:'.format(epoch, epochs))
+            cur_lr = self.lr * (1.0 - epoch / epochs)             # main.py:61
+            r = self.train_epoch(cur_lr)
+            train_line = 'TRAIN:\t{:.2f}\t{:.2f}\t{:.2f}\t{:.2f}\t'.format(*r)
+            self.log.info(train_line + '({:.0f} clips/s)'.format(self.clips_per_s))
+            test_line = ''
+            r1i7 = r[2]
+            if self.test_set is not None:
+                t = self.test_epoch()
+                test_line = 'TEST:\t{:.2f}\t{:.2f}\t{:.2f}\t{:.2f}\t'.format(*t)
+                self.log.info(test_line)
+                r1i7 = t[2]
+            if r1i7 > best:                                       # main.py:71-75
+                best = r1i7
+                self.save(os.path.join(self.ckpt_dir, 'best_SeqPAN.npz'))
+                best_lines = '\n' + train_line + '\n' + test_line
+        self.log.info('\n\nHighest R1i7 epoch\n')
+        self.log.info(best_lines)
+        return best
+
+    def test(self):
+        self.load(os.path.join(self.ckpt_dir, 'best_SeqPAN.npz'))
+        t = self.test_epoch()
+        self.log.info('TEST:\t{:.2f}\t{:.2f}\t{:.2f}\t{:.2f}\t'.format(*t))
+        return t
+
+    # ------------------------------------------------------------------ main.py --mode infer_trainset (:99-111)
+    def infer_trainset(self, path=None, mc_dropout=None, load_best=True):
+        """results/<task>/<suffix>.pkl of runner_utils.py:103-104.  mc_dropout=None: as the reference runs."""
+        if load_best:
+            self.load(os.path.join(self.ckpt_dir, 'best_SeqPAN.npz'))
+        ds = self.train_set
+
+        def batches():                                            # TrainNoSuffleLoader.test_iter (data_loader.py:167-206)
+            for lo in range(0, len(ds), self.batch_size):
+                sel = np.arange(lo, min(len(ds), lo + self.batch_size))
+                f = ds.assemble(sel, labels=False, min_chars=4)
+                yield [ds.records[i] for i in sel], f['video'], f['video_seq_len'], f['word_ids'], f['char_ids']
+        records, ious = al.infer_trainset(self.model, batches(), mc_dropout=mc_dropout)
+        if path:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, 'wb') as f:
+                pickle.dump(records, f)
+        m = al.iou_metrics(ious)
+        self.log.info('predict train set:\t{:.2f}\t{:.2f}\t{:.2f}\t{:.2f}\t'.format(*m))
+        return records, m
+
+    # ------------------------------------------------------------------ checkpoints by TF variable name
+    def save(self, path):
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        np.savez(path, **{k.replace('/', '|'): v for k, v in self.model.state_dict().items()})
+
+    def load(self, path):
+        with np.load(path) as z:
+            self.model.load_state_dict({k.replace('|', '/'): z[k] for k in z.files})

@@ -1,4 +1,6 @@
 import os, sys, ctypes, numpy as np, torch
+# NOTE: needs the temporary STAMP() instrumentation of gemm_bf16_body + hual_debug_stamps() (see git history of this file's commit);
+# kept as the record of how the in-kernel phase split quoted in DESIGN.md 6 was measured.
 sys.path.insert(0, os.getcwd())
 import bench
 from hual_amd import lib
