@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 PEAK_BF16_MATRIX_TFLOPS = 2516.8  # MI355X_MICROARCH.md: bf16 MFMA = 16 x the fp32 matrix rate (~2.5 PF dense)
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILE = 'r1e_pmc_traffic.json'     # per-kernel HBM bytes per launch from the PMC passes of this round
+TRAFFIC_FILE = 'r1f_pmc_traffic.json'     # per-kernel HBM bytes per launch from the PMC passes of this round
 FEATURE_LOAD_KERNEL = 'feature_ksplit_kernel'
 
 
