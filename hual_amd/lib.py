@@ -73,6 +73,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles its own libamdhip64, and a process must end up with ONE HIP runtime - if this library
+    # were loaded before torch it would bind /opt/rocm's copy and its launches would not see torch's device context
+    # ("no ROCm-capable device is detected")
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise HualError('%s not found: build it with `python -m hual_amd.build` (or __graft_entry__.build())' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
