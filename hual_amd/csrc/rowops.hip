@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_bwd_kernel(ConvBwd a, RowSpace 
 
 // ------------------------------------------------------------------------------------------------------
 struct ColsumBatch { ColsumJob j[HUAL_COLSUM_MAX_JOBS]; };
-#define COLSUM_SPLIT 4
+#define COLSUM_SPLIT 16   // independent row slices per (job, vector): the kernel is a chain of dependent-latency loads (18.5 us at 4, see profiles)
 __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch batch) {
   __shared__ float part[HUAL_D];
   const ColsumJob& job = batch.j[blockIdx.x];
