@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times one active-learning round (update_label -> train -> infer_trainset) on a synthetic, HBM-resident training set
 and the CPU oracle's update_label on the same inputs (BASELINE.json configs[4], scaled to one GPU).
-    python scripts/bench_al_round.py [--n 4096] [--epochs 1] [--task anet]
+    python scripts/bench_al_round.py [--n 4096] [--epochs 1] [--task anet] [--cpu-baseline]
 Prints one JSON line."""
 import argparse
 import copy
@@ -26,7 +26,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--epochs', type=int, default=1)
     ap.add_argument('--task', default='anet')
-    ap.add_argument('--no-oracle', action='store_true')
+    ap.add_argument('--cpu-baseline', action='store_true',
+                    help='also time the CPU oracle (oracle/al_ref.py) on the same update_label inputs and compare the results - the\n                    checker / baseline leg, off by default: the measured path never touches oracle/')
     args = ap.parse_args()
     import al_synth
     from hual_amd import al, lib
@@ -53,7 +54,7 @@ def main():
     prop0, _ = al.infer_trainset(model, batches(), mc_dropout=0.5)
     out = dict(n_samples=args.n, max_vlen=args.max_vlen, vdim=args.vdim, batch=args.batch, epochs=args.epochs, task=args.task,
                dataset_upload_s=round(t_upload, 3), feature_bank_gb=round(ds.feat_bank.numel() * 4 / 1e9, 3))
-    if not args.no_oracle:
+    if args.cpu_baseline:
         from oracle import al_ref as A
         t0 = time.perf_counter()
         ref = A.update_labels(copy.deepcopy(data_old), data_gt, prop0, A.get_coff(args.task, 1))
@@ -62,7 +63,7 @@ def main():
     al.update_labels(copy.deepcopy(data_old), data_gt, prop0, al.get_coff(args.task, 1))
     new_data, prop1, m = al.run_round(model, ds, copy.deepcopy(data_old), data_gt, prop0, args.task, 1, epochs=args.epochs,
                                       batch_size=args.batch, lr=1e-4, drop_rate=0.2, log=lambda s: print(s, file=sys.stderr))
-    if not args.no_oracle:
+    if args.cpu_baseline:
         out['update_label_equal_to_oracle'] = all(a[2] == b[2] and a[4] == b[4] for a, b in zip(new_data, ref))
     out.update({k: (round(v, 4) if isinstance(v, float) else v) for k, v in m.items()})
     print(json.dumps(out))
