@@ -134,7 +134,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--aux', action='store_true', help='second stream for the weight-gradient launches (experiment)')
+    ap.add_argument('--aux', action='store_true', help='side stream for the alignment-loss branch of forward (experiment)')
     ap.add_argument('--prewarm', type=int, default=400, help='untimed steps before the warm-up steps (clock ramp)')
     args = ap.parse_args()
 

@@ -24,8 +24,10 @@ class Trainer:
         self.shape = None
         self._tables_ready = False
         self._lib = lib.load()
-        # optional second stream + fork/join events (hual_run_opts.aux).  Measured on MI355X: overlapping the
-        # weight-gradient launch with the rest of backward does not pay (3.55 vs 3.50 ms/step), so it is off by default.
+        # optional second stream + fork/join events (hual_run_opts.aux): the alignment-loss branch of forward runs there,
+        # under the predictor.  Measured on MI355X: 2.297 vs 2.300 ms/step - the main chain's launches fill every CU, so
+        # the side branch buys nothing and the option stays off.  (The weight-gradient launch on the side stream,
+        # HUAL_DW_AUX=1, costs +1.4 %.)
         self.aux = None
         if use_aux:
             self.aux = lib.hual_aux()
