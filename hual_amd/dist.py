@@ -22,10 +22,20 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def _host_staged(t):
+    """gloo (the CPU / single-GPU rehearsal backend) moves device tensors through the host; RCCL works on them in place"""
+    return t.is_cuda and dist.get_backend() == 'gloo'
+
+
 def allreduce_sum_(flat):
     """in-place sum of the flat gradient bucket over ranks"""
     if world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if _host_staged(flat):
+            h = flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
@@ -33,6 +43,8 @@ def global_count(local_count, device):
     """sum of a python/0-d count over ranks -> float"""
     t = torch.tensor([float(local_count)], device=device, dtype=torch.float64)
     if world_size() > 1:
+        if _host_staged(t):
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -49,8 +61,13 @@ def gather_features(that, vhat):
     if w == 1:
         return that, vhat
     both = torch.cat([that, vhat], dim=1).contiguous()
-    out = torch.empty((w * both.shape[0], both.shape[1]), dtype=both.dtype, device=both.device)
-    dist.all_gather_into_tensor(out, both)
+    if _host_staged(both):
+        parts = [torch.empty(both.shape, dtype=both.dtype) for _ in range(w)]
+        dist.all_gather(parts, both.cpu())
+        out = torch.cat(parts, dim=0).to(both.device)
+    else:
+        out = torch.empty((w * both.shape[0], both.shape[1]), dtype=both.dtype, device=both.device)
+        dist.all_gather_into_tensor(out, both)
     d = that.shape[1]
     return out[:, :d].contiguous(), out[:, d:].contiguous()
 
