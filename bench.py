@@ -260,6 +260,12 @@ def main():
                         roof['feature_load']['traffic'] = tr_tab[d['kernel']]['hbm_bytes_per_launch']
                 except NameError:
                     pass
+        # the attention contractions (QK^T, PV and their gradients) run on the exact-fp32 matrix pipe: algorithmic TFLOP/s of
+        # those launches against its 157.3 TFLOP/s (north_star: "MFMA utilisation on the attention GEMMs")
+        roof['attention'] = [dict(kernel=d['kernel'], achieved=round(d['flops'] / d['us'] / 1e6, 2), peak=PEAK_F32_MATRIX_TFLOPS,
+                                  unit='TFLOP/s', frac=round(d['flops'] / d['us'] / 1e6 / PEAK_F32_MATRIX_TFLOPS, 4),
+                                  us_per_step=round(d['us'] / psteps, 1))
+                             for d in fam if d['kernel'].startswith('attn_') and d['flops'] > 0]
         roof['families'] = [dict(kernel=d['kernel'], launches_per_step=d['launches'] // psteps,
                                  us_per_step=round(d['us'] / psteps, 1),
                                  tflops=round(d['flops'] / d['us'] / 1e6, 2) if d['flops'] > 0 else None,
