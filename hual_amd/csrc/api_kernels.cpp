@@ -2,6 +2,9 @@
 #include "../../include/hual_seqpan.h"
 #include "common.h"
 #include "gemm.h"
+#include "attn.h"
+#include "heads.h"
+#include "rowops.h"
 
 namespace hual {
 const char* last_error_cstr();
@@ -68,6 +71,37 @@ int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, con
   }
   DropCfg d = make_dropcfg(nullptr, 0.f);
   return launch_gemm_bf16(&j, 1, d, (hipStream_t)stream);
+}
+
+int hual_layer_norm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int R,
+                        void* stream) {
+  HUAL_REQUIRE(x && gamma && beta && y && R > 0, "hual_layer_norm_fwd: null / empty");
+  LnFwd a{};
+  a.x = x; a.R = R; a.g1 = gamma; a.b1 = beta; a.y1 = y; a.mean = mean; a.rstd = rstd; a.drop_site = -1;
+  RowSpace rs{};
+  rs.R = R; rs.Nv = R; rs.T = R; rs.B = 1;
+  DropCfg d = make_dropcfg(nullptr, 0.f);
+  return launch_ln_fwd(a, rs, d, (hipStream_t)stream);
+}
+
+int hual_attention_fwd(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
+                       int Tk, const float* qmask, const float* kmask, void* stream) {
+  HUAL_REQUIRE(Q && K && V && O && qmask && kmask, "hual_attention_fwd: null pointer");
+  AttnJob j;
+  attn_job_init(j);
+  j.Q = Q; j.ldq = ldq; j.K = K; j.V = V; j.ldkv = ldkv; j.O = O; j.ldo = ldo;
+  j.B = B; j.Tq = Tq; j.Tk = Tk; j.qrow0 = 0; j.krow0 = 0; j.qmask = qmask; j.kmask = kmask;
+  DropCfg d = make_dropcfg(nullptr, 0.f);
+  return launch_attn_fwd(&j, 1, d, (hipStream_t)stream);
+}
+
+int hual_span_argmax(const float* start_logits, const float* end_logits, const float* vmask, int64_t* start_index,
+                     int64_t* end_index, int B, int T, void* stream) {
+  HUAL_REQUIRE(start_logits && end_logits && vmask && start_index && end_index && B > 0 && T > 0, "hual_span_argmax: null / empty");
+  LocArgs a{};
+  a.s_logit = start_logits; a.e_logit = end_logits; a.vmask = vmask; a.start_index = start_index; a.end_index = end_index;
+  a.inv_batch = 1.0f / (float)B;
+  return launch_loc(a, B, T, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -205,6 +205,22 @@ int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, con
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
                    int N, int rows_per_block, void* stream);
 
+/* layer_norm (models/layers.py:7-17): y = (x - mean) * rsqrt(var + 1e-6) * gamma + beta over the 128 columns of each row;
+ * mean / rstd (optional, [R]) are what the backward needs. */
+int hual_layer_norm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int R,
+                        void* stream);
+
+/* multi-head attention core of dual_multihead_attention / top_self_attention (models/layers.py:80-96, modules.py:104-119):
+ * 8 heads of size 16 kept merged in [rows,128]; scores / sqrt(16) + (1 - qmask x kmask) * (-1e30), softmax, P.V.
+ * Q rows b*Tq + t, K/V rows b*Tk + t; masks are [B*Tq] / [B*Tk] floats (0/1).  Tk <= 256. */
+int hual_attention_fwd(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
+                       int Tk, const float* qmask, const float* kmask, void* stream);
+
+/* ans_predictor (models/layers.py:194-203): softmax of the masked logits, upper-triangular outer product, start = argmax
+ * over rows of the row maxima, end = argmax over columns of the column maxima, first index on ties.  T <= 256. */
+int hual_span_argmax(const float* start_logits, const float* end_logits, const float* vmask, int64_t* start_index,
+                     int64_t* end_index, int B, int T, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Device-side batch assembly: TrainLoader.process_batch / TestLoader.process_batch
  * (/root/reference/utils/data_loader.py:30-98,145-164) from a training set that stays resident in HBM.
