@@ -14,6 +14,18 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {   // blockDim m
   for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sm[i];
   return s;   // sm must hold blockDim.x/64 floats
 }
+// double-precision block sum (the span selection's softmax denominator: the sum of <= 256 floats in double is exact
+// to ~2^-53, so its float rounding does not depend on the order of the additions)
+__device__ __forceinline__ double block_sum_d(double v, double* sm) {
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sm[i];
+  return s;
+}
 __device__ __forceinline__ float block_max(float v, float* sm) {
   v = wave_max64(v);
   const int w = threadIdx.x >> 6;
@@ -352,6 +364,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(DotArgs a, DotBwd g) {
 __global__ __launch_bounds__(256) void loc_kernel(LocArgs a, int T) {
   __shared__ float ps[256], pe[256];
   __shared__ float sm[4];
+  __shared__ double smd[4];
   __shared__ float bestv[2][4];
   __shared__ int besti[2][4];
   const int b = blockIdx.x, t = threadIdx.x;
@@ -364,11 +377,15 @@ __global__ __launch_bounds__(256) void loc_kernel(LocArgs a, int T) {
   }
   const float mxs = block_max(zs, sm);
   const float mxe = block_max(ze, sm);
-  const float xs = in ? expf(zs - mxs) : 0.f;
-  const float xe = in ? expf(ze - mxe) : 0.f;
-  const float sums = block_sum(xs, sm);
-  const float sume = block_sum(xe, sm);
-  const float p_s = xs / sums, p_e = xe / sume;
+  // Reproducible float32 softmax (the span indices must be BIT EXACT, north_star): exp of the float32 difference is
+  // evaluated in double and rounded once to float32 (= the correctly rounded float32 exp), the denominator is the
+  // double-precision sum of those floats rounded once, the quotient is an IEEE float32 division.  None of the three
+  // depends on the platform's libm or on a summation order; oracle/seqpan_ref.py::softmax_cr does the same arithmetic.
+  const float xs = in ? (float)exp((double)(zs - mxs)) : 0.f;
+  const float xe = in ? (float)exp((double)(ze - mxe)) : 0.f;
+  const float sums = (float)block_sum_d((double)xs, smd);
+  const float sume = (float)block_sum_d((double)xe, smd);
+  const float p_s = __fdiv_rn(xs, sums), p_e = __fdiv_rn(xe, sume);
   ps[t] = p_s;
   pe[t] = p_e;
   if (a.y1) {

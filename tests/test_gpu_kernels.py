@@ -54,9 +54,23 @@ def test_attention_fwd(dev, B, Tq, Tk):
     assert (O.double() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize('B,T', [(4, 7), (16, 64), (3, 256)])
-def test_span_argmax_bit_exact(dev, B, T):
+def _span_ref(s, e, m):
+    """ans_predictor of the oracle (oracle/seqpan_ref.py, layers.py:194-203) on CPU float32"""
+    from oracle import seqpan_ref as R
+    return R.ans_predictor(s.cpu(), e.cpu(), m.cpu())
+
+
+def _span_hip(dev, s, e, m):
     from hual_amd import lib
+    B, T = s.shape
+    si = torch.empty(B, dtype=torch.int64, device=dev)
+    ei = torch.empty(B, dtype=torch.int64, device=dev)
+    lib.check(lib.load().hual_span_argmax(lib.ptr(s), lib.ptr(e), lib.ptr(m), lib.ptr(si), lib.ptr(ei), B, T, lib.stream_ptr()))
+    return si.cpu(), ei.cpu()
+
+
+@pytest.mark.parametrize('B,T', [(4, 7), (16, 64), (3, 256), (64, 128)])
+def test_span_argmax_bit_exact(dev, B, T):
     g = torch.Generator().manual_seed(B + T)
     s = (torch.randn(B, T, generator=g) * 3).to(dev)
     e = (torch.randn(B, T, generator=g) * 3).to(dev)
@@ -64,21 +78,31 @@ def test_span_argmax_bit_exact(dev, B, T):
     lens = torch.randint(1, T + 1, (B,), generator=g)
     lens[0] = T
     m = (torch.arange(T)[None, :] < lens[:, None]).float().to(dev)
-    si = torch.empty(B, dtype=torch.int64, device=dev)
-    ei = torch.empty(B, dtype=torch.int64, device=dev)
-    lib.check(lib.load().hual_span_argmax(lib.ptr(s), lib.ptr(e), lib.ptr(m), lib.ptr(si), lib.ptr(ei), B, T, lib.stream_ptr()))
-    # float32 reference with the reference's op order (layers.py:194-203)
-    sm = s.cpu() * m.cpu() + (-1e30) * (1.0 - m.cpu())
-    em = e.cpu() * m.cpu() + (-1e30) * (1.0 - m.cpu())
-    ps, pe = torch.softmax(sm, 1), torch.softmax(em, 1)
-    outer = torch.triu(ps.unsqueeze(2) * pe.unsqueeze(1))
-    rs = torch.max(torch.max(outer, dim=2)[0], dim=1)[1]
-    re_ = torch.max(torch.max(outer, dim=1)[0], dim=1)[1]
-    assert (si.cpu() <= ei.cpu()).all()
-    # the kernel's softmax uses its own exp: indices must agree wherever the top two candidates differ by more than rounding
-    for b in range(B):
-        if int(si[b]) != int(rs[b]) or int(ei[b]) != int(re_[b]):
-            rowmax = torch.max(outer[b], dim=1)[0]
-            colmax = torch.max(outer[b], dim=0)[0]
-            assert abs(float(rowmax[int(si[b])] - rowmax[int(rs[b])])) <= 1e-6 * float(rowmax.max())
-            assert abs(float(colmax[int(ei[b])] - colmax[int(re_[b])])) <= 1e-6 * float(colmax.max())
+    si, ei = _span_hip(dev, s, e, m)
+    rs, re_ = _span_ref(s, e, m)
+    assert (si <= ei).all()
+    assert torch.equal(si, rs) and torch.equal(ei, re_)
+
+
+def test_span_argmax_near_ties_bit_exact(dev):
+    """candidates whose products differ by a few float32 ulps or not at all: the winner is decided by the rounding of
+    exp, of the softmax denominator and of the product, which the kernel and the oracle perform identically
+    (correctly rounded exp, order-independent denominator, IEEE division and product)"""
+    B, T = 512, 96
+    g = torch.Generator().manual_seed(2024)
+    base_s = torch.randn(B, 1, generator=g) * 2
+    base_e = torch.randn(B, 1, generator=g) * 2
+    # logits = a common level + a few ulps of jitter: every (i <= j) pair is a near tie
+    s = base_s + torch.randint(-3, 4, (B, T), generator=g).float() * 2.0 ** -21
+    e = base_e + torch.randint(-3, 4, (B, T), generator=g).float() * 2.0 ** -21
+    # half of the batch: two plateaus of exactly equal logits far apart (exact ties -> first index)
+    s[B // 2:, 10:20] = s[B // 2:, 10:11]
+    s[B // 2:, 60:70] = s[B // 2:, 10:11]
+    e[B // 2:, 30:40] = e[B // 2:, 30:31]
+    e[B // 2:, 80:90] = e[B // 2:, 30:31]
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+    m = (torch.arange(T)[None, :] < lens[:, None]).float()
+    s, e, m = s.to(dev), e.to(dev), m.to(dev)
+    si, ei = _span_hip(dev, s, e, m)
+    rs, re_ = _span_ref(s, e, m)
+    assert torch.equal(si, rs) and torch.equal(ei, re_)

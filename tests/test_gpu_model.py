@@ -16,7 +16,7 @@ def _assert_rows(rows, kinds):
 
 @pytest.mark.parametrize('drop', [0.0, 0.2])
 def test_forward_backward_parity_small(drop):
-    case = pu.well_conditioned_case(drop_rate=drop)
+    case = pu.make_case()
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=drop)
     _assert_rows(rows, ('tap', 'out', 'loss'))
     assert idx_equal
@@ -24,7 +24,7 @@ def test_forward_backward_parity_small(drop):
 
 
 def test_second_shape_with_dropout():
-    case = pu.well_conditioned_case(drop_rate=0.2, B=4, T=24, L=7, C=5, seed=21)
+    case = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2)
     _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
     assert idx_equal
@@ -32,7 +32,7 @@ def test_second_shape_with_dropout():
 
 def test_ragged_shapes_parity():
     # T, L not multiples of 16; C = 4 (minimum); one clip of length 1-ish neighbours
-    case = pu.well_conditioned_case(drop_rate=0.1, B=3, T=37, L=9, C=4, seed=11, max_vlen=40)
+    case = pu.make_case(B=3, T=37, L=9, C=4, seed=11, max_vlen=40)
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.1)
     _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
     assert idx_equal
@@ -46,7 +46,7 @@ def test_fusion_switch_variants_parity(flags, monkeypatch):
     monkeypatch.setenv('HUAL_FUSE_LN', flags[0])
     monkeypatch.setenv('HUAL_FUSE_BWD', flags[1])
     monkeypatch.setenv('HUAL_FUSE_ROW', flags[2])
-    case = pu.well_conditioned_case(drop_rate=0.2, B=3, T=37, L=9, C=4, seed=11, max_vlen=40)
+    case = pu.make_case(B=3, T=37, L=9, C=4, seed=11, max_vlen=40)
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2)
     _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
     assert idx_equal

@@ -137,3 +137,32 @@ def test_adam_weight_decay_semantics():
     upd = (0.1 * 0.5) / (np.sqrt(0.001 * 0.25) + 1e-6)           # no bias correction (ops.py:166-168)
     assert abs(float(p2['a/bias'][0]) - (1 - 0.1 * upd)) < 1e-6
     assert abs(float(p2['a/kernel'][0]) - (1 - 0.1 * (upd + 0.01))) < 1e-6
+
+
+def test_softmax_cr_is_a_float32_softmax():
+    """the reproducible softmax used for the span selection agrees with torch's float32 softmax to a few ulps and with
+    the float64 softmax to float32 rounding; rows sum to 1"""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(32, 200, generator=g) * 4
+    x[:, 150:] = -1e30                                            # masked tail (ops.py:89)
+    p = R.softmax_cr(x)
+    ref64 = torch.softmax(x.double(), dim=1)
+    assert float((p.double() - ref64).abs().max()) < 2e-7
+    assert float((p - torch.softmax(x, dim=1)).abs().max()) < 3e-7
+    assert float((p.sum(1) - 1).abs().max()) < 1e-5
+    assert float(p[:, 150:].abs().max()) == 0.0
+
+
+def test_relu_pin_only_moves_rounding_level_units():
+    """relu_pin (test aid): pinning the active sets to the oracle's own signs changes nothing; flipping the unit closest
+    to zero changes the forward by at most |z| of that unit"""
+    cfg = R.default_cfg(max_vlen=32, num_words=60)
+    p = R.init_params(cfg, seed=1)
+    wv = R.init_word_vectors(cfg)
+    b = R.synthetic_batch(cfg, 2, 12, 5, 5, seed=3)
+    out = R.forward(p, cfg, wv, b['video'], b['lens'], b['word_ids'], b['char_ids'], want_tap=True)
+    tap = out['tap']
+    pins = {'cb.v': [tap['cb.y%d.v' % i] > 0 for i in range(4)], 'cb.q': [tap['cb.y%d.q' % i] > 0 for i in range(4)],
+            'fe0': [tap['fe0.y%d' % i] > 0 for i in range(4)], 'fe1': [tap['fe1.y%d' % i] > 0 for i in range(4)]}
+    out2 = R.forward(p, cfg, wv, b['video'], b['lens'], b['word_ids'], b['char_ids'], relu_pin=pins)
+    assert torch.equal(out['start_logits'], out2['start_logits'])
