@@ -32,6 +32,14 @@ int fail(int code, const std::string& msg);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// raise a kernel's dynamic-LDS limit once per (device, kernel); thread safe (core.cpp)
+int ensure_dyn_lds(const void* fn, int bytes);
+#define HUAL_DYN_LDS(fn, bytes)                                          \
+  do {                                                                   \
+    int _rc = ::hual::ensure_dyn_lds((const void*)(fn), (bytes));        \
+    if (_rc) return _rc;                                                 \
+  } while (0)
+
 // ---- dropout parameters shared by every kernel (derived from drop_rate on the host) -----------
 // The Philox key/offset live in DEVICE memory (state[0]=seed lo, [1]=seed hi, [2]=offset) so that a captured
 // hipGraph can be replayed with a fresh offset every step without re-capturing.

@@ -425,11 +425,7 @@ int launch_tri_prep(const CqBufs& b, const CqParams& p, const RowSpace& rs, cons
 int launch_cq_fwd(const CqBufs& b, const RowSpace& rs, hipStream_t s) {
   const int bytes = cq_lds_bytes(rs, 3);
   HUAL_REQUIRE(bytes <= 160 * 1024, "cq_fwd: T x L score matrix does not fit LDS");
-  static bool attr = false;
-  if (!attr) {
-    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)cq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  HUAL_DYN_LDS(cq_fwd_kernel, 160 * 1024);
   HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_kernel, dim3(rs.B, 2), dim3(cq_threads()), bytes, s, b, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
@@ -447,11 +443,7 @@ int launch_cq_bwd_pre(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, h
 int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, float* dXa, float* dXb, hipStream_t s) {
   const int bytes = cq_lds_bytes(rs, 4);
   HUAL_REQUIRE(bytes <= 160 * 1024, "cq_bwd: T x L score matrix does not fit LDS");
-  static bool attr = false;
-  if (!attr) {
-    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)cq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  HUAL_DYN_LDS(cq_bwd_kernel, 160 * 1024);
   HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_kernel, dim3(rs.B, 2), dim3(cq_threads()), bytes, s, b, g, rs, dXa, dXb);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

@@ -1345,16 +1345,14 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
       HUAL_LAUNCH(flops, bytes, gemm_kernel<false>, grid, block, 0, stream, b, drop);
   } else {
     const size_t lds = (size_t)(dual ? 4 : 2) * GL_STAGE * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    {
       const void* fns[] = {(const void*)gemm_lds_kernel<true, 2>,     (const void*)gemm_lds_kernel<false, 2>,
                            (const void*)gemm_lds_kernel<true, 3>,     (const void*)gemm_lds_kernel<false, 3>,
                            (const void*)gemm_lds_kernel<true, 4>,     (const void*)gemm_lds_kernel<false, 4>,
                            (const void*)gemm_lds_kernel<true, 6>,     (const void*)gemm_lds_kernel<false, 6>,
                            (const void*)gemm_lds_px_kernel<true, 2>,  (const void*)gemm_lds_px_kernel<false, 2>,
                            (const void*)gemm_lds_px_kernel<true, 3>,  (const void*)gemm_lds_px_kernel<false, 3>};
-      for (const void* f : fns) HUAL_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr = true;
+      for (const void* f : fns) HUAL_DYN_LDS(f, 160 * 1024);
     }
     static const int rt_env = []() { const char* e = getenv("HUAL_GEMM_RT"); return e ? atoi(e) : 0; }();
     const int ncol = cdiv(maxN, 128);
@@ -1441,12 +1439,10 @@ int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_
   }
   for (int i = 0; i < n; ++i)
     HUAL_REQUIRE((jobs[i].comb != COMB_NONE) == dual, "launch_gemm_bf16: cannot mix dual and single jobs in one launch");
-  static bool attr = false;
-  if (!attr) {
+  {
     const void* fns[] = {(const void*)gemm_bf16_kernel<true, 2>, (const void*)gemm_bf16_kernel<false, 2>,
                          (const void*)gemm_bf16_kernel<true, 3>, (const void*)gemm_bf16_kernel<false, 3>};
-    for (const void* f : fns) HUAL_CHECK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
+    for (const void* f : fns) HUAL_DYN_LDS(f, 160 * 1024);
   }
   const size_t lds = (size_t)(dual ? 4 : 2) * GB_STAGE;
   static const int rt_env = []() { const char* e = getenv("HUAL_GEMM_RT"); return e ? atoi(e) : 0; }();
@@ -1460,11 +1456,7 @@ int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_
   if (rt_env == 2 || rt_env == 3) rt = rt_env;
   const dim3 g(cdiv(maxM, 16 * rt), ncol, n), blk(128 * rt);
   if (kmax >= 768 && !dual && rt == 2) {
-    static bool fattr = false;
-    if (!fattr) {
-      HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)feature_load_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      fattr = true;
-    }
+    HUAL_DYN_LDS(feature_load_gemm_kernel<2>, 160 * 1024);
     HUAL_LAUNCH(flops, bytes, feature_load_gemm_kernel<2>, g, blk, lds, stream, b, drop);
   } else if (rt == 3) {
     if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 3>), g, blk, lds, stream, b, drop);
@@ -1491,13 +1483,12 @@ int launch_feature_ksplit(const FkJob* jobs, int n, const DropCfg& drop, hipStre
     maxM = j.M > maxM ? j.M : maxM;
     maxKS = j.KS > maxKS ? j.KS : maxKS;
     flops += 2.0 * j.M * (double)j.K * 128.0;
-    bytes += 4.0 * ((double)j.M * j.K + (double)j.K * 128 + 4.0 * j.M * 128);      // features + weights in, 4 partial slabs out
+    // ALGORITHMIC bytes (T.(V+D).e per clip + weights): features + weights in, ONE [M,128] projection out.  The
+    // four K-quarter partial slabs this kernel actually writes (4.M.128 floats, summed by the layer-norm launch behind it)
+    // are implementation traffic: they show up in the measured PMC bytes, not here.
+    bytes += 4.0 * ((double)j.M * j.K + (double)j.K * 128 + (double)j.M * 128);
   }
-  static bool attr = false;
-  if (!attr) {
-    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)feature_ksplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  HUAL_DYN_LDS(feature_ksplit_kernel, 160 * 1024);
   const size_t lds = (size_t)(maxKS / 64) * GB_STAGE;
   HUAL_LAUNCH(flops, bytes, feature_ksplit_kernel, dim3(cdiv(maxM, FK_ROWS), 4, n), dim3(512), lds, stream, b, drop);
   HUAL_CHECK_HIP(hipGetLastError());
@@ -1527,12 +1518,8 @@ int launch_gemm_chain(const GemmJob* jobs, int n, const DropCfg& drop, hipStream
     flops += 2.0 * j.M * kt * j.N * mult;
     bytes += 4.0 * ((double)j.M * kt + kt * j.N * mult + (double)j.M * j.N);
   }
-  static bool attr = false;
-  if (!attr) {
-    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_chain_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  HUAL_DYN_LDS(gemm_chain_kernel<2>, 160 * 1024);
+  HUAL_DYN_LDS(gemm_chain_kernel<3>, 160 * 1024);
   const size_t lds = (size_t)(dual ? 4 : 2) * GB_STAGE;
   const int rt = (cdiv(M, 32) > 256 && M > 48) ? 3 : 2;
   const dim3 g(cdiv(M, 16 * rt), 1, 1), blk(128 * rt);
@@ -1591,19 +1578,12 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
   static const int rows_env = []() { const char* e = getenv("HUAL_DW_ROWS"); return e ? atoi(e) : 0; }();
   if (rows_per_block == 0) rows_per_block = rows_env > 0 ? rows_env : dw_auto_rows(jobs, n);
   HUAL_REQUIRE(rows_per_block >= DW_TM && (rows_per_block % DW_TM) == 0, "launch_dw: rows_per_block must be a multiple of 32");
-  static bool attr = false, attr2 = false;
-  if (!attr) {
-    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr = true;
-  }
+  HUAL_DYN_LDS(dw_kernel<true>, 96 * 1024);
+  HUAL_DYN_LDS(dw_kernel<false>, 96 * 1024);
   // HUAL_DW_IMPL=0: fp32 MFMA kernel (dw_kernel); default: split-bf16 kernel (dw_bf16_kernel)
   const int dw_impl = []() { const char* e = getenv("HUAL_DW_IMPL"); return e ? atoi(e) : 1; }();     // read per call (tests)
-  if (!attr2) {
-    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    HUAL_CHECK_HIP(hipFuncSetAttribute((const void*)dw_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr2 = true;
-  }
+  HUAL_DYN_LDS(dw_bf16_kernel<true>, 96 * 1024);
+  HUAL_DYN_LDS(dw_bf16_kernel<false>, 96 * 1024);
   size_t lds = dw_impl ? (size_t)8 * DWB_PLANE : (size_t)4 * DW_TM * DW_LD * sizeof(float);
   // HUAL_DW_LDS_KB pads the LDS request: above 80 KB only ONE block fits a CU, which leaves room for the blocks of
   // other kernels when the launch runs on a side stream under the dX chain (experiment)
