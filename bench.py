@@ -28,7 +28,15 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 PEAK_BF16_MATRIX_TFLOPS = 2516.8  # MI355X_MICROARCH.md: bf16 MFMA = 16 x the fp32 matrix rate (~2.5 PF dense)
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILE = 'r1f_pmc_traffic.json'     # per-kernel HBM bytes per launch from the PMC passes of this round
+def _traffic_file():
+    """newest committed per-kernel HBM-traffic summary (scripts/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes)"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    return os.path.basename(fs[-1]) if fs else 'r1f_pmc_traffic.json'
+
+
+TRAFFIC_FILE = _traffic_file()
+MFLOP_PER_CLIP_C2 = 1126.5               # BASELINE.md section 2: fwd+bwd, T=128 vdim=1024 L=20 C=8 (72.1 GFLOP per B=64 step)
 FEATURE_LOAD_KERNEL = 'feature_ksplit_kernel'
 
 
@@ -120,10 +128,33 @@ def cpu_baseline(seconds_budget=20.0):
     return out
 
 
+def gpu_at_cpu_shape(dev, drop, steps=400):
+    """the same train step on the GPU at the shape the CPU baseline is timed on (BASELINE configs[0]: B16 T64 vdim1024 L20 C8)"""
+    from hual_amd import lib
+    from hual_amd.model import SeqPAN
+    from hual_amd.train import Trainer
+    cfg = lib.make_cfg(vdim=1024, max_vlen=64, num_words=1000, num_chars=40)
+    wv = np.random.default_rng(777).normal(0, 0.4, size=(998, 300)).astype(np.float32)
+    model = SeqPAN(cfg, wv, device=dev, seed=12345, rng_seed=12345)
+    b = synth_batch(16, 64, 20, 8, 1024, 1000, 40, 12345)
+    tr = Trainer(model, world=1, use_graph=True)
+    tr.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'])
+    for _ in range(50):
+        tr.step(lr=1e-4, drop_rate=drop)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(lr=1e-4, drop_rate=drop)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(value=round(16 * steps / dt, 1), unit='clips/s', ms_per_step=round(dt / steps * 1e3, 4), steps=steps,
+                shape='B16 T64 vdim1024 L20 C8 (the cpu_baseline shape)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--T', type=int, default=128)
@@ -135,7 +166,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--aux', action='store_true', help='side stream for the alignment-loss branch of forward (experiment)')
-    ap.add_argument('--prewarm', type=int, default=400, help='untimed steps before the warm-up steps (clock ramp)')
+    ap.add_argument('--prewarm', type=int, default=200, help='untimed steps before the warm-up steps (clock ramp)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -186,6 +217,22 @@ def main():
     loss = float(trainer.last_loss())
     clips = args.batch * world * args.steps
 
+    rccl = None
+    if world > 1:
+        # the step's one collective of size: all-reduce(sum) of the flat fp32 gradient bucket, timed on its own
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            torch.distributed.all_reduce(model.grads)
+        barrier()
+        ev0.record()
+        for _ in range(50):
+            torch.distributed.all_reduce(model.grads)
+        ev1.record()
+        torch.cuda.synchronize()
+        rccl = dict(rccl_ranks=world, allreduce_us=round(ev0.elapsed_time(ev1) * 1e3 / 50, 1),
+                    allreduce_bytes=int(model.grads.numel() * 4), backend=torch.distributed.get_backend(),
+                    step_launch='hipGraph with the collectives captured' if trainer.graph is not None else 'eager')
+        model.grads.zero_()
     roof = None
     print('[bench] timed region done: %.3f ms/step' % (dt / args.steps * 1e3), file=sys.stderr, flush=True)
     if rank == 0 and not args.no_roofline:
@@ -266,6 +313,32 @@ def main():
                                   unit='TFLOP/s', frac=round(d['flops'] / d['us'] / 1e6 / PEAK_F32_MATRIX_TFLOPS, 4),
                                   us_per_step=round(d['us'] / psteps, 1))
                              for d in fam if d['kernel'].startswith('attn_') and d['flops'] > 0]
+        # whole step: algorithmic FLOPs (BASELINE.md section 2 for the c2 shape, else the launch wrappers' own sums) over the timed
+        # ms/step; HBM bytes per step measured by the PMC passes (sum over kernels of bytes/launch x launches/step) against
+        # the compulsory bytes (clip features + query ids + labels read once, outputs written, parameters read once,
+        # gradients written + read, AdamWD reading p, m, v and writing p, m, v)
+        n_par = model.params.numel() * 4
+        compulsory = (args.batch * args.T * args.vdim * 4 + args.batch * args.L * (1 + args.C) * 4 + args.batch * args.T * 4 * 4
+                      + args.batch * args.T * 6 * 4 + 9 * n_par)
+        is_c2 = (args.T, args.vdim, args.L, args.C) == (128, 1024, 20, 8)
+        gflop = MFLOP_PER_CLIP_C2 * args.batch / 1e3 if is_c2 else sum(d['flops'] for d in fam) / psteps / 1e9
+        ms = dt / args.steps * 1e3
+        step = dict(algorithmic_gflop_per_step=round(gflop, 2), tflops=round(gflop / ms, 2),
+                    frac_of_fp32_matrix_peak=round(gflop / ms / PEAK_F32_MATRIX_TFLOPS, 4),
+                    frac_of_bf16_matrix_peak=round(gflop / ms / PEAK_BF16_MATRIX_TFLOPS, 4),
+                    compulsory_hbm_bytes_per_step=int(compulsory), launches_per_step=sum(d['launches'] for d in fam) // psteps,
+                    kernel_time_us_per_step=round(total_us / psteps, 1))
+        try:
+            meas, covered = 0.0, 0
+            for d in fam:
+                if d['kernel'] in tr_tab:
+                    meas += tr_tab[d['kernel']]['hbm_bytes_per_launch'] * (d['launches'] // psteps)
+                    covered += 1
+            step.update(measured_hbm_bytes_per_step=int(meas), measured_over_compulsory=round(meas / compulsory, 1),
+                        traffic_source='profiles/' + TRAFFIC_FILE, kernels_covered='%d of %d' % (covered, len(fam)))
+        except NameError:
+            pass
+        roof['step'] = step
         roof['families'] = [dict(kernel=d['kernel'], launches_per_step=d['launches'] // psteps,
                                  us_per_step=round(d['us'] / psteps, 1),
                                  tflops=round(d['flops'] / d['us'] / 1e6, 2) if d['flops'] > 0 else None,
@@ -274,6 +347,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+        try:
+            cpu['gpu_at_cpu_shape'] = gpu_at_cpu_shape(dev, args.drop)
+            cpu['gpu_over_cpu_same_shape'] = round(cpu['gpu_at_cpu_shape']['value'] / cpu['value'], 1)
+        except Exception as e:      # never cost the bench line
+            cpu['gpu_at_cpu_shape'] = dict(error=str(e)[:200])
 
     if rank == 0:
         out = dict(metric='train clips/sec', value=round(clips / dt, 2), unit='clips/s', n_gpus=world, steps=args.steps,
@@ -286,6 +364,8 @@ def main():
                                parallelism='dp%d' % world, launch='eager' if args.no_graph else 'hipGraph',
                                final_loss=round(loss, 4)),
                    roofline=roof, cpu_baseline=cpu)
+        if rccl is not None:
+            out['rccl'] = rccl
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -27,6 +27,44 @@ __device__ __forceinline__ void bf16_split4(const float4& x, uint2& hi, uint2& l
   bf16_split_pair(x.z, x.w, hi.y, lo.y);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// fp16 variant of the same three-pass scheme, used by the forward / dX dense kernels ("f16x3"):
+//   x' = x * 2^s (exact),  hi = f16(x'),  lo = f16(x' - hi)      ->  x' = hi + lo up to 2^-22 |x'|
+// fp16 carries 11 significant bits per term (bf16: 8), so two terms represent a float32 to 22 bits and the three-pass
+// product a_hi*b_hi + a_hi*b_lo + a_lo*b_hi is as accurate as an fp32 FMA chain (measured: 7e-8 rms relative at K = 128
+// against 4.5e-6 for the bf16 split; end to end the whole-model gradients move from ~5e-4 to ~3e-5 of the fp64 oracle).
+// fp16's narrow exponent range is handled by exact power-of-two scaling: every A row (per 128-deep K chunk) is scaled so
+// that its largest magnitude lies in [2^13, 2^14) - no overflow (max 65504), and every element within 2^16 of the row
+// maximum keeps a normal-range `lo` - and the weights by the fixed 2^HUAL_F16_WSCALE_LOG2 (|w| < 2^5 assumed; dense weights
+// are O(0.1)).  The fp32 accumulator of the chunk is multiplied by the exact inverse when it is folded into the total.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+#define HUAL_F16_WSCALE_LOG2 10
+#define HUAL_F16_WSCALE 1024.0f
+
+__device__ __forceinline__ void f16_split_pair(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  const f16x2_t h = __builtin_convertvector((f32x2_t){x0, x1}, f16x2_t);          // round to nearest even
+  hi = __builtin_bit_cast(uint32_t, h);
+  const f32x2_t hf = __builtin_convertvector(h, f32x2_t);
+  const f16x2_t l = __builtin_convertvector((f32x2_t){x0 - hf[0], x1 - hf[1]}, f16x2_t);   // x - hi is exact in fp32
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ void f16_split4(const float4& x, uint2& hi, uint2& lo) {
+  f16_split_pair(x.x, x.y, hi.x, lo.x);
+  f16_split_pair(x.z, x.w, hi.y, lo.y);
+}
+__device__ __forceinline__ float f4absmax(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+// power-of-two scale that brings a row maximum rmax >= 0 into [2^13, 2^14) (rmax below 2^-100, incl. 0: scale 2^113, still
+// finite); inv = 1 / (scale * 2^HUAL_F16_WSCALE_LOG2), both exact powers of two
+__device__ __forceinline__ float f16_row_scale(float rmax, float& inv) {
+  uint32_t eb = (__float_as_uint(rmax) >> 23) & 0xffu;
+  eb = eb < 27u ? 27u : (eb > 254u ? 254u : eb);
+  inv = __uint_as_float((eb - 13u - (uint32_t)HUAL_F16_WSCALE_LOG2) << 23);
+  return __uint_as_float((267u - eb) << 23);
+}
+__device__ __forceinline__ float4 f4scale1(const float4& v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+__device__ __forceinline__ f16x8 join_tr_f16(s16x4 a, s16x4 b);
+
 // Byte offset of 16-byte chunk `ch` (0..15) of row `row` in a [rows][128 x bf16] LDS tile with plain 256-byte rows and the
 // XOR swizzle that keeps BOTH ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads conflict free
 // (cdna_hip_programming.md T10, image (b)).
@@ -44,4 +82,9 @@ __device__ __forceinline__ bf16x8 join_tr(s16x4 a, s16x4 b) {
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ f16x8 join_tr_f16(s16x4 a, s16x4 b) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(f16x8, v);
 }

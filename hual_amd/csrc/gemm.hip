@@ -465,7 +465,7 @@ __global__ __launch_bounds__(RT * 128) void gemm_lds_kernel(GemmBatch batch, Dro
 
 // MODE 0: single accumulator; 1: dual (cross gating / bilinear); 2: decided per job at run time (chained launches)
 template <int MODE, int RT, class J>
-__device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop, char* ldsb) {
+__device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop, char* ldsb, int dbg = 0) {
   const bool DUAL = MODE == 1 || (MODE == 2 && job.comb != COMB_NONE);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -541,44 +541,59 @@ __device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop
   // transposed-read addressing: 16-lane group g takes rows 32 ks + 8 g + 4 rr + q, lane 4q+pp supplies stored columns
   // 64 (wave&1) + 16 t + 4 pp .. +3
   const int tq = (lane >> 2) & 3, tp = lane & 3;
-  auto compute = [&](int bufi, int k0, int kw, const float4 (&a)[4], const float4 (&a2)[4]) {
+  f32x4 accp[4], accp2[4];     // accumulators of the current 128-deep chunk (operands carry the chunk's row scale)
+  // sc / sc2: this lane's A row scale of the chunk (bf16x3.h "f16x3")
+  auto compute = [&](int bufi, int k0, int kw, const float4 (&a)[4], const float4 (&a2)[4], float sc, float sc2) {
     const char* hi = Ws + bufi * GB_STAGE;
     const char* hi2 = W2s + bufi * GB_STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (k0 + 32 * ks < kw) {             // block-uniform
         uint2 h0, l0, h1, l1;
-        bf16_split4(a[2 * ks], h0, l0);
-        bf16_split4(a[2 * ks + 1], h1, l1);
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
-        const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
-        bf16x8 bh, bl, ch, cl;
+        f16_split4(f4scale1(a[2 * ks], sc), h0, l0);
+        f16_split4(f4scale1(a[2 * ks + 1], sc), h1, l1);
+        const f16x8 ah = __builtin_bit_cast(f16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
+        const f16x8 al = __builtin_bit_cast(f16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
+        f16x8 bh, bl, ch, cl;
         if (MODE && DUAL) {
-          bf16_split4(a2[2 * ks], h0, l0);
-          bf16_split4(a2[2 * ks + 1], h1, l1);
-          bh = __builtin_bit_cast(bf16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
-          bl = __builtin_bit_cast(bf16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
+          f16_split4(f4scale1(a2[2 * ks], sc2), h0, l0);
+          f16_split4(f4scale1(a2[2 * ks + 1], sc2), h1, l1);
+          bh = __builtin_bit_cast(f16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
+          bl = __builtin_bit_cast(f16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
         }
         const int r0 = 32 * ks + 8 * g + tq, r1 = r0 + 4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int chunk = 8 * (wave & 1) + 2 * t + (tp >> 1);
           const int o0 = tile256_off(r0, chunk) + 8 * (tp & 1), o1 = tile256_off(r1, chunk) + 8 * (tp & 1);
-          const bf16x8 wh = join_tr(lds_read_tr16(hi, o0), lds_read_tr16(hi, o1));
-          const bf16x8 wl = join_tr(lds_read_tr16(hi + GB_TILE, o0), lds_read_tr16(hi + GB_TILE, o1));
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, acc[t], 0, 0, 0);
+          const f16x8 wh = join_tr_f16(lds_read_tr16(hi, o0), lds_read_tr16(hi, o1));
+          const f16x8 wl = join_tr_f16(lds_read_tr16(hi + GB_TILE, o0), lds_read_tr16(hi + GB_TILE, o1));
+          accp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, accp[t], 0, 0, 0);
+          accp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, accp[t], 0, 0, 0);
+          accp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, accp[t], 0, 0, 0);
           if (MODE && DUAL) {
-            ch = join_tr(lds_read_tr16(hi2, o0), lds_read_tr16(hi2, o1));
-            cl = join_tr(lds_read_tr16(hi2 + GB_TILE, o0), lds_read_tr16(hi2 + GB_TILE, o1));
-            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ch, acc2[t], 0, 0, 0);
-            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, cl, acc2[t], 0, 0, 0);
-            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ch, acc2[t], 0, 0, 0);
+            ch = join_tr_f16(lds_read_tr16(hi2, o0), lds_read_tr16(hi2, o1));
+            cl = join_tr_f16(lds_read_tr16(hi2 + GB_TILE, o0), lds_read_tr16(hi2 + GB_TILE, o1));
+            accp2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ch, accp2[t], 0, 0, 0);
+            accp2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, cl, accp2[t], 0, 0, 0);
+            accp2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ch, accp2[t], 0, 0, 0);
           }
         }
       }
     }
+  };
+  // largest magnitude of this lane's row over the fragments of the resident stages -> row scale (all 4 lanes of a row
+  // agree after the two shuffles)
+  auto row_scale = [&](const float4 (&x0)[4], const float4 (&x1)[4], bool two, float& inv) {
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      m = fmaxf(m, f4absmax(x0[u]));
+      if (two) m = fmaxf(m, f4absmax(x1[u]));
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    return f16_row_scale(m, inv);
   };
 
   float4 a0[4], a1[4], c0[4], c1[4];
@@ -592,8 +607,31 @@ __device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop
   for (int s = 0; s < nstages; s += 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // DMA of the resident stages has landed (this wave's part)
     __syncthreads();                                      // ... and everybody else's
-    compute(0, k00, kw0, a0, c0);                         // every wave: the transposed reads need EXEC all ones
-    if (s + 1 < nstages) compute(1, k01, kw1, a1, c1);
+    const bool two = s + 1 < nstages;
+    float inv = 0.f, inv2 = 0.f, sc2 = 0.f;
+    float sc;
+    if (dbg & 1) { sc = 64.f; inv = 1.0f / 65536.f; }       // timing experiment (HUAL_F16_DBG): fixed scale, no row maximum
+    else sc = row_scale(a0, a1, two, inv);
+    if (MODE && DUAL) sc2 = row_scale(c0, c1, two, inv2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      accp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      accp2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    compute(0, k00, kw0, a0, c0, sc, sc2);                // every wave: the transposed reads need EXEC all ones
+    if (two) compute(1, k01, kw1, a1, c1, sc, sc2);
+    // fold the chunk into the total: accumulator register r is row 4g + r of the tile, whose scale lives in lanes j = 4g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ir = (dbg & 2) ? inv : __shfl(inv, 4 * g + r);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t][r] = fmaf(accp[t][r], ir, acc[t][r]);
+      if (MODE && DUAL) {
+        const float ir2 = __shfl(inv2, 4 * g + r);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc2[t][r] = fmaf(accp2[t][r], ir2, acc2[t][r]);
+      }
+    }
     if (s + 2 < nstages) {
       __syncthreads();                                    // both buffers consumed by every wave
       issue(s + 2, a0, c0, kw0, k00);
@@ -607,9 +645,9 @@ __device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop
 }
 
 template <bool DUAL, int RT>
-__global__ __launch_bounds__(RT * 128) void gemm_bf16_kernel(GemmBatch batch, DropCfg drop) {
+__global__ __launch_bounds__(RT * 128) void gemm_bf16_kernel(GemmBatch batch, DropCfg drop, int dbg) {
   extern __shared__ float lds[];     // Ws[2][GB_STAGE] (+ W2s[2][GB_STAGE] when DUAL)
-  gemm_bf16_body<DUAL ? 1 : 0, RT>(batch.j[blockIdx.z], drop, reinterpret_cast<char*>(lds));
+  gemm_bf16_body<DUAL ? 1 : 0, RT>(batch.j[blockIdx.z], drop, reinterpret_cast<char*>(lds), dbg);
 }
 
 // The same kernel under its own symbol for the deep-K launch of a step - video_conv1d (+ query_conv1d), model.py:42,48: the
@@ -683,22 +721,34 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
       c0 = apply_drop4(drop, (uint32_t)job.drop_site, adrow, cg, c0);
       c1 = apply_drop4(drop, (uint32_t)job.drop_site, adrow, cg + 1u, c1);
     }
+    // f16x3 (bf16x3.h): the row scale is taken per 32-deep k-step (the features of a row arrive over the whole loop)
+    float rmax = fmaxf(f4absmax(c0), f4absmax(c1));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 16));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
+    float inv;
+    const float sc = f16_row_scale(rmax, inv);
     uint2 h0, l0, h1, l1;
-    bf16_split4(c0, h0, l0);
-    bf16_split4(c1, h1, l1);
-    const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
-    const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
+    f16_split4(f4scale1(c0, sc), h0, l0);
+    f16_split4(f4scale1(c1, sc), h1, l1);
+    const f16x8 ah = __builtin_bit_cast(f16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
+    const f16x8 al = __builtin_bit_cast(f16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
     const char* hi = ldsb + (ks >> 1) * GB_STAGE;
     const int r0 = 32 * (ks & 1) + 8 * g + tq, r1 = r0 + 4;
+    float ir[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ir[r] = __shfl(inv, 4 * g + r);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int chunk = 2 * t + (tp >> 1);
       const int o0 = tile256_off(r0, chunk) + 8 * (tp & 1), o1 = tile256_off(r1, chunk) + 8 * (tp & 1);
-      const bf16x8 wh = join_tr(lds_read_tr16(hi, o0), lds_read_tr16(hi, o1));
-      const bf16x8 wl = join_tr(lds_read_tr16(hi + GB_TILE, o0), lds_read_tr16(hi + GB_TILE, o1));
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh, acc[t], 0, 0, 0);
+      const f16x8 wh = join_tr_f16(lds_read_tr16(hi, o0), lds_read_tr16(hi, o1));
+      const f16x8 wl = join_tr_f16(lds_read_tr16(hi + GB_TILE, o0), lds_read_tr16(hi + GB_TILE, o1));
+      f32x4 p = (f32x4){0.f, 0.f, 0.f, 0.f};
+      p = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, p, 0, 0, 0);
+      p = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, p, 0, 0, 0);
+      p = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, p, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(p[r], ir[r], acc[t][r]);
     }
     c0 = n0; c1 = n1; n0 = f0; n1 = f1;
   }
@@ -762,7 +812,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
       const int r = idx >> 6, sp = idx & 63;
       if (k0 + r < job.K) {
         uint32_t hi, lo;
-        bf16_split_pair(tile[r][pack_perm(2 * sp)], tile[r][pack_perm(2 * sp + 1)], hi, lo);
+        f16_split_pair(tile[r][pack_perm(2 * sp)] * HUAL_F16_WSCALE, tile[r][pack_perm(2 * sp + 1)] * HUAL_F16_WSCALE, hi, lo);
         *reinterpret_cast<uint32_t*>(img + (size_t)(k0 + r) * 512 + 4 * sp) = hi;
         *reinterpret_cast<uint32_t*>(img + (size_t)(k0 + r) * 512 + 256 + 4 * sp) = lo;
       }
@@ -781,7 +831,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
       const int c = cbase + r;
       const int s = 64 * (c >> 6) + 16 * (c & 3) + ((c & 63) >> 2);
       uint32_t hi, lo;
-      bf16_split_pair(tile[r][kk], tile[r + 4][kk], hi, lo);
+      f16_split_pair(tile[r][kk] * HUAL_F16_WSCALE, tile[r + 4][kk] * HUAL_F16_WSCALE, hi, lo);
       *reinterpret_cast<uint32_t*>(img + (size_t)kk * 512 + 2 * s) = hi;
       *reinterpret_cast<uint32_t*>(img + (size_t)kk * 512 + 256 + 2 * s) = lo;
     }
@@ -1446,6 +1496,7 @@ int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_
   }
   const size_t lds = (size_t)(dual ? 4 : 2) * GB_STAGE;
   static const int rt_env = []() { const char* e = getenv("HUAL_GEMM_RT"); return e ? atoi(e) : 0; }();
+  const int dbg = []() { const char* e = getenv("HUAL_F16_DBG"); return e ? atoi(e) : 0; }();     // timing experiments only
   const int ncol = cdiv(maxN, 128);
   int rt = (cdiv(maxM, 32) * ncol * n > 256 && maxM > 48) ? 3 : 2;
   // deep-K jobs (video_conv1d: K = vdim, with Philox dropout on its A operand) are bound by per-wave VALU / MFMA work, not by
@@ -1459,11 +1510,11 @@ int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_
     HUAL_DYN_LDS(feature_load_gemm_kernel<2>, 160 * 1024);
     HUAL_LAUNCH(flops, bytes, feature_load_gemm_kernel<2>, g, blk, lds, stream, b, drop);
   } else if (rt == 3) {
-    if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 3>), g, blk, lds, stream, b, drop);
-    else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 3>), g, blk, lds, stream, b, drop);
+    if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 3>), g, blk, lds, stream, b, drop, dbg);
+    else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 3>), g, blk, lds, stream, b, drop, dbg);
   } else {
-    if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 2>), g, blk, lds, stream, b, drop);
-    else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 2>), g, blk, lds, stream, b, drop);
+    if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 2>), g, blk, lds, stream, b, drop, dbg);
+    else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 2>), g, blk, lds, stream, b, drop, dbg);
   }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

@@ -6,6 +6,7 @@
 #include "attn.h"
 #include "prof.h"
 #include "cq.h"
+#include "convblock.h"
 #include "embed.h"
 #include "gemm.h"
 #include "heads.h"
@@ -71,6 +72,8 @@ struct Ctx {
   bool static_tables = false;   // hual_run_opts.static_tables
   //   HUAL_GEMM_BF16=0  dense layers on the fp32 matrix cores (gemm_lds_kernel) instead of the split-bf16 kernel
   bool use_bf16 = true;
+  //   HUAL_FUSE_CB=0    conv_block as 4 x (ln_dwconv_fwd + dense) launches instead of the fused kernels (convblock.h)
+  bool fuse_cb = true;
   struct DenseW { size_t off; int K; size_t boff; };
   std::vector<DenseW> dense;          // every [K,128] weight of the graph, sorted by offset
   char* PKF = nullptr;                // pre-split images (gemm.h launch_pack_weights): forward ...
@@ -341,6 +344,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
   { const char* e = getenv("HUAL_FUSE_ROW"); c.fuse_row = !c.fuse_bwd && !(e && atoi(e) == 0); }
   { const char* e = getenv("HUAL_GEMM_BF16"); c.use_bf16 = !(e && atoi(e) == 0); }
   { const char* e = getenv("HUAL_CHAIN"); c.use_chain = !(e && atoi(e) == 0); }
+  { const char* e = getenv("HUAL_FUSE_CB"); c.fuse_cb = c.use_bf16 && !c.fuse_ln && !c.fuse_bwd && c.fuse_row && !(e && atoi(e) == 0); }
   {
     const ParamMap& pm = c.pm;
     const int D = HUAL_D, catw = cfg->word_dim + 100;
@@ -376,8 +380,36 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
 // ======================================================================================================
 
 // conv_block (modules.py:59-70) on rows described by `rs`; x0 -> returns x4.  tag prefixes the buffer names.
-float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP& cp, const RowSpace& rs, int site0) {
+// pos_src / pos (predictor feature encoder, modules.py:124): x0 = pos_src + pos[t] is formed on the way in.
+float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP& cp, const RowSpace& rs, int site0,
+                      const float* pos_src = nullptr, const float* pos = nullptr) {
   const int R = rs.R;
+  if (c.fuse_cb) {       // all four layers in one launch (convblock.h)
+    CbFwdArgs a{};
+    a.x0 = pos_src ? pos_src : x; a.pos = pos; a.x0_out = pos_src ? x : nullptr;
+    a.MT = conv_block_fused_rows(R); a.drop_row0 = 0;
+    float* xin = x;
+    for (int i = 0; i < 4; ++i) {
+      const std::string is = std::to_string(i);
+      CbLayerFwd& L = a.l[i];
+      L.c = c.buf(tag + ".c" + is, R, HUAL_D);
+      L.y = c.buf(tag + ".y" + is, R, HUAL_D);
+      L.xout = c.buf(tag + ".x" + std::to_string(i + 1), R, HUAL_D);
+      L.mean = c.buf(tag + ".mean" + is, R, 1);
+      L.rstd = c.buf(tag + ".rstd" + is, R, 1);
+      L.ln_g = c.p(cp.ln[i].g); L.ln_b = c.p(cp.ln[i].b); L.dw = c.p(cp.dw[i]);
+      L.wimg = reinterpret_cast<const float*>(c.PKF + cp.pw[i] * 4); L.bias = c.p(cp.b[i]);
+      L.drop_site = site0 + i;
+      xin = L.xout;
+    }
+    if (!c.dry && c.ok()) c.chk(launch_conv_block_fwd(a, rs, c.drop, c.stream));
+    return xin;
+  }
+  if (pos_src) {
+    EwArgs e{};
+    e.op = EW_ADD_POS; e.R = R; e.a = pos_src; e.out = x; e.pos = pos; e.T = rs.T; e.drop_site = -1;
+    c.ew(e);
+  }
   for (int i = 0; i < 4; ++i) {
     const std::string is = std::to_string(i);
     float* cbuf = c.buf(tag + ".c" + is, R, HUAL_D);
@@ -709,12 +741,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     const std::string t = "fe" + std::to_string(ps);
     const int site = HUAL_SITE_FE + 16 * ps;
     float* x0 = c.actv(t + ".x0");
-    {
-      EwArgs e{};
-      e.op = EW_ADD_POS; e.R = Nv; e.a = fin; e.out = x0; e.pos = c.p(pm.fe_pos); e.T = T; e.drop_site = -1;
-      c.ew(e);
-    }
-    float* f = conv_block_fwd(c, t, x0, pm.fe_cb, c.rsv, site);
+    float* f = conv_block_fwd(c, t, x0, pm.fe_cb, c.rsv, site, fin, c.p(pm.fe_pos));
     float* a1 = c.actv(t + ".a");
     float* mean = c.buf(t + ".ln1.mean", Nv, 1);
     float* rstd = c.buf(t + ".ln1.rstd", Nv, 1);

@@ -1,0 +1,47 @@
+"""GPU: the fused multi-layer kernels against the launch sequences they replace (same arithmetic, operation for
+operation, so the saved intermediates and outputs must agree BIT FOR BIT), at shapes that exercise tile boundaries:
+clips shorter / longer than a workgroup's rows, row counts that are not multiples of the tile, single clips."""
+import numpy as np
+import pytest
+import torch
+
+import parity_util as pu
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(case, drop, env, monkeypatch, names, backward=False):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg, p, wv, b, labels = case
+    m = pu.hip_model(cfg, p, wv)
+    m.set_rng(5, 7)
+    out = m.forward(b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(), drop_rate=drop,
+                    labels=tuple(x.numpy() for x in labels))
+    if backward:
+        m.backward()
+    torch.cuda.synchronize()
+    taps = {n: m.tap(n).clone() for n in names}
+    res = {k: out[k].clone() for k in ('start_logits', 'end_logits', 'match_scores')}
+    grads = m.grads.clone() if backward else None
+    for k in env:
+        monkeypatch.delenv(k)
+    return taps, res, grads
+
+
+CB_FWD_TAPS = ['cb.x0'] + ['%s.%s%d' % (t, n, i) for t in ('cb', 'fe0', 'fe1') for n in ('c', 'y', 'mean', 'rstd') for i in range(4)] + \
+              ['%s.x%d' % (t, i) for t in ('cb', 'fe0', 'fe1') for i in range(1, 5)] + ['fe0.x0', 'fe1.x0']
+
+
+@pytest.mark.parametrize('shape', [dict(B=3, T=37, L=9, C=4, seed=11, max_vlen=40), dict(B=1, T=5, L=3, C=4, seed=2, max_vlen=8),
+                                   dict(B=8, T=64, L=20, C=8, seed=9, max_vlen=64), dict(B=5, T=100, L=30, C=6, seed=4, max_vlen=100),
+                                   dict(B=2, T=256, L=24, C=6, seed=51, max_vlen=256)])
+@pytest.mark.parametrize('drop', [0.0, 0.2])
+def test_fused_conv_block_forward_bit_exact(shape, drop, monkeypatch):
+    case = pu.make_case(**shape)
+    t1, r1, _ = _run(case, drop, {'HUAL_FUSE_CB': '1'}, monkeypatch, CB_FWD_TAPS)
+    t0, r0, _ = _run(case, drop, {'HUAL_FUSE_CB': '0'}, monkeypatch, CB_FWD_TAPS)
+    for n in CB_FWD_TAPS:
+        assert torch.equal(t1[n], t0[n]), (n, float((t1[n] - t0[n]).abs().max()))
+    for k in r1:
+        assert torch.equal(r1[k], r0[k]), k
