@@ -48,8 +48,6 @@ struct CbBwdArgs {
   const float* y3;                           // relu output of layer 3
   int drop_site3;
   float* dx_out;                             // gradient wrt x_0 [R,128]
-  // optional second output for the consumer of dx_out: dz_out = dropout'(dx_out, site) * (relu > 0)
-  float* dz_out; int dz_out_site; const float* dz_out_relu;
   CbLayerBwd l[4];
   int MT;
   uint32_t drop_row0;

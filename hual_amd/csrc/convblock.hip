@@ -12,95 +12,26 @@
 //         ds_read_b64_tr_b16, 48 x v_mfma_f32_16x16x32_f16
 //     P3  bias, relu (saved), Philox dropout, + x_l from LDS -> x_{l+1} back into X (+ HBM for the owned rows)
 #include "convblock.h"
-#include "bf16x3.h"
-#include "philox.h"
+#include "tilecore.h"
 #include "prof.h"
 
 using namespace hual;
 
-#define LN_EPS 1e-6f   // models/layers.py:15
-#define CB_THREADS 512
-#define CB_TILE 16384            // one [64][128 x 16 bit] tile
-#define CB_STAGE (2 * CB_TILE)   // hi + lo tile of 64 K rows
-#define CB_WBYTES (2 * CB_STAGE) // a whole [128,128] weight image
-
-__device__ __forceinline__ float4 cb_fma(float4 a, float4 b, float4 c) {
-  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
-}
-__device__ __forceinline__ float4 cb_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-__device__ __forceinline__ float4 cb_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float cb_hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
-
-// clip segment [lo, hi) of unified row `row` (rowops.h RowSpace)
-__device__ __forceinline__ void cb_segment(int row, const RowSpace& rs, int& lo, int& hi) {
-  if (row < rs.Nv) { const int b = row / rs.T; lo = b * rs.T; hi = lo + rs.T; }
-  else { const int q = row - rs.Nv; const int b = q / rs.L; lo = rs.Nv + b * rs.L; hi = lo + rs.L; }
-}
-
-// LDS-DMA of one [128,128] weight image (pack_weights_kernel layout: per K row 256 B of fp16 high parts, 256 B of
-// residuals) into two stages of {hi tile, lo tile}; the XOR swizzle of tile256_off is applied on the global side
-__device__ __forceinline__ void cb_dma_weight(const float* wimg, char* Wl, int wave, int lane, int nwaves) {
-  const char* img = reinterpret_cast<const char*>(wimg);
-  const int chp = lane & 15, rr = lane >> 4;
-  for (int pc = wave; pc < 64; pc += nwaves) {
-    const int st = pc >> 5, pl = pc & 31;
-    const int r = 4 * (pl & 15) + rr;
-    const int ch = chp ^ (((r & 3) << 2) | ((r >> 2) & 3));
-    const char* src = img + (size_t)(64 * st + r) * 512 + (pl >> 4) * 256 + 16 * ch;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(Wl + st * CB_STAGE + pl * 1024), 16, 0, 0);
-  }
-}
-
-// 16 x 64 output tile of A[16 rows of the LDS planes] . W: wave-level, accumulators in the column order of the epilogue
-// (accumulator t, register r, lane (j, g) = row 4g + r, column 64 ch + 4j + t)
-__device__ __forceinline__ void cb_tile_mma(const char* Ahi, const char* Alo, const char* Wl, int mt, int ch, int lane,
-                                            f32x4 (&acc)[4]) {
-  const int j = lane & 15, g = lane >> 4;
-  const int tq = (lane >> 2) & 3, tp = lane & 3;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int aoff = tile256_off(16 * mt + j, 4 * ks + g);
-    const f16x8 ah = *reinterpret_cast<const f16x8*>(Ahi + aoff);
-    const f16x8 al = *reinterpret_cast<const f16x8*>(Alo + aoff);
-    const char* hi = Wl + (ks >> 1) * CB_STAGE;
-    const int r0 = 32 * (ks & 1) + 8 * g + tq, r1 = r0 + 4;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int chunk = 8 * ch + 2 * t + (tp >> 1);
-      const int o0 = tile256_off(r0, chunk) + 8 * (tp & 1), o1 = tile256_off(r1, chunk) + 8 * (tp & 1);
-      const f16x8 wh = join_tr_f16(lds_read_tr16(hi, o0), lds_read_tr16(hi, o1));
-      const f16x8 wl = join_tr_f16(lds_read_tr16(hi + CB_TILE, o0), lds_read_tr16(hi + CB_TILE, o1));
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, acc[t], 0, 0, 0);
-    }
-  }
-}
-
-// row of the operand planes: scale to fp16 range, split, store (8 bytes per lane and plane); returns the inverse scale
-__device__ __forceinline__ float cb_store_operand(char* Ahi, char* Alo, int arow, int l32, float4 v) {
-  float inv;
-  const float sc = f16_row_scale(half_max32(f4absmax(v)), inv);
-  uint2 h, l;
-  f16_split4(f4scale1(v, sc), h, l);
-  const int off = tile256_off(arow, l32 >> 1) + 8 * (l32 & 1);
-  *reinterpret_cast<uint2*>(Ahi + off) = h;
-  *reinterpret_cast<uint2*>(Alo + off) = l;
-  return inv;
-}
+#define CB_XS 33          // float4 per X row: 528-byte rows spread the 128-byte column quarters of the statistics pass over the banks
+#define CB_NPAR 10        // small parameter vectors of a layer staged in LDS: w[0..6], gamma, beta, bias
 
 __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a, RowSpace rs, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char cb_lds[];
   const int MT = a.MT;
   const int XR = MT + 24;                                   // rows of X
-  float4* X = reinterpret_cast<float4*>(cb_lds);            // [XR][32] float4
-  char* Ahi = cb_lds + (size_t)XR * 512;                    // [64][256 B]
+  float4* X = reinterpret_cast<float4*>(cb_lds);            // [XR][CB_XS] float4
+  char* Ahi = cb_lds + (size_t)XR * CB_XS * 16;             // [64][256 B]
   char* Alo = Ahi + 64 * 256;
   char* Wl = Alo + 64 * 256;                                // CB_WBYTES
   float* ainv = reinterpret_cast<float*>(Wl + CB_WBYTES);   // [64] inverse operand scale per A row
+  float* smean = ainv + 64;                                 // [72] layer-norm statistics of the X rows
+  float* srstd = smean + 72;                                // [72]
+  float4* par = reinterpret_cast<float4*>(srstd + 72);      // [4][CB_NPAR][32] float4
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;          // 16 groups of 32 lanes: one row = 32 x float4
   const int col = 4 * l32;
@@ -108,34 +39,43 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
   const int r0 = blockIdx.x * MT;
   const int xbase = r0 - 12;                                 // global row of X[0]
 
+  const DropRegs dr = drop_load(drop);
   cb_dma_weight(a.l[0].wimg, Wl, wave, lane, CB_THREADS / 64);
-  // ---- block input (+ position embeddings for the predictor's feature encoder): every group requests its (at most 5)
-  // rows before it touches any of them - one memory round trip instead of one per row
+  // ---- block input (+ position embeddings for the predictor's feature encoder) and the small parameters of all four
+  // layers: everything is requested before anything is used - one memory round trip.  The loads are unconditional on
+  // clamped rows (a load behind a lane-dependent branch is waited for inside that branch: one round trip per load)
   {
-    float4 xv[5], pv[5];
+    float4 xv[5], pv[5], qv[4];
+    const float* posp = a.pos ? a.pos : a.x0;
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
-      const int i = grp + 16 * u, row = xbase + i;
-      const bool ok = i < XR && row >= 0 && row < R;
-      xv[u] = ok ? ld4(a.x0 + (size_t)row * HUAL_D + col) : f4zero();
-      pv[u] = f4zero();
-      if (ok && a.pos) {
-        int lo, hi;
-        cb_segment(row, rs, lo, hi);
-        pv[u] = ld4(a.pos + (size_t)(row - lo) * HUAL_D + col);
-      }
+      const int i = grp + 16 * u, row = min(max(xbase + i, 0), R - 1);
+      int lo, hi;
+      cb_segment(row, rs, lo, hi);
+      xv[u] = ld4(a.x0 + (size_t)row * HUAL_D + col);
+      pv[u] = ld4(posp + (size_t)(a.pos ? row - lo : row) * HUAL_D + col);
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {                            // group k < CB_NPAR stages parameter vector k of every layer
+      const CbLayerFwd& L = a.l[l];
+      const float* src = grp < 7 ? L.dw + grp * HUAL_D : (grp == 7 ? L.ln_g : (grp == 8 ? L.ln_b : L.bias));
+      qv[l] = ld4(src + col);
     }
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       const int i = grp + 16 * u, row = xbase + i;
       if (i >= XR) continue;
-      float4 v = xv[u];
+      const bool ok = row >= 0 && row < R;
+      float4 v = ok ? xv[u] : f4zero();
       if (a.pos) {
-        v = cb_add(v, pv[u]);
+        v = ok ? cb_add(v, pv[u]) : v;
         if (row >= r0 && row < r0 + MT && row < R) st4(a.x0_out + (size_t)row * HUAL_D + col, v);
       }
-      X[i * 32 + l32] = v;
+      X[i * CB_XS + l32] = v;
     }
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (grp < CB_NPAR) par[(l * CB_NPAR + grp) * 32 + l32] = qv[l];
   }
   __syncthreads();
 
@@ -147,32 +87,66 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
     const int ntile = (nout + 15) >> 4;
     const int obase = r0 - H;                                // global row of output / operand row 0
     const int mt = wave >> 1, ch = wave & 1;                 // P2 / P3: row tile and column half of this wave
-    float4 bias = ld4(L.bias + 64 * ch + 4 * (lane & 15));
-    // ---------------- P1: layer norm + depthwise conv -> operand planes
+    const float4* lp = par + l * CB_NPAR * 32;
+    // ---------------- P1a: layer-norm statistics of the nout + 6 input rows, once per row.  Thread (row, quarter) owns 32
+    // columns; the partial sums are associated exactly like the 32-lane butterfly of row_stats() in rowops.hip (lane =
+    // float4 column group: xor 1, 2, 4 inside the thread, xor 8 / 16 across the four quarter threads), so the values are
+    // bit-identical to the unfused kernels'
     {
-      const float4 gam = ld4(L.ln_g + col), bet = ld4(L.ln_b + col);
+      const int ri = threadIdx.x >> 2, q = threadIdx.x & 3;
+      const int xi = ri + 9 - H;                             // X row of input row obase - 3 + ri
+      const int t = xbase + xi;
+      const bool ok = ri < nout + 6 && t >= 0 && t < R;      // (quad-uniform)
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = ok ? X[xi * CB_XS + 8 * q + k] : f4zero();
+      float p[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p[k] = cb_hsum(v[k]);
+      float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      s += dpp_xor_partner(s, 1);
+      s += dpp_xor_partner(s, 2);
+      const float mean = s * (1.0f / HUAL_D);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 d = make_float4(v[k].x - mean, v[k].y - mean, v[k].z - mean, v[k].w - mean);
+        p[k] = cb_hsum(cb_mul(d, d));
+      }
+      s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+      s += dpp_xor_partner(s, 1);
+      s += dpp_xor_partner(s, 2);
+      const float rstd = rsqrtf(s * (1.0f / HUAL_D) + LN_EPS);
+      if (ok && q == 0) {
+        smean[xi] = mean;
+        srstd[xi] = rstd;
+        if (t >= r0 && t < r0 + MT) { L.mean[t] = mean; L.rstd[t] = rstd; }
+      }
+    }
+    __syncthreads();
+    // ---------------- P1b: depthwise conv over a sliding window of normalised rows -> operand planes
+    {
+      const float4 gam = lp[7 * 32 + l32], bet = lp[8 * 32 + l32];
       float4 w[7];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) w[k] = ld4(L.dw + k * HUAL_D + col);
-      const int chunk = (16 * ntile + 15) >> 4;              // operand rows per group (incl. the zero rows up to 16*ntile)
-      const int la = grp * chunk, lb = min(la + chunk, 16 * ntile);
+      for (int k = 0; k < 7; ++k) w[k] = lp[k * 32 + l32];
+      const int la = grp * ntile, lb = la + ntile;           // operand rows of this group (16 groups x ntile = all 16*ntile rows)
       float4 h0 = f4zero(), h1 = f4zero(), h2 = f4zero(), h3 = f4zero(), h4 = f4zero(), h5 = f4zero(), h6 = f4zero();
-      for (int li = la - 3; li < lb + 3; ++li) {
+#pragma unroll
+      for (int s = 0; s < 10; ++s) {                         // ntile <= 4 rows + 6 halo rows
+        const int li = la - 3 + s;
         // h of global row t = LN(x_l[t]) (zero outside the tensor): enters the window as its newest row
         const int t = obase + li;
         float4 hn = f4zero();
-        if (li < nout + 3 && t >= 0 && t < R) {
-          const float4 v = X[(t - xbase) * 32 + l32];
-          const float mean = half_sum32(cb_hsum(v)) * (1.0f / HUAL_D);
-          const float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
-          const float var = half_sum32(cb_hsum(cb_mul(d, d))) * (1.0f / HUAL_D);
-          const float rstd = rsqrtf(var + LN_EPS);
+        if (s < ntile + 6 && li < nout + 3 && t >= 0 && t < R) {
+          const int xi = t - xbase;
+          const float4 v = X[xi * CB_XS + l32];
+          const float mean = smean[xi], rstd = srstd[xi];
           hn = cb_fma(make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd), gam, bet);
-          if (l32 == 0 && li >= la && li < lb && t >= r0 && t < r0 + MT) { L.mean[t] = mean; L.rstd[t] = rstd; }
         }
         h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = h5; h5 = h6; h6 = hn;
+        if (s < 6) continue;
         const int lo_ = li - 3;                              // operand row whose window (lo_-3 .. lo_+3) is complete now
-        if (lo_ < la) continue;
+        if (lo_ >= lb) continue;
         const int o = obase + lo_;
         float4 c = f4zero();
         const bool live = lo_ < nout && o >= 0 && o < R;
@@ -194,9 +168,6 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the weight image has landed
-    // make the compiler place its own wait for `bias` here, where nothing is in flight: a wait it inserted later would
-    // be a vmcnt(0) that also drains the next layer's LDS-DMA (cdna_hip_programming.md, "Pipelining across barriers")
-    asm volatile("" : "+v"(bias.x), "+v"(bias.y), "+v"(bias.z), "+v"(bias.w));
     __syncthreads();
     // ---------------- P2: pointwise convolution on the matrix cores
     f32x4 acc[4];
@@ -207,6 +178,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
     if (mt < ntile) {
       const int j = lane & 15, g = lane >> 4;
       const int ecol = 64 * ch + 4 * j;
+      const float4 bias = lp[9 * 32 + (ecol >> 2)];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int lr = 16 * mt + 4 * g + r;
@@ -218,15 +190,252 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
         v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         const bool own = o >= r0 && o < r0 + MT;
         if (own) st4(L.y + (size_t)o * HUAL_D + ecol, v);
-        if (L.drop_site >= 0 && drop.enabled)
-          v = apply_drop4(drop, (uint32_t)L.drop_site, a.drop_row0 + (uint32_t)o, (uint32_t)(ecol >> 2), v);
-        float4* xp = X + (o - xbase) * 32 + (ecol >> 2);
+        if (L.drop_site >= 0 && dr.enabled)
+          v = apply_drop4_r(dr, (uint32_t)L.drop_site, a.drop_row0 + (uint32_t)o, (uint32_t)(ecol >> 2), v);
+        float4* xp = X + (o - xbase) * CB_XS + (ecol >> 2);
         v = cb_add(v, *xp);
         *xp = v;
         if (own) st4(L.xout + (size_t)o * HUAL_D + ecol, v);
       }
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Backward of the four layers in one launch.  Workgroup = MT owned rows (MT <= 40) + halo; per layer i = 3..0 with
+// E1 = 3(i+1) halo rows of its input gradient and E0 = 3i of its output gradient:
+//   LDS  DX  [MT+24][128] fp32   gradient wrt x_{i+1}, replaced in place by the gradient wrt x_i
+//        A / DC (one region)     operand planes of dZ_i = dropout'(dx_{i+1}) * relu'(y_i) for the dX product, then its result
+//                                dC_i = dZ_i . W_i^T as fp32 rows (the depthwise taps need it at t-3 .. t+3)
+//        W   64 KB               image of W_i^T, requested while layer i+1 is in its row phase
+//   G   wave (mt, ch): dC tile on the matrix cores (rows r0-E1 .. r0+MT+E1)
+//   R   32-lane groups, <= 4 rows each (rows r0-E0 .. r0+MT+E0): transposed depthwise conv over a sliding window of dC,
+//       layer-norm backward, + residual gradient -> DX; operand dZ_{i-1} of the next product; the parameter sums
+//       (7 depthwise taps, gamma, beta) are taken over the OWNED rows only and leave as one partial row set per workgroup
+//       (folded by colsum_kernel), dZ_i of the owned rows goes to HBM for the pointwise weight-gradient job.
+// Same arithmetic as dwconv_ln_bwd_kernel + gemm_bf16_kernel for dx / dZ (bit for bit); the parameter sums are
+// associated differently (per row instead of per tap position).
+__global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a, RowSpace rs, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char cb_lds[];
+  const int MT = a.MT;
+  const int XR = MT + 24;
+  float4* DX = reinterpret_cast<float4*>(cb_lds);            // [XR][32] float4
+  char* Ahi = cb_lds + (size_t)XR * 512;                     // operand planes [64][256 B] x 2 ...
+  char* Alo = Ahi + 64 * 256;
+  float4* DC = reinterpret_cast<float4*>(Ahi);               // ... or dC as [64][32] float4 (same 32 KB)
+  char* Wl = Ahi + 64 * 512;
+  float* ainv = reinterpret_cast<float*>(Wl + CB_WBYTES);    // [64]
+  float4* par = reinterpret_cast<float4*>(ainv + 64);        // [9][32] float4: w[0..6], gamma, beta of the current layer
+  float4* pbuf = par + 9 * 32;                               // [4][9][32] float4: per-wave parameter-gradient sums (one batch)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int col = 4 * l32;
+  const int R = rs.R;
+  const int r0 = blockIdx.x * MT;
+  const int xbase = r0 - 12;
+  const int mt = wave >> 1, ch = wave & 1;
+
+  const DropRegs dr = drop_load(drop);
+  cb_dma_weight(a.l[3].wimg_t, Wl, wave, lane, CB_THREADS / 64);
+  // ---- prologue: gradient wrt the block output -> DX; dZ_3 -> operand planes (+ HBM for the owned rows)
+  {
+    float4 dv[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                             // unconditional loads on clamped rows, see the forward kernel
+      const int i = grp + 16 * u, row = min(max(xbase + i, 0), R - 1);
+      dv[u] = ld4(a.dx_in + (size_t)row * HUAL_D + col);
+      yv[u] = ld4(a.y3 + (size_t)row * HUAL_D + col);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = grp + 16 * u, row = xbase + i;
+      if (i >= 64) continue;
+      const bool ok = i < XR && row >= 0 && row < R;
+      float4 v = ok ? dv[u] : f4zero();
+      if (i < XR) DX[i * 32 + l32] = v;
+      if (ok && a.drop_site3 >= 0 && dr.enabled) v = apply_drop4_r(dr, (uint32_t)a.drop_site3, a.drop_row0 + (uint32_t)row, (uint32_t)l32, v);
+      const float4 y = ok ? yv[u] : f4zero();
+      v = make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
+      if (ok && row >= r0 && row < r0 + MT) st4(a.l[3].dz + (size_t)row * HUAL_D + col, v);
+      const float inv = cb_store_operand(Ahi, Alo, i, l32, v);
+      if (l32 == 0) ainv[i] = ok ? inv : 0.f;
+    }
+  }
+
+#pragma unroll 1
+  for (int i = 3; i >= 0; --i) {
+    const CbLayerBwd& L = a.l[i];
+    const int E1 = 3 * (i + 1), E0 = 3 * i;
+    const int nG = MT + 2 * E1, ntile = (nG + 15) >> 4, gbase = r0 - E1;      // dC rows
+    const int nR = MT + 2 * E0, rbase = r0 - E0;                               // rows of the row phase
+    const int chunk = (nR + 15) >> 4;                                          // <= 4 rows per group
+    const int ra = grp * chunk, rb = min(ra + chunk, nR);
+    // ---- operands of the row phase, requested before the matrix phase (their latency hides under it)
+    float4 xv[4], yv[4];
+    float mu[4], rsd[4];
+    const float* yprev = L.y_prev ? L.y_prev : L.x;           // layer 0 has no relu below it: the loaded rows are ignored
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                             // unconditional loads on clamped rows
+      const int tc = min(max(rbase + ra + u, 0), R - 1);
+      xv[u] = ld4(L.x + (size_t)tc * HUAL_D + col);
+      yv[u] = ld4(yprev + (size_t)tc * HUAL_D + col);
+      mu[u] = L.mean[tc];
+      rsd[u] = L.rstd[tc];
+    }
+    // the layer's small parameters go through LDS (9 x 512 B; group k stages vector k): registers are scarce in the row phase
+    float4 pv = f4zero();
+    if (grp < 7) pv = ld4(L.dw + grp * HUAL_D + col);
+    else if (grp == 7) pv = ld4(L.ln_g + col);
+    else if (grp == 8) pv = ld4(L.ln_b + col);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // weight image + the operands above have landed
+    if (grp < 9) par[grp * 32 + l32] = pv;
+    // relu'(y_{i-1}) as 4 bits per row (bit c = column col + c is active), rows packed into one register
+    uint32_t ybits = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      asm volatile("" : "+v"(xv[u].x), "+v"(xv[u].y), "+v"(xv[u].z), "+v"(xv[u].w), "+v"(yv[u].x), "+v"(yv[u].y), "+v"(yv[u].z),
+                   "+v"(yv[u].w), "+v"(mu[u]), "+v"(rsd[u]));
+      const uint32_t b = (yv[u].x > 0.f ? 1u : 0u) | (yv[u].y > 0.f ? 2u : 0u) | (yv[u].z > 0.f ? 4u : 0u) | (yv[u].w > 0.f ? 8u : 0u);
+      ybits |= b << (4 * u);
+    }
+    __syncthreads();                                          // (1) operand planes + parameters complete
+    // ---- G: dC_i = dZ_i . W_i^T
+    f32x4 acc[4];
+    if (mt < ntile) cb_tile_mma(Ahi, Alo, Wl, mt, ch, lane, acc);
+    __syncthreads();                                          // (2) planes and weight image free
+    if (mt < ntile) {
+      const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = 16 * mt + 4 * g + r;
+        const float ir = ainv[lr];
+        DC[lr * 32 + 16 * ch + j] = make_float4(acc[0][r] * ir, acc[1][r] * ir, acc[2][r] * ir, acc[3][r] * ir);
+      }
+    }
+    __syncthreads();                                          // (3) dC visible
+    // next layer's weight image: requested only now, behind the barrier (a __syncthreads() with an LDS-DMA in flight
+    // waits for it), so that it lands under the row phase
+    if (i > 0) cb_dma_weight(a.l[i - 1].wimg_t, Wl, wave, lane, CB_THREADS / 64);
+    // ---- R: transposed depthwise conv + layer-norm backward
+    float4 sw[7], sg = f4zero(), sb = f4zero();
+    uint32_t zbits = 0;                                        // keep-bits of dZ_{i-1} = dropout keep & relu', 4 per row
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sw[k] = f4zero();
+    {
+      float4 d0 = f4zero(), d1 = f4zero(), d2 = f4zero(), d3 = f4zero(), d4 = f4zero(), d5 = f4zero(), d6 = f4zero();
+      // window rows tt = first-3 .. last+3 ; after pushing tt the window is centred on t = tt - 3
+#pragma unroll
+      for (int s = 0; s < 10; ++s) {
+        const int tt = rbase + ra - 3 + s;
+        const int di = tt - gbase;
+        float4 dn = f4zero();
+        if (s < (rb - ra) + 6 && di >= 0 && di < nG && tt >= 0 && tt < R) dn = DC[di * 32 + l32];
+        d0 = d1; d1 = d2; d2 = d3; d3 = d4; d4 = d5; d5 = d6; d6 = dn;
+        if (s < 6) continue;
+        const int u = s - 6;                                  // compile-time index of this group's row
+        const int lr = ra + u, t = rbase + lr;
+        if (!(lr < rb && t >= 0 && t < R)) continue;
+        int slo, shi;
+        cb_segment(t, rs, slo, shi);
+        // dh[t] = sum_k dC[t - k + 3] * w[k] over the taps whose source position lies in the clip (order k = 0..6)
+        const float4 e0 = (t + 3 < shi) ? d6 : f4zero(), e1 = (t + 2 < shi) ? d5 : f4zero(), e2 = (t + 1 < shi) ? d4 : f4zero();
+        const float4 e4 = (t - 1 >= slo) ? d2 : f4zero(), e5 = (t - 2 >= slo) ? d1 : f4zero(), e6 = (t - 3 >= slo) ? d0 : f4zero();
+        float4 dh = f4zero();
+        dh = cb_fma(e0, par[0 * 32 + l32], dh); dh = cb_fma(e1, par[1 * 32 + l32], dh); dh = cb_fma(e2, par[2 * 32 + l32], dh);
+        dh = cb_fma(d3, par[3 * 32 + l32], dh);
+        dh = cb_fma(e4, par[4 * 32 + l32], dh); dh = cb_fma(e5, par[5 * 32 + l32], dh); dh = cb_fma(e6, par[6 * 32 + l32], dh);
+        const float4 gam = par[7 * 32 + l32];
+        const float4 v = xv[u];
+        const float mean = mu[u], rstd = rsd[u];
+        const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+        if (t >= r0 && t < r0 + MT) {                         // parameter gradients: owned rows only
+          const float4 h = cb_fma(xh, gam, par[8 * 32 + l32]);
+          sw[0] = cb_fma(h, e0, sw[0]); sw[1] = cb_fma(h, e1, sw[1]); sw[2] = cb_fma(h, e2, sw[2]); sw[3] = cb_fma(h, d3, sw[3]);
+          sw[4] = cb_fma(h, e4, sw[4]); sw[5] = cb_fma(h, e5, sw[5]); sw[6] = cb_fma(h, e6, sw[6]);
+          sb = cb_add(sb, dh);
+          sg = cb_fma(dh, xh, sg);
+        }
+        const float4 gv = cb_mul(dh, gam);
+        const float m1 = fast_sum32(cb_hsum(gv)) * (1.0f / HUAL_D);
+        const float m2 = fast_sum32(cb_hsum(cb_mul(gv, xh))) * (1.0f / HUAL_D);
+        float4 dx = make_float4(rstd * (gv.x - m1 - xh.x * m2), rstd * (gv.y - m1 - xh.y * m2),
+                                rstd * (gv.z - m1 - xh.z * m2), rstd * (gv.w - m1 - xh.w * m2));
+        float4* dxp = DX + (t - xbase) * 32 + l32;
+        // + gradient through the residual connection; __fadd_rn keeps the product above and this sum two separately
+        // rounded operations, as in dwconv_ln_bwd_kernel (where the sum sits behind a branch and is never contracted)
+        const float4 dres = *dxp;
+        dx = make_float4(__fadd_rn(dx.x, dres.x), __fadd_rn(dx.y, dres.y), __fadd_rn(dx.z, dres.z), __fadd_rn(dx.w, dres.w));
+        *dxp = dx;
+        if (i == 0) {
+          st4(a.dx_out + (size_t)t * HUAL_D + col, dx);
+        } else {
+          // operand of the next product: dZ_{i-1} = dropout'(dx_i, site_{i-1}) * relu'(y_{i-1}); only its keep-bits are
+          // held across the barrier, the values are re-read from DX
+          uint32_t keep = 0xfu;
+          if (L.drop_site_prev >= 0 && dr.enabled)
+            keep = drop_bits4_r(dr, (uint32_t)L.drop_site_prev, a.drop_row0 + (uint32_t)t, (uint32_t)l32);
+          zbits |= (keep & (ybits >> (4 * u)) & 0xfu) << (4 * u);
+        }
+      }
+    }
+    // workgroup sums of the parameter gradients, without atomics (an LDS float atomic was measured at ~600 stall cycles per
+    // wave-instruction here): the two 32-lane groups of a wave are added in registers (v_permlane32_swap), the 8 per-wave
+    // partials go through LDS in two batches of four, and thread e owns sums e, e + 512, e + 1024 of the 9 x 128
+    {
+      auto xor32_sum = [&](float v) {
+        const unsigned x = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        return v + __builtin_bit_cast(float, (lane & 32) ? r[0] : r[1]);
+      };
+      auto xor32_sum4 = [&](float4 v) { return make_float4(xor32_sum(v.x), xor32_sum(v.y), xor32_sum(v.z), xor32_sum(v.w)); };
+#pragma unroll
+      for (int k = 0; k < 7; ++k) sw[k] = xor32_sum4(sw[k]);
+      sg = xor32_sum4(sg);
+      sb = xor32_sum4(sb);
+      float pacc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int batch = 0; batch < 2; ++batch) {
+        if ((wave >> 2) == batch && lane < 32) {
+          float4* dst = pbuf + (wave & 3) * 9 * 32 + l32;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) dst[k * 32] = sw[k];
+          dst[7 * 32] = sg;
+          dst[8 * 32] = sb;
+        }
+        __syncthreads();                                      // (4) on the first pass: dC consumed as well
+        const float* pf = reinterpret_cast<const float*>(pbuf);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int e = threadIdx.x + CB_THREADS * q;
+          if (e < 9 * HUAL_D) pacc[q] += (pf[e] + pf[e + 9 * HUAL_D]) + (pf[e + 2 * 9 * HUAL_D] + pf[e + 3 * 9 * HUAL_D]);
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int e = threadIdx.x + CB_THREADS * q;
+        if (e < 9 * HUAL_D) L.part[(size_t)blockIdx.x * 9 * HUAL_D + e] = pacc[q];
+      }
+    }
+    if (i > 0) {
+      // operand rows of the next product: index 0 = global row r0 - E0 (= rbase); rows up to the next 16-row tile edge zeroed
+      const int ntn = (nR + 15) >> 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int lr = ra + u, t = rbase + lr;
+        if (lr >= ra + chunk || lr >= 16 * ntn) continue;
+        const bool ok = lr < rb && t >= 0 && t < R;
+        float4 v = f4zero();
+        if (ok) {
+          const float dscale = (L.drop_site_prev >= 0 && dr.enabled) ? dr.scale : 1.0f;
+          v = cb_mul(DX[(t - xbase) * 32 + l32], mask_from_bits4((zbits >> (4 * u)) & 0xfu, dscale));
+        }
+        if (ok && t >= r0 && t < r0 + MT) st4(L.dz_prev + (size_t)t * HUAL_D + col, v);
+        const float inv = cb_store_operand(Ahi, Alo, lr, l32, v);
+        if (l32 == 0) ainv[lr] = ok ? inv : 0.f;
+      }
+    }
   }
 }
 
@@ -241,7 +450,7 @@ int conv_block_fused_rows(int R) {
   return mt;
 }
 
-static size_t cb_fwd_lds(int MT) { return (size_t)(MT + 24) * 512 + 2 * 64 * 256 + CB_WBYTES + 64 * sizeof(float); }
+static size_t cb_fwd_lds(int MT) { return (size_t)(MT + 24) * CB_XS * 16 + 2 * 64 * 256 + CB_WBYTES + (64 + 72 + 72) * sizeof(float) + 4 * CB_NPAR * 512; }
 
 int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.x0 && rs.R > 0 && a.MT >= 1 && a.MT <= HUAL_CB_MAXMT, "conv_block_fwd: bad arguments");
@@ -255,6 +464,31 @@ int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg&
   // algorithmic work: 4 pointwise products; bytes: x0 in, (c, y, x) out per layer, weights
   HUAL_LAUNCH(4.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 13.0 + 4.0 * HUAL_D * HUAL_D), conv_block_fwd_kernel,
               dim3(cdiv(rs.R, a.MT)), dim3(CB_THREADS), cb_fwd_lds(a.MT), s, a, rs, drop);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int conv_block_fused_rows_bwd(int R) {
+  int mt = cdiv(R, 256);
+  if (mt < 16) mt = 16;
+  if (mt > HUAL_CB_BWD_MAXMT) mt = HUAL_CB_BWD_MAXMT;
+  return mt;
+}
+int conv_block_bwd_blocks(int R) { return cdiv(R, conv_block_fused_rows_bwd(R)); }
+
+static size_t cb_bwd_lds(int MT) { return (size_t)(MT + 24) * 512 + 64 * 512 + CB_WBYTES + 64 * sizeof(float) + (1 + 4) * 9 * HUAL_D * sizeof(float); }
+
+int launch_conv_block_bwd(const CbBwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
+  HUAL_REQUIRE(a.dx_in && a.y3 && a.dx_out && rs.R > 0 && a.MT >= 1 && a.MT <= HUAL_CB_BWD_MAXMT, "conv_block_bwd: bad arguments");
+  for (int l = 0; l < 4; ++l) {
+    const CbLayerBwd& L = a.l[l];
+    HUAL_REQUIRE(L.ln_g && L.ln_b && L.dw && L.wimg_t && L.x && L.mean && L.rstd && L.dz && L.part, "conv_block_bwd: null layer tensor");
+    HUAL_REQUIRE(l == 0 || (L.y_prev && L.dz_prev), "conv_block_bwd: layers 1-3 need y_prev / dz_prev");
+  }
+  HUAL_DYN_LDS(conv_block_bwd_kernel, 160 * 1024);
+  const double rows = (double)rs.R;
+  HUAL_LAUNCH(4.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 14.0 + 4.0 * HUAL_D * HUAL_D), conv_block_bwd_kernel,
+              dim3(cdiv(rs.R, a.MT)), dim3(CB_THREADS), cb_bwd_lds(a.MT), s, a, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(RT * 128) void gemm_lds_kernel(GemmBatch batch, Dro
 
 // MODE 0: single accumulator; 1: dual (cross gating / bilinear); 2: decided per job at run time (chained launches)
 template <int MODE, int RT, class J>
-__device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop, char* ldsb, int dbg = 0) {
+__device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop, char* ldsb) {
   const bool DUAL = MODE == 1 || (MODE == 2 && job.comb != COMB_NONE);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -609,9 +609,7 @@ __device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop
     __syncthreads();                                      // ... and everybody else's
     const bool two = s + 1 < nstages;
     float inv = 0.f, inv2 = 0.f, sc2 = 0.f;
-    float sc;
-    if (dbg & 1) { sc = 64.f; inv = 1.0f / 65536.f; }       // timing experiment (HUAL_F16_DBG): fixed scale, no row maximum
-    else sc = row_scale(a0, a1, two, inv);
+    const float sc = row_scale(a0, a1, two, inv);
     if (MODE && DUAL) sc2 = row_scale(c0, c1, two, inv2);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -623,7 +621,7 @@ __device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop
     // fold the chunk into the total: accumulator register r is row 4g + r of the tile, whose scale lives in lanes j = 4g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float ir = (dbg & 2) ? inv : __shfl(inv, 4 * g + r);
+      const float ir = __shfl(inv, 4 * g + r);
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t][r] = fmaf(accp[t][r], ir, acc[t][r]);
       if (MODE && DUAL) {
@@ -645,9 +643,9 @@ __device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop
 }
 
 template <bool DUAL, int RT>
-__global__ __launch_bounds__(RT * 128) void gemm_bf16_kernel(GemmBatch batch, DropCfg drop, int dbg) {
+__global__ __launch_bounds__(RT * 128) void gemm_bf16_kernel(GemmBatch batch, DropCfg drop) {
   extern __shared__ float lds[];     // Ws[2][GB_STAGE] (+ W2s[2][GB_STAGE] when DUAL)
-  gemm_bf16_body<DUAL ? 1 : 0, RT>(batch.j[blockIdx.z], drop, reinterpret_cast<char*>(lds), dbg);
+  gemm_bf16_body<DUAL ? 1 : 0, RT>(batch.j[blockIdx.z], drop, reinterpret_cast<char*>(lds));
 }
 
 // The same kernel under its own symbol for the deep-K launch of a step - video_conv1d (+ query_conv1d), model.py:42,48: the
@@ -1496,7 +1494,6 @@ int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_
   }
   const size_t lds = (size_t)(dual ? 4 : 2) * GB_STAGE;
   static const int rt_env = []() { const char* e = getenv("HUAL_GEMM_RT"); return e ? atoi(e) : 0; }();
-  const int dbg = []() { const char* e = getenv("HUAL_F16_DBG"); return e ? atoi(e) : 0; }();     // timing experiments only
   const int ncol = cdiv(maxN, 128);
   int rt = (cdiv(maxM, 32) * ncol * n > 256 && maxM > 48) ? 3 : 2;
   // deep-K jobs (video_conv1d: K = vdim, with Philox dropout on its A operand) are bound by per-wave VALU / MFMA work, not by
@@ -1510,11 +1507,11 @@ int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_
     HUAL_DYN_LDS(feature_load_gemm_kernel<2>, 160 * 1024);
     HUAL_LAUNCH(flops, bytes, feature_load_gemm_kernel<2>, g, blk, lds, stream, b, drop);
   } else if (rt == 3) {
-    if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 3>), g, blk, lds, stream, b, drop, dbg);
-    else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 3>), g, blk, lds, stream, b, drop, dbg);
+    if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 3>), g, blk, lds, stream, b, drop);
+    else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 3>), g, blk, lds, stream, b, drop);
   } else {
-    if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 2>), g, blk, lds, stream, b, drop, dbg);
-    else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 2>), g, blk, lds, stream, b, drop, dbg);
+    if (dual) HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<true, 2>), g, blk, lds, stream, b, drop);
+    else HUAL_LAUNCH(flops, bytes, (gemm_bf16_kernel<false, 2>), g, blk, lds, stream, b, drop);
   }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

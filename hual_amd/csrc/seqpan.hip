@@ -435,6 +435,34 @@ float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP
 float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, const ConvBlockP& cp, const RowSpace& rs,
                       int site0, bool dz3_ready) {
   const int R = rs.R;
+  if (c.fuse_cb) {       // all four layers in one launch (convblock.h); dZ_3 is formed inside from dx and y3
+    CbBwdArgs a{};
+    a.dx_in = dx; a.y3 = c.buf(tag + ".y3", R, HUAL_D); a.drop_site3 = site0 + 3;
+    a.dx_out = c.buf("d." + tag + ".x0", R, HUAL_D);
+    a.MT = conv_block_fused_rows_bwd(R); a.drop_row0 = 0;
+    const int nblk = conv_block_bwd_blocks(R);
+    for (int i = 3; i >= 0; --i) {
+      const std::string is = std::to_string(i);
+      CbLayerBwd& L = a.l[i];
+      L.ln_g = c.p(cp.ln[i].g); L.ln_b = c.p(cp.ln[i].b); L.dw = c.p(cp.dw[i]);
+      L.wimg_t = reinterpret_cast<const float*>(c.PKB + cp.pw[i] * 4);
+      L.x = i == 0 ? x0 : c.buf(tag + ".x" + is, R, HUAL_D);
+      L.mean = c.buf(tag + ".mean" + is, R, 1); L.rstd = c.buf(tag + ".rstd" + is, R, 1);
+      L.y_prev = i > 0 ? c.buf(tag + ".y" + std::to_string(i - 1), R, HUAL_D) : nullptr;
+      L.dz = c.buf("d." + tag + ".z" + is, R, HUAL_D);
+      L.dz_prev = i > 0 ? c.buf("d." + tag + ".z" + std::to_string(i - 1), R, HUAL_D) : nullptr;
+      L.drop_site_prev = site0 + i - 1;
+      L.part = c.buf("part." + std::to_string(c.colsum.size()), (size_t)nblk * 9, HUAL_D);
+      ColsumJob cj{};
+      cj.src = L.part; cj.nblk = nblk; cj.nvec = 9;
+      for (int k = 0; k < 7; ++k) cj.dst[k] = c.g(cp.dw[i]) + k * HUAL_D;
+      cj.dst[7] = c.g(cp.ln[i].g); cj.dst[8] = c.g(cp.ln[i].b);
+      c.colsum.push_back(cj);
+      c.dwjobs.push_back(mkdw(c.buf(tag + ".c" + is, R, HUAL_D), HUAL_D, HUAL_D, L.dz, HUAL_D, R, c.g(cp.pw[i]), c.g(cp.b[i])));
+    }
+    if (!c.dry && c.ok()) c.chk(launch_conv_block_bwd(a, rs, c.drop, c.stream));
+    return a.dx_out;
+  }
   for (int i = 3; i >= 0; --i) {
     const std::string is = std::to_string(i);
     float* xin = i == 0 ? x0 : c.buf(tag + ".x" + is, R, HUAL_D);
@@ -991,7 +1019,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       a.x = f; a.mean = mean; a.rstd = rstd; a.R = Nv; a.dy1 = d_a; a.g1 = c.p(pm.fe_ln1.g);
       a.dg1 = c.g(pm.fe_ln1.g); a.db1 = c.g(pm.fe_ln1.b); a.drop_site1 = site + 4; a.drop_row0 = 0; a.add1 = d_res;
       a.dx = d_f;
-      if (c.fuse_row) { a.dz = c.actv("d." + t + ".z3"); a.dz_site = site + 3; a.dz_relu = c.actv(t + ".y3"); }
+      if (c.fuse_row && !c.fuse_cb) { a.dz = c.actv("d." + t + ".z3"); a.dz_site = site + 3; a.dz_relu = c.actv(t + ".y3"); }
       c.ln_bwd(a);
     }
     float* d_x0 = conv_block_bwd(c, t, x0, d_f, pm.fe_cb, c.rsv, site, c.fuse_row);
@@ -1259,7 +1287,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       a.add1 = d_res; a.dx = d_xin;
       if (c.fuse_row) {      // operand of the next dX GEMM down the stack: previous layer's dense_2, or the conv block's layer 3
         if (li > 0) { a.dz = c.act("d.da" + std::to_string(li - 1) + ".z2"); a.dz_site = HUAL_SITE_DA + 8 * (li - 1) + 4; }
-        else { a.dz = c.act("d.cb.z3"); a.dz_site = HUAL_SITE_CONV + 3; a.dz_relu = c.act("cb.y3"); }
+        else if (!c.fuse_cb) { a.dz = c.act("d.cb.z3"); a.dz_site = HUAL_SITE_CONV + 3; a.dz_relu = c.act("cb.y3"); }
       }
       c.ln_bwd(a);
     }

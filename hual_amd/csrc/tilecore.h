@@ -1,0 +1,167 @@
+// Building blocks of the fused multi-layer kernels (convblock.hip, dablock.hip): a workgroup of 512 threads keeps a tile of
+// activation rows in LDS as pre-split fp16 operand planes (bf16x3.h "f16x3"), streams one [128,128] weight image at a time
+// into LDS by LDS-DMA, and each wave multiplies a 16-row tile by a 64-column half on the matrix cores.
+#pragma once
+#include "common.h"
+#include "rowops.h"
+#include "bf16x3.h"
+#include "philox.h"
+
+#define LN_EPS 1e-6f   // models/layers.py:15
+#define CB_THREADS 512
+#define CB_TILE 16384            // one [64][128 x 16 bit] tile
+#define CB_STAGE (2 * CB_TILE)   // hi + lo tile of 64 K rows
+#define CB_WBYTES (2 * CB_STAGE) // a whole [128,128] weight image
+
+__device__ __forceinline__ float4 cb_fma(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 cb_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 cb_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float cb_hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+// ---- 32-lane butterfly reductions on the VALU (DPP + v_permlane16_swap) --------------------------------------------------
+// Same pairs, same order as common.h half_sum32 / half_max32 (xor 1, 2, 4, 8, 16: bit-identical results), but without the
+// five dependent ds_bpermute round trips (~100+ cycles each) those cost: at one workgroup per CU the fused kernels are
+// latency bound and a row reduction per ds_bpermute chain was measured to dominate them (15 us per conv_block layer).
+__device__ __forceinline__ float dpp_xor_partner(float v, int step) {
+  const int x = __builtin_bit_cast(int, v);
+  int r;
+  if (step == 1) r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);          // quad_perm [1,0,3,2]
+  else if (step == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+  else if (step == 4) {
+    r = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);                       // row_shl:4 -> lanes 0-3, 8-11 read lane + 4
+    r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);                       // row_shr:4 -> lanes 4-7, 12-15 read lane - 4
+  } else {
+    r = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xF, 0x3, false);                       // row_shl:8 -> lanes 0-7 read lane + 8
+    r = __builtin_amdgcn_update_dpp(r, x, 0x118, 0xF, 0xC, false);                       // row_shr:8 -> lanes 8-15 read lane - 8
+  }
+  return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float lane_xor16_partner(float v) {
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);    // r[0]: odd rows <- even rows, r[1]: even rows <- odd rows
+  const unsigned p = (threadIdx.x & 16) ? r[0] : r[1];
+  return __builtin_bit_cast(float, p);
+}
+__device__ __forceinline__ float fast_sum32(float v) {
+  v += dpp_xor_partner(v, 1);
+  v += dpp_xor_partner(v, 2);
+  v += dpp_xor_partner(v, 4);
+  v += dpp_xor_partner(v, 8);
+  v += lane_xor16_partner(v);
+  return v;
+}
+__device__ __forceinline__ float fast_max32(float v) {
+  v = fmaxf(v, dpp_xor_partner(v, 1));
+  v = fmaxf(v, dpp_xor_partner(v, 2));
+  v = fmaxf(v, dpp_xor_partner(v, 4));
+  v = fmaxf(v, dpp_xor_partner(v, 8));
+  v = fmaxf(v, lane_xor16_partner(v));
+  return v;
+}
+
+// ---- dropout with the Philox key / offset held in registers ---------------------------------------------------------------
+// philox.h's drop_mask4 reads the three state words from global memory on every call; in a latency-bound fused kernel that
+// is a memory round trip per call (and, next to an LDS-DMA in flight, a vmcnt(0) that also waits for every store issued
+// before it).  The fused kernels read the state once at entry.
+struct DropRegs { uint32_t k0, k1, off, thresh; float scale; int enabled; };
+__device__ __forceinline__ DropRegs drop_load(const hual::DropCfg& d) {
+  DropRegs r;
+  r.enabled = d.enabled; r.thresh = d.thresh; r.scale = d.scale; r.k0 = 0; r.k1 = 0; r.off = 0;
+  if (d.enabled) {
+    r.k0 = __builtin_amdgcn_readfirstlane(d.state[0]);
+    r.k1 = __builtin_amdgcn_readfirstlane(d.state[1]);
+    r.off = __builtin_amdgcn_readfirstlane(d.state[2]);
+  }
+  return r;
+}
+// keep bits of the 4 columns [4*col4, 4*col4+3] of `row` at call-site `site` (same draw as philox.h drop_bits4)
+__device__ __forceinline__ uint32_t drop_bits4_r(const DropRegs& d, uint32_t site, uint32_t row, uint32_t col4) {
+  const uint4_ r = philox4x32_10(col4, row, site, d.off, d.k0, d.k1);
+  return (r.x < d.thresh ? 1u : 0u) | (r.y < d.thresh ? 2u : 0u) | (r.z < d.thresh ? 4u : 0u) | (r.w < d.thresh ? 8u : 0u);
+}
+__device__ __forceinline__ float4 apply_drop4_r(const DropRegs& d, uint32_t site, uint32_t row, uint32_t col4, float4 v) {
+  const float4 m = mask_from_bits4(drop_bits4_r(d, site, row, col4), d.scale);
+  v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+  return v;
+}
+
+// clip segment [lo, hi) of unified row `row` (rowops.h RowSpace)
+__device__ __forceinline__ void cb_segment(int row, const hual::RowSpace& rs, int& lo, int& hi) {
+  if (row < rs.Nv) { const int b = row / rs.T; lo = b * rs.T; hi = lo + rs.T; }
+  else { const int q = row - rs.Nv; const int b = q / rs.L; lo = rs.Nv + b * rs.L; hi = lo + rs.L; }
+}
+
+// One LDS-DMA piece (global_load_lds_dwordx4: 64 lanes x 16 bytes -> 1 KB of LDS at the wave-uniform byte address `lds`),
+// issued from inline asm so that hipcc does not know about the pending LDS write.  With the builtin the compiler keeps a
+// DMA in flight "visible" to its wait insertion: every LDS read that may alias the destination and every __syncthreads()
+// is preceded by s_waitcnt vmcnt(0), which drains the DMA (and every store issued before it) at the first LDS access of
+// the phase the DMA was meant to run under.  The callers wait explicitly (s_waitcnt vmcnt(0) + barrier) before the
+// first read of the image (cdna_hip_programming.md 5.7: M0 is written in the same statement that uses it).
+__device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds)
+               : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)p;
+}
+
+// LDS-DMA of one [128,128] weight image (pack_weights_kernel layout: per K row 256 B of fp16 high parts, 256 B of
+// residuals) into two stages of {hi tile, lo tile}; the XOR swizzle of tile256_off is applied on the global side
+__device__ __forceinline__ void cb_dma_weight(const float* wimg, char* Wl, int wave, int lane, int nwaves) {
+  const char* img = reinterpret_cast<const char*>(wimg);
+  const int chp = lane & 15, rr = lane >> 4;
+  const uint32_t wbase = __builtin_amdgcn_readfirstlane(lds_addr_of(Wl));
+  for (int pc = wave; pc < 64; pc += nwaves) {
+    const int st = pc >> 5, pl = pc & 31;
+    const int r = 4 * (pl & 15) + rr;
+    const int ch = chp ^ (((r & 3) << 2) | ((r >> 2) & 3));
+    const char* src = img + (size_t)(64 * st + r) * 512 + (pl >> 4) * 256 + 16 * ch;
+    glds16_asm(src, __builtin_amdgcn_readfirstlane(wbase + (uint32_t)(st * CB_STAGE + pl * 1024)));
+  }
+}
+
+// 16 x 64 output tile of A[16 rows of the LDS planes] . W: wave-level, accumulators in the column order of the epilogue
+// (accumulator t, register r, lane (j, g) = row 4g + r, column 64 ch + 4j + t)
+__device__ __forceinline__ void cb_tile_mma(const char* Ahi, const char* Alo, const char* Wl, int mt, int ch, int lane,
+                                            f32x4 (&acc)[4]) {
+  const int j = lane & 15, g = lane >> 4;
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int aoff = tile256_off(16 * mt + j, 4 * ks + g);
+    const f16x8 ah = *reinterpret_cast<const f16x8*>(Ahi + aoff);
+    const f16x8 al = *reinterpret_cast<const f16x8*>(Alo + aoff);
+    const char* hi = Wl + (ks >> 1) * CB_STAGE;
+    const int r0 = 32 * (ks & 1) + 8 * g + tq, r1 = r0 + 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int chunk = 8 * ch + 2 * t + (tp >> 1);
+      const int o0 = tile256_off(r0, chunk) + 8 * (tp & 1), o1 = tile256_off(r1, chunk) + 8 * (tp & 1);
+      const f16x8 wh = join_tr_f16(lds_read_tr16(hi, o0), lds_read_tr16(hi, o1));
+      const f16x8 wl = join_tr_f16(lds_read_tr16(hi + CB_TILE, o0), lds_read_tr16(hi + CB_TILE, o1));
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, acc[t], 0, 0, 0);
+    }
+  }
+}
+
+// row of the operand planes: scale to fp16 range, split, store (8 bytes per lane and plane); returns the inverse scale
+__device__ __forceinline__ float cb_store_operand(char* Ahi, char* Alo, int arow, int l32, float4 v) {
+  float inv;
+  const float sc = f16_row_scale(fast_max32(f4absmax(v)), inv);
+  uint2 h, l;
+  f16_split4(f4scale1(v, sc), h, l);
+  const int off = tile256_off(arow, l32 >> 1) + 8 * (l32 & 1);
+  *reinterpret_cast<uint2*>(Ahi + off) = h;
+  *reinterpret_cast<uint2*>(Alo + off) = l;
+  return inv;
+}
+

@@ -45,3 +45,30 @@ def test_fused_conv_block_forward_bit_exact(shape, drop, monkeypatch):
         assert torch.equal(t1[n], t0[n]), (n, float((t1[n] - t0[n]).abs().max()))
     for k in r1:
         assert torch.equal(r1[k], r0[k]), k
+
+
+CB_BWD_TAPS = ['d.%s.x0' % t for t in ('cb', 'fe0', 'fe1')] + ['d.%s.z%d' % (t, i) for t in ('cb', 'fe0', 'fe1') for i in range(4)]
+
+
+@pytest.mark.parametrize('shape', [dict(B=3, T=37, L=9, C=4, seed=11, max_vlen=40), dict(B=1, T=5, L=3, C=4, seed=2, max_vlen=8),
+                                   dict(B=8, T=64, L=20, C=8, seed=9, max_vlen=64), dict(B=5, T=100, L=30, C=6, seed=4, max_vlen=100),
+                                   dict(B=2, T=256, L=24, C=6, seed=51, max_vlen=256)])
+@pytest.mark.parametrize('drop', [0.0, 0.2])
+def test_fused_conv_block_backward(shape, drop, monkeypatch):
+    """gradient wrt the block input and every dZ operand: to 5e-6 of the tensor's scale (the two paths agree to the last bit
+    or two per layer - the compiler contracts a*b+c chains of the row phase differently - and the difference is carried
+    through the layers below); parameter gradients (sums over all rows, taken in a different association and - in both
+    paths - with float atomics): to 2e-5 of the tensor's scale"""
+    case = pu.make_case(**shape)
+    t1, _, g1 = _run(case, drop, {'HUAL_FUSE_CB': '1'}, monkeypatch, CB_BWD_TAPS, backward=True)
+    t0, _, g0 = _run(case, drop, {'HUAL_FUSE_CB': '0'}, monkeypatch, CB_BWD_TAPS, backward=True)
+    for n in CB_BWD_TAPS:
+        d, sc = float((t1[n] - t0[n]).abs().max()), float(t0[n].abs().max())
+        assert d <= 5e-6 * max(sc, 1e-30), (n, d, sc)
+    cfg, p, wv, b, labels = case
+    m = pu.hip_model(cfg, p, wv)
+    d1, d0 = m.table.unpack(g1.cpu().numpy()), m.table.unpack(g0.cpu().numpy())
+    for k in d1:
+        scale = float(np.abs(d0[k]).max())
+        # (+ 1e-6 absolute: gradients that are zero in exact arithmetic - the key biases under the softmax - are rounding noise)
+        assert float(np.abs(d1[k] - d0[k]).max()) <= 2e-5 * scale + 1e-6, (k, float(np.abs(d1[k] - d0[k]).max()), scale)
