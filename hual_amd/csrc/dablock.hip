@@ -1,0 +1,405 @@
+// Fused row-local chains of the dual attention block (see dablock.h).  Built from the pieces of tilecore.h: operand planes
+// in LDS, one weight image at a time by LDS-DMA (requested as soon as the previous image has been consumed, so that it
+// lands under the epilogue), wave (mt, ch) = 16 rows x 64 columns on the matrix cores, epilogue tiles in registers.
+#include "dablock.h"
+#include "tilecore.h"
+#include "prof.h"
+
+using namespace hual;
+
+// maximum over the 16 lanes that share lane >> 4 (one DPP row): the lanes holding the 64 columns of a tile row
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_xor_partner(v, 1));
+  v = fmaxf(v, dpp_xor_partner(v, 2));
+  v = fmaxf(v, dpp_xor_partner(v, 4));
+  v = fmaxf(v, dpp_xor_partner(v, 8));
+  return v;
+}
+__device__ __forceinline__ float4 sig4(float4 v) { return make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)); }
+
+// layer norm of one row held as one float4 per lane of a 32-lane group (models/layers.py:7-17; the butterfly of row_stats())
+__device__ __forceinline__ float4 ln_row(float4 v, float& mean, float& rstd) {
+  mean = fast_sum32(cb_hsum(v)) * (1.0f / HUAL_D);
+  const float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+  const float var = fast_sum32(cb_hsum(cb_mul(d, d))) * (1.0f / HUAL_D);
+  rstd = rsqrtf(var + LN_EPS);
+  return make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+}
+
+// ------------------------------------------------------------------------------------------------------
+#define LP_ROWS 64
+__global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char lp_lds[];
+  char* P1 = lp_lds;                                  // hi plane [64][256 B] | lo plane
+  char* P2 = P1 + 2 * LP_ROWS * 256;
+  char* Wl = P2 + 2 * LP_ROWS * 256;
+  float* ainv1 = reinterpret_cast<float*>(Wl + CB_WBYTES);
+  float* ainv2 = ainv1 + LP_ROWS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int col = 4 * l32;
+  const int MT = a.MT, ntile = MT >> 4, R = a.R;
+  const int r0 = blockIdx.x * MT;
+  const int mt = wave >> 1, ch = wave & 1;
+  const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
+  const DropRegs dr = drop_load(drop);
+
+  cb_dma_weight(a.wimg[0], Wl, wave, lane, CB_THREADS / 64);
+  // every operand of the kernel is requested up front: rows (unconditional loads on clamped rows), layer-norm parameters, biases
+  float4 xv[4], bias[HUAL_LNPROJ_MAX];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) xv[u] = ld4(a.x + (size_t)min(r0 + grp + 16 * u, R - 1) * HUAL_D + col);
+  const float4 g1 = ld4(a.g1 + col), b1 = ld4(a.b1 + col);
+  const float4 g2 = a.g2 ? ld4(a.g2 + col) : f4zero(), b2 = a.g2 ? ld4(a.b2 + col) : f4zero();
+#pragma unroll
+  for (int p = 0; p < HUAL_LNPROJ_MAX; ++p) bias[p] = (p < a.nproj && a.bias[p]) ? ld4(a.bias[p] + ecol) : f4zero();
+  // ---- layer norm(s) -> operand planes
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int lr = grp + 16 * u, row = r0 + lr;
+    if (lr >= MT) continue;
+    const bool ok = row < R;
+    float mean, rstd;
+    const float4 xh = ln_row(xv[u], mean, rstd);
+    float4 y1 = cb_fma(xh, g1, b1);
+    if (a.drop_site1 >= 0 && dr.enabled) y1 = apply_drop4_r(dr, (uint32_t)a.drop_site1, a.drop_row0 + (uint32_t)row, (uint32_t)l32, y1);
+    if (!ok) y1 = f4zero();
+    if (ok) {
+      st4(a.y1 + (size_t)row * HUAL_D + col, y1);
+      if (l32 == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    }
+    const float i1 = cb_store_operand(P1, P1 + LP_ROWS * 256, lr, l32, y1);
+    if (l32 == 0) ainv1[lr] = ok ? i1 : 0.f;
+    if (a.g2) {
+      const float4 y2 = ok ? cb_fma(xh, g2, b2) : f4zero();
+      if (ok) st4(a.y2 + (size_t)row * HUAL_D + col, y2);
+      const float i2 = cb_store_operand(P2, P2 + LP_ROWS * 256, lr, l32, y2);
+      if (l32 == 0) ainv2[lr] = ok ? i2 : 0.f;
+    }
+  }
+  // ---- the projections, one weight image at a time
+#pragma unroll
+  for (int p = 0; p < HUAL_LNPROJ_MAX; ++p) {
+    if (p >= a.nproj) break;                                 // uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the image (and its stores) done
+    __syncthreads();
+    const char* P = a.src[p] ? P2 : P1;
+    const float* ai = a.src[p] ? ainv2 : ainv1;
+    f32x4 acc[4];
+    if (mt < ntile) cb_tile_mma(P, P + LP_ROWS * 256, Wl, mt, ch, lane, acc);
+    __syncthreads();                                         // image consumed
+    if (p + 1 < a.nproj) cb_dma_weight(a.wimg[p + 1], Wl, wave, lane, CB_THREADS / 64);
+    if (mt < ntile) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = 16 * mt + 4 * g + r, row = r0 + lr;
+        if (row >= R) continue;
+        const float ir = ai[lr];
+        const float4 v = make_float4(fmaf(acc[0][r], ir, 0.f) + bias[p].x, fmaf(acc[1][r], ir, 0.f) + bias[p].y,
+                                     fmaf(acc[2][r], ir, 0.f) + bias[p].z, fmaf(acc[3][r], ir, 0.f) + bias[p].w);
+        st4(a.out[p] + (size_t)row * a.ldo[p] + ecol, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+#define DP_ROWS 48
+#define DP_PLANE (DP_ROWS * 256)          // one plane of an operand slot
+#define DP_SLOT (2 * DP_PLANE)
+#define DP_NB 11                          // small vectors in LDS: 9 biases + ln2 gamma, beta
+
+__global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char dp_lds[];
+  char* P0 = dp_lds;
+  char* P1 = P0 + DP_SLOT;
+  char* P2 = P1 + DP_SLOT;
+  char* Wl = P2 + DP_SLOT;
+  float4* bl = reinterpret_cast<float4*>(Wl + CB_WBYTES);        // [DP_NB][32] float4
+  float* ainv0 = reinterpret_cast<float*>(bl + DP_NB * 32);       // [48] per slot
+  float* ainv1 = ainv0 + DP_ROWS;
+  float* ainv2 = ainv1 + DP_ROWS;
+  float* smax = ainv2 + DP_ROWS;                                   // [48][2] half-row maxima of the tile being written
+  float4* scratch = reinterpret_cast<float4*>(P0);                 // fp32 rows [48][32] float4 for the LN2 pass (= slot 0)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int col = 4 * l32;
+  const int MT = a.MT, ntile = MT >> 4, R = a.R;
+  const int r0 = blockIdx.x * MT;
+  const int mt = wave >> 1, ch = wave & 1;
+  const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
+  const bool act = mt < ntile;                                     // wave owns an output tile
+  const DropRegs dr = drop_load(drop);
+
+  cb_dma_weight(a.w[0], Wl, wave, lane, CB_THREADS / 64);
+  // ---- everything read from HBM is requested up front: the attention outputs and ln1 rows of the row phases, the residual
+  // rows / row mask of the epilogues, the small vectors
+  float4 sa[3], xa[3], l1[3], xin[4];
+  float rm[4];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const size_t off = (size_t)min(r0 + grp + 16 * u, R - 1) * HUAL_D + col;
+    sa[u] = ld4(a.s_att + off);
+    xa[u] = ld4(a.x_att + off);
+    l1[u] = ld4(a.ln1 + off);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = min(r0 + 16 * mt + 4 * g + r, R - 1);
+    xin[r] = ld4(a.x + (size_t)row * HUAL_D + ecol);
+    rm[r] = a.rowmask[row];
+  }
+  {
+    float4 pv = f4zero();
+    if (grp < 9) pv = ld4(a.b[grp] + col);
+    else if (grp == 9) pv = ld4(a.ln2_g + col);
+    else if (grp == 10) pv = ld4(a.ln2_b + col);
+    if (grp < DP_NB) bl[grp * 32 + l32] = pv;
+  }
+  // ---- RP0: attention outputs -> slots 0, 1
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int lr = grp + 16 * u;
+    if (lr >= MT) continue;
+    const bool ok = r0 + lr < R;
+    const float i0 = cb_store_operand(P0, P0 + DP_PLANE, lr, l32, ok ? sa[u] : f4zero());
+    const float i1 = cb_store_operand(P1, P1 + DP_PLANE, lr, l32, ok ? xa[u] : f4zero());
+    if (l32 == 0) { ainv0[lr] = ok ? i0 : 0.f; ainv1[lr] = ok ? i1 : 0.f; }
+  }
+
+  // one weight step: wait for the image, multiply slot P by it, free the image and request the next one
+  f32x4 accp[4];
+  auto step = [&](const char* P, const float* next) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (act) cb_tile_mma(P, P + DP_PLANE, Wl, mt, ch, lane, accp);
+    __syncthreads();
+    if (next) cb_dma_weight(next, Wl, wave, lane, CB_THREADS / 64);
+  };
+  // acc (+)= accp * inverse operand scale of the rows
+  auto fold = [&](float4 (&acc)[4], const float* ai, bool first) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ir = ai[16 * mt + 4 * g + r];
+      if (first) acc[r] = make_float4(fmaf(accp[0][r], ir, 0.f), fmaf(accp[1][r], ir, 0.f), fmaf(accp[2][r], ir, 0.f), fmaf(accp[3][r], ir, 0.f));
+      else acc[r] = make_float4(fmaf(accp[0][r], ir, acc[r].x), fmaf(accp[1][r], ir, acc[r].y), fmaf(accp[2][r], ir, acc[r].z), fmaf(accp[3][r], ir, acc[r].w));
+    }
+  };
+  auto addb = [&](float4 v, int k) { const float4 b = bl[k * 32 + (ecol >> 2)]; return make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w); };
+  auto save = [&](float* dst, int r, float4 v) {
+    const int row = r0 + 16 * mt + 4 * g + r;
+    if (row < R) st4(dst + (size_t)row * HUAL_D + ecol, v);
+  };
+  // tile -> operand slot, part 1: half-row maxima to LDS (the other column half of a row lives in the partner wave)
+  auto put_max = [&](const float4 (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float m = row16_max(f4absmax(v[r]));
+      if (j == 0) smax[(16 * mt + 4 * g + r) * 2 + ch] = m;
+    }
+  };
+  // part 2 (behind a barrier): common row scale, split, store
+  auto put_planes = [&](char* P, float* ai, const float4 (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = 16 * mt + 4 * g + r;
+      float inv;
+      const float sc = f16_row_scale(fmaxf(smax[lr * 2], smax[lr * 2 + 1]), inv);
+      uint2 h, l;
+      f16_split4(f4scale1(v[r], sc), h, l);
+      const int off = tile256_off(lr, ecol >> 3) + 8 * (j & 1);
+      *reinterpret_cast<uint2*>(P + off) = h;
+      *reinterpret_cast<uint2*>(P + DP_PLANE + off) = l;
+      if (ch == 0 && j == 0) ai[lr] = (r0 + lr < R) ? inv : 0.f;
+    }
+  };
+  auto zero_invalid = [&](float4 (&v)[4]) {      // rows beyond the tensor carry zeros through the chain
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (r0 + 16 * mt + 4 * g + r >= R) v[r] = f4zero();
+  };
+
+  float4 SV[4], XV[4], T1[4], T2[4];
+  // ---- s_value = s_att . Ws + b  (layers.py:93)
+  step(P0, a.w[1]);
+  if (act) {
+    fold(SV, ainv0, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { SV[r] = addb(SV[r], 0); save(a.sv, r, SV[r]); }
+    zero_invalid(SV);
+    put_max(SV);
+  }
+  __syncthreads();
+  if (act) put_planes(P2, ainv2, SV);
+  // ---- x_value = x_att . Wx + b  (layers.py:94)
+  step(P1, a.w[2]);
+  if (act) {
+    fold(XV, ainv1, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { XV[r] = addb(XV[r], 1); save(a.xv, r, XV[r]); }
+    zero_invalid(XV);
+    put_max(XV);
+  }
+  __syncthreads();
+  if (act) put_planes(P0, ainv0, XV);
+  // ---- cross gating (layers.py:96-103): o = sigmoid(s_value . Wsg + b) * x_value + sigmoid(x_value . Wxg + b) * s_value
+  step(P2, a.w[3]);
+  if (act) fold(T1, ainv2, true);
+  step(P0, a.w[4]);
+  if (act) {
+    fold(T2, ainv0, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4 sg = sig4(addb(T1[r], 2)), xg = sig4(addb(T2[r], 3));
+      save(a.sg, r, sg);
+      save(a.xg, r, xg);
+      T1[r] = cb_add(cb_mul(sg, XV[r]), cb_mul(xg, SV[r]));
+      save(a.o, r, T1[r]);
+    }
+    zero_invalid(T1);
+    put_max(T1);
+  }
+  __syncthreads();
+  if (act) put_planes(P1, ainv1, T1);
+  // ---- guided dense (layers.py:104)
+  step(P1, a.w[5]);
+  if (act) {
+    fold(T1, ainv1, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { T1[r] = addb(T1[r], 4); save(a.gd, r, T1[r]); }
+    zero_invalid(T1);
+    put_max(T1);
+  }
+  // RP1: the layer-normed input (ln1) -> slot 0 (free since the x_gate product)
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int lr = grp + 16 * u;
+    if (lr >= MT) continue;
+    const bool ok = r0 + lr < R;
+    const float i0 = cb_store_operand(P0, P0 + DP_PLANE, lr, l32, ok ? l1[u] : f4zero());
+    if (l32 == 0) ainv0[lr] = ok ? i0 : 0.f;
+  }
+  __syncthreads();
+  if (act) put_planes(P2, ainv2, T1);
+  // ---- bilinear gate and value (layers.py:48-56, 106-110): scores = ln1 . W11 + g . W12 + b1 ; values = ln1 . W21 + g . W22 + b2
+  step(P0, a.w[6]);
+  if (act) fold(T1, ainv0, true);
+  step(P2, a.w[7]);
+  if (act) fold(T1, ainv2, false);
+  step(P0, a.w[8]);
+  if (act) fold(T2, ainv0, true);
+  step(P2, a.w[9]);
+  if (act) {
+    fold(T2, ainv2, false);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float4 gate = addb(T1[r], 5);
+      gate = rm[r] != 0.f ? sig4(gate) : f4zero();             // sigmoid(mask_logits(scores, mask)) (layers.py:110)
+      const float4 val = addb(T2[r], 6);
+      save(a.gate, r, gate);
+      save(a.val, r, val);
+      T1[r] = cb_mul(gate, val);
+      save(a.mha, r, T1[r]);
+    }
+    zero_invalid(T1);
+    put_max(T1);
+  }
+  __syncthreads();
+  if (act) put_planes(P1, ainv1, T1);
+  // ---- dense_1 + dropout + residual (modules.py:82-83); the rows also go to LDS as fp32 for the layer norm
+  step(P1, a.w[10]);
+  if (act) {
+    fold(SV, ainv1, true);                                      // SV now holds `res`
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = 16 * mt + 4 * g + r;
+      float4 v = addb(SV[r], 7);
+      if (dr.enabled) v = apply_drop4_r(dr, (uint32_t)(a.site + 2), a.drop_row0 + (uint32_t)(r0 + lr), (uint32_t)(ecol >> 2), v);
+      v = cb_add(v, xin[r]);
+      SV[r] = v;
+      save(a.res, r, v);
+      scratch[lr * 32 + (ecol >> 2)] = v;
+    }
+  }
+  __syncthreads();
+  // ---- RP2: layer_norm_2 + dropout (modules.py:85-86) -> slot 2
+  {
+    const float4 g2 = bl[9 * 32 + l32], b2 = bl[10 * 32 + l32];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int lr = grp + 16 * u, row = r0 + lr;
+      if (lr >= MT) continue;
+      const bool ok = row < R;
+      float mean, rstd;
+      const float4 xh = ln_row(scratch[lr * 32 + l32], mean, rstd);
+      float4 y = cb_fma(xh, g2, b2);
+      if (dr.enabled) y = apply_drop4_r(dr, (uint32_t)(a.site + 3), a.drop_row0 + (uint32_t)row, (uint32_t)l32, y);
+      if (!ok) y = f4zero();
+      if (ok) {
+        st4(a.l2 + (size_t)row * HUAL_D + col, y);
+        if (l32 == 0) { a.mean2[row] = mean; a.rstd2[row] = rstd; }
+      }
+      const float i2 = cb_store_operand(P2, P2 + DP_PLANE, lr, l32, y);
+      if (l32 == 0) ainv2[lr] = ok ? i2 : 0.f;
+    }
+  }
+  // ---- dense_2 + dropout + residual (modules.py:87-88)
+  step(P2, nullptr);
+  if (act) {
+    fold(T1, ainv2, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = 16 * mt + 4 * g + r;
+      float4 v = addb(T1[r], 8);
+      if (dr.enabled) v = apply_drop4_r(dr, (uint32_t)(a.site + 4), a.drop_row0 + (uint32_t)(r0 + lr), (uint32_t)(ecol >> 2), v);
+      v = cb_add(v, SV[r]);
+      save(a.out, r, v);
+    }
+  }
+}
+
+namespace hual {
+
+static int tile_rows(int R, int max_rows) {
+  int t = cdiv(cdiv(R, 256), 16);
+  if (t < 1) t = 1;
+  if (16 * t > max_rows) t = max_rows / 16;
+  return 16 * t;
+}
+int ln_proj_rows(int R) { return tile_rows(R, LP_ROWS); }
+int da_post_rows(int R) { return tile_rows(R, DP_ROWS); }
+
+int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s) {
+  HUAL_REQUIRE(a.x && a.g1 && a.b1 && a.y1 && a.mean && a.rstd && a.R > 0, "ln_proj: null / empty");
+  HUAL_REQUIRE(a.MT >= 16 && a.MT <= LP_ROWS && (a.MT % 16) == 0, "ln_proj: MT must be 16, 32, 48 or 64");
+  HUAL_REQUIRE(a.nproj >= 1 && a.nproj <= HUAL_LNPROJ_MAX, "ln_proj: projection count");
+  HUAL_REQUIRE(!a.g2 || (a.b2 && a.y2), "ln_proj: second layer norm incomplete");
+  for (int p = 0; p < a.nproj; ++p) {
+    HUAL_REQUIRE(a.wimg[p] && a.out[p] && (a.ldo[p] % 4) == 0, "ln_proj: projection operand");
+    HUAL_REQUIRE(a.src[p] == 0 || a.g2, "ln_proj: projection reads the absent second layer norm");
+  }
+  HUAL_DYN_LDS(ln_proj_kernel, 160 * 1024);
+  const size_t lds = (size_t)4 * LP_ROWS * 256 + CB_WBYTES + 2 * LP_ROWS * sizeof(float);
+  const double rows = (double)a.R;
+  HUAL_LAUNCH(2.0 * rows * HUAL_D * HUAL_D * a.nproj, 4.0 * (rows * HUAL_D * (2.0 + (a.g2 ? 1.0 : 0.0) + a.nproj) + (double)a.nproj * HUAL_D * HUAL_D),
+              ln_proj_kernel, dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), lds, s, a, drop);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s) {
+  HUAL_REQUIRE(a.s_att && a.x_att && a.ln1 && a.x && a.rowmask && a.ln2_g && a.ln2_b && a.R > 0, "da_post: null / empty");
+  HUAL_REQUIRE(a.MT >= 16 && a.MT <= DP_ROWS && (a.MT % 16) == 0, "da_post: MT must be 16, 32 or 48");
+  for (int k = 0; k < 11; ++k) HUAL_REQUIRE(a.w[k] != nullptr, "da_post: null weight image");
+  for (int k = 0; k < 9; ++k) HUAL_REQUIRE(a.b[k] != nullptr, "da_post: null bias");
+  HUAL_REQUIRE(a.sv && a.xv && a.sg && a.xg && a.o && a.gd && a.gate && a.val && a.mha && a.res && a.l2 && a.out && a.mean2 && a.rstd2,
+               "da_post: null output");
+  HUAL_DYN_LDS(da_post_kernel, 160 * 1024);
+  const size_t lds = (size_t)3 * DP_SLOT + CB_WBYTES + DP_NB * 512 + (3 * DP_ROWS + 2 * DP_ROWS) * sizeof(float);
+  const double rows = (double)a.R;
+  HUAL_LAUNCH(11.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 16.0 + 11.0 * HUAL_D * HUAL_D), da_post_kernel,
+              dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), lds, s, a, drop);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace hual

@@ -7,6 +7,7 @@
 #include "prof.h"
 #include "cq.h"
 #include "convblock.h"
+#include "dablock.h"
 #include "embed.h"
 #include "gemm.h"
 #include "heads.h"
@@ -74,6 +75,8 @@ struct Ctx {
   bool use_bf16 = true;
   //   HUAL_FUSE_CB=0    conv_block as 4 x (ln_dwconv_fwd + dense) launches instead of the fused kernels (convblock.h)
   bool fuse_cb = true;
+  //   HUAL_FUSE_DA=0    dual attention block as ln / dense / chained launches instead of the fused row-local kernels (dablock.h)
+  bool fuse_da = true;
   struct DenseW { size_t off; int K; size_t boff; };
   std::vector<DenseW> dense;          // every [K,128] weight of the graph, sorted by offset
   char* PKF = nullptr;                // pre-split images (gemm.h launch_pack_weights): forward ...
@@ -344,6 +347,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
   { const char* e = getenv("HUAL_FUSE_ROW"); c.fuse_row = !c.fuse_bwd && !(e && atoi(e) == 0); }
   { const char* e = getenv("HUAL_GEMM_BF16"); c.use_bf16 = !(e && atoi(e) == 0); }
   { const char* e = getenv("HUAL_CHAIN"); c.use_chain = !(e && atoi(e) == 0); }
+  { const char* e = getenv("HUAL_FUSE_DA"); c.fuse_da = c.use_bf16 && !c.fuse_ln && !(e && atoi(e) == 0); }
   { const char* e = getenv("HUAL_FUSE_CB"); c.fuse_cb = c.use_bf16 && !c.fuse_ln && !c.fuse_bwd && c.fuse_row && !(e && atoi(e) == 0); }
   {
     const ParamMap& pm = c.pm;
@@ -597,7 +601,19 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* rstd = c.vec(t + ".rstd");
     float* qkv = c.buf(t + ".qkv", R, 3 * D);
     float* ktvt = c.buf(t + ".ktvt", R, 2 * D);
-    {
+    auto img = [&](size_t off) { return reinterpret_cast<const float*>(c.PKF + off * 4); };
+    if (c.fuse_da) {       // layer norms + the five projections in one launch (dablock.h)
+      LnProjArgs lp{};
+      lp.x = x; lp.g1 = c.p(d.ln1.g); lp.b1 = c.p(d.ln1.b); lp.y1 = ln1; lp.drop_site1 = -1;
+      lp.g2 = c.p(d.lnt.g); lp.b2 = c.p(d.lnt.b); lp.y2 = lnt; lp.mean = mean; lp.rstd = rstd;
+      lp.nproj = 5; lp.R = R; lp.MT = ln_proj_rows(R); lp.drop_row0 = 0;
+      const DenseP* pr[5] = {&d.query, &d.f_key, &d.f_value, &d.t_key, &d.t_value};
+      float* outs[5] = {qkv, qkv + D, qkv + 2 * D, ktvt, ktvt + D};
+      for (int k = 0; k < 5; ++k) {
+        lp.wimg[k] = img(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = outs[k]; lp.ldo[k] = k < 3 ? 3 * D : 2 * D; lp.src[k] = k < 3 ? 0 : 1;
+      }
+      if (!c.dry && c.ok()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
+    } else {
       GemmJob j[5];
       // both layer norms of x (layers.py:73-74) run in the projections' A prologue; job 0 / 3 keep ln1 / lnt + statistics
       j[0] = mkjob(x, D, R, D, c.p(d.query.k), c.p(d.query.b), qkv, 3 * D);
@@ -650,6 +666,24 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* val = c.act(t + ".val");
     float* mha = c.act(t + ".mha");
     float* res = c.act(t + ".res");
+    float* l2 = c.act(t + ".l2");
+    float* mean2 = c.vec(t + ".mean2");
+    float* rstd2 = c.vec(t + ".rstd2");
+    float* xo = c.act(t + ".out");
+    if (c.fuse_da) {       // the whole chain behind the attention kernels in one launch (dablock.h)
+      DaPostArgs pa{};
+      pa.s_att = s_att; pa.x_att = x_att; pa.ln1 = ln1; pa.x = x; pa.rowmask = rowmask;
+      const size_t wo[11] = {d.s_dense.k, d.x_dense.k, d.s_gate.k, d.x_gate.k, d.guided.k, d.bl1_d1, d.bl1_d2, d.bl2_d1, d.bl2_d2,
+                             d.dense1.k, d.dense2.k};
+      const size_t bo[9] = {d.s_dense.b, d.x_dense.b, d.s_gate.b, d.x_gate.b, d.guided.b, d.bl1_b, d.bl2_b, d.dense1.b, d.dense2.b};
+      for (int k = 0; k < 11; ++k) pa.w[k] = img(wo[k]);
+      for (int k = 0; k < 9; ++k) pa.b[k] = c.p(bo[k]);
+      pa.ln2_g = c.p(d.ln2.g); pa.ln2_b = c.p(d.ln2.b);
+      pa.sv = sv; pa.xv = xv; pa.sg = sg; pa.xg = xg; pa.o = o; pa.gd = gd; pa.gate = gate; pa.val = val; pa.mha = mha; pa.res = res;
+      pa.l2 = l2; pa.out = xo; pa.mean2 = mean2; pa.rstd2 = rstd2;
+      pa.site = site; pa.R = R; pa.MT = da_post_rows(R); pa.drop_row0 = 0;
+      if (!c.dry && c.ok()) c.chk(launch_da_post(pa, c.drop, c.stream));
+    } else {
     {
       GemmJob j[6];
       j[0] = mkjob(s_att, D, R, D, c.p(d.s_dense.k), c.p(d.s_dense.b), sv, D);
@@ -673,15 +707,12 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       const int gsz[5] = {2, 1, 1, 1, 1};
       c.gemm_chain(j, gsz, 5);
     }
-    float* l2 = c.act(t + ".l2");
-    float* mean2 = c.vec(t + ".mean2");
-    float* rstd2 = c.vec(t + ".rstd2");
-    float* xo = c.act(t + ".out");
     {
       GemmJob j = mkjob(res, D, R, D, c.p(d.dense2.k), c.p(d.dense2.b), xo, D);
       ln_into_jobs(c, &j, 1, res, R, rs, c.p(d.ln2.g), c.p(d.ln2.b), mean2, rstd2, l2, site + 3);
       j.drop_site = site + 4; j.add = res; j.ldadd = D;
       c.gemm(&j, 1);
+    }
     }
     x = xo;
   }

@@ -72,3 +72,22 @@ def test_fused_conv_block_backward(shape, drop, monkeypatch):
         scale = float(np.abs(d0[k]).max())
         # (+ 1e-6 absolute: gradients that are zero in exact arithmetic - the key biases under the softmax - are rounding noise)
         assert float(np.abs(d1[k] - d0[k]).max()) <= 2e-5 * scale + 1e-6, (k, float(np.abs(d1[k] - d0[k]).max()), scale)
+
+
+DA_FWD_TAPS = ['da%d.%s' % (li, n) for li in range(2) for n in ('ln1', 'lnt', 'mean', 'rstd', 'qkv', 'ktvt', 's_att', 'x_att', 's', 'x', 'sg',
+                                                                'xg', 'o', 'g', 'gate', 'val', 'mha', 'res', 'l2', 'mean2', 'rstd2', 'out')]
+
+
+@pytest.mark.parametrize('shape', [dict(B=3, T=37, L=9, C=4, seed=11, max_vlen=40), dict(B=1, T=5, L=3, C=4, seed=2, max_vlen=8),
+                                   dict(B=8, T=64, L=20, C=8, seed=9, max_vlen=64), dict(B=64, T=128, L=20, C=8, seed=12345, max_vlen=128)])
+@pytest.mark.parametrize('drop', [0.0, 0.2])
+def test_fused_dual_attention_forward_bit_exact(shape, drop, monkeypatch):
+    """ln_proj_kernel + da_post_kernel against ln_fwd / dense / chained launches: every saved tensor of both layers and the
+    model outputs, bit for bit (B=64 T=128: three-tile workgroups, the bench shape)"""
+    case = pu.make_case(**shape)
+    t1, r1, _ = _run(case, drop, {'HUAL_FUSE_DA': '1'}, monkeypatch, DA_FWD_TAPS)
+    t0, r0, _ = _run(case, drop, {'HUAL_FUSE_DA': '0'}, monkeypatch, DA_FWD_TAPS)
+    for n in DA_FWD_TAPS:
+        assert torch.equal(t1[n], t0[n]), (n, float((t1[n] - t0[n]).abs().max()))
+    for k in r1:
+        assert torch.equal(r1[k], r0[k]), k
