@@ -15,6 +15,8 @@ namespace hual {
 #define HUAL_LNPROJ_MAX 5
 struct LnProjArgs {
   const float* x;                                  // [R,128]
+  const float* xa; int pre_site; float* x_out;     // optional: x := dropout(xa, pre_site) + x, written to x_out (modules.py:132)
+  const float* x2;                                 // optional raw second operand [R,128] (exclusive with g2): src = 1 reads it
   const float* g1; const float* b1; float* y1;     // y1 = dropout(LN(x; g1, b1), drop_site1)   [R,128]
   int drop_site1;                                  // < 0: no dropout
   const float* g2; const float* b2; float* y2;     // optional second layer norm of the same rows (null: absent)
@@ -23,7 +25,11 @@ struct LnProjArgs {
   const float* wimg[HUAL_LNPROJ_MAX];              // forward weight images
   const float* bias[HUAL_LNPROJ_MAX];              // [128]
   float* out[HUAL_LNPROJ_MAX]; int ldo[HUAL_LNPROJ_MAX];
-  int src[HUAL_LNPROJ_MAX];                        // 0: reads y1, 1: reads y2
+  int src[HUAL_LNPROJ_MAX];                        // 0: reads y1, 1: reads y2 (or x2)
+  int accum[HUAL_LNPROJ_MAX];                      // 1: no epilogue, the product is added to the next projection's (K-concatenation)
+  int act[HUAL_LNPROJ_MAX];                        // 1: relu
+  int out_site[HUAL_LNPROJ_MAX];                   // >= 0: dropout on the output
+  int add_x[HUAL_LNPROJ_MAX];                      // 1: + the layer-norm input rows (residual; needs g2 == x2 == null)
   int R; int MT;                                   // rows, rows per workgroup (16, 32, 48 or 64)
   uint32_t drop_row0;
 };

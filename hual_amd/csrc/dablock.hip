@@ -46,21 +46,36 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropC
 
   cb_dma_weight(a.wimg[0], Wl, wave, lane, CB_THREADS / 64);
   // every operand of the kernel is requested up front: rows (unconditional loads on clamped rows), layer-norm parameters, biases
-  float4 xv[4], bias[HUAL_LNPROJ_MAX];
+  float4 xv[4], av[4], rv[4], bias[HUAL_LNPROJ_MAX];
+  const float* xap = a.xa ? a.xa : a.x;
+  const float* x2p = a.x2 ? a.x2 : a.x;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) xv[u] = ld4(a.x + (size_t)min(r0 + grp + 16 * u, R - 1) * HUAL_D + col);
+  for (int u = 0; u < 4; ++u) {
+    const size_t off = (size_t)min(r0 + grp + 16 * u, R - 1) * HUAL_D + col;
+    xv[u] = ld4(a.x + off);
+    av[u] = ld4(xap + off);
+    rv[u] = ld4(x2p + off);
+  }
   const float4 g1 = ld4(a.g1 + col), b1 = ld4(a.b1 + col);
   const float4 g2 = a.g2 ? ld4(a.g2 + col) : f4zero(), b2 = a.g2 ? ld4(a.b2 + col) : f4zero();
 #pragma unroll
   for (int p = 0; p < HUAL_LNPROJ_MAX; ++p) bias[p] = (p < a.nproj && a.bias[p]) ? ld4(a.bias[p] + ecol) : f4zero();
-  // ---- layer norm(s) -> operand planes
+  float4* scratch = reinterpret_cast<float4*>(P2);           // fp32 rows [64][32] float4 of the layer-norm input (residual)
+  // ---- (residual) + layer norm(s) -> operand planes
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int lr = grp + 16 * u, row = r0 + lr;
     if (lr >= MT) continue;
     const bool ok = row < R;
+    float4 xr = xv[u];
+    if (a.xa) {
+      float4 t = av[u];
+      if (a.pre_site >= 0 && dr.enabled) t = apply_drop4_r(dr, (uint32_t)a.pre_site, a.drop_row0 + (uint32_t)row, (uint32_t)l32, t);
+      xr = cb_add(t, xr);
+      if (ok) st4(a.x_out + (size_t)row * HUAL_D + col, xr);
+    }
     float mean, rstd;
-    const float4 xh = ln_row(xv[u], mean, rstd);
+    const float4 xh = ln_row(xr, mean, rstd);
     float4 y1 = cb_fma(xh, g1, b1);
     if (a.drop_site1 >= 0 && dr.enabled) y1 = apply_drop4_r(dr, (uint32_t)a.drop_site1, a.drop_row0 + (uint32_t)row, (uint32_t)l32, y1);
     if (!ok) y1 = f4zero();
@@ -70,14 +85,18 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropC
     }
     const float i1 = cb_store_operand(P1, P1 + LP_ROWS * 256, lr, l32, y1);
     if (l32 == 0) ainv1[lr] = ok ? i1 : 0.f;
-    if (a.g2) {
-      const float4 y2 = ok ? cb_fma(xh, g2, b2) : f4zero();
-      if (ok) st4(a.y2 + (size_t)row * HUAL_D + col, y2);
+    if (a.g2 || a.x2) {
+      const float4 y2 = !ok ? f4zero() : (a.g2 ? cb_fma(xh, g2, b2) : rv[u]);
+      if (ok && a.g2) st4(a.y2 + (size_t)row * HUAL_D + col, y2);
       const float i2 = cb_store_operand(P2, P2 + LP_ROWS * 256, lr, l32, y2);
       if (l32 == 0) ainv2[lr] = ok ? i2 : 0.f;
+    } else {
+      scratch[lr * 32 + l32] = xr;
     }
   }
   // ---- the projections, one weight image at a time
+  float4 acc[4];
+  bool fresh = true;
 #pragma unroll
   for (int p = 0; p < HUAL_LNPROJ_MAX; ++p) {
     if (p >= a.nproj) break;                                 // uniform
@@ -85,20 +104,29 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropC
     __syncthreads();
     const char* P = a.src[p] ? P2 : P1;
     const float* ai = a.src[p] ? ainv2 : ainv1;
-    f32x4 acc[4];
-    if (mt < ntile) cb_tile_mma(P, P + LP_ROWS * 256, Wl, mt, ch, lane, acc);
+    f32x4 accp[4];
+    if (mt < ntile) cb_tile_mma(P, P + LP_ROWS * 256, Wl, mt, ch, lane, accp);
     __syncthreads();                                         // image consumed
     if (p + 1 < a.nproj) cb_dma_weight(a.wimg[p + 1], Wl, wave, lane, CB_THREADS / 64);
     if (mt < ntile) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int lr = 16 * mt + 4 * g + r, row = r0 + lr;
-        if (row >= R) continue;
-        const float ir = ai[lr];
-        const float4 v = make_float4(fmaf(acc[0][r], ir, 0.f) + bias[p].x, fmaf(acc[1][r], ir, 0.f) + bias[p].y,
-                                     fmaf(acc[2][r], ir, 0.f) + bias[p].z, fmaf(acc[3][r], ir, 0.f) + bias[p].w);
-        st4(a.out[p] + (size_t)row * a.ldo[p] + ecol, v);
+        const float ir = ai[16 * mt + 4 * g + r];
+        if (fresh) acc[r] = make_float4(fmaf(accp[0][r], ir, 0.f), fmaf(accp[1][r], ir, 0.f), fmaf(accp[2][r], ir, 0.f), fmaf(accp[3][r], ir, 0.f));
+        else acc[r] = make_float4(fmaf(accp[0][r], ir, acc[r].x), fmaf(accp[1][r], ir, acc[r].y), fmaf(accp[2][r], ir, acc[r].z), fmaf(accp[3][r], ir, acc[r].w));
       }
+    }
+    fresh = a.accum[p] == 0;
+    if (a.accum[p] || mt >= ntile) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = 16 * mt + 4 * g + r, row = r0 + lr;
+      if (row >= R) continue;
+      float4 v = make_float4(acc[r].x + bias[p].x, acc[r].y + bias[p].y, acc[r].z + bias[p].z, acc[r].w + bias[p].w);
+      if (a.act[p]) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (a.out_site[p] >= 0 && dr.enabled) v = apply_drop4_r(dr, (uint32_t)a.out_site[p], a.drop_row0 + (uint32_t)row, (uint32_t)(ecol >> 2), v);
+      if (a.add_x[p]) v = cb_add(v, scratch[lr * 32 + (ecol >> 2)]);
+      st4(a.out[p] + (size_t)row * a.ldo[p] + ecol, v);
     }
   }
 }
@@ -373,9 +401,13 @@ int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.MT >= 16 && a.MT <= LP_ROWS && (a.MT % 16) == 0, "ln_proj: MT must be 16, 32, 48 or 64");
   HUAL_REQUIRE(a.nproj >= 1 && a.nproj <= HUAL_LNPROJ_MAX, "ln_proj: projection count");
   HUAL_REQUIRE(!a.g2 || (a.b2 && a.y2), "ln_proj: second layer norm incomplete");
+  HUAL_REQUIRE(!(a.g2 && a.x2), "ln_proj: second layer norm and raw second operand are exclusive");
+  HUAL_REQUIRE(!a.xa || a.x_out, "ln_proj: xa needs x_out");
   for (int p = 0; p < a.nproj; ++p) {
-    HUAL_REQUIRE(a.wimg[p] && a.out[p] && (a.ldo[p] % 4) == 0, "ln_proj: projection operand");
-    HUAL_REQUIRE(a.src[p] == 0 || a.g2, "ln_proj: projection reads the absent second layer norm");
+    HUAL_REQUIRE(a.wimg[p] && (a.accum[p] || (a.out[p] && (a.ldo[p] % 4) == 0)), "ln_proj: projection operand");
+    HUAL_REQUIRE(a.src[p] == 0 || a.g2 || a.x2, "ln_proj: projection reads an absent second operand");
+    HUAL_REQUIRE(!a.add_x[p] || !(a.g2 || a.x2), "ln_proj: the residual rows share LDS with the second operand");
+    HUAL_REQUIRE(!a.accum[p] || p + 1 < a.nproj, "ln_proj: the last projection cannot be marked accum");
   }
   HUAL_DYN_LDS(ln_proj_kernel, 160 * 1024);
   const size_t lds = (size_t)4 * LP_ROWS * 256 + CB_WBYTES + 2 * LP_ROWS * sizeof(float);

@@ -604,13 +604,14 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     auto img = [&](size_t off) { return reinterpret_cast<const float*>(c.PKF + off * 4); };
     if (c.fuse_da) {       // layer norms + the five projections in one launch (dablock.h)
       LnProjArgs lp{};
-      lp.x = x; lp.g1 = c.p(d.ln1.g); lp.b1 = c.p(d.ln1.b); lp.y1 = ln1; lp.drop_site1 = -1;
+      lp.x = x; lp.g1 = c.p(d.ln1.g); lp.b1 = c.p(d.ln1.b); lp.y1 = ln1; lp.drop_site1 = -1; lp.pre_site = -1;
       lp.g2 = c.p(d.lnt.g); lp.b2 = c.p(d.lnt.b); lp.y2 = lnt; lp.mean = mean; lp.rstd = rstd;
       lp.nproj = 5; lp.R = R; lp.MT = ln_proj_rows(R); lp.drop_row0 = 0;
       const DenseP* pr[5] = {&d.query, &d.f_key, &d.f_value, &d.t_key, &d.t_value};
       float* outs[5] = {qkv, qkv + D, qkv + 2 * D, ktvt, ktvt + D};
       for (int k = 0; k < 5; ++k) {
         lp.wimg[k] = img(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = outs[k]; lp.ldo[k] = k < 3 ? 3 * D : 2 * D; lp.src[k] = k < 3 ? 0 : 1;
+        lp.out_site[k] = -1;
       }
       if (!c.dry && c.ok()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
     } else {
@@ -805,7 +806,17 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* mean = c.buf(t + ".ln1.mean", Nv, 1);
     float* rstd = c.buf(t + ".ln1.rstd", Nv, 1);
     float* qkv = c.buf(t + ".qkv", Nv, 3 * D);
-    {
+    auto img = [&](size_t off) { return reinterpret_cast<const float*>(c.PKF + off * 4); };
+    if (c.fuse_da) {       // layer_norm_1 + dropout + query / key / value in one launch (dablock.h)
+      LnProjArgs lp{};
+      lp.x = f; lp.g1 = c.p(pm.fe_ln1.g); lp.b1 = c.p(pm.fe_ln1.b); lp.y1 = a1; lp.drop_site1 = site + 4; lp.pre_site = -1;
+      lp.mean = mean; lp.rstd = rstd; lp.nproj = 3; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
+      const DenseP* pr[3] = {&pm.fe_q, &pm.fe_k, &pm.fe_v};
+      for (int k = 0; k < 3; ++k) {
+        lp.wimg[k] = img(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = qkv + k * D; lp.ldo[k] = 3 * D; lp.out_site[k] = -1;
+      }
+      if (!c.dry && c.ok()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
+    } else {
       GemmJob j[3];
       j[0] = mkjob(f, D, Nv, D, c.p(pm.fe_q.k), c.p(pm.fe_q.b), qkv, 3 * D);
       j[1] = mkjob(f, D, Nv, D, c.p(pm.fe_k.k), c.p(pm.fe_k.b), qkv + D, 3 * D);
@@ -824,16 +835,23 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       c.attn_fwd(&a, 1);
     }
     float* res = c.actv(t + ".res");
-    {
-      EwArgs e{};
-      e.op = EW_DROP_ADD; e.R = Nv; e.a = att; e.b = f; e.out = res; e.drop_site = site + 6; e.drop_row0 = 0;
-      c.ew(e);
-    }
     float* l2 = c.actv(t + ".l2");
     float* mean2 = c.buf(t + ".ln2.mean", Nv, 1);
     float* rstd2 = c.buf(t + ".ln2.rstd", Nv, 1);
     float* fo = c.actv(t + ".out");
-    {
+    if (c.fuse_da) {       // residual + layer_norm_2 + dropout + dense + dropout + residual in one launch (modules.py:132-139)
+      LnProjArgs lp{};
+      lp.x = f; lp.xa = att; lp.pre_site = site + 6; lp.x_out = res;
+      lp.g1 = c.p(pm.fe_ln2.g); lp.b1 = c.p(pm.fe_ln2.b); lp.y1 = l2; lp.drop_site1 = site + 7; lp.mean = mean2; lp.rstd = rstd2;
+      lp.nproj = 1; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
+      lp.wimg[0] = img(pm.fe_dense.k); lp.bias[0] = c.p(pm.fe_dense.b); lp.out[0] = fo; lp.ldo[0] = D; lp.out_site[0] = site + 8; lp.add_x[0] = 1;
+      if (!c.dry && c.ok()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
+    } else {
+      {
+        EwArgs e{};
+        e.op = EW_DROP_ADD; e.R = Nv; e.a = att; e.b = f; e.out = res; e.drop_site = site + 6; e.drop_row0 = 0;
+        c.ew(e);
+      }
       GemmJob j = mkjob(res, D, Nv, D, c.p(pm.fe_dense.k), c.p(pm.fe_dense.b), fo, D);
       ln_into_jobs(c, &j, 1, res, Nv, c.rsv, c.p(pm.fe_ln2.g), c.p(pm.fe_ln2.b), mean2, rstd2, l2, site + 7);
       j.drop_site = site + 8; j.add = res; j.ldadd = D;
@@ -848,7 +866,20 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* hrstd = c.buf("head.rstd", (size_t)2 * Nv, 1);
   float* hs = c.actv("head.hs");
   float* he = c.actv("head.he");
-  {
+  if (c.fuse_da) {         // start / end layer norm + hidden layer ([LN(feats), outputs] . W + b, relu) (modules.py:152-157)
+    for (int h = 0; h < 2; ++h) {
+      const DenseP& hp = h == 0 ? pm.shid : pm.ehid;
+      const LnP& lnp = h == 0 ? pm.sln : pm.eln;
+      LnProjArgs lp{};
+      lp.x = feo[h]; lp.g1 = c.p(lnp.g); lp.b1 = c.p(lnp.b); lp.y1 = h == 0 ? sfn : efn; lp.drop_site1 = -1; lp.pre_site = -1;
+      lp.mean = hmean + (size_t)h * Nv; lp.rstd = hrstd + (size_t)h * Nv; lp.x2 = outputs;
+      lp.nproj = 2; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
+      lp.wimg[0] = reinterpret_cast<const float*>(c.PKF + hp.k * 4); lp.src[0] = 0; lp.accum[0] = 1; lp.out_site[0] = -1;
+      lp.wimg[1] = reinterpret_cast<const float*>(c.PKF + (hp.k + (size_t)D * D) * 4); lp.src[1] = 1; lp.bias[1] = c.p(hp.b);
+      lp.act[1] = 1; lp.out[1] = h == 0 ? hs : he; lp.ldo[1] = D; lp.out_site[1] = -1;
+      if (!c.dry && c.ok()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
+    }
+  } else {
     GemmJob j[2];
     // start / end layer norms (modules.py:152-153) in the A prologue
     j[0] = mkjob(feo[0], D, Nv, D, c.p(pm.shid.k), c.p(pm.shid.b), hs, D);

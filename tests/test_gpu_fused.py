@@ -75,15 +75,17 @@ def test_fused_conv_block_backward(shape, drop, monkeypatch):
 
 
 DA_FWD_TAPS = ['da%d.%s' % (li, n) for li in range(2) for n in ('ln1', 'lnt', 'mean', 'rstd', 'qkv', 'ktvt', 's_att', 'x_att', 's', 'x', 'sg',
-                                                                'xg', 'o', 'g', 'gate', 'val', 'mha', 'res', 'l2', 'mean2', 'rstd2', 'out')]
+                                                                'xg', 'o', 'g', 'gate', 'val', 'mha', 'res', 'l2', 'mean2', 'rstd2', 'out')] + \
+              ['fe%d.%s' % (ps, n) for ps in range(2) for n in ('a', 'ln1.mean', 'ln1.rstd', 'qkv', 'att', 'res', 'l2', 'ln2.mean', 'ln2.rstd', 'out')] + \
+              ['head.sfn', 'head.efn', 'head.mean', 'head.rstd', 'head.hs', 'head.he']
 
 
 @pytest.mark.parametrize('shape', [dict(B=3, T=37, L=9, C=4, seed=11, max_vlen=40), dict(B=1, T=5, L=3, C=4, seed=2, max_vlen=8),
                                    dict(B=8, T=64, L=20, C=8, seed=9, max_vlen=64), dict(B=64, T=128, L=20, C=8, seed=12345, max_vlen=128)])
 @pytest.mark.parametrize('drop', [0.0, 0.2])
 def test_fused_dual_attention_forward_bit_exact(shape, drop, monkeypatch):
-    """ln_proj_kernel + da_post_kernel against ln_fwd / dense / chained launches: every saved tensor of both layers and the
-    model outputs, bit for bit (B=64 T=128: three-tile workgroups, the bench shape)"""
+    """ln_proj_kernel + da_post_kernel against ln_fwd / dense / chained launches (dual attention layers, the predictor's
+    feature encoders and hidden layers): every saved tensor and the model outputs, bit for bit (B=64 T=128: the bench shape)"""
     case = pu.make_case(**shape)
     t1, r1, _ = _run(case, drop, {'HUAL_FUSE_DA': '1'}, monkeypatch, DA_FWD_TAPS)
     t0, r0, _ = _run(case, drop, {'HUAL_FUSE_DA': '0'}, monkeypatch, DA_FWD_TAPS)
