@@ -52,3 +52,44 @@ int da_post_rows(int R);
 int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s);
 
 }  // namespace hual
+
+namespace hual {
+
+// dX products into a layer norm's output gradient(s), then the layer norm(s) backward, in one launch:
+//   dy_o = sum_{k: dst[k] = o} f(A[k]) . W[k]^T (+ add_dy1 for o = 0);  dx = LNbwd(x; dropout'(dy_0), g1) (+ LNbwd(x; dy_1, g2)) + add1
+// covers layer_norm_1 / layer_norm_t behind the five projections (6 products), layer_norm_2 behind dense_2 (1 product) and the
+// predictor encoder's two layer norms (3 products / 1 product).  Same arithmetic as gemm_bf16_kernel + ln_bwd_kernel.
+#define HUAL_LNBWD_MAX 6
+struct LnProjBwdArgs {
+  int nsteps;
+  const float* A[HUAL_LNBWD_MAX]; int lda[HUAL_LNBWD_MAX];     // gradient operands: rows of 128 floats with row stride lda
+  int a_site[HUAL_LNBWD_MAX];                                  // >= 0: the operand is dropout'(A, site) ...
+  float* a_save[HUAL_LNBWD_MAX];                               // ... and (optional) is stored here [R,128] for the weight-gradient job
+  const float* wimg_t[HUAL_LNBWD_MAX];                         // images of the transposed weights
+  int dst[HUAL_LNBWD_MAX];                                     // 0 / 1: which layer norm's output gradient the product belongs to
+  const float* add_dy1;                                        // optional [R,128] added to dy_0
+  int dy1_site;                                                // >= 0: the first layer norm's output went through dropout
+  const float* x; const float* mean; const float* rstd;        // layer-norm input and statistics
+  const float* g1; const float* g2;                            // g2 null: one layer norm
+  const float* add1;                                           // optional gradient arriving through the residual path
+  float* dx;
+  float* dz; int dz_site; const float* dz_relu;                // optional: dz = dropout'(dx, dz_site) * (dz_relu > 0)
+  float* part;                                                 // [grid][4][128] partial sums: dgamma1, dbeta1, dgamma2, dbeta2
+  int R; int MT; uint32_t drop_row0;
+};
+int ln_proj_bwd_rows(int R);
+int ln_proj_bwd_blocks(int R);
+int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t s);
+
+// backward of the gated middle of dual_multihead_attention (layers.py:93-110): from dZ1 = dropout'(d res) down to the
+// gradients of the two attention outputs; every intermediate gradient that a weight-gradient job needs is written once.
+struct DaMidBwdArgs {
+  const float* dz1;                                            // [R,128]
+  const float *gate, *val, *sg, *xg, *sv, *xv;                 // saved by the forward chain
+  const float* w[10];     // transposed images: dense_1, bl1.dense_1, bl2.dense_1, bl1.dense_2, bl2.dense_2, guided, s_gate, x_gate, s_dense, x_dense
+  float *d_sc, *d_val, *d_ln1a, *d_g, *dz_sg, *dz_xg, *d_sv, *d_xv, *d_satt, *d_xatt;
+  int R; int MT;
+};
+int launch_da_mid_bwd(const DaMidBwdArgs& a, hipStream_t s);
+
+}  // namespace hual

@@ -385,6 +385,368 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// dX products -> layer norm(s) backward (LnProjBwdArgs).  Two operand slots are filled alternately from HBM rows (the
+// rows of product k+1 are requested before product k's wait and written behind its matrix phase); the two output tiles
+// stay in registers until the last product, then go to LDS as fp32 rows for the row phase.
+#define LB_ROWS 64
+__global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char lb_lds[];
+  char* S0 = lb_lds;                                   // operand slot 0: hi | lo planes [64][256 B]; later dy_0 as fp32 rows
+  char* S1 = S0 + 2 * LB_ROWS * 256;                   // operand slot 1; later dy_1
+  char* Wl = S1 + 2 * LB_ROWS * 256;                   // weight image; later the per-wave parameter sums
+  float* ainv0 = reinterpret_cast<float*>(Wl + CB_WBYTES);
+  float* ainv1 = ainv0 + LB_ROWS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int col = 4 * l32;
+  const int MT = a.MT, ntile = MT >> 4, R = a.R;
+  const int r0 = blockIdx.x * MT;
+  const int mt = wave >> 1, ch = wave & 1;
+  const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
+  const bool act = mt < ntile;
+  const DropRegs dr = drop_load(drop);
+
+  cb_dma_weight(a.wimg_t[0], Wl, wave, lane, CB_THREADS / 64);
+  // operand rows of product 0 and everything the row phase needs (unconditional loads on clamped rows)
+  float4 nv[4], xv[4], a1v[4];
+  float mu[4], rsd[4];
+  const float* add1p = a.add1 ? a.add1 : a.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int row = min(r0 + grp + 16 * u, R - 1);
+    nv[u] = ld4(a.A[0] + (size_t)row * a.lda[0] + col);
+    xv[u] = ld4(a.x + (size_t)row * HUAL_D + col);
+    a1v[u] = ld4(add1p + (size_t)row * HUAL_D + col);
+    mu[u] = a.mean[row];
+    rsd[u] = a.rstd[row];
+  }
+  const float4 g1 = ld4(a.g1 + col);
+  const float4 g2 = a.g2 ? ld4(a.g2 + col) : f4zero();
+  float4 addt[4];                                      // add_dy1 in the epilogue layout
+  const float* addp = a.add_dy1 ? a.add_dy1 : a.x;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) addt[r] = ld4(addp + (size_t)min(r0 + 16 * mt + 4 * g + r, R - 1) * HUAL_D + ecol);
+  // rows -> operand planes of slot `k & 1` (with the operand's dropout', saved for the weight-gradient job)
+  auto fill = [&](int k) {
+    char* S = (k & 1) ? S1 : S0;
+    float* ai = (k & 1) ? ainv1 : ainv0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int lr = grp + 16 * u, row = r0 + lr;
+      if (lr >= MT) continue;
+      const bool ok = row < R;
+      float4 v = ok ? nv[u] : f4zero();
+      if (a.a_site[k] >= 0) {
+        if (dr.enabled) v = apply_drop4_r(dr, (uint32_t)a.a_site[k], a.drop_row0 + (uint32_t)row, (uint32_t)l32, v);
+        if (ok && a.a_save[k]) st4(a.a_save[k] + (size_t)row * HUAL_D + col, v);
+      }
+      const float inv = cb_store_operand(S, S + LB_ROWS * 256, lr, l32, v);
+      if (l32 == 0) ai[lr] = ok ? inv : 0.f;
+    }
+  };
+  fill(0);
+  float4 acc0[4], acc1[4];
+  bool first0 = true, first1 = true;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc0[r] = f4zero(); acc1[r] = f4zero(); }
+#pragma unroll 1
+  for (int k = 0; k < a.nsteps; ++k) {
+    if (k + 1 < a.nsteps) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) nv[u] = ld4(a.A[k + 1] + (size_t)min(r0 + grp + 16 * u, R - 1) * a.lda[k + 1] + col);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* S = (k & 1) ? S1 : S0;
+    const float* ai = (k & 1) ? ainv1 : ainv0;
+    f32x4 accp[4];
+    if (act) cb_tile_mma(S, S + LB_ROWS * 256, Wl, mt, ch, lane, accp);
+    __syncthreads();
+    if (k + 1 < a.nsteps) cb_dma_weight(a.wimg_t[k + 1], Wl, wave, lane, CB_THREADS / 64);
+    if (act) {
+      const bool to1 = a.dst[k] != 0;
+      const bool first = to1 ? first1 : first0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ir = ai[16 * mt + 4 * g + r];
+        const float4 o = to1 ? acc1[r] : acc0[r];
+        const float4 n = first ? make_float4(fmaf(accp[0][r], ir, 0.f), fmaf(accp[1][r], ir, 0.f), fmaf(accp[2][r], ir, 0.f), fmaf(accp[3][r], ir, 0.f))
+                               : make_float4(fmaf(accp[0][r], ir, o.x), fmaf(accp[1][r], ir, o.y), fmaf(accp[2][r], ir, o.z), fmaf(accp[3][r], ir, o.w));
+        if (to1) acc1[r] = n; else acc0[r] = n;
+      }
+    }
+    if (a.dst[k] != 0) first1 = false; else first0 = false;
+    if (k + 1 < a.nsteps) fill(k + 1);                 // slot (k+1)&1 was last read by product k-1
+  }
+  // ---- the two output-gradient tiles -> LDS as fp32 rows (both slots are free behind the last matrix phase)
+  float4* D0 = reinterpret_cast<float4*>(S0);
+  float4* D1 = reinterpret_cast<float4*>(S1);
+  if (act) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = 16 * mt + 4 * g + r;
+      float4 v = acc0[r];
+      if (a.add_dy1) v = cb_add(v, addt[r]);
+      D0[lr * 32 + (ecol >> 2)] = v;
+      if (a.g2) D1[lr * 32 + (ecol >> 2)] = acc1[r];
+    }
+  }
+  __syncthreads();
+  // ---- row phase: layer norm(s) backward.  dy = dy*g ; dx = rstd * (gv - mean(gv) - xhat * mean(gv * xhat))   (ln_bwd_kernel)
+  float4 sg1 = f4zero(), sb1 = f4zero(), sg2 = f4zero(), sb2 = f4zero();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int lr = grp + 16 * u, row = r0 + lr;
+    if (lr >= MT || row >= R) continue;
+    const size_t off = (size_t)row * HUAL_D + col;
+    const float4 v = xv[u];
+    const float mean = mu[u], rstd = rsd[u];
+    const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+    float4 dy = D0[lr * 32 + l32];
+    if (a.dy1_site >= 0 && dr.enabled) dy = apply_drop4_r(dr, (uint32_t)a.dy1_site, a.drop_row0 + (uint32_t)row, (uint32_t)l32, dy);
+    sb1 = cb_add(sb1, dy);
+    sg1 = cb_fma(dy, xh, sg1);
+    float4 gv = cb_mul(dy, g1);
+    if (a.g2) {
+      const float4 dy2 = D1[lr * 32 + l32];
+      sb2 = cb_add(sb2, dy2);
+      sg2 = cb_fma(dy2, xh, sg2);
+      gv = cb_fma(dy2, g2, gv);
+    }
+    const float m1 = fast_sum32(cb_hsum(gv)) * (1.0f / HUAL_D);
+    const float m2 = fast_sum32(cb_hsum(cb_mul(gv, xh))) * (1.0f / HUAL_D);
+    float4 dx = make_float4(rstd * (gv.x - m1 - xh.x * m2), rstd * (gv.y - m1 - xh.y * m2),
+                            rstd * (gv.z - m1 - xh.z * m2), rstd * (gv.w - m1 - xh.w * m2));
+    if (a.add1) dx = make_float4(__fadd_rn(dx.x, a1v[u].x), __fadd_rn(dx.y, a1v[u].y), __fadd_rn(dx.z, a1v[u].z), __fadd_rn(dx.w, a1v[u].w));
+    st4(a.dx + off, dx);
+    if (a.dz) {
+      if (a.dz_site >= 0 && dr.enabled) dx = apply_drop4_r(dr, (uint32_t)a.dz_site, a.drop_row0 + (uint32_t)row, (uint32_t)l32, dx);
+      if (a.dz_relu) {
+        const float4 y = ld4(a.dz_relu + off);
+        dx = make_float4(y.x > 0.f ? dx.x : 0.f, y.y > 0.f ? dx.y : 0.f, y.z > 0.f ? dx.z : 0.f, y.w > 0.f ? dx.w : 0.f);
+      }
+      st4(a.dz + off, dx);
+    }
+  }
+  // ---- parameter sums of the workgroup: halves of a wave in registers, the 8 waves through LDS (the weight buffer is free)
+  {
+    auto xor32_sum = [&](float v) {
+      const unsigned x = __builtin_bit_cast(unsigned, v);
+      const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+      return v + __builtin_bit_cast(float, (lane & 32) ? r[0] : r[1]);
+    };
+    auto xor32_sum4 = [&](float4 v) { return make_float4(xor32_sum(v.x), xor32_sum(v.y), xor32_sum(v.z), xor32_sum(v.w)); };
+    sg1 = xor32_sum4(sg1); sb1 = xor32_sum4(sb1); sg2 = xor32_sum4(sg2); sb2 = xor32_sum4(sb2);
+    float4* pb = reinterpret_cast<float4*>(Wl);        // [8 waves][4 vectors][32] float4
+    if (lane < 32) {
+      float4* dst = pb + wave * 4 * 32 + l32;
+      dst[0] = sg1; dst[32] = sb1; dst[64] = sg2; dst[96] = sb2;
+    }
+    __syncthreads();
+    const float* pf = reinterpret_cast<const float*>(pb);
+    const int e = threadIdx.x;                         // 4 x 128 sums, one per thread
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += pf[w * 4 * HUAL_D + e];
+    a.part[(size_t)blockIdx.x * 4 * HUAL_D + e] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Backward of the gated middle of the dual attention (DaMidBwdArgs): ten weight steps, three operand slots.
+__global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char dm_lds[];
+  char* P0 = dm_lds;
+  char* P1 = P0 + DP_SLOT;
+  char* P2 = P1 + DP_SLOT;
+  char* Wl = P2 + DP_SLOT;
+  float* ainv0 = reinterpret_cast<float*>(Wl + CB_WBYTES);
+  float* ainv1 = ainv0 + DP_ROWS;
+  float* ainv2 = ainv1 + DP_ROWS;
+  float* smaxA = ainv2 + DP_ROWS;                      // [48][2] half-row maxima of the (first) tile being written
+  float* smaxB = smaxA + 2 * DP_ROWS;                  // ... and of the second
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int col = 4 * l32;
+  const int MT = a.MT, ntile = MT >> 4, R = a.R;
+  const int r0 = blockIdx.x * MT;
+  const int mt = wave >> 1, ch = wave & 1;
+  const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
+  const bool act = mt < ntile;
+
+  cb_dma_weight(a.w[0], Wl, wave, lane, CB_THREADS / 64);
+  {
+    float4 zv[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) zv[u] = ld4(a.dz1 + (size_t)min(r0 + grp + 16 * u, R - 1) * HUAL_D + col);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int lr = grp + 16 * u;
+      if (lr >= MT) continue;
+      const bool ok = r0 + lr < R;
+      const float inv = cb_store_operand(P1, P1 + DP_PLANE, lr, l32, ok ? zv[u] : f4zero());
+      if (l32 == 0) ainv1[lr] = ok ? inv : 0.f;
+    }
+  }
+  f32x4 accp[4];
+  auto step = [&](const char* P, const float* next) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (act) cb_tile_mma(P, P + DP_PLANE, Wl, mt, ch, lane, accp);
+    __syncthreads();
+    if (next) cb_dma_weight(next, Wl, wave, lane, CB_THREADS / 64);
+  };
+  auto fold = [&](float4 (&acc)[4], const float* ai, bool first) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ir = ai[16 * mt + 4 * g + r];
+      if (first) acc[r] = make_float4(fmaf(accp[0][r], ir, 0.f), fmaf(accp[1][r], ir, 0.f), fmaf(accp[2][r], ir, 0.f), fmaf(accp[3][r], ir, 0.f));
+      else acc[r] = make_float4(fmaf(accp[0][r], ir, acc[r].x), fmaf(accp[1][r], ir, acc[r].y), fmaf(accp[2][r], ir, acc[r].z), fmaf(accp[3][r], ir, acc[r].w));
+    }
+  };
+  auto tile_ld = [&](const float* src, float4 (&t)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = ld4(src + (size_t)min(r0 + 16 * mt + 4 * g + r, R - 1) * HUAL_D + ecol);
+  };
+  auto save = [&](float* dst, int r, float4 v) {
+    const int row = r0 + 16 * mt + 4 * g + r;
+    if (row < R) st4(dst + (size_t)row * HUAL_D + ecol, v);
+  };
+  auto put_max = [&](float* sm, const float4 (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float m = row16_max(f4absmax(v[r]));
+      if (j == 0) sm[(16 * mt + 4 * g + r) * 2 + ch] = m;
+    }
+  };
+  auto put_planes = [&](char* P, float* ai, const float* sm, const float4 (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = 16 * mt + 4 * g + r;
+      float inv;
+      const float sc = f16_row_scale(fmaxf(sm[lr * 2], sm[lr * 2 + 1]), inv);
+      uint2 h, l;
+      f16_split4(f4scale1(v[r], sc), h, l);
+      const int off = tile256_off(lr, ecol >> 3) + 8 * (j & 1);
+      *reinterpret_cast<uint2*>(P + off) = h;
+      *reinterpret_cast<uint2*>(P + DP_PLANE + off) = l;
+      if (ch == 0 && j == 0) ai[lr] = (r0 + lr < R) ? inv : 0.f;
+    }
+  };
+  auto zero_invalid = [&](float4 (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (r0 + 16 * mt + 4 * g + r >= R) v[r] = f4zero();
+  };
+
+  float4 T1[4], T2[4], U1[4], U2[4], U3[4], U4[4];
+  // ---- d mha = dZ1 . Wd1^T ; bilinear backward (layers.py:110): d scores = d mha * val * gate * (1 - gate), d values = d mha * gate
+  tile_ld(a.gate, U1);
+  tile_ld(a.val, U2);
+  step(P1, a.w[1]);
+  if (act) {
+    fold(T1, ainv1, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4 d0 = T1[r], gt = U1[r], vl = U2[r];
+      T1[r] = make_float4(d0.x * vl.x * gt.x * (1.f - gt.x), d0.y * vl.y * gt.y * (1.f - gt.y), d0.z * vl.z * gt.z * (1.f - gt.z),
+                          d0.w * vl.w * gt.w * (1.f - gt.w));
+      T2[r] = cb_mul(d0, gt);
+      save(a.d_sc, r, T1[r]);
+      save(a.d_val, r, T2[r]);
+    }
+    zero_invalid(T1);
+    zero_invalid(T2);
+    put_max(smaxA, T1);
+    put_max(smaxB, T2);
+  }
+  __syncthreads();
+  if (act) { put_planes(P0, ainv0, smaxA, T1); put_planes(P2, ainv2, smaxB, T2); }
+  // ---- gradient of ln1 through the two bilinear layers: d scores . W11^T + d values . W21^T
+  step(P0, a.w[2]);
+  if (act) fold(T1, ainv0, true);
+  step(P2, a.w[3]);
+  if (act) {
+    fold(T1, ainv2, false);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) save(a.d_ln1a, r, T1[r]);
+  }
+  // ---- gradient of the guided features: d scores . W12^T + d values . W22^T
+  step(P0, a.w[4]);
+  if (act) fold(T1, ainv0, true);
+  tile_ld(a.sg, U1);
+  tile_ld(a.xg, U2);
+  tile_ld(a.sv, U3);
+  tile_ld(a.xv, U4);
+  step(P2, a.w[5]);
+  if (act) {
+    fold(T1, ainv2, false);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) save(a.d_g, r, T1[r]);
+    zero_invalid(T1);
+    put_max(smaxA, T1);
+  }
+  __syncthreads();
+  if (act) put_planes(P1, ainv1, smaxA, T1);
+  // ---- d o = d g . Wg^T ; cross gating backward (layers.py:96-103): o = sg * x + xg * s
+  step(P1, a.w[6]);
+  if (act) {
+    fold(T1, ainv1, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4 d0 = T1[r], sg = U1[r], xg = U2[r], sv = U3[r], xv = U4[r];
+      T1[r] = make_float4(d0.x * xv.x * sg.x * (1.f - sg.x), d0.y * xv.y * sg.y * (1.f - sg.y), d0.z * xv.z * sg.z * (1.f - sg.z),
+                          d0.w * xv.w * sg.w * (1.f - sg.w));                        // dZ of s_gate
+      T2[r] = make_float4(d0.x * sv.x * xg.x * (1.f - xg.x), d0.y * sv.y * xg.y * (1.f - xg.y), d0.z * sv.z * xg.z * (1.f - xg.z),
+                          d0.w * sv.w * xg.w * (1.f - xg.w));                        // dZ of x_gate
+      U3[r] = cb_mul(d0, xg);                                                         // direct part of d s_value
+      U4[r] = cb_mul(d0, sg);                                                         // direct part of d x_value
+      save(a.dz_sg, r, T1[r]);
+      save(a.dz_xg, r, T2[r]);
+    }
+    zero_invalid(T1);
+    zero_invalid(T2);
+    put_max(smaxA, T1);
+    put_max(smaxB, T2);
+  }
+  __syncthreads();
+  if (act) { put_planes(P0, ainv0, smaxA, T1); put_planes(P2, ainv2, smaxB, T2); }
+  // ---- d s_value = dZ_sg . Wsg^T + d o * xg ; d x_value = dZ_xg . Wxg^T + d o * sg
+  step(P0, a.w[7]);
+  if (act) {
+    fold(T1, ainv0, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { T1[r] = cb_add(T1[r], U3[r]); save(a.d_sv, r, T1[r]); }
+    zero_invalid(T1);
+    put_max(smaxA, T1);
+  }
+  __syncthreads();
+  if (act) put_planes(P1, ainv1, smaxA, T1);
+  step(P2, a.w[8]);
+  if (act) {
+    fold(T2, ainv2, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { T2[r] = cb_add(T2[r], U4[r]); save(a.d_xv, r, T2[r]); }
+    zero_invalid(T2);
+    put_max(smaxB, T2);
+  }
+  __syncthreads();
+  if (act) put_planes(P0, ainv0, smaxB, T2);
+  // ---- gradients of the two attention outputs
+  step(P1, a.w[9]);
+  if (act) {
+    fold(T1, ainv1, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) save(a.d_satt, r, T1[r]);
+  }
+  step(P0, nullptr);
+  if (act) {
+    fold(T2, ainv0, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) save(a.d_xatt, r, T2[r]);
+  }
+}
+
 namespace hual {
 
 static int tile_rows(int R, int max_rows) {
@@ -430,6 +792,43 @@ int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s) {
   const double rows = (double)a.R;
   HUAL_LAUNCH(11.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 16.0 + 11.0 * HUAL_D * HUAL_D), da_post_kernel,
               dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), lds, s, a, drop);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int ln_proj_bwd_rows(int R) { return tile_rows(R, LB_ROWS); }
+int ln_proj_bwd_blocks(int R) { return cdiv(R, ln_proj_bwd_rows(R)); }
+
+int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t s) {
+  HUAL_REQUIRE(a.nsteps >= 1 && a.nsteps <= HUAL_LNBWD_MAX && a.R > 0, "ln_proj_bwd: step count / rows");
+  HUAL_REQUIRE(a.MT >= 16 && a.MT <= LB_ROWS && (a.MT % 16) == 0, "ln_proj_bwd: MT must be 16, 32, 48 or 64");
+  HUAL_REQUIRE(a.x && a.mean && a.rstd && a.g1 && a.dx && a.part, "ln_proj_bwd: null tensor");
+  bool any1 = false;
+  for (int k = 0; k < a.nsteps; ++k) {
+    HUAL_REQUIRE(a.A[k] && a.wimg_t[k] && (a.lda[k] % 4) == 0, "ln_proj_bwd: product operand");
+    HUAL_REQUIRE(a.dst[k] == 0 || a.g2, "ln_proj_bwd: product for the absent second layer norm");
+    any1 = any1 || a.dst[k] != 0;
+  }
+  HUAL_REQUIRE(!a.g2 || any1, "ln_proj_bwd: second layer norm without a product");
+  HUAL_DYN_LDS(ln_proj_bwd_kernel, 160 * 1024);
+  const size_t lds = (size_t)4 * LB_ROWS * 256 + CB_WBYTES + 2 * LB_ROWS * sizeof(float);
+  const double rows = (double)a.R;
+  HUAL_LAUNCH(2.0 * rows * HUAL_D * HUAL_D * a.nsteps, 4.0 * (rows * HUAL_D * (4.0 + a.nsteps) + (double)a.nsteps * HUAL_D * HUAL_D),
+              ln_proj_bwd_kernel, dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), lds, s, a, drop);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_da_mid_bwd(const DaMidBwdArgs& a, hipStream_t s) {
+  HUAL_REQUIRE(a.dz1 && a.gate && a.val && a.sg && a.xg && a.sv && a.xv && a.R > 0, "da_mid_bwd: null / empty");
+  HUAL_REQUIRE(a.MT >= 16 && a.MT <= DP_ROWS && (a.MT % 16) == 0, "da_mid_bwd: MT must be 16, 32 or 48");
+  for (int k = 0; k < 10; ++k) HUAL_REQUIRE(a.w[k] != nullptr, "da_mid_bwd: null weight image");
+  HUAL_REQUIRE(a.d_sc && a.d_val && a.d_ln1a && a.d_g && a.dz_sg && a.dz_xg && a.d_sv && a.d_xv && a.d_satt && a.d_xatt, "da_mid_bwd: null output");
+  HUAL_DYN_LDS(da_mid_bwd_kernel, 160 * 1024);
+  const size_t lds = (size_t)3 * DP_SLOT + CB_WBYTES + (3 * DP_ROWS + 4 * DP_ROWS) * sizeof(float);
+  const double rows = (double)a.R;
+  HUAL_LAUNCH(10.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 17.0 + 10.0 * HUAL_D * HUAL_D), da_mid_bwd_kernel,
+              dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), lds, s, a);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

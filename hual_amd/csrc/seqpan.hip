@@ -205,6 +205,18 @@ struct Ctx {
     colsum.push_back(cj);
     if (!dry && ok()) chk(launch_dwconv_ln_bwd(a, r, drop, stream));
   }
+  // fused dX products + layer norm(s) backward (dablock.h); the per-workgroup parameter sums are folded in by flush_colsum()
+  void ln_proj_bwd(const LnProjBwdArgs& a0, float* dg1, float* db1, float* dg2, float* db2) {
+    LnProjBwdArgs a = a0;
+    a.MT = ln_proj_bwd_rows(a.R);
+    const int nblk = ln_proj_bwd_blocks(a.R);
+    a.part = buf("part." + std::to_string(colsum.size()), (size_t)nblk * 4, HUAL_D);
+    ColsumJob cj{};
+    cj.src = a.part; cj.nblk = nblk; cj.nvec = 4;
+    cj.dst[0] = dg1; cj.dst[1] = db1; cj.dst[2] = dg2; cj.dst[3] = db2;
+    colsum.push_back(cj);
+    if (!dry && ok()) chk(launch_ln_proj_bwd(a, drop, stream));
+  }
   void flush_colsum() {
     for (size_t i = 0; i < colsum.size() && !dry && ok(); i += HUAL_COLSUM_MAX_JOBS)
       chk(launch_colsum(colsum.data() + i, (int)std::min<size_t>(HUAL_COLSUM_MAX_JOBS, colsum.size() - i), stream));
@@ -347,7 +359,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
   { const char* e = getenv("HUAL_FUSE_ROW"); c.fuse_row = !c.fuse_bwd && !(e && atoi(e) == 0); }
   { const char* e = getenv("HUAL_GEMM_BF16"); c.use_bf16 = !(e && atoi(e) == 0); }
   { const char* e = getenv("HUAL_CHAIN"); c.use_chain = !(e && atoi(e) == 0); }
-  { const char* e = getenv("HUAL_FUSE_DA"); c.fuse_da = c.use_bf16 && !c.fuse_ln && !(e && atoi(e) == 0); }
+  { const char* e = getenv("HUAL_FUSE_DA"); c.fuse_da = c.use_bf16 && !c.fuse_ln && !c.fuse_bwd && c.fuse_row && !(e && atoi(e) == 0); }
   { const char* e = getenv("HUAL_FUSE_CB"); c.fuse_cb = c.use_bf16 && !c.fuse_ln && !c.fuse_bwd && c.fuse_row && !(e && atoi(e) == 0); }
   {
     const ParamMap& pm = c.pm;
@@ -1035,9 +1047,16 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* dzd = c.actv("d." + t + ".zd");
     c.dwjobs.push_back(mkdw(l2, D, D, dzd, D, Nv, c.g(pm.fe_dense.k), c.g(pm.fe_dense.b)));
     float* d_l2 = c.actv("d." + t + ".l2");
-    dx_after_dropout(c, d_feout, dzd, Nv, site + 8, c.pt(pm.fe_dense.k), d_l2, c.fuse_row);
     float* d_res = c.actv("d." + t + ".res");
-    {
+    auto imgt = [&](size_t off) { return reinterpret_cast<const float*>(c.PKB + off * 4); };
+    if (c.fuse_da) {       // dense^T + layer_norm_2 backward in one launch (dablock.h); dZ of the dense layer came from upstream
+      LnProjBwdArgs lb{};
+      lb.nsteps = 1; lb.A[0] = dzd; lb.lda[0] = D; lb.a_site[0] = -1; lb.wimg_t[0] = imgt(pm.fe_dense.k); lb.dst[0] = 0;
+      lb.dy1_site = site + 7; lb.x = res; lb.mean = mean2; lb.rstd = rstd2; lb.g1 = c.p(pm.fe_ln2.g); lb.add1 = d_feout;
+      lb.dx = d_res; lb.dz = c.actv("d." + t + ".att"); lb.dz_site = site + 6; lb.R = Nv; lb.drop_row0 = 0;
+      c.ln_proj_bwd(lb, c.g(pm.fe_ln2.g), c.g(pm.fe_ln2.b), nullptr, nullptr);
+    } else {
+      dx_after_dropout(c, d_feout, dzd, Nv, site + 8, c.pt(pm.fe_dense.k), d_l2, c.fuse_row);
       LnBwd a{};
       a.x = res; a.mean = mean2; a.rstd = rstd2; a.R = Nv; a.dy1 = d_l2; a.g1 = c.p(pm.fe_ln2.g);
       a.dg1 = c.g(pm.fe_ln2.g); a.db1 = c.g(pm.fe_ln2.b); a.drop_site1 = site + 7; a.drop_row0 = 0; a.add1 = d_feout;
@@ -1068,15 +1087,24 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.dwjobs.push_back(mkdw(a1, D, D, d_qkv + D, 3 * D, Nv, c.g(pm.fe_k.k), c.g(pm.fe_k.b)));
     c.dwjobs.push_back(mkdw(a1, D, D, d_qkv + 2 * D, 3 * D, Nv, c.g(pm.fe_v.k), c.g(pm.fe_v.b)));
     float* d_a = c.actv("d." + t + ".a");
-    {
-      GemmJob j = mkjob_dx(d_qkv, 3 * D, Nv, D, c.pt(pm.fe_q.k), D, d_a, D);
-      j.npieces = 3;
-      j.A[1] = d_qkv + D; j.lda[1] = 3 * D; j.kw[1] = D; j.W[1] = c.pt(pm.fe_k.k);
-      j.A[2] = d_qkv + 2 * D; j.lda[2] = 3 * D; j.kw[2] = D; j.W[2] = c.pt(pm.fe_v.k);
-      c.gemm(&j, 1);
-    }
     float* d_f = c.actv("d." + t + ".x4");
-    {
+    if (c.fuse_da) {       // query / key / value ^T + layer_norm_1 backward in one launch
+      LnProjBwdArgs lb{};
+      lb.nsteps = 3;
+      const size_t wo[3] = {pm.fe_q.k, pm.fe_k.k, pm.fe_v.k};
+      for (int k = 0; k < 3; ++k) { lb.A[k] = d_qkv + k * D; lb.lda[k] = 3 * D; lb.a_site[k] = -1; lb.wimg_t[k] = imgt(wo[k]); lb.dst[k] = 0; }
+      lb.dy1_site = site + 4; lb.x = f; lb.mean = mean; lb.rstd = rstd; lb.g1 = c.p(pm.fe_ln1.g); lb.add1 = d_res;
+      lb.dx = d_f; lb.dz_site = -1; lb.R = Nv; lb.drop_row0 = 0;
+      if (!c.fuse_cb) { lb.dz = c.actv("d." + t + ".z3"); lb.dz_site = site + 3; lb.dz_relu = c.actv(t + ".y3"); }
+      c.ln_proj_bwd(lb, c.g(pm.fe_ln1.g), c.g(pm.fe_ln1.b), nullptr, nullptr);
+    } else {
+      {
+        GemmJob j = mkjob_dx(d_qkv, 3 * D, Nv, D, c.pt(pm.fe_q.k), D, d_a, D);
+        j.npieces = 3;
+        j.A[1] = d_qkv + D; j.lda[1] = 3 * D; j.kw[1] = D; j.W[1] = c.pt(pm.fe_k.k);
+        j.A[2] = d_qkv + 2 * D; j.lda[2] = 3 * D; j.kw[2] = D; j.W[2] = c.pt(pm.fe_v.k);
+        c.gemm(&j, 1);
+      }
       LnBwd a{};
       a.x = f; a.mean = mean; a.rstd = rstd; a.R = Nv; a.dy1 = d_a; a.g1 = c.p(pm.fe_ln1.g);
       a.dg1 = c.g(pm.fe_ln1.g); a.db1 = c.g(pm.fe_ln1.b); a.drop_site1 = site + 4; a.drop_row0 = 0; a.add1 = d_res;
@@ -1220,8 +1248,54 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* dz2 = c.act(dt + ".z2");
     c.dwjobs.push_back(mkdw(l2, D, D, dz2, D, R, c.g(d.dense2.k), c.g(d.dense2.b)));
     float* d_l2 = c.act(dt + ".l2");
-    dx_after_dropout(c, dx, dz2, R, site + 4, c.pt(d.dense2.k), d_l2, c.fuse_row && li < c.cfg->attn_layer - 1);
     float* d_res = c.act(dt + ".res");
+    float* dz1 = c.act(dt + ".z1");
+    float* d_mha = c.act(dt + ".mha");
+    float* d_sc = c.act(dt + ".sc");
+    float* d_val = c.act(dt + ".val");
+    float* d_ln1a = c.act(dt + ".ln1a");
+    float* d_g = c.act(dt + ".g");
+    float* d_o = c.act(dt + ".o");
+    float* dz_sg = c.act(dt + ".zsg");
+    float* dz_xg = c.act(dt + ".zxg");
+    float* ds_part = c.act(dt + ".sp");
+    float* dx_part = c.act(dt + ".xp");
+    float* d_sv = c.act(dt + ".s");
+    float* d_xv = c.act(dt + ".x");
+    float* d_satt = c.act(dt + ".s_att");
+    float* d_xatt = c.act(dt + ".x_att");
+    auto imgt = [&](size_t off) { return reinterpret_cast<const float*>(c.PKB + off * 4); };
+    const bool dz2_ready = c.fuse_row && li < c.cfg->attn_layer - 1;     // the layer above left dropout'(dx) in dz2
+    // weight-gradient jobs of this half of the block (operands are written by whichever path runs below)
+    c.dwjobs.push_back(mkdw(mha, D, D, dz1, D, R, c.g(d.dense1.k), c.g(d.dense1.b)));
+    for (int k = 0; k < 2; ++k) {
+      DwJob j = mkdw(ln1, D, D, k == 0 ? d_sc : d_val, D, R, c.g(k == 0 ? d.bl1_d1 : d.bl2_d1), c.g(k == 0 ? d.bl1_b : d.bl2_b));
+      j.npieces = 2; j.A[1] = gd; j.lda[1] = D; j.kw[1] = D; j.dW[1] = c.g(k == 0 ? d.bl1_d2 : d.bl2_d2);
+      c.dwjobs.push_back(j);
+    }
+    c.dwjobs.push_back(mkdw(o, D, D, d_g, D, R, c.g(d.guided.k), c.g(d.guided.b)));
+    c.dwjobs.push_back(mkdw(sv, D, D, dz_sg, D, R, c.g(d.s_gate.k), c.g(d.s_gate.b)));
+    c.dwjobs.push_back(mkdw(xv, D, D, dz_xg, D, R, c.g(d.x_gate.k), c.g(d.x_gate.b)));
+    c.dwjobs.push_back(mkdw(s_att, D, D, d_sv, D, R, c.g(d.s_dense.k), c.g(d.s_dense.b)));
+    c.dwjobs.push_back(mkdw(x_att, D, D, d_xv, D, R, c.g(d.x_dense.k), c.g(d.x_dense.b)));
+    if (c.fuse_da) {
+      // (1) dense_2^T + layer_norm_2 backward -> d res, dZ1     (2) the gated middle, ten weight steps     (dablock.h)
+      LnProjBwdArgs lb{};
+      lb.nsteps = 1; lb.lda[0] = D; lb.wimg_t[0] = imgt(d.dense2.k); lb.dst[0] = 0;
+      if (dz2_ready) { lb.A[0] = dz2; lb.a_site[0] = -1; }
+      else { lb.A[0] = dx; lb.a_site[0] = site + 4; lb.a_save[0] = dz2; }
+      lb.dy1_site = site + 3; lb.x = res; lb.mean = mean2; lb.rstd = rstd2; lb.g1 = c.p(d.ln2.g); lb.add1 = dx;
+      lb.dx = d_res; lb.dz = dz1; lb.dz_site = site + 2; lb.R = R; lb.drop_row0 = 0;
+      c.ln_proj_bwd(lb, c.g(d.ln2.g), c.g(d.ln2.b), nullptr, nullptr);
+      DaMidBwdArgs mb{};
+      mb.dz1 = dz1; mb.gate = gate; mb.val = val; mb.sg = sg; mb.xg = xg; mb.sv = sv; mb.xv = xv;
+      const size_t wo[10] = {d.dense1.k, d.bl1_d1, d.bl2_d1, d.bl1_d2, d.bl2_d2, d.guided.k, d.s_gate.k, d.x_gate.k, d.s_dense.k, d.x_dense.k};
+      for (int k = 0; k < 10; ++k) mb.w[k] = imgt(wo[k]);
+      mb.d_sc = d_sc; mb.d_val = d_val; mb.d_ln1a = d_ln1a; mb.d_g = d_g; mb.dz_sg = dz_sg; mb.dz_xg = dz_xg; mb.d_sv = d_sv; mb.d_xv = d_xv;
+      mb.d_satt = d_satt; mb.d_xatt = d_xatt; mb.R = R; mb.MT = da_post_rows(R);
+      if (!c.dry && c.ok()) c.chk(launch_da_mid_bwd(mb, c.stream));
+    } else {
+    dx_after_dropout(c, dx, dz2, R, site + 4, c.pt(d.dense2.k), d_l2, dz2_ready);
     {
       LnBwd a{};
       a.x = res; a.mean = mean2; a.rstd = rstd2; a.R = R; a.dy1 = d_l2; a.g1 = c.p(d.ln2.g); a.dg1 = c.g(d.ln2.g);
@@ -1230,25 +1304,13 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       c.ln_bwd(a);
     }
     // res = dropout(mha . Wd1 + b, s2) + xin
-    float* dz1 = c.act(dt + ".z1");
-    c.dwjobs.push_back(mkdw(mha, D, D, dz1, D, R, c.g(d.dense1.k), c.g(d.dense1.b)));
-    float* d_mha = c.act(dt + ".mha");
     dx_after_dropout(c, d_res, dz1, R, site + 2, c.pt(d.dense1.k), d_mha, c.fuse_row);
     // mha = gate * val
-    float* d_sc = c.act(dt + ".sc");
-    float* d_val = c.act(dt + ".val");
     {
       EwArgs e{};
       e.op = EW_BILINEAR_BWD; e.R = R; e.a = d_mha; e.b = gate; e.c = val; e.out = d_sc; e.out2 = d_val; e.drop_site = -1;
       c.ew(e);
     }
-    for (int k = 0; k < 2; ++k) {
-      DwJob j = mkdw(ln1, D, D, k == 0 ? d_sc : d_val, D, R, c.g(k == 0 ? d.bl1_d1 : d.bl2_d1), c.g(k == 0 ? d.bl1_b : d.bl2_b));
-      j.npieces = 2; j.A[1] = gd; j.lda[1] = D; j.kw[1] = D; j.dW[1] = c.g(k == 0 ? d.bl1_d2 : d.bl2_d2);
-      c.dwjobs.push_back(j);
-    }
-    float* d_ln1a = c.act(dt + ".ln1a");
-    float* d_g = c.act(dt + ".g");
     {
       GemmJob j[2];
       j[0] = mkjob_dx(d_sc, D, R, D, c.pt(d.bl1_d1), D, d_ln1a, D);
@@ -1258,27 +1320,17 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       c.gemm(j, 2);
     }
     // g = o . Wg + b
-    c.dwjobs.push_back(mkdw(o, D, D, d_g, D, R, c.g(d.guided.k), c.g(d.guided.b)));
-    float* d_o = c.act(dt + ".o");
     {
       GemmJob j = mkjob_dx(d_g, D, R, D, c.pt(d.guided.k), D, d_o, D);
       c.gemm(&j, 1);
     }
     // o = sg * x + xg * s
-    float* dz_sg = c.act(dt + ".zsg");
-    float* dz_xg = c.act(dt + ".zxg");
-    float* ds_part = c.act(dt + ".sp");
-    float* dx_part = c.act(dt + ".xp");
     {
       EwArgs e{};
       e.op = EW_GATE_BWD; e.R = R; e.a = d_o; e.b = sg; e.c = xg; e.d = sv; e.e = xv;
       e.out = dz_sg; e.out2 = dz_xg; e.out3 = ds_part; e.out4 = dx_part; e.drop_site = -1;
       c.ew(e);
     }
-    c.dwjobs.push_back(mkdw(sv, D, D, dz_sg, D, R, c.g(d.s_gate.k), c.g(d.s_gate.b)));
-    c.dwjobs.push_back(mkdw(xv, D, D, dz_xg, D, R, c.g(d.x_gate.k), c.g(d.x_gate.b)));
-    float* d_sv = c.act(dt + ".s");
-    float* d_xv = c.act(dt + ".x");
     {
       GemmJob j[2];
       j[0] = mkjob_dx(dz_sg, D, R, D, c.pt(d.s_gate.k), D, d_sv, D);
@@ -1287,15 +1339,12 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       j[1].add = dx_part; j[1].ldadd = D;
       c.gemm(j, 2);
     }
-    c.dwjobs.push_back(mkdw(s_att, D, D, d_sv, D, R, c.g(d.s_dense.k), c.g(d.s_dense.b)));
-    c.dwjobs.push_back(mkdw(x_att, D, D, d_xv, D, R, c.g(d.x_dense.k), c.g(d.x_dense.b)));
-    float* d_satt = c.act(dt + ".s_att");
-    float* d_xatt = c.act(dt + ".x_att");
     {
       GemmJob j[2];
       j[0] = mkjob_dx(d_sv, D, R, D, c.pt(d.s_dense.k), D, d_satt, D);
       j[1] = mkjob_dx(d_xv, D, R, D, c.pt(d.x_dense.k), D, d_xatt, D);
       c.gemm(j, 2);
+    }
     }
     // the four attentions
     float* dq_self = c.act(dt + ".q_self");
@@ -1328,6 +1377,24 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.dwjobs.push_back(mkdw(lnt, D, D, d_ktvt + D, 2 * D, R, c.g(d.t_value.k), c.g(d.t_value.b)));
     float* d_ln1 = c.act(dt + ".ln1");
     float* d_lnt = c.act(dt + ".lnt");
+    float* d_xin = c.act(dt + ".in");
+    // operand of the next dX product down the stack: previous layer's dense_2, or (unfused conv block) its layer 3
+    float* nz = nullptr; int nz_site = -1; const float* nz_relu = nullptr;
+    if (c.fuse_row) {
+      if (li > 0) { nz = c.act("d.da" + std::to_string(li - 1) + ".z2"); nz_site = HUAL_SITE_DA + 8 * (li - 1) + 4; }
+      else if (!c.fuse_cb) { nz = c.act("d.cb.z3"); nz_site = HUAL_SITE_CONV + 3; nz_relu = c.act("cb.y3"); }
+    }
+    if (c.fuse_da) {       // the six projection^T products + layer_norm_1 / layer_norm_t backward in one launch (dablock.h)
+      LnProjBwdArgs lb{};
+      lb.nsteps = 6;
+      const float* As[6] = {dq_self, dq_cross, d_qkv + D, d_qkv + 2 * D, d_ktvt, d_ktvt + D};
+      const int lds_[6] = {D, D, 3 * D, 3 * D, 2 * D, 2 * D};
+      const size_t wo[6] = {d.query.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
+      for (int k = 0; k < 6; ++k) { lb.A[k] = As[k]; lb.lda[k] = lds_[k]; lb.a_site[k] = -1; lb.wimg_t[k] = imgt(wo[k]); lb.dst[k] = k < 4 ? 0 : 1; }
+      lb.add_dy1 = d_ln1a; lb.dy1_site = -1; lb.x = xin; lb.mean = mean; lb.rstd = rstd; lb.g1 = c.p(d.ln1.g); lb.g2 = c.p(d.lnt.g);
+      lb.add1 = d_res; lb.dx = d_xin; lb.dz = nz; lb.dz_site = nz_site; lb.dz_relu = nz_relu; lb.R = R; lb.drop_row0 = 0;
+      c.ln_proj_bwd(lb, c.g(d.ln1.g), c.g(d.ln1.b), c.g(d.lnt.g), c.g(d.lnt.b));
+    } else {
     {
       GemmJob j[2];
       j[0] = mkjob_dx(dq_self, D, R, D, c.pt(d.query.k), D, d_ln1, D);
@@ -1341,17 +1408,14 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       j[1].A[1] = d_ktvt + D; j[1].lda[1] = 2 * D; j[1].kw[1] = D; j[1].W[1] = c.pt(d.t_value.k);
       c.gemm(j, 2);
     }
-    float* d_xin = c.act(dt + ".in");
     {
       LnBwd a{};
       a.x = xin; a.mean = mean; a.rstd = rstd; a.R = R; a.dy1 = d_ln1; a.g1 = c.p(d.ln1.g); a.dg1 = c.g(d.ln1.g);
       a.db1 = c.g(d.ln1.b); a.drop_site1 = -1; a.dy2 = d_lnt; a.g2 = c.p(d.lnt.g); a.dg2 = c.g(d.lnt.g); a.db2 = c.g(d.lnt.b);
       a.add1 = d_res; a.dx = d_xin;
-      if (c.fuse_row) {      // operand of the next dX GEMM down the stack: previous layer's dense_2, or the conv block's layer 3
-        if (li > 0) { a.dz = c.act("d.da" + std::to_string(li - 1) + ".z2"); a.dz_site = HUAL_SITE_DA + 8 * (li - 1) + 4; }
-        else if (!c.fuse_cb) { a.dz = c.act("d.cb.z3"); a.dz_site = HUAL_SITE_CONV + 3; a.dz_relu = c.act("cb.y3"); }
-      }
+      a.dz = nz; a.dz_site = nz_site; a.dz_relu = nz_relu;
       c.ln_bwd(a);
+    }
     }
     dx = d_xin;
     flush_dw(c);

@@ -70,8 +70,9 @@ def test_fused_conv_block_backward(shape, drop, monkeypatch):
     d1, d0 = m.table.unpack(g1.cpu().numpy()), m.table.unpack(g0.cpu().numpy())
     for k in d1:
         scale = float(np.abs(d0[k]).max())
-        # (+ 1e-6 absolute: gradients that are zero in exact arithmetic - the key biases under the softmax - are rounding noise)
-        assert float(np.abs(d1[k] - d0[k]).max()) <= 2e-5 * scale + 1e-6, (k, float(np.abs(d1[k] - d0[k]).max()), scale)
+        # (+ 3e-6 absolute: gradients that are zero in exact arithmetic - the key biases under the softmax - are rounding noise,
+        # and the float atomics of tri_bwd_kernel make the trilinear gradients vary by ~1e-6 from run to run)
+        assert float(np.abs(d1[k] - d0[k]).max()) <= 2e-5 * scale + 3e-6, (k, float(np.abs(d1[k] - d0[k]).max()), scale)
 
 
 DA_FWD_TAPS = ['da%d.%s' % (li, n) for li in range(2) for n in ('ln1', 'lnt', 'mean', 'rstd', 'qkv', 'ktvt', 's_att', 'x_att', 's', 'x', 'sg',
@@ -93,3 +94,28 @@ def test_fused_dual_attention_forward_bit_exact(shape, drop, monkeypatch):
         assert torch.equal(t1[n], t0[n]), (n, float((t1[n] - t0[n]).abs().max()))
     for k in r1:
         assert torch.equal(r1[k], r0[k]), k
+
+
+DA_BWD_TAPS = ['d.da%d.%s' % (li, n) for li in (1, 0) for n in ('res', 'z1', 'sc', 'val', 'ln1a', 'g', 'zsg', 'zxg', 's', 'x', 's_att', 'x_att', 'in')] + \
+              ['d.fe%d.%s' % (ps, n) for ps in (1, 0) for n in ('res', 'att', 'x4')] + ['d.cb.x0']
+
+
+@pytest.mark.parametrize('shape', [dict(B=3, T=37, L=9, C=4, seed=11, max_vlen=40), dict(B=1, T=5, L=3, C=4, seed=2, max_vlen=8),
+                                   dict(B=8, T=64, L=20, C=8, seed=9, max_vlen=64), dict(B=64, T=128, L=20, C=8, seed=12345, max_vlen=128)])
+@pytest.mark.parametrize('drop', [0.0, 0.2])
+def test_fused_dual_attention_backward(shape, drop, monkeypatch):
+    """ln_proj_bwd_kernel + da_mid_bwd_kernel against the dense / elementwise / ln_bwd launches they replace: every gradient
+    tensor a later kernel or a weight-gradient job reads, to 5e-6 of its scale (see test_fused_conv_block_backward), and
+    all parameter gradients to 2e-5"""
+    case = pu.make_case(**shape)
+    t1, _, g1 = _run(case, drop, {'HUAL_FUSE_DA': '1'}, monkeypatch, DA_BWD_TAPS, backward=True)
+    t0, _, g0 = _run(case, drop, {'HUAL_FUSE_DA': '0'}, monkeypatch, DA_BWD_TAPS, backward=True)
+    for n in DA_BWD_TAPS:
+        d, sc = float((t1[n] - t0[n]).abs().max()), float(t0[n].abs().max())
+        assert d <= 5e-6 * max(sc, 1e-30), (n, d, sc)
+    cfg, p, wv, b, labels = case
+    m = pu.hip_model(cfg, p, wv)
+    d1, d0 = m.table.unpack(g1.cpu().numpy()), m.table.unpack(g0.cpu().numpy())
+    for k in d1:
+        scale = float(np.abs(d0[k]).max())
+        assert float(np.abs(d1[k] - d0[k]).max()) <= 2e-5 * scale + 3e-6, (k, float(np.abs(d1[k] - d0[k]).max()), scale)
