@@ -77,7 +77,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
     for (int l = 0; l < 4; ++l)
       if (grp < CB_NPAR) par[(l * CB_NPAR + grp) * 32 + l32] = qv[l];
   }
-  __syncthreads();
+  cb_barrier();
 
 #pragma unroll 1
   for (int l = 0; l < 4; ++l) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
         if (t >= r0 && t < r0 + MT) { L.mean[t] = mean; L.rstd[t] = rstd; }
       }
     }
-    __syncthreads();
+    cb_barrier();
     // ---------------- P1b: depthwise conv over a sliding window of normalised rows -> operand planes
     {
       const float4 gam = lp[7 * 32 + l32], bet = lp[8 * 32 + l32];
@@ -168,11 +168,11 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the weight image has landed
-    __syncthreads();
+    cb_barrier();
     // ---------------- P2: pointwise convolution on the matrix cores
     f32x4 acc[4];
     if (mt < ntile) cb_tile_mma(Ahi, Alo, Wl, mt, ch, lane, acc);
-    __syncthreads();                                         // operand planes and weight image are free again
+    cb_barrier();                                         // operand planes and weight image are free again
     if (l + 1 < 4) cb_dma_weight(a.l[l + 1].wimg, Wl, wave, lane, CB_THREADS / 64);
     // ---------------- P3: bias, relu, dropout, residual
     if (mt < ntile) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
         if (own) st4(L.xout + (size_t)o * HUAL_D + ecol, v);
       }
     }
-    __syncthreads();
+    cb_barrier();
   }
 }
 
@@ -299,11 +299,11 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
       const uint32_t b = (yv[u].x > 0.f ? 1u : 0u) | (yv[u].y > 0.f ? 2u : 0u) | (yv[u].z > 0.f ? 4u : 0u) | (yv[u].w > 0.f ? 8u : 0u);
       ybits |= b << (4 * u);
     }
-    __syncthreads();                                          // (1) operand planes + parameters complete
+    cb_barrier();                                          // (1) operand planes + parameters complete
     // ---- G: dC_i = dZ_i . W_i^T
     f32x4 acc[4];
     if (mt < ntile) cb_tile_mma(Ahi, Alo, Wl, mt, ch, lane, acc);
-    __syncthreads();                                          // (2) planes and weight image free
+    cb_barrier();                                          // (2) planes and weight image free
     if (mt < ntile) {
       const int j = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
         DC[lr * 32 + 16 * ch + j] = make_float4(acc[0][r] * ir, acc[1][r] * ir, acc[2][r] * ir, acc[3][r] * ir);
       }
     }
-    __syncthreads();                                          // (3) dC visible
+    cb_barrier();                                          // (3) dC visible
     // next layer's weight image: requested only now, behind the barrier (a __syncthreads() with an LDS-DMA in flight
     // waits for it), so that it lands under the row phase
     if (i > 0) cb_dma_weight(a.l[i - 1].wimg_t, Wl, wave, lane, CB_THREADS / 64);
@@ -403,14 +403,14 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
           dst[7 * 32] = sg;
           dst[8 * 32] = sb;
         }
-        __syncthreads();                                      // (4) on the first pass: dC consumed as well
+        cb_barrier();                                      // (4) on the first pass: dC consumed as well
         const float* pf = reinterpret_cast<const float*>(pbuf);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
           const int e = threadIdx.x + CB_THREADS * q;
           if (e < 9 * HUAL_D) pacc[q] += (pf[e] + pf[e + 9 * HUAL_D]) + (pf[e + 2 * 9 * HUAL_D] + pf[e + 3 * 9 * HUAL_D]);
         }
-        __syncthreads();
+        cb_barrier();
       }
 #pragma unroll
       for (int q = 0; q < 3; ++q) {

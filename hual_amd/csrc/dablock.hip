@@ -101,12 +101,12 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropC
   for (int p = 0; p < HUAL_LNPROJ_MAX; ++p) {
     if (p >= a.nproj) break;                                 // uniform
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the image (and its stores) done
-    __syncthreads();
+    cb_barrier();
     const char* P = a.src[p] ? P2 : P1;
     const float* ai = a.src[p] ? ainv2 : ainv1;
     f32x4 accp[4];
     if (mt < ntile) cb_tile_mma(P, P + LP_ROWS * 256, Wl, mt, ch, lane, accp);
-    __syncthreads();                                         // image consumed
+    cb_barrier();                                         // image consumed
     if (p + 1 < a.nproj) cb_dma_weight(a.wimg[p + 1], Wl, wave, lane, CB_THREADS / 64);
     if (mt < ntile) {
 #pragma unroll
@@ -199,9 +199,9 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   f32x4 accp[4];
   auto step = [&](const char* P, const float* next) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    cb_barrier();
     if (act) cb_tile_mma(P, P + DP_PLANE, Wl, mt, ch, lane, accp);
-    __syncthreads();
+    cb_barrier();
     if (next) cb_dma_weight(next, Wl, wave, lane, CB_THREADS / 64);
   };
   // acc (+)= accp * inverse operand scale of the rows
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     zero_invalid(SV);
     put_max(SV);
   }
-  __syncthreads();
+  cb_barrier();
   if (act) put_planes(P2, ainv2, SV);
   // ---- x_value = x_att . Wx + b  (layers.py:94)
   step(P1, a.w[2]);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     zero_invalid(XV);
     put_max(XV);
   }
-  __syncthreads();
+  cb_barrier();
   if (act) put_planes(P0, ainv0, XV);
   // ---- cross gating (layers.py:96-103): o = sigmoid(s_value . Wsg + b) * x_value + sigmoid(x_value . Wxg + b) * s_value
   step(P2, a.w[3]);
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     zero_invalid(T1);
     put_max(T1);
   }
-  __syncthreads();
+  cb_barrier();
   if (act) put_planes(P1, ainv1, T1);
   // ---- guided dense (layers.py:104)
   step(P1, a.w[5]);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     const float i0 = cb_store_operand(P0, P0 + DP_PLANE, lr, l32, ok ? l1[u] : f4zero());
     if (l32 == 0) ainv0[lr] = ok ? i0 : 0.f;
   }
-  __syncthreads();
+  cb_barrier();
   if (act) put_planes(P2, ainv2, T1);
   // ---- bilinear gate and value (layers.py:48-56, 106-110): scores = ln1 . W11 + g . W12 + b1 ; values = ln1 . W21 + g . W22 + b2
   step(P0, a.w[6]);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     zero_invalid(T1);
     put_max(T1);
   }
-  __syncthreads();
+  cb_barrier();
   if (act) put_planes(P1, ainv1, T1);
   // ---- dense_1 + dropout + residual (modules.py:82-83); the rows also go to LDS as fp32 for the layer norm
   step(P1, a.w[10]);
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
       scratch[lr * 32 + (ecol >> 2)] = v;
     }
   }
-  __syncthreads();
+  cb_barrier();
   // ---- RP2: layer_norm_2 + dropout (modules.py:85-86) -> slot 2
   {
     const float4 g2 = bl[9 * 32 + l32], b2 = bl[10 * 32 + l32];
@@ -457,12 +457,12 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       for (int u = 0; u < 4; ++u) nv[u] = ld4(a.A[k + 1] + (size_t)min(r0 + grp + 16 * u, R - 1) * a.lda[k + 1] + col);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    cb_barrier();
     const char* S = (k & 1) ? S1 : S0;
     const float* ai = (k & 1) ? ainv1 : ainv0;
     f32x4 accp[4];
     if (act) cb_tile_mma(S, S + LB_ROWS * 256, Wl, mt, ch, lane, accp);
-    __syncthreads();
+    cb_barrier();
     if (k + 1 < a.nsteps) cb_dma_weight(a.wimg_t[k + 1], Wl, wave, lane, CB_THREADS / 64);
     if (act) {
       const bool to1 = a.dst[k] != 0;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       if (a.g2) D1[lr * 32 + (ecol >> 2)] = acc1[r];
     }
   }
-  __syncthreads();
+  cb_barrier();
   // ---- row phase: layer norm(s) backward.  dy = dy*g ; dx = rstd * (gv - mean(gv) - xhat * mean(gv * xhat))   (ln_bwd_kernel)
   float4 sg1 = f4zero(), sb1 = f4zero(), sg2 = f4zero(), sb2 = f4zero();
 #pragma unroll
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       float4* dst = pb + wave * 4 * 32 + l32;
       dst[0] = sg1; dst[32] = sb1; dst[64] = sg2; dst[96] = sb2;
     }
-    __syncthreads();
+    cb_barrier();
     const float* pf = reinterpret_cast<const float*>(pb);
     const int e = threadIdx.x;                         // 4 x 128 sums, one per thread
     float s = 0.f;
@@ -592,9 +592,9 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   f32x4 accp[4];
   auto step = [&](const char* P, const float* next) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    cb_barrier();
     if (act) cb_tile_mma(P, P + DP_PLANE, Wl, mt, ch, lane, accp);
-    __syncthreads();
+    cb_barrier();
     if (next) cb_dma_weight(next, Wl, wave, lane, CB_THREADS / 64);
   };
   auto fold = [&](float4 (&acc)[4], const float* ai, bool first) {
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
     put_max(smaxA, T1);
     put_max(smaxB, T2);
   }
-  __syncthreads();
+  cb_barrier();
   if (act) { put_planes(P0, ainv0, smaxA, T1); put_planes(P2, ainv2, smaxB, T2); }
   // ---- gradient of ln1 through the two bilinear layers: d scores . W11^T + d values . W21^T
   step(P0, a.w[2]);
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
     zero_invalid(T1);
     put_max(smaxA, T1);
   }
-  __syncthreads();
+  cb_barrier();
   if (act) put_planes(P1, ainv1, smaxA, T1);
   // ---- d o = d g . Wg^T ; cross gating backward (layers.py:96-103): o = sg * x + xg * s
   step(P1, a.w[6]);
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
     put_max(smaxA, T1);
     put_max(smaxB, T2);
   }
-  __syncthreads();
+  cb_barrier();
   if (act) { put_planes(P0, ainv0, smaxA, T1); put_planes(P2, ainv2, smaxB, T2); }
   // ---- d s_value = dZ_sg . Wsg^T + d o * xg ; d x_value = dZ_xg . Wxg^T + d o * sg
   step(P0, a.w[7]);
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
     zero_invalid(T1);
     put_max(smaxA, T1);
   }
-  __syncthreads();
+  cb_barrier();
   if (act) put_planes(P1, ainv1, smaxA, T1);
   step(P2, a.w[8]);
   if (act) {
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
     zero_invalid(T2);
     put_max(smaxB, T2);
   }
-  __syncthreads();
+  cb_barrier();
   if (act) put_planes(P0, ainv0, smaxB, T2);
   // ---- gradients of the two attention outputs
   step(P1, a.w[9]);

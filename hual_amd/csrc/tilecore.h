@@ -93,6 +93,16 @@ __device__ __forceinline__ void cb_segment(int row, const hual::RowSpace& rs, in
   else { const int q = row - rs.Nv; const int b = q / rs.L; lo = rs.Nv + b * rs.L; hi = lo + rs.L; }
 }
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the fence makes
+// hipcc wait for every outstanding global store of the wave (s_waitcnt vmcnt(0)) - at one workgroup per CU that puts a
+// store round trip in front of every barrier of an epilogue.  The fused kernels never read back their own global
+// stores, so they only wait for their LDS operations.
+__device__ __forceinline__ void cb_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // One LDS-DMA piece (global_load_lds_dwordx4: 64 lanes x 16 bytes -> 1 KB of LDS at the wave-uniform byte address `lds`),
 // issued from inline asm so that hipcc does not know about the pending LDS write.  With the builtin the compiler keeps a
 // DMA in flight "visible" to its wait insertion: every LDS read that may alias the destination and every __syncthreads()
