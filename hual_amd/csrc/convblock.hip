@@ -171,7 +171,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
     cb_barrier();
     // ---------------- P2: pointwise convolution on the matrix cores
     f32x4 acc[4];
-    if (mt < ntile) cb_tile_mma(Ahi, Alo, Wl, mt, ch, lane, acc);
+    if (mt < ntile) cb_tile_mma_t<64 * 256>(Ahi, Wl, mt, ch, lane, acc);
     cb_barrier();                                         // operand planes and weight image are free again
     if (l + 1 < 4) cb_dma_weight(a.l[l + 1].wimg, Wl, wave, lane, CB_THREADS / 64);
     // ---------------- P3: bias, relu, dropout, residual
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
     cb_barrier();                                          // (1) operand planes + parameters complete
     // ---- G: dC_i = dZ_i . W_i^T
     f32x4 acc[4];
-    if (mt < ntile) cb_tile_mma(Ahi, Alo, Wl, mt, ch, lane, acc);
+    if (mt < ntile) cb_tile_mma_t<64 * 256>(Ahi, Wl, mt, ch, lane, acc);
     cb_barrier();                                          // (2) planes and weight image free
     if (mt < ntile) {
       const int j = lane & 15, g = lane >> 4;

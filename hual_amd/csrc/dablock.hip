@@ -105,7 +105,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropC
     const char* P = a.src[p] ? P2 : P1;
     const float* ai = a.src[p] ? ainv2 : ainv1;
     f32x4 accp[4];
-    if (mt < ntile) cb_tile_mma(P, P + LP_ROWS * 256, Wl, mt, ch, lane, accp);
+    if (mt < ntile) cb_tile_mma_t<LP_ROWS * 256>(P, Wl, mt, ch, lane, accp);
     cb_barrier();                                         // image consumed
     if (p + 1 < a.nproj) cb_dma_weight(a.wimg[p + 1], Wl, wave, lane, CB_THREADS / 64);
     if (mt < ntile) {
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   const bool act = mt < ntile;                                     // wave owns an output tile
   const DropRegs dr = drop_load(drop);
 
+  HUAL_STAMP(0);
   cb_dma_weight(a.w[0], Wl, wave, lane, CB_THREADS / 64);
   // ---- everything read from HBM is requested up front: the attention outputs and ln1 rows of the row phases, the residual
   // rows / row mask of the epilogues, the small vectors
@@ -197,11 +198,15 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
 
   // one weight step: wait for the image, multiply slot P by it, free the image and request the next one
   f32x4 accp[4];
+  int si = 1;
   auto step = [&](const char* P, const float* next) {
+    HUAL_STAMP(si); ++si;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     cb_barrier();
-    if (act) cb_tile_mma(P, P + DP_PLANE, Wl, mt, ch, lane, accp);
+    HUAL_STAMP(si); ++si;
+    if (act) cb_tile_mma_t<DP_PLANE>(P, Wl, mt, ch, lane, accp);
     cb_barrier();
+    HUAL_STAMP(si); ++si;
     if (next) cb_dma_weight(next, Wl, wave, lane, CB_THREADS / 64);
   };
   // acc (+)= accp * inverse operand scale of the rows
@@ -383,6 +388,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
       save(a.out, r, v);
     }
   }
+  HUAL_STAMP(si);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     const char* S = (k & 1) ? S1 : S0;
     const float* ai = (k & 1) ? ainv1 : ainv0;
     f32x4 accp[4];
-    if (act) cb_tile_mma(S, S + LB_ROWS * 256, Wl, mt, ch, lane, accp);
+    if (act) cb_tile_mma_t<LB_ROWS * 256>(S, Wl, mt, ch, lane, accp);
     cb_barrier();
     if (k + 1 < a.nsteps) cb_dma_weight(a.wimg_t[k + 1], Wl, wave, lane, CB_THREADS / 64);
     if (act) {
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   auto step = [&](const char* P, const float* next) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     cb_barrier();
-    if (act) cb_tile_mma(P, P + DP_PLANE, Wl, mt, ch, lane, accp);
+    if (act) cb_tile_mma_t<DP_PLANE>(P, Wl, mt, ch, lane, accp);
     cb_barrier();
     if (next) cb_dma_weight(next, Wl, wave, lane, CB_THREADS / 64);
   };
@@ -746,6 +752,13 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
     for (int r = 0; r < 4; ++r) save(a.d_xatt, r, T2[r]);
   }
 }
+
+#ifdef HUAL_STAMPS
+__device__ unsigned long long g_hual_stamps[512 * HUAL_STAMP_SLOTS];
+extern "C" int hual_debug_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hual_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 
 namespace hual {
 

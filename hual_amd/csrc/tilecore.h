@@ -7,6 +7,16 @@
 #include "bf16x3.h"
 #include "philox.h"
 
+// ---- debug: in-kernel phase timestamps (-DHUAL_STAMPS, scripts/exp/stamps.py).  Thread 0 of every workgroup writes the
+// shader clock at phase boundaries into a device-global table read back through hual_debug_stamps().
+#ifdef HUAL_STAMPS
+#define HUAL_STAMP_SLOTS 64
+extern __device__ unsigned long long g_hual_stamps[512 * HUAL_STAMP_SLOTS];
+#define HUAL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (i) < HUAL_STAMP_SLOTS) g_hual_stamps[blockIdx.x * HUAL_STAMP_SLOTS + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HUAL_STAMP(i) do { } while (0)
+#endif
+
 #define LN_EPS 1e-6f   // models/layers.py:15
 #define CB_THREADS 512
 #define CB_TILE 16384            // one [64][128 x 16 bit] tile
@@ -121,46 +131,44 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 }
 
 // LDS-DMA of one [128,128] weight image (pack_weights_kernel layout: per K row 256 B of fp16 high parts, 256 B of
-// residuals) into two stages of {hi tile, lo tile}; the XOR swizzle of tile256_off is applied on the global side
+// residuals) into two stages of {hi tile, lo tile}; the XOR swizzle of tile256_off is applied on the global side.
+// All 8 waves of the workgroup take part, 8 pieces of 1 KB (4 tile rows) each: wave w, piece k is tile row group
+// w + 8 (k & 1) of plane (k >> 1) & 1 of stage k >> 2, so the swizzle term of a lane ((row >> 2) & 3 = w & 3) and with it
+// the lane's byte offset are the same for all 8 pieces - one pointer per lane, compile-time strides per piece.
 __device__ __forceinline__ void cb_dma_weight(const float* wimg, char* Wl, int wave, int lane, int nwaves) {
-  const char* img = reinterpret_cast<const char*>(wimg);
+  (void)nwaves;                                       // CB_THREADS / 64 = 8 at every call site
   const int chp = lane & 15, rr = lane >> 4;
-  const uint32_t wbase = __builtin_amdgcn_readfirstlane(lds_addr_of(Wl));
-  for (int pc = wave; pc < 64; pc += nwaves) {
-    const int st = pc >> 5, pl = pc & 31;
-    const int r = 4 * (pl & 15) + rr;
-    const int ch = chp ^ (((r & 3) << 2) | ((r >> 2) & 3));
-    const char* src = img + (size_t)(64 * st + r) * 512 + (pl >> 4) * 256 + 16 * ch;
-    glds16_asm(src, __builtin_amdgcn_readfirstlane(wbase + (uint32_t)(st * CB_STAGE + pl * 1024)));
-  }
+  const char* lp = reinterpret_cast<const char*>(wimg) + 2048 * wave + 512 * rr + 16 * (chp ^ ((rr << 2) | (wave & 3)));
+  const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds_addr_of(Wl) + 1024u * (uint32_t)wave);
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    glds16_asm(lp + (32768 * (k >> 2) + 16384 * (k & 1) + 256 * ((k >> 1) & 1)), ldsw + (uint32_t)(CB_STAGE * (k >> 2) + 8192 * (k & 3)));
 }
 
 // 16 x 64 output tile of A[16 rows of the LDS planes] . W: wave-level, accumulators in the column order of the epilogue
-// (accumulator t, register r, lane (j, g) = row 4g + r, column 64 ch + 4j + t)
-__device__ __forceinline__ void cb_tile_mma(const char* Ahi, const char* Alo, const char* Wl, int mt, int ch, int lane,
-                                            f32x4 (&acc)[4]) {
+// (accumulator t, register r, lane (j, g) = row 4g + r, column 64 ch + 4j + t).  The instruction stream is written out by
+// scripts/gen_tile_mma.py (software-pipelined LDS reads under the MFMAs; same summation order as the plain loop:
+// k-step major, hi.hi + hi.lo + lo.hi per 32-deep step).  ALO = byte distance from the hi to the lo operand plane.
+#include "tile_mma_asm.inc"
+template <int ALO>
+__device__ __forceinline__ void cb_tile_mma_t(const char* Ahi, const char* Wl, int mt, int ch, int lane, f32x4 (&acc)[4]) {
   const int j = lane & 15, g = lane >> 4;
   const int tq = (lane >> 2) & 3, tp = lane & 3;
+  const uint32_t ab = lds_addr_of(Ahi), wb = lds_addr_of(Wl);
+  uint32_t aa[4], wa[8];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < 4; ++ks) aa[ks] = ab + (uint32_t)tile256_off(16 * mt + j, 4 * ks + g);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int aoff = tile256_off(16 * mt + j, 4 * ks + g);
-    const f16x8 ah = *reinterpret_cast<const f16x8*>(Ahi + aoff);
-    const f16x8 al = *reinterpret_cast<const f16x8*>(Alo + aoff);
-    const char* hi = Wl + (ks >> 1) * CB_STAGE;
-    const int r0 = 32 * (ks & 1) + 8 * g + tq, r1 = r0 + 4;
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int chunk = 8 * ch + 2 * t + (tp >> 1);
-      const int o0 = tile256_off(r0, chunk) + 8 * (tp & 1), o1 = tile256_off(r1, chunk) + 8 * (tp & 1);
-      const f16x8 wh = join_tr_f16(lds_read_tr16(hi, o0), lds_read_tr16(hi, o1));
-      const f16x8 wl = join_tr_f16(lds_read_tr16(hi + CB_TILE, o0), lds_read_tr16(hi + CB_TILE, o1));
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, acc[t], 0, 0, 0);
-    }
-  }
+    for (int d = 0; d < 2; ++d)
+      wa[2 * t + d] = wb + (uint32_t)(tile256_off(8 * g + tq + 4 * d, 8 * ch + 2 * t + (tp >> 1)) + 8 * (tp & 1));
+  asm volatile(CB_TILE_MMA_TEXT
+               : [c0] "=&v"(acc[0]), [c1] "=&v"(acc[1]), [c2] "=&v"(acc[2]), [c3] "=&v"(acc[3])
+               : [a0] "v"(aa[0]), [a1] "v"(aa[1]), [a2] "v"(aa[2]), [a3] "v"(aa[3]),
+                 [w00] "v"(wa[0]), [w01] "v"(wa[1]), [w10] "v"(wa[2]), [w11] "v"(wa[3]),
+                 [w20] "v"(wa[4]), [w21] "v"(wa[5]), [w30] "v"(wa[6]), [w31] "v"(wa[7]), [alo] "i"(ALO)
+               : "memory", CB_TILE_MMA_CLOBBERS);
 }
 
 // row of the operand planes: scale to fp16 range, split, store (8 bytes per lane and plane); returns the inverse scale

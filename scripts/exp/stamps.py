@@ -1,32 +1,38 @@
-import os, sys, ctypes, numpy as np, torch
-# NOTE: needs the temporary STAMP() instrumentation of gemm_bf16_body + hual_debug_stamps() (see git history of this file's commit);
-# kept as the record of how the in-kernel phase split quoted in DESIGN.md 6 was measured.
-sys.path.insert(0, os.getcwd())
+"""Phase timeline of da_post_kernel from in-kernel clock stamps (debug build: HUAL_STAMPS=1 python -m hual_amd.build)."""
+import ctypes, sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from hual_amd import lib
 from hual_amd.model import SeqPAN
+from hual_amd.train import Trainer
+dev = torch.device('cuda', 0)
 cfg = lib.make_cfg(vdim=1024, max_vlen=128, num_words=1000, num_chars=40)
 wv = np.random.default_rng(777).normal(0, 0.4, size=(998, 300)).astype(np.float32)
-m = SeqPAN(cfg, wv)
+model = SeqPAN(cfg, wv, device=dev, seed=12345, rng_seed=12345)
 b = bench.synth_batch(64, 128, 20, 8, 1024, 1000, 40, 12345)
-labels = (b['y1'], b['y2'], b['match'], b['inner'])
-for _ in range(20):
-    m.forward(b['video'], b['lens'], b['word_ids'], b['char_ids'], drop_rate=0.2, labels=labels)
+tr = Trainer(model, world=1, use_graph=False)
+tr.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'])
+for _ in range(30):
+    tr.step(lr=1e-4, drop_rate=0.2)
 torch.cuda.synchronize()
-buf = torch.zeros(4096, dtype=torch.int64, device='cuda')
 l = lib.load()
-l.hual_debug_stamps.argtypes = [ctypes.c_void_p]
-l.hual_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
-m.forward(b['video'], b['lens'], b['word_ids'], b['char_ids'], drop_rate=0.2, labels=labels)
-torch.cuda.synchronize()
-t = buf.cpu().numpy()
-n = int((t != 0).sum())
-t = t[:n]
-print('stamps', n)
-# stamps per job (nstages<=2): start, before-wait, after-wait, after-barrier, before-epilogue, end  => 6
-d = np.diff(t)
-for i in range(0, n, 6):
-    seg = t[i:i + 6]
-    if len(seg) < 6: break
-    print(i // 6, 'issue %5d  wait %5d  barrier %5d  compute %5d  epilogue %5d  | gap-to-next %s' % (
-        seg[1] - seg[0], seg[2] - seg[1], seg[3] - seg[2], seg[4] - seg[3], seg[5] - seg[4], (t[i + 6] - seg[5]) if i + 6 < n else '-'))
+n = 512 * 64
+buf = (ctypes.c_ulonglong * n)()
+l.hual_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+rc = l.hual_debug_stamps(buf, n)
+st = np.frombuffer(buf, dtype=np.uint64).reshape(512, 64).astype(np.int64)
+nb = int((st[:, 0] > 0).sum())
+st = st[:nb]
+ns = int((st[0] > 0).sum())
+print('rc', rc, 'blocks', nb, 'stamps', ns)
+d = np.diff(st[:, :ns], axis=1)
+tot = st[:, ns - 1] - st[:, 0]
+print('total cycles: mean %.0f min %d max %d' % (tot.mean(), tot.min(), tot.max()))
+print('kernel span (first start..last end) cycles:', st[:, ns - 1].max() - st[:, 0].min())
+names = []
+for k in range(ns - 1):
+    ph = ['epilogue/rows -> wait', 'dma wait+barrier', 'mma+barrier'][k % 3] if k else 'start'
+    print('%2d %-24s mean %7.0f  p10 %7.0f  p90 %7.0f' % (k, ['rows/epilogue before', 'dma wait + barrier', 'mma + barrier'][k % 3], d[:, k].mean(), np.percentile(d[:, k], 10), np.percentile(d[:, k], 90)))
+for nm, sel in (('before (epilogue+row phases)', 0), ('dma wait + barrier', 1), ('mma + barrier', 2)):
+    print('%-30s sum of means %8.0f cycles' % (nm, d[:, sel::3].mean(axis=0).sum()))
