@@ -95,6 +95,39 @@ int hual_attention_fwd(const float* Q, int ldq, const float* K, const float* V, 
   return launch_attn_fwd(&j, 1, d, (hipStream_t)stream);
 }
 
+int hual_attention_fwd_save(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
+                            int Tk, const float* qmask, const float* kmask, float* stats, uint8_t* keep_bytes, int ldm,
+                            const uint32_t* rng_state, float drop_rate, int drop_site, void* stream) {
+  HUAL_REQUIRE(Q && K && V && O && qmask && kmask && stats, "hual_attention_fwd_save: null pointer");
+  HUAL_REQUIRE(drop_rate >= 0.f && drop_rate < 1.f && (drop_rate == 0.f || (rng_state && keep_bytes)), "hual_attention_fwd_save: dropout needs rng_state and keep_bytes");
+  AttnJob j;
+  attn_job_init(j);
+  j.Q = Q; j.ldq = ldq; j.K = K; j.V = V; j.ldkv = ldkv; j.O = O; j.ldo = ldo;
+  j.B = B; j.Tq = Tq; j.Tk = Tk; j.qrow0 = 0; j.krow0 = 0; j.qmask = qmask; j.kmask = kmask;
+  j.stats = stats; j.dmask = keep_bytes; j.ldm = ldm; j.drop_site = drop_rate > 0.f ? drop_site : -1; j.drop_row0 = 0;
+  DropCfg d = make_dropcfg(rng_state, drop_rate);
+  return launch_attn_fwd(&j, 1, d, (hipStream_t)stream);
+}
+
+int hual_attention_bwd(const float* Q, int ldq, const float* K, const float* V, int ldkv, const float* O, int ldo,
+                       const float* stats, const uint8_t* keep_bytes, int ldm, const float* dO, int lddo, float* dQ, int lddq,
+                       float* dK, float* dV, int lddkv, int B, int Tq, int Tk, const float* qmask, const float* kmask,
+                       const uint32_t* rng_state, float drop_rate, int drop_site, void* stream) {
+  HUAL_REQUIRE(Q && K && V && O && stats && dO && dQ && dK && dV && qmask && kmask, "hual_attention_bwd: null pointer");
+  HUAL_REQUIRE(drop_rate >= 0.f && drop_rate < 1.f && (drop_rate == 0.f || (rng_state && keep_bytes)), "hual_attention_bwd: dropout needs rng_state and keep_bytes");
+  AttnJob j;
+  attn_job_init(j);
+  j.Q = Q; j.ldq = ldq; j.K = K; j.V = V; j.ldkv = ldkv; j.O = const_cast<float*>(O); j.ldo = ldo;
+  j.B = B; j.Tq = Tq; j.Tk = Tk; j.qrow0 = 0; j.krow0 = 0; j.qmask = qmask; j.kmask = kmask;
+  j.stats = const_cast<float*>(stats); j.dmask = const_cast<uint8_t*>(keep_bytes); j.ldm = ldm;
+  j.drop_site = drop_rate > 0.f ? drop_site : -1; j.drop_row0 = 0;
+  j.dO = dO; j.lddo = lddo; j.dQ = dQ; j.lddq = lddq; j.dK = dK; j.dV = dV; j.lddkv = lddkv;
+  DropCfg d = make_dropcfg(rng_state, drop_rate);
+  return launch_attn_bwd(&j, 1, d, (hipStream_t)stream);
+}
+
+int hual_attention_keep_row_bytes(int Tk) { return attn_ldm(Tk); }
+
 int hual_span_argmax(const float* start_logits, const float* end_logits, const float* vmask, int64_t* start_index,
                      int64_t* end_index, int B, int T, void* stream) {
   HUAL_REQUIRE(start_logits && end_logits && vmask && start_index && end_index && B > 0 && T > 0, "hual_span_argmax: null / empty");

@@ -12,14 +12,14 @@ struct AttnJob {
   const float* Q; int ldq;
   const float* K; const float* V; int ldkv;
   float* O; int ldo;                       // forward output, merged heads [rows,128] (an input of the backward)
-  float* stats;                            // [2][B*Tq*8]: row max, 1/rowsum per (query, head); written by the forward
-                                           // when non-null, required by the backward
+  float* stats;                            // [2][B*Tq*8]: row max (of the scores in the log2 domain), 1/rowsum per
+                                           // (query, head); written by the forward when non-null, required by the backward
   int B, Tq, Tk, qrow0, krow0;
   const float* qmask; const float* kmask;  // [rows] floats
-  int drop_site; uint32_t drop_row0;       // Philox row = (drop_row0 + qrow) * 8 + head ; col = key index
-  // keep bits of the dropout on the probabilities, one byte per Philox call (4 keys): byte [((b*Tq + q)*8 + h)*ldm + key/4].
-  // Written by the forward when non-null, read by both backward kernels (null: they redo the Philox draws).
-  uint8_t* dmask; int ldm;                 // ldm >= 4*ceil(Tk/16), multiple of 4
+  int drop_site; uint32_t drop_row0;       // Philox row = (drop_row0 + qrow) * 8 + head ; 8-bit decisions, see attn.hip
+  // keep bits of the dropout on the probabilities: row ((b*Tq + q)*8 + h) of ldm bytes; key k = 16 kt + 4 g + r is bit r of
+  // byte g * (ldm / 4) + kt.  Written by the forward when non-null; the backward needs it whenever dropout is on.
+  uint8_t* dmask; int ldm;                 // ldm >= attn_ldm(Tk), multiple of 16
   // backward
   const float* dO; int lddo;
   float* dQ; int lddq;                     // written (not accumulated)
@@ -32,6 +32,7 @@ struct AttnBatch {
 };
 
 void attn_job_init(AttnJob& j);
+int attn_ldm(int Tk);                     // bytes per keep-byte row for Tk keys
 int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t s);
 // dQ, dK, dV in one launch (needs O and stats of the forward)
 int launch_attn_bwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t s);

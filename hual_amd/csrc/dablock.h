@@ -30,7 +30,7 @@ struct LnProjArgs {
   int act[HUAL_LNPROJ_MAX];                        // 1: relu
   int out_site[HUAL_LNPROJ_MAX];                   // >= 0: dropout on the output
   int add_x[HUAL_LNPROJ_MAX];                      // 1: + the layer-norm input rows (residual; needs g2 == x2 == null)
-  int R; int MT;                                   // rows, rows per workgroup (16, 32, 48 or 64)
+  int R; int MT;                                   // rows, rows per workgroup (1..64)
   uint32_t drop_row0;
 };
 int ln_proj_rows(int R);
@@ -45,7 +45,7 @@ struct DaPostArgs {
   float *sv, *xv, *sg, *xg, *o, *gd, *gate, *val, *mha, *res, *l2, *out;       // [R,128] saved tensors
   float *mean2, *rstd2;                                                         // [R]
   int site;                // dropout sites site+2 (dense_1 output), site+3 (LN2 output), site+4 (dense_2 output)
-  int R; int MT;           // MT = 16, 32 or 48
+  int R; int MT;           // MT = 1..48
   uint32_t drop_row0;
 };
 int da_post_rows(int R);

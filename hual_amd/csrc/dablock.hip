@@ -38,8 +38,9 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropC
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
-  const int MT = a.MT, ntile = MT >> 4, R = a.R;
+  const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
   const int r0 = blockIdx.x * MT;
+  const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int mt = wave >> 1, ch = wave & 1;
   const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
   const DropRegs dr = drop_load(drop);
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropC
   for (int u = 0; u < 4; ++u) {
     const int lr = grp + 16 * u, row = r0 + lr;
     if (lr >= MT) continue;
-    const bool ok = row < R;
+    const bool ok = row < RE;
     float4 xr = xv[u];
     if (a.xa) {
       float4 t = av[u];
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropC
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int lr = 16 * mt + 4 * g + r, row = r0 + lr;
-      if (row >= R) continue;
+      if (row >= RE) continue;
       float4 v = make_float4(acc[r].x + bias[p].x, acc[r].y + bias[p].y, acc[r].z + bias[p].z, acc[r].w + bias[p].w);
       if (a.act[p]) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
       if (a.out_site[p] >= 0 && dr.enabled) v = apply_drop4_r(dr, (uint32_t)a.out_site[p], a.drop_row0 + (uint32_t)row, (uint32_t)(ecol >> 2), v);
@@ -152,8 +153,9 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
-  const int MT = a.MT, ntile = MT >> 4, R = a.R;
+  const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
   const int r0 = blockIdx.x * MT;
+  const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int mt = wave >> 1, ch = wave & 1;
   const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
   const bool act = mt < ntile;                                     // wave owns an output tile
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   for (int u = 0; u < 3; ++u) {
     const int lr = grp + 16 * u;
     if (lr >= MT) continue;
-    const bool ok = r0 + lr < R;
+    const bool ok = r0 + lr < RE;
     const float i0 = cb_store_operand(P0, P0 + DP_PLANE, lr, l32, ok ? sa[u] : f4zero());
     const float i1 = cb_store_operand(P1, P1 + DP_PLANE, lr, l32, ok ? xa[u] : f4zero());
     if (l32 == 0) { ainv0[lr] = ok ? i0 : 0.f; ainv1[lr] = ok ? i1 : 0.f; }
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   auto addb = [&](float4 v, int k) { const float4 b = bl[k * 32 + (ecol >> 2)]; return make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w); };
   auto save = [&](float* dst, int r, float4 v) {
     const int row = r0 + 16 * mt + 4 * g + r;
-    if (row < R) st4(dst + (size_t)row * HUAL_D + ecol, v);
+    if (row < RE) st4(dst + (size_t)row * HUAL_D + ecol, v);
   };
   // tile -> operand slot, part 1: half-row maxima to LDS (the other column half of a row lives in the partner wave)
   auto put_max = [&](const float4 (&v)[4]) {
@@ -243,12 +245,12 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
       const int off = tile256_off(lr, ecol >> 3) + 8 * (j & 1);
       *reinterpret_cast<uint2*>(P + off) = h;
       *reinterpret_cast<uint2*>(P + DP_PLANE + off) = l;
-      if (ch == 0 && j == 0) ai[lr] = (r0 + lr < R) ? inv : 0.f;
+      if (ch == 0 && j == 0) ai[lr] = (r0 + lr < RE) ? inv : 0.f;
     }
   };
   auto zero_invalid = [&](float4 (&v)[4]) {      // rows beyond the tensor carry zeros through the chain
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (r0 + 16 * mt + 4 * g + r >= R) v[r] = f4zero();
+    for (int r = 0; r < 4; ++r) if (r0 + 16 * mt + 4 * g + r >= RE) v[r] = f4zero();
   };
 
   float4 SV[4], XV[4], T1[4], T2[4];
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   for (int u = 0; u < 3; ++u) {
     const int lr = grp + 16 * u;
     if (lr >= MT) continue;
-    const bool ok = r0 + lr < R;
+    const bool ok = r0 + lr < RE;
     const float i0 = cb_store_operand(P0, P0 + DP_PLANE, lr, l32, ok ? l1[u] : f4zero());
     if (l32 == 0) ainv0[lr] = ok ? i0 : 0.f;
   }
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     for (int u = 0; u < 3; ++u) {
       const int lr = grp + 16 * u, row = r0 + lr;
       if (lr >= MT) continue;
-      const bool ok = row < R;
+      const bool ok = row < RE;
       float mean, rstd;
       const float4 xh = ln_row(scratch[lr * 32 + l32], mean, rstd);
       float4 y = cb_fma(xh, g2, b2);
@@ -406,8 +408,9 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
-  const int MT = a.MT, ntile = MT >> 4, R = a.R;
+  const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
   const int r0 = blockIdx.x * MT;
+  const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int mt = wave >> 1, ch = wave & 1;
   const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
   const bool act = mt < ntile;
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     for (int u = 0; u < 4; ++u) {
       const int lr = grp + 16 * u, row = r0 + lr;
       if (lr >= MT) continue;
-      const bool ok = row < R;
+      const bool ok = row < RE;
       float4 v = ok ? nv[u] : f4zero();
       if (a.a_site[k] >= 0) {
         if (dr.enabled) v = apply_drop4_r(dr, (uint32_t)a.a_site[k], a.drop_row0 + (uint32_t)row, (uint32_t)l32, v);
@@ -575,8 +578,9 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
-  const int MT = a.MT, ntile = MT >> 4, R = a.R;
+  const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
   const int r0 = blockIdx.x * MT;
+  const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int mt = wave >> 1, ch = wave & 1;
   const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
   const bool act = mt < ntile;
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
     for (int u = 0; u < 3; ++u) {
       const int lr = grp + 16 * u;
       if (lr >= MT) continue;
-      const bool ok = r0 + lr < R;
+      const bool ok = r0 + lr < RE;
       const float inv = cb_store_operand(P1, P1 + DP_PLANE, lr, l32, ok ? zv[u] : f4zero());
       if (l32 == 0) ainv1[lr] = ok ? inv : 0.f;
     }
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   };
   auto save = [&](float* dst, int r, float4 v) {
     const int row = r0 + 16 * mt + 4 * g + r;
-    if (row < R) st4(dst + (size_t)row * HUAL_D + ecol, v);
+    if (row < RE) st4(dst + (size_t)row * HUAL_D + ecol, v);
   };
   auto put_max = [&](float* sm, const float4 (&v)[4]) {
 #pragma unroll
@@ -637,12 +641,12 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
       const int off = tile256_off(lr, ecol >> 3) + 8 * (j & 1);
       *reinterpret_cast<uint2*>(P + off) = h;
       *reinterpret_cast<uint2*>(P + DP_PLANE + off) = l;
-      if (ch == 0 && j == 0) ai[lr] = (r0 + lr < R) ? inv : 0.f;
+      if (ch == 0 && j == 0) ai[lr] = (r0 + lr < RE) ? inv : 0.f;
     }
   };
   auto zero_invalid = [&](float4 (&v)[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (r0 + 16 * mt + 4 * g + r >= R) v[r] = f4zero();
+    for (int r = 0; r < 4; ++r) if (r0 + 16 * mt + 4 * g + r >= RE) v[r] = f4zero();
   };
 
   float4 T1[4], T2[4], U1[4], U2[4], U3[4], U4[4];
@@ -762,18 +766,21 @@ extern "C" int hual_debug_stamps(unsigned long long* out, int n) {
 
 namespace hual {
 
+// rows per workgroup: one workgroup per CU when the rows allow it (every workgroup streams all the weight images of its
+// launch, so fewer, taller workgroups cost nothing extra).  Any count from 16 to max_rows: the matrix phase works on
+// whole 16-row tiles, rows of the last tile beyond the workgroup's own are computed on stale operands and discarded.
 static int tile_rows(int R, int max_rows) {
-  int t = cdiv(cdiv(R, 256), 16);
-  if (t < 1) t = 1;
-  if (16 * t > max_rows) t = max_rows / 16;
-  return 16 * t;
+  int t = cdiv(R, 256);
+  if (t < 16) t = 16;
+  if (t > max_rows) t = max_rows;
+  return t;
 }
 int ln_proj_rows(int R) { return tile_rows(R, LP_ROWS); }
 int da_post_rows(int R) { return tile_rows(R, DP_ROWS); }
 
 int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.x && a.g1 && a.b1 && a.y1 && a.mean && a.rstd && a.R > 0, "ln_proj: null / empty");
-  HUAL_REQUIRE(a.MT >= 16 && a.MT <= LP_ROWS && (a.MT % 16) == 0, "ln_proj: MT must be 16, 32, 48 or 64");
+  HUAL_REQUIRE(a.MT >= 1 && a.MT <= LP_ROWS, "ln_proj: MT must be 1..64");
   HUAL_REQUIRE(a.nproj >= 1 && a.nproj <= HUAL_LNPROJ_MAX, "ln_proj: projection count");
   HUAL_REQUIRE(!a.g2 || (a.b2 && a.y2), "ln_proj: second layer norm incomplete");
   HUAL_REQUIRE(!(a.g2 && a.x2), "ln_proj: second layer norm and raw second operand are exclusive");
@@ -795,7 +802,7 @@ int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s) {
 
 int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.s_att && a.x_att && a.ln1 && a.x && a.rowmask && a.ln2_g && a.ln2_b && a.R > 0, "da_post: null / empty");
-  HUAL_REQUIRE(a.MT >= 16 && a.MT <= DP_ROWS && (a.MT % 16) == 0, "da_post: MT must be 16, 32 or 48");
+  HUAL_REQUIRE(a.MT >= 1 && a.MT <= DP_ROWS, "da_post: MT must be 1..48");
   for (int k = 0; k < 11; ++k) HUAL_REQUIRE(a.w[k] != nullptr, "da_post: null weight image");
   for (int k = 0; k < 9; ++k) HUAL_REQUIRE(a.b[k] != nullptr, "da_post: null bias");
   HUAL_REQUIRE(a.sv && a.xv && a.sg && a.xg && a.o && a.gd && a.gate && a.val && a.mha && a.res && a.l2 && a.out && a.mean2 && a.rstd2,
@@ -814,7 +821,7 @@ int ln_proj_bwd_blocks(int R) { return cdiv(R, ln_proj_bwd_rows(R)); }
 
 int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.nsteps >= 1 && a.nsteps <= HUAL_LNBWD_MAX && a.R > 0, "ln_proj_bwd: step count / rows");
-  HUAL_REQUIRE(a.MT >= 16 && a.MT <= LB_ROWS && (a.MT % 16) == 0, "ln_proj_bwd: MT must be 16, 32, 48 or 64");
+  HUAL_REQUIRE(a.MT >= 1 && a.MT <= LB_ROWS, "ln_proj_bwd: MT must be 1..64");
   HUAL_REQUIRE(a.x && a.mean && a.rstd && a.g1 && a.dx && a.part, "ln_proj_bwd: null tensor");
   bool any1 = false;
   for (int k = 0; k < a.nsteps; ++k) {
@@ -834,7 +841,7 @@ int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t 
 
 int launch_da_mid_bwd(const DaMidBwdArgs& a, hipStream_t s) {
   HUAL_REQUIRE(a.dz1 && a.gate && a.val && a.sg && a.xg && a.sv && a.xv && a.R > 0, "da_mid_bwd: null / empty");
-  HUAL_REQUIRE(a.MT >= 16 && a.MT <= DP_ROWS && (a.MT % 16) == 0, "da_mid_bwd: MT must be 16, 32 or 48");
+  HUAL_REQUIRE(a.MT >= 1 && a.MT <= DP_ROWS, "da_mid_bwd: MT must be 1..48");
   for (int k = 0; k < 10; ++k) HUAL_REQUIRE(a.w[k] != nullptr, "da_mid_bwd: null weight image");
   HUAL_REQUIRE(a.d_sc && a.d_val && a.d_ln1a && a.d_g && a.dz_sg && a.dz_xg && a.d_sv && a.d_xv && a.d_satt && a.d_xatt, "da_mid_bwd: null output");
   HUAL_DYN_LDS(da_mid_bwd_kernel, 160 * 1024);

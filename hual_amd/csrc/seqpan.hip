@@ -275,7 +275,7 @@ void set_embed_scratch(EmbedArgs& ea, float* base, int Nq, int C, int char_dim) 
 // keep-byte buffer of an attention job's probability dropout (attn.h): B*Tq*8 rows of ldm bytes
 // + the softmax statistics the forward leaves for the backward
 void set_dmask(Ctx& c, AttnJob& a, const std::string& name) {
-  a.ldm = 4 * cdiv(a.Tk, 16);
+  a.ldm = attn_ldm(a.Tk);
   a.dmask = reinterpret_cast<uint8_t*>(c.buf(name, (size_t)a.B * a.Tq * 8, a.ldm / 4));
   a.stats = c.buf(name + ".st", (size_t)2 * a.B * a.Tq * 8, 1);
 }

@@ -216,6 +216,23 @@ int hual_layer_norm_fwd(const float* x, const float* gamma, const float* beta, f
 int hual_attention_fwd(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
                        int Tk, const float* qmask, const float* kmask, void* stream);
 
+/* The same with what a backward pass needs: stats [2][B*Tq*8] (row max of the scaled scores in the log2 domain, 1 / row sum,
+ * per query and head) and - when drop_rate > 0 - the dropout of layers.py:86,91 / modules.py:114 on the probabilities with
+ * the build's Philox stream (rng_state = device u32[3] {seed lo, seed hi, offset}, call site `drop_site`, RNG row =
+ * query row * 8 + head; 8-bit decisions, see DESIGN.md "Dropout") and its keep bits: row (b*Tq + q)*8 + h of `ldm` bytes,
+ * ldm >= hual_attention_keep_row_bytes(Tk) and a multiple of 16. */
+int hual_attention_fwd_save(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
+                            int Tk, const float* qmask, const float* kmask, float* stats, uint8_t* keep_bytes, int ldm,
+                            const uint32_t* rng_state, float drop_rate, int drop_site, void* stream);
+int hual_attention_keep_row_bytes(int Tk);
+
+/* gradient of the attention core (tf.gradients through layers.py:80-96): dQ, dK, dV [rows,128] (written, not accumulated)
+ * from dO, the forward output O, `stats` and `keep_bytes` of hual_attention_fwd_save with the same arguments.  Tq, Tk <= 256. */
+int hual_attention_bwd(const float* Q, int ldq, const float* K, const float* V, int ldkv, const float* O, int ldo,
+                       const float* stats, const uint8_t* keep_bytes, int ldm, const float* dO, int lddo, float* dQ, int lddq,
+                       float* dK, float* dV, int lddkv, int B, int Tq, int Tk, const float* qmask, const float* kmask,
+                       const uint32_t* rng_state, float drop_rate, int drop_site, void* stream);
+
 /* ans_predictor (models/layers.py:194-203): softmax of the masked logits, upper-triangular outer product, start = argmax
  * over rows of the row maxima, end = argmax over columns of the column maxima, first index on ties.  T <= 256. */
 int hual_span_argmax(const float* start_logits, const float* end_logits, const float* vmask, int64_t* start_index,

@@ -16,6 +16,13 @@ The four 32-bit outputs belong to columns 4*c0 + {0,1,2,3}.
 An element is KEPT iff  out < thresh,  thresh = floor((1 - rate) * 2**32)
 (clamped to 2**32-1) and kept elements are scaled by float32(1)/(float32(1)-float32(rate)).
 
+The dropout on the attention probabilities (layers.py:86,91; modules.py:114 - half of all decisions of a step) draws
+16 decisions from the 16 bytes of ONE call (hual_amd/csrc/attn.hip): key k = 16 kt + 4 g + r of RNG row `rid` uses
+the call with c0 = g + 4 (kt >> 2), output word kt & 3, byte r of that word (little endian); the element is KEPT iff
+byte < t8, t8 = round(keep_prob * 256) in [1, 256] (computed from the 32-bit threshold as (thresh + 2**23) >> 24), and kept
+elements are scaled by float32(256) / float32(t8): inverted dropout at the keep probability t8 / 256 closest to
+1 - rate (0.80078 for rate 0.2), unbiased.
+
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
 import numpy as np
@@ -69,6 +76,12 @@ def keep_scale(rate):
     return np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
 
 
+def keep_threshold8(rate):
+    """8-bit threshold of the attention-probability dropout: keep iff byte < t8"""
+    t = (keep_threshold(rate) + (1 << 23)) >> 24
+    return max(1, min(t, 256))
+
+
 class DropoutRNG:
     """mask(site, rows, ncols) -> float32 array [len(rows), ncols] of {0, scale}."""
 
@@ -80,6 +93,8 @@ class DropoutRNG:
         self.k1 = (self.seed >> 32) & 0xFFFFFFFF
         self.thresh = keep_threshold(rate)
         self.scale = keep_scale(rate)
+        self.t8 = keep_threshold8(rate)
+        self.scale8 = np.float32(256.0) / np.float32(self.t8)
 
     def bits(self, site, rows, ncols):
         rows = np.asarray(rows, dtype=np.uint64).reshape(-1, 1)
@@ -94,3 +109,18 @@ class DropoutRNG:
             return np.ones((len(np.atleast_1d(rows)), ncols), dtype=np.float32)
         b = self.bits(site, rows, ncols)
         return np.where(b < np.uint32(self.thresh), self.scale, np.float32(0.0)).astype(np.float32)
+
+    def mask8(self, site, rows, ncols):
+        """8-bit decisions of the attention-probability sites: [len(rows), ncols] float32 of {0, 256 / t8}."""
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.uint64)).reshape(-1, 1)
+        if self.rate == 0.0:
+            return np.ones((rows.shape[0], ncols), dtype=np.float32)
+        k = np.arange(ncols, dtype=np.int64)
+        kt, g, r = k >> 4, (k >> 2) & 3, k & 3
+        ncall = 4 * ((int(kt.max()) >> 2) + 1)
+        c0 = np.arange(ncall, dtype=np.uint64).reshape(1, -1)
+        o = philox4x32_10(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
+        words = np.stack(o, axis=-1)                                   # [rows, call, word]
+        w = words[:, g + 4 * (kt >> 2), kt & 3]                        # [rows, ncols]
+        byte = (w >> (8 * r).astype(np.uint32)) & np.uint32(0xFF)
+        return np.where(byte < np.uint32(self.t8), self.scale8, np.float32(0.0)).astype(np.float32)

@@ -20,7 +20,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o p --outp
 st=$(ls $out/prof_$tag/*/*kernel_stats.csv $out/prof_$tag/*kernel_stats.csv 2>/dev/null | head -1)
 tr=$(ls $out/prof_$tag/*/*kernel_trace.csv $out/prof_$tag/*kernel_trace.csv 2>/dev/null | head -1)
 cp "$st" $out/${tag}_bench_kernel_stats.csv
-python $R/scripts/step_timeline.py "$tr" > $out/${tag}_step_timeline.txt 2>&1
+python $R/scripts/step_timeline.py "$tr" --stats $out/${tag}_bench_kernel_stats_workload.csv > $out/${tag}_step_timeline.txt 2>&1
 rm -rf $out/prof_$tag
 echo "[2] rocprof stats: $(head -3 $out/${tag}_bench_kernel_stats.csv | cut -c1-200)"
 short="--steps 5 --warmup 2 --prewarm 20 --no-cpu-baseline --no-roofline --no-graph"

@@ -12,7 +12,7 @@ import csv
 import glob
 import re
 import sys
-from collections import defaultdict
+from collections import Counter, defaultdict
 
 
 def short(name):
@@ -27,6 +27,7 @@ def main():
     ap.add_argument('csv')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--group', action='store_true', help='only the per-kernel-name totals')
+    ap.add_argument('--stats', default=None, help='write per-kernel launch statistics of the selected step shape to this CSV')
     a = ap.parse_args()
     paths = glob.glob(a.csv)
     rows = []
@@ -39,9 +40,26 @@ def main():
     if len(starts) < 3:
         sys.exit('no steps found')
     steps = [rows[starts[i]:starts[i + 1]] for i in range(len(starts) - 1)]
-    n = max(set(len(s) for s in steps), key=[len(s) for s in steps].count)
-    steps = [s for s in steps if len(s) == n][-a.steps:]
-    print('%d kernels per step, averaging %d steps' % (n, len(steps)))
+    # a run may hold steps of several shapes (bench.py's gpu_at_cpu_shape leg runs the c1 shape after the timed c2 steps):
+    # template arguments differ between shapes (attn_fwd_kernel<8> vs <4>), so the most frequent launch sequence is the
+    # timed workload
+    sigs = Counter(tuple(k[2] for k in s) for s in steps)
+    sig = sigs.most_common(1)[0][0]
+    n = len(sig)
+    same = [s for s in steps if tuple(k[2] for k in s) == sig]
+    print('%d kernels per step, %d steps with this launch sequence in the trace (of %d), averaging the last %d'
+          % (n, len(same), len(steps), min(a.steps, len(same))))
+    if a.stats:
+        # per-kernel launch statistics over ALL steps of that sequence (the profiler's own --stats file mixes shapes)
+        acc = defaultdict(list)
+        for s in same:
+            for k in s:
+                acc[k[2]].append(k[1] - k[0])
+        with open(a.stats, 'w') as f:
+            f.write('"Name","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs"\n')
+            for nm, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+                f.write('"%s",%d,%d,%.3f,%d,%d\n' % (nm, len(v), sum(v), sum(v) / len(v), min(v), max(v)))
+    steps = same[-a.steps:]
     tot = defaultdict(lambda: [0, 0.0, 0.0])
     t_sum = g_sum = 0.0
     for k in range(n):

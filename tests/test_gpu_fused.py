@@ -70,9 +70,10 @@ def test_fused_conv_block_backward(shape, drop, monkeypatch):
     d1, d0 = m.table.unpack(g1.cpu().numpy()), m.table.unpack(g0.cpu().numpy())
     for k in d1:
         scale = float(np.abs(d0[k]).max())
-        # (+ 3e-6 absolute: gradients that are zero in exact arithmetic - the key biases under the softmax - are rounding noise,
-        # and the float atomics of tri_bwd_kernel make the trilinear gradients vary by ~1e-6 from run to run)
-        assert float(np.abs(d1[k] - d0[k]).max()) <= 2e-5 * scale + 3e-6, (k, float(np.abs(d1[k] - d0[k]).max()), scale)
+        # (+ 1e-5 absolute: gradients that are zero in exact arithmetic - the key biases under the softmax - are rounding noise
+        # of the split-bf16 attention products (~5e-6 on sums over all rows), and the float atomics of tri_bwd_kernel make the
+        # trilinear gradients vary by ~1e-6 from run to run)
+        assert float(np.abs(d1[k] - d0[k]).max()) <= 2e-5 * scale + 1e-5, (k, float(np.abs(d1[k] - d0[k]).max()), scale)
 
 
 DA_FWD_TAPS = ['da%d.%s' % (li, n) for li in range(2) for n in ('ln1', 'lnt', 'mean', 'rstd', 'qkv', 'ktvt', 's_att', 'x_att', 's', 'x', 'sg',
@@ -118,4 +119,4 @@ def test_fused_dual_attention_backward(shape, drop, monkeypatch):
     d1, d0 = m.table.unpack(g1.cpu().numpy()), m.table.unpack(g0.cpu().numpy())
     for k in d1:
         scale = float(np.abs(d0[k]).max())
-        assert float(np.abs(d1[k] - d0[k]).max()) <= 2e-5 * scale + 3e-6, (k, float(np.abs(d1[k] - d0[k]).max()), scale)
+        assert float(np.abs(d1[k] - d0[k]).max()) <= 2e-5 * scale + 1e-5, (k, float(np.abs(d1[k] - d0[k]).max()), scale)

@@ -2,6 +2,7 @@
 (layer_norm layers.py:7-17, attention core layers.py:80-96, ans_predictor layers.py:194-203)."""
 import ctypes
 
+import numpy as np
 import pytest
 import torch
 
@@ -30,28 +31,81 @@ def test_layer_norm_fwd(dev, R):
     assert (mean.double() - mu[:, 0]).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize('B,Tq,Tk', [(2, 16, 16), (3, 37, 9), (2, 128, 128), (1, 20, 256)])
-def test_attention_fwd(dev, B, Tq, Tk):
-    from hual_amd import lib
-    g = torch.Generator().manual_seed(B * 1000 + Tq + Tk)
+def _attn_case(dev, B, Tq, Tk, seed):
+    g = torch.Generator().manual_seed(seed)
     Q = torch.randn(B * Tq, 128, generator=g).to(dev)
     K = torch.randn(B * Tk, 128, generator=g).to(dev)
     V = torch.randn(B * Tk, 128, generator=g).to(dev)
     qlen = torch.randint(1, Tq + 1, (B,), generator=g)
     klen = torch.randint(1, Tk + 1, (B,), generator=g)
+    qlen[0], klen[0] = Tq, Tk
     qm = (torch.arange(Tq)[None, :] < qlen[:, None]).float().reshape(-1).to(dev)
     km = (torch.arange(Tk)[None, :] < klen[:, None]).float().reshape(-1).to(dev)
+    return Q, K, V, qm, km
+
+
+def _attn_ref(Q, K, V, qm, km, B, Tq, Tk, drop=None):
+    """float64 restatement of layers.py:80-96 for merged heads; drop = (seed, offset, rate, site) uses the oracle's 8-bit
+    Philox decisions (oracle/philox.py mask8) with RNG row = query row * 8 + head"""
+    q = Q.view(B, Tq, 8, 16).transpose(1, 2)
+    k = K.view(B, Tk, 8, 16).transpose(1, 2)
+    v = V.view(B, Tk, 8, 16).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / 4.0
+    mask = qm.view(B, 1, Tq, 1) * km.view(B, 1, 1, Tk)
+    s = s + (1.0 - mask) * (-1e30)                               # additive mask: fully masked rows become uniform
+    pr = torch.softmax(s, -1)
+    if drop is not None:
+        from oracle import philox as px
+        seed, offset, rate, site = drop
+        rng = px.DropoutRNG(seed, offset, rate)
+        rid = (np.arange(B * Tq).reshape(B, 1, Tq) * 8 + np.arange(8).reshape(1, 8, 1)).reshape(-1)
+        m = torch.from_numpy(rng.mask8(site, rid, Tk)).to(pr.dtype).reshape(B, 8, Tq, Tk).to(pr.device)
+        pr = pr * m
+    return (pr @ v).transpose(1, 2).reshape(B * Tq, 128)
+
+
+@pytest.mark.parametrize('B,Tq,Tk', [(2, 16, 16), (3, 37, 9), (2, 128, 128), (1, 20, 256), (2, 100, 30), (1, 256, 256), (3, 1, 1)])
+def test_attention_fwd(dev, B, Tq, Tk):
+    """split-bf16 products (three passes, ~2^-16 per product) + fp32 softmax: 2e-4 absolute on O(1) outputs (bar: 1e-3)"""
+    from hual_amd import lib
+    Q, K, V, qm, km = _attn_case(dev, B, Tq, Tk, B * 1000 + Tq + Tk)
     O = torch.empty(B * Tq, 128, device=dev)
     lib.check(lib.load().hual_attention_fwd(lib.ptr(Q), 128, lib.ptr(K), lib.ptr(V), 128, lib.ptr(O), 128, B, Tq, Tk, lib.ptr(qm),
                                             lib.ptr(km), lib.stream_ptr()))
-    q = Q.double().view(B, Tq, 8, 16).transpose(1, 2)
-    k = K.double().view(B, Tk, 8, 16).transpose(1, 2)
-    v = V.double().view(B, Tk, 8, 16).transpose(1, 2)
-    s = q @ k.transpose(-1, -2) / 4.0
-    mask = qm.double().view(B, 1, Tq, 1) * km.double().view(B, 1, 1, Tk)
-    s = s + (1.0 - mask) * (-1e30)                               # additive mask: fully masked rows become uniform
-    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * Tq, 128)
-    assert (O.double() - ref).abs().max().item() < 2e-5
+    ref = _attn_ref(Q.double(), K.double(), V.double(), qm.double(), km.double(), B, Tq, Tk)
+    assert (O.double() - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize('B,Tq,Tk', [(2, 16, 16), (3, 37, 9), (2, 128, 128), (1, 20, 256), (2, 128, 20), (2, 100, 100), (1, 256, 256), (3, 1, 1)])
+@pytest.mark.parametrize('rate', [0.0, 0.2])
+def test_attention_fwd_bwd_with_dropout(dev, B, Tq, Tk, rate):
+    """hual_attention_fwd_save + hual_attention_bwd against float64 autograd of the same function with the oracle's dropout
+    mask: the kernels drop exactly the same probabilities, gradients within 1e-3 of each tensor's scale"""
+    from hual_amd import lib
+    l = lib.load()
+    Q, K, V, qm, km = _attn_case(dev, B, Tq, Tk, 77 + B * 1000 + Tq + Tk)
+    g = torch.Generator().manual_seed(5)
+    dO = torch.randn(B * Tq, 128, generator=g).to(dev)
+    seed, offset, site = 0x1234567800000042, 3, 9
+    rng_state = torch.tensor(np.array([seed & 0xffffffff, seed >> 32, offset], dtype=np.uint32).view(np.int32)).to(dev)
+    ldm = l.hual_attention_keep_row_bytes(Tk)
+    keep = torch.zeros(B * Tq * 8, ldm, dtype=torch.uint8, device=dev)
+    stats = torch.zeros(2, B * Tq * 8, device=dev)
+    O = torch.empty(B * Tq, 128, device=dev)
+    lib.check(l.hual_attention_fwd_save(lib.ptr(Q), 128, lib.ptr(K), lib.ptr(V), 128, lib.ptr(O), 128, B, Tq, Tk, lib.ptr(qm), lib.ptr(km),
+                                        lib.ptr(stats), lib.ptr(keep), ldm, lib.ptr(rng_state), rate, site, lib.stream_ptr()))
+    dQ, dK, dV = torch.full_like(Q, 7.0), torch.full_like(K, 7.0), torch.full_like(V, 7.0)      # written, not accumulated
+    lib.check(l.hual_attention_bwd(lib.ptr(Q), 128, lib.ptr(K), lib.ptr(V), 128, lib.ptr(O), 128, lib.ptr(stats), lib.ptr(keep), ldm,
+                                   lib.ptr(dO), 128, lib.ptr(dQ), 128, lib.ptr(dK), lib.ptr(dV), 128, B, Tq, Tk, lib.ptr(qm), lib.ptr(km),
+                                   lib.ptr(rng_state), rate, site, lib.stream_ptr()))
+    Qd, Kd, Vd = (t.double().cpu().requires_grad_(True) for t in (Q, K, V))
+    ref = _attn_ref(Qd, Kd, Vd, qm.double().cpu(), km.double().cpu(), B, Tq, Tk, (seed, offset, rate, site) if rate > 0 else None)
+    assert (O.double().cpu() - ref.detach()).abs().max().item() < 3e-4
+    ref.backward(dO.double().cpu())
+    for name, got, want in (('dQ', dQ, Qd.grad), ('dK', dK, Kd.grad), ('dV', dV, Vd.grad)):
+        err = (got.double().cpu() - want).abs().max().item()
+        # (+ 5e-5 absolute: with a single key the softmax is constant and dQ, dK are rounding noise around an exact zero)
+        assert err <= 1e-3 * want.abs().max().item() + 5e-5, (name, err, want.abs().max().item())
 
 
 def _span_ref(s, e, m):
