@@ -167,6 +167,8 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--aux', action='store_true', help='side stream for the alignment-loss branch of forward (experiment)')
     ap.add_argument('--prewarm', type=int, default=200, help='untimed steps before the warm-up steps (clock ramp)')
+    ap.add_argument('--video-dtype', choices=['f32', 'bf16'], default='f32',
+                    help='element type of the clip features in HBM (hual_batch.video_dtype); arithmetic is the same')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -189,7 +191,8 @@ def main():
     model = SeqPAN(cfg, wv, device=dev, seed=12345, rng_seed=12345 + rank)
     b = synth_batch(args.batch, args.T, args.L, args.C, args.vdim, num_words, num_chars, 12345 + rank)
     trainer = Trainer(model, world=world, use_graph=not args.no_graph, use_aux=args.aux)
-    trainer.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'])
+    vdt = torch.bfloat16 if args.video_dtype == 'bf16' else torch.float32
+    trainer.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'], video_dtype=vdt)
 
     def barrier():
         if world > 1:
@@ -239,7 +242,7 @@ def main():
         # roofline leg: same step launched eagerly; every launch carries start/stop events of its own dispatch
         l = lib.load()
         eager = Trainer(model, world=1, use_graph=False)
-        eager.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'])
+        eager.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'], video_dtype=vdt)
         eager.step(lr=1e-4, drop_rate=args.drop)
         torch.cuda.synchronize()
         l.hual_prof_begin()
@@ -353,6 +356,27 @@ def main():
         except Exception as e:      # never cost the bench line
             cpu['gpu_at_cpu_shape'] = dict(error=str(e)[:200])
 
+    other_feed = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the same step with the clip features held in HBM in the other element type (BASELINE configs[1] says bf16 features;
+        # the headline number is measured on the reference's float32 placeholder)
+        try:
+            odt = torch.float32 if vdt == torch.bfloat16 else torch.bfloat16
+            t2 = Trainer(model, world=1, use_graph=not args.no_graph)
+            t2.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'], video_dtype=odt)
+            for _ in range(100):
+                t2.step(lr=1e-4, drop_rate=args.drop)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(500):
+                t2.step(lr=1e-4, drop_rate=args.drop)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t0
+            other_feed = dict(video_dtype='f32' if odt == torch.float32 else 'bf16', ms_per_step=round(d2 / 500 * 1e3, 4),
+                              value=round(args.batch * 500 / d2, 1), unit='clips/s', steps=500)
+        except Exception as e:      # never cost the bench line
+            other_feed = dict(error=str(e)[:200])
+
     if rank == 0:
         out = dict(metric='train clips/sec', value=round(clips / dt, 2), unit='clips/s', n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
@@ -362,8 +386,11 @@ def main():
                                         % (args.drop, args.batch, args.T, args.vdim, args.L, args.C),
                                global_batch=args.batch * world, T=args.T, vdim=args.vdim, L=args.L,
                                parallelism='dp%d' % world, launch='eager' if args.no_graph else 'hipGraph',
+                               video_dtype=args.video_dtype,
                                final_loss=round(loss, 4)),
                    roofline=roof, cpu_baseline=cpu)
+        if other_feed is not None:
+            out['other_feature_dtype'] = other_feed
         if rccl is not None:
             out['rccl'] = rccl
         print(json.dumps(out))

@@ -73,6 +73,7 @@ struct DwJob {
   const float* dY; int ldy;
   int M, N;
   float* db;
+  int a_bf16;                 // 1: A[0] points at bfloat16 elements (lda in elements); single piece, no A2
 };
 
 #define HUAL_MAX_DW_JOBS 12
@@ -100,6 +101,7 @@ struct FkJob {
   const float* Wimg;
   float* part; size_t part_stride;
   int drop_site; uint32_t drop_row0;
+  int a_bf16;                 // 1: A points at bfloat16 elements (lda in elements)
 };
 #define HUAL_MAX_FK_JOBS 2
 struct FkBatch { FkJob j[HUAL_MAX_FK_JOBS]; };

@@ -700,8 +700,18 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
   for (int t = 0; t < 8; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float* Ap = job.A + (size_t)arow * job.lda;
   const int nks = KS / 32;
+  const uint16_t* Ap16 = reinterpret_cast<const uint16_t*>(job.A) + (size_t)arow * job.lda;
+  const bool a16 = job.a_bf16 != 0;
   auto a_fetch = [&](int ks, float4& x0, float4& x1) {
     const int kk = q * KS + 32 * ks + 8 * g;
+    if (a16) {                                          // bfloat16 features: 16 bytes = the lane's 8 values, widened exactly
+      const uint4 raw = kk < K ? *reinterpret_cast<const uint4*>(Ap16 + kk) : make_uint4(0u, 0u, 0u, 0u);
+      x0 = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                       __uint_as_float(raw.y & 0xffff0000u));
+      x1 = make_float4(__uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u), __uint_as_float(raw.w << 16),
+                       __uint_as_float(raw.w & 0xffff0000u));
+      return;
+    }
     x0 = kk < K ? ld4(Ap + kk) : f4zero();              // K is a multiple of 8: a lane's 8 values are in or out together
     x1 = kk < K ? ld4(Ap + kk + 4) : f4zero();
   };
@@ -1100,7 +1110,13 @@ __global__ __launch_bounds__(256) void dw_kernel(DwBatch batch, const DwJob* __r
       if (m < m_hi) {
         const int k = k0 + 4 * c4;
         if (k < kw) {
-          a = ld4(Ap + (size_t)m * lda + k);
+          if (job.a_bf16) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(Ap) + (size_t)m * lda + k);
+            a = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                            __uint_as_float(raw.y & 0xffff0000u));
+          } else {
+            a = ld4(Ap + (size_t)m * lda + k);
+          }
           if (A2p) a = f4mul(a, ld4(A2p + (size_t)m * lda2 + k));
           if (adrop) a = apply_drop4(drop, asite, arow0 + (uint32_t)m, (uint32_t)(k >> 2), a);
         }
@@ -1232,7 +1248,13 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(DwBatch batch, const DwJob
       if (m < m_hi) {
         const int k = k0 + 4 * c4;
         if (k < kw) {
-          a = ld4(Ap + (size_t)m * lda + k);
+          if (job.a_bf16) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(Ap) + (size_t)m * lda + k);
+            a = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                            __uint_as_float(raw.y & 0xffff0000u));
+          } else {
+            a = ld4(Ap + (size_t)m * lda + k);
+          }
           if (A2p) a = f4mul(a, ld4(A2p + (size_t)m * lda2 + k));
           if (adrop) a = apply_drop4(drop, asite, arow0 + (uint32_t)m, (uint32_t)(k >> 2), a);
         }
@@ -1534,7 +1556,7 @@ int launch_feature_ksplit(const FkJob* jobs, int n, const DropCfg& drop, hipStre
     // ALGORITHMIC bytes (T.(V+D).e per clip + weights): features + weights in, ONE [M,128] projection out.  The
     // four K-quarter partial slabs this kernel actually writes (4.M.128 floats, summed by the layer-norm launch behind it)
     // are implementation traffic: they show up in the measured PMC bytes, not here.
-    bytes += 4.0 * ((double)j.M * j.K + (double)j.K * 128 + (double)j.M * 128);
+    bytes += (j.a_bf16 ? 2.0 : 4.0) * (double)j.M * j.K + 4.0 * ((double)j.K * 128 + (double)j.M * 128);
   }
   HUAL_DYN_LDS(feature_ksplit_kernel, 160 * 1024);
   const size_t lds = (size_t)(maxKS / 64) * GB_STAGE;
@@ -1633,6 +1655,9 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
   HUAL_DYN_LDS(dw_bf16_kernel<true>, 96 * 1024);
   HUAL_DYN_LDS(dw_bf16_kernel<false>, 96 * 1024);
   size_t lds = dw_impl ? (size_t)8 * DWB_PLANE : (size_t)4 * DW_TM * DW_LD * sizeof(float);
+  for (int i = 0; i < n; ++i)
+    HUAL_REQUIRE(!jobs[i].a_bf16 || (dw_impl && jobs[i].npieces == 1 && !jobs[i].A2[0] && (jobs[i].lda[0] % 4) == 0),
+                 "dw: a bfloat16 operand needs the split-bf16 kernel, one piece, no product prologue");
   // HUAL_DW_LDS_KB pads the LDS request: above 80 KB only ONE block fits a CU, which leaves room for the blocks of
   // other kernels when the launch runs on a side stream under the dX chain (experiment)
   static const int lds_kb = []() { const char* e = getenv("HUAL_DW_LDS_KB"); return e ? atoi(e) : 0; }();

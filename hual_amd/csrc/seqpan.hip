@@ -573,15 +573,17 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   if (ksplit) {
     if (!c.dry && c.ok()) {
       FkJob fj[2];
-      fj[0] = FkJob{bt->video, c.cfg->vdim, Nv, c.cfg->vdim, c.cfg->vdim / 4, reinterpret_cast<const float*>(c.PKF + pm.vconv.k * 4),
-                    vpart, (size_t)R * D, HUAL_SITE_VIDEO, 0};
+      fj[0] = FkJob{reinterpret_cast<const float*>(bt->video), c.cfg->vdim, Nv, c.cfg->vdim, c.cfg->vdim / 4,
+                    reinterpret_cast<const float*>(c.PKF + pm.vconv.k * 4), vpart, (size_t)R * D, HUAL_SITE_VIDEO, 0,
+                    bt->video_dtype == HUAL_DTYPE_BF16 ? 1 : 0};
       fj[1] = FkJob{cat, catw, Nq, catw, qks, reinterpret_cast<const float*>(c.PKF + pm.qconv.k * 4),
-                    vpart + (size_t)Nv * D, (size_t)R * D, -1, 0};
+                    vpart + (size_t)Nv * D, (size_t)R * D, -1, 0, 0};
       c.chk(launch_feature_ksplit(fj, 2, c.drop, c.stream));
     }
   } else {
+    if (!c.dry && bt->video_dtype != HUAL_DTYPE_F32) return fail(HUAL_ERR_UNSUPPORTED, "bfloat16 video features need the K-split feature-load kernel (vdim % 256 == 0, vdim <= 1024)");
     GemmJob j[2];
-    j[0] = mkjob(c.dry ? nullptr : bt->video, c.cfg->vdim, Nv, c.cfg->vdim, c.p(pm.vconv.k), c.p(pm.vconv.b), lin, D);
+    j[0] = mkjob(c.dry ? nullptr : reinterpret_cast<const float*>(bt->video), c.cfg->vdim, Nv, c.cfg->vdim, c.p(pm.vconv.k), c.p(pm.vconv.b), lin, D);
     j[0].a_drop_site = HUAL_SITE_VIDEO; j[0].a_drop_row0 = 0;
     j[1] = mkjob(cat, catw, Nq, catw, c.p(pm.qconv.k), c.p(pm.qconv.b), lin + (size_t)Nv * D, D);
     c.gemm(j, 2);
@@ -1440,8 +1442,9 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   }
   float* cat = c.buf("cat", Nq, catw);
   {
-    DwJob j = mkdw(c.dry ? nullptr : bt->video, c.cfg->vdim, c.cfg->vdim, d_lin, D, Nv, c.g(pm.vconv.k), c.g(pm.vconv.b));
+    DwJob j = mkdw(c.dry ? nullptr : reinterpret_cast<const float*>(bt->video), c.cfg->vdim, c.cfg->vdim, d_lin, D, Nv, c.g(pm.vconv.k), c.g(pm.vconv.b));
     j.a_drop_site = HUAL_SITE_VIDEO; j.a_drop_row0 = 0;
+    j.a_bf16 = (!c.dry && bt->video_dtype == HUAL_DTYPE_BF16) ? 1 : 0;
     c.dwjobs.push_back(j);
     c.dwjobs.push_back(mkdw(cat, catw, catw, d_lin + (size_t)Nv * D, D, Nq, c.g(pm.qconv.k), c.g(pm.qconv.b)));
   }
@@ -1552,6 +1555,8 @@ static int check_common(const hual_cfg* cfg, const float* params, const hual_bat
                         void* workspace) {
   HUAL_REQUIRE(cfg && params && batch && opts && workspace, "null argument");
   HUAL_REQUIRE(batch->video && batch->video_seq_len && batch->word_ids && batch->char_ids, "null batch tensor");
+  HUAL_REQUIRE(batch->video_dtype == HUAL_DTYPE_F32 || batch->video_dtype == HUAL_DTYPE_BF16, "video_dtype: HUAL_DTYPE_F32 or HUAL_DTYPE_BF16");
+  HUAL_REQUIRE(((uintptr_t)batch->video & 15) == 0, "video features must be 16-byte aligned");
   HUAL_REQUIRE(opts->drop_rate >= 0.f && opts->drop_rate < 1.f, "drop_rate in [0,1)");
   HUAL_REQUIRE(opts->drop_rate == 0.f || opts->rng_state != nullptr, "rng_state required when drop_rate > 0");
   HUAL_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)params & 15) == 0, "workspace/params alignment");

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libhual_seqpan.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -30,7 +30,7 @@ class hual_param_entry(ctypes.Structure):
 class hual_batch(ctypes.Structure):
     _fields_ = [('video', ctypes.c_void_p), ('video_seq_len', ctypes.c_void_p), ('word_ids', ctypes.c_void_p),
                 ('char_ids', ctypes.c_void_p), ('B', ctypes.c_int32), ('T', ctypes.c_int32), ('L', ctypes.c_int32),
-                ('C', ctypes.c_int32)]
+                ('C', ctypes.c_int32), ('video_dtype', ctypes.c_int32)]
 
 
 class hual_labels(ctypes.Structure):

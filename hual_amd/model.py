@@ -122,7 +122,9 @@ class SeqPAN:
             if int(lens_h.max()) != int(np.shape(video_inputs)[1]):
                 raise ValueError('video_inputs T (%d) must equal max(video_seq_len) (%d) - model.py:31'
                                  % (np.shape(video_inputs)[1], int(lens_h.max())))
-        v = self._to_dev(video_inputs, torch.float32)
+        # float32 features (the reference's placeholder) or, as a torch tensor, bfloat16 ones (hual_batch.video_dtype)
+        vdt = torch.bfloat16 if isinstance(video_inputs, torch.Tensor) and video_inputs.dtype == torch.bfloat16 else torch.float32
+        v = self._to_dev(video_inputs, vdt)
         ln = self._to_dev(video_seq_len, torch.int32)
         w = self._to_dev(word_ids, torch.int32)
         c = self._to_dev(char_ids, torch.int32)
@@ -132,7 +134,8 @@ class SeqPAN:
         L, C = w.shape[1], c.shape[2]
         if C < 4:   # pad_char_seq can produce < 4 chars; the reference's VALID width-4 conv would fail too
             raise ValueError('char_ids needs at least 4 chars per word')
-        bt = lib.hual_batch(lib.ptr(v).value, lib.ptr(ln).value, lib.ptr(w).value, lib.ptr(c).value, B, T, L, C)
+        bt = lib.hual_batch(lib.ptr(v).value, lib.ptr(ln).value, lib.ptr(w).value, lib.ptr(c).value, B, T, L, C,
+                            1 if vdt == torch.bfloat16 else 0)
         return bt, (v, ln, w, c), (B, T, L, C)
 
     def _outputs(self, B, T, with_loss):

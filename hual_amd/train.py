@@ -34,19 +34,21 @@ class Trainer:
             lib.check(self._lib.hual_aux_create(ctypes.byref(self.aux)))
 
     # ------------------------------------------------------------------ static batch buffers
-    def set_batch(self, video, lens, word_ids, char_ids, y1, y2, match_labels, inner_labels):
+    def set_batch(self, video, lens, word_ids, char_ids, y1, y2, match_labels, inner_labels, video_dtype=torch.float32):
+        """video_dtype=torch.bfloat16 keeps the clip features in HBM as bfloat16 (hual_batch.video_dtype; the float32 input is
+        rounded once here)"""
         m, dev = self.m, self.m.device
         B, T, V = np.shape(video)
         L, C = np.shape(word_ids)[1], np.shape(char_ids)[2]
         if int(np.max(lens)) != T:
             raise ValueError('video T must equal max(video_seq_len) - model.py:31')
-        shape = (B, T, L, C)
+        shape = (B, T, L, C, video_dtype)
         if shape != self.shape:
             self.shape = shape
             self.graph = None
             self._tables_ready = False
             f32, i32 = torch.float32, torch.int32
-            self.video = torch.empty(B, T, V, device=dev, dtype=f32)
+            self.video = torch.empty(B, T, V, device=dev, dtype=video_dtype)
             self.lens = torch.empty(B, device=dev, dtype=i32)
             self.word_ids = torch.empty(B, L, device=dev, dtype=i32)
             self.char_ids = torch.empty(B, L, C, device=dev, dtype=i32)
@@ -63,7 +65,7 @@ class Trainer:
             self.ws = m._workspace(B, T, L, C)
             p = lib.ptr
             self.bt = lib.hual_batch(p(self.video).value, p(self.lens).value, p(self.word_ids).value,
-                                     p(self.char_ids).value, B, T, L, C)
+                                     p(self.char_ids).value, B, T, L, C, 1 if video_dtype == torch.bfloat16 else 0)
             self.lab = lib.hual_labels(p(self.y1).value, p(self.y2).value, p(self.match).value, p(self.inner).value)
             self.out = lib.hual_outputs(p(self.start_logits).value, p(self.end_logits).value, p(self.match_scores).value,
                                         p(self.start_index).value, p(self.end_index).value, p(self.loss_terms).value)
@@ -76,7 +78,7 @@ class Trainer:
 
         def put(dst, src, dt):
             dst.copy_(torch.as_tensor(np.ascontiguousarray(src), dtype=dt), non_blocking=False)
-        put(self.video, video, torch.float32)
+        put(self.video, video, torch.float32)        # copy_ converts to the buffer's dtype
         put(self.lens, lens, torch.int32)
         put(self.word_ids, word_ids, torch.int32)
         put(self.char_ids, char_ids, torch.int32)
@@ -98,8 +100,9 @@ class Trainer:
         self._tables_ready = False
         self.video, self.lens, self.word_ids, self.char_ids = (feeds[k] for k in ('video', 'video_seq_len', 'word_ids', 'char_ids'))
         self.y1, self.y2, self.match, self.inner = (feeds[k] for k in ('y1', 'y2', 'match_labels', 'inner_labels'))
-        if (B, T, L, C) != self.shape:
-            self.shape = (B, T, L, C)
+        vdt = self.video.dtype
+        if (B, T, L, C, vdt) != self.shape:
+            self.shape = (B, T, L, C, vdt)
             self.start_logits = torch.empty(B, T, device=dev)
             self.end_logits = torch.empty(B, T, device=dev)
             self.match_scores = torch.empty(B, T, 4, device=dev)
@@ -115,7 +118,7 @@ class Trainer:
         self.ws = m._workspace(B, T, L, C)
         p = lib.ptr
         self.bt = lib.hual_batch(p(self.video).value, p(self.lens).value, p(self.word_ids).value, p(self.char_ids).value,
-                                 B, T, L, C)
+                                 B, T, L, C, 1 if vdt == torch.bfloat16 else 0)
         self.lab = lib.hual_labels(p(self.y1).value, p(self.y2).value, p(self.match).value, p(self.inner).value)
         self.out = lib.hual_outputs(p(self.start_logits).value, p(self.end_logits).value, p(self.match_scores).value,
                                     p(self.start_index).value, p(self.end_index).value, p(self.loss_terms).value)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HUAL_ABI_VERSION 1
+#define HUAL_ABI_VERSION 2
 
 #define HUAL_OK 0
 #define HUAL_ERR_INVALID (-1)
@@ -89,12 +89,18 @@ int hual_seqpan_param_count(const hual_cfg* cfg, uint64_t* padded_floats, uint64
 int hual_seqpan_param_table(const hual_cfg* cfg, hual_param_entry* out, int max_entries);
 
 /* feeds of model.py:15-27 (`_add_placeholders`); all device pointers */
+#define HUAL_DTYPE_F32 0
+#define HUAL_DTYPE_BF16 1
 typedef struct hual_batch {
-  const float* video;             /* video_inputs  f32 [B,T,vdim], rows beyond video_seq_len zero padded */
+  const void* video;              /* video_inputs [B,T,vdim] of `video_dtype`, rows beyond video_seq_len zero padded */
   const int32_t* video_seq_len;   /* [B]; max must equal T (model.py:31) */
   const int32_t* word_ids;        /* [B,L], 0 = PAD, 1 = unk */
   const int32_t* char_ids;        /* [B,L,C], 0 = PAD, C >= 4 */
   int32_t B, T, L, C;
+  int32_t video_dtype;            /* HUAL_DTYPE_F32 (the reference's float32 placeholder, model.py:17) or HUAL_DTYPE_BF16:
+                                     bfloat16 clip features (BASELINE.json configs[1]), read as the float32 values they
+                                     are - half the bytes of the feature-load phase, same arithmetic behind the load.
+                                     Needs vdim % 256 == 0 and vdim <= 1024 (the K-split feature-load kernel). */
 } hual_batch;
 
 typedef struct hual_labels {

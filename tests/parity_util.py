@@ -128,16 +128,23 @@ def relu_pins(m, B, T, L):
     return pin
 
 
-def compare(cfg, p, wv, b, labels, drop_rate=0.0, seed=5, offset=7, with_grads=True, device='cuda:0', pin_relu=True):
+def compare(cfg, p, wv, b, labels, drop_rate=0.0, seed=5, offset=7, with_grads=True, device='cuda:0', pin_relu=True,
+            video_bf16=False):
     """returns (report rows [(kind, name, maxabs_diff, ref_maxabs)], indices equal, oracle out, hip out, hip model).
     pin_relu: the oracle evaluates its ReLUs with the active sets of the HIP forward (relu_pins), which makes every
     gradient tensor comparable at 1e-3 whatever the shape; the row ('pin', 'relu_disagree', n, total) counts the units
     where the oracle's own sign of z differs (they must be rounding-level: the forward taps are still held to 1e-3)."""
     B, T = b['video'].shape[:2]
     L = b['word_ids'].shape[1]
+    # video_bf16: the HIP path is fed bfloat16 clip features (hual_batch.video_dtype), the oracle the same values as float32
+    video_feed = b['video'].numpy()
+    if video_bf16:
+        b = dict(b)
+        video_feed = b['video'].to(torch.bfloat16)
+        b['video'] = video_feed.to(torch.float32)
     m = hip_model(cfg, p, wv, device)
     m.set_rng(seed, offset)
-    h_out = m.forward(b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(),
+    h_out = m.forward(video_feed, b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(),
                       drop_rate=drop_rate, labels=tuple(x.numpy() for x in labels))
     torch.cuda.synchronize()
     pins = relu_pins(m, B, T, L) if pin_relu else None

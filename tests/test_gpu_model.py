@@ -50,3 +50,23 @@ def test_fusion_switch_variants_parity(flags, monkeypatch):
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2)
     _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
     assert idx_equal
+
+
+@pytest.mark.parametrize('shape', [dict(), dict(B=4, T=64, L=12, C=6, seed=8, max_vlen=64, vdim=512)])
+def test_bfloat16_video_feed_parity(shape):
+    """hual_batch.video_dtype = HUAL_DTYPE_BF16 (BASELINE configs[1]: bf16 clip features): the feature-load and the
+    video_conv1d weight-gradient kernels read bfloat16 features; same graph on the same values in the oracle"""
+    case = pu.make_case(**shape)
+    rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2, video_bf16=True)
+    _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
+    assert idx_equal
+
+
+def test_bfloat16_video_feed_needs_the_ksplit_kernel():
+    """vdim 320 has no K-split feature-load kernel: the library must refuse bfloat16 features, not read them as float32"""
+    from hual_amd import lib
+    case = pu.make_case(vdim=320)
+    cfg, p, wv, b, labels = case
+    m = pu.hip_model(cfg, p, wv)
+    with pytest.raises(lib.HualError):
+        m.forward(b['video'].to(torch.bfloat16), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(), drop_rate=0.0)
