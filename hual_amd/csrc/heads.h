@@ -52,7 +52,8 @@ int launch_match_denominator(float* loss_acc, float override_denom, hipStream_t 
 // ortho term ||(E E^T) * (1-I)||_F (model.py:88-91): loss_acc[LA_ORTHO] = norm ; dE += lambda * d norm / dE
 int launch_ortho(const float* E, float* dE, float* loss_acc, float lambda, hipStream_t s);
 // forward: ortho term + match denominator + the reported loss terms (loss_out[4], may be null) in one launch
-int launch_loss_tail(const float* E, float* loss_acc, float lambda, float override_denom, float* loss_out, hipStream_t s);
+int launch_loss_tail(const float* E, float* loss_acc, float lambda, float override_denom, const float* denom_dev, float* loss_out,
+                     hipStream_t s);
 
 // ---- start/end logit heads: logit = h . w + b  (predictor/{start,end}_dense, modules.py:155-156)
 struct DotArgs {
@@ -91,9 +92,11 @@ int launch_align_pool(const AlignPool& a, const RowSpace& rs, hipStream_t s);
 struct AlignSim {
   const float* that; const float* vhat; int Bg;
   float* dq; float* da;         // [Bg,Bg] scratch
-  float* dthat; float* dvhat;   // [Bg,128] written
+  float* dthat; float* dvhat;   // [nrows,128] written: gradient rows row0 .. row0 + nrows - 1
   float* loss_acc;
   float scale;                  // multiplies the gradients (world size in exact data-parallel mode)
+  int ld;                       // row stride of that / vhat (128, or 256 when both sit side by side in one gathered buffer)
+  int row0, nrows;              // window of gradient rows wanted (0, Bg: all)
 };
 int launch_align_sim(const AlignSim& a, hipStream_t s);
 struct AlignPoolBwd {

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
 // ortho: one block of 128 threads
 // forward use (tail != 0) also closes the loss: match denominator (layers.py:173) and the four reported loss terms
 __global__ __launch_bounds__(128) void ortho_kernel(const float* E, float* dE, float* loss_acc, float lambda, int tail,
-                                                    float override_denom, float* loss_out) {
+                                                    float override_denom, const float* denom_dev, float* loss_out) {
   __shared__ float M[16];
   __shared__ float sm[4];
   const int c = threadIdx.x;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(128) void ortho_kernel(const float* E, float* dE, f
   if (c == 0) {
     loss_acc[LA_ORTHO] = nrm;
     if (tail) {
-      const float denom = override_denom > 0.f ? override_denom : loss_acc[LA_MASK_SUM] + 1e-12f;
+      const float denom = denom_dev ? *denom_dev : (override_denom > 0.f ? override_denom : loss_acc[LA_MASK_SUM] + 1e-12f);
       loss_acc[LA_DENOM] = denom;
       if (loss_out) {
         const float match = loss_acc[LA_MATCH_SUM] / denom + nrm;             // layers.py:173 + model.py:91
@@ -468,11 +468,12 @@ __global__ __launch_bounds__(256) void align_sim_rows_kernel(AlignSim a) {
   __shared__ float sm[4];
   __shared__ float sa[1024], sq[1024];
   const int i = blockIdx.x, tid = threadIdx.x, Bg = a.Bg;
-  if (tid < HUAL_D) { ti[tid] = a.that[i * HUAL_D + tid]; vi[tid] = a.vhat[i * HUAL_D + tid]; }
+  const int ld = a.ld;
+  if (tid < HUAL_D) { ti[tid] = a.that[(size_t)i * ld + tid]; vi[tid] = a.vhat[(size_t)i * ld + tid]; }
   __syncthreads();
   float mxa = -INFINITY, mxq = -INFINITY;
   for (int j = tid; j < Bg; j += 256) {
-    const float* vj = a.vhat + (size_t)j * HUAL_D;
+    const float* vj = a.vhat + (size_t)j * ld;
     float da = 0.f, dq = 0.f;
     for (int k = 0; k < HUAL_D; ++k) { da = fmaf(vi[k], vj[k], da); dq = fmaf(ti[k], vj[k], dq); }
     sa[j] = da; sq[j] = dq;
@@ -510,31 +511,32 @@ __global__ __launch_bounds__(256) void align_sim_rows_kernel(AlignSim a) {
   }
   __syncthreads();
   // dthat_i = sum_j dq[i][j] vhat_j ; dvhat_i (row part) = sum_j da[i][j] vhat_j
-  if (tid < HUAL_D) {
+  // only the rows [row0, row0 + nrows) are wanted (exact data parallel: a rank keeps the gradient rows of its own samples)
+  if (tid < HUAL_D && i >= a.row0 && i < a.row0 + a.nrows) {
     float st = 0.f, sv = 0.f;
     for (int j = 0; j < Bg; ++j) {
-      const float v = a.vhat[(size_t)j * HUAL_D + tid];
+      const float v = a.vhat[(size_t)j * ld + tid];
       st = fmaf(sq[j], v, st);
       sv = fmaf(sa[j], v, sv);
     }
-    a.dthat[i * HUAL_D + tid] = st;
-    a.dvhat[i * HUAL_D + tid] = sv;
+    a.dthat[(i - a.row0) * HUAL_D + tid] = st;
+    a.dvhat[(i - a.row0) * HUAL_D + tid] = sv;
   }
 }
 // column part: dvhat_j += sum_i dq[i][j] that_i + da[i][j] vhat_i
 __global__ __launch_bounds__(256) void align_sim_cols_kernel(AlignSim a) {
   __shared__ float cq[1024], ca[1024];
   __shared__ float part[HUAL_D];
-  const int j = blockIdx.x, c = threadIdx.x & 127, half = threadIdx.x >> 7, Bg = a.Bg;
+  const int j = a.row0 + blockIdx.x, c = threadIdx.x & 127, half = threadIdx.x >> 7, Bg = a.Bg, ld = a.ld;
   for (int i = threadIdx.x; i < Bg; i += 256) { cq[i] = a.dq[(size_t)i * Bg + j]; ca[i] = a.da[(size_t)i * Bg + j]; }
   __syncthreads();
   float s = 0.f;
 #pragma unroll 4
   for (int i = half; i < Bg; i += 2)
-    s += cq[i] * a.that[(size_t)i * HUAL_D + c] + ca[i] * a.vhat[(size_t)i * HUAL_D + c];
+    s += cq[i] * a.that[(size_t)i * ld + c] + ca[i] * a.vhat[(size_t)i * ld + c];
   if (half) part[c] = s;
   __syncthreads();
-  if (!half) a.dvhat[j * HUAL_D + c] += s + part[c];
+  if (!half) a.dvhat[blockIdx.x * HUAL_D + c] += s + part[c];
 }
 
 __global__ __launch_bounds__(512) void align_pool_bwd_kernel(AlignPool a, AlignPoolBwd g, RowSpace rs) {
@@ -598,12 +600,13 @@ int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, 
   return 0;
 }
 int launch_ortho(const float* E, float* dE, float* loss_acc, float lambda, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, dE, loss_acc, lambda, 0, 0.f, (float*)nullptr);
+  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, dE, loss_acc, lambda, 0, 0.f, (const float*)nullptr, (float*)nullptr);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
-int launch_loss_tail(const float* E, float* loss_acc, float lambda, float override_denom, float* loss_out, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, (float*)nullptr, loss_acc, lambda, 1, override_denom, loss_out);
+int launch_loss_tail(const float* E, float* loss_acc, float lambda, float override_denom, const float* denom_dev, float* loss_out,
+                     hipStream_t s) {
+  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, (float*)nullptr, loss_acc, lambda, 1, override_denom, denom_dev, loss_out);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -630,8 +633,9 @@ int launch_align_pool(const AlignPool& a, const RowSpace& rs, hipStream_t s) {
 }
 int launch_align_sim(const AlignSim& a, hipStream_t s) {
   HUAL_REQUIRE(a.Bg >= 1 && a.Bg <= 1024, "align: global batch <= 1024");
+  HUAL_REQUIRE(a.ld >= HUAL_D && a.row0 >= 0 && a.nrows >= 1 && a.row0 + a.nrows <= a.Bg, "align: row window / leading dimension");
   HUAL_LAUNCH(0.0, 0.0, align_sim_rows_kernel, dim3(a.Bg), dim3(256), 0, s, a);
-  HUAL_LAUNCH(0.0, 0.0, align_sim_cols_kernel, dim3(a.Bg), dim3(256), 0, s, a);
+  HUAL_LAUNCH(0.0, 0.0, align_sim_cols_kernel, dim3(a.nrows), dim3(256), 0, s, a);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -803,7 +803,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     }
     c.chk(launch_align_pool(ap, c.rs, as_stream));
     if (!opt->align_external) {
-      AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, d_that, d_vhat, loss_acc, 1.0f};
+      AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, d_that, d_vhat, loss_acc, 1.0f, D, 0, B};
       if (c.ok()) c.chk(launch_align_sim(as, as_stream));
     }
     if (c.align_forked) HUAL_CHECK_HIP(hipEventRecord((hipEvent_t)c.aux->ev_join, as_stream));
@@ -922,8 +922,8 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     if (c.ok()) c.chk(launch_loc(la, B, T, c.stream));
     if (lab && c.ok()) {
       if (c.align_forked) HUAL_CHECK_HIP(hipStreamWaitEvent(c.stream, (hipEvent_t)c.aux->ev_join, 0));
-      c.chk(launch_loss_tail(c.p(pm.label_emb), loss_acc, c.cfg->match_lambda, opt->match_denom_override, out->loss_terms,
-                             c.stream));
+      c.chk(launch_loss_tail(c.p(pm.label_emb), loss_acc, c.cfg->match_lambda, opt->match_denom_override, opt->match_denom_dev,
+                             out->loss_terms, c.stream));
     }
   }
   return c.rc;
@@ -1652,7 +1652,14 @@ int hual_align_loss(const float* that, const float* vhat, int Bg, float* scratch
                     float* loss, float grad_scale, void* stream) {
   HUAL_REQUIRE(that && vhat && scratch && d_that && d_vhat && loss, "hual_align_loss: null pointer");
   // loss accumulates into loss[0]: present it as an accumulator array whose LA_ALIGN slot is loss[0]
-  AlignSim as{that, vhat, Bg, scratch, scratch + (size_t)Bg * Bg, d_that, d_vhat, loss - LA_ALIGN, grad_scale};
+  AlignSim as{that, vhat, Bg, scratch, scratch + (size_t)Bg * Bg, d_that, d_vhat, loss - LA_ALIGN, grad_scale, HUAL_D, 0, Bg};
+  return launch_align_sim(as, (hipStream_t)stream);
+}
+
+int hual_align_loss_rows(const float* that, const float* vhat, int ld, int Bg, int row0, int nrows, float* scratch, float* d_that,
+                         float* d_vhat, float* loss, float grad_scale, void* stream) {
+  HUAL_REQUIRE(that && vhat && scratch && d_that && d_vhat && loss, "hual_align_loss_rows: null pointer");
+  AlignSim as{that, vhat, Bg, scratch, scratch + (size_t)Bg * Bg, d_that, d_vhat, loss - LA_ALIGN, grad_scale, ld, row0, nrows};
   return launch_align_sim(as, (hipStream_t)stream);
 }
 

@@ -14,12 +14,22 @@ import torch
 import torch.distributed as dist
 
 
+def _forced():
+    """HUAL_DP_FORCE_COLLECTIVES=1: issue the collectives on a 1-rank group too (tests of the RCCL code path on one GPU)"""
+    import os
+    return os.environ.get('HUAL_DP_FORCE_COLLECTIVES') == '1' and dist.is_available() and dist.is_initialized()
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def backend():
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
 
 
 def _host_staged(t):
@@ -29,7 +39,7 @@ def _host_staged(t):
 
 def allreduce_sum_(flat):
     """in-place sum of the flat gradient bucket over ranks"""
-    if world_size() > 1:
+    if world_size() > 1 or _forced():
         if _host_staged(flat):
             h = flat.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -70,6 +80,20 @@ def gather_features(that, vhat):
         dist.all_gather_into_tensor(out, both)
     d = that.shape[1]
     return out[:, :d].contiguous(), out[:, d:].contiguous()
+
+
+def allgather_rows_(out, local):
+    """out[w*B:(w+1)*B] = rank w's `local` [B,C] (equal B per rank); in place, no host round trip on RCCL"""
+    w = world_size()
+    if w == 1 and not _forced():
+        out.copy_(local)
+    elif _host_staged(local):
+        parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(w)]
+        dist.all_gather(parts, local.cpu())
+        out.copy_(torch.cat(parts, dim=0))
+    else:
+        dist.all_gather_into_tensor(out, local)
+    return out
 
 
 def local_rows(t, batch):

@@ -49,7 +49,8 @@ class hual_aux(ctypes.Structure):
 
 class hual_run_opts(ctypes.Structure):
     _fields_ = [('drop_rate', ctypes.c_float), ('rng_state', ctypes.c_void_p), ('match_denom_override', ctypes.c_float),
-                ('align_external', ctypes.c_int32), ('aux', ctypes.POINTER(hual_aux)), ('static_tables', ctypes.c_int32)]
+                ('align_external', ctypes.c_int32), ('aux', ctypes.POINTER(hual_aux)), ('static_tables', ctypes.c_int32),
+                ('match_denom_dev', ctypes.c_void_p)]
 
 
 class hual_al_set(ctypes.Structure):
@@ -99,6 +100,7 @@ def load():
     lib.hual_adamw_clip_step.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp]
     lib.hual_adamw_clip_step_rng.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp, vp]
     lib.hual_align_loss.argtypes = [vp, vp, i32, vp, vp, vp, vp, f32, vp]
+    lib.hual_align_loss_rows.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp]
     lib.hual_prof_get.argtypes = [i32, ctypes.c_char_p, i32, P(ctypes.c_int64), P(ctypes.c_double), P(ctypes.c_double),
                                   P(ctypes.c_double)]
     lib.hual_aux_create.argtypes = [P(hual_aux)]

@@ -40,7 +40,10 @@ class Trainer:
         m, dev = self.m, self.m.device
         B, T, V = np.shape(video)
         L, C = np.shape(word_ids)[1], np.shape(char_ids)[2]
-        if int(np.max(lens)) != T:
+        # model.py:31 pads to the longest clip of the batch.  A data-parallel shard must be padded to the longest clip of the
+        # GLOBAL batch to reproduce the single-process numbers (the reference's conv_block does not mask: rows behind a clip's
+        # end feed its last valid rows, so the results depend on the padded length) - hence T >= max(lens) there.
+        if int(np.max(lens)) != T and not (self.dp and int(np.max(lens)) < T):
             raise ValueError('video T must equal max(video_seq_len) - model.py:31')
         shape = (B, T, L, C, video_dtype)
         if shape != self.shape:
@@ -70,11 +73,7 @@ class Trainer:
             self.out = lib.hual_outputs(p(self.start_logits).value, p(self.end_logits).value, p(self.match_scores).value,
                                         p(self.start_index).value, p(self.end_index).value, p(self.loss_terms).value)
             if self.dp:
-                Bg = B * self.world
-                self.align_scratch = torch.empty(2 * Bg * Bg, device=dev)
-                self.d_that_all = torch.empty(Bg, 128, device=dev)
-                self.d_vhat_all = torch.empty(Bg, 128, device=dev)
-                self.align_loss = torch.zeros(1, device=dev)
+                self._alloc_dp(B)
 
         def put(dst, src, dt):
             dst.copy_(torch.as_tensor(np.ascontiguousarray(src), dtype=dt), non_blocking=False)
@@ -86,9 +85,30 @@ class Trainer:
         put(self.y2, y2, torch.float32)
         put(self.match, match_labels, torch.int32)
         put(self.inner, inner_labels, torch.float32)
+        self._update_match_denominator()
+
+    def _alloc_dp(self, B):
+        """static buffers of the data-parallel exchange: [that | vhat] of the local / all samples, the [Bg,Bg] scratch of the
+        alignment loss, its value, and the device scalar holding the matching-loss denominator"""
+        dev, Bg = self.m.device, B * self.world
+        self.align_scratch = torch.empty(2 * Bg * Bg, device=dev)
+        self.feat_local = torch.empty(B, 256, device=dev)
+        self.feat_all = torch.empty(Bg, 256, device=dev)
+        self.align_loss = torch.zeros(1, device=dev)
+        self.denom_dev = torch.zeros(1, device=dev)
+        self.graph = None
+
+    def _update_match_denominator(self):
+        """exact data parallel: the masked matching loss divides by the GLOBAL valid-frame count; every rank
+        uses n_global / world (+1e-12 of layers.py:173 on the global count) so that the rank average is the global masked
+        mean.  Device side: sum of the lengths -> all-reduce -> scalar the kernels read (hual_run_opts.match_denom_dev);
+        no host round trip, so it can sit in front of every batch of a device-fed loop."""
         self.match_denom = 0.0
-        if self.dp:
-            self.match_denom = hdist.match_denominator(int(np.sum(np.asarray(lens))), dev)
+        if not self.dp:
+            return
+        torch.sum(self.lens.to(torch.float32), dim=0, keepdim=True, out=self.denom_dev)
+        hdist.allreduce_sum_(self.denom_dev)
+        self.denom_dev.add_(1e-12).div_(float(self.world))
 
     def set_batch_device(self, feeds):
         """Point the step at feeds that already live on the device (DeviceDataset.assemble): no host copy, no upload.
@@ -110,11 +130,7 @@ class Trainer:
             self.end_index = torch.empty(B, device=dev, dtype=torch.int64)
             self.loss_terms = torch.zeros(4, device=dev)
             if self.dp:
-                Bg = B * self.world
-                self.align_scratch = torch.empty(2 * Bg * Bg, device=dev)
-                self.d_that_all = torch.empty(Bg, 128, device=dev)
-                self.d_vhat_all = torch.empty(Bg, 128, device=dev)
-                self.align_loss = torch.zeros(1, device=dev)
+                self._alloc_dp(B)
         self.ws = m._workspace(B, T, L, C)
         p = lib.ptr
         self.bt = lib.hual_batch(p(self.video).value, p(self.lens).value, p(self.word_ids).value, p(self.char_ids).value,
@@ -122,9 +138,7 @@ class Trainer:
         self.lab = lib.hual_labels(p(self.y1).value, p(self.y2).value, p(self.match).value, p(self.inner).value)
         self.out = lib.hual_outputs(p(self.start_logits).value, p(self.end_logits).value, p(self.match_scores).value,
                                     p(self.start_index).value, p(self.end_index).value, p(self.loss_terms).value)
-        self.match_denom = 0.0
-        if self.dp:
-            self.match_denom = hdist.match_denominator(int(feeds['video_seq_len'].sum().item()), dev)
+        self._update_match_denominator()
 
     # ------------------------------------------------------------------ one step
     def _opts(self, drop_rate, align_external):
@@ -132,7 +146,8 @@ class Trainer:
         # in the workspace stay valid (hual_run_opts.static_tables)
         return lib.hual_run_opts(float(drop_rate), lib.ptr(self.m.rng_state).value, float(self.match_denom),
                                  int(align_external), ctypes.pointer(self.aux) if self.aux is not None else None,
-                                 1 if (self._tables_ready and not os.environ.get('HUAL_NO_STATIC_TABLES')) else 0)
+                                 1 if (self._tables_ready and not os.environ.get('HUAL_NO_STATIC_TABLES')) else 0,
+                                 lib.ptr(self.denom_dev).value if self.dp else None)
 
     def _forward(self, opts):
         m = self.m
@@ -162,16 +177,20 @@ class Trainer:
         self._adam(1.0)
 
     def _enqueue_dp(self, drop_rate):
+        """one data-parallel step, enqueued without any host synchronisation: forward -> all-gather of the [B,256] alignment
+        features -> global [Bg,Bg] alignment loss, gradient rows of the own samples written straight into the backward's
+        workspace buffers -> backward -> ONE all-reduce of the flat gradient bucket -> clip + AdamWD on the averaged gradient"""
         m, B = self.m, self.shape[0]
         opts = self._opts(drop_rate, 1)
         self._forward(opts)
-        that, vhat = hdist.gather_features(m.tap('align.that'), m.tap('align.vhat'))
+        torch.cat([m.tap('align.that'), m.tap('align.vhat')], dim=1, out=self.feat_local)
+        hdist.allgather_rows_(self.feat_all, self.feat_local)
         self.align_loss.zero_()
-        lib.check(self._lib.hual_align_loss(lib.ptr(that), lib.ptr(vhat), that.shape[0], lib.ptr(self.align_scratch),
-                                            lib.ptr(self.d_that_all), lib.ptr(self.d_vhat_all), lib.ptr(self.align_loss),
-                                            float(self.world), lib.stream_ptr()))
-        m.tap('d.align.that').copy_(hdist.local_rows(self.d_that_all, B))
-        m.tap('d.align.vhat').copy_(hdist.local_rows(self.d_vhat_all, B))
+        fa = self.feat_all
+        lib.check(self._lib.hual_align_loss_rows(
+            lib.ptr(fa), ctypes.c_void_p(fa.data_ptr() + 128 * 4), 256, fa.shape[0], hdist.rank() * B if self.world > 1 else 0, B,
+            lib.ptr(self.align_scratch), lib.ptr(m.tap('d.align.that')), lib.ptr(m.tap('d.align.vhat')), lib.ptr(self.align_loss),
+            float(self.world), lib.stream_ptr()))
         self._backward(opts)
         hdist.allreduce_sum_(m.grads)
         self._adam(1.0 / self.world)
@@ -182,7 +201,7 @@ class Trainer:
             m.lr.fill_(float(lr))
             m.lr_value = float(lr)
         if self.dp:
-            self._enqueue_dp(drop_rate)
+            self._step_dp(drop_rate)
         elif not self.use_graph:
             self._enqueue_single(drop_rate)
         else:
@@ -201,6 +220,28 @@ class Trainer:
                 self.graph, self.graph_drop = g, drop_rate
             self.graph.replay()
         m.global_step += 1
+
+    def _step_dp(self, drop_rate):
+        """HUAL_DP_GRAPH=1: the data-parallel step, RCCL collectives included, is captured once into a hipGraph and replayed
+        (only with the nccl backend, whose collectives are stream operations).  Default: eager launch - measured on one rank
+        within 0.5 % of the replayed graph (the chain is GPU bound), and it does not depend on graph capture of RCCL."""
+        want_graph = os.environ.get('HUAL_DP_GRAPH') == '1' and self.world >= 1 and hdist.backend() == 'nccl'
+        if not want_graph:
+            self._enqueue_dp(drop_rate)
+            return
+        m = self.m
+        if self.graph is None or self.graph_drop != drop_rate:
+            snap = [t.clone() for t in (m.params, m.adam_m, m.adam_v, m.rng_state)]
+            self._enqueue_dp(drop_rate)              # warm-up outside capture (first-use attributes, RCCL channel setup)
+            torch.cuda.synchronize()
+            for t, sn in zip((m.params, m.adam_m, m.adam_v, m.rng_state), snap):
+                t.copy_(sn)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue_dp(drop_rate)
+            self.graph, self.graph_drop = g, drop_rate
+        self.graph.replay()
 
     def last_loss(self):
         """total loss of the last step (device sync).  DP: local loc/match terms + the global alignment loss."""

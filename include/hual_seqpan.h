@@ -142,6 +142,9 @@ typedef struct hual_run_opts {
                                         cfg, shapes, params / grads / workspace / batch pointers, so the device-resident
                                         job tables it left in the workspace are still valid and are not rewritten
                                         (saves six tiny launches per step inside a replayed hipGraph) */
+  const float* match_denom_dev;   /* non-NULL: the denominator of the masked matching loss is read from this DEVICE scalar
+                                        when the kernels run (takes precedence over match_denom_override): a data-parallel
+                                        step can all-reduce the valid-frame count on the stream without a host round trip */
 } hual_run_opts;
 
 /* bytes of workspace needed for one forward(+backward) of this shape */
@@ -185,6 +188,11 @@ int hual_adamw_clip_step_rng(float* params, const float* grads, float* adam_m, f
  * Writes d_that / d_vhat [Bg,128] (scaled by grad_scale) and ADDS the loss to *loss (device scalar). */
 int hual_align_loss(const float* that, const float* vhat, int Bg, float* scratch, float* d_that, float* d_vhat,
                     float* loss, float grad_scale, void* stream);
+/* the same for a rank of a data-parallel group: that / vhat are rows of stride `ld` floats (256 when the all-gather left
+ * [that | vhat] side by side), and only the gradient rows row0 .. row0 + nrows - 1 (the rank's own samples) are written,
+ * to d_that / d_vhat [nrows,128] - straight into the workspace buffers "d.align.that" / "d.align.vhat" of the backward. */
+int hual_align_loss_rows(const float* that, const float* vhat, int ld, int Bg, int row0, int nrows, float* scratch, float* d_that,
+                         float* d_vhat, float* loss, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-kernel entry points (unit parity tests call these through ctypes).

@@ -13,12 +13,60 @@ import parity_util as pu
 pytestmark = pytest.mark.gpu
 
 
-def test_dp_path_on_one_rank_matches_single_path():
-    from hual_amd.train import Trainer
+@pytest.fixture(scope='module')
+def rccl_group():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 300))
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    yield
+    dist.destroy_process_group()
+
+
+def _dp_run(monkeypatch, graph, steps=3, sync_check=False):
+    """the data-parallel step on the 1-rank RCCL group with the collectives really issued (HUAL_DP_FORCE_COLLECTIVES)"""
+    from hual_amd.train import Trainer
+    monkeypatch.setenv('HUAL_DP_FORCE_COLLECTIVES', '1')
+    monkeypatch.setenv('HUAL_DP_GRAPH', '1' if graph else '0')
+    cfg, p, wv, b, labels = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
+    feeds = (b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(), *[x.numpy() for x in labels])
+    m = pu.hip_model(cfg, p, wv)
+    m.set_rng(7, 3)
+    tr = Trainer(m, world=1, use_graph=False, force_dp=True)
+    tr.set_batch(*feeds)
+    tr.step(lr=1e-4, drop_rate=0.2)                  # first step: allocations, RCCL channel setup, (graph capture)
+    torch.cuda.synchronize()
+    if sync_check:
+        torch.cuda.set_sync_debug_mode('error')      # any synchronising torch call (.item(), host copies) raises from here on
     try:
+        for _ in range(steps - 1):
+            tr.step(lr=1e-4, drop_rate=0.2)
+    finally:
+        if sync_check:
+            torch.cuda.set_sync_debug_mode('default')
+    torch.cuda.synchronize()
+    return float(tr.last_loss()), m.params.detach().cpu().numpy().copy(), tr
+
+
+def test_dp_step_enqueues_without_host_synchronisation(rccl_group, monkeypatch):
+    """steady-state data-parallel steps (RCCL all-gather + all-reduce included) must not synchronise the host: the
+    matching-loss denominator is a device scalar, the alignment gradient rows go straight into the workspace"""
+    loss, params, tr = _dp_run(monkeypatch, graph=False, steps=4, sync_check=True)
+    assert np.isfinite(loss) and np.isfinite(params).all()
+    assert tr.graph is None
+
+
+def test_dp_step_captured_as_graph_matches_eager(rccl_group, monkeypatch):
+    """HUAL_DP_GRAPH=1: the whole data-parallel step with its RCCL collectives replayed as one hipGraph"""
+    l0, p0, _ = _dp_run(monkeypatch, graph=False)
+    l1, p1, tr = _dp_run(monkeypatch, graph=True, sync_check=True)
+    assert tr.graph is not None
+    np.testing.assert_allclose(l0, l1, rtol=2e-4, atol=2e-4)
+    assert np.abs(p0 - p1).max() < 5e-4      # three Adam steps without bias correction move every weight by ~1e-3
+
+
+def test_dp_path_on_one_rank_matches_single_path(rccl_group):
+    from hual_amd.train import Trainer
+    if True:
         cfg, p, wv, b, labels = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
         feeds = (b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(),
                  *[x.numpy() for x in labels])
@@ -41,5 +89,3 @@ def test_dp_path_on_one_rank_matches_single_path():
         np.testing.assert_allclose(l0[1:], l1[1:], rtol=2e-4, atol=2e-4)
         assert np.abs(g0 - g1).max() <= 1e-4 * max(1.0, np.abs(g0).max())
         assert np.abs(p0 - p1).max() < 5e-4      # Adam's first steps move every weight by ~3e-4 at lr 1e-4
-    finally:
-        dist.destroy_process_group()

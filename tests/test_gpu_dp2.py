@@ -13,22 +13,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _case():
+def _case(lens=(18, 11, 18, 7)):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import parity_util as pu
     from hual_amd import data
     cfg, p, wv, b, labels = pu.make_case(B=4, T=18, L=6, C=5, seed=33, max_vlen=24)
-    lens = np.array([18, 11, 18, 7], dtype=np.int32)          # every shard of two clips contains a full-length clip
+    lens = np.array(lens, dtype=np.int32)
     b['lens'] = torch.tensor(lens)
     for k in range(4):
         b['video'][k, lens[k]:] = 0.0
-    s = np.array([1, 2, 3, 1]); e = np.array([15, 8, 12, 5])
+    s = np.array([1, 2, 3, 1]); e = np.minimum(np.array([15, 8, 12, 5]), lens - 2)
     y1, y2, mm, ii = data.make_labels(s, e, lens, max_len=18)
     labels = (torch.tensor(y1), torch.tensor(y2), torch.tensor(mm), torch.tensor(ii, dtype=torch.float32))
     return cfg, p, wv, b, labels
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, lens):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import parity_util as pu
     from hual_amd.train import Trainer
-    cfg, p, wv, b, labels = _case()
+    cfg, p, wv, b, labels = _case(lens)
     B = 4 // world
     sl = slice(rank * B, (rank + 1) * B)
     m = pu.hip_model(cfg, p, wv)
@@ -51,14 +51,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_process():
+@pytest.mark.parametrize('lens', [(18, 11, 18, 7), (18, 11, 9, 7)])
+def test_two_ranks_on_one_gpu_match_single_process(lens):
+    """lens (18, 11, 9, 7): the second shard holds no full-length clip; it is padded to the GLOBAL T = 18 (Trainer.set_batch,
+    data-parallel mode), which is what keeps the decomposition exact - with a shard-local T the reference's unmasked
+    conv_block (modules.py:59-70) would see different rows behind each clip's end"""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import parity_util as pu
     from hual_amd.train import Trainer
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29800 + (os.getpid() % 150)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29800 + (os.getpid() % 150) + (7 if lens[2] == 9 else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, lens)) for r in range(2)]
     for pr in procs:
         pr.start()
     got = dict()
@@ -68,7 +72,7 @@ def test_two_ranks_on_one_gpu_match_single_process():
     for pr in procs:
         pr.join(timeout=120)
         assert pr.exitcode == 0
-    cfg, p, wv, b, labels = _case()
+    cfg, p, wv, b, labels = _case(lens)
     m = pu.hip_model(cfg, p, wv)
     tr = Trainer(m, world=1, use_graph=False)
     tr.set_batch(b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(), *[x.numpy() for x in labels])
