@@ -68,25 +68,58 @@ __device__ __forceinline__ float wave_sum16(float v) {   // sum across the 16 la
   v += __shfl_xor(v, 8);
   return v;
 }
-__device__ __forceinline__ float half_sum32(float v) {   // sum across the 32 lanes sharing lane>>5
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 16);
+// ---- 32-lane butterfly reductions on the VALU (DPP + v_permlane16_swap) --------------------------------------------------
+// Same pairs, same order as common.h half_sum32 / half_max32 (xor 1, 2, 4, 8, 16: bit-identical results), but without the
+// five dependent ds_bpermute round trips (~100+ cycles each) those cost: at one workgroup per CU the fused kernels are
+// latency bound and a row reduction per ds_bpermute chain was measured to dominate them (15 us per conv_block layer).
+__device__ __forceinline__ float dpp_xor_partner(float v, int step) {
+  const int x = __builtin_bit_cast(int, v);
+  int r;
+  if (step == 1) r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);          // quad_perm [1,0,3,2]
+  else if (step == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+  else if (step == 4) {
+    r = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);                       // row_shl:4 -> lanes 0-3, 8-11 read lane + 4
+    r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);                       // row_shr:4 -> lanes 4-7, 12-15 read lane - 4
+  } else {
+    r = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xF, 0x3, false);                       // row_shl:8 -> lanes 0-7 read lane + 8
+    r = __builtin_amdgcn_update_dpp(r, x, 0x118, 0xF, 0xC, false);                       // row_shr:8 -> lanes 8-15 read lane - 8
+  }
+  return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float lane_xor16_partner(float v) {
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);    // r[0]: odd rows <- even rows, r[1]: even rows <- odd rows
+  const unsigned p = (threadIdx.x & 16) ? r[0] : r[1];
+  return __builtin_bit_cast(float, p);
+}
+__device__ __forceinline__ float fast_sum32(float v) {
+  v += dpp_xor_partner(v, 1);
+  v += dpp_xor_partner(v, 2);
+  v += dpp_xor_partner(v, 4);
+  v += dpp_xor_partner(v, 8);
+  v += lane_xor16_partner(v);
   return v;
 }
-__device__ __forceinline__ float half_max32(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1));
-  v = fmaxf(v, __shfl_xor(v, 2));
-  v = fmaxf(v, __shfl_xor(v, 4));
-  v = fmaxf(v, __shfl_xor(v, 8));
-  v = fmaxf(v, __shfl_xor(v, 16));
+__device__ __forceinline__ float fast_max32(float v) {
+  v = fmaxf(v, dpp_xor_partner(v, 1));
+  v = fmaxf(v, dpp_xor_partner(v, 2));
+  v = fmaxf(v, dpp_xor_partner(v, 4));
+  v = fmaxf(v, dpp_xor_partner(v, 8));
+  v = fmaxf(v, lane_xor16_partner(v));
   return v;
+}
+
+// sum / max across the 32 lanes sharing lane >> 5 (the row of 128 floats a half wave holds as one float4 per lane)
+__device__ __forceinline__ float half_sum32(float v) { return fast_sum32(v); }
+__device__ __forceinline__ float half_max32(float v) { return fast_max32(v); }
+__device__ __forceinline__ float lane_xor32_partner(float v) {
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 __device__ __forceinline__ float wave_sum64(float v) {
   v = half_sum32(v);
-  v += __shfl_xor(v, 32);
+  v += lane_xor32_partner(v);
   return v;
 }
 __device__ __forceinline__ float wave_max64(float v) {

@@ -38,12 +38,17 @@ struct MatchArgs {
   float* probs2;          // optional second copy (kept in the workspace for the backward pass)
   float* outputs;         // [Nv,128]
   float* loss_acc;        // accumulators (LA_*), may be null when labels is null
+  float* part;            // [match_fwd_blocks(Nv)][2] per-block (cross-entropy sum, mask sum): summed by launch_loss_tail - float
+                          // atomics queued on one address retire at ~30 ns each, 2 x 128 of them were half of this kernel
 };
+int match_fwd_blocks(int Nv);
 int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, hipStream_t s);
 struct MatchBwd {
   const float* dOut;      // [Nv,128] gradient wrt outputs
+  const float* dOut2;     // optional second part of it (added on the fly: the predictor's heads and encoders both read `outputs`)
   float* dFuse;           // [Nv,128] written
   float* dWm; float* dbm; float* dE;   // accumulated
+  const float* dE_ortho;  // optional [4,128]: gradient of the orthogonality term left by launch_loss_tail, added to dE
   float lambda;           // loss.match_lambda
 };
 int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, hipStream_t s);
@@ -53,7 +58,7 @@ int launch_match_denominator(float* loss_acc, float override_denom, hipStream_t 
 int launch_ortho(const float* E, float* dE, float* loss_acc, float lambda, hipStream_t s);
 // forward: ortho term + match denominator + the reported loss terms (loss_out[4], may be null) in one launch
 int launch_loss_tail(const float* E, float* loss_acc, float lambda, float override_denom, const float* denom_dev, float* loss_out,
-                     hipStream_t s);
+                     const float* match_part, int match_nblk, float* dE_ortho, hipStream_t s);
 
 // ---- start/end logit heads: logit = h . w + b  (predictor/{start,end}_dense, modules.py:155-156)
 struct DotArgs {

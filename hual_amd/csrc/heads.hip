@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void match_fwd_kernel(MatchArgs a, RowSpace rs
     if (threadIdx.x == 0) {
       float c = 0.f, m = 0.f;
       for (int i = 0; i < 8; ++i) { c += red[0][i]; m += red[1][i]; }
-      atomicAdd(a.loss_acc + LA_MATCH_SUM, c);
-      atomicAdd(a.loss_acc + LA_MASK_SUM, m);
+      if (a.part) { a.part[2 * blockIdx.x] = c; a.part[2 * blockIdx.x + 1] = m; }
+      else { atomicAdd(a.loss_acc + LA_MATCH_SUM, c); atomicAdd(a.loss_acc + LA_MASK_SUM, m); }
     }
   }
 }
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
     const size_t off = (size_t)row * HUAL_D + col;
     const float mk = rs.rowmask[row];
     float4 d = ld4(g.dOut + off);
+    if (g.dOut2) { const float4 d2 = ld4(g.dOut2 + off); d = make_float4(d.x + d2.x, d.y + d2.y, d.z + d2.z, d.w + d2.w); }
     d = make_float4(d.x * mk, d.y * mk, d.z * mk, d.w * mk);   // through the *v_mask of model.py:97
     const float4 f = ld4(a.fuse + off);
     const float4 p = *reinterpret_cast<const float4*>(a.probs + (size_t)row * 4);
@@ -266,15 +267,26 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
     for (int k = 0; k < 8; ++k) s += redb[k][threadIdx.x];
     atomicAdd(g.dbm + threadIdx.x, s);
   }
+  if (g.dE_ortho && blockIdx.x == 0)      // gradient of the orthogonality term (model.py:88-91), computed by the forward's loss tail
+    for (int idx = threadIdx.x; idx < 4 * HUAL_D; idx += 256) atomicAdd(g.dE + idx, g.dE_ortho[idx]);
 }
 
 // ortho: one block of 128 threads
 // forward use (tail != 0) also closes the loss: match denominator (layers.py:173) and the four reported loss terms
 __global__ __launch_bounds__(128) void ortho_kernel(const float* E, float* dE, float* loss_acc, float lambda, int tail,
-                                                    float override_denom, const float* denom_dev, float* loss_out) {
+                                                    float override_denom, const float* denom_dev, float* loss_out,
+                                                    const float* match_part, int match_nblk, float* dE_store) {
   __shared__ float M[16];
   __shared__ float sm[4];
   const int c = threadIdx.x;
+  if (tail && match_part) {      // per-block partial sums of match_fwd_kernel, in a fixed order
+    float cs = 0.f, ms = 0.f;
+    for (int i = c; i < match_nblk; i += 128) { cs += match_part[2 * i]; ms += match_part[2 * i + 1]; }
+    cs = block_sum(cs, sm);
+    ms = block_sum(ms, sm);
+    if (c == 0) { loss_acc[LA_MATCH_SUM] = cs; loss_acc[LA_MASK_SUM] = ms; }
+    __syncthreads();
+  }
   float e[4];
   for (int i = 0; i < 4; ++i) e[i] = E[i * HUAL_D + c];
   for (int i = 0; i < 4; ++i)
@@ -306,6 +318,13 @@ __global__ __launch_bounds__(128) void ortho_kernel(const float* E, float* dE, f
       float s = 0.f;
       for (int k = 0; k < 4; ++k) s += M[i * 4 + k] * e[k];
       dE[i * HUAL_D + c] += lambda * 2.0f * s / nrm;
+    }
+  }
+  if (dE_store) {      // the same gradient, left in scratch for match_bwd_kernel to fold in (one launch fewer in backward)
+    for (int i = 0; i < 4; ++i) {
+      float s = 0.f;
+      for (int k = 0; k < 4; ++k) s += M[i * 4 + k] * e[k];
+      dE_store[i * HUAL_D + c] = nrm > 0.f ? lambda * 2.0f * s / nrm : 0.f;
     }
   }
 }
@@ -584,8 +603,9 @@ static int rowgrid(int R, int cap) {
   int g = cdiv(R, 8);
   return g < cap ? (g > 0 ? g : 1) : cap;
 }
+int match_fwd_blocks(int Nv) { return rowgrid(Nv, 512); }
 int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, match_fwd_kernel, dim3(rowgrid(rs.Nv, 128)), dim3(256), 0, s, a, rs);
+  HUAL_LAUNCH(0.0, 0.0, match_fwd_kernel, dim3(a.part ? match_fwd_blocks(rs.Nv) : rowgrid(rs.Nv, 128)), dim3(256), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -600,13 +620,15 @@ int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, 
   return 0;
 }
 int launch_ortho(const float* E, float* dE, float* loss_acc, float lambda, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, dE, loss_acc, lambda, 0, 0.f, (const float*)nullptr, (float*)nullptr);
+  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, dE, loss_acc, lambda, 0, 0.f, (const float*)nullptr, (float*)nullptr,
+              (const float*)nullptr, 0, (float*)nullptr);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_loss_tail(const float* E, float* loss_acc, float lambda, float override_denom, const float* denom_dev, float* loss_out,
-                     hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, (float*)nullptr, loss_acc, lambda, 1, override_denom, denom_dev, loss_out);
+                     const float* match_part, int match_nblk, float* dE_ortho, hipStream_t s) {
+  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, (float*)nullptr, loss_acc, lambda, 1, override_denom, denom_dev, loss_out,
+              match_part, match_nblk, dE_ortho);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

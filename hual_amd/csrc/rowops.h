@@ -26,6 +26,9 @@ struct LnFwd {
   // optional: x is not given ready but as nparts partial sums (feature_ksplit_kernel): x = sum_q part[q*part_stride + ...]
   // + part_bias; the sum is also written to x_out (the pre-LN tensor backward needs)
   const float* part; int nparts; size_t part_stride; const float* part_bias; float* x_out;
+  // optional second parameter set for the rows >= split (video rows and query rows of the unified row space in one launch:
+  // v_layer_norm / q_layer_norm and the two projection biases, model.py:43,49); split <= 0: one set for all rows
+  int split; const float* g1_hi; const float* b1_hi; const float* part_bias_hi;
 };
 int launch_ln_fwd(const LnFwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
 
@@ -74,8 +77,13 @@ struct ColsumJob {
 };
 int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s);
 
-// dpos[t] += sum_b dx[b,t] over both sides (pos table shared by video and query, model.py:53,56)
-int launch_pos_bwd(const float* dx, float* dpos, const RowSpace& rs, int do_v, int do_q, hipStream_t s);
+// dpos[t] += sum_b dx[b,t] (over the video rows, the query rows or both: the shared table serves both sides, model.py:53,56)
+// for up to HUAL_POS_MAX_JOBS tables in one launch; a job sums up to two gradient tensors (the predictor's two encoder
+// passes share one table).  Jobs must have distinct dpos.
+#define HUAL_POS_MAX_JOBS 2
+struct PosBwdJob { const float* dx[2]; float* dpos; int do_v, do_q; };
+struct PosBwdBatch { PosBwdJob j[HUAL_POS_MAX_JOBS]; };
+int launch_pos_bwd(const PosBwdJob* jobs, int njobs, const RowSpace& rs, hipStream_t s);
 
 // generic elementwise helpers on [R,128] tensors -----------------------------------------------------------
 enum EwOp {

@@ -48,8 +48,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd a, RowSpace rs, DropC
   const int col = 4 * l32;
   for (int row = blockIdx.x * 8 + grp; row < a.R; row += gridDim.x * 8) {
     float4 v;
+    const bool hi = a.split > 0 && row >= a.split;
     if (a.part) {       // K-split partial sums of the producing dense layer (+ its bias)
-      v = ld4(a.part_bias + col);
+      v = ld4((hi ? a.part_bias_hi : a.part_bias) + col);
       for (int q = 0; q < a.nparts; ++q) v = f4add_(v, ld4(a.part + (size_t)q * a.part_stride + (size_t)row * HUAL_D + col));
       st4(a.x_out + (size_t)row * HUAL_D + col, v);
     } else {
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd a, RowSpace rs, DropC
     float mean, rstd;
     row_stats(v, mean, rstd);
     float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
-    float4 y = f4fma_(xh, ld4(a.g1 + col), ld4(a.b1 + col));
+    float4 y = f4fma_(xh, ld4((hi ? a.g1_hi : a.g1) + col), ld4((hi ? a.b1_hi : a.b1) + col));
     if (a.pos) {
       int t, n, base;
       row_to_clip(row + a.row0, rs.Nv, rs.T, rs.L, t, n, base);
@@ -267,17 +268,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch batch) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void pos_bwd_kernel(const float* dx, float* dpos, RowSpace rs, int do_v, int do_q) {
+__global__ __launch_bounds__(512) void pos_bwd_kernel(PosBwdBatch batch, RowSpace rs) {
   __shared__ float part[4][HUAL_D];
+  const PosBwdJob& job = batch.j[blockIdx.y];
   const int t = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
   float s = 0.f;
-  if (do_v && t < rs.T)
-    for (int b = grp; b < rs.B; b += 4) s += dx[(size_t)(b * rs.T + t) * HUAL_D + c];
-  if (do_q && t < rs.L)
-    for (int b = grp; b < rs.B; b += 4) s += dx[(size_t)(rs.Nv + b * rs.L + t) * HUAL_D + c];
+  for (int k = 0; k < 2; ++k) {
+    const float* dx = job.dx[k];
+    if (!dx) continue;
+    if (job.do_v && t < rs.T)
+      for (int b = grp; b < rs.B; b += 4) s += dx[(size_t)(b * rs.T + t) * HUAL_D + c];
+    if (job.do_q && t < rs.L)
+      for (int b = grp; b < rs.B; b += 4) s += dx[(size_t)(rs.Nv + b * rs.L + t) * HUAL_D + c];
+  }
   part[grp][c] = s;
   __syncthreads();
-  if (grp == 0) dpos[(size_t)t * HUAL_D + c] += part[0][c] + part[1][c] + part[2][c] + part[3][c];
+  if (grp == 0 && ((job.do_v && t < rs.T) || (job.do_q && t < rs.L)))
+    job.dpos[(size_t)t * HUAL_D + c] += part[0][c] + part[1][c] + part[2][c] + part[3][c];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -400,12 +407,19 @@ int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s) {
   return 0;
 }
 
-int launch_pos_bwd(const float* dx, float* dpos, const RowSpace& rs, int do_v, int do_q, hipStream_t s) {
+int launch_pos_bwd(const PosBwdJob* jobs, int njobs, const RowSpace& rs, hipStream_t s) {
+  HUAL_REQUIRE(njobs >= 1 && njobs <= HUAL_POS_MAX_JOBS, "pos_bwd: job count");
+  PosBwdBatch b;
+  ::memset((void*)&b, 0, sizeof(b));
   int n = 0;
-  if (do_v) n = rs.T;
-  if (do_q && rs.L > n) n = rs.L;
+  for (int i = 0; i < njobs; ++i) {
+    HUAL_REQUIRE(jobs[i].dx[0] && jobs[i].dpos, "pos_bwd: null tensor");
+    b.j[i] = jobs[i];
+    if (jobs[i].do_v && rs.T > n) n = rs.T;
+    if (jobs[i].do_q && rs.L > n) n = rs.L;
+  }
   if (n == 0) return 0;
-  HUAL_LAUNCH(0.0, 0.0, pos_bwd_kernel, dim3(n), dim3(512), 0, s, dx, dpos, rs, do_v, do_q);
+  HUAL_LAUNCH(0.0, 0.0, pos_bwd_kernel, dim3(n, njobs), dim3(512), 0, s, b, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

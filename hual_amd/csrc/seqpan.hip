@@ -592,14 +592,15 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* lin_mean = c.vec("lin.mean");
   float* lin_rstd = c.vec("lin.rstd");
   {
+    // v_layer_norm on the video rows, q_layer_norm on the query rows (+ position embeddings): one launch over the unified rows
     LnFwd a{};
-    a.x = lin; a.R = Nv; a.g1 = c.p(pm.vln.g); a.b1 = c.p(pm.vln.b); a.y1 = x; a.mean = lin_mean; a.rstd = lin_rstd;
+    a.x = lin; a.R = R; a.g1 = c.p(pm.vln.g); a.b1 = c.p(pm.vln.b); a.y1 = x; a.mean = lin_mean; a.rstd = lin_rstd;
     a.pos = c.p(pm.pos); a.drop_site = -1; a.row0 = 0;
-    if (ksplit) { a.x = nullptr; a.part = vpart; a.nparts = 4; a.part_stride = (size_t)R * D; a.part_bias = c.p(pm.vconv.b); a.x_out = lin; }
-    c.ln_fwd(a, rs);
-    a.x = lin + (size_t)Nv * D; a.R = Nq; a.g1 = c.p(pm.qln.g); a.b1 = c.p(pm.qln.b); a.y1 = x + (size_t)Nv * D;
-    a.mean = lin_mean + Nv; a.rstd = lin_rstd + Nv; a.row0 = Nv;
-    if (ksplit) { a.x = nullptr; a.part = vpart + (size_t)Nv * D; a.part_bias = c.p(pm.qconv.b); a.x_out = lin + (size_t)Nv * D; }
+    a.split = Nv; a.g1_hi = c.p(pm.qln.g); a.b1_hi = c.p(pm.qln.b);
+    if (ksplit) {
+      a.x = nullptr; a.part = vpart; a.nparts = 4; a.part_stride = (size_t)R * D; a.part_bias = c.p(pm.vconv.b);
+      a.part_bias_hi = c.p(pm.qconv.b); a.x_out = lin;
+    }
     c.ln_fwd(a, rs);
   }
   // ---------------- shared conv block (model.py:54-58)
@@ -781,6 +782,8 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   // private copy for the backward pass (the caller owns match_scores and may overwrite it)
   float* probs_keep = c.buf("match.probs", Nv, 4);
   ma.probs2 = (lab && !c.dry) ? probs_keep : nullptr;
+  float* match_part = c.buf("match.part", (size_t)match_fwd_blocks(Nv), 2);
+  ma.part = match_part;
   if (!c.dry && c.ok()) c.chk(launch_match_fwd(ma, c.rs, c.stream));
   // ---------------- alignment loss, per-sample part (model.py:76)
   AlignPool ap{};
@@ -923,7 +926,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     if (lab && c.ok()) {
       if (c.align_forked) HUAL_CHECK_HIP(hipStreamWaitEvent(c.stream, (hipEvent_t)c.aux->ev_join, 0));
       c.chk(launch_loss_tail(c.p(pm.label_emb), loss_acc, c.cfg->match_lambda, opt->match_denom_override, opt->match_denom_dev,
-                             out->loss_terms, c.stream));
+                             out->loss_terms, match_part, match_fwd_blocks(Nv), c.buf("ortho.dE", 4, D), c.stream));
     }
   }
   return c.rc;
@@ -1022,6 +1025,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.ln_bwd(a);
   }
   float* d_in = nullptr;
+  float* fe_dx0[2] = {nullptr, nullptr};
   for (int ps = 1; ps >= 0; --ps) {
     const std::string t = "fe" + std::to_string(ps);
     const int site = HUAL_SITE_FE + 16 * ps;
@@ -1115,17 +1119,13 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       c.ln_bwd(a);
     }
     float* d_x0 = conv_block_bwd(c, t, x0, d_f, pm.fe_cb, c.rsv, site, c.fuse_row);
-    if (!c.dry && c.ok()) c.chk(launch_pos_bwd(d_x0, c.g(pm.fe_pos), c.rsv, 1, 0, c.stream));
+    fe_dx0[ps] = d_x0;            // the position-table gradients of the step are summed in ONE launch at the end
     d_in = d_x0;
   }
   flush_dw(c);
   // ---------------- gradient wrt `outputs`, matching head
-  float* d_outputs = c.actv("d.outputs");
-  {
-    EwArgs e{};
-    e.op = EW_ADD; e.R = Nv; e.a = d_in; e.b = d_out_heads; e.out = d_outputs; e.drop_site = -1;
-    c.ew(e);
-  }
+  // (gradient wrt `outputs` = what the encoders sent back + what the two hidden layers of the heads sent back: summed by
+  //  match_bwd_kernel on the way in)
   float* fuse = c.actv("fuse");
   float* d_fuse = c.actv("d.fuse");
   if (!c.dry && c.ok()) {
@@ -1135,11 +1135,12 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     // probs were written to the caller's match_scores buffer; keep a private copy for backward
     ma.probs = c.buf("match.probs", Nv, 4);
     MatchBwd mb{};
-    mb.dOut = d_outputs; mb.dFuse = d_fuse; mb.dWm = c.g(pm.match.k); mb.dbm = c.g(pm.match.b); mb.dE = c.g(pm.label_emb);
+    mb.dOut = d_in; mb.dOut2 = d_out_heads; mb.dFuse = d_fuse; mb.dWm = c.g(pm.match.k); mb.dbm = c.g(pm.match.b); mb.dE = c.g(pm.label_emb);
     mb.lambda = c.cfg->match_lambda;
+    mb.dE_ortho = c.buf("ortho.dE", 4, D);
     c.chk(launch_match_bwd(ma, mb, c.rs, c.stream));
-    if (c.ok()) c.chk(launch_ortho(c.p(pm.label_emb), c.g(pm.label_emb), loss_acc, c.cfg->match_lambda, c.stream));
   } else {
+    c.buf("ortho.dE", 4, D);
     c.buf("match.probs", Nv, 4);
   }
   // ---------------- cq_concat
@@ -1425,7 +1426,12 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   // ---------------- shared conv block, position table, input layer norms, projections
   float* x0 = c.act("cb.x0");
   float* d_x0 = conv_block_bwd(c, "cb", x0, dx, pm.cb, c.rs, HUAL_SITE_CONV, c.fuse_row && c.cfg->attn_layer > 0);
-  if (!c.dry && c.ok()) c.chk(launch_pos_bwd(d_x0, c.g(pm.pos), c.rs, 1, 1, c.stream));
+  if (!c.dry && c.ok()) {
+    PosBwdJob pj[2];
+    pj[0] = PosBwdJob{{d_x0, nullptr}, c.g(pm.pos), 1, 1};
+    pj[1] = PosBwdJob{{fe_dx0[1], fe_dx0[0]}, c.g(pm.fe_pos), 1, 0};
+    c.chk(launch_pos_bwd(pj, 2, c.rs, c.stream));
+  }
   float* lin = c.act("lin");
   float* lin_mean = c.vec("lin.mean");
   float* lin_rstd = c.vec("lin.rstd");
