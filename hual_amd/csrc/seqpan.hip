@@ -37,6 +37,9 @@ __global__ void prep_masks_kernel(const int32_t* lens, const int32_t* word_ids, 
 }
 namespace {
 
+// stages of the graph (forward order; backward runs them in reverse)
+enum { ST_ALWAYS = 0, ST_INPUT = 1, ST_CONV = 2, ST_DA = 3, ST_CQ = 4, ST_FUSE = 5, ST_PRED = 6 };
+
 struct WsEntry { std::string name; size_t off, rows, cols; };
 
 struct Ctx {
@@ -86,6 +89,7 @@ struct Ctx {
   float* buf(const std::string& name, size_t rows, size_t cols) {
     auto it = index.find(name);
     if (it != index.end()) return reinterpret_cast<float*>(base + entries[it->second].off);
+    if (!dry) { if (rc == 0) rc = fail(HUAL_ERR_WORKSPACE, "internal: workspace buffer requested outside the planning pass"); return reinterpret_cast<float*>(base); }
     WsEntry e{name, used, rows, cols};
     size_t bytes = (rows * cols * sizeof(float) + 255) & ~(size_t)255;
     used += bytes + 256;     // 256 B guard: clamped fragment loads never leave the workspace
@@ -102,6 +106,16 @@ struct Ctx {
   float* g(size_t off) const { return G + off; }
   bool ok() const { return rc == 0; }
   void chk(int r) { if (rc == 0 && r != 0) rc = r; }
+  // ---- stage selection (per-block entry points, include/hual_seqpan.h): the graph is cut into stages; with sel_stage >= 0
+  // only the prologue (masks, weight images) and that stage enqueue work - buffer naming / allocation is unaffected
+  int sel_stage = -1, sel_sub = 0;
+  bool active = true;
+  bool want_bwd = false;      // forward keeps what a backward pass needs (labels given, or a block entry point asks for it)
+  int part_seq = 0;           // running id of the per-block partial-sum scratch buffers (stable whatever runs)
+  void stage(int st, int sub = 0) { active = sel_stage < 0 || st == ST_ALWAYS || (st == sel_stage && (st != ST_DA || sub == sel_sub)); }
+  bool stage_on(int st, int sub = 0) const { return sel_stage < 0 || (st == sel_stage && (st != ST_DA || sub == sel_sub)); }
+  bool live() const { return !dry && active && rc == 0; }
+  void push_dw(const DwJob& j) { if (active) dwjobs.push_back(j); }
 
   // ---- launch wrappers (skipped in the dry pass) ----
   const DenseW* find_dense(size_t x) const {      // the weight whose [off, off + K*128) holds float offset x
@@ -148,7 +162,7 @@ struct Ctx {
     return true;
   }
   void gemm(const GemmJob* j, int n) {
-    if (dry || !ok()) return;
+    if (!live()) return;
     if (use_bf16 && n <= HUAL_MAX_JOBS) {
       GemmJob pk[HUAL_MAX_JOBS];
       bool all = true;
@@ -168,7 +182,7 @@ struct Ctx {
   // `ngroups` consecutive groups of jobs (group g has gsz[g] jobs) where every group only reads, of the outputs of the
   // earlier groups, rows of its own row block: one chained launch (gemm_chain_kernel) or, as fallback, one launch per group
   void gemm_chain(const GemmJob* j, const int* gsz, int ngroups) {
-    if (dry || !ok()) return;
+    if (!live()) return;
     int n = 0;
     for (int g = 0; g < ngroups; ++g) n += gsz[g];
     if (use_bf16 && use_chain && n <= HUAL_MAX_JOBS) {
@@ -182,50 +196,50 @@ struct Ctx {
     }
     for (int g = 0, i = 0; g < ngroups; i += gsz[g], ++g) gemm(j + i, gsz[g]);
   }
-  void ln_fwd(const LnFwd& a, const RowSpace& r) { if (!dry && ok()) chk(launch_ln_fwd(a, r, drop, stream)); }
+  void ln_fwd(const LnFwd& a, const RowSpace& r) { if (live()) chk(launch_ln_fwd(a, r, drop, stream)); }
   // layer-norm backward; the per-block dgamma / dbeta sums go to scratch and are folded in by flush_colsum()
   void ln_bwd(const LnBwd& a0) {
     LnBwd a = a0;
     const int nblk = ln_bwd_blocks(a.R);
-    a.part = buf("part." + std::to_string(colsum.size()), (size_t)nblk * 4, HUAL_D);
+    a.part = buf("part." + std::to_string(part_seq++), (size_t)nblk * 4, HUAL_D);
     ColsumJob cj{};
     cj.src = a.part; cj.nblk = nblk; cj.nvec = 4;      // scratch layout [blk][4][128]; null dst = unused vector
     cj.dst[0] = a.dg1; cj.dst[1] = a.db1; cj.dst[2] = a.dg2; cj.dst[3] = a.db2;
-    colsum.push_back(cj);
-    if (!dry && ok()) chk(launch_ln_bwd(a, drop, stream));
+    if (active) colsum.push_back(cj);
+    if (live()) chk(launch_ln_bwd(a, drop, stream));
   }
   void dwconv_ln_bwd(const ConvBwd& a0, const RowSpace& r) {
     ConvBwd a = a0;
     const int nblk = dwconv_bwd_blocks(r);
-    a.part = buf("part." + std::to_string(colsum.size()), (size_t)nblk * 9, HUAL_D);
+    a.part = buf("part." + std::to_string(part_seq++), (size_t)nblk * 9, HUAL_D);
     ColsumJob cj{};
     cj.src = a.part; cj.nblk = nblk; cj.nvec = 9;
     for (int k = 0; k < 7; ++k) cj.dst[k] = a.ddw + k * HUAL_D;
     cj.dst[7] = a.dg; cj.dst[8] = a.db;
-    colsum.push_back(cj);
-    if (!dry && ok()) chk(launch_dwconv_ln_bwd(a, r, drop, stream));
+    if (active) colsum.push_back(cj);
+    if (live()) chk(launch_dwconv_ln_bwd(a, r, drop, stream));
   }
   // fused dX products + layer norm(s) backward (dablock.h); the per-workgroup parameter sums are folded in by flush_colsum()
   void ln_proj_bwd(const LnProjBwdArgs& a0, float* dg1, float* db1, float* dg2, float* db2) {
     LnProjBwdArgs a = a0;
     a.MT = ln_proj_bwd_rows(a.R);
     const int nblk = ln_proj_bwd_blocks(a.R);
-    a.part = buf("part." + std::to_string(colsum.size()), (size_t)nblk * 4, HUAL_D);
+    a.part = buf("part." + std::to_string(part_seq++), (size_t)nblk * 4, HUAL_D);
     ColsumJob cj{};
     cj.src = a.part; cj.nblk = nblk; cj.nvec = 4;
     cj.dst[0] = dg1; cj.dst[1] = db1; cj.dst[2] = dg2; cj.dst[3] = db2;
-    colsum.push_back(cj);
-    if (!dry && ok()) chk(launch_ln_proj_bwd(a, drop, stream));
+    if (active) colsum.push_back(cj);
+    if (live()) chk(launch_ln_proj_bwd(a, drop, stream));
   }
   void flush_colsum() {
-    for (size_t i = 0; i < colsum.size() && !dry && ok(); i += HUAL_COLSUM_MAX_JOBS)
+    for (size_t i = 0; i < colsum.size() && !dry && ok(); i += HUAL_COLSUM_MAX_JOBS)   // (whatever stages ran)
       chk(launch_colsum(colsum.data() + i, (int)std::min<size_t>(HUAL_COLSUM_MAX_JOBS, colsum.size() - i), stream));
     colsum.clear();
   }
-  void ew(const EwArgs& a) { if (!dry && ok()) chk(launch_ew(a, drop, stream)); }
-  void attn_fwd(const AttnJob* j, int n) { if (!dry && ok()) chk(launch_attn_fwd(j, n, drop, stream)); }
+  void ew(const EwArgs& a) { if (live()) chk(launch_ew(a, drop, stream)); }
+  void attn_fwd(const AttnJob* j, int n) { if (live()) chk(launch_attn_fwd(j, n, drop, stream)); }
   void attn_bwd(const AttnJob* j, int n) {
-    if (!dry && ok()) chk(launch_attn_bwd(j, n, drop, stream));
+    if (live()) chk(launch_attn_bwd(j, n, drop, stream));
   }
 };
 
@@ -418,7 +432,7 @@ float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP
       L.drop_site = site0 + i;
       xin = L.xout;
     }
-    if (!c.dry && c.ok()) c.chk(launch_conv_block_fwd(a, rs, c.drop, c.stream));
+    if (c.live()) c.chk(launch_conv_block_fwd(a, rs, c.drop, c.stream));
     return xin;
   }
   if (pos_src) {
@@ -434,7 +448,7 @@ float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP
     float* mean = c.buf(tag + ".mean" + is, R, 1);
     float* rstd = c.buf(tag + ".rstd" + is, R, 1);
     ConvFwd cf{x, c.p(cp.ln[i].g), c.p(cp.ln[i].b), c.p(cp.dw[i]), cbuf, mean, rstd};
-    if (!c.dry && c.ok()) c.chk(launch_ln_dwconv_fwd(cf, rs, c.stream));
+    if (c.live()) c.chk(launch_ln_dwconv_fwd(cf, rs, c.stream));
     GemmJob j = mkjob(cbuf, HUAL_D, R, HUAL_D, c.p(cp.pw[i]), c.p(cp.b[i]), xn, HUAL_D);
     j.act = ACT_RELU;
     j.save = y; j.ldsave = HUAL_D;
@@ -468,15 +482,15 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
       L.dz = c.buf("d." + tag + ".z" + is, R, HUAL_D);
       L.dz_prev = i > 0 ? c.buf("d." + tag + ".z" + std::to_string(i - 1), R, HUAL_D) : nullptr;
       L.drop_site_prev = site0 + i - 1;
-      L.part = c.buf("part." + std::to_string(c.colsum.size()), (size_t)nblk * 9, HUAL_D);
+      L.part = c.buf("part." + std::to_string(c.part_seq++), (size_t)nblk * 9, HUAL_D);
       ColsumJob cj{};
       cj.src = L.part; cj.nblk = nblk; cj.nvec = 9;
       for (int k = 0; k < 7; ++k) cj.dst[k] = c.g(cp.dw[i]) + k * HUAL_D;
       cj.dst[7] = c.g(cp.ln[i].g); cj.dst[8] = c.g(cp.ln[i].b);
-      c.colsum.push_back(cj);
-      c.dwjobs.push_back(mkdw(c.buf(tag + ".c" + is, R, HUAL_D), HUAL_D, HUAL_D, L.dz, HUAL_D, R, c.g(cp.pw[i]), c.g(cp.b[i])));
+      if (c.active) c.colsum.push_back(cj);
+      c.push_dw(mkdw(c.buf(tag + ".c" + is, R, HUAL_D), HUAL_D, HUAL_D, L.dz, HUAL_D, R, c.g(cp.pw[i]), c.g(cp.b[i])));
     }
-    if (!c.dry && c.ok()) c.chk(launch_conv_block_bwd(a, rs, c.drop, c.stream));
+    if (c.live()) c.chk(launch_conv_block_bwd(a, rs, c.drop, c.stream));
     return a.dx_out;
   }
   for (int i = 3; i >= 0; --i) {
@@ -490,7 +504,7 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
     float* dC = c.buf("d." + tag + ".c" + is, R, HUAL_D);
     float* dxin = c.buf("d." + tag + ".x" + is, R, HUAL_D);
     // dZ = dropout'(dx) * relu'(y): its own elementwise launch, or formed in the GEMM's A prologue (c.fuse_bwd)
-    c.dwjobs.push_back(mkdw(cbuf, HUAL_D, HUAL_D, dZ, HUAL_D, R, c.g(cp.pw[i]), c.g(cp.b[i])));
+    c.push_dw(mkdw(cbuf, HUAL_D, HUAL_D, dZ, HUAL_D, R, c.g(cp.pw[i]), c.g(cp.b[i])));
     const bool dz_ready = i == 3 ? dz3_ready : c.fuse_row;
     if (dz_ready) {
       GemmJob j = mkjob_dx(dZ, HUAL_D, R, HUAL_D, c.pt(cp.pw[i]), HUAL_D, dC, HUAL_D);
@@ -534,6 +548,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   c.rs.rowmask = rowmask;
   c.rsv.rowmask = rowmask;
   float* loss_acc = c.buf("loss_acc", 8, 1);
+  c.stage(ST_ALWAYS);
   if (!c.dry) {
     HUAL_LAUNCH(0.0, 0.0, prep_masks_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.stream, bt->video_seq_len, bt->word_ids,
                 rowmask, B, T, L, loss_acc);
@@ -546,9 +561,10 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     std::vector<uint32_t> offs, boffs;
     std::vector<int> Ks;
     for (const auto& d : c.dense) { offs.push_back((uint32_t)d.off); Ks.push_back(d.K); boffs.push_back((uint32_t)d.boff); }
-    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, lab ? c.PKB : nullptr, c.stream));
+    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream));
   }
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
+  c.stage(ST_INPUT);
   float* cat = c.buf("cat", Nq, catw);
   int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
   float* embed_scratch = c.buf("embed.scratch", embed_layout(Nq, c.C, c.cfg->char_dim).total, 1);
@@ -560,7 +576,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     ea.cat = cat; ea.ldcat = catw; ea.char_arg = char_arg;
     set_embed_scratch(ea, embed_scratch, Nq, c.C, c.cfg->char_dim);
     ea.word_dim = c.cfg->word_dim; ea.char_dim = c.cfg->char_dim; ea.C = c.C; ea.num_chars = c.cfg->num_chars;
-    if (c.ok()) c.chk(launch_embed_fwd(ea, Nq, c.drop, c.stream));
+    if (c.live()) c.chk(launch_embed_fwd(ea, Nq, c.drop, c.stream));
   }
   // ---------------- the two input projections (model.py:42,48) as one launch; LN + pos (model.py:43,49,53,56)
   float* lin = c.act("lin");
@@ -571,7 +587,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   const bool ksplit = c.use_bf16 && ksplit_env && (c.cfg->vdim % 256) == 0 && c.cfg->vdim <= 1024 && (catw % 8) == 0 && qks <= 256;
   float* vpart = c.buf("lin.part", (size_t)4 * R, D);
   if (ksplit) {
-    if (!c.dry && c.ok()) {
+    if (c.live()) {
       FkJob fj[2];
       fj[0] = FkJob{reinterpret_cast<const float*>(bt->video), c.cfg->vdim, Nv, c.cfg->vdim, c.cfg->vdim / 4,
                     reinterpret_cast<const float*>(c.PKF + pm.vconv.k * 4), vpart, (size_t)R * D, HUAL_SITE_VIDEO, 0,
@@ -581,7 +597,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       c.chk(launch_feature_ksplit(fj, 2, c.drop, c.stream));
     }
   } else {
-    if (!c.dry && bt->video_dtype != HUAL_DTYPE_F32) return fail(HUAL_ERR_UNSUPPORTED, "bfloat16 video features need the K-split feature-load kernel (vdim % 256 == 0, vdim <= 1024)");
+    if (c.live() && bt->video_dtype != HUAL_DTYPE_F32) return fail(HUAL_ERR_UNSUPPORTED, "bfloat16 video features need the K-split feature-load kernel (vdim % 256 == 0, vdim <= 1024)");
     GemmJob j[2];
     j[0] = mkjob(c.dry ? nullptr : reinterpret_cast<const float*>(bt->video), c.cfg->vdim, Nv, c.cfg->vdim, c.p(pm.vconv.k), c.p(pm.vconv.b), lin, D);
     j[0].a_drop_site = HUAL_SITE_VIDEO; j[0].a_drop_row0 = 0;
@@ -604,12 +620,14 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     c.ln_fwd(a, rs);
   }
   // ---------------- shared conv block (model.py:54-58)
+  c.stage(ST_CONV);
   x = conv_block_fwd(c, "cb", x, pm.cb, rs, HUAL_SITE_CONV);
   // ---------------- dual attention layers (model.py:60-68)
   for (int li = 0; li < c.cfg->attn_layer; ++li) {
     const DualAttnP& d = pm.da[li];
     const std::string t = "da" + std::to_string(li);
     const int site = HUAL_SITE_DA + 8 * li;
+    c.stage(ST_DA, li);
     float* ln1 = c.act(t + ".ln1");
     float* lnt = c.act(t + ".lnt");
     float* mean = c.vec(t + ".mean");
@@ -628,7 +646,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
         lp.wimg[k] = img(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = outs[k]; lp.ldo[k] = k < 3 ? 3 * D : 2 * D; lp.src[k] = k < 3 ? 0 : 1;
         lp.out_site[k] = -1;
       }
-      if (!c.dry && c.ok()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
+      if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
     } else {
       GemmJob j[5];
       // both layer norms of x (layers.py:73-74) run in the projections' A prologue; job 0 / 3 keep ln1 / lnt + statistics
@@ -698,7 +716,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       pa.sv = sv; pa.xv = xv; pa.sg = sg; pa.xg = xg; pa.o = o; pa.gd = gd; pa.gate = gate; pa.val = val; pa.mha = mha; pa.res = res;
       pa.l2 = l2; pa.out = xo; pa.mean2 = mean2; pa.rstd2 = rstd2;
       pa.site = site; pa.R = R; pa.MT = da_post_rows(R); pa.drop_row0 = 0;
-      if (!c.dry && c.ok()) c.chk(launch_da_post(pa, c.drop, c.stream));
+      if (c.live()) c.chk(launch_da_post(pa, c.drop, c.stream));
     } else {
     {
       GemmJob j[6];
@@ -733,6 +751,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     x = xo;
   }
   // ---------------- context-query attention in both directions (model.py:70-73)
+  c.stage(ST_CQ);
   CqBufs cq{};
   cq.X = x;
   cq.D1W = c.act("cq.d1w"); cq.D2 = c.act("cq.d2"); cq.S0 = c.vec("cq.s0"); cq.S1 = c.vec("cq.s1");
@@ -743,8 +762,8 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   cq.M2 = c.buf("cq.m2", (size_t)2 * B * cq_m2_rows_host(T, L), D);
   CqParams cqp{};
   for (int i = 0; i < 2; ++i) { cqp.w0[i] = c.p(pm.cq[i].w0); cqp.w1[i] = c.p(pm.cq[i].w1); cqp.wm[i] = c.p(pm.cq[i].wm); }
-  if (!c.dry && c.ok()) c.chk(launch_tri_prep(cq, cqp, c.rs, c.drop, c.stream));
-  if (!c.dry && c.ok()) c.chk(launch_cq_fwd(cq, c.rs, c.stream));
+  if (c.live()) c.chk(launch_tri_prep(cq, cqp, c.rs, c.drop, c.stream));
+  if (c.live()) c.chk(launch_cq_fwd(cq, c.rs, c.stream));
   float* cqf = c.act("cq.feats");      // q2v_feats (video rows) | v2q_feats (query rows)
   {
     GemmJob j[2];
@@ -763,10 +782,11 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     c.gemm(j, 2);
   }
   // ---------------- cq_concat (layers.py:145-154)
+  c.stage(ST_FUSE);
   PoolArgs pa{};
   pa.F2 = cqf; pa.wp = c.p(pm.pool_w); pa.Wbot = c.p(pm.cqcat.k) + (size_t)D * D;
   pa.alpha = c.buf("pool.alpha", B, L); pa.pooled = c.buf("pool.pooled", B, D); pa.PW = c.buf("pool.pw", B, D);
-  if (!c.dry && c.ok()) c.chk(launch_pool_fwd(pa, c.rs, c.stream));
+  if (c.live()) c.chk(launch_pool_fwd(pa, c.rs, c.stream));
   float* fuse = c.actv("fuse");
   {
     GemmJob j = mkjob(cqf, D, Nv, D, c.p(pm.cqcat.k), c.p(pm.cqcat.b), fuse, D);
@@ -784,7 +804,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   ma.probs2 = (lab && !c.dry) ? probs_keep : nullptr;
   float* match_part = c.buf("match.part", (size_t)match_fwd_blocks(Nv), 2);
   ma.part = match_part;
-  if (!c.dry && c.ok()) c.chk(launch_match_fwd(ma, c.rs, c.stream));
+  if (c.live()) c.chk(launch_match_fwd(ma, c.rs, c.stream));
   // ---------------- alignment loss, per-sample part (model.py:76)
   AlignPool ap{};
   ap.F2 = cqf; ap.F1 = cqf; ap.inner = (lab && !c.dry) ? lab->inner_labels : nullptr;
@@ -796,7 +816,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   // The alignment-loss branch (3 small, latency-bound launches) depends only on cq.feats and is needed again by the loss tail
   // at the very end of forward: with a side stream (hual_run_opts.aux) it is forked here and runs under the predictor.
   c.align_forked = false;
-  if (lab && !c.dry && c.ok()) {
+  if (lab && c.live()) {
     hipStream_t as_stream = c.stream;
     if (c.aux && c.aux->stream && !opt->align_external) {
       as_stream = (hipStream_t)c.aux->stream;
@@ -812,6 +832,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     if (c.align_forked) HUAL_CHECK_HIP(hipEventRecord((hipEvent_t)c.aux->ev_join, as_stream));
   }
   // ---------------- conditioned predictor (modules.py:143-160)
+  c.stage(ST_PRED);
   float* fin = outputs;
   float* feo[2];
   for (int ps = 0; ps < 2; ++ps) {
@@ -832,7 +853,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       for (int k = 0; k < 3; ++k) {
         lp.wimg[k] = img(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = qkv + k * D; lp.ldo[k] = 3 * D; lp.out_site[k] = -1;
       }
-      if (!c.dry && c.ok()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
+      if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
     } else {
       GemmJob j[3];
       j[0] = mkjob(f, D, Nv, D, c.p(pm.fe_q.k), c.p(pm.fe_q.b), qkv, 3 * D);
@@ -862,7 +883,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       lp.g1 = c.p(pm.fe_ln2.g); lp.b1 = c.p(pm.fe_ln2.b); lp.y1 = l2; lp.drop_site1 = site + 7; lp.mean = mean2; lp.rstd = rstd2;
       lp.nproj = 1; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
       lp.wimg[0] = img(pm.fe_dense.k); lp.bias[0] = c.p(pm.fe_dense.b); lp.out[0] = fo; lp.ldo[0] = D; lp.out_site[0] = site + 8; lp.add_x[0] = 1;
-      if (!c.dry && c.ok()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
+      if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
     } else {
       {
         EwArgs e{};
@@ -894,7 +915,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       lp.wimg[0] = reinterpret_cast<const float*>(c.PKF + hp.k * 4); lp.src[0] = 0; lp.accum[0] = 1; lp.out_site[0] = -1;
       lp.wimg[1] = reinterpret_cast<const float*>(c.PKF + (hp.k + (size_t)D * D) * 4); lp.src[1] = 1; lp.bias[1] = c.p(hp.b);
       lp.act[1] = 1; lp.out[1] = h == 0 ? hs : he; lp.ldo[1] = D; lp.out_site[1] = -1;
-      if (!c.dry && c.ok()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
+      if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
     }
   } else {
     GemmJob j[2];
@@ -911,7 +932,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   }
   float* d_s = c.buf("d.s_logit", B, T);
   float* d_e = c.buf("d.e_logit", B, T);
-  if (!c.dry && c.ok()) {
+  if (c.live()) {
     DotArgs da{};
     da.h[0] = hs; da.h[1] = he; da.w[0] = c.p(pm.sdense.k); da.w[1] = c.p(pm.edense.k);
     da.b[0] = c.p(pm.sdense.b); da.b[1] = c.p(pm.edense.b);
@@ -945,11 +966,13 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* loss_acc = c.buf("loss_acc", 8, 1);
   c.dwjobs.clear();
   c.colsum.clear();
+  c.part_seq = 0;
   c.dw_flushed = 0;
   c.dw_flushes = 0;
+  c.stage(ST_ALWAYS);
   // (a kernel, not hipMemsetAsync: memset nodes of a captured graph were seen to pick up the fill pattern of later eager
   //  memsets on this ROCm - every 4th gradient came back as the caller's learning rate)
-  if (!c.dry && c.ok()) c.chk(launch_zero(c.G, pm.total, c.stream));
+  if (c.live()) c.chk(launch_zero(c.G, pm.total, c.stream));
   // transposed copies of every dense weight that a dX product reads (weights are constant within a step)
   float* PT = c.buf("params.T", pm.total, 1);
   c.PT = PT;
@@ -980,6 +1003,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   }
   float* outputs = c.actv("outputs");
   // ---------------- heads
+  c.stage(ST_PRED);
   float* hs = c.actv("head.hs");
   float* he = c.actv("head.he");
   float* sfn = c.actv("head.sfn");
@@ -990,7 +1014,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* d_e = c.buf("d.e_logit", B, T);
   float* dz_hs = c.actv("d.head.zs");
   float* dz_he = c.actv("d.head.ze");
-  if (!c.dry && c.ok()) {
+  if (c.live()) {
     DotArgs da{};
     da.h[0] = hs; da.h[1] = he; da.w[0] = c.p(pm.sdense.k); da.w[1] = c.p(pm.edense.k); da.R = Nv;
     DotBwd db{};
@@ -1002,7 +1026,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     const DenseP& hp = h == 0 ? pm.shid : pm.ehid;
     DwJob j = mkdw(h == 0 ? sfn : efn, D, D, h == 0 ? dz_hs : dz_he, D, Nv, c.g(hp.k), c.g(hp.b));
     j.npieces = 2; j.A[1] = outputs; j.lda[1] = D; j.kw[1] = D; j.dW[1] = c.g(hp.k) + (size_t)D * D;
-    c.dwjobs.push_back(j);
+    c.push_dw(j);
   }
   float* d_sfn = c.actv("d.head.sfn");
   float* d_efn = c.actv("d.head.efn");
@@ -1051,7 +1075,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     }
     // out = dropout(l2 . Wd + b, s8) + res
     float* dzd = c.actv("d." + t + ".zd");
-    c.dwjobs.push_back(mkdw(l2, D, D, dzd, D, Nv, c.g(pm.fe_dense.k), c.g(pm.fe_dense.b)));
+    c.push_dw(mkdw(l2, D, D, dzd, D, Nv, c.g(pm.fe_dense.k), c.g(pm.fe_dense.b)));
     float* d_l2 = c.actv("d." + t + ".l2");
     float* d_res = c.actv("d." + t + ".res");
     auto imgt = [&](size_t off) { return reinterpret_cast<const float*>(c.PKB + off * 4); };
@@ -1089,9 +1113,9 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       set_dmask(c, a, t + ".dm");
       c.attn_bwd(&a, 1);
     }
-    c.dwjobs.push_back(mkdw(a1, D, D, d_qkv, 3 * D, Nv, c.g(pm.fe_q.k), c.g(pm.fe_q.b)));
-    c.dwjobs.push_back(mkdw(a1, D, D, d_qkv + D, 3 * D, Nv, c.g(pm.fe_k.k), c.g(pm.fe_k.b)));
-    c.dwjobs.push_back(mkdw(a1, D, D, d_qkv + 2 * D, 3 * D, Nv, c.g(pm.fe_v.k), c.g(pm.fe_v.b)));
+    c.push_dw(mkdw(a1, D, D, d_qkv, 3 * D, Nv, c.g(pm.fe_q.k), c.g(pm.fe_q.b)));
+    c.push_dw(mkdw(a1, D, D, d_qkv + D, 3 * D, Nv, c.g(pm.fe_k.k), c.g(pm.fe_k.b)));
+    c.push_dw(mkdw(a1, D, D, d_qkv + 2 * D, 3 * D, Nv, c.g(pm.fe_v.k), c.g(pm.fe_v.b)));
     float* d_a = c.actv("d." + t + ".a");
     float* d_f = c.actv("d." + t + ".x4");
     if (c.fuse_da) {       // query / key / value ^T + layer_norm_1 backward in one launch
@@ -1124,11 +1148,12 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   }
   flush_dw(c);
   // ---------------- gradient wrt `outputs`, matching head
+  c.stage(ST_FUSE);
   // (gradient wrt `outputs` = what the encoders sent back + what the two hidden layers of the heads sent back: summed by
   //  match_bwd_kernel on the way in)
   float* fuse = c.actv("fuse");
   float* d_fuse = c.actv("d.fuse");
-  if (!c.dry && c.ok()) {
+  if (c.live()) {
     MatchArgs ma{};
     ma.fuse = fuse; ma.Wm = c.p(pm.match.k); ma.bm = c.p(pm.match.b); ma.E = c.p(pm.label_emb);
     ma.labels = lab->match_labels; ma.probs = nullptr; ma.outputs = outputs; ma.loss_acc = loss_acc;
@@ -1146,18 +1171,18 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   // ---------------- cq_concat
   float* cqf = c.act("cq.feats");
   float* d_cqf = c.act("d.cq.feats");
-  c.dwjobs.push_back(mkdw(cqf, D, D, d_fuse, D, Nv, c.g(pm.cqcat.k), c.g(pm.cqcat.b)));
+  c.push_dw(mkdw(cqf, D, D, d_fuse, D, Nv, c.g(pm.cqcat.k), c.g(pm.cqcat.b)));
   {
     GemmJob j = mkjob_dx(d_fuse, D, Nv, D, c.pt(pm.cqcat.k), 2 * D, d_cqf, D);
     c.gemm(&j, 1);
   }
   AlignPool ap{};
-  ap.F2 = cqf; ap.F1 = cqf; ap.inner = c.dry ? nullptr : lab->inner_labels;
+  ap.F2 = cqf; ap.F1 = cqf; ap.inner = (c.dry || !lab) ? nullptr : lab->inner_labels;
   ap.tpre = c.buf("align.tpre", B, D); ap.vpre = c.buf("align.vpre", B, D);
   ap.that = c.buf("align.that", B, D); ap.vhat = c.buf("align.vhat", B, D);
   float* d_that = c.buf("d.align.that", B, D);
   float* d_vhat = c.buf("d.align.vhat", B, D);
-  if (!c.dry && c.ok()) {
+  if (c.live()) {
     AlignPoolBwd ab{d_that, d_vhat, d_cqf, d_cqf};
     c.chk(launch_align_pool_bwd(ap, ab, c.rs, c.stream));      // writes the query rows, accumulates the video rows
   }
@@ -1165,12 +1190,13 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   pa.F2 = cqf; pa.wp = c.p(pm.pool_w); pa.Wbot = c.p(pm.cqcat.k) + (size_t)D * D;
   pa.alpha = c.buf("pool.alpha", B, L); pa.pooled = c.buf("pool.pooled", B, D); pa.PW = c.buf("pool.pw", B, D);
   float* d_pw = c.buf("d.pool.pw", B, D);
-  if (!c.dry && c.ok()) {
+  if (c.live()) {
     PoolBwd pb{d_fuse, d_pw, d_cqf, c.g(pm.pool_w)};
     c.chk(launch_pool_bwd(pa, pb, c.rs, c.stream));
   }
-  c.dwjobs.push_back(mkdw(pa.pooled, D, D, d_pw, D, B, c.g(pm.cqcat.k) + (size_t)D * D, nullptr));
+  c.push_dw(mkdw(pa.pooled, D, D, d_pw, D, B, c.g(pm.cqcat.k) + (size_t)D * D, nullptr));
   // ---------------- the two cq_attention dense layers
+  c.stage(ST_CQ);
   float* xf = c.cfg->attn_layer > 0 ? c.act("da" + std::to_string(c.cfg->attn_layer - 1) + ".out") : nullptr;
   CqBufs cq{};
   cq.X = xf;
@@ -1190,7 +1216,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       j.A[p] = a1[p]; j.A2[p] = a2[p]; j.lda[p] = D; j.lda2[p] = D; j.kw[p] = D;
       j.dW[p] = c.g(pm.cq[s].dense) + (size_t)p * D * D;
     }
-    c.dwjobs.push_back(j);
+    c.push_dw(j);
   }
   float* d_cat4 = c.buf("d.cq.cat", R, 4 * D);
   {
@@ -1212,7 +1238,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     cqp.w0[i] = c.p(pm.cq[i].w0); cqp.w1[i] = c.p(pm.cq[i].w1); cqp.wm[i] = c.p(pm.cq[i].wm);
     cqg.w0[i] = c.g(pm.cq[i].w0); cqg.w1[i] = c.g(pm.cq[i].w1); cqg.wm[i] = c.g(pm.cq[i].wm);
   }
-  if (!c.dry && c.ok()) {
+  if (c.live()) {
     c.chk(launch_cq_bwd_pre(cq, cg, c.rs, c.stream));
     if (c.ok()) c.chk(launch_cq_bwd_impl(cq, cg, c.rs, dXa, dXb, c.stream));
     if (c.ok()) c.chk(launch_tri_bwd_impl(cq, cg, cqp, cqg, c.rs, c.drop, dXa, dXb, c.stream));
@@ -1224,6 +1250,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     const DualAttnP& d = pm.da[li];
     const std::string t = "da" + std::to_string(li);
     const int site = HUAL_SITE_DA + 8 * li;
+    c.stage(ST_DA, li);
     float* xin = li == 0 ? c.act("cb.x4") : c.act("da" + std::to_string(li - 1) + ".out");
     float* ln1 = c.act(t + ".ln1");
     float* lnt = c.act(t + ".lnt");
@@ -1249,7 +1276,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     const std::string dt = "d." + t;
     // out = dropout(l2 . Wd2 + b, s4) + res
     float* dz2 = c.act(dt + ".z2");
-    c.dwjobs.push_back(mkdw(l2, D, D, dz2, D, R, c.g(d.dense2.k), c.g(d.dense2.b)));
+    c.push_dw(mkdw(l2, D, D, dz2, D, R, c.g(d.dense2.k), c.g(d.dense2.b)));
     float* d_l2 = c.act(dt + ".l2");
     float* d_res = c.act(dt + ".res");
     float* dz1 = c.act(dt + ".z1");
@@ -1268,19 +1295,19 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* d_satt = c.act(dt + ".s_att");
     float* d_xatt = c.act(dt + ".x_att");
     auto imgt = [&](size_t off) { return reinterpret_cast<const float*>(c.PKB + off * 4); };
-    const bool dz2_ready = c.fuse_row && li < c.cfg->attn_layer - 1;     // the layer above left dropout'(dx) in dz2
+    const bool dz2_ready = c.fuse_row && li < c.cfg->attn_layer - 1 && c.sel_stage < 0;     // the layer above left dropout'(dx) in dz2
     // weight-gradient jobs of this half of the block (operands are written by whichever path runs below)
-    c.dwjobs.push_back(mkdw(mha, D, D, dz1, D, R, c.g(d.dense1.k), c.g(d.dense1.b)));
+    c.push_dw(mkdw(mha, D, D, dz1, D, R, c.g(d.dense1.k), c.g(d.dense1.b)));
     for (int k = 0; k < 2; ++k) {
       DwJob j = mkdw(ln1, D, D, k == 0 ? d_sc : d_val, D, R, c.g(k == 0 ? d.bl1_d1 : d.bl2_d1), c.g(k == 0 ? d.bl1_b : d.bl2_b));
       j.npieces = 2; j.A[1] = gd; j.lda[1] = D; j.kw[1] = D; j.dW[1] = c.g(k == 0 ? d.bl1_d2 : d.bl2_d2);
-      c.dwjobs.push_back(j);
+      c.push_dw(j);
     }
-    c.dwjobs.push_back(mkdw(o, D, D, d_g, D, R, c.g(d.guided.k), c.g(d.guided.b)));
-    c.dwjobs.push_back(mkdw(sv, D, D, dz_sg, D, R, c.g(d.s_gate.k), c.g(d.s_gate.b)));
-    c.dwjobs.push_back(mkdw(xv, D, D, dz_xg, D, R, c.g(d.x_gate.k), c.g(d.x_gate.b)));
-    c.dwjobs.push_back(mkdw(s_att, D, D, d_sv, D, R, c.g(d.s_dense.k), c.g(d.s_dense.b)));
-    c.dwjobs.push_back(mkdw(x_att, D, D, d_xv, D, R, c.g(d.x_dense.k), c.g(d.x_dense.b)));
+    c.push_dw(mkdw(o, D, D, d_g, D, R, c.g(d.guided.k), c.g(d.guided.b)));
+    c.push_dw(mkdw(sv, D, D, dz_sg, D, R, c.g(d.s_gate.k), c.g(d.s_gate.b)));
+    c.push_dw(mkdw(xv, D, D, dz_xg, D, R, c.g(d.x_gate.k), c.g(d.x_gate.b)));
+    c.push_dw(mkdw(s_att, D, D, d_sv, D, R, c.g(d.s_dense.k), c.g(d.s_dense.b)));
+    c.push_dw(mkdw(x_att, D, D, d_xv, D, R, c.g(d.x_dense.k), c.g(d.x_dense.b)));
     if (c.fuse_da) {
       // (1) dense_2^T + layer_norm_2 backward -> d res, dZ1     (2) the gated middle, ten weight steps     (dablock.h)
       LnProjBwdArgs lb{};
@@ -1296,7 +1323,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       for (int k = 0; k < 10; ++k) mb.w[k] = imgt(wo[k]);
       mb.d_sc = d_sc; mb.d_val = d_val; mb.d_ln1a = d_ln1a; mb.d_g = d_g; mb.dz_sg = dz_sg; mb.dz_xg = dz_xg; mb.d_sv = d_sv; mb.d_xv = d_xv;
       mb.d_satt = d_satt; mb.d_xatt = d_xatt; mb.R = R; mb.MT = da_post_rows(R);
-      if (!c.dry && c.ok()) c.chk(launch_da_mid_bwd(mb, c.stream));
+      if (c.live()) c.chk(launch_da_mid_bwd(mb, c.stream));
     } else {
     dx_after_dropout(c, dx, dz2, R, site + 4, c.pt(d.dense2.k), d_l2, dz2_ready);
     {
@@ -1372,12 +1399,12 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       for (int k = 0; k < 4; ++k) set_dmask(c, a[k], t + ".dm" + std::to_string(k));
       c.attn_bwd(a, 4);
     }
-    c.dwjobs.push_back(mkdw(ln1, D, D, dq_self, D, R, c.g(d.query.k), c.g(d.query.b)));
-    c.dwjobs.push_back(mkdw(ln1, D, D, dq_cross, D, R, c.g(d.query.k), c.g(d.query.b)));
-    c.dwjobs.push_back(mkdw(ln1, D, D, d_qkv + D, 3 * D, R, c.g(d.f_key.k), c.g(d.f_key.b)));
-    c.dwjobs.push_back(mkdw(ln1, D, D, d_qkv + 2 * D, 3 * D, R, c.g(d.f_value.k), c.g(d.f_value.b)));
-    c.dwjobs.push_back(mkdw(lnt, D, D, d_ktvt, 2 * D, R, c.g(d.t_key.k), c.g(d.t_key.b)));
-    c.dwjobs.push_back(mkdw(lnt, D, D, d_ktvt + D, 2 * D, R, c.g(d.t_value.k), c.g(d.t_value.b)));
+    c.push_dw(mkdw(ln1, D, D, dq_self, D, R, c.g(d.query.k), c.g(d.query.b)));
+    c.push_dw(mkdw(ln1, D, D, dq_cross, D, R, c.g(d.query.k), c.g(d.query.b)));
+    c.push_dw(mkdw(ln1, D, D, d_qkv + D, 3 * D, R, c.g(d.f_key.k), c.g(d.f_key.b)));
+    c.push_dw(mkdw(ln1, D, D, d_qkv + 2 * D, 3 * D, R, c.g(d.f_value.k), c.g(d.f_value.b)));
+    c.push_dw(mkdw(lnt, D, D, d_ktvt, 2 * D, R, c.g(d.t_key.k), c.g(d.t_key.b)));
+    c.push_dw(mkdw(lnt, D, D, d_ktvt + D, 2 * D, R, c.g(d.t_value.k), c.g(d.t_value.b)));
     float* d_ln1 = c.act(dt + ".ln1");
     float* d_lnt = c.act(dt + ".lnt");
     float* d_xin = c.act(dt + ".in");
@@ -1425,13 +1452,17 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   }
   // ---------------- shared conv block, position table, input layer norms, projections
   float* x0 = c.act("cb.x0");
-  float* d_x0 = conv_block_bwd(c, "cb", x0, dx, pm.cb, c.rs, HUAL_SITE_CONV, c.fuse_row && c.cfg->attn_layer > 0);
-  if (!c.dry && c.ok()) {
+  c.stage(ST_CONV);
+  float* d_x0 = conv_block_bwd(c, "cb", x0, dx, pm.cb, c.rs, HUAL_SITE_CONV, c.fuse_row && c.cfg->attn_layer > 0 && c.sel_stage < 0);
+  c.stage(ST_ALWAYS);
+  if (c.live()) {      // position-table gradients of the stages that ran
     PosBwdJob pj[2];
-    pj[0] = PosBwdJob{{d_x0, nullptr}, c.g(pm.pos), 1, 1};
-    pj[1] = PosBwdJob{{fe_dx0[1], fe_dx0[0]}, c.g(pm.fe_pos), 1, 0};
-    c.chk(launch_pos_bwd(pj, 2, c.rs, c.stream));
+    int npj = 0;
+    if (c.stage_on(ST_INPUT)) pj[npj++] = PosBwdJob{{d_x0, nullptr}, c.g(pm.pos), 1, 1};     // the table is added in the input stage
+    if (c.stage_on(ST_PRED)) pj[npj++] = PosBwdJob{{fe_dx0[1], fe_dx0[0]}, c.g(pm.fe_pos), 1, 0};
+    if (npj) c.chk(launch_pos_bwd(pj, npj, c.rs, c.stream));
   }
+  c.stage(ST_INPUT);
   float* lin = c.act("lin");
   float* lin_mean = c.vec("lin.mean");
   float* lin_rstd = c.vec("lin.rstd");
@@ -1451,8 +1482,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     DwJob j = mkdw(c.dry ? nullptr : reinterpret_cast<const float*>(bt->video), c.cfg->vdim, c.cfg->vdim, d_lin, D, Nv, c.g(pm.vconv.k), c.g(pm.vconv.b));
     j.a_drop_site = HUAL_SITE_VIDEO; j.a_drop_row0 = 0;
     j.a_bf16 = (!c.dry && bt->video_dtype == HUAL_DTYPE_BF16) ? 1 : 0;
-    c.dwjobs.push_back(j);
-    c.dwjobs.push_back(mkdw(cat, catw, catw, d_lin + (size_t)Nv * D, D, Nq, c.g(pm.qconv.k), c.g(pm.qconv.b)));
+    c.push_dw(j);
+    c.push_dw(mkdw(cat, catw, catw, d_lin + (size_t)Nv * D, D, Nq, c.g(pm.qconv.k), c.g(pm.qconv.b)));
   }
   float* d_cat = c.buf("d.cat", Nq, catw);
   {
@@ -1468,7 +1499,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   ea.word_dim = c.cfg->word_dim; ea.char_dim = c.cfg->char_dim; ea.C = c.C; ea.num_chars = c.cfg->num_chars;
   DwJob embed_dw;
   embed_dw_job(ea, Nq, &embed_dw);
-  if (!c.dry && c.ok()) {
+  if (c.live()) {
     ea.word_ids = bt->word_ids; ea.char_ids = bt->char_ids; ea.word_table = c.word_table; ea.unk = c.p(pm.unk);
     ea.char_table = c.p(pm.char_table);
     for (int i = 0; i < 4; ++i) { ea.filt[i] = c.p(pm.filt[i]); ea.fbias[i] = c.p(pm.fbias[i]); }
@@ -1477,11 +1508,13 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     for (int i = 0; i < 4; ++i) { eg.dfilt[i] = c.g(pm.filt[i]); eg.dfbias[i] = c.g(pm.fbias[i]); }
     c.chk(launch_embed_bwd(ea, eg, Nq, c.drop, c.stream, &embed_dw));
   }
-  c.dwjobs.push_back(embed_dw);
+  c.push_dw(embed_dw);
+  const bool input_ran = c.active;
+  c.stage(ST_ALWAYS);
   c.flush_colsum();       // layer-norm / depthwise-conv parameter gradients: one reduction of the per-block partial sums
   flush_dw(c, true);      // every dense / conv weight gradient of the step: one launch
   join_aux(c);
-  if (!c.dry && c.ok()) c.chk(launch_embed_unpack(ea, eg, c.stream));
+  if (c.live() && input_ran) c.chk(launch_embed_unpack(ea, eg, c.stream));
   (void)opt;
   return c.rc;
 }
@@ -1588,6 +1621,7 @@ int hual_seqpan_forward(const hual_cfg* cfg, const float* params, const float* w
   c.P = params;
   c.word_table = word_table;
   c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
+  c.want_bwd = labels != nullptr;
   rc = forward_graph(c, batch, labels, out, opts);
   if (rc) return rc;
   return 0;
@@ -1667,6 +1701,152 @@ int hual_align_loss_rows(const float* that, const float* vhat, int ld, int Bg, i
   HUAL_REQUIRE(that && vhat && scratch && d_that && d_vhat && loss, "hual_align_loss_rows: null pointer");
   AlignSim as{that, vhat, Bg, scratch, scratch + (size_t)Bg * Bg, d_that, d_vhat, loss - LA_ALIGN, grad_scale, ld, row0, nrows};
   return launch_align_sim(as, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ======================================================================================================
+// per-block entry points: ONE stage of the graph on caller-supplied inputs, through the very launch
+// sequence the whole model uses (Ctx::sel_stage).  Inputs are copied into the stage's input buffer in the workspace,
+// results copied out of it; a backward call must follow the forward call of the same block on the same workspace.
+// ======================================================================================================
+namespace {
+struct BlkCopy { std::string name; const float* src; float* dst; size_t row0, rows; };   // src: caller -> ws ; dst: ws -> caller
+
+int run_block(const hual_cfg* cfg, const float* params, const float* word_table, const hual_batch* batch, const hual_run_opts* opts,
+              float* grads, void* workspace, uint64_t ws_bytes, void* stream, int stage, int sub, bool backward,
+              const std::vector<BlkCopy>& pre, const std::vector<BlkCopy>& post, const hual_outputs* out, const float** sum2_out = nullptr) {
+  int rc = check_common(cfg, params, batch, opts, workspace);
+  if (rc) return rc;
+  HUAL_REQUIRE(!backward || (grads != nullptr && ((uintptr_t)grads & 15) == 0), "null/unaligned grads");
+  { const char* e1 = getenv("HUAL_FUSE_CB"); const char* e2 = getenv("HUAL_FUSE_DA"); const char* e3 = getenv("HUAL_FUSE_ROW");
+    HUAL_REQUIRE(!(e1 && atoi(e1) == 0) && !(e2 && atoi(e2) == 0) && !(e3 && atoi(e3) == 0), "block entry points need the default kernel-fusion switches"); }
+  Ctx c;
+  rc = plan(c, cfg, batch->B, batch->T, batch->L, batch->C);
+  if (rc) return rc;
+  if (c.used + 4096 > ws_bytes) return fail(HUAL_ERR_WORKSPACE, "workspace too small: call hual_seqpan_query_workspace");
+  c.dry = false;
+  c.base = (char*)workspace;
+  c.stream = (hipStream_t)stream;
+  c.P = params;
+  c.G = grads;
+  c.word_table = word_table;
+  c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
+  c.sel_stage = stage; c.sel_sub = sub; c.want_bwd = true;
+  c.part_seq = 0;
+  c.rs.rowmask = c.vec("rowmask");
+  c.rsv.rowmask = c.rs.rowmask;
+  auto locate = [&](const BlkCopy& k, float*& ptr, size_t& cols) -> int {
+    auto it = c.index.find(k.name);
+    HUAL_REQUIRE(it != c.index.end(), "block entry point: unknown workspace buffer");
+    const WsEntry& e = c.entries[it->second];
+    HUAL_REQUIRE(k.row0 + k.rows <= e.rows, "block entry point: row window");
+    ptr = reinterpret_cast<float*>(c.base + e.off) + k.row0 * e.cols;
+    cols = e.cols;
+    return 0;
+  };
+  for (const BlkCopy& k : pre) {
+    float* ptr; size_t cols;
+    if ((rc = locate(k, ptr, cols))) return rc;
+    HUAL_CHECK_HIP(hipMemcpyAsync(ptr, k.src, k.rows * cols * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+  }
+  hual_outputs dummy{};
+  static const hual_run_opts o0{};
+  (void)o0;
+  rc = backward ? backward_graph(c, batch, nullptr, opts) : forward_graph(c, batch, nullptr, out ? out : &dummy, opts);
+  if (rc) return rc;
+  for (const BlkCopy& k : post) {
+    float* ptr; size_t cols;
+    if ((rc = locate(k, ptr, cols))) return rc;
+    if (sum2_out && &k == &post.back() && post.size() == 2) {      // last two entries: dst = first + second (predictor backward)
+      float* a; size_t ca;
+      if ((rc = locate(post[0], a, ca))) return rc;
+      EwArgs e{};
+      e.op = EW_ADD; e.R = (int)k.rows; e.a = a; e.b = ptr; e.out = k.dst; e.drop_site = -1;
+      return launch_ew(e, c.drop, c.stream);
+    }
+    if (sum2_out && post.size() == 2) continue;
+    HUAL_CHECK_HIP(hipMemcpyAsync(k.dst, ptr, k.rows * cols * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+  }
+  return 0;
+}
+std::string da_out_name(const hual_cfg* cfg, int layer) { return layer < 0 ? "cb.x4" : "da" + std::to_string(layer) + ".out"; }
+std::string da_din_name(const hual_cfg* cfg, int layer) { return layer >= cfg->attn_layer ? "d.cq.x" : "d.da" + std::to_string(layer) + ".in"; }
+}  // namespace
+
+extern "C" {
+
+int hual_video_proj_ln_fwd(const hual_cfg* cfg, const float* params, const float* word_table, const hual_batch* batch,
+                           const hual_run_opts* opts, float* x0, void* workspace, uint64_t ws_bytes, void* stream) {
+  HUAL_REQUIRE(cfg && batch && x0 && word_table, "hual_video_proj_ln_fwd: null argument");
+  const size_t R = (size_t)batch->B * (batch->T + batch->L);
+  return run_block(cfg, params, word_table, batch, opts, nullptr, workspace, ws_bytes, stream, ST_INPUT, 0, false, {},
+                   {BlkCopy{"cb.x0", nullptr, x0, 0, R}}, nullptr);
+}
+
+int hual_conv_block_fwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* x,
+                        float* y, void* workspace, uint64_t ws_bytes, void* stream) {
+  HUAL_REQUIRE(cfg && batch && x && y, "hual_conv_block_fwd: null argument");
+  const size_t R = (size_t)batch->B * (batch->T + batch->L);
+  return run_block(cfg, params, nullptr, batch, opts, nullptr, workspace, ws_bytes, stream, ST_CONV, 0, false,
+                   {BlkCopy{"cb.x0", x, nullptr, 0, R}}, {BlkCopy{"cb.x4", nullptr, y, 0, R}}, nullptr);
+}
+int hual_conv_block_bwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* dy,
+                        float* dx, float* grads, void* workspace, uint64_t ws_bytes, void* stream) {
+  HUAL_REQUIRE(cfg && batch && dy && dx, "hual_conv_block_bwd: null argument");
+  const size_t R = (size_t)batch->B * (batch->T + batch->L);
+  return run_block(cfg, params, nullptr, batch, opts, grads, workspace, ws_bytes, stream, ST_CONV, 0, true,
+                   {BlkCopy{da_din_name(cfg, 0), dy, nullptr, 0, R}}, {BlkCopy{"d.cb.x0", nullptr, dx, 0, R}}, nullptr);
+}
+
+int hual_dual_attn_fwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, int layer,
+                       const float* x, float* y, void* workspace, uint64_t ws_bytes, void* stream) {
+  HUAL_REQUIRE(cfg && batch && x && y && layer >= 0 && layer < cfg->attn_layer, "hual_dual_attn_fwd: null argument / layer");
+  const size_t R = (size_t)batch->B * (batch->T + batch->L);
+  return run_block(cfg, params, nullptr, batch, opts, nullptr, workspace, ws_bytes, stream, ST_DA, layer, false,
+                   {BlkCopy{da_out_name(cfg, layer - 1), x, nullptr, 0, R}}, {BlkCopy{da_out_name(cfg, layer), nullptr, y, 0, R}}, nullptr);
+}
+int hual_dual_attn_bwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, int layer,
+                       const float* dy, float* dx, float* grads, void* workspace, uint64_t ws_bytes, void* stream) {
+  HUAL_REQUIRE(cfg && batch && dy && dx && layer >= 0 && layer < cfg->attn_layer, "hual_dual_attn_bwd: null argument / layer");
+  const size_t R = (size_t)batch->B * (batch->T + batch->L);
+  return run_block(cfg, params, nullptr, batch, opts, grads, workspace, ws_bytes, stream, ST_DA, layer, true,
+                   {BlkCopy{da_din_name(cfg, layer + 1), dy, nullptr, 0, R}}, {BlkCopy{da_din_name(cfg, layer), nullptr, dx, 0, R}}, nullptr);
+}
+
+int hual_cq_attn_fwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* x,
+                     float* feats, void* workspace, uint64_t ws_bytes, void* stream) {
+  HUAL_REQUIRE(cfg && batch && x && feats, "hual_cq_attn_fwd: null argument");
+  const size_t R = (size_t)batch->B * (batch->T + batch->L);
+  return run_block(cfg, params, nullptr, batch, opts, nullptr, workspace, ws_bytes, stream, ST_CQ, 0, false,
+                   {BlkCopy{da_out_name(cfg, cfg->attn_layer - 1), x, nullptr, 0, R}}, {BlkCopy{"cq.feats", nullptr, feats, 0, R}}, nullptr);
+}
+int hual_cq_attn_bwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* dfeats,
+                     float* dx, float* grads, void* workspace, uint64_t ws_bytes, void* stream) {
+  HUAL_REQUIRE(cfg && batch && dfeats && dx, "hual_cq_attn_bwd: null argument");
+  const size_t R = (size_t)batch->B * (batch->T + batch->L);
+  return run_block(cfg, params, nullptr, batch, opts, grads, workspace, ws_bytes, stream, ST_CQ, 0, true,
+                   {BlkCopy{"d.cq.feats", dfeats, nullptr, 0, R}}, {BlkCopy{"d.cq.x", nullptr, dx, 0, R}}, nullptr);
+}
+
+int hual_predictor_fwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* outputs,
+                       float* start_logits, float* end_logits, int64_t* start_index, int64_t* end_index, void* workspace,
+                       uint64_t ws_bytes, void* stream) {
+  HUAL_REQUIRE(cfg && batch && outputs && start_logits && end_logits && start_index && end_index, "hual_predictor_fwd: null argument");
+  const size_t Nv = (size_t)batch->B * batch->T;
+  hual_outputs o{};
+  o.start_logits = start_logits; o.end_logits = end_logits; o.start_index = start_index; o.end_index = end_index;
+  return run_block(cfg, params, nullptr, batch, opts, nullptr, workspace, ws_bytes, stream, ST_PRED, 0, false,
+                   {BlkCopy{"outputs", outputs, nullptr, 0, Nv}}, {}, &o);
+}
+int hual_predictor_bwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* d_start,
+                       const float* d_end, float* d_outputs, float* grads, void* workspace, uint64_t ws_bytes, void* stream) {
+  HUAL_REQUIRE(cfg && batch && d_start && d_end && d_outputs, "hual_predictor_bwd: null argument");
+  const size_t Nv = (size_t)batch->B * batch->T;
+  const float* marker = nullptr;
+  return run_block(cfg, params, nullptr, batch, opts, grads, workspace, ws_bytes, stream, ST_PRED, 0, true,
+                   {BlkCopy{"d.s_logit", d_start, nullptr, 0, (size_t)batch->B}, BlkCopy{"d.e_logit", d_end, nullptr, 0, (size_t)batch->B}},
+                   {BlkCopy{"d.fe0.x0", nullptr, nullptr, 0, Nv}, BlkCopy{"d.outputs.heads", nullptr, d_outputs, 0, Nv}}, nullptr, &marker);
 }
 
 }  // extern "C"

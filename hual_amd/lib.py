@@ -101,6 +101,16 @@ def load():
     lib.hual_adamw_clip_step_rng.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp, vp]
     lib.hual_align_loss.argtypes = [vp, vp, i32, vp, vp, vp, vp, f32, vp]
     lib.hual_align_loss_rows.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp]
+    blk = [P(hual_cfg), vp, P(hual_batch), P(hual_run_opts)]
+    lib.hual_video_proj_ln_fwd.argtypes = [P(hual_cfg), vp, vp, P(hual_batch), P(hual_run_opts), vp, vp, u64, vp]
+    lib.hual_conv_block_fwd.argtypes = blk + [vp, vp, vp, u64, vp]
+    lib.hual_conv_block_bwd.argtypes = blk + [vp, vp, vp, vp, u64, vp]
+    lib.hual_dual_attn_fwd.argtypes = blk + [i32, vp, vp, vp, u64, vp]
+    lib.hual_dual_attn_bwd.argtypes = blk + [i32, vp, vp, vp, vp, u64, vp]
+    lib.hual_cq_attn_fwd.argtypes = blk + [vp, vp, vp, u64, vp]
+    lib.hual_cq_attn_bwd.argtypes = blk + [vp, vp, vp, vp, u64, vp]
+    lib.hual_predictor_fwd.argtypes = blk + [vp, vp, vp, vp, vp, vp, u64, vp]
+    lib.hual_predictor_bwd.argtypes = blk + [vp, vp, vp, vp, vp, u64, vp]
     lib.hual_prof_get.argtypes = [i32, ctypes.c_char_p, i32, P(ctypes.c_int64), P(ctypes.c_double), P(ctypes.c_double),
                                   P(ctypes.c_double)]
     lib.hual_aux_create.argtypes = [P(hual_aux)]

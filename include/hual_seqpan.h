@@ -195,6 +195,43 @@ int hual_align_loss_rows(const float* that, const float* vhat, int ld, int Bg, i
                          float* d_vhat, float* loss, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-block entry points: ONE block of the graph on caller-supplied activations, enqueued through the same launch
+ * sequence the whole model uses (unit parity against the corresponding function of the reference).
+ * Activations live in the unified row space: [B*T video rows, then B*L query rows] x 128 floats.  `batch` supplies the
+ * shapes and the masks (video_seq_len, word_ids); `workspace` is the model workspace (hual_seqpan_query_workspace).  A *_bwd
+ * call must follow the *_fwd call of the same block on the same workspace, batch and rng_state; it OVERWRITES `grads` (flat
+ * parameter layout) with the gradients of the block's parameters (zero elsewhere).  Default kernel-fusion switches only.
+ * ------------------------------------------------------------------------------------------ */
+/* model.py:36-56: embeddings, query_conv1d / video_conv1d (the feature-load phase), q_/v_layer_norm, position embeddings
+ * -> x0 [B*(T+L),128] */
+int hual_video_proj_ln_fwd(const hual_cfg* cfg, const float* params, const float* word_table, const hual_batch* batch,
+                           const hual_run_opts* opts, float* x0, void* workspace, uint64_t ws_bytes, void* stream);
+/* modules.py:59-70 conv_block (shared weights, video and query rows in one pass): y = conv_block(x) */
+int hual_conv_block_fwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* x,
+                        float* y, void* workspace, uint64_t ws_bytes, void* stream);
+int hual_conv_block_bwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* dy,
+                        float* dx, float* grads, void* workspace, uint64_t ws_bytes, void* stream);
+/* modules.py:73-89 + layers.py:59-111 dual_attn_block `layer` in both directions (v <- (v,q) and q <- (q,v), shared weights,
+ * both from the OLD features, model.py:60-68): y = [dual_attn_block(v, q), dual_attn_block(q, v)] */
+int hual_dual_attn_fwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, int layer,
+                       const float* x, float* y, void* workspace, uint64_t ws_bytes, void* stream);
+int hual_dual_attn_bwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, int layer,
+                       const float* dy, float* dx, float* grads, void* workspace, uint64_t ws_bytes, void* stream);
+/* layers.py:114-130 cq_attention in both directions (model.py:70-73): feats = [q2v_attn(v, q) on the video rows,
+ * v2q_attn(q, v) on the query rows] */
+int hual_cq_attn_fwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* x,
+                     float* feats, void* workspace, uint64_t ws_bytes, void* stream);
+int hual_cq_attn_bwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* dfeats,
+                     float* dx, float* grads, void* workspace, uint64_t ws_bytes, void* stream);
+/* modules.py:143-160 conditioned_predictor on `outputs` [B*T,128] -> raw start / end logits [B,T] and the span argmax of
+ * layers.py:194-203; the backward takes the gradients of the two logit tensors */
+int hual_predictor_fwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* outputs,
+                       float* start_logits, float* end_logits, int64_t* start_index, int64_t* end_index, void* workspace,
+                       uint64_t ws_bytes, void* stream);
+int hual_predictor_bwd(const hual_cfg* cfg, const float* params, const hual_batch* batch, const hual_run_opts* opts, const float* d_start,
+                       const float* d_end, float* d_outputs, float* grads, void* workspace, uint64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel entry points (unit parity tests call these through ctypes).
  * ------------------------------------------------------------------------------------------ */
 
