@@ -310,10 +310,13 @@ def main():
                         roof['feature_load']['traffic'] = tr_tab[d['kernel']]['hbm_bytes_per_launch']
                 except NameError:
                     pass
-        # the attention contractions (QK^T, PV and their gradients) run on the exact-fp32 matrix pipe: algorithmic TFLOP/s of
-        # those launches against its 157.3 TFLOP/s (north_star: "MFMA utilisation on the attention GEMMs")
+        # the attention contractions (QK^T, PV and their gradients; north_star: "MFMA utilisation on the attention GEMMs"): algorithmic
+        # TFLOP/s of those launches against the fp32-matrix peak (the figure of the round-1 kernels, which ran on that pipe)
+        # and against the bf16 pipe the kernels now use with three passes per product (csrc/attn.hip)
         roof['attention'] = [dict(kernel=d['kernel'], achieved=round(d['flops'] / d['us'] / 1e6, 2), peak=PEAK_F32_MATRIX_TFLOPS,
                                   unit='TFLOP/s', frac=round(d['flops'] / d['us'] / 1e6 / PEAK_F32_MATRIX_TFLOPS, 4),
+                                  pipe='v_mfma_f32_16x16x32_bf16, 3 passes per product',
+                                  mfma_issue_frac_of_bf16_pipe=round(3 * d['flops'] / d['us'] / 1e6 / PEAK_BF16_MATRIX_TFLOPS, 4),
                                   us_per_step=round(d['us'] / psteps, 1))
                              for d in fam if d['kernel'].startswith('attn_') and d['flops'] > 0]
         # whole step: algorithmic FLOPs (BASELINE.md section 2 for the c2 shape, else the launch wrappers' own sums) over the timed
