@@ -359,19 +359,21 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
 
 // backward, step 3 (row kernel): through the two dropouts and the rank-1 terms; parameter gradients.
 // Rows [row_lo,row_hi) must all be video rows or all query rows (the small weights differ per side).
+// The first `nvb` workgroups stride over the video rows, the others over the query rows (the small weights differ per side).
 __global__ __launch_bounds__(256) void tri_bwd_kernel(CqBufs b, CqBwdBufs gb, CqParams p, CqGrads pg, RowSpace rs,
-                                                      DropCfg drop, const float* dXa, const float* dXb, int row_lo,
-                                                      int row_hi) {
+                                                      DropCfg drop, const float* dXa, const float* dXb, int nvb) {
   __shared__ float4 red[3][8][32];
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
-  const bool isv = row_lo < rs.Nv;
+  const bool isv = (int)blockIdx.x < nvb;
+  const int row_lo = isv ? 0 : rs.Nv, row_hi = isv ? rs.Nv : rs.R;
+  const int bid = isv ? (int)blockIdx.x : (int)blockIdx.x - nvb, nblk = isv ? nvb : (int)gridDim.x - nvb;
   const int d1 = isv ? 0 : 1, d2 = isv ? 1 : 0;
   const uint32_t site1 = (uint32_t)HUAL_SITE_TRI + (isv ? 0u : 2u);
   const uint32_t site2 = (uint32_t)HUAL_SITE_TRI + (isv ? 3u : 1u);
   const float4 w0 = ld4(p.w0[d1] + col), wm = ld4(p.wm[d1] + col), w1 = ld4(p.w1[d2] + col);
   float4 gwm = f4zero(), gw0 = f4zero(), gw1 = f4zero();
-  for (int row = row_lo + blockIdx.x * 8 + grp; row < row_hi; row += gridDim.x * 8) {
+  for (int row = row_lo + bid * 8 + grp; row < row_hi; row += nblk * 8) {
     const size_t off = (size_t)row * HUAL_D + col;
     float4 x = ld4(b.X + off);
     float4 mk1 = make_float4(1.f, 1.f, 1.f, 1.f), mk2 = mk1;
@@ -453,12 +455,11 @@ int launch_tri_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const CqParams& p, 
                         const DropCfg& drop, const float* dXa, const float* dXb, hipStream_t s) {
   // every block ends in 384 float atomics on the same 384 addresses (~30 ns each when queued on one address): cap the
   // grid and let the blocks stride over the rows
-  int n = cdiv(rs.Nv, 8);
-  n = n < 128 ? n : 128;
-  HUAL_LAUNCH(0.0, 0.0, tri_bwd_kernel, dim3(n), dim3(256), 0, s, b, g, p, pg, rs, drop, dXa, dXb, 0, rs.Nv);
-  n = cdiv(rs.Nq, 8);
-  n = n < 64 ? n : 64;
-  HUAL_LAUNCH(0.0, 0.0, tri_bwd_kernel, dim3(n), dim3(256), 0, s, b, g, p, pg, rs, drop, dXa, dXb, rs.Nv, rs.R);
+  int nv = cdiv(rs.Nv, 8);
+  nv = nv < 128 ? nv : 128;
+  int nq = cdiv(rs.Nq, 8);
+  nq = nq < 64 ? nq : 64;
+  HUAL_LAUNCH(0.0, 0.0, tri_bwd_kernel, dim3(nv + nq), dim3(256), 0, s, b, g, p, pg, rs, drop, dXa, dXb, nv);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -35,6 +35,7 @@ struct LnProjArgs {
 };
 int ln_proj_rows(int R);
 int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s);
+int launch_ln_proj_pair(const LnProjArgs& a0, const LnProjArgs& a1, const DropCfg& drop, hipStream_t s);   // two problems, one launch
 
 struct DaPostArgs {
   const float* s_att; const float* x_att; const float* ln1; const float* x;    // [R,128] inputs (x: the layer input, residual)

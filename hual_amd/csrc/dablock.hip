@@ -28,7 +28,7 @@ __device__ __forceinline__ float4 ln_row(float4 v, float& mean, float& rstd) {
 
 // ------------------------------------------------------------------------------------------------------
 #define LP_ROWS 64
-__global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropCfg drop) {
+__device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg& drop) {
   extern __shared__ __attribute__((aligned(16))) char lp_lds[];
   char* P1 = lp_lds;                                  // hi plane [64][256 B] | lo plane
   char* P2 = P1 + 2 * LP_ROWS * 256;
@@ -130,6 +130,13 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropC
       st4(a.out[p] + (size_t)row * a.ldo[p] + ecol, v);
     }
   }
+}
+
+__global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropCfg drop) { ln_proj_body(a, drop); }
+// two independent problems of the same row count in one launch (the start / end hidden layers of the predictor heads)
+__global__ __launch_bounds__(CB_THREADS) void ln_proj_pair_kernel(LnProjArgs a0, LnProjArgs a1, DropCfg drop) {
+  if (blockIdx.y == 0) ln_proj_body(a0, drop);
+  else ln_proj_body(a1, drop);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -778,7 +785,7 @@ static int tile_rows(int R, int max_rows) {
 int ln_proj_rows(int R) { return tile_rows(R, LP_ROWS); }
 int da_post_rows(int R) { return tile_rows(R, DP_ROWS); }
 
-int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s) {
+static int check_ln_proj(const LnProjArgs& a) {
   HUAL_REQUIRE(a.x && a.g1 && a.b1 && a.y1 && a.mean && a.rstd && a.R > 0, "ln_proj: null / empty");
   HUAL_REQUIRE(a.MT >= 1 && a.MT <= LP_ROWS, "ln_proj: MT must be 1..64");
   HUAL_REQUIRE(a.nproj >= 1 && a.nproj <= HUAL_LNPROJ_MAX, "ln_proj: projection count");
@@ -791,11 +798,36 @@ int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s) {
     HUAL_REQUIRE(!a.add_x[p] || !(a.g2 || a.x2), "ln_proj: the residual rows share LDS with the second operand");
     HUAL_REQUIRE(!a.accum[p] || p + 1 < a.nproj, "ln_proj: the last projection cannot be marked accum");
   }
-  HUAL_DYN_LDS(ln_proj_kernel, 160 * 1024);
-  const size_t lds = (size_t)4 * LP_ROWS * 256 + CB_WBYTES + 2 * LP_ROWS * sizeof(float);
+  return 0;
+}
+static const size_t kLnProjLds = (size_t)4 * LP_ROWS * 256 + CB_WBYTES + 2 * LP_ROWS * sizeof(float);
+static void ln_proj_work(const LnProjArgs& a, double& flops, double& bytes) {
   const double rows = (double)a.R;
-  HUAL_LAUNCH(2.0 * rows * HUAL_D * HUAL_D * a.nproj, 4.0 * (rows * HUAL_D * (2.0 + (a.g2 ? 1.0 : 0.0) + a.nproj) + (double)a.nproj * HUAL_D * HUAL_D),
-              ln_proj_kernel, dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), lds, s, a, drop);
+  flops += 2.0 * rows * HUAL_D * HUAL_D * a.nproj;
+  bytes += 4.0 * (rows * HUAL_D * (2.0 + (a.g2 ? 1.0 : 0.0) + a.nproj) + (double)a.nproj * HUAL_D * HUAL_D);
+}
+
+int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s) {
+  int rc = check_ln_proj(a);
+  if (rc) return rc;
+  HUAL_DYN_LDS(ln_proj_kernel, 160 * 1024);
+  double flops = 0.0, bytes = 0.0;
+  ln_proj_work(a, flops, bytes);
+  HUAL_LAUNCH(flops, bytes, ln_proj_kernel, dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), kLnProjLds, s, a, drop);
+  HUAL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_ln_proj_pair(const LnProjArgs& a0, const LnProjArgs& a1, const DropCfg& drop, hipStream_t s) {
+  int rc = check_ln_proj(a0);
+  if (rc) return rc;
+  if ((rc = check_ln_proj(a1))) return rc;
+  HUAL_REQUIRE(a0.R == a1.R && a0.MT == a1.MT, "ln_proj_pair: the two problems must have the same rows / tile");
+  HUAL_DYN_LDS(ln_proj_pair_kernel, 160 * 1024);
+  double flops = 0.0, bytes = 0.0;
+  ln_proj_work(a0, flops, bytes);
+  ln_proj_work(a1, flops, bytes);
+  HUAL_LAUNCH(flops, bytes, ln_proj_pair_kernel, dim3(cdiv(a0.R, a0.MT), 2), dim3(CB_THREADS), kLnProjLds, s, a0, a1, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

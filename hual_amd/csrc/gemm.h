@@ -89,8 +89,14 @@ int launch_transpose_weights(const uint32_t* offs, const int* Ks, const int* Ns,
 // (ceil(K/128) blocks of 64 KB); either destination may be null.  launch_gemm_bf16 takes jobs whose W[p] / W2[p] point at
 // such images (reinterpreted) - N > 128 walks the 64 KB column blocks of a backward image.
 #define HUAL_PACK_BLOCK_BYTES (128 * 512)
+// `extra` (optional): work of the step's prologue that rides in the same launch as one more row of workgroups - the row
+// masks of model.py:31-32 (+ the loss accumulators cleared) and, when zero_ptr is set, the flat gradient buffer zeroed
+struct PackExtra {
+  const int32_t* lens; const int32_t* word_ids; float* rowmask; float* loss_acc; int B, T, L;
+  float* zero_ptr; size_t zero_n;      // zero_n floats (multiple of 4), 16-byte aligned
+};
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
-                        hipStream_t stream);
+                        hipStream_t stream, const PackExtra* extra = nullptr);
 int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
 // the same jobs executed one after the other inside each block (row-local dependent layers; same M, N = 128)
 int launch_gemm_chain(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);

@@ -802,8 +802,19 @@ struct PackJob { uint32_t off; int K; uint32_t boff; };
 #define HUAL_MAX_PACK 96
 struct PackBatch { PackJob j[HUAL_MAX_PACK]; };
 __device__ __forceinline__ int pack_perm(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
-__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* bwd) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* bwd, int njobs, PackExtra ex) {
   __shared__ float tile[16][129];
+  if ((int)blockIdx.y >= njobs) {      // the extra row: masks, loss accumulators, gradient zeroing (grid-stride)
+    const int nt = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+    const int Nv = ex.B * ex.T, Nq = ex.B * ex.L;
+    if (t0 < 8) ex.loss_acc[t0] = 0.f;
+    for (int i = t0; i < Nv + Nq; i += nt)
+      ex.rowmask[i] = i < Nv ? ((i % ex.T) < ex.lens[i / ex.T] ? 1.0f : 0.0f)       // tf.sequence_mask, model.py:31
+                             : (ex.word_ids[i - Nv] != 0 ? 1.0f : 0.0f);            // model.py:32
+    if (ex.zero_ptr)
+      for (size_t i = t0; i < ex.zero_n / 4; i += nt) reinterpret_cast<float4*>(ex.zero_ptr)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const PackJob job = b.j[blockIdx.y];
   const int k0 = blockIdx.x * 16;
   if (k0 >= ((job.K + 127) & ~127)) return;          // block-uniform
@@ -1459,7 +1470,10 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
 }
 
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
-                        hipStream_t stream) {
+                        hipStream_t stream, const PackExtra* extra) {
+  HUAL_REQUIRE(!extra || (extra->lens && extra->word_ids && extra->rowmask && extra->loss_acc && (extra->zero_n % 4) == 0 &&
+                          (reinterpret_cast<uintptr_t>(extra->zero_ptr) & 15) == 0), "pack: extra prologue work");
+  PackExtra ex{};
   for (int base = 0; base < n; base += HUAL_MAX_PACK) {
     const int cnt = n - base < HUAL_MAX_PACK ? n - base : HUAL_MAX_PACK;
     PackBatch b;
@@ -1472,8 +1486,10 @@ int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* bof
       maxK = kp > maxK ? kp : maxK;
       elems += (double)Ks[base + i] * 128;
     }
-    HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(maxK / 16, cnt), dim3(256), 0,
-                stream, b, P, fwd, bwd);
+    const bool with_extra = extra && base == 0;
+    if (with_extra) ex = *extra;
+    HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(maxK / 16, cnt + (with_extra ? 1 : 0)),
+                dim3(256), 0, stream, b, P, fwd, bwd, cnt, ex);
   }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

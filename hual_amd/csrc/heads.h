@@ -18,14 +18,18 @@ struct PoolArgs {
   float* pooled;          // [B, 128]
   float* PW;              // [B, 128]  pooled . Wbot
 };
-int launch_pool_fwd(const PoolArgs& a, const RowSpace& rs, hipStream_t s);
+struct AlignPool;
+struct AlignPoolBwd;
+// weighted pooling (+ pooled . Wbot) and - ap non-null - the per-sample alignment pooling, one launch
+int launch_pool_align_fwd(const PoolArgs& a, const AlignPool* ap, const RowSpace& rs, hipStream_t s);
 struct PoolBwd {
   const float* dFuse;     // [Nv,128] gradient wrt the fuse GEMM output
   float* dPW;             // [B,128]  out: sum_t dFuse
   float* dF2;             // v2q_feats gradient (q rows), ACCUMULATED (+=)
   float* dwp;             // [128] accumulated (atomics)
 };
-int launch_pool_bwd(const PoolArgs& a, const PoolBwd& g, const RowSpace& rs, hipStream_t s);
+// backward of both, one launch (alignment part first: it WRITES the query rows the pooling part accumulates into)
+int launch_pool_align_bwd(const PoolArgs& a, const PoolBwd& g, const AlignPool& ap, const AlignPoolBwd& ab, const RowSpace& rs, hipStream_t s);
 
 // ---- matching head, label embeddings, masked outputs (layers.py:157-174, model.py:82-97)
 struct MatchArgs {
@@ -92,7 +96,6 @@ struct AlignPool {
   float* tpre; float* vpre;     // [B,128] pre-normalisation
   float* that; float* vhat;     // [B,128] l2-normalised
 };
-int launch_align_pool(const AlignPool& a, const RowSpace& rs, hipStream_t s);
 // all-rows similarity part.  that/vhat: [Bg,128] (gathered over ranks); gradients for ALL rows are produced.
 struct AlignSim {
   const float* that; const float* vhat; int Bg;
@@ -109,6 +112,5 @@ struct AlignPoolBwd {
   float* dF2;   // v2q_feats gradient, q rows: WRITTEN (=)
   float* dF1;   // q2v_feats gradient, v rows: ACCUMULATED (+=)
 };
-int launch_align_pool_bwd(const AlignPool& a, const AlignPoolBwd& g, const RowSpace& rs, hipStream_t s);
 
 }  // namespace hual

@@ -40,11 +40,12 @@ __device__ __forceinline__ float block_max(float v, float* sm) {
 // ------------------------------------------------------------------------------------------------------
 // weighted pooling + pooled half of cq_cat/dense.  One block of 256 threads per clip: the L row dots are spread over
 // 8 groups of 32 lanes (float4 per lane, shuffle reduction) instead of L block-wide reductions in sequence.
-__global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs a, RowSpace rs) {
+// weighted_pooling + the pooled half of cq_concat for clip b (layers.py:133-154); written for 256 threads
+__device__ __forceinline__ void pool_fwd_body(const PoolArgs& a, const RowSpace& rs, int b) {
   __shared__ float al[256];
   __shared__ float pooled[HUAL_D];
   __shared__ float part[HUAL_D];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int l32 = tid & 31, grp = tid >> 5;
   const int L = rs.L;
   const float* F = a.F2 + (size_t)(rs.Nv + b * L) * HUAL_D;
@@ -82,55 +83,63 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs a, RowSpace rs) 
 }
 
 // stage 1 (512 threads): dPW[b] = sum_t dFuse[b,t,:]   (4 row groups, then LDS)
-__global__ __launch_bounds__(512) void pool_dpw_kernel(PoolBwd g, RowSpace rs) {
-  __shared__ float part[4][HUAL_D];
-  const int b = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
-  const int T = rs.T;
-  float s = 0.f;
-  const float* dfu = g.dFuse + (size_t)b * T * HUAL_D;
-  for (int t = grp; t < T; t += 4) s += dfu[(size_t)t * HUAL_D + c];
-  part[grp][c] = s;
-  __syncthreads();
-  if (grp == 0) g.dPW[b * HUAL_D + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
-}
-
-__global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs a, PoolBwd g, RowSpace rs) {
+// backward of weighted_pooling + cq_concat's pooled half for clip b, 512 threads; dPW = sum_t dFuse is formed here
+__device__ __forceinline__ void pool_bwd_body(const PoolArgs& a, const PoolBwd& g, const RowSpace& rs, int b) {
+  __shared__ float part4[4][HUAL_D];
   __shared__ float dpw[HUAL_D];
   __shared__ float dps[HUAL_D];
   __shared__ float part[HUAL_D];
   __shared__ float da[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int c = tid & 127, half = tid >> 7;
-  const int l32 = tid & 31, grp = tid >> 5;
-  const int L = rs.L;
-  if (tid < HUAL_D) dpw[tid] = g.dPW[b * HUAL_D + tid];
+  const int tid = threadIdx.x;
+  const int L = rs.L, T = rs.T;
+  {
+    const int c = tid & 127, grp = tid >> 7;
+    float s = 0.f;
+    const float* dfu = g.dFuse + (size_t)b * T * HUAL_D;
+#pragma unroll 8
+    for (int t = grp; t < T; t += 4) s += dfu[(size_t)t * HUAL_D + c];
+    part4[grp][c] = s;
+    __syncthreads();
+    if (grp == 0) {
+      const float v = part4[0][c] + part4[1][c] + part4[2][c] + part4[3][c];
+      g.dPW[b * HUAL_D + c] = v;
+      dpw[c] = v;
+    }
+  }
   __syncthreads();
+  const bool on = tid < 256;
+  const int c = tid & 127, half = (tid >> 7) & 1;
+  const int l32 = tid & 31, grp = (tid >> 5) & 7;
   // dpooled[c] = sum_n dPW[n] * Wbot[c][n]   (two halves of n, float4 loads along the row of Wbot)
   float dp = 0.f;
-  const float* wrow = a.Wbot + (size_t)c * HUAL_D + half * 64;
+  if (on) {
+    const float* wrow = a.Wbot + (size_t)c * HUAL_D + half * 64;
 #pragma unroll 4
-  for (int n = 0; n < 64; n += 4) {
-    const float4 w = ld4(wrow + n);
-    const float* d = dpw + half * 64 + n;
-    dp += d[0] * w.x + d[1] * w.y + d[2] * w.z + d[3] * w.w;
+    for (int n = 0; n < 64; n += 4) {
+      const float4 w = ld4(wrow + n);
+      const float* d = dpw + half * 64 + n;
+      dp += d[0] * w.x + d[1] * w.y + d[2] * w.z + d[3] * w.w;
+    }
+    if (half) part[c] = dp;
   }
-  if (half) part[c] = dp;
   __syncthreads();
-  if (!half) dps[c] = dp + part[c];
+  if (on && !half) dps[c] = dp + part[c];
   __syncthreads();
   const float* F = a.F2 + (size_t)(rs.Nv + b * L) * HUAL_D;
   const float* m = rs.rowmask + rs.Nv + b * L;
   // dalpha[l] = dpooled . F[l]
-  const float4 dp4 = *reinterpret_cast<const float4*>(dps + 4 * l32);
-  for (int l = grp; l < L; l += 8) {
-    const float4 f = ld4(F + (size_t)l * HUAL_D + 4 * l32);
-    const float d = half_sum32(f.x * dp4.x + f.y * dp4.y + f.z * dp4.z + f.w * dp4.w);
-    if (l32 == 0) da[l] = d;
+  if (on) {
+    const float4 dp4 = *reinterpret_cast<const float4*>(dps + 4 * l32);
+    for (int l = grp; l < L; l += 8) {
+      const float4 f = ld4(F + (size_t)l * HUAL_D + 4 * l32);
+      const float d = half_sum32(f.x * dp4.x + f.y * dp4.y + f.z * dp4.z + f.w * dp4.w);
+      if (l32 == 0) da[l] = d;
+    }
   }
   __syncthreads();
+  if (!on || half) return;
   float dot_acc = 0.f;
   for (int l = 0; l < L; ++l) dot_acc += a.alpha[b * L + l] * da[l];     // identical in every thread
-  if (half) return;
   dp = dps[c];
   const float w = a.wp[c];
   float dw = 0.f;
@@ -144,9 +153,6 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs a, PoolBwd g, Ro
   }
   atomicAdd(g.dwp + c, dw);
 }
-
-// ------------------------------------------------------------------------------------------------------
-// matching head.  32 lanes per row, 8 rows per block iteration.
 __global__ __launch_bounds__(256) void match_fwd_kernel(MatchArgs a, RowSpace rs) {
   __shared__ float red[2][8];
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -452,10 +458,10 @@ __global__ __launch_bounds__(256) void loc_kernel(LocArgs a, int T) {
 // ------------------------------------------------------------------------------------------------------
 // alignment loss
 #define L2_EPS 1e-12f
-__global__ __launch_bounds__(512) void align_pool_kernel(AlignPool a, RowSpace rs) {
+__device__ __forceinline__ void align_pool_body(const AlignPool& a, const RowSpace& rs, int b) {
   __shared__ float sm[8];
   __shared__ float part[2][4][HUAL_D];
-  const int b = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
+  const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
   const int L = rs.L, T = rs.T;
   float tc = 0.f, vc = 0.f;
   for (int l = threadIdx.x; l < L; l += 512) tc += rs.rowmask[rs.Nv + b * L + l];
@@ -558,9 +564,9 @@ __global__ __launch_bounds__(256) void align_sim_cols_kernel(AlignSim a) {
   if (!half) a.dvhat[blockIdx.x * HUAL_D + c] += s + part[c];
 }
 
-__global__ __launch_bounds__(512) void align_pool_bwd_kernel(AlignPool a, AlignPoolBwd g, RowSpace rs) {
+__device__ __forceinline__ void align_pool_bwd_body(const AlignPool& a, const AlignPoolBwd& g, const RowSpace& rs, int b) {
   __shared__ float sm[8];
-  const int b = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
+  const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
   const int L = rs.L, T = rs.T;
   // l2_normalize backward: x_hat = x * r, r = rsqrt(max(|x|^2, eps)); dx = r * (dxh - x_hat * (x_hat . dxh)) when |x|^2 > eps
   const float tp = a.tpre[b * HUAL_D + c], vp = a.vpre[b * HUAL_D + c];
@@ -582,17 +588,35 @@ __global__ __launch_bounds__(512) void align_pool_bwd_kernel(AlignPool a, AlignP
   for (int t = grp; t < T; t += 4) g.dF1[(size_t)(b * T + t) * HUAL_D + c] += dvp * (a.inner[b * T + t] / vc);
 }
 
+// per-clip forward kernels that only read cq.feats, in ONE launch: blockIdx.y = 0 weighted pooling (+ pooled . Wbot),
+// 1 = the per-sample part of the alignment loss (when labels are present)
+__global__ __launch_bounds__(512) void pool_align_fwd_kernel(PoolArgs pa, AlignPool ap, RowSpace rs) {
+  if (blockIdx.y == 0) {
+    if (threadIdx.x >= 256) return;      // whole waves leave: the body is written for 256 threads
+    pool_fwd_body(pa, rs, blockIdx.x);
+  } else {
+    align_pool_body(ap, rs, blockIdx.x);
+  }
+}
+// per-clip backward: alignment pooling (writes the query rows of d cq.feats, accumulates the video rows), then weighted
+// pooling / cq_concat's pooled half (accumulates into the query rows the first part just wrote - same workgroup, same clip)
+__global__ __launch_bounds__(512) void pool_align_bwd_kernel(PoolArgs pa, PoolBwd pb, AlignPool ap, AlignPoolBwd ab, RowSpace rs) {
+  align_pool_bwd_body(ap, ab, rs, blockIdx.x);
+  __syncthreads();
+  pool_bwd_body(pa, pb, rs, blockIdx.x);
+}
+
 namespace hual {
 
-int launch_pool_fwd(const PoolArgs& a, const RowSpace& rs, hipStream_t s) {
+int launch_pool_align_fwd(const PoolArgs& a, const AlignPool* ap, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(rs.L <= 256, "pool: L <= 256");
-  HUAL_LAUNCH(0.0, 0.0, pool_fwd_kernel, dim3(rs.B), dim3(256), 0, s, a, rs);
+  AlignPool z{};
+  HUAL_LAUNCH(0.0, 0.0, pool_align_fwd_kernel, dim3(rs.B, ap ? 2 : 1), dim3(512), 0, s, a, ap ? *ap : z, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
-int launch_pool_bwd(const PoolArgs& a, const PoolBwd& g, const RowSpace& rs, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, pool_dpw_kernel, dim3(rs.B), dim3(512), 0, s, g, rs);
-  HUAL_LAUNCH(0.0, 0.0, pool_bwd_kernel, dim3(rs.B), dim3(256), 0, s, a, g, rs);
+int launch_pool_align_bwd(const PoolArgs& a, const PoolBwd& g, const AlignPool& ap, const AlignPoolBwd& ab, const RowSpace& rs, hipStream_t s) {
+  HUAL_LAUNCH(0.0, 0.0, pool_align_bwd_kernel, dim3(rs.B), dim3(512), 0, s, a, g, ap, ab, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -648,21 +672,11 @@ int launch_loc(const LocArgs& a, int B, int T, hipStream_t s) {
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
-int launch_align_pool(const AlignPool& a, const RowSpace& rs, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, align_pool_kernel, dim3(rs.B), dim3(512), 0, s, a, rs);
-  HUAL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
 int launch_align_sim(const AlignSim& a, hipStream_t s) {
   HUAL_REQUIRE(a.Bg >= 1 && a.Bg <= 1024, "align: global batch <= 1024");
   HUAL_REQUIRE(a.ld >= HUAL_D && a.row0 >= 0 && a.nrows >= 1 && a.row0 + a.nrows <= a.Bg, "align: row window / leading dimension");
   HUAL_LAUNCH(0.0, 0.0, align_sim_rows_kernel, dim3(a.Bg), dim3(256), 0, s, a);
   HUAL_LAUNCH(0.0, 0.0, align_sim_cols_kernel, dim3(a.nrows), dim3(256), 0, s, a);
-  HUAL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-int launch_align_pool_bwd(const AlignPool& a, const AlignPoolBwd& g, const RowSpace& rs, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, align_pool_bwd_kernel, dim3(rs.B), dim3(512), 0, s, a, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

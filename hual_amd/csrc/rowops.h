@@ -45,6 +45,9 @@ struct LnBwd {
   // optional second output for the consumer of dx: dz = dropout'(dx, dz_site) * (dz_relu > 0)   (site < 0: no dropout,
   // dz_relu null: no mask) - saves the elementwise launch in front of the next dX GEMM
   float* dz; int dz_site; uint32_t dz_row0; const float* dz_relu;
+  // optional second scale vector for the rows >= split (the two input layer norms in one launch, as LnFwd::split): the first
+  // ln_bwd_blocks(split) workgroups take the rows below split, the others the rows from split on; needs `part`
+  int split; const float* g1_hi;
 };
 int ln_bwd_blocks(int R);
 int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s);

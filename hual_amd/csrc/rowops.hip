@@ -80,9 +80,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) {
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   float4 sg1 = f4zero(), sb1 = f4zero(), sg2 = f4zero(), sb2 = f4zero();
-  const float4 g1 = ld4(a.g1 + col);
+  const int nlo = a.split > 0 ? (a.split + 31) / 32 : 0;
+  const bool hi = a.split > 0 && (int)blockIdx.x >= nlo;
+  const int row_lo = hi ? a.split : 0, row_hi = (a.split > 0 && !hi) ? a.split : a.R;
+  const int bid = hi ? (int)blockIdx.x - nlo : (int)blockIdx.x, nblk = a.split > 0 ? (hi ? (int)gridDim.x - nlo : nlo) : (int)gridDim.x;
+  const float4 g1 = ld4((hi ? a.g1_hi : a.g1) + col);
   const float4 g2 = a.dy2 ? ld4(a.g2 + col) : f4zero();
-  for (int row = blockIdx.x * 8 + grp; row < a.R; row += gridDim.x * 8) {
+  for (int row = row_lo + bid * 8 + grp; row < row_hi; row += nblk * 8) {
     const size_t off = (size_t)row * HUAL_D + col;
     float4 v = ld4(a.x + off);
     float mean = a.mean[row], rstd = a.rstd[row];
@@ -365,6 +369,10 @@ int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s) {
   int g = cdiv(a.R, 8);
   g = g < 128 ? g : 128;     // every block ends with 256-512 same-address float atomics: keep the count low
   if (a.part) g = ln_bwd_blocks(a.R);
+  if (a.split > 0) {
+    HUAL_REQUIRE(a.part && a.g1_hi && a.split < a.R && !a.dy2, "ln_bwd: split needs part, g1_hi, one layer norm");
+    g = ln_bwd_blocks(a.split) + ln_bwd_blocks(a.R - a.split);
+  }
   HUAL_LAUNCH(0.0, 12.0 * a.R * HUAL_D, ln_bwd_kernel, dim3(g), dim3(256), 0, s, a, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

@@ -208,6 +208,20 @@ struct Ctx {
     if (active) colsum.push_back(cj);
     if (live()) chk(launch_ln_bwd(a, drop, stream));
   }
+  // the two input layer norms (rows below / from a.split on) in one launch: two reductions of the partial sums
+  void ln_bwd_split(const LnBwd& a0, float* dg_lo, float* db_lo, float* dg_hi, float* db_hi) {
+    LnBwd a = a0;
+    const int nlo = ln_bwd_blocks(a.split), nhi = ln_bwd_blocks(a.R - a.split);
+    a.part = buf("part." + std::to_string(part_seq++), (size_t)(nlo + nhi) * 4, HUAL_D);
+    ColsumJob cj{};
+    cj.src = a.part; cj.nblk = nlo; cj.nvec = 4;
+    cj.dst[0] = dg_lo; cj.dst[1] = db_lo;
+    if (active) colsum.push_back(cj);
+    cj.src = a.part + (size_t)nlo * 4 * HUAL_D; cj.nblk = nhi;
+    cj.dst[0] = dg_hi; cj.dst[1] = db_hi;
+    if (active) colsum.push_back(cj);
+    if (live()) chk(launch_ln_bwd(a, drop, stream));
+  }
   void dwconv_ln_bwd(const ConvBwd& a0, const RowSpace& r) {
     ConvBwd a = a0;
     const int nblk = dwconv_bwd_blocks(r);
@@ -549,11 +563,8 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   c.rsv.rowmask = rowmask;
   float* loss_acc = c.buf("loss_acc", 8, 1);
   c.stage(ST_ALWAYS);
-  if (!c.dry) {
-    HUAL_LAUNCH(0.0, 0.0, prep_masks_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.stream, bt->video_seq_len, bt->word_ids,
-                rowmask, B, T, L, loss_acc);
-  }
-  // ---------------- pre-split images of every dense weight for the bf16 kernels (weights are constant within a step)
+  // ---------------- prologue: row masks (model.py:31-32), cleared loss accumulators, pre-split images of every dense weight for
+  // the split kernels (weights are constant within a step) and - hual_run_opts.grads_prezero - the gradient buffer zeroed: ONE launch
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
   c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
   c.PT = c.buf("params.T", pm.total, 1);
@@ -561,7 +572,12 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     std::vector<uint32_t> offs, boffs;
     std::vector<int> Ks;
     for (const auto& d : c.dense) { offs.push_back((uint32_t)d.off); Ks.push_back(d.K); boffs.push_back((uint32_t)d.boff); }
-    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream));
+    PackExtra ex{bt->video_seq_len, bt->word_ids, rowmask, loss_acc, B, T, L, (lab && opt->grads_prezero) ? opt->grads_prezero : nullptr,
+                 (size_t)((pm.total + 3) & ~(size_t)3)};
+    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex));
+  } else if (!c.dry) {
+    HUAL_LAUNCH(0.0, 0.0, prep_masks_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.stream, bt->video_seq_len, bt->word_ids,
+                rowmask, B, T, L, loss_acc);
   }
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
   c.stage(ST_INPUT);
@@ -786,7 +802,12 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   PoolArgs pa{};
   pa.F2 = cqf; pa.wp = c.p(pm.pool_w); pa.Wbot = c.p(pm.cqcat.k) + (size_t)D * D;
   pa.alpha = c.buf("pool.alpha", B, L); pa.pooled = c.buf("pool.pooled", B, D); pa.PW = c.buf("pool.pw", B, D);
-  if (c.live()) c.chk(launch_pool_fwd(pa, c.rs, c.stream));
+  // the per-sample part of the alignment loss (model.py:76) also only reads cq.feats: same launch
+  AlignPool ap{};
+  ap.F2 = cqf; ap.F1 = cqf; ap.inner = (lab && !c.dry) ? lab->inner_labels : nullptr;
+  ap.tpre = c.buf("align.tpre", B, D); ap.vpre = c.buf("align.vpre", B, D);
+  ap.that = c.buf("align.that", B, D); ap.vhat = c.buf("align.vhat", B, D);
+  if (c.live()) c.chk(launch_pool_align_fwd(pa, lab ? &ap : nullptr, c.rs, c.stream));
   float* fuse = c.actv("fuse");
   {
     GemmJob j = mkjob(cqf, D, Nv, D, c.p(pm.cqcat.k), c.p(pm.cqcat.b), fuse, D);
@@ -805,31 +826,14 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* match_part = c.buf("match.part", (size_t)match_fwd_blocks(Nv), 2);
   ma.part = match_part;
   if (c.live()) c.chk(launch_match_fwd(ma, c.rs, c.stream));
-  // ---------------- alignment loss, per-sample part (model.py:76)
-  AlignPool ap{};
-  ap.F2 = cqf; ap.F1 = cqf; ap.inner = (lab && !c.dry) ? lab->inner_labels : nullptr;
-  ap.tpre = c.buf("align.tpre", B, D); ap.vpre = c.buf("align.vpre", B, D);
-  ap.that = c.buf("align.that", B, D); ap.vhat = c.buf("align.vhat", B, D);
+  // ---------------- alignment loss, cross-sample part (layers.py:232-247); exact data parallel evaluates it outside
   float* d_that = c.buf("d.align.that", B, D);
   float* d_vhat = c.buf("d.align.vhat", B, D);
   float* align_scratch = c.buf("align.scratch", (size_t)2 * B, B);
-  // The alignment-loss branch (3 small, latency-bound launches) depends only on cq.feats and is needed again by the loss tail
-  // at the very end of forward: with a side stream (hual_run_opts.aux) it is forked here and runs under the predictor.
   c.align_forked = false;
-  if (lab && c.live()) {
-    hipStream_t as_stream = c.stream;
-    if (c.aux && c.aux->stream && !opt->align_external) {
-      as_stream = (hipStream_t)c.aux->stream;
-      HUAL_CHECK_HIP(hipEventRecord((hipEvent_t)c.aux->ev_fork, c.stream));
-      HUAL_CHECK_HIP(hipStreamWaitEvent(as_stream, (hipEvent_t)c.aux->ev_fork, 0));
-      c.align_forked = true;
-    }
-    c.chk(launch_align_pool(ap, c.rs, as_stream));
-    if (!opt->align_external) {
-      AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, d_that, d_vhat, loss_acc, 1.0f, D, 0, B};
-      if (c.ok()) c.chk(launch_align_sim(as, as_stream));
-    }
-    if (c.align_forked) HUAL_CHECK_HIP(hipEventRecord((hipEvent_t)c.aux->ev_join, as_stream));
+  if (lab && c.live() && !opt->align_external) {
+    AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, d_that, d_vhat, loss_acc, 1.0f, D, 0, B};
+    c.chk(launch_align_sim(as, c.stream));
   }
   // ---------------- conditioned predictor (modules.py:143-160)
   c.stage(ST_PRED);
@@ -904,7 +908,8 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* hrstd = c.buf("head.rstd", (size_t)2 * Nv, 1);
   float* hs = c.actv("head.hs");
   float* he = c.actv("head.he");
-  if (c.fuse_da) {         // start / end layer norm + hidden layer ([LN(feats), outputs] . W + b, relu) (modules.py:152-157)
+  if (c.fuse_da) {         // start / end layer norm + hidden layer ([LN(feats), outputs] . W + b, relu) (modules.py:152-157): one launch
+    LnProjArgs lp2[2];
     for (int h = 0; h < 2; ++h) {
       const DenseP& hp = h == 0 ? pm.shid : pm.ehid;
       const LnP& lnp = h == 0 ? pm.sln : pm.eln;
@@ -915,8 +920,9 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       lp.wimg[0] = reinterpret_cast<const float*>(c.PKF + hp.k * 4); lp.src[0] = 0; lp.accum[0] = 1; lp.out_site[0] = -1;
       lp.wimg[1] = reinterpret_cast<const float*>(c.PKF + (hp.k + (size_t)D * D) * 4); lp.src[1] = 1; lp.bias[1] = c.p(hp.b);
       lp.act[1] = 1; lp.out[1] = h == 0 ? hs : he; lp.ldo[1] = D; lp.out_site[1] = -1;
-      if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
+      lp2[h] = lp;
     }
+    if (c.live()) c.chk(launch_ln_proj_pair(lp2[0], lp2[1], c.drop, c.stream));
   } else {
     GemmJob j[2];
     // start / end layer norms (modules.py:152-153) in the A prologue
@@ -945,7 +951,6 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     la.ds = lab ? d_s : nullptr; la.de = lab ? d_e : nullptr; la.loss_acc = loss_acc; la.inv_batch = 1.0f / (float)B;
     if (c.ok()) c.chk(launch_loc(la, B, T, c.stream));
     if (lab && c.ok()) {
-      if (c.align_forked) HUAL_CHECK_HIP(hipStreamWaitEvent(c.stream, (hipEvent_t)c.aux->ev_join, 0));
       c.chk(launch_loss_tail(c.p(pm.label_emb), loss_acc, c.cfg->match_lambda, opt->match_denom_override, opt->match_denom_dev,
                              out->loss_terms, match_part, match_fwd_blocks(Nv), c.buf("ortho.dE", 4, D), c.stream));
     }
@@ -972,7 +977,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   c.stage(ST_ALWAYS);
   // (a kernel, not hipMemsetAsync: memset nodes of a captured graph were seen to pick up the fill pattern of later eager
   //  memsets on this ROCm - every 4th gradient came back as the caller's learning rate)
-  if (c.live()) c.chk(launch_zero(c.G, pm.total, c.stream));
+  if (c.live() && !(opt->grads_prezero && opt->grads_prezero == c.G && c.use_bf16 && c.sel_stage < 0))
+    c.chk(launch_zero(c.G, pm.total, c.stream));
   // transposed copies of every dense weight that a dX product reads (weights are constant within a step)
   float* PT = c.buf("params.T", pm.total, 1);
   c.PT = PT;
@@ -1182,17 +1188,14 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   ap.that = c.buf("align.that", B, D); ap.vhat = c.buf("align.vhat", B, D);
   float* d_that = c.buf("d.align.that", B, D);
   float* d_vhat = c.buf("d.align.vhat", B, D);
-  if (c.live()) {
-    AlignPoolBwd ab{d_that, d_vhat, d_cqf, d_cqf};
-    c.chk(launch_align_pool_bwd(ap, ab, c.rs, c.stream));      // writes the query rows, accumulates the video rows
-  }
   PoolArgs pa{};
   pa.F2 = cqf; pa.wp = c.p(pm.pool_w); pa.Wbot = c.p(pm.cqcat.k) + (size_t)D * D;
   pa.alpha = c.buf("pool.alpha", B, L); pa.pooled = c.buf("pool.pooled", B, D); pa.PW = c.buf("pool.pw", B, D);
   float* d_pw = c.buf("d.pool.pw", B, D);
   if (c.live()) {
-    PoolBwd pb{d_fuse, d_pw, d_cqf, c.g(pm.pool_w)};
-    c.chk(launch_pool_bwd(pa, pb, c.rs, c.stream));
+    AlignPoolBwd ab{d_that, d_vhat, d_cqf, d_cqf};     // writes the query rows, accumulates the video rows
+    PoolBwd pb{d_fuse, d_pw, d_cqf, c.g(pm.pool_w)};    // accumulates into the query rows
+    c.chk(launch_pool_align_bwd(pa, pb, ap, ab, c.rs, c.stream));
   }
   c.push_dw(mkdw(pa.pooled, D, D, d_pw, D, B, c.g(pm.cqcat.k) + (size_t)D * D, nullptr));
   // ---------------- the two cq_attention dense layers
@@ -1468,14 +1471,11 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* lin_rstd = c.vec("lin.rstd");
   float* d_lin = c.act("d.lin");
   {
+    // v_layer_norm (video rows) and q_layer_norm (query rows) backward: one launch over the unified rows
     LnBwd a{};
-    a.x = lin; a.mean = lin_mean; a.rstd = lin_rstd; a.R = Nv; a.dy1 = d_x0; a.g1 = c.p(pm.vln.g); a.dg1 = c.g(pm.vln.g);
-    a.db1 = c.g(pm.vln.b); a.drop_site1 = -1; a.dx = d_lin;
-    c.ln_bwd(a);
-    const size_t ro = (size_t)Nv * D;
-    a.x = lin + ro; a.mean = lin_mean + Nv; a.rstd = lin_rstd + Nv; a.R = Nq; a.dy1 = d_x0 + ro; a.g1 = c.p(pm.qln.g);
-    a.dg1 = c.g(pm.qln.g); a.db1 = c.g(pm.qln.b); a.dx = d_lin + ro;
-    c.ln_bwd(a);
+    a.x = lin; a.mean = lin_mean; a.rstd = lin_rstd; a.R = R; a.dy1 = d_x0; a.g1 = c.p(pm.vln.g);
+    a.drop_site1 = -1; a.dx = d_lin; a.split = Nv; a.g1_hi = c.p(pm.qln.g);
+    c.ln_bwd_split(a, c.g(pm.vln.g), c.g(pm.vln.b), c.g(pm.qln.g), c.g(pm.qln.b));
   }
   float* cat = c.buf("cat", Nq, catw);
   {

@@ -50,7 +50,7 @@ class hual_aux(ctypes.Structure):
 class hual_run_opts(ctypes.Structure):
     _fields_ = [('drop_rate', ctypes.c_float), ('rng_state', ctypes.c_void_p), ('match_denom_override', ctypes.c_float),
                 ('align_external', ctypes.c_int32), ('aux', ctypes.POINTER(hual_aux)), ('static_tables', ctypes.c_int32),
-                ('match_denom_dev', ctypes.c_void_p)]
+                ('match_denom_dev', ctypes.c_void_p), ('grads_prezero', ctypes.c_void_p)]
 
 
 class hual_al_set(ctypes.Structure):

@@ -145,6 +145,9 @@ typedef struct hual_run_opts {
   const float* match_denom_dev;   /* non-NULL: the denominator of the masked matching loss is read from this DEVICE scalar
                                         when the kernels run (takes precedence over match_denom_override): a data-parallel
                                         step can all-reduce the valid-frame count on the stream without a host round trip */
+  float* grads_prezero;           /* non-NULL, hual_seqpan_forward with labels: this flat gradient buffer is zeroed by the
+                                        forward's first launch; a hual_seqpan_backward call given the same pointer here and as
+                                        its `grads` then skips its own zeroing launch (one launch fewer per step) */
 } hual_run_opts;
 
 /* bytes of workspace needed for one forward(+backward) of this shape */
