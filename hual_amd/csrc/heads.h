@@ -51,10 +51,12 @@ struct MatchBwd {
   const float* dOut;      // [Nv,128] gradient wrt outputs
   const float* dOut2;     // optional second part of it (added on the fly: the predictor's heads and encoders both read `outputs`)
   float* dFuse;           // [Nv,128] written
-  float* dWm; float* dbm; float* dE;   // accumulated
+  float* dWm; float* dbm; float* dE;   // destinations (through `part` and the colsum job the caller queues)
   const float* dE_ortho;  // optional [4,128]: gradient of the orthogonality term left by launch_loss_tail, added to dE
+  float* part;            // [match_bwd_blocks(Nv)][9][128] per-workgroup sums (dE rows, dWm flat, dbm): folded by launch_colsum
   float lambda;           // loss.match_lambda
 };
+int match_bwd_blocks(int Nv);
 int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, hipStream_t s);
 // denominator of the masked mean: loss_acc[LA_DENOM] = override > 0 ? override : loss_acc[LA_MASK_SUM] + 1e-12
 int launch_match_denominator(float* loss_acc, float override_denom, hipStream_t s);

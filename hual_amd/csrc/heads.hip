@@ -144,6 +144,7 @@ __device__ __forceinline__ void pool_bwd_body(const PoolArgs& a, const PoolBwd& 
   const float w = a.wp[c];
   float dw = 0.f;
   float* dF = g.dF2 + (size_t)(rs.Nv + b * L) * HUAL_D;
+#pragma unroll 4
   for (int l = 0; l < L; ++l) {
     const float alpha = a.alpha[b * L + l];
     const float dal = alpha * (da[l] - dot_acc) * m[l];
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
   float4 dE0 = f4zero(), dE1 = f4zero(), dE2 = f4zero(), dE3 = f4zero();
   float4 dW0 = f4zero(), dW1 = f4zero(), dW2 = f4zero(), dW3 = f4zero();   // dWk = column k of dWm over this lane's 4 rows
   float db0 = 0.f, db1 = 0.f, db2 = 0.f, db3 = 0.f;
+#pragma unroll 2
   for (int row = blockIdx.x * 8 + grp; row < rs.Nv; row += gridDim.x * 8) {
     const size_t off = (size_t)row * HUAL_D + col;
     const float mk = rs.rowmask[row];
@@ -260,21 +262,28 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
   red[4][grp][l32] = dW0; red[5][grp][l32] = dW1; red[6][grp][l32] = dW2; red[7][grp][l32] = dW3;
   if (l32 == 0) { redb[grp][0] = db0; redb[grp][1] = db1; redb[grp][2] = db2; redb[grp][3] = db3; }
   __syncthreads();
+  // per-workgroup sums -> g.part[blk][9][128] (folded by launch_colsum): vectors 0-3 = rows of dE, 4-7 = dWm flat ([128,4]:
+  // element c*4 + class), 8 = dbm in its first 4 entries.  Workgroup 0 adds the gradient of the orthogonality term
+  // (model.py:88-91), computed by the forward's loss tail.
+  float* part = g.part + (size_t)blockIdx.x * 9 * HUAL_D;
   for (int idx = threadIdx.x; idx < 8 * 128; idx += 256) {
     const int vec = idx >> 7, c = idx & 127;
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += reinterpret_cast<const float*>(&red[vec][k][c >> 2])[c & 3];
-    if (vec < 4) atomicAdd(g.dE + vec * HUAL_D + c, s);
-    else atomicAdd(g.dWm + c * 4 + (vec - 4), s);
+    if (vec < 4) {
+      if (g.dE_ortho && blockIdx.x == 0) s += g.dE_ortho[vec * HUAL_D + c];
+      part[vec * HUAL_D + c] = s;
+    } else {
+      part[4 * HUAL_D + c * 4 + (vec - 4)] = s;
+    }
   }
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < HUAL_D) {
     float s = 0.f;
-    for (int k = 0; k < 8; ++k) s += redb[k][threadIdx.x];
-    atomicAdd(g.dbm + threadIdx.x, s);
+    if (threadIdx.x < 4)
+      for (int k = 0; k < 8; ++k) s += redb[k][threadIdx.x];
+    part[8 * HUAL_D + threadIdx.x] = s;
   }
-  if (g.dE_ortho && blockIdx.x == 0)      // gradient of the orthogonality term (model.py:88-91), computed by the forward's loss tail
-    for (int idx = threadIdx.x; idx < 4 * HUAL_D; idx += 256) atomicAdd(g.dE + idx, g.dE_ortho[idx]);
 }
 
 // ortho: one block of 128 threads
@@ -469,7 +478,9 @@ __device__ __forceinline__ void align_pool_body(const AlignPool& a, const RowSpa
   tc = block_sum(tc, sm);       // exact: the mask is 0/1
   vc = block_sum(vc, sm);
   float ts = 0.f, vs = 0.f;
+#pragma unroll 8
   for (int l = grp; l < L; l += 4) ts += a.F2[(size_t)(rs.Nv + b * L + l) * HUAL_D + c];     // padded words included (layers.py:214)
+#pragma unroll 8
   for (int t = grp; t < T; t += 4) vs += a.F1[(size_t)(b * T + t) * HUAL_D + c] * (a.inner[b * T + t] / vc);
   part[0][grp][c] = ts;
   part[1][grp][c] = vs;
@@ -500,6 +511,7 @@ __global__ __launch_bounds__(256) void align_sim_rows_kernel(AlignSim a) {
   for (int j = tid; j < Bg; j += 256) {
     const float* vj = a.vhat + (size_t)j * ld;
     float da = 0.f, dq = 0.f;
+#pragma unroll 16
     for (int k = 0; k < HUAL_D; ++k) { da = fmaf(vi[k], vj[k], da); dq = fmaf(ti[k], vj[k], dq); }
     sa[j] = da; sq[j] = dq;
     mxa = fmaxf(mxa, da); mxq = fmaxf(mxq, dq);
@@ -539,6 +551,7 @@ __global__ __launch_bounds__(256) void align_sim_rows_kernel(AlignSim a) {
   // only the rows [row0, row0 + nrows) are wanted (exact data parallel: a rank keeps the gradient rows of its own samples)
   if (tid < HUAL_D && i >= a.row0 && i < a.row0 + a.nrows) {
     float st = 0.f, sv = 0.f;
+#pragma unroll 8
     for (int j = 0; j < Bg; ++j) {
       const float v = a.vhat[(size_t)j * ld + tid];
       st = fmaf(sq[j], v, st);
@@ -585,6 +598,7 @@ __device__ __forceinline__ void align_pool_bwd_body(const AlignPool& a, const Al
   vc = block_sum(vc, sm);
   const float dts = dtp / tc;
   for (int l = grp; l < L; l += 4) g.dF2[(size_t)(rs.Nv + b * L + l) * HUAL_D + c] = dts;
+#pragma unroll 8
   for (int t = grp; t < T; t += 4) g.dF1[(size_t)(b * T + t) * HUAL_D + c] += dvp * (a.inner[b * T + t] / vc);
 }
 
@@ -628,6 +642,7 @@ static int rowgrid(int R, int cap) {
   return g < cap ? (g > 0 ? g : 1) : cap;
 }
 int match_fwd_blocks(int Nv) { return rowgrid(Nv, 512); }
+int match_bwd_blocks(int Nv) { return rowgrid(Nv, 256); }
 int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, hipStream_t s) {
   HUAL_LAUNCH(0.0, 0.0, match_fwd_kernel, dim3(a.part ? match_fwd_blocks(rs.Nv) : rowgrid(rs.Nv, 128)), dim3(256), 0, s, a, rs);
   HUAL_CHECK_HIP(hipGetLastError());
@@ -639,7 +654,8 @@ int launch_match_denominator(float* loss_acc, float override_denom, hipStream_t 
   return 0;
 }
 int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, match_bwd_kernel, dim3(rowgrid(rs.Nv, 64)), dim3(256), 0, s, a, g, rs);
+  HUAL_REQUIRE(g.part != nullptr, "match_bwd: partial-sum scratch");
+  HUAL_LAUNCH(0.0, 0.0, match_bwd_kernel, dim3(match_bwd_blocks(rs.Nv)), dim3(256), 0, s, a, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

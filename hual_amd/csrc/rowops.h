@@ -77,6 +77,7 @@ int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, const DropCfg& dr
 struct ColsumJob {
   const float* src; int nblk; int nvec;
   float* dst[HUAL_COLSUM_MAX_VEC];     // null entries are skipped
+  int last_ncols;                      // > 0: the LAST vector only has this many columns (a destination shorter than 128)
 };
 int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s);
 

@@ -265,10 +265,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch batch) {
   if (vec >= job.nvec || job.dst[vec] == nullptr) return;     // block-uniform
   const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
   float s = 0.f;
+#pragma unroll 8
   for (int r = blockIdx.z * 2 + half; r < job.nblk; r += 2 * COLSUM_SPLIT) s += job.src[((size_t)r * job.nvec + vec) * HUAL_D + c];
   if (half) part[c] = s;
   __syncthreads();
-  if (!half) atomicAdd(job.dst[vec] + c, s + part[c]);
+  if (!half && !(job.last_ncols > 0 && vec == job.nvec - 1 && c >= job.last_ncols)) atomicAdd(job.dst[vec] + c, s + part[c]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -280,10 +281,14 @@ __global__ __launch_bounds__(512) void pos_bwd_kernel(PosBwdBatch batch, RowSpac
   for (int k = 0; k < 2; ++k) {
     const float* dx = job.dx[k];
     if (!dx) continue;
-    if (job.do_v && t < rs.T)
+    if (job.do_v && t < rs.T) {
+#pragma unroll 8
       for (int b = grp; b < rs.B; b += 4) s += dx[(size_t)(b * rs.T + t) * HUAL_D + c];
-    if (job.do_q && t < rs.L)
+    }
+    if (job.do_q && t < rs.L) {
+#pragma unroll 8
       for (int b = grp; b < rs.B; b += 4) s += dx[(size_t)(rs.Nv + b * rs.L + t) * HUAL_D + c];
+    }
   }
   part[grp][c] = s;
   __syncthreads();

@@ -1159,6 +1159,14 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   //  match_bwd_kernel on the way in)
   float* fuse = c.actv("fuse");
   float* d_fuse = c.actv("d.fuse");
+  float* match_part_b = c.buf("part." + std::to_string(c.part_seq++), (size_t)match_bwd_blocks(Nv) * 9, D);
+  {
+    ColsumJob cj{};
+    cj.src = match_part_b; cj.nblk = match_bwd_blocks(Nv); cj.nvec = 9; cj.last_ncols = 4;
+    for (int k = 0; k < 4; ++k) { cj.dst[k] = c.g(pm.label_emb) + k * D; cj.dst[4 + k] = c.g(pm.match.k) + k * D; }
+    cj.dst[8] = c.g(pm.match.b);
+    if (c.active) c.colsum.push_back(cj);
+  }
   if (c.live()) {
     MatchArgs ma{};
     ma.fuse = fuse; ma.Wm = c.p(pm.match.k); ma.bm = c.p(pm.match.b); ma.E = c.p(pm.label_emb);
@@ -1169,6 +1177,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     mb.dOut = d_in; mb.dOut2 = d_out_heads; mb.dFuse = d_fuse; mb.dWm = c.g(pm.match.k); mb.dbm = c.g(pm.match.b); mb.dE = c.g(pm.label_emb);
     mb.lambda = c.cfg->match_lambda;
     mb.dE_ortho = c.buf("ortho.dE", 4, D);
+    mb.part = match_part_b;
     c.chk(launch_match_bwd(ma, mb, c.rs, c.stream));
   } else {
     c.buf("ortho.dE", 4, D);
