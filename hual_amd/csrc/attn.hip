@@ -106,9 +106,10 @@ __device__ __forceinline__ bf16x8 panel_tr(const char* panel, int plane, int row
 // ======================================================================================================
 // NKT = key tiles of 16 staged and processed (compile time: the tile loops carry no conditions; tiles beyond Tk hold zero
 // keys with an additive term of -inf, i.e. probability 0).  One Philox call per lane covers a group of 4 tiles.
-template <int NKT>
+// DROP: dropout on the probabilities (compile time: the mask code carries no run-time branches)
+template <int NKT, bool DROP, int NT>      // NT threads per workgroup (NT / 64 query tiles in flight)
 __device__ __forceinline__ void attn_fwd_body(const AttnJob& job, int b, int h, char* lds, const DropCfg& drop) {
-  constexpr int Tkp = 16 * NKT, NKQ = (NKT + 3) / 4, NST = (Tkp * 4 + 255) / 256;
+  constexpr int Tkp = 16 * NKT, NKQ = (NKT + 3) / 4, NST = (Tkp * 4 + NT - 1) / NT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnJob& job, int b, int h, 
     float4 kv[NST], vv[NST];
 #pragma unroll
     for (int it = 0; it < NST; ++it) {
-      const int idx = threadIdx.x + 256 * it, row = min(idx >> 2, Tk - 1), c4 = idx & 3;
+      const int idx = threadIdx.x + NT * it, row = min(idx >> 2, Tk - 1), c4 = idx & 3;
       kv[it] = ld4(Kg + (size_t)row * job.ldkv + 4 * c4);
       vv[it] = ld4(Vg + (size_t)row * job.ldkv + 4 * c4);
     }
@@ -142,7 +143,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnJob& job, int b, int h, 
     if (threadIdx.x < Tkp) km = job.kmask[kbase + min((int)threadIdx.x, Tk - 1)];
 #pragma unroll
     for (int it = 0; it < NST; ++it) {
-      const int idx = threadIdx.x + 256 * it, row = idx >> 2, c4 = idx & 3;
+      const int idx = threadIdx.x + NT * it, row = idx >> 2, c4 = idx & 3;
       if (row < Tkp) {
         panel_store(Kp, row, c4, row < Tk ? kv[it] : f4zero());
         panel_store(Vp, row, c4, row < Tk ? vv[it] : f4zero());
@@ -155,12 +156,12 @@ __device__ __forceinline__ void attn_fwd_body(const AttnJob& job, int b, int h, 
     }
   }
   __syncthreads();
-  const bool dodrop = job.drop_site >= 0 && drop.enabled;
+  constexpr bool dodrop = DROP;
   uint32_t k0 = 0, k1 = 0, off = 0;
   if (dodrop) { k0 = drop.state[0]; k1 = drop.state[1]; off = drop.state[2]; }
   const uint32_t t8 = drop_t8(drop);
   const float scale8 = 256.0f / (float)t8;
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += NT / 64) {
     const int q0 = qt * 16;
     const bool qok = q0 + j < Tq;
     const int qrow = qbase + min(q0 + j, Tq - 1);
@@ -253,9 +254,11 @@ __device__ __forceinline__ void attn_fwd_body(const AttnJob& job, int b, int h, 
 }
 
 // MAXNKT: the largest tile count among the jobs of the launch (the kernel's register budget is that of its largest body)
-// (forcing 4 waves per SIMD - 128 registers - spills 25 of them in the 8-tile body: 12.7 -> 15.9 us for the 128 x 128 job)
-template <int MAXNKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, int njobs, DropCfg drop) {
+// (limiting the kernel to 128 registers - 4 waves per SIMD - spills 17 of them in the 8-tile body and is SLOWER, with 4- or
+//  8-wave workgroups alike: 13.4 vs 10.7 us for the 128 x 128 job.  The kernel is VALU-issue bound: ~25 vector instructions per
+//  score - 10 for mask / max / exp / sum, 7.5 Philox, 3 keep decision + keep bits, 3.5 operand split - not latency bound.)
+template <int MAXNKT, int NT>
+__global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnBatch batch, int njobs, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int lid = xcd_logical_id();
   const int h = lid & 7; lid >>= 3;
@@ -263,10 +266,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnBatch batch, int njob
   const int b = lid / njobs;
   if (b >= job.B) return;   // block-uniform
   const int nkt = (job.Tk + 15) >> 4;
-  if (nkt <= 2) attn_fwd_body<2>(job, b, h, lds, drop);
-  else if (MAXNKT >= 4 && nkt <= 4) attn_fwd_body<4>(job, b, h, lds, drop);
-  else if (MAXNKT >= 8 && nkt <= 8) attn_fwd_body<8>(job, b, h, lds, drop);
-  else if (MAXNKT >= 16) attn_fwd_body<16>(job, b, h, lds, drop);
+  if (job.drop_site >= 0 && drop.enabled) {
+    if (nkt <= 2) attn_fwd_body<2, true, NT>(job, b, h, lds, drop);
+    else if (MAXNKT >= 4 && nkt <= 4) attn_fwd_body<4, true, NT>(job, b, h, lds, drop);
+    else if (MAXNKT >= 8 && nkt <= 8) attn_fwd_body<8, true, NT>(job, b, h, lds, drop);
+    else if (MAXNKT >= 16) attn_fwd_body<16, true, NT>(job, b, h, lds, drop);
+  } else {
+    if (nkt <= 2) attn_fwd_body<2, false, NT>(job, b, h, lds, drop);
+    else if (MAXNKT >= 4 && nkt <= 4) attn_fwd_body<4, false, NT>(job, b, h, lds, drop);
+    else if (MAXNKT >= 8 && nkt <= 8) attn_fwd_body<8, false, NT>(job, b, h, lds, drop);
+    else if (MAXNKT >= 16) attn_fwd_body<16, false, NT>(job, b, h, lds, drop);
+  }
 }
 
 // ======================================================================================================
@@ -296,19 +306,14 @@ __host__ __device__ inline BwdLds bwd_lds(int Tq, int Tk, int ldm) {
   return l;
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBatch batch, int njobs, DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  int lid = xcd_logical_id();
-  const int h = lid & 7; lid >>= 3;
-  const AttnJob& job = batch.j[lid % njobs];
-  const int b = lid / njobs;
-  if (b >= job.B) return;   // block-uniform
+template <bool DROP>
+__device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, char* lds, const DropCfg& drop) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
   const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
   const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
-  const bool dodrop = job.drop_site >= 0 && drop.enabled;
+  constexpr bool dodrop = DROP;
   const int ldm = dodrop ? job.ldm : 0;
   const BwdLds L = bwd_lds(Tq, Tk, ldm);
   char* Qp = lds + L.qp; char* Dp = lds + L.dp; char* Kp = lds + L.kp;
@@ -498,6 +503,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBatch batch, int njob
   }
 }
 
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBatch batch, int njobs, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int lid = xcd_logical_id();
+  const int h = lid & 7; lid >>= 3;
+  const AttnJob& job = batch.j[lid % njobs];
+  const int b = lid / njobs;
+  if (b >= job.B) return;   // block-uniform
+  if (job.drop_site >= 0 && drop.enabled) attn_bwd_body<true>(job, b, h, lds, drop);
+  else attn_bwd_body<false>(job, b, h, lds, drop);
+}
+
 namespace hual {
 
 static int check_jobs(const AttnJob* jobs, int n, bool bwd, const DropCfg& drop, int& maxTq, int& maxTk, int& maxB) {
@@ -538,10 +554,21 @@ int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
   const int nkt = cdiv(maxTk, 16);
   const int Tkp = 16 * (nkt <= 2 ? 2 : nkt <= 4 ? 4 : nkt <= 8 ? 8 : 16);
   const size_t lds = (size_t)2 * Tkp * 64 + 2 * Tkp * sizeof(float);
-  if (nkt <= 2) HUAL_LAUNCH(flops, 0.0, attn_fwd_kernel<2>, grid, block, lds, s, b, n, drop);
-  else if (nkt <= 4) HUAL_LAUNCH(flops, 0.0, attn_fwd_kernel<4>, grid, block, lds, s, b, n, drop);
-  else if (nkt <= 8) HUAL_LAUNCH(flops, 0.0, attn_fwd_kernel<8>, grid, block, lds, s, b, n, drop);
-  else HUAL_LAUNCH(flops, 0.0, attn_fwd_kernel<16>, grid, block, lds, s, b, n, drop);
+  // 8 waves per workgroup (one query tile each) when some job has more than 4 query tiles: half the per-wave chain
+  static const int nt_env = []() { const char* e = getenv("HUAL_ATTN_FWD_THREADS"); return e ? atoi(e) : 0; }();
+  const bool wide = nt_env == 512;      // measured equal at 156 registers (one 8-wave workgroup per CU instead of two 4-wave ones)
+  const dim3 block512(512);
+  if (wide) {
+    if (nkt <= 2) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<2, 512>), grid, block512, lds, s, b, n, drop);
+    else if (nkt <= 4) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<4, 512>), grid, block512, lds, s, b, n, drop);
+    else if (nkt <= 8) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<8, 512>), grid, block512, lds, s, b, n, drop);
+    else HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<16, 512>), grid, block512, lds, s, b, n, drop);
+  } else {
+    if (nkt <= 2) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<2, 256>), grid, block, lds, s, b, n, drop);
+    else if (nkt <= 4) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<4, 256>), grid, block, lds, s, b, n, drop);
+    else if (nkt <= 8) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<8, 256>), grid, block, lds, s, b, n, drop);
+    else HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<16, 256>), grid, block, lds, s, b, n, drop);
+  }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -26,6 +26,7 @@ __device__ __forceinline__ f32x4 tile_mma(const float* A, int lda, int imax, con
                                           int kmaxA, int kmaxB, int i0, int n0, int j, int g, f32x4 acc) {
   const int ia = min(i0 + j, imax - 1);
   const int nb = min(n0 + j, nmax - 1);
+#pragma unroll 4
   for (int k0 = 0; k0 < K; k0 += 16) {
     float a[4], b[4];
     if (AK) {
