@@ -161,7 +161,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
           c = cb_fma((o + 1 < shi) ? h4 : f4zero(), w[4], c);
           c = cb_fma((o + 2 < shi) ? h5 : f4zero(), w[5], c);
           c = cb_fma((o + 3 < shi) ? h6 : f4zero(), w[6], c);
-          if (o >= r0 && o < r0 + MT) st4(L.c + (size_t)o * HUAL_D + col, c);
+          if (o >= r0 && o < r0 + MT) st4_nt(L.c + (size_t)o * HUAL_D + col, c);
         }
         const float inv = cb_store_operand(Ahi, Alo, lo_, l32, c);
         if (l32 == 0) ainv[lo_] = live ? inv : 0.f;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
                                fmaf(acc[2][r], ir, 0.f) + bias.z, fmaf(acc[3][r], ir, 0.f) + bias.w);
         v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         const bool own = o >= r0 && o < r0 + MT;
-        if (own) st4(L.y + (size_t)o * HUAL_D + ecol, v);
+        if (own) st4_nt(L.y + (size_t)o * HUAL_D + ecol, v);
         if (L.drop_site >= 0 && dr.enabled)
           v = apply_drop4_r(dr, (uint32_t)L.drop_site, a.drop_row0 + (uint32_t)o, (uint32_t)(ecol >> 2), v);
         float4* xp = X + (o - xbase) * CB_XS + (ecol >> 2);

@@ -232,6 +232,10 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     const int row = r0 + 16 * mt + 4 * g + r;
     if (row < RE) st4(dst + (size_t)row * HUAL_D + ecol, v);
   };
+  auto save_nt = [&](float* dst, int r, float4 v) {      // tensors only the backward pass reads
+    const int row = r0 + 16 * mt + 4 * g + r;
+    if (row < RE) st4_nt(dst + (size_t)row * HUAL_D + ecol, v);
+  };
   // tile -> operand slot, part 1: half-row maxima to LDS (the other column half of a row lives in the partner wave)
   auto put_max = [&](const float4 (&v)[4]) {
 #pragma unroll
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   if (act) {
     fold(SV, ainv0, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { SV[r] = addb(SV[r], 0); save(a.sv, r, SV[r]); }
+    for (int r = 0; r < 4; ++r) { SV[r] = addb(SV[r], 0); save_nt(a.sv, r, SV[r]); }
     zero_invalid(SV);
     put_max(SV);
   }
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   if (act) {
     fold(XV, ainv1, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { XV[r] = addb(XV[r], 1); save(a.xv, r, XV[r]); }
+    for (int r = 0; r < 4; ++r) { XV[r] = addb(XV[r], 1); save_nt(a.xv, r, XV[r]); }
     zero_invalid(XV);
     put_max(XV);
   }
@@ -292,10 +296,10 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float4 sg = sig4(addb(T1[r], 2)), xg = sig4(addb(T2[r], 3));
-      save(a.sg, r, sg);
-      save(a.xg, r, xg);
+      save_nt(a.sg, r, sg);
+      save_nt(a.xg, r, xg);
       T1[r] = cb_add(cb_mul(sg, XV[r]), cb_mul(xg, SV[r]));
-      save(a.o, r, T1[r]);
+      save_nt(a.o, r, T1[r]);
     }
     zero_invalid(T1);
     put_max(T1);
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   if (act) {
     fold(T1, ainv1, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { T1[r] = addb(T1[r], 4); save(a.gd, r, T1[r]); }
+    for (int r = 0; r < 4; ++r) { T1[r] = addb(T1[r], 4); save_nt(a.gd, r, T1[r]); }
     zero_invalid(T1);
     put_max(T1);
   }
@@ -337,10 +341,10 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
       float4 gate = addb(T1[r], 5);
       gate = rm[r] != 0.f ? sig4(gate) : f4zero();             // sigmoid(mask_logits(scores, mask)) (layers.py:110)
       const float4 val = addb(T2[r], 6);
-      save(a.gate, r, gate);
-      save(a.val, r, val);
+      save_nt(a.gate, r, gate);
+      save_nt(a.val, r, val);
       T1[r] = cb_mul(gate, val);
-      save(a.mha, r, T1[r]);
+      save_nt(a.mha, r, T1[r]);
     }
     zero_invalid(T1);
     put_max(T1);
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
       if (dr.enabled) y = apply_drop4_r(dr, (uint32_t)(a.site + 3), a.drop_row0 + (uint32_t)row, (uint32_t)l32, y);
       if (!ok) y = f4zero();
       if (ok) {
-        st4(a.l2 + (size_t)row * HUAL_D + col, y);
+        st4_nt(a.l2 + (size_t)row * HUAL_D + col, y);
         if (l32 == 0) { a.mean2[row] = mean; a.rstd2[row] = rstd; }
       }
       const float i2 = cb_store_operand(P2, P2 + DP_PLANE, lr, l32, y);
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       float4 v = ok ? nv[u] : f4zero();
       if (a.a_site[k] >= 0) {
         if (dr.enabled) v = apply_drop4_r(dr, (uint32_t)a.a_site[k], a.drop_row0 + (uint32_t)row, (uint32_t)l32, v);
-        if (ok && a.a_save[k]) st4(a.a_save[k] + (size_t)row * HUAL_D + col, v);
+        if (ok && a.a_save[k]) st4_nt(a.a_save[k] + (size_t)row * HUAL_D + col, v);
       }
       const float inv = cb_store_operand(S, S + LB_ROWS * 256, lr, l32, v);
       if (l32 == 0) ai[lr] = ok ? inv : 0.f;
@@ -630,6 +634,10 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
     const int row = r0 + 16 * mt + 4 * g + r;
     if (row < RE) st4(dst + (size_t)row * HUAL_D + ecol, v);
   };
+  auto save_nt = [&](float* dst, int r, float4 v) {      // operands of the weight-gradient launch only
+    const int row = r0 + 16 * mt + 4 * g + r;
+    if (row < RE) st4_nt(dst + (size_t)row * HUAL_D + ecol, v);
+  };
   auto put_max = [&](float* sm, const float4 (&v)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -669,8 +677,8 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
       T1[r] = make_float4(d0.x * vl.x * gt.x * (1.f - gt.x), d0.y * vl.y * gt.y * (1.f - gt.y), d0.z * vl.z * gt.z * (1.f - gt.z),
                           d0.w * vl.w * gt.w * (1.f - gt.w));
       T2[r] = cb_mul(d0, gt);
-      save(a.d_sc, r, T1[r]);
-      save(a.d_val, r, T2[r]);
+      save_nt(a.d_sc, r, T1[r]);
+      save_nt(a.d_val, r, T2[r]);
     }
     zero_invalid(T1);
     zero_invalid(T2);
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   if (act) {
     fold(T1, ainv2, false);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) save(a.d_g, r, T1[r]);
+    for (int r = 0; r < 4; ++r) save_nt(a.d_g, r, T1[r]);
     zero_invalid(T1);
     put_max(smaxA, T1);
   }
@@ -718,8 +726,8 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
                           d0.w * sv.w * xg.w * (1.f - xg.w));                        // dZ of x_gate
       U3[r] = cb_mul(d0, xg);                                                         // direct part of d s_value
       U4[r] = cb_mul(d0, sg);                                                         // direct part of d x_value
-      save(a.dz_sg, r, T1[r]);
-      save(a.dz_xg, r, T2[r]);
+      save_nt(a.dz_sg, r, T1[r]);
+      save_nt(a.dz_xg, r, T2[r]);
     }
     zero_invalid(T1);
     zero_invalid(T2);
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   if (act) {
     fold(T1, ainv0, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { T1[r] = cb_add(T1[r], U3[r]); save(a.d_sv, r, T1[r]); }
+    for (int r = 0; r < 4; ++r) { T1[r] = cb_add(T1[r], U3[r]); save_nt(a.d_sv, r, T1[r]); }
     zero_invalid(T1);
     put_max(smaxA, T1);
   }
@@ -743,7 +751,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   if (act) {
     fold(T2, ainv2, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { T2[r] = cb_add(T2[r], U4[r]); save(a.d_xv, r, T2[r]); }
+    for (int r = 0; r < 4; ++r) { T2[r] = cb_add(T2[r], U4[r]); save_nt(a.d_xv, r, T2[r]); }
     zero_invalid(T2);
     put_max(smaxB, T2);
   }
