@@ -1437,9 +1437,7 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
     }
     static const int rt_env = []() { const char* e = getenv("HUAL_GEMM_RT"); return e ? atoi(e) : 0; }();
     const int ncol = cdiv(maxN, 128);
-    // 32-row blocks (4 waves): with the launches that are left outside the fused kernels (CQ dense and its dX, cq_concat, heads' dX)
-  // 1.6219 ms/step against 1.6317 with 48-row blocks for the large launches (HUAL_GEMM_RT=3 forces those)
-  int rt = 2;
+    int rt = (cdiv(maxM, 32) * ncol * n > 256 && maxM > 48) ? 3 : 2;
     if (rt_env == 2 || rt_env == 3) rt = rt_env;
     // launches with many blocks per CU (several jobs / column blocks): bigger blocks share one weight panel among more
     // row tiles (HUAL_GEMM_RTBIG = 4 or 6; experiment)
