@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace -d gpurun_out/tl -o tl --output-format csv -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline
     python scripts/step_timeline.py gpurun_out/tl/*kernel_trace.csv [--steps 20] [--group]
 
-A step starts at every `prep_masks_kernel`; the last --steps complete steps are averaged position by position
+A step starts at every `pack_weights_kernel` (the first launch of the forward; `prep_masks_kernel` in older traces); the last --steps complete steps are averaged position by position
 (duration and the idle gap in front of the kernel).
 """
 import argparse
@@ -36,7 +36,8 @@ def main():
             for r in csv.DictReader(f):
                 rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if 'prep_masks_kernel' in r[2]]
+    first = 'pack_weights_kernel' if any('pack_weights_kernel' in r[2] for r in rows) else 'prep_masks_kernel'
+    starts = [i for i, r in enumerate(rows) if first in r[2]]
     if len(starts) < 3:
         sys.exit('no steps found')
     steps = [rows[starts[i]:starts[i + 1]] for i in range(len(starts) - 1)]
