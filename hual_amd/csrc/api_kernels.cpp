@@ -35,7 +35,7 @@ int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, int trans_
 }
 
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
-                   int N, int rows_per_block, void* stream) {
+                   int N, int rows_per_block, void* scratch, uint64_t scratch_bytes, void* stream) {
   HUAL_REQUIRE(A && dY && dW, "hual_linear_dw: null pointer");
   HUAL_REQUIRE(M > 0 && K % 16 == 0 && N == 128, "hual_linear_dw: K % 16 == 0 and N == 128 required");
   DwJob j;
@@ -44,6 +44,11 @@ int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW,
   j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.dW[0] = dW; j.ldw = ldw;
   j.dY = dY; j.ldy = ldy; j.M = M; j.N = N; j.db = db;
   DropCfg d = make_dropcfg(nullptr, 0.f);
+  if (rows_per_block < 0) {
+    // the balanced launch of the training step (job table in device memory), on -rows_per_block workgroups
+    HUAL_REQUIRE(scratch && scratch_bytes >= 4 * dw_table_words(1), "hual_linear_dw: balanced launch needs a scratch table");
+    return launch_dw(&j, 1, d, 0, (hipStream_t)stream, reinterpret_cast<DwJob*>(scratch), true, -rows_per_block);
+  }
   return launch_dw(&j, 1, d, rows_per_block > 0 ? rows_per_block : 1024, (hipStream_t)stream);
 }
 

@@ -57,6 +57,19 @@ DropCfg make_dropcfg(const uint32_t* state, float rate);
 // ---- device helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// loads through a pointer that was itself read from device memory (job tables): without the address-space cast they are
+// FLAT loads, which count in lgkmcnt as well - every wait for an LDS read then waits for the global loads in flight
+typedef float gvec_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int gvec_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld4_global(const void* p) {
+  const gvec_f4 v = *(const __attribute__((address_space(1))) gvec_f4*)(uintptr_t)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t ld1_global(const void* p) { return *(const __attribute__((address_space(1))) uint8_t*)(uintptr_t)p; }
+__device__ __forceinline__ uint2 ld2_global(const void* p) {
+  const gvec_u2 v = *(const __attribute__((address_space(1))) gvec_u2*)(uintptr_t)p;
+  return make_uint2(v.x, v.y);
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // streaming store: tensors that are written once and only read again much later (saved for the backward pass, operands of the
 // weight-gradient launch at the end of the step) - measured -4 % on da_post_kernel against plain stores

@@ -74,6 +74,9 @@ struct DwJob {
   int M, N;
   float* db;
   int a_bf16;                 // 1: A[0] points at bfloat16 elements (lda in elements); single piece, no A2
+  // keep bits of the a_drop_site dropout as the forward stored them (one byte per 4 columns, ld_keep bytes per row;
+  // FkJob::keep_out): the kernel then skips the Philox rounds.  Single piece.
+  const uint8_t* a_keep; int ld_keep;
 };
 
 #define HUAL_MAX_DW_JOBS 12
@@ -108,6 +111,7 @@ struct FkJob {
   float* part; size_t part_stride;
   int drop_site; uint32_t drop_row0;
   int a_bf16;                 // 1: A points at bfloat16 elements (lda in elements)
+  uint8_t* keep_out; int ld_keep;   // optional: the dropout keep bits, one byte per 4 columns (bit c = column 4g + c)
 };
 #define HUAL_MAX_FK_JOBS 2
 struct FkBatch { FkJob j[HUAL_MAX_FK_JOBS]; };
@@ -119,7 +123,9 @@ int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t str
 // enqueue `n` gradient jobs (any n; split into launches of HUAL_MAX_DW_JOBS); rows_per_block tunes split-M
 // table != null: jobs are read from that device-resident table (any job count, one launch); write_table = false skips
 // filling it (the caller vouches that it still holds exactly these jobs)
+// words of a device job table for n jobs: the descriptors followed by 3 (n + 1) integers (plan of the balanced launch)
+inline size_t dw_table_words(size_t n) { return (n * sizeof(DwJob) + 3 * (n + 1) * sizeof(int) + 3) / 4; }
 int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block, hipStream_t stream,
-              DwJob* table = nullptr, bool write_table = true);   // table: device buffer of n entries -> all jobs in ONE launch
+              DwJob* table = nullptr, bool write_table = true, int balanced_blocks = 0);   // table: device buffer of n entries -> all jobs in ONE launch
 
 }  // namespace hual

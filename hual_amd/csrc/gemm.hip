@@ -726,8 +726,17 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
     if (ks + 2 < nks) a_fetch(ks + 2, f0, f1);       // two k-steps ahead
     if (adrop) {
       const uint32_t cg = (uint32_t)((q * KS + 32 * ks + 8 * g) >> 2);
-      c0 = apply_drop4(drop, (uint32_t)job.drop_site, adrow, cg, c0);
-      c1 = apply_drop4(drop, (uint32_t)job.drop_site, adrow, cg + 1u, c1);
+      if (job.keep_out) {                             // block-uniform: the bits go to the weight-gradient job (DwJob::a_keep)
+        const uint32_t b0 = drop_bits4(drop, (uint32_t)job.drop_site, adrow, cg);
+        const uint32_t b1 = drop_bits4(drop, (uint32_t)job.drop_site, adrow, cg + 1u);
+        c0 = f4mul(c0, mask_from_bits4(b0, drop.scale));
+        c1 = f4mul(c1, mask_from_bits4(b1, drop.scale));
+        if (rowbase + j < M && (int)(4u * cg) < K)
+          *reinterpret_cast<uint16_t*>(job.keep_out + (size_t)arow * job.ld_keep + cg) = (uint16_t)(b0 | (b1 << 8));
+      } else {
+        c0 = apply_drop4(drop, (uint32_t)job.drop_site, adrow, cg, c0);
+        c1 = apply_drop4(drop, (uint32_t)job.drop_site, adrow, cg + 1u, c1);
+      }
     }
     // f16x3 (bf16x3.h): the row scale is taken per 32-deep k-step (the features of a row arrive over the whole loop)
     float rmax = fmaxf(f4absmax(c0), f4absmax(c1));
@@ -1061,9 +1070,23 @@ __global__ __launch_bounds__(256) void transpose_weights_kernel(TrBatch b, const
 #define DW_TM 32            // rows per LDS tile
 #define DW_LD 132           // padded leading dimension (floats)
 // copies a slice of job descriptors (passed by value, so graph-capture safe) into the device-resident job table
-__global__ void dw_table_write_kernel(DwBatch part, DwJob* table, int base, int cnt) {
+// and, behind the n descriptors, what the balanced launch needs per job: tiles in front of it, cost in front of it and
+// the cost of one of its tiles (dw_plan)
+struct DwPlanPart { int tiles[HUAL_MAX_DW_JOBS + 1], cost[HUAL_MAX_DW_JOBS + 1], w[HUAL_MAX_DW_JOBS + 1]; };
+struct DwPlan { int* tiles; int* cost; int* w; };      // (n + 1) entries each
+__device__ __host__ inline DwPlan dw_plan(const DwJob* table, int n) {
+  int* base = const_cast<int*>(reinterpret_cast<const int*>(table + n));
+  return DwPlan{base, base + (n + 1), base + 2 * (n + 1)};
+}
+__global__ void dw_table_write_kernel(DwBatch part, DwPlanPart pre, DwJob* table, int base, int cnt, int n) {
   const int t = threadIdx.x;
   if (t < cnt) table[base + t] = part.j[t];
+  if (t <= cnt) {
+    const DwPlan pl = dw_plan(table, n);
+    pl.tiles[base + t] = pre.tiles[t];
+    pl.cost[base + t] = pre.cost[t];
+    pl.w[base + t] = pre.w[t];
+  }
 }
 
 template <bool FROM_TABLE>
@@ -1205,90 +1228,116 @@ __global__ __launch_bounds__(256) void dw_kernel(DwBatch batch, const DwJob* __r
 // and read back with ds_read_b64_tr_b16, the LDS transpose read, so each lane receives 8 consecutive rows of its column.
 // Per 32-row tile and wave: 24 MFMAs (768 cycles) instead of 64 (4096 cycles); the kernel is then bound by streaming
 // the operands from HBM (every job reads its A and dY once).
-#define DWB_PLANE (DW_TM * 256)          // bytes of one [32][128] bf16 plane
-template <bool FROM_TABLE>
-__global__ __launch_bounds__(256) void dw_bf16_kernel(DwBatch batch, const DwJob* __restrict__ table, DropCfg drop,
-                                                      int rows_per_block) {
-  extern __shared__ float lds[];     // 2 buffers x {A_hi, A_lo, Y_hi, Y_lo} planes
-  __shared__ float4 bred[8][32];
-  char* ldsb = reinterpret_cast<char*>(lds);
-  const DwJob& job = FROM_TABLE ? table[blockIdx.z] : batch.j[blockIdx.z];
+#define DWB_PLANE (64 * 256)             // bytes of one [DWB_TM][128] bf16 plane
+// one segment: rows [m_lo, m_hi) of k-block kb of piece p of a job -> atomics into its 128 x 128 gradient tile.
+// 512 threads: wave (kq, nq) owns the 64 x 32 block of gradient rows 64kq.., columns 32nq.. (two 32x32 accumulators,
+// <= 128 registers per lane, so two workgroups share a CU).  The launch is bound by how many bytes a CU keeps in flight
+// (one workgroup per CU runs 1.7x longer than two), hence two register stages: the loads of tile t+2 are issued before
+// the products of tile t and consumed (split, stored to LDS) at the end of iteration t+1.
+#define DWB_THREADS 512
+#define DWB_TM 64             // rows per LDS tile: one workgroup barrier per 64 rows
+#define DWB_RU (DWB_TM / 16)  // rows a thread stages per tile
+// MODE: DWB_PLAIN fp32 A without a prologue (all but a handful of jobs); DWB_PROD product prologue A[p] * A2[p] (its
+// second operand is staged like the first: DEPTH 2 keeps the registers below 256); DWB_DROP dropout prologue (keep bits
+// from the forward, or the Philox rounds) and / or bfloat16 A
+#define DWB_PLAIN 0
+#define DWB_PROD 1
+#define DWB_DROP 2
+template <int MODE, int DEPTH>
+__device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, const int kb, const int m_lo, const int m_hi,
+                                                const DropCfg& drop, char* ldsb, float4 (*bred)[32], const int dbg = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int kq = wave >> 1, nq = wave & 1;
-  const int M = job.M;
-  int p = 0, kb = blockIdx.y;
-  for (p = 0; p < job.npieces; ++p) {
-    const int nkb = (job.kw[p] + 127) >> 7;
-    if (kb < nkb) break;
-    kb -= nkb;
-  }
-  if (p >= job.npieces) return;                 // block-uniform
-  const int m_lo = blockIdx.x * rows_per_block;
-  if (m_lo >= M) return;                        // block-uniform
-  const int m_hi = min(m_lo + rows_per_block, M);
+  const int kq = wave >> 2, nq = wave & 3;
   const int k0 = kb * 128;
   const int kw = job.kw[p];
-  const float* Ap = job.A[p];
-  const float* A2p = job.A2[p];
+  const char* Ap = reinterpret_cast<const char*>(job.A[p]);
+  const char* A2p = MODE == DWB_PROD ? reinterpret_cast<const char*>(job.A2[p]) : nullptr;
   const int lda = job.lda[p], lda2 = job.lda2[p];
-  const float* Yp = job.dY;
+  const char* Yp = reinterpret_cast<const char*>(job.dY);
   const int ldy = job.ldy;
-  const bool adrop = job.a_drop_site >= 0 && drop.enabled;
+  constexpr bool PLAIN = MODE == DWB_PLAIN;
+  const bool adrop = MODE == DWB_DROP && job.a_drop_site >= 0 && drop.enabled;
   const uint32_t asite = (uint32_t)job.a_drop_site;
   const uint32_t arow0 = job.a_drop_row0;
   const bool dob = (job.db != nullptr) && p == 0 && kb == 0;
+  const bool abf = MODE == DWB_DROP && job.a_bf16 != 0;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
   float4 bsum = f4zero();
 
-  // staging: thread -> rows (tid>>5) + 8u, columns 4*(tid&31)..+3 of both tiles
+  // staging: thread -> rows (tid>>5) + 16u, columns 4*(tid&31)..+3 of both tiles; prologues (bf16 widening, product,
+  // dropout) are applied at the store, so that a load is only waited for one iteration after its issue.  Addresses are
+  // a uniform base per tile plus a 32-bit byte offset per thread (one register each for A and dY).
   const int srow = threadIdx.x >> 5, c4 = threadIdx.x & 31;
-  float4 ra[4], ry[4];
-  auto stage_load = [&](int mt) {
+  const int kcol = k0 + 4 * c4;
+  const bool kin = kcol < kw;
+  const uint32_t esz = abf ? 2u : 4u;
+  const uint32_t aoff = ((uint32_t)srow * (uint32_t)lda + (uint32_t)kcol) * esz;
+  const uint32_t yoff = ((uint32_t)srow * (uint32_t)ldy + 4u * (uint32_t)c4) * 4u;
+  struct Stage { float4 a[DWB_RU], y[DWB_RU], a2[MODE == DWB_PROD ? DWB_RU : 1]; uint32_t keep[DWB_RU]; };
+  const uint32_t a2off = ((uint32_t)srow * (uint32_t)lda2 + (uint32_t)kcol) * 4u;
+  const uint8_t* keepp = MODE == DWB_DROP ? job.a_keep : nullptr;
+  const uint32_t koff = (uint32_t)srow * (uint32_t)job.ld_keep + (uint32_t)(kcol >> 2);
+  Stage st[DEPTH - 1];      // tile i in LDS, tiles i+1 .. i+DEPTH-1 in (or on their way to) registers
+  auto stage_load = [&](int mt, Stage& st) {
+    const char* Ab = Ap + (size_t)mt * lda * esz;
+    const char* Yb = Yp + (size_t)mt * ldy * 4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int m = mt + srow + 8 * u;
+    for (int u = 0; u < DWB_RU; ++u) {
+      const int m = mt + srow + 16 * u;
       float4 a = f4zero(), y = f4zero();
-      if (m < m_hi) {
-        const int k = k0 + 4 * c4;
-        if (k < kw) {
-          if (job.a_bf16) {
-            const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(Ap) + (size_t)m * lda + k);
-            a = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
-                            __uint_as_float(raw.y & 0xffff0000u));
+      if (m < m_hi && !(dbg & 2)) {
+        if (kin) {
+          if (abf) {
+            const uint2 raw = ld2_global(Ab + 16u * u * (uint32_t)lda * 2u + aoff);
+            a.x = __uint_as_float(raw.x);
+            a.y = __uint_as_float(raw.y);
           } else {
-            a = ld4(Ap + (size_t)m * lda + k);
+            a = ld4_global(Ab + 16u * u * (uint32_t)lda * 4u + aoff);
           }
-          if (A2p) a = f4mul(a, ld4(A2p + (size_t)m * lda2 + k));
-          if (adrop) a = apply_drop4(drop, asite, arow0 + (uint32_t)m, (uint32_t)(k >> 2), a);
+          if (MODE == DWB_PROD && A2p) st.a2[u] = ld4_global(A2p + (size_t)mt * lda2 * 4 + 16u * u * (uint32_t)lda2 * 4u + a2off);
         }
-        y = ld4(Yp + (size_t)m * ldy + 4 * c4);
+        y = ld4_global(Yb + 16u * u * (uint32_t)ldy * 4u + yoff);
+        if (MODE == DWB_DROP && keepp && kin) st.keep[u] = ld1_global(keepp + (size_t)mt * job.ld_keep + 16u * u * (uint32_t)job.ld_keep + koff);
       }
-      ra[u] = a;
-      ry[u] = y;
+      st.a[u] = a;
+      st.y[u] = y;
     }
   };
-  auto stage_store = [&](int buf) {
+  auto stage_store = [&](int buf, int mt, const Stage& st) {
     char* base = ldsb + buf * 4 * DWB_PLANE;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int row = srow + 8 * u;
+    for (int u = 0; u < DWB_RU; ++u) {
+      const int row = srow + 16 * u;
       const int off = tile256_off(row, c4 >> 1) + 8 * (c4 & 1);
+      float4 a = st.a[u];
+      if (!PLAIN) {
+        const int m = mt + row;
+        const bool live = m < m_hi && kin;
+        if (abf) {
+          const uint32_t r0 = __float_as_uint(a.x), r1 = __float_as_uint(a.y);
+          a = make_float4(__uint_as_float(r0 << 16), __uint_as_float(r0 & 0xffff0000u), __uint_as_float(r1 << 16),
+                          __uint_as_float(r1 & 0xffff0000u));
+        }
+        if (MODE == DWB_PROD && A2p && live) a = f4mul(a, st.a2[u]);
+        if (adrop && live) {
+          if (keepp) a = f4mul(a, mask_from_bits4(st.keep[u], drop.scale));
+          else a = apply_drop4(drop, asite, arow0 + (uint32_t)m, (uint32_t)(kcol >> 2), a);
+        }
+      }
       uint2 hi, lo;
-      bf16_split4(ra[u], hi, lo);
+      bf16_split4(a, hi, lo);
       *reinterpret_cast<uint2*>(base + off) = hi;
       *reinterpret_cast<uint2*>(base + DWB_PLANE + off) = lo;
-      bf16_split4(ry[u], hi, lo);
+      bf16_split4(st.y[u], hi, lo);
       *reinterpret_cast<uint2*>(base + 2 * DWB_PLANE + off) = hi;
       *reinterpret_cast<uint2*>(base + 3 * DWB_PLANE + off) = lo;
-      bsum = f4add(bsum, ry[u]);
+      bsum = f4add(bsum, st.y[u]);
     }
   };
   // transposed-read addressing: 16-lane group g' = lane>>4 takes the 4-row x 16-column block of columns
@@ -1299,55 +1348,66 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(DwBatch batch, const DwJob
     const int ch = ((colbase + 16 * ghalf) >> 3) + (gp >> 1);
     return tile256_off(row, ch) + 8 * (gp & 1);
   };
-
-  stage_load(m_lo);
-  stage_store(0);
-  __syncthreads();
-  int buf = 0;
-  for (int mt = m_lo; mt < m_hi; mt += DW_TM) {
-    const bool more = (mt + DW_TM) < m_hi;
-    if (more) stage_load(mt + DW_TM);            // global loads in flight under the MFMAs below
+  auto products = [&](int buf) {
     const char* base = ldsb + buf * 4 * DWB_PLANE;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[2], al[2], yh[2], yl[2];
+    for (int ks = 0; ks < DWB_TM / 16; ++ks) {
+      const int y0 = tr_off(nq * 32, ks, 0), y1 = tr_off(nq * 32, ks, 1);
+      const bf16x8 yh = join_tr(lds_read_tr16(base + 2 * DWB_PLANE, y0), lds_read_tr16(base + 2 * DWB_PLANE, y1));
+      const bf16x8 yl = join_tr(lds_read_tr16(base + 3 * DWB_PLANE, y0), lds_read_tr16(base + 3 * DWB_PLANE, y1));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int o0 = tr_off(kq * 64 + 32 * c, ks, 0), o1 = tr_off(kq * 64 + 32 * c, ks, 1);
-        ah[c] = join_tr(lds_read_tr16(base, o0), lds_read_tr16(base, o1));
-        al[c] = join_tr(lds_read_tr16(base + DWB_PLANE, o0), lds_read_tr16(base + DWB_PLANE, o1));
-        const int y0 = tr_off(nq * 64 + 32 * c, ks, 0), y1 = tr_off(nq * 64 + 32 * c, ks, 1);
-        yh[c] = join_tr(lds_read_tr16(base + 2 * DWB_PLANE, y0), lds_read_tr16(base + 2 * DWB_PLANE, y1));
-        yl[c] = join_tr(lds_read_tr16(base + 3 * DWB_PLANE, y0), lds_read_tr16(base + 3 * DWB_PLANE, y1));
+        const bf16x8 ah = join_tr(lds_read_tr16(base, o0), lds_read_tr16(base, o1));
+        const bf16x8 al = join_tr(lds_read_tr16(base + DWB_PLANE, o0), lds_read_tr16(base + DWB_PLANE, o1));
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, yh, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, yl, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, yh, acc[c], 0, 0, 0);
       }
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], yh[t], acc[c][t], 0, 0, 0);
-          acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], yl[t], acc[c][t], 0, 0, 0);
-          acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c], yh[t], acc[c][t], 0, 0, 0);
-        }
     }
-    if (more) stage_store(buf ^ 1);
-    __syncthreads();
+  };
+
+  // tile i sits in LDS buffer i&1 while the registers hold tiles i+1 .. i+DEPTH-1 (the last of them just issued)
+#pragma unroll
+  for (int q = 0; q < DEPTH - 1; ++q) stage_load(m_lo + q * DWB_TM, st[q]);     // rows at or beyond m_hi load nothing
+  stage_store(0, m_lo, st[0]);
+  __syncthreads();
+  int buf = 0, mt = m_lo;
+  // one tile: issue the loads of tile i+DEPTH-1 into `in` (the stage tile i left), multiply tile i, move tile i+1 from
+  // `out` to the other buffer
+  auto step = [&](Stage& in, const Stage& out) -> bool {
+    stage_load(mt + (DEPTH - 1) * DWB_TM, in);
+    if (!(dbg & 1)) products(buf);
+    if (mt + DWB_TM >= m_hi) return true;      // block-uniform
+    stage_store(buf ^ 1, mt + DWB_TM, out);
+    if (!(dbg & 16)) __syncthreads();
+    mt += DWB_TM;
     buf ^= 1;
+    return false;
+  };
+  static_assert(DEPTH == 2 || DEPTH == 4, "the rotations below are written out for one and three stages");
+  if (DEPTH == 2) {
+    for (;;)
+      if (step(st[0], st[0])) break;
+  } else {
+    for (;;) {       // st[0] held tile i (now in LDS) and receives tile i+3; st[1] holds tile i+1
+      if (step(st[0], st[1])) break;
+      if (step(st[1], st[2])) break;
+      if (step(st[2], st[0])) break;
+    }
   }
 
-  // each wave owns its quadrant: no cross-wave reduction, straight to global atomics.  Accumulator register r of lane
-  // (i, h) is gradient row 32c + (r&3) + 8*(r>>2) + 4h, column 32t + i of the quadrant.
+  // each wave owns its block: no cross-wave reduction, straight to global atomics.  Accumulator register r of lane
+  // (i, h) is gradient row 32c + (r&3) + 8*(r>>2) + 4h, column i of the block.
   float* dWp = job.dW[p];
-  const int kbase = k0 + kq * 64, nbase = nq * 64;
+  const int kbase = k0 + kq * 64, n = nq * 32 + i;
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = kbase + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int n = nbase + 32 * t + i;
-        if (k < kw) atomicAdd(dWp + (size_t)k * job.ldw + n, acc[c][t][r]);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int k = kbase + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (k < kw && !(dbg & 4)) atomicAdd(dWp + (size_t)k * job.ldw + n, acc[c][r]);
+    }
   if (dob) {                                   // block-uniform
     bred[srow][c4] = bsum;
     __syncthreads();
@@ -1355,10 +1415,123 @@ __global__ __launch_bounds__(256) void dw_bf16_kernel(DwBatch batch, const DwJob
       const int cc = threadIdx.x;
       float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += reinterpret_cast<const float*>(&bred[k][cc >> 2])[cc & 3];
+      for (int k = 0; k < 16; ++k) s += reinterpret_cast<const float*>(&bred[k][cc >> 2])[cc & 3];
       atomicAdd(job.db + cc, s);
     }
   }
+}
+
+// block-uniform choice of the variant (launch_dw rejects a product prologue together with dropout / bfloat16)
+__device__ __forceinline__ void dw_bf16_any_segment(const DwJob& job, const int p, const int kb, const int m_lo, const int m_hi,
+                                                    const DropCfg& drop, char* ldsb, float4 (*bred)[32], const int dbg) {
+  if (job.A2[p]) dw_bf16_segment<DWB_PROD, 2>(job, p, kb, m_lo, m_hi, drop, ldsb, bred, dbg);
+  else if (job.a_bf16 || job.a_drop_site >= 0) dw_bf16_segment<DWB_DROP, 4>(job, p, kb, m_lo, m_hi, drop, ldsb, bred, dbg);
+  else dw_bf16_segment<DWB_PLAIN, 4>(job, p, kb, m_lo, m_hi, drop, ldsb, bred, dbg);
+}
+
+// grid = (row chunks, k-blocks, jobs): one segment per block
+template <bool FROM_TABLE>
+__global__ __launch_bounds__(DWB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void dw_bf16_kernel(DwBatch batch, const DwJob* __restrict__ table, DropCfg drop, int rows_per_block) {
+  extern __shared__ float lds[];     // 2 buffers x {A_hi, A_lo, Y_hi, Y_lo} planes
+  __shared__ float4 bred[16][32];
+  const DwJob& job = FROM_TABLE ? table[blockIdx.z] : batch.j[blockIdx.z];
+  int p = 0, kb = blockIdx.y;
+  for (p = 0; p < job.npieces; ++p) {
+    const int nkb = (job.kw[p] + 127) >> 7;
+    if (kb < nkb) break;
+    kb -= nkb;
+  }
+  if (p >= job.npieces) return;                 // block-uniform
+  const int m_lo = blockIdx.x * rows_per_block;
+  if (m_lo >= job.M) return;                    // block-uniform
+  dw_bf16_any_segment(job, p, kb, m_lo, min(m_lo + rows_per_block, job.M), drop, reinterpret_cast<char*>(lds), bred, 0);
+}
+
+// Balanced launch: the 64-row tiles of all (job, piece, k-block) units form one list (job-major; plan.tiles[j] = tiles in
+// front of job j) that is cut into gridDim.x runs of equal COST, one per workgroup (one workgroup per CU); a workgroup
+// walks its run segment by segment and flushes its accumulators with atomics whenever the unit changes.  The cost of a
+// tile depends on its job's prologue (strided clip features + keep bytes, product operands), and every unit carries a
+// fixed cost in front of its first tile (DW_UNIT_COST: the flush, the pipeline refill): plan.cost[j] = cost in front of
+// job j, plan.w[j] = cost per tile.  256 workgroups x 58 jobs: ~340 flushes of 64 KB instead of ~1500 with a fixed row
+// split (float atomics run at 1.3 TB/s chip-wide), no round quantisation, no tail.
+#ifdef HUAL_STAMPS
+// debug: per-workgroup clock stamps of the balanced launch (scripts/exp/dw_stamps.py)
+#define DW_STAMP_SLOTS 16
+__device__ unsigned long long g_dw_stamps[2048 * DW_STAMP_SLOTS];
+extern "C" int hual_debug_dw_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#define DW_STAMP(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 2048 && (i) < DW_STAMP_SLOTS) g_dw_stamps[blockIdx.x * DW_STAMP_SLOTS + (i)] = (v); } while (0)
+#else
+#define DW_STAMP(i, v) do { } while (0)
+#endif
+#define DW_UNIT_COST 72
+__global__ __launch_bounds__(DWB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void dw_bf16_balanced_kernel(const DwJob* __restrict__ table, int n, DropCfg drop, int dbg) {
+  extern __shared__ float lds[];
+  __shared__ float4 bred[16][32];
+  int* s_job = reinterpret_cast<int*>(&bred[0][0]);     // (no further static array: the planes must stay 16-byte aligned)
+  DW_STAMP(0, __builtin_readcyclecounter());
+  const DwPlan pl = dw_plan(table, n);
+  const int total_cost = pl.cost[n];
+  // run boundaries in cost space -> global tile index
+  int cb[2];
+  cb[0] = (int)(((long)blockIdx.x * total_cost) / gridDim.x);
+  cb[1] = (int)(((long)(blockIdx.x + 1) * total_cost) / gridDim.x);
+  for (int j = threadIdx.x; j < n; j += DWB_THREADS)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (pl.cost[j] <= cb[e] && cb[e] < pl.cost[j + 1]) s_job[e] = j;
+  __syncthreads();
+  int tb[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    if (cb[e] >= total_cost) { tb[e] = pl.tiles[n]; continue; }
+    const int j = s_job[e];
+    const int per_unit = (table[j].M + DWB_TM - 1) / DWB_TM;
+    const int w = pl.w[j];
+    const int ucost = DW_UNIT_COST + per_unit * w;
+    const int local = cb[e] - pl.cost[j];
+    const int unit = local / ucost;
+    const int r = local - unit * ucost - DW_UNIT_COST;
+    tb[e] = pl.tiles[j] + unit * per_unit + (r > 0 ? r / w : 0);
+  }
+  int t = tb[0];
+  const int t_end = tb[1];
+  int j = s_job[0];
+  __syncthreads();                              // s_job lives in bred
+  if (t >= t_end) return;                       // block-uniform
+  const int* prefix = pl.tiles;
+  DW_STAMP(1, __builtin_readcyclecounter());
+  DW_STAMP(3, (unsigned long long)(t_end - t));
+  DW_STAMP(5, (unsigned long long)j);
+  int nseg = 0, nnp = 0;
+  while (t < t_end) {
+    const DwJob& job = table[j];
+    const int per_unit = (job.M + DWB_TM - 1) / DWB_TM;
+    const int local = t - prefix[j];
+    int unit = local / per_unit;
+    const int tile = local - unit * per_unit;
+    const int cnt = min(per_unit - tile, t_end - t);
+    int p = 0;
+    for (p = 0; p < job.npieces; ++p) {
+      const int nkb = (job.kw[p] + 127) >> 7;
+      if (unit < nkb) break;
+      unit -= nkb;
+    }
+    const bool plain = !job.a_bf16 && !job.A2[p] && job.a_drop_site < 0;      // (stamps)
+    dw_bf16_any_segment(job, p, unit, tile * DWB_TM, min((tile + cnt) * DWB_TM, job.M), drop, reinterpret_cast<char*>(lds), bred, dbg);
+    t += cnt;
+    if (t >= prefix[j + 1]) ++j;
+    __syncthreads();                            // LDS planes and bred are reused by the next segment
+    DW_STAMP(7 + nseg, __builtin_readcyclecounter());
+    ++nseg;
+    nnp += plain ? 0 : 1;
+  }
+  DW_STAMP(2, __builtin_readcyclecounter());
+  DW_STAMP(4, (unsigned long long)nseg);
+  DW_STAMP(6, (unsigned long long)nnp);
 }
 
 namespace hual {
@@ -1662,7 +1835,7 @@ static int dw_auto_rows(const DwJob* jobs, int n) {
 }
 
 int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block, hipStream_t stream, DwJob* table,
-              bool write_table) {
+              bool write_table, int balanced_blocks) {
   static const int rows_env = []() { const char* e = getenv("HUAL_DW_ROWS"); return e ? atoi(e) : 0; }();
   if (rows_per_block == 0) rows_per_block = rows_env > 0 ? rows_env : dw_auto_rows(jobs, n);
   HUAL_REQUIRE(rows_per_block >= DW_TM && (rows_per_block % DW_TM) == 0, "launch_dw: rows_per_block must be a multiple of 32");
@@ -1670,8 +1843,8 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
   HUAL_DYN_LDS(dw_kernel<false>, 96 * 1024);
   // HUAL_DW_IMPL=0: fp32 MFMA kernel (dw_kernel); default: split-bf16 kernel (dw_bf16_kernel)
   const int dw_impl = []() { const char* e = getenv("HUAL_DW_IMPL"); return e ? atoi(e) : 1; }();     // read per call (tests)
-  HUAL_DYN_LDS(dw_bf16_kernel<true>, 96 * 1024);
-  HUAL_DYN_LDS(dw_bf16_kernel<false>, 96 * 1024);
+  HUAL_DYN_LDS(dw_bf16_kernel<true>, 144 * 1024);
+  HUAL_DYN_LDS(dw_bf16_kernel<false>, 144 * 1024);
   size_t lds = dw_impl ? (size_t)8 * DWB_PLANE : (size_t)4 * DW_TM * DW_LD * sizeof(float);
   for (int i = 0; i < n; ++i)
     HUAL_REQUIRE(!jobs[i].a_bf16 || (dw_impl && jobs[i].npieces == 1 && !jobs[i].A2[0] && (jobs[i].lda[0] % 4) == 0),
@@ -1683,23 +1856,61 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
   if (table != nullptr) {
     int maxM = 0, maxKb = 0;
     double flops = 0.0, bytes = 0.0;
+    int tiles = 0, cost = 0;                     // running tile count / cost of the balanced launch
+    // cost of one 64-row tile by prologue (per-tile cycles of the workgroups, scripts/exp/dw_stamps.py: plain 6.5 k, product
+    // and strided clip features + keep bytes 8-9 k; the launch time is flat from 44 to 52, scripts/exp/dw_weights.sh);
+    // HUAL_DW_WEIGHTS="plain,prod,drop" overrides
+    static int wts[3] = {32, 46, 46};
+    static const bool wts_env = []() {
+      const char* e = getenv("HUAL_DW_WEIGHTS");
+      if (e) sscanf(e, "%d,%d,%d", &wts[0], &wts[1], &wts[2]);
+      return e != nullptr;
+    }();
+    (void)wts_env;
     for (int base = 0; base < n; base += HUAL_MAX_DW_JOBS) {
       const int cnt = n - base < HUAL_MAX_DW_JOBS ? n - base : HUAL_MAX_DW_JOBS;
       DwBatch b;
+      DwPlanPart pre;
       for (int i = 0; i < cnt; ++i) {
+        const DwJob& jb = jobs[base + i];
         int kbs;
-        int rc = dw_check(jobs[base + i], kbs, flops, bytes);
+        int rc = dw_check(jb, kbs, flops, bytes);
         if (rc) return rc;
-        b.j[i] = jobs[base + i];
-        maxM = jobs[base + i].M > maxM ? jobs[base + i].M : maxM;
+        b.j[i] = jb;
+        maxM = jb.M > maxM ? jb.M : maxM;
         maxKb = kbs > maxKb ? kbs : maxKb;
+        bool prod = false;
+        for (int p = 0; p < jb.npieces; ++p) prod = prod || jb.A2[p] != nullptr;
+        const int w = (jb.a_drop_site >= 0 || jb.a_bf16) ? wts[2] : prod ? wts[1] : wts[0];
+        pre.tiles[i] = tiles;
+        pre.cost[i] = cost;
+        pre.w[i] = w;
+        tiles += kbs * cdiv(jb.M, DWB_TM);
+        cost += kbs * (DW_UNIT_COST + cdiv(jb.M, DWB_TM) * w);
       }
-      if (write_table) HUAL_LAUNCH(0.0, 0.0, dw_table_write_kernel, dim3(1), dim3(64), 0, stream, b, table, base, cnt);
+      for (int i = cnt; i <= HUAL_MAX_DW_JOBS; ++i) { pre.tiles[i] = tiles; pre.cost[i] = cost; pre.w[i] = 1; }
+      if (write_table) HUAL_LAUNCH(0.0, 0.0, dw_table_write_kernel, dim3(1), dim3(64), 0, stream, b, pre, table, base, cnt, n);
+    }
+    // HUAL_DW_BALANCED=0: the fixed row split (grid of row chunks x k-blocks x jobs)
+    const int balanced = []() { const char* e = getenv("HUAL_DW_BALANCED"); return e ? atoi(e) : 1; }();     // read per call (tests)
+    if (dw_impl && balanced) {
+      // one 512-thread workgroup per CU; HUAL_DW_BLOCKS overrides the count
+      static const int blocks_env = []() { const char* e = getenv("HUAL_DW_BLOCKS"); return e ? atoi(e) : 0; }();
+      int dev = 0, cus = 256;
+      HUAL_CHECK_HIP(hipGetDevice(&dev));
+      HUAL_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      static const int dbg_env = []() { const char* e = getenv("HUAL_DW_DBG"); return e ? atoi(e) : 0; }();
+      int nblocks = balanced_blocks > 0 ? balanced_blocks : blocks_env > 0 ? blocks_env : cus;
+      if (nblocks > tiles) nblocks = tiles;
+      HUAL_DYN_LDS(dw_bf16_balanced_kernel, 144 * 1024);
+      HUAL_LAUNCH(flops, bytes, dw_bf16_balanced_kernel, dim3(nblocks), dim3(DWB_THREADS), lds, stream, (const DwJob*)table, n, drop, dbg_env);
+      HUAL_CHECK_HIP(hipGetLastError());
+      return 0;
     }
     DwBatch dummy;
     dw_job_init(dummy.j[0]);
     dim3 grid(cdiv(maxM, rows_per_block), maxKb, n), block(256);
-    if (dw_impl) HUAL_LAUNCH(flops, bytes, dw_bf16_kernel<true>, grid, block, lds, stream, dummy, (const DwJob*)table, drop, rows_per_block);
+    if (dw_impl) HUAL_LAUNCH(flops, bytes, dw_bf16_kernel<true>, grid, dim3(DWB_THREADS), lds, stream, dummy, (const DwJob*)table, drop, rows_per_block);
     else HUAL_LAUNCH(flops, bytes, dw_kernel<true>, grid, block, lds, stream, dummy, (const DwJob*)table, drop, rows_per_block);
     HUAL_CHECK_HIP(hipGetLastError());
     return 0;
@@ -1718,7 +1929,7 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, int rows_per_block,
       maxKb = kbs > maxKb ? kbs : maxKb;
     }
     dim3 grid(cdiv(maxM, rows_per_block), maxKb, cnt), block(256);
-    if (dw_impl) HUAL_LAUNCH(flops, bytes, dw_bf16_kernel<false>, grid, block, lds, stream, b, (const DwJob*)nullptr, drop, rows_per_block);
+    if (dw_impl) HUAL_LAUNCH(flops, bytes, dw_bf16_kernel<false>, grid, dim3(DWB_THREADS), lds, stream, b, (const DwJob*)nullptr, drop, rows_per_block);
     else HUAL_LAUNCH(flops, bytes, dw_kernel<false>, grid, block, lds, stream, b, (const DwJob*)nullptr, drop, rows_per_block);
     HUAL_CHECK_HIP(hipGetLastError());
   }

@@ -334,6 +334,15 @@ DwJob mkdw(const float* A, int lda, int K, const float* dY, int ldy, int M, floa
   return j;
 }
 
+// feature-load path of the two input projections: the K-split kernel (gemm.h launch_feature_ksplit) when the shapes allow;
+// HUAL_FEATURE_KSPLIT=0 (read per call: tests) or an unsupported vdim selects the generic dense launch
+int feature_qks(int catw) { return ((catw + 3) / 4 + 63) & ~63; }      // quarter size of query_conv1d's K (multiple of 64)
+bool feature_ksplit_ok(const Ctx& c, int catw) {
+  const char* e = getenv("HUAL_FEATURE_KSPLIT");
+  const int on = e ? atoi(e) : 1;
+  return c.use_bf16 && on && (c.cfg->vdim % 256) == 0 && c.cfg->vdim <= 1024 && (catw % 8) == 0 && feature_qks(catw) <= 256;
+}
+
 // Launch the weight-gradient jobs queued since the last flush.  With an aux stream they run there, forked from the
 // main stream at this point (their operands are complete) and overlapping the dX chain that continues on main.
 void flush_dw(Ctx& c, bool last = false) {
@@ -347,7 +356,7 @@ void flush_dw(Ctx& c, bool last = false) {
   static const int nosort = []() { const char* e = getenv("HUAL_DW_NOSORT"); return e ? atoi(e) : 0; }();
   if (!nosort)
     std::stable_sort(c.dwjobs.begin() + c.dw_flushed, c.dwjobs.end(), [](const DwJob& a, const DwJob& b) { return a.M > b.M; });
-  DwJob* table = reinterpret_cast<DwJob*>(c.buf("dw.table." + std::to_string(c.dw_flushes), n, (sizeof(DwJob) + 3) / 4));
+  DwJob* table = reinterpret_cast<DwJob*>(c.buf("dw.table." + std::to_string(c.dw_flushes), 1, dw_table_words(n)));
   if (!c.dry && c.ok()) {
     hipStream_t s = c.stream;
     // HUAL_DW_AUX=1: the weight-gradient launch on the side stream, under the embedding backward (measured: +1.4 % step time)
@@ -598,18 +607,20 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* lin = c.act("lin");
   // feature-load path: K-split kernel with LDS-resident weight quarters (gemm.h launch_feature_ksplit); its four partial
   // slabs are summed by the layer-norm launch.  HUAL_FEATURE_KSPLIT=0 or an unsupported vdim: the generic dense launch.
-  const int ksplit_env = []() { const char* e = getenv("HUAL_FEATURE_KSPLIT"); return e ? atoi(e) : 1; }();     // per call (tests)
-  const int qks = ((catw + 3) / 4 + 63) & ~63;                   // quarter size of query_conv1d's K (multiple of 64)
-  const bool ksplit = c.use_bf16 && ksplit_env && (c.cfg->vdim % 256) == 0 && c.cfg->vdim <= 1024 && (catw % 8) == 0 && qks <= 256;
+  const int qks = feature_qks(catw);
+  const bool ksplit = feature_ksplit_ok(c, catw);
   float* vpart = c.buf("lin.part", (size_t)4 * R, D);
+  // keep bits of the clip-feature dropout, one byte per 4 features: the weight-gradient job of video_conv1d reads them
+  // instead of repeating the Philox rounds for all B*T*vdim elements
+  uint8_t* vkeep = reinterpret_cast<uint8_t*>(c.buf("video.keep", (size_t)Nv, (size_t)(c.cfg->vdim + 15) / 16));
   if (ksplit) {
     if (c.live()) {
       FkJob fj[2];
       fj[0] = FkJob{reinterpret_cast<const float*>(bt->video), c.cfg->vdim, Nv, c.cfg->vdim, c.cfg->vdim / 4,
                     reinterpret_cast<const float*>(c.PKF + pm.vconv.k * 4), vpart, (size_t)R * D, HUAL_SITE_VIDEO, 0,
-                    bt->video_dtype == HUAL_DTYPE_BF16 ? 1 : 0};
+                    bt->video_dtype == HUAL_DTYPE_BF16 ? 1 : 0, c.want_bwd ? vkeep : nullptr, c.cfg->vdim / 4};
       fj[1] = FkJob{cat, catw, Nq, catw, qks, reinterpret_cast<const float*>(c.PKF + pm.qconv.k * 4),
-                    vpart + (size_t)Nv * D, (size_t)R * D, -1, 0, 0};
+                    vpart + (size_t)Nv * D, (size_t)R * D, -1, 0, 0, nullptr, 0};
       c.chk(launch_feature_ksplit(fj, 2, c.drop, c.stream));
     }
   } else {
@@ -1491,6 +1502,9 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     DwJob j = mkdw(c.dry ? nullptr : reinterpret_cast<const float*>(bt->video), c.cfg->vdim, c.cfg->vdim, d_lin, D, Nv, c.g(pm.vconv.k), c.g(pm.vconv.b));
     j.a_drop_site = HUAL_SITE_VIDEO; j.a_drop_row0 = 0;
     j.a_bf16 = (!c.dry && bt->video_dtype == HUAL_DTYPE_BF16) ? 1 : 0;
+    // written by the K-split feature-load kernel
+    j.a_keep = feature_ksplit_ok(c, catw) ? reinterpret_cast<const uint8_t*>(c.buf("video.keep", 0, 0)) : nullptr;
+    j.ld_keep = c.cfg->vdim / 4;
     c.push_dw(j);
     c.push_dw(mkdw(cat, catw, catw, d_lin + (size_t)Nv * D, D, Nq, c.g(pm.qconv.k), c.g(pm.qconv.b)));
   }

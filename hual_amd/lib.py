@@ -124,7 +124,7 @@ def load():
                                        vp, f32, i32, vp]
     lib.hual_attention_keep_row_bytes.argtypes = [i32]
     lib.hual_span_argmax.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
-    lib.hual_linear_dw.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]
+    lib.hual_linear_dw.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, u64, vp]
     lib.hual_al_score.argtypes = [P(hual_al_set), vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]
     lib.hual_al_renew.argtypes = [P(hual_al_set), vp, i32, vp, vp, vp, P(ctypes.c_double), vp, vp]
     lib.hual_assemble_batch.argtypes = [P(hual_dataset), vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -217,5 +217,7 @@ def linear_bf16x3(A, W, bias=None, act=0, trans_w=False):
 def linear_dw(A, dY, dW, db=None, rows_per_block=1024):
     M, K = A.shape
     N = dY.shape[1]
+    import torch
+    scratch = torch.empty(256, dtype=torch.float32, device=A.device) if rows_per_block < 0 else None
     check(load().hual_linear_dw(ptr(A), A.stride(0), ptr(dY), dY.stride(0), ptr(dW), dW.stride(0), ptr(db), M, K, N,
-                                rows_per_block, stream_ptr()))
+                                rows_per_block, ptr(scratch), 1024 if scratch is not None else 0, stream_ptr()))

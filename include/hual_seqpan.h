@@ -255,9 +255,11 @@ int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, con
 
 /* gradients of the dense above: dW[K,N] += A^T . dY ; db[N] += colsum(dY) (db may be NULL).
   * N must be 128 (every dense layer of the graph has 128 outputs); rows_per_block (multiple of 32, 0 = 1024) sets the
- * split over M.  Accumulates with float atomics: zero the destinations first. */
+ * split over M; rows_per_block = -G selects the launch the training step uses: the 32-row tiles of all jobs dealt evenly
+ * to G persistent workgroups, the job table living in `scratch` (device, >= 512 bytes; otherwise unused, may be NULL).
+ * Accumulates with float atomics: zero the destinations first. */
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
-                   int N, int rows_per_block, void* stream);
+                   int N, int rows_per_block, void* scratch, uint64_t scratch_bytes, void* stream);
 
 /* layer_norm (models/layers.py:7-17): y = (x - mean) * rsqrt(var + 1e-6) * gamma + beta over the 128 columns of each row;
  * mean / rstd (optional, [R]) are what the backward needs. */

@@ -14,11 +14,11 @@ def run(M, K, lda, tag, rpb=512):
     dW = torch.zeros(K, 128, device=dev)
     db = torch.zeros(128, device=dev)
     for _ in range(3):
-        lib.check(l.hual_linear_dw(lib.ptr(A), lda, lib.ptr(dY), 128, lib.ptr(dW), 128, lib.ptr(db), M, K, 128, rpb, lib.stream_ptr()))
+        lib.check(l.hual_linear_dw(lib.ptr(A), lda, lib.ptr(dY), 128, lib.ptr(dW), 128, lib.ptr(db), M, K, 128, rpb, None, 0, lib.stream_ptr()))
     torch.cuda.synchronize()
     l.hual_prof_begin()
     for _ in range(10):
-        lib.check(l.hual_linear_dw(lib.ptr(A), lda, lib.ptr(dY), 128, lib.ptr(dW), 128, lib.ptr(db), M, K, 128, rpb, lib.stream_ptr()))
+        lib.check(l.hual_linear_dw(lib.ptr(A), lda, lib.ptr(dY), 128, lib.ptr(dW), 128, lib.ptr(db), M, K, 128, rpb, None, 0, lib.stream_ptr()))
     n = l.hual_prof_end()
     for i in range(n):
         name = ctypes.create_string_buffer(128)

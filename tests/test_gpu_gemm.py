@@ -53,7 +53,10 @@ def test_linear_dx_transposed_weight(dev, M, K, N):
 
 
 @pytest.mark.parametrize('M,K,N,rpw', [(64, 64, 128, 32), (37, 128, 128, 32), (1000, 400, 128, 64), (9472, 128, 128, 1024),
-                                       (4096, 1024, 128, 256), (513, 16, 128, 96), (33, 272, 128, 1024)])
+                                       (4096, 1024, 128, 256), (513, 16, 128, 96), (33, 272, 128, 1024),
+                                       # rows_per_block = -G: the balanced launch of the training step on G workgroups
+                                       (64, 64, 128, -1), (37, 128, 128, -2), (1000, 400, 128, -7), (9472, 128, 128, -512),
+                                       (4096, 1024, 128, -100), (513, 16, 128, -512), (33, 272, 128, -3)])
 def test_linear_dw(dev, M, K, N, rpw):
     from hual_amd import lib
     g = torch.Generator(device='cpu').manual_seed(M + K + N)
