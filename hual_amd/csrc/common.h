@@ -65,6 +65,10 @@ __device__ __forceinline__ float4 ld4_global(const void* p) {
   const gvec_f4 v = *(const __attribute__((address_space(1))) gvec_f4*)(uintptr_t)p;
   return make_float4(v.x, v.y, v.z, v.w);
 }
+// float atomic add through a global-address-space pointer (a FLAT atomic would also count in lgkmcnt)
+__device__ __forceinline__ void atomic_add_global(float* p, float v) {
+  __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)(uintptr_t)p, v);
+}
 __device__ __forceinline__ uint32_t ld1_global(const void* p) { return *(const __attribute__((address_space(1))) uint8_t*)(uintptr_t)p; }
 __device__ __forceinline__ uint2 ld2_global(const void* p) {
   const gvec_u2 v = *(const __attribute__((address_space(1))) gvec_u2*)(uintptr_t)p;

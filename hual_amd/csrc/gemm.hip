@@ -1406,7 +1406,7 @@ __device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, c
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = kbase + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (k < kw && !(dbg & 4)) atomicAdd(dWp + (size_t)k * job.ldw + n, acc[c][r]);
+      if (k < kw && !(dbg & 4)) atomic_add_global(dWp + (size_t)k * job.ldw + n, acc[c][r]);
     }
   if (dob) {                                   // block-uniform
     bred[srow][c4] = bsum;
@@ -1416,7 +1416,7 @@ __device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, c
       float s = 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) s += reinterpret_cast<const float*>(&bred[k][cc >> 2])[cc & 3];
-      atomicAdd(job.db + cc, s);
+      atomic_add_global(job.db + cc, s);
     }
   }
 }
