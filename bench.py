@@ -261,41 +261,50 @@ def main():
                                 bytes=byts.value))
         fam.sort(key=lambda d: -d['us'])
         total_us = sum(d['us'] for d in fam)
-        top = fam[0]
-        # which roof bounds the dominant kernel: arithmetic intensity of its launches (algorithmic FLOPs / algorithmic bytes,
-        # both summed by the launch wrappers) against the ridge of the pipe it runs on.  A [M,128]x[128,128] fp32-in/out
-        # layer has 32 FLOP/B: above the fp32-matrix ridge (157.3 TF / 8 TB/s = 20 FLOP/B) but below the split-bf16 ridge
-        # (2516.8 / 3 passes / 8 TB/s = 105 FLOP/B), so with the split-bf16 kernels the dense layers are HBM-bound.
-        tflops = top['flops'] / top['us'] / 1e6 if top['flops'] > 0 else 0.0      # algorithmic TFLOP/s
-        gbs = top['bytes'] / top['us'] / 1e3                                       # algorithmic GB/s
-        peak, passes = mfma_peak(top['kernel'])
-        ai = top['flops'] / top['bytes'] if top['bytes'] > 0 else float('inf')
-        ridge = (peak / passes) * 1e3 / PEAK_HBM_GBS
-        common = dict(kernel=top['kernel'], avg_launch_us=round(top['us'] / top['launches'], 2),
-                      launches_per_step=top['launches'] // psteps, share_of_kernel_time=round(top['us'] / total_us, 3),
-                      arithmetic_intensity_flop_per_byte=round(ai, 1), ridge_flop_per_byte=round(ridge, 1))
-        if top['flops'] > 0 and ai >= ridge:
-            roof = dict(bound='mfma', achieved=round(tflops, 2), peak=peak, unit='TFLOP/s', frac=round(tflops / peak, 4),
-                        traffic=None, **common)
-        else:
-            roof = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
-                        traffic=None, **common)
-        if top['flops'] > 0:
-            roof.update(algorithmic_tflops=round(tflops, 2), mfma_pipe_peak_tflops=peak, mfma_passes=passes,
-                        mfma_issue_frac=round(passes * tflops / peak, 4),
-                        frac_of_fp32_matrix_peak=round(tflops / PEAK_F32_MATRIX_TFLOPS, 4))
-        # HBM traffic of that kernel: rocprofv3 PMC passes cannot run inside this process, so the per-launch figure is
-        # read from the committed summary of the separate FETCH_SIZE / WRITE_SIZE passes (scripts/pmc_traffic.py,
-        # gfx950 correction applied there); null when the file does not cover the kernel.
         try:
             tr_tab = json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)))
+        except (OSError, ValueError):
+            tr_tab = {}
+
+        def roof_of(top):
+            # which roof bounds a kernel: arithmetic intensity of its launches (algorithmic FLOPs / algorithmic bytes, both
+            # summed by the launch wrappers) against the ridge of the pipe it runs on.  A [M,128]x[128,128] fp32-in/out
+            # layer has 32 FLOP/B: above the fp32-matrix ridge (157.3 TF / 8 TB/s = 20 FLOP/B) but below the split-bf16 ridge
+            # (2516.8 / 3 passes / 8 TB/s = 105 FLOP/B), so with the split-bf16 kernels the dense layers are HBM-bound.
+            tflops = top['flops'] / top['us'] / 1e6 if top['flops'] > 0 else 0.0      # algorithmic TFLOP/s
+            gbs = top['bytes'] / top['us'] / 1e3                                       # algorithmic GB/s
+            peak, passes = mfma_peak(top['kernel'])
+            ai = top['flops'] / top['bytes'] if top['bytes'] > 0 else float('inf')
+            ridge = (peak / passes) * 1e3 / PEAK_HBM_GBS
+            common = dict(kernel=top['kernel'], avg_launch_us=round(top['us'] / top['launches'], 2),
+                          launches_per_step=top['launches'] // psteps, share_of_kernel_time=round(top['us'] / total_us, 3),
+                          arithmetic_intensity_flop_per_byte=round(ai, 1), ridge_flop_per_byte=round(ridge, 1))
+            if top['flops'] > 0 and ai >= ridge:
+                roof = dict(bound='mfma', achieved=round(tflops, 2), peak=peak, unit='TFLOP/s', frac=round(tflops / peak, 4),
+                            traffic=None, **common)
+            else:
+                roof = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
+                            traffic=None, **common)
+            if top['flops'] > 0:
+                roof.update(algorithmic_tflops=round(tflops, 2), mfma_pipe_peak_tflops=peak, mfma_passes=passes,
+                            mfma_issue_frac=round(passes * tflops / peak, 4),
+                            frac_of_fp32_matrix_peak=round(tflops / PEAK_F32_MATRIX_TFLOPS, 4))
+            # HBM traffic of that kernel: rocprofv3 PMC passes cannot run inside this process, so the per-launch figure is
+            # read from the committed summary of the separate FETCH_SIZE / WRITE_SIZE passes (scripts/pmc_traffic.py,
+            # gfx950 correction applied there); null when the file does not cover the kernel.
             if top['kernel'] in tr_tab:
                 roof['traffic'] = tr_tab[top['kernel']]['hbm_bytes_per_launch']
                 roof['traffic_unit'] = 'bytes/launch'
                 roof['traffic_source'] = 'profiles/' + TRAFFIC_FILE
-                roof['algorithmic_bytes_per_launch'] = round(top['bytes'] / top['launches'])
-        except (OSError, ValueError):
-            pass
+            roof['algorithmic_bytes_per_launch'] = round(top['bytes'] / top['launches'])
+            return roof
+
+        # the dominant kernel = the kernel function with the largest time per step (all its launches); when another kernel
+        # has the longest single launch, its roofline rides along as `largest_launch`
+        roof = roof_of(fam[0])
+        big = max(fam, key=lambda d: d['us'] / d['launches'])
+        if big is not fam[0]:
+            roof['largest_launch'] = roof_of(big)
         # the feature-load phase (video_conv1d + query_conv1d: streams the [B,T,vdim] clip features once, writes the four
         # K-quarter partial slabs) against HBM
         for d in fam:
@@ -305,11 +314,8 @@ def main():
                                             frac=round(gbs / PEAK_HBM_GBS, 4), avg_launch_us=round(d['us'] / d['launches'], 2),
                                             algorithmic_bytes_per_launch=round(d['bytes'] / d['launches']),
                                             tflops=round(d['flops'] / d['us'] / 1e6, 2))
-                try:
-                    if d['kernel'] in tr_tab:
-                        roof['feature_load']['traffic'] = tr_tab[d['kernel']]['hbm_bytes_per_launch']
-                except NameError:
-                    pass
+                if d['kernel'] in tr_tab:
+                    roof['feature_load']['traffic'] = tr_tab[d['kernel']]['hbm_bytes_per_launch']
         # the attention contractions (QK^T, PV and their gradients; north_star: "MFMA utilisation on the attention GEMMs"): algorithmic
         # TFLOP/s of those launches against the fp32-matrix peak (the figure of the round-1 kernels, which ran on that pipe)
         # and against the bf16 pipe the kernels now use with three passes per product (csrc/attn.hip)
@@ -334,7 +340,7 @@ def main():
                     frac_of_bf16_matrix_peak=round(gflop / ms / PEAK_BF16_MATRIX_TFLOPS, 4),
                     compulsory_hbm_bytes_per_step=int(compulsory), launches_per_step=sum(d['launches'] for d in fam) // psteps,
                     kernel_time_us_per_step=round(total_us / psteps, 1))
-        try:
+        if tr_tab:
             meas, covered = 0.0, 0
             for d in fam:
                 if d['kernel'] in tr_tab:
@@ -342,8 +348,6 @@ def main():
                     covered += 1
             step.update(measured_hbm_bytes_per_step=int(meas), measured_over_compulsory=round(meas / compulsory, 1),
                         traffic_source='profiles/' + TRAFFIC_FILE, kernels_covered='%d of %d' % (covered, len(fam)))
-        except NameError:
-            pass
         roof['step'] = step
         roof['families'] = [dict(kernel=d['kernel'], launches_per_step=d['launches'] // psteps,
                                  us_per_step=round(d['us'] / psteps, 1),

@@ -26,7 +26,7 @@ __device__ __forceinline__ f32x4 tile_mma(const float* A, int lda, int imax, con
                                           int kmaxA, int kmaxB, int i0, int n0, int j, int g, f32x4 acc) {
   const int ia = min(i0 + j, imax - 1);
   const int nb = min(n0 + j, nmax - 1);
-#pragma unroll 4
+#pragma unroll 8
   for (int k0 = 0; k0 < K; k0 += 16) {
     float a[4], b[4];
     if (AK) {
@@ -49,6 +49,16 @@ __device__ __forceinline__ f32x4 tile_mma(const float* A, int lda, int imax, con
   return acc;
 }
 
+#ifdef HUAL_STAMPS
+// debug: clock stamps of the per-clip kernels' phases (scripts/exp/cq_stamps.py); slot 0..15 forward, 16..31 backward
+__device__ unsigned long long g_cq_stamps[256 * 32];
+extern "C" int hual_debug_cq_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cq_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#define CQ_STAMP(i) do { if (threadIdx.x == 0) g_cq_stamps[(blockIdx.y * gridDim.x + blockIdx.x) % 256 * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CQ_STAMP(i) do { } while (0)
+#endif
 // per-clip kernels: one block = one (clip, direction); 16 waves share the tiles / rows of every phase
 #define CQ_MAX_THREADS 1024
 #define CQ_THREADS ((int)blockDim.x)
@@ -113,25 +123,35 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
   float* S = lds;
   float* Sr = lds + msz;
   float* Sc = lds + 2 * msz;
-  const float* m1 = rs.rowmask + c.x1base;
-  const float* m2 = rs.rowmask + c.x2base;
+  // the two row masks of the clip, staged once: the softmax passes below read them per element (from global memory every
+  // pass paid an L2 round trip)
+  float* m1 = lds + 3 * msz;
+  float* m2 = m1 + c.N1p;
+  for (int idx = threadIdx.x; idx < c.N1p + c.N2p; idx += CQ_THREADS) {
+    const bool first = idx < c.N1p;
+    const int k = first ? idx : idx - c.N1p;
+    m1[idx] = (k < (first ? c.N1 : c.N2)) ? rs.rowmask[(first ? c.x1base : c.x2base) + k] : 0.f;
+  }
   const float* X1 = b.X + (size_t)c.x1base * HUAL_D;
   const float* X2 = b.X + (size_t)c.x2base * HUAL_D;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  CQ_STAMP(0);
   // ---- score = d1w . d2^T + s0 + s1
   const int nj = c.N2p >> 4, ni = c.N1p >> 4;
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+    // (the rank-1 terms are requested before the product: one memory round trip for the whole tile)
+    const float s1 = b.S1[c.x2base + min(n0 + j, c.N2 - 1)];
+    float s0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s0[r] = b.S0[c.x1base + min(i0 + 4 * g + r, c.N1 - 1)];
     f32x4 acc = tile_mma<true, true>(b.D1W + (size_t)c.x1base * HUAL_D, HUAL_D, c.N1, b.D2 + (size_t)c.x2base * HUAL_D,
                                      HUAL_D, c.N2, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
-    const float s1 = b.S1[c.x2base + min(n0 + j, c.N2 - 1)];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = i0 + 4 * g + r;
-      S[i * c.ld + n0 + j] = acc[r] + b.S0[c.x1base + min(i, c.N1 - 1)] + s1;
-    }
+    for (int r = 0; r < 4; ++r) S[(i0 + 4 * g + r) * c.ld + n0 + j] = acc[r] + s0[r] + s1;
   }
   __syncthreads();
+  CQ_STAMP(1);
   // ---- row softmax over j with mask2 (layers.py:122-123) ; zero outside the valid block
   for (int i = wave; i < c.N1p; i += CQ_WAVES) {
     float mx = -INFINITY;
@@ -158,6 +178,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
       Sr[i * c.ld + jj] = v;
     }
   }
+  CQ_STAMP(2);
   // ---- column softmax over i with mask1 (layers.py:124-125)
   for (int jj = wave; jj < c.N2p; jj += CQ_WAVES) {
     float mx = -INFINITY;
@@ -185,11 +206,13 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
     }
   }
   __syncthreads();
+  CQ_STAMP(3);
   // ---- save both softmaxes for the backward pass
   const size_t mat = cq_mat_elems(rs.T, rs.L);
   float* gSr = b.SR + ((size_t)dir * rs.B + clip) * mat;
   float* gSc = b.SC + ((size_t)dir * rs.B + clip) * mat;
   for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { gSr[idx] = Sr[idx]; gSc[idx] = Sc[idx]; }
+  CQ_STAMP(4);
   // ---- c2q = Sr . x2   and   M2 = Sc^T . x1
   float* M2 = b.M2 + ((size_t)dir * rs.B + clip) * cq_m2_rows(rs.T, rs.L) * HUAL_D;
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
@@ -201,6 +224,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
       if (i < c.N1) b.C2Q[(size_t)(c.x1base + i) * HUAL_D + n0 + j] = acc[r];
     }
   }
+  CQ_STAMP(5);
   for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;   // rows of M2 = index j of the score
     f32x4 acc = tile_mma<false, false>(Sc, c.ld, c.N2p, X1, HUAL_D, HUAL_D, c.N1p, c.N1p, c.N1, i0, n0, j, g, zero);
@@ -208,6 +232,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
     for (int r = 0; r < 4; ++r) M2[(size_t)(i0 + 4 * g + r) * HUAL_D + n0 + j] = acc[r];
   }
   __syncthreads();
+  CQ_STAMP(6);
   // ---- q2c = Sr . M2          (= (Sr.Sc^T).x1 of layers.py:127, re-associated)
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
@@ -218,6 +243,231 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
       if (i < c.N1) b.Q2C[(size_t)(c.x1base + i) * HUAL_D + n0 + j] = acc[r];
     }
   }
+  CQ_STAMP(7);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// cq_fwd_staged_kernel: the same computation for clips whose operands fit LDS next to the three score matrices
+// (T + L <= 160 rows after padding).  In cq_fwd_kernel every matrix phase starts with round trips to the memory side
+// for its [rows,128] operands (~2 us each on a loaded chip: the rows were written by other XCDs) and the phases of a clip
+// are strictly ordered, so the kernel ran at 70 k cycles per clip for 20 k cycles of work.  Here the operands of a
+// phase are staged in LDS ([rows][CQ_LDX] floats: 16 rows x one float4 cover the 64 banks) and the next phase's operands
+// are requested while the current one computes:
+//   bufA (x1 rows): D1W, then X1          bufB (x2 rows): D2, then X2, then M2
+#define CQ_LDX 132
+#define CQ_STAGE_MAX 5          // float4 per thread of a 1024-thread workgroup: (N1p + N2p) * 32 / 1024
+struct CqRows { float4 v[CQ_STAGE_MAX]; };
+// request rows [0,n1) of A (N1p staged rows) and [0,n2) of B (N2p staged rows), zero beyond
+__device__ __forceinline__ void cq_rows_load(CqRows& r, const float* A, int n1, int N1p, const float* B, int n2, int N2p) {
+#pragma unroll
+  for (int u = 0; u < CQ_STAGE_MAX; ++u) {
+    const int idx = threadIdx.x + CQ_MAX_THREADS * u, row = idx >> 5, c4 = idx & 31;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < N1p) { if (row < n1) v = ld4(A + (size_t)row * HUAL_D + 4 * c4); }
+    else if (row - N1p < n2) v = ld4(B + (size_t)(row - N1p) * HUAL_D + 4 * c4);
+    r.v[u] = v;
+  }
+}
+__device__ __forceinline__ void cq_rows_store(const CqRows& r, float* bufA, int N1p, float* bufB, int N2p) {
+#pragma unroll
+  for (int u = 0; u < CQ_STAGE_MAX; ++u) {
+    const int idx = threadIdx.x + CQ_MAX_THREADS * u, row = idx >> 5, c4 = idx & 31;
+    if (row < N1p) *reinterpret_cast<float4*>(bufA + row * CQ_LDX + 4 * c4) = r.v[u];
+    else if (row - N1p < N2p) *reinterpret_cast<float4*>(bufB + (row - N1p) * CQ_LDX + 4 * c4) = r.v[u];
+  }
+}
+
+__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b, RowSpace rs) {
+  extern __shared__ float lds[];
+  const int clip = blockIdx.x, dir = blockIdx.y;
+  const ClipGeom c = clip_geom(rs, clip, dir);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int msz = c.N1p * c.ld;
+  float* S = lds;
+  float* Sr = lds + msz;
+  float* Sc = lds + 2 * msz;
+  float* m1 = lds + 3 * msz;            // row masks and rank-1 terms of the clip: m1, s0 [N1p]; m2, s1 [N2p]
+  float* m2 = m1 + c.N1p;
+  float* s0 = m2 + c.N2p;
+  float* s1 = s0 + c.N1p;
+  float* bufA = s1 + c.N2p;             // [N1p][CQ_LDX]
+  float* bufB = bufA + c.N1p * CQ_LDX;  // [N2p][CQ_LDX]
+  const float* X1 = b.X + (size_t)c.x1base * HUAL_D;
+  const float* X2 = b.X + (size_t)c.x2base * HUAL_D;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int nj = c.N2p >> 4, ni = c.N1p >> 4;
+  CQ_STAMP(0);
+  // ---- stage D1W / D2, masks and rank-1 terms: one round trip
+  CqRows rows, xrows;
+  cq_rows_load(rows, b.D1W + (size_t)c.x1base * HUAL_D, c.N1, c.N1p, b.D2 + (size_t)c.x2base * HUAL_D, c.N2, c.N2p);
+  cq_rows_load(xrows, X1, c.N1, c.N1p, X2, c.N2, c.N2p);      // needed after the score: arrives under it
+  {
+    const int idx = threadIdx.x;
+    if (idx < c.N1p + c.N2p) {
+      const bool first = idx < c.N1p;
+      const int k = first ? idx : idx - c.N1p, n = first ? c.N1 : c.N2, base = first ? c.x1base : c.x2base;
+      const float mk = k < n ? rs.rowmask[base + k] : 0.f;
+      const float sv = k < n ? (first ? b.S0[base + k] : b.S1[base + k]) : 0.f;
+      m1[idx] = mk;                      // (m2 follows m1, s1 follows s0)
+      s0[idx] = sv;
+    }
+  }
+  cq_rows_store(rows, bufA, c.N1p, bufB, c.N2p);
+  __syncthreads();
+  CQ_STAMP(1);
+  // ---- score = d1w . d2^T + s0 + s1
+  for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
+    const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+    f32x4 acc = tile_mma<true, true>(bufA, CQ_LDX, c.N1p, bufB, CQ_LDX, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(i0 + 4 * g + r) * c.ld + n0 + j] = acc[r] + s0[i0 + 4 * g + r] + s1[n0 + j];
+  }
+  __syncthreads();
+  CQ_STAMP(2);
+  cq_rows_store(xrows, bufA, c.N1p, bufB, c.N2p);      // X1, X2
+  // ---- row softmax over j with mask2 (layers.py:122-123) ; zero outside the valid block.  Rows of at most 32 columns go
+  // two per wave (a 32-lane half each; the half-wave reductions add the same pairs in the same order as wave_*64 with
+  // the upper half idle, so the values are those of cq_fwd_kernel)
+  if (c.N2p <= 32) {
+    const int hh = lane >> 5, l32 = lane & 31;
+    for (int i = 2 * wave + hh; i < c.N1p; i += 2 * CQ_WAVES) {
+      const bool ok = i < c.N1 && l32 < c.N2;
+      float lg = -INFINITY;
+      if (ok) {
+        const float mk = m2[l32];
+        lg = S[i * c.ld + l32] * mk + HUAL_MASK_VALUE * (1.0f - mk);
+      }
+      const float mx = half_max32(lg);
+      const float e = ok ? __expf(lg - mx) : 0.f;
+      const float inv = 1.0f / half_sum32(e);
+      if (l32 < c.N2p) Sr[i * c.ld + l32] = ok ? e * inv : 0.f;
+    }
+  } else {
+    for (int i = wave; i < c.N1p; i += CQ_WAVES) {
+      float mx = -INFINITY;
+      if (i < c.N1)
+        for (int jj = lane; jj < c.N2; jj += 64) {
+          const float mk = m2[jj];
+          mx = fmaxf(mx, S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk));
+        }
+      mx = wave_max64(mx);
+      float sum = 0.f;
+      if (i < c.N1)
+        for (int jj = lane; jj < c.N2; jj += 64) {
+          const float mk = m2[jj];
+          sum += __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx);
+        }
+      sum = wave_sum64(sum);
+      const float inv = 1.0f / sum;
+      for (int jj = lane; jj < c.N2p; jj += 64) {
+        float v = 0.f;
+        if (i < c.N1 && jj < c.N2) {
+          const float mk = m2[jj];
+          v = __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx) * inv;
+        }
+        Sr[i * c.ld + jj] = v;
+      }
+    }
+  }
+  // ---- column softmax over i with mask1 (layers.py:124-125); columns of at most 32 rows go two per wave
+  if (c.N1p <= 32) {
+    const int hh = lane >> 5, l32 = lane & 31;
+    for (int jj = 2 * wave + hh; jj < c.N2p; jj += 2 * CQ_WAVES) {
+      const bool ok = jj < c.N2 && l32 < c.N1;
+      float lg = -INFINITY;
+      if (ok) {
+        const float mk = m1[l32];
+        lg = S[l32 * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk);
+      }
+      const float mx = half_max32(lg);
+      const float e = ok ? __expf(lg - mx) : 0.f;
+      const float inv = 1.0f / half_sum32(e);
+      if (l32 < c.N1p) Sc[l32 * c.ld + jj] = ok ? e * inv : 0.f;
+    }
+  } else {
+    for (int jj = wave; jj < c.N2p; jj += CQ_WAVES) {
+      float mx = -INFINITY;
+      if (jj < c.N2)
+        for (int i = lane; i < c.N1; i += 64) {
+          const float mk = m1[i];
+          mx = fmaxf(mx, S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk));
+        }
+      mx = wave_max64(mx);
+      float sum = 0.f;
+      if (jj < c.N2)
+        for (int i = lane; i < c.N1; i += 64) {
+          const float mk = m1[i];
+          sum += __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx);
+        }
+      sum = wave_sum64(sum);
+      const float inv = 1.0f / sum;
+      for (int i = lane; i < c.N1p; i += 64) {
+        float v = 0.f;
+        if (i < c.N1 && jj < c.N2) {
+          const float mk = m1[i];
+          v = __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx) * inv;
+        }
+        Sc[i * c.ld + jj] = v;
+      }
+    }
+  }
+  __syncthreads();
+  CQ_STAMP(3);
+  // ---- save both softmaxes for the backward pass
+  const size_t mat = cq_mat_elems(rs.T, rs.L);
+  float* gSr = b.SR + ((size_t)dir * rs.B + clip) * mat;
+  float* gSc = b.SC + ((size_t)dir * rs.B + clip) * mat;
+  for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { gSr[idx] = Sr[idx]; gSc[idx] = Sc[idx]; }
+  CQ_STAMP(4);
+  // ---- c2q = Sr . x2   and   M2 = Sc^T . x1 (kept in registers until every wave is done with X2)
+  float* M2 = b.M2 + ((size_t)dir * rs.B + clip) * cq_m2_rows(rs.T, rs.L) * HUAL_D;
+  for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
+    const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
+    f32x4 acc = tile_mma<true, false>(Sr, c.ld, c.N1p, bufB, CQ_LDX, HUAL_D, c.N2p, c.N2p, c.N2p, i0, n0, j, g, zero);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * g + r;
+      if (i < c.N1) b.C2Q[(size_t)(c.x1base + i) * HUAL_D + n0 + j] = acc[r];
+    }
+  }
+  CQ_STAMP(5);
+  f32x4 m2acc[4];                        // nj * 8 <= 64 tiles over 16 waves
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int tile = wave + CQ_WAVES * q;
+    m2acc[q] = zero;
+    if (tile < nj * 8) {
+      const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;   // rows of M2 = index j of the score
+      m2acc[q] = tile_mma<false, false>(Sc, c.ld, c.N2p, bufA, CQ_LDX, HUAL_D, c.N1p, c.N1p, c.N1p, i0, n0, j, g, zero);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int tile = wave + CQ_WAVES * q;
+    if (tile < nj * 8) {
+      const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        M2[(size_t)(i0 + 4 * g + r) * HUAL_D + n0 + j] = m2acc[q][r];
+        bufB[(i0 + 4 * g + r) * CQ_LDX + n0 + j] = m2acc[q][r];
+      }
+    }
+  }
+  __syncthreads();
+  CQ_STAMP(6);
+  // ---- q2c = Sr . M2          (= (Sr.Sc^T).x1 of layers.py:127, re-associated)
+  for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
+    const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
+    f32x4 acc = tile_mma<true, false>(Sr, c.ld, c.N1p, bufB, CQ_LDX, HUAL_D, c.N2p, c.N2p, c.N2p, i0, n0, j, g, zero);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * g + r;
+      if (i < c.N1) b.Q2C[(size_t)(c.x1base + i) * HUAL_D + n0 + j] = acc[r];
+    }
+  }
+  CQ_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -252,8 +502,13 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
   float* Sc = lds + msz;
   float* dSr = lds + 2 * msz;    // becomes dscore
   float* dSc = lds + 3 * msz;
-  const float* m1 = rs.rowmask + c.x1base;
-  const float* m2 = rs.rowmask + c.x2base;
+  float* m1 = lds + 4 * msz;     // the two row masks of the clip (see cq_fwd_kernel)
+  float* m2 = m1 + c.N1p;
+  for (int idx = threadIdx.x; idx < c.N1p + c.N2p; idx += CQ_THREADS) {
+    const bool first = idx < c.N1p;
+    const int k = first ? idx : idx - c.N1p;
+    m1[idx] = (k < (first ? c.N1 : c.N2)) ? rs.rowmask[(first ? c.x1base : c.x2base) + k] : 0.f;
+  }
   const float* X1 = b.X + (size_t)c.x1base * HUAL_D;
   const float* X2 = b.X + (size_t)c.x2base * HUAL_D;
   const float* dC2Q = gb.dC2Q + (size_t)c.x1base * HUAL_D;
@@ -266,8 +521,10 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
   float* dM2 = gb.dM2 + m2off;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const int nj = c.N2p >> 4, ni = c.N1p >> 4;
+  CQ_STAMP(16);
   for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { Sr[idx] = gSr[idx]; Sc[idx] = gSc[idx]; dSr[idx] = 0.f; dSc[idx] = 0.f; }
   __syncthreads();
+  CQ_STAMP(17);
   // dSr = dc2q . x2^T + dq2c . M2^T
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
@@ -276,6 +533,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
 #pragma unroll
     for (int r = 0; r < 4; ++r) dSr[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
   }
+  CQ_STAMP(18);
   // dM2 = Sr^T . dq2c ;  dXb (x2 rows) = Sr^T . dc2q
   for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
@@ -289,6 +547,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
     }
   }
   __syncthreads();
+  CQ_STAMP(19);
   // dSc = x1 . dM2^T ;  dXa (x1 rows) = Sc . dM2
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
@@ -306,6 +565,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
     }
   }
   __syncthreads();
+  CQ_STAMP(20);
   // softmax backward -> dscore (in dSr).  mask_logits is multiplicative, so its derivative is the mask.
   for (int i = wave; i < c.N1; i += CQ_WAVES) {
     float dot = 0.f;
@@ -329,12 +589,14 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
     if (lane == 0) gb.dS1[c.x2base + jj] = colsum;
   }
   __syncthreads();
+  CQ_STAMP(21);
   for (int i = wave; i < c.N1; i += CQ_WAVES) {
     float rowsum = 0.f;
     for (int jj = lane; jj < c.N2; jj += 64) rowsum += dSr[i * c.ld + jj];
     rowsum = wave_sum64(rowsum);
     if (lane == 0) gb.dS0[c.x1base + i] = rowsum;
   }
+  CQ_STAMP(22);
   // dD1W = dscore . d2 ;  dD2 = dscore^T . d1w
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
@@ -356,6 +618,181 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
       if (jj < c.N2) gb.dD2[(size_t)(c.x2base + jj) * HUAL_D + n0 + j] = acc[r];
     }
   }
+  CQ_STAMP(23);
+}
+
+// cq_bwd_staged_kernel: cq_bwd_kernel with the [rows,128] operands of every product staged in LDS and requested one
+// phase ahead (see cq_fwd_staged_kernel).   bufA (x1 rows): dC2Q, dQ2C, X1, D1W      bufB (x2 rows): X2, M2, dM2, D2
+__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb) {
+  extern __shared__ float lds[];
+  const int clip = blockIdx.x, dir = blockIdx.y;
+  const ClipGeom c = clip_geom(rs, clip, dir);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int msz = c.N1p * c.ld;
+  float* Sr = lds;
+  float* Sc = lds + msz;
+  float* dSr = lds + 2 * msz;    // becomes dscore
+  float* dSc = lds + 3 * msz;
+  float* m1 = lds + 4 * msz;
+  float* m2 = m1 + c.N1p;
+  float* bufA = m2 + c.N2p;             // [N1p][CQ_LDX]
+  float* bufB = bufA + c.N1p * CQ_LDX;  // [N2p][CQ_LDX]
+  const size_t x1off = (size_t)c.x1base * HUAL_D, x2off = (size_t)c.x2base * HUAL_D;
+  const size_t mat = cq_mat_elems(rs.T, rs.L);
+  const float* gSr = b.SR + ((size_t)dir * rs.B + clip) * mat;
+  const float* gSc = b.SC + ((size_t)dir * rs.B + clip) * mat;
+  const size_t m2off = ((size_t)dir * rs.B + clip) * cq_m2_rows(rs.T, rs.L) * HUAL_D;
+  float* dM2 = gb.dM2 + m2off;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int nj = c.N2p >> 4, ni = c.N1p >> 4;
+  CQ_STAMP(16);
+  // ---- requests of the first two operand pairs, the saved softmaxes and the masks: one round trip
+  CqRows r1, r2;
+  cq_rows_load(r1, gb.dC2Q + x1off, c.N1, c.N1p, b.X + x2off, c.N2, c.N2p);
+  cq_rows_load(r2, gb.dQ2C + x1off, c.N1, c.N1p, b.M2 + m2off, c.N2p, c.N2p);
+  if ((int)threadIdx.x < c.N1p + c.N2p) {
+    const int idx = threadIdx.x;
+    const bool first = idx < c.N1p;
+    const int k = first ? idx : idx - c.N1p;
+    m1[idx] = (k < (first ? c.N1 : c.N2)) ? rs.rowmask[(first ? c.x1base : c.x2base) + k] : 0.f;     // (m2 follows m1)
+  }
+  for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { Sr[idx] = gSr[idx]; Sc[idx] = gSc[idx]; dSr[idx] = 0.f; dSc[idx] = 0.f; }
+  cq_rows_store(r1, bufA, c.N1p, bufB, c.N2p);          // dC2Q, X2
+  __syncthreads();
+  CQ_STAMP(17);
+  // ---- first half of dSr = dc2q . x2^T (+ dq2c . M2^T below) ;  dXb (x2 rows) = Sr^T . dc2q
+  cq_rows_load(r1, b.X + x1off, c.N1, c.N1p, nullptr, 0, c.N2p);      // X1, for the dSc product
+  f32x4 sacc[2] = {zero, zero};                          // ni * nj <= 25 tiles over 16 waves
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int tile = wave + CQ_WAVES * q;
+    if (tile < ni * nj) {
+      const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+      sacc[q] = tile_mma<true, true>(bufA, CQ_LDX, c.N1p, bufB, CQ_LDX, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
+    }
+  }
+  for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
+    const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
+    f32x4 acc2 = tile_mma<false, false>(Sr, c.ld, c.N2p, bufA, CQ_LDX, HUAL_D, c.N1p, c.N1p, c.N1p, i0, n0, j, g, zero);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = i0 + 4 * g + r;
+      if (jj < c.N2) dXb[(size_t)(c.x2base + jj) * HUAL_D + n0 + j] = acc2[r];
+    }
+  }
+  __syncthreads();
+  CQ_STAMP(18);
+  cq_rows_store(r2, bufA, c.N1p, bufB, c.N2p);          // dQ2C, M2
+  __syncthreads();
+  cq_rows_load(r2, b.D1W + x1off, c.N1, c.N1p, b.D2 + x2off, c.N2, c.N2p);     // for the last two products
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int tile = wave + CQ_WAVES * q;
+    if (tile < ni * nj) {
+      const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+      const f32x4 acc = tile_mma<true, true>(bufA, CQ_LDX, c.N1p, bufB, CQ_LDX, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, sacc[q]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dSr[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
+    }
+  }
+  // dM2 = Sr^T . dq2c (kept in registers until every wave is done with M2)
+  f32x4 macc[4];                                          // nj * 8 <= 64 tiles over 16 waves
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int tile = wave + CQ_WAVES * q;
+    macc[q] = zero;
+    if (tile < nj * 8) {
+      const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
+      macc[q] = tile_mma<false, false>(Sr, c.ld, c.N2p, bufA, CQ_LDX, HUAL_D, c.N1p, c.N1p, c.N1p, i0, n0, j, g, zero);
+    }
+  }
+  __syncthreads();
+  CQ_STAMP(19);
+  cq_rows_store(r1, bufA, c.N1p, bufB, 0);               // X1 (bufB receives dM2 below)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int tile = wave + CQ_WAVES * q;
+    if (tile < nj * 8) {
+      const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dM2[(size_t)(i0 + 4 * g + r) * HUAL_D + n0 + j] = macc[q][r];
+        bufB[(i0 + 4 * g + r) * CQ_LDX + n0 + j] = macc[q][r];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- dSc = x1 . dM2^T ;  dXa (x1 rows) = Sc . dM2
+  for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
+    const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+    f32x4 acc = tile_mma<true, true>(bufA, CQ_LDX, c.N1p, bufB, CQ_LDX, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dSc[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
+  }
+  for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
+    const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
+    f32x4 acc = tile_mma<true, false>(Sc, c.ld, c.N1p, bufB, CQ_LDX, HUAL_D, c.N2p, c.N2p, c.N2p, i0, n0, j, g, zero);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * g + r;
+      if (i < c.N1) dXa[(size_t)(c.x1base + i) * HUAL_D + n0 + j] = acc[r];
+    }
+  }
+  __syncthreads();
+  CQ_STAMP(20);
+  cq_rows_store(r2, bufA, c.N1p, bufB, c.N2p);          // D1W, D2
+  // ---- softmax backward -> dscore (in dSr).  mask_logits is multiplicative, so its derivative is the mask.
+  for (int i = wave; i < c.N1; i += CQ_WAVES) {
+    float dot = 0.f;
+    for (int jj = lane; jj < c.N2; jj += 64) dot += Sr[i * c.ld + jj] * dSr[i * c.ld + jj];
+    dot = wave_sum64(dot);
+    for (int jj = lane; jj < c.N2; jj += 64)
+      dSr[i * c.ld + jj] = Sr[i * c.ld + jj] * (dSr[i * c.ld + jj] - dot) * m2[jj];
+  }
+  __syncthreads();
+  for (int jj = wave; jj < c.N2; jj += CQ_WAVES) {
+    float dot = 0.f;
+    for (int i = lane; i < c.N1; i += 64) dot += Sc[i * c.ld + jj] * dSc[i * c.ld + jj];
+    dot = wave_sum64(dot);
+    float colsum = 0.f;
+    for (int i = lane; i < c.N1; i += 64) {
+      const float v = dSr[i * c.ld + jj] + Sc[i * c.ld + jj] * (dSc[i * c.ld + jj] - dot) * m1[i];
+      dSr[i * c.ld + jj] = v;
+      colsum += v;
+    }
+    colsum = wave_sum64(colsum);
+    if (lane == 0) gb.dS1[c.x2base + jj] = colsum;
+  }
+  __syncthreads();
+  CQ_STAMP(21);
+  for (int i = wave; i < c.N1; i += CQ_WAVES) {
+    float rowsum = 0.f;
+    for (int jj = lane; jj < c.N2; jj += 64) rowsum += dSr[i * c.ld + jj];
+    rowsum = wave_sum64(rowsum);
+    if (lane == 0) gb.dS0[c.x1base + i] = rowsum;
+  }
+  CQ_STAMP(22);
+  // ---- dD1W = dscore . d2 ;  dD2 = dscore^T . d1w
+  for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
+    const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
+    f32x4 acc = tile_mma<true, false>(dSr, c.ld, c.N1p, bufB, CQ_LDX, HUAL_D, c.N2p, c.N2p, c.N2p, i0, n0, j, g, zero);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * g + r;
+      if (i < c.N1) gb.dD1W[(size_t)(c.x1base + i) * HUAL_D + n0 + j] = acc[r];
+    }
+  }
+  for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
+    const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
+    f32x4 acc = tile_mma<false, false>(dSr, c.ld, c.N2p, bufA, CQ_LDX, HUAL_D, c.N1p, c.N1p, c.N1p, i0, n0, j, g, zero);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = i0 + 4 * g + r;
+      if (jj < c.N2) gb.dD2[(size_t)(c.x2base + jj) * HUAL_D + n0 + j] = acc[r];
+    }
+  }
+  CQ_STAMP(23);
 }
 
 // backward, step 3 (row kernel): through the two dropouts and the rank-1 terms; parameter gradients.
@@ -415,7 +852,9 @@ static int cq_threads() {
   static const int t = []() { const char* e = getenv("HUAL_CQ_THREADS"); int v = e ? atoi(e) : 1024; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
   return t;
 }
-static int cq_lds_bytes(const RowSpace& rs, int nmats) { return (int)(cq_mat_elems(rs.T, rs.L) * nmats * sizeof(float)); }
+static int cq_lds_bytes(const RowSpace& rs, int nmats) {      // the matrices + the two staged row masks
+  return (int)((cq_mat_elems(rs.T, rs.L) * nmats + cq_padded(rs.T) + cq_padded(rs.L)) * sizeof(float));
+}
 
 int launch_tri_prep(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   int g = cdiv(rs.R, 8);
@@ -425,7 +864,23 @@ int launch_tri_prep(const CqBufs& b, const CqParams& p, const RowSpace& rs, cons
   return 0;
 }
 
+// LDS of the staged kernels: `nmats` score matrices, 2 x (masks or rank-1 terms) and the two operand buffers
+static int cq_staged_bytes(const RowSpace& rs, int nmats) {
+  const int Tp = cq_padded(rs.T), Lp = cq_padded(rs.L);
+  return (int)((cq_mat_elems(rs.T, rs.L) * nmats + 2 * (Tp + Lp) + (size_t)(Tp + Lp) * CQ_LDX) * sizeof(float));
+}
+static bool cq_staged_ok(const RowSpace& rs, int nmats) {
+  static const int on = []() { const char* e = getenv("HUAL_CQ_STAGED"); return e ? atoi(e) : 1; }();
+  return on && (cq_padded(rs.T) + cq_padded(rs.L)) * 32 <= CQ_STAGE_MAX * CQ_MAX_THREADS && cq_staged_bytes(rs, nmats) <= 160 * 1024;
+}
+
 int launch_cq_fwd(const CqBufs& b, const RowSpace& rs, hipStream_t s) {
+  if (cq_staged_ok(rs, 3)) {
+    HUAL_DYN_LDS(cq_fwd_staged_kernel, 160 * 1024);
+    HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_staged_kernel, dim3(rs.B, 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 3), s, b, rs);
+    HUAL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const int bytes = cq_lds_bytes(rs, 3);
   HUAL_REQUIRE(bytes <= 160 * 1024, "cq_fwd: T x L score matrix does not fit LDS");
   HUAL_DYN_LDS(cq_fwd_kernel, 160 * 1024);
@@ -444,6 +899,12 @@ int launch_cq_bwd_pre(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, h
 
 // dXa/dXb scratch = g.dC2Q / g.dQ2C can NOT be reused (read by the kernel); callers pass dedicated buffers
 int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, float* dXa, float* dXb, hipStream_t s) {
+  if (cq_staged_ok(rs, 4)) {
+    HUAL_DYN_LDS(cq_bwd_staged_kernel, 160 * 1024);
+    HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_staged_kernel, dim3(rs.B, 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 4), s, b, g, rs, dXa, dXb);
+    HUAL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const int bytes = cq_lds_bytes(rs, 4);
   HUAL_REQUIRE(bytes <= 160 * 1024, "cq_bwd: T x L score matrix does not fit LDS");
   HUAL_DYN_LDS(cq_bwd_kernel, 160 * 1024);
