@@ -743,34 +743,67 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b,
   CQ_STAMP(20);
   cq_rows_store(r2, bufA, c.N1p, bufB, c.N2p);          // D1W, D2
   // ---- softmax backward -> dscore (in dSr).  mask_logits is multiplicative, so its derivative is the mask.
-  for (int i = wave; i < c.N1; i += CQ_WAVES) {
-    float dot = 0.f;
-    for (int jj = lane; jj < c.N2; jj += 64) dot += Sr[i * c.ld + jj] * dSr[i * c.ld + jj];
-    dot = wave_sum64(dot);
-    for (int jj = lane; jj < c.N2; jj += 64)
-      dSr[i * c.ld + jj] = Sr[i * c.ld + jj] * (dSr[i * c.ld + jj] - dot) * m2[jj];
+  // (rows / columns of at most 32 elements go two per wave, as in the forward kernel: same sums, same order)
+  const int hh = lane >> 5, l32 = lane & 31;
+  if (c.N2p <= 32) {
+    for (int i = 2 * wave + hh; i < c.N1p; i += 2 * CQ_WAVES) {
+      const bool ok = i < c.N1 && l32 < c.N2;
+      const float sr = ok ? Sr[i * c.ld + l32] : 0.f, ds = ok ? dSr[i * c.ld + l32] : 0.f;
+      const float dot = half_sum32(sr * ds);
+      if (ok) dSr[i * c.ld + l32] = sr * (ds - dot) * m2[l32];
+    }
+  } else {
+    for (int i = wave; i < c.N1; i += CQ_WAVES) {
+      float dot = 0.f;
+      for (int jj = lane; jj < c.N2; jj += 64) dot += Sr[i * c.ld + jj] * dSr[i * c.ld + jj];
+      dot = wave_sum64(dot);
+      for (int jj = lane; jj < c.N2; jj += 64)
+        dSr[i * c.ld + jj] = Sr[i * c.ld + jj] * (dSr[i * c.ld + jj] - dot) * m2[jj];
+    }
   }
   __syncthreads();
-  for (int jj = wave; jj < c.N2; jj += CQ_WAVES) {
-    float dot = 0.f;
-    for (int i = lane; i < c.N1; i += 64) dot += Sc[i * c.ld + jj] * dSc[i * c.ld + jj];
-    dot = wave_sum64(dot);
-    float colsum = 0.f;
-    for (int i = lane; i < c.N1; i += 64) {
-      const float v = dSr[i * c.ld + jj] + Sc[i * c.ld + jj] * (dSc[i * c.ld + jj] - dot) * m1[i];
-      dSr[i * c.ld + jj] = v;
-      colsum += v;
+  if (c.N1p <= 32) {
+    for (int jj = 2 * wave + hh; jj < c.N2p; jj += 2 * CQ_WAVES) {
+      const bool ok = jj < c.N2 && l32 < c.N1;
+      const float sc = ok ? Sc[l32 * c.ld + jj] : 0.f, ds = ok ? dSc[l32 * c.ld + jj] : 0.f;
+      const float dot = half_sum32(sc * ds);
+      float v = 0.f;
+      if (ok) {
+        v = dSr[l32 * c.ld + jj] + sc * (ds - dot) * m1[l32];
+        dSr[l32 * c.ld + jj] = v;
+      }
+      const float colsum = half_sum32(v);
+      if (l32 == 0 && jj < c.N2) gb.dS1[c.x2base + jj] = colsum;
     }
-    colsum = wave_sum64(colsum);
-    if (lane == 0) gb.dS1[c.x2base + jj] = colsum;
+  } else {
+    for (int jj = wave; jj < c.N2; jj += CQ_WAVES) {
+      float dot = 0.f;
+      for (int i = lane; i < c.N1; i += 64) dot += Sc[i * c.ld + jj] * dSc[i * c.ld + jj];
+      dot = wave_sum64(dot);
+      float colsum = 0.f;
+      for (int i = lane; i < c.N1; i += 64) {
+        const float v = dSr[i * c.ld + jj] + Sc[i * c.ld + jj] * (dSc[i * c.ld + jj] - dot) * m1[i];
+        dSr[i * c.ld + jj] = v;
+        colsum += v;
+      }
+      colsum = wave_sum64(colsum);
+      if (lane == 0) gb.dS1[c.x2base + jj] = colsum;
+    }
   }
   __syncthreads();
   CQ_STAMP(21);
-  for (int i = wave; i < c.N1; i += CQ_WAVES) {
-    float rowsum = 0.f;
-    for (int jj = lane; jj < c.N2; jj += 64) rowsum += dSr[i * c.ld + jj];
-    rowsum = wave_sum64(rowsum);
-    if (lane == 0) gb.dS0[c.x1base + i] = rowsum;
+  if (c.N2p <= 32) {
+    for (int i = 2 * wave + hh; i < c.N1p; i += 2 * CQ_WAVES) {
+      const float rowsum = half_sum32((i < c.N1 && l32 < c.N2) ? dSr[i * c.ld + l32] : 0.f);
+      if (l32 == 0 && i < c.N1) gb.dS0[c.x1base + i] = rowsum;
+    }
+  } else {
+    for (int i = wave; i < c.N1; i += CQ_WAVES) {
+      float rowsum = 0.f;
+      for (int jj = lane; jj < c.N2; jj += 64) rowsum += dSr[i * c.ld + jj];
+      rowsum = wave_sum64(rowsum);
+      if (lane == 0) gb.dS0[c.x1base + i] = rowsum;
+    }
   }
   CQ_STAMP(22);
   // ---- dD1W = dscore . d2 ;  dD2 = dscore^T . d1w
