@@ -43,7 +43,11 @@ struct CqBwdBufs {
 int launch_cq_bwd_pre(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, hipStream_t s);
 // dXa / dXb: dedicated [R,128] scratch (partial dX of the x1-role rows / x2-role rows of each direction)
 int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, float* dXa, float* dXb, hipStream_t s);
-int launch_tri_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const CqParams& p, const CqGrads& pg, const RowSpace& rs,
+// part: [tri_bwd_blocks_v + tri_bwd_blocks_q][3][128] per-workgroup sums of (d wm, d w0, d w1): the video-side workgroups first
+// (-> wm[0], w0[0], w1[1]), then the query side (-> wm[1], w0[1], w1[0]); the caller folds them (colsum_kernel)
+int tri_bwd_blocks_v(const RowSpace& rs);
+int tri_bwd_blocks_q(const RowSpace& rs);
+int launch_tri_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const CqParams& p, float* part, const RowSpace& rs,
                         const DropCfg& drop, const float* dXa, const float* dXb, hipStream_t s);
 size_t cq_mat_elems_host(int T, int L);   // floats per saved softmax matrix (per clip, per direction)
 size_t cq_m2_rows_host(int T, int L);     // rows of the per-clip M2 scratch

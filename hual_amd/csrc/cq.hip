@@ -829,9 +829,10 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b,
 }
 
 // backward, step 3 (row kernel): through the two dropouts and the rank-1 terms; parameter gradients.
-// Rows [row_lo,row_hi) must all be video rows or all query rows (the small weights differ per side).
-// The first `nvb` workgroups stride over the video rows, the others over the query rows (the small weights differ per side).
-__global__ __launch_bounds__(256) void tri_bwd_kernel(CqBufs b, CqBwdBufs gb, CqParams p, CqGrads pg, RowSpace rs,
+// The first `nvb` workgroups take the video rows, the others the query rows (the small weights differ per side), 8 rows
+// each: one memory round trip per workgroup (a grid-stride loop paid one per iteration, ~2 us each).  The parameter sums
+// leave as per-workgroup partials.
+__global__ __launch_bounds__(256) void tri_bwd_kernel(CqBufs b, CqBwdBufs gb, CqParams p, float* part, RowSpace rs,
                                                       DropCfg drop, const float* dXa, const float* dXb, int nvb) {
   __shared__ float4 red[3][8][32];
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -874,8 +875,7 @@ __global__ __launch_bounds__(256) void tri_bwd_kernel(CqBufs b, CqBwdBufs gb, Cq
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += reinterpret_cast<const float*>(&red[vec][k][cc >> 2])[cc & 3];
-    float* dst = vec == 0 ? pg.wm[d1] : (vec == 1 ? pg.w0[d1] : pg.w1[d2]);
-    atomicAdd(dst + cc, s);
+    part[((size_t)blockIdx.x * 3 + vec) * HUAL_D + cc] = s;      // [block][wm, w0, w1][128], folded by colsum_kernel
   }
 }
 
@@ -946,15 +946,13 @@ int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, 
   return 0;
 }
 
-int launch_tri_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const CqParams& p, const CqGrads& pg, const RowSpace& rs,
+int tri_bwd_blocks_v(const RowSpace& rs) { return cdiv(rs.Nv, 8); }
+int tri_bwd_blocks_q(const RowSpace& rs) { return cdiv(rs.Nq, 8); }
+int launch_tri_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const CqParams& p, float* part, const RowSpace& rs,
                         const DropCfg& drop, const float* dXa, const float* dXb, hipStream_t s) {
-  // every block ends in 384 float atomics on the same 384 addresses (~30 ns each when queued on one address): cap the
-  // grid and let the blocks stride over the rows
-  int nv = cdiv(rs.Nv, 8);
-  nv = nv < 128 ? nv : 128;
-  int nq = cdiv(rs.Nq, 8);
-  nq = nq < 64 ? nq : 64;
-  HUAL_LAUNCH(0.0, 0.0, tri_bwd_kernel, dim3(nv + nq), dim3(256), 0, s, b, g, p, pg, rs, drop, dXa, dXb, nv);
+  HUAL_REQUIRE(part != nullptr, "tri_bwd: null partial-sum buffer");
+  const int nv = tri_bwd_blocks_v(rs), nq = tri_bwd_blocks_q(rs);
+  HUAL_LAUNCH(0.0, 0.0, tri_bwd_kernel, dim3(nv + nq), dim3(256), 0, s, b, g, p, part, rs, drop, dXa, dXb, nv);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -1261,10 +1261,18 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     cqp.w0[i] = c.p(pm.cq[i].w0); cqp.w1[i] = c.p(pm.cq[i].w1); cqp.wm[i] = c.p(pm.cq[i].wm);
     cqg.w0[i] = c.g(pm.cq[i].w0); cqg.w1[i] = c.g(pm.cq[i].w1); cqg.wm[i] = c.g(pm.cq[i].wm);
   }
+  const int tri_nv = tri_bwd_blocks_v(c.rs), tri_nq = tri_bwd_blocks_q(c.rs);
+  float* tri_part = c.buf("part." + std::to_string(c.part_seq++), (size_t)(tri_nv + tri_nq) * 3, D);
+  for (int side = 0; side < 2; ++side) {      // video-side workgroups: direction 0 plays x1, direction 1 x2; query side: the reverse
+    ColsumJob cj{};
+    cj.src = tri_part + (side == 0 ? 0 : (size_t)tri_nv * 3 * D); cj.nblk = side == 0 ? tri_nv : tri_nq; cj.nvec = 3;
+    cj.dst[0] = cqg.wm[side]; cj.dst[1] = cqg.w0[side]; cj.dst[2] = cqg.w1[1 - side];
+    if (c.active) c.colsum.push_back(cj);
+  }
   if (c.live()) {
     c.chk(launch_cq_bwd_pre(cq, cg, c.rs, c.stream));
     if (c.ok()) c.chk(launch_cq_bwd_impl(cq, cg, c.rs, dXa, dXb, c.stream));
-    if (c.ok()) c.chk(launch_tri_bwd_impl(cq, cg, cqp, cqg, c.rs, c.drop, dXa, dXb, c.stream));
+    if (c.ok()) c.chk(launch_tri_bwd_impl(cq, cg, cqp, tri_part, c.rs, c.drop, dXa, dXb, c.stream));
   }
   flush_dw(c);
   float* dx = cg.dX;
