@@ -325,6 +325,46 @@ def main():
                                   mfma_issue_frac_of_bf16_pipe=round(3 * d['flops'] / d['us'] / 1e6 / PEAK_BF16_MATRIX_TFLOPS, 4),
                                   us_per_step=round(d['us'] / psteps, 1))
                              for d in fam if d['kernel'].startswith('attn_') and d['flops'] > 0]
+        # the same attention forward at head size 64 (8 heads, dim 512; csrc/attn_wide.hip): NOT part of the SeqPAN step (its
+        # configs fix 8 heads of 16) - the matrix-core utilisation the attention products reach when the head is wide enough
+        # for them to carry the kernel (north_star: "MFMA utilisation on the attention GEMMs"), timed by graph replay
+        try:
+            Bh, Th, Hh = args.batch, args.T, 8
+            gq = torch.Generator().manual_seed(7)
+            Qh = torch.randn(Bh * Th, 64 * Hh, generator=gq).to(dev)
+            Kh = torch.randn(Bh * Th, 64 * Hh, generator=gq).to(dev)
+            Vh = torch.randn(Bh * Th, 64 * Hh, generator=gq).to(dev)
+            mh = (torch.arange(Th)[None, :] < torch.randint(Th // 2 + 1, Th + 1, (Bh, 1), generator=gq)).float().reshape(-1).to(dev)
+            Oh = torch.empty(Bh * Th, 64 * Hh, device=dev)
+            rs_h = torch.tensor(np.array([1, 2, 3], dtype=np.uint32).view(np.int32)).to(dev)
+
+            def wide():
+                lib.check(l.hual_attention_fwd_wide(lib.ptr(Qh), 64 * Hh, lib.ptr(Kh), lib.ptr(Vh), 64 * Hh, lib.ptr(Oh), 64 * Hh, Bh, Th, Th,
+                                                    Hh, lib.ptr(mh), lib.ptr(mh), lib.ptr(rs_h), args.drop, 9, lib.stream_ptr()))
+            for _ in range(3):
+                wide()
+            torch.cuda.synchronize()
+            gr_h = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr_h):
+                for _ in range(50):
+                    wide()
+            gr_h.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                gr_h.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us_h = e0.elapsed_time(e1) * 1e3 / 200
+            tf_h = 4.0 * Bh * Hh * Th * Th * 64 / us_h / 1e6
+            roof['attention_head64'] = dict(kernel='attn_fwd_wide_kernel<8>', note='head size 64, 8 heads, dim 512, self attention over '
+                                            'T keys with the step\'s dropout rate; not a launch of the SeqPAN step (8 heads of 16)',
+                                            us_per_launch=round(us_h, 2), achieved=round(tf_h, 2), peak=PEAK_F32_MATRIX_TFLOPS,
+                                            unit='TFLOP/s', frac=round(tf_h / PEAK_F32_MATRIX_TFLOPS, 4),
+                                            mfma_issue_frac_of_bf16_pipe=round(3 * tf_h / PEAK_BF16_MATRIX_TFLOPS, 4))
+        except Exception as ex:                                  # (a demonstration leg: never fails the bench line)
+            roof['attention_head64'] = dict(error=str(ex))
         # whole step: algorithmic FLOPs (BASELINE.md section 2 for the c2 shape, else the launch wrappers' own sums) over the timed
         # ms/step; HBM bytes per step measured by the PMC passes (sum over kernels of bytes/launch x launches/step) against
         # the compulsory bytes (clip features + query ids + labels read once, outputs written, parameters read once,

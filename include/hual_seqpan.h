@@ -282,6 +282,14 @@ int hual_attention_fwd_save(const float* Q, int ldq, const float* K, const float
                             const uint32_t* rng_state, float drop_rate, int drop_site, void* stream);
 int hual_attention_keep_row_bytes(int Tk);
 
+/* The forward of the same attention core at head size 64: `heads` heads merged in [rows, 64 * heads], Tk <= 128, dropout on
+ * the probabilities with RNG row = query row * heads + head.  SeqPAN's configs use 8 heads of 16 (dim 128) and never reach
+ * this entry point; it exists to measure the attention products at a head size where the matrix cores carry the kernel
+ * (BASELINE.json north_star "MFMA utilisation on the attention GEMMs"; scripts/bench_attn.py --wide). */
+int hual_attention_fwd_wide(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
+                            int Tk, int heads, const float* qmask, const float* kmask, const uint32_t* rng_state,
+                            float drop_rate, int drop_site, void* stream);
+
 /* gradient of the attention core (tf.gradients through layers.py:80-96): dQ, dK, dV [rows,128] (written, not accumulated)
  * from dO, the forward output O, `stats` and `keep_bytes` of hual_attention_fwd_save with the same arguments.  Tq, Tk <= 256. */
 int hual_attention_bwd(const float* Q, int ldq, const float* K, const float* V, int ldkv, const float* O, int ldo,
