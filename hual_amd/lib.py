@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libhual_seqpan.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HUAL_ABI_VERSION 2
+#define HUAL_ABI_VERSION 3
 
 #define HUAL_OK 0
 #define HUAL_ERR_INVALID (-1)
