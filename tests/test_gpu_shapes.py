@@ -58,6 +58,13 @@ def test_t256_configs3_shape():
     _check_all(case, 0.1)
 
 
+def test_long_queries():
+    """L = 40 words (> 32): the staged context-query kernels take their general softmax branches (rows / columns longer than
+    a 32-lane half) - T + L still within their 160 padded rows"""
+    case = pu.make_case(B=3, T=64, L=40, C=5, seed=47, max_vlen=64)
+    _check_all(case, 0.2)
+
+
 def test_single_clip_batch():
     case = pu.make_case(B=1, T=33, L=5, C=4, seed=61, max_vlen=40)
     _check_all(case, 0.0)
