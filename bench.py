@@ -165,7 +165,6 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--aux', action='store_true', help='side stream for the alignment-loss branch of forward (experiment)')
     ap.add_argument('--prewarm', type=int, default=200, help='untimed steps before the warm-up steps (clock ramp)')
     ap.add_argument('--video-dtype', choices=['f32', 'bf16'], default='f32',
                     help='element type of the clip features in HBM (hual_batch.video_dtype); arithmetic is the same')
@@ -190,7 +189,7 @@ def main():
     wv = np.random.default_rng(777).normal(0, 0.4, size=(num_words - 2, 300)).astype(np.float32)
     model = SeqPAN(cfg, wv, device=dev, seed=12345, rng_seed=12345 + rank)
     b = synth_batch(args.batch, args.T, args.L, args.C, args.vdim, num_words, num_chars, 12345 + rank)
-    trainer = Trainer(model, world=world, use_graph=not args.no_graph, use_aux=args.aux)
+    trainer = Trainer(model, world=world, use_graph=not args.no_graph)
     vdt = torch.bfloat16 if args.video_dtype == 'bf16' else torch.float32
     trainer.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'], video_dtype=vdt)
 

@@ -22,7 +22,7 @@ def _sources():
 
 def _stamp(src):
     h = hashlib.sha1()
-    for f in [src] + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, '..', 'include', 'hual_seqpan.h')]:
+    for f in [src] + sorted(glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc'))) + [os.path.join(HERE, '..', 'include', 'hual_seqpan.h')]:
         with open(f, 'rb') as fh:
             h.update(fh.read())
     h.update(' '.join(FLAGS).encode())

@@ -17,39 +17,35 @@ extern "C" {
 int hual_abi_version(void) { return HUAL_ABI_VERSION; }
 const char* hual_last_error(void) { return hual::last_error_cstr(); }
 
-int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, int trans_w, const float* bias, float* Y,
-                    int ldy, int M, int K, int N, int act, void* stream) {
+int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int K, int N,
+                    int act, void* stream) {
   HUAL_REQUIRE(A && W && Y, "hual_linear_fwd: null pointer");
   HUAL_REQUIRE(M > 0 && K > 0 && N > 0, "hual_linear_fwd: empty shape");
   HUAL_REQUIRE(K % 16 == 0 && N % 64 == 0, "hual_linear_fwd: K % 16 == 0 and N % 64 == 0 required");
   HUAL_REQUIRE(act >= 0 && act <= 2, "hual_linear_fwd: act");
   GemmJob j;
   gemm_job_init(j);
-  // split K into pieces of <= 4 column blocks so the job table can carry it
   j.npieces = 1;
   j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.W[0] = W;
-  j.ldw = ldw; j.transW = trans_w; j.bias = bias;
+  j.ldw = ldw; j.bias = bias;
   j.M = M; j.N = N; j.act = act; j.Y = Y; j.ldy = ldy;
   DropCfg d = make_dropcfg(nullptr, 0.f);
   return launch_gemm(&j, 1, d, (hipStream_t)stream);
 }
 
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
-                   int N, int rows_per_block, void* scratch, uint64_t scratch_bytes, void* stream) {
+                   int N, int workgroups, void* scratch, uint64_t scratch_bytes, void* stream) {
   HUAL_REQUIRE(A && dY && dW, "hual_linear_dw: null pointer");
   HUAL_REQUIRE(M > 0 && K % 16 == 0 && N == 128, "hual_linear_dw: K % 16 == 0 and N == 128 required");
+  HUAL_REQUIRE(workgroups >= 0, "hual_linear_dw: workgroups >= 0 (0: one per CU)");
+  HUAL_REQUIRE(scratch && scratch_bytes >= 4 * dw_table_words(1), "hual_linear_dw: scratch table too small");
   DwJob j;
   dw_job_init(j);
   j.npieces = 1;
   j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.dW[0] = dW; j.ldw = ldw;
   j.dY = dY; j.ldy = ldy; j.M = M; j.N = N; j.db = db;
   DropCfg d = make_dropcfg(nullptr, 0.f);
-  if (rows_per_block < 0) {
-    // the balanced launch of the training step (job table in device memory), on -rows_per_block workgroups
-    HUAL_REQUIRE(scratch && scratch_bytes >= 4 * dw_table_words(1), "hual_linear_dw: balanced launch needs a scratch table");
-    return launch_dw(&j, 1, d, 0, (hipStream_t)stream, reinterpret_cast<DwJob*>(scratch), true, -rows_per_block);
-  }
-  return launch_dw(&j, 1, d, rows_per_block > 0 ? rows_per_block : 1024, (hipStream_t)stream);
+  return launch_dw(&j, 1, d, (hipStream_t)stream, reinterpret_cast<DwJob*>(scratch), true, workgroups);
 }
 
 int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, const float* bias, float* Y, int ldy, int M,

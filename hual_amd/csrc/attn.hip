@@ -554,21 +554,11 @@ int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
   const int nkt = cdiv(maxTk, 16);
   const int Tkp = 16 * (nkt <= 2 ? 2 : nkt <= 4 ? 4 : nkt <= 8 ? 8 : 16);
   const size_t lds = (size_t)2 * Tkp * 64 + 2 * Tkp * sizeof(float);
-  // 8 waves per workgroup (one query tile each) when some job has more than 4 query tiles: half the per-wave chain
-  static const int nt_env = []() { const char* e = getenv("HUAL_ATTN_FWD_THREADS"); return e ? atoi(e) : 0; }();
-  const bool wide = nt_env == 512;      // measured equal at 156 registers (one 8-wave workgroup per CU instead of two 4-wave ones)
-  const dim3 block512(512);
-  if (wide) {
-    if (nkt <= 2) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<2, 512>), grid, block512, lds, s, b, n, drop);
-    else if (nkt <= 4) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<4, 512>), grid, block512, lds, s, b, n, drop);
-    else if (nkt <= 8) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<8, 512>), grid, block512, lds, s, b, n, drop);
-    else HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<16, 512>), grid, block512, lds, s, b, n, drop);
-  } else {
-    if (nkt <= 2) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<2, 256>), grid, block, lds, s, b, n, drop);
-    else if (nkt <= 4) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<4, 256>), grid, block, lds, s, b, n, drop);
-    else if (nkt <= 8) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<8, 256>), grid, block, lds, s, b, n, drop);
-    else HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<16, 256>), grid, block, lds, s, b, n, drop);
-  }
+  // (8 waves per workgroup - one 8-wave workgroup per CU instead of two 4-wave ones - measured equal)
+  if (nkt <= 2) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<2, 256>), grid, block, lds, s, b, n, drop);
+  else if (nkt <= 4) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<4, 256>), grid, block, lds, s, b, n, drop);
+  else if (nkt <= 8) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<8, 256>), grid, block, lds, s, b, n, drop);
+  else HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<16, 256>), grid, block, lds, s, b, n, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -881,10 +881,7 @@ __global__ __launch_bounds__(256) void tri_bwd_kernel(CqBufs b, CqBwdBufs gb, Cq
 
 namespace hual {
 
-static int cq_threads() {
-  static const int t = []() { const char* e = getenv("HUAL_CQ_THREADS"); int v = e ? atoi(e) : 1024; return (v == 256 || v == 512 || v == 1024) ? v : 1024; }();
-  return t;
-}
+static int cq_threads() { return 1024; }
 static int cq_lds_bytes(const RowSpace& rs, int nmats) {      // the matrices + the two staged row masks
   return (int)((cq_mat_elems(rs.T, rs.L) * nmats + cq_padded(rs.T) + cq_padded(rs.L)) * sizeof(float));
 }
@@ -903,8 +900,7 @@ static int cq_staged_bytes(const RowSpace& rs, int nmats) {
   return (int)((cq_mat_elems(rs.T, rs.L) * nmats + 2 * (Tp + Lp) + (size_t)(Tp + Lp) * CQ_LDX) * sizeof(float));
 }
 static bool cq_staged_ok(const RowSpace& rs, int nmats) {
-  static const int on = []() { const char* e = getenv("HUAL_CQ_STAGED"); return e ? atoi(e) : 1; }();
-  return on && (cq_padded(rs.T) + cq_padded(rs.L)) * 32 <= CQ_STAGE_MAX * CQ_MAX_THREADS && cq_staged_bytes(rs, nmats) <= 160 * 1024;
+  return (cq_padded(rs.T) + cq_padded(rs.L)) * 32 <= CQ_STAGE_MAX * CQ_MAX_THREADS && cq_staged_bytes(rs, nmats) <= 160 * 1024;
 }
 
 int launch_cq_fwd(const CqBufs& b, const RowSpace& rs, hipStream_t s) {

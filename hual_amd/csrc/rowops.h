@@ -52,25 +52,7 @@ struct LnBwd {
 int ln_bwd_blocks(int R);
 int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s);
 
-// c = depthwise_conv7(LN(x))  (SAME zero padding inside each clip, NO length mask)     layers.py:32-45, modules.py:59-70
-struct ConvFwd {
-  const float* x; const float* g; const float* b; const float* dw;   // dw [7,128]
-  float* c; float* mean; float* rstd;
-};
-int launch_ln_dwconv_fwd(const ConvFwd& a, const RowSpace& rs, hipStream_t s);
-
-struct ConvBwd {
-  const float* dc; const float* x; const float* mean; const float* rstd;
-  const float* g; const float* b; const float* dw;
-  const float* dres;            // gradient arriving through the residual connection (added to dx)
-  float* dx; float* dg; float* db; float* ddw;
-  float* part;                  // optional [dwconv_bwd_blocks(rs)][9][128] scratch (ddw[0..6], dg, db), as in LnBwd
-  float* dz; int dz_site; uint32_t dz_row0; const float* dz_relu;     // optional second output, as in LnBwd
-};
-int dwconv_bwd_blocks(const RowSpace& rs);
-int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
-
-// dst[v][c] += sum_blk src[(blk*nvec + v)*128 + c] for the per-block partial sums left by the two kernels above.
+// dst[v][c] += sum_blk src[(blk*nvec + v)*128 + c] for the per-block partial sums left by the backward kernels.
 // All jobs of a backward pass go into ONE launch at its end.
 #define HUAL_COLSUM_MAX_VEC 9
 #define HUAL_COLSUM_MAX_JOBS 40
@@ -89,25 +71,7 @@ struct PosBwdJob { const float* dx[2]; float* dpos; int do_v, do_q; };
 struct PosBwdBatch { PosBwdJob j[HUAL_POS_MAX_JOBS]; };
 int launch_pos_bwd(const PosBwdJob* jobs, int njobs, const RowSpace& rs, hipStream_t s);
 
-// generic elementwise helpers on [R,128] tensors -----------------------------------------------------------
-enum EwOp {
-  EW_DROP_DRELU = 1,    // out = dropout(a, site) * (b > 0)                    (dZ of relu->dropout)
-  EW_DROP = 2,          // out = dropout(a, site)
-  EW_GATE_BWD = 3,      // cross gating backward, see rowops.hip
-  EW_BILINEAR_BWD = 4,  // out = d*val*gate*(1-gate) ; out2 = d*gate
-  EW_ADD = 5,           // out = a + b
-  EW_MASKROWS = 6,      // out = a * rowmask
-  EW_ADD_POS = 7,       // out = a + pos[row % T]                            (modules.py:41-56; a = video rows)
-  EW_DROP_ADD = 8       // out = dropout(a, site) + b
-};
-struct EwArgs {
-  int op; int R;
-  const float* a; const float* b; const float* c; const float* d; const float* e;
-  float* out; float* out2; float* out3; float* out4;
-  int drop_site; uint32_t drop_row0;
-  const float* rowmask;
-  const float* pos; int T;
-};
-int launch_ew(const EwArgs& a, const DropCfg& drop, hipStream_t s);
+// out = a + b on [R,128] tensors (per-block entry points: sum of two gradient tensors)
+int launch_add_rows(const float* a, const float* b, float* out, int R, hipStream_t s);
 
 }  // namespace hual

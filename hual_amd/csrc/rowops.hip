@@ -131,131 +131,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// conv_block layer front half: c = dwconv7(LN(x)).   One block = one 32-row segment of one clip (+3 halo rows each side).
-#define SEG 32
-#define HALO 3
-__global__ __launch_bounds__(256) void ln_dwconv_fwd_kernel(ConvFwd a, RowSpace rs) {
-  __shared__ float4 hbuf[SEG + 2 * HALO][32];
-  const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int col = 4 * l32;
-  const int segs_v = cdiv_dev(rs.T, SEG), segs_q = 0;
-  (void)segs_q;
-  int blk = blockIdx.x;
-  int base, n, t0;
-  if (blk < rs.B * segs_v) { int b = blk / segs_v; t0 = (blk - b * segs_v) * SEG; n = rs.T; base = b * rs.T; }
-  else { blk -= rs.B * segs_v; int sq = cdiv_dev(rs.L, SEG); int b = blk / sq; t0 = (blk - b * sq) * SEG; n = rs.L; base = rs.Nv + b * rs.L; }
-  const float4 g = ld4(a.g + col), be = ld4(a.b + col);
-  for (int i = grp; i < SEG + 2 * HALO; i += 8) {
-    const int t = t0 - HALO + i;
-    float4 h = f4zero();
-    if (t >= 0 && t < n) {
-      const int row = base + t;
-      float4 v = ld4(a.x + (size_t)row * HUAL_D + col);
-      float mean, rstd;
-      row_stats(v, mean, rstd);
-      h = f4fma_(make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd), g, be);
-      if (l32 == 0 && i >= HALO && i < HALO + SEG) { a.mean[row] = mean; a.rstd[row] = rstd; }
-    }
-    hbuf[i][l32] = h;
-  }
-  __syncthreads();
-  float4 w[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) w[k] = ld4(a.dw + k * HUAL_D + col);
-  for (int i = grp; i < SEG; i += 8) {
-    const int t = t0 + i;
-    if (t >= n) break;
-    float4 c = f4zero();
-#pragma unroll
-    for (int k = 0; k < 7; ++k) c = f4fma_(hbuf[i + k][l32], w[k], c);   // h[t + k - 3]
-    st4(a.c + (size_t)(base + t) * HUAL_D + col, c);
-  }
-}
-
-// backward of the front half:  dh = dwconv^T(dc) ; ddw ; LN backward ; + residual gradient
-__global__ __launch_bounds__(256) void dwconv_ln_bwd_kernel(ConvBwd a, RowSpace rs, DropCfg drop) {
-  __shared__ float4 hbuf[SEG + 2 * HALO][32];
-  __shared__ float4 dbuf[SEG + 2 * HALO][32];
-  __shared__ float4 red[9][8][32];
-  const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int col = 4 * l32;
-  const int segs_v = cdiv_dev(rs.T, SEG);
-  const int nseg = rs.B * segs_v + (rs.Nq > 0 ? rs.B * cdiv_dev(rs.L, SEG) : 0);
-  const float4 g = ld4(a.g + col), be = ld4(a.b + col);
-  float4 w[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) w[k] = ld4(a.dw + k * HUAL_D + col);
-  float4 sw[7], sg = f4zero(), sb = f4zero();
-#pragma unroll
-  for (int k = 0; k < 7; ++k) sw[k] = f4zero();
-  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-  int blk = seg;
-  int base, n, t0;
-  if (blk < rs.B * segs_v) { int b = blk / segs_v; t0 = (blk - b * segs_v) * SEG; n = rs.T; base = b * rs.T; }
-  else { blk -= rs.B * segs_v; int sq = cdiv_dev(rs.L, SEG); int b = blk / sq; t0 = (blk - b * sq) * SEG; n = rs.L; base = rs.Nv + b * rs.L; }
-  __syncthreads();
-  for (int i = grp; i < SEG + 2 * HALO; i += 8) {
-    const int t = t0 - HALO + i;
-    float4 h = f4zero(), d = f4zero();
-    if (t >= 0 && t < n) {
-      const size_t off = (size_t)(base + t) * HUAL_D + col;
-      float4 v = ld4(a.x + off);
-      const float mean = a.mean[base + t], rstd = a.rstd[base + t];
-      h = f4fma_(make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd), g, be);
-      d = ld4(a.dc + off);
-    }
-    hbuf[i][l32] = h;
-    dbuf[i][l32] = d;
-  }
-  __syncthreads();
-  for (int i = grp; i < SEG; i += 8) {
-    const int t = t0 + i;
-    if (t >= n) break;
-    const int row = base + t;
-    const size_t off = (size_t)row * HUAL_D + col;
-    // dh[t] = sum_k dc[t - k + 3] * w[k]   ;   ddw[k] += dc[t] * h[t + k - 3]
-    float4 dh = f4zero();
-    const float4 dct = dbuf[i + HALO][l32];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      dh = f4fma_(dbuf[i + 2 * HALO - k][l32], w[k], dh);
-      sw[k] = f4fma_(dct, hbuf[i + k][l32], sw[k]);
-    }
-    float4 v = ld4(a.x + off);
-    const float mean = a.mean[row], rstd = a.rstd[row];
-    float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
-    sb = f4add_(sb, dh);
-    sg = f4fma_(dh, xh, sg);
-    float4 gv = f4mul_(dh, g);
-    float m1 = half_sum32(f4hsum_(gv)) * (1.0f / HUAL_D);
-    float m2 = half_sum32(f4hsum_(f4mul_(gv, xh))) * (1.0f / HUAL_D);
-    float4 dx = make_float4(rstd * (gv.x - m1 - xh.x * m2), rstd * (gv.y - m1 - xh.y * m2),
-                            rstd * (gv.z - m1 - xh.z * m2), rstd * (gv.w - m1 - xh.w * m2));
-    if (a.dres) dx = f4add_(dx, ld4(a.dres + off));
-    st4(a.dx + off, dx);
-    if (a.dz) store_dz(a.dz, a.dz_site, a.dz_row0 + (uint32_t)row, a.dz_relu, off, l32, dx, drop);
-  }
-  }   // segment loop
-#pragma unroll
-  for (int k = 0; k < 7; ++k) red[k][grp][l32] = sw[k];
-  red[7][grp][l32] = sg;
-  red[8][grp][l32] = sb;
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < 9 * 128; idx += 256) {
-    const int vec = idx >> 7, c = idx & 127;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += reinterpret_cast<const float*>(&red[vec][k][c >> 2])[c & 3];
-    if (a.part) {
-      a.part[((size_t)blockIdx.x * 9 + vec) * HUAL_D + c] = s;
-      continue;
-    }
-    float* dst = vec < 7 ? a.ddw + vec * HUAL_D : (vec == 7 ? a.dg : a.db);
-    atomicAdd(dst + c, s);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
 struct ColsumBatch { ColsumJob j[HUAL_COLSUM_MAX_JOBS]; };
 #define COLSUM_SPLIT 16   // independent row slices per (job, vector): the kernel is a chain of dependent-latency loads (18.5 us at 4, see profiles)
 __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch batch) {
@@ -297,59 +172,11 @@ __global__ __launch_bounds__(512) void pos_bwd_kernel(PosBwdBatch batch, RowSpac
 }
 
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ew_kernel(EwArgs a, DropCfg drop) {
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* a, const float* b, float* out, int R) {
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int col = 4 * l32;
-  for (int row = blockIdx.x * 8 + grp; row < a.R; row += gridDim.x * 8) {
-    const size_t off = (size_t)row * HUAL_D + col;
-    switch (a.op) {
-      case EW_DROP_DRELU: {
-        float4 v = ld4(a.a + off);
-        if (a.drop_site >= 0 && drop.enabled)
-          v = apply_drop4(drop, (uint32_t)a.drop_site, a.drop_row0 + (uint32_t)row, (uint32_t)l32, v);
-        float4 y = ld4(a.b + off);
-        st4(a.out + off, make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f));
-      } break;
-      case EW_DROP: {
-        float4 v = ld4(a.a + off);
-        if (a.drop_site >= 0 && drop.enabled)
-          v = apply_drop4(drop, (uint32_t)a.drop_site, a.drop_row0 + (uint32_t)row, (uint32_t)l32, v);
-        st4(a.out + off, v);
-      } break;
-      case EW_GATE_BWD: {
-        // o = sg*x + xg*s  (layers.py:101-103).  inputs: a=do, b=sg, c=xg, d=s, e=x
-        // out = dz_sg = do*x*sg*(1-sg) ; out2 = dz_xg = do*s*xg*(1-xg) ; out3 = ds_part = do*xg ; out4 = dx_part = do*sg
-        float4 d0 = ld4(a.a + off), sg = ld4(a.b + off), xg = ld4(a.c + off), s = ld4(a.d + off), x = ld4(a.e + off);
-        st4(a.out + off, make_float4(d0.x * x.x * sg.x * (1.f - sg.x), d0.y * x.y * sg.y * (1.f - sg.y),
-                                     d0.z * x.z * sg.z * (1.f - sg.z), d0.w * x.w * sg.w * (1.f - sg.w)));
-        st4(a.out2 + off, make_float4(d0.x * s.x * xg.x * (1.f - xg.x), d0.y * s.y * xg.y * (1.f - xg.y),
-                                      d0.z * s.z * xg.z * (1.f - xg.z), d0.w * s.w * xg.w * (1.f - xg.w)));
-        st4(a.out3 + off, f4mul_(d0, xg));
-        st4(a.out4 + off, f4mul_(d0, sg));
-      } break;
-      case EW_BILINEAR_BWD: {
-        // out_mha = gate*val (layers.py:110): a=d_out, b=gate, c=val -> out = d_scores = d*val*gate*(1-gate), out2 = d_values = d*gate
-        float4 d0 = ld4(a.a + off), gt = ld4(a.b + off), vl = ld4(a.c + off);
-        st4(a.out + off, make_float4(d0.x * vl.x * gt.x * (1.f - gt.x), d0.y * vl.y * gt.y * (1.f - gt.y),
-                                     d0.z * vl.z * gt.z * (1.f - gt.z), d0.w * vl.w * gt.w * (1.f - gt.w)));
-        st4(a.out2 + off, f4mul_(d0, gt));
-      } break;
-      case EW_ADD:
-        st4(a.out + off, f4add_(ld4(a.a + off), ld4(a.b + off)));
-        break;
-      case EW_MASKROWS:
-        st4(a.out + off, f4scale_(ld4(a.a + off), a.rowmask[row]));
-        break;
-      case EW_ADD_POS:
-        st4(a.out + off, f4add_(ld4(a.a + off), ld4(a.pos + (size_t)(row % a.T) * HUAL_D + col)));
-        break;
-      case EW_DROP_ADD: {
-        float4 v = ld4(a.a + off);
-        if (a.drop_site >= 0 && drop.enabled)
-          v = apply_drop4(drop, (uint32_t)a.drop_site, a.drop_row0 + (uint32_t)row, (uint32_t)l32, v);
-        st4(a.out + off, f4add_(v, ld4(a.b + off)));
-      } break;
-    }
+  for (int row = blockIdx.x * 8 + grp; row < R; row += gridDim.x * 8) {
+    const size_t off = (size_t)row * HUAL_D + 4 * l32;
+    st4(out + off, f4add_(ld4(a + off), ld4(b + off)));
   }
 }
 
@@ -382,27 +209,6 @@ int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s) {
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
-
-static int conv_blocks(const RowSpace& rs) { return rs.B * cdiv(rs.T, SEG) + (rs.Nq > 0 ? rs.B * cdiv(rs.L, SEG) : 0); }
-
-int launch_ln_dwconv_fwd(const ConvFwd& a, const RowSpace& rs, hipStream_t s) {
-  HUAL_REQUIRE(a.x && a.g && a.b && a.dw && a.c && a.mean && a.rstd, "ln_dwconv_fwd: null");
-  HUAL_LAUNCH(0.0, 8.0 * rs.R * HUAL_D, ln_dwconv_fwd_kernel, dim3(conv_blocks(rs)), dim3(256), 0, s, a, rs);
-  HUAL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-int launch_dwconv_ln_bwd(const ConvBwd& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
-  HUAL_REQUIRE(a.dc && a.x && a.mean && a.rstd && a.g && a.b && a.dw && a.dx && a.dg && a.db && a.ddw, "dwconv_ln_bwd: null");
-  int grid = conv_blocks(rs);
-  grid = grid < 128 ? grid : 128;      // each block ends with 9x128 same-address float atomics
-  if (a.part) grid = conv_blocks(rs);
-  HUAL_LAUNCH(0.0, 16.0 * rs.R * HUAL_D, dwconv_ln_bwd_kernel, dim3(grid), dim3(256), 0, s, a, rs, drop);
-  HUAL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-int dwconv_bwd_blocks(const RowSpace& rs) { return conv_blocks(rs); }
 
 int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s) {
   if (n == 0) return 0;
@@ -437,9 +243,9 @@ int launch_pos_bwd(const PosBwdJob* jobs, int njobs, const RowSpace& rs, hipStre
   return 0;
 }
 
-int launch_ew(const EwArgs& a, const DropCfg& drop, hipStream_t s) {
-  HUAL_REQUIRE(a.R > 0 && a.a && a.out, "ew: null/empty");
-  HUAL_LAUNCH(0.0, 12.0 * a.R * HUAL_D, ew_kernel, dim3(row_grid(a.R)), dim3(256), 0, s, a, drop);
+int launch_add_rows(const float* a, const float* b, float* out, int R, hipStream_t s) {
+  HUAL_REQUIRE(R > 0 && a && b && out, "add_rows: null/empty");
+  HUAL_LAUNCH(0.0, 12.0 * R * HUAL_D, add_rows_kernel, dim3(row_grid(R)), dim3(256), 0, s, a, b, out, R);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -25,16 +25,6 @@ const char* last_error_cstr();
 }
 using namespace hual;
 
-// ------------------------------------------------------------------------------------------------------
-// small kernels that belong to no family
-__global__ void prep_masks_kernel(const int32_t* lens, const int32_t* word_ids, float* rowmask, int B, int T, int L,
-                                  float* loss_acc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 8) loss_acc[i] = 0.f;
-  const int Nv = B * T, Nq = B * L;
-  if (i < Nv) rowmask[i] = (i % T) < lens[i / T] ? 1.0f : 0.0f;           // tf.sequence_mask, model.py:31
-  else if (i < Nv + Nq) rowmask[i] = word_ids[i - Nv] != 0 ? 1.0f : 0.0f;   // model.py:32
-}
 namespace {
 
 // stages of the graph (forward order; backward runs them in reverse)
@@ -60,26 +50,8 @@ struct Ctx {
   std::unordered_map<std::string, size_t> index;
   std::vector<DwJob> dwjobs;
   std::vector<ColsumJob> colsum;
-  size_t dw_flushed = 0;
-  int dw_flushes = 0;
-  const hual_aux* aux = nullptr;
   int rc = 0;
-  // kernel-fusion switches (environment, read per call so that tests can run both settings):
-  //   HUAL_FUSE_LN=1   layer norms that feed dense layers run in the GEMM A prologue instead of ln_fwd launches
-  //   HUAL_FUSE_BWD=1  dropout' / relu' in front of dX GEMMs run in the GEMM A prologue instead of ew launches
-  // Measured on MI355X (DESIGN.md "Fusion experiments"): both lengthen the latency-bound GEMMs by more than the
-  // launches they remove, so they default to off.
-  bool fuse_ln = false, fuse_bwd = false;
-  //   HUAL_FUSE_ROW=0  (default on) the row kernel that produces a gradient also writes dropout'(.) * relu'(.) of it for
-  //                    the next dX GEMM, instead of an elementwise launch in between
-  bool fuse_row = true;
   bool static_tables = false;   // hual_run_opts.static_tables
-  //   HUAL_GEMM_BF16=0  dense layers on the fp32 matrix cores (gemm_lds_kernel) instead of the split-bf16 kernel
-  bool use_bf16 = true;
-  //   HUAL_FUSE_CB=0    conv_block as 4 x (ln_dwconv_fwd + dense) launches instead of the fused kernels (convblock.h)
-  bool fuse_cb = true;
-  //   HUAL_FUSE_DA=0    dual attention block as ln / dense / chained launches instead of the fused row-local kernels (dablock.h)
-  bool fuse_da = true;
   struct DenseW { size_t off; int K; size_t boff; };
   std::vector<DenseW> dense;          // every [K,128] weight of the graph, sorted by offset
   char* PKF = nullptr;                // pre-split images (gemm.h launch_pack_weights): forward ...
@@ -100,7 +72,9 @@ struct Ctx {
   float* act(const std::string& name) { return buf(name, (size_t)rs.R, HUAL_D); }     // [R,128]
   float* actv(const std::string& name) { return buf(name, (size_t)rs.Nv, HUAL_D); }   // [Nv,128]
   float* vec(const std::string& name) { return buf(name, (size_t)rs.R, 1); }
-  const float* PT = nullptr;  // transposed copies of the dense weights (same offsets), made at the start of backward
+  // dX jobs name the transposed weight by an address inside a range ("params.T") that mirrors the flat parameters and is
+  // never read or written: packed_ptr() maps it to the image of the transposed weight in PKB
+  const float* PT = nullptr;
   const float* p(size_t off) const { return P + off; }
   const float* pt(size_t off) const { return PT + off; }
   float* g(size_t off) const { return G + off; }
@@ -147,54 +121,23 @@ struct Ctx {
     return nullptr;
   }
   bool to_packed(GemmJob& j) const {
-    if (j.ln_g || j.a_relu || j.a_save || j.transW) return false;
     for (int p = 0; p < j.npieces; ++p) {
       if (j.kw[p] % 8) return false;
       const float* w = packed_ptr(j.W[p], j.ldw, j.N);
       if (!w) return false;
       j.W[p] = w;
-      if (j.comb != COMB_NONE) {
-        const float* w2 = packed_ptr(j.W2[p], j.ldw, j.N);
-        if (!w2) return false;
-        j.W2[p] = w2;
-      }
     }
     return true;
   }
+  // up to HUAL_MAX_JOBS dense jobs as one launch of the split kernel on the pre-split weight images
   void gemm(const GemmJob* j, int n) {
     if (!live()) return;
-    if (use_bf16 && n <= HUAL_MAX_JOBS) {
-      GemmJob pk[HUAL_MAX_JOBS];
-      bool all = true;
-      for (int i = 0; i < n && all; ++i) { pk[i] = j[i]; all = to_packed(pk[i]); }
-      if (all) { chk(launch_gemm_bf16(pk, n, drop, stream)); return; }
-      for (int i = 0; i < n; ++i)
-        for (int p = 0; p < j[i].npieces; ++p)
-          if (pt_skipped && PT && j[i].W[p] >= PT && j[i].W[p] < PT + pm.total) { chk(fail(-1, "dX job outside the packed path while the transposed copies are skipped")); return; }
+    GemmJob pk[HUAL_MAX_JOBS];
+    for (int i = 0; i < n; ++i) {
+      pk[i] = j[i];
+      if (!to_packed(pk[i])) { chk(fail(HUAL_ERR_INVALID, "internal: dense job without a pre-split weight image")); return; }
     }
-    chk(launch_gemm(j, n, drop, stream));
-  }
-  bool pt_skipped = false;
-  bool dw_forked = false;
-  bool align_forked = false;      // forward: the alignment-loss branch runs on the side stream (joined before the loss tail)
-  //   HUAL_CHAIN=0  launch the dense layers of a row-local chain one by one instead of as one chained launch
-  bool use_chain = true;
-  // `ngroups` consecutive groups of jobs (group g has gsz[g] jobs) where every group only reads, of the outputs of the
-  // earlier groups, rows of its own row block: one chained launch (gemm_chain_kernel) or, as fallback, one launch per group
-  void gemm_chain(const GemmJob* j, const int* gsz, int ngroups) {
-    if (!live()) return;
-    int n = 0;
-    for (int g = 0; g < ngroups; ++g) n += gsz[g];
-    if (use_bf16 && use_chain && n <= HUAL_MAX_JOBS) {
-      GemmJob pk[HUAL_MAX_JOBS];
-      bool all = true;
-      for (int i = 0; i < n && all; ++i) {
-        pk[i] = j[i];
-        all = to_packed(pk[i]) && pk[i].M == j[0].M && pk[i].N == HUAL_D;
-      }
-      if (all) { chk(launch_gemm_chain(pk, n, drop, stream)); return; }
-    }
-    for (int g = 0, i = 0; g < ngroups; i += gsz[g], ++g) gemm(j + i, gsz[g]);
+    chk(launch_gemm_bf16(pk, n, drop, stream));
   }
   void ln_fwd(const LnFwd& a, const RowSpace& r) { if (live()) chk(launch_ln_fwd(a, r, drop, stream)); }
   // layer-norm backward; the per-block dgamma / dbeta sums go to scratch and are folded in by flush_colsum()
@@ -222,17 +165,6 @@ struct Ctx {
     if (active) colsum.push_back(cj);
     if (live()) chk(launch_ln_bwd(a, drop, stream));
   }
-  void dwconv_ln_bwd(const ConvBwd& a0, const RowSpace& r) {
-    ConvBwd a = a0;
-    const int nblk = dwconv_bwd_blocks(r);
-    a.part = buf("part." + std::to_string(part_seq++), (size_t)nblk * 9, HUAL_D);
-    ColsumJob cj{};
-    cj.src = a.part; cj.nblk = nblk; cj.nvec = 9;
-    for (int k = 0; k < 7; ++k) cj.dst[k] = a.ddw + k * HUAL_D;
-    cj.dst[7] = a.dg; cj.dst[8] = a.db;
-    if (active) colsum.push_back(cj);
-    if (live()) chk(launch_dwconv_ln_bwd(a, r, drop, stream));
-  }
   // fused dX products + layer norm(s) backward (dablock.h); the per-workgroup parameter sums are folded in by flush_colsum()
   void ln_proj_bwd(const LnProjBwdArgs& a0, float* dg1, float* db1, float* dg2, float* db2) {
     LnProjBwdArgs a = a0;
@@ -250,7 +182,6 @@ struct Ctx {
       chk(launch_colsum(colsum.data() + i, (int)std::min<size_t>(HUAL_COLSUM_MAX_JOBS, colsum.size() - i), stream));
     colsum.clear();
   }
-  void ew(const EwArgs& a) { if (live()) chk(launch_ew(a, drop, stream)); }
   void attn_fwd(const AttnJob* j, int n) { if (live()) chk(launch_attn_fwd(j, n, drop, stream)); }
   void attn_bwd(const AttnJob* j, int n) {
     if (live()) chk(launch_attn_bwd(j, n, drop, stream));
@@ -271,29 +202,9 @@ GemmJob mkjob_dx(const float* dY, int lddy, int M, int N, const float* WT, int l
   GemmJob j;
   gemm_job_init(j);
   j.npieces = 1;
-  j.A[0] = dY; j.lda[0] = lddy; j.kw[0] = N; j.W[0] = WT; j.ldw = ldwt; j.transW = 0;
+  j.A[0] = dY; j.lda[0] = lddy; j.kw[0] = N; j.W[0] = WT; j.ldw = ldwt;
   j.M = M; j.N = K; j.Y = dX; j.ldy = lddx;
   return j;
-}
-// A-prologue layer norm of piece 0: the GEMM consumes dropout(LN(A[0])); `save` receives that operand, mean / rstd the
-// row statistics (both optional - only one job of a group that shares the input needs to write them).
-void set_ln(GemmJob& j, const float* g, const float* b, float* mean, float* rstd, float* save, int drop_site) {
-  j.ln_g = g; j.ln_b = b; j.ln_mean = mean; j.ln_rstd = rstd;
-  j.a_save = save; j.lda_save = HUAL_D;
-  j.a_drop_site = drop_site; j.a_drop_row0 = 0;
-}
-// y = dropout(LN(x)) feeding `njobs` dense jobs that read x as piece 0.  Fused (c.fuse_ln): every job normalises in its
-// A prologue and job 0 keeps y + statistics.  Otherwise one ln_fwd launch and the jobs read y.
-void ln_into_jobs(Ctx& c, GemmJob* j, int njobs, const float* x, int M, const RowSpace& rs, const float* g, const float* b,
-                  float* mean, float* rstd, float* y, int drop_site) {
-  if (c.fuse_ln) {
-    for (int k = 0; k < njobs; ++k) set_ln(j[k], g, b, k == 0 ? mean : nullptr, k == 0 ? rstd : nullptr, k == 0 ? y : nullptr, drop_site);
-    return;
-  }
-  LnFwd a{};
-  a.x = x; a.R = M; a.g1 = g; a.b1 = b; a.y1 = y; a.mean = mean; a.rstd = rstd; a.drop_site = drop_site; a.drop_row0 = 0;
-  c.ln_fwd(a, rs);
-  for (int k = 0; k < njobs; ++k) j[k].A[0] = y;
 }
 void set_embed_scratch(EmbedArgs& ea, float* base, int Nq, int C, int char_dim) {
   const EmbedLayout el = embed_layout(Nq, C, char_dim);
@@ -307,24 +218,6 @@ void set_dmask(Ctx& c, AttnJob& a, const std::string& name) {
   a.dmask = reinterpret_cast<uint8_t*>(c.buf(name, (size_t)a.B * a.Tq * 8, a.ldm / 4));
   a.stats = c.buf(name + ".st", (size_t)2 * a.B * a.Tq * 8, 1);
 }
-// dX = dropout'(dY, site) . W^T with dZ = dropout'(dY) kept for the weight-gradient job: one elementwise launch +
-// plain GEMM, or the GEMM's A prologue (c.fuse_bwd)
-void dx_after_dropout(Ctx& c, const float* dY, float* dZ, int M, int site, const float* WT, float* dX, bool dz_ready) {
-  if (dz_ready) {      // the kernel that produced dY already wrote dZ (Ctx::fuse_row)
-    GemmJob j = mkjob_dx(dZ, HUAL_D, M, HUAL_D, WT, HUAL_D, dX, HUAL_D);
-    c.gemm(&j, 1);
-  } else if (c.fuse_bwd) {
-    GemmJob j = mkjob_dx(dY, HUAL_D, M, HUAL_D, WT, HUAL_D, dX, HUAL_D);
-    j.a_drop_site = site; j.a_drop_row0 = 0; j.a_save = dZ; j.lda_save = HUAL_D;
-    c.gemm(&j, 1);
-  } else {
-    EwArgs e{};
-    e.op = EW_DROP; e.R = M; e.a = dY; e.out = dZ; e.drop_site = site; e.drop_row0 = 0;
-    c.ew(e);
-    GemmJob j = mkjob_dx(dZ, HUAL_D, M, HUAL_D, WT, HUAL_D, dX, HUAL_D);
-    c.gemm(&j, 1);
-  }
-}
 DwJob mkdw(const float* A, int lda, int K, const float* dY, int ldy, int M, float* dW, float* db, int N = HUAL_D) {
   DwJob j;
   dw_job_init(j);
@@ -334,51 +227,23 @@ DwJob mkdw(const float* A, int lda, int K, const float* dY, int ldy, int M, floa
   return j;
 }
 
-// feature-load path of the two input projections: the K-split kernel (gemm.h launch_feature_ksplit) when the shapes allow;
-// HUAL_FEATURE_KSPLIT=0 (read per call: tests) or an unsupported vdim selects the generic dense launch
+// feature-load path of the two input projections: the K-split kernel (gemm.h launch_feature_ksplit) when the shapes allow
+// (weight quarter resident in LDS: vdim a multiple of 256, <= 1024), else the generic dense launch
 int feature_qks(int catw) { return ((catw + 3) / 4 + 63) & ~63; }      // quarter size of query_conv1d's K (multiple of 64)
 bool feature_ksplit_ok(const Ctx& c, int catw) {
-  const char* e = getenv("HUAL_FEATURE_KSPLIT");
-  const int on = e ? atoi(e) : 1;
-  return c.use_bf16 && on && (c.cfg->vdim % 256) == 0 && c.cfg->vdim <= 1024 && (catw % 8) == 0 && feature_qks(catw) <= 256;
+  return (c.cfg->vdim % 256) == 0 && c.cfg->vdim <= 1024 && (catw % 8) == 0 && feature_qks(catw) <= 256;
 }
 
-// Launch the weight-gradient jobs queued since the last flush.  With an aux stream they run there, forked from the
-// main stream at this point (their operands are complete) and overlapping the dX chain that continues on main.
-void flush_dw(Ctx& c, bool last = false) {
-  // measured: early flushes (dW overlapping the dX chain) cost more than they hide - the two compete for the same CUs;
-  // only the last launch is forked, so that it overlaps the embedding backward.  HUAL_DW_EARLY=1 restores early flushes.
-  static const int early = []() { const char* e = getenv("HUAL_DW_EARLY"); return e ? atoi(e) : 0; }();
-  if (!last && !early) return;
-  const size_t n = c.dwjobs.size() - c.dw_flushed;
+// Launch every weight-gradient job of the step as ONE persistent launch (gemm.h launch_dw): long-row jobs first, so that the
+// launch ends on the short ones.  (Measured: flushing earlier, under the dX chain, or on a side stream costs more than it
+// hides - the two compete for the same CUs.)
+void flush_dw(Ctx& c) {
+  const size_t n = c.dwjobs.size();
   if (n == 0) return;
-  // blocks are dispatched in job order: long-row jobs first, so that the launch ends on the short ones (tail)
-  static const int nosort = []() { const char* e = getenv("HUAL_DW_NOSORT"); return e ? atoi(e) : 0; }();
-  if (!nosort)
-    std::stable_sort(c.dwjobs.begin() + c.dw_flushed, c.dwjobs.end(), [](const DwJob& a, const DwJob& b) { return a.M > b.M; });
-  DwJob* table = reinterpret_cast<DwJob*>(c.buf("dw.table." + std::to_string(c.dw_flushes), 1, dw_table_words(n)));
-  if (!c.dry && c.ok()) {
-    hipStream_t s = c.stream;
-    // HUAL_DW_AUX=1: the weight-gradient launch on the side stream, under the embedding backward (measured: +1.4 % step time)
-    const int dw_aux = []() { const char* e = getenv("HUAL_DW_AUX"); return e ? atoi(e) : 0; }();
-    c.dw_forked = false;
-    if (dw_aux && c.aux && c.aux->stream) {
-      s = (hipStream_t)c.aux->stream;
-      hipEventRecord((hipEvent_t)c.aux->ev_fork, c.stream);
-      hipStreamWaitEvent(s, (hipEvent_t)c.aux->ev_fork, 0);
-      c.dw_forked = true;
-    }
-    static const int rows = []() { const char* e = getenv("HUAL_DW_ROWS"); return e ? atoi(e) : 0; }();      // 0 = automatic split
-    c.chk(launch_dw(c.dwjobs.data() + c.dw_flushed, (int)n, c.drop, rows, s, table, !c.static_tables));
-  }
-  c.dw_flushed = c.dwjobs.size();
-  c.dw_flushes++;
-}
-void join_aux(Ctx& c) {
-  if (!c.dry && c.dw_forked && c.aux && c.aux->stream) {
-    hipEventRecord((hipEvent_t)c.aux->ev_join, (hipStream_t)c.aux->stream);
-    hipStreamWaitEvent(c.stream, (hipEvent_t)c.aux->ev_join, 0);
-  }
+  std::stable_sort(c.dwjobs.begin(), c.dwjobs.end(), [](const DwJob& a, const DwJob& b) { return a.M > b.M; });
+  DwJob* table = reinterpret_cast<DwJob*>(c.buf("dw.table.0", 1, dw_table_words(n)));
+  if (!c.dry && c.ok()) c.chk(launch_dw(c.dwjobs.data(), (int)n, c.drop, c.stream, table, !c.static_tables));
+  c.dwjobs.clear();
 }
 
 int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
@@ -391,13 +256,6 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
   HUAL_REQUIRE(C >= 4, "char_ids need C >= 4 (conv width 4, VALID)");
   HUAL_REQUIRE((long long)B * (T + L) * 8 < (1ll << 28), "batch too large for 32-bit RNG row ids");
   c.cfg = cfg; c.B = B; c.T = T; c.L = L; c.C = C;
-  { const char* e = getenv("HUAL_FUSE_LN"); c.fuse_ln = e && atoi(e) != 0; }
-  { const char* e = getenv("HUAL_FUSE_BWD"); c.fuse_bwd = e && atoi(e) != 0; }
-  { const char* e = getenv("HUAL_FUSE_ROW"); c.fuse_row = !c.fuse_bwd && !(e && atoi(e) == 0); }
-  { const char* e = getenv("HUAL_GEMM_BF16"); c.use_bf16 = !(e && atoi(e) == 0); }
-  { const char* e = getenv("HUAL_CHAIN"); c.use_chain = !(e && atoi(e) == 0); }
-  { const char* e = getenv("HUAL_FUSE_DA"); c.fuse_da = c.use_bf16 && !c.fuse_ln && !c.fuse_bwd && c.fuse_row && !(e && atoi(e) == 0); }
-  { const char* e = getenv("HUAL_FUSE_CB"); c.fuse_cb = c.use_bf16 && !c.fuse_ln && !c.fuse_bwd && c.fuse_row && !(e && atoi(e) == 0); }
   {
     const ParamMap& pm = c.pm;
     const int D = HUAL_D, catw = cfg->word_dim + 100;
@@ -437,7 +295,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
 float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP& cp, const RowSpace& rs, int site0,
                       const float* pos_src = nullptr, const float* pos = nullptr) {
   const int R = rs.R;
-  if (c.fuse_cb) {       // all four layers in one launch (convblock.h)
+  {                      // all four layers in one launch (convblock.h)
     CbFwdArgs a{};
     a.x0 = pos_src ? pos_src : x; a.pos = pos; a.x0_out = pos_src ? x : nullptr;
     a.MT = conv_block_fused_rows(R); a.drop_row0 = 0;
@@ -458,37 +316,12 @@ float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP
     if (c.live()) c.chk(launch_conv_block_fwd(a, rs, c.drop, c.stream));
     return xin;
   }
-  if (pos_src) {
-    EwArgs e{};
-    e.op = EW_ADD_POS; e.R = R; e.a = pos_src; e.out = x; e.pos = pos; e.T = rs.T; e.drop_site = -1;
-    c.ew(e);
-  }
-  for (int i = 0; i < 4; ++i) {
-    const std::string is = std::to_string(i);
-    float* cbuf = c.buf(tag + ".c" + is, R, HUAL_D);
-    float* y = c.buf(tag + ".y" + is, R, HUAL_D);
-    float* xn = c.buf(tag + ".x" + std::to_string(i + 1), R, HUAL_D);
-    float* mean = c.buf(tag + ".mean" + is, R, 1);
-    float* rstd = c.buf(tag + ".rstd" + is, R, 1);
-    ConvFwd cf{x, c.p(cp.ln[i].g), c.p(cp.ln[i].b), c.p(cp.dw[i]), cbuf, mean, rstd};
-    if (c.live()) c.chk(launch_ln_dwconv_fwd(cf, rs, c.stream));
-    GemmJob j = mkjob(cbuf, HUAL_D, R, HUAL_D, c.p(cp.pw[i]), c.p(cp.b[i]), xn, HUAL_D);
-    j.act = ACT_RELU;
-    j.save = y; j.ldsave = HUAL_D;
-    j.drop_site = site0 + i; j.drop_row0 = 0;
-    j.add = x; j.ldadd = HUAL_D;
-    c.gemm(&j, 1);
-    x = xn;
-  }
-  return x;
 }
 
 // backward of conv_block: d_out = gradient wrt x4 -> returns gradient wrt x0
-// dz3_ready: the producer of dx already left dropout'(dx) * relu'(y3) in "d.<tag>.z3" (Ctx::fuse_row)
-float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, const ConvBlockP& cp, const RowSpace& rs,
-                      int site0, bool dz3_ready) {
+float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, const ConvBlockP& cp, const RowSpace& rs, int site0) {
   const int R = rs.R;
-  if (c.fuse_cb) {       // all four layers in one launch (convblock.h); dZ_3 is formed inside from dx and y3
+  {                      // all four layers in one launch (convblock.h); dZ_3 is formed inside from dx and y3
     CbBwdArgs a{};
     a.dx_in = dx; a.y3 = c.buf(tag + ".y3", R, HUAL_D); a.drop_site3 = site0 + 3;
     a.dx_out = c.buf("d." + tag + ".x0", R, HUAL_D);
@@ -516,46 +349,6 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
     if (c.live()) c.chk(launch_conv_block_bwd(a, rs, c.drop, c.stream));
     return a.dx_out;
   }
-  for (int i = 3; i >= 0; --i) {
-    const std::string is = std::to_string(i);
-    float* xin = i == 0 ? x0 : c.buf(tag + ".x" + is, R, HUAL_D);
-    float* cbuf = c.buf(tag + ".c" + is, R, HUAL_D);
-    float* y = c.buf(tag + ".y" + is, R, HUAL_D);
-    float* mean = c.buf(tag + ".mean" + is, R, 1);
-    float* rstd = c.buf(tag + ".rstd" + is, R, 1);
-    float* dZ = c.buf("d." + tag + ".z" + is, R, HUAL_D);
-    float* dC = c.buf("d." + tag + ".c" + is, R, HUAL_D);
-    float* dxin = c.buf("d." + tag + ".x" + is, R, HUAL_D);
-    // dZ = dropout'(dx) * relu'(y): its own elementwise launch, or formed in the GEMM's A prologue (c.fuse_bwd)
-    c.push_dw(mkdw(cbuf, HUAL_D, HUAL_D, dZ, HUAL_D, R, c.g(cp.pw[i]), c.g(cp.b[i])));
-    const bool dz_ready = i == 3 ? dz3_ready : c.fuse_row;
-    if (dz_ready) {
-      GemmJob j = mkjob_dx(dZ, HUAL_D, R, HUAL_D, c.pt(cp.pw[i]), HUAL_D, dC, HUAL_D);
-      c.gemm(&j, 1);
-    } else if (c.fuse_bwd) {
-      GemmJob j = mkjob_dx(dx, HUAL_D, R, HUAL_D, c.pt(cp.pw[i]), HUAL_D, dC, HUAL_D);
-      j.a_drop_site = site0 + i; j.a_drop_row0 = 0;
-      j.a_relu = y; j.lda_relu = HUAL_D;
-      j.a_save = dZ; j.lda_save = HUAL_D;
-      c.gemm(&j, 1);
-    } else {
-      EwArgs e{};
-      e.op = EW_DROP_DRELU; e.R = R; e.a = dx; e.b = y; e.out = dZ; e.drop_site = site0 + i; e.drop_row0 = 0;
-      c.ew(e);
-      GemmJob j = mkjob_dx(dZ, HUAL_D, R, HUAL_D, c.pt(cp.pw[i]), HUAL_D, dC, HUAL_D);
-      c.gemm(&j, 1);
-    }
-    ConvBwd cb{dC, xin, mean, rstd, c.p(cp.ln[i].g), c.p(cp.ln[i].b), c.p(cp.dw[i]), dx, dxin,
-               c.g(cp.ln[i].g), c.g(cp.ln[i].b), c.g(cp.dw[i])};
-    if (c.fuse_row && i > 0) {
-      cb.dz = c.buf("d." + tag + ".z" + std::to_string(i - 1), R, HUAL_D);
-      cb.dz_site = site0 + i - 1; cb.dz_row0 = 0;
-      cb.dz_relu = c.buf(tag + ".y" + std::to_string(i - 1), R, HUAL_D);
-    }
-    c.dwconv_ln_bwd(cb, rs);
-    dx = dxin;
-  }
-  return dx;
 }
 
 // ======================================================================================================
@@ -577,16 +370,13 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
   c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
   c.PT = c.buf("params.T", pm.total, 1);
-  if (!c.dry && c.ok() && c.use_bf16) {
+  if (!c.dry && c.ok()) {
     std::vector<uint32_t> offs, boffs;
     std::vector<int> Ks;
     for (const auto& d : c.dense) { offs.push_back((uint32_t)d.off); Ks.push_back(d.K); boffs.push_back((uint32_t)d.boff); }
     PackExtra ex{bt->video_seq_len, bt->word_ids, rowmask, loss_acc, B, T, L, (lab && opt->grads_prezero) ? opt->grads_prezero : nullptr,
                  (size_t)((pm.total + 3) & ~(size_t)3)};
     c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex));
-  } else if (!c.dry) {
-    HUAL_LAUNCH(0.0, 0.0, prep_masks_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.stream, bt->video_seq_len, bt->word_ids,
-                rowmask, B, T, L, loss_acc);
   }
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
   c.stage(ST_INPUT);
@@ -662,7 +452,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* qkv = c.buf(t + ".qkv", R, 3 * D);
     float* ktvt = c.buf(t + ".ktvt", R, 2 * D);
     auto img = [&](size_t off) { return reinterpret_cast<const float*>(c.PKF + off * 4); };
-    if (c.fuse_da) {       // layer norms + the five projections in one launch (dablock.h)
+    {                      // layer norms + the five projections in one launch (dablock.h)
       LnProjArgs lp{};
       lp.x = x; lp.g1 = c.p(d.ln1.g); lp.b1 = c.p(d.ln1.b); lp.y1 = ln1; lp.drop_site1 = -1; lp.pre_site = -1;
       lp.g2 = c.p(d.lnt.g); lp.b2 = c.p(d.lnt.b); lp.y2 = lnt; lp.mean = mean; lp.rstd = rstd;
@@ -674,25 +464,6 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
         lp.out_site[k] = -1;
       }
       if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
-    } else {
-      GemmJob j[5];
-      // both layer norms of x (layers.py:73-74) run in the projections' A prologue; job 0 / 3 keep ln1 / lnt + statistics
-      j[0] = mkjob(x, D, R, D, c.p(d.query.k), c.p(d.query.b), qkv, 3 * D);
-      j[1] = mkjob(x, D, R, D, c.p(d.f_key.k), c.p(d.f_key.b), qkv + D, 3 * D);
-      j[2] = mkjob(x, D, R, D, c.p(d.f_value.k), c.p(d.f_value.b), qkv + 2 * D, 3 * D);
-      j[3] = mkjob(x, D, R, D, c.p(d.t_key.k), c.p(d.t_key.b), ktvt, 2 * D);
-      j[4] = mkjob(x, D, R, D, c.p(d.t_value.k), c.p(d.t_value.b), ktvt + D, 2 * D);
-      if (c.fuse_ln) {
-        for (int k = 0; k < 3; ++k) set_ln(j[k], c.p(d.ln1.g), c.p(d.ln1.b), k == 0 ? mean : nullptr, k == 0 ? rstd : nullptr, k == 0 ? ln1 : nullptr, -1);
-        for (int k = 3; k < 5; ++k) set_ln(j[k], c.p(d.lnt.g), c.p(d.lnt.b), nullptr, nullptr, k == 3 ? lnt : nullptr, -1);
-      } else {
-        LnFwd a{};
-        a.x = x; a.R = R; a.g1 = c.p(d.ln1.g); a.b1 = c.p(d.ln1.b); a.y1 = ln1; a.g2 = c.p(d.lnt.g); a.b2 = c.p(d.lnt.b);
-        a.y2 = lnt; a.mean = mean; a.rstd = rstd; a.drop_site = -1;
-        c.ln_fwd(a, rs);
-        for (int k = 0; k < 5; ++k) j[k].A[0] = k < 3 ? ln1 : lnt;
-      }
-      c.gemm(j, 5);
     }
     float* s_att = c.act(t + ".s_att");
     float* x_att = c.act(t + ".x_att");
@@ -731,7 +502,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* mean2 = c.vec(t + ".mean2");
     float* rstd2 = c.vec(t + ".rstd2");
     float* xo = c.act(t + ".out");
-    if (c.fuse_da) {       // the whole chain behind the attention kernels in one launch (dablock.h)
+    {                      // the whole chain behind the attention kernels in one launch (dablock.h)
       DaPostArgs pa{};
       pa.s_att = s_att; pa.x_att = x_att; pa.ln1 = ln1; pa.x = x; pa.rowmask = rowmask;
       const size_t wo[11] = {d.s_dense.k, d.x_dense.k, d.s_gate.k, d.x_gate.k, d.guided.k, d.bl1_d1, d.bl1_d2, d.bl2_d1, d.bl2_d2,
@@ -744,36 +515,6 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       pa.l2 = l2; pa.out = xo; pa.mean2 = mean2; pa.rstd2 = rstd2;
       pa.site = site; pa.R = R; pa.MT = da_post_rows(R); pa.drop_row0 = 0;
       if (c.live()) c.chk(launch_da_post(pa, c.drop, c.stream));
-    } else {
-    {
-      GemmJob j[6];
-      j[0] = mkjob(s_att, D, R, D, c.p(d.s_dense.k), c.p(d.s_dense.b), sv, D);
-      j[1] = mkjob(x_att, D, R, D, c.p(d.x_dense.k), c.p(d.x_dense.b), xv, D);
-      j[2] = mkjob(sv, D, R, D, c.p(d.s_gate.k), c.p(d.s_gate.b), o, D);
-      j[2].act = ACT_SIGMOID;
-      j[2].comb = COMB_CROSSGATE;
-      j[2].Ab[0] = xv; j[2].ldab[0] = D; j[2].W2[0] = c.p(d.x_gate.k); j[2].bias2 = c.p(d.x_gate.b);
-      j[2].save = sg; j[2].ldsave = D; j[2].save2 = xg; j[2].ldsave2 = D;
-      j[2].aux1 = xv; j[2].aux2 = sv; j[2].ldaux = D;      // o = sg * x + xg * s   (layers.py:101-103)
-      j[3] = mkjob(o, D, R, D, c.p(d.guided.k), c.p(d.guided.b), gd, D);
-      j[4] = mkjob(ln1, D, R, D, c.p(d.bl1_d1), c.p(d.bl1_b), mha, D);
-      j[4].npieces = 2;
-      j[4].A[1] = gd; j[4].lda[1] = D; j[4].kw[1] = D; j[4].W[1] = c.p(d.bl1_d2);
-      j[4].act = ACT_SIGMOID_ROWMASK; j[4].rowmask = rowmask;
-      j[4].comb = COMB_GATE_VAL;
-      j[4].W2[0] = c.p(d.bl2_d1); j[4].W2[1] = c.p(d.bl2_d2); j[4].bias2 = c.p(d.bl2_b);
-      j[4].save = gate; j[4].ldsave = D; j[4].save2 = val; j[4].ldsave2 = D;
-      j[5] = mkjob(mha, D, R, D, c.p(d.dense1.k), c.p(d.dense1.b), res, D);
-      j[5].drop_site = site + 2; j[5].add = x; j[5].ldadd = D;
-      const int gsz[5] = {2, 1, 1, 1, 1};
-      c.gemm_chain(j, gsz, 5);
-    }
-    {
-      GemmJob j = mkjob(res, D, R, D, c.p(d.dense2.k), c.p(d.dense2.b), xo, D);
-      ln_into_jobs(c, &j, 1, res, R, rs, c.p(d.ln2.g), c.p(d.ln2.b), mean2, rstd2, l2, site + 3);
-      j.drop_site = site + 4; j.add = res; j.ldadd = D;
-      c.gemm(&j, 1);
-    }
     }
     x = xo;
   }
@@ -841,7 +582,6 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* d_that = c.buf("d.align.that", B, D);
   float* d_vhat = c.buf("d.align.vhat", B, D);
   float* align_scratch = c.buf("align.scratch", (size_t)2 * B, B);
-  c.align_forked = false;
   if (lab && c.live() && !opt->align_external) {
     AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, d_that, d_vhat, loss_acc, 1.0f, D, 0, B};
     c.chk(launch_align_sim(as, c.stream));
@@ -860,7 +600,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* rstd = c.buf(t + ".ln1.rstd", Nv, 1);
     float* qkv = c.buf(t + ".qkv", Nv, 3 * D);
     auto img = [&](size_t off) { return reinterpret_cast<const float*>(c.PKF + off * 4); };
-    if (c.fuse_da) {       // layer_norm_1 + dropout + query / key / value in one launch (dablock.h)
+    {                      // layer_norm_1 + dropout + query / key / value in one launch (dablock.h)
       LnProjArgs lp{};
       lp.x = f; lp.g1 = c.p(pm.fe_ln1.g); lp.b1 = c.p(pm.fe_ln1.b); lp.y1 = a1; lp.drop_site1 = site + 4; lp.pre_site = -1;
       lp.mean = mean; lp.rstd = rstd; lp.nproj = 3; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
@@ -869,13 +609,6 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
         lp.wimg[k] = img(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = qkv + k * D; lp.ldo[k] = 3 * D; lp.out_site[k] = -1;
       }
       if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
-    } else {
-      GemmJob j[3];
-      j[0] = mkjob(f, D, Nv, D, c.p(pm.fe_q.k), c.p(pm.fe_q.b), qkv, 3 * D);
-      j[1] = mkjob(f, D, Nv, D, c.p(pm.fe_k.k), c.p(pm.fe_k.b), qkv + D, 3 * D);
-      j[2] = mkjob(f, D, Nv, D, c.p(pm.fe_v.k), c.p(pm.fe_v.b), qkv + 2 * D, 3 * D);
-      ln_into_jobs(c, j, 3, f, Nv, c.rsv, c.p(pm.fe_ln1.g), c.p(pm.fe_ln1.b), mean, rstd, a1, site + 4);
-      c.gemm(j, 3);
     }
     float* att = c.actv(t + ".att");
     {
@@ -892,23 +625,13 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* mean2 = c.buf(t + ".ln2.mean", Nv, 1);
     float* rstd2 = c.buf(t + ".ln2.rstd", Nv, 1);
     float* fo = c.actv(t + ".out");
-    if (c.fuse_da) {       // residual + layer_norm_2 + dropout + dense + dropout + residual in one launch (modules.py:132-139)
+    {                      // residual + layer_norm_2 + dropout + dense + dropout + residual in one launch (modules.py:132-139)
       LnProjArgs lp{};
       lp.x = f; lp.xa = att; lp.pre_site = site + 6; lp.x_out = res;
       lp.g1 = c.p(pm.fe_ln2.g); lp.b1 = c.p(pm.fe_ln2.b); lp.y1 = l2; lp.drop_site1 = site + 7; lp.mean = mean2; lp.rstd = rstd2;
       lp.nproj = 1; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
       lp.wimg[0] = img(pm.fe_dense.k); lp.bias[0] = c.p(pm.fe_dense.b); lp.out[0] = fo; lp.ldo[0] = D; lp.out_site[0] = site + 8; lp.add_x[0] = 1;
       if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
-    } else {
-      {
-        EwArgs e{};
-        e.op = EW_DROP_ADD; e.R = Nv; e.a = att; e.b = f; e.out = res; e.drop_site = site + 6; e.drop_row0 = 0;
-        c.ew(e);
-      }
-      GemmJob j = mkjob(res, D, Nv, D, c.p(pm.fe_dense.k), c.p(pm.fe_dense.b), fo, D);
-      ln_into_jobs(c, &j, 1, res, Nv, c.rsv, c.p(pm.fe_ln2.g), c.p(pm.fe_ln2.b), mean2, rstd2, l2, site + 7);
-      j.drop_site = site + 8; j.add = res; j.ldadd = D;
-      c.gemm(&j, 1);
     }
     feo[ps] = fo;
     fin = fo;
@@ -919,7 +642,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* hrstd = c.buf("head.rstd", (size_t)2 * Nv, 1);
   float* hs = c.actv("head.hs");
   float* he = c.actv("head.he");
-  if (c.fuse_da) {         // start / end layer norm + hidden layer ([LN(feats), outputs] . W + b, relu) (modules.py:152-157): one launch
+  {                        // start / end layer norm + hidden layer ([LN(feats), outputs] . W + b, relu) (modules.py:152-157): one launch
     LnProjArgs lp2[2];
     for (int h = 0; h < 2; ++h) {
       const DenseP& hp = h == 0 ? pm.shid : pm.ehid;
@@ -934,18 +657,6 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       lp2[h] = lp;
     }
     if (c.live()) c.chk(launch_ln_proj_pair(lp2[0], lp2[1], c.drop, c.stream));
-  } else {
-    GemmJob j[2];
-    // start / end layer norms (modules.py:152-153) in the A prologue
-    j[0] = mkjob(feo[0], D, Nv, D, c.p(pm.shid.k), c.p(pm.shid.b), hs, D);
-    ln_into_jobs(c, &j[0], 1, feo[0], Nv, c.rsv, c.p(pm.sln.g), c.p(pm.sln.b), hmean, hrstd, sfn, -1);
-    j[0].npieces = 2; j[0].A[1] = outputs; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.p(pm.shid.k) + (size_t)D * D;
-    j[0].act = ACT_RELU;
-    j[1] = mkjob(feo[1], D, Nv, D, c.p(pm.ehid.k), c.p(pm.ehid.b), he, D);
-    ln_into_jobs(c, &j[1], 1, feo[1], Nv, c.rsv, c.p(pm.eln.g), c.p(pm.eln.b), hmean + Nv, hrstd + Nv, efn, -1);
-    j[1].npieces = 2; j[1].A[1] = outputs; j[1].lda[1] = D; j[1].kw[1] = D; j[1].W[1] = c.p(pm.ehid.k) + (size_t)D * D;
-    j[1].act = ACT_RELU;
-    c.gemm(j, 2);
   }
   float* d_s = c.buf("d.s_logit", B, T);
   float* d_e = c.buf("d.e_logit", B, T);
@@ -983,41 +694,16 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   c.dwjobs.clear();
   c.colsum.clear();
   c.part_seq = 0;
-  c.dw_flushed = 0;
-  c.dw_flushes = 0;
   c.stage(ST_ALWAYS);
   // (a kernel, not hipMemsetAsync: memset nodes of a captured graph were seen to pick up the fill pattern of later eager
   //  memsets on this ROCm - every 4th gradient came back as the caller's learning rate)
-  if (c.live() && !(opt->grads_prezero && opt->grads_prezero == c.G && c.use_bf16 && c.sel_stage < 0))
+  if (c.live() && !(opt->grads_prezero && opt->grads_prezero == c.G && c.sel_stage < 0))
     c.chk(launch_zero(c.G, pm.total, c.stream));
-  // transposed copies of every dense weight that a dX product reads (weights are constant within a step)
-  float* PT = c.buf("params.T", pm.total, 1);
-  c.PT = PT;
+  // every dX product reads the image of the transposed weight that forward's pack launch left in the workspace (PKB);
+  // "params.T" is only the address range that names those weights (Ctx::PT)
+  c.PT = c.buf("params.T", pm.total, 1);
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
   c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
-  // with the split-bf16 kernel every dX product reads the image of the transposed weight that forward's pack launch left
-  // in the workspace; the fp32 transposed copies are only made for the fp32 kernels / the A-prologue fusion experiments
-  c.pt_skipped = c.use_bf16 && !c.fuse_ln && !c.fuse_bwd;
-  if (!c.dry && c.ok() && !c.pt_skipped) {
-    std::vector<uint32_t> offs;
-    std::vector<int> Ks, Ns;
-    auto add = [&](size_t off, int K, int N) { offs.push_back((uint32_t)off); Ks.push_back(K); Ns.push_back(N); };
-    add(pm.shid.k, 2 * D, D); add(pm.ehid.k, 2 * D, D);
-    add(pm.fe_dense.k, D, D); add(pm.fe_q.k, D, D); add(pm.fe_k.k, D, D); add(pm.fe_v.k, D, D);
-    for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D, D); add(pm.cb.pw[i], D, D); }
-    add(pm.cqcat.k, 2 * D, D); add(pm.cq[0].dense, 4 * D, D); add(pm.cq[1].dense, 4 * D, D);
-    add(pm.qconv.k, catw, D);
-    for (int li = 0; li < c.cfg->attn_layer; ++li) {
-      const DualAttnP& d = pm.da[li];
-      const size_t w[] = {d.dense1.k, d.dense2.k, d.bl1_d1, d.bl1_d2, d.bl2_d1, d.bl2_d2, d.guided.k, d.s_gate.k, d.x_gate.k,
-                          d.s_dense.k, d.x_dense.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
-      for (size_t o : w) add(o, D, D);
-    }
-    for (size_t base = 0; base < offs.size() && c.ok(); base += 96) {
-      const int cnt = (int)std::min<size_t>(96, offs.size() - base);
-      c.chk(launch_transpose_weights(offs.data() + base, Ks.data() + base, Ns.data() + base, cnt, c.P, PT, c.stream));
-    }
-  }
   float* outputs = c.actv("outputs");
   // ---------------- heads
   c.stage(ST_PRED);
@@ -1062,7 +748,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     LnBwd a{};
     a.x = c.actv("fe1.out"); a.mean = hmean + Nv; a.rstd = hrstd + Nv; a.R = Nv; a.dy1 = d_efn; a.g1 = c.p(pm.eln.g);
     a.dg1 = c.g(pm.eln.g); a.db1 = c.g(pm.eln.b); a.drop_site1 = -1; a.dx = d_feout;
-    if (c.fuse_row) { a.dz = c.actv("d.fe1.zd"); a.dz_site = HUAL_SITE_FE + 16 + 8; }
+    a.dz = c.actv("d.fe1.zd"); a.dz_site = HUAL_SITE_FE + 16 + 8;      // dropout'(.) of it for the dense^T product below
     c.ln_bwd(a);
   }
   float* d_in = nullptr;
@@ -1086,38 +772,24 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       LnBwd a{};
       a.x = c.actv("fe0.out"); a.mean = hmean; a.rstd = hrstd; a.R = Nv; a.dy1 = d_sfn; a.g1 = c.p(pm.sln.g);
       a.dg1 = c.g(pm.sln.g); a.db1 = c.g(pm.sln.b); a.drop_site1 = -1; a.add1 = d_in; a.dx = d0;
-      if (c.fuse_row) { a.dz = c.actv("d.fe0.zd"); a.dz_site = HUAL_SITE_FE + 8; }
+      a.dz = c.actv("d.fe0.zd"); a.dz_site = HUAL_SITE_FE + 8;
       c.ln_bwd(a);
       d_feout = d0;
     }
     // out = dropout(l2 . Wd + b, s8) + res
     float* dzd = c.actv("d." + t + ".zd");
     c.push_dw(mkdw(l2, D, D, dzd, D, Nv, c.g(pm.fe_dense.k), c.g(pm.fe_dense.b)));
-    float* d_l2 = c.actv("d." + t + ".l2");
     float* d_res = c.actv("d." + t + ".res");
     auto imgt = [&](size_t off) { return reinterpret_cast<const float*>(c.PKB + off * 4); };
-    if (c.fuse_da) {       // dense^T + layer_norm_2 backward in one launch (dablock.h); dZ of the dense layer came from upstream
+    {                      // dense^T + layer_norm_2 backward in one launch (dablock.h); dZ of the dense layer came from upstream
       LnProjBwdArgs lb{};
       lb.nsteps = 1; lb.A[0] = dzd; lb.lda[0] = D; lb.a_site[0] = -1; lb.wimg_t[0] = imgt(pm.fe_dense.k); lb.dst[0] = 0;
       lb.dy1_site = site + 7; lb.x = res; lb.mean = mean2; lb.rstd = rstd2; lb.g1 = c.p(pm.fe_ln2.g); lb.add1 = d_feout;
       lb.dx = d_res; lb.dz = c.actv("d." + t + ".att"); lb.dz_site = site + 6; lb.R = Nv; lb.drop_row0 = 0;
       c.ln_proj_bwd(lb, c.g(pm.fe_ln2.g), c.g(pm.fe_ln2.b), nullptr, nullptr);
-    } else {
-      dx_after_dropout(c, d_feout, dzd, Nv, site + 8, c.pt(pm.fe_dense.k), d_l2, c.fuse_row);
-      LnBwd a{};
-      a.x = res; a.mean = mean2; a.rstd = rstd2; a.R = Nv; a.dy1 = d_l2; a.g1 = c.p(pm.fe_ln2.g);
-      a.dg1 = c.g(pm.fe_ln2.g); a.db1 = c.g(pm.fe_ln2.b); a.drop_site1 = site + 7; a.drop_row0 = 0; a.add1 = d_feout;
-      a.dx = d_res;
-      if (c.fuse_row) { a.dz = c.actv("d." + t + ".att"); a.dz_site = site + 6; }
-      c.ln_bwd(a);
     }
-    // res = dropout(att, s6) + f
+    // res = dropout(att, s6) + f: dropout'(d res) was written by the launch above
     float* d_att = c.actv("d." + t + ".att");
-    if (!c.fuse_row) {
-      EwArgs e{};
-      e.op = EW_DROP; e.R = Nv; e.a = d_res; e.out = d_att; e.drop_site = site + 6; e.drop_row0 = 0;
-      c.ew(e);
-    }
     float* d_qkv = c.buf("d." + t + ".qkv", Nv, 3 * D);
     {
       AttnJob a;
@@ -1133,37 +805,20 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.push_dw(mkdw(a1, D, D, d_qkv, 3 * D, Nv, c.g(pm.fe_q.k), c.g(pm.fe_q.b)));
     c.push_dw(mkdw(a1, D, D, d_qkv + D, 3 * D, Nv, c.g(pm.fe_k.k), c.g(pm.fe_k.b)));
     c.push_dw(mkdw(a1, D, D, d_qkv + 2 * D, 3 * D, Nv, c.g(pm.fe_v.k), c.g(pm.fe_v.b)));
-    float* d_a = c.actv("d." + t + ".a");
     float* d_f = c.actv("d." + t + ".x4");
-    if (c.fuse_da) {       // query / key / value ^T + layer_norm_1 backward in one launch
+    {                      // query / key / value ^T + layer_norm_1 backward in one launch
       LnProjBwdArgs lb{};
       lb.nsteps = 3;
       const size_t wo[3] = {pm.fe_q.k, pm.fe_k.k, pm.fe_v.k};
       for (int k = 0; k < 3; ++k) { lb.A[k] = d_qkv + k * D; lb.lda[k] = 3 * D; lb.a_site[k] = -1; lb.wimg_t[k] = imgt(wo[k]); lb.dst[k] = 0; }
       lb.dy1_site = site + 4; lb.x = f; lb.mean = mean; lb.rstd = rstd; lb.g1 = c.p(pm.fe_ln1.g); lb.add1 = d_res;
       lb.dx = d_f; lb.dz_site = -1; lb.R = Nv; lb.drop_row0 = 0;
-      if (!c.fuse_cb) { lb.dz = c.actv("d." + t + ".z3"); lb.dz_site = site + 3; lb.dz_relu = c.actv(t + ".y3"); }
       c.ln_proj_bwd(lb, c.g(pm.fe_ln1.g), c.g(pm.fe_ln1.b), nullptr, nullptr);
-    } else {
-      {
-        GemmJob j = mkjob_dx(d_qkv, 3 * D, Nv, D, c.pt(pm.fe_q.k), D, d_a, D);
-        j.npieces = 3;
-        j.A[1] = d_qkv + D; j.lda[1] = 3 * D; j.kw[1] = D; j.W[1] = c.pt(pm.fe_k.k);
-        j.A[2] = d_qkv + 2 * D; j.lda[2] = 3 * D; j.kw[2] = D; j.W[2] = c.pt(pm.fe_v.k);
-        c.gemm(&j, 1);
-      }
-      LnBwd a{};
-      a.x = f; a.mean = mean; a.rstd = rstd; a.R = Nv; a.dy1 = d_a; a.g1 = c.p(pm.fe_ln1.g);
-      a.dg1 = c.g(pm.fe_ln1.g); a.db1 = c.g(pm.fe_ln1.b); a.drop_site1 = site + 4; a.drop_row0 = 0; a.add1 = d_res;
-      a.dx = d_f;
-      if (c.fuse_row && !c.fuse_cb) { a.dz = c.actv("d." + t + ".z3"); a.dz_site = site + 3; a.dz_relu = c.actv(t + ".y3"); }
-      c.ln_bwd(a);
     }
-    float* d_x0 = conv_block_bwd(c, t, x0, d_f, pm.fe_cb, c.rsv, site, c.fuse_row);
+    float* d_x0 = conv_block_bwd(c, t, x0, d_f, pm.fe_cb, c.rsv, site);
     fe_dx0[ps] = d_x0;            // the position-table gradients of the step are summed in ONE launch at the end
     d_in = d_x0;
   }
-  flush_dw(c);
   // ---------------- gradient wrt `outputs`, matching head
   c.stage(ST_FUSE);
   // (gradient wrt `outputs` = what the encoders sent back + what the two hidden layers of the heads sent back: summed by
@@ -1274,7 +929,6 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     if (c.ok()) c.chk(launch_cq_bwd_impl(cq, cg, c.rs, dXa, dXb, c.stream));
     if (c.ok()) c.chk(launch_tri_bwd_impl(cq, cg, cqp, tri_part, c.rs, c.drop, dXa, dXb, c.stream));
   }
-  flush_dw(c);
   float* dx = cg.dX;
   // ---------------- dual attention layers, last to first
   for (int li = c.cfg->attn_layer - 1; li >= 0; --li) {
@@ -1308,25 +962,20 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     // out = dropout(l2 . Wd2 + b, s4) + res
     float* dz2 = c.act(dt + ".z2");
     c.push_dw(mkdw(l2, D, D, dz2, D, R, c.g(d.dense2.k), c.g(d.dense2.b)));
-    float* d_l2 = c.act(dt + ".l2");
     float* d_res = c.act(dt + ".res");
     float* dz1 = c.act(dt + ".z1");
-    float* d_mha = c.act(dt + ".mha");
     float* d_sc = c.act(dt + ".sc");
     float* d_val = c.act(dt + ".val");
     float* d_ln1a = c.act(dt + ".ln1a");
     float* d_g = c.act(dt + ".g");
-    float* d_o = c.act(dt + ".o");
     float* dz_sg = c.act(dt + ".zsg");
     float* dz_xg = c.act(dt + ".zxg");
-    float* ds_part = c.act(dt + ".sp");
-    float* dx_part = c.act(dt + ".xp");
     float* d_sv = c.act(dt + ".s");
     float* d_xv = c.act(dt + ".x");
     float* d_satt = c.act(dt + ".s_att");
     float* d_xatt = c.act(dt + ".x_att");
     auto imgt = [&](size_t off) { return reinterpret_cast<const float*>(c.PKB + off * 4); };
-    const bool dz2_ready = c.fuse_row && li < c.cfg->attn_layer - 1 && c.sel_stage < 0;     // the layer above left dropout'(dx) in dz2
+    const bool dz2_ready = li < c.cfg->attn_layer - 1 && c.sel_stage < 0;     // the layer above left dropout'(dx) in dz2
     // weight-gradient jobs of this half of the block (operands are written by whichever path runs below)
     c.push_dw(mkdw(mha, D, D, dz1, D, R, c.g(d.dense1.k), c.g(d.dense1.b)));
     for (int k = 0; k < 2; ++k) {
@@ -1339,7 +988,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.push_dw(mkdw(xv, D, D, dz_xg, D, R, c.g(d.x_gate.k), c.g(d.x_gate.b)));
     c.push_dw(mkdw(s_att, D, D, d_sv, D, R, c.g(d.s_dense.k), c.g(d.s_dense.b)));
     c.push_dw(mkdw(x_att, D, D, d_xv, D, R, c.g(d.x_dense.k), c.g(d.x_dense.b)));
-    if (c.fuse_da) {
+    {
       // (1) dense_2^T + layer_norm_2 backward -> d res, dZ1     (2) the gated middle, ten weight steps     (dablock.h)
       LnProjBwdArgs lb{};
       lb.nsteps = 1; lb.lda[0] = D; lb.wimg_t[0] = imgt(d.dense2.k); lb.dst[0] = 0;
@@ -1355,57 +1004,6 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       mb.d_sc = d_sc; mb.d_val = d_val; mb.d_ln1a = d_ln1a; mb.d_g = d_g; mb.dz_sg = dz_sg; mb.dz_xg = dz_xg; mb.d_sv = d_sv; mb.d_xv = d_xv;
       mb.d_satt = d_satt; mb.d_xatt = d_xatt; mb.R = R; mb.MT = da_post_rows(R);
       if (c.live()) c.chk(launch_da_mid_bwd(mb, c.stream));
-    } else {
-    dx_after_dropout(c, dx, dz2, R, site + 4, c.pt(d.dense2.k), d_l2, dz2_ready);
-    {
-      LnBwd a{};
-      a.x = res; a.mean = mean2; a.rstd = rstd2; a.R = R; a.dy1 = d_l2; a.g1 = c.p(d.ln2.g); a.dg1 = c.g(d.ln2.g);
-      a.db1 = c.g(d.ln2.b); a.drop_site1 = site + 3; a.drop_row0 = 0; a.add1 = dx; a.dx = d_res;
-      if (c.fuse_row) { a.dz = c.act(dt + ".z1"); a.dz_site = site + 2; }
-      c.ln_bwd(a);
-    }
-    // res = dropout(mha . Wd1 + b, s2) + xin
-    dx_after_dropout(c, d_res, dz1, R, site + 2, c.pt(d.dense1.k), d_mha, c.fuse_row);
-    // mha = gate * val
-    {
-      EwArgs e{};
-      e.op = EW_BILINEAR_BWD; e.R = R; e.a = d_mha; e.b = gate; e.c = val; e.out = d_sc; e.out2 = d_val; e.drop_site = -1;
-      c.ew(e);
-    }
-    {
-      GemmJob j[2];
-      j[0] = mkjob_dx(d_sc, D, R, D, c.pt(d.bl1_d1), D, d_ln1a, D);
-      j[0].npieces = 2; j[0].A[1] = d_val; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.pt(d.bl2_d1);
-      j[1] = mkjob_dx(d_sc, D, R, D, c.pt(d.bl1_d2), D, d_g, D);
-      j[1].npieces = 2; j[1].A[1] = d_val; j[1].lda[1] = D; j[1].kw[1] = D; j[1].W[1] = c.pt(d.bl2_d2);
-      c.gemm(j, 2);
-    }
-    // g = o . Wg + b
-    {
-      GemmJob j = mkjob_dx(d_g, D, R, D, c.pt(d.guided.k), D, d_o, D);
-      c.gemm(&j, 1);
-    }
-    // o = sg * x + xg * s
-    {
-      EwArgs e{};
-      e.op = EW_GATE_BWD; e.R = R; e.a = d_o; e.b = sg; e.c = xg; e.d = sv; e.e = xv;
-      e.out = dz_sg; e.out2 = dz_xg; e.out3 = ds_part; e.out4 = dx_part; e.drop_site = -1;
-      c.ew(e);
-    }
-    {
-      GemmJob j[2];
-      j[0] = mkjob_dx(dz_sg, D, R, D, c.pt(d.s_gate.k), D, d_sv, D);
-      j[0].add = ds_part; j[0].ldadd = D;
-      j[1] = mkjob_dx(dz_xg, D, R, D, c.pt(d.x_gate.k), D, d_xv, D);
-      j[1].add = dx_part; j[1].ldadd = D;
-      c.gemm(j, 2);
-    }
-    {
-      GemmJob j[2];
-      j[0] = mkjob_dx(d_sv, D, R, D, c.pt(d.s_dense.k), D, d_satt, D);
-      j[1] = mkjob_dx(d_xv, D, R, D, c.pt(d.x_dense.k), D, d_xatt, D);
-      c.gemm(j, 2);
-    }
     }
     // the four attentions
     float* dq_self = c.act(dt + ".q_self");
@@ -1436,16 +1034,11 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.push_dw(mkdw(ln1, D, D, d_qkv + 2 * D, 3 * D, R, c.g(d.f_value.k), c.g(d.f_value.b)));
     c.push_dw(mkdw(lnt, D, D, d_ktvt, 2 * D, R, c.g(d.t_key.k), c.g(d.t_key.b)));
     c.push_dw(mkdw(lnt, D, D, d_ktvt + D, 2 * D, R, c.g(d.t_value.k), c.g(d.t_value.b)));
-    float* d_ln1 = c.act(dt + ".ln1");
-    float* d_lnt = c.act(dt + ".lnt");
     float* d_xin = c.act(dt + ".in");
     // operand of the next dX product down the stack: previous layer's dense_2, or (unfused conv block) its layer 3
     float* nz = nullptr; int nz_site = -1; const float* nz_relu = nullptr;
-    if (c.fuse_row) {
-      if (li > 0) { nz = c.act("d.da" + std::to_string(li - 1) + ".z2"); nz_site = HUAL_SITE_DA + 8 * (li - 1) + 4; }
-      else if (!c.fuse_cb) { nz = c.act("d.cb.z3"); nz_site = HUAL_SITE_CONV + 3; nz_relu = c.act("cb.y3"); }
-    }
-    if (c.fuse_da) {       // the six projection^T products + layer_norm_1 / layer_norm_t backward in one launch (dablock.h)
+    if (li > 0) { nz = c.act("d.da" + std::to_string(li - 1) + ".z2"); nz_site = HUAL_SITE_DA + 8 * (li - 1) + 4; }
+    {                      // the six projection^T products + layer_norm_1 / layer_norm_t backward in one launch (dablock.h)
       LnProjBwdArgs lb{};
       lb.nsteps = 6;
       const float* As[6] = {dq_self, dq_cross, d_qkv + D, d_qkv + 2 * D, d_ktvt, d_ktvt + D};
@@ -1455,36 +1048,13 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       lb.add_dy1 = d_ln1a; lb.dy1_site = -1; lb.x = xin; lb.mean = mean; lb.rstd = rstd; lb.g1 = c.p(d.ln1.g); lb.g2 = c.p(d.lnt.g);
       lb.add1 = d_res; lb.dx = d_xin; lb.dz = nz; lb.dz_site = nz_site; lb.dz_relu = nz_relu; lb.R = R; lb.drop_row0 = 0;
       c.ln_proj_bwd(lb, c.g(d.ln1.g), c.g(d.ln1.b), c.g(d.lnt.g), c.g(d.lnt.b));
-    } else {
-    {
-      GemmJob j[2];
-      j[0] = mkjob_dx(dq_self, D, R, D, c.pt(d.query.k), D, d_ln1, D);
-      j[0].npieces = 4;
-      j[0].A[1] = dq_cross; j[0].lda[1] = D; j[0].kw[1] = D; j[0].W[1] = c.pt(d.query.k);
-      j[0].A[2] = d_qkv + D; j[0].lda[2] = 3 * D; j[0].kw[2] = D; j[0].W[2] = c.pt(d.f_key.k);
-      j[0].A[3] = d_qkv + 2 * D; j[0].lda[3] = 3 * D; j[0].kw[3] = D; j[0].W[3] = c.pt(d.f_value.k);
-      j[0].add = d_ln1a; j[0].ldadd = D;
-      j[1] = mkjob_dx(d_ktvt, 2 * D, R, D, c.pt(d.t_key.k), D, d_lnt, D);
-      j[1].npieces = 2;
-      j[1].A[1] = d_ktvt + D; j[1].lda[1] = 2 * D; j[1].kw[1] = D; j[1].W[1] = c.pt(d.t_value.k);
-      c.gemm(j, 2);
-    }
-    {
-      LnBwd a{};
-      a.x = xin; a.mean = mean; a.rstd = rstd; a.R = R; a.dy1 = d_ln1; a.g1 = c.p(d.ln1.g); a.dg1 = c.g(d.ln1.g);
-      a.db1 = c.g(d.ln1.b); a.drop_site1 = -1; a.dy2 = d_lnt; a.g2 = c.p(d.lnt.g); a.dg2 = c.g(d.lnt.g); a.db2 = c.g(d.lnt.b);
-      a.add1 = d_res; a.dx = d_xin;
-      a.dz = nz; a.dz_site = nz_site; a.dz_relu = nz_relu;
-      c.ln_bwd(a);
-    }
     }
     dx = d_xin;
-    flush_dw(c);
   }
   // ---------------- shared conv block, position table, input layer norms, projections
   float* x0 = c.act("cb.x0");
   c.stage(ST_CONV);
-  float* d_x0 = conv_block_bwd(c, "cb", x0, dx, pm.cb, c.rs, HUAL_SITE_CONV, c.fuse_row && c.cfg->attn_layer > 0 && c.sel_stage < 0);
+  float* d_x0 = conv_block_bwd(c, "cb", x0, dx, pm.cb, c.rs, HUAL_SITE_CONV);
   c.stage(ST_ALWAYS);
   if (c.live()) {      // position-table gradients of the stages that ran
     PosBwdJob pj[2];
@@ -1543,8 +1113,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   const bool input_ran = c.active;
   c.stage(ST_ALWAYS);
   c.flush_colsum();       // layer-norm / depthwise-conv parameter gradients: one reduction of the per-block partial sums
-  flush_dw(c, true);      // every dense / conv weight gradient of the step: one launch
-  join_aux(c);
+  flush_dw(c);            // every dense / conv weight gradient of the step: one launch
   if (c.live() && input_ran) c.chk(launch_embed_unpack(ea, eg, c.stream));
   (void)opt;
   return c.rc;
@@ -1674,33 +1243,12 @@ int hual_seqpan_backward(const hual_cfg* cfg, const float* params, const float* 
   c.stream = (hipStream_t)stream;
   c.P = params;
   c.G = grads;
-  c.aux = opts->aux;
   c.static_tables = opts->static_tables != 0;
   c.word_table = word_table;
   c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
   c.rs.rowmask = c.vec("rowmask");
   c.rsv.rowmask = c.rs.rowmask;
   return backward_graph(c, batch, labels, opts);
-}
-
-int hual_aux_create(hual_aux* aux) {
-  HUAL_REQUIRE(aux != nullptr, "hual_aux_create: null");
-  hipStream_t st;
-  hipEvent_t e1, e2;
-  HUAL_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  HUAL_CHECK_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-  HUAL_CHECK_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-  aux->stream = st; aux->ev_fork = e1; aux->ev_join = e2;
-  return 0;
-}
-
-int hual_aux_destroy(hual_aux* aux) {
-  if (!aux) return 0;
-  if (aux->ev_fork) hipEventDestroy((hipEvent_t)aux->ev_fork);
-  if (aux->ev_join) hipEventDestroy((hipEvent_t)aux->ev_join);
-  if (aux->stream) hipStreamDestroy((hipStream_t)aux->stream);
-  aux->stream = aux->ev_fork = aux->ev_join = nullptr;
-  return 0;
 }
 
 int hual_adamw_clip_step(float* params, const float* grads, float* adam_m, float* adam_v, const float* decay,
@@ -1750,8 +1298,6 @@ int run_block(const hual_cfg* cfg, const float* params, const float* word_table,
   int rc = check_common(cfg, params, batch, opts, workspace);
   if (rc) return rc;
   HUAL_REQUIRE(!backward || (grads != nullptr && ((uintptr_t)grads & 15) == 0), "null/unaligned grads");
-  { const char* e1 = getenv("HUAL_FUSE_CB"); const char* e2 = getenv("HUAL_FUSE_DA"); const char* e3 = getenv("HUAL_FUSE_ROW");
-    HUAL_REQUIRE(!(e1 && atoi(e1) == 0) && !(e2 && atoi(e2) == 0) && !(e3 && atoi(e3) == 0), "block entry points need the default kernel-fusion switches"); }
   Ctx c;
   rc = plan(c, cfg, batch->B, batch->T, batch->L, batch->C);
   if (rc) return rc;
@@ -1792,9 +1338,7 @@ int run_block(const hual_cfg* cfg, const float* params, const float* word_table,
     if (sum2_out && &k == &post.back() && post.size() == 2) {      // last two entries: dst = first + second (predictor backward)
       float* a; size_t ca;
       if ((rc = locate(post[0], a, ca))) return rc;
-      EwArgs e{};
-      e.op = EW_ADD; e.R = (int)k.rows; e.a = a; e.b = ptr; e.out = k.dst; e.drop_site = -1;
-      return launch_ew(e, c.drop, c.stream);
+      return launch_add_rows(a, ptr, k.dst, (int)k.rows, c.stream);
     }
     if (sum2_out && post.size() == 2) continue;
     HUAL_CHECK_HIP(hipMemcpyAsync(k.dst, ptr, k.rows * cols * sizeof(float), hipMemcpyDeviceToDevice, c.stream));

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libhual_seqpan.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -43,13 +43,9 @@ class hual_outputs(ctypes.Structure):
                 ('start_index', ctypes.c_void_p), ('end_index', ctypes.c_void_p), ('loss_terms', ctypes.c_void_p)]
 
 
-class hual_aux(ctypes.Structure):
-    _fields_ = [('stream', ctypes.c_void_p), ('ev_fork', ctypes.c_void_p), ('ev_join', ctypes.c_void_p)]
-
-
 class hual_run_opts(ctypes.Structure):
     _fields_ = [('drop_rate', ctypes.c_float), ('rng_state', ctypes.c_void_p), ('match_denom_override', ctypes.c_float),
-                ('align_external', ctypes.c_int32), ('aux', ctypes.POINTER(hual_aux)), ('static_tables', ctypes.c_int32),
+                ('align_external', ctypes.c_int32), ('static_tables', ctypes.c_int32),
                 ('match_denom_dev', ctypes.c_void_p), ('grads_prezero', ctypes.c_void_p)]
 
 
@@ -113,9 +109,7 @@ def load():
     lib.hual_predictor_bwd.argtypes = blk + [vp, vp, vp, vp, vp, u64, vp]
     lib.hual_prof_get.argtypes = [i32, ctypes.c_char_p, i32, P(ctypes.c_int64), P(ctypes.c_double), P(ctypes.c_double),
                                   P(ctypes.c_double)]
-    lib.hual_aux_create.argtypes = [P(hual_aux)]
-    lib.hual_aux_destroy.argtypes = [P(hual_aux)]
-    lib.hual_linear_fwd.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.hual_linear_fwd.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.hual_linear_bf16x3.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, u64, vp]
     lib.hual_layer_norm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     lib.hual_attention_fwd.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp]
@@ -192,13 +186,12 @@ def ws_table(cfg, B, T, L, C):
 
 
 # ---------------------------------------------------------------- per-kernel entry points
-def linear_fwd(A, W, bias=None, act=0, trans_w=False, out=None):
+def linear_fwd(A, W, bias=None, act=0, out=None):
     import torch
     M, K = A.shape
-    N = W.shape[0] if trans_w else W.shape[1]
+    N = W.shape[1]
     Y = torch.empty(M, N, device=A.device, dtype=torch.float32) if out is None else out
-    check(load().hual_linear_fwd(ptr(A), A.stride(0), ptr(W), W.stride(0), int(trans_w), ptr(bias), ptr(Y),
-                                 Y.stride(0), M, K, N, act, stream_ptr()))
+    check(load().hual_linear_fwd(ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(Y), Y.stride(0), M, K, N, act, stream_ptr()))
     return Y
 
 
@@ -215,10 +208,10 @@ def linear_bf16x3(A, W, bias=None, act=0, trans_w=False):
     return Y
 
 
-def linear_dw(A, dY, dW, db=None, rows_per_block=1024):
+def linear_dw(A, dY, dW, db=None, workgroups=0):
     M, K = A.shape
     N = dY.shape[1]
     import torch
-    scratch = torch.empty(256, dtype=torch.float32, device=A.device) if rows_per_block < 0 else None
+    scratch = torch.empty(256, dtype=torch.float32, device=A.device)
     check(load().hual_linear_dw(ptr(A), A.stride(0), ptr(dY), dY.stride(0), ptr(dW), dW.stride(0), ptr(db), M, K, N,
-                                rows_per_block, ptr(scratch), 1024 if scratch is not None else 0, stream_ptr()))
+                                workgroups, ptr(scratch), 1024, stream_ptr()))

@@ -155,8 +155,7 @@ class SeqPAN:
         return lib.hual_labels(*[lib.ptr(x).value for x in t]), t
 
     def _opts(self, drop_rate, match_denom=0.0, align_external=0):
-        return lib.hual_run_opts(float(drop_rate), lib.ptr(self.rng_state).value, float(match_denom), int(align_external),
-                                 None, 0)
+        return lib.hual_run_opts(float(drop_rate), lib.ptr(self.rng_state).value, float(match_denom), int(align_external), 0)
 
     # ------------------------------------------------------------------ fetches
     def forward(self, video_inputs, video_seq_len, word_ids, char_ids, drop_rate=0.0, labels=None, _opts=None):

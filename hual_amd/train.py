@@ -14,7 +14,7 @@ from . import lib
 
 
 class Trainer:
-    def __init__(self, model, world=1, use_graph=True, force_dp=False, use_aux=False):
+    def __init__(self, model, world=1, use_graph=True, force_dp=False):
         self.m = model
         self.world = world
         self.dp = world > 1 or force_dp          # force_dp: run the data-parallel code path on one rank (tests)
@@ -24,14 +24,6 @@ class Trainer:
         self.shape = None
         self._tables_ready = False
         self._lib = lib.load()
-        # optional second stream + fork/join events (hual_run_opts.aux): the alignment-loss branch of forward runs there,
-        # under the predictor.  Measured on MI355X: 2.297 vs 2.300 ms/step - the main chain's launches fill every CU, so
-        # the side branch buys nothing and the option stays off.  (The weight-gradient launch on the side stream,
-        # HUAL_DW_AUX=1, costs +1.4 %.)
-        self.aux = None
-        if use_aux:
-            self.aux = lib.hual_aux()
-            lib.check(self._lib.hual_aux_create(ctypes.byref(self.aux)))
 
     # ------------------------------------------------------------------ static batch buffers
     def set_batch(self, video, lens, word_ids, char_ids, y1, y2, match_labels, inner_labels, video_dtype=torch.float32):
@@ -145,7 +137,7 @@ class Trainer:
         # static_tables: all buffers of this trainer are static per shape, so after one backward on them the job tables
         # in the workspace stay valid (hual_run_opts.static_tables)
         return lib.hual_run_opts(float(drop_rate), lib.ptr(self.m.rng_state).value, float(self.match_denom),
-                                 int(align_external), ctypes.pointer(self.aux) if self.aux is not None else None,
+                                 int(align_external),
                                  1 if (self._tables_ready and not os.environ.get('HUAL_NO_STATIC_TABLES')) else 0,
                                  lib.ptr(self.denom_dev).value if self.dp else None,
                                  # the forward's first launch zeroes the gradient bucket (one launch fewer in backward)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HUAL_ABI_VERSION 3
+#define HUAL_ABI_VERSION 4
 
 #define HUAL_OK 0
 #define HUAL_ERR_INVALID (-1)
@@ -120,24 +120,12 @@ typedef struct hual_outputs {
   float* loss_terms;              /* f32 [4]: loss, loc_loss, match_loss, align_loss (written only with labels) */
 } hual_outputs;
 
-/* Optional second stream for work that is independent of the critical path (the weight-gradient GEMMs of
- * backward run there while the dX chain continues on the main stream).  Caller-owned handles created with
- * hual_aux_create(); fork/join use the two events, so the pair can be captured into one hipGraph. */
-typedef struct hual_aux {
-  void* stream;                   /* hipStream_t */
-  void* ev_fork;                  /* hipEvent_t  */
-  void* ev_join;                  /* hipEvent_t  */
-} hual_aux;
-int hual_aux_create(hual_aux* aux);
-int hual_aux_destroy(hual_aux* aux);
-
 typedef struct hual_run_opts {
   float drop_rate;                /* the `dropout_rate` placeholder (0 = inference) */
   const uint32_t* rng_state;      /* device u32[3] = {seed lo, seed hi, offset}; may be NULL when drop_rate == 0 */
   float match_denom_override;     /* > 0: denominator of the masked matching loss (exact data parallel) */
   int32_t align_external;         /* 1: the [B,B] alignment loss is evaluated by the caller through
                                         hual_align_loss() on gathered features (exact data parallel) */
-  const hual_aux* aux;            /* NULL: everything on `stream` */
   int32_t static_tables;          /* 1: the caller guarantees that a previous hual_seqpan_backward ran with the SAME
                                         cfg, shapes, params / grads / workspace / batch pointers, so the device-resident
                                         job tables it left in the workspace are still valid and are not rewritten
@@ -239,10 +227,11 @@ int hual_predictor_bwd(const hual_cfg* cfg, const float* params, const hual_batc
  * ------------------------------------------------------------------------------------------ */
 
 /* conv1d(kernel_size=1) == dense  (models/layers.py:20-29):
- *   Y[M,N] = act(A[M,K] . W + bias),  W is [K,N] (trans_w=0) or [N,K] read transposed (trans_w=1, = dX of a dense)
- *   act: 0 none, 1 relu, 2 sigmoid.  K % 16 == 0, N % 64 == 0, leading dims % 4 == 0. */
-int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, int trans_w, const float* bias, float* Y,
-                    int ldy, int M, int K, int N, int act, void* stream);
+ *   Y[M,N] = act(A[M,K] . W[K,N] + bias) in exact fp32 on the matrix cores (the kernel of the char-CNN product);
+ *   act: 0 none, 1 relu, 2 sigmoid.  K % 16 == 0, N % 64 == 0, leading dims % 4 == 0.  (Products with a transposed
+ *   weight - dX of a dense layer - go through hual_linear_bf16x3, as in the model path.) */
+int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int K, int N,
+                    int act, void* stream);
 
 /* The same dense layer on the bf16 matrix cores with split operands (x = hi + lo, three MFMA passes, fp32 accumulate;
  * ~1e-6 relative to the fp32 product) - the kernel the model path uses for every [K,128] weight.
@@ -253,13 +242,12 @@ int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, int trans_
 int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, const float* bias, float* Y, int ldy, int M,
                        int K, int N, int act, void* scratch, uint64_t scratch_bytes, void* stream);
 
-/* gradients of the dense above: dW[K,N] += A^T . dY ; db[N] += colsum(dY) (db may be NULL).
-  * N must be 128 (every dense layer of the graph has 128 outputs); rows_per_block (multiple of 32, 0 = 1024) sets the
- * split over M; rows_per_block = -G selects the launch the training step uses: the 32-row tiles of all jobs dealt evenly
- * to G persistent workgroups, the job table living in `scratch` (device, >= 512 bytes; otherwise unused, may be NULL).
- * Accumulates with float atomics: zero the destinations first. */
+/* gradients of the dense above: dW[K,N] += A^T . dY ; db[N] += colsum(dY) (db may be NULL), through the persistent
+ * weight-gradient launch of the training step: the 64-row tiles of the job dealt evenly to `workgroups` workgroups
+ * (0 = one per CU), the job table living in `scratch` (device, >= 512 bytes).  N must be 128 (every dense layer of the
+ * graph has 128 outputs).  Accumulates with float atomics: zero the destinations first. */
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
-                   int N, int rows_per_block, void* scratch, uint64_t scratch_bytes, void* stream);
+                   int N, int workgroups, void* scratch, uint64_t scratch_bytes, void* stream);
 
 /* layer_norm (models/layers.py:7-17): y = (x - mean) * rsqrt(var + 1e-6) * gamma + beta over the 128 columns of each row;
  * mean / rstd (optional, [R]) are what the backward needs. */

@@ -128,12 +128,56 @@ def relu_pins(m, B, T, L):
     return pin
 
 
+PIN_Z_TOL = 1e-4        # a unit whose pin differs from the oracle's own sign of z must have |z| <= PIN_Z_TOL * max|z| of its tensor
+PIN_FRAC_TOL = 1e-4     # ... and at most this fraction of all ReLU units may differ
+
+
+def audit_units(sites):
+    """sites: [(name, z_oracle, pin)].  Returns (n_disagree, n_units, worst |z| / max|z| over the disagreeing units, where)."""
+    n = total = 0
+    worst, where = 0.0, ''
+    for name, z, pin in sites:
+        z = z.detach().double()
+        dis = (z > 0) != pin.reshape(z.shape)
+        total += z.numel()
+        k = int(dis.sum())
+        if k:
+            n += k
+            r = float(z[dis].abs().max() / z.abs().max())
+            if r > worst:
+                worst, where = r, name
+    return n, total, worst, where
+
+
+def assert_pins_ok(sites):
+    n, total, worst, where = audit_units(sites)
+    assert worst <= PIN_Z_TOL, 'ReLU pin disagrees with the oracle at a unit with |z| = %.2e max|z| (%s)' % (worst, where)
+    assert n <= max(1, PIN_FRAC_TOL * total), 'ReLU pins disagree with the oracle at %d of %d units' % (n, total)
+    return n, total
+
+
+def audit_pins(o_tap, pins):
+    """The pins come from the implementation under test, so they are audited against the oracle's OWN pre-activations z
+    (taps cb.z*, fe*.z*, head.zs/ze of the pinned oracle run): wherever (z_oracle > 0) differs from the pin, |z_oracle| has
+    to be rounding-level.  A ReLU unit the kernels wrongly zero (or wrongly keep) shows up here with |z| of ordinary size."""
+    sites = []
+    for i in range(4):
+        sites.append(('cb.z%d.v' % i, o_tap['cb.z%d.v' % i], pins['cb.v'][i]))
+        sites.append(('cb.z%d.q' % i, o_tap['cb.z%d.q' % i], pins['cb.q'][i]))
+        for ps in range(2):
+            sites.append(('fe%d.z%d' % (ps, i), o_tap['fe%d.z%d' % (ps, i)], pins['fe%d' % ps][i]))
+    sites.append(('head.zs', o_tap['head.zs'], pins['head.hs']))
+    sites.append(('head.ze', o_tap['head.ze'], pins['head.he']))
+    return assert_pins_ok(sites)
+
+
 def compare(cfg, p, wv, b, labels, drop_rate=0.0, seed=5, offset=7, with_grads=True, device='cuda:0', pin_relu=True,
-            video_bf16=False):
+            video_bf16=False, oracle_dtype=torch.float32):
     """returns (report rows [(kind, name, maxabs_diff, ref_maxabs)], indices equal, oracle out, hip out, hip model).
     pin_relu: the oracle evaluates its ReLUs with the active sets of the HIP forward (relu_pins), which makes every
-    gradient tensor comparable at 1e-3 whatever the shape; the row ('pin', 'relu_disagree', n, total) counts the units
-    where the oracle's own sign of z differs (they must be rounding-level: the forward taps are still held to 1e-3)."""
+    gradient tensor comparable at 1e-3 whatever the shape.  The pins are AUDITED (audit_pins): the row
+    ('pin', 'relu_disagree', n, total) counts the units where the oracle's own sign of z differs, and compare() itself
+    asserts that each of them has |z_oracle| <= 1e-4 max|z| and that n / total <= 1e-4.  pin_relu=False: plain oracle."""
     B, T = b['video'].shape[:2]
     L = b['word_ids'].shape[1]
     # video_bf16: the HIP path is fed bfloat16 clip features (hual_batch.video_dtype), the oracle the same values as float32
@@ -148,8 +192,12 @@ def compare(cfg, p, wv, b, labels, drop_rate=0.0, seed=5, offset=7, with_grads=T
                       drop_rate=drop_rate, labels=tuple(x.numpy() for x in labels))
     torch.cuda.synchronize()
     pins = relu_pins(m, B, T, L) if pin_relu else None
-    o_out, o_grads = oracle_run(cfg, p, wv, b, labels, drop_rate, seed, offset, with_grads=with_grads, relu_pin=pins)
+    o_out, o_grads = oracle_run(cfg, p, wv, b, labels, drop_rate, seed, offset, dtype=oracle_dtype, with_grads=with_grads,
+                                relu_pin=pins)
     rows = []
+    if pin_relu:
+        n, total = audit_pins(o_out['tap'], pins)
+        rows.append(('pin', 'relu_disagree', n, total))
 
     def add(kind, name, hip, ref):
         hip = hip.detach().double().cpu().reshape(-1)

@@ -117,8 +117,12 @@ def test_conv_block_fwd_bwd(shape):
     pr = blk.oracle_params()
     xr = x.clone().requires_grad_(True)
     xv, xq = blk.split(xr)
-    yv = R.conv_block(xv, pr, 'conv_block', blk.rng, px.SITE_CONV, blk.rows_v, None, None, pins_v)
-    yq = R.conv_block(xq, pr, 'conv_block', blk.rng, px.SITE_CONV, blk.rows_q, None, None, pins_q)
+    tv, tq = {}, {}
+    yv = R.conv_block(xv, pr, 'conv_block', blk.rng, px.SITE_CONV, blk.rows_v, tv, 'cb', pins_v)
+    yq = R.conv_block(xq, pr, 'conv_block', blk.rng, px.SITE_CONV, blk.rows_q, tq, 'cb', pins_q)
+    # the pins are the kernel's own active sets: audit them against the oracle's pre-activations
+    pu.assert_pins_ok([('v%d' % i, tv['cb.z%d' % i], pins_v[i]) for i in range(4)] +
+                      [('q%d' % i, tq['cb.z%d' % i], pins_q[i]) for i in range(4)])
     ref = torch.cat([yv.reshape(blk.Nv, 128), yq.reshape(blk.Nq, 128)])
     _close('y', y.cpu(), ref.detach())
     ref.backward(dy)
@@ -194,7 +198,10 @@ def test_predictor_fwd_bwd(shape):
     pin['head.he'] = (blk.m.tap('head.he').cpu() > 0).reshape(B, T, -1)
     pr = blk.oracle_params()
     xr = x.clone().requires_grad_(True)
-    s_ref, e_ref = R.conditioned_predictor(xr.reshape(B, T, 128), pr, blk.cfg.num_heads, blk.v_mask, blk.rng, blk.rows_v, None, pin)
+    tap = {}
+    s_ref, e_ref = R.conditioned_predictor(xr.reshape(B, T, 128), pr, blk.cfg.num_heads, blk.v_mask, blk.rng, blk.rows_v, tap, pin)
+    pu.assert_pins_ok([('fe%d.z%d' % (ps, i), tap['fe%d.z%d' % (ps, i)], pin['fe%d' % ps][i]) for ps in range(2) for i in range(4)] +
+                      [('head.zs', tap['head.zs'], pin['head.hs']), ('head.ze', tap['head.ze'], pin['head.he'])])
     _close('start_logits', s_log.cpu(), s_ref.detach())
     _close('end_logits', e_log.cpu(), e_ref.detach())
     # the span argmax on the kernel's own logits (rounding-level differences in the logits may move a near tie)

@@ -41,36 +41,24 @@ def test_linear_fwd(dev, M, K, N, act):
     assert (Y.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize('M,K,N', [(37, 128, 128), (500, 64, 384), (9472, 128, 128), (100, 128, 1024)])
-def test_linear_dx_transposed_weight(dev, M, K, N):
-    """dX[M,N'] = dY[M,K] . W^T where W is stored [N',K]."""
-    from hual_amd import lib
-    g = torch.Generator(device='cpu').manual_seed(M + K + N)
-    dY = torch.randint(-3, 4, (M, K), generator=g).float().to(dev)
-    W = torch.randint(-3, 4, (N, K), generator=g).float().to(dev)
-    out = lib.linear_fwd(dY, W, trans_w=True)
-    assert torch.equal(out, dY @ W.t())
-
-
-@pytest.mark.parametrize('M,K,N,rpw', [(64, 64, 128, 32), (37, 128, 128, 32), (1000, 400, 128, 64), (9472, 128, 128, 1024),
-                                       (4096, 1024, 128, 256), (513, 16, 128, 96), (33, 272, 128, 1024),
-                                       # rows_per_block = -G: the balanced launch of the training step on G workgroups
-                                       (64, 64, 128, -1), (37, 128, 128, -2), (1000, 400, 128, -7), (9472, 128, 128, -512),
-                                       (4096, 1024, 128, -100), (513, 16, 128, -512), (33, 272, 128, -3)])
-def test_linear_dw(dev, M, K, N, rpw):
+# G: workgroups of the persistent weight-gradient launch of the training step (0 = one per CU)
+@pytest.mark.parametrize('M,K,N,G', [(64, 64, 128, 1), (37, 128, 128, 2), (1000, 400, 128, 7), (9472, 128, 128, 512),
+                                     (4096, 1024, 128, 100), (513, 16, 128, 512), (33, 272, 128, 3), (9472, 128, 128, 0),
+                                     (1000, 400, 128, 0), (64, 64, 128, 0)])
+def test_linear_dw(dev, M, K, N, G):
     from hual_amd import lib
     g = torch.Generator(device='cpu').manual_seed(M + K + N)
     A = torch.randint(-2, 3, (M, K), generator=g).float().to(dev)
     dY = torch.randint(-2, 3, (M, N), generator=g).float().to(dev)
     dW = torch.zeros(K, N, device=dev)
     db = torch.zeros(N, device=dev)
-    lib.linear_dw(A, dY, dW, db, rows_per_block=rpw)
+    lib.linear_dw(A, dY, dW, db, workgroups=G)
     assert torch.equal(dW, A.t() @ dY)          # small integers: exact in fp32 regardless of summation order
     assert torch.equal(db, dY.sum(0))
     A = torch.randn(M, K, generator=g).to(dev)
     dY = torch.randn(M, N, generator=g).to(dev)
     dW.zero_(); db.zero_()
-    lib.linear_dw(A, dY, dW, db, rows_per_block=rpw)
+    lib.linear_dw(A, dY, dW, db, workgroups=G)
     ref = A.double().t() @ dY.double()
     assert (dW.double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item()) * (M ** 0.5)
 

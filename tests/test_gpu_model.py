@@ -38,20 +38,6 @@ def test_ragged_shapes_parity():
     assert idx_equal
 
 
-@pytest.mark.parametrize('flags', [('1', '0', '1'), ('0', '1', '1'), ('1', '1', '1'), ('0', '0', '0')])
-def test_fusion_switch_variants_parity(flags, monkeypatch):
-    """HUAL_FUSE_LN / HUAL_FUSE_BWD move layer norms and dropout'/relu' into the GEMM A prologue
-    (gemm_lds_px_kernel); HUAL_FUSE_ROW=0 puts the elementwise launches back between row kernels and dX GEMMs.
-    Same numbers in every setting."""
-    monkeypatch.setenv('HUAL_FUSE_LN', flags[0])
-    monkeypatch.setenv('HUAL_FUSE_BWD', flags[1])
-    monkeypatch.setenv('HUAL_FUSE_ROW', flags[2])
-    case = pu.make_case(B=3, T=37, L=9, C=4, seed=11, max_vlen=40)
-    rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2)
-    _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
-    assert idx_equal
-
-
 @pytest.mark.parametrize('shape', [dict(), dict(B=4, T=64, L=12, C=6, seed=8, max_vlen=64, vdim=512)])
 def test_bfloat16_video_feed_parity(shape):
     """hual_batch.video_dtype = HUAL_DTYPE_BF16 (BASELINE configs[1]: bf16 clip features): the feature-load and the

@@ -34,7 +34,9 @@ def test_three_train_steps_match_oracle(use_graph):
         tr.step(lr=lr, drop_rate=drop)
         torch.cuda.synchronize()
         pins = pu.relu_pins(m, B, T, L)
-        rp, rm, rv, info = R.train_step(rp, rm, rv, cfg, wv, batch, labels, lr, drop, seed=seed, offset=off + s, relu_pin=pins)
+        rp, rm, rv, info = R.train_step(rp, rm, rv, cfg, wv, batch, labels, lr, drop, seed=seed, offset=off + s, relu_pin=pins,
+                                        want_tap=True)
+        pu.audit_pins(info['tap'], pins)          # the pins are the kernels' own active sets: rounding-level disagreements only
         np.testing.assert_allclose(float(tr.last_loss()), float(info['loss']), rtol=1e-3, atol=1e-3)
         assert torch.equal(tr.start_index.cpu(), info['start_index']) and torch.equal(tr.end_index.cpu(), info['end_index'])
         got = m.state_dict()
@@ -48,6 +50,67 @@ def test_three_train_steps_match_oracle(use_graph):
         rp = collections.OrderedDict((k, torch.from_numpy(got[k])) for k in rp)
         rm = {k: torch.from_numpy(a) for k, a in m.table.unpack(m.adam_m.cpu().numpy()).items()}
         rv = {k: torch.from_numpy(a) for k, a in m.table.unpack(m.adam_v.cpu().numpy()).items()}
+
+
+def _free_run(cfg, p, wv, b, labels, dtype, lr, drop, seed, off, steps):
+    rp = collections.OrderedDict((k, v.clone().to(dtype)) for k, v in p.items())
+    rm = {k: torch.zeros_like(v) for k, v in rp.items()}
+    rv = {k: torch.zeros_like(v) for k, v in rp.items()}
+    batch = (b['video'].to(dtype), b['lens'], b['word_ids'], b['char_ids'])
+    lab = tuple(x.to(dtype) if x.dtype.is_floating_point else x for x in labels)
+    out = []
+    for s in range(steps):
+        rp, rm, rv, info = R.train_step(rp, rm, rv, cfg, wv.to(dtype), batch, lab, lr, drop, seed=seed, offset=off + s)
+        out.append((float(info['loss']), info['start_logits'].double(), info['end_logits'].double(),
+                    info['start_index'], info['end_index']))
+    return out
+
+
+def test_thirty_step_trajectory_against_free_running_oracle():
+    """30 consecutive steps on one batch at the reference's settings (lr 1e-4, dropout 0.2: configs/charades/SeqPAN.yaml).
+    The oracle runs ON ITS OWN - its own parameters, Adam slots and ReLU signs, never re-seeded from the HIP state; only the
+    dropout stream (seed, step) is shared.
+
+    What two correct implementations can agree on is bounded by the optimizer, not by the kernels: AdamWeightDecay without
+    bias correction (ops.py:149-174) moves a weight by ~lr.m/sqrt(v) = O(lr) whatever the size of its gradient, so
+    rounding-level gradient differences become O(lr) parameter differences and the trajectories separate exponentially.
+    Measured for this batch: the float32 PyTorch oracle leaves the float64 oracle's trajectory at 1.3x (GPU box's host CPU)
+    to 1.6x (build container: logit difference 0.64 at step 17, first differing span at step 21) per step depending on the
+    machine's float32 kernels.  The test runs all three trajectories, prints them side by side, and demands of the HIP path:
+      * steps 0-11: loss within 1e-2 relative (1e-2 absolute below 1) of the float64 oracle's and the spans EQUAL;
+      * all 30 steps: logit deviation from the float64 trajectory inside the envelope 2e-4 . 1.75^step - i.e. a first-step
+        difference at float32 level and no faster separation than float32 PyTorch shows against float64;
+      * the float64 loss actually falls (an optimizer that does nothing would pass the rest)."""
+    from hual_amd.train import Trainer
+    lr, drop, seed, off, steps = 1e-4, 0.2, 31, 11, 30
+    cfg, p, wv, b, labels = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
+    m = pu.hip_model(cfg, p, wv)
+    m.set_rng(seed, off)
+    tr = Trainer(m, world=1, use_graph=True)
+    tr.set_batch(b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(),
+                 *[x.numpy() for x in labels])
+    o64 = _free_run(cfg, p, wv, b, labels, torch.float64, lr, drop, seed, off, steps)
+    o32 = _free_run(cfg, p, wv, b, labels, torch.float32, lr, drop, seed, off, steps)
+
+    def dev(a, ref):
+        return max(float((a[1] - ref[1]).abs().max()), float((a[2] - ref[2]).abs().max()))
+
+    dev_h, dev_o = [], []
+    for s in range(steps):
+        tr.step(lr=lr, drop_rate=drop)
+        torch.cuda.synchronize()
+        hip = (float(tr.last_loss()), tr.start_logits.cpu().double(), tr.end_logits.cpu().double())
+        dev_h.append(dev(hip, o64[s]))
+        dev_o.append(dev(o32[s], o64[s]))
+        print('step %2d  loss hip %.5f  f64 %.5f  f32 %.5f   logit deviation from f64: hip %.2e  f32 oracle %.2e' %
+              (s, hip[0], o64[s][0], o32[s][0], dev_h[-1], dev_o[-1]))
+        if s < 12:
+            assert abs(hip[0] - o64[s][0]) <= 1e-2 * max(abs(o64[s][0]), 1.0), (s, hip[0], o64[s][0])
+            assert torch.equal(tr.start_index.cpu(), o64[s][3]) and torch.equal(tr.end_index.cpu(), o64[s][4]), s
+
+    for s in range(steps):
+        assert dev_h[s] <= 2e-4 * 1.75 ** s, (s, dev_h[s], 2e-4 * 1.75 ** s)
+    assert o64[-1][0] < o64[0][0] - 1.0
 
 
 def test_weight_decay_mask_and_clip_on_device():
