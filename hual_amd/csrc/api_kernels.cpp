@@ -78,7 +78,7 @@ int hual_layer_norm_fwd(const float* x, const float* gamma, const float* beta, f
                         void* stream) {
   HUAL_REQUIRE(x && gamma && beta && y && R > 0, "hual_layer_norm_fwd: null / empty");
   LnFwd a{};
-  a.x = x; a.R = R; a.g1 = gamma; a.b1 = beta; a.y1 = y; a.mean = mean; a.rstd = rstd; a.drop_site = -1;
+  a.x = x; a.R = R; a.g1 = gamma; a.b1 = beta; a.y1 = y; a.mean = mean; a.rstd = rstd;
   RowSpace rs{};
   rs.R = R; rs.Nv = R; rs.T = R; rs.B = 1;
   DropCfg d = make_dropcfg(nullptr, 0.f);

@@ -17,7 +17,9 @@ struct CbLayerFwd {
   const float* dw;                           // depthwise filter [7,128]
   const float* wimg;                         // forward image of the pointwise weight [128,128] (pack_weights_kernel)
   const float* bias;                         // [128]
-  float* c; float* y; float* xout;           // [R,128] each: depthwise output, relu output, layer output
+  float* c; float* xout;                     // [R,128] each: depthwise output, layer output
+  float* y;                                  // optional [R,128]: the relu output (parity taps only; backward reads the bit planes)
+  uint8_t* relu_bits; uint8_t* keep_bits;    // bit planes [R][16] bytes (tilecore.h): y > 0, dropout keep decisions (written when dropout is on)
   float* mean; float* rstd;                  // [R]
   int drop_site;
 };
@@ -37,16 +39,14 @@ struct CbLayerBwd {
   const float* wimg_t;                       // image of the transposed pointwise weight (dX)
   const float* x;                            // layer input x_l [R,128]
   const float* mean; const float* rstd;      // [R]
-  const float* y_prev;                       // relu output of layer l-1 (null for l = 0)
+  const uint8_t* relu_prev; const uint8_t* keep_prev;   // bit planes of layer l-1 (relu active set, dropout keep set; null for l = 0)
   float* dz;                                 // [R,128] dZ_l = dropout'(dx_{l+1}) * relu'(y_l): operand of this layer's dW job
   float* dz_prev;                            // [R,128] dZ_{l-1} (null for l = 0), written for the owned rows
-  int drop_site_prev;                        // dropout site of layer l-1
   float* part;                               // [grid][9][128] per-workgroup partial sums: ddw[0..6], dgamma, dbeta
 };
 struct CbBwdArgs {
   const float* dx_in;                        // gradient wrt the block output x_4 [R,128]
-  const float* y3;                           // relu output of layer 3
-  int drop_site3;
+  const uint8_t* relu_bits3; const uint8_t* keep_bits3;   // bit planes of layer 3
   float* dx_out;                             // gradient wrt x_0 [R,128]
   CbLayerBwd l[4];
   int MT;

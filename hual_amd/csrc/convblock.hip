@@ -40,6 +40,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
   const int xbase = r0 - 12;                                 // global row of X[0]
 
   const DropRegs dr = drop_load(drop);
+  HUAL_STAMP_K(2, 0);
   cb_dma_weight(a.l[0].wimg, Wl, wave, lane, CB_THREADS / 64);
   // ---- block input (+ position embeddings for the predictor's feature encoder) and the small parameters of all four
   // layers: everything is requested before anything is used - one memory round trip.  The loads are unconditional on
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
       if (grp < CB_NPAR) par[(l * CB_NPAR + grp) * 32 + l32] = qv[l];
   }
   cb_barrier();
+  HUAL_STAMP_K(2, 1);
 
 #pragma unroll 1
   for (int l = 0; l < 4; ++l) {
@@ -123,82 +125,129 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
       }
     }
     cb_barrier();
+    HUAL_STAMP_K(2, 2 + 6 * l);
     // ---------------- P1b: depthwise conv over a sliding window of normalised rows -> operand planes
+    // The wait for this wave's share of the weight image sits HERE, in front of the stores of this phase: vmcnt counts stores
+    // as well, and behind them the same wait would drain them (a store round trip per layer) before the matrix phase starts.
+    // The image was requested a whole phase ago; the barrier behind this phase publishes every wave's share.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
       const float4 gam = lp[7 * 32 + l32], bet = lp[8 * 32 + l32];
       float4 w[7];
 #pragma unroll
       for (int k = 0; k < 7; ++k) w[k] = lp[k * 32 + l32];
       const int la = grp * ntile, lb = la + ntile;           // operand rows of this group (16 groups x ntile = all 16*ntile rows)
-      float4 h0 = f4zero(), h1 = f4zero(), h2 = f4zero(), h3 = f4zero(), h4 = f4zero(), h5 = f4zero(), h6 = f4zero();
+      // the group's ntile + 6 input rows, normalised, in registers: every LDS read of the phase is issued before anything
+      // depends on one (with two waves per SIMD a read per window step was a full LDS round trip per step)
+      float4 hv[10];
+      {
+        float4 xr[10];
+        float mr[10], sr[10];
 #pragma unroll
-      for (int s = 0; s < 10; ++s) {                         // ntile <= 4 rows + 6 halo rows
-        const int li = la - 3 + s;
-        // h of global row t = LN(x_l[t]) (zero outside the tensor): enters the window as its newest row
-        const int t = obase + li;
-        float4 hn = f4zero();
-        if (s < ntile + 6 && li < nout + 3 && t >= 0 && t < R) {
-          const int xi = t - xbase;
-          const float4 v = X[xi * CB_XS + l32];
-          const float mean = smean[xi], rstd = srstd[xi];
-          hn = cb_fma(make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd), gam, bet);
+        for (int s = 0; s < 10; ++s) {
+          const int t = obase + la - 3 + s;
+          const int xi = min(max(t - xbase, 0), XR - 1);
+          xr[s] = X[xi * CB_XS + l32];
+          mr[s] = smean[xi];
+          sr[s] = srstd[xi];
         }
-        h0 = h1; h1 = h2; h2 = h3; h3 = h4; h4 = h5; h5 = h6; h6 = hn;
-        if (s < 6) continue;
-        const int lo_ = li - 3;                              // operand row whose window (lo_-3 .. lo_+3) is complete now
+#pragma unroll
+        for (int s = 0; s < 10; ++s) {
+          const int li = la - 3 + s, t = obase + li;
+          const bool in = s < ntile + 6 && li < nout + 3 && t >= 0 && t < R;      // zero outside the tensor
+          const float4 v = xr[s];
+          const float mean = mr[s], rstd = sr[s];
+          const float4 hn = cb_fma(make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd), gam, bet);
+          hv[s] = in ? hn : f4zero();
+        }
+      }
+      // clip segment of the group's first output row; the following rows step through it (one integer division per group)
+      int slo, shi;
+      cb_segment(min(max(obase + la, 0), R - 1), rs, slo, shi);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                          // output row la + u: window hv[u] .. hv[u + 6]
+        const int lo_ = la + u;
         if (lo_ >= lb) continue;
         const int o = obase + lo_;
         float4 c = f4zero();
         const bool live = lo_ < nout && o >= 0 && o < R;
         if (live) {
-          int slo, shi;
-          cb_segment(o, rs, slo, shi);
-          // taps outside the clip are zero padding (SAME, modules.py:66); same accumulation order as ln_dwconv_fwd_kernel
-          c = cb_fma((o - 3 >= slo) ? h0 : f4zero(), w[0], c);
-          c = cb_fma((o - 2 >= slo) ? h1 : f4zero(), w[1], c);
-          c = cb_fma((o - 1 >= slo) ? h2 : f4zero(), w[2], c);
-          c = cb_fma(h3, w[3], c);
-          c = cb_fma((o + 1 < shi) ? h4 : f4zero(), w[4], c);
-          c = cb_fma((o + 2 < shi) ? h5 : f4zero(), w[5], c);
-          c = cb_fma((o + 3 < shi) ? h6 : f4zero(), w[6], c);
+          if (o >= shi) { slo = shi; shi = slo + (slo < rs.Nv ? rs.T : rs.L); }
+          // taps outside the clip are zero padding (SAME, modules.py:66); accumulation order of the taps: 0 .. 6
+          c = cb_fma((o - 3 >= slo) ? hv[u] : f4zero(), w[0], c);
+          c = cb_fma((o - 2 >= slo) ? hv[u + 1] : f4zero(), w[1], c);
+          c = cb_fma((o - 1 >= slo) ? hv[u + 2] : f4zero(), w[2], c);
+          c = cb_fma(hv[u + 3], w[3], c);
+          c = cb_fma((o + 1 < shi) ? hv[u + 4] : f4zero(), w[4], c);
+          c = cb_fma((o + 2 < shi) ? hv[u + 5] : f4zero(), w[5], c);
+          c = cb_fma((o + 3 < shi) ? hv[u + 6] : f4zero(), w[6], c);
           if (o >= r0 && o < r0 + MT) st4_nt(L.c + (size_t)o * HUAL_D + col, c);
         }
         const float inv = cb_store_operand(Ahi, Alo, lo_, l32, c);
         if (l32 == 0) ainv[lo_] = live ? inv : 0.f;
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the weight image has landed
-    cb_barrier();
+    HUAL_STAMP_K(2, 3 + 6 * l);
+    cb_barrier();                                         // operand planes complete; every wave passed its weight-image wait above
+    HUAL_STAMP_K(2, 4 + 6 * l);
     // ---------------- P2: pointwise convolution on the matrix cores
     f32x4 acc[4];
     if (mt < ntile) cb_tile_mma_t<64 * 256>(Ahi, Wl, mt, ch, lane, acc);
     cb_barrier();                                         // operand planes and weight image are free again
+    HUAL_STAMP_K(2, 5 + 6 * l);
     if (l + 1 < 4) cb_dma_weight(a.l[l + 1].wimg, Wl, wave, lane, CB_THREADS / 64);
-    // ---------------- P3: bias, relu, dropout, residual
+    HUAL_STAMP_K(2, 6 + 6 * l);
+    HUAL_STAMP_K(7, 0 + 4 * l);
+    // ---------------- P3: bias, relu, dropout, residual.  The relu active set and the dropout keep set of the owned rows leave
+    // as bit planes (tilecore.h): all the backward pass needs of y_l
     if (mt < ntile) {
       const int j = lane & 15, g = lane >> 4;
       const int ecol = 64 * ch + 4 * j;
       const float4 bias = lp[9 * 32 + (ecol >> 2)];
+      const int lr0 = 16 * mt + 4 * g, o0 = obase + lr0;
+      const bool dropping = L.drop_site >= 0 && dr.enabled;
+      bool own[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) own[r] = lr0 + r < nout && o0 + r >= r0 && o0 + r < r0 + MT && o0 + r < R;
+      uint32_t nib[4] = {15u, 15u, 15u, 15u};
+      if (dropping) {      // (wave-uniform) two calls per lane for its 4 rows; the keep bytes of the owned rows go to the plane
+        drop_nib2_store_r(dr, (uint32_t)L.drop_site, a.drop_row0, o0, o0 + 1, own[0], own[1], (uint32_t)(ecol >> 2), L.keep_bits, nib[0], nib[1]);
+        drop_nib2_store_r(dr, (uint32_t)L.drop_site, a.drop_row0, o0 + 2, o0 + 3, own[2], own[3], (uint32_t)(ecol >> 2), L.keep_bits, nib[2], nib[3]);
+      }
+      HUAL_STAMP_K(7, 1 + 4 * l);
+      uint32_t rb[4] = {0u, 0u, 0u, 0u};
+      // the four LDS reads per row (operand scale, residual row) are issued up front: the stores into X below would otherwise
+      // order every later read behind them
+      float irv[4];
+      float4 xres[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int lr = 16 * mt + 4 * g + r;
-        const int o = obase + lr;
+        irv[r] = ainv[min(lr0 + r, 63)];
+        xres[r] = X[min(max(o0 + r - xbase, 0), XR - 1) * CB_XS + (ecol >> 2)];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = lr0 + r;
+        const int o = o0 + r;
         if (lr >= nout || o < 0 || o >= R) continue;
-        const float ir = ainv[lr];
+        const float ir = irv[r];
         float4 v = make_float4(fmaf(acc[0][r], ir, 0.f) + bias.x, fmaf(acc[1][r], ir, 0.f) + bias.y,
                                fmaf(acc[2][r], ir, 0.f) + bias.z, fmaf(acc[3][r], ir, 0.f) + bias.w);
         v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        const bool own = o >= r0 && o < r0 + MT;
-        if (own) st4_nt(L.y + (size_t)o * HUAL_D + ecol, v);
-        if (L.drop_site >= 0 && dr.enabled)
-          v = apply_drop4_r(dr, (uint32_t)L.drop_site, a.drop_row0 + (uint32_t)o, (uint32_t)(ecol >> 2), v);
-        float4* xp = X + (o - xbase) * CB_XS + (ecol >> 2);
-        v = cb_add(v, *xp);
-        *xp = v;
-        if (own) st4(L.xout + (size_t)o * HUAL_D + ecol, v);
+        if (own[r] && L.y) st4_nt(L.y + (size_t)o * HUAL_D + ecol, v);
+        rb[r] = f4_posbits(v);
+        if (dropping) v = f4_select(nib[r], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
+        v = cb_add(v, xres[r]);
+        X[(o - xbase) * CB_XS + (ecol >> 2)] = v;
+        if (own[r]) st4(L.xout + (size_t)o * HUAL_D + ecol, v);
       }
+      HUAL_STAMP_K(7, 2 + 4 * l);
+      bits_store2(L.relu_bits, o0, o0 + 1, own[0], own[1], ecol >> 2, rb[0], rb[1]);
+      bits_store2(L.relu_bits, o0 + 2, o0 + 3, own[2], own[3], ecol >> 2, rb[2], rb[3]);
+      HUAL_STAMP_K(7, 3 + 4 * l);
     }
     cb_barrier();
+    HUAL_STAMP_K(2, 7 + 6 * l);
   }
 }
 
@@ -237,15 +286,18 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
   const int mt = wave >> 1, ch = wave & 1;
 
   const DropRegs dr = drop_load(drop);
+  const float dscale3 = dr.enabled ? dr.scale : 1.0f;         // every dropout site of the block has the same rate
+  HUAL_STAMP_K(3, 0);
   cb_dma_weight(a.l[3].wimg_t, Wl, wave, lane, CB_THREADS / 64);
   // ---- prologue: gradient wrt the block output -> DX; dZ_3 -> operand planes (+ HBM for the owned rows)
   {
-    float4 dv[4], yv[4];
+    float4 dv[4];
+    uint32_t zn[4];                                           // keep & relu' nibbles of layer 3 (bit planes of the forward)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                             // unconditional loads on clamped rows, see the forward kernel
       const int i = grp + 16 * u, row = min(max(xbase + i, 0), R - 1);
       dv[u] = ld4(a.dx_in + (size_t)row * HUAL_D + col);
-      yv[u] = ld4(a.y3 + (size_t)row * HUAL_D + col);
+      zn[u] = bits_nibble(a.relu_bits3, row, l32) & (dr.enabled ? bits_nibble(a.keep_bits3, row, l32) : 15u);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -254,15 +306,14 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
       const bool ok = i < XR && row >= 0 && row < R;
       float4 v = ok ? dv[u] : f4zero();
       if (i < XR) DX[i * 32 + l32] = v;
-      if (ok && a.drop_site3 >= 0 && dr.enabled) v = apply_drop4_r(dr, (uint32_t)a.drop_site3, a.drop_row0 + (uint32_t)row, (uint32_t)l32, v);
-      const float4 y = ok ? yv[u] : f4zero();
-      v = make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
+      v = f4_select(ok ? zn[u] : 0u, make_float4(v.x * dscale3, v.y * dscale3, v.z * dscale3, v.w * dscale3));
       if (ok && row >= r0 && row < r0 + MT) st4(a.l[3].dz + (size_t)row * HUAL_D + col, v);
       const float inv = cb_store_operand(Ahi, Alo, i, l32, v);
       if (l32 == 0) ainv[i] = ok ? inv : 0.f;
     }
   }
 
+  HUAL_STAMP_K(3, 1);
 #pragma unroll 1
   for (int i = 3; i >= 0; --i) {
     const CbLayerBwd& L = a.l[i];
@@ -272,14 +323,16 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
     const int chunk = (nR + 15) >> 4;                                          // <= 4 rows per group
     const int ra = grp * chunk, rb = min(ra + chunk, nR);
     // ---- operands of the row phase, requested before the matrix phase (their latency hides under it)
-    float4 xv[4], yv[4];
+    float4 xv[4];
     float mu[4], rsd[4];
-    const float* yprev = L.y_prev ? L.y_prev : L.x;           // layer 0 has no relu below it: the loaded rows are ignored
+    uint32_t zb[4];                                           // keep & relu' nibbles of layer i-1 for this group's rows
+    const uint8_t* rprev = L.relu_prev ? L.relu_prev : a.relu_bits3;      // layer 0 has no layer below it: the loaded bytes are ignored
+    const uint8_t* kprev = L.keep_prev ? L.keep_prev : a.keep_bits3;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                             // unconditional loads on clamped rows
       const int tc = min(max(rbase + ra + u, 0), R - 1);
       xv[u] = ld4(L.x + (size_t)tc * HUAL_D + col);
-      yv[u] = ld4(yprev + (size_t)tc * HUAL_D + col);
+      zb[u] = bits_nibble(rprev, tc, l32) & (dr.enabled ? bits_nibble(kprev, tc, l32) : 15u);
       mu[u] = L.mean[tc];
       rsd[u] = L.rstd[tc];
     }
@@ -290,20 +343,21 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
     else if (grp == 8) pv = ld4(L.ln_b + col);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // weight image + the operands above have landed
     if (grp < 9) par[grp * 32 + l32] = pv;
-    // relu'(y_{i-1}) as 4 bits per row (bit c = column col + c is active), rows packed into one register
-    uint32_t ybits = 0;
+    // keep & relu' of dZ_{i-1}, 4 bits per row (bit c = column col + c), rows packed into one register
+    uint32_t zbits = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      asm volatile("" : "+v"(xv[u].x), "+v"(xv[u].y), "+v"(xv[u].z), "+v"(xv[u].w), "+v"(yv[u].x), "+v"(yv[u].y), "+v"(yv[u].z),
-                   "+v"(yv[u].w), "+v"(mu[u]), "+v"(rsd[u]));
-      const uint32_t b = (yv[u].x > 0.f ? 1u : 0u) | (yv[u].y > 0.f ? 2u : 0u) | (yv[u].z > 0.f ? 4u : 0u) | (yv[u].w > 0.f ? 8u : 0u);
-      ybits |= b << (4 * u);
+      asm volatile("" : "+v"(xv[u].x), "+v"(xv[u].y), "+v"(xv[u].z), "+v"(xv[u].w), "+v"(zb[u]), "+v"(mu[u]), "+v"(rsd[u]));
+      zbits |= zb[u] << (4 * u);
     }
+    HUAL_STAMP_K(3, 2 + 7 * (3 - i));
     cb_barrier();                                          // (1) operand planes + parameters complete
+    HUAL_STAMP_K(3, 3 + 7 * (3 - i));
     // ---- G: dC_i = dZ_i . W_i^T
     f32x4 acc[4];
     if (mt < ntile) cb_tile_mma_t<64 * 256>(Ahi, Wl, mt, ch, lane, acc);
     cb_barrier();                                          // (2) planes and weight image free
+    HUAL_STAMP_K(3, 4 + 7 * (3 - i));
     if (mt < ntile) {
       const int j = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -317,9 +371,9 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
     // next layer's weight image: requested only now, behind the barrier (a __syncthreads() with an LDS-DMA in flight
     // waits for it), so that it lands under the row phase
     if (i > 0) cb_dma_weight(a.l[i - 1].wimg_t, Wl, wave, lane, CB_THREADS / 64);
+    HUAL_STAMP_K(3, 5 + 7 * (3 - i));
     // ---- R: transposed depthwise conv + layer-norm backward
     float4 sw[7], sg = f4zero(), sb = f4zero();
-    uint32_t zbits = 0;                                        // keep-bits of dZ_{i-1} = dropout keep & relu', 4 per row
 #pragma unroll
     for (int k = 0; k < 7; ++k) sw[k] = f4zero();
     {
@@ -367,18 +421,12 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
         const float4 dres = *dxp;
         dx = make_float4(__fadd_rn(dx.x, dres.x), __fadd_rn(dx.y, dres.y), __fadd_rn(dx.z, dres.z), __fadd_rn(dx.w, dres.w));
         *dxp = dx;
-        if (i == 0) {
-          st4(a.dx_out + (size_t)t * HUAL_D + col, dx);
-        } else {
-          // operand of the next product: dZ_{i-1} = dropout'(dx_i, site_{i-1}) * relu'(y_{i-1}); only its keep-bits are
-          // held across the barrier, the values are re-read from DX
-          uint32_t keep = 0xfu;
-          if (L.drop_site_prev >= 0 && dr.enabled)
-            keep = drop_bits4_r(dr, (uint32_t)L.drop_site_prev, a.drop_row0 + (uint32_t)t, (uint32_t)l32);
-          zbits |= (keep & (ybits >> (4 * u)) & 0xfu) << (4 * u);
-        }
+        if (i == 0) st4(a.dx_out + (size_t)t * HUAL_D + col, dx);
+        // (i > 0: the operand of the next product, dZ_{i-1} = dropout'(dx_i) * relu'(y_{i-1}), is formed behind the parameter sums
+        //  from DX and the keep & relu' bits the forward left)
       }
     }
+    HUAL_STAMP_K(3, 6 + 7 * (3 - i));
     // workgroup sums of the parameter gradients, without atomics (an LDS float atomic was measured at ~600 stall cycles per
     // wave-instruction here): the two 32-lane groups of a wave are added in registers (v_permlane32_swap), the 8 per-wave
     // partials go through LDS in two batches of four, and thread e owns sums e, e + 512, e + 1024 of the 9 x 128
@@ -418,6 +466,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
         if (e < 9 * HUAL_D) L.part[(size_t)blockIdx.x * 9 * HUAL_D + e] = pacc[q];
       }
     }
+    HUAL_STAMP_K(3, 7 + 7 * (3 - i));
     if (i > 0) {
       // operand rows of the next product: index 0 = global row r0 - E0 (= rbase); rows up to the next 16-row tile edge zeroed
       const int ntn = (nR + 15) >> 4;
@@ -428,16 +477,22 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
         const bool ok = lr < rb && t >= 0 && t < R;
         float4 v = f4zero();
         if (ok) {
-          const float dscale = (L.drop_site_prev >= 0 && dr.enabled) ? dr.scale : 1.0f;
-          v = cb_mul(DX[(t - xbase) * 32 + l32], mask_from_bits4((zbits >> (4 * u)) & 0xfu, dscale));
+          v = cb_mul(DX[(t - xbase) * 32 + l32], mask_from_bits4((zbits >> (4 * u)) & 0xfu, dscale3));
         }
         if (ok && t >= r0 && t < r0 + MT) st4(L.dz_prev + (size_t)t * HUAL_D + col, v);
         const float inv = cb_store_operand(Ahi, Alo, lr, l32, v);
         if (l32 == 0) ainv[lr] = ok ? inv : 0.f;
       }
     }
+    HUAL_STAMP_K(3, 8 + 7 * (3 - i));
   }
 }
+
+#if defined(HUAL_STAMPS) && (HUAL_STAMPS == 2 || HUAL_STAMPS == 3 || HUAL_STAMPS == 7)
+extern "C" int hual_debug_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hual_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 
 namespace hual {
 
@@ -457,7 +512,7 @@ int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg&
   HUAL_REQUIRE(!a.pos || a.x0_out, "conv_block_fwd: pos needs x0_out");
   for (int l = 0; l < 4; ++l) {
     const CbLayerFwd& L = a.l[l];
-    HUAL_REQUIRE(L.ln_g && L.ln_b && L.dw && L.wimg && L.bias && L.c && L.y && L.xout && L.mean && L.rstd, "conv_block_fwd: null layer tensor");
+    HUAL_REQUIRE(L.ln_g && L.ln_b && L.dw && L.wimg && L.bias && L.c && L.xout && L.mean && L.rstd && L.relu_bits && L.keep_bits, "conv_block_fwd: null layer tensor");
   }
   HUAL_DYN_LDS(conv_block_fwd_kernel, 160 * 1024);
   const double rows = (double)rs.R;
@@ -479,11 +534,11 @@ int conv_block_bwd_blocks(int R) { return cdiv(R, conv_block_fused_rows_bwd(R));
 static size_t cb_bwd_lds(int MT) { return (size_t)(MT + 24) * 512 + 64 * 512 + CB_WBYTES + 64 * sizeof(float) + (1 + 4) * 9 * HUAL_D * sizeof(float); }
 
 int launch_conv_block_bwd(const CbBwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
-  HUAL_REQUIRE(a.dx_in && a.y3 && a.dx_out && rs.R > 0 && a.MT >= 1 && a.MT <= HUAL_CB_BWD_MAXMT, "conv_block_bwd: bad arguments");
+  HUAL_REQUIRE(a.dx_in && a.relu_bits3 && a.keep_bits3 && a.dx_out && rs.R > 0 && a.MT >= 1 && a.MT <= HUAL_CB_BWD_MAXMT, "conv_block_bwd: bad arguments");
   for (int l = 0; l < 4; ++l) {
     const CbLayerBwd& L = a.l[l];
     HUAL_REQUIRE(L.ln_g && L.ln_b && L.dw && L.wimg_t && L.x && L.mean && L.rstd && L.dz && L.part, "conv_block_bwd: null layer tensor");
-    HUAL_REQUIRE(l == 0 || (L.y_prev && L.dz_prev), "conv_block_bwd: layers 1-3 need y_prev / dz_prev");
+    HUAL_REQUIRE(l == 0 || (L.relu_prev && L.keep_prev && L.dz_prev), "conv_block_bwd: layers 1-3 need the bit planes of the layer below / dz_prev");
   }
   HUAL_DYN_LDS(conv_block_bwd_kernel, 160 * 1024);
   const double rows = (double)rs.R;

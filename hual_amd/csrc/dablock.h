@@ -16,6 +16,7 @@ namespace hual {
 struct LnProjArgs {
   const float* x;                                  // [R,128]
   const float* xa; int pre_site; float* x_out;     // optional: x := dropout(xa, pre_site) + x, written to x_out (modules.py:132)
+  uint8_t* pre_bits; uint8_t* y1_bits;             // keep-bit planes [R][16] bytes (tilecore.h) of pre_site / drop_site1 for backward
   const float* x2;                                 // optional raw second operand [R,128] (exclusive with g2): src = 1 reads it
   const float* g1; const float* b1; float* y1;     // y1 = dropout(LN(x; g1, b1), drop_site1)   [R,128]
   int drop_site1;                                  // < 0: no dropout
@@ -28,7 +29,8 @@ struct LnProjArgs {
   int src[HUAL_LNPROJ_MAX];                        // 0: reads y1, 1: reads y2 (or x2)
   int accum[HUAL_LNPROJ_MAX];                      // 1: no epilogue, the product is added to the next projection's (K-concatenation)
   int act[HUAL_LNPROJ_MAX];                        // 1: relu
-  int out_site[HUAL_LNPROJ_MAX];                   // >= 0: dropout on the output
+  int out_site[HUAL_LNPROJ_MAX];                   // >= 0: dropout on the output ...
+  uint8_t* out_bits[HUAL_LNPROJ_MAX];              // ... and where its keep bits go
   int add_x[HUAL_LNPROJ_MAX];                      // 1: + the layer-norm input rows (residual; needs g2 == x2 == null)
   int R; int MT;                                   // rows, rows per workgroup (1..64)
   uint32_t drop_row0;
@@ -46,6 +48,7 @@ struct DaPostArgs {
   float *sv, *xv, *sg, *xg, *o, *gd, *gate, *val, *mha, *res, *l2, *out;       // [R,128] saved tensors
   float *mean2, *rstd2;                                                         // [R]
   int site;                // dropout sites site+2 (dense_1 output), site+3 (LN2 output), site+4 (dense_2 output)
+  uint8_t *bits2, *bits3, *bits4;   // their keep-bit planes [R][16] bytes (tilecore.h), read by the backward kernels
   int R; int MT;           // MT = 1..48
   uint32_t drop_row0;
 };
@@ -64,17 +67,17 @@ namespace hual {
 struct LnProjBwdArgs {
   int nsteps;
   const float* A[HUAL_LNBWD_MAX]; int lda[HUAL_LNBWD_MAX];     // gradient operands: rows of 128 floats with row stride lda
-  int a_site[HUAL_LNBWD_MAX];                                  // >= 0: the operand is dropout'(A, site) ...
+  const uint8_t* a_bits[HUAL_LNBWD_MAX];                       // non-null: the operand is dropout'(A) with these keep bits (forward) ...
   float* a_save[HUAL_LNBWD_MAX];                               // ... and (optional) is stored here [R,128] for the weight-gradient job
   const float* wimg_t[HUAL_LNBWD_MAX];                         // images of the transposed weights
   int dst[HUAL_LNBWD_MAX];                                     // 0 / 1: which layer norm's output gradient the product belongs to
   const float* add_dy1;                                        // optional [R,128] added to dy_0
-  int dy1_site;                                                // >= 0: the first layer norm's output went through dropout
+  const uint8_t* dy1_bits;                                     // non-null: the first layer norm's output went through dropout (keep bits)
   const float* x; const float* mean; const float* rstd;        // layer-norm input and statistics
   const float* g1; const float* g2;                            // g2 null: one layer norm
   const float* add1;                                           // optional gradient arriving through the residual path
   float* dx;
-  float* dz; int dz_site; const float* dz_relu;                // optional: dz = dropout'(dx, dz_site) * (dz_relu > 0)
+  float* dz; const uint8_t* dz_bits;                           // optional: dz = dropout'(dx) with the keep bits dz_bits (null: dz = dx)
   float* part;                                                 // [grid][4][128] partial sums: dgamma1, dbeta1, dgamma2, dbeta2
   int R; int MT; uint32_t drop_row0;
 };

@@ -62,6 +62,20 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
 #pragma unroll
   for (int p = 0; p < HUAL_LNPROJ_MAX; ++p) bias[p] = (p < a.nproj && a.bias[p]) ? ld4(a.bias[p] + ecol) : f4zero();
   float4* scratch = reinterpret_cast<float4*>(P2);           // fp32 rows [64][32] float4 of the layer-norm input (residual)
+  // dropout decisions of the two row-layout sites for this group's four rows (two rows per call, tilecore.h); the keep bytes
+  // go to the bit planes the backward pass reads
+  uint32_t nbp[4] = {15u, 15u, 15u, 15u}, nb1[4] = {15u, 15u, 15u, 15u};
+  if (dr.enabled) {
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int lrA = grp + 32 * pr, lrB = lrA + 16;
+      const bool okA = lrA < MT && r0 + lrA < RE, okB = lrB < MT && r0 + lrB < RE;
+      if (a.xa && a.pre_site >= 0)
+        drop_nib2_store_r(dr, (uint32_t)a.pre_site, a.drop_row0, r0 + lrA, r0 + lrB, okA, okB, (uint32_t)l32, a.pre_bits, nbp[2 * pr], nbp[2 * pr + 1]);
+      if (a.drop_site1 >= 0)
+        drop_nib2_store_r(dr, (uint32_t)a.drop_site1, a.drop_row0, r0 + lrA, r0 + lrB, okA, okB, (uint32_t)l32, a.y1_bits, nb1[2 * pr], nb1[2 * pr + 1]);
+    }
+  }
   // ---- (residual) + layer norm(s) -> operand planes
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -71,14 +85,14 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
     float4 xr = xv[u];
     if (a.xa) {
       float4 t = av[u];
-      if (a.pre_site >= 0 && dr.enabled) t = apply_drop4_r(dr, (uint32_t)a.pre_site, a.drop_row0 + (uint32_t)row, (uint32_t)l32, t);
+      if (a.pre_site >= 0 && dr.enabled) t = f4_select(nbp[u], make_float4(t.x * dr.scale, t.y * dr.scale, t.z * dr.scale, t.w * dr.scale));
       xr = cb_add(t, xr);
       if (ok) st4(a.x_out + (size_t)row * HUAL_D + col, xr);
     }
     float mean, rstd;
     const float4 xh = ln_row(xr, mean, rstd);
     float4 y1 = cb_fma(xh, g1, b1);
-    if (a.drop_site1 >= 0 && dr.enabled) y1 = apply_drop4_r(dr, (uint32_t)a.drop_site1, a.drop_row0 + (uint32_t)row, (uint32_t)l32, y1);
+    if (a.drop_site1 >= 0 && dr.enabled) y1 = f4_select(nb1[u], make_float4(y1.x * dr.scale, y1.y * dr.scale, y1.z * dr.scale, y1.w * dr.scale));
     if (!ok) y1 = f4zero();
     if (ok) {
       st4(a.y1 + (size_t)row * HUAL_D + col, y1);
@@ -119,13 +133,20 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
     }
     fresh = a.accum[p] == 0;
     if (a.accum[p] || mt >= ntile) continue;
+    uint32_t nbo[4] = {15u, 15u, 15u, 15u};
+    const bool dropo = a.out_site[p] >= 0 && dr.enabled;
+    if (dropo) {
+      const int ra = r0 + 16 * mt + 4 * g;
+      drop_nib2_store_r(dr, (uint32_t)a.out_site[p], a.drop_row0, ra, ra + 1, ra < RE, ra + 1 < RE, (uint32_t)(ecol >> 2), a.out_bits[p], nbo[0], nbo[1]);
+      drop_nib2_store_r(dr, (uint32_t)a.out_site[p], a.drop_row0, ra + 2, ra + 3, ra + 2 < RE, ra + 3 < RE, (uint32_t)(ecol >> 2), a.out_bits[p], nbo[2], nbo[3]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int lr = 16 * mt + 4 * g + r, row = r0 + lr;
       if (row >= RE) continue;
       float4 v = make_float4(acc[r].x + bias[p].x, acc[r].y + bias[p].y, acc[r].z + bias[p].z, acc[r].w + bias[p].w);
       if (a.act[p]) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-      if (a.out_site[p] >= 0 && dr.enabled) v = apply_drop4_r(dr, (uint32_t)a.out_site[p], a.drop_row0 + (uint32_t)row, (uint32_t)(ecol >> 2), v);
+      if (dropo) v = f4_select(nbo[r], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
       if (a.add_x[p]) v = cb_add(v, scratch[lr * 32 + (ecol >> 2)]);
       st4(a.out[p] + (size_t)row * a.ldo[p] + ecol, v);
     }
@@ -355,11 +376,17 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   step(P1, a.w[10]);
   if (act) {
     fold(SV, ainv1, true);                                      // SV now holds `res`
+    uint32_t nbd[4] = {15u, 15u, 15u, 15u};
+    if (dr.enabled) {
+      const int ra = r0 + 16 * mt + 4 * g;
+      drop_nib2_store_r(dr, (uint32_t)(a.site + 2), a.drop_row0, ra, ra + 1, ra < RE, ra + 1 < RE, (uint32_t)(ecol >> 2), a.bits2, nbd[0], nbd[1]);
+      drop_nib2_store_r(dr, (uint32_t)(a.site + 2), a.drop_row0, ra + 2, ra + 3, ra + 2 < RE, ra + 3 < RE, (uint32_t)(ecol >> 2), a.bits2, nbd[2], nbd[3]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int lr = 16 * mt + 4 * g + r;
       float4 v = addb(SV[r], 7);
-      if (dr.enabled) v = apply_drop4_r(dr, (uint32_t)(a.site + 2), a.drop_row0 + (uint32_t)(r0 + lr), (uint32_t)(ecol >> 2), v);
+      if (dr.enabled) v = f4_select(nbd[r], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
       v = cb_add(v, xin[r]);
       SV[r] = v;
       save(a.res, r, v);
@@ -370,6 +397,14 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   // ---- RP2: layer_norm_2 + dropout (modules.py:85-86) -> slot 2
   {
     const float4 g2 = bl[9 * 32 + l32], b2 = bl[10 * 32 + l32];
+    uint32_t nb3[4] = {15u, 15u, 15u, 15u};
+    if (dr.enabled) {      // rows grp, grp + 16 share one call per lane pair, row grp + 32 takes one alone
+      const int lrA = grp, lrB = grp + 16, lrC = grp + 32;
+      drop_nib2_store_r(dr, (uint32_t)(a.site + 3), a.drop_row0, r0 + lrA, r0 + lrB, lrA < MT && r0 + lrA < RE, lrB < MT && r0 + lrB < RE,
+                        (uint32_t)l32, a.bits3, nb3[0], nb3[1]);
+      drop_nib2_store_r(dr, (uint32_t)(a.site + 3), a.drop_row0, r0 + lrC, r0 + lrC, lrC < MT && r0 + lrC < RE, lrC < MT && r0 + lrC < RE,
+                        (uint32_t)l32, a.bits3, nb3[2], nb3[3]);
+    }
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int lr = grp + 16 * u, row = r0 + lr;
@@ -378,7 +413,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
       float mean, rstd;
       const float4 xh = ln_row(scratch[lr * 32 + l32], mean, rstd);
       float4 y = cb_fma(xh, g2, b2);
-      if (dr.enabled) y = apply_drop4_r(dr, (uint32_t)(a.site + 3), a.drop_row0 + (uint32_t)row, (uint32_t)l32, y);
+      if (dr.enabled) y = f4_select(nb3[u], make_float4(y.x * dr.scale, y.y * dr.scale, y.z * dr.scale, y.w * dr.scale));
       if (!ok) y = f4zero();
       if (ok) {
         st4_nt(a.l2 + (size_t)row * HUAL_D + col, y);
@@ -392,11 +427,16 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   step(P2, nullptr);
   if (act) {
     fold(T1, ainv2, true);
+    uint32_t nbe[4] = {15u, 15u, 15u, 15u};
+    if (dr.enabled) {
+      const int ra = r0 + 16 * mt + 4 * g;
+      drop_nib2_store_r(dr, (uint32_t)(a.site + 4), a.drop_row0, ra, ra + 1, ra < RE, ra + 1 < RE, (uint32_t)(ecol >> 2), a.bits4, nbe[0], nbe[1]);
+      drop_nib2_store_r(dr, (uint32_t)(a.site + 4), a.drop_row0, ra + 2, ra + 3, ra + 2 < RE, ra + 3 < RE, (uint32_t)(ecol >> 2), a.bits4, nbe[2], nbe[3]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int lr = 16 * mt + 4 * g + r;
       float4 v = addb(T1[r], 8);
-      if (dr.enabled) v = apply_drop4_r(dr, (uint32_t)(a.site + 4), a.drop_row0 + (uint32_t)(r0 + lr), (uint32_t)(ecol >> 2), v);
+      if (dr.enabled) v = f4_select(nbe[r], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
       v = cb_add(v, SV[r]);
       save(a.out, r, v);
     }
@@ -457,8 +497,8 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       if (lr >= MT) continue;
       const bool ok = row < RE;
       float4 v = ok ? nv[u] : f4zero();
-      if (a.a_site[k] >= 0) {
-        if (dr.enabled) v = apply_drop4_r(dr, (uint32_t)a.a_site[k], a.drop_row0 + (uint32_t)row, (uint32_t)l32, v);
+      if (a.a_bits[k]) {      // dropout' with the keep bits the forward left
+        if (dr.enabled) v = f4_select(bits_nibble(a.a_bits[k], min(row, R - 1), l32), make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
         if (ok && a.a_save[k]) st4_nt(a.a_save[k] + (size_t)row * HUAL_D + col, v);
       }
       const float inv = cb_store_operand(S, S + LB_ROWS * 256, lr, l32, v);
@@ -524,7 +564,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     const float mean = mu[u], rstd = rsd[u];
     const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
     float4 dy = D0[lr * 32 + l32];
-    if (a.dy1_site >= 0 && dr.enabled) dy = apply_drop4_r(dr, (uint32_t)a.dy1_site, a.drop_row0 + (uint32_t)row, (uint32_t)l32, dy);
+    if (a.dy1_bits && dr.enabled) dy = f4_select(bits_nibble(a.dy1_bits, row, l32), make_float4(dy.x * dr.scale, dy.y * dr.scale, dy.z * dr.scale, dy.w * dr.scale));
     sb1 = cb_add(sb1, dy);
     sg1 = cb_fma(dy, xh, sg1);
     float4 gv = cb_mul(dy, g1);
@@ -541,11 +581,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     if (a.add1) dx = make_float4(__fadd_rn(dx.x, a1v[u].x), __fadd_rn(dx.y, a1v[u].y), __fadd_rn(dx.z, a1v[u].z), __fadd_rn(dx.w, a1v[u].w));
     st4(a.dx + off, dx);
     if (a.dz) {
-      if (a.dz_site >= 0 && dr.enabled) dx = apply_drop4_r(dr, (uint32_t)a.dz_site, a.drop_row0 + (uint32_t)row, (uint32_t)l32, dx);
-      if (a.dz_relu) {
-        const float4 y = ld4(a.dz_relu + off);
-        dx = make_float4(y.x > 0.f ? dx.x : 0.f, y.y > 0.f ? dx.y : 0.f, y.z > 0.f ? dx.z : 0.f, y.w > 0.f ? dx.w : 0.f);
-      }
+      if (a.dz_bits && dr.enabled) dx = f4_select(bits_nibble(a.dz_bits, row, l32), make_float4(dx.x * dr.scale, dx.y * dr.scale, dx.z * dr.scale, dx.w * dr.scale));
       st4(a.dz + off, dx);
     }
   }
@@ -772,8 +808,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   }
 }
 
-#ifdef HUAL_STAMPS
-__device__ unsigned long long g_hual_stamps[512 * HUAL_STAMP_SLOTS];
+#if defined(HUAL_STAMPS) && (HUAL_STAMPS == 1 || (HUAL_STAMPS >= 4 && HUAL_STAMPS <= 6))
 extern "C" int hual_debug_stamps(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hual_stamps), sizeof(unsigned long long) * (size_t)n);
 }

@@ -14,14 +14,13 @@ struct RowSpace {
   const float* rowmask;   // [R] 1.0 valid / 0.0 padded (v: t < video_seq_len[b]; q: word_ids != 0)
 };
 
-// y1 = LN(x; g1,b1) (+pos[t]) (dropout) ; y2 = LN(x; g2,b2)          models/layers.py:7-17
+// y1 = LN(x; g1,b1) (+pos[t]) ; y2 = LN(x; g2,b2)          models/layers.py:7-17
 struct LnFwd {
   const float* x; int R;
   const float* g1; const float* b1; float* y1;
   const float* g2; const float* b2; float* y2;     // optional
   float* mean; float* rstd;                        // optional [R]
   const float* pos;                                // optional [max_vlen,128]: y1 += pos[t]   (modules.py:41-56)
-  int drop_site; uint32_t drop_row0;               // optional dropout on y1
   int row0;                                        // unified row index of x's first row (pos / clip lookup)
   // optional: x is not given ready but as nparts partial sums (feature_ksplit_kernel): x = sum_q part[q*part_stride + ...]
   // + part_bias; the sum is also written to x_out (the pre-LN tensor backward needs)
@@ -35,16 +34,16 @@ int launch_ln_fwd(const LnFwd& a, const RowSpace& rs, const DropCfg& drop, hipSt
 // dx = LNbwd(x; dy1,g1) + LNbwd(x; dy2,g2) + add1 + add2 ; dgamma/dbeta accumulated with atomics
 struct LnBwd {
   const float* x; const float* mean; const float* rstd; int R;
-  const float* dy1; const float* g1; float* dg1; float* db1; int drop_site1; uint32_t drop_row0;
+  const float* dy1; const float* g1; float* dg1; float* db1;
   const float* dy2; const float* g2; float* dg2; float* db2;
   const float* add1; const float* add2;
   float* dx;
   // optional [ln_bwd_blocks(R)][4][128] scratch: per-block column sums (dg1, db1, dg2, db2) are written there with plain
   // stores instead of atomics on dg/db, so the launch can use every CU; launch_colsum() folds them into the gradients
   float* part;
-  // optional second output for the consumer of dx: dz = dropout'(dx, dz_site) * (dz_relu > 0)   (site < 0: no dropout,
-  // dz_relu null: no mask) - saves the elementwise launch in front of the next dX GEMM
-  float* dz; int dz_site; uint32_t dz_row0; const float* dz_relu;
+  // optional second output for the consumer of dx: dz = dropout'(dx) with the keep bits the forward left in the bit plane
+  // dz_bits ([R][16] bytes, csrc/tilecore.h; null: dz = dx) - saves the elementwise launch in front of the next dX product
+  float* dz; const uint8_t* dz_bits;
   // optional second scale vector for the rows >= split (the two input layer norms in one launch, as LnFwd::split): the first
   // ln_bwd_blocks(split) workgroups take the rows below split, the others the rows from split on; needs `part`
   int split; const float* g1_hi;

@@ -26,13 +26,12 @@ __device__ __forceinline__ void row_stats(float4 v, float& mean, float& rstd) {
   rstd = rsqrtf(var + LN_EPS);
 }
 
-// dz = dropout'(dx, site) * (relu > 0): the operand of the next dX GEMM, written next to dx
-__device__ __forceinline__ void store_dz(float* dz, int site, uint32_t row, const float* relu, size_t off, int l32, float4 dx,
-                                         const hual::DropCfg& drop) {
-  if (site >= 0 && drop.enabled) dx = apply_drop4(drop, (uint32_t)site, row, (uint32_t)l32, dx);
-  if (relu) {
-    const float4 y = ld4(relu + off);
-    dx = make_float4(y.x > 0.f ? dx.x : 0.f, y.y > 0.f ? dx.y : 0.f, y.z > 0.f ? dx.z : 0.f, y.w > 0.f ? dx.w : 0.f);
+// dz = dropout'(dx) with the keep bits the forward left (bit plane: byte [row * 16 + (col >> 3)], bit col & 7; csrc/tilecore.h):
+// the operand of the next dX product, written next to dx
+__device__ __forceinline__ void store_dz(float* dz, const uint8_t* bits, float scale, int row, size_t off, int l32, float4 dx) {
+  if (bits) {
+    const uint32_t nib = ((uint32_t)bits[(size_t)row * 16 + (l32 >> 1)] >> (4 * (l32 & 1))) & 15u;
+    dx = make_float4((nib & 1u) ? dx.x * scale : 0.f, (nib & 2u) ? dx.y * scale : 0.f, (nib & 4u) ? dx.z * scale : 0.f, (nib & 8u) ? dx.w * scale : 0.f);
   }
   st4(dz + off, dx);
 }
@@ -65,8 +64,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd a, RowSpace rs, DropC
       row_to_clip(row + a.row0, rs.Nv, rs.T, rs.L, t, n, base);
       y = f4add_(y, ld4(a.pos + (size_t)t * HUAL_D + col));
     }
-    if (a.drop_site >= 0 && drop.enabled)
-      y = apply_drop4(drop, (uint32_t)a.drop_site, a.drop_row0 + (uint32_t)row, (uint32_t)l32, y);
     st4(a.y1 + (size_t)row * HUAL_D + col, y);
     if (a.y2) st4(a.y2 + (size_t)row * HUAL_D + col, f4fma_(xh, ld4(a.g2 + col), ld4(a.b2 + col)));
     if (a.mean && l32 == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
@@ -92,8 +89,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) {
     float mean = a.mean[row], rstd = a.rstd[row];
     float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
     float4 dy = ld4(a.dy1 + off);
-    if (a.drop_site1 >= 0 && drop.enabled)
-      dy = apply_drop4(drop, (uint32_t)a.drop_site1, a.drop_row0 + (uint32_t)row, (uint32_t)l32, dy);
     sb1 = f4add_(sb1, dy);
     sg1 = f4fma_(dy, xh, sg1);
     float4 gv = f4mul_(dy, g1);
@@ -110,7 +105,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) {
     if (a.add1) dx = f4add_(dx, ld4(a.add1 + off));
     if (a.add2) dx = f4add_(dx, ld4(a.add2 + off));
     st4(a.dx + off, dx);
-    if (a.dz) store_dz(a.dz, a.dz_site, a.dz_row0 + (uint32_t)row, a.dz_relu, off, l32, dx, drop);
+    if (a.dz) store_dz(a.dz, drop.enabled ? a.dz_bits : nullptr, drop.scale, row, off, l32, dx);
   }
   red[0][grp][l32] = sg1; red[1][grp][l32] = sb1; red[2][grp][l32] = sg2; red[3][grp][l32] = sb2;
   __syncthreads();

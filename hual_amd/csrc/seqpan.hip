@@ -70,6 +70,9 @@ struct Ctx {
     return reinterpret_cast<float*>(base + e.off);
   }
   float* act(const std::string& name) { return buf(name, (size_t)rs.R, HUAL_D); }     // [R,128]
+  // bit plane of a [rows,128] tensor (csrc/tilecore.h): 16 bytes per row
+  uint8_t* bits(const std::string& name, size_t rows) { return reinterpret_cast<uint8_t*>(buf(name, rows, 4)); }
+  bool debug_taps = false;    // hual_run_opts.debug_taps: also write the tensors only parity tests read (conv_block relu outputs)
   float* actv(const std::string& name) { return buf(name, (size_t)rs.Nv, HUAL_D); }   // [Nv,128]
   float* vec(const std::string& name) { return buf(name, (size_t)rs.R, 1); }
   // dX jobs name the transposed weight by an address inside a range ("params.T") that mirrors the flat parameters and is
@@ -305,6 +308,9 @@ float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP
       CbLayerFwd& L = a.l[i];
       L.c = c.buf(tag + ".c" + is, R, HUAL_D);
       L.y = c.buf(tag + ".y" + is, R, HUAL_D);
+      if (!c.debug_taps) L.y = nullptr;                       // backward reads the bit planes, not y
+      L.relu_bits = c.bits(tag + ".rb" + is, R);
+      L.keep_bits = c.bits(tag + ".kb" + is, R);
       L.xout = c.buf(tag + ".x" + std::to_string(i + 1), R, HUAL_D);
       L.mean = c.buf(tag + ".mean" + is, R, 1);
       L.rstd = c.buf(tag + ".rstd" + is, R, 1);
@@ -323,7 +329,7 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
   const int R = rs.R;
   {                      // all four layers in one launch (convblock.h); dZ_3 is formed inside from dx and y3
     CbBwdArgs a{};
-    a.dx_in = dx; a.y3 = c.buf(tag + ".y3", R, HUAL_D); a.drop_site3 = site0 + 3;
+    a.dx_in = dx; a.relu_bits3 = c.bits(tag + ".rb3", R); a.keep_bits3 = c.bits(tag + ".kb3", R);
     a.dx_out = c.buf("d." + tag + ".x0", R, HUAL_D);
     a.MT = conv_block_fused_rows_bwd(R); a.drop_row0 = 0;
     const int nblk = conv_block_bwd_blocks(R);
@@ -334,10 +340,10 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
       L.wimg_t = reinterpret_cast<const float*>(c.PKB + cp.pw[i] * 4);
       L.x = i == 0 ? x0 : c.buf(tag + ".x" + is, R, HUAL_D);
       L.mean = c.buf(tag + ".mean" + is, R, 1); L.rstd = c.buf(tag + ".rstd" + is, R, 1);
-      L.y_prev = i > 0 ? c.buf(tag + ".y" + std::to_string(i - 1), R, HUAL_D) : nullptr;
+      L.relu_prev = i > 0 ? c.bits(tag + ".rb" + std::to_string(i - 1), R) : nullptr;
+      L.keep_prev = i > 0 ? c.bits(tag + ".kb" + std::to_string(i - 1), R) : nullptr;
       L.dz = c.buf("d." + tag + ".z" + is, R, HUAL_D);
       L.dz_prev = i > 0 ? c.buf("d." + tag + ".z" + std::to_string(i - 1), R, HUAL_D) : nullptr;
-      L.drop_site_prev = site0 + i - 1;
       L.part = c.buf("part." + std::to_string(c.part_seq++), (size_t)nblk * 9, HUAL_D);
       ColsumJob cj{};
       cj.src = L.part; cj.nblk = nblk; cj.nvec = 9;
@@ -428,7 +434,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     // v_layer_norm on the video rows, q_layer_norm on the query rows (+ position embeddings): one launch over the unified rows
     LnFwd a{};
     a.x = lin; a.R = R; a.g1 = c.p(pm.vln.g); a.b1 = c.p(pm.vln.b); a.y1 = x; a.mean = lin_mean; a.rstd = lin_rstd;
-    a.pos = c.p(pm.pos); a.drop_site = -1; a.row0 = 0;
+    a.pos = c.p(pm.pos); a.row0 = 0;
     a.split = Nv; a.g1_hi = c.p(pm.qln.g); a.b1_hi = c.p(pm.qln.b);
     if (ksplit) {
       a.x = nullptr; a.part = vpart; a.nparts = 4; a.part_stride = (size_t)R * D; a.part_bias = c.p(pm.vconv.b);
@@ -514,6 +520,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       pa.sv = sv; pa.xv = xv; pa.sg = sg; pa.xg = xg; pa.o = o; pa.gd = gd; pa.gate = gate; pa.val = val; pa.mha = mha; pa.res = res;
       pa.l2 = l2; pa.out = xo; pa.mean2 = mean2; pa.rstd2 = rstd2;
       pa.site = site; pa.R = R; pa.MT = da_post_rows(R); pa.drop_row0 = 0;
+      pa.bits2 = c.bits(t + ".kb2", R); pa.bits3 = c.bits(t + ".kb3", R); pa.bits4 = c.bits(t + ".kb4", R);
       if (c.live()) c.chk(launch_da_post(pa, c.drop, c.stream));
     }
     x = xo;
@@ -603,6 +610,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     {                      // layer_norm_1 + dropout + query / key / value in one launch (dablock.h)
       LnProjArgs lp{};
       lp.x = f; lp.g1 = c.p(pm.fe_ln1.g); lp.b1 = c.p(pm.fe_ln1.b); lp.y1 = a1; lp.drop_site1 = site + 4; lp.pre_site = -1;
+      lp.y1_bits = c.bits(t + ".kb4", Nv);
       lp.mean = mean; lp.rstd = rstd; lp.nproj = 3; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
       const DenseP* pr[3] = {&pm.fe_q, &pm.fe_k, &pm.fe_v};
       for (int k = 0; k < 3; ++k) {
@@ -628,6 +636,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     {                      // residual + layer_norm_2 + dropout + dense + dropout + residual in one launch (modules.py:132-139)
       LnProjArgs lp{};
       lp.x = f; lp.xa = att; lp.pre_site = site + 6; lp.x_out = res;
+      lp.pre_bits = c.bits(t + ".kb6", Nv); lp.y1_bits = c.bits(t + ".kb7", Nv); lp.out_bits[0] = c.bits(t + ".kb8", Nv);
       lp.g1 = c.p(pm.fe_ln2.g); lp.b1 = c.p(pm.fe_ln2.b); lp.y1 = l2; lp.drop_site1 = site + 7; lp.mean = mean2; lp.rstd = rstd2;
       lp.nproj = 1; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
       lp.wimg[0] = img(pm.fe_dense.k); lp.bias[0] = c.p(pm.fe_dense.b); lp.out[0] = fo; lp.ldo[0] = D; lp.out_site[0] = site + 8; lp.add_x[0] = 1;
@@ -747,8 +756,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   {
     LnBwd a{};
     a.x = c.actv("fe1.out"); a.mean = hmean + Nv; a.rstd = hrstd + Nv; a.R = Nv; a.dy1 = d_efn; a.g1 = c.p(pm.eln.g);
-    a.dg1 = c.g(pm.eln.g); a.db1 = c.g(pm.eln.b); a.drop_site1 = -1; a.dx = d_feout;
-    a.dz = c.actv("d.fe1.zd"); a.dz_site = HUAL_SITE_FE + 16 + 8;      // dropout'(.) of it for the dense^T product below
+    a.dg1 = c.g(pm.eln.g); a.db1 = c.g(pm.eln.b); a.dx = d_feout;
+    a.dz = c.actv("d.fe1.zd"); a.dz_bits = c.bits("fe1.kb8", Nv);      // dropout'(.) of it for the dense^T product below
     c.ln_bwd(a);
   }
   float* d_in = nullptr;
@@ -771,8 +780,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       float* d0 = c.actv("d.fe0.out");
       LnBwd a{};
       a.x = c.actv("fe0.out"); a.mean = hmean; a.rstd = hrstd; a.R = Nv; a.dy1 = d_sfn; a.g1 = c.p(pm.sln.g);
-      a.dg1 = c.g(pm.sln.g); a.db1 = c.g(pm.sln.b); a.drop_site1 = -1; a.add1 = d_in; a.dx = d0;
-      a.dz = c.actv("d.fe0.zd"); a.dz_site = HUAL_SITE_FE + 8;
+      a.dg1 = c.g(pm.sln.g); a.db1 = c.g(pm.sln.b); a.add1 = d_in; a.dx = d0;
+      a.dz = c.actv("d.fe0.zd"); a.dz_bits = c.bits("fe0.kb8", Nv);
       c.ln_bwd(a);
       d_feout = d0;
     }
@@ -783,9 +792,9 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     auto imgt = [&](size_t off) { return reinterpret_cast<const float*>(c.PKB + off * 4); };
     {                      // dense^T + layer_norm_2 backward in one launch (dablock.h); dZ of the dense layer came from upstream
       LnProjBwdArgs lb{};
-      lb.nsteps = 1; lb.A[0] = dzd; lb.lda[0] = D; lb.a_site[0] = -1; lb.wimg_t[0] = imgt(pm.fe_dense.k); lb.dst[0] = 0;
-      lb.dy1_site = site + 7; lb.x = res; lb.mean = mean2; lb.rstd = rstd2; lb.g1 = c.p(pm.fe_ln2.g); lb.add1 = d_feout;
-      lb.dx = d_res; lb.dz = c.actv("d." + t + ".att"); lb.dz_site = site + 6; lb.R = Nv; lb.drop_row0 = 0;
+      lb.nsteps = 1; lb.A[0] = dzd; lb.lda[0] = D; lb.wimg_t[0] = imgt(pm.fe_dense.k); lb.dst[0] = 0;
+      lb.dy1_bits = c.bits(t + ".kb7", Nv); lb.x = res; lb.mean = mean2; lb.rstd = rstd2; lb.g1 = c.p(pm.fe_ln2.g); lb.add1 = d_feout;
+      lb.dx = d_res; lb.dz = c.actv("d." + t + ".att"); lb.dz_bits = c.bits(t + ".kb6", Nv); lb.R = Nv; lb.drop_row0 = 0;
       c.ln_proj_bwd(lb, c.g(pm.fe_ln2.g), c.g(pm.fe_ln2.b), nullptr, nullptr);
     }
     // res = dropout(att, s6) + f: dropout'(d res) was written by the launch above
@@ -810,9 +819,9 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       LnProjBwdArgs lb{};
       lb.nsteps = 3;
       const size_t wo[3] = {pm.fe_q.k, pm.fe_k.k, pm.fe_v.k};
-      for (int k = 0; k < 3; ++k) { lb.A[k] = d_qkv + k * D; lb.lda[k] = 3 * D; lb.a_site[k] = -1; lb.wimg_t[k] = imgt(wo[k]); lb.dst[k] = 0; }
-      lb.dy1_site = site + 4; lb.x = f; lb.mean = mean; lb.rstd = rstd; lb.g1 = c.p(pm.fe_ln1.g); lb.add1 = d_res;
-      lb.dx = d_f; lb.dz_site = -1; lb.R = Nv; lb.drop_row0 = 0;
+      for (int k = 0; k < 3; ++k) { lb.A[k] = d_qkv + k * D; lb.lda[k] = 3 * D; lb.wimg_t[k] = imgt(wo[k]); lb.dst[k] = 0; }
+      lb.dy1_bits = c.bits(t + ".kb4", Nv); lb.x = f; lb.mean = mean; lb.rstd = rstd; lb.g1 = c.p(pm.fe_ln1.g); lb.add1 = d_res;
+      lb.dx = d_f; lb.R = Nv; lb.drop_row0 = 0;
       c.ln_proj_bwd(lb, c.g(pm.fe_ln1.g), c.g(pm.fe_ln1.b), nullptr, nullptr);
     }
     float* d_x0 = conv_block_bwd(c, t, x0, d_f, pm.fe_cb, c.rsv, site);
@@ -992,10 +1001,10 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       // (1) dense_2^T + layer_norm_2 backward -> d res, dZ1     (2) the gated middle, ten weight steps     (dablock.h)
       LnProjBwdArgs lb{};
       lb.nsteps = 1; lb.lda[0] = D; lb.wimg_t[0] = imgt(d.dense2.k); lb.dst[0] = 0;
-      if (dz2_ready) { lb.A[0] = dz2; lb.a_site[0] = -1; }
-      else { lb.A[0] = dx; lb.a_site[0] = site + 4; lb.a_save[0] = dz2; }
-      lb.dy1_site = site + 3; lb.x = res; lb.mean = mean2; lb.rstd = rstd2; lb.g1 = c.p(d.ln2.g); lb.add1 = dx;
-      lb.dx = d_res; lb.dz = dz1; lb.dz_site = site + 2; lb.R = R; lb.drop_row0 = 0;
+      if (dz2_ready) { lb.A[0] = dz2; }
+      else { lb.A[0] = dx; lb.a_bits[0] = c.bits(t + ".kb4", R); lb.a_save[0] = dz2; }
+      lb.dy1_bits = c.bits(t + ".kb3", R); lb.x = res; lb.mean = mean2; lb.rstd = rstd2; lb.g1 = c.p(d.ln2.g); lb.add1 = dx;
+      lb.dx = d_res; lb.dz = dz1; lb.dz_bits = c.bits(t + ".kb2", R); lb.R = R; lb.drop_row0 = 0;
       c.ln_proj_bwd(lb, c.g(d.ln2.g), c.g(d.ln2.b), nullptr, nullptr);
       DaMidBwdArgs mb{};
       mb.dz1 = dz1; mb.gate = gate; mb.val = val; mb.sg = sg; mb.xg = xg; mb.sv = sv; mb.xv = xv;
@@ -1036,17 +1045,17 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.push_dw(mkdw(lnt, D, D, d_ktvt + D, 2 * D, R, c.g(d.t_value.k), c.g(d.t_value.b)));
     float* d_xin = c.act(dt + ".in");
     // operand of the next dX product down the stack: previous layer's dense_2, or (unfused conv block) its layer 3
-    float* nz = nullptr; int nz_site = -1; const float* nz_relu = nullptr;
-    if (li > 0) { nz = c.act("d.da" + std::to_string(li - 1) + ".z2"); nz_site = HUAL_SITE_DA + 8 * (li - 1) + 4; }
+    float* nz = nullptr; const uint8_t* nz_bits = nullptr;
+    if (li > 0) { nz = c.act("d.da" + std::to_string(li - 1) + ".z2"); nz_bits = c.bits("da" + std::to_string(li - 1) + ".kb4", R); }
     {                      // the six projection^T products + layer_norm_1 / layer_norm_t backward in one launch (dablock.h)
       LnProjBwdArgs lb{};
       lb.nsteps = 6;
       const float* As[6] = {dq_self, dq_cross, d_qkv + D, d_qkv + 2 * D, d_ktvt, d_ktvt + D};
       const int lds_[6] = {D, D, 3 * D, 3 * D, 2 * D, 2 * D};
       const size_t wo[6] = {d.query.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
-      for (int k = 0; k < 6; ++k) { lb.A[k] = As[k]; lb.lda[k] = lds_[k]; lb.a_site[k] = -1; lb.wimg_t[k] = imgt(wo[k]); lb.dst[k] = k < 4 ? 0 : 1; }
-      lb.add_dy1 = d_ln1a; lb.dy1_site = -1; lb.x = xin; lb.mean = mean; lb.rstd = rstd; lb.g1 = c.p(d.ln1.g); lb.g2 = c.p(d.lnt.g);
-      lb.add1 = d_res; lb.dx = d_xin; lb.dz = nz; lb.dz_site = nz_site; lb.dz_relu = nz_relu; lb.R = R; lb.drop_row0 = 0;
+      for (int k = 0; k < 6; ++k) { lb.A[k] = As[k]; lb.lda[k] = lds_[k]; lb.wimg_t[k] = imgt(wo[k]); lb.dst[k] = k < 4 ? 0 : 1; }
+      lb.add_dy1 = d_ln1a; lb.x = xin; lb.mean = mean; lb.rstd = rstd; lb.g1 = c.p(d.ln1.g); lb.g2 = c.p(d.lnt.g);
+      lb.add1 = d_res; lb.dx = d_xin; lb.dz = nz; lb.dz_bits = nz_bits; lb.R = R; lb.drop_row0 = 0;
       c.ln_proj_bwd(lb, c.g(d.ln1.g), c.g(d.ln1.b), c.g(d.lnt.g), c.g(d.lnt.b));
     }
     dx = d_xin;
@@ -1072,7 +1081,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     // v_layer_norm (video rows) and q_layer_norm (query rows) backward: one launch over the unified rows
     LnBwd a{};
     a.x = lin; a.mean = lin_mean; a.rstd = lin_rstd; a.R = R; a.dy1 = d_x0; a.g1 = c.p(pm.vln.g);
-    a.drop_site1 = -1; a.dx = d_lin; a.split = Nv; a.g1_hi = c.p(pm.qln.g);
+    a.dx = d_lin; a.split = Nv; a.g1_hi = c.p(pm.qln.g);
     c.ln_bwd_split(a, c.g(pm.vln.g), c.g(pm.vln.b), c.g(pm.qln.g), c.g(pm.qln.b));
   }
   float* cat = c.buf("cat", Nq, catw);
@@ -1222,6 +1231,7 @@ int hual_seqpan_forward(const hual_cfg* cfg, const float* params, const float* w
   c.word_table = word_table;
   c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
   c.want_bwd = labels != nullptr;
+  c.debug_taps = opts->debug_taps != 0;
   rc = forward_graph(c, batch, labels, out, opts);
   if (rc) return rc;
   return 0;
@@ -1310,6 +1320,7 @@ int run_block(const hual_cfg* cfg, const float* params, const float* word_table,
   c.word_table = word_table;
   c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
   c.sel_stage = stage; c.sel_sub = sub; c.want_bwd = true;
+  c.debug_taps = opts->debug_taps != 0;
   c.part_seq = 0;
   c.rs.rowmask = c.vec("rowmask");
   c.rsv.rowmask = c.rs.rowmask;

@@ -11,11 +11,14 @@
 // shader clock at phase boundaries into a device-global table read back through hual_debug_stamps().
 #ifdef HUAL_STAMPS
 #define HUAL_STAMP_SLOTS 64
-extern __device__ unsigned long long g_hual_stamps[512 * HUAL_STAMP_SLOTS];
-#define HUAL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (i) < HUAL_STAMP_SLOTS) g_hual_stamps[blockIdx.x * HUAL_STAMP_SLOTS + (i)] = __builtin_readcyclecounter(); } while (0)
+static __device__ unsigned long long g_hual_stamps[512 * HUAL_STAMP_SLOTS];      // one table per translation unit
+// HUAL_STAMPS selects the kernel that writes: 1 da_post_kernel, 2 conv_block_fwd_kernel, 3 conv_block_bwd_kernel,
+// 4 ln_proj_bwd_kernel, 5 da_mid_bwd_kernel, 6 ln_proj_kernel (build: HUAL_EXP_DEFS=HUAL_STAMPS=<n>)
+#define HUAL_STAMP_K(k, i) do { if (HUAL_STAMPS == (k) && threadIdx.x == 0 && blockIdx.x < 512 && (i) < HUAL_STAMP_SLOTS) g_hual_stamps[blockIdx.x * HUAL_STAMP_SLOTS + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
-#define HUAL_STAMP(i) do { } while (0)
+#define HUAL_STAMP_K(k, i) do { } while (0)
 #endif
+#define HUAL_STAMP(i) HUAL_STAMP_K(1, i)
 
 #define LN_EPS 1e-6f   // models/layers.py:15
 #define CB_THREADS 512
@@ -36,10 +39,13 @@ __device__ __forceinline__ float cb_hsum(float4 a) { return (a.x + a.y) + (a.z +
 // philox.h's drop_mask4 reads the three state words from global memory on every call; in a latency-bound fused kernel that
 // is a memory round trip per call (and, next to an LDS-DMA in flight, a vmcnt(0) that also waits for every store issued
 // before it).  The fused kernels read the state once at entry.
-struct DropRegs { uint32_t k0, k1, off, thresh; float scale; int enabled; };
+struct DropRegs { uint32_t k0, k1, off, thresh, t16; float scale; int enabled; };
 __device__ __forceinline__ DropRegs drop_load(const hual::DropCfg& d) {
   DropRegs r;
   r.enabled = d.enabled; r.thresh = d.thresh; r.scale = d.scale; r.k0 = 0; r.k1 = 0; r.off = 0;
+  // 16-bit threshold of the row-local sites (oracle/philox.py keep_threshold16): round(keep_prob * 65536) in [1, 65536]
+  const uint32_t t = (uint32_t)(((uint64_t)d.thresh + (1ull << 15)) >> 16);
+  r.t16 = t < 1u ? 1u : (t > 65536u ? 65536u : t);
   if (d.enabled) {
     r.k0 = __builtin_amdgcn_readfirstlane(d.state[0]);
     r.k1 = __builtin_amdgcn_readfirstlane(d.state[1]);
@@ -47,15 +53,57 @@ __device__ __forceinline__ DropRegs drop_load(const hual::DropCfg& d) {
   }
   return r;
 }
-// keep bits of the 4 columns [4*col4, 4*col4+3] of `row` at call-site `site` (same draw as philox.h drop_bits4)
-__device__ __forceinline__ uint32_t drop_bits4_r(const DropRegs& d, uint32_t site, uint32_t row, uint32_t col4) {
-  const uint4_ r = philox4x32_10(col4, row, site, d.off, d.k0, d.k1);
-  return (r.x < d.thresh ? 1u : 0u) | (r.y < d.thresh ? 2u : 0u) | (r.z < d.thresh ? 4u : 0u) | (r.w < d.thresh ? 8u : 0u);
+// Dropout decisions of the row-local sites inside the fused kernels: ONE Philox call decides the 8 consecutive columns
+// 8 col8 .. 8 col8 + 7 of a row from its eight 16-bit halves (element e = col & 7: word e >> 1, half e & 1; kept iff half <
+// t16) - bit e of the result.  Half the generator work per element of the 32-bit scheme of philox.h, keep probability
+// t16 / 65536 (0.800003 for rate 0.2; tf.nn.dropout's own float32 uniform is no finer than 2^-23).
+__device__ __forceinline__ uint32_t drop_bits8_r(const DropRegs& d, uint32_t site, uint32_t row, uint32_t col8) {
+  const uint4_ r = philox4x32_10(col8, row, site, d.off, d.k0, d.k1);
+  const uint32_t t = d.t16;
+  return ((r.x & 0xffffu) < t ? 1u : 0u) | ((r.x >> 16) < t ? 2u : 0u) | ((r.y & 0xffffu) < t ? 4u : 0u) | ((r.y >> 16) < t ? 8u : 0u) |
+         ((r.z & 0xffffu) < t ? 16u : 0u) | ((r.z >> 16) < t ? 32u : 0u) | ((r.w & 0xffffu) < t ? 64u : 0u) | ((r.w >> 16) < t ? 128u : 0u);
 }
-__device__ __forceinline__ float4 apply_drop4_r(const DropRegs& d, uint32_t site, uint32_t row, uint32_t col4, float4 v) {
-  const float4 m = mask_from_bits4(drop_bits4_r(d, site, row, col4), d.scale);
-  v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-  return v;
+__device__ __forceinline__ uint32_t dpp_xor1_u32(uint32_t v) { return __builtin_bit_cast(uint32_t, dpp_xor_partner(__builtin_bit_cast(float, v), 1)); }
+// Keep nibbles (bit c = column 4 col4 + c) of this lane's four columns for the TWO rows rowA and rowB.  The lanes col4 and
+// col4 ^ 1 (DPP neighbours in both layouts of the fused kernels: the 32-lane row layout, col4 = lane & 31, and the
+// accumulator layout, col4 = 16 ch + (lane & 15)) share an 8-column group: the even one draws rowA's call, the odd one
+// rowB's, and they swap the halves.  All lanes of the wave must be active.
+__device__ __forceinline__ uint32_t drop_nib2_r(const DropRegs& d, uint32_t site, uint32_t rowA, uint32_t rowB, uint32_t col4, uint32_t& nibA,
+                                                uint32_t& nibB) {
+  const bool odd = (col4 & 1u) != 0u;
+  const uint32_t b = drop_bits8_r(d, site, odd ? rowB : rowA, col4 >> 1);
+  const uint32_t o = dpp_xor1_u32(b);
+  nibA = odd ? (o >> 4) : (b & 15u);
+  nibB = odd ? (b >> 4) : (o & 15u);
+  return b;        // the whole byte of the bit plane for (odd ? rowB : rowA, col4 >> 1)
+}
+// the same + the keep bytes stored into `plane` (rows are indices into the plane; rowoff = RNG row - plane row)
+__device__ __forceinline__ void drop_nib2_store_r(const DropRegs& d, uint32_t site, uint32_t rowoff, int rowA, int rowB, bool okA, bool okB,
+                                                  uint32_t col4, uint8_t* plane, uint32_t& nibA, uint32_t& nibB) {
+  const uint32_t b = drop_nib2_r(d, site, rowoff + (uint32_t)rowA, rowoff + (uint32_t)rowB, col4, nibA, nibB);
+  const bool odd = (col4 & 1u) != 0u;
+  if (plane && (odd ? okB : okA)) plane[(size_t)(odd ? rowB : rowA) * 16 + (col4 >> 1)] = (uint8_t)b;
+}
+
+// ---- bit planes of a [R,128] tensor (dropout keep bits, relu active sets): byte [row * 16 + (col >> 3)], bit col & 7 - 16 bytes
+// per row.  In both layouts of the fused kernels a lane holds 4 consecutive columns of a row (col4 = col >> 2) and its DPP
+// neighbour col4 ^ 1 the other half of the byte.
+__device__ __forceinline__ uint32_t bits_nibble(const uint8_t* plane, int row, int col4) {
+  return ((uint32_t)plane[(size_t)row * 16 + (col4 >> 1)] >> (4 * (col4 & 1))) & 15u;
+}
+// nibbles of TWO rows -> bytes: the even lane of a pair stores rowA's byte, the odd lane rowB's (okA / okB: row is stored)
+__device__ __forceinline__ void bits_store2(uint8_t* plane, int rowA, int rowB, bool okA, bool okB, int col4, uint32_t nibA, uint32_t nibB) {
+  const bool odd = (col4 & 1) != 0;
+  const uint32_t mine = nibA | (nibB << 4);                  // even lane: [A lo | B lo], odd lane: [A hi | B hi]
+  const uint32_t other = dpp_xor1_u32(mine);
+  const uint32_t byte = odd ? ((other >> 4) | (mine & 0xf0u)) : ((mine & 15u) | ((other & 15u) << 4));
+  if (odd ? okB : okA) plane[(size_t)(odd ? rowB : rowA) * 16 + (col4 >> 1)] = (uint8_t)byte;
+}
+__device__ __forceinline__ float4 f4_select(uint32_t nib, float4 v) {
+  return make_float4((nib & 1u) ? v.x : 0.f, (nib & 2u) ? v.y : 0.f, (nib & 4u) ? v.z : 0.f, (nib & 8u) ? v.w : 0.f);
+}
+__device__ __forceinline__ uint32_t f4_posbits(float4 v) {
+  return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
 }
 
 // clip segment [lo, hi) of unified row `row` (rowops.h RowSpace)

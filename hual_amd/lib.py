@@ -46,7 +46,7 @@ class hual_outputs(ctypes.Structure):
 class hual_run_opts(ctypes.Structure):
     _fields_ = [('drop_rate', ctypes.c_float), ('rng_state', ctypes.c_void_p), ('match_denom_override', ctypes.c_float),
                 ('align_external', ctypes.c_int32), ('static_tables', ctypes.c_int32),
-                ('match_denom_dev', ctypes.c_void_p), ('grads_prezero', ctypes.c_void_p)]
+                ('match_denom_dev', ctypes.c_void_p), ('debug_taps', ctypes.c_int32), ('grads_prezero', ctypes.c_void_p)]
 
 
 class hual_al_set(ctypes.Structure):
@@ -109,6 +109,7 @@ def load():
     lib.hual_predictor_bwd.argtypes = blk + [vp, vp, vp, vp, vp, u64, vp]
     lib.hual_prof_get.argtypes = [i32, ctypes.c_char_p, i32, P(ctypes.c_int64), P(ctypes.c_double), P(ctypes.c_double),
                                   P(ctypes.c_double)]
+    lib.hual_prof_kernel_pipe.argtypes = [ctypes.c_char_p, P(i32), P(i32)]
     lib.hual_linear_fwd.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.hual_linear_bf16x3.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, u64, vp]
     lib.hual_layer_norm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]

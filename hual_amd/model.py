@@ -110,6 +110,13 @@ class SeqPAN:
         off, rows, cols = self._ws_table[name]
         return self._ws[off:off + rows * cols * 4].view(torch.float32).view(rows, cols)
 
+    def tap_bits(self, name):
+        """bool [rows, 128] view of a bit plane of the workspace (relu active sets "*.rb*", dropout keep sets "*.kb*":
+        byte [row * 16 + (col >> 3)], bit col & 7 - csrc/tilecore.h)"""
+        off, rows, cols = self._ws_table[name]
+        by = self._ws[off:off + rows * 16].view(rows, 16).cpu().numpy()
+        return torch.from_numpy(np.unpackbits(by, axis=1, bitorder='little').astype(bool))
+
     # ------------------------------------------------------------------ feeds
     def _to_dev(self, a, dtype):
         if isinstance(a, torch.Tensor):
@@ -154,8 +161,11 @@ class SeqPAN:
              self._to_dev(inner_labels, torch.float32))
         return lib.hual_labels(*[lib.ptr(x).value for x in t]), t
 
+    debug_taps = False       # True: forward also writes the tensors only parity tests read (hual_run_opts.debug_taps)
+
     def _opts(self, drop_rate, match_denom=0.0, align_external=0):
-        return lib.hual_run_opts(float(drop_rate), lib.ptr(self.rng_state).value, float(match_denom), int(align_external), 0)
+        return lib.hual_run_opts(float(drop_rate), lib.ptr(self.rng_state).value, float(match_denom), int(align_external), 0, None,
+                                 1 if self.debug_taps else 0, None)
 
     # ------------------------------------------------------------------ fetches
     def forward(self, video_inputs, video_seq_len, word_ids, char_ids, drop_rate=0.0, labels=None, _opts=None):

@@ -139,7 +139,7 @@ class Trainer:
         return lib.hual_run_opts(float(drop_rate), lib.ptr(self.m.rng_state).value, float(self.match_denom),
                                  int(align_external),
                                  1 if (self._tables_ready and not os.environ.get('HUAL_NO_STATIC_TABLES')) else 0,
-                                 lib.ptr(self.denom_dev).value if self.dp else None,
+                                 lib.ptr(self.denom_dev).value if self.dp else None, 0,
                                  # the forward's first launch zeroes the gradient bucket (one launch fewer in backward)
                                  lib.ptr(self.m.grads).value)
 

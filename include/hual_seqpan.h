@@ -133,6 +133,9 @@ typedef struct hual_run_opts {
   const float* match_denom_dev;   /* non-NULL: the denominator of the masked matching loss is read from this DEVICE scalar
                                         when the kernels run (takes precedence over match_denom_override): a data-parallel
                                         step can all-reduce the valid-frame count on the stream without a host round trip */
+  int32_t debug_taps;             /* 1: the forward also writes the tensors that only parity tests read (the relu outputs of the
+                                        conv_block layers, "cb.y*" / "fe*.y*" of the workspace table); the backward pass never
+                                        reads them (it reads the bit planes "*.rb*" / "*.kb*") */
   float* grads_prezero;           /* non-NULL, hual_seqpan_forward with labels: this flat gradient buffer is zeroed by the
                                         forward's first launch; a hual_seqpan_backward call given the same pointer here and as
                                         its `grads` then skips its own zeroing launch (one launch fewer per step) */
@@ -361,6 +364,12 @@ int hual_al_renew(const hual_al_set* set, const int32_t* sel, int nsel, const fl
 int hual_prof_begin(void);
 int hual_prof_end(void);
 int hual_prof_get(int i, char* name, int name_cap, int64_t* launches, double* usec, double* flops, double* bytes);
+/* the matrix pipe kernel `kernel` (a name hual_prof_get returned) runs its products on, and the MFMA passes one algorithmic
+ * product costs there (split operands: 3) - what a TFLOP/s figure of that kernel has to be priced against */
+#define HUAL_PIPE_NONE 0       /* no matrix instructions */
+#define HUAL_PIPE_MATRIX32 1   /* v_mfma_f32_*_f32: 157.3 TFLOP/s dense peak */
+#define HUAL_PIPE_MATRIX16 2   /* v_mfma_f32_*_{f16,bf16}: 2516.8 TFLOP/s dense peak */
+int hual_prof_kernel_pipe(const char* kernel, int* pipe, int* passes);
 
 #ifdef __cplusplus
 }

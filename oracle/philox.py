@@ -23,6 +23,15 @@ byte < t8, t8 = round(keep_prob * 256) in [1, 256] (computed from the 32-bit thr
 elements are scaled by float32(256) / float32(t8): inverted dropout at the keep probability t8 / 256 closest to
 1 - rate (0.80078 for rate 0.2), unbiased.
 
+The row-local sites INSIDE the network (every dropout of conv_block, dual_attn_block and the predictor's feature encoders
+that is not an attention-probability site: SITE_CONV+l, SITE_DA+8li+{2,3,4}, SITE_FE+16p+{0..4,6,7,8}) draw 8 decisions
+from the eight 16-bit halves of one call (hual_amd/csrc/tilecore.h drop_bits8_r): counter c0 = col >> 3, c1 = row; element
+e = col & 7 uses word e >> 1, half e & 1 (little endian) and is KEPT iff half < t16, t16 = round(keep_prob * 65536) in
+[1, 65536] (= (thresh + 2**15) >> 16); kept elements are scaled by 1 / (1 - rate) exactly as tf.nn.dropout does.  The keep
+probability is t16 / 65536 (0.8000031 for rate 0.2 - closer to 1 - rate than the 2**-23 grid of TensorFlow's own float32
+uniform draw allows it to be).  The input sites (word / char embeddings, clip features) and the trilinear sites keep one
+decision per 32-bit word.
+
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
 import numpy as np
@@ -76,6 +85,23 @@ def keep_scale(rate):
     return np.float32(1.0) / (np.float32(1.0) - np.float32(rate))
 
 
+def keep_threshold16(rate):
+    """16-bit threshold of the row-local sites inside the network: keep iff half < t16"""
+    t = (keep_threshold(rate) + (1 << 15)) >> 16
+    return max(1, min(t, 65536))
+
+
+def uses_16bit_decisions(site):
+    """row-local dropout sites of conv_block / dual_attn_block / feature_encoder (not the attention probabilities)"""
+    if SITE_CONV <= site < SITE_CONV + 4:
+        return True
+    if SITE_DA <= site < SITE_TRI:
+        return (site - SITE_DA) % 8 in (2, 3, 4)
+    if site >= SITE_FE:
+        return (site - SITE_FE) % 16 in (0, 1, 2, 3, 4, 6, 7, 8)
+    return False
+
+
 def keep_threshold8(rate):
     """8-bit threshold of the attention-probability dropout: keep iff byte < t8"""
     t = (keep_threshold(rate) + (1 << 23)) >> 24
@@ -93,6 +119,7 @@ class DropoutRNG:
         self.k1 = (self.seed >> 32) & 0xFFFFFFFF
         self.thresh = keep_threshold(rate)
         self.scale = keep_scale(rate)
+        self.t16 = keep_threshold16(rate)
         self.t8 = keep_threshold8(rate)
         self.scale8 = np.float32(256.0) / np.float32(self.t8)
 
@@ -104,9 +131,22 @@ class DropoutRNG:
         out = np.stack(o, axis=-1).reshape(rows.shape[0], nblk * 4)
         return out[:, :ncols]
 
+    def mask16(self, site, rows, ncols):
+        """16-bit decisions (module docstring): [len(rows), ncols] float32 of {0, 1 / (1 - rate)}"""
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.uint64)).reshape(-1, 1)
+        nblk = (ncols + 7) // 8
+        c0 = np.arange(nblk, dtype=np.uint64).reshape(1, -1)
+        o = philox4x32_10(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
+        words = np.stack(o, axis=-1)                                   # [rows, call, word]
+        halves = np.stack([words & np.uint32(0xFFFF), words >> np.uint32(16)], axis=-1)     # [rows, call, word, half]
+        h = halves.reshape(rows.shape[0], nblk * 8)[:, :ncols]
+        return np.where(h < np.uint32(self.t16), self.scale, np.float32(0.0)).astype(np.float32)
+
     def mask(self, site, rows, ncols):
         if self.rate == 0.0:
             return np.ones((len(np.atleast_1d(rows)), ncols), dtype=np.float32)
+        if uses_16bit_decisions(int(site)):
+            return self.mask16(site, rows, ncols)
         b = self.bits(site, rows, ncols)
         return np.where(b < np.uint32(self.thresh), self.scale, np.float32(0.0)).astype(np.float32)
 

@@ -112,17 +112,18 @@ def tap_pairs(o_tap, B, T, L, n_layers=2):
 
 
 def relu_pins(m, B, T, L):
-    """ReLU active sets of the HIP forward that just ran (its saved relu outputs > 0), in the layout
-    oracle.seqpan_ref.forward(relu_pin=...) takes.  See seqpan_ref._relu: with the active sets shared, gradients
-    are comparable element by element even where a pre-activation sits within float32 rounding of zero."""
+    """ReLU active sets of the HIP forward that just ran (the bit planes it leaves for its backward pass, "*.rb*"; the hidden
+    layers of the heads: saved relu outputs > 0), in the layout oracle.seqpan_ref.forward(relu_pin=...) takes.  See
+    seqpan_ref._relu: with the active sets shared, gradients are comparable element by element even where a
+    pre-activation sits within float32 rounding of zero."""
     Nv = B * T
     pin = {'cb.v': [], 'cb.q': [], 'fe0': [], 'fe1': []}
     for i in range(4):
-        y = m.tap('cb.y%d' % i).cpu()
-        pin['cb.v'].append((y[:Nv] > 0).reshape(B, T, -1))
-        pin['cb.q'].append((y[Nv:] > 0).reshape(B, L, -1))
+        rb = m.tap_bits('cb.rb%d' % i)
+        pin['cb.v'].append(rb[:Nv].reshape(B, T, -1))
+        pin['cb.q'].append(rb[Nv:].reshape(B, L, -1))
         for ps in range(2):
-            pin['fe%d' % ps].append((m.tap('fe%d.y%d' % (ps, i)).cpu() > 0).reshape(B, T, -1))
+            pin['fe%d' % ps].append(m.tap_bits('fe%d.rb%d' % (ps, i)).reshape(B, T, -1))
     pin['head.hs'] = (m.tap('head.hs').cpu() > 0).reshape(B, T, -1)
     pin['head.he'] = (m.tap('head.he').cpu() > 0).reshape(B, T, -1)
     return pin
@@ -188,6 +189,7 @@ def compare(cfg, p, wv, b, labels, drop_rate=0.0, seed=5, offset=7, with_grads=T
         b['video'] = video_feed.to(torch.float32)
     m = hip_model(cfg, p, wv, device)
     m.set_rng(seed, offset)
+    m.debug_taps = True          # the relu outputs of the conv_block layers ("cb.y*"): written for the tap comparison only
     h_out = m.forward(video_feed, b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(),
                       drop_rate=drop_rate, labels=tuple(x.numpy() for x in labels))
     torch.cuda.synchronize()

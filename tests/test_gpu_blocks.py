@@ -112,8 +112,8 @@ def test_conv_block_fwd_bwd(shape):
     lib.check(blk.l.hual_conv_block_fwd(*blk.args(), lib.ptr(xd), lib.ptr(y), *blk.tail()))
     lib.check(blk.l.hual_conv_block_bwd(*blk.args(), lib.ptr(dyd), lib.ptr(dx), lib.ptr(blk.grads), *blk.tail()))
     torch.cuda.synchronize()
-    pins_v = [(blk.m.tap('cb.y%d' % i).cpu()[:blk.Nv] > 0).reshape(blk.B, blk.T, -1) for i in range(4)]
-    pins_q = [(blk.m.tap('cb.y%d' % i).cpu()[blk.Nv:] > 0).reshape(blk.B, blk.L, -1) for i in range(4)]
+    pins_v = [blk.m.tap_bits('cb.rb%d' % i)[:blk.Nv].reshape(blk.B, blk.T, -1) for i in range(4)]
+    pins_q = [blk.m.tap_bits('cb.rb%d' % i)[blk.Nv:].reshape(blk.B, blk.L, -1) for i in range(4)]
     pr = blk.oracle_params()
     xr = x.clone().requires_grad_(True)
     xv, xq = blk.split(xr)
@@ -193,7 +193,7 @@ def test_predictor_fwd_bwd(shape):
     torch.cuda.synchronize()
     pin = {}
     for ps in range(2):
-        pin['fe%d' % ps] = [(blk.m.tap('fe%d.y%d' % (ps, i)).cpu() > 0).reshape(B, T, -1) for i in range(4)]
+        pin['fe%d' % ps] = [blk.m.tap_bits('fe%d.rb%d' % (ps, i)).reshape(B, T, -1) for i in range(4)]
     pin['head.hs'] = (blk.m.tap('head.hs').cpu() > 0).reshape(B, T, -1)
     pin['head.he'] = (blk.m.tap('head.he').cpu() > 0).reshape(B, T, -1)
     pr = blk.oracle_params()
