@@ -141,10 +141,10 @@ int hual_attention_fwd_wide(const float* Q, int ldq, const float* K, const float
 int hual_span_argmax(const float* start_logits, const float* end_logits, const float* vmask, int64_t* start_index,
                      int64_t* end_index, int B, int T, void* stream) {
   HUAL_REQUIRE(start_logits && end_logits && vmask && start_index && end_index && B > 0 && T > 0, "hual_span_argmax: null / empty");
-  LocArgs a{};
-  a.s_logit = start_logits; a.e_logit = end_logits; a.vmask = vmask; a.start_index = start_index; a.end_index = end_index;
-  a.inv_batch = 1.0f / (float)B;
-  return launch_loc(a, B, T, (hipStream_t)stream);
+  HeadsArgs a{};
+  a.logit[0] = const_cast<float*>(start_logits); a.logit[1] = const_cast<float*>(end_logits); a.vmask = vmask;
+  a.start_index = start_index; a.end_index = end_index; a.inv_batch = 1.0f / (float)B;
+  return launch_heads(a, B, T, (hipStream_t)stream);
 }
 
 }  // extern "C"

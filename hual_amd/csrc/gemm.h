@@ -73,6 +73,7 @@ struct DwBatch {
 struct PackExtra {
   const int32_t* lens; const int32_t* word_ids; float* rowmask; float* loss_acc; int B, T, L;
   float* zero_ptr; size_t zero_n;      // zero_n floats (multiple of 4), 16-byte aligned
+  const float* E; float lambda; float* dE_ortho;   // optional: label_emb [4,128] -> loss_acc[LA_ORTHO] and lambda * d ortho / dE (ortho.h)
 };
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
                         hipStream_t stream, const PackExtra* extra = nullptr);

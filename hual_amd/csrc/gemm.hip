@@ -9,6 +9,7 @@
 #include "philox.h"
 #include "bf16x3.h"
 #include "prof.h"
+#include "ortho.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -522,6 +523,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
                              : (ex.word_ids[i - Nv] != 0 ? 1.0f : 0.0f);            // model.py:32
     if (ex.zero_ptr)
       for (size_t i = t0; i < ex.zero_n / 4; i += nt) reinterpret_cast<float4*>(ex.zero_ptr)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ex.E && blockIdx.x == 0) {      // orthogonality term of the label embeddings (parameters only, ortho.h)
+      __shared__ float osm[20];
+      __syncthreads();                  // behind the zeroing of the loss accumulators above
+      ortho_body(ex.E, ex.loss_acc + 2 /* LA_ORTHO */, ex.lambda, ex.dE_ortho, osm);
+    }
     return;
   }
   const PackJob job = b.j[blockIdx.y];

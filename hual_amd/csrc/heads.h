@@ -6,7 +6,7 @@
 
 namespace hual {
 
-// loss accumulator slots (float[8], zeroed each step)
+// loss accumulator slots (float[8], zeroed each step by the prologue launch)
 enum { LA_MATCH_SUM = 0, LA_MASK_SUM = 1, LA_ORTHO = 2, LA_LOC = 3, LA_ALIGN = 4, LA_DENOM = 5 };
 
 // ---- cq_concat: weighted pooling of v2q_feats + the pooled half of the 2D->D dense (layers.py:133-154)
@@ -46,49 +46,41 @@ struct MatchArgs {
                           // atomics queued on one address retire at ~30 ns each, 2 x 128 of them were half of this kernel
 };
 int match_fwd_blocks(int Nv);
-int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, hipStream_t s);
+struct AlignSim;
+int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, const AlignSim* as, hipStream_t s);
 struct MatchBwd {
   const float* dOut;      // [Nv,128] gradient wrt outputs
   const float* dOut2;     // optional second part of it (added on the fly: the predictor's heads and encoders both read `outputs`)
   float* dFuse;           // [Nv,128] written
   float* dWm; float* dbm; float* dE;   // destinations (through `part` and the colsum job the caller queues)
-  const float* dE_ortho;  // optional [4,128]: gradient of the orthogonality term left by launch_loss_tail, added to dE
+  const float* dE_ortho;  // optional [4,128]: gradient of the orthogonality term left by the step's prologue (ortho.h), added to dE
   float* part;            // [match_bwd_blocks(Nv)][9][128] per-workgroup sums (dE rows, dWm flat, dbm): folded by launch_colsum
   float lambda;           // loss.match_lambda
 };
 int match_bwd_blocks(int Nv);
 int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, hipStream_t s);
-// denominator of the masked mean: loss_acc[LA_DENOM] = override > 0 ? override : loss_acc[LA_MASK_SUM] + 1e-12
-int launch_match_denominator(float* loss_acc, float override_denom, hipStream_t s);
-// ortho term ||(E E^T) * (1-I)||_F (model.py:88-91): loss_acc[LA_ORTHO] = norm ; dE += lambda * d norm / dE
-int launch_ortho(const float* E, float* dE, float* loss_acc, float lambda, hipStream_t s);
-// forward: ortho term + match denominator + the reported loss terms (loss_out[4], may be null) in one launch
-int launch_loss_tail(const float* E, float* loss_acc, float lambda, float override_denom, const float* denom_dev, float* loss_out,
-                     const float* match_part, int match_nblk, float* dE_ortho, hipStream_t s);
-
-// ---- start/end logit heads: logit = h . w + b  (predictor/{start,end}_dense, modules.py:155-156)
-struct DotArgs {
-  const float* h[2]; const float* w[2]; const float* b[2]; float* logit[2];   // two heads per launch
-  int R;
-};
-int launch_rowdot_fwd(const DotArgs& a, hipStream_t s);
-struct DotBwd {
-  const float* dlogit[2]; float* dZ[2];   // dZ = dlogit * w * (h > 0)   (h = relu output of the hidden dense)
-  float* dw[2]; float* db[2];
-};
-int launch_rowdot_bwd(const DotArgs& a, const DotBwd& g, hipStream_t s);
-
-// ---- localizing loss (layers.py:177-191) + span argmax (layers.py:194-203); one block per clip
-struct LocArgs {
-  const float* s_logit; const float* e_logit;     // [B,T]
+// ---- the predictor's output end (heads.hip heads_kernel): start / end logits (modules.py:155-156), localizing loss and its
+// gradient (layers.py:177-191), span argmax (layers.py:194-203) and the gradients of the two hidden layers' outputs
+struct HeadsArgs {
+  const float* h[2]; const float* w[2]; const float* b[2];   // hidden relu outputs [B*T,128], dense kernels [128], biases [1]; h null: logits are inputs
+  float* logit[2];                                // [B,T] start / end logits (written, or read when h is null)
   const float* vmask;                             // [B,T] floats
-  const float* y1; const float* y2;               // labels or null
+  const float* y1; const float* y2;               // soft labels or null (inference)
   int64_t* start_index; int64_t* end_index;       // [B]
-  float* ds; float* de;                           // [B,T] gradients (null: skip)
-  float* loss_acc;
+  float* ds; float* de;                           // optional [B,T]: d loss / d logits (grad_only: INPUTS)
+  int grad_only;                                  // 1: only step 3 from the given d logits (per-block entry point of the predictor)
+  float* dZ[2];                                   // optional [B*T,128]: dZ = dlogit * w * (h > 0), the operand of the hidden layers' backward
+  float* part[2];                                 // with dZ: [B][2][128] per-clip sums (vector 0 = d w, vector 1[0] = d b), folded by colsum_kernel
+  float* loc_part;                                // [B] per-clip loss terms (summed in a fixed order by the last workgroup)
   float inv_batch;                                // 1/B (reduce_mean over the batch)
 };
-int launch_loc(const LocArgs& a, int B, int T, hipStream_t s);
+int launch_heads(const HeadsArgs& a, int B, int T, hipStream_t s);
+// matching-loss denominator (layers.py:173) + the four reported loss terms (model.py:120) from the partial sums
+struct LossTailArgs {
+  float* loss_acc; const float* match_part; int match_nblk; const float* loc_part; int loc_nblk;
+  float lambda, override_denom; const float* denom_dev; float* loss_out;
+};
+int launch_loss_tail(const LossTailArgs& a, hipStream_t s);
 
 // ---- alignment loss (layers.py:205-248)
 struct AlignPool {
@@ -113,6 +105,9 @@ struct AlignPoolBwd {
   const float* dthat; const float* dvhat;   // [B,128] (local slice)
   float* dF2;   // v2q_feats gradient, q rows: WRITTEN (=)
   float* dF1;   // q2v_feats gradient, v rows: ACCUMULATED (+=)
+  // optional: the column part of d vhat is still missing from dvhat (the similarity rows ran inside launch_match_fwd): it is
+  // formed here from the [Bg,Bg] scratch matrices of that launch
+  const float* col_dq; const float* col_da; int col_Bg;
 };
 
 }  // namespace hual

@@ -4,6 +4,16 @@
 
 using namespace hual;
 
+#if defined(HUAL_STAMPS) && HUAL_STAMPS == 8      // debug build: phase clock stamps of heads_kernel (scripts/exp/stamps_generic.py)
+static __device__ unsigned long long g_heads_stamps[512 * 64];
+extern "C" int hual_debug_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_heads_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#define HEADS_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_heads_stamps[blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HEADS_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ float block_sum(float v, float* sm) {   // blockDim multiple of 64, <= 256
   v = wave_sum64(v);
   const int w = threadIdx.x >> 6;
@@ -46,15 +56,18 @@ __device__ __forceinline__ void pool_fwd_body(const PoolArgs& a, const RowSpace&
   __shared__ float pooled[HUAL_D];
   __shared__ float part[HUAL_D];
   const int tid = threadIdx.x;
+  const bool on = tid < 256;            // the work is laid out for 256 threads; the other waves only take part in the barriers
   const int l32 = tid & 31, grp = tid >> 5;
   const int L = rs.L;
   const float* F = a.F2 + (size_t)(rs.Nv + b * L) * HUAL_D;
   const float* m = rs.rowmask + rs.Nv + b * L;
-  const float4 w4 = ld4(a.wp + 4 * l32);
-  for (int l = grp; l < L; l += 8) {
-    const float4 f = ld4(F + (size_t)l * HUAL_D + 4 * l32);
-    const float d = half_sum32(f.x * w4.x + f.y * w4.y + f.z * w4.z + f.w * w4.w);
-    if (l32 == 0) al[l] = d * m[l] + HUAL_MASK_VALUE * (1.0f - m[l]);   // mask_logits, layers.py:139
+  if (on) {
+    const float4 w4 = ld4(a.wp + 4 * l32);
+    for (int l = grp; l < L; l += 8) {
+      const float4 f = ld4(F + (size_t)l * HUAL_D + 4 * l32);
+      const float d = half_sum32(f.x * w4.x + f.y * w4.y + f.z * w4.z + f.w * w4.w);
+      if (l32 == 0) al[l] = d * m[l] + HUAL_MASK_VALUE * (1.0f - m[l]);   // mask_logits, layers.py:139
+    }
   }
   __syncthreads();
   float mx = -INFINITY;
@@ -62,8 +75,8 @@ __device__ __forceinline__ void pool_fwd_body(const PoolArgs& a, const RowSpace&
   float sum = 0.f;
   for (int l = 0; l < L; ++l) sum += __expf(al[l] - mx);
   const float inv = 1.0f / sum;
-  const int c = tid & 127, half = tid >> 7;
-  if (half == 0) {
+  const int c = tid & 127, half = (tid >> 7) & 1;
+  if (on && half == 0) {
     float p = 0.f;
     for (int l = 0; l < L; ++l) {
       const float alpha = __expf(al[l] - mx) * inv;
@@ -75,86 +88,16 @@ __device__ __forceinline__ void pool_fwd_body(const PoolArgs& a, const RowSpace&
   }
   __syncthreads();
   float o = 0.f;
+  if (on) {
 #pragma unroll 8
-  for (int k = half * 64; k < half * 64 + 64; ++k) o = fmaf(pooled[k], a.Wbot[(size_t)k * HUAL_D + c], o);
-  if (half) part[c] = o;
+    for (int k = half * 64; k < half * 64 + 64; ++k) o = fmaf(pooled[k], a.Wbot[(size_t)k * HUAL_D + c], o);
+    if (half) part[c] = o;
+  }
   __syncthreads();
-  if (!half) a.PW[b * HUAL_D + c] = o + part[c];
+  if (on && !half) a.PW[b * HUAL_D + c] = o + part[c];
 }
 
-// stage 1 (512 threads): dPW[b] = sum_t dFuse[b,t,:]   (4 row groups, then LDS)
-// backward of weighted_pooling + cq_concat's pooled half for clip b, 512 threads; dPW = sum_t dFuse is formed here
-__device__ __forceinline__ void pool_bwd_body(const PoolArgs& a, const PoolBwd& g, const RowSpace& rs, int b) {
-  __shared__ float part4[4][HUAL_D];
-  __shared__ float dpw[HUAL_D];
-  __shared__ float dps[HUAL_D];
-  __shared__ float part[HUAL_D];
-  __shared__ float da[256];
-  const int tid = threadIdx.x;
-  const int L = rs.L, T = rs.T;
-  {
-    const int c = tid & 127, grp = tid >> 7;
-    float s = 0.f;
-    const float* dfu = g.dFuse + (size_t)b * T * HUAL_D;
-#pragma unroll 8
-    for (int t = grp; t < T; t += 4) s += dfu[(size_t)t * HUAL_D + c];
-    part4[grp][c] = s;
-    __syncthreads();
-    if (grp == 0) {
-      const float v = part4[0][c] + part4[1][c] + part4[2][c] + part4[3][c];
-      g.dPW[b * HUAL_D + c] = v;
-      dpw[c] = v;
-    }
-  }
-  __syncthreads();
-  const bool on = tid < 256;
-  const int c = tid & 127, half = (tid >> 7) & 1;
-  const int l32 = tid & 31, grp = (tid >> 5) & 7;
-  // dpooled[c] = sum_n dPW[n] * Wbot[c][n]   (two halves of n, float4 loads along the row of Wbot)
-  float dp = 0.f;
-  if (on) {
-    const float* wrow = a.Wbot + (size_t)c * HUAL_D + half * 64;
-#pragma unroll 4
-    for (int n = 0; n < 64; n += 4) {
-      const float4 w = ld4(wrow + n);
-      const float* d = dpw + half * 64 + n;
-      dp += d[0] * w.x + d[1] * w.y + d[2] * w.z + d[3] * w.w;
-    }
-    if (half) part[c] = dp;
-  }
-  __syncthreads();
-  if (on && !half) dps[c] = dp + part[c];
-  __syncthreads();
-  const float* F = a.F2 + (size_t)(rs.Nv + b * L) * HUAL_D;
-  const float* m = rs.rowmask + rs.Nv + b * L;
-  // dalpha[l] = dpooled . F[l]
-  if (on) {
-    const float4 dp4 = *reinterpret_cast<const float4*>(dps + 4 * l32);
-    for (int l = grp; l < L; l += 8) {
-      const float4 f = ld4(F + (size_t)l * HUAL_D + 4 * l32);
-      const float d = half_sum32(f.x * dp4.x + f.y * dp4.y + f.z * dp4.z + f.w * dp4.w);
-      if (l32 == 0) da[l] = d;
-    }
-  }
-  __syncthreads();
-  if (!on || half) return;
-  float dot_acc = 0.f;
-  for (int l = 0; l < L; ++l) dot_acc += a.alpha[b * L + l] * da[l];     // identical in every thread
-  dp = dps[c];
-  const float w = a.wp[c];
-  float dw = 0.f;
-  float* dF = g.dF2 + (size_t)(rs.Nv + b * L) * HUAL_D;
-#pragma unroll 4
-  for (int l = 0; l < L; ++l) {
-    const float alpha = a.alpha[b * L + l];
-    const float dal = alpha * (da[l] - dot_acc) * m[l];
-    const float f = F[(size_t)l * HUAL_D + c];
-    dF[(size_t)l * HUAL_D + c] += alpha * dp + dal * w;
-    dw = fmaf(dal, f, dw);
-  }
-  atomicAdd(g.dwp + c, dw);
-}
-__global__ __launch_bounds__(256) void match_fwd_kernel(MatchArgs a, RowSpace rs) {
+__device__ __forceinline__ void match_fwd_body(const MatchArgs& a, const RowSpace& rs, int bid, int nblk) {
   __shared__ float red[2][8];
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
@@ -163,7 +106,7 @@ __global__ __launch_bounds__(256) void match_fwd_kernel(MatchArgs a, RowSpace rs
   float4 w0 = ld4(a.Wm + (col + 0) * 4), w1 = ld4(a.Wm + (col + 1) * 4), w2 = ld4(a.Wm + (col + 2) * 4), w3 = ld4(a.Wm + (col + 3) * 4);
   const float4 bm = ld4(a.bm);
   float4 e0 = ld4(a.E + col), e1 = ld4(a.E + HUAL_D + col), e2 = ld4(a.E + 2 * HUAL_D + col), e3 = ld4(a.E + 3 * HUAL_D + col);
-  for (int row = blockIdx.x * 8 + grp; row < rs.Nv; row += gridDim.x * 8) {
+  for (int row = bid * 8 + grp; row < rs.Nv; row += nblk * 8) {
     const size_t off = (size_t)row * HUAL_D + col;
     const float4 f = ld4(a.fuse + off);
     float l0 = f.x * w0.x + f.y * w1.x + f.z * w2.x + f.w * w3.x;
@@ -199,14 +142,10 @@ __global__ __launch_bounds__(256) void match_fwd_kernel(MatchArgs a, RowSpace rs
     if (threadIdx.x == 0) {
       float c = 0.f, m = 0.f;
       for (int i = 0; i < 8; ++i) { c += red[0][i]; m += red[1][i]; }
-      if (a.part) { a.part[2 * blockIdx.x] = c; a.part[2 * blockIdx.x + 1] = m; }
+      if (a.part) { a.part[2 * bid] = c; a.part[2 * bid + 1] = m; }
       else { atomicAdd(a.loss_acc + LA_MATCH_SUM, c); atomicAdd(a.loss_acc + LA_MASK_SUM, m); }
     }
   }
-}
-
-__global__ void match_denominator_kernel(float* loss_acc, float override_denom) {
-  loss_acc[LA_DENOM] = override_denom > 0.f ? override_denom : loss_acc[LA_MASK_SUM] + 1e-12f;
 }
 
 __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g, RowSpace rs) {
@@ -286,181 +225,238 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
   }
 }
 
-// ortho: one block of 128 threads
-// forward use (tail != 0) also closes the loss: match denominator (layers.py:173) and the four reported loss terms
-__global__ __launch_bounds__(128) void ortho_kernel(const float* E, float* dE, float* loss_acc, float lambda, int tail,
-                                                    float override_denom, const float* denom_dev, float* loss_out,
-                                                    const float* match_part, int match_nblk, float* dE_store) {
-  __shared__ float M[16];
-  __shared__ float sm[4];
-  const int c = threadIdx.x;
-  if (tail && match_part) {      // per-block partial sums of match_fwd_kernel, in a fixed order
-    float cs = 0.f, ms = 0.f;
-    for (int i = c; i < match_nblk; i += 128) { cs += match_part[2 * i]; ms += match_part[2 * i + 1]; }
-    cs = block_sum(cs, sm);
-    ms = block_sum(ms, sm);
-    if (c == 0) { loss_acc[LA_MATCH_SUM] = cs; loss_acc[LA_MASK_SUM] = ms; }
-    __syncthreads();
-  }
-  float e[4];
-  for (int i = 0; i < 4; ++i) e[i] = E[i * HUAL_D + c];
-  for (int i = 0; i < 4; ++i)
-    for (int k = 0; k < 4; ++k) {
-      float d = block_sum(e[i] * e[k], sm);
-      if (c == 0) M[i * 4 + k] = (i == k) ? 0.f : d;
-    }
-  __syncthreads();
-  float ss = 0.f;
-  for (int i = 0; i < 16; ++i) ss += M[i] * M[i];
-  const float nrm = sqrtf(ss);
-  if (c == 0) {
-    loss_acc[LA_ORTHO] = nrm;
-    if (tail) {
-      const float denom = denom_dev ? *denom_dev : (override_denom > 0.f ? override_denom : loss_acc[LA_MASK_SUM] + 1e-12f);
-      loss_acc[LA_DENOM] = denom;
-      if (loss_out) {
-        const float match = loss_acc[LA_MATCH_SUM] / denom + nrm;             // layers.py:173 + model.py:91
-        const float loc = loss_acc[LA_LOC], align = loss_acc[LA_ALIGN];
-        loss_out[0] = loc + lambda * match + align;                           // model.py:120
-        loss_out[1] = loc;
-        loss_out[2] = match;
-        loss_out[3] = align;
-      }
-    }
-  }
-  if (dE && nrm > 0.f) {
-    for (int i = 0; i < 4; ++i) {
-      float s = 0.f;
-      for (int k = 0; k < 4; ++k) s += M[i * 4 + k] * e[k];
-      dE[i * HUAL_D + c] += lambda * 2.0f * s / nrm;
-    }
-  }
-  if (dE_store) {      // the same gradient, left in scratch for match_bwd_kernel to fold in (one launch fewer in backward)
-    for (int i = 0; i < 4; ++i) {
-      float s = 0.f;
-      for (int k = 0; k < 4; ++k) s += M[i * 4 + k] * e[k];
-      dE_store[i * HUAL_D + c] = nrm > 0.f ? lambda * 2.0f * s / nrm : 0.f;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rowdot_fwd_kernel(DotArgs a) {
-  const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int col = 4 * l32;
-  const int hd = blockIdx.y;
-  const float4 w = ld4(a.w[hd] + col);
-  const float b = a.b[hd][0];
-  for (int row = blockIdx.x * 8 + grp; row < a.R; row += gridDim.x * 8) {
-    const float4 h = ld4(a.h[hd] + (size_t)row * HUAL_D + col);
-    float d = half_sum32(h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w);
-    if (l32 == 0) a.logit[hd][row] = d + b;
-  }
-}
-
-__global__ __launch_bounds__(256) void rowdot_bwd_kernel(DotArgs a, DotBwd g) {
-  __shared__ float4 red[8][32];
-  __shared__ float redb[8];
-  const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int col = 4 * l32;
-  const int hd = blockIdx.y;
-  const float4 w = ld4(a.w[hd] + col);
-  float4 dw = f4zero();
-  float db = 0.f;
-  for (int row = blockIdx.x * 8 + grp; row < a.R; row += gridDim.x * 8) {
-    const size_t off = (size_t)row * HUAL_D + col;
-    const float4 h = ld4(a.h[hd] + off);
-    const float dl = g.dlogit[hd][row];
-    st4(g.dZ[hd] + off, make_float4(h.x > 0.f ? dl * w.x : 0.f, h.y > 0.f ? dl * w.y : 0.f, h.z > 0.f ? dl * w.z : 0.f,
-                                    h.w > 0.f ? dl * w.w : 0.f));
-    dw = make_float4(dw.x + dl * h.x, dw.y + dl * h.y, dw.z + dl * h.z, dw.w + dl * h.w);
-    if (l32 == 0) db += dl;
-  }
-  red[grp][l32] = dw;
-  if (l32 == 0) redb[grp] = db;
+// The predictor's output end in ONE launch, one workgroup (512 threads) per clip:
+//   1. start / end logits = hidden . w + b                      (predictor/{start,end}_dense, modules.py:155-156)
+//   2. localizing loss + its gradient, span argmax              (layers.py:177-203)
+//   3. dZ = dlogit * w * (hidden > 0) for the two hidden layers and the per-clip sums of d w, d b (folded by colsum_kernel)
+//   4. the workgroup that finishes last closes the loss: matching-loss denominator and the four reported terms
+// With `h` null the logits are read instead of computed (hual_span_argmax).
+// two block-wide reductions for one pair of barriers
+__device__ __forceinline__ void block_max2(float& a, float& b, float* sm) {       // sm: 2 * (blockDim.x / 64) floats
+  a = wave_max64(a); b = wave_max64(b);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   __syncthreads();
-  if (threadIdx.x < 128) {
-    const int c = threadIdx.x;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += reinterpret_cast<const float*>(&red[k][c >> 2])[c & 3];
-    atomicAdd(g.dw[hd] + c, s);
-  }
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int k = 0; k < 8; ++k) s += redb[k];
-    atomicAdd(g.db[hd], s);
-  }
+  if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[nw + w] = b; }
+  __syncthreads();
+  float x = -INFINITY, y = -INFINITY;
+  for (int i = 0; i < nw; ++i) { x = fmaxf(x, sm[i]); y = fmaxf(y, sm[nw + i]); }
+  a = x; b = y;
+}
+__device__ __forceinline__ void block_sum2_d(double& a, double& b, double* sm) {
+  for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[nw + w] = b; }
+  __syncthreads();
+  double x = 0.0, y = 0.0;
+  for (int i = 0; i < nw; ++i) { x += sm[i]; y += sm[nw + i]; }
+  a = x; b = y;
+}
+__device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float* sm) {
+  a = wave_sum64(a); b = wave_sum64(b); c = wave_sum64(c);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sm[w] = a; sm[nw + w] = b; sm[2 * nw + w] = c; }
+  __syncthreads();
+  float x = 0.f, y = 0.f, z = 0.f;
+  for (int i = 0; i < nw; ++i) { x += sm[i]; y += sm[nw + i]; z += sm[2 * nw + i]; }
+  a = x; b = y; c = z;
 }
 
-// ------------------------------------------------------------------------------------------------------
-// localizing loss + span argmax.  One block (256 threads) per clip, T <= 256.
-__global__ __launch_bounds__(256) void loc_kernel(LocArgs a, int T) {
-  __shared__ float ps[256], pe[256];
-  __shared__ float sm[4];
-  __shared__ double smd[4];
+// NR = rows of the clip per 32-lane group (T <= 16 NR): the hidden rows are loaded ONCE, all loads in flight together, and stay
+// in registers for step 3
+template <int NR>
+__global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a, int T) {
+  __shared__ float zs_[256], ze_[256], ps[256], pe[256], dls[256], dle[256];
+  __shared__ float sm[24];
+  __shared__ double smd[16];
+  __shared__ float wtot[2][4];
   __shared__ float bestv[2][4];
   __shared__ int besti[2][4];
-  const int b = blockIdx.x, t = threadIdx.x;
-  const bool in = t < T;
-  const float m = in ? a.vmask[b * T + t] : 0.f;
-  float zs = -INFINITY, ze = -INFINITY;
-  if (in) {
-    zs = a.s_logit[b * T + t] * m + HUAL_MASK_VALUE * (1.0f - m);
-    ze = a.e_logit[b * T + t] * m + HUAL_MASK_VALUE * (1.0f - m);
-  }
-  const float mxs = block_max(zs, sm);
-  const float mxe = block_max(ze, sm);
-  // Reproducible float32 softmax (the span indices must be BIT EXACT, north_star): exp of the float32 difference is
-  // evaluated in double and rounded once to float32 (= the correctly rounded float32 exp), the denominator is the
-  // double-precision sum of those floats rounded once, the quotient is an IEEE float32 division.  None of the three
-  // depends on the platform's libm or on a summation order; oracle/seqpan_ref.py::softmax_cr does the same arithmetic.
-  const float xs = in ? (float)exp((double)(zs - mxs)) : 0.f;
-  const float xe = in ? (float)exp((double)(ze - mxe)) : 0.f;
-  const float sums = (float)block_sum_d((double)xs, smd);
-  const float sume = (float)block_sum_d((double)xe, smd);
-  const float p_s = __fdiv_rn(xs, sums), p_e = __fdiv_rn(xe, sume);
-  ps[t] = p_s;
-  pe[t] = p_e;
-  if (a.y1) {
-    const float y1 = in ? a.y1[b * T + t] : 0.f, y2 = in ? a.y2[b * T + t] : 0.f;
-    const float lsm_s = zs - mxs - logf(sums), lsm_e = ze - mxe - logf(sume);
-    float l = in ? -(y1 * lsm_s + y2 * lsm_e) : 0.f;
-    const float lsum = block_sum(l, sm);
-    const float y1s = block_sum(y1, sm), y2s = block_sum(y2, sm);
-    if (t == 0 && a.loss_acc) atomicAdd(a.loss_acc + LA_LOC, lsum * a.inv_batch);
-    if (a.ds && in) {
-      a.ds[b * T + t] = (p_s * y1s - y1) * m * a.inv_batch;
-      a.de[b * T + t] = (p_e * y2s - y2) * m * a.inv_batch;
+  __shared__ float4 red[2][16][32];
+  __shared__ float redb[2][16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int l32 = tid & 31, grp = tid >> 5;
+  const int col = 4 * l32;
+  HEADS_STAMP(0);
+  float4 hs[NR], he[NR];
+  float4 ws = f4zero(), we = f4zero();
+  if (a.h[0]) {
+    ws = ld4(a.w[0] + col); we = ld4(a.w[1] + col);
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int t = min(grp + 16 * u, T - 1);
+      hs[u] = ld4(a.h[0] + (size_t)(b * T + t) * HUAL_D + col);
+      he[u] = ld4(a.h[1] + (size_t)(b * T + t) * HUAL_D + col);
     }
   }
-  __syncthreads();
-  // start = argmax_i p_s[i] * max_{j>=i} p_e[j] ;  end = argmax_j max_{i<=j} p_s[i] * p_e[j]   (first index on ties)
-  float vs = -1.f, ve = -1.f;
-  if (in) {
-    float sufmax = 0.f, premax = 0.f;
-    for (int jx = t; jx < T; ++jx) sufmax = fmaxf(sufmax, pe[jx]);
-    for (int ix = 0; ix <= t; ++ix) premax = fmaxf(premax, ps[ix]);
-    vs = p_s * sufmax;
-    ve = premax * p_e;
+  if (a.grad_only) {      // per-block entry point: d logits are inputs, only step 3 runs
+    if (tid < T) { dls[tid] = a.ds[b * T + tid]; dle[tid] = a.de[b * T + tid]; }
+  } else if (a.h[0]) {
+    // ---- 1. logits
+    const float bs = a.b[0][0], be = a.b[1][0];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int t = grp + 16 * u;
+      const float ds = half_sum32(hs[u].x * ws.x + hs[u].y * ws.y + hs[u].z * ws.z + hs[u].w * ws.w) + bs;
+      const float de = half_sum32(he[u].x * we.x + he[u].y * we.y + he[u].z * we.z + he[u].w * we.w) + be;
+      if (l32 == 0 && t < T) { zs_[t] = ds; ze_[t] = de; a.logit[0][b * T + t] = ds; a.logit[1][b * T + t] = de; }
+    }
+  } else if (tid < T) {
+    zs_[tid] = a.logit[0][b * T + tid];
+    ze_[tid] = a.logit[1][b * T + tid];
   }
-  // wave argmax with first-index ties, then across the 4 waves
-  int is = t, ie = t;
-  for (int off = 32; off >= 1; off >>= 1) {
-    float ovs = __shfl_xor(vs, off); int ois = __shfl_xor(is, off);
-    if (ovs > vs || (ovs == vs && ois < is)) { vs = ovs; is = ois; }
-    float ove = __shfl_xor(ve, off); int oie = __shfl_xor(ie, off);
-    if (ove > ve || (ove == ve && oie < ie)) { ve = ove; ie = oie; }
-  }
-  if ((t & 63) == 0) { bestv[0][t >> 6] = vs; besti[0][t >> 6] = is; bestv[1][t >> 6] = ve; besti[1][t >> 6] = ie; }
   __syncthreads();
-  if (t == 0) {
-    float v = bestv[0][0]; int i = besti[0][0];
-    for (int w = 1; w < 4; ++w) if (bestv[0][w] > v || (bestv[0][w] == v && besti[0][w] < i)) { v = bestv[0][w]; i = besti[0][w]; }
-    a.start_index[b] = i;
-    v = bestv[1][0]; i = besti[1][0];
-    for (int w = 1; w < 4; ++w) if (bestv[1][w] > v || (bestv[1][w] == v && besti[1][w] < i)) { v = bestv[1][w]; i = besti[1][w]; }
-    a.end_index[b] = i;
+  HEADS_STAMP(1);
+  // ---- 2. localizing loss + span argmax (threads 0..T-1 hold one frame each; the block-wide reductions take all 512)
+  if (!a.grad_only) {
+    const int t = tid;
+    const bool in = t < T;
+    const float m = in ? a.vmask[b * T + t] : 0.f;
+    float zs = -INFINITY, ze = -INFINITY;
+    if (in) {
+      zs = zs_[t] * m + HUAL_MASK_VALUE * (1.0f - m);
+      ze = ze_[t] * m + HUAL_MASK_VALUE * (1.0f - m);
+    }
+    float mxs = zs, mxe = ze;
+    block_max2(mxs, mxe, sm);
+    // Reproducible float32 softmax (the span indices must be BIT EXACT, north_star): exp of the float32 difference is
+    // evaluated in double and rounded once to float32 (= the correctly rounded float32 exp), the denominator is the
+    // double-precision sum of those floats rounded once, the quotient is an IEEE float32 division.  None of the three
+    // depends on the platform's libm or on a summation order; oracle/seqpan_ref.py::softmax_cr does the same arithmetic.
+    const float xs = in ? (float)exp((double)(zs - mxs)) : 0.f;
+    const float xe = in ? (float)exp((double)(ze - mxe)) : 0.f;
+    double dss = (double)xs, dse = (double)xe;
+    block_sum2_d(dss, dse, smd);
+    const float sums = (float)dss, sume = (float)dse;
+    const float p_s = __fdiv_rn(xs, sums), p_e = __fdiv_rn(xe, sume);
+    HEADS_STAMP(2);
+    if (a.y1) {
+      const float y1 = in ? a.y1[b * T + t] : 0.f, y2 = in ? a.y2[b * T + t] : 0.f;
+      const float lsm_s = zs - mxs - logf(sums), lsm_e = ze - mxe - logf(sume);
+      float lsum = in ? -(y1 * lsm_s + y2 * lsm_e) : 0.f, y1s = y1, y2s = y2;
+      block_sum3(lsum, y1s, y2s, sm);
+      if (t == 0 && a.loc_part) a.loc_part[b] = lsum * a.inv_batch;
+      if (in) {
+        const float ds = (p_s * y1s - y1) * m * a.inv_batch, de = (p_e * y2s - y2) * m * a.inv_batch;
+        dls[t] = ds; dle[t] = de;
+        if (a.ds) { a.ds[b * T + t] = ds; a.de[b * T + t] = de; }
+      }
+    }
+    HEADS_STAMP(3);
+    // start = argmax_i p_s[i] * max_{j>=i} p_e[j] ;  end = argmax_j max_{i<=j} p_s[i] * p_e[j]   (first index on ties).
+    // Inclusive prefix maximum of p_s / suffix maximum of p_e: in-wave scans (6 steps), wave totals combined through LDS.
+    // (max is exact and order independent, so the scan gives the same numbers as a sequential pass)
+    if (tid < 256) {
+      const int lane = tid & 63, w = tid >> 6;
+      float pre = in ? p_s : 0.f, suf = in ? p_e : 0.f;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float up = __shfl_up(pre, off), dn = __shfl_down(suf, off);
+        if (lane >= off) pre = fmaxf(pre, up);
+        if (lane + off < 64) suf = fmaxf(suf, dn);
+      }
+      if (lane == 63) wtot[0][w] = pre;
+      if (lane == 0) wtot[1][w] = suf;
+      ps[tid] = pre; pe[tid] = suf;
+    }
+    __syncthreads();
+    float vs = -1.f, ve = -1.f;
+    if (in) {
+      const int w = t >> 6;
+      float premax = ps[t], sufmax = pe[t];
+      for (int k = 0; k < w; ++k) premax = fmaxf(premax, wtot[0][k]);
+      for (int k = w + 1; k < 4; ++k) sufmax = fmaxf(sufmax, wtot[1][k]);
+      vs = p_s * sufmax;
+      ve = premax * p_e;
+    }
+    if (tid < 256) {
+      int is = t, ie = t;
+      for (int off = 32; off >= 1; off >>= 1) {
+        float ovs = __shfl_xor(vs, off); int ois = __shfl_xor(is, off);
+        if (ovs > vs || (ovs == vs && ois < is)) { vs = ovs; is = ois; }
+        float ove = __shfl_xor(ve, off); int oie = __shfl_xor(ie, off);
+        if (ove > ve || (ove == ve && oie < ie)) { ve = ove; ie = oie; }
+      }
+      if ((t & 63) == 0) { bestv[0][t >> 6] = vs; besti[0][t >> 6] = is; bestv[1][t >> 6] = ve; besti[1][t >> 6] = ie; }
+    }
+    __syncthreads();
+    if (t == 0) {
+      float v = bestv[0][0]; int i = besti[0][0];
+      for (int w = 1; w < 4; ++w) if (bestv[0][w] > v || (bestv[0][w] == v && besti[0][w] < i)) { v = bestv[0][w]; i = besti[0][w]; }
+      a.start_index[b] = i;
+      v = bestv[1][0]; i = besti[1][0];
+      for (int w = 1; w < 4; ++w) if (bestv[1][w] > v || (bestv[1][w] == v && besti[1][w] < i)) { v = bestv[1][w]; i = besti[1][w]; }
+      a.end_index[b] = i;
+    }
+  } else {
+    __syncthreads();
+  }
+  HEADS_STAMP(4);
+  HEADS_STAMP(5);
+  // ---- 3. gradients of the two hidden layers' outputs + per-clip sums of d w / d b (the hidden rows are still in registers)
+  if (a.dZ[0] && (a.y1 || a.grad_only)) {
+    float4 dws = f4zero(), dwe = f4zero();
+    float dbs = 0.f, dbe = 0.f;
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int tt = grp + 16 * u;
+      if (tt >= T) continue;
+      const size_t off = (size_t)(b * T + tt) * HUAL_D + col;
+      const float dl0 = dls[tt], dl1 = dle[tt];
+      st4(a.dZ[0] + off, make_float4(hs[u].x > 0.f ? dl0 * ws.x : 0.f, hs[u].y > 0.f ? dl0 * ws.y : 0.f, hs[u].z > 0.f ? dl0 * ws.z : 0.f,
+                                     hs[u].w > 0.f ? dl0 * ws.w : 0.f));
+      st4(a.dZ[1] + off, make_float4(he[u].x > 0.f ? dl1 * we.x : 0.f, he[u].y > 0.f ? dl1 * we.y : 0.f, he[u].z > 0.f ? dl1 * we.z : 0.f,
+                                     he[u].w > 0.f ? dl1 * we.w : 0.f));
+      dws = make_float4(dws.x + dl0 * hs[u].x, dws.y + dl0 * hs[u].y, dws.z + dl0 * hs[u].z, dws.w + dl0 * hs[u].w);
+      dwe = make_float4(dwe.x + dl1 * he[u].x, dwe.y + dl1 * he[u].y, dwe.z + dl1 * he[u].z, dwe.w + dl1 * he[u].w);
+      if (l32 == 0) { dbs += dl0; dbe += dl1; }
+    }
+    red[0][grp][l32] = dws; red[1][grp][l32] = dwe;
+    if (l32 == 0) { redb[0][grp] = dbs; redb[1][grp] = dbe; }
+    __syncthreads();
+    // part[hd][b][2][128]: vector 0 = d w, vector 1 = d b in its first entry
+    if (tid < 256) {
+      const int hd = tid >> 7, c = tid & 127;
+      float sw = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sw += reinterpret_cast<const float*>(&red[hd][k][c >> 2])[c & 3];
+      float sb = 0.f;
+      if (c == 0)
+        for (int k = 0; k < 16; ++k) sb += redb[hd][k];
+      float* part = a.part[hd] + (size_t)b * 2 * HUAL_D;
+      part[c] = sw;
+      part[HUAL_D + c] = sb;
+    }
+  }
+  HEADS_STAMP(6);
+}
+
+// Closes the loss (layers.py:173, model.py:91,120): sums the per-workgroup partials of match_fwd_kernel and heads_kernel in a
+// fixed order, sets the matching-loss denominator and writes the four reported terms.  A launch of its own: taking a
+// "last workgroup" ticket inside heads_kernel needs a device-scope release fence in every workgroup, which on this part
+// writes back the L2 (measured: 19 k cycles per workgroup).
+__global__ __launch_bounds__(256) void loss_tail_kernel(LossTailArgs a) {
+  __shared__ float sm[12];
+  const int tid = threadIdx.x;
+  float cs = 0.f, ms = 0.f, ls = 0.f;
+  for (int i = tid; i < a.match_nblk; i += 256) { cs += a.match_part[2 * i]; ms += a.match_part[2 * i + 1]; }
+  for (int i = tid; i < a.loc_nblk; i += 256) ls += a.loc_part[i];
+  block_sum3(cs, ms, ls, sm);
+  if (tid == 0) {
+    float* la = a.loss_acc;
+    la[LA_MATCH_SUM] = cs; la[LA_MASK_SUM] = ms; la[LA_LOC] = ls;
+    const float denom = a.denom_dev ? *a.denom_dev : (a.override_denom > 0.f ? a.override_denom : ms + 1e-12f);
+    la[LA_DENOM] = denom;
+    if (a.loss_out) {
+      const float match = cs / denom + la[LA_ORTHO];
+      const float align = la[LA_ALIGN];
+      a.loss_out[0] = ls + a.lambda * match + align;
+      a.loss_out[1] = ls;
+      a.loss_out[2] = match;
+      a.loss_out[3] = align;
+    }
   }
 }
 
@@ -499,11 +495,11 @@ __device__ __forceinline__ void align_pool_body(const AlignPool& a, const RowSpa
 }
 
 // row i of the [Bg,Bg] similarity matrices; one block (256 threads) per row, Bg <= 1024
-__global__ __launch_bounds__(256) void align_sim_rows_kernel(AlignSim a) {
+__device__ __forceinline__ void align_sim_rows_body(const AlignSim& a, int i) {
   __shared__ float ti[HUAL_D], vi[HUAL_D];
   __shared__ float sm[4];
   __shared__ float sa[1024], sq[1024];
-  const int i = blockIdx.x, tid = threadIdx.x, Bg = a.Bg;
+  const int tid = threadIdx.x, Bg = a.Bg;
   const int ld = a.ld;
   if (tid < HUAL_D) { ti[tid] = a.that[(size_t)i * ld + tid]; vi[tid] = a.vhat[(size_t)i * ld + tid]; }
   __syncthreads();
@@ -561,6 +557,13 @@ __global__ __launch_bounds__(256) void align_sim_rows_kernel(AlignSim a) {
     a.dvhat[(i - a.row0) * HUAL_D + tid] = sv;
   }
 }
+__global__ __launch_bounds__(256) void align_sim_rows_kernel(AlignSim a) { align_sim_rows_body(a, blockIdx.x); }
+// the matching head (workgroups [0, nmatch)) and the rows of the alignment similarity (the rest) in one launch: both only
+// depend on kernels further up the stream
+__global__ __launch_bounds__(256) void match_align_fwd_kernel(MatchArgs ma, RowSpace rs, AlignSim as, int nmatch) {
+  if ((int)blockIdx.x < nmatch) match_fwd_body(ma, rs, blockIdx.x, nmatch);
+  else align_sim_rows_body(as, (int)blockIdx.x - nmatch);
+}
 // column part: dvhat_j += sum_i dq[i][j] that_i + da[i][j] vhat_i
 __global__ __launch_bounds__(256) void align_sim_cols_kernel(AlignSim a) {
   __shared__ float cq[1024], ca[1024];
@@ -577,47 +580,145 @@ __global__ __launch_bounds__(256) void align_sim_cols_kernel(AlignSim a) {
   if (!half) a.dvhat[blockIdx.x * HUAL_D + c] += s + part[c];
 }
 
-__device__ __forceinline__ void align_pool_bwd_body(const AlignPool& a, const AlignPoolBwd& g, const RowSpace& rs, int b) {
-  __shared__ float sm[8];
-  const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
-  const int L = rs.L, T = rs.T;
-  // l2_normalize backward: x_hat = x * r, r = rsqrt(max(|x|^2, eps)); dx = r * (dxh - x_hat * (x_hat . dxh)) when |x|^2 > eps
-  const float tp = a.tpre[b * HUAL_D + c], vp = a.vpre[b * HUAL_D + c];
-  const float th = a.that[b * HUAL_D + c], vh = a.vhat[b * HUAL_D + c];
-  const float dth = g.dthat[b * HUAL_D + c], dvh = g.dvhat[b * HUAL_D + c];
-  const float w0 = grp == 0 ? 1.f : 0.f;     // every group holds the same 128 values: count them once
-  const float tn = block_sum(w0 * tp * tp, sm), vn = block_sum(w0 * vp * vp, sm);
-  const float tdot = block_sum(w0 * th * dth, sm), vdot = block_sum(w0 * vh * dvh, sm);
-  const float rt = rsqrtf(fmaxf(tn, L2_EPS)), rv = rsqrtf(fmaxf(vn, L2_EPS));
-  const float dtp = tn > L2_EPS ? rt * (dth - th * tdot) : rt * dth;
-  const float dvp = vn > L2_EPS ? rv * (dvh - vh * vdot) : rv * dvh;
-  float tc = 0.f, vc = 0.f;
-  for (int l = threadIdx.x; l < L; l += 512) tc += rs.rowmask[rs.Nv + b * L + l];
-  for (int t = threadIdx.x; t < T; t += 512) vc += rs.rowmask[b * T + t];
-  tc = block_sum(tc, sm);
-  vc = block_sum(vc, sm);
-  const float dts = dtp / tc;
-  for (int l = grp; l < L; l += 4) g.dF2[(size_t)(rs.Nv + b * L + l) * HUAL_D + c] = dts;
-#pragma unroll 8
-  for (int t = grp; t < T; t += 4) g.dF1[(size_t)(b * T + t) * HUAL_D + c] += dvp * (a.inner[b * T + t] / vc);
-}
-
 // per-clip forward kernels that only read cq.feats, in ONE launch: blockIdx.y = 0 weighted pooling (+ pooled . Wbot),
 // 1 = the per-sample part of the alignment loss (when labels are present)
 __global__ __launch_bounds__(512) void pool_align_fwd_kernel(PoolArgs pa, AlignPool ap, RowSpace rs) {
   if (blockIdx.y == 0) {
-    if (threadIdx.x >= 256) return;      // whole waves leave: the body is written for 256 threads
     pool_fwd_body(pa, rs, blockIdx.x);
   } else {
     align_pool_body(ap, rs, blockIdx.x);
   }
 }
-// per-clip backward: alignment pooling (writes the query rows of d cq.feats, accumulates the video rows), then weighted
-// pooling / cq_concat's pooled half (accumulates into the query rows the first part just wrote - same workgroup, same clip)
+// per-clip backward of the alignment pooling (layers.py:213-229) and of weighted_pooling / cq_concat's pooled half
+// (layers.py:133-154), one workgroup of 512 threads per clip: thread (c, grp) owns column c of the rows t = grp + 4 k.
+// Every global operand is requested in the first phase (the rows of d fuse and of d cq.feats of this clip sit in registers,
+// up to 64 + 64 + 8 per thread), so the kernel pays ONE memory round trip instead of one per reduction step:
+//   d cq.feats[v rows] += d vpre * inner / n_v                                  (alignment, video side)
+//   d cq.feats[q rows]  = d tpre / n_q + alpha_l * d pooled + d alpha_l * w_pool  (alignment + pooling, query side)
+// KT = rows of the video side per thread (T <= 4 KT), KL likewise for the query side.
+template <int KT, int KL>
 __global__ __launch_bounds__(512) void pool_align_bwd_kernel(PoolArgs pa, PoolBwd pb, AlignPool ap, AlignPoolBwd ab, RowSpace rs) {
-  align_pool_bwd_body(ap, ab, rs, blockIdx.x);
+  __shared__ float sm[48];
+  __shared__ float part[4][HUAL_D];
+  __shared__ float vecs[2][HUAL_D];      // [1]: dPW
+  __shared__ float da[256], al[256], qm[256], dap[2][256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int c = tid & 127, grp = tid >> 7;
+  const int L = rs.L, T = rs.T;
+  const size_t vrow0 = (size_t)b * T, qrow0 = (size_t)rs.Nv + (size_t)b * L;
+  // ---- phase 0: every load
+  float rdf[KT], rf1[KT], rin[KT], rF[KL];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    const int t = min(grp + 4 * k, T - 1);
+    rdf[k] = pb.dFuse[(vrow0 + t) * HUAL_D + c];
+    rf1[k] = ab.dF1[(vrow0 + t) * HUAL_D + c];
+    rin[k] = ap.inner[vrow0 + t];
+  }
+#pragma unroll
+  for (int k = 0; k < KL; ++k) rF[k] = pa.F2[(qrow0 + min(grp + 4 * k, L - 1)) * HUAL_D + c];
+  const float tp = ap.tpre[b * HUAL_D + c], vp = ap.vpre[b * HUAL_D + c];
+  const float th = ap.that[b * HUAL_D + c], vh = ap.vhat[b * HUAL_D + c];
+  const float dth = ab.dthat[b * HUAL_D + c];
+  float dvh = ab.dvhat[b * HUAL_D + c];
+  const float wpc = pa.wp[c];
+  float tc = 0.f, vc = 0.f;
+  for (int l = tid; l < L; l += 512) { const float m = rs.rowmask[qrow0 + l]; qm[l] = m; al[l] = pa.alpha[b * L + l]; tc += m; }
+  for (int t = tid; t < T; t += 512) vc += rs.rowmask[vrow0 + t];
+  // column part of d vhat_b (align_sim_cols_kernel's sum, when the similarity was evaluated inside the forward)
+  float colsum = 0.f;
+  if (ab.col_dq) {
+    const int Bg = ab.col_Bg;
+#pragma unroll 4
+    for (int i = grp; i < Bg; i += 4)
+      colsum += ab.col_dq[(size_t)i * Bg + b] * ap.that[(size_t)i * HUAL_D + c] + ab.col_da[(size_t)i * Bg + b] * ap.vhat[(size_t)i * HUAL_D + c];
+  }
+  // ---- phase 1: workgroup sums.  dPW[c] = sum_t dFuse[t][c]; the column part; the six scalars of the two l2-normalisations
+  float sdf = 0.f;
+#pragma unroll
+  for (int k = 0; k < KT; ++k) sdf += (grp + 4 * k < T) ? rdf[k] : 0.f;
+  part[grp][c] = sdf;
   __syncthreads();
-  pool_bwd_body(pa, pb, rs, blockIdx.x);
+  const float dpw = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+  if (grp == 0) { pb.dPW[b * HUAL_D + c] = dpw; vecs[1][c] = dpw; }
+  __syncthreads();
+  if (ab.col_dq) {
+    part[grp][c] = colsum;
+    __syncthreads();
+    dvh += (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    __syncthreads();
+  }
+  {
+    // l2_normalize backward: x_hat = x * r, r = rsqrt(max(|x|^2, eps)); dx = r * (dxh - x_hat * (x_hat . dxh)) when |x|^2 > eps
+    const float w0 = grp == 0 ? 1.f : 0.f;       // every group holds the same 128 values: count them once
+    float v[6] = {w0 * tp * tp, w0 * vp * vp, w0 * th * dth, w0 * vh * dvh, tc, vc};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v[q] = wave_sum64(v[q]);
+    if ((tid & 63) == 0)
+      for (int q = 0; q < 6; ++q) sm[q * 8 + (tid >> 6)] = v[q];
+  }
+  __syncthreads();
+  float red6[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    float x = 0.f;
+    for (int w = 0; w < 8; ++w) x += sm[q * 8 + w];
+    red6[q] = x;
+  }
+  const float tn = red6[0], vn = red6[1], tdot = red6[2], vdot = red6[3];
+  tc = red6[4]; vc = red6[5];
+  const float rt = rsqrtf(fmaxf(tn, L2_EPS)), rv = rsqrtf(fmaxf(vn, L2_EPS));
+  const float dtp = tn > L2_EPS ? rt * (dth - th * tdot) : rt * dth;
+  const float dvp = vn > L2_EPS ? rv * (dvh - vh * vdot) : rv * dvh;
+  const float dts = dtp / tc;
+  // ---- video rows: d cq.feats += d vpre * inner / n_v
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    const int t = grp + 4 * k;
+    if (t < T) ab.dF1[(vrow0 + t) * HUAL_D + c] = rf1[k] + dvp * (rin[k] / vc);
+  }
+  // ---- d pooled[c] = sum_n dPW[n] * Wbot[c][n]  (four slices of n)
+  {
+    float dp = 0.f;
+    const float* wrow = pa.Wbot + (size_t)c * HUAL_D + grp * 32;
+#pragma unroll
+    for (int n = 0; n < 32; n += 4) {
+      const float4 w = ld4(wrow + n);
+      const float* d = vecs[1] + grp * 32 + n;
+      dp += d[0] * w.x + d[1] * w.y + d[2] * w.z + d[3] * w.w;
+    }
+    part[grp][c] = dp;
+  }
+  __syncthreads();
+  const float dpc = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+  __syncthreads();
+  // ---- d alpha[l] = d pooled . F[l]: row l = grp + 4 k belongs to this thread's group; reduce over c within the 128 threads
+  //      (two waves) of the group
+#pragma unroll
+  for (int k = 0; k < KL; ++k) {
+    const int l = grp + 4 * k;
+    const float d = wave_sum64(dpc * rF[k]);
+    if ((tid & 63) == 0 && l < L) dap[(tid >> 6) & 1][l] = d;        // two partials per row: waves 2 grp, 2 grp + 1
+  }
+  __syncthreads();
+  if (tid < L) da[tid] = dap[0][tid] + dap[1][tid];
+  __syncthreads();
+  float dot_acc = 0.f;
+  for (int l = 0; l < L; ++l) dot_acc += al[l] * da[l];              // identical in every thread
+  // ---- query rows: d cq.feats = d tpre / n_q + alpha * d pooled + d alpha_l * w_pool ; d w_pool[c] += sum_l d alpha_l F[l][c]
+  float dw = 0.f;
+#pragma unroll
+  for (int k = 0; k < KL; ++k) {
+    const int l = grp + 4 * k;
+    if (l >= L) continue;
+    const float alpha = al[l];
+    const float dal = alpha * (da[l] - dot_acc) * qm[l];
+    ab.dF2[(qrow0 + l) * HUAL_D + c] = dts + alpha * dpc + dal * wpc;
+    dw = fmaf(dal, rF[k], dw);
+  }
+  part[grp][c] = dw;
+  __syncthreads();
+  if (grp == 0) atomicAdd(pb.dwp + c, (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
 }
 
 namespace hual {
@@ -630,7 +731,10 @@ int launch_pool_align_fwd(const PoolArgs& a, const AlignPool* ap, const RowSpace
   return 0;
 }
 int launch_pool_align_bwd(const PoolArgs& a, const PoolBwd& g, const AlignPool& ap, const AlignPoolBwd& ab, const RowSpace& rs, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, pool_align_bwd_kernel, dim3(rs.B), dim3(512), 0, s, a, g, ap, ab, rs);
+  HUAL_REQUIRE(rs.T <= 256 && rs.L <= 256, "pool_align_bwd: T, L <= 256");
+  HUAL_REQUIRE(ab.dF2 == g.dF2, "pool_align_bwd: the two parts write the same query rows");
+  if (rs.T <= 128 && rs.L <= 32) HUAL_LAUNCH(0.0, 0.0, (pool_align_bwd_kernel<32, 8>), dim3(rs.B), dim3(512), 0, s, a, g, ap, ab, rs);
+  else HUAL_LAUNCH(0.0, 0.0, (pool_align_bwd_kernel<64, 64>), dim3(rs.B), dim3(512), 0, s, a, g, ap, ab, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -643,13 +747,17 @@ static int rowgrid(int R, int cap) {
 }
 int match_fwd_blocks(int Nv) { return rowgrid(Nv, 512); }
 int match_bwd_blocks(int Nv) { return rowgrid(Nv, 256); }
-int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, match_fwd_kernel, dim3(a.part ? match_fwd_blocks(rs.Nv) : rowgrid(rs.Nv, 128)), dim3(256), 0, s, a, rs);
-  HUAL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-int launch_match_denominator(float* loss_acc, float override_denom, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, match_denominator_kernel, dim3(1), dim3(1), 0, s, loss_acc, override_denom);
+// matching head; `as` non-null: the rows of the alignment similarity ride in the same launch (their column part is left to
+// pool_align_bwd_kernel: AlignPoolBwd::col_*)
+int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, const AlignSim* as, hipStream_t s) {
+  HUAL_REQUIRE(a.part != nullptr, "match_fwd: partial-sum scratch");
+  const int nm = match_fwd_blocks(rs.Nv);
+  AlignSim z{};
+  if (as) {
+    HUAL_REQUIRE(as->Bg >= 1 && as->Bg <= 1024 && as->ld >= HUAL_D && as->row0 == 0 && as->nrows == as->Bg, "align: global batch <= 1024");
+    z = *as;
+  }
+  HUAL_LAUNCH(0.0, 0.0, match_align_fwd_kernel, dim3(nm + (as ? as->Bg : 0)), dim3(256), 0, s, a, rs, z, nm);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -659,32 +767,19 @@ int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, 
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
-int launch_ortho(const float* E, float* dE, float* loss_acc, float lambda, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, dE, loss_acc, lambda, 0, 0.f, (const float*)nullptr, (float*)nullptr,
-              (const float*)nullptr, 0, (float*)nullptr);
+int launch_heads(const HeadsArgs& a, int B, int T, hipStream_t s) {
+  HUAL_REQUIRE(T >= 1 && T <= 256 && B >= 1, "heads: T <= 256");
+  HUAL_REQUIRE(a.grad_only ? (a.ds && a.de && a.dZ[0]) : (a.logit[0] && a.logit[1] && a.vmask && a.start_index && a.end_index), "heads: null tensor");
+  HUAL_REQUIRE(!a.h[0] || (a.h[1] && a.w[0] && a.w[1] && a.b[0] && a.b[1]), "heads: hidden layers incomplete");
+  HUAL_REQUIRE(!a.dZ[0] || (a.dZ[1] && a.part[0] && a.part[1] && a.h[0]), "heads: gradient outputs incomplete");
+  if (T <= 128) HUAL_LAUNCH(0.0, 0.0, heads_kernel<8>, dim3(B), dim3(512), 0, s, a, T);
+  else HUAL_LAUNCH(0.0, 0.0, heads_kernel<16>, dim3(B), dim3(512), 0, s, a, T);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
-int launch_loss_tail(const float* E, float* loss_acc, float lambda, float override_denom, const float* denom_dev, float* loss_out,
-                     const float* match_part, int match_nblk, float* dE_ortho, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, ortho_kernel, dim3(1), dim3(128), 0, s, E, (float*)nullptr, loss_acc, lambda, 1, override_denom, denom_dev, loss_out,
-              match_part, match_nblk, dE_ortho);
-  HUAL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-int launch_rowdot_fwd(const DotArgs& a, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, rowdot_fwd_kernel, dim3(rowgrid(a.R, 1024), 2), dim3(256), 0, s, a);
-  HUAL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-int launch_rowdot_bwd(const DotArgs& a, const DotBwd& g, hipStream_t s) {
-  HUAL_LAUNCH(0.0, 0.0, rowdot_bwd_kernel, dim3(rowgrid(a.R, 64), 2), dim3(256), 0, s, a, g);
-  HUAL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-int launch_loc(const LocArgs& a, int B, int T, hipStream_t s) {
-  HUAL_REQUIRE(T <= 256, "loc: T <= 256");
-  HUAL_LAUNCH(0.0, 0.0, loc_kernel, dim3(B), dim3(256), 0, s, a, T);
+int launch_loss_tail(const LossTailArgs& a, hipStream_t s) {
+  HUAL_REQUIRE(a.loss_acc && a.match_part && a.loc_part, "loss_tail: null");
+  HUAL_LAUNCH(0.0, 0.0, loss_tail_kernel, dim3(1), dim3(256), 0, s, a);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

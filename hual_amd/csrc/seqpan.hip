@@ -376,12 +376,15 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
   c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
   c.PT = c.buf("params.T", pm.total, 1);
+  float* ortho_dE = c.buf("ortho.dE", 4, HUAL_D);
   if (!c.dry && c.ok()) {
     std::vector<uint32_t> offs, boffs;
     std::vector<int> Ks;
     for (const auto& d : c.dense) { offs.push_back((uint32_t)d.off); Ks.push_back(d.K); boffs.push_back((uint32_t)d.boff); }
     PackExtra ex{bt->video_seq_len, bt->word_ids, rowmask, loss_acc, B, T, L, (lab && opt->grads_prezero) ? opt->grads_prezero : nullptr,
-                 (size_t)((pm.total + 3) & ~(size_t)3)};
+                 (size_t)((pm.total + 3) & ~(size_t)3),
+                 // the orthogonality term of the label embeddings depends on the parameters only: evaluated here (ortho.h)
+                 lab ? c.p(pm.label_emb) : nullptr, c.cfg->match_lambda, ortho_dE};
     c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex));
   }
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
@@ -584,14 +587,14 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   ma.probs2 = (lab && !c.dry) ? probs_keep : nullptr;
   float* match_part = c.buf("match.part", (size_t)match_fwd_blocks(Nv), 2);
   ma.part = match_part;
-  if (c.live()) c.chk(launch_match_fwd(ma, c.rs, c.stream));
-  // ---------------- alignment loss, cross-sample part (layers.py:232-247); exact data parallel evaluates it outside
+  // ---------------- alignment loss, cross-sample part (layers.py:232-247), rows of the [B,B] similarity in the same launch (its
+  // column part is formed by the backward's pool_align launch); exact data parallel evaluates it outside
   float* d_that = c.buf("d.align.that", B, D);
   float* d_vhat = c.buf("d.align.vhat", B, D);
   float* align_scratch = c.buf("align.scratch", (size_t)2 * B, B);
-  if (lab && c.live() && !opt->align_external) {
+  if (c.live()) {
     AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, d_that, d_vhat, loss_acc, 1.0f, D, 0, B};
-    c.chk(launch_align_sim(as, c.stream));
+    c.chk(launch_match_fwd(ma, c.rs, (lab && !opt->align_external) ? &as : nullptr, c.stream));
   }
   // ---------------- conditioned predictor (modules.py:143-160)
   c.stage(ST_PRED);
@@ -669,21 +672,28 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   }
   float* d_s = c.buf("d.s_logit", B, T);
   float* d_e = c.buf("d.e_logit", B, T);
+  // ---------------- logits, localizing loss, span argmax, the gradients of the two hidden layers' outputs and the loss tail:
+  // one launch (heads.h)
+  float* dz_hs = c.actv("d.head.zs");
+  float* dz_he = c.actv("d.head.ze");
+  float* hpart_s = c.buf("head.part.s", (size_t)B * 2, D);
+  float* hpart_e = c.buf("head.part.e", (size_t)B * 2, D);
+  float* loc_part = c.buf("loc.part", B, 1);
   if (c.live()) {
-    DotArgs da{};
-    da.h[0] = hs; da.h[1] = he; da.w[0] = c.p(pm.sdense.k); da.w[1] = c.p(pm.edense.k);
-    da.b[0] = c.p(pm.sdense.b); da.b[1] = c.p(pm.edense.b);
-    da.logit[0] = out->start_logits; da.logit[1] = out->end_logits; da.R = Nv;
-    c.chk(launch_rowdot_fwd(da, c.stream));
-    LocArgs la{};
-    la.s_logit = out->start_logits; la.e_logit = out->end_logits; la.vmask = rowmask;
-    la.y1 = lab ? lab->y1 : nullptr; la.y2 = lab ? lab->y2 : nullptr;
-    la.start_index = out->start_index; la.end_index = out->end_index;
-    la.ds = lab ? d_s : nullptr; la.de = lab ? d_e : nullptr; la.loss_acc = loss_acc; la.inv_batch = 1.0f / (float)B;
-    if (c.ok()) c.chk(launch_loc(la, B, T, c.stream));
+    HeadsArgs ha{};
+    ha.h[0] = hs; ha.h[1] = he; ha.w[0] = c.p(pm.sdense.k); ha.w[1] = c.p(pm.edense.k);
+    ha.b[0] = c.p(pm.sdense.b); ha.b[1] = c.p(pm.edense.b);
+    ha.logit[0] = out->start_logits; ha.logit[1] = out->end_logits; ha.vmask = rowmask;
+    ha.y1 = lab ? lab->y1 : nullptr; ha.y2 = lab ? lab->y2 : nullptr;
+    ha.start_index = out->start_index; ha.end_index = out->end_index;
+    ha.ds = lab ? d_s : nullptr; ha.de = lab ? d_e : nullptr;
+    if (lab) { ha.dZ[0] = dz_hs; ha.dZ[1] = dz_he; ha.part[0] = hpart_s; ha.part[1] = hpart_e; }
+    ha.loc_part = loc_part; ha.inv_batch = 1.0f / (float)B;
+    c.chk(launch_heads(ha, B, T, c.stream));
     if (lab && c.ok()) {
-      c.chk(launch_loss_tail(c.p(pm.label_emb), loss_acc, c.cfg->match_lambda, opt->match_denom_override, opt->match_denom_dev,
-                             out->loss_terms, match_part, match_fwd_blocks(Nv), c.buf("ortho.dE", 4, D), c.stream));
+      LossTailArgs lt{loss_acc, match_part, match_fwd_blocks(Nv), loc_part, B, c.cfg->match_lambda, opt->match_denom_override,
+                      opt->match_denom_dev, out->loss_terms};
+      c.chk(launch_loss_tail(lt, c.stream));
     }
   }
   return c.rc;
@@ -726,13 +736,22 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* d_e = c.buf("d.e_logit", B, T);
   float* dz_hs = c.actv("d.head.zs");
   float* dz_he = c.actv("d.head.ze");
-  if (c.live()) {
-    DotArgs da{};
-    da.h[0] = hs; da.h[1] = he; da.w[0] = c.p(pm.sdense.k); da.w[1] = c.p(pm.edense.k); da.R = Nv;
-    DotBwd db{};
-    db.dlogit[0] = d_s; db.dlogit[1] = d_e; db.dZ[0] = dz_hs; db.dZ[1] = dz_he;
-    db.dw[0] = c.g(pm.sdense.k); db.dw[1] = c.g(pm.edense.k); db.db[0] = c.g(pm.sdense.b); db.db[1] = c.g(pm.edense.b);
-    c.chk(launch_rowdot_bwd(da, db, c.stream));
+  // dZ of the two hidden layers and the per-clip sums of d w / d b of start_dense / end_dense were left by the forward's heads
+  // launch; a per-block call (gradients of the logits supplied by the caller) forms them here
+  float* hpart_s = c.buf("head.part.s", (size_t)B * 2, D);
+  float* hpart_e = c.buf("head.part.e", (size_t)B * 2, D);
+  if (c.live() && c.sel_stage >= 0) {
+    HeadsArgs ha{};
+    ha.grad_only = 1;
+    ha.h[0] = hs; ha.h[1] = he; ha.w[0] = c.p(pm.sdense.k); ha.w[1] = c.p(pm.edense.k); ha.b[0] = c.p(pm.sdense.b); ha.b[1] = c.p(pm.edense.b);
+    ha.ds = d_s; ha.de = d_e; ha.dZ[0] = dz_hs; ha.dZ[1] = dz_he; ha.part[0] = hpart_s; ha.part[1] = hpart_e;
+    c.chk(launch_heads(ha, B, T, c.stream));
+  }
+  for (int h = 0; h < 2; ++h) {
+    ColsumJob cj{};
+    cj.src = h == 0 ? hpart_s : hpart_e; cj.nblk = B; cj.nvec = 2; cj.last_ncols = 1;
+    cj.dst[0] = c.g(h == 0 ? pm.sdense.k : pm.edense.k); cj.dst[1] = c.g(h == 0 ? pm.sdense.b : pm.edense.b);
+    if (c.active) c.colsum.push_back(cj);
   }
   for (int h = 0; h < 2; ++h) {
     const DenseP& hp = h == 0 ? pm.shid : pm.ehid;
@@ -877,7 +896,11 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   pa.alpha = c.buf("pool.alpha", B, L); pa.pooled = c.buf("pool.pooled", B, D); pa.PW = c.buf("pool.pw", B, D);
   float* d_pw = c.buf("d.pool.pw", B, D);
   if (c.live()) {
-    AlignPoolBwd ab{d_that, d_vhat, d_cqf, d_cqf};     // writes the query rows, accumulates the video rows
+    AlignPoolBwd ab{d_that, d_vhat, d_cqf, d_cqf, nullptr, nullptr, 0};     // writes the query rows, accumulates the video rows
+    if (!opt->align_external && c.sel_stage < 0) {      // column part of d vhat: from the similarity scratch of the forward
+      float* asc = c.buf("align.scratch", (size_t)2 * B, B);
+      ab.col_dq = asc; ab.col_da = asc + (size_t)B * B; ab.col_Bg = B;
+    }
     PoolBwd pb{d_fuse, d_pw, d_cqf, c.g(pm.pool_w)};    // accumulates into the query rows
     c.chk(launch_pool_align_bwd(pa, pb, ap, ab, c.rs, c.stream));
   }
