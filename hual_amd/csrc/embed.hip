@@ -11,8 +11,9 @@
 //     Wall[dk*CP + d][off_k + n] = filter_k[dk][d][n]   (zero for dk >= k, for the padding columns and d >= char_dim)
 // Yall = windows . Wall + ball gives every channel of every width at every start position in one [M x 128] GEMM
 // (M = words * C).  Windows that run past a word's last slot are computed and ignored.
-//   forward : embed_gather_kernel (lookups, dropout, Wall / Wall^T / ball) -> launch_gemm -> char_pool_kernel
-//             (relu, max over the valid start positions, arg-max)
+//   forward : the gather (lookups, dropout, ball) and the pre-split images of Wall / Wall^T ride in the step's prologue launch
+//             (pack_weights_kernel: embed_gather.h, gemm.h PackExtra) -> launch_gemm_bf16 -> char_pool_kernel (relu, max over
+//             the valid start positions, arg-max)
 //   backward: char_pool_bwd_kernel scatters the channel gradients to the arg-max rows of dYall [M x 128];
 //             d filters / d bias = windows^T . dYall is one more job of the step's weight-gradient launch (dw_kernel),
 //             into the packed scratch dFall which embed_unpack_kernel adds to the real gradients;
@@ -24,15 +25,7 @@
 
 using namespace hual;
 
-#define NCH 100          // 10+20+30+40 channels
-#define NALL 128         // padded channel count = GEMM N
-__device__ __host__ __forceinline__ int bank_off(int k) { return k == 1 ? 0 : (k == 2 ? 10 : (k == 3 ? 30 : 60)); }
-__device__ __forceinline__ void chan_to_kernel(int ch, int& k, int& chk) {
-  if (ch < 10) { k = 1; chk = ch; }
-  else if (ch < 30) { k = 2; chk = ch - 10; }
-  else if (ch < 60) { k = 3; chk = ch - 30; }
-  else { k = 4; chk = ch - 60; }
-}
+#include "embed_gather.h"
 
 namespace hual {
 static inline int cpad(int char_dim) { return (char_dim + 15) / 16 * 16; }
@@ -43,8 +36,6 @@ EmbedLayout embed_layout(int nrows, int C, int char_dim) {
   l.CP = CP;
   size_t off = 0;
   l.cemb = off; off += (M + 4) * CP;
-  l.wall = off; off += (size_t)4 * CP * NALL;
-  l.wallt = off; off += (size_t)NALL * 4 * CP;
   l.ball = off; off += NALL;
   l.yall = off; off += M * NALL;
   l.dxall = off; off += M * 4 * CP;
@@ -53,66 +44,6 @@ EmbedLayout embed_layout(int nrows, int C, int char_dim) {
   return l;
 }
 }  // namespace hual
-
-// ------------------------------------------------------------------------------------------------------
-// one task = 4 consecutive columns of a word row or of a char slot row; tail tasks build Wall / Wall^T / ball
-__global__ __launch_bounds__(256) void embed_gather_kernel(EmbedArgs a, DropCfg drop, int nrows, int CP, int ntask_words) {
-  const int wd = a.word_dim, cd = a.char_dim, C = a.C;
-  const int ngw = wd >> 2, ngc = CP >> 2;
-  const int per_word = ngw + C * ngc;
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (gid < ntask_words) {
-    const int row = gid / per_word, t = gid - row * per_word;
-    if (t < ngw) {
-      const int wid = a.word_ids[row];
-      float4 v = f4zero();
-      if (wid == 1) v = ld4(a.unk + 4 * t);
-      else if (wid >= 2) v = ld4(a.word_table + (size_t)(wid - 2) * wd + 4 * t);
-      if (drop.enabled) v = apply_drop4(drop, HUAL_SITE_WORD, (uint32_t)row, (uint32_t)t, v);
-      st4(a.cat + (size_t)row * a.ldcat + 4 * t, v);
-    } else {
-      const int u = t - ngw, c = u / ngc, g4 = u - c * ngc;
-      const int cid = a.char_ids[(size_t)row * C + c];
-      float e[4] = {0.f, 0.f, 0.f, 0.f};
-      if (cid > 0) {
-        const float* src = a.char_table + (size_t)(cid - 1) * cd;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (4 * g4 + q < cd) e[q] = src[4 * g4 + q];
-      }
-      float4 v = make_float4(e[0], e[1], e[2], e[3]);
-      if (drop.enabled && 4 * g4 < cd) v = apply_drop4(drop, HUAL_SITE_CHAR, (uint32_t)(row * C + c), (uint32_t)g4, v);
-      st4(a.cemb + ((size_t)row * C + c) * CP + 4 * g4, v);
-    }
-    return;
-  }
-  int x = gid - ntask_words;
-  if (x < 4 * CP) { a.cemb[(size_t)nrows * C * CP + x] = 0.f; return; }      // guard rows behind the last window
-  x -= 4 * CP;
-  if (x < 4 * CP * NALL) {
-    const int r = x / NALL, n = x - r * NALL;       // Wall[r][n]
-    const int dk = r / CP, d = r - dk * CP;
-    float v = 0.f;
-    if (n < NCH && d < cd) {
-      int k, chk;
-      chan_to_kernel(n, k, chk);
-      if (dk < k) v = a.filt[k - 1][(size_t)(dk * cd + d) * (10 * k) + chk];
-    }
-    a.wall[x] = v;
-    a.wallt[(size_t)n * 4 * CP + r] = v;
-    return;
-  }
-  x -= 4 * CP * NALL;
-  if (x < NALL) {
-    float v = 0.f;
-    if (x < NCH) {
-      int k, chk;
-      chan_to_kernel(x, k, chk);
-      v = a.fbias[k - 1][chk];
-    }
-    a.ball[x] = v;
-  }
-}
 
 // relu + max over the C - k + 1 valid window starts; thread = (word, channel)
 __global__ __launch_bounds__(256) void char_pool_kernel(EmbedArgs a, int nrows) {
@@ -228,27 +159,28 @@ namespace hual {
 static int check_args(const EmbedArgs& a) {
   HUAL_REQUIRE(a.C >= 4, "char_ids need at least 4 chars per word (conv width 4, VALID) - modules.py:33");
   HUAL_REQUIRE((a.word_dim % 4) == 0 && a.char_dim >= 1, "embed: word_dim must be a multiple of 4");
-  HUAL_REQUIRE(a.cemb && a.wall && a.wallt && a.ball && a.yall && a.dxall && a.dfall, "embed: null scratch");
+  HUAL_REQUIRE(a.cemb && a.wall_img && a.ball && a.yall && a.dxall && a.dfall, "embed: null scratch");
   return 0;
 }
 
+int embed_cpad(int char_dim) { return cpad(char_dim); }
+int embed_gather_tasks(const EmbedArgs& a, int nrows) {
+  const int CP = cpad(a.char_dim);
+  return nrows * (a.word_dim / 4 + a.C * (CP / 4)) + 4 * CP + NALL;
+}
+
+// (the gather ran in the step's prologue launch) char CNN as one split-operand product on the pre-split image of Wall, then the pooling
 int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStream_t s) {
   int rc = check_args(a);
   if (rc) return rc;
   const int CP = cpad(a.char_dim);
-  const int per_word = a.word_dim / 4 + a.C * (CP / 4);
-  const int ntask_words = nrows * per_word;
-  const int ntail = 4 * CP + 4 * CP * NALL + NALL;
-  HUAL_LAUNCH(0.0, 0.0, embed_gather_kernel, dim3(cdiv(ntask_words + ntail, 256)), dim3(256), 0, s, a, drop, nrows, CP,
-              ntask_words);
-  HUAL_CHECK_HIP(hipGetLastError());
   GemmJob g;
   gemm_job_init(g);
   g.npieces = 1;
   g.A[0] = a.cemb; g.lda[0] = CP; g.kw[0] = 4 * CP;          // overlapping rows: window r = slot rows r .. r+3
-  g.W[0] = a.wall; g.ldw = NALL; g.bias = a.ball;
+  g.W[0] = a.wall_img; g.ldw = NALL; g.bias = a.ball;
   g.M = nrows * a.C; g.N = NALL; g.Y = a.yall; g.ldy = NALL;
-  rc = launch_gemm(&g, 1, drop, s);
+  rc = launch_gemm_bf16(&g, 1, drop, s);
   if (rc) return rc;
   HUAL_LAUNCH(0.0, 0.0, char_pool_kernel, dim3(cdiv(nrows * NCH, 256)), dim3(256), 0, s, a, nrows);
   HUAL_CHECK_HIP(hipGetLastError());
@@ -271,9 +203,10 @@ int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const D
   GemmJob j;
   gemm_job_init(j);
   j.npieces = 1;
-  j.A[0] = a.yall; j.lda[0] = NALL; j.kw[0] = NALL; j.W[0] = a.wallt; j.ldw = 4 * CP;
+  HUAL_REQUIRE(a.wall_img_t != nullptr, "embed_bwd: image of the transposed filter bank");
+  j.A[0] = a.yall; j.lda[0] = NALL; j.kw[0] = NALL; j.W[0] = a.wall_img_t; j.ldw = 4 * CP;
   j.M = M; j.N = 4 * CP; j.Y = a.dxall; j.ldy = 4 * CP;
-  rc = launch_gemm(&j, 1, drop, s);
+  rc = launch_gemm_bf16(&j, 1, drop, s);
   if (rc) return rc;
   const size_t lds = (size_t)(a.num_chars - 1) * cd * sizeof(float);
   HUAL_REQUIRE(lds <= 64 * 1024, "embed_bwd: char table too large for the LDS accumulator");

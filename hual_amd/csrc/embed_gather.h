@@ -1,0 +1,70 @@
+// Device pieces of the text-encoder front end that run inside the step's prologue launch (pack_weights_kernel, gemm.hip): the
+// embedding gather (word lookup, char lookup, their dropout, the packed bias vector) and the element formula of the packed
+// char-CNN filter bank "Wall" (embed.hip) from which the prologue writes the pre-split images.
+#pragma once
+#include "embed_args.h"
+#include "philox.h"
+
+#define NCH 100          // 10+20+30+40 channels
+#define NALL 128         // padded channel count = GEMM N
+__device__ __host__ __forceinline__ int bank_off(int k) { return k == 1 ? 0 : (k == 2 ? 10 : (k == 3 ? 30 : 60)); }
+__device__ __forceinline__ void chan_to_kernel(int ch, int& k, int& chk) {
+  if (ch < 10) { k = 1; chk = ch; }
+  else if (ch < 30) { k = 2; chk = ch - 10; }
+  else if (ch < 60) { k = 3; chk = ch - 30; }
+  else { k = 4; chk = ch - 60; }
+}
+
+// Wall[r][n], r = dk * CP + d: filter_k[dk][d][chk] for channel n = (k, chk), zero for dk >= k, padding columns / dims
+__device__ __forceinline__ float wall_value(const float* const (&filt)[4], int cd, int CP, int r, int n) {
+  const int dk = r / CP, d = r - dk * CP;
+  if (n >= NCH || d >= cd) return 0.f;
+  int k, chk;
+  chan_to_kernel(n, k, chk);
+  return dk < k ? filt[k - 1][(size_t)(dk * cd + d) * (10 * k) + chk] : 0.f;
+}
+
+// one task = 4 consecutive columns of a word row or of a char slot row; tail tasks: guard rows of cemb, the packed biases.
+// ntask_words = nrows * (word_dim / 4 + C * CP / 4); tasks gid >= embed_gather_tasks(...) do nothing
+__device__ __forceinline__ void embed_gather_task(const hual::EmbedArgs& a, const hual::DropCfg& drop, int nrows, int CP, int ntask_words, int gid) {
+  const int wd = a.word_dim, cd = a.char_dim, C = a.C;
+  const int ngw = wd >> 2, ngc = CP >> 2;
+  const int per_word = ngw + C * ngc;
+  if (gid < ntask_words) {
+    const int row = gid / per_word, t = gid - row * per_word;
+    if (t < ngw) {
+      const int wid = a.word_ids[row];
+      float4 v = f4zero();
+      if (wid == 1) v = ld4(a.unk + 4 * t);
+      else if (wid >= 2) v = ld4(a.word_table + (size_t)(wid - 2) * wd + 4 * t);
+      if (drop.enabled) v = apply_drop4(drop, HUAL_SITE_WORD, (uint32_t)row, (uint32_t)t, v);
+      st4(a.cat + (size_t)row * a.ldcat + 4 * t, v);
+    } else {
+      const int u = t - ngw, c = u / ngc, g4 = u - c * ngc;
+      const int cid = a.char_ids[(size_t)row * C + c];
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      if (cid > 0) {
+        const float* src = a.char_table + (size_t)(cid - 1) * cd;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * g4 + q < cd) e[q] = src[4 * g4 + q];
+      }
+      float4 v = make_float4(e[0], e[1], e[2], e[3]);
+      if (drop.enabled && 4 * g4 < cd) v = apply_drop4(drop, HUAL_SITE_CHAR, (uint32_t)(row * C + c), (uint32_t)g4, v);
+      st4(a.cemb + ((size_t)row * C + c) * CP + 4 * g4, v);
+    }
+    return;
+  }
+  int x = gid - ntask_words;
+  if (x < 4 * CP) { a.cemb[(size_t)nrows * C * CP + x] = 0.f; return; }      // guard rows behind the last window
+  x -= 4 * CP;
+  if (x < NALL) {
+    float v = 0.f;
+    if (x < NCH) {
+      int k, chk;
+      chan_to_kernel(x, k, chk);
+      v = a.fbias[k - 1][chk];
+    }
+    a.ball[x] = v;
+  }
+}

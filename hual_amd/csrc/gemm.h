@@ -3,6 +3,7 @@
 // weight gradients - goes through these launches.
 #pragma once
 #include "common.h"
+#include "embed_args.h"
 
 namespace hual {
 
@@ -74,6 +75,11 @@ struct PackExtra {
   const int32_t* lens; const int32_t* word_ids; float* rowmask; float* loss_acc; int B, T, L;
   float* zero_ptr; size_t zero_n;      // zero_n floats (multiple of 4), 16-byte aligned
   const float* E; float lambda; float* dE_ortho;   // optional: label_emb [4,128] -> loss_acc[LA_ORTHO] and lambda * d ortho / dE (ortho.h)
+  // optional: the embedding gather of the text encoder (embed_gather.h) as further rows of workgroups, and the packed char-CNN
+  // filter bank Wall [4 CP, 128] (embed.hip) as one more pack job whose elements come from the four filters: its forward
+  // image goes to fwd + wall_off * 4, the image of its transpose to bwd + wall_boff
+  int gather_tasks; int gather_rows; EmbedArgs emb; DropCfg drop;
+  int wall_K; uint32_t wall_off, wall_boff;
 };
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
                         hipStream_t stream, const PackExtra* extra = nullptr);

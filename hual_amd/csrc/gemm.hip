@@ -10,6 +10,7 @@
 #include "bf16x3.h"
 #include "prof.h"
 #include "ortho.h"
+#include "embed_gather.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -514,7 +515,13 @@ struct PackBatch { PackJob j[HUAL_MAX_PACK]; };
 __device__ __forceinline__ int pack_perm(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
 __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* bwd, int njobs, PackExtra ex) {
   __shared__ float tile[16][129];
-  if ((int)blockIdx.y >= njobs) {      // the extra row: masks, loss accumulators, gradient zeroing (grid-stride)
+  if ((int)blockIdx.y > njobs) {       // further rows: the embedding gather of the text encoder, one task per thread
+    const int gid = (((int)blockIdx.y - njobs - 1) * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
+    if (gid < ex.gather_tasks)
+      embed_gather_task(ex.emb, ex.drop, ex.gather_rows, ex.wall_K / 4, ex.gather_tasks - ex.wall_K - NALL, gid);
+    return;
+  }
+  if ((int)blockIdx.y == njobs) {      // the extra row: masks, loss accumulators, gradient zeroing (grid-stride)
     const int nt = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
     const int Nv = ex.B * ex.T, Nq = ex.B * ex.L;
     if (t0 < 8) ex.loss_acc[t0] = 0.f;
@@ -534,9 +541,12 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
   const int k0 = blockIdx.x * 16;
   if (k0 >= ((job.K + 127) & ~127)) return;          // block-uniform
   const float* W = P + job.off;
+  const bool virt = ex.wall_K > 0 && job.off == ex.wall_off;      // the char-CNN filter bank: elements from the four filters
   for (int idx = threadIdx.x; idx < 16 * 128; idx += 256) {
     const int r = idx >> 7, n = idx & 127;
-    tile[r][n] = (k0 + r) < job.K ? W[(size_t)(k0 + r) * 128 + n] : 0.f;
+    float v = 0.f;
+    if ((k0 + r) < job.K) v = virt ? wall_value(ex.emb.filt, ex.emb.char_dim, ex.wall_K / 4, k0 + r, n) : W[(size_t)(k0 + r) * 128 + n];
+    tile[r][n] = v;
   }
   __syncthreads();
   // forward image: 16 rows x 64 column pairs
@@ -946,7 +956,9 @@ int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* bof
     }
     const bool with_extra = extra && base == 0;
     if (with_extra) ex = *extra;
-    HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(maxK / 16, cnt + (with_extra ? 1 : 0)),
+    const int gx = maxK / 16;
+    const int grows = (with_extra && ex.gather_tasks > 0) ? cdiv(ex.gather_tasks, gx * 256) : 0;      // rows of workgroups of the gather
+    HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(gx, cnt + (with_extra ? 1 + grows : 0)),
                 dim3(256), 0, stream, b, P, fwd, bwd, cnt, ex);
   }
   HUAL_CHECK_HIP(hipGetLastError());

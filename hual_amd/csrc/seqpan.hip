@@ -52,6 +52,7 @@ struct Ctx {
   std::vector<ColsumJob> colsum;
   int rc = 0;
   bool static_tables = false;   // hual_run_opts.static_tables
+  int wall_K = 0; uint32_t wall_off = 0, wall_boff = 0;      // packed char-CNN filter bank inside PKF / PKB (setup_ctx)
   struct DenseW { size_t off; int K; size_t boff; };
   std::vector<DenseW> dense;          // every [K,128] weight of the graph, sorted by offset
   char* PKF = nullptr;                // pre-split images (gemm.h launch_pack_weights): forward ...
@@ -211,8 +212,20 @@ GemmJob mkjob_dx(const float* dY, int lddy, int M, int N, const float* WT, int l
 }
 void set_embed_scratch(EmbedArgs& ea, float* base, int Nq, int C, int char_dim) {
   const EmbedLayout el = embed_layout(Nq, C, char_dim);
-  ea.cemb = base + el.cemb; ea.wall = base + el.wall; ea.wallt = base + el.wallt; ea.ball = base + el.ball;
+  ea.cemb = base + el.cemb; ea.ball = base + el.ball;
   ea.yall = base + el.yall; ea.dxall = base + el.dxall; ea.dfall = base + el.dfall;
+}
+// everything of EmbedArgs that does not depend on the gradients
+void fill_embed_args(Ctx& c, EmbedArgs& ea, const hual_batch* bt, float* cat, int catw, int32_t* char_arg, float* scratch) {
+  const ParamMap& pm = c.pm;
+  ea.word_ids = bt->word_ids; ea.char_ids = bt->char_ids; ea.word_table = c.word_table; ea.unk = c.p(pm.unk);
+  ea.char_table = c.p(pm.char_table);
+  for (int i = 0; i < 4; ++i) { ea.filt[i] = c.p(pm.filt[i]); ea.fbias[i] = c.p(pm.fbias[i]); }
+  ea.cat = cat; ea.ldcat = catw; ea.char_arg = char_arg;
+  set_embed_scratch(ea, scratch, c.rs.Nq, c.C, c.cfg->char_dim);
+  ea.word_dim = c.cfg->word_dim; ea.char_dim = c.cfg->char_dim; ea.C = c.C; ea.num_chars = c.cfg->num_chars;
+  ea.wall_img = reinterpret_cast<const float*>(c.PKF + (size_t)c.wall_off * 4);
+  ea.wall_img_t = reinterpret_cast<const float*>(c.PKB + c.wall_boff);
 }
 // keep-byte buffer of an attention job's probability dropout (attn.h): B*Tq*8 rows of ldm bytes
 // + the softmax statistics the forward leaves for the backward
@@ -282,6 +295,13 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
     extra = (extra + 255) & ~(size_t)255;
     for (auto& d : c.dense)
       if (d.K % 128) { d.boff = extra; extra += (size_t)((d.K + 127) / 128) * HUAL_PACK_BLOCK_BYTES; }
+    // the packed char-CNN filter bank Wall [4 CP, 128] (embed.hip): forward image at PKF + wall_off * 4, image of its
+    // transpose at PKB + wall_boff - the same byte offset in both buffers
+    c.wall_K = 4 * embed_cpad(cfg->char_dim);
+    c.wall_off = (uint32_t)(extra / 4);
+    c.wall_boff = (uint32_t)extra;
+    const size_t wf = (size_t)c.wall_K * 512, wb = (size_t)((c.wall_K + 127) / 128) * HUAL_PACK_BLOCK_BYTES;
+    extra += wf > wb ? wf : wb;
     c.pk_bytes = extra;
   }
   c.rs.B = B; c.rs.T = T; c.rs.L = L; c.rs.Nv = B * T; c.rs.Nq = B * L; c.rs.R = B * (T + L); c.rs.rowmask = nullptr;
@@ -377,31 +397,32 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
   c.PT = c.buf("params.T", pm.total, 1);
   float* ortho_dE = c.buf("ortho.dE", 4, HUAL_D);
-  if (!c.dry && c.ok()) {
-    std::vector<uint32_t> offs, boffs;
-    std::vector<int> Ks;
-    for (const auto& d : c.dense) { offs.push_back((uint32_t)d.off); Ks.push_back(d.K); boffs.push_back((uint32_t)d.boff); }
-    PackExtra ex{bt->video_seq_len, bt->word_ids, rowmask, loss_acc, B, T, L, (lab && opt->grads_prezero) ? opt->grads_prezero : nullptr,
-                 (size_t)((pm.total + 3) & ~(size_t)3),
-                 // the orthogonality term of the label embeddings depends on the parameters only: evaluated here (ortho.h)
-                 lab ? c.p(pm.label_emb) : nullptr, c.cfg->match_lambda, ortho_dE};
-    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex));
-  }
-  // ---------------- text encoder front: word + char embeddings (model.py:36-41)
-  c.stage(ST_INPUT);
+  // (the text encoder's gather - word / char lookups with their dropout, model.py:36-41 - rides in the same launch)
   float* cat = c.buf("cat", Nq, catw);
   int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
   float* embed_scratch = c.buf("embed.scratch", embed_layout(Nq, c.C, c.cfg->char_dim).total, 1);
   EmbedArgs ea{};
-  if (!c.dry) {
-    ea.word_ids = bt->word_ids; ea.char_ids = bt->char_ids; ea.word_table = c.word_table; ea.unk = c.p(pm.unk);
-    ea.char_table = c.p(pm.char_table);
-    for (int i = 0; i < 4; ++i) { ea.filt[i] = c.p(pm.filt[i]); ea.fbias[i] = c.p(pm.fbias[i]); }
-    ea.cat = cat; ea.ldcat = catw; ea.char_arg = char_arg;
-    set_embed_scratch(ea, embed_scratch, Nq, c.C, c.cfg->char_dim);
-    ea.word_dim = c.cfg->word_dim; ea.char_dim = c.cfg->char_dim; ea.C = c.C; ea.num_chars = c.cfg->num_chars;
-    if (c.live()) c.chk(launch_embed_fwd(ea, Nq, c.drop, c.stream));
+  if (!c.dry && c.ok()) {
+    std::vector<uint32_t> offs, boffs;
+    std::vector<int> Ks;
+    for (const auto& d : c.dense) { offs.push_back((uint32_t)d.off); Ks.push_back(d.K); boffs.push_back((uint32_t)d.boff); }
+    offs.push_back(c.wall_off); Ks.push_back(c.wall_K); boffs.push_back(c.wall_boff);      // the char-CNN filter bank (virtual source)
+    fill_embed_args(c, ea, bt, cat, catw, char_arg, embed_scratch);
+    PackExtra ex{};
+    ex.lens = bt->video_seq_len; ex.word_ids = bt->word_ids; ex.rowmask = rowmask; ex.loss_acc = loss_acc; ex.B = B; ex.T = T; ex.L = L;
+    ex.zero_ptr = (lab && opt->grads_prezero) ? opt->grads_prezero : nullptr;
+    ex.zero_n = (size_t)((pm.total + 3) & ~(size_t)3);
+    // the orthogonality term of the label embeddings depends on the parameters only: evaluated here (ortho.h)
+    ex.E = lab ? c.p(pm.label_emb) : nullptr; ex.lambda = c.cfg->match_lambda; ex.dE_ortho = ortho_dE;
+    // (per-block entry points of other stages run without the text encoder's inputs: no gather then)
+    ex.gather_tasks = (c.stage_on(ST_INPUT) && c.word_table) ? embed_gather_tasks(ea, Nq) : 0;
+    ex.gather_rows = Nq; ex.emb = ea; ex.drop = c.drop;
+    ex.wall_K = c.wall_K; ex.wall_off = c.wall_off; ex.wall_boff = c.wall_boff;
+    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex));
   }
+  // ---------------- text encoder front: word + char embeddings (model.py:36-41)
+  c.stage(ST_INPUT);
+  if (c.live()) c.chk(launch_embed_fwd(ea, Nq, c.drop, c.stream));      // char CNN on the gathered embeddings
   // ---------------- the two input projections (model.py:42,48) as one launch; LN + pos (model.py:43,49,53,56)
   float* lin = c.act("lin");
   // feature-load path: K-split kernel with LDS-resident weight quarters (gemm.h launch_feature_ksplit); its four partial
@@ -1133,10 +1154,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   DwJob embed_dw;
   embed_dw_job(ea, Nq, &embed_dw);
   if (c.live()) {
-    ea.word_ids = bt->word_ids; ea.char_ids = bt->char_ids; ea.word_table = c.word_table; ea.unk = c.p(pm.unk);
-    ea.char_table = c.p(pm.char_table);
-    for (int i = 0; i < 4; ++i) { ea.filt[i] = c.p(pm.filt[i]); ea.fbias[i] = c.p(pm.fbias[i]); }
-    ea.cat = cat; ea.ldcat = catw; ea.char_arg = char_arg;
+    fill_embed_args(c, ea, bt, cat, catw, char_arg, embed_scratch);
     eg.dcat = d_cat; eg.lddcat = catw; eg.dunk = c.g(pm.unk); eg.dchar_table = c.g(pm.char_table);
     for (int i = 0; i < 4; ++i) { eg.dfilt[i] = c.g(pm.filt[i]); eg.dfbias[i] = c.g(pm.fbias[i]); }
     c.chk(launch_embed_bwd(ea, eg, Nq, c.drop, c.stream, &embed_dw));
