@@ -2,6 +2,7 @@
 #include "../../include/hual_seqpan.h"
 #include "common.h"
 #include "gemm.h"
+#include "mproj.h"
 #include "attn.h"
 #include "heads.h"
 #include "rowops.h"
@@ -16,22 +17,6 @@ extern "C" {
 
 int hual_abi_version(void) { return HUAL_ABI_VERSION; }
 const char* hual_last_error(void) { return hual::last_error_cstr(); }
-
-int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int K, int N,
-                    int act, void* stream) {
-  HUAL_REQUIRE(A && W && Y, "hual_linear_fwd: null pointer");
-  HUAL_REQUIRE(M > 0 && K > 0 && N > 0, "hual_linear_fwd: empty shape");
-  HUAL_REQUIRE(K % 16 == 0 && N % 64 == 0, "hual_linear_fwd: K % 16 == 0 and N % 64 == 0 required");
-  HUAL_REQUIRE(act >= 0 && act <= 2, "hual_linear_fwd: act");
-  GemmJob j;
-  gemm_job_init(j);
-  j.npieces = 1;
-  j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.W[0] = W;
-  j.ldw = ldw; j.bias = bias;
-  j.M = M; j.N = N; j.act = act; j.Y = Y; j.ldy = ldy;
-  DropCfg d = make_dropcfg(nullptr, 0.f);
-  return launch_gemm(&j, 1, d, (hipStream_t)stream);
-}
 
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
                    int N, int workgroups, void* scratch, uint64_t scratch_bytes, void* stream) {
@@ -51,27 +36,36 @@ int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW,
 int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, const float* bias, float* Y, int ldy, int M,
                        int K, int N, int act, void* scratch, uint64_t scratch_bytes, void* stream) {
   HUAL_REQUIRE(A && W && Y && scratch, "hual_linear_bf16x3: null pointer");
-  HUAL_REQUIRE(M > 0 && K > 0 && N > 0 && act >= 0 && act <= 2, "hual_linear_bf16x3: bad shape / act");
-  GemmJob j;
-  gemm_job_init(j);
-  j.npieces = 1;
-  j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.ldw = 128; j.bias = bias;
-  j.M = M; j.N = N; j.act = act; j.Y = Y; j.ldy = ldy;
-  j.W[0] = reinterpret_cast<const float*>(scratch);
+  HUAL_REQUIRE(M > 0 && K > 0 && N > 0 && act >= 0 && act <= 1, "hual_linear_bf16x3: bad shape / act (0 none, 1 relu)");
+  HUAL_REQUIRE((lda % 4) == 0 && (ldy % 4) == 0, "hual_linear_bf16x3: leading dims must be multiples of 4");
   const uint32_t off = 0, boff = 0;
-  if (!trans_w) {        // Y = act(A[M,K] . W[K,128] + bias)
+  MProjArgs g{};
+  g.R = M; g.MT = mproj_rows(M);
+  if (!trans_w) {        // Y = act(A[M,K] . W[K,128] + bias): ceil(K / 128) weight steps over one deep operand
     HUAL_REQUIRE(N == 128 && K % 8 == 0, "hual_linear_bf16x3: W must be [K,128] with K % 8 == 0");
     HUAL_REQUIRE(scratch_bytes >= (uint64_t)K * 512, "hual_linear_bf16x3: scratch too small (K * 512 bytes)");
     int rc = launch_pack_weights(&off, &K, nullptr, 1, W, (char*)scratch, nullptr, (hipStream_t)stream);
     if (rc) return rc;
-  } else {               // Y[M,N] = A[M,128] . W^T, W stored [N,128]  (dX of a dense layer with weight W)
-    HUAL_REQUIRE(K == 128 && N % 8 == 0, "hual_linear_bf16x3: transposed use needs K == 128 and N % 8 == 0");
+    g.nsteps = 1;
+    MProjStep& st = g.s[0];
+    st.A = A; st.lda = lda; st.rep = (K + 127) / 128; st.ktot = K; st.kw = K < 128 ? K : 128; st.wimg = reinterpret_cast<const float*>(scratch); st.wrows = K;
+    st.first = 1; st.last = 1; st.drop_site = -1; st.add_div = 1; st.bias = bias; st.act = act; st.out = Y; st.ldo = ldy; st.ncol = 128;
+  } else {               // Y[M,N] = A[M,128] . W^T, W stored [N,128]  (dX of a dense layer with weight W): ceil(N / 128) column blocks
+    HUAL_REQUIRE(K == 128 && N % 8 == 0 && (N + 127) / 128 <= MP_MAX, "hual_linear_bf16x3: transposed use needs K == 128, N % 8 == 0, N <= 1024");
     HUAL_REQUIRE(scratch_bytes >= (uint64_t)((N + 127) / 128) * HUAL_PACK_BLOCK_BYTES, "hual_linear_bf16x3: scratch too small");
     int rc = launch_pack_weights(&off, &N, &boff, 1, W, nullptr, (char*)scratch, (hipStream_t)stream);
     if (rc) return rc;
+    g.nsteps = (N + 127) / 128;
+    for (int p = 0; p < g.nsteps; ++p) {
+      MProjStep& st = g.s[p];
+      st.A = A; st.lda = lda; st.kw = 128; st.reuse = p > 0 ? 1 : 0; st.rep = 1;
+      st.wimg = reinterpret_cast<const float*>((const char*)scratch + (size_t)p * HUAL_PACK_BLOCK_BYTES); st.wrows = 128;
+      st.first = 1; st.last = 1; st.drop_site = -1; st.add_div = 1; st.act = act;
+      st.out = Y + (size_t)p * 128; st.ldo = ldy; st.ncol = N - 128 * p < 128 ? N - 128 * p : 128;
+    }
   }
   DropCfg d = make_dropcfg(nullptr, 0.f);
-  return launch_gemm_bf16(&j, 1, d, (hipStream_t)stream);
+  return launch_mproj(&g, 1, d, (hipStream_t)stream);
 }
 
 int hual_layer_norm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int R,

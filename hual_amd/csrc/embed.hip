@@ -20,6 +20,7 @@
 //             d windows = dYall . Wall^T (launch_gemm) and embed_finish_kernel folds the overlapping windows back to
 //             char slots, applies the dropout mask and accumulates char-table rows (LDS, then global atomics).
 #include "embed.h"
+#include "mproj.h"
 #include "philox.h"
 #include "prof.h"
 
@@ -174,13 +175,15 @@ int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStre
   int rc = check_args(a);
   if (rc) return rc;
   const int CP = cpad(a.char_dim);
-  GemmJob g;
-  gemm_job_init(g);
-  g.npieces = 1;
-  g.A[0] = a.cemb; g.lda[0] = CP; g.kw[0] = 4 * CP;          // overlapping rows: window r = slot rows r .. r+3
-  g.W[0] = a.wall_img; g.ldw = NALL; g.bias = a.ball;
-  g.M = nrows * a.C; g.N = NALL; g.Y = a.yall; g.ldy = NALL;
-  rc = launch_gemm_bf16(&g, 1, drop, s);
+  // windows . Wall + ball: the 4 CP-deep windows (overlapping rows: window r = slot rows r .. r + 3, row stride CP) against the
+  // pre-split image of the filter bank, ceil(4 CP / 128) weight steps (mproj.h)
+  MProjArgs g{};
+  g.R = nrows * a.C; g.MT = mproj_rows(g.R); g.nsteps = 1;
+  MProjStep& st = g.s[0];
+  st.A = a.cemb; st.lda = CP; st.rep = cdiv(4 * CP, 128); st.ktot = 4 * CP; st.kw = 4 * CP < 128 ? 4 * CP : 128; st.wimg = a.wall_img; st.wrows = 4 * CP;
+  st.first = 1; st.last = 1; st.drop_site = -1; st.add_div = 1;
+  st.bias = a.ball; st.out = a.yall; st.ldo = NALL; st.ncol = NALL;
+  rc = launch_mproj(&g, 1, drop, s);
   if (rc) return rc;
   HUAL_LAUNCH(0.0, 0.0, char_pool_kernel, dim3(cdiv(nrows * NCH, 256)), dim3(256), 0, s, a, nrows);
   HUAL_CHECK_HIP(hipGetLastError());
@@ -200,13 +203,17 @@ int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const D
   // d filters / d bias: one more job for the step's weight-gradient launch
   embed_dw_job(a, nrows, dwjob);
   // d windows = dYall . Wall^T
-  GemmJob j;
-  gemm_job_init(j);
-  j.npieces = 1;
-  HUAL_REQUIRE(a.wall_img_t != nullptr, "embed_bwd: image of the transposed filter bank");
-  j.A[0] = a.yall; j.lda[0] = NALL; j.kw[0] = NALL; j.W[0] = a.wall_img_t; j.ldw = 4 * CP;
-  j.M = M; j.N = 4 * CP; j.Y = a.dxall; j.ldy = 4 * CP;
-  rc = launch_gemm_bf16(&j, 1, drop, s);
+  HUAL_REQUIRE(a.wall_img_t != nullptr && cdiv(4 * CP, 128) <= MP_MAX, "embed_bwd: image of the transposed filter bank");
+  MProjArgs j{};
+  j.R = M; j.MT = mproj_rows(M); j.nsteps = cdiv(4 * CP, 128);
+  for (int p = 0; p < j.nsteps; ++p) {      // column block p of d windows: one operand, ceil(4 CP / 128) images of Wall^T
+    MProjStep& st = j.s[p];
+    st.A = a.yall; st.lda = NALL; st.kw = NALL; st.reuse = p > 0 ? 1 : 0; st.rep = 1;
+    st.wimg = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.wall_img_t) + (size_t)p * HUAL_PACK_BLOCK_BYTES); st.wrows = NALL;
+    st.first = 1; st.last = 1; st.drop_site = -1; st.add_div = 1;
+    st.out = a.dxall + (size_t)p * 128; st.ldo = 4 * CP; st.ncol = 4 * CP - 128 * p < 128 ? 4 * CP - 128 * p : 128;
+  }
+  rc = launch_mproj(&j, 1, drop, s);
   if (rc) return rc;
   const size_t lds = (size_t)(a.num_chars - 1) * cd * sizeof(float);
   HUAL_REQUIRE(lds <= 64 * 1024, "embed_bwd: char table too large for the LDS accumulator");

@@ -7,36 +7,7 @@
 
 namespace hual {
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
-
 #define HUAL_MAX_PIECES 4
-#define HUAL_MAX_JOBS 6
-
-// Y[M,N] = epilogue( sum_p prologue(A[p])[M,kw[p]] . W[p] )   (N multiple of 64, kw multiple of 16)
-struct GemmJob {
-  // ---- A operand: up to 4 column pieces (concatenation along K), optional elementwise multiplier
-  const float* A[HUAL_MAX_PIECES];
-  const float* A2[HUAL_MAX_PIECES];
-  int lda[HUAL_MAX_PIECES];
-  int lda2[HUAL_MAX_PIECES];
-  int kw[HUAL_MAX_PIECES];
-  int npieces;
-  int a_drop_site;            // >=0: A = dropout(A) (tf.nn.dropout on the GEMM input, model.py:47)
-  uint32_t a_drop_row0;
-  // ---- B operand: one weight block per piece, W[p][k][n] (ldw) - or its pre-split image (launch_gemm_bf16)
-  const float* W[HUAL_MAX_PIECES];
-  int ldw;
-  const float* bias;          // [N] or null
-  int M, N;
-  // ---- epilogue: +bias -> act -> +add[row / add_div] -> Y
-  int act;
-  const float* add; int ldadd; int add_div;
-  float* Y; int ldy;
-};
-
-struct GemmBatch {
-  GemmJob j[HUAL_MAX_JOBS];
-};
 
 // dW[p][k][n] += sum_m prologue(A[p])[m][k] * dY[m][n] ;  db[n] += sum_m dY[m][n]     (N multiple of 64)
 struct DwJob {
@@ -64,10 +35,10 @@ struct DwBatch {
   DwJob j[HUAL_MAX_DW_JOBS];
 };
 
-// Split-bf16 path (gemm_bf16_kernel, bf16x3.h).  launch_pack_weights writes, for n dense weights [K,128] at float offsets
-// offs[] of P, the forward image at fwd + 4*off and the image of the transposed weight (for dX) at bwd + boffs[]
-// (ceil(K/128) blocks of 64 KB); either destination may be null.  launch_gemm_bf16 takes jobs whose W[p] point at
-// such images (reinterpreted) - N > 128 walks the 64 KB column blocks of a backward image.
+// Pre-split weight images (bf16x3.h "f16x3").  launch_pack_weights writes, for n dense weights [K,128] at float offsets offs[] of
+// P, the forward image at fwd + 4*off and the image of the transposed weight (for dX) at bwd + boffs[] (ceil(K/128) blocks
+// of 64 KB); either destination may be null.  The fused kernels, the multi-step kernel (mproj.h) and the feature-load kernel
+// stream these images into LDS.
 #define HUAL_PACK_BLOCK_BYTES (128 * 512)
 // `extra` (optional): work of the step's prologue that rides in the same launch as one more row of workgroups - the row
 // masks of model.py:31-32 (+ the loss accumulators cleared) and, when zero_ptr is set, the flat gradient buffer zeroed
@@ -83,7 +54,6 @@ struct PackExtra {
 };
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
                         hipStream_t stream, const PackExtra* extra = nullptr);
-int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
 // Feature-load kernel: part[q][M][128] = dropout(A)[M, q*KS .. q*KS+KS) . W[q*KS .., :] for the four K-quarters q (Wimg =
 // forward image of the [K,128] weight, K <= 4*KS); the sum over q (+ bias) is taken by the consumer (ln_fwd_kernel's `part`).
 struct FkJob {
@@ -97,10 +67,7 @@ struct FkJob {
 #define HUAL_MAX_FK_JOBS 2
 struct FkBatch { FkJob j[HUAL_MAX_FK_JOBS]; };
 int launch_feature_ksplit(const FkJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
-void gemm_job_init(GemmJob& j);
 void dw_job_init(DwJob& j);
-// enqueue `n` jobs (n <= HUAL_MAX_JOBS) as ONE launch on `stream`
-int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream);
 // words of a device job table for n jobs: the descriptors followed by 3 (n + 1) integers (plan of the balanced launch)
 inline size_t dw_table_words(size_t n) { return (n * sizeof(DwJob) + 3 * (n + 1) * sizeof(int) + 3) / 4; }
 // enqueue `n` gradient jobs (any n) as ONE persistent launch that reads them from the device-resident `table`;

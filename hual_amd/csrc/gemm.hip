@@ -1,13 +1,12 @@
-// Job-table dense kernels (see gemm.h).
-//   gemm_lds_kernel         exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32): the char-CNN product (embed.hip) and
-//                           the hual_linear_fwd unit entry point
-//   gemm_bf16_kernel        the dense layers left outside the fused row-local kernels, three MFMA passes on split operands
-//   feature_ksplit_kernel   the feature-load phase (video_conv1d + query_conv1d)
-//   pack_weights_kernel     once per step: pre-split images of every dense weight (+ the step prologue)
+// Dense kernels outside the fused row-local kernels and the multi-step kernel (see gemm.h):
+//   feature_ksplit_kernel   the feature-load phase (video_conv1d + query_conv1d) when the weight quarters fit LDS
+//   pack_weights_kernel     once per step: pre-split images of every dense weight (+ the step prologue: masks, gradient zeroing,
+//                           orthogonality term, embedding gather)
 //   dw_bf16_balanced_kernel every weight / bias gradient of a step in one persistent launch
 #include "gemm.h"
 #include "philox.h"
 #include "bf16x3.h"
+#include "tilecore.h"
 #include "prof.h"
 #include "ortho.h"
 #include "embed_gather.h"
@@ -17,11 +16,6 @@
 
 namespace hual {
 
-void gemm_job_init(GemmJob& j) {
-  ::memset((void*)&j, 0, sizeof(j));
-  j.a_drop_site = -1;
-  j.add_div = 1;
-}
 void dw_job_init(DwJob& j) {
   ::memset((void*)&j, 0, sizeof(j));
   j.a_drop_site = -1;
@@ -31,353 +25,13 @@ void dw_job_init(DwJob& j) {
 
 using namespace hual;
 
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ float f4get(const float4& v, int i) {
-  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
-}
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-// lane (j, g): a = A[row j][k 4g .. 4g+3], b[c] = W[k 4g+c][n 4j .. 4j+3]; accumulator t holds output column 4j + t
-__device__ __forceinline__ void mma_frag(f32x4 (&acc)[4], const float4& a, const float4 (&b)[4]) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float av = f4get(a, c);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = mfma16(av, f4get(b[c], t), acc[t]);
-  }
-}
 
-// ------------------------------------------------------------------------------------------------------
-// gemm_lds_kernel: one wave computes a 16(row) x 64(col) output tile as four 16x16 accumulators with
-// v_mfma_f32_16x16x4_f32, built to expose ONE memory round trip per block:
-//   * the weight panel (all 128 output columns x 64 K rows per stage, 32 KB) goes global -> LDS by LDS-DMA
-//     (global_load_lds_dwordx4: no staging registers), once per BLOCK, shared by the four waves; two stages (= a
-//     whole K=128 layer) are requested in the prologue, later stages are requested as soon as a buffer is free;
-//   * each wave requests the A fragments of those stages and its epilogue operands (bias, residual rows) in the
-//     same prologue, so they are in registers when the MFMAs / the epilogue need them;
-//   * the panel image is the plain [64][128] row-major tile: for the B-fragment ds_read_b128 (lane (j,g) reads 16 B
-//     at row 4g+c, column 4j) the hardware's 16-lane groups then cover disjoint bank ranges - conflict free.
-// Weights are stored [K,N].
-#define GL_KS 64            // K rows per stage
-#define GL_STAGE (GL_KS * 128)   // floats per staged panel
-
-struct EpiRegs {
-  float4 bias;
-  float4 add[4];
-};
-
-template <class J>
-__device__ __forceinline__ void epi_prefetch(const J& job, EpiRegs& e, int rowbase, int n0, int j, int g) {
-  const int M = job.M, N = job.N;
-  const int col = n0 + 4 * j;
-  const bool cok = col < N;
-  e.bias = (job.bias && cok) ? ld4(job.bias + col) : f4zero();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = min(rowbase + 4 * g + r, M - 1);
-    e.add[r] = (job.add && cok) ? ld4(job.add + (size_t)(row / job.add_div) * job.ldadd + col) : f4zero();
-  }
-}
-
-// lane (j, g) owns rows rowbase + 4g + r (r = 0..3), columns n0 + 4j .. + 3; accumulator t = column 4j + t
-template <class J>
-__device__ __forceinline__ void epi_apply(const J& job, const EpiRegs& e, f32x4 (&acc)[4], int rowbase, int n0, int j, int g) {
-  const int M = job.M, N = job.N;
-  const int col = n0 + 4 * j;
-  if (col >= N) return;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = rowbase + 4 * g + r;
-    if (row >= M) continue;
-    float4 v = make_float4(acc[0][r] + e.bias.x, acc[1][r] + e.bias.y, acc[2][r] + e.bias.z, acc[3][r] + e.bias.w);
-    if (job.act == ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-    else if (job.act == ACT_SIGMOID) v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
-    if (job.add) v = f4add(v, e.add[r]);
-    st4(job.Y + (size_t)row * job.ldy + col, v);
-  }
-}
-
-// stage index (64 K rows each, over the concatenated pieces) -> piece and K offset inside it (block-uniform)
-template <class J>
-__device__ __forceinline__ void stage_to_piece(const J& job, int st, int& p, int& k0) {
-  p = 0;
-  while (p + 1 < job.npieces) {
-    const int n = (job.kw[p] + GL_KS - 1) / GL_KS;
-    if (st < n) break;
-    st -= n;
-    ++p;
-  }
-  k0 = st * GL_KS;
-}
-
-// RT = 16-row tiles per block (block = 2*RT waves = RT row tiles x 2 column halves).  RT = 3 (48 rows, 384 threads)
-// is picked when it brings a launch down to one block per CU: the kernel is bound by what each CU can pull through
-// its vector-memory path (64 KB of weights per block + the activations), so fewer, taller blocks win.
-template <int RT>
-__global__ __launch_bounds__(RT * 128) void gemm_lds_kernel(GemmBatch batch, DropCfg drop) {
-  extern __shared__ float lds[];     // Ws[2][GL_STAGE]
-  const GemmJob& job = batch.j[blockIdx.z];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, g = lane >> 4;
-  const int M = job.M, N = job.N;
-  const int blockrow = blockIdx.x * (16 * RT);
-  const int nblk = blockIdx.y * 128;
-  if (blockrow >= M || nblk >= N) return;          // block-uniform
-  const int rowbase = blockrow + (wave >> 1) * 16;
-  const int n0 = nblk + (wave & 1) * 64;
-  const bool wave_on = rowbase < M && n0 < N;       // idle waves still take part in staging and barriers
-  const int arow = min(rowbase + j, M - 1);
-  const int ldw = job.ldw;
-  const bool adrop = job.a_drop_site >= 0 && drop.enabled;
-  const uint32_t asite = (uint32_t)job.a_drop_site;
-  const uint32_t adrow = job.a_drop_row0 + (uint32_t)arow;
-  float* Ws = lds;
-  int nstages = 0;
-  for (int p = 0; p < job.npieces; ++p) nstages += (job.kw[p] + GL_KS - 1) / GL_KS;
-
-  f32x4 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // LDS-DMA of one stage: 32 pieces of 1 KB (2 panel rows each), 8 per wave; lane l -> row 2*pc + (l>>5), 16 B at
-  // column 4*(l&31).  Out-of-range rows / columns are clamped to valid memory (never multiplied / never stored).
-  auto dma_stage = [&](const float* Wp, int k0, int kw, float* dst) {
-    const int c4 = lane & 31, rr = lane >> 5;
-    const int n = min(nblk + 4 * c4, N - 4);
-    for (int pc = wave; pc < 32; pc += 2 * RT) {
-      const int kk = min(k0 + 2 * pc + rr, kw - 1);
-      const float* src = Wp + (size_t)kk * ldw + n;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
-    }
-  };
-  auto a_load = [&](const float* Ap, const float* A2p, int k0, int kw, float4 (&a)[4]) {
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      const int kk = k0 + kc * 16;
-      float4 v = f4zero();
-      if (kk < kw) {
-        v = ld4(Ap + kk + 4 * g);
-        if (A2p) v = f4mul(v, ld4(A2p + kk + 4 * g));
-        if (adrop) v = apply_drop4(drop, asite, adrow, (uint32_t)((kk + 4 * g) >> 2), v);
-      }
-      a[kc] = v;
-    }
-  };
-  // request stage s: weight panel(s) by DMA into buffer (s & 1), A fragments into the given register slot
-  auto issue = [&](int s, float4 (&a)[4], int& kw_out, int& k0_out) {
-    int p, k0;
-    stage_to_piece(job, s, p, k0);
-    const int kw = job.kw[p];
-    dma_stage(job.W[p], k0, kw, Ws + (s & 1) * GL_STAGE);
-    const float* Ap = job.A[p] + (size_t)arow * job.lda[p];
-    const float* A2p = job.A2[p] ? job.A2[p] + (size_t)arow * job.lda2[p] : nullptr;
-    a_load(Ap, A2p, k0, kw, a);
-    kw_out = kw;
-    k0_out = k0;
-  };
-  auto compute = [&](int bufi, int k0, int kw, const float4 (&a)[4]) {
-    const float* wsb = Ws + bufi * GL_STAGE + (wave & 1) * 64 + 4 * j;
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      if (k0 + kc * 16 < kw) {
-        float4 b[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(wsb + (kc * 16 + 4 * g + c) * 128);
-        mma_frag(acc, a[kc], b);
-      }
-    }
-  };
-
-  float4 a0[4], a1[4];
-  int kw0 = 0, kw1 = 0, k00 = 0, k01 = 0;
-  EpiRegs epi;
-  // prologue: the first TWO stages (a whole K=128 layer) + everything the epilogue will read
-  issue(0, a0, kw0, k00);
-  if (nstages > 1) issue(1, a1, kw1, k01);
-  epi_prefetch(job, epi, rowbase, n0, j, g);
-  for (int s = 0; s < nstages; s += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // DMA of the resident stages has landed (this wave's part)
-    __syncthreads();                                      // ... and everybody else's
-    if (wave_on) compute(0, k00, kw0, a0);
-    if (s + 1 < nstages && wave_on) compute(1, k01, kw1, a1);
-    if (s + 2 < nstages) {
-      __syncthreads();                                    // both buffers consumed by every wave
-      issue(s + 2, a0, kw0, k00);
-      if (s + 3 < nstages) issue(s + 3, a1, kw1, k01);
-    }
-  }
-  if (!wave_on) return;
-  epi_apply(job, epi, acc, rowbase, n0, j, g);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Split-bf16 dense kernel.  Same jobs, same wave -> (16 rows x 64 columns) mapping, same two-stage LDS-DMA pipeline and
-// the same epilogue as gemm_lds_kernel; the products run as three v_mfma_f32_16x16x32_bf16 passes on split operands
-// (bf16x3.h): 48 MFMAs x 16 cycles per 128-deep layer and wave instead of 128 x 32.
-//   * weights come pre-split from pack_weights_kernel: per K row 256 B of bf16 high parts then 256 B of residuals, the
-//     128 columns stored in the order that makes the transposed LDS read hand lane j of tile t column 4j + t (the
-//     accumulator -> column map of the epilogue).  A stage (64 K rows) is two [64][256 B] tiles (hi, lo) in the
-//     XOR-swizzled dual-use layout of bf16x3.h; the swizzle is applied on the GLOBAL side of the LDS-DMA (lane l of a
-//     1 KB piece fetches chunk (l&15) ^ sw(row) of its row), the LDS side of global_load_lds being lane-linear.
-//   * B fragments: ds_read_b64_tr_b16 (k is the strided direction of a [k][n] image), 2 reads per tile and plane;
-//   * A fragments: lane (j, g) loads 8 consecutive k of row j as two float4 and splits them right before the MFMAs.
-// dX = dY.W^T uses the same kernel on the image of the transposed weight (pack_weights_kernel writes both).
-#define GB_TILE (GL_KS * 256)            // bytes of one [64][128 x bf16] tile
+#define GL_KS 64                         // K rows per stage of a weight image
+#define GB_TILE (GL_KS * 256)            // bytes of one [64][128 x 16 bit] tile
 #define GB_STAGE (2 * GB_TILE)           // hi + lo
-#define GB_COLBLOCK (128 * 512)          // bytes between the images of consecutive 128-column blocks (dX with N > 128)
-
-template <int RT, class J>
-__device__ __forceinline__ void gemm_bf16_body(const J& job, const DropCfg& drop, char* ldsb) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, g = lane >> 4;
-  const int M = job.M, N = job.N;
-  const int blockrow = blockIdx.x * (16 * RT);
-  const int nblk = blockIdx.y * 128;
-  if (blockrow >= M || nblk >= N) return;          // block-uniform
-  const int rowbase = blockrow + (wave >> 1) * 16;
-  const int n0 = nblk + (wave & 1) * 64;
-  const bool wave_on = rowbase < M && n0 < N;       // idle waves still take part in staging, barriers and LDS reads
-  const int arow = min(rowbase + j, M - 1);
-  const bool adrop = job.a_drop_site >= 0 && drop.enabled;
-  const uint32_t asite = (uint32_t)job.a_drop_site;
-  const uint32_t adrow = job.a_drop_row0 + (uint32_t)arow;
-  char* Ws = ldsb;
-  int nstages = 0;
-  for (int p = 0; p < job.npieces; ++p) nstages += (job.kw[p] + GL_KS - 1) / GL_KS;
-
-  f32x4 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // LDS-DMA of one stage: 32 pieces of 1 KB = 4 tile rows each (pieces 0-15: hi tile, 16-31: lo tile)
-  auto dma_stage = [&](const float* Wimg, int k0, int kw, char* dst) {
-    const char* img = reinterpret_cast<const char*>(Wimg) + (size_t)blockIdx.y * GB_COLBLOCK;
-    const int chp = lane & 15, rr = lane >> 4;
-    for (int pc = wave; pc < 32; pc += 2 * RT) {
-      const int r = 4 * (pc & 15) + rr;
-      const int kk = min(k0 + r, kw - 1);
-      const int ch = chp ^ (((r & 3) << 2) | ((r >> 2) & 3));
-      const char* src = img + (size_t)kk * 512 + (pc >> 4) * 256 + 16 * ch;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
-    }
-  };
-  // raw A fragments of one stage: a[2*ks + half] = row arow, k = k0 + 32 ks + 8 g + 4 half .. +3
-  auto a_load = [&](const float* Ap, const float* A2p, int k0, int kw, float4 (&a)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int kk = k0 + 32 * (u >> 1) + 8 * g + 4 * (u & 1);
-      float4 v = f4zero();
-      if (kk < kw) {
-        v = ld4(Ap + kk);
-        if (A2p) v = f4mul(v, ld4(A2p + kk));
-        if (adrop) v = apply_drop4(drop, asite, adrow, (uint32_t)(kk >> 2), v);
-      }
-      a[u] = v;
-    }
-  };
-  auto issue = [&](int s, float4 (&a)[4], int& kw_out, int& k0_out) {
-    int p, k0;
-    stage_to_piece(job, s, p, k0);
-    const int kw = job.kw[p];
-    dma_stage(job.W[p], k0, kw, Ws + (s & 1) * GB_STAGE);
-    const float* Ap = job.A[p] + (size_t)arow * job.lda[p];
-    const float* A2p = job.A2[p] ? job.A2[p] + (size_t)arow * job.lda2[p] : nullptr;
-    a_load(Ap, A2p, k0, kw, a);
-    kw_out = kw;
-    k0_out = k0;
-  };
-  // transposed-read addressing: 16-lane group g takes rows 32 ks + 8 g + 4 rr + q, lane 4q+pp supplies stored columns
-  // 64 (wave&1) + 16 t + 4 pp .. +3
-  const int tq = (lane >> 2) & 3, tp = lane & 3;
-  f32x4 accp[4];     // accumulators of the current 128-deep chunk (operands carry the chunk's row scale)
-  // sc: this lane's A row scale of the chunk (bf16x3.h "f16x3")
-  auto compute = [&](int bufi, int k0, int kw, const float4 (&a)[4], float sc) {
-    const char* hi = Ws + bufi * GB_STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (k0 + 32 * ks < kw) {             // block-uniform
-        uint2 h0, l0, h1, l1;
-        f16_split4(f4scale1(a[2 * ks], sc), h0, l0);
-        f16_split4(f4scale1(a[2 * ks + 1], sc), h1, l1);
-        const f16x8 ah = __builtin_bit_cast(f16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
-        const f16x8 al = __builtin_bit_cast(f16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
-        const int r0 = 32 * ks + 8 * g + tq, r1 = r0 + 4;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int chunk = 8 * (wave & 1) + 2 * t + (tp >> 1);
-          const int o0 = tile256_off(r0, chunk) + 8 * (tp & 1), o1 = tile256_off(r1, chunk) + 8 * (tp & 1);
-          const f16x8 wh = join_tr_f16(lds_read_tr16(hi, o0), lds_read_tr16(hi, o1));
-          const f16x8 wl = join_tr_f16(lds_read_tr16(hi + GB_TILE, o0), lds_read_tr16(hi + GB_TILE, o1));
-          accp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, accp[t], 0, 0, 0);
-          accp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, accp[t], 0, 0, 0);
-          accp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, accp[t], 0, 0, 0);
-        }
-      }
-    }
-  };
-  // largest magnitude of this lane's row over the fragments of the resident stages -> row scale (all 4 lanes of a row
-  // agree after the two shuffles)
-  auto row_scale = [&](const float4 (&x0)[4], const float4 (&x1)[4], bool two, float& inv) {
-    float m = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      m = fmaxf(m, f4absmax(x0[u]));
-      if (two) m = fmaxf(m, f4absmax(x1[u]));
-    }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    return f16_row_scale(m, inv);
-  };
-
-  float4 a0[4], a1[4];
-  int kw0 = 0, kw1 = 0, k00 = 0, k01 = 0;
-  EpiRegs epi;
-  issue(0, a0, kw0, k00);
-  if (nstages > 1) issue(1, a1, kw1, k01);
-  epi_prefetch(job, epi, rowbase, n0, j, g);
-  for (int s = 0; s < nstages; s += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // DMA of the resident stages has landed (this wave's part)
-    __syncthreads();                                      // ... and everybody else's
-    const bool two = s + 1 < nstages;
-    float inv = 0.f;
-    const float sc = row_scale(a0, a1, two, inv);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) accp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    compute(0, k00, kw0, a0, sc);                         // every wave: the transposed reads need EXEC all ones
-    if (two) compute(1, k01, kw1, a1, sc);
-    // fold the chunk into the total: accumulator register r is row 4g + r of the tile, whose scale lives in lanes j = 4g + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float ir = __shfl(inv, 4 * g + r);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t][r] = fmaf(accp[t][r], ir, acc[t][r]);
-    }
-    if (s + 2 < nstages) {
-      __syncthreads();                                    // both buffers consumed by every wave
-      issue(s + 2, a0, kw0, k00);
-      if (s + 3 < nstages) issue(s + 3, a1, kw1, k01);
-    }
-  }
-  if (!wave_on) return;
-  epi_apply(job, epi, acc, rowbase, n0, j, g);
-}
-
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBatch batch, DropCfg drop) {
-  extern __shared__ float lds[];     // Ws[2][GB_STAGE]
-  gemm_bf16_body<2>(batch.j[blockIdx.z], drop, reinterpret_cast<char*>(lds));
-}
-
-// The same kernel under its own symbol for the deep-K launch of a step - video_conv1d (+ query_conv1d), model.py:42,48: the
-// FEATURE-LOAD phase that streams the [B,T,vdim] clip features from HBM - so that rocprofv3 and bench.py's per-kernel
-// table show that phase separately from the 128-deep layers.
-__global__ __launch_bounds__(256) void feature_load_gemm_kernel(GemmBatch batch, DropCfg drop) {
-  extern __shared__ float lds[];
-  gemm_bf16_body<2>(batch.j[blockIdx.z], drop, reinterpret_cast<char*>(lds));
-}
+#define GB_COLBLOCK (128 * 512)          // bytes between the images of consecutive 128-column blocks of a transposed weight
 
 // ------------------------------------------------------------------------------------------------------
 // Feature-load kernel: partial products of video_conv1d (model.py:47-48), Y_q[rows, 128] = dropout(video)[rows, Kq] . W[Kq, :]
@@ -401,6 +55,7 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
   const int arow = min(rowbase + j, M - 1);
   const bool adrop = job.drop_site >= 0 && drop.enabled;
   const uint32_t adrow = job.drop_row0 + (uint32_t)arow;
+  const DropRegs drk = drop_load(drop);
   const int nst = KS / 64;
   // the block's weight quarter: rows q*KS .. of the forward image (clamped to the last real row: the operand is zero
   // there), 32 one-KB pieces per stage
@@ -447,18 +102,13 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
     float4 f0 = f4zero(), f1 = f4zero();
     if (ks + 2 < nks) a_fetch(ks + 2, f0, f1);       // two k-steps ahead
     if (adrop) {
-      const uint32_t cg = (uint32_t)((q * KS + 32 * ks + 8 * g) >> 2);
-      if (job.keep_out) {                             // block-uniform: the bits go to the weight-gradient job (DwJob::a_keep)
-        const uint32_t b0 = drop_bits4(drop, (uint32_t)job.drop_site, adrow, cg);
-        const uint32_t b1 = drop_bits4(drop, (uint32_t)job.drop_site, adrow, cg + 1u);
-        c0 = f4mul(c0, mask_from_bits4(b0, drop.scale));
-        c1 = f4mul(c1, mask_from_bits4(b1, drop.scale));
-        if (rowbase + j < M && (int)(4u * cg) < K)
-          *reinterpret_cast<uint16_t*>(job.keep_out + (size_t)arow * job.ld_keep + cg) = (uint16_t)(b0 | (b1 << 8));
-      } else {
-        c0 = apply_drop4(drop, (uint32_t)job.drop_site, adrow, cg, c0);
-        c1 = apply_drop4(drop, (uint32_t)job.drop_site, adrow, cg + 1u, c1);
-      }
+      // the lane's 8 consecutive features are ONE call of the 16-bit decision scheme (tilecore.h drop_bits8_r, oracle/philox.py
+      // mask16); the keep byte goes to the bit plane the weight-gradient job reads (DwJob::a_keep)
+      const uint32_t c8 = (uint32_t)((q * KS + 32 * ks + 8 * g) >> 3);
+      const uint32_t b = drop_bits8_r(drk, (uint32_t)job.drop_site, adrow, c8);
+      c0 = f4mul(c0, mask_from_bits4(b & 15u, drop.scale));
+      c1 = f4mul(c1, mask_from_bits4(b >> 4, drop.scale));
+      if (job.keep_out && rowbase + j < M && (int)(8u * c8) < K) job.keep_out[(size_t)arow * job.ld_keep + c8] = (uint8_t)b;
     }
     // f16x3 (bf16x3.h): the row scale is taken per 32-deep k-step (the features of a row arrive over the whole loop)
     float rmax = fmaxf(f4absmax(c0), f4absmax(c1));
@@ -666,7 +316,7 @@ __device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, c
   struct Stage { float4 a[DWB_RU], y[DWB_RU], a2[MODE == DWB_PROD ? DWB_RU : 1]; uint32_t keep[DWB_RU]; };
   const uint32_t a2off = ((uint32_t)srow * (uint32_t)lda2 + (uint32_t)kcol) * 4u;
   const uint8_t* keepp = MODE == DWB_DROP ? job.a_keep : nullptr;
-  const uint32_t koff = (uint32_t)srow * (uint32_t)job.ld_keep + (uint32_t)(kcol >> 2);
+  const uint32_t koff = (uint32_t)srow * (uint32_t)job.ld_keep + (uint32_t)(kcol >> 3);      // bit plane: one byte per 8 columns
   Stage st[DEPTH - 1];      // tile i in LDS, tiles i+1 .. i+DEPTH-1 in (or on their way to) registers
   auto stage_load = [&](int mt, Stage& st) {
     const char* Ab = Ap + (size_t)mt * lda * esz;
@@ -710,8 +360,7 @@ __device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, c
         }
         if (MODE == DWB_PROD && A2p && live) a = f4mul(a, st.a2[u]);
         if (adrop && live) {
-          if (keepp) a = f4mul(a, mask_from_bits4(st.keep[u], drop.scale));
-          else a = apply_drop4(drop, asite, arow0 + (uint32_t)m, (uint32_t)(kcol >> 2), a);
+          a = f4mul(a, mask_from_bits4((st.keep[u] >> (4 * (c4 & 1))) & 15u, drop.scale));
         }
       }
       uint2 hi, lo;
@@ -901,42 +550,6 @@ void dw_bf16_balanced_kernel(const DwJob* __restrict__ table, int n, DropCfg dro
 
 namespace hual {
 
-int launch_gemm(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream) {
-  HUAL_REQUIRE(n >= 1 && n <= HUAL_MAX_JOBS, "launch_gemm: job count");
-  GemmBatch b;
-  int maxM = 0, maxN = 0;
-  double flops = 0.0, bytes = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const GemmJob& j = jobs[i];
-    HUAL_REQUIRE(j.M > 0 && j.N >= 4 && (j.N % 4) == 0, "launch_gemm: N must be a positive multiple of 4");
-    HUAL_REQUIRE(j.npieces >= 1 && j.npieces <= HUAL_MAX_PIECES, "launch_gemm: pieces");
-    double kt = 0.0;
-    for (int p = 0; p < j.npieces; ++p) {
-      HUAL_REQUIRE(j.kw[p] > 0 && (j.kw[p] % 16) == 0, "launch_gemm: piece width must be a multiple of 16");
-      HUAL_REQUIRE(j.A[p] && j.W[p], "launch_gemm: null operand");
-      HUAL_REQUIRE((j.lda[p] % 4) == 0 && (j.ldw % 4) == 0, "launch_gemm: leading dims must be multiples of 4");
-      kt += j.kw[p];
-    }
-    HUAL_REQUIRE(j.Y != nullptr, "launch_gemm: null output");
-    HUAL_REQUIRE(j.add_div >= 1, "launch_gemm: add_div");
-    b.j[i] = j;
-    maxM = j.M > maxM ? j.M : maxM;
-    maxN = j.N > maxN ? j.N : maxN;
-    flops += 2.0 * j.M * kt * j.N;
-    bytes += 4.0 * ((double)j.M * kt + kt * j.N + (double)j.M * j.N);
-  }
-  HUAL_DYN_LDS(gemm_lds_kernel<2>, 160 * 1024);
-  HUAL_DYN_LDS(gemm_lds_kernel<3>, 160 * 1024);
-  const size_t lds = (size_t)2 * GL_STAGE * sizeof(float);
-  const int ncol = cdiv(maxN, 128);
-  const int rt = (cdiv(maxM, 32) * ncol * n > 256 && maxM > 48) ? 3 : 2;      // taller blocks once there is > 1 block per CU
-  const dim3 g(cdiv(maxM, 16 * rt), ncol, n), blk(128 * rt);
-  if (rt == 3) HUAL_LAUNCH(flops, bytes, gemm_lds_kernel<3>, g, blk, lds, stream, b, drop);
-  else HUAL_LAUNCH(flops, bytes, gemm_lds_kernel<2>, g, blk, lds, stream, b, drop);
-  HUAL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
                         hipStream_t stream, const PackExtra* extra) {
   HUAL_REQUIRE(!extra || (extra->lens && extra->word_ids && extra->rowmask && extra->loss_acc && (extra->zero_n % 4) == 0 &&
@@ -961,43 +574,6 @@ int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* bof
     HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(gx, cnt + (with_extra ? 1 + grows : 0)),
                 dim3(256), 0, stream, b, P, fwd, bwd, cnt, ex);
   }
-  HUAL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-// jobs whose W[p] already point at packed images (pack_weights_kernel); N multiple of 128 column blocks of the image
-int launch_gemm_bf16(const GemmJob* jobs, int n, const DropCfg& drop, hipStream_t stream) {
-  HUAL_REQUIRE(n >= 1 && n <= HUAL_MAX_JOBS, "launch_gemm_bf16: job count");
-  GemmBatch b;
-  int maxM = 0, maxN = 0, kmax = 0;
-  double flops = 0.0, bytes = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const GemmJob& j = jobs[i];
-    HUAL_REQUIRE(j.M > 0 && j.N >= 4 && (j.N % 4) == 0, "launch_gemm_bf16: N must be a positive multiple of 4");
-    HUAL_REQUIRE(j.npieces >= 1 && j.npieces <= HUAL_MAX_PIECES, "launch_gemm_bf16: pieces");
-    int kt = 0;
-    for (int p = 0; p < j.npieces; ++p) {
-      HUAL_REQUIRE(j.kw[p] > 0 && (j.kw[p] % 8) == 0, "launch_gemm_bf16: piece width must be a multiple of 8");
-      HUAL_REQUIRE(j.A[p] && j.W[p], "launch_gemm_bf16: null operand");
-      HUAL_REQUIRE((j.lda[p] % 4) == 0, "launch_gemm_bf16: leading dims must be multiples of 4");
-      kt += j.kw[p];
-    }
-    HUAL_REQUIRE(j.Y != nullptr && j.add_div >= 1, "launch_gemm_bf16: output");
-    b.j[i] = j;
-    maxM = j.M > maxM ? j.M : maxM;
-    maxN = j.N > maxN ? j.N : maxN;
-    kmax = kt > kmax ? kt : kmax;
-    flops += 2.0 * j.M * (double)kt * j.N;
-    bytes += 4.0 * ((double)j.M * kt + (double)kt * j.N + (double)j.M * j.N);
-  }
-  HUAL_DYN_LDS(gemm_bf16_kernel, 160 * 1024);
-  HUAL_DYN_LDS(feature_load_gemm_kernel, 160 * 1024);
-  const size_t lds = (size_t)2 * GB_STAGE;
-  // 32-row blocks (4 waves, one per SIMD): measured best both for the 128-deep launches left outside the fused kernels and for
-  // the deep-K generic feature-load launch, which is bound by per-wave VALU / MFMA work
-  const dim3 g(cdiv(maxM, 32), cdiv(maxN, 128), n), blk(256);
-  if (kmax >= 768) HUAL_LAUNCH(flops, bytes, feature_load_gemm_kernel, g, blk, lds, stream, b, drop);
-  else HUAL_LAUNCH(flops, bytes, gemm_bf16_kernel, g, blk, lds, stream, b, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -11,6 +11,7 @@
 #include "embed.h"
 #include "gemm.h"
 #include "heads.h"
+#include "mproj.h"
 #include "optim.h"
 #include "params.h"
 #include "rowops.h"
@@ -54,6 +55,7 @@ struct Ctx {
   bool static_tables = false;   // hual_run_opts.static_tables
   int wall_K = 0; uint32_t wall_off = 0, wall_boff = 0;      // packed char-CNN filter bank inside PKF / PKB (setup_ctx)
   struct DenseW { size_t off; int K; size_t boff; };
+  typedef DenseW DenseW_t;
   std::vector<DenseW> dense;          // every [K,128] weight of the graph, sorted by offset
   char* PKF = nullptr;                // pre-split images (gemm.h launch_pack_weights): forward ...
   char* PKB = nullptr;                // ... and of the transposed weights, for dX
@@ -76,11 +78,7 @@ struct Ctx {
   bool debug_taps = false;    // hual_run_opts.debug_taps: also write the tensors only parity tests read (conv_block relu outputs)
   float* actv(const std::string& name) { return buf(name, (size_t)rs.Nv, HUAL_D); }   // [Nv,128]
   float* vec(const std::string& name) { return buf(name, (size_t)rs.R, 1); }
-  // dX jobs name the transposed weight by an address inside a range ("params.T") that mirrors the flat parameters and is
-  // never read or written: packed_ptr() maps it to the image of the transposed weight in PKB
-  const float* PT = nullptr;
   const float* p(size_t off) const { return P + off; }
-  const float* pt(size_t off) const { return PT + off; }
   float* g(size_t off) const { return G + off; }
   bool ok() const { return rc == 0; }
   void chk(int r) { if (rc == 0 && r != 0) rc = r; }
@@ -96,54 +94,6 @@ struct Ctx {
   void push_dw(const DwJob& j) { if (active) dwjobs.push_back(j); }
 
   // ---- launch wrappers (skipped in the dry pass) ----
-  const DenseW* find_dense(size_t x) const {      // the weight whose [off, off + K*128) holds float offset x
-    size_t lo = 0, hi = dense.size();
-    while (lo < hi) {
-      const size_t mid = (lo + hi) / 2;
-      if (dense[mid].off <= x) lo = mid + 1; else hi = mid;
-    }
-    if (lo == 0) return nullptr;
-    const DenseW& d = dense[lo - 1];
-    return x < d.off + (size_t)d.K * HUAL_D ? &d : nullptr;
-  }
-  // W pointer of a job piece -> pointer into the pre-split images, or null when the piece cannot take the bf16 kernel
-  const float* packed_ptr(const float* w, int ldw, int N) const {
-    if (w >= P && w < P + pm.total) {                       // forward use: rows k0.. of a [K,128] weight
-      const size_t x = (size_t)(w - P);
-      const DenseW* d = find_dense(x);
-      if (!d || ldw != HUAL_D || N != HUAL_D || ((x - d->off) % HUAL_D) != 0) return nullptr;
-      return reinterpret_cast<const float*>(PKF + x * 4);
-    }
-    if (PT && w >= PT && w < PT + pm.total) {               // dX: the transposed copy [128, K], column block col0
-      const size_t x = (size_t)(w - PT);
-      const DenseW* d = find_dense(x);
-      if (!d) return nullptr;
-      const size_t col0 = x - d->off;
-      if (col0 >= (size_t)d->K || (col0 % 128) != 0 || ldw != d->K || (size_t)N > (size_t)((d->K + 127) & ~127) - col0) return nullptr;
-      return reinterpret_cast<const float*>(PKB + d->boff + (col0 / 128) * HUAL_PACK_BLOCK_BYTES);
-    }
-    return nullptr;
-  }
-  bool to_packed(GemmJob& j) const {
-    for (int p = 0; p < j.npieces; ++p) {
-      if (j.kw[p] % 8) return false;
-      const float* w = packed_ptr(j.W[p], j.ldw, j.N);
-      if (!w) return false;
-      j.W[p] = w;
-    }
-    return true;
-  }
-  // up to HUAL_MAX_JOBS dense jobs as one launch of the split kernel on the pre-split weight images
-  void gemm(const GemmJob* j, int n) {
-    if (!live()) return;
-    GemmJob pk[HUAL_MAX_JOBS];
-    for (int i = 0; i < n; ++i) {
-      pk[i] = j[i];
-      if (!to_packed(pk[i])) { chk(fail(HUAL_ERR_INVALID, "internal: dense job without a pre-split weight image")); return; }
-    }
-    chk(launch_gemm_bf16(pk, n, drop, stream));
-  }
-  void ln_fwd(const LnFwd& a, const RowSpace& r) { if (live()) chk(launch_ln_fwd(a, r, drop, stream)); }
   // layer-norm backward; the per-block dgamma / dbeta sums go to scratch and are folded in by flush_colsum()
   void ln_bwd(const LnBwd& a0) {
     LnBwd a = a0;
@@ -192,24 +142,6 @@ struct Ctx {
   }
 };
 
-GemmJob mkjob(const float* A, int lda, int M, int K, const float* W, const float* bias, float* Y, int ldy, int N = HUAL_D) {
-  GemmJob j;
-  gemm_job_init(j);
-  j.npieces = 1;
-  j.A[0] = A; j.lda[0] = lda; j.kw[0] = K; j.W[0] = W; j.ldw = N; j.bias = bias;
-  j.M = M; j.N = N; j.Y = Y; j.ldy = ldy;
-  return j;
-}
-// dX[M,K] = dY[M,N] . W^T through the transposed copy WT[N, Ktot] (row stride ldwt = rows of the original weight);
-// WT points at column 0 of the K block wanted.
-GemmJob mkjob_dx(const float* dY, int lddy, int M, int N, const float* WT, int ldwt, float* dX, int lddx, int K = HUAL_D) {
-  GemmJob j;
-  gemm_job_init(j);
-  j.npieces = 1;
-  j.A[0] = dY; j.lda[0] = lddy; j.kw[0] = N; j.W[0] = WT; j.ldw = ldwt;
-  j.M = M; j.N = K; j.Y = dX; j.ldy = lddx;
-  return j;
-}
 void set_embed_scratch(EmbedArgs& ea, float* base, int Nq, int C, int char_dim) {
   const EmbedLayout el = embed_layout(Nq, C, char_dim);
   ea.cemb = base + el.cemb; ea.ball = base + el.ball;
@@ -243,11 +175,24 @@ DwJob mkdw(const float* A, int lda, int K, const float* dY, int ldy, int M, floa
   return j;
 }
 
-// feature-load path of the two input projections: the K-split kernel (gemm.h launch_feature_ksplit) when the shapes allow
-// (weight quarter resident in LDS: vdim a multiple of 256, <= 1024), else the generic dense launch
-int feature_qks(int catw) { return ((catw + 3) / 4 + 63) & ~63; }      // quarter size of query_conv1d's K (multiple of 64)
-bool feature_ksplit_ok(const Ctx& c, int catw) {
-  return (c.cfg->vdim % 256) == 0 && c.cfg->vdim <= 1024 && (catw % 8) == 0 && feature_qks(catw) <= 256;
+// ---- steps of the multi-step dense kernel (mproj.h)
+// one 128-deep (or shorter) operand block A[rows, kw] times the image `img` (wrows valid K rows)
+MProjStep mstep(const float* A, int lda, int kw, const float* img, int wrows, bool first, bool last) {
+  MProjStep s{};
+  s.A = A; s.lda = lda; s.kw = kw; s.wimg = img; s.wrows = wrows; s.first = first ? 1 : 0; s.last = last ? 1 : 0;
+  s.drop_site = -1; s.rep = 1; s.add_div = 1; s.ncol = HUAL_D;
+  return s;
+}
+MProjStep mstep_reuse(const float* img, int wrows, bool first, bool last) {
+  MProjStep s = mstep(nullptr, 0, 0, img, wrows, first, last);
+  s.reuse = 1;
+  return s;
+}
+void mstep_out(MProjStep& s, float* out, int ldo, const float* bias = nullptr, int ncol = HUAL_D) { s.out = out; s.ldo = ldo; s.bias = bias; s.ncol = ncol; }
+MProjArgs margs(int R, int R_other = 0) {      // R_other: rows of the problem launched beside this one
+  MProjArgs a{};
+  a.R = R; a.MT = mproj_rows(R, R_other); a.drop_row0 = 0;
+  return a;
 }
 
 // Launch every weight-gradient job of the step as ONE persistent launch (gemm.h launch_dw): long-row jobs first, so that the
@@ -395,7 +340,6 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   // the split kernels (weights are constant within a step) and - hual_run_opts.grads_prezero - the gradient buffer zeroed: ONE launch
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
   c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
-  c.PT = c.buf("params.T", pm.total, 1);
   float* ortho_dE = c.buf("ortho.dE", 4, HUAL_D);
   // (the text encoder's gather - word / char lookups with their dropout, model.py:36-41 - rides in the same launch)
   float* cat = c.buf("cat", Nq, catw);
@@ -425,46 +369,59 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   if (c.live()) c.chk(launch_embed_fwd(ea, Nq, c.drop, c.stream));      // char CNN on the gathered embeddings
   // ---------------- the two input projections (model.py:42,48) as one launch; LN + pos (model.py:43,49,53,56)
   float* lin = c.act("lin");
-  // feature-load path: K-split kernel with LDS-resident weight quarters (gemm.h launch_feature_ksplit); its four partial
-  // slabs are summed by the layer-norm launch.  HUAL_FEATURE_KSPLIT=0 or an unsupported vdim: the generic dense launch.
-  const int qks = feature_qks(catw);
-  const bool ksplit = feature_ksplit_ok(c, catw);
+  // feature-load phase (video_conv1d / query_conv1d + v / q layer norm + position embeddings).  Two paths:
+  //   * K-split kernel (gemm.h launch_feature_ksplit) when the weight quarters fit LDS (vdim a multiple of 256, <= 1024): four
+  //     K-quarter partial slabs, summed by the layer-norm launch behind it - the faster one (34 vs 45 us at the bench shape);
+  //   * any other width: K / 128 weight steps per workgroup of rows with the layer norm in the row phase behind the last step
+  //     (mproj.h): ONE launch, one slab.
+  // The keep bytes of the clip-feature dropout (bit plane, one byte per 8 features) go to the weight-gradient job of video_conv1d.
+  uint8_t* vkeep = reinterpret_cast<uint8_t*>(c.buf("video.keep", (size_t)Nv, (size_t)(c.cfg->vdim + 31) / 32));
+  float* x = c.act("cb.x0");
+  float* lin_mean = c.vec("lin.mean");
+  float* lin_rstd = c.vec("lin.rstd");
+  const int qks = ((catw + 3) / 4 + 63) & ~63;        // quarter size of query_conv1d's K (multiple of 64)
+  const bool ksplit = (c.cfg->vdim % 256) == 0 && c.cfg->vdim <= 1024 && (catw % 8) == 0 && qks <= 256;
   float* vpart = c.buf("lin.part", (size_t)4 * R, D);
-  // keep bits of the clip-feature dropout, one byte per 4 features: the weight-gradient job of video_conv1d reads them
-  // instead of repeating the Philox rounds for all B*T*vdim elements
-  uint8_t* vkeep = reinterpret_cast<uint8_t*>(c.buf("video.keep", (size_t)Nv, (size_t)(c.cfg->vdim + 15) / 16));
   if (ksplit) {
     if (c.live()) {
       FkJob fj[2];
       fj[0] = FkJob{reinterpret_cast<const float*>(bt->video), c.cfg->vdim, Nv, c.cfg->vdim, c.cfg->vdim / 4,
                     reinterpret_cast<const float*>(c.PKF + pm.vconv.k * 4), vpart, (size_t)R * D, HUAL_SITE_VIDEO, 0,
-                    bt->video_dtype == HUAL_DTYPE_BF16 ? 1 : 0, c.want_bwd ? vkeep : nullptr, c.cfg->vdim / 4};
+                    bt->video_dtype == HUAL_DTYPE_BF16 ? 1 : 0, c.want_bwd ? vkeep : nullptr, (c.cfg->vdim + 7) / 8};
       fj[1] = FkJob{cat, catw, Nq, catw, qks, reinterpret_cast<const float*>(c.PKF + pm.qconv.k * 4),
                     vpart + (size_t)Nv * D, (size_t)R * D, -1, 0, 0, nullptr, 0};
       c.chk(launch_feature_ksplit(fj, 2, c.drop, c.stream));
-    }
-  } else {
-    if (c.live() && bt->video_dtype != HUAL_DTYPE_F32) return fail(HUAL_ERR_UNSUPPORTED, "bfloat16 video features need the K-split feature-load kernel (vdim % 256 == 0, vdim <= 1024)");
-    GemmJob j[2];
-    j[0] = mkjob(c.dry ? nullptr : reinterpret_cast<const float*>(bt->video), c.cfg->vdim, Nv, c.cfg->vdim, c.p(pm.vconv.k), c.p(pm.vconv.b), lin, D);
-    j[0].a_drop_site = HUAL_SITE_VIDEO; j[0].a_drop_row0 = 0;
-    j[1] = mkjob(cat, catw, Nq, catw, c.p(pm.qconv.k), c.p(pm.qconv.b), lin + (size_t)Nv * D, D);
-    c.gemm(j, 2);
-  }
-  float* x = c.act("cb.x0");
-  float* lin_mean = c.vec("lin.mean");
-  float* lin_rstd = c.vec("lin.rstd");
-  {
-    // v_layer_norm on the video rows, q_layer_norm on the query rows (+ position embeddings): one launch over the unified rows
-    LnFwd a{};
-    a.x = lin; a.R = R; a.g1 = c.p(pm.vln.g); a.b1 = c.p(pm.vln.b); a.y1 = x; a.mean = lin_mean; a.rstd = lin_rstd;
-    a.pos = c.p(pm.pos); a.row0 = 0;
-    a.split = Nv; a.g1_hi = c.p(pm.qln.g); a.b1_hi = c.p(pm.qln.b);
-    if (ksplit) {
+      // v_layer_norm on the video rows, q_layer_norm on the query rows (+ position embeddings): one launch over the unified rows
+      LnFwd a{};
+      a.R = R; a.g1 = c.p(pm.vln.g); a.b1 = c.p(pm.vln.b); a.y1 = x; a.mean = lin_mean; a.rstd = lin_rstd;
+      a.pos = c.p(pm.pos); a.row0 = 0;
+      a.split = Nv; a.g1_hi = c.p(pm.qln.g); a.b1_hi = c.p(pm.qln.b);
       a.x = nullptr; a.part = vpart; a.nparts = 4; a.part_stride = (size_t)R * D; a.part_bias = c.p(pm.vconv.b);
       a.part_bias_hi = c.p(pm.qconv.b); a.x_out = lin;
+      if (c.ok()) c.chk(launch_ln_fwd(a, rs, c.drop, c.stream));
     }
-    c.ln_fwd(a, rs);
+  } else
+  if (c.live()) {
+    const int V = c.cfg->vdim;
+    MProjArgs pr[2];
+    pr[0] = margs(Nv, Nq);
+    pr[0].nsteps = 1;
+    pr[0].s[0] = mstep(reinterpret_cast<const float*>(bt->video), V, std::min(V, 128), reinterpret_cast<const float*>(c.PKF + pm.vconv.k * 4), V, true, true);
+    pr[0].s[0].a_bf16 = bt->video_dtype == HUAL_DTYPE_BF16 ? 1 : 0;
+    pr[0].s[0].rep = cdiv(V, 128); pr[0].s[0].ktot = V;
+    pr[0].s[0].drop_site = HUAL_SITE_VIDEO; pr[0].s[0].col0 = 0;
+    pr[0].s[0].keep_out = c.want_bwd ? vkeep : nullptr; pr[0].s[0].ld_keep = (V + 7) / 8;
+    pr[0].s[0].bias = c.p(pm.vconv.b);
+    pr[0].ln_g = c.p(pm.vln.g); pr[0].ln_b = c.p(pm.vln.b); pr[0].pos = c.p(pm.pos); pr[0].row_in_clip0 = 0; pr[0].Tc = T;
+    pr[0].x_out = lin; pr[0].y_out = x; pr[0].mean = lin_mean; pr[0].rstd = lin_rstd;
+    pr[1] = margs(Nq, Nv);
+    pr[1].nsteps = 1;
+    pr[1].s[0] = mstep(cat, catw, std::min(catw, 128), reinterpret_cast<const float*>(c.PKF + pm.qconv.k * 4), catw, true, true);
+    pr[1].s[0].rep = cdiv(catw, 128); pr[1].s[0].ktot = catw;
+    pr[1].s[0].bias = c.p(pm.qconv.b);
+    pr[1].ln_g = c.p(pm.qln.g); pr[1].ln_b = c.p(pm.qln.b); pr[1].pos = c.p(pm.pos); pr[1].row_in_clip0 = 0; pr[1].Tc = L;
+    pr[1].x_out = lin + (size_t)Nv * D; pr[1].y_out = x + (size_t)Nv * D; pr[1].mean = lin_mean + Nv; pr[1].rstd = lin_rstd + Nv;
+    c.chk(launch_mproj(pr, 2, c.drop, c.stream));
   }
   // ---------------- shared conv block (model.py:54-58)
   c.stage(ST_CONV);
@@ -564,21 +521,22 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   if (c.live()) c.chk(launch_tri_prep(cq, cqp, c.rs, c.drop, c.stream));
   if (c.live()) c.chk(launch_cq_fwd(cq, c.rs, c.stream));
   float* cqf = c.act("cq.feats");      // q2v_feats (video rows) | v2q_feats (query rows)
-  {
-    GemmJob j[2];
-    for (int s = 0; s < 2; ++s) {
-      const size_t ro = s == 0 ? 0 : (size_t)Nv * D;
-      const float* W = c.p(pm.cq[s].dense);
-      j[s] = mkjob(x + ro, D, s == 0 ? Nv : Nq, D, W, nullptr, cqf + ro, D);
-      j[s].npieces = 4;
+  if (c.live()) {      // dense over [x, c2q, x * c2q, x * q2c] (layers.py:127-130): four weight steps per direction, one launch
+    MProjArgs pr[2];
+    for (int sd = 0; sd < 2; ++sd) {
+      const size_t ro = sd == 0 ? 0 : (size_t)Nv * D;
+      const char* img = c.PKF + pm.cq[sd].dense * 4;
+      pr[sd] = margs(sd == 0 ? Nv : Nq, sd == 0 ? Nq : Nv);
+      pr[sd].nsteps = 4;
       const float* a1[4] = {x + ro, cq.C2Q + ro, x + ro, x + ro};
       const float* a2[4] = {nullptr, nullptr, cq.C2Q + ro, cq.Q2C + ro};
       for (int p = 0; p < 4; ++p) {
-        j[s].A[p] = a1[p]; j[s].A2[p] = a2[p]; j[s].lda[p] = D; j[s].lda2[p] = D; j[s].kw[p] = D;
-        j[s].W[p] = W + (size_t)p * D * D;
+        pr[sd].s[p] = mstep(a1[p], D, D, reinterpret_cast<const float*>(img + (size_t)p * D * 512), D, p == 0, p == 3);
+        pr[sd].s[p].A2 = a2[p]; pr[sd].s[p].lda2 = D;
       }
+      mstep_out(pr[sd].s[3], cqf + ro, D);
     }
-    c.gemm(j, 2);
+    c.chk(launch_mproj(pr, 2, c.drop, c.stream));
   }
   // ---------------- cq_concat (layers.py:145-154)
   c.stage(ST_FUSE);
@@ -592,10 +550,13 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   ap.that = c.buf("align.that", B, D); ap.vhat = c.buf("align.vhat", B, D);
   if (c.live()) c.chk(launch_pool_align_fwd(pa, lab ? &ap : nullptr, c.rs, c.stream));
   float* fuse = c.actv("fuse");
-  {
-    GemmJob j = mkjob(cqf, D, Nv, D, c.p(pm.cqcat.k), c.p(pm.cqcat.b), fuse, D);
-    j.add = pa.PW; j.ldadd = D; j.add_div = T;
-    c.gemm(&j, 1);
+  if (c.live()) {      // fuse = q2v_feats . W_top + b + (pooled . W_bot)[clip]   (layers.py:150-153)
+    MProjArgs pr = margs(Nv);
+    pr.nsteps = 1;
+    pr.s[0] = mstep(cqf, D, D, reinterpret_cast<const float*>(c.PKF + pm.cqcat.k * 4), D, true, true);
+    mstep_out(pr.s[0], fuse, D, c.p(pm.cqcat.b));
+    pr.s[0].add = pa.PW; pr.s[0].ldadd = D; pr.s[0].add_div = T;
+    c.chk(launch_mproj(&pr, 1, c.drop, c.stream));
   }
   // ---------------- matching head + label embeddings (model.py:82-97)
   float* outputs = c.actv("outputs");
@@ -739,9 +700,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   //  memsets on this ROCm - every 4th gradient came back as the caller's learning rate)
   if (c.live() && !(opt->grads_prezero && opt->grads_prezero == c.G && c.sel_stage < 0))
     c.chk(launch_zero(c.G, pm.total, c.stream));
-  // every dX product reads the image of the transposed weight that forward's pack launch left in the workspace (PKB);
-  // "params.T" is only the address range that names those weights (Ctx::PT)
-  c.PT = c.buf("params.T", pm.total, 1);
+  // every dX product reads the image of the transposed weight that forward's pack launch left in the workspace (PKB)
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
   c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
   float* outputs = c.actv("outputs");
@@ -783,13 +742,15 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* d_sfn = c.actv("d.head.sfn");
   float* d_efn = c.actv("d.head.efn");
   float* d_out_heads = c.actv("d.outputs.heads");
-  {
-    GemmJob j[3];
-    j[0] = mkjob_dx(dz_hs, D, Nv, D, c.pt(pm.shid.k), 2 * D, d_sfn, D);
-    j[1] = mkjob_dx(dz_he, D, Nv, D, c.pt(pm.ehid.k), 2 * D, d_efn, D);
-    j[2] = mkjob_dx(dz_hs, D, Nv, D, c.pt(pm.shid.k) + D, 2 * D, d_out_heads, D);
-    j[2].npieces = 2; j[2].A[1] = dz_he; j[2].lda[1] = D; j[2].kw[1] = D; j[2].W[1] = c.pt(pm.ehid.k) + D;
-    c.gemm(j, 3);
+  if (c.live()) {      // the two hidden layers backward: d sfn, d efn and the part of d outputs that came through them - four weight steps
+    auto imgt = [&](size_t off, int blk) { return reinterpret_cast<const float*>(c.PKB + off * 4 + (size_t)blk * HUAL_PACK_BLOCK_BYTES); };
+    MProjArgs pr = margs(Nv);
+    pr.nsteps = 4;
+    pr.s[0] = mstep(dz_hs, D, D, imgt(pm.shid.k, 0), D, true, true);      mstep_out(pr.s[0], d_sfn, D);
+    pr.s[1] = mstep_reuse(imgt(pm.shid.k, 1), D, true, false);
+    pr.s[2] = mstep(dz_he, D, D, imgt(pm.ehid.k, 1), D, false, true);     mstep_out(pr.s[2], d_out_heads, D);
+    pr.s[3] = mstep_reuse(imgt(pm.ehid.k, 0), D, true, true);             mstep_out(pr.s[3], d_efn, D);
+    c.chk(launch_mproj(&pr, 1, c.drop, c.stream));
   }
   // ---------------- feature encoders, pass 1 then pass 0
   float* d_feout = c.actv("d.fe1.out");
@@ -902,9 +863,12 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* cqf = c.act("cq.feats");
   float* d_cqf = c.act("d.cq.feats");
   c.push_dw(mkdw(cqf, D, D, d_fuse, D, Nv, c.g(pm.cqcat.k), c.g(pm.cqcat.b)));
-  {
-    GemmJob j = mkjob_dx(d_fuse, D, Nv, D, c.pt(pm.cqcat.k), 2 * D, d_cqf, D);
-    c.gemm(&j, 1);
+  if (c.live()) {
+    MProjArgs pr = margs(Nv);
+    pr.nsteps = 1;
+    pr.s[0] = mstep(d_fuse, D, D, reinterpret_cast<const float*>(c.PKB + pm.cqcat.k * 4), D, true, true);
+    mstep_out(pr.s[0], d_cqf, D);
+    c.chk(launch_mproj(&pr, 1, c.drop, c.stream));
   }
   AlignPool ap{};
   ap.F2 = cqf; ap.F1 = cqf; ap.inner = (c.dry || !lab) ? nullptr : lab->inner_labels;
@@ -950,11 +914,19 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.push_dw(j);
   }
   float* d_cat4 = c.buf("d.cq.cat", R, 4 * D);
-  {
-    GemmJob j[2];
-    j[0] = mkjob_dx(d_cqf, D, Nv, D, c.pt(pm.cq[0].dense), 4 * D, d_cat4, 4 * D, 4 * D);
-    j[1] = mkjob_dx(d_cqf + (size_t)Nv * D, D, Nq, D, c.pt(pm.cq[1].dense), 4 * D, d_cat4 + (size_t)Nv * 4 * D, 4 * D, 4 * D);
-    c.gemm(j, 2);
+  if (c.live()) {      // d [x, c2q, x * c2q, x * q2c] = d feats . W^T: four column blocks of one operand per direction, one launch
+    MProjArgs pr[2];
+    for (int sd = 0; sd < 2; ++sd) {
+      const size_t ro = sd == 0 ? 0 : (size_t)Nv;
+      pr[sd] = margs(sd == 0 ? Nv : Nq, sd == 0 ? Nq : Nv);
+      pr[sd].nsteps = 4;
+      for (int p = 0; p < 4; ++p) {
+        const float* img = reinterpret_cast<const float*>(c.PKB + pm.cq[sd].dense * 4 + (size_t)p * HUAL_PACK_BLOCK_BYTES);
+        pr[sd].s[p] = p == 0 ? mstep(d_cqf + ro * D, D, D, img, D, true, true) : mstep_reuse(img, D, true, true);
+        mstep_out(pr[sd].s[p], d_cat4 + ro * 4 * D + (size_t)p * D, 4 * D);
+      }
+    }
+    c.chk(launch_mproj(pr, 2, c.drop, c.stream));
   }
   CqBwdBufs cg{};
   cg.dCat = d_cat4; cg.ldcat = 4 * D;
@@ -1134,15 +1106,24 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     j.a_drop_site = HUAL_SITE_VIDEO; j.a_drop_row0 = 0;
     j.a_bf16 = (!c.dry && bt->video_dtype == HUAL_DTYPE_BF16) ? 1 : 0;
     // written by the K-split feature-load kernel
-    j.a_keep = feature_ksplit_ok(c, catw) ? reinterpret_cast<const uint8_t*>(c.buf("video.keep", 0, 0)) : nullptr;
-    j.ld_keep = c.cfg->vdim / 4;
+    j.a_keep = reinterpret_cast<const uint8_t*>(c.buf("video.keep", 0, 0));      // written by the feature-load launch
+    j.ld_keep = (c.cfg->vdim + 7) / 8;
     c.push_dw(j);
     c.push_dw(mkdw(cat, catw, catw, d_lin + (size_t)Nv * D, D, Nq, c.g(pm.qconv.k), c.g(pm.qconv.b)));
   }
   float* d_cat = c.buf("d.cat", Nq, catw);
-  {
-    GemmJob j = mkjob_dx(d_lin + (size_t)Nv * D, D, Nq, D, c.pt(pm.qconv.k), catw, d_cat, catw, catw);
-    c.gemm(&j, 1);
+  if (c.live()) {      // d cat = d lin[q rows] . W_q^T: ceil(catw / 128) column blocks of one operand
+    const Ctx::DenseW_t* dwq = nullptr;
+    for (const auto& d : c.dense) if (d.off == pm.qconv.k) dwq = &d;
+    HUAL_REQUIRE(dwq != nullptr && cdiv(catw, 128) <= MP_MAX, "internal: query_conv1d image");
+    MProjArgs pr = margs(Nq);
+    pr.nsteps = cdiv(catw, 128);
+    for (int p = 0; p < pr.nsteps; ++p) {
+      const float* img = reinterpret_cast<const float*>(c.PKB + dwq->boff + (size_t)p * HUAL_PACK_BLOCK_BYTES);
+      pr.s[p] = p == 0 ? mstep(d_lin + (size_t)Nv * D, D, D, img, D, true, true) : mstep_reuse(img, D, true, true);
+      mstep_out(pr.s[p], d_cat + (size_t)p * D, catw, nullptr, std::min(D, catw - p * D));
+    }
+    c.chk(launch_mproj(&pr, 1, c.drop, c.stream));
   }
   // ---------------- text encoder front end (embed.hip); its filter gradients ride in the weight-gradient launch
   int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));

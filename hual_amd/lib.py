@@ -110,7 +110,6 @@ def load():
     lib.hual_prof_get.argtypes = [i32, ctypes.c_char_p, i32, P(ctypes.c_int64), P(ctypes.c_double), P(ctypes.c_double),
                                   P(ctypes.c_double)]
     lib.hual_prof_kernel_pipe.argtypes = [ctypes.c_char_p, P(i32), P(i32)]
-    lib.hual_linear_fwd.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.hual_linear_bf16x3.argtypes = [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, u64, vp]
     lib.hual_layer_norm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     lib.hual_attention_fwd.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp]
@@ -187,15 +186,6 @@ def ws_table(cfg, B, T, L, C):
 
 
 # ---------------------------------------------------------------- per-kernel entry points
-def linear_fwd(A, W, bias=None, act=0, out=None):
-    import torch
-    M, K = A.shape
-    N = W.shape[1]
-    Y = torch.empty(M, N, device=A.device, dtype=torch.float32) if out is None else out
-    check(load().hual_linear_fwd(ptr(A), A.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(Y), Y.stride(0), M, K, N, act, stream_ptr()))
-    return Y
-
-
 def linear_bf16x3(A, W, bias=None, act=0, trans_w=False):
     """split-bf16 dense: W [K,128] (trans_w False) or [N,128] used transposed (dX)"""
     import torch

@@ -229,16 +229,10 @@ int hual_predictor_bwd(const hual_cfg* cfg, const float* params, const hual_batc
  * Per-kernel entry points (unit parity tests call these through ctypes).
  * ------------------------------------------------------------------------------------------ */
 
-/* conv1d(kernel_size=1) == dense  (models/layers.py:20-29):
- *   Y[M,N] = act(A[M,K] . W[K,N] + bias) in exact fp32 on the matrix cores (the kernel of the char-CNN product);
- *   act: 0 none, 1 relu, 2 sigmoid.  K % 16 == 0, N % 64 == 0, leading dims % 4 == 0.  (Products with a transposed
- *   weight - dX of a dense layer - go through hual_linear_bf16x3, as in the model path.) */
-int hual_linear_fwd(const float* A, int lda, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int K, int N,
-                    int act, void* stream);
-
-/* The same dense layer on the bf16 matrix cores with split operands (x = hi + lo, three MFMA passes, fp32 accumulate;
- * ~1e-6 relative to the fp32 product) - the kernel the model path uses for every [K,128] weight.
- *   trans_w = 0: Y[M,128] = act(A[M,K] . W[K,128] + bias), K % 8 == 0; scratch >= K * 512 bytes
+/* conv1d(kernel_size=1) == dense  (models/layers.py:20-29) on the 16-bit matrix cores with split operands (x = hi + lo, three
+ * MFMA passes, fp32 accumulate; ~1e-6 relative to the fp32 product) - the kernel the model path uses for the dense layers outside
+ * its fused kernels:
+ *   trans_w = 0: Y[M,128] = act(A[M,K] . W[K,128] + bias), K % 8 == 0, act: 0 none, 1 relu; scratch >= K * 512 bytes
  *   trans_w = 1: Y[M,N]   = A[M,128] . W^T with W stored [N,128] (dX of a dense layer), N % 8 == 0;
  *                scratch >= ceil(N/128) * 65536 bytes
  * scratch (device) receives the pre-split weight image. */

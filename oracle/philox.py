@@ -29,8 +29,8 @@ from the eight 16-bit halves of one call (hual_amd/csrc/tilecore.h drop_bits8_r)
 e = col & 7 uses word e >> 1, half e & 1 (little endian) and is KEPT iff half < t16, t16 = round(keep_prob * 65536) in
 [1, 65536] (= (thresh + 2**15) >> 16); kept elements are scaled by 1 / (1 - rate) exactly as tf.nn.dropout does.  The keep
 probability is t16 / 65536 (0.8000031 for rate 0.2 - closer to 1 - rate than the 2**-23 grid of TensorFlow's own float32
-uniform draw allows it to be).  The input sites (word / char embeddings, clip features) and the trilinear sites keep one
-decision per 32-bit word.
+uniform draw allows it to be).  The clip-feature site SITE_VIDEO (model.py:47) uses the same 16-bit decisions; the word /
+char embedding sites and the trilinear sites keep one decision per 32-bit word.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
@@ -92,8 +92,9 @@ def keep_threshold16(rate):
 
 
 def uses_16bit_decisions(site):
-    """row-local dropout sites of conv_block / dual_attn_block / feature_encoder (not the attention probabilities)"""
-    if SITE_CONV <= site < SITE_CONV + 4:
+    """the clip features + the row-local dropout sites of conv_block / dual_attn_block / feature_encoder (not the attention
+    probabilities)"""
+    if site == SITE_VIDEO or SITE_CONV <= site < SITE_CONV + 4:
         return True
     if SITE_DA <= site < SITE_TRI:
         return (site - SITE_DA) % 8 in (2, 3, 4)

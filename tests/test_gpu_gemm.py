@@ -22,25 +22,6 @@ def _ref(A, W, b, act):
     return y
 
 
-@pytest.mark.parametrize('M,K,N', [(16, 16, 64), (37, 128, 128), (1000, 400, 128), (2048, 1024, 128), (333, 128, 384),
-                                   (64, 256, 64), (9472, 128, 128)])
-@pytest.mark.parametrize('act', [0, 1, 2])
-def test_linear_fwd(dev, M, K, N, act):
-    from hual_amd import lib
-    g = torch.Generator(device='cpu').manual_seed(M * 7 + K + N + act)
-    A = torch.randn(M, K, generator=g).to(dev)
-    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(dev)
-    # asymmetric integer-valued check first: catches row/col swaps exactly
-    Ai = torch.randint(-3, 4, (M, K), generator=g).float().to(dev)
-    Wi = torch.randint(-3, 4, (K, N), generator=g).float().to(dev)
-    Yi = lib.linear_fwd(Ai, Wi)
-    assert torch.equal(Yi, Ai @ Wi)
-    b = torch.randn(N, generator=g).to(dev)
-    Y = lib.linear_fwd(A, W, b, act=act)
-    ref = _ref(A, W, b, act)
-    assert (Y.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
-
-
 # G: workgroups of the persistent weight-gradient launch of the training step (0 = one per CU)
 @pytest.mark.parametrize('M,K,N,G', [(64, 64, 128, 1), (37, 128, 128, 2), (1000, 400, 128, 7), (9472, 128, 128, 512),
                                      (4096, 1024, 128, 100), (513, 16, 128, 512), (33, 272, 128, 3), (9472, 128, 128, 0),
@@ -64,7 +45,7 @@ def test_linear_dw(dev, M, K, N, G):
 
 
 @pytest.mark.parametrize('M,K', [(16, 64), (37, 128), (1000, 400), (2048, 1024), (9472, 128), (100, 256), (48, 8)])
-@pytest.mark.parametrize('act', [0, 1, 2])
+@pytest.mark.parametrize('act', [0, 1])
 def test_linear_bf16x3_forward(dev, M, K, act):
     """split dense (three MFMA passes on fp16 hi/lo operands with per-row power-of-two scaling, bf16x3.h "f16x3"): exact
     on small integers, fp32-level accuracy on random data"""

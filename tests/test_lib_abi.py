@@ -27,7 +27,7 @@ def test_bad_arguments_fail_loudly_without_a_gpu():
     from hual_amd import lib
     import pytest
     l = lib.load()
-    rc = l.hual_linear_fwd(None, 0, None, 0, None, None, 0, 4, 16, 64, 0, None)
+    rc = l.hual_linear_bf16x3(None, 0, None, 0, None, None, 0, 4, 16, 128, 0, None, 0, None)
     assert rc != 0 and b'null pointer' in l.hual_last_error()
     with pytest.raises(lib.HualError):
         lib.check(rc)
