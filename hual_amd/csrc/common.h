@@ -40,6 +40,14 @@ int ensure_dyn_lds(const void* fn, int bytes);
     if (_rc) return _rc;                                                 \
   } while (0)
 
+// ---- XCD-aware order of row tiles / clips.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, each with
+// a private 4 MB L2, and what one kernel of a graph wrote is still in the writer's L2 when the next kernel starts (measured: a
+// 4.8 MB tensor re-read from the XCD that wrote it costs a launch floor, from another XCD 2.1 us more - scripts/exp/xcd_locality.hip).
+// Every kernel that owns rows or clips therefore hands XCD x the x-th contiguous eighth of its tiles (grids are rounded up to a
+// multiple of 8, tiles beyond the end return at once), the same eighth of the row space the attention kernels give it.
+__host__ __device__ inline int xcd_round8(int n) { return (n + 7) & ~7; }
+__device__ __forceinline__ int xcd_tile(int b, int nblk) { return (b & 7) * (nblk >> 3) + (b >> 3); }      // nblk: multiple of 8
+
 // ---- dropout parameters shared by every kernel (derived from drop_rate on the host) -----------
 // The Philox key/offset live in DEVICE memory (state[0]=seed lo, [1]=seed hi, [2]=offset) so that a captured
 // hipGraph can be replayed with a fresh offset every step without re-capturing.

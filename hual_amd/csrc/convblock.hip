@@ -36,7 +36,8 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;          // 16 groups of 32 lanes: one row = 32 x float4
   const int col = 4 * l32;
   const int R = rs.R;
-  const int r0 = blockIdx.x * MT;
+  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;      // XCD-aware tile order (common.h)
+  if (r0 >= rs.R) return;
   const int xbase = r0 - 12;                                 // global row of X[0]
 
   const DropRegs dr = drop_load(drop);
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int R = rs.R;
-  const int r0 = blockIdx.x * MT;
+  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;      // XCD-aware tile order (common.h)
+  if (r0 >= rs.R) return;
   const int xbase = r0 - 12;
   const int mt = wave >> 1, ch = wave & 1;
 
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int e = threadIdx.x + CB_THREADS * q;
-        if (e < 9 * HUAL_D) L.part[(size_t)blockIdx.x * 9 * HUAL_D + e] = pacc[q];
+        if (e < 9 * HUAL_D) L.part[(size_t)xcd_tile(blockIdx.x, gridDim.x) * 9 * HUAL_D + e] = pacc[q];
       }
     }
     HUAL_STAMP_K(3, 7 + 7 * (3 - i));
@@ -518,7 +520,7 @@ int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg&
   const double rows = (double)rs.R;
   // algorithmic work: 4 pointwise products; bytes: x0 in, (c, y, x) out per layer, weights
   HUAL_LAUNCH(4.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 13.0 + 4.0 * HUAL_D * HUAL_D), conv_block_fwd_kernel,
-              dim3(cdiv(rs.R, a.MT)), dim3(CB_THREADS), cb_fwd_lds(a.MT), s, a, rs, drop);
+              dim3(xcd_round8(cdiv(rs.R, a.MT))), dim3(CB_THREADS), cb_fwd_lds(a.MT), s, a, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -543,7 +545,7 @@ int launch_conv_block_bwd(const CbBwdArgs& a, const RowSpace& rs, const DropCfg&
   HUAL_DYN_LDS(conv_block_bwd_kernel, 160 * 1024);
   const double rows = (double)rs.R;
   HUAL_LAUNCH(4.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 14.0 + 4.0 * HUAL_D * HUAL_D), conv_block_bwd_kernel,
-              dim3(cdiv(rs.R, a.MT)), dim3(CB_THREADS), cb_bwd_lds(a.MT), s, a, rs, drop);
+              dim3(xcd_round8(cdiv(rs.R, a.MT))), dim3(CB_THREADS), cb_bwd_lds(a.MT), s, a, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

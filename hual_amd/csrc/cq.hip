@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void tri_prep_kernel(CqBufs b, CqParams p, Row
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpace rs) {
   extern __shared__ float lds[];
-  const int clip = blockIdx.x, dir = blockIdx.y;
+  const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
+  if (clip >= rs.B) return;
   const ClipGeom c = clip_geom(rs, clip, dir);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -279,7 +280,8 @@ __device__ __forceinline__ void cq_rows_store(const CqRows& r, float* bufA, int 
 
 __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b, RowSpace rs) {
   extern __shared__ float lds[];
-  const int clip = blockIdx.x, dir = blockIdx.y;
+  const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
+  if (clip >= rs.B) return;
   const ClipGeom c = clip_geom(rs, clip, dir);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -493,7 +495,8 @@ __global__ __launch_bounds__(256) void cq_bwd_pre_kernel(CqBufs b, CqBwdBufs gb,
 //   not possible (different dropout), so it is written to gb.dC2Q rows?  -> see below: uses dedicated slices.
 __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb) {
   extern __shared__ float lds[];
-  const int clip = blockIdx.x, dir = blockIdx.y;
+  const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
+  if (clip >= rs.B) return;
   const ClipGeom c = clip_geom(rs, clip, dir);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -625,7 +628,8 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
 // phase ahead (see cq_fwd_staged_kernel).   bufA (x1 rows): dC2Q, dQ2C, X1, D1W      bufB (x2 rows): X2, M2, dM2, D2
 __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb) {
   extern __shared__ float lds[];
-  const int clip = blockIdx.x, dir = blockIdx.y;
+  const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
+  if (clip >= rs.B) return;
   const ClipGeom c = clip_geom(rs, clip, dir);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -906,14 +910,14 @@ static bool cq_staged_ok(const RowSpace& rs, int nmats) {
 int launch_cq_fwd(const CqBufs& b, const RowSpace& rs, hipStream_t s) {
   if (cq_staged_ok(rs, 3)) {
     HUAL_DYN_LDS(cq_fwd_staged_kernel, 160 * 1024);
-    HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_staged_kernel, dim3(rs.B, 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 3), s, b, rs);
+    HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_staged_kernel, dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 3), s, b, rs);
     HUAL_CHECK_HIP(hipGetLastError());
     return 0;
   }
   const int bytes = cq_lds_bytes(rs, 3);
   HUAL_REQUIRE(bytes <= 160 * 1024, "cq_fwd: T x L score matrix does not fit LDS");
   HUAL_DYN_LDS(cq_fwd_kernel, 160 * 1024);
-  HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_kernel, dim3(rs.B, 2), dim3(cq_threads()), bytes, s, b, rs);
+  HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_kernel, dim3(xcd_round8(rs.B), 2), dim3(cq_threads()), bytes, s, b, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -930,14 +934,14 @@ int launch_cq_bwd_pre(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, h
 int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, float* dXa, float* dXb, hipStream_t s) {
   if (cq_staged_ok(rs, 4)) {
     HUAL_DYN_LDS(cq_bwd_staged_kernel, 160 * 1024);
-    HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_staged_kernel, dim3(rs.B, 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 4), s, b, g, rs, dXa, dXb);
+    HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_staged_kernel, dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 4), s, b, g, rs, dXa, dXb);
     HUAL_CHECK_HIP(hipGetLastError());
     return 0;
   }
   const int bytes = cq_lds_bytes(rs, 4);
   HUAL_REQUIRE(bytes <= 160 * 1024, "cq_bwd: T x L score matrix does not fit LDS");
   HUAL_DYN_LDS(cq_bwd_kernel, 160 * 1024);
-  HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_kernel, dim3(rs.B, 2), dim3(cq_threads()), bytes, s, b, g, rs, dXa, dXb);
+  HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_kernel, dim3(xcd_round8(rs.B), 2), dim3(cq_threads()), bytes, s, b, g, rs, dXa, dXb);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -39,7 +39,8 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
-  const int r0 = blockIdx.x * MT;
+  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
+  if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int mt = wave >> 1, ch = wave & 1;
   const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
@@ -166,8 +167,9 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_pair_kernel(LnProjArgs a0,
 #define DP_SLOT (2 * DP_PLANE)
 #define DP_NB 11                          // small vectors in LDS: 9 biases + ln2 gamma, beta
 
-__global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropCfg drop) {
+__global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs ain, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char dp_lds[];
+  const DaPostArgs a = args_now(ain);                  // (tilecore.h: every argument in a register before the first phase)
   char* P0 = dp_lds;
   char* P1 = P0 + DP_SLOT;
   char* P2 = P1 + DP_SLOT;
@@ -182,7 +184,8 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
-  const int r0 = blockIdx.x * MT;
+  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
+  if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int mt = wave >> 1, ch = wave & 1;
   const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   }
   {
     float4 pv = f4zero();
-    if (grp < 9) pv = ld4(a.b[grp] + col);
+    if (grp < 9) pv = ld4(ain.b[grp] + col);
     else if (grp == 9) pv = ld4(a.ln2_g + col);
     else if (grp == 10) pv = ld4(a.ln2_b + col);
     if (grp < DP_NB) bl[grp * 32 + l32] = pv;
@@ -460,7 +463,8 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
-  const int r0 = blockIdx.x * MT;
+  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
+  if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int mt = wave >> 1, ch = wave & 1;
   const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
@@ -605,14 +609,15 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) s += pf[w * 4 * HUAL_D + e];
-    a.part[(size_t)blockIdx.x * 4 * HUAL_D + e] = s;
+    a.part[(size_t)xcd_tile(blockIdx.x, gridDim.x) * 4 * HUAL_D + e] = s;
   }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // Backward of the gated middle of the dual attention (DaMidBwdArgs): ten weight steps, three operand slots.
-__global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) {
+__global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs ain) {
   extern __shared__ __attribute__((aligned(16))) char dm_lds[];
+  const DaMidBwdArgs a = args_now(ain);
   char* P0 = dm_lds;
   char* P1 = P0 + DP_SLOT;
   char* P2 = P1 + DP_SLOT;
@@ -626,7 +631,8 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
-  const int r0 = blockIdx.x * MT;
+  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
+  if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int mt = wave >> 1, ch = wave & 1;
   const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
@@ -856,7 +862,7 @@ int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s) {
   HUAL_DYN_LDS(ln_proj_kernel, 160 * 1024);
   double flops = 0.0, bytes = 0.0;
   ln_proj_work(a, flops, bytes);
-  HUAL_LAUNCH(flops, bytes, ln_proj_kernel, dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), kLnProjLds, s, a, drop);
+  HUAL_LAUNCH(flops, bytes, ln_proj_kernel, dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), kLnProjLds, s, a, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -870,7 +876,7 @@ int launch_ln_proj_pair(const LnProjArgs& a0, const LnProjArgs& a1, const DropCf
   double flops = 0.0, bytes = 0.0;
   ln_proj_work(a0, flops, bytes);
   ln_proj_work(a1, flops, bytes);
-  HUAL_LAUNCH(flops, bytes, ln_proj_pair_kernel, dim3(cdiv(a0.R, a0.MT), 2), dim3(CB_THREADS), kLnProjLds, s, a0, a1, drop);
+  HUAL_LAUNCH(flops, bytes, ln_proj_pair_kernel, dim3(xcd_round8(cdiv(a0.R, a0.MT)), 2), dim3(CB_THREADS), kLnProjLds, s, a0, a1, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -886,7 +892,7 @@ int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s) {
   const size_t lds = (size_t)3 * DP_SLOT + CB_WBYTES + DP_NB * 512 + (3 * DP_ROWS + 2 * DP_ROWS) * sizeof(float);
   const double rows = (double)a.R;
   HUAL_LAUNCH(11.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 16.0 + 11.0 * HUAL_D * HUAL_D), da_post_kernel,
-              dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), lds, s, a, drop);
+              dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), lds, s, a, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -909,7 +915,7 @@ int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t 
   const size_t lds = (size_t)4 * LB_ROWS * 256 + CB_WBYTES + 2 * LB_ROWS * sizeof(float);
   const double rows = (double)a.R;
   HUAL_LAUNCH(2.0 * rows * HUAL_D * HUAL_D * a.nsteps, 4.0 * (rows * HUAL_D * (4.0 + a.nsteps) + (double)a.nsteps * HUAL_D * HUAL_D),
-              ln_proj_bwd_kernel, dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), lds, s, a, drop);
+              ln_proj_bwd_kernel, dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), lds, s, a, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -923,7 +929,7 @@ int launch_da_mid_bwd(const DaMidBwdArgs& a, hipStream_t s) {
   const size_t lds = (size_t)3 * DP_SLOT + CB_WBYTES + (3 * DP_ROWS + 4 * DP_ROWS) * sizeof(float);
   const double rows = (double)a.R;
   HUAL_LAUNCH(10.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 17.0 + 10.0 * HUAL_D * HUAL_D), da_mid_bwd_kernel,
-              dim3(cdiv(a.R, a.MT)), dim3(CB_THREADS), lds, s, a);
+              dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), lds, s, a);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

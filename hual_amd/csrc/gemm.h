@@ -52,8 +52,9 @@ struct PackExtra {
   int gather_tasks; int gather_rows; EmbedArgs emb; DropCfg drop;
   int wall_K; uint32_t wall_off, wall_boff;
 };
+// timg / nimg (optional): images for the register-resident weights of the T-form kernels (tilecore.h), blocks of 64 KB at boffs[]
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
-                        hipStream_t stream, const PackExtra* extra = nullptr);
+                        hipStream_t stream, const PackExtra* extra = nullptr, char* timg = nullptr, char* nimg = nullptr);
 // Feature-load kernel: part[q][M][128] = dropout(A)[M, q*KS .. q*KS+KS) . W[q*KS .., :] for the four K-quarters q (Wimg =
 // forward image of the [K,128] weight, K <= 4*KS); the sum over q (+ bias) is taken by the consumer (ln_fwd_kernel's `part`).
 struct FkJob {

@@ -163,7 +163,7 @@ struct PackJob { uint32_t off; int K; uint32_t boff; };
 #define HUAL_MAX_PACK 96
 struct PackBatch { PackJob j[HUAL_MAX_PACK]; };
 __device__ __forceinline__ int pack_perm(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
-__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* bwd, int njobs, PackExtra ex) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* bwd, char* timg, char* nimg, int njobs, PackExtra ex) {
   __shared__ float tile[16][129];
   if ((int)blockIdx.y > njobs) {       // further rows: the embedding gather of the text encoder, one task per thread
     const int gid = (((int)blockIdx.y - njobs - 1) * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
@@ -210,6 +210,29 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
         *reinterpret_cast<uint32_t*>(img + (size_t)(k0 + r) * 512 + 4 * sp) = hi;
         *reinterpret_cast<uint32_t*>(img + (size_t)(k0 + r) * 512 + 256 + 4 * sp) = lo;
       }
+    }
+  }
+  // register-resident weights (tilecore.h "T-form"): one 64 KB block per 128 K rows at boff, [column][index] fp16 hi | lo
+  if (timg) {        // T image: W^T - column n, index k
+    char* img = timg + job.boff + (size_t)(k0 >> 7) * TF_BLOCK;
+    const int kb = k0 & 127;
+    for (int idx = threadIdx.x; idx < 128 * 8; idx += 256) {
+      const int n = idx >> 3, pr = idx & 7;             // k pair (k0 + 2 pr, + 1) of column n
+      uint32_t hi, lo;
+      f16_split_pair(tile[2 * pr][n] * HUAL_F16_WSCALE, tile[2 * pr + 1][n] * HUAL_F16_WSCALE, hi, lo);
+      *reinterpret_cast<uint32_t*>(img + (size_t)n * 256 + 2 * (kb + 2 * pr)) = hi;
+      *reinterpret_cast<uint32_t*>(img + 32768 + (size_t)n * 256 + 2 * (kb + 2 * pr)) = lo;
+    }
+  }
+  if (nimg) {        // N image: W itself - "column" k, index n
+    char* img = nimg + job.boff + (size_t)(k0 >> 7) * TF_BLOCK;
+    const int kb = k0 & 127;
+    for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+      const int r = idx >> 6, np = idx & 63;            // n pair (2 np, 2 np + 1) of row k0 + r
+      uint32_t hi, lo;
+      f16_split_pair(tile[r][2 * np] * HUAL_F16_WSCALE, tile[r][2 * np + 1] * HUAL_F16_WSCALE, hi, lo);
+      *reinterpret_cast<uint32_t*>(img + (size_t)(kb + r) * 256 + 4 * np) = hi;
+      *reinterpret_cast<uint32_t*>(img + 32768 + (size_t)(kb + r) * 256 + 4 * np) = lo;
     }
   }
   // backward image: the 16 original rows k0..k0+15 are columns c = k0 % 128 + (0..15) of block k0 / 128; for every kk
@@ -551,7 +574,7 @@ void dw_bf16_balanced_kernel(const DwJob* __restrict__ table, int n, DropCfg dro
 namespace hual {
 
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
-                        hipStream_t stream, const PackExtra* extra) {
+                        hipStream_t stream, const PackExtra* extra, char* timg, char* nimg) {
   HUAL_REQUIRE(!extra || (extra->lens && extra->word_ids && extra->rowmask && extra->loss_acc && (extra->zero_n % 4) == 0 &&
                           (reinterpret_cast<uintptr_t>(extra->zero_ptr) & 15) == 0), "pack: extra prologue work");
   PackExtra ex{};
@@ -572,7 +595,7 @@ int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* bof
     const int gx = maxK / 16;
     const int grows = (with_extra && ex.gather_tasks > 0) ? cdiv(ex.gather_tasks, gx * 256) : 0;      // rows of workgroups of the gather
     HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(gx, cnt + (with_extra ? 1 + grows : 0)),
-                dim3(256), 0, stream, b, P, fwd, bwd, cnt, ex);
+                dim3(256), 0, stream, b, P, fwd, bwd, timg, nimg, cnt, ex);
   }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

@@ -267,7 +267,7 @@ __device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float* 
 // NR = rows of the clip per 32-lane group (T <= 16 NR): the hidden rows are loaded ONCE, all loads in flight together, and stay
 // in registers for step 3
 template <int NR>
-__global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a, int T) {
+__global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a, int T, int B) {
   __shared__ float zs_[256], ze_[256], ps[256], pe[256], dls[256], dle[256];
   __shared__ float sm[24];
   __shared__ double smd[16];
@@ -276,7 +276,8 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a, int T) {
   __shared__ int besti[2][4];
   __shared__ float4 red[2][16][32];
   __shared__ float redb[2][16];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = xcd_tile(blockIdx.x, gridDim.x), tid = threadIdx.x;      // XCD-aware clip order (common.h)
+  if (b >= B) return;
   const int l32 = tid & 31, grp = tid >> 5;
   const int col = 4 * l32;
   HEADS_STAMP(0);
@@ -583,10 +584,12 @@ __global__ __launch_bounds__(256) void align_sim_cols_kernel(AlignSim a) {
 // per-clip forward kernels that only read cq.feats, in ONE launch: blockIdx.y = 0 weighted pooling (+ pooled . Wbot),
 // 1 = the per-sample part of the alignment loss (when labels are present)
 __global__ __launch_bounds__(512) void pool_align_fwd_kernel(PoolArgs pa, AlignPool ap, RowSpace rs) {
+  const int clip = xcd_tile(blockIdx.x, gridDim.x);      // XCD-aware clip order (common.h)
+  if (clip >= rs.B) return;
   if (blockIdx.y == 0) {
-    pool_fwd_body(pa, rs, blockIdx.x);
+    pool_fwd_body(pa, rs, clip);
   } else {
-    align_pool_body(ap, rs, blockIdx.x);
+    align_pool_body(ap, rs, clip);
   }
 }
 // per-clip backward of the alignment pooling (layers.py:213-229) and of weighted_pooling / cq_concat's pooled half
@@ -602,7 +605,8 @@ __global__ __launch_bounds__(512) void pool_align_bwd_kernel(PoolArgs pa, PoolBw
   __shared__ float part[4][HUAL_D];
   __shared__ float vecs[2][HUAL_D];      // [1]: dPW
   __shared__ float da[256], al[256], qm[256], dap[2][256];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = xcd_tile(blockIdx.x, gridDim.x), tid = threadIdx.x;      // XCD-aware clip order (common.h)
+  if (b >= rs.B) return;
   const int c = tid & 127, grp = tid >> 7;
   const int L = rs.L, T = rs.T;
   const size_t vrow0 = (size_t)b * T, qrow0 = (size_t)rs.Nv + (size_t)b * L;
@@ -726,15 +730,15 @@ namespace hual {
 int launch_pool_align_fwd(const PoolArgs& a, const AlignPool* ap, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(rs.L <= 256, "pool: L <= 256");
   AlignPool z{};
-  HUAL_LAUNCH(0.0, 0.0, pool_align_fwd_kernel, dim3(rs.B, ap ? 2 : 1), dim3(512), 0, s, a, ap ? *ap : z, rs);
+  HUAL_LAUNCH(0.0, 0.0, pool_align_fwd_kernel, dim3(xcd_round8(rs.B), ap ? 2 : 1), dim3(512), 0, s, a, ap ? *ap : z, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_pool_align_bwd(const PoolArgs& a, const PoolBwd& g, const AlignPool& ap, const AlignPoolBwd& ab, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(rs.T <= 256 && rs.L <= 256, "pool_align_bwd: T, L <= 256");
   HUAL_REQUIRE(ab.dF2 == g.dF2, "pool_align_bwd: the two parts write the same query rows");
-  if (rs.T <= 128 && rs.L <= 32) HUAL_LAUNCH(0.0, 0.0, (pool_align_bwd_kernel<32, 8>), dim3(rs.B), dim3(512), 0, s, a, g, ap, ab, rs);
-  else HUAL_LAUNCH(0.0, 0.0, (pool_align_bwd_kernel<64, 64>), dim3(rs.B), dim3(512), 0, s, a, g, ap, ab, rs);
+  if (rs.T <= 128 && rs.L <= 32) HUAL_LAUNCH(0.0, 0.0, (pool_align_bwd_kernel<32, 8>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
+  else HUAL_LAUNCH(0.0, 0.0, (pool_align_bwd_kernel<64, 64>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -772,8 +776,8 @@ int launch_heads(const HeadsArgs& a, int B, int T, hipStream_t s) {
   HUAL_REQUIRE(a.grad_only ? (a.ds && a.de && a.dZ[0]) : (a.logit[0] && a.logit[1] && a.vmask && a.start_index && a.end_index), "heads: null tensor");
   HUAL_REQUIRE(!a.h[0] || (a.h[1] && a.w[0] && a.w[1] && a.b[0] && a.b[1]), "heads: hidden layers incomplete");
   HUAL_REQUIRE(!a.dZ[0] || (a.dZ[1] && a.part[0] && a.part[1] && a.h[0]), "heads: gradient outputs incomplete");
-  if (T <= 128) HUAL_LAUNCH(0.0, 0.0, heads_kernel<8>, dim3(B), dim3(512), 0, s, a, T);
-  else HUAL_LAUNCH(0.0, 0.0, heads_kernel<16>, dim3(B), dim3(512), 0, s, a, T);
+  if (T <= 128) HUAL_LAUNCH(0.0, 0.0, heads_kernel<8>, dim3(xcd_round8(B)), dim3(512), 0, s, a, T, B);
+  else HUAL_LAUNCH(0.0, 0.0, heads_kernel<16>, dim3(xcd_round8(B)), dim3(512), 0, s, a, T, B);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

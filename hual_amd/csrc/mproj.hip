@@ -1,87 +1,92 @@
-// Multi-step dense kernel (see mproj.h).  Product loop of ln_proj_bwd_kernel (dablock.hip): two operand slots filled
-// alternately from HBM rows - the rows of step k+1 are requested before step k's wait and written behind its matrix phase -,
-// one weight image at a time by LDS-DMA, wave (mt, ch) = 16 rows x 64 columns on the matrix cores.
+// Multi-step dense kernel (see mproj.h).  Two operand slots are filled alternately from HBM rows - the rows of step k+1 are
+// requested before step k's matrix phase and written behind it -; the weights never touch LDS: wave ws keeps the fragments of
+// its 16 output columns in registers ("T-form", tilecore.h), requested one step ahead straight from the L2-resident image.
+// One workgroup barrier per step (operand planes complete), no wait on vector memory in front of the matrix phase.
 #include "mproj.h"
 #include "tilecore.h"
 #include "prof.h"
+#include <cstdlib>
+#include <cstddef>
 
 using namespace hual;
 
 #define MP_ROWS 64
+// compile-time feature set of a launch (any step of any problem uses ...): the loop body is straight-line for the features
+// that are off and branch-free (pointer selects, predicated lanes) for those that are on - a uniform branch around a vector
+// load makes the wait-count pass give up on the loads in flight across it (vmcnt(0) right behind the prefetch)
+enum { MPF_A2 = 1, MPF_BF16 = 2, MPF_DROP = 4, MPF_ADD = 8, MPF_LN = 16, MPF_REUSE = 32 };
 
-// LDS-DMA of a weight image whose K rows beyond `wrows` do not exist (K not a multiple of 128): those tile rows are fetched from
-// the last valid row (finite numbers; the operand columns they meet are zero).  Same piece order as cb_dma_weight.
-__device__ __forceinline__ void mp_dma_weight(const float* wimg, char* Wl, int wave, int lane, int wrows) {
-  if (wrows >= 128) { cb_dma_weight(wimg, Wl, wave, lane, CB_THREADS / 64); return; }
-  const int chp = lane & 15, rr = lane >> 4;
-  const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds_addr_of(Wl) + 1024u * (uint32_t)wave);
-  const int sw = (rr << 2) | (wave & 3);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int row = 4 * wave + rr + 64 * (k >> 2) + 32 * (k & 1);
-    const int kk = min(row, wrows - 1);
-    const char* src = reinterpret_cast<const char*>(wimg) + (size_t)kk * 512 + 256 * ((k >> 1) & 1) + 16 * (chp ^ sw);
-    glds16_asm(src, ldsw + (uint32_t)(CB_STAGE * (k >> 2) + 8192 * (k & 3)));
-  }
-}
-
+// NT = row tiles of a workgroup (MT <= 16 NT)
+template <int NT, int F>
 __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& drop) {
   extern __shared__ __attribute__((aligned(16))) char mp_lds[];
   char* S0 = mp_lds;                                   // operand slot 0: hi | lo planes [64][256 B]; LN mode: x as fp32 rows
   char* S1 = S0 + 2 * MP_ROWS * 256;
-  char* Wl = S1 + 2 * MP_ROWS * 256;
-  float* ainv0 = reinterpret_cast<float*>(Wl + CB_WBYTES);
+  float* ainv0 = reinterpret_cast<float*>(S1 + 2 * MP_ROWS * 256);
   float* ainv1 = ainv0 + MP_ROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
-  const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
-  const int r0 = blockIdx.x * MT;
-  if (r0 >= R) return;                                 // (pair launches: the smaller problem has fewer workgroups)
+  const int MT = a.MT, R = a.R;
+  const int nblk = xcd_round8((R + MT - 1) / MT);      // XCD-aware tile order (common.h) over this problem's own tiles: in a pair
+  if ((int)blockIdx.x >= nblk) return;                 // launch every XCD gets an eighth of EACH problem
+  const int r0 = xcd_tile(blockIdx.x, nblk) * MT;
+  if (r0 >= R) return;
   const int RE = min(R, r0 + MT);
-  const int mt = wave >> 1, ch = wave & 1;
-  const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
-  const bool act = mt < ntile;
+  const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;      // T-form: lane = row j of a tile, columns ecol .. ecol + 3
   const DropRegs dr = drop_load(drop);
+  constexpr int NU = NT;                               // 16-row groups a thread loads / fills (MT <= 16 NT)
 
+  // the step descriptors go through LDS once: a scalar load of a kernel-argument line that is not in the scalar cache yet is a
+  // full memory round trip, and a walk over the descriptors takes one (or two, dependent) of those per step
+  constexpr int SW = sizeof(MProjStep) / 4;
+  __shared__ uint32_t sdesc[MP_MAX * SW];
+  {
+    const uint32_t* ka = reinterpret_cast<const uint32_t*>(&a.s[0]);
+    for (int i = threadIdx.x; i < a.nsteps * SW; i += CB_THREADS) sdesc[i] = ka[i];
+  }
+  __syncthreads();
+  auto step_at = [&](int si) {
+    struct alignas(8) Raw { uint32_t w[SW]; } r;
+#pragma unroll
+    for (int q = 0; q < SW; ++q) r.w[q] = __builtin_amdgcn_readfirstlane(sdesc[si * SW + q]);
+    return __builtin_bit_cast(MProjStep, r);
+  };
   // step descriptors with the repetitions unrolled: (descriptor index, repetition) of flat step k
   int nflat = 0;
-  for (int i = 0; i < a.nsteps; ++i) nflat += a.s[i].rep;
+  for (int i = 0; i < a.nsteps; ++i) nflat += (int)__builtin_amdgcn_readfirstlane(sdesc[i * SW + offsetof(MProjStep, rep) / 4]);
   auto expand = [&](int si, int ri) {
-    MProjStep st = a.s[si];
+    MProjStep st = step_at(si);
     if (st.rep > 1) {
       st.A = st.a_bf16 ? (const void*)(reinterpret_cast<const uint16_t*>(st.A) + 128 * ri) : (const void*)(reinterpret_cast<const float*>(st.A) + 128 * ri);
       st.kw = min(128, st.ktot - 128 * ri);
       st.col0 += 128 * ri;
       st.wimg = reinterpret_cast<const float*>(reinterpret_cast<const char*>(st.wimg) + (size_t)ri * 128 * 512);
-      st.wrows = st.wrows - 128 * ri;
       st.first = st.first && ri == 0;
       st.last = st.last && ri == st.rep - 1;
     }
     return st;
   };
-  mp_dma_weight(a.s[0].wimg, Wl, wave, lane, a.s[0].wrows);
+  TfW wc, wn;
+  tf_load_w(wc, step_at(0).wimg, wave, lane);
   // raw operand rows of one step -> registers (unconditional loads on clamped rows / columns)
-  float4 nv[4], n2[4];
-  auto rows_load_to = [&](const MProjStep& st, float4 (&dst)[4]) {      // (bfloat16 rows travel raw in .x / .y, widened in fill)
+  float4 nv[NU], n2[NU];
+  auto rows_load = [&](const MProjStep& st) {      // (bfloat16 rows travel raw in .x / .y, widened in fill)
     const int kc = min(col, max(st.kw - 4, 0));        // kw is a multiple of 4: a lane's 4 columns are in or out together
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const size_t row = (size_t)min(r0 + grp + 16 * u, R - 1);
-      if (st.a_bf16) {      // (the widening happens at the consumer: the raw 8 bytes travel in .x / .y)
+      if ((F & MPF_BF16) && st.a_bf16) {      // (the widening happens at the consumer: the raw 8 bytes travel in .x / .y)
         const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(st.A) + row * st.lda + kc);
-        dst[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), 0.f, 0.f);
+        nv[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), 0.f, 0.f);
       } else {
-        dst[u] = ld4(reinterpret_cast<const float*>(st.A) + row * st.lda + kc);
+        nv[u] = ld4(reinterpret_cast<const float*>(st.A) + row * st.lda + kc);
       }
-    }
-  };
-  auto rows_load = [&](const MProjStep& st) {
-    rows_load_to(st, nv);
-    if (st.A2) {
-      const int kc = min(col, max(st.kw - 4, 0));
-#pragma unroll
-      for (int u = 0; u < 4; ++u) n2[u] = ld4(st.A2 + (size_t)min(r0 + grp + 16 * u, R - 1) * st.lda2 + kc);
+      if (F & MPF_A2) {      // no factor: the operand itself is read once more (a hit) and not used
+        const float* p2 = st.A2 ? st.A2 : reinterpret_cast<const float*>(st.A);
+        const int ld2 = st.A2 ? st.lda2 : st.lda;
+        n2[u] = ld4(p2 + row * ld2 + kc);
+      }
     }
   };
   // registers -> operand planes of slot `slot` (prologue: factor, dropout; columns >= kw and rows beyond the tensor are zero)
@@ -90,10 +95,11 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
     float* ai = slot ? ainv1 : ainv0;
     const bool cin = col < st.kw;
     uint32_t nb[4] = {15u, 15u, 15u, 15u};
-    if (st.drop_site >= 0 && dr.enabled) {
+    constexpr int NPR = (NU + 1) / 2;
+    if ((F & MPF_DROP) && st.drop_site >= 0 && dr.enabled) {
       const uint32_t c4 = (uint32_t)((st.col0 + col) >> 2);
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
+      for (int pr = 0; pr < NPR; ++pr) {
         const int lrA = grp + 32 * pr, lrB = lrA + 16;
         const bool okA = cin && lrA < MT && r0 + lrA < RE, okB = cin && lrB < MT && r0 + lrB < RE;
         uint32_t na, nbb;
@@ -106,86 +112,109 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int lr = grp + 16 * u, row = r0 + lr;
-      if (lr >= MT) continue;
-      const bool ok = row < RE && cin;
+      const bool ok = row < RE && cin && lr < MT;
       float4 v = nv[u];
-      if (st.a_bf16) {
+      if ((F & MPF_BF16) && st.a_bf16) {
         const uint32_t w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y);
         v = make_float4(__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u));
       }
+      if ((F & MPF_A2) && st.A2) v = cb_mul(v, n2[u]);
       if (!ok) v = f4zero();
-      if (st.A2 && ok) v = cb_mul(v, n2[u]);
-      if (st.drop_site >= 0 && dr.enabled) v = f4_select(nb[u], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
-      const float inv = cb_store_operand(S, S + MP_ROWS * 256, lr, l32, v);
+      if ((F & MPF_DROP) && st.drop_site >= 0 && dr.enabled) v = f4_select(nb[u], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
+      const float inv = cb_store_operand(S, S + MP_ROWS * 256, lr, l32, v);      // (rows MT .. 16 NT - 1 of a slot: zeros)
       if (l32 == 0) ai[lr] = row < RE ? inv : 0.f;
     }
   };
+#define MP_STAMP(i) HUAL_STAMP_K(9, i)
+  MP_STAMP(0);
   MProjStep cur = expand(0, 0);
   rows_load(cur);
   fill(cur, 0);
+  MP_STAMP(1);
   int slot = 0, si = 0, ri = 0;
-  float4 acc[4];
+  float4 acc[NT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = f4zero();
+  for (int rt = 0; rt < NT; ++rt) acc[rt] = f4zero();
 #pragma unroll 1
   for (int k = 0; k < nflat; ++k) {
+    MP_STAMP(2 + 7 * k);
     const MProjStep st = cur;
     const bool more = k + 1 < nflat;
     MProjStep nxt = st;
     if (more) {
-      if (++ri == a.s[si].rep) { ri = 0; ++si; }
+      if (++ri == (int)__builtin_amdgcn_readfirstlane(sdesc[si * SW + offsetof(MProjStep, rep) / 4])) { ri = 0; ++si; }
       nxt = expand(si, ri);
     }
-    const bool refill = more && !nxt.reuse;
-    if (refill) rows_load(nxt);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    cb_barrier();
-    const char* S = slot ? S1 : S0;
-    const float* ai = slot ? ainv1 : ainv0;
-    f32x4 accp[4];
-    if (act) cb_tile_mma_t<MP_ROWS * 256>(S, Wl, mt, ch, lane, accp);
-    cb_barrier();
-    if (more) mp_dma_weight(nxt.wimg, Wl, wave, lane, nxt.wrows);
-    if (act) {
+    MP_STAMP(3 + 7 * k);
+    // what the closing phase reads from memory, requested FIRST: vmcnt counts in order, so a wait for
+    // these must not have the prefetches below in front of it
+    const bool closes = st.last && st.out && ecol < st.ncol;
+    const float* wdummy = st.wimg + 4 * lane;
+    const float4 bias = ld4(st.bias ? st.bias + ecol : wdummy);
+    float4 addv[NT];
+    if (F & MPF_ADD) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ir = ai[16 * mt + 4 * g + r];
-        const float4 o = acc[r];
-        acc[r] = st.first ? make_float4(fmaf(accp[0][r], ir, 0.f), fmaf(accp[1][r], ir, 0.f), fmaf(accp[2][r], ir, 0.f), fmaf(accp[3][r], ir, 0.f))
-                          : make_float4(fmaf(accp[0][r], ir, o.x), fmaf(accp[1][r], ir, o.y), fmaf(accp[2][r], ir, o.z), fmaf(accp[3][r], ir, o.w));
-      }
-      if (st.last && st.out) {      // close the tile: bias, relu, addend, store
-        const float4 bias = st.bias ? ld4(st.bias + ecol) : f4zero();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = r0 + 16 * mt + 4 * g + r;
-          if (row >= RE || ecol >= st.ncol) continue;
-          float4 v = cb_add(acc[r], bias);
-          if (st.act) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-          if (st.add) v = cb_add(v, ld4(st.add + (size_t)(row / st.add_div) * st.ldadd + ecol));
-          st4(st.out + (size_t)row * st.ldo + ecol, v);
-        }
+      for (int rt = 0; rt < NT; ++rt) {
+        const int row = min(r0 + 16 * rt + j, R - 1);
+        addv[rt] = ld4((st.add && closes) ? st.add + (size_t)(row / st.add_div) * st.ldadd + ecol : wdummy);
       }
     }
-    if (refill) { slot ^= 1; fill(nxt, slot); }      // the other slot was last read by product k - 1 (or never)
+    // next step's weight fragments and operand rows: in flight under this step (the last step asks for its own again)
+    tf_load_w(wn, nxt.wimg, wave, lane);
+    bool refill = true;
+    if (F & MPF_REUSE) {
+      refill = more && !nxt.reuse;
+      if (refill) rows_load(nxt);
+    } else {
+      rows_load(nxt);
+    }
+    MP_STAMP(4 + 7 * k);
+    cb_barrier();                                       // operand planes of this step complete (LDS only: nothing waits for HBM here)
+    MP_STAMP(5 + 7 * k);
+    const char* S = slot ? S1 : S0;
+    const float* ai = slot ? ainv1 : ainv0;
+    f32x4 accp[NT];
+    tf_mma<NT, MP_ROWS * 256>(S, wc, lane, accp);
+    MP_STAMP(6 + 7 * k);
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      const float ir = ai[16 * rt + j];
+      const float4 o = st.first ? f4zero() : acc[rt];
+      acc[rt] = make_float4(fmaf(accp[rt][0], ir, o.x), fmaf(accp[rt][1], ir, o.y), fmaf(accp[rt][2], ir, o.z), fmaf(accp[rt][3], ir, o.w));
+    }
+    {      // close the tile: bias, relu, addend, store (lanes outside the tensor / a step that does not close: no store)
+      float* outp = st.out ? st.out : const_cast<float*>(wdummy);
+#pragma unroll
+      for (int rt = 0; rt < NT; ++rt) {
+        const int row = r0 + 16 * rt + j;
+        float4 v = st.bias ? cb_add(acc[rt], bias) : acc[rt];
+        if (st.act) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if ((F & MPF_ADD) && st.add) v = cb_add(v, addv[rt]);
+        if (closes && 16 * rt + j < MT && row < RE) st4(outp + (size_t)row * st.ldo + ecol, v);
+      }
+    }
+    MP_STAMP(7 + 7 * k);
+    if (refill && more) { slot ^= 1; fill(nxt, slot); }      // the other slot was last read by product k - 1: every wave is past it (barrier above)
+    MP_STAMP(8 + 7 * k);
+    wc = wn;
     cur = nxt;
   }
-  if (!a.ln_g) return;
+  if (!(F & MPF_LN) || !a.ln_g) return;
   // ---- LN mode: the last tile (+ bias) -> LDS as fp32 rows -> layer norm (+ position embeddings) row by row
   float4* D0 = reinterpret_cast<float4*>(S0);                // both slots are free behind the last matrix phase (barrier above)
-  cb_barrier();
-  if (act) {
-    const float* lb = a.s[a.nsteps - 1].bias;
+  cb_barrier();                                         // every wave is past the last matrix phase
+  {
+    const float* lb = step_at(a.nsteps - 1).bias;
     const float4 bias = lb ? ld4(lb + ecol) : f4zero();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) D0[(16 * mt + 4 * g + r) * 32 + (ecol >> 2)] = cb_add(acc[r], bias);
+    for (int rt = 0; rt < NT; ++rt) D0[(16 * rt + j) * 32 + (ecol >> 2)] = cb_add(acc[rt], bias);
   }
   const float4 gam = ld4(a.ln_g + col), bet = ld4(a.ln_b + col);
   cb_barrier();
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int lr = grp + 16 * u, row = r0 + lr;
     if (lr >= MT || row >= RE) continue;
     const float4 x = D0[lr * 32 + l32];
@@ -203,11 +232,19 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
   }
 }
 
-__global__ __launch_bounds__(CB_THREADS) void mproj_kernel(MProjArgs a, DropCfg drop) { mproj_body(a, drop); }
+template <int NT, int F>
+__global__ __launch_bounds__(CB_THREADS) void mproj_kernel(MProjArgs a, DropCfg drop) { mproj_body<NT, F>(a, drop); }
+template <int NT, int F>
 __global__ __launch_bounds__(CB_THREADS) void mproj_pair_kernel(MProjArgs a0, MProjArgs a1, DropCfg drop) {
-  if (blockIdx.y == 0) mproj_body(a0, drop);
-  else mproj_body(a1, drop);
+  if (blockIdx.y == 0) mproj_body<NT, F>(a0, drop);
+  else mproj_body<NT, F>(a1, drop);
 }
+
+#if defined(HUAL_STAMPS) && HUAL_STAMPS == 9
+extern "C" int hual_debug_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hual_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 
 namespace hual {
 
@@ -219,7 +256,7 @@ int mproj_rows(int R0, int R1) {
   return t;
 }
 
-static int check_mproj(const MProjArgs& a, double& flops, double& bytes) {
+static int check_mproj(const MProjArgs& a, double& flops, double& bytes, int& feat) {
   HUAL_REQUIRE(a.nsteps >= 1 && a.nsteps <= MP_MAX && a.R > 0 && a.MT >= 1 && a.MT <= MP_ROWS, "mproj: steps / rows");
   HUAL_REQUIRE(a.s[0].first && !a.s[0].reuse && a.s[a.nsteps - 1].last, "mproj: first step starts a tile, last step closes one");
   for (int k = 0; k < a.nsteps; ++k) {
@@ -228,6 +265,7 @@ static int check_mproj(const MProjArgs& a, double& flops, double& bytes) {
     HUAL_REQUIRE(s.reuse || (s.A && (s.rep > 1 || (s.kw >= 4 && s.kw <= 128 && (s.kw % 4) == 0)) && (s.lda % 4) == 0), "mproj: operand");
     HUAL_REQUIRE(!s.reuse || k > 0, "mproj: nothing to reuse");
     HUAL_REQUIRE(s.wimg && s.wrows >= 1, "mproj: weight image");
+    feat |= (s.A2 ? MPF_A2 : 0) | (s.a_bf16 ? MPF_BF16 : 0) | (s.drop_site >= 0 ? MPF_DROP : 0) | (s.add ? MPF_ADD : 0) | (s.reuse ? MPF_REUSE : 0);
     HUAL_REQUIRE(!s.last || (a.ln_g && k == a.nsteps - 1 && !s.out) || (s.out && (s.ldo % 4) == 0 && s.ncol >= 4 && s.ncol <= 128 && (s.ncol % 4) == 0),
                  "mproj: closing step needs a destination");
     HUAL_REQUIRE(!s.add || s.add_div >= 1, "mproj: add_div");
@@ -239,6 +277,7 @@ static int check_mproj(const MProjArgs& a, double& flops, double& bytes) {
     if (s.last && s.out) bytes += 4.0 * a.R * s.ncol;
   }
   if (a.ln_g) {
+    feat |= MPF_LN;
     HUAL_REQUIRE(a.ln_b && a.y_out && a.mean && a.rstd && (!a.pos || a.Tc >= 1), "mproj: layer-norm outputs");
     bytes += 4.0 * a.R * 128.0 * (a.x_out ? 2.0 : 1.0);
   }
@@ -248,22 +287,44 @@ static int check_mproj(const MProjArgs& a, double& flops, double& bytes) {
 int launch_mproj(const MProjArgs* a, int nprob, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a && (nprob == 1 || nprob == 2), "mproj: one or two problems");
   double flops = 0.0, bytes = 0.0;
-  int blocks = 0;
+  int blocks = 0, feat = 0;
   for (int i = 0; i < nprob; ++i) {
-    int rc = check_mproj(a[i], flops, bytes);
+    int rc = check_mproj(a[i], flops, bytes, feat);
     if (rc) return rc;
     const int nb = cdiv(a[i].R, a[i].MT);
     blocks = nb > blocks ? nb : blocks;
   }
-  const size_t lds = (size_t)4 * MP_ROWS * 256 + CB_WBYTES + 2 * MP_ROWS * sizeof(float);
+  blocks = xcd_round8(blocks);
+  const size_t lds = (size_t)4 * MP_ROWS * 256 + 2 * MP_ROWS * sizeof(float);
   if (nprob == 2) HUAL_REQUIRE(a[0].MT == a[1].MT, "mproj: problems of one launch share the rows per workgroup");
-  if (nprob == 1) {
-    HUAL_DYN_LDS(mproj_kernel, 160 * 1024);
-    HUAL_LAUNCH(flops, bytes, mproj_kernel, dim3(blocks), dim3(CB_THREADS), lds, s, a[0], drop);
-  } else {
-    HUAL_DYN_LDS(mproj_pair_kernel, 160 * 1024);
-    HUAL_LAUNCH(flops, bytes, mproj_pair_kernel, dim3(blocks, 2), dim3(CB_THREADS), lds, s, a[0], a[1], drop);
+  const int nt = (a[0].MT + 15) / 16;
+  // instantiated feature sets: none, reuse, factor, addend, reuse + addend, everything
+  const int fsets[] = {0, MPF_REUSE, MPF_A2, MPF_ADD, MPF_REUSE | MPF_ADD, MPF_A2 | MPF_BF16 | MPF_DROP | MPF_ADD | MPF_LN | MPF_REUSE};
+  int fs = 5;
+  for (int i = 4; i >= 0; --i) if ((feat & ~fsets[i]) == 0) fs = i;
+#define MPROJ_LAUNCH(NT, FS)                                                                                               \
+  do {                                                                                                                     \
+    HUAL_DYN_LDS((mproj_kernel<NT, FS>), 96 * 1024);                                                                       \
+    HUAL_DYN_LDS((mproj_pair_kernel<NT, FS>), 96 * 1024);                                                                  \
+    if (nprob == 1) HUAL_LAUNCH(flops, bytes, (mproj_kernel<NT, FS>), dim3(blocks), dim3(CB_THREADS), lds, s, a[0], drop); \
+    else HUAL_LAUNCH(flops, bytes, (mproj_pair_kernel<NT, FS>), dim3(blocks, 2), dim3(CB_THREADS), lds, s, a[0], a[1], drop); \
+  } while (0)
+#define MPROJ_NT(FS)                                                                                                       \
+  do {                                                                                                                     \
+    if (nt <= 2) MPROJ_LAUNCH(2, FS);                                                                                      \
+    else if (nt == 3) MPROJ_LAUNCH(3, FS);                                                                                 \
+    else MPROJ_LAUNCH(4, FS);                                                                                              \
+  } while (0)
+  switch (fs) {
+    case 0: MPROJ_NT(0); break;
+    case 1: MPROJ_NT(MPF_REUSE); break;
+    case 2: MPROJ_NT(MPF_A2); break;
+    case 3: MPROJ_NT(MPF_ADD); break;
+    case 4: MPROJ_NT(MPF_REUSE | MPF_ADD); break;
+    default: MPROJ_NT(MPF_A2 | MPF_BF16 | MPF_DROP | MPF_ADD | MPF_LN | MPF_REUSE); break;
   }
+#undef MPROJ_NT
+#undef MPROJ_LAUNCH
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

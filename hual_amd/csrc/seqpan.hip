@@ -59,6 +59,14 @@ struct Ctx {
   std::vector<DenseW> dense;          // every [K,128] weight of the graph, sorted by offset
   char* PKF = nullptr;                // pre-split images (gemm.h launch_pack_weights): forward ...
   char* PKB = nullptr;                // ... and of the transposed weights, for dX
+  char* PKT = nullptr;                // images for the register-resident weights of the T-form kernels (tilecore.h): W^T blocks (forward) ...
+  char* PKN = nullptr;                // ... and W blocks (dX), 64 KB per 128 contraction indices, at DenseW::boff
+  const float* timg(size_t off, int blk = 0) const { return reinterpret_cast<const float*>(PKT + boff_of(off) + (size_t)blk * 65536); }
+  const float* nimg(size_t off, int blk = 0) const { return reinterpret_cast<const float*>(PKN + boff_of(off) + (size_t)blk * 65536); }
+  size_t boff_of(size_t off) const {
+    for (const auto& d : dense) if (d.off == off) return d.boff;
+    return off * 4;      // (virtual jobs: the char-CNN filter bank sits at wall_boff = wall_off * 4)
+  }
   size_t pk_bytes = 0;
 
   float* buf(const std::string& name, size_t rows, size_t cols) {
@@ -156,8 +164,8 @@ void fill_embed_args(Ctx& c, EmbedArgs& ea, const hual_batch* bt, float* cat, in
   ea.cat = cat; ea.ldcat = catw; ea.char_arg = char_arg;
   set_embed_scratch(ea, scratch, c.rs.Nq, c.C, c.cfg->char_dim);
   ea.word_dim = c.cfg->word_dim; ea.char_dim = c.cfg->char_dim; ea.C = c.C; ea.num_chars = c.cfg->num_chars;
-  ea.wall_img = reinterpret_cast<const float*>(c.PKF + (size_t)c.wall_off * 4);
-  ea.wall_img_t = reinterpret_cast<const float*>(c.PKB + c.wall_boff);
+  ea.wall_img = reinterpret_cast<const float*>(c.PKT + c.wall_boff);      // T image (forward), N image (d windows): tilecore.h
+  ea.wall_img_t = reinterpret_cast<const float*>(c.PKN + c.wall_boff);
 }
 // keep-byte buffer of an attention job's probability dropout (attn.h): B*Tq*8 rows of ldm bytes
 // + the softmax statistics the forward leaves for the backward
@@ -340,6 +348,8 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   // the split kernels (weights are constant within a step) and - hual_run_opts.grads_prezero - the gradient buffer zeroed: ONE launch
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
   c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
+  c.PKT = reinterpret_cast<char*>(c.buf("params.pkt", (c.pk_bytes + 3) / 4, 1));
+  c.PKN = reinterpret_cast<char*>(c.buf("params.pkn", (c.pk_bytes + 3) / 4, 1));
   float* ortho_dE = c.buf("ortho.dE", 4, HUAL_D);
   // (the text encoder's gather - word / char lookups with their dropout, model.py:36-41 - rides in the same launch)
   float* cat = c.buf("cat", Nq, catw);
@@ -362,7 +372,8 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     ex.gather_tasks = (c.stage_on(ST_INPUT) && c.word_table) ? embed_gather_tasks(ea, Nq) : 0;
     ex.gather_rows = Nq; ex.emb = ea; ex.drop = c.drop;
     ex.wall_K = c.wall_K; ex.wall_off = c.wall_off; ex.wall_boff = c.wall_boff;
-    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex));
+    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex,
+                              c.PKT, c.want_bwd ? c.PKN : nullptr));
   }
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
   c.stage(ST_INPUT);
@@ -406,7 +417,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     MProjArgs pr[2];
     pr[0] = margs(Nv, Nq);
     pr[0].nsteps = 1;
-    pr[0].s[0] = mstep(reinterpret_cast<const float*>(bt->video), V, std::min(V, 128), reinterpret_cast<const float*>(c.PKF + pm.vconv.k * 4), V, true, true);
+    pr[0].s[0] = mstep(reinterpret_cast<const float*>(bt->video), V, std::min(V, 128), c.timg(pm.vconv.k), V, true, true);
     pr[0].s[0].a_bf16 = bt->video_dtype == HUAL_DTYPE_BF16 ? 1 : 0;
     pr[0].s[0].rep = cdiv(V, 128); pr[0].s[0].ktot = V;
     pr[0].s[0].drop_site = HUAL_SITE_VIDEO; pr[0].s[0].col0 = 0;
@@ -416,7 +427,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     pr[0].x_out = lin; pr[0].y_out = x; pr[0].mean = lin_mean; pr[0].rstd = lin_rstd;
     pr[1] = margs(Nq, Nv);
     pr[1].nsteps = 1;
-    pr[1].s[0] = mstep(cat, catw, std::min(catw, 128), reinterpret_cast<const float*>(c.PKF + pm.qconv.k * 4), catw, true, true);
+    pr[1].s[0] = mstep(cat, catw, std::min(catw, 128), c.timg(pm.qconv.k), catw, true, true);
     pr[1].s[0].rep = cdiv(catw, 128); pr[1].s[0].ktot = catw;
     pr[1].s[0].bias = c.p(pm.qconv.b);
     pr[1].ln_g = c.p(pm.qln.g); pr[1].ln_b = c.p(pm.qln.b); pr[1].pos = c.p(pm.pos); pr[1].row_in_clip0 = 0; pr[1].Tc = L;
@@ -525,13 +536,12 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     MProjArgs pr[2];
     for (int sd = 0; sd < 2; ++sd) {
       const size_t ro = sd == 0 ? 0 : (size_t)Nv * D;
-      const char* img = c.PKF + pm.cq[sd].dense * 4;
       pr[sd] = margs(sd == 0 ? Nv : Nq, sd == 0 ? Nq : Nv);
       pr[sd].nsteps = 4;
       const float* a1[4] = {x + ro, cq.C2Q + ro, x + ro, x + ro};
       const float* a2[4] = {nullptr, nullptr, cq.C2Q + ro, cq.Q2C + ro};
       for (int p = 0; p < 4; ++p) {
-        pr[sd].s[p] = mstep(a1[p], D, D, reinterpret_cast<const float*>(img + (size_t)p * D * 512), D, p == 0, p == 3);
+        pr[sd].s[p] = mstep(a1[p], D, D, c.timg(pm.cq[sd].dense, p), D, p == 0, p == 3);
         pr[sd].s[p].A2 = a2[p]; pr[sd].s[p].lda2 = D;
       }
       mstep_out(pr[sd].s[3], cqf + ro, D);
@@ -553,7 +563,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   if (c.live()) {      // fuse = q2v_feats . W_top + b + (pooled . W_bot)[clip]   (layers.py:150-153)
     MProjArgs pr = margs(Nv);
     pr.nsteps = 1;
-    pr.s[0] = mstep(cqf, D, D, reinterpret_cast<const float*>(c.PKF + pm.cqcat.k * 4), D, true, true);
+    pr.s[0] = mstep(cqf, D, D, c.timg(pm.cqcat.k), D, true, true);
     mstep_out(pr.s[0], fuse, D, c.p(pm.cqcat.b));
     pr.s[0].add = pa.PW; pr.s[0].ldadd = D; pr.s[0].add_div = T;
     c.chk(launch_mproj(&pr, 1, c.drop, c.stream));
@@ -703,6 +713,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   // every dX product reads the image of the transposed weight that forward's pack launch left in the workspace (PKB)
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
   c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
+  c.PKT = reinterpret_cast<char*>(c.buf("params.pkt", (c.pk_bytes + 3) / 4, 1));
+  c.PKN = reinterpret_cast<char*>(c.buf("params.pkn", (c.pk_bytes + 3) / 4, 1));
   float* outputs = c.actv("outputs");
   // ---------------- heads
   c.stage(ST_PRED);
@@ -743,7 +755,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   float* d_efn = c.actv("d.head.efn");
   float* d_out_heads = c.actv("d.outputs.heads");
   if (c.live()) {      // the two hidden layers backward: d sfn, d efn and the part of d outputs that came through them - four weight steps
-    auto imgt = [&](size_t off, int blk) { return reinterpret_cast<const float*>(c.PKB + off * 4 + (size_t)blk * HUAL_PACK_BLOCK_BYTES); };
+    auto imgt = [&](size_t off, int blk) { return c.nimg(off, blk); };
     MProjArgs pr = margs(Nv);
     pr.nsteps = 4;
     pr.s[0] = mstep(dz_hs, D, D, imgt(pm.shid.k, 0), D, true, true);      mstep_out(pr.s[0], d_sfn, D);
@@ -866,7 +878,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   if (c.live()) {
     MProjArgs pr = margs(Nv);
     pr.nsteps = 1;
-    pr.s[0] = mstep(d_fuse, D, D, reinterpret_cast<const float*>(c.PKB + pm.cqcat.k * 4), D, true, true);
+    pr.s[0] = mstep(d_fuse, D, D, c.nimg(pm.cqcat.k), D, true, true);
     mstep_out(pr.s[0], d_cqf, D);
     c.chk(launch_mproj(&pr, 1, c.drop, c.stream));
   }
@@ -921,7 +933,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       pr[sd] = margs(sd == 0 ? Nv : Nq, sd == 0 ? Nq : Nv);
       pr[sd].nsteps = 4;
       for (int p = 0; p < 4; ++p) {
-        const float* img = reinterpret_cast<const float*>(c.PKB + pm.cq[sd].dense * 4 + (size_t)p * HUAL_PACK_BLOCK_BYTES);
+        const float* img = c.nimg(pm.cq[sd].dense, p);
         pr[sd].s[p] = p == 0 ? mstep(d_cqf + ro * D, D, D, img, D, true, true) : mstep_reuse(img, D, true, true);
         mstep_out(pr[sd].s[p], d_cat4 + ro * 4 * D + (size_t)p * D, 4 * D);
       }
@@ -1113,13 +1125,11 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   }
   float* d_cat = c.buf("d.cat", Nq, catw);
   if (c.live()) {      // d cat = d lin[q rows] . W_q^T: ceil(catw / 128) column blocks of one operand
-    const Ctx::DenseW_t* dwq = nullptr;
-    for (const auto& d : c.dense) if (d.off == pm.qconv.k) dwq = &d;
-    HUAL_REQUIRE(dwq != nullptr && cdiv(catw, 128) <= MP_MAX, "internal: query_conv1d image");
+    HUAL_REQUIRE(cdiv(catw, 128) <= MP_MAX, "internal: query_conv1d image");
     MProjArgs pr = margs(Nq);
     pr.nsteps = cdiv(catw, 128);
     for (int p = 0; p < pr.nsteps; ++p) {
-      const float* img = reinterpret_cast<const float*>(c.PKB + dwq->boff + (size_t)p * HUAL_PACK_BLOCK_BYTES);
+      const float* img = c.nimg(pm.qconv.k, p);
       pr.s[p] = p == 0 ? mstep(d_lin + (size_t)Nv * D, D, D, img, D, true, true) : mstep_reuse(img, D, true, true);
       mstep_out(pr.s[p], d_cat + (size_t)p * D, catw, nullptr, std::min(D, catw - p * D));
     }

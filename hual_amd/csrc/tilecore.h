@@ -7,13 +7,46 @@
 #include "bf16x3.h"
 #include "philox.h"
 
+// ---- kernel arguments.  A scalar load of a kernel-argument line that is not in the scalar cache yet is a full memory round trip
+// (~1.5 us measured), and the compiler sinks those loads to the first use: a kernel that walks a large argument struct phase by
+// phase pays one round trip per phase.  args_now() makes every dword of the struct live in a scalar register at the top of the
+// kernel (one burst of s_load_dwordx16, one round trip); structs that are indexed dynamically go through LDS instead
+// (args_to_lds + uni()).
+template <class T>
+__device__ __forceinline__ T args_now(const T& a) {
+  static_assert(sizeof(T) % 4 == 0, "argument structs are dword multiples");
+  struct Raw { uint32_t w[sizeof(T) / 4]; };
+  Raw r = __builtin_bit_cast(Raw, a);
+#pragma unroll
+  for (int q = 0; q < (int)(sizeof(T) / 4); ++q) asm volatile("" : "+s"(r.w[q]));
+  return __builtin_bit_cast(T, r);
+}
+// cooperative copy of an argument struct into LDS (caller: barrier before the first read)
+template <class T>
+__device__ __forceinline__ void args_to_lds(const T& a, T* dst, int tid, int nthreads) {
+  static_assert(sizeof(T) % 4 == 0, "argument structs are dword multiples");
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&a);
+  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+  for (int i = tid; i < (int)(sizeof(T) / 4); i += nthreads) d[i] = src[i];
+}
+// a workgroup-uniform value read from LDS -> scalar registers
+template <class U>
+__device__ __forceinline__ U uni(const U& v) {
+  static_assert(sizeof(U) % 4 == 0, "dword multiples");
+  struct Raw { uint32_t w[sizeof(U) / 4]; };
+  Raw r = __builtin_bit_cast(Raw, v);
+#pragma unroll
+  for (int q = 0; q < (int)(sizeof(U) / 4); ++q) r.w[q] = __builtin_amdgcn_readfirstlane(r.w[q]);
+  return __builtin_bit_cast(U, r);
+}
+
 // ---- debug: in-kernel phase timestamps (-DHUAL_STAMPS, scripts/exp/stamps.py).  Thread 0 of every workgroup writes the
 // shader clock at phase boundaries into a device-global table read back through hual_debug_stamps().
 #ifdef HUAL_STAMPS
 #define HUAL_STAMP_SLOTS 64
 static __device__ unsigned long long g_hual_stamps[512 * HUAL_STAMP_SLOTS];      // one table per translation unit
 // HUAL_STAMPS selects the kernel that writes: 1 da_post_kernel, 2 conv_block_fwd_kernel, 3 conv_block_bwd_kernel,
-// 4 ln_proj_bwd_kernel, 5 da_mid_bwd_kernel, 6 ln_proj_kernel (build: HUAL_EXP_DEFS=HUAL_STAMPS=<n>)
+// 4 ln_proj_bwd_kernel, 5 da_mid_bwd_kernel, 6 ln_proj_kernel, 9 mproj kernels (build: HUAL_STAMPS=<n> python -m hual_amd.build)
 #define HUAL_STAMP_K(k, i) do { if (HUAL_STAMPS == (k) && threadIdx.x == 0 && blockIdx.x < 512 && (i) < HUAL_STAMP_SLOTS) g_hual_stamps[blockIdx.x * HUAL_STAMP_SLOTS + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define HUAL_STAMP_K(k, i) do { } while (0)
@@ -178,6 +211,52 @@ __device__ __forceinline__ void cb_tile_mma_t(const char* Ahi, const char* Wl, i
                  [w00] "v"(wa[0]), [w01] "v"(wa[1]), [w10] "v"(wa[2]), [w11] "v"(wa[3]),
                  [w20] "v"(wa[4]), [w21] "v"(wa[5]), [w30] "v"(wa[6]), [w31] "v"(wa[7]), [alo] "i"(ALO)
                : "memory", CB_TILE_MMA_CLOBBERS);
+}
+
+// ---- "T-form" tile product: register-resident weights -----------------------------------------------------------------
+// Y^T = W^T . X^T: the weight block is the MFMA's A operand (M = output columns), the activation rows are its B operand
+// (N = rows).  Wave `ws` of a workgroup owns the 16 output columns 16 ws .. 16 ws + 15 for ALL row tiles of the workgroup:
+//   * its weight fragments (16 columns x 128 k, hi + lo = 32 registers) come STRAIGHT from the L2-resident image into
+//     registers with 16-byte global loads - requested a whole step ahead, no LDS staging, no DMA wait, no barrier for weights;
+//   * the activation fragments are plain ds_read_b128 of the row-major operand planes (lane (j, g): row j, k 8 g .. 8 g + 7
+//     of a 32-deep step) - no transposed reads; every wave reads all rows (24 KB per 48 rows and step);
+//   * accumulator rt, element r of lane (j, g) = row 16 rt + j, column 16 ws + 4 g + r: four ADJACENT columns of one row.
+// Images (pack_weights_kernel, one 64 KB block per 128 contraction indices): [output column c][contraction index i] fp16 high
+// parts, 256 B per column (32 KB), then the residuals (32 KB).  For a forward product the block is W^T (c = n, i = k: "T image"),
+// for dX = dY . W^T it is W itself (c = k, i = n: "N image").  Values are scaled by 2^HUAL_F16_WSCALE_LOG2 as in the LDS images.
+#define TF_BLOCK 65536
+struct TfW { f16x8 h[4], l[4]; };
+__device__ __forceinline__ f16x8 tf_ld16(const char* p) { return __builtin_bit_cast(f16x8, ld4_global(p)); }
+__device__ __forceinline__ void tf_load_w(TfW& w, const void* img, int ws, int lane) {
+  const char* p = reinterpret_cast<const char*>(img) + (16 * ws + (lane & 15)) * 256 + 16 * (lane >> 4);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    w.h[ks] = tf_ld16(p + 64 * ks);
+    w.l[ks] = tf_ld16(p + 32768 + 64 * ks);
+  }
+}
+// acc[rt] = (this wave's columns of) rows 16 rt .. 16 rt + 15 of the operand planes (hi at Ahi, lo at Ahi + ALO) . block
+template <int NT, int ALO>
+__device__ __forceinline__ void tf_mma(const char* Ahi, const TfW& w, int lane, f32x4 (&acc)[NT]) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int rt = 0; rt < NT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    f16x8 xh[NT], xl[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      const int off = tile256_off(16 * rt + j, 4 * ks + g);
+      xh[rt] = *reinterpret_cast<const f16x8*>(Ahi + off);
+      xl[rt] = *reinterpret_cast<const f16x8*>(Ahi + ALO + off);
+    }
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[ks], xh[rt], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[ks], xl[rt], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[ks], xh[rt], acc[rt], 0, 0, 0);
+    }
+  }
 }
 
 // row of the operand planes: scale to fp16 range, split, store (8 bytes per lane and plane); returns the inverse scale

@@ -192,7 +192,7 @@ def linear_bf16x3(A, W, bias=None, act=0, trans_w=False):
     M, K = A.shape
     N = W.shape[0] if trans_w else W.shape[1]
     Y = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    nbytes = ((N + 127) // 128) * 65536 if trans_w else K * 512
+    nbytes = ((N + 127) // 128) * 65536 if trans_w else ((K + 127) // 128) * 65536
     scratch = torch.zeros(nbytes, dtype=torch.uint8, device=A.device)
     check(load().hual_linear_bf16x3(ptr(A), A.stride(0), ptr(W), int(trans_w), ptr(bias), ptr(Y), Y.stride(0), M, K, N, act,
                                     ptr(scratch), nbytes, stream_ptr()))

@@ -232,7 +232,7 @@ int hual_predictor_bwd(const hual_cfg* cfg, const float* params, const hual_batc
 /* conv1d(kernel_size=1) == dense  (models/layers.py:20-29) on the 16-bit matrix cores with split operands (x = hi + lo, three
  * MFMA passes, fp32 accumulate; ~1e-6 relative to the fp32 product) - the kernel the model path uses for the dense layers outside
  * its fused kernels:
- *   trans_w = 0: Y[M,128] = act(A[M,K] . W[K,128] + bias), K % 8 == 0, act: 0 none, 1 relu; scratch >= K * 512 bytes
+ *   trans_w = 0: Y[M,128] = act(A[M,K] . W[K,128] + bias), K % 8 == 0, act: 0 none, 1 relu; scratch >= ceil(K/128) * 65536 bytes
  *   trans_w = 1: Y[M,N]   = A[M,128] . W^T with W stored [N,128] (dX of a dense layer), N % 8 == 0;
  *                scratch >= ceil(N/128) * 65536 bytes
  * scratch (device) receives the pre-split weight image. */
