@@ -251,9 +251,12 @@ def main():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # HUAL_DP_FORCE_COLLECTIVES=1: the multi-rank code path (RCCL group, data-parallel step, rccl block, MAX-reduce of the time)
+    # on however many ranks there are - one included (tests/test_gpu_dp.py runs it that way on a single GPU)
+    dp = world > 1 or os.environ.get('HUAL_DP_FORCE_COLLECTIVES') == '1'
+    if dp:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     from hual_amd import lib
     from hual_amd.model import SeqPAN
     from hual_amd.train import Trainer
@@ -263,12 +266,12 @@ def main():
     wv = np.random.default_rng(777).normal(0, 0.4, size=(num_words - 2, 300)).astype(np.float32)
     model = SeqPAN(cfg, wv, device=dev, seed=12345, rng_seed=12345 + rank)
     b = synth_batch(args.batch, args.T, args.L, args.C, args.vdim, num_words, num_chars, 12345 + rank)
-    trainer = Trainer(model, world=world, use_graph=not args.no_graph)
+    trainer = Trainer(model, world=world, use_graph=not args.no_graph, force_dp=dp)
     vdt = torch.bfloat16 if args.video_dtype == 'bf16' else torch.float32
     trainer.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'], video_dtype=vdt)
 
     def barrier():
-        if world > 1:
+        if dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -286,7 +289,7 @@ def main():
         trainer.step(lr=1e-4, drop_rate=args.drop)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -294,7 +297,7 @@ def main():
     clips = args.batch * world * args.steps
 
     rccl = None
-    if world > 1:
+    if dp:
         # the step's one collective of size: all-reduce(sum) of the flat fp32 gradient bucket, timed on its own
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(5):
@@ -531,7 +534,7 @@ def main():
         if rccl is not None:
             out['rccl'] = rccl
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         torch.distributed.destroy_process_group()
 
 

@@ -88,12 +88,15 @@ struct AlignPool {
   const float* F1;        // q2v_feats (v rows)
   const float* inner;     // [B,T] inner_labels (float)
   float* tpre; float* vpre;     // [B,128] pre-normalisation
-  float* that; float* vhat;     // [B,128] l2-normalised
+  float* that; float* vhat;     // [B,128] l2-normalised, rows of stride ld (256: side by side in ONE [B,256] buffer, the rows a
+  int ld;                       // data-parallel rank hands to the all-gather as they are)
 };
 // all-rows similarity part.  that/vhat: [Bg,128] (gathered over ranks); gradients for ALL rows are produced.
 struct AlignSim {
   const float* that; const float* vhat; int Bg;
   float* dq; float* da;         // [Bg,Bg] scratch
+  float* row_loss;              // optional [Bg]: the rows' loss terms go here and the column launch WRITES their sum (fixed order) to
+                                // loss_acc[LA_ALIGN]; null: every row adds its term to loss_acc[LA_ALIGN] (zeroed by the caller)
   float* dthat; float* dvhat;   // [nrows,128] written: gradient rows row0 .. row0 + nrows - 1
   float* loss_acc;
   float scale;                  // multiplies the gradients (world size in exact data-parallel mode)

@@ -490,8 +490,8 @@ __device__ __forceinline__ void align_pool_body(const AlignPool& a, const RowSpa
   if (grp == 0) {
     a.tpre[b * HUAL_D + c] = tp;
     a.vpre[b * HUAL_D + c] = vs;
-    a.that[b * HUAL_D + c] = tp * rsqrtf(fmaxf(tn, L2_EPS));
-    a.vhat[b * HUAL_D + c] = vs * rsqrtf(fmaxf(vn, L2_EPS));
+    a.that[(size_t)b * a.ld + c] = tp * rsqrtf(fmaxf(tn, L2_EPS));
+    a.vhat[(size_t)b * a.ld + c] = vs * rsqrtf(fmaxf(vn, L2_EPS));
   }
 }
 
@@ -532,7 +532,10 @@ __device__ __forceinline__ void align_sim_rows_body(const AlignSim& a, int i) {
   li = block_sum(li, sm);
   dotq = block_sum(dotq, sm);
   dota = block_sum(dota, sm);
-  if (tid == 0 && a.loss_acc) atomicAdd(a.loss_acc + LA_ALIGN, li);
+  if (tid == 0) {
+    if (a.row_loss) a.row_loss[i] = li;
+    else if (a.loss_acc) atomicAdd(a.loss_acc + LA_ALIGN, li);
+  }
   __syncthreads();
   for (int j = tid; j < Bg; j += 256) {
     const float lpv = sa[j] - lsa, lpq = sq[j] - lsq;
@@ -579,6 +582,11 @@ __global__ __launch_bounds__(256) void align_sim_cols_kernel(AlignSim a) {
   if (half) part[c] = s;
   __syncthreads();
   if (!half) a.dvhat[blockIdx.x * HUAL_D + c] += s + part[c];
+  if (a.row_loss && blockIdx.x == 0 && threadIdx.x == 0) {      // the loss: sum of the row terms in row order, written (no zeroing launch)
+    float l = 0.f;
+    for (int i = 0; i < Bg; ++i) l += a.row_loss[i];
+    a.loss_acc[LA_ALIGN] = l;
+  }
 }
 
 // per-clip forward kernels that only read cq.feats, in ONE launch: blockIdx.y = 0 weighted pooling (+ pooled . Wbot),
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(512) void pool_align_bwd_kernel(PoolArgs pa, PoolBw
 #pragma unroll
   for (int k = 0; k < KL; ++k) rF[k] = pa.F2[(qrow0 + min(grp + 4 * k, L - 1)) * HUAL_D + c];
   const float tp = ap.tpre[b * HUAL_D + c], vp = ap.vpre[b * HUAL_D + c];
-  const float th = ap.that[b * HUAL_D + c], vh = ap.vhat[b * HUAL_D + c];
+  const float th = ap.that[(size_t)b * ap.ld + c], vh = ap.vhat[(size_t)b * ap.ld + c];
   const float dth = ab.dthat[b * HUAL_D + c];
   float dvh = ab.dvhat[b * HUAL_D + c];
   const float wpc = pa.wp[c];
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(512) void pool_align_bwd_kernel(PoolArgs pa, PoolBw
     const int Bg = ab.col_Bg;
 #pragma unroll 4
     for (int i = grp; i < Bg; i += 4)
-      colsum += ab.col_dq[(size_t)i * Bg + b] * ap.that[(size_t)i * HUAL_D + c] + ab.col_da[(size_t)i * Bg + b] * ap.vhat[(size_t)i * HUAL_D + c];
+      colsum += ab.col_dq[(size_t)i * Bg + b] * ap.that[(size_t)i * ap.ld + c] + ab.col_da[(size_t)i * Bg + b] * ap.vhat[(size_t)i * ap.ld + c];
   }
   // ---- phase 1: workgroup sums.  dPW[c] = sum_t dFuse[t][c]; the column part; the six scalars of the two l2-normalisations
   float sdf = 0.f;

@@ -364,7 +364,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     fill_embed_args(c, ea, bt, cat, catw, char_arg, embed_scratch);
     PackExtra ex{};
     ex.lens = bt->video_seq_len; ex.word_ids = bt->word_ids; ex.rowmask = rowmask; ex.loss_acc = loss_acc; ex.B = B; ex.T = T; ex.L = L;
-    ex.zero_ptr = (lab && opt->grads_prezero) ? opt->grads_prezero : nullptr;
+    ex.zero_ptr = (lab && opt->grads_prezero && opt->prezero_token) ? opt->grads_prezero : nullptr;
     ex.zero_n = (size_t)((pm.total + 3) & ~(size_t)3);
     // the orthogonality term of the label embeddings depends on the parameters only: evaluated here (ortho.h)
     ex.E = lab ? c.p(pm.label_emb) : nullptr; ex.lambda = c.cfg->match_lambda; ex.dE_ortho = ortho_dE;
@@ -374,6 +374,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     ex.wall_K = c.wall_K; ex.wall_off = c.wall_off; ex.wall_boff = c.wall_boff;
     c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex,
                               c.PKT, c.want_bwd ? c.PKN : nullptr));
+    if (opt->prezero_token) *opt->prezero_token = (ex.zero_ptr && c.ok()) ? (uint64_t)(uintptr_t)ex.zero_ptr : 0;      // the receipt
   }
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
   c.stage(ST_INPUT);
@@ -557,7 +558,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   AlignPool ap{};
   ap.F2 = cqf; ap.F1 = cqf; ap.inner = (lab && !c.dry) ? lab->inner_labels : nullptr;
   ap.tpre = c.buf("align.tpre", B, D); ap.vpre = c.buf("align.vpre", B, D);
-  ap.that = c.buf("align.that", B, D); ap.vhat = c.buf("align.vhat", B, D);
+  ap.that = c.buf("align.tv", B, 2 * D); ap.vhat = ap.that + D; ap.ld = 2 * D;      // [that | vhat]: one [B,256] buffer
   if (c.live()) c.chk(launch_pool_align_fwd(pa, lab ? &ap : nullptr, c.rs, c.stream));
   float* fuse = c.actv("fuse");
   if (c.live()) {      // fuse = q2v_feats . W_top + b + (pooled . W_bot)[clip]   (layers.py:150-153)
@@ -585,7 +586,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* d_vhat = c.buf("d.align.vhat", B, D);
   float* align_scratch = c.buf("align.scratch", (size_t)2 * B, B);
   if (c.live()) {
-    AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, d_that, d_vhat, loss_acc, 1.0f, D, 0, B};
+    AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, nullptr, d_that, d_vhat, loss_acc, 1.0f, ap.ld, 0, B};
     c.chk(launch_match_fwd(ma, c.rs, (lab && !opt->align_external) ? &as : nullptr, c.stream));
   }
   // ---------------- conditioned predictor (modules.py:143-160)
@@ -708,8 +709,11 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   c.stage(ST_ALWAYS);
   // (a kernel, not hipMemsetAsync: memset nodes of a captured graph were seen to pick up the fill pattern of later eager
   //  memsets on this ROCm - every 4th gradient came back as the caller's learning rate)
-  if (c.live() && !(opt->grads_prezero && opt->grads_prezero == c.G && c.sel_stage < 0))
-    c.chk(launch_zero(c.G, pm.total, c.stream));
+  {      // the bucket was zeroed by the forward's first launch iff the caller's token says so (hual_run_opts.prezero_token)
+    const bool prezeroed = !c.dry && opt->prezero_token && *opt->prezero_token == (uint64_t)(uintptr_t)c.G && c.sel_stage < 0;
+    if (!c.dry && opt->prezero_token) *opt->prezero_token = 0;
+    if (c.live() && !prezeroed) c.chk(launch_zero(c.G, pm.total, c.stream));
+  }
   // every dX product reads the image of the transposed weight that forward's pack launch left in the workspace (PKB)
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
   c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
@@ -885,7 +889,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   AlignPool ap{};
   ap.F2 = cqf; ap.F1 = cqf; ap.inner = (c.dry || !lab) ? nullptr : lab->inner_labels;
   ap.tpre = c.buf("align.tpre", B, D); ap.vpre = c.buf("align.vpre", B, D);
-  ap.that = c.buf("align.that", B, D); ap.vhat = c.buf("align.vhat", B, D);
+  ap.that = c.buf("align.tv", B, 2 * D); ap.vhat = ap.that + D; ap.ld = 2 * D;      // [that | vhat]: one [B,256] buffer
   float* d_that = c.buf("d.align.that", B, D);
   float* d_vhat = c.buf("d.align.vhat", B, D);
   PoolArgs pa{};
@@ -1312,15 +1316,15 @@ int hual_adamw_clip_step_rng(float* params, const float* grads, float* adam_m, f
 int hual_align_loss(const float* that, const float* vhat, int Bg, float* scratch, float* d_that, float* d_vhat,
                     float* loss, float grad_scale, void* stream) {
   HUAL_REQUIRE(that && vhat && scratch && d_that && d_vhat && loss, "hual_align_loss: null pointer");
-  // loss accumulates into loss[0]: present it as an accumulator array whose LA_ALIGN slot is loss[0]
-  AlignSim as{that, vhat, Bg, scratch, scratch + (size_t)Bg * Bg, d_that, d_vhat, loss - LA_ALIGN, grad_scale, HUAL_D, 0, Bg};
+  // loss[0] is presented as the LA_ALIGN slot of an accumulator array; the row terms go through the tail of the scratch
+  AlignSim as{that, vhat, Bg, scratch, scratch + (size_t)Bg * Bg, scratch + (size_t)2 * Bg * Bg, d_that, d_vhat, loss - LA_ALIGN, grad_scale, HUAL_D, 0, Bg};
   return launch_align_sim(as, (hipStream_t)stream);
 }
 
 int hual_align_loss_rows(const float* that, const float* vhat, int ld, int Bg, int row0, int nrows, float* scratch, float* d_that,
                          float* d_vhat, float* loss, float grad_scale, void* stream) {
   HUAL_REQUIRE(that && vhat && scratch && d_that && d_vhat && loss, "hual_align_loss_rows: null pointer");
-  AlignSim as{that, vhat, Bg, scratch, scratch + (size_t)Bg * Bg, d_that, d_vhat, loss - LA_ALIGN, grad_scale, ld, row0, nrows};
+  AlignSim as{that, vhat, Bg, scratch, scratch + (size_t)Bg * Bg, scratch + (size_t)2 * Bg * Bg, d_that, d_vhat, loss - LA_ALIGN, grad_scale, ld, row0, nrows};
   return launch_align_sim(as, (hipStream_t)stream);
 }
 

@@ -59,6 +59,16 @@ def global_count(local_count, device):
     return float(t.item())
 
 
+def global_max(local_value):
+    """max of a python integer over ranks (host collective: set_batch's shape check)"""
+    t = torch.tensor([int(local_value)], dtype=torch.int64)
+    if world_size() > 1:
+        if dist.get_backend() == 'nccl':
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 def match_denominator(local_valid_frames, device):
     """denominator each rank must use for the masked matching loss (+1e-12 of layers.py:173 on the global count)"""
     w = world_size()

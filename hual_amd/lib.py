@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libhual_seqpan.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -46,7 +46,8 @@ class hual_outputs(ctypes.Structure):
 class hual_run_opts(ctypes.Structure):
     _fields_ = [('drop_rate', ctypes.c_float), ('rng_state', ctypes.c_void_p), ('match_denom_override', ctypes.c_float),
                 ('align_external', ctypes.c_int32), ('static_tables', ctypes.c_int32),
-                ('match_denom_dev', ctypes.c_void_p), ('debug_taps', ctypes.c_int32), ('grads_prezero', ctypes.c_void_p)]
+                ('match_denom_dev', ctypes.c_void_p), ('debug_taps', ctypes.c_int32), ('grads_prezero', ctypes.c_void_p),
+                ('prezero_token', ctypes.c_void_p)]
 
 
 class hual_al_set(ctypes.Structure):

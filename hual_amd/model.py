@@ -107,6 +107,9 @@ class SeqPAN:
 
     def tap(self, name):
         """fp32 view of a named intermediate in the workspace (debugging / parity tests)."""
+        if name in ('align.that', 'align.vhat'):      # the two halves of the [B,256] buffer the forward leaves side by side
+            tv = self.tap('align.tv')
+            return tv[:, :128] if name == 'align.that' else tv[:, 128:]
         off, rows, cols = self._ws_table[name]
         return self._ws[off:off + rows * cols * 4].view(torch.float32).view(rows, cols)
 

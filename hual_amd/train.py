@@ -5,6 +5,7 @@ Equivalent of the loop body of /root/reference/utils/runner_utils.py:144-147 (fe
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 import torch
@@ -19,6 +20,9 @@ class Trainer:
         self.world = world
         self.dp = world > 1 or force_dp          # force_dp: run the data-parallel code path on one rank (tests)
         self.use_graph = use_graph and not self.dp
+        self.dp_graph = use_graph and self.dp     # data-parallel step as a graph (nccl backend only, see _step_dp)
+        self._dp_graph_failed = False
+        self._prezero_token = ctypes.c_uint64(0)
         self.graph = None
         self.graph_drop = None
         self.shape = None
@@ -37,6 +41,10 @@ class Trainer:
         # end feed its last valid rows, so the results depend on the padded length) - hence T >= max(lens) there.
         if int(np.max(lens)) != T and not (self.dp and int(np.max(lens)) < T):
             raise ValueError('video T must equal max(video_seq_len) - model.py:31')
+        if self.dp and os.environ.get('HUAL_DP_SKIP_T_CHECK') != '1':
+            gmax = hdist.global_max(int(np.max(lens)))      # a shard padded beyond the global longest clip no longer reproduces model.py:31
+            if gmax != T:
+                raise ValueError('data parallel: T (%d) must equal the longest clip of the GLOBAL batch (%d) - model.py:31' % (T, gmax))
         shape = (B, T, L, C, video_dtype)
         if shape != self.shape:
             self.shape = shape
@@ -83,8 +91,7 @@ class Trainer:
         """static buffers of the data-parallel exchange: [that | vhat] of the local / all samples, the [Bg,Bg] scratch of the
         alignment loss, its value, and the device scalar holding the matching-loss denominator"""
         dev, Bg = self.m.device, B * self.world
-        self.align_scratch = torch.empty(2 * Bg * Bg, device=dev)
-        self.feat_local = torch.empty(B, 256, device=dev)
+        self.align_scratch = torch.empty(2 * Bg * Bg + Bg, device=dev)
         self.feat_all = torch.empty(Bg, 256, device=dev)
         self.align_loss = torch.zeros(1, device=dev)
         self.denom_dev = torch.zeros(1, device=dev)
@@ -108,7 +115,7 @@ class Trainer:
         m, dev = self.m, self.m.device
         B, T, V = feeds['video'].shape
         L, C = feeds['word_ids'].shape[1], feeds['char_ids'].shape[2]
-        self.use_graph, self.graph = False, None
+        self.use_graph, self.dp_graph, self.graph = False, False, None
         self._tables_ready = False
         self.video, self.lens, self.word_ids, self.char_ids = (feeds[k] for k in ('video', 'video_seq_len', 'word_ids', 'char_ids'))
         self.y1, self.y2, self.match, self.inner = (feeds[k] for k in ('y1', 'y2', 'match_labels', 'inner_labels'))
@@ -140,8 +147,9 @@ class Trainer:
                                  int(align_external),
                                  1 if (self._tables_ready and not os.environ.get('HUAL_NO_STATIC_TABLES')) else 0,
                                  lib.ptr(self.denom_dev).value if self.dp else None, 0,
-                                 # the forward's first launch zeroes the gradient bucket (one launch fewer in backward)
-                                 lib.ptr(self.m.grads).value)
+                                 # the forward's first launch zeroes the gradient bucket (one launch fewer in backward); the
+                                 # host word is the receipt the backward call checks and clears (hual_run_opts.prezero_token)
+                                 lib.ptr(self.m.grads).value, ctypes.addressof(self._prezero_token))
 
     def _forward(self, opts):
         m = self.m
@@ -177,9 +185,7 @@ class Trainer:
         m, B = self.m, self.shape[0]
         opts = self._opts(drop_rate, 1)
         self._forward(opts)
-        torch.cat([m.tap('align.that'), m.tap('align.vhat')], dim=1, out=self.feat_local)
-        hdist.allgather_rows_(self.feat_all, self.feat_local)
-        self.align_loss.zero_()
+        hdist.allgather_rows_(self.feat_all, m.tap('align.tv'))      # [that | vhat] rows as the forward left them: no copy
         fa = self.feat_all
         lib.check(self._lib.hual_align_loss_rows(
             lib.ptr(fa), ctypes.c_void_p(fa.data_ptr() + 128 * 4), 256, fa.shape[0], hdist.rank() * B if self.world > 1 else 0, B,
@@ -216,10 +222,12 @@ class Trainer:
         m.global_step += 1
 
     def _step_dp(self, drop_rate):
-        """HUAL_DP_GRAPH=1: the data-parallel step, RCCL collectives included, is captured once into a hipGraph and replayed
-        (only with the nccl backend, whose collectives are stream operations).  Default: eager launch - measured on one rank
-        within 0.5 % of the replayed graph (the chain is GPU bound), and it does not depend on graph capture of RCCL."""
-        want_graph = os.environ.get('HUAL_DP_GRAPH') == '1' and self.world >= 1 and hdist.backend() == 'nccl'
+        """With the nccl backend (RCCL: its collectives are stream operations) the data-parallel step, collectives included, is
+        captured once into a hipGraph and replayed; HUAL_DP_GRAPH=0 or a failed capture falls back to the eager launch of the
+        same sequence (the failed capture has executed nothing: the step then runs eagerly from the restored state).  Other
+        backends (gloo: host collectives) always launch eagerly."""
+        want_graph = (os.environ.get('HUAL_DP_GRAPH', '1') != '0' and self.dp_graph and not self._dp_graph_failed
+                      and hdist.backend() == 'nccl')
         if not want_graph:
             self._enqueue_dp(drop_rate)
             return
@@ -231,9 +239,17 @@ class Trainer:
             for t, sn in zip((m.params, m.adam_m, m.adam_v, m.rng_state), snap):
                 t.copy_(sn)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue_dp(drop_rate)
+            except Exception as e:                   # capture of the collectives refused: eager from here on
+                self._dp_graph_failed = True
+                self.graph = None
+                torch.cuda.synchronize()
+                print('[hual] data-parallel step: graph capture failed (%s) - eager launches' % (str(e).splitlines()[0],), file=sys.stderr)
                 self._enqueue_dp(drop_rate)
+                return
             self.graph, self.graph_drop = g, drop_rate
         self.graph.replay()
 

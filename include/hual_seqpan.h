@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HUAL_ABI_VERSION 4
+#define HUAL_ABI_VERSION 5
 
 #define HUAL_OK 0
 #define HUAL_ERR_INVALID (-1)
@@ -136,9 +136,13 @@ typedef struct hual_run_opts {
   int32_t debug_taps;             /* 1: the forward also writes the tensors that only parity tests read (the relu outputs of the
                                         conv_block layers, "cb.y*" / "fe*.y*" of the workspace table); the backward pass never
                                         reads them (it reads the bit planes "*.rb*" / "*.kb*") */
-  float* grads_prezero;           /* non-NULL, hual_seqpan_forward with labels: this flat gradient buffer is zeroed by the
-                                        forward's first launch; a hual_seqpan_backward call given the same pointer here and as
-                                        its `grads` then skips its own zeroing launch (one launch fewer per step) */
+  float* grads_prezero;           /* non-NULL together with prezero_token, hual_seqpan_forward with labels: this flat gradient
+                                        buffer is zeroed by the forward's first launch (one launch fewer per step) */
+  uint64_t* prezero_token;        /* HOST word owned by the caller, the receipt of that zeroing: the forward stores the address of
+                                        the buffer it zeroed there once the launch is enqueued; hual_seqpan_backward skips its own
+                                        zeroing launch only if the word holds the address of its `grads`, and clears it.  Any
+                                        sequence that breaks the pairing (two backward calls, a forward that failed or had no
+                                        labels) therefore zeroes the bucket in backward as before.  NULL: no pre-zeroing. */
 } hual_run_opts;
 
 /* bytes of workspace needed for one forward(+backward) of this shape */
@@ -178,12 +182,13 @@ int hual_adamw_clip_step_rng(float* params, const float* grads, float* adam_m, f
                              uint32_t* rng_state, void* stream);
 
 /* cross-sample part of lossfun_aligment (layers.py:232-247) on [Bg,128] l2-normalised features
- * (all-gathered over ranks in exact data-parallel mode).  scratch: 2*Bg*Bg floats.
- * Writes d_that / d_vhat [Bg,128] (scaled by grad_scale) and ADDS the loss to *loss (device scalar). */
+ * (all-gathered over ranks in exact data-parallel mode).  scratch: 2*Bg*Bg + Bg floats.
+ * Writes d_that / d_vhat [Bg,128] (scaled by grad_scale) and WRITES the loss to *loss (device scalar: the row terms are summed
+ * in row order by the second launch - no zeroing launch in front, no atomics). */
 int hual_align_loss(const float* that, const float* vhat, int Bg, float* scratch, float* d_that, float* d_vhat,
                     float* loss, float grad_scale, void* stream);
 /* the same for a rank of a data-parallel group: that / vhat are rows of stride `ld` floats (256 when the all-gather left
- * [that | vhat] side by side), and only the gradient rows row0 .. row0 + nrows - 1 (the rank's own samples) are written,
+ * [that | vhat] side by side - the layout of the workspace buffer "align.tv" [B,256] the forward leaves), and only the gradient rows row0 .. row0 + nrows - 1 (the rank's own samples) are written,
  * to d_that / d_vhat [nrows,128] - straight into the workspace buffers "d.align.that" / "d.align.vhat" of the backward. */
 int hual_align_loss_rows(const float* that, const float* vhat, int ld, int Bg, int row0, int nrows, float* scratch, float* d_that,
                          float* d_vhat, float* loss, float grad_scale, void* stream);

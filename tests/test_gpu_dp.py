@@ -31,7 +31,7 @@ def _dp_run(monkeypatch, graph, steps=3, sync_check=False):
     feeds = (b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(), *[x.numpy() for x in labels])
     m = pu.hip_model(cfg, p, wv)
     m.set_rng(7, 3)
-    tr = Trainer(m, world=1, use_graph=False, force_dp=True)
+    tr = Trainer(m, world=1, use_graph=graph, force_dp=True)      # graph: the default with the nccl backend
     tr.set_batch(*feeds)
     tr.step(lr=1e-4, drop_rate=0.2)                  # first step: allocations, RCCL channel setup, (graph capture)
     torch.cuda.synchronize()
@@ -56,7 +56,7 @@ def test_dp_step_enqueues_without_host_synchronisation(rccl_group, monkeypatch):
 
 
 def test_dp_step_captured_as_graph_matches_eager(rccl_group, monkeypatch):
-    """HUAL_DP_GRAPH=1: the whole data-parallel step with its RCCL collectives replayed as one hipGraph"""
+    """the default with the nccl backend: the whole data-parallel step with its RCCL collectives replayed as one hipGraph"""
     l0, p0, _ = _dp_run(monkeypatch, graph=False)
     l1, p1, tr = _dp_run(monkeypatch, graph=True, sync_check=True)
     assert tr.graph is not None
@@ -89,3 +89,26 @@ def test_dp_path_on_one_rank_matches_single_path(rccl_group):
         np.testing.assert_allclose(l0[1:], l1[1:], rtol=2e-4, atol=2e-4)
         assert np.abs(g0 - g1).max() <= 1e-4 * max(1.0, np.abs(g0).max())
         assert np.abs(p0 - p1).max() < 5e-4      # Adam's first steps move every weight by ~3e-4 at lr 1e-4
+
+
+def test_bench_multi_rank_path_on_one_rank(tmp_path):
+    """bench.py's N > 1 code path - RCCL process group, data-parallel step (captured with its collectives), the timed all-reduce
+    of the gradient bucket, MAX-reduce of the elapsed time - on a 1-rank nccl group (HUAL_DP_FORCE_COLLECTIVES=1)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HUAL_DP_FORCE_COLLECTIVES='1', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(29900 + os.getpid() % 90))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--batch', '8', '--T', '32', '--L', '8', '--C', '5',
+                        '--vdim', '256', '--steps', '4', '--warmup', '1', '--prewarm', '2', '--no-cpu-baseline', '--no-roofline'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 1 and out['value'] > 0 and out['steps'] == 4
+    assert out['config']['parallelism'] == 'dp1'
+    rc = out['rccl']
+    assert rc['rccl_ranks'] == 1 and rc['backend'] == 'nccl' and rc['allreduce_us'] > 0
+    assert rc['step_launch'].startswith('hipGraph')          # the captured data-parallel step is the default with nccl
+    assert np.isfinite(out['config']['final_loss'])

@@ -18,7 +18,9 @@ def test_train_steps_match_oracle(use_graph, nsteps):
     from the same state with the ReLU active sets of that HIP forward (parity_util.relu_pins, audited), so loss, spans and
     parameters are comparable tightly at EVERY step of the trajectory (the free-running comparison is the next test)"""
     from hual_amd.train import Trainer
-    lr, drop, seed, off = 1e-3, 0.2, 99, 5
+    # the short run uses a 10x learning rate; the long one the reference's (configs/*/SeqPAN.yaml: 1e-4) - at 1e-3 this tiny batch
+    # diverges (loss 10 -> 130 within 15 steps) and ill-conditioned pre-activations then sit within rounding of the ReLU kink
+    lr, drop, seed, off = (1e-3 if nsteps <= 3 else 1e-4), 0.2, 99, 5
     cfg, p, wv, b, labels = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
     B, T, L = 4, 24, 7
     m = pu.hip_model(cfg, p, wv)
@@ -133,3 +135,28 @@ def test_weight_decay_mask_and_clip_on_device():
     exp = p0 - 0.5 * upd
     assert float((m.params - exp).abs().max()) < 5e-5
     assert float((m.adam_m - nm).abs().max()) < 1e-7
+
+
+def test_backward_zeroes_the_bucket_unless_the_forward_left_a_receipt():
+    """hual_run_opts.prezero_token: the forward's first launch zeroes the gradient bucket and leaves a host-side receipt; a second
+    backward call on the same forward finds no receipt and zeroes the bucket itself - gradients are not accumulated twice"""
+    from hual_amd.train import Trainer
+    cfg, p, wv, b, labels = pu.make_case(B=3, T=20, L=6, C=5, seed=5)
+    feeds = (b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(), *[x.numpy() for x in labels])
+    m = pu.hip_model(cfg, p, wv)
+    m.set_rng(3, 1)
+    tr = Trainer(m, world=1, use_graph=False)
+    tr.set_batch(*feeds)
+    opts = tr._opts(0.1, 0)
+    m.grads.fill_(7.0)                               # garbage the forward has to clear
+    tr._forward(opts)
+    assert tr._prezero_token.value == m.grads.data_ptr()
+    tr._backward(opts)
+    assert tr._prezero_token.value == 0
+    g1 = m.grads.detach().clone()
+    tr._backward(opts)                               # no receipt: zeroes, then accumulates the same gradient again
+    g2 = m.grads.detach().clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) < 1e3
+    scale = float(g1.abs().max())
+    assert float((g1 - g2).abs().max()) <= 1e-5 * scale      # (atomics: the summation order differs between the two launches)
