@@ -41,6 +41,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 #define HUAL_F16_WSCALE_LOG2 10
 #define HUAL_F16_WSCALE 1024.0f
+#define HUAL_F16_WMAX 63.0f              // |w| beyond this does not fit the scaled fp16 image (65504 / 1024): flagged by the pack launch
 
 __device__ __forceinline__ void f16_split_pair(float x0, float x1, uint32_t& hi, uint32_t& lo) {
   const f16x2_t h = __builtin_convertvector((f32x2_t){x0, x1}, f16x2_t);          // round to nearest even

@@ -30,7 +30,7 @@ struct CqBufs {
 
 int cq_padded(int n);      // rows padded to a multiple of 16
 int launch_tri_prep(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
-int launch_cq_fwd(const CqBufs& b, const RowSpace& rs, hipStream_t s);
+int launch_cq_fwd(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s);      // tri_prep included
 
 struct CqBwdBufs {
   const float* dCat; int ldcat;   // [R,512]: gradient wrt [x1, c2q, x1*c2q, x1*q2c]

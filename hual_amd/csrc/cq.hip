@@ -278,7 +278,10 @@ __device__ __forceinline__ void cq_rows_store(const CqRows& r, float* bufA, int 
   }
 }
 
-__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b, RowSpace rs) {
+// (the tri_prep step - dropout on both roles of a row, the rank-1 terms, ops.py:104-114 - happens here on the rows as they are
+//  staged: in direction `dir` the x1 rows of the clip get their D1W / S0, the x2 rows their D2 / S1, so over the two directions
+//  every row is prepared exactly once in each role; the prepared rows are also written out for the backward pass)
+__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b, CqParams p, RowSpace rs, DropCfg drop) {
   extern __shared__ float lds[];
   const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
   if (clip >= rs.B) return;
@@ -300,19 +303,41 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const int nj = c.N2p >> 4, ni = c.N1p >> 4;
   CQ_STAMP(0);
-  // ---- stage D1W / D2, masks and rank-1 terms: one round trip
+  // ---- stage the rows (X1, X2) and the masks: one round trip; D1W / D2 and the rank-1 terms are formed from the rows in registers
   CqRows rows, xrows;
-  cq_rows_load(rows, b.D1W + (size_t)c.x1base * HUAL_D, c.N1, c.N1p, b.D2 + (size_t)c.x2base * HUAL_D, c.N2, c.N2p);
-  cq_rows_load(xrows, X1, c.N1, c.N1p, X2, c.N2, c.N2p);      // needed after the score: arrives under it
+  cq_rows_load(xrows, X1, c.N1, c.N1p, X2, c.N2, c.N2p);
   {
     const int idx = threadIdx.x;
     if (idx < c.N1p + c.N2p) {
       const bool first = idx < c.N1p;
       const int k = first ? idx : idx - c.N1p, n = first ? c.N1 : c.N2, base = first ? c.x1base : c.x2base;
-      const float mk = k < n ? rs.rowmask[base + k] : 0.f;
-      const float sv = k < n ? (first ? b.S0[base + k] : b.S1[base + k]) : 0.f;
-      m1[idx] = mk;                      // (m2 follows m1, s1 follows s0)
-      s0[idx] = sv;
+      m1[idx] = k < n ? rs.rowmask[base + k] : 0.f;      // (m2 follows m1)
+    }
+  }
+  {
+    const uint32_t site1 = (uint32_t)HUAL_SITE_TRI + (dir == 0 ? 0u : 2u), site2 = (uint32_t)HUAL_SITE_TRI + (dir == 0 ? 1u : 3u);
+    const int c4 = threadIdx.x & 31;
+    const float4 w0 = ld4(p.w0[dir] + 4 * c4), wm = ld4(p.wm[dir] + 4 * c4), w1 = ld4(p.w1[dir] + 4 * c4);
+#pragma unroll
+    for (int u = 0; u < CQ_STAGE_MAX; ++u) {
+      const int idx = threadIdx.x + CQ_MAX_THREADS * u, row = idx >> 5;
+      const bool first = row < c.N1p;
+      const int k = first ? row : row - c.N1p;
+      const bool live = first ? k < c.N1 : k < c.N2;
+      const int grow = (first ? c.x1base : c.x2base) + (live ? k : 0);      // unified row (dropout counter, destination)
+      float4 x = xrows.v[u];
+      if (drop.enabled) x = apply_drop4(drop, first ? site1 : site2, (uint32_t)grow, (uint32_t)c4, x);
+      const float4 w = first ? w0 : w1;
+      const float sv = half_sum32(x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w);
+      const float4 o = first ? make_float4(x.x * wm.x, x.y * wm.y, x.z * wm.z, x.w * wm.w) : x;
+      rows.v[u] = o;
+      if (row < c.N1p + c.N2p) {
+        if (c4 == 0) s0[row] = live ? sv : 0.f;          // (s1 follows s0)
+        if (live) {
+          st4((first ? b.D1W : b.D2) + (size_t)grow * HUAL_D + 4 * c4, o);
+          if (c4 == 0) (first ? b.S0 : b.S1)[grow] = sv;
+        }
+      }
     }
   }
   cq_rows_store(rows, bufA, c.N1p, bufB, c.N2p);
@@ -907,13 +932,17 @@ static bool cq_staged_ok(const RowSpace& rs, int nmats) {
   return (cq_padded(rs.T) + cq_padded(rs.L)) * 32 <= CQ_STAGE_MAX * CQ_MAX_THREADS && cq_staged_bytes(rs, nmats) <= 160 * 1024;
 }
 
-int launch_cq_fwd(const CqBufs& b, const RowSpace& rs, hipStream_t s) {
+// tri_prep (dropout on both roles of every row, rank-1 terms) + the attention itself: one launch when the clip fits the staged
+// kernel (it prepares the rows as it stages them), else two
+int launch_cq_fwd(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   if (cq_staged_ok(rs, 3)) {
     HUAL_DYN_LDS(cq_fwd_staged_kernel, 160 * 1024);
-    HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_staged_kernel, dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 3), s, b, rs);
+    HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_staged_kernel, dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 3), s, b, p, rs, drop);
     HUAL_CHECK_HIP(hipGetLastError());
     return 0;
   }
+  int rc = launch_tri_prep(b, p, rs, drop, s);
+  if (rc) return rc;
   const int bytes = cq_lds_bytes(rs, 3);
   HUAL_REQUIRE(bytes <= 160 * 1024, "cq_fwd: T x L score matrix does not fit LDS");
   HUAL_DYN_LDS(cq_fwd_kernel, 160 * 1024);

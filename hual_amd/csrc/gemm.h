@@ -51,7 +51,13 @@ struct PackExtra {
   // image goes to fwd + wall_off * 4, the image of its transpose to bwd + wall_boff
   int gather_tasks; int gather_rows; EmbedArgs emb; DropCfg drop;
   int wall_K; uint32_t wall_off, wall_boff;
+  // optional: one word per workgroup of the job rows, [job][x] with stride ovf_stride: 1 when a weight of its 16 K rows has a
+  // magnitude the scaled fp16 image cannot hold (|w| >= HUAL_F16_WMAX, or NaN) - every word is written, no zeroing needed;
+  // the loss launch turns any set word into a NaN loss (heads.h LossTailArgs)
+  uint32_t* ovf; int ovf_stride;
 };
+#define HUAL_MAX_PACK 96                 // jobs of one pack launch
+inline int pack_ovf_stride(int maxK) { return ((maxK + 127) & ~127) / 16; }
 // timg / nimg (optional): images for the register-resident weights of the T-form kernels (tilecore.h), blocks of 64 KB at boffs[]
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
                         hipStream_t stream, const PackExtra* extra = nullptr, char* timg = nullptr, char* nimg = nullptr);

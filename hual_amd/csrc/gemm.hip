@@ -160,7 +160,6 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
 //                                   (rows kk, columns c; zero where 128b + c >= K)
 // perm(s) = 64 (s>>6) + 4 (s&15) + ((s>>4)&3): stored column 16 t + i of a 64-column half is original column 4 i + t.
 struct PackJob { uint32_t off; int K; uint32_t boff; };
-#define HUAL_MAX_PACK 96
 struct PackBatch { PackJob j[HUAL_MAX_PACK]; };
 __device__ __forceinline__ int pack_perm(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
 __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* bwd, char* timg, char* nimg, int njobs, PackExtra ex) {
@@ -189,16 +188,23 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
   }
   const PackJob job = b.j[blockIdx.y];
   const int k0 = blockIdx.x * 16;
-  if (k0 >= ((job.K + 127) & ~127)) return;          // block-uniform
+  uint32_t* ovf = ex.ovf ? ex.ovf + (size_t)blockIdx.y * ex.ovf_stride + blockIdx.x : nullptr;
+  if (k0 >= ((job.K + 127) & ~127)) {                // block-uniform
+    if (ovf && threadIdx.x == 0 && (int)blockIdx.x < ex.ovf_stride) *ovf = 0u;
+    return;
+  }
   const float* W = P + job.off;
   const bool virt = ex.wall_K > 0 && job.off == ex.wall_off;      // the char-CNN filter bank: elements from the four filters
+  bool bad = false;
   for (int idx = threadIdx.x; idx < 16 * 128; idx += 256) {
     const int r = idx >> 7, n = idx & 127;
     float v = 0.f;
     if ((k0 + r) < job.K) v = virt ? wall_value(ex.emb.filt, ex.emb.char_dim, ex.wall_K / 4, k0 + r, n) : W[(size_t)(k0 + r) * 128 + n];
+    bad |= !(fabsf(v) < HUAL_F16_WMAX);              // (NaN included)
     tile[r][n] = v;
   }
-  __syncthreads();
+  const int anybad = __syncthreads_or(bad ? 1 : 0);
+  if (ovf && threadIdx.x == 0) *ovf = anybad ? 1u : 0u;
   // forward image: 16 rows x 64 column pairs
   if (fwd) {
     char* img = fwd + (size_t)job.off * 4;
@@ -592,6 +598,8 @@ int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* bof
     }
     const bool with_extra = extra && base == 0;
     if (with_extra) ex = *extra;
+    HUAL_REQUIRE(!(ex.ovf && n > HUAL_MAX_PACK), "pack: the overflow words cover one batch of jobs");
+    HUAL_REQUIRE(!ex.ovf || ex.ovf_stride >= maxK / 16, "pack: overflow word stride");
     const int gx = maxK / 16;
     const int grows = (with_extra && ex.gather_tasks > 0) ? cdiv(ex.gather_tasks, gx * 256) : 0;      // rows of workgroups of the gather
     HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(gx, cnt + (with_extra ? 1 + grows : 0)),

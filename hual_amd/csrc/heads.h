@@ -79,6 +79,7 @@ int launch_heads(const HeadsArgs& a, int B, int T, hipStream_t s);
 struct LossTailArgs {
   float* loss_acc; const float* match_part; int match_nblk; const float* loc_part; int loc_nblk;
   float lambda, override_denom; const float* denom_dev; float* loss_out;
+  const uint32_t* ovf; int novf;      // optional: the pack launch's overflow words (gemm.h PackExtra): any set -> the losses are NaN
 };
 int launch_loss_tail(const LossTailArgs& a, hipStream_t s);
 

@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256) void loss_tail_kernel(LossTailArgs a) {
   float cs = 0.f, ms = 0.f, ls = 0.f;
   for (int i = tid; i < a.match_nblk; i += 256) { cs += a.match_part[2 * i]; ms += a.match_part[2 * i + 1]; }
   for (int i = tid; i < a.loc_nblk; i += 256) ls += a.loc_part[i];
+  int bad = 0;
+  for (int i = tid; i < a.novf; i += 256) bad |= a.ovf[i] != 0u;
+  bad = __syncthreads_or(bad);
   block_sum3(cs, ms, ls, sm);
   if (tid == 0) {
     float* la = a.loss_acc;
@@ -453,10 +456,12 @@ __global__ __launch_bounds__(256) void loss_tail_kernel(LossTailArgs a) {
     if (a.loss_out) {
       const float match = cs / denom + la[LA_ORTHO];
       const float align = la[LA_ALIGN];
-      a.loss_out[0] = ls + a.lambda * match + align;
-      a.loss_out[1] = ls;
-      a.loss_out[2] = match;
-      a.loss_out[3] = align;
+      // a dense weight outside the range of the scaled fp16 images (|w| >= 63): the products of this step are not to be trusted
+      const float poison = bad ? __builtin_nanf("") : 0.f;
+      a.loss_out[0] = ls + a.lambda * match + align + poison;
+      a.loss_out[1] = ls + poison;
+      a.loss_out[2] = match + poison;
+      a.loss_out[3] = align + poison;
     }
   }
 }

@@ -49,7 +49,9 @@ struct LnBwd {
   int split; const float* g1_hi;
 };
 int ln_bwd_blocks(int R);
-int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s);
+struct PosBwdJob;
+// pos / npos / rs (optional): position-table jobs (below) that ride in the same launch
+int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s, const PosBwdJob* pos = nullptr, int npos = 0, const RowSpace* rs = nullptr);
 
 // dst[v][c] += sum_blk src[(blk*nvec + v)*128 + c] for the per-block partial sums left by the backward kernels.
 // All jobs of a backward pass go into ONE launch at its end.

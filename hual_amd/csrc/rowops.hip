@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd a, RowSpace rs, DropC
 
 // ------------------------------------------------------------------------------------------------------
 // LN backward.  For y = xhat*g + b:  gv = dy*g ;  dx = rstd * (gv - mean(gv) - xhat * mean(gv*xhat))
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) {
+// (ngrid = workgroups of the layer-norm part of the launch)
+__device__ __forceinline__ void ln_bwd_body(const LnBwd& a, const DropCfg& drop, int ngrid) {
   __shared__ float4 red[4][8][32];
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) {
   const int nlo = a.split > 0 ? (a.split + 31) / 32 : 0;
   const bool hi = a.split > 0 && (int)blockIdx.x >= nlo;
   const int row_lo = hi ? a.split : 0, row_hi = (a.split > 0 && !hi) ? a.split : a.R;
-  const int bid = hi ? (int)blockIdx.x - nlo : (int)blockIdx.x, nblk = a.split > 0 ? (hi ? (int)gridDim.x - nlo : nlo) : (int)gridDim.x;
+  const int bid = hi ? (int)blockIdx.x - nlo : (int)blockIdx.x, nblk = a.split > 0 ? (hi ? ngrid - nlo : nlo) : ngrid;
   const float4 g1 = ld4((hi ? a.g1_hi : a.g1) + col);
   const float4 g2 = a.dy2 ? ld4(a.g2 + col) : f4zero();
   for (int row = row_lo + bid * 8 + grp; row < row_hi; row += nblk * 8) {
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) {
     if (dst) atomicAdd(dst + c, s);
   }
 }
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) { ln_bwd_body(a, drop, (int)gridDim.x); }
 
 // ------------------------------------------------------------------------------------------------------
 struct ColsumBatch { ColsumJob j[HUAL_COLSUM_MAX_JOBS]; };
@@ -143,27 +145,40 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch batch) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void pos_bwd_kernel(PosBwdBatch batch, RowSpace rs) {
-  __shared__ float part[4][HUAL_D];
-  const PosBwdJob& job = batch.j[blockIdx.y];
-  const int t = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
+// NG = groups of 128 threads; (t, jb) = position, job of the workgroup
+template <int NG>
+__device__ __forceinline__ void pos_bwd_body(const PosBwdBatch& batch, const RowSpace& rs, int t, int jb) {
+  __shared__ float part[NG][HUAL_D];
+  const PosBwdJob& job = batch.j[jb];
+  const int c = threadIdx.x & 127, grp = threadIdx.x >> 7;
   float s = 0.f;
   for (int k = 0; k < 2; ++k) {
     const float* dx = job.dx[k];
     if (!dx) continue;
     if (job.do_v && t < rs.T) {
 #pragma unroll 8
-      for (int b = grp; b < rs.B; b += 4) s += dx[(size_t)(b * rs.T + t) * HUAL_D + c];
+      for (int b = grp; b < rs.B; b += NG) s += dx[(size_t)(b * rs.T + t) * HUAL_D + c];
     }
     if (job.do_q && t < rs.L) {
 #pragma unroll 8
-      for (int b = grp; b < rs.B; b += 4) s += dx[(size_t)(rs.Nv + b * rs.L + t) * HUAL_D + c];
+      for (int b = grp; b < rs.B; b += NG) s += dx[(size_t)(rs.Nv + b * rs.L + t) * HUAL_D + c];
     }
   }
   part[grp][c] = s;
   __syncthreads();
-  if (grp == 0 && ((job.do_v && t < rs.T) || (job.do_q && t < rs.L)))
-    job.dpos[(size_t)t * HUAL_D + c] += part[0][c] + part[1][c] + part[2][c] + part[3][c];
+  if (grp == 0 && ((job.do_v && t < rs.T) || (job.do_q && t < rs.L))) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) tot += part[k][c];
+    job.dpos[(size_t)t * HUAL_D + c] += tot;
+  }
+}
+__global__ __launch_bounds__(512) void pos_bwd_kernel(PosBwdBatch batch, RowSpace rs) { pos_bwd_body<4>(batch, rs, blockIdx.x, blockIdx.y); }
+// a layer-norm backward and position-table jobs that read the same gradient tensor, one launch: workgroups [0, nln) the former,
+// the rest the latter (npos positions per job)
+__global__ __launch_bounds__(256) void ln_pos_bwd_kernel(LnBwd a, DropCfg drop, PosBwdBatch batch, RowSpace rs, int nln, int npos) {
+  if ((int)blockIdx.x < nln) ln_bwd_body(a, drop, nln);
+  else pos_bwd_body<2>(batch, rs, ((int)blockIdx.x - nln) % npos, ((int)blockIdx.x - nln) / npos);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -191,7 +206,7 @@ int launch_ln_fwd(const LnFwd& a, const RowSpace& rs, const DropCfg& drop, hipSt
 
 int ln_bwd_blocks(int R) { return cdiv(R, 32); }     // 4 rows per 32-lane group
 
-int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s) {
+int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s, const PosBwdJob* pos, int npos, const RowSpace* rs) {
   HUAL_REQUIRE(a.x && a.mean && a.rstd && a.dy1 && a.g1 && a.dx && a.R > 0, "ln_bwd: null/empty");
   int g = cdiv(a.R, 8);
   g = g < 128 ? g : 128;     // every block ends with 256-512 same-address float atomics: keep the count low
@@ -200,7 +215,21 @@ int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s) {
     HUAL_REQUIRE(a.part && a.g1_hi && a.split < a.R && !a.dy2, "ln_bwd: split needs part, g1_hi, one layer norm");
     g = ln_bwd_blocks(a.split) + ln_bwd_blocks(a.R - a.split);
   }
-  HUAL_LAUNCH(0.0, 12.0 * a.R * HUAL_D, ln_bwd_kernel, dim3(g), dim3(256), 0, s, a, drop);
+  if (npos > 0) {
+    HUAL_REQUIRE(pos && rs && npos <= HUAL_POS_MAX_JOBS, "ln_bwd: position-table jobs");
+    PosBwdBatch b;
+    ::memset((void*)&b, 0, sizeof(b));
+    int n = 0;
+    for (int i = 0; i < npos; ++i) {
+      HUAL_REQUIRE(pos[i].dx[0] && pos[i].dpos, "pos_bwd: null tensor");
+      b.j[i] = pos[i];
+      if (pos[i].do_v && rs->T > n) n = rs->T;
+      if (pos[i].do_q && rs->L > n) n = rs->L;
+    }
+    HUAL_LAUNCH(0.0, 12.0 * a.R * HUAL_D, ln_pos_bwd_kernel, dim3(g + n * npos), dim3(256), 0, s, a, drop, b, *rs, g, n);
+  } else {
+    HUAL_LAUNCH(0.0, 12.0 * a.R * HUAL_D, ln_bwd_kernel, dim3(g), dim3(256), 0, s, a, drop);
+  }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

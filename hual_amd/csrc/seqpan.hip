@@ -83,6 +83,7 @@ struct Ctx {
   float* act(const std::string& name) { return buf(name, (size_t)rs.R, HUAL_D); }     // [R,128]
   // bit plane of a [rows,128] tensor (csrc/tilecore.h): 16 bytes per row
   uint8_t* bits(const std::string& name, size_t rows) { return reinterpret_cast<uint8_t*>(buf(name, rows, 4)); }
+  int novf = 0;               // words of "params.ovf" the loss launch reads
   bool debug_taps = false;    // hual_run_opts.debug_taps: also write the tensors only parity tests read (conv_block relu outputs)
   float* actv(const std::string& name) { return buf(name, (size_t)rs.Nv, HUAL_D); }   // [Nv,128]
   float* vec(const std::string& name) { return buf(name, (size_t)rs.R, 1); }
@@ -114,7 +115,7 @@ struct Ctx {
     if (live()) chk(launch_ln_bwd(a, drop, stream));
   }
   // the two input layer norms (rows below / from a.split on) in one launch: two reductions of the partial sums
-  void ln_bwd_split(const LnBwd& a0, float* dg_lo, float* db_lo, float* dg_hi, float* db_hi) {
+  void ln_bwd_split(const LnBwd& a0, float* dg_lo, float* db_lo, float* dg_hi, float* db_hi, const PosBwdJob* pos = nullptr, int npos = 0) {
     LnBwd a = a0;
     const int nlo = ln_bwd_blocks(a.split), nhi = ln_bwd_blocks(a.R - a.split);
     a.part = buf("part." + std::to_string(part_seq++), (size_t)(nlo + nhi) * 4, HUAL_D);
@@ -125,7 +126,7 @@ struct Ctx {
     cj.src = a.part + (size_t)nlo * 4 * HUAL_D; cj.nblk = nhi;
     cj.dst[0] = dg_hi; cj.dst[1] = db_hi;
     if (active) colsum.push_back(cj);
-    if (live()) chk(launch_ln_bwd(a, drop, stream));
+    if (live()) chk(launch_ln_bwd(a, drop, stream, pos, npos, &rs));
   }
   // fused dX products + layer norm(s) backward (dablock.h); the per-workgroup parameter sums are folded in by flush_colsum()
   void ln_proj_bwd(const LnProjBwdArgs& a0, float* dg1, float* db1, float* dg2, float* db2) {
@@ -351,6 +352,14 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   c.PKT = reinterpret_cast<char*>(c.buf("params.pkt", (c.pk_bytes + 3) / 4, 1));
   c.PKN = reinterpret_cast<char*>(c.buf("params.pkn", (c.pk_bytes + 3) / 4, 1));
   float* ortho_dE = c.buf("ortho.dE", 4, HUAL_D);
+  // one word per workgroup of the pack launch's job rows: set when a weight does not fit the scaled fp16 images (gemm.h PackExtra);
+  // the loss launch reads them
+  int pk_maxK = c.wall_K;
+  for (const auto& d : c.dense) pk_maxK = d.K > pk_maxK ? d.K : pk_maxK;
+  const int ovf_stride = pack_ovf_stride(pk_maxK);
+  const int npack = (int)c.dense.size() + 1;
+  uint32_t* ovf = reinterpret_cast<uint32_t*>(c.buf("params.ovf", (size_t)npack * ovf_stride, 1));
+  c.novf = npack <= HUAL_MAX_PACK ? npack * ovf_stride : 0;
   // (the text encoder's gather - word / char lookups with their dropout, model.py:36-41 - rides in the same launch)
   float* cat = c.buf("cat", Nq, catw);
   int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
@@ -372,6 +381,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     ex.gather_tasks = (c.stage_on(ST_INPUT) && c.word_table) ? embed_gather_tasks(ea, Nq) : 0;
     ex.gather_rows = Nq; ex.emb = ea; ex.drop = c.drop;
     ex.wall_K = c.wall_K; ex.wall_off = c.wall_off; ex.wall_boff = c.wall_boff;
+    if ((int)offs.size() <= HUAL_MAX_PACK) { ex.ovf = ovf; ex.ovf_stride = ovf_stride; }
     c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex,
                               c.PKT, c.want_bwd ? c.PKN : nullptr));
     if (opt->prezero_token) *opt->prezero_token = (ex.zero_ptr && c.ok()) ? (uint64_t)(uintptr_t)ex.zero_ptr : 0;      // the receipt
@@ -530,8 +540,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   cq.M2 = c.buf("cq.m2", (size_t)2 * B * cq_m2_rows_host(T, L), D);
   CqParams cqp{};
   for (int i = 0; i < 2; ++i) { cqp.w0[i] = c.p(pm.cq[i].w0); cqp.w1[i] = c.p(pm.cq[i].w1); cqp.wm[i] = c.p(pm.cq[i].wm); }
-  if (c.live()) c.chk(launch_tri_prep(cq, cqp, c.rs, c.drop, c.stream));
-  if (c.live()) c.chk(launch_cq_fwd(cq, c.rs, c.stream));
+  if (c.live()) c.chk(launch_cq_fwd(cq, cqp, c.rs, c.drop, c.stream));      // (tri_prep inside)
   float* cqf = c.act("cq.feats");      // q2v_feats (video rows) | v2q_feats (query rows)
   if (c.live()) {      // dense over [x, c2q, x * c2q, x * q2c] (layers.py:127-130): four weight steps per direction, one launch
     MProjArgs pr[2];
@@ -685,7 +694,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     c.chk(launch_heads(ha, B, T, c.stream));
     if (lab && c.ok()) {
       LossTailArgs lt{loss_acc, match_part, match_fwd_blocks(Nv), loc_part, B, c.cfg->match_lambda, opt->match_denom_override,
-                      opt->match_denom_dev, out->loss_terms};
+                      opt->match_denom_dev, out->loss_terms, ovf, c.novf};
       c.chk(launch_loss_tail(lt, c.stream));
     }
   }
@@ -1097,13 +1106,14 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   c.stage(ST_CONV);
   float* d_x0 = conv_block_bwd(c, "cb", x0, dx, pm.cb, c.rs, HUAL_SITE_CONV);
   c.stage(ST_ALWAYS);
-  if (c.live()) {      // position-table gradients of the stages that ran
-    PosBwdJob pj[2];
-    int npj = 0;
-    if (c.stage_on(ST_INPUT)) pj[npj++] = PosBwdJob{{d_x0, nullptr}, c.g(pm.pos), 1, 1};     // the table is added in the input stage
-    if (c.stage_on(ST_PRED)) pj[npj++] = PosBwdJob{{fe_dx0[1], fe_dx0[0]}, c.g(pm.fe_pos), 1, 0};
-    if (npj) c.chk(launch_pos_bwd(pj, npj, c.rs, c.stream));
-  }
+  // position-table gradients of the stages that ran: in the whole model they ride in the launch of the input layer norms' backward
+  // (same gradient tensor, independent work); a per-block call launches them on their own
+  PosBwdJob pj[2];
+  int npj = 0;
+  if (!c.dry && c.stage_on(ST_INPUT)) pj[npj++] = PosBwdJob{{d_x0, nullptr}, c.g(pm.pos), 1, 1};     // the table is added in the input stage
+  if (!c.dry && c.stage_on(ST_PRED)) pj[npj++] = PosBwdJob{{fe_dx0[1], fe_dx0[0]}, c.g(pm.fe_pos), 1, 0};
+  const bool pos_rides = c.sel_stage < 0;
+  if (c.live() && npj && !pos_rides) c.chk(launch_pos_bwd(pj, npj, c.rs, c.stream));
   c.stage(ST_INPUT);
   float* lin = c.act("lin");
   float* lin_mean = c.vec("lin.mean");
@@ -1114,7 +1124,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     LnBwd a{};
     a.x = lin; a.mean = lin_mean; a.rstd = lin_rstd; a.R = R; a.dy1 = d_x0; a.g1 = c.p(pm.vln.g);
     a.dx = d_lin; a.split = Nv; a.g1_hi = c.p(pm.qln.g);
-    c.ln_bwd_split(a, c.g(pm.vln.g), c.g(pm.vln.b), c.g(pm.qln.g), c.g(pm.qln.b));
+    c.ln_bwd_split(a, c.g(pm.vln.g), c.g(pm.vln.b), c.g(pm.qln.g), c.g(pm.qln.b), pj, pos_rides ? npj : 0);
   }
   float* cat = c.buf("cat", Nq, catw);
   {

@@ -1,5 +1,6 @@
 """End-to-end GPU parity: HIP SeqPAN (through the C ABI) vs the CPU oracle on identical seeded inputs.
 Tolerance 1e-3 (north_star), span argmax indices bit exact."""
+import numpy as np
 import pytest
 import torch
 
@@ -54,3 +55,19 @@ def test_bfloat16_video_feed_any_width():
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2, video_bf16=True)
     _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
     assert idx_equal
+
+
+def test_weight_outside_the_fp16_image_range_poisons_the_loss():
+    """the dense weights travel as fp16 hi + lo images scaled by 2^10 (csrc/bf16x3.h): |w| >= 63 does not fit.  The pack launch
+    flags such a weight and the loss launch turns the flag into NaN losses instead of silently wrong products"""
+    import collections
+    cfg, p, wv, b, labels = pu.make_case(B=2, T=16, L=6, C=5, seed=3)
+    feeds = (b['video'], b['lens'], b['word_ids'], b['char_ids'])
+    m = pu.hip_model(cfg, p, wv)
+    ok = m.forward(*feeds, drop_rate=0.0, labels=labels)
+    assert np.isfinite(float(ok['loss']))
+    p2 = collections.OrderedDict((k, v.clone()) for k, v in p.items())
+    p2['d_attn_0/dual_multihead_attention/f_key/kernel'].view(-1)[5] = 100.0
+    m2 = pu.hip_model(cfg, p2, wv)
+    bad = m2.forward(*feeds, drop_rate=0.0, labels=labels)
+    assert np.isnan(float(bad['loss'])) and np.isnan(float(bad['loc_loss']))
