@@ -51,16 +51,26 @@ struct PackExtra {
   // image goes to fwd + wall_off * 4, the image of its transpose to bwd + wall_boff
   int gather_tasks; int gather_rows; EmbedArgs emb; DropCfg drop;
   int wall_K; uint32_t wall_off, wall_boff;
-  // optional: one word per workgroup of the job rows, [job][x] with stride ovf_stride: 1 when a weight of its 16 K rows has a
+  // optional: one word per workgroup of the job rows (novf of them: pack_ovf_words): 1 when a weight of its 16 K rows has a
   // magnitude the scaled fp16 image cannot hold (|w| >= HUAL_F16_WMAX, or NaN) - every word is written, no zeroing needed;
   // the loss launch turns any set word into a NaN loss (heads.h LossTailArgs)
-  uint32_t* ovf; int ovf_stride;
+  uint32_t* ovf; int novf;
 };
 #define HUAL_MAX_PACK 96                 // jobs of one pack launch
-inline int pack_ovf_stride(int maxK) { return ((maxK + 127) & ~127) / 16; }
+#define HUAL_PACK_GX 64                  // workgroups per row of its grid
+// words the pack launch writes for jobs of these K: its job rows hold ceil(K / 128) * 8 workgroups per job, back to back
+inline int pack_ovf_words(const int* Ks, int n) {
+  int nblk = 0;
+  for (int i = 0; i < n; ++i) nblk += ((Ks[i] + 127) & ~127) / 16;
+  return (nblk + HUAL_PACK_GX - 1) / HUAL_PACK_GX * HUAL_PACK_GX;
+}
 // timg / nimg (optional): images for the register-resident weights of the T-form kernels (tilecore.h), blocks of 64 KB at boffs[]
+// needs (optional, one byte per job): which of the images a weight is wanted in - the forward / transposed images of the LDS-DMA
+// kernels (F, B), the T / N images; default all that have a destination
+enum { HUAL_PACK_F = 1, HUAL_PACK_B = 2, HUAL_PACK_T = 4, HUAL_PACK_N = 8 };
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
-                        hipStream_t stream, const PackExtra* extra = nullptr, char* timg = nullptr, char* nimg = nullptr);
+                        hipStream_t stream, const PackExtra* extra = nullptr, char* timg = nullptr, char* nimg = nullptr,
+                        const uint8_t* needs = nullptr);
 // Feature-load kernel: part[q][M][128] = dropout(A)[M, q*KS .. q*KS+KS) . W[q*KS .., :] for the four K-quarters q (Wimg =
 // forward image of the [K,128] weight, K <= 4*KS); the sum over q (+ bias) is taken by the consumer (ln_fwd_kernel's `part`).
 struct FkJob {

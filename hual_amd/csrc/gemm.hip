@@ -159,18 +159,20 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
 //   backward image at bwd + boff:   block b (64 KB) = the forward-style image of the 128 x 128 matrix W[128b + c][kk]^T
 //                                   (rows kk, columns c; zero where 128b + c >= K)
 // perm(s) = 64 (s>>6) + 4 (s&15) + ((s>>4)&3): stored column 16 t + i of a 64-column half is original column 4 i + t.
-struct PackJob { uint32_t off; int K; uint32_t boff; };
-struct PackBatch { PackJob j[HUAL_MAX_PACK]; };
+struct PackJob { uint32_t off; int K; uint32_t boff; uint32_t need; };      // need: HUAL_PACK_* images wanted of this weight
+// start[j] = first 16-row block of job j in the packed block order (start[njobs] = total): the job rows of the launch hold the
+// blocks of all jobs back to back (a [K,128] weight has ceil(K / 128) * 8 of them) instead of one padded row per job
+struct PackBatch { PackJob j[HUAL_MAX_PACK]; uint16_t start[HUAL_MAX_PACK + 1]; };
 __device__ __forceinline__ int pack_perm(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
-__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* bwd, char* timg, char* nimg, int njobs, PackExtra ex) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* bwd, char* timg, char* nimg, int njobs, int jrows, PackExtra ex) {
   __shared__ float tile[16][129];
-  if ((int)blockIdx.y > njobs) {       // further rows: the embedding gather of the text encoder, one task per thread
-    const int gid = (((int)blockIdx.y - njobs - 1) * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
+  if ((int)blockIdx.y > jrows) {       // further rows: the embedding gather of the text encoder, one task per thread
+    const int gid = (((int)blockIdx.y - jrows - 1) * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
     if (gid < ex.gather_tasks)
       embed_gather_task(ex.emb, ex.drop, ex.gather_rows, ex.wall_K / 4, ex.gather_tasks - ex.wall_K - NALL, gid);
     return;
   }
-  if ((int)blockIdx.y == njobs) {      // the extra row: masks, loss accumulators, gradient zeroing (grid-stride)
+  if ((int)blockIdx.y == jrows) {      // the extra row: masks, loss accumulators, gradient zeroing (grid-stride)
     const int nt = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
     const int Nv = ex.B * ex.T, Nq = ex.B * ex.L;
     if (t0 < 8) ex.loss_acc[t0] = 0.f;
@@ -186,13 +188,16 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
     }
     return;
   }
-  const PackJob job = b.j[blockIdx.y];
-  const int k0 = blockIdx.x * 16;
-  uint32_t* ovf = ex.ovf ? ex.ovf + (size_t)blockIdx.y * ex.ovf_stride + blockIdx.x : nullptr;
-  if (k0 >= ((job.K + 127) & ~127)) {                // block-uniform
-    if (ovf && threadIdx.x == 0 && (int)blockIdx.x < ex.ovf_stride) *ovf = 0u;
+  const int lb = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;      // packed block index
+  uint32_t* ovf = ex.ovf ? ex.ovf + lb : nullptr;
+  if (lb >= (int)b.start[njobs]) {                   // block-uniform: the tail of the last job row
+    if (ovf && threadIdx.x == 0) *ovf = 0u;
     return;
   }
+  int jlo = 0, jhi = njobs;                          // job of the block: start[jlo] <= lb < start[jlo + 1]
+  while (jhi - jlo > 1) { const int mid = (jlo + jhi) >> 1; if (lb >= (int)b.start[mid]) jlo = mid; else jhi = mid; }
+  const PackJob job = b.j[jlo];
+  const int k0 = (lb - (int)b.start[jlo]) * 16;
   const float* W = P + job.off;
   const bool virt = ex.wall_K > 0 && job.off == ex.wall_off;      // the char-CNN filter bank: elements from the four filters
   bool bad = false;
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
   const int anybad = __syncthreads_or(bad ? 1 : 0);
   if (ovf && threadIdx.x == 0) *ovf = anybad ? 1u : 0u;
   // forward image: 16 rows x 64 column pairs
-  if (fwd) {
+  if (fwd && (job.need & HUAL_PACK_F)) {
     char* img = fwd + (size_t)job.off * 4;
     for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
       const int r = idx >> 6, sp = idx & 63;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
     }
   }
   // register-resident weights (tilecore.h "T-form"): one 64 KB block per 128 K rows at boff, [column][index] fp16 hi | lo
-  if (timg) {        // T image: W^T - column n, index k
+  if (timg && (job.need & HUAL_PACK_T)) {        // T image: W^T - column n, index k
     char* img = timg + job.boff + (size_t)(k0 >> 7) * TF_BLOCK;
     const int kb = k0 & 127;
     for (int idx = threadIdx.x; idx < 128 * 8; idx += 256) {
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
       *reinterpret_cast<uint32_t*>(img + 32768 + (size_t)n * 256 + 2 * (kb + 2 * pr)) = lo;
     }
   }
-  if (nimg) {        // N image: W itself - "column" k, index n
+  if (nimg && (job.need & HUAL_PACK_N)) {        // N image: W itself - "column" k, index n
     char* img = nimg + job.boff + (size_t)(k0 >> 7) * TF_BLOCK;
     const int kb = k0 & 127;
     for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
   }
   // backward image: the 16 original rows k0..k0+15 are columns c = k0 % 128 + (0..15) of block k0 / 128; for every kk
   // they sit at stored columns s with perm(s) = c, i.e. s = 64 (c>>6) + 16 t + i with 4 i + t = c & 63
-  if (bwd) {
+  if (bwd && (job.need & HUAL_PACK_B)) {
     char* img = bwd + job.boff + (size_t)(k0 >> 7) * GB_COLBLOCK;
     const int cbase = k0 & 127;
     for (int idx = threadIdx.x; idx < 128 * 8; idx += 256) {
@@ -580,30 +585,36 @@ void dw_bf16_balanced_kernel(const DwJob* __restrict__ table, int n, DropCfg dro
 namespace hual {
 
 int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
-                        hipStream_t stream, const PackExtra* extra, char* timg, char* nimg) {
+                        hipStream_t stream, const PackExtra* extra, char* timg, char* nimg, const uint8_t* needs) {
   HUAL_REQUIRE(!extra || (extra->lens && extra->word_ids && extra->rowmask && extra->loss_acc && (extra->zero_n % 4) == 0 &&
                           (reinterpret_cast<uintptr_t>(extra->zero_ptr) & 15) == 0), "pack: extra prologue work");
   PackExtra ex{};
   for (int base = 0; base < n; base += HUAL_MAX_PACK) {
     const int cnt = n - base < HUAL_MAX_PACK ? n - base : HUAL_MAX_PACK;
     PackBatch b;
-    int maxK = 0;
+    int maxK = 0, nblk = 0;
     double elems = 0.0;
     for (int i = 0; i < cnt; ++i) {
+      b.start[i] = (uint16_t)nblk;
+      nblk += ((Ks[base + i] + 127) & ~127) / 16;
       HUAL_REQUIRE(Ks[base + i] > 0 && (Ks[base + i] % 8) == 0, "pack: K must be a positive multiple of 8");
       b.j[i].off = offs[base + i]; b.j[i].K = Ks[base + i]; b.j[i].boff = boffs ? boffs[base + i] : 0;
+      b.j[i].need = needs ? needs[base + i] : (HUAL_PACK_F | HUAL_PACK_B | HUAL_PACK_T | HUAL_PACK_N);
       const int kp = (Ks[base + i] + 127) & ~127;
       maxK = kp > maxK ? kp : maxK;
       elems += (double)Ks[base + i] * 128;
     }
+    b.start[cnt] = (uint16_t)nblk;
+    HUAL_REQUIRE(nblk < 65536, "pack: too many blocks");
     const bool with_extra = extra && base == 0;
     if (with_extra) ex = *extra;
+    const int gx = HUAL_PACK_GX;
+    const int jrows = cdiv(nblk, gx);
     HUAL_REQUIRE(!(ex.ovf && n > HUAL_MAX_PACK), "pack: the overflow words cover one batch of jobs");
-    HUAL_REQUIRE(!ex.ovf || ex.ovf_stride >= maxK / 16, "pack: overflow word stride");
-    const int gx = maxK / 16;
+    HUAL_REQUIRE(!ex.ovf || ex.novf >= jrows * gx, "pack: overflow words");
     const int grows = (with_extra && ex.gather_tasks > 0) ? cdiv(ex.gather_tasks, gx * 256) : 0;      // rows of workgroups of the gather
-    HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(gx, cnt + (with_extra ? 1 + grows : 0)),
-                dim3(256), 0, stream, b, P, fwd, bwd, timg, nimg, cnt, ex);
+    HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(gx, jrows + (with_extra ? 1 + grows : 0)),
+                dim3(256), 0, stream, b, P, fwd, bwd, timg, nimg, cnt, jrows, ex);
   }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

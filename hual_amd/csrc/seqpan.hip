@@ -54,7 +54,8 @@ struct Ctx {
   int rc = 0;
   bool static_tables = false;   // hual_run_opts.static_tables
   int wall_K = 0; uint32_t wall_off = 0, wall_boff = 0;      // packed char-CNN filter bank inside PKF / PKB (setup_ctx)
-  struct DenseW { size_t off; int K; size_t boff; };
+  struct DenseW { size_t off; int K; size_t boff; uint8_t need; };      // need: HUAL_PACK_* images the kernels read of this weight
+  bool ksplit = false;                // feature-load phase on the K-split kernel (plan)
   typedef DenseW DenseW_t;
   std::vector<DenseW> dense;          // every [K,128] weight of the graph, sorted by offset
   char* PKF = nullptr;                // pre-split images (gemm.h launch_pack_weights): forward ...
@@ -230,17 +231,23 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
     const ParamMap& pm = c.pm;
     const int D = HUAL_D, catw = cfg->word_dim + 100;
     c.dense.clear();
-    auto add = [&](size_t off, int K) { if (K % 8 == 0) c.dense.push_back({off, K, off * 4}); };
-    add(pm.vconv.k, cfg->vdim); add(pm.qconv.k, catw);
-    add(pm.shid.k, 2 * D); add(pm.ehid.k, 2 * D);
-    add(pm.fe_dense.k, D); add(pm.fe_q.k, D); add(pm.fe_k.k, D); add(pm.fe_v.k, D);
-    for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D); add(pm.cb.pw[i], D); }
-    add(pm.cqcat.k, 2 * D); add(pm.cq[0].dense, 4 * D); add(pm.cq[1].dense, 4 * D);
+    // which images of a weight the kernels read: F / B - forward and dX products of the LDS-DMA kernels (fused row-local chains,
+    // K-split feature load); T / N - the same two for the register-resident weights of mproj (gemm.h HUAL_PACK_*)
+    const uint8_t FB = HUAL_PACK_F | HUAL_PACK_B, TN = HUAL_PACK_T | HUAL_PACK_N;
+    auto add = [&](size_t off, int K, uint8_t need) { if (K % 8 == 0) c.dense.push_back({off, K, off * 4, need}); };
+    const int qks = ((catw + 3) / 4 + 63) & ~63;        // quarter size of query_conv1d's K (multiple of 64)
+    c.ksplit = (cfg->vdim % 256) == 0 && cfg->vdim <= 1024 && (catw % 8) == 0 && qks <= 256;
+    add(pm.vconv.k, cfg->vdim, c.ksplit ? HUAL_PACK_F : HUAL_PACK_T);
+    add(pm.qconv.k, catw, (c.ksplit ? HUAL_PACK_F : HUAL_PACK_T) | HUAL_PACK_N);
+    add(pm.shid.k, 2 * D, HUAL_PACK_F | HUAL_PACK_N); add(pm.ehid.k, 2 * D, HUAL_PACK_F | HUAL_PACK_N);
+    add(pm.fe_dense.k, D, FB); add(pm.fe_q.k, D, FB); add(pm.fe_k.k, D, FB); add(pm.fe_v.k, D, FB);
+    for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D, FB); add(pm.cb.pw[i], D, FB); }
+    add(pm.cqcat.k, 2 * D, TN); add(pm.cq[0].dense, 4 * D, TN); add(pm.cq[1].dense, 4 * D, TN);
     for (int li = 0; li < cfg->attn_layer; ++li) {
       const DualAttnP& d = pm.da[li];
       const size_t w[] = {d.dense1.k, d.dense2.k, d.bl1_d1, d.bl1_d2, d.bl2_d1, d.bl2_d2, d.guided.k, d.s_gate.k, d.x_gate.k,
                           d.s_dense.k, d.x_dense.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
-      for (size_t o : w) add(o, D);
+      for (size_t o : w) add(o, D, FB);
     }
     std::sort(c.dense.begin(), c.dense.end(), [](const Ctx::DenseW& a, const Ctx::DenseW& b) { return a.off < b.off; });
     // the image of a transposed weight takes ceil(K/128) blocks of 64 KB: it fits the weight's own byte range when K is a
@@ -354,12 +361,12 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* ortho_dE = c.buf("ortho.dE", 4, HUAL_D);
   // one word per workgroup of the pack launch's job rows: set when a weight does not fit the scaled fp16 images (gemm.h PackExtra);
   // the loss launch reads them
-  int pk_maxK = c.wall_K;
-  for (const auto& d : c.dense) pk_maxK = d.K > pk_maxK ? d.K : pk_maxK;
-  const int ovf_stride = pack_ovf_stride(pk_maxK);
-  const int npack = (int)c.dense.size() + 1;
-  uint32_t* ovf = reinterpret_cast<uint32_t*>(c.buf("params.ovf", (size_t)npack * ovf_stride, 1));
-  c.novf = npack <= HUAL_MAX_PACK ? npack * ovf_stride : 0;
+  std::vector<int> pkK;
+  for (const auto& d : c.dense) pkK.push_back(d.K);
+  pkK.push_back(c.wall_K);
+  const int ovf_words = pack_ovf_words(pkK.data(), (int)pkK.size());
+  uint32_t* ovf = reinterpret_cast<uint32_t*>(c.buf("params.ovf", (size_t)ovf_words, 1));
+  c.novf = (int)pkK.size() <= HUAL_MAX_PACK ? ovf_words : 0;
   // (the text encoder's gather - word / char lookups with their dropout, model.py:36-41 - rides in the same launch)
   float* cat = c.buf("cat", Nq, catw);
   int32_t* char_arg = reinterpret_cast<int32_t*>(c.buf("char_arg", Nq, 100));
@@ -368,8 +375,10 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   if (!c.dry && c.ok()) {
     std::vector<uint32_t> offs, boffs;
     std::vector<int> Ks;
-    for (const auto& d : c.dense) { offs.push_back((uint32_t)d.off); Ks.push_back(d.K); boffs.push_back((uint32_t)d.boff); }
+    std::vector<uint8_t> needs;
+    for (const auto& d : c.dense) { offs.push_back((uint32_t)d.off); Ks.push_back(d.K); boffs.push_back((uint32_t)d.boff); needs.push_back(d.need); }
     offs.push_back(c.wall_off); Ks.push_back(c.wall_K); boffs.push_back(c.wall_boff);      // the char-CNN filter bank (virtual source)
+    needs.push_back(HUAL_PACK_T | HUAL_PACK_N);
     fill_embed_args(c, ea, bt, cat, catw, char_arg, embed_scratch);
     PackExtra ex{};
     ex.lens = bt->video_seq_len; ex.word_ids = bt->word_ids; ex.rowmask = rowmask; ex.loss_acc = loss_acc; ex.B = B; ex.T = T; ex.L = L;
@@ -381,9 +390,9 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     ex.gather_tasks = (c.stage_on(ST_INPUT) && c.word_table) ? embed_gather_tasks(ea, Nq) : 0;
     ex.gather_rows = Nq; ex.emb = ea; ex.drop = c.drop;
     ex.wall_K = c.wall_K; ex.wall_off = c.wall_off; ex.wall_boff = c.wall_boff;
-    if ((int)offs.size() <= HUAL_MAX_PACK) { ex.ovf = ovf; ex.ovf_stride = ovf_stride; }
+    if (c.novf) { ex.ovf = ovf; ex.novf = c.novf; }
     c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex,
-                              c.PKT, c.want_bwd ? c.PKN : nullptr));
+                              c.PKT, c.want_bwd ? c.PKN : nullptr, needs.data()));
     if (opt->prezero_token) *opt->prezero_token = (ex.zero_ptr && c.ok()) ? (uint64_t)(uintptr_t)ex.zero_ptr : 0;      // the receipt
   }
   // ---------------- text encoder front: word + char embeddings (model.py:36-41)
@@ -402,7 +411,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* lin_mean = c.vec("lin.mean");
   float* lin_rstd = c.vec("lin.rstd");
   const int qks = ((catw + 3) / 4 + 63) & ~63;        // quarter size of query_conv1d's K (multiple of 64)
-  const bool ksplit = (c.cfg->vdim % 256) == 0 && c.cfg->vdim <= 1024 && (catw % 8) == 0 && qks <= 256;
+  const bool ksplit = c.ksplit;
   float* vpart = c.buf("lin.part", (size_t)4 * R, D);
   if (ksplit) {
     if (c.live()) {
