@@ -18,5 +18,7 @@ int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStre
 void embed_dw_job(const EmbedArgs& a, int nrows, DwJob* dwjob);
 int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const DropCfg& drop, hipStream_t s, DwJob* dwjob);
 int launch_embed_unpack(const EmbedArgs& a, const EmbedGrads& g, hipStream_t s);
+int embed_unpack_tasks(const EmbedArgs& a);      // tasks / char_dim padding of the unpack (for the launch it rides in: rowops.h)
+int embed_unpack_cpad(const EmbedArgs& a);
 
 }  // namespace hual

@@ -135,24 +135,10 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(EmbedArgs a, EmbedGra
   }
 }
 
-// backward 3 (after the weight-gradient launch): packed dFall / dball -> filter and bias gradients
+// backward 3 (after the weight-gradient launch): packed dFall / dball -> filter and bias gradients (embed_gather.h embed_unpack_task;
+// in the training step the tasks ride in the launch that folds the per-workgroup partial sums, rowops.h launch_colsum)
 __global__ __launch_bounds__(256) void embed_unpack_kernel(EmbedArgs a, EmbedGrads gr, int CP) {
-  const int cd = a.char_dim;
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int nfil = cd * (10 + 40 + 90 + 160);
-  if (gid < nfil) {
-    const int foff[4] = {0, cd * 10, cd * 10 + 2 * cd * 20, cd * 10 + 2 * cd * 20 + 3 * cd * 30};
-    const int k = gid < foff[1] ? 1 : (gid < foff[2] ? 2 : (gid < foff[3] ? 3 : 4));
-    const int rel = gid - foff[k - 1];             // (dk*cd + d) * 10k + n
-    const int n = rel % (10 * k), tap = rel / (10 * k);
-    const int dk = tap / cd, d = tap - dk * cd;
-    gr.dfilt[k - 1][rel] += a.dfall[(size_t)(dk * CP + d) * NALL + bank_off(k) + n];
-  } else if (gid < nfil + NCH) {
-    const int ch = gid - nfil;
-    int k, chk;
-    chan_to_kernel(ch, k, chk);
-    gr.dfbias[k - 1][chk] += a.dfall[(size_t)4 * CP * NALL + ch];
-  }
+  embed_unpack_task(a, gr, CP, blockIdx.x * 256 + threadIdx.x);
 }
 
 namespace hual {
@@ -231,6 +217,8 @@ void embed_dw_job(const EmbedArgs& a, int nrows, DwJob* dwjob) {
   dwjob->db = a.dfall + (size_t)4 * CP * NALL;
 }
 
+int embed_unpack_tasks(const EmbedArgs& a) { return a.char_dim * 300 + NCH; }
+int embed_unpack_cpad(const EmbedArgs& a) { return cpad(a.char_dim); }
 int launch_embed_unpack(const EmbedArgs& a, const EmbedGrads& g, hipStream_t s) {
   const int cd = a.char_dim;
   const int n = cd * 300 + NCH;

@@ -68,3 +68,22 @@ __device__ __forceinline__ void embed_gather_task(const hual::EmbedArgs& a, cons
     a.ball[x] = v;
   }
 }
+
+// backward 3 (after the weight-gradient launch): packed dFall / dball -> filter and bias gradients; task gid of cd * 300 + NCH
+__device__ __forceinline__ void embed_unpack_task(const hual::EmbedArgs& a, const hual::EmbedGrads& gr, int CP, int gid) {
+  const int cd = a.char_dim;
+  const int nfil = cd * (10 + 40 + 90 + 160);
+  if (gid < nfil) {
+    const int foff[4] = {0, cd * 10, cd * 10 + 2 * cd * 20, cd * 10 + 2 * cd * 20 + 3 * cd * 30};
+    const int k = gid < foff[1] ? 1 : (gid < foff[2] ? 2 : (gid < foff[3] ? 3 : 4));
+    const int rel = gid - foff[k - 1];             // (dk*cd + d) * 10k + n
+    const int n = rel % (10 * k), tap = rel / (10 * k);
+    const int dk = tap / cd, d = tap - dk * cd;
+    gr.dfilt[k - 1][rel] += a.dfall[(size_t)(dk * CP + d) * NALL + bank_off(k) + n];
+  } else if (gid < nfil + NCH) {
+    const int ch = gid - nfil;
+    int k, chk;
+    chan_to_kernel(ch, k, chk);
+    gr.dfbias[k - 1][chk] += a.dfall[(size_t)4 * CP * NALL + ch];
+  }
+}

@@ -6,6 +6,7 @@
 // (/root/reference/models/model.py:53-68: conv_block and dual_attn_block with reuse=True) run as ONE launch.
 #pragma once
 #include "common.h"
+#include "embed_args.h"
 
 namespace hual {
 
@@ -62,7 +63,9 @@ struct ColsumJob {
   float* dst[HUAL_COLSUM_MAX_VEC];     // null entries are skipped
   int last_ncols;                      // > 0: the LAST vector only has this many columns (a destination shorter than 128)
 };
-int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s);
+// unpack (optional): the char-CNN filter-gradient unpack (embed_gather.h embed_unpack_task) as further workgroups of the launch
+struct EmbedUnpack { EmbedArgs a; EmbedGrads g; int CP; int ntasks; };
+int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s, const EmbedUnpack* unpack = nullptr);
 
 // dpos[t] += sum_b dx[b,t] (over the video rows, the query rows or both: the shared table serves both sides, model.py:53,56)
 // for up to HUAL_POS_MAX_JOBS tables in one launch; a job sums up to two gradient tensors (the predictor's two encoder

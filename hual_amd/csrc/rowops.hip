@@ -2,6 +2,7 @@
 // works on 8 rows at a time; row reductions are wave shuffles inside a 32-lane half (no LDS, no barrier).
 #include <string.h>
 #include "rowops.h"
+#include "embed_gather.h"
 #include "philox.h"
 #include "prof.h"
 
@@ -130,8 +131,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) { ln
 // ------------------------------------------------------------------------------------------------------
 struct ColsumBatch { ColsumJob j[HUAL_COLSUM_MAX_JOBS]; };
 #define COLSUM_SPLIT 16   // independent row slices per (job, vector): the kernel is a chain of dependent-latency loads (18.5 us at 4, see profiles)
-__global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch batch) {
+__global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch batch, int njobs, EmbedUnpack eu) {
   __shared__ float part[HUAL_D];
+  if ((int)blockIdx.x >= njobs) {      // the workgroups behind the jobs: unpack tasks, one per thread
+    const int lid = (((int)blockIdx.x - njobs) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.z + (int)blockIdx.z;
+    const int gid = lid * 256 + (int)threadIdx.x;
+    if (gid < eu.ntasks) embed_unpack_task(eu.a, eu.g, eu.CP, gid);
+    return;
+  }
   const ColsumJob& job = batch.j[blockIdx.x];
   const int vec = blockIdx.y;
   if (vec >= job.nvec || job.dst[vec] == nullptr) return;     // block-uniform
@@ -234,9 +241,9 @@ int launch_ln_bwd(const LnBwd& a, const DropCfg& drop, hipStream_t s, const PosB
   return 0;
 }
 
-int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s) {
-  if (n == 0) return 0;
-  HUAL_REQUIRE(n > 0 && n <= HUAL_COLSUM_MAX_JOBS, "colsum: job count");
+int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s, const EmbedUnpack* unpack) {
+  if (n == 0 && !unpack) return 0;
+  HUAL_REQUIRE(n >= 0 && n <= HUAL_COLSUM_MAX_JOBS, "colsum: job count");
   ColsumBatch b;
   ::memset((void*)&b, 0, sizeof(b));
   int maxvec = 0;
@@ -245,7 +252,11 @@ int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s) {
     b.j[i] = jobs[i];
     maxvec = jobs[i].nvec > maxvec ? jobs[i].nvec : maxvec;
   }
-  HUAL_LAUNCH(0.0, 0.0, colsum_kernel, dim3(n, maxvec, COLSUM_SPLIT), dim3(256), 0, s, b);
+  if (maxvec == 0) maxvec = 1;
+  EmbedUnpack eu{};
+  int xu = 0;
+  if (unpack) { eu = *unpack; xu = cdiv(cdiv(eu.ntasks, 256), maxvec * COLSUM_SPLIT); }
+  HUAL_LAUNCH(0.0, 0.0, colsum_kernel, dim3(n + xu, maxvec, COLSUM_SPLIT), dim3(256), 0, s, b, n, eu);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -141,9 +141,13 @@ struct Ctx {
     if (active) colsum.push_back(cj);
     if (live()) chk(launch_ln_proj_bwd(a, drop, stream));
   }
-  void flush_colsum() {
-    for (size_t i = 0; i < colsum.size() && !dry && ok(); i += HUAL_COLSUM_MAX_JOBS)   // (whatever stages ran)
-      chk(launch_colsum(colsum.data() + i, (int)std::min<size_t>(HUAL_COLSUM_MAX_JOBS, colsum.size() - i), stream));
+  // (unpack: the char-CNN filter-gradient unpack rides in the last of these launches - it has to follow the weight-gradient launch)
+  void flush_colsum(const EmbedUnpack* unpack = nullptr) {
+    for (size_t i = 0; i < colsum.size() && !dry && ok(); i += HUAL_COLSUM_MAX_JOBS) {   // (whatever stages ran)
+      const bool last = i + HUAL_COLSUM_MAX_JOBS >= colsum.size();
+      chk(launch_colsum(colsum.data() + i, (int)std::min<size_t>(HUAL_COLSUM_MAX_JOBS, colsum.size() - i), stream, last ? unpack : nullptr));
+    }
+    if (colsum.empty() && unpack && !dry && ok()) chk(launch_colsum(nullptr, 0, stream, unpack));
     colsum.clear();
   }
   void attn_fwd(const AttnJob* j, int n) { if (live()) chk(launch_attn_fwd(j, n, drop, stream)); }
@@ -1176,9 +1180,13 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   c.push_dw(embed_dw);
   const bool input_ran = c.active;
   c.stage(ST_ALWAYS);
-  c.flush_colsum();       // layer-norm / depthwise-conv parameter gradients: one reduction of the per-block partial sums
   flush_dw(c);            // every dense / conv weight gradient of the step: one launch
-  if (c.live() && input_ran) c.chk(launch_embed_unpack(ea, eg, c.stream));
+  // layer-norm / depthwise-conv parameter gradients: one reduction of the per-block partial sums, with the unpack of the char-CNN
+  // filter gradients (behind the weight-gradient launch) as further workgroups of the same launch
+  EmbedUnpack eu{};
+  const bool unpack = !c.dry && input_ran && c.active;
+  if (unpack) { eu.a = ea; eu.g = eg; eu.CP = embed_unpack_cpad(ea); eu.ntasks = embed_unpack_tasks(ea); }
+  c.flush_colsum(unpack ? &eu : nullptr);
   (void)opt;
   return c.rc;
 }
