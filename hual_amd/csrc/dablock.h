@@ -80,6 +80,10 @@ struct LnProjBwdArgs {
   float* dz; const uint8_t* dz_bits;                           // optional: dz = dropout'(dx) with the keep bits dz_bits (null: dz = dx)
   float* part;                                                 // [grid][4][128] partial sums: dgamma1, dbeta1, dgamma2, dbeta2
   int R; int MT; uint32_t drop_row0;
+  // optional prologue (needs g2 == null, add1 == null): the gradient operand of product 0 is itself a layer norm's input gradient,
+  //   dxp = LNbwd(pre_x; pre_dy, pre_g) (+ pre_add);   A[0] := dxp (a_bits[0] / a_save[0] apply as usual);   add1 := dxp
+  // and that layer norm's dgamma / dbeta sums take the slots of the second layer norm in `part` (ln_bwd_kernel's arithmetic)
+  const float* pre_x; const float* pre_mean; const float* pre_rstd; const float* pre_g; const float* pre_dy; const float* pre_add;
 };
 int ln_proj_bwd_rows(int R);
 int ln_proj_bwd_blocks(int R);

@@ -475,17 +475,44 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   // operand rows of product 0 and everything the row phase needs (unconditional loads on clamped rows)
   float4 nv[4], xv[4], a1v[4];
   float mu[4], rsd[4];
-  const float* add1p = a.add1 ? a.add1 : a.x;
+  const bool pre = a.pre_x != nullptr;
+  const float* add1p = pre ? (a.pre_add ? a.pre_add : a.x) : (a.add1 ? a.add1 : a.x);
+  const float* a0p = pre ? a.pre_dy : a.A[0];
+  const int lda0 = pre ? HUAL_D : a.lda[0];
+  float4 pxv[4];                                       // prologue: rows / statistics of the layer norm in front
+  float pmu[4], prs[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int row = min(r0 + grp + 16 * u, R - 1);
-    nv[u] = ld4(a.A[0] + (size_t)row * a.lda[0] + col);
+    nv[u] = ld4(a0p + (size_t)row * lda0 + col);
     xv[u] = ld4(a.x + (size_t)row * HUAL_D + col);
     a1v[u] = ld4(add1p + (size_t)row * HUAL_D + col);
     mu[u] = a.mean[row];
     rsd[u] = a.rstd[row];
+    if (pre) { pxv[u] = ld4(a.pre_x + (size_t)row * HUAL_D + col); pmu[u] = a.pre_mean[row]; prs[u] = a.pre_rstd[row]; }
   }
   const float4 g1 = ld4(a.g1 + col);
+  float4 sg2 = f4zero(), sb2 = f4zero();               // second layer norm's parameter sums - or the prologue layer norm's
+  if (pre) {      // dxp = LNbwd(pre_x; pre_dy, pre_g) + pre_add -> operand of product 0 and the residual addend of the row phase
+    const float4 pg = ld4(a.pre_g + col);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int lr = grp + 16 * u;
+      const bool ok = lr < MT && r0 + lr < RE;
+      const float4 v = pxv[u], dy = nv[u];
+      const float mean = pmu[u], rstd = prs[u];
+      const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+      if (ok) { sb2 = cb_add(sb2, dy); sg2 = cb_fma(dy, xh, sg2); }
+      const float4 gv = cb_mul(dy, pg);
+      const float m1 = fast_sum32(cb_hsum(gv)) * (1.0f / HUAL_D);
+      const float m2 = fast_sum32(cb_hsum(cb_mul(gv, xh))) * (1.0f / HUAL_D);
+      float4 dx = make_float4(rstd * (gv.x - m1 - xh.x * m2), rstd * (gv.y - m1 - xh.y * m2),
+                              rstd * (gv.z - m1 - xh.z * m2), rstd * (gv.w - m1 - xh.w * m2));
+      if (a.pre_add) dx = make_float4(__fadd_rn(dx.x, a1v[u].x), __fadd_rn(dx.y, a1v[u].y), __fadd_rn(dx.z, a1v[u].z), __fadd_rn(dx.w, a1v[u].w));
+      nv[u] = dx;
+      a1v[u] = dx;
+    }
+  }
   const float4 g2 = a.g2 ? ld4(a.g2 + col) : f4zero();
   float4 addt[4];                                      // add_dy1 in the epilogue layout
   const float* addp = a.add_dy1 ? a.add_dy1 : a.x;
@@ -558,7 +585,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   }
   cb_barrier();
   // ---- row phase: layer norm(s) backward.  dy = dy*g ; dx = rstd * (gv - mean(gv) - xhat * mean(gv * xhat))   (ln_bwd_kernel)
-  float4 sg1 = f4zero(), sb1 = f4zero(), sg2 = f4zero(), sb2 = f4zero();
+  float4 sg1 = f4zero(), sb1 = f4zero();
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int lr = grp + 16 * u, row = r0 + lr;
@@ -582,7 +609,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     const float m2 = fast_sum32(cb_hsum(cb_mul(gv, xh))) * (1.0f / HUAL_D);
     float4 dx = make_float4(rstd * (gv.x - m1 - xh.x * m2), rstd * (gv.y - m1 - xh.y * m2),
                             rstd * (gv.z - m1 - xh.z * m2), rstd * (gv.w - m1 - xh.w * m2));
-    if (a.add1) dx = make_float4(__fadd_rn(dx.x, a1v[u].x), __fadd_rn(dx.y, a1v[u].y), __fadd_rn(dx.z, a1v[u].z), __fadd_rn(dx.w, a1v[u].w));
+    if (a.add1 || pre) dx = make_float4(__fadd_rn(dx.x, a1v[u].x), __fadd_rn(dx.y, a1v[u].y), __fadd_rn(dx.z, a1v[u].z), __fadd_rn(dx.w, a1v[u].w));
     st4(a.dx + off, dx);
     if (a.dz) {
       if (a.dz_bits && dr.enabled) dx = f4_select(bits_nibble(a.dz_bits, row, l32), make_float4(dx.x * dr.scale, dx.y * dr.scale, dx.z * dr.scale, dx.w * dr.scale));
@@ -906,11 +933,12 @@ int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t 
   HUAL_REQUIRE(a.x && a.mean && a.rstd && a.g1 && a.dx && a.part, "ln_proj_bwd: null tensor");
   bool any1 = false;
   for (int k = 0; k < a.nsteps; ++k) {
-    HUAL_REQUIRE(a.A[k] && a.wimg_t[k] && (a.lda[k] % 4) == 0, "ln_proj_bwd: product operand");
+    HUAL_REQUIRE((a.A[k] || (k == 0 && a.pre_x)) && a.wimg_t[k] && (a.lda[k] % 4) == 0, "ln_proj_bwd: product operand");
     HUAL_REQUIRE(a.dst[k] == 0 || a.g2, "ln_proj_bwd: product for the absent second layer norm");
     any1 = any1 || a.dst[k] != 0;
   }
   HUAL_REQUIRE(!a.g2 || any1, "ln_proj_bwd: second layer norm without a product");
+  HUAL_REQUIRE(!a.pre_x || (!a.g2 && !a.add1 && a.pre_mean && a.pre_rstd && a.pre_g && a.pre_dy), "ln_proj_bwd: layer-norm prologue");
   HUAL_DYN_LDS(ln_proj_bwd_kernel, 160 * 1024);
   const size_t lds = (size_t)4 * LB_ROWS * 256 + CB_WBYTES + 2 * LB_ROWS * sizeof(float);
   const double rows = (double)a.R;

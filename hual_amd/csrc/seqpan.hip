@@ -791,14 +791,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     c.chk(launch_mproj(&pr, 1, c.drop, c.stream));
   }
   // ---------------- feature encoders, pass 1 then pass 0
-  float* d_feout = c.actv("d.fe1.out");
-  {
-    LnBwd a{};
-    a.x = c.actv("fe1.out"); a.mean = hmean + Nv; a.rstd = hrstd + Nv; a.R = Nv; a.dy1 = d_efn; a.g1 = c.p(pm.eln.g);
-    a.dg1 = c.g(pm.eln.g); a.db1 = c.g(pm.eln.b); a.dx = d_feout;
-    a.dz = c.actv("d.fe1.zd"); a.dz_bits = c.bits("fe1.kb8", Nv);      // dropout'(.) of it for the dense^T product below
-    c.ln_bwd(a);
-  }
+  // (start / end layer norm backward: the prologue of the launch that takes dense^T + layer_norm_2 backward of the encoder pass
+  //  below - LnProjBwdArgs::pre_*; its input gradient never leaves the registers)
   float* d_in = nullptr;
   float* fe_dx0[2] = {nullptr, nullptr};
   for (int ps = 1; ps >= 0; --ps) {
@@ -814,16 +808,6 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* l2 = c.actv(t + ".l2");
     float* mean2 = c.buf(t + ".ln2.mean", Nv, 1);
     float* rstd2 = c.buf(t + ".ln2.rstd", Nv, 1);
-    if (ps == 0) {
-      // gradient wrt fe0.out = start_layer_norm backward + what pass 1 sent back to its input
-      float* d0 = c.actv("d.fe0.out");
-      LnBwd a{};
-      a.x = c.actv("fe0.out"); a.mean = hmean; a.rstd = hrstd; a.R = Nv; a.dy1 = d_sfn; a.g1 = c.p(pm.sln.g);
-      a.dg1 = c.g(pm.sln.g); a.db1 = c.g(pm.sln.b); a.add1 = d_in; a.dx = d0;
-      a.dz = c.actv("d.fe0.zd"); a.dz_bits = c.bits("fe0.kb8", Nv);
-      c.ln_bwd(a);
-      d_feout = d0;
-    }
     // out = dropout(l2 . Wd + b, s8) + res
     float* dzd = c.actv("d." + t + ".zd");
     c.push_dw(mkdw(l2, D, D, dzd, D, Nv, c.g(pm.fe_dense.k), c.g(pm.fe_dense.b)));
@@ -831,10 +815,16 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     auto imgt = [&](size_t off) { return reinterpret_cast<const float*>(c.PKB + off * 4); };
     {                      // dense^T + layer_norm_2 backward in one launch (dablock.h); dZ of the dense layer came from upstream
       LnProjBwdArgs lb{};
-      lb.nsteps = 1; lb.A[0] = dzd; lb.lda[0] = D; lb.wimg_t[0] = imgt(pm.fe_dense.k); lb.dst[0] = 0;
-      lb.dy1_bits = c.bits(t + ".kb7", Nv); lb.x = res; lb.mean = mean2; lb.rstd = rstd2; lb.g1 = c.p(pm.fe_ln2.g); lb.add1 = d_feout;
+      // prologue: gradient wrt fe<ps>.out = end / start layer norm backward (+ what pass 1 sent back to its input, for pass 0);
+      // dropout'(.) of it (site 8) is the dense layer's dZ: operand of the product below, saved for the weight-gradient job
+      const LnP& hl = ps == 1 ? pm.eln : pm.sln;
+      lb.pre_x = c.actv(t + ".out"); lb.pre_mean = hmean + (ps == 1 ? Nv : 0); lb.pre_rstd = hrstd + (ps == 1 ? Nv : 0);
+      lb.pre_g = c.p(hl.g); lb.pre_dy = ps == 1 ? d_efn : d_sfn; lb.pre_add = ps == 1 ? nullptr : d_in;
+      lb.a_bits[0] = c.bits(t + ".kb8", Nv); lb.a_save[0] = dzd;
+      lb.nsteps = 1; lb.A[0] = nullptr; lb.lda[0] = D; lb.wimg_t[0] = imgt(pm.fe_dense.k); lb.dst[0] = 0;
+      lb.dy1_bits = c.bits(t + ".kb7", Nv); lb.x = res; lb.mean = mean2; lb.rstd = rstd2; lb.g1 = c.p(pm.fe_ln2.g);
       lb.dx = d_res; lb.dz = c.actv("d." + t + ".att"); lb.dz_bits = c.bits(t + ".kb6", Nv); lb.R = Nv; lb.drop_row0 = 0;
-      c.ln_proj_bwd(lb, c.g(pm.fe_ln2.g), c.g(pm.fe_ln2.b), nullptr, nullptr);
+      c.ln_proj_bwd(lb, c.g(pm.fe_ln2.g), c.g(pm.fe_ln2.b), c.g(hl.g), c.g(hl.b));
     }
     // res = dropout(att, s6) + f: dropout'(d res) was written by the launch above
     float* d_att = c.actv("d." + t + ".att");
