@@ -42,6 +42,11 @@ struct MProjArgs {
   // LN mode (ln_g non-null): the LAST closed tile (+ bias) is x; x_out = x, y_out = LN(x; ln_g, ln_b) + pos[(row0 + row) % Tc]
   const float* ln_g; const float* ln_b; const float* pos; int row_in_clip0; int Tc;
   float* x_out; float* y_out; float* mean; float* rstd;
+  // "quad" epilogue (quad_x non-null; exactly four steps, each closing a tile, no destinations): the four tiles d0 .. d3 of a row are
+  // the gradient of [x, c2q, x * c2q, x * q2c] (cq_attention's concat, layers.py:127-130) and leave the kernel already split,
+  //   dc2q = d1 + d2 * x,   dq2c = d3 * x,   dx = d0 + d2 * c2q + d3 * q2c      (rows of 128 floats, the problem's row index)
+  const float* quad_x; const float* quad_c2q; const float* quad_q2c;
+  float* quad_dc2q; float* quad_dq2c; float* quad_dx;
 };
 int mproj_rows(int R0, int R1 = 0);      // rows per workgroup for one problem / a pair launched together
 // one or two independent problems (blockIdx.y) in one launch

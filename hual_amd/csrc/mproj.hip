@@ -14,7 +14,7 @@ using namespace hual;
 // compile-time feature set of a launch (any step of any problem uses ...): the loop body is straight-line for the features
 // that are off and branch-free (pointer selects, predicated lanes) for those that are on - a uniform branch around a vector
 // load makes the wait-count pass give up on the loads in flight across it (vmcnt(0) right behind the prefetch)
-enum { MPF_A2 = 1, MPF_BF16 = 2, MPF_DROP = 4, MPF_ADD = 8, MPF_LN = 16, MPF_REUSE = 32 };
+enum { MPF_A2 = 1, MPF_BF16 = 2, MPF_DROP = 4, MPF_ADD = 8, MPF_LN = 16, MPF_REUSE = 32, MPF_QUAD = 64 };
 
 // NT = row tiles of a workgroup (MT <= 16 NT)
 template <int NT, int F>
@@ -135,6 +135,7 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
   MP_STAMP(1);
   int slot = 0, si = 0, ri = 0;
   float4 acc[NT];
+  float4 qd[(F & MPF_QUAD) ? 4 : 1][NT];               // quad epilogue: the closed tiles of the four steps
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) acc[rt] = f4zero();
 #pragma unroll 1
@@ -193,6 +194,10 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
         if (st.act) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         if ((F & MPF_ADD) && st.add) v = cb_add(v, addv[rt]);
         if (closes && 16 * rt + j < MT && row < RE) st4(outp + (size_t)row * st.ldo + ecol, v);
+        if (F & MPF_QUAD) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (k == q) qd[q][rt] = v;
+        }
       }
     }
     MP_STAMP(7 + 7 * k);
@@ -200,6 +205,21 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
     MP_STAMP(8 + 7 * k);
     wc = wn;
     cur = nxt;
+  }
+  if ((F & MPF_QUAD) && a.quad_x) {      // the four tiles leave split (mproj.h)
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      const int row = r0 + 16 * rt + j;
+      if (16 * rt + j >= MT || row >= RE) continue;
+      const size_t off = (size_t)row * HUAL_D + ecol;
+      const float4 x = ld4(a.quad_x + off), c2q = ld4(a.quad_c2q + off), q2c = ld4(a.quad_q2c + off);
+      const float4 d0 = qd[0][rt], d1 = qd[1][rt], d2 = qd[2][rt], d3 = qd[3][rt];
+      st4(a.quad_dc2q + off, make_float4(d1.x + d2.x * x.x, d1.y + d2.y * x.y, d1.z + d2.z * x.z, d1.w + d2.w * x.w));
+      st4(a.quad_dq2c + off, make_float4(d3.x * x.x, d3.y * x.y, d3.z * x.z, d3.w * x.w));
+      st4(a.quad_dx + off, make_float4(d0.x + d2.x * c2q.x + d3.x * q2c.x, d0.y + d2.y * c2q.y + d3.y * q2c.y,
+                                       d0.z + d2.z * c2q.z + d3.z * q2c.z, d0.w + d2.w * c2q.w + d3.w * q2c.w));
+    }
+    return;
   }
   if (!(F & MPF_LN) || !a.ln_g) return;
   // ---- LN mode: the last tile (+ bias) -> LDS as fp32 rows -> layer norm (+ position embeddings) row by row
@@ -266,8 +286,8 @@ static int check_mproj(const MProjArgs& a, double& flops, double& bytes, int& fe
     HUAL_REQUIRE(!s.reuse || k > 0, "mproj: nothing to reuse");
     HUAL_REQUIRE(s.wimg && s.wrows >= 1, "mproj: weight image");
     feat |= (s.A2 ? MPF_A2 : 0) | (s.a_bf16 ? MPF_BF16 : 0) | (s.drop_site >= 0 ? MPF_DROP : 0) | (s.add ? MPF_ADD : 0) | (s.reuse ? MPF_REUSE : 0);
-    HUAL_REQUIRE(!s.last || (a.ln_g && k == a.nsteps - 1 && !s.out) || (s.out && (s.ldo % 4) == 0 && s.ncol >= 4 && s.ncol <= 128 && (s.ncol % 4) == 0),
-                 "mproj: closing step needs a destination");
+    HUAL_REQUIRE(!s.last || (a.ln_g && k == a.nsteps - 1 && !s.out) || (a.quad_x && !s.out) ||
+                 (s.out && (s.ldo % 4) == 0 && s.ncol >= 4 && s.ncol <= 128 && (s.ncol % 4) == 0), "mproj: closing step needs a destination");
     HUAL_REQUIRE(!s.add || s.add_div >= 1, "mproj: add_div");
     HUAL_REQUIRE(k == 0 || s.first == a.s[k - 1].last, "mproj: a tile starts exactly behind a closed one");
     const double kdeep = s.rep > 1 ? s.ktot : (s.reuse ? a.s[k - 1].kw : s.kw);
@@ -275,6 +295,12 @@ static int check_mproj(const MProjArgs& a, double& flops, double& bytes, int& fe
     if (!s.reuse) bytes += (s.a_bf16 ? 2.0 : 4.0) * a.R * kdeep + (s.A2 ? 4.0 * a.R * kdeep : 0.0);
     bytes += 4.0 * 128.0 * (s.rep > 1 ? s.ktot : (s.wrows < 128 ? s.wrows : 128));
     if (s.last && s.out) bytes += 4.0 * a.R * s.ncol;
+  }
+  if (a.quad_x) {
+    feat |= MPF_QUAD;
+    HUAL_REQUIRE(a.nsteps == 4 && a.quad_c2q && a.quad_q2c && a.quad_dc2q && a.quad_dq2c && a.quad_dx && !a.ln_g, "mproj: quad epilogue");
+    for (int k = 0; k < 4; ++k) HUAL_REQUIRE(a.s[k].first && a.s[k].last && a.s[k].rep == 1 && !a.s[k].out, "mproj: quad epilogue takes four closing steps");
+    bytes += 4.0 * a.R * 128.0 * 6.0;
   }
   if (a.ln_g) {
     feat |= MPF_LN;
@@ -299,9 +325,14 @@ int launch_mproj(const MProjArgs* a, int nprob, const DropCfg& drop, hipStream_t
   if (nprob == 2) HUAL_REQUIRE(a[0].MT == a[1].MT, "mproj: problems of one launch share the rows per workgroup");
   const int nt = (a[0].MT + 15) / 16;
   // instantiated feature sets: none, reuse, factor, addend, reuse + addend, everything
-  const int fsets[] = {0, MPF_REUSE, MPF_A2, MPF_ADD, MPF_REUSE | MPF_ADD, MPF_A2 | MPF_BF16 | MPF_DROP | MPF_ADD | MPF_LN | MPF_REUSE};
+  const int fsets[] = {0, MPF_REUSE, MPF_A2, MPF_ADD, MPF_REUSE | MPF_ADD, MPF_A2 | MPF_BF16 | MPF_DROP | MPF_ADD | MPF_LN | MPF_REUSE,
+                       MPF_REUSE | MPF_QUAD};
   int fs = 5;
   for (int i = 4; i >= 0; --i) if ((feat & ~fsets[i]) == 0) fs = i;
+  if (feat & MPF_QUAD) {
+    HUAL_REQUIRE((feat & ~fsets[6]) == 0, "mproj: the quad epilogue goes with plain / reused operands only");
+    fs = 6;
+  }
 #define MPROJ_LAUNCH(NT, FS)                                                                                               \
   do {                                                                                                                     \
     HUAL_DYN_LDS((mproj_kernel<NT, FS>), 96 * 1024);                                                                       \
@@ -321,6 +352,7 @@ int launch_mproj(const MProjArgs* a, int nprob, const DropCfg& drop, hipStream_t
     case 2: MPROJ_NT(MPF_A2); break;
     case 3: MPROJ_NT(MPF_ADD); break;
     case 4: MPROJ_NT(MPF_REUSE | MPF_ADD); break;
+    case 6: MPROJ_NT(MPF_REUSE | MPF_QUAD); break;
     default: MPROJ_NT(MPF_A2 | MPF_BF16 | MPF_DROP | MPF_ADD | MPF_LN | MPF_REUSE); break;
   }
 #undef MPROJ_NT

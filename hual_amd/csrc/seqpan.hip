@@ -941,9 +941,11 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     }
     c.push_dw(j);
   }
-  float* d_cat4 = c.buf("d.cq.cat", R, 4 * D);
-  if (c.live()) {      // d [x, c2q, x * c2q, x * q2c] = d feats . W^T: four column blocks of one operand per direction, one launch
-    MProjArgs pr[2];
+  CqBwdBufs cg{};
+  cg.dCat = nullptr; cg.ldcat = 4 * D;
+  cg.dC2Q = c.act("d.cq.c2q"); cg.dQ2C = c.act("d.cq.q2c"); cg.dX = c.act("d.cq.x");
+  if (c.live()) {      // d [x, c2q, x * c2q, x * q2c] = d feats . W^T: four column blocks of one operand per direction, one launch; the
+    MProjArgs pr[2];   // four tiles of a row leave the kernel already split into d c2q, d q2c and the direct part of d x (mproj.h quad_*)
     for (int sd = 0; sd < 2; ++sd) {
       const size_t ro = sd == 0 ? 0 : (size_t)Nv;
       pr[sd] = margs(sd == 0 ? Nv : Nq, sd == 0 ? Nq : Nv);
@@ -951,14 +953,12 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       for (int p = 0; p < 4; ++p) {
         const float* img = c.nimg(pm.cq[sd].dense, p);
         pr[sd].s[p] = p == 0 ? mstep(d_cqf + ro * D, D, D, img, D, true, true) : mstep_reuse(img, D, true, true);
-        mstep_out(pr[sd].s[p], d_cat4 + ro * 4 * D + (size_t)p * D, 4 * D);
       }
+      pr[sd].quad_x = xf + ro * D; pr[sd].quad_c2q = cq.C2Q + ro * D; pr[sd].quad_q2c = cq.Q2C + ro * D;
+      pr[sd].quad_dc2q = cg.dC2Q + ro * D; pr[sd].quad_dq2c = cg.dQ2C + ro * D; pr[sd].quad_dx = cg.dX + ro * D;
     }
     c.chk(launch_mproj(pr, 2, c.drop, c.stream));
   }
-  CqBwdBufs cg{};
-  cg.dCat = d_cat4; cg.ldcat = 4 * D;
-  cg.dC2Q = c.act("d.cq.c2q"); cg.dQ2C = c.act("d.cq.q2c"); cg.dX = c.act("d.cq.x");
   cg.dD1W = c.act("d.cq.d1w"); cg.dD2 = c.act("d.cq.d2"); cg.dS0 = c.vec("d.cq.s0"); cg.dS1 = c.vec("d.cq.s1");
   cg.dM2 = c.buf("d.cq.m2", (size_t)2 * B * cq_m2_rows_host(T, L), D);
   float* dXa = c.act("d.cq.xa");
@@ -978,8 +978,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     if (c.active) c.colsum.push_back(cj);
   }
   if (c.live()) {
-    c.chk(launch_cq_bwd_pre(cq, cg, c.rs, c.stream));
-    if (c.ok()) c.chk(launch_cq_bwd_impl(cq, cg, c.rs, dXa, dXb, c.stream));
+    c.chk(launch_cq_bwd_impl(cq, cg, c.rs, dXa, dXb, c.stream));
     if (c.ok()) c.chk(launch_tri_bwd_impl(cq, cg, cqp, tri_part, c.rs, c.drop, dXa, dXb, c.stream));
   }
   float* dx = cg.dX;
