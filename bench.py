@@ -122,13 +122,19 @@ def cpu_baseline(seconds_budget=20.0):
     v = {k: torch.zeros_like(t) for k, t in p.items()}
     # thread count: the oracle's matrices are small ([1024,128] x [128,128]), more threads than that work feeds are slower -
     # time one step at each candidate count up to ALL affinity cores and keep the fastest (the scan is reported)
+    # (ascending; the scan stops at the first count that is clearly slower than the best so far - oversubscribed counts take many
+    #  seconds per step - and every candidate prints a progress line: a silent bench is taken for a hung one)
     scan = {}
+    torch.set_num_threads(max(1, min(ncores, 16)))
+    R.train_step(p, m, v, cfg, wv, batch, labels, 1e-4, 0.2, seed=1, offset=0)          # warm-up (result discarded)
     for nt in sorted({min(ncores, c) for c in (16, 32, 64, 128, ncores)}):
         torch.set_num_threads(max(1, nt))
-        R.train_step(p, m, v, cfg, wv, batch, labels, 1e-4, 0.2, seed=1, offset=0)      # warm-up (result discarded)
         t0 = time.perf_counter()
         R.train_step(p, m, v, cfg, wv, batch, labels, 1e-4, 0.2, seed=1, offset=0)
         scan[nt] = round(time.perf_counter() - t0, 3)
+        print('[bench] cpu baseline: %d threads %.3f s/step' % (nt, scan[nt]), file=sys.stderr, flush=True)
+        if scan[nt] > 1.3 * min(scan.values()):
+            break
     best = min(scan, key=scan.get)
     torch.set_num_threads(best)
     print('[bench] cpu baseline on %d threads (affinity %d, cpu_count %d; s/step by thread count: %s)'
@@ -140,6 +146,8 @@ def cpu_baseline(seconds_budget=20.0):
         losses.append(float(info['loss']))
         n += 1
         dt = time.perf_counter() - t0
+        if n % 5 == 0:
+            print('[bench] cpu baseline: %d steps, %.1f s' % (n, dt), file=sys.stderr, flush=True)
         if dt > seconds_budget or n >= 200:
             break
     out = dict(value=round(16 * n / dt, 2), unit='clips/s', cores=best, kind='port',
