@@ -452,6 +452,8 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs ain, Dro
 // rows of product k+1 are requested before product k's wait and written behind its matrix phase); the two output tiles
 // stay in registers until the last product, then go to LDS as fp32 rows for the row phase.
 #define LB_ROWS 64
+// PRE: with the layer-norm prologue (LnProjBwdArgs::pre_*) - a compile-time switch, the plain launches do not pay for its branches
+template <bool PRE>
 __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char lb_lds[];
   char* S0 = lb_lds;                                   // operand slot 0: hi | lo planes [64][256 B]; later dy_0 as fp32 rows
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   // operand rows of product 0 and everything the row phase needs (unconditional loads on clamped rows)
   float4 nv[4], xv[4], a1v[4];
   float mu[4], rsd[4];
-  const bool pre = a.pre_x != nullptr;
+  constexpr bool pre = PRE;
   const float* add1p = pre ? (a.pre_add ? a.pre_add : a.x) : (a.add1 ? a.add1 : a.x);
   const float* a0p = pre ? a.pre_dy : a.A[0];
   const int lda0 = pre ? HUAL_D : a.lda[0];
@@ -939,11 +941,16 @@ int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t 
   }
   HUAL_REQUIRE(!a.g2 || any1, "ln_proj_bwd: second layer norm without a product");
   HUAL_REQUIRE(!a.pre_x || (!a.g2 && !a.add1 && a.pre_mean && a.pre_rstd && a.pre_g && a.pre_dy), "ln_proj_bwd: layer-norm prologue");
-  HUAL_DYN_LDS(ln_proj_bwd_kernel, 160 * 1024);
+  HUAL_DYN_LDS(ln_proj_bwd_kernel<false>, 160 * 1024);
+  HUAL_DYN_LDS(ln_proj_bwd_kernel<true>, 160 * 1024);
   const size_t lds = (size_t)4 * LB_ROWS * 256 + CB_WBYTES + 2 * LB_ROWS * sizeof(float);
   const double rows = (double)a.R;
-  HUAL_LAUNCH(2.0 * rows * HUAL_D * HUAL_D * a.nsteps, 4.0 * (rows * HUAL_D * (4.0 + a.nsteps) + (double)a.nsteps * HUAL_D * HUAL_D),
-              ln_proj_bwd_kernel, dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), lds, s, a, drop);
+  if (a.pre_x)
+    HUAL_LAUNCH(2.0 * rows * HUAL_D * HUAL_D * a.nsteps, 4.0 * (rows * HUAL_D * (7.0 + a.nsteps) + (double)a.nsteps * HUAL_D * HUAL_D),
+                ln_proj_bwd_kernel<true>, dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), lds, s, a, drop);
+  else
+    HUAL_LAUNCH(2.0 * rows * HUAL_D * HUAL_D * a.nsteps, 4.0 * (rows * HUAL_D * (4.0 + a.nsteps) + (double)a.nsteps * HUAL_D * HUAL_D),
+                ln_proj_bwd_kernel<false>, dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), lds, s, a, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
