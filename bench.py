@@ -528,7 +528,7 @@ def main():
     if rank == 0:
         out = dict(metric='train clips/sec', value=round(clips / dt, 2), unit='clips/s', n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
-                   scaling='weak', vs_baseline=None, dtype='f32 (3xbf16 split MFMA, fp32 accumulate)', data='synthetic',
+                   scaling='weak', vs_baseline=None, dtype='f32 (fp16x3 / bf16x3 split-operand MFMA, fp32 accumulate)', data='synthetic',
                    config=dict(workload='Charades-STA SeqPAN train step (fwd+bwd+clip+AdamWD, dropout %.1f), batch %d/GPU, '
                                         'T=%d, vdim=%d, L=%d, C=%d, dim=128, 8 heads, 2 attention layers, random init'
                                         % (args.drop, args.batch, args.T, args.vdim, args.L, args.C),
