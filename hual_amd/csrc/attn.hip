@@ -339,7 +339,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
       kmv[t] = job.kmask[kbase + krow];
     }
   };
-  if (wave < nkp) load_v(wave);
+  // ONE block of <= 32 keys and at least four 32-query pairs (the video -> query jobs): the waves split the QUERIES instead of the
+  // keys - all four work on key block 0, wave w takes the query pairs w, w + 4, ..; dQ rows are then disjoint (one slot), and the
+  // partial dK / dV of the waves are summed through the three free slots
+  const bool qsplit = nkp == 1 && nqp >= 4;
+  if (wave < nkp || qsplit) load_v(qsplit ? 0 : wave);
   // ---- staging: per pass every thread requests its piece of all three panels (+ O for delta = dO . O) before any split
   const int stat_n = job.B * Tq * 8;
   const int npass = (max(Tqp, Tkp) * 4 + 255) >> 8;
@@ -385,13 +389,14 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
   }
   __syncthreads();
   const float scale8 = 256.0f / (float)drop_t8(drop);
-  float* slot = dQw + wave * Tqp * 16;
+  float* slot = dQw + (qsplit ? 0 : wave) * Tqp * 16;
   bool first = true;
-  for (int kp = wave; kp < nkp; kp += 4) {
+  const int qp0 = qsplit ? wave : 0, qpstep = qsplit ? 4 : 1;
+  for (int kp = qsplit ? 0 : wave; kp < nkp; kp += 4) {
     // B operands of this wave's 32 keys: [K_hi | K_hi], [K_lo | 0] and the same of V, per 16-key tile t
     bf16x8 Kb1[2], Kb2[2], Vb1[2], Vb2[2];
     int bsel[2];
-    if (kp != wave) load_v(kp);
+    if (kp != wave && !qsplit) load_v(kp);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int key = 32 * kp + 16 * t + j;
@@ -404,7 +409,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
     }
     const bf16x8 kh = panel_tr(Kp, 0, 32 * kp, lane), kl = panel_tr(Kp, 32, 32 * kp, lane);      // B operand of dQ
     f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int qp = 0; qp < nqp; ++qp) {
+    for (int qp = qp0; qp < nqp; qp += qpstep) {
       float pd[2][2][4], ds[2][2][4];          // [t][u][r]
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -478,6 +483,17 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
       }
     }
     first = false;
+    if (qsplit) {      // partial dK / dV of this wave's queries -> slots 1 .. 3 as [wave][dk | dv][t][r][lane]; summed below
+      float* red = dQw + Tqp * 16 + wave * 1024;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          red[(t * 4 + r) * 64 + lane] = dk[t][r];
+          red[512 + (t * 4 + r) * 64 + lane] = dv[t][r];
+        }
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -490,8 +506,20 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
       }
   }
   __syncthreads();
+  if (qsplit) {      // dK / dV of key block 0: the four waves' partials, in wave order
+    const float* red = dQw + Tqp * 16;
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+      const int which = idx >> 9, e = (idx >> 6) & 7, ln = idx & 63;      // e = t * 4 + r, lane ln = (j, g)
+      const float v = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+      const int kk = 16 * (e >> 2) + 4 * (ln >> 4) + (e & 3);
+      if (kk < Tk) {
+        float* dst = which ? job.dV : job.dK;
+        dst[(size_t)(kbase + kk) * job.lddkv + 16 * h + (ln & 15)] = which ? v : v * 0.25f;
+      }
+    }
+  }
   // dQ = 0.25 * sum of the slots of the waves that had keys
-  const int nw = min(4, nkp);
+  const int nw = qsplit ? 1 : min(4, nkp);
   for (int idx = threadIdx.x; idx < Tq * 4; idx += 256) {
     const int q = idx >> 2, c4 = idx & 3;
     float4 v = reinterpret_cast<const float4*>(dQw)[idx];

@@ -76,7 +76,7 @@ def test_attention_fwd(dev, B, Tq, Tk):
     assert (O.double() - ref).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize('B,Tq,Tk', [(2, 16, 16), (3, 37, 9), (2, 128, 128), (1, 20, 256), (2, 128, 20), (2, 100, 100), (1, 256, 256), (3, 1, 1)])
+@pytest.mark.parametrize('B,Tq,Tk', [(2, 16, 16), (3, 37, 9), (2, 128, 128), (1, 20, 256), (2, 128, 20), (1, 256, 20), (2, 200, 32), (2, 100, 100), (1, 256, 256), (3, 1, 1)])
 @pytest.mark.parametrize('rate', [0.0, 0.2])
 def test_attention_fwd_bwd_with_dropout(dev, B, Tq, Tk, rate):
     """hual_attention_fwd_save + hual_attention_bwd against float64 autograd of the same function with the oracle's dropout
