@@ -346,14 +346,18 @@ int launch_mproj(const MProjArgs* a, int nprob, const DropCfg& drop, hipStream_t
     else if (nt == 3) MPROJ_LAUNCH(3, FS);                                                                                 \
     else MPROJ_LAUNCH(4, FS);                                                                                              \
   } while (0)
+  // (numeric literals: the launch macro stringifies its kernel argument for the profiler, and the names must be the ones rocprofv3
+  //  prints - mproj_kernel<2, 32>, not mproj_kernel<2, MPF_REUSE>)
+  static_assert(MPF_A2 == 1 && MPF_ADD == 8 && MPF_REUSE == 32 && MPF_QUAD == 64 && (MPF_A2 | MPF_BF16 | MPF_DROP | MPF_ADD | MPF_LN | MPF_REUSE) == 63,
+                "feature-set literals below");
   switch (fs) {
     case 0: MPROJ_NT(0); break;
-    case 1: MPROJ_NT(MPF_REUSE); break;
-    case 2: MPROJ_NT(MPF_A2); break;
-    case 3: MPROJ_NT(MPF_ADD); break;
-    case 4: MPROJ_NT(MPF_REUSE | MPF_ADD); break;
-    case 6: MPROJ_NT(MPF_REUSE | MPF_QUAD); break;
-    default: MPROJ_NT(MPF_A2 | MPF_BF16 | MPF_DROP | MPF_ADD | MPF_LN | MPF_REUSE); break;
+    case 1: MPROJ_NT(32); break;      // reuse
+    case 2: MPROJ_NT(1); break;       // operand factor
+    case 3: MPROJ_NT(8); break;       // addend
+    case 4: MPROJ_NT(40); break;      // reuse + addend
+    case 6: MPROJ_NT(96); break;      // reuse + quad epilogue
+    default: MPROJ_NT(63); break;     // everything but the quad epilogue
   }
 #undef MPROJ_NT
 #undef MPROJ_LAUNCH
