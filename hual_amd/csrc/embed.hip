@@ -169,6 +169,16 @@ int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStre
   st.A = a.cemb; st.lda = CP; st.rep = cdiv(4 * CP, 128); st.ktot = 4 * CP; st.kw = 4 * CP < 128 ? 4 * CP : 128; st.wimg = a.wall_img; st.wrows = 4 * CP;
   st.first = 1; st.last = 1; st.drop_site = -1; st.add_div = 1;
   st.bias = a.ball; st.out = a.yall; st.ldo = NALL; st.ncol = NALL;
+  // relu + max over the window starts: in the same launch (the tile never leaves the registers: mproj.h pool epilogue) when the
+  // chars per word are a power of two that divides the rows of a workgroup, else a launch of its own on the stored tile
+  const int C = a.C;
+  const int mtp = (g.MT + C - 1) / C * C;
+  if ((C & (C - 1)) == 0 && C <= 16 && mtp <= 64) {
+    g.MT = mtp;
+    st.out = nullptr;
+    g.pool_cat = a.cat; g.pool_ldcat = a.ldcat; g.pool_col0 = a.word_dim; g.pool_arg = a.char_arg; g.pool_C = C;
+    return launch_mproj(&g, 1, drop, s);
+  }
   rc = launch_mproj(&g, 1, drop, s);
   if (rc) return rc;
   HUAL_LAUNCH(0.0, 0.0, char_pool_kernel, dim3(cdiv(nrows * NCH, 256)), dim3(256), 0, s, a, nrows);

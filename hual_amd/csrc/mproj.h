@@ -47,6 +47,11 @@ struct MProjArgs {
   //   dc2q = d1 + d2 * x,   dq2c = d3 * x,   dx = d0 + d2 * c2q + d3 * q2c      (rows of 128 floats, the problem's row index)
   const float* quad_x; const float* quad_c2q; const float* quad_q2c;
   float* quad_dc2q; float* quad_dq2c; float* quad_dx;
+  // "pool" epilogue (pool_cat non-null; the char CNN, modules.py:26-38): the LAST closed tile (+ bias) holds, for every word, its
+  // pool_C consecutive window rows x the 100 channels of the four filter banks; what leaves the kernel is relu + max over the valid
+  // window starts of each channel, pool_cat[word * pool_ldcat + pool_col0 + ch], and the arg-max start (-1: none positive) for the
+  // backward pass, pool_arg[word * 100 + ch].  Needs pool_C in {1, 2, 4, 8, 16} and MT % pool_C == 0; no tile is stored.
+  float* pool_cat; int pool_ldcat; int pool_col0; int32_t* pool_arg; int pool_C;
 };
 int mproj_rows(int R0, int R1 = 0);      // rows per workgroup for one problem / a pair launched together
 // one or two independent problems (blockIdx.y) in one launch

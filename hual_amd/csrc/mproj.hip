@@ -14,7 +14,7 @@ using namespace hual;
 // compile-time feature set of a launch (any step of any problem uses ...): the loop body is straight-line for the features
 // that are off and branch-free (pointer selects, predicated lanes) for those that are on - a uniform branch around a vector
 // load makes the wait-count pass give up on the loads in flight across it (vmcnt(0) right behind the prefetch)
-enum { MPF_A2 = 1, MPF_BF16 = 2, MPF_DROP = 4, MPF_ADD = 8, MPF_LN = 16, MPF_REUSE = 32, MPF_QUAD = 64 };
+enum { MPF_A2 = 1, MPF_BF16 = 2, MPF_DROP = 4, MPF_ADD = 8, MPF_LN = 16, MPF_REUSE = 32, MPF_QUAD = 64, MPF_POOL = 128 };
 
 // NT = row tiles of a workgroup (MT <= 16 NT)
 template <int NT, int F>
@@ -221,6 +221,58 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
     }
     return;
   }
+  if ((F & MPF_POOL) && a.pool_cat) {      // relu + max over the window starts of a word (mproj.h): lanes j of a tile = rows
+    const float* lb = step_at(a.nsteps - 1).bias;
+    const float4 bias = lb ? ld4(lb + ecol) : f4zero();
+    const int C = a.pool_C;
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      const int lr = 16 * rt + j, row = r0 + lr;
+      const int p = lr & (C - 1);                        // window start inside the word (MT % C == 0: words do not straddle workgroups)
+      const float4 v4 = cb_add(acc[rt], bias);
+      const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+      float best[4];
+      int arg[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = ecol + q;
+        const int k = ch < 10 ? 1 : (ch < 30 ? 2 : (ch < 60 ? 3 : 4));      // filter width of the channel's bank
+        best[q] = (p + k <= C) ? vv[q] : -INFINITY;
+        arg[q] = p;
+      }
+      // butterfly over the C rows of the word (DPP: lanes j of a 16-lane row): larger value, earlier start on ties
+      auto merge = [&](int step) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float ov = dpp_xor_partner(best[q], step);
+          const int oa = __builtin_bit_cast(int, dpp_xor_partner(__builtin_bit_cast(float, arg[q]), step));
+          const bool take = ov > best[q] || (ov == best[q] && oa < arg[q]);
+          best[q] = take ? ov : best[q];
+          arg[q] = take ? oa : arg[q];
+        }
+      };
+      if (C > 1) merge(1);
+      if (C > 2) merge(2);
+      if (C > 4) merge(4);
+      if (C > 8) merge(8);
+      if (p == 0 && lr < MT && row < RE && ecol < 100) {
+        const int word = row / C;
+        float o[4];
+        int oa[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool pos = best[q] > 0.f;
+          o[q] = pos ? best[q] : 0.f;
+          oa[q] = pos ? arg[q] : -1;
+        }
+        float* cp = a.pool_cat + (size_t)word * a.pool_ldcat + a.pool_col0 + ecol;
+        if (((a.pool_ldcat | a.pool_col0) & 3) == 0) st4(cp, make_float4(o[0], o[1], o[2], o[3]));      // (16-byte aligned rows: one store)
+        else { cp[0] = o[0]; cp[1] = o[1]; cp[2] = o[2]; cp[3] = o[3]; }
+        *reinterpret_cast<int4*>(a.pool_arg + (size_t)word * 100 + ecol) = make_int4(oa[0], oa[1], oa[2], oa[3]);
+      }
+    }
+    return;
+  }
   if (!(F & MPF_LN) || !a.ln_g) return;
   // ---- LN mode: the last tile (+ bias) -> LDS as fp32 rows -> layer norm (+ position embeddings) row by row
   float4* D0 = reinterpret_cast<float4*>(S0);                // both slots are free behind the last matrix phase (barrier above)
@@ -286,7 +338,7 @@ static int check_mproj(const MProjArgs& a, double& flops, double& bytes, int& fe
     HUAL_REQUIRE(!s.reuse || k > 0, "mproj: nothing to reuse");
     HUAL_REQUIRE(s.wimg && s.wrows >= 1, "mproj: weight image");
     feat |= (s.A2 ? MPF_A2 : 0) | (s.a_bf16 ? MPF_BF16 : 0) | (s.drop_site >= 0 ? MPF_DROP : 0) | (s.add ? MPF_ADD : 0) | (s.reuse ? MPF_REUSE : 0);
-    HUAL_REQUIRE(!s.last || (a.ln_g && k == a.nsteps - 1 && !s.out) || (a.quad_x && !s.out) ||
+    HUAL_REQUIRE(!s.last || (a.ln_g && k == a.nsteps - 1 && !s.out) || (a.quad_x && !s.out) || (a.pool_cat && k == a.nsteps - 1 && !s.out) ||
                  (s.out && (s.ldo % 4) == 0 && s.ncol >= 4 && s.ncol <= 128 && (s.ncol % 4) == 0), "mproj: closing step needs a destination");
     HUAL_REQUIRE(!s.add || s.add_div >= 1, "mproj: add_div");
     HUAL_REQUIRE(k == 0 || s.first == a.s[k - 1].last, "mproj: a tile starts exactly behind a closed one");
@@ -301,6 +353,13 @@ static int check_mproj(const MProjArgs& a, double& flops, double& bytes, int& fe
     HUAL_REQUIRE(a.nsteps == 4 && a.quad_c2q && a.quad_q2c && a.quad_dc2q && a.quad_dq2c && a.quad_dx && !a.ln_g, "mproj: quad epilogue");
     for (int k = 0; k < 4; ++k) HUAL_REQUIRE(a.s[k].first && a.s[k].last && a.s[k].rep == 1 && !a.s[k].out, "mproj: quad epilogue takes four closing steps");
     bytes += 4.0 * a.R * 128.0 * 6.0;
+  }
+  if (a.pool_cat) {
+    feat |= MPF_POOL;
+    const int C = a.pool_C;
+    HUAL_REQUIRE(a.pool_arg && (C == 1 || C == 2 || C == 4 || C == 8 || C == 16) && (a.MT % C) == 0 && (a.R % C) == 0 && !a.ln_g && !a.quad_x,
+                 "mproj: pool epilogue needs a power-of-two window count <= 16 that divides the rows of a workgroup");
+    bytes += 8.0 * (a.R / C) * 100.0;
   }
   if (a.ln_g) {
     feat |= MPF_LN;
@@ -333,6 +392,10 @@ int launch_mproj(const MProjArgs* a, int nprob, const DropCfg& drop, hipStream_t
     HUAL_REQUIRE((feat & ~fsets[6]) == 0, "mproj: the quad epilogue goes with plain / reused operands only");
     fs = 6;
   }
+  if (feat & MPF_POOL) {
+    HUAL_REQUIRE(feat == MPF_POOL, "mproj: the pool epilogue goes with plain operands only");
+    fs = 7;
+  }
 #define MPROJ_LAUNCH(NT, FS)                                                                                               \
   do {                                                                                                                     \
     HUAL_DYN_LDS((mproj_kernel<NT, FS>), 96 * 1024);                                                                       \
@@ -348,7 +411,7 @@ int launch_mproj(const MProjArgs* a, int nprob, const DropCfg& drop, hipStream_t
   } while (0)
   // (numeric literals: the launch macro stringifies its kernel argument for the profiler, and the names must be the ones rocprofv3
   //  prints - mproj_kernel<2, 32>, not mproj_kernel<2, MPF_REUSE>)
-  static_assert(MPF_A2 == 1 && MPF_ADD == 8 && MPF_REUSE == 32 && MPF_QUAD == 64 && (MPF_A2 | MPF_BF16 | MPF_DROP | MPF_ADD | MPF_LN | MPF_REUSE) == 63,
+  static_assert(MPF_A2 == 1 && MPF_ADD == 8 && MPF_REUSE == 32 && MPF_QUAD == 64 && MPF_POOL == 128 && (MPF_A2 | MPF_BF16 | MPF_DROP | MPF_ADD | MPF_LN | MPF_REUSE) == 63,
                 "feature-set literals below");
   switch (fs) {
     case 0: MPROJ_NT(0); break;
@@ -357,6 +420,7 @@ int launch_mproj(const MProjArgs* a, int nprob, const DropCfg& drop, hipStream_t
     case 3: MPROJ_NT(8); break;       // addend
     case 4: MPROJ_NT(40); break;      // reuse + addend
     case 6: MPROJ_NT(96); break;      // reuse + quad epilogue
+    case 7: MPROJ_NT(128); break;     // pool epilogue
     default: MPROJ_NT(63); break;     // everything but the quad epilogue
   }
 #undef MPROJ_NT
