@@ -123,9 +123,11 @@ def test_other_feature_widths(vdim):
 
 
 @pytest.mark.parametrize('shape', [dict(B=1, T=5, L=3, C=4, seed=2, max_vlen=8), dict(B=8, T=64, L=20, C=8, seed=9, max_vlen=64),
-                                   dict(B=5, T=100, L=30, C=6, seed=4, max_vlen=100), dict(B=3, T=37, L=9, C=4, seed=11, max_vlen=40)])
+                                   dict(B=5, T=100, L=30, C=6, seed=4, max_vlen=100), dict(B=3, T=37, L=9, C=4, seed=11, max_vlen=40),
+                                   dict(B=2, T=9, L=5, C=16, seed=13, max_vlen=16)])
 @pytest.mark.parametrize('drop', [0.0, 0.2])
 def test_tile_boundary_shapes(shape, drop):
     """shapes that exercise the tile boundaries of the fused multi-layer kernels: clips shorter / longer than a workgroup's
-    rows, row counts that are not multiples of the tile, a single 5-frame clip"""
+    rows, row counts that are not multiples of the tile, a single 5-frame clip; chars per word 4 / 8 / 16 (the char CNN's pool epilogue)
+    and 6 (its stand-alone pooling kernel)"""
     _check_all(pu.make_case(**shape), drop)
