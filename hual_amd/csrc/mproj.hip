@@ -136,6 +136,16 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
   int slot = 0, si = 0, ri = 0;
   float4 acc[NT];
   float4 qd[(F & MPF_QUAD) ? 4 : 1][NT];               // quad epilogue: the closed tiles of the four steps
+  float4 lastb = f4zero();                             // bias of the step in flight (the LN / pool epilogues add the last step's)
+  constexpr bool QPRE = (F & MPF_QUAD) && NT <= 3;     // (four row tiles: the 48 extra registers would spill)
+  float4 qx[QPRE ? NT : 1], qc[QPRE ? NT : 1], qq[QPRE ? NT : 1];
+  if (QPRE && a.quad_x) {      // what the quad epilogue reads: requested here, arrives under the four steps
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      const size_t off = (size_t)min(r0 + 16 * rt + j, R - 1) * HUAL_D + ecol;
+      qx[rt] = ld4(a.quad_x + off); qc[rt] = ld4(a.quad_c2q + off); qq[rt] = ld4(a.quad_q2c + off);
+    }
+  }
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) acc[rt] = f4zero();
 #pragma unroll 1
@@ -185,6 +195,7 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
       const float4 o = st.first ? f4zero() : acc[rt];
       acc[rt] = make_float4(fmaf(accp[rt][0], ir, o.x), fmaf(accp[rt][1], ir, o.y), fmaf(accp[rt][2], ir, o.z), fmaf(accp[rt][3], ir, o.w));
     }
+    lastb = st.bias ? bias : f4zero();
     {      // close the tile: bias, relu, addend, store (lanes outside the tensor / a step that does not close: no store)
       float* outp = st.out ? st.out : const_cast<float*>(wdummy);
 #pragma unroll
@@ -212,7 +223,8 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
       const int row = r0 + 16 * rt + j;
       if (16 * rt + j >= MT || row >= RE) continue;
       const size_t off = (size_t)row * HUAL_D + ecol;
-      const float4 x = ld4(a.quad_x + off), c2q = ld4(a.quad_c2q + off), q2c = ld4(a.quad_q2c + off);
+      const float4 x = QPRE ? qx[QPRE ? rt : 0] : ld4(a.quad_x + off), c2q = QPRE ? qc[QPRE ? rt : 0] : ld4(a.quad_c2q + off),
+                   q2c = QPRE ? qq[QPRE ? rt : 0] : ld4(a.quad_q2c + off);
       const float4 d0 = qd[0][rt], d1 = qd[1][rt], d2 = qd[2][rt], d3 = qd[3][rt];
       st4(a.quad_dc2q + off, make_float4(d1.x + d2.x * x.x, d1.y + d2.y * x.y, d1.z + d2.z * x.z, d1.w + d2.w * x.w));
       st4(a.quad_dq2c + off, make_float4(d3.x * x.x, d3.y * x.y, d3.z * x.z, d3.w * x.w));
@@ -222,8 +234,7 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
     return;
   }
   if ((F & MPF_POOL) && a.pool_cat) {      // relu + max over the window starts of a word (mproj.h): lanes j of a tile = rows
-    const float* lb = step_at(a.nsteps - 1).bias;
-    const float4 bias = lb ? ld4(lb + ecol) : f4zero();
+    const float4 bias = lastb;                           // (loaded with the last step's operands: no round trip here)
     const int C = a.pool_C;
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
@@ -278,10 +289,8 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
   float4* D0 = reinterpret_cast<float4*>(S0);                // both slots are free behind the last matrix phase (barrier above)
   cb_barrier();                                         // every wave is past the last matrix phase
   {
-    const float* lb = step_at(a.nsteps - 1).bias;
-    const float4 bias = lb ? ld4(lb + ecol) : f4zero();
 #pragma unroll
-    for (int rt = 0; rt < NT; ++rt) D0[(16 * rt + j) * 32 + (ecol >> 2)] = cb_add(acc[rt], bias);
+    for (int rt = 0; rt < NT; ++rt) D0[(16 * rt + j) * 32 + (ecol >> 2)] = cb_add(acc[rt], lastb);
   }
   const float4 gam = ld4(a.ln_g + col), bet = ld4(a.ln_b + col);
   cb_barrier();
