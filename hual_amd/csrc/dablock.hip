@@ -481,12 +481,15 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   const float* add1p = pre ? (a.pre_add ? a.pre_add : a.x) : (a.add1 ? a.add1 : a.x);
   const float* a0p = pre ? a.pre_dy : a.A[0];
   const int lda0 = pre ? HUAL_D : a.lda[0];
+  uint32_t nkb[4];                                     // keep-bit bytes of the operand rows in flight
+  const uint8_t* kb0p = a.a_bits[0] ? a.a_bits[0] : reinterpret_cast<const uint8_t*>(a.x);
   float4 pxv[4];                                       // prologue: rows / statistics of the layer norm in front
   float pmu[4], prs[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int row = min(r0 + grp + 16 * u, R - 1);
     nv[u] = ld4(a0p + (size_t)row * lda0 + col);
+    nkb[u] = kb0p[(size_t)row * 16 + (l32 >> 1)];
     xv[u] = ld4(a.x + (size_t)row * HUAL_D + col);
     a1v[u] = ld4(add1p + (size_t)row * HUAL_D + col);
     mu[u] = a.mean[row];
@@ -530,8 +533,8 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       if (lr >= MT) continue;
       const bool ok = row < RE;
       float4 v = ok ? nv[u] : f4zero();
-      if (a.a_bits[k]) {      // dropout' with the keep bits the forward left
-        if (dr.enabled) v = f4_select(bits_nibble(a.a_bits[k], min(row, R - 1), l32), make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
+      if (a.a_bits[k]) {      // dropout' with the keep bits the forward left (requested with the rows)
+        if (dr.enabled) v = f4_select((nkb[u] >> (4 * (l32 & 1))) & 15u, make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
         if (ok && a.a_save[k]) st4_nt(a.a_save[k] + (size_t)row * HUAL_D + col, v);
       }
       const float inv = cb_store_operand(S, S + LB_ROWS * 256, lr, l32, v);
@@ -546,8 +549,13 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
 #pragma unroll 1
   for (int k = 0; k < a.nsteps; ++k) {
     if (k + 1 < a.nsteps) {
+      const uint8_t* nbp = a.a_bits[k + 1] ? a.a_bits[k + 1] : reinterpret_cast<const uint8_t*>(a.x);      // (no bits: a byte that is ignored)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) nv[u] = ld4(a.A[k + 1] + (size_t)min(r0 + grp + 16 * u, R - 1) * a.lda[k + 1] + col);
+      for (int u = 0; u < 4; ++u) {
+        const size_t row = (size_t)min(r0 + grp + 16 * u, R - 1);
+        nv[u] = ld4(a.A[k + 1] + row * a.lda[k + 1] + col);
+        nkb[u] = nbp[row * 16 + (l32 >> 1)];
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     cb_barrier();
@@ -585,6 +593,19 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       if (a.g2) D1[lr * 32 + (ecol >> 2)] = acc1[r];
     }
   }
+  // keep bits of the row phase (dropout' of dy_0 / of dx): requested together in front of the barrier - a load behind a branch
+  // inside the row loop is a round trip of its own per row (absent planes: a byte of x that is not used)
+  uint32_t kb1[4], kbz[4];
+  {
+    const uint8_t* b1p = a.dy1_bits ? a.dy1_bits : reinterpret_cast<const uint8_t*>(a.x);
+    const uint8_t* bzp = a.dz_bits ? a.dz_bits : reinterpret_cast<const uint8_t*>(a.x);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t row = (size_t)min(r0 + grp + 16 * u, R - 1);
+      kb1[u] = b1p[row * 16 + (l32 >> 1)];
+      kbz[u] = bzp[row * 16 + (l32 >> 1)];
+    }
+  }
   cb_barrier();
   // ---- row phase: layer norm(s) backward.  dy = dy*g ; dx = rstd * (gv - mean(gv) - xhat * mean(gv * xhat))   (ln_bwd_kernel)
   float4 sg1 = f4zero(), sb1 = f4zero();
@@ -597,7 +618,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     const float mean = mu[u], rstd = rsd[u];
     const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
     float4 dy = D0[lr * 32 + l32];
-    if (a.dy1_bits && dr.enabled) dy = f4_select(bits_nibble(a.dy1_bits, row, l32), make_float4(dy.x * dr.scale, dy.y * dr.scale, dy.z * dr.scale, dy.w * dr.scale));
+    if (a.dy1_bits && dr.enabled) dy = f4_select((kb1[u] >> (4 * (l32 & 1))) & 15u, make_float4(dy.x * dr.scale, dy.y * dr.scale, dy.z * dr.scale, dy.w * dr.scale));
     sb1 = cb_add(sb1, dy);
     sg1 = cb_fma(dy, xh, sg1);
     float4 gv = cb_mul(dy, g1);
@@ -614,7 +635,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     if (a.add1 || pre) dx = make_float4(__fadd_rn(dx.x, a1v[u].x), __fadd_rn(dx.y, a1v[u].y), __fadd_rn(dx.z, a1v[u].z), __fadd_rn(dx.w, a1v[u].w));
     st4(a.dx + off, dx);
     if (a.dz) {
-      if (a.dz_bits && dr.enabled) dx = f4_select(bits_nibble(a.dz_bits, row, l32), make_float4(dx.x * dr.scale, dx.y * dr.scale, dx.z * dr.scale, dx.w * dr.scale));
+      if (a.dz_bits && dr.enabled) dx = f4_select((kbz[u] >> (4 * (l32 & 1))) & 15u, make_float4(dx.x * dr.scale, dx.y * dr.scale, dx.z * dr.scale, dx.w * dr.scale));
       st4(a.dz + off, dx);
     }
   }
