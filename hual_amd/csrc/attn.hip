@@ -118,16 +118,23 @@ __device__ __forceinline__ void attn_fwd_body(const AttnJob& job, int b, int h, 
   char* Vp = Kp + Tkp * 64;                         // [Tkp][64]
   float* Bias = reinterpret_cast<float*>(Vp + Tkp * 64);      // [2][Tkp]: additive term of a key for padded / valid queries
   const int nqt = (Tq + 15) >> 4;
-  // the wave's first query tile is requested before the staging so that it arrives under it
-  float4 qv0 = f4zero(), qv1 = f4zero();
-  float mq = 0.f;
-  auto load_q = [&](int qt) {
+  // the dropout stream's key / offset live in device memory: read at the top (behind the barrier the load was a round trip of its own)
+  constexpr bool dodrop = DROP;
+  uint32_t k0 = 0, k1 = 0, off = 0;
+  if (dodrop) {      // (through the constant address space: scalar loads, no vector-memory wait in front of the staging loads)
+    const __attribute__((address_space(4))) uint32_t* sp = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)drop.state;
+    k0 = sp[0]; k1 = sp[1]; off = sp[2];
+  }
+  // the wave's first query tile is requested before the staging so that it arrives under it, every further one while the tile
+  // in front of it is computed (two register sets); the query mask is read in the staging phase, from LDS afterwards
+  float4 qv0 = f4zero(), qv1 = f4zero(), nq0 = f4zero(), nq1 = f4zero();
+  auto load_q = [&](int qt, float4& d0, float4& d1) {
     const int qrow = qbase + min(16 * qt + j, Tq - 1);
     const float* qp = job.Q + (size_t)qrow * job.ldq + 16 * h + 8 * (g & 1);
-    qv0 = ld4(qp); qv1 = ld4(qp + 4);
-    mq = job.qmask[qrow];
+    d0 = ld4(qp); d1 = ld4(qp + 4);
   };
-  if (wave < nqt) load_q(wave);
+  if (wave < nqt) load_q(wave, qv0, qv1);
+  float qmk = 0.f;                                   // mask of query wave * 16 + j (the wave's first tile): requested behind the panels
   {
     // all loads of the block's panels first, then the splits and LDS stores
     const float* Kg = job.K + (size_t)kbase * job.ldkv + 16 * h;
@@ -139,8 +146,9 @@ __device__ __forceinline__ void attn_fwd_body(const AttnJob& job, int b, int h, 
       kv[it] = ld4(Kg + (size_t)row * job.ldkv + 4 * c4);
       vv[it] = ld4(Vg + (size_t)row * job.ldkv + 4 * c4);
     }
-    float km = 0.f;
-    if (threadIdx.x < Tkp) km = job.kmask[kbase + min((int)threadIdx.x, Tk - 1)];
+    // (unconditional on a clamped index: a load behind a lane-dependent branch is waited for inside that branch)
+    const float km = job.kmask[kbase + min((int)threadIdx.x, Tk - 1)];
+    qmk = job.qmask[qbase + min(16 * min(wave, nqt - 1) + j, Tq - 1)];
 #pragma unroll
     for (int it = 0; it < NST; ++it) {
       const int idx = threadIdx.x + NT * it, row = idx >> 2, c4 = idx & 3;
@@ -156,16 +164,19 @@ __device__ __forceinline__ void attn_fwd_body(const AttnJob& job, int b, int h, 
     }
   }
   __syncthreads();
-  constexpr bool dodrop = DROP;
-  uint32_t k0 = 0, k1 = 0, off = 0;
-  if (dodrop) { k0 = drop.state[0]; k1 = drop.state[1]; off = drop.state[2]; }
   const uint32_t t8 = drop_t8(drop);
   const float scale8 = 256.0f / (float)t8;
   for (int qt = wave; qt < nqt; qt += NT / 64) {
     const int q0 = qt * 16;
     const bool qok = q0 + j < Tq;
     const int qrow = qbase + min(q0 + j, Tq - 1);
-    if (qt != wave) load_q(qt);
+    if (qt != wave) { qv0 = nq0; qv1 = nq1; }
+    const bool more_q = qt + NT / 64 < nqt;
+    const int qnext = more_q ? qt + NT / 64 : qt;     // (the last tile asks for itself again: no branch around the loads)
+    load_q(qnext, nq0, nq1);
+    const float mqn = job.qmask[qbase + min(16 * qnext + j, Tq - 1)];
+    const float mq = qmk;
+    qmk = mqn;
     // B operands: [Q_hi | Q_hi] and [Q_lo | 0] over the 32 slots (lane g covers head dims 8 (g & 1) .. + 7)
     uint4 qh, ql;
     split8(qv0, qv1, qh, ql);
