@@ -83,6 +83,19 @@ __device__ __forceinline__ uint2 ld2_global(const void* p) {
   return make_uint2(v.x, v.y);
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// stores through a pointer whose address space the compiler cannot see (read from LDS / a device table): as FLAT stores they
+// would count in lgkmcnt too
+__device__ __forceinline__ void st4_global(float* p, float4 v) {
+  const gvec_f4 vv = {v.x, v.y, v.z, v.w};
+  *(__attribute__((address_space(1))) gvec_f4*)(uintptr_t)p = vv;
+}
+__device__ __forceinline__ void st1f_global(float* p, float v) { *(__attribute__((address_space(1))) float*)(uintptr_t)p = v; }
+__device__ __forceinline__ void st1b_global(uint8_t* p, uint8_t v) { *(__attribute__((address_space(1))) uint8_t*)(uintptr_t)p = v; }
+typedef int gvec_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4i_global(int32_t* p, int a, int b, int c, int d) {
+  const gvec_i4 vv = {a, b, c, d};
+  *(__attribute__((address_space(1))) gvec_i4*)(uintptr_t)p = vv;
+}
 // streaming store: tensors that are written once and only read again much later (saved for the backward pass, operands of the
 // weight-gradient launch at the end of the step) - measured -4 % on da_post_kernel against plain stores
 __device__ __forceinline__ void st4_nt(float* p, float4 v) {

@@ -299,7 +299,9 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
     for (int u = 0; u < 4; ++u) {                             // unconditional loads on clamped rows, see the forward kernel
       const int i = grp + 16 * u, row = min(max(xbase + i, 0), R - 1);
       dv[u] = ld4(a.dx_in + (size_t)row * HUAL_D + col);
-      zn[u] = bits_nibble(a.relu_bits3, row, l32) & (dr.enabled ? bits_nibble(a.keep_bits3, row, l32) : 15u);
+      // (both planes read unconditionally: a load behind the dropout branch would be waited for inside it, a round trip per row)
+      const uint32_t kn = bits_nibble(a.keep_bits3, row, l32);
+      zn[u] = bits_nibble(a.relu_bits3, row, l32) & (dr.enabled ? kn : 15u);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -334,7 +336,8 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
     for (int u = 0; u < 4; ++u) {                             // unconditional loads on clamped rows
       const int tc = min(max(rbase + ra + u, 0), R - 1);
       xv[u] = ld4(L.x + (size_t)tc * HUAL_D + col);
-      zb[u] = bits_nibble(rprev, tc, l32) & (dr.enabled ? bits_nibble(kprev, tc, l32) : 15u);
+      const uint32_t kn = bits_nibble(kprev, tc, l32);      // (unconditional, see the prologue)
+      zb[u] = bits_nibble(rprev, tc, l32) & (dr.enabled ? kn : 15u);
       mu[u] = L.mean[tc];
       rsd[u] = L.rstd[tc];
     }

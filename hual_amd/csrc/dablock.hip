@@ -167,9 +167,8 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_pair_kernel(LnProjArgs a0,
 #define DP_SLOT (2 * DP_PLANE)
 #define DP_NB 11                          // small vectors in LDS: 9 biases + ln2 gamma, beta
 
-__global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs ain, DropCfg drop) {
+__global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char dp_lds[];
-  const DaPostArgs a = args_now(ain);                  // (tilecore.h: every argument in a register before the first phase)
   char* P0 = dp_lds;
   char* P1 = P0 + DP_SLOT;
   char* P2 = P1 + DP_SLOT;
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs ain, Dro
   }
   {
     float4 pv = f4zero();
-    if (grp < 9) pv = ld4(ain.b[grp] + col);
+    if (grp < 9) pv = ld4(a.b[grp] + col);
     else if (grp == 9) pv = ld4(a.ln2_g + col);
     else if (grp == 10) pv = ld4(a.ln2_b + col);
     if (grp < DP_NB) bl[grp * 32 + l32] = pv;
@@ -665,9 +664,8 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
 
 // ------------------------------------------------------------------------------------------------------
 // Backward of the gated middle of the dual attention (DaMidBwdArgs): ten weight steps, three operand slots.
-__global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs ain) {
+__global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char dm_lds[];
-  const DaMidBwdArgs a = args_now(ain);
   char* P0 = dm_lds;
   char* P1 = P0 + DP_SLOT;
   char* P2 = P1 + DP_SLOT;

@@ -10,6 +10,13 @@
 
 using namespace hual;
 
+// Every pointer of this kernel comes out of the LDS copy of the step descriptors (or sits next to them in the argument struct): the
+// compiler cannot see its address space and would emit FLAT loads / stores, which count in lgkmcnt as well as vmcnt - every wait
+// for an LDS read of the matrix phase would then wait for the operand prefetch too.  All memory traffic goes through the
+// global-address-space helpers of common.h.
+#define ld4 ld4_global
+#define st4 st4_global
+
 #define MP_ROWS 64
 // compile-time feature set of a launch (any step of any problem uses ...): the loop body is straight-line for the features
 // that are off and branch-free (pointer selects, predicated lanes) for those that are on - a uniform branch around a vector
@@ -77,7 +84,7 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
     for (int u = 0; u < NU; ++u) {
       const size_t row = (size_t)min(r0 + grp + 16 * u, R - 1);
       if ((F & MPF_BF16) && st.a_bf16) {      // (the widening happens at the consumer: the raw 8 bytes travel in .x / .y)
-        const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(st.A) + row * st.lda + kc);
+        const uint2 raw = ld2_global(reinterpret_cast<const uint16_t*>(st.A) + row * st.lda + kc);
         nv[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), 0.f, 0.f);
       } else {
         nv[u] = ld4(reinterpret_cast<const float*>(st.A) + row * st.lda + kc);
@@ -107,7 +114,7 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
         nb[2 * pr] = na; nb[2 * pr + 1] = nbb;
         if (st.keep_out) {      // even lane: row A's byte, odd lane: row B's (tilecore.h drop_nib2_r)
           const bool odd = (c4 & 1u) != 0u;
-          if (odd ? okB : okA) st.keep_out[(size_t)(r0 + (odd ? lrB : lrA)) * st.ld_keep + (c4 >> 1)] = (uint8_t)byte;
+          if (odd ? okB : okA) st1b_global(st.keep_out + (size_t)(r0 + (odd ? lrB : lrA)) * st.ld_keep + (c4 >> 1), (uint8_t)byte);
         }
       }
     }
@@ -278,8 +285,8 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
         }
         float* cp = a.pool_cat + (size_t)word * a.pool_ldcat + a.pool_col0 + ecol;
         if (((a.pool_ldcat | a.pool_col0) & 3) == 0) st4(cp, make_float4(o[0], o[1], o[2], o[3]));      // (16-byte aligned rows: one store)
-        else { cp[0] = o[0]; cp[1] = o[1]; cp[2] = o[2]; cp[3] = o[3]; }
-        *reinterpret_cast<int4*>(a.pool_arg + (size_t)word * 100 + ecol) = make_int4(oa[0], oa[1], oa[2], oa[3]);
+        else { st1f_global(cp, o[0]); st1f_global(cp + 1, o[1]); st1f_global(cp + 2, o[2]); st1f_global(cp + 3, o[3]); }
+        st4i_global(a.pool_arg + (size_t)word * 100 + ecol, oa[0], oa[1], oa[2], oa[3]);
       }
     }
     return;
@@ -309,7 +316,7 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
     const size_t off = (size_t)row * HUAL_D + col;
     if (a.x_out) st4(a.x_out + off, x);
     st4(a.y_out + off, y);
-    if (l32 == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    if (l32 == 0) { st1f_global(a.mean + row, mean); st1f_global(a.rstd + row, rstd); }
   }
 }
 
@@ -320,6 +327,9 @@ __global__ __launch_bounds__(CB_THREADS) void mproj_pair_kernel(MProjArgs a0, MP
   if (blockIdx.y == 0) mproj_body<NT, F>(a0, drop);
   else mproj_body<NT, F>(a1, drop);
 }
+
+#undef ld4
+#undef st4
 
 #if defined(HUAL_STAMPS) && HUAL_STAMPS == 9
 extern "C" int hual_debug_stamps(unsigned long long* out, int n) {

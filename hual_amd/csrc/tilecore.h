@@ -11,7 +11,9 @@
 // (~1.5 us measured), and the compiler sinks those loads to the first use: a kernel that walks a large argument struct phase by
 // phase pays one round trip per phase.  args_now() makes every dword of the struct live in a scalar register at the top of the
 // kernel (one burst of s_load_dwordx16, one round trip); structs that are indexed dynamically go through LDS instead
-// (args_to_lds + uni()).
+// (args_to_lds + uni()).  CAUTION: a pointer that went through args_now() / uni() has lost its address space - loads / stores
+// through it are FLAT instructions, which count in lgkmcnt as well as vmcnt (every LDS wait then waits for them too: measured on
+// mproj, whose operand prefetch no longer ran under the matrix phase): go through ld4_global / st4_global (common.h) with them.
 template <class T>
 __device__ __forceinline__ T args_now(const T& a) {
   static_assert(sizeof(T) % 4 == 0, "argument structs are dword multiples");
@@ -80,9 +82,10 @@ __device__ __forceinline__ DropRegs drop_load(const hual::DropCfg& d) {
   const uint32_t t = (uint32_t)(((uint64_t)d.thresh + (1ull << 15)) >> 16);
   r.t16 = t < 1u ? 1u : (t > 65536u ? 65536u : t);
   if (d.enabled) {
-    r.k0 = __builtin_amdgcn_readfirstlane(d.state[0]);
-    r.k1 = __builtin_amdgcn_readfirstlane(d.state[1]);
-    r.off = __builtin_amdgcn_readfirstlane(d.state[2]);
+    // scalar loads (constant address space: the state is only written by the optimizer launch): a vector load + readfirstlane
+    // here is waited for on the spot - a memory round trip at the top of every fused kernel before its operand loads are issued
+    const __attribute__((address_space(4))) uint32_t* sp = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)d.state;
+    r.k0 = sp[0]; r.k1 = sp[1]; r.off = sp[2];
   }
   return r;
 }
