@@ -211,10 +211,15 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     rm[r] = a.rowmask[row];
   }
   {
-    float4 pv = f4zero();
-    if (grp < 9) pv = ld4(a.b[grp] + col);
-    else if (grp == 9) pv = ld4(a.ln2_g + col);
-    else if (grp == 10) pv = ld4(a.ln2_b + col);
+    // the group's vector.  Indexing the pointer array of the argument struct with the lane-dependent group is a vector load of the
+    // POINTER followed by the load through it - two dependent round trips; the two groups of a wave are wave-uniform, so their
+    // pointers come out of the argument struct by scalar loads and the lane picks its half's (groups 11 .. 15 read a vector they
+    // do not store)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    auto vec_ptr = [&](int k) -> const float* { return k < 9 ? a.b[k] : (k == 9 ? a.ln2_g : a.ln2_b); };
+    const float* pe = vec_ptr(min(2 * wv, 10));
+    const float* po = vec_ptr(min(2 * wv + 1, 10));
+    const float4 pv = ld4_global(((lane & 32) ? po : pe) + col);
     if (grp < DP_NB) bl[grp * 32 + l32] = pv;
   }
   // ---- RP0: attention outputs -> slots 0, 1
