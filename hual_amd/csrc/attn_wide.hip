@@ -105,7 +105,7 @@ __device__ __forceinline__ void aw_body(const AwArgs& a, int b, int h, char* lds
   }
   __syncthreads();
   uint32_t k0 = 0, k1 = 0, off = 0;
-  if (DROP) { k0 = drop.state[0]; k1 = drop.state[1]; off = drop.state[2]; }
+  if (DROP) { k0 = drop_state(drop, 0); k1 = drop_state(drop, 1); off = drop_state(drop, 2); }      // scalar loads (philox.h)
   const uint32_t t8 = aw_t8(drop);
   const float scale8 = 256.0f / (float)t8;
   for (int qt = wave; qt < nqt; qt += 4) {

@@ -32,8 +32,13 @@ __device__ __forceinline__ uint4_ philox4x32_10(uint32_t c0, uint32_t c1, uint32
 }
 
 // multiplicative keep-mask {0, scale} for the 4 columns [4*c0, 4*c0+3] of `row` at call-site `site`
+// word i of the dropout stream's state (key lo, key hi, step): through the constant address space - scalar loads out of the scalar
+// cache (the state is only written by the optimizer launch); as vector loads every call waited for a memory access of its own
+__device__ __forceinline__ uint32_t drop_state(const hual::DropCfg& d, int i) {
+  return ((const __attribute__((address_space(4))) uint32_t*)(uintptr_t)d.state)[i];
+}
 __device__ __forceinline__ float4 drop_mask4(const hual::DropCfg& d, uint32_t site, uint32_t row, uint32_t col4) {
-  uint4_ r = philox4x32_10(col4, row, site, d.state[2], d.state[0], d.state[1]);
+  uint4_ r = philox4x32_10(col4, row, site, drop_state(d, 2), drop_state(d, 0), drop_state(d, 1));
   float4 m;
   m.x = r.x < d.thresh ? d.scale : 0.f;
   m.y = r.y < d.thresh ? d.scale : 0.f;
@@ -45,7 +50,7 @@ __device__ __forceinline__ float4 drop_mask4(const hual::DropCfg& d, uint32_t si
 // the same draw as 4 keep bits (bit c = column 4*col4 + c is kept).  Forward kernels store this byte so that backward
 // kernels do not have to repeat the Philox rounds (40 quarter-rate integer multiplies per call on CDNA4).
 __device__ __forceinline__ uint32_t drop_bits4(const hual::DropCfg& d, uint32_t site, uint32_t row, uint32_t col4) {
-  uint4_ r = philox4x32_10(col4, row, site, d.state[2], d.state[0], d.state[1]);
+  uint4_ r = philox4x32_10(col4, row, site, drop_state(d, 2), drop_state(d, 0), drop_state(d, 1));
   return (r.x < d.thresh ? 1u : 0u) | (r.y < d.thresh ? 2u : 0u) | (r.z < d.thresh ? 4u : 0u) | (r.w < d.thresh ? 8u : 0u);
 }
 __device__ __forceinline__ float4 mask_from_bits4(uint32_t bits, float scale) {
