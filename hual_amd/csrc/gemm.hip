@@ -81,16 +81,18 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
   const bool a16 = job.a_bf16 != 0;
   auto a_fetch = [&](int ks, float4& x0, float4& x1) {
     const int kk = q * KS + 32 * ks + 8 * g;
-    if (a16) {                                          // bfloat16 features: 16 bytes = the lane's 8 values, widened exactly
-      const uint4 raw = kk < K ? *reinterpret_cast<const uint4*>(Ap16 + kk) : make_uint4(0u, 0u, 0u, 0u);
-      x0 = make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
-                       __uint_as_float(raw.y & 0xffff0000u));
-      x1 = make_float4(__uint_as_float(raw.z << 16), __uint_as_float(raw.z & 0xffff0000u), __uint_as_float(raw.w << 16),
-                       __uint_as_float(raw.w & 0xffff0000u));
+    if (a16) {      // bfloat16 features: 16 bytes = the lane's 8 values; they travel RAW in x0 and are widened where they are used
+      // (widening here would wait for the load just issued: a memory round trip per k-step - the bfloat16 feed was no faster)
+      const uint4 raw = *reinterpret_cast<const uint4*>(Ap16 + min(kk, K - 8));
+      x0 = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
       return;
     }
-    x0 = kk < K ? ld4(Ap + kk) : f4zero();              // K is a multiple of 8: a lane's 8 values are in or out together
-    x1 = kk < K ? ld4(Ap + kk + 4) : f4zero();
+    // K is a multiple of 8: a lane's 8 values are in or out together.  Unconditional loads on a clamped column (a load behind
+    // the lane-dependent branch is waited for inside it), selected to zero beyond K at the top of their k-step
+    // (the select happens where the values are used: at the load it would be a wait for the load just issued)
+    const int kc = min(kk, K - 8);
+    x0 = ld4(Ap + kc);
+    x1 = ld4(Ap + kc + 4);
   };
   float4 c0, c1, n0 = f4zero(), n1 = f4zero();
   a_fetch(0, c0, c1);
@@ -101,6 +103,12 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
   for (int ks = 0; ks < nks; ++ks) {
     float4 f0 = f4zero(), f1 = f4zero();
     if (ks + 2 < nks) a_fetch(ks + 2, f0, f1);       // two k-steps ahead
+    if (!(q * KS + 32 * ks + 8 * g < K)) { c0 = f4zero(); c1 = f4zero(); }      // beyond K: zeros (raw bf16 zeros widen to zeros)
+    if (a16) {                                       // widen this k-step's raw bfloat16 pairs (exact)
+      const uint32_t w0 = __float_as_uint(c0.x), w1 = __float_as_uint(c0.y), w2 = __float_as_uint(c0.z), w3 = __float_as_uint(c0.w);
+      c0 = make_float4(__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u));
+      c1 = make_float4(__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u), __uint_as_float(w3 << 16), __uint_as_float(w3 & 0xffff0000u));
+    }
     if (adrop) {
       // the lane's 8 consecutive features are ONE call of the 16-bit decision scheme (tilecore.h drop_bits8_r, oracle/philox.py
       // mask16); the keep byte goes to the bit plane the weight-gradient job reads (DwJob::a_keep)
