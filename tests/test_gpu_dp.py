@@ -76,18 +76,22 @@ def test_dp_path_on_one_rank_matches_single_path(rccl_group):
             m.set_rng(7, 3)
             tr = Trainer(m, world=1, use_graph=False, force_dp=force_dp)
             tr.set_batch(*feeds)
-            losses = []
+            losses, grads = [], []
             for _ in range(2):
                 tr.step(lr=1e-4, drop_rate=0.2)
                 losses.append(float(tr.last_loss()))
-            out.append((losses, m.params.detach().cpu().numpy().copy(), m.grads.detach().cpu().numpy().copy()))
+                grads.append(m.grads.detach().cpu().numpy().copy())
+            out.append((losses, m.params.detach().cpu().numpy().copy(), grads))
         (l0, p0, g0), (l1, p1, g1) = out
         np.testing.assert_allclose(l0[:1], l1[:1], rtol=1e-5, atol=1e-5)
+        # step 1: same weights, same masks - the two paths differ by the summation order of the alignment loss and of the float atomics
+        assert np.abs(g0[0] - g1[0]).max() <= 1e-4 * max(1.0, np.abs(g0[0]).max())
         # step 2 starts from weights that Adam (no bias correction: the first update is ~lr * 3.16 * sign-like) moved by
-        # amounts that depend on rounding where a gradient is ~0 (the two paths sum the alignment loss and the float
-        # atomics of dW in different orders), so its loss agrees to ~1e-5 relative, not to the last bits
+        # amounts that depend on rounding where a gradient is ~0, so its loss agrees to ~1e-5 relative, not to the last bits - and
+        # now and then (about one run in twenty) a ReLU unit within rounding of its kink flips between the two paths, which moves
+        # single gradient entries by O(0.1): the step-2 gradients are compared in norm
         np.testing.assert_allclose(l0[1:], l1[1:], rtol=2e-4, atol=2e-4)
-        assert np.abs(g0 - g1).max() <= 1e-4 * max(1.0, np.abs(g0).max())
+        assert np.linalg.norm(g0[1] - g1[1]) <= 1e-2 * np.linalg.norm(g0[1])
         assert np.abs(p0 - p1).max() < 5e-4      # Adam's first steps move every weight by ~3e-4 at lr 1e-4
 
 
