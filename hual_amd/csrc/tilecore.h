@@ -7,40 +7,12 @@
 #include "bf16x3.h"
 #include "philox.h"
 
-// ---- kernel arguments.  A scalar load of a kernel-argument line that is not in the scalar cache yet is a full memory round trip
-// (~1.5 us measured), and the compiler sinks those loads to the first use: a kernel that walks a large argument struct phase by
-// phase pays one round trip per phase.  args_now() makes every dword of the struct live in a scalar register at the top of the
-// kernel (one burst of s_load_dwordx16, one round trip); structs that are indexed dynamically go through LDS instead
-// (args_to_lds + uni()).  CAUTION: a pointer that went through args_now() / uni() has lost its address space - loads / stores
-// through it are FLAT instructions, which count in lgkmcnt as well as vmcnt (every LDS wait then waits for them too: measured on
-// mproj, whose operand prefetch no longer ran under the matrix phase): go through ld4_global / st4_global (common.h) with them.
-template <class T>
-__device__ __forceinline__ T args_now(const T& a) {
-  static_assert(sizeof(T) % 4 == 0, "argument structs are dword multiples");
-  struct Raw { uint32_t w[sizeof(T) / 4]; };
-  Raw r = __builtin_bit_cast(Raw, a);
-#pragma unroll
-  for (int q = 0; q < (int)(sizeof(T) / 4); ++q) asm volatile("" : "+s"(r.w[q]));
-  return __builtin_bit_cast(T, r);
-}
-// cooperative copy of an argument struct into LDS (caller: barrier before the first read)
-template <class T>
-__device__ __forceinline__ void args_to_lds(const T& a, T* dst, int tid, int nthreads) {
-  static_assert(sizeof(T) % 4 == 0, "argument structs are dword multiples");
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(&a);
-  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-  for (int i = tid; i < (int)(sizeof(T) / 4); i += nthreads) d[i] = src[i];
-}
-// a workgroup-uniform value read from LDS -> scalar registers
-template <class U>
-__device__ __forceinline__ U uni(const U& v) {
-  static_assert(sizeof(U) % 4 == 0, "dword multiples");
-  struct Raw { uint32_t w[sizeof(U) / 4]; };
-  Raw r = __builtin_bit_cast(Raw, v);
-#pragma unroll
-  for (int q = 0; q < (int)(sizeof(U) / 4); ++q) r.w[q] = __builtin_amdgcn_readfirstlane(r.w[q]);
-  return __builtin_bit_cast(U, r);
-}
+// ---- kernel arguments (what round 3 measured).  A scalar load of a kernel-argument line that is not in the
+// scalar cache yet is a full memory round trip (~1.5 us), and the compiler sinks those loads to the first use: a kernel that WALKS
+// a large argument struct pays one per step - mproj copies its step descriptors to LDS once (vector loads) and reads them back with
+// readfirstlane.  A pointer that went through LDS / readfirstlane / an asm barrier has lost its address space: loads and stores
+// through it are FLAT instructions, which count in lgkmcnt as well as vmcnt (every LDS wait then waits for them too) - use
+// ld4_global / st4_global (common.h) with such pointers.
 
 // ---- debug: in-kernel phase timestamps (-DHUAL_STAMPS, scripts/exp/stamps.py).  Thread 0 of every workgroup writes the
 // shader clock at phase boundaries into a device-global table read back through hual_debug_stamps().
