@@ -53,10 +53,14 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
     for (int i = threadIdx.x; i < a.nsteps * SW; i += CB_THREADS) sdesc[i] = ka[i];
   }
   __syncthreads();
+  // (one LDS read per lane - lane q holds dword q of the descriptor - and a readlane per field: reading the dwords one by one
+  //  was a chain of ~10 dependent LDS round trips per step)
+  static_assert(SW <= 64, "a step descriptor fits one dword per lane");
   auto step_at = [&](int si) {
     struct alignas(8) Raw { uint32_t w[SW]; } r;
+    const uint32_t mine = sdesc[si * SW + min(lane, SW - 1)];
 #pragma unroll
-    for (int q = 0; q < SW; ++q) r.w[q] = __builtin_amdgcn_readfirstlane(sdesc[si * SW + q]);
+    for (int q = 0; q < SW; ++q) r.w[q] = __builtin_amdgcn_readlane(mine, q);
     return __builtin_bit_cast(MProjStep, r);
   };
   // step descriptors with the repetitions unrolled: (descriptor index, repetition) of flat step k
