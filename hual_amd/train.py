@@ -241,7 +241,8 @@ class Trainer:
             torch.cuda.synchronize()
             try:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: the process group's watchdog thread may touch the device while this thread captures
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._enqueue_dp(drop_rate)
             except Exception as e:                   # capture of the collectives refused: eager from here on
                 self._dp_graph_failed = True
