@@ -543,6 +543,7 @@ def main():
             out['rccl'] = rccl
         print(json.dumps(out))
     if dp:
+        torch.distributed.barrier()      # rank 0 ran the roofline leg alone: leave together
         torch.distributed.destroy_process_group()
 
 
