@@ -326,35 +326,30 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
     const int nR = MT + 2 * E0, rbase = r0 - E0;                               // rows of the row phase
     const int chunk = (nR + 15) >> 4;                                          // <= 4 rows per group
     const int ra = grp * chunk, rb = min(ra + chunk, nR);
-    // ---- operands of the row phase, requested before the matrix phase (their latency hides under it)
+    // the layer's small parameters go through LDS (9 x 512 B; group k stages vector k): registers are scarce in the row phase.
+    // One unconditional load through a selected pointer (groups 9 .. 15 read a vector they do not store): a load behind the
+    // lane-dependent branch would be waited for inside it.
+    const float4 pv = ld4((grp < 7 ? L.dw + grp * HUAL_D : (grp == 7 ? L.ln_g : L.ln_b)) + col);
+    asm volatile("" ::: "memory");                           // (the 20 loads below stay behind this one: the wait counts on it)
+    // ---- operands of the row phase, requested before the matrix phase: their latency hides under it.  EXACTLY 20 vector loads
+    // (4 rows x: x, two bit bytes, mean, rstd); the wait below lets exactly these stay in flight - vmcnt counts in order, so the
+    // weight image (LDS-DMA, requested a phase ago) and the parameter vector have landed when at most 20 operations are outstanding
     float4 xv[4];
     float mu[4], rsd[4];
-    uint32_t zb[4];                                           // keep & relu' nibbles of layer i-1 for this group's rows
+    uint32_t zb[4], zk[4];                                    // relu' / keep nibbles of layer i-1 for this group's rows
     const uint8_t* rprev = L.relu_prev ? L.relu_prev : a.relu_bits3;      // layer 0 has no layer below it: the loaded bytes are ignored
     const uint8_t* kprev = L.keep_prev ? L.keep_prev : a.keep_bits3;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                             // unconditional loads on clamped rows
       const int tc = min(max(rbase + ra + u, 0), R - 1);
       xv[u] = ld4(L.x + (size_t)tc * HUAL_D + col);
-      const uint32_t kn = bits_nibble(kprev, tc, l32);      // (unconditional, see the prologue)
-      zb[u] = bits_nibble(rprev, tc, l32) & (dr.enabled ? kn : 15u);
+      zk[u] = kprev[(size_t)tc * 16 + (l32 >> 1)];
+      zb[u] = rprev[(size_t)tc * 16 + (l32 >> 1)];
       mu[u] = L.mean[tc];
       rsd[u] = L.rstd[tc];
     }
-    // the layer's small parameters go through LDS (9 x 512 B; group k stages vector k): registers are scarce in the row phase
-    float4 pv = f4zero();
-    if (grp < 7) pv = ld4(L.dw + grp * HUAL_D + col);
-    else if (grp == 7) pv = ld4(L.ln_g + col);
-    else if (grp == 8) pv = ld4(L.ln_b + col);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // weight image + the operands above have landed
+    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");        // weight image + parameter vector have landed
     if (grp < 9) par[grp * 32 + l32] = pv;
-    // keep & relu' of dZ_{i-1}, 4 bits per row (bit c = column col + c), rows packed into one register
-    uint32_t zbits = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      asm volatile("" : "+v"(xv[u].x), "+v"(xv[u].y), "+v"(xv[u].z), "+v"(xv[u].w), "+v"(zb[u]), "+v"(mu[u]), "+v"(rsd[u]));
-      zbits |= zb[u] << (4 * u);
-    }
     HUAL_STAMP_K(3, 2 + 7 * (3 - i));
     cb_barrier();                                          // (1) operand planes + parameters complete
     HUAL_STAMP_K(3, 3 + 7 * (3 - i));
@@ -373,6 +368,16 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
       }
     }
     cb_barrier();                                          // (3) dC visible
+    // the row-phase operands requested at the top are taken here (the pins keep the loads up there and the wait down here, in
+    // FRONT of the next image's DMA - the compiler does not see those eight operations and a wait behind them would wait for them)
+    // keep & relu' of dZ_{i-1}, 4 bits per row (bit c = column col + c), rows packed into one register
+    uint32_t zbits = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      asm volatile("" : "+v"(xv[u].x), "+v"(xv[u].y), "+v"(xv[u].z), "+v"(xv[u].w), "+v"(zb[u]), "+v"(zk[u]), "+v"(mu[u]), "+v"(rsd[u]));
+      const uint32_t sh = 4 * (l32 & 1);
+      zbits |= (((zb[u] >> sh) & 15u) & (dr.enabled ? ((zk[u] >> sh) & 15u) : 15u)) << (4 * u);
+    }
     // next layer's weight image: requested only now, behind the barrier (a __syncthreads() with an LDS-DMA in flight
     // waits for it), so that it lands under the row phase
     if (i > 0) cb_dma_weight(a.l[i - 1].wimg_t, Wl, wave, lane, CB_THREADS / 64);
