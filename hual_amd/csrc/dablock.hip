@@ -713,6 +713,20 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
     cb_barrier();
     if (next) cb_dma_weight(next, Wl, wave, lane, CB_THREADS / 64);
   };
+  // the same in two halves, for the steps in front of which saved tiles are requested (tile_ld): KEEP of those loads - issued last -
+  // stay in flight under the matrix phase (vmcnt counts in order: at most KEEP outstanding = the weight image has landed); the
+  // caller takes the tiles (pin) between the halves, in FRONT of the next image's DMA, which the compiler does not see
+#define DM_STEP_HEAD(P, KEEP)                                      \
+  do {                                                             \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");    \
+    cb_barrier();                                                  \
+    if (act) cb_tile_mma_t<DP_PLANE>(P, Wl, mt, ch, lane, accp);   \
+    cb_barrier();                                                  \
+  } while (0)
+  auto pin4 = [&](float4 (&t)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(t[r].x), "+v"(t[r].y), "+v"(t[r].z), "+v"(t[r].w));
+  };
   auto fold = [&](float4 (&acc)[4], const float* ai, bool first) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -761,9 +775,12 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
 
   float4 T1[4], T2[4], U1[4], U2[4], U3[4], U4[4];
   // ---- d mha = dZ1 . Wd1^T ; bilinear backward (layers.py:110): d scores = d mha * val * gate * (1 - gate), d values = d mha * gate
+  asm volatile("" ::: "memory");                       // (the eight loads below are the youngest vector-memory operations)
   tile_ld(a.gate, U1);
   tile_ld(a.val, U2);
-  step(P1, a.w[1]);
+  DM_STEP_HEAD(P1, 8);
+  pin4(U1); pin4(U2);
+  cb_dma_weight(a.w[1], Wl, wave, lane, CB_THREADS / 64);
   if (act) {
     fold(T1, ainv1, true);
 #pragma unroll
@@ -794,11 +811,14 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   // ---- gradient of the guided features: d scores . W12^T + d values . W22^T
   step(P0, a.w[4]);
   if (act) fold(T1, ainv0, true);
+  asm volatile("" ::: "memory");
   tile_ld(a.sg, U1);
   tile_ld(a.xg, U2);
   tile_ld(a.sv, U3);
   tile_ld(a.xv, U4);
-  step(P2, a.w[5]);
+  DM_STEP_HEAD(P2, 16);
+  pin4(U1); pin4(U2); pin4(U3); pin4(U4);
+  cb_dma_weight(a.w[5], Wl, wave, lane, CB_THREADS / 64);
   if (act) {
     fold(T1, ainv2, false);
 #pragma unroll
