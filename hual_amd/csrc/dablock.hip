@@ -552,23 +552,37 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   for (int r = 0; r < 4; ++r) { acc0[r] = f4zero(); acc1[r] = f4zero(); }
 #pragma unroll 1
   for (int k = 0; k < a.nsteps; ++k) {
-    if (k + 1 < a.nsteps) {
+    const bool more = k + 1 < a.nsteps;                // uniform
+    if (more) {
+      // the next product's operand rows: EXACTLY eight vector loads, the youngest vector-memory operations at the wait below, which
+      // therefore leaves them in flight under the matrix phase (vmcnt counts in order: everything older - the weight image, the
+      // stores of the previous fill - has landed); they are taken (pinned) in FRONT of the next image's DMA, which the compiler
+      // does not see and would otherwise wait for together with them
       const uint8_t* nbp = a.a_bits[k + 1] ? a.a_bits[k + 1] : reinterpret_cast<const uint8_t*>(a.x);      // (no bits: a byte that is ignored)
+      const float* nap = a.A[k + 1];
+      const int nld = a.lda[k + 1];
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const size_t row = (size_t)min(r0 + grp + 16 * u, R - 1);
-        nv[u] = ld4(a.A[k + 1] + row * a.lda[k + 1] + col);
+        nv[u] = ld4(nap + row * nld + col);
         nkb[u] = nbp[row * 16 + (l32 >> 1)];
       }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     cb_barrier();
     const char* S = (k & 1) ? S1 : S0;
     const float* ai = (k & 1) ? ainv1 : ainv0;
     f32x4 accp[4];
     if (act) cb_tile_mma_t<LB_ROWS * 256>(S, Wl, mt, ch, lane, accp);
     cb_barrier();
-    if (k + 1 < a.nsteps) cb_dma_weight(a.wimg_t[k + 1], Wl, wave, lane, CB_THREADS / 64);
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(nv[u].x), "+v"(nv[u].y), "+v"(nv[u].z), "+v"(nv[u].w), "+v"(nkb[u]));
+      cb_dma_weight(a.wimg_t[k + 1], Wl, wave, lane, CB_THREADS / 64);
+    }
     if (act) {
       const bool to1 = a.dst[k] != 0;
       const bool first = to1 ? first1 : first0;
