@@ -12,6 +12,8 @@ OBJ = os.path.join(HERE, 'csrc', 'build')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 if os.environ.get('HUAL_STAMPS'):        # debug build: in-kernel phase timestamps of one fused tile kernel (csrc/tilecore.h)
     FLAGS.append('-DHUAL_STAMPS=' + os.environ['HUAL_STAMPS'])
+    if os.environ.get('HUAL_STAMPS_FIRST'):
+        FLAGS.append('-DHUAL_STAMPS_FIRST')
 if os.environ.get('HUAL_EXP_DEFS'):      # experiment builds: extra -D switches (scripts/exp)
     FLAGS.extend('-D' + d for d in os.environ['HUAL_EXP_DEFS'].split(','))
 

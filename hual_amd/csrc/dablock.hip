@@ -46,6 +46,7 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
   const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
   const DropRegs dr = drop_load(drop);
 
+  HUAL_STAMP_K(6, 0);
   cb_dma_weight(a.wimg[0], Wl, wave, lane, CB_THREADS / 64);
   // every operand of the kernel is requested up front: rows (unconditional loads on clamped rows), layer-norm parameters, biases
   float4 xv[4], av[4], rv[4], bias[HUAL_LNPROJ_MAX];
@@ -77,6 +78,7 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
         drop_nib2_store_r(dr, (uint32_t)a.drop_site1, a.drop_row0, r0 + lrA, r0 + lrB, okA, okB, (uint32_t)l32, a.y1_bits, nb1[2 * pr], nb1[2 * pr + 1]);
     }
   }
+  HUAL_STAMP_K(6, 1);
   // ---- (residual) + layer norm(s) -> operand planes
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -116,13 +118,17 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
 #pragma unroll
   for (int p = 0; p < HUAL_LNPROJ_MAX; ++p) {
     if (p >= a.nproj) break;                                 // uniform
+    HUAL_STAMP_K(6, 2 + 4 * p);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the image (and its stores) done
+    HUAL_STAMP_K(6, 3 + 4 * p);
     cb_barrier();
+    HUAL_STAMP_K(6, 4 + 4 * p);
     const char* P = a.src[p] ? P2 : P1;
     const float* ai = a.src[p] ? ainv2 : ainv1;
     f32x4 accp[4];
     if (mt < ntile) cb_tile_mma_t<LP_ROWS * 256>(P, Wl, mt, ch, lane, accp);
     cb_barrier();                                         // image consumed
+    HUAL_STAMP_K(6, 5 + 4 * p);
     if (p + 1 < a.nproj) cb_dma_weight(a.wimg[p + 1], Wl, wave, lane, CB_THREADS / 64);
     if (mt < ntile) {
 #pragma unroll
@@ -152,6 +158,7 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
       st4(a.out[p] + (size_t)row * a.ldo[p] + ecol, v);
     }
   }
+  HUAL_STAMP_K(6, 2 + 4 * a.nproj);
 }
 
 __global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropCfg drop) { ln_proj_body(a, drop); }
@@ -683,29 +690,33 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
 
 // ------------------------------------------------------------------------------------------------------
 // Backward of the gated middle of the dual attention (DaMidBwdArgs): ten weight steps, three operand slots.
+// T-form (tilecore.h): wave `wave` owns the 16 output columns 16 wave .. 16 wave + 15 of ALL NT row tiles of the workgroup - every
+// wave works whatever the row count (the 16 x 64 tiles of the LDS-image form leave two of eight waves idle at three row tiles, on
+// two of the four SIMDs) - and reads its weight fragments straight from the L2-resident N images into registers, a step ahead:
+// no weight buffer in LDS, no DMA wait, no barrier for weights.  Accumulator rt of lane (j, g) = row 16 rt + j, columns
+// 16 wave + 4 g .. + 3.
+template <int NT>
 __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char dm_lds[];
   char* P0 = dm_lds;
   char* P1 = P0 + DP_SLOT;
   char* P2 = P1 + DP_SLOT;
-  char* Wl = P2 + DP_SLOT;
-  float* ainv0 = reinterpret_cast<float*>(Wl + CB_WBYTES);
+  float* ainv0 = reinterpret_cast<float*>(P2 + DP_SLOT);
   float* ainv1 = ainv0 + DP_ROWS;
   float* ainv2 = ainv1 + DP_ROWS;
-  float* smaxA = ainv2 + DP_ROWS;                      // [48][2] half-row maxima of the (first) tile being written
-  float* smaxB = smaxA + 2 * DP_ROWS;                  // ... and of the second
+  float* smaxA = ainv2 + DP_ROWS;                      // [48][8] maxima of the 16-column slices of the (first) tile being written
+  float* smaxB = smaxA + 8 * DP_ROWS;                  // ... and of the second
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
-  const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
+  const int MT = a.MT, R = a.R;
   const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
   if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
-  const int mt = wave >> 1, ch = wave & 1;
-  const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
-  const bool act = mt < ntile;
+  const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;
 
-  cb_dma_weight(a.w[0], Wl, wave, lane, CB_THREADS / 64);
+  TfW wa, wb;
+  tf_load_w(wa, a.w[0], wave, lane);
   {
     float4 zv[3];
 #pragma unroll
@@ -719,191 +730,174 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
       if (l32 == 0) ainv1[lr] = ok ? inv : 0.f;
     }
   }
-  f32x4 accp[4];
-  auto step = [&](const char* P, const float* next) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    cb_barrier();
-    if (act) cb_tile_mma_t<DP_PLANE>(P, Wl, mt, ch, lane, accp);
-    cb_barrier();
-    if (next) cb_dma_weight(next, Wl, wave, lane, CB_THREADS / 64);
-  };
-  // the same in two halves, for the steps in front of which saved tiles are requested (tile_ld): KEEP of those loads - issued last -
-  // stay in flight under the matrix phase (vmcnt counts in order: at most KEEP outstanding = the weight image has landed); the
-  // caller takes the tiles (pin) between the halves, in FRONT of the next image's DMA, which the compiler does not see
-#define DM_STEP_HEAD(P, KEEP)                                      \
-  do {                                                             \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");    \
-    cb_barrier();                                                  \
-    if (act) cb_tile_mma_t<DP_PLANE>(P, Wl, mt, ch, lane, accp);   \
-    cb_barrier();                                                  \
-  } while (0)
-  auto pin4 = [&](float4 (&t)[4]) {
+  f32x4 accp[NT];
+  auto fold = [&](float4 (&acc)[NT], const float* ai, bool first) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(t[r].x), "+v"(t[r].y), "+v"(t[r].z), "+v"(t[r].w));
-  };
-  auto fold = [&](float4 (&acc)[4], const float* ai, bool first) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float ir = ai[16 * mt + 4 * g + r];
-      if (first) acc[r] = make_float4(fmaf(accp[0][r], ir, 0.f), fmaf(accp[1][r], ir, 0.f), fmaf(accp[2][r], ir, 0.f), fmaf(accp[3][r], ir, 0.f));
-      else acc[r] = make_float4(fmaf(accp[0][r], ir, acc[r].x), fmaf(accp[1][r], ir, acc[r].y), fmaf(accp[2][r], ir, acc[r].z), fmaf(accp[3][r], ir, acc[r].w));
+    for (int rt = 0; rt < NT; ++rt) {
+      const float ir = ai[16 * rt + j];
+      if (first) acc[rt] = make_float4(fmaf(accp[rt][0], ir, 0.f), fmaf(accp[rt][1], ir, 0.f), fmaf(accp[rt][2], ir, 0.f), fmaf(accp[rt][3], ir, 0.f));
+      else acc[rt] = make_float4(fmaf(accp[rt][0], ir, acc[rt].x), fmaf(accp[rt][1], ir, acc[rt].y), fmaf(accp[rt][2], ir, acc[rt].z), fmaf(accp[rt][3], ir, acc[rt].w));
     }
   };
-  auto tile_ld = [&](const float* src, float4 (&t)[4]) {
+  // element offsets of the lane's NT tile rows (clamped to the tensor: loads are unconditional, stores are guarded by row < RE) as
+  // 32-bit values: uniform base + 32-bit lane offset addressing, one register per row for every tensor of the kernel
+  uint32_t eoff[NT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = ld4(src + (size_t)min(r0 + 16 * mt + 4 * g + r, R - 1) * HUAL_D + ecol);
-  };
-  auto save = [&](float* dst, int r, float4 v) {
-    const int row = r0 + 16 * mt + 4 * g + r;
-    if (row < RE) st4(dst + (size_t)row * HUAL_D + ecol, v);
-  };
-  auto save_nt = [&](float* dst, int r, float4 v) {      // operands of the weight-gradient launch only
-    const int row = r0 + 16 * mt + 4 * g + r;
-    if (row < RE) st4_nt(dst + (size_t)row * HUAL_D + ecol, v);
-  };
-  auto put_max = [&](float* sm, const float4 (&v)[4]) {
+  for (int rt = 0; rt < NT; ++rt) eoff[rt] = (uint32_t)min(r0 + 16 * rt + j, R - 1) * (uint32_t)HUAL_D + (uint32_t)ecol;
+  auto tile_ld = [&](const float* src, float4 (&t)[NT]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float m = row16_max(f4absmax(v[r]));
-      if (j == 0) sm[(16 * mt + 4 * g + r) * 2 + ch] = m;
+    for (int rt = 0; rt < NT; ++rt) t[rt] = ld4(src + eoff[rt]);
+  };
+  auto save = [&](float* dst, int rt, float4 v) {
+    if (r0 + 16 * rt + j < RE) st4(dst + eoff[rt], v);
+  };
+  auto save_nt = [&](float* dst, int rt, float4 v) {      // operands of the weight-gradient launch only
+    if (r0 + 16 * rt + j < RE) st4_nt(dst + eoff[rt], v);
+  };
+  auto put_max = [&](float* sm, const float4 (&v)[NT]) {
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      const float m = slice16_max(f4absmax(v[rt]), lane);
+      if (g == 0) sm[(16 * rt + j) * 8 + wave] = m;
     }
   };
-  auto put_planes = [&](char* P, float* ai, const float* sm, const float4 (&v)[4]) {
+  auto put_planes = [&](char* P, float* ai, const float* sm, const float4 (&v)[NT]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lr = 16 * mt + 4 * g + r;
+    for (int rt = 0; rt < NT; ++rt) {
+      const int lr = 16 * rt + j;
+      const float4 ma = *reinterpret_cast<const float4*>(sm + lr * 8), mb = *reinterpret_cast<const float4*>(sm + lr * 8 + 4);
       float inv;
-      const float sc = f16_row_scale(fmaxf(sm[lr * 2], sm[lr * 2 + 1]), inv);
+      const float sc = f16_row_scale(fmaxf(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w)), fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w))), inv);
       uint2 h, l;
-      f16_split4(f4scale1(v[r], sc), h, l);
-      const int off = tile256_off(lr, ecol >> 3) + 8 * (j & 1);
+      f16_split4(f4scale1(v[rt], sc), h, l);
+      const int off = tile256_off(lr, ecol >> 3) + 8 * (g & 1);
       *reinterpret_cast<uint2*>(P + off) = h;
       *reinterpret_cast<uint2*>(P + DP_PLANE + off) = l;
-      if (ch == 0 && j == 0) ai[lr] = (r0 + lr < RE) ? inv : 0.f;
+      if (wave == 0 && g == 0) ai[lr] = (r0 + lr < RE) ? inv : 0.f;
     }
   };
-  auto zero_invalid = [&](float4 (&v)[4]) {
+  auto zero_invalid = [&](float4 (&v)[NT]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (r0 + 16 * mt + 4 * g + r >= RE) v[r] = f4zero();
+    for (int rt = 0; rt < NT; ++rt) if (r0 + 16 * rt + j >= RE) v[rt] = f4zero();
   };
 
-  float4 T1[4], T2[4], U1[4], U2[4], U3[4], U4[4];
+  float4 T1[NT], T2[NT], U1[NT], U2[NT], U3[NT], U4[NT];
   // ---- d mha = dZ1 . Wd1^T ; bilinear backward (layers.py:110): d scores = d mha * val * gate * (1 - gate), d values = d mha * gate
-  asm volatile("" ::: "memory");                       // (the eight loads below are the youngest vector-memory operations)
+  tf_load_w(wb, a.w[1], wave, lane);
   tile_ld(a.gate, U1);
   tile_ld(a.val, U2);
-  DM_STEP_HEAD(P1, 8);
-  pin4(U1); pin4(U2);
-  cb_dma_weight(a.w[1], Wl, wave, lane, CB_THREADS / 64);
-  if (act) {
-    fold(T1, ainv1, true);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float4 d0 = T1[r], gt = U1[r], vl = U2[r];
-      T1[r] = make_float4(d0.x * vl.x * gt.x * (1.f - gt.x), d0.y * vl.y * gt.y * (1.f - gt.y), d0.z * vl.z * gt.z * (1.f - gt.z),
-                          d0.w * vl.w * gt.w * (1.f - gt.w));
-      T2[r] = cb_mul(d0, gt);
-      save_nt(a.d_sc, r, T1[r]);
-      save_nt(a.d_val, r, T2[r]);
-    }
-    zero_invalid(T1);
-    zero_invalid(T2);
-    put_max(smaxA, T1);
-    put_max(smaxB, T2);
-  }
   cb_barrier();
-  if (act) { put_planes(P0, ainv0, smaxA, T1); put_planes(P2, ainv2, smaxB, T2); }
-  // ---- gradient of ln1 through the two bilinear layers: d scores . W11^T + d values . W21^T
-  step(P0, a.w[2]);
-  if (act) fold(T1, ainv0, true);
-  step(P2, a.w[3]);
-  if (act) {
-    fold(T1, ainv2, false);
+  tf_mma_lean<NT, DP_PLANE>(P1, wa, lane, accp);
+  fold(T1, ainv1, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) save(a.d_ln1a, r, T1[r]);
+  for (int rt = 0; rt < NT; ++rt) {
+    const float4 d0 = T1[rt], gt = U1[rt], vl = U2[rt];
+    T1[rt] = make_float4(d0.x * vl.x * gt.x * (1.f - gt.x), d0.y * vl.y * gt.y * (1.f - gt.y), d0.z * vl.z * gt.z * (1.f - gt.z),
+                         d0.w * vl.w * gt.w * (1.f - gt.w));
+    T2[rt] = cb_mul(d0, gt);
+    save_nt(a.d_sc, rt, T1[rt]);
+    save_nt(a.d_val, rt, T2[rt]);
   }
+  zero_invalid(T1);
+  zero_invalid(T2);
+  put_max(smaxA, T1);
+  put_max(smaxB, T2);
+  tf_load_w(wa, a.w[2], wave, lane);
+  cb_barrier();
+  put_planes(P0, ainv0, smaxA, T1);
+  put_planes(P2, ainv2, smaxB, T2);
+  cb_barrier();
+  // ---- gradient of ln1 through the two bilinear layers: d scores . W11^T + d values . W21^T
+  tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
+  fold(T1, ainv0, true);
+  tf_load_w(wb, a.w[3], wave, lane);
+  tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
+  fold(T1, ainv2, false);
+#pragma unroll
+  for (int rt = 0; rt < NT; ++rt) save(a.d_ln1a, rt, T1[rt]);
   // ---- gradient of the guided features: d scores . W12^T + d values . W22^T
-  step(P0, a.w[4]);
-  if (act) fold(T1, ainv0, true);
-  asm volatile("" ::: "memory");
+  tf_load_w(wa, a.w[4], wave, lane);
+  tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
+  fold(T1, ainv0, true);
+  tf_load_w(wb, a.w[5], wave, lane);
   tile_ld(a.sg, U1);
   tile_ld(a.xg, U2);
   tile_ld(a.sv, U3);
   tile_ld(a.xv, U4);
-  DM_STEP_HEAD(P2, 16);
-  pin4(U1); pin4(U2); pin4(U3); pin4(U4);
-  cb_dma_weight(a.w[5], Wl, wave, lane, CB_THREADS / 64);
-  if (act) {
-    fold(T1, ainv2, false);
+  tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
+  fold(T1, ainv2, false);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) save_nt(a.d_g, r, T1[r]);
-    zero_invalid(T1);
-    put_max(smaxA, T1);
-  }
+  for (int rt = 0; rt < NT; ++rt) save_nt(a.d_g, rt, T1[rt]);
+  zero_invalid(T1);
+  put_max(smaxA, T1);
+  tf_load_w(wa, a.w[6], wave, lane);
   cb_barrier();
-  if (act) put_planes(P1, ainv1, smaxA, T1);
+  put_planes(P1, ainv1, smaxA, T1);
+  cb_barrier();
   // ---- d o = d g . Wg^T ; cross gating backward (layers.py:96-103): o = sg * x + xg * s
-  step(P1, a.w[6]);
-  if (act) {
-    fold(T1, ainv1, true);
+  tf_mma_lean<NT, DP_PLANE>(P1, wb, lane, accp);
+  fold(T1, ainv1, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float4 d0 = T1[r], sg = U1[r], xg = U2[r], sv = U3[r], xv = U4[r];
-      T1[r] = make_float4(d0.x * xv.x * sg.x * (1.f - sg.x), d0.y * xv.y * sg.y * (1.f - sg.y), d0.z * xv.z * sg.z * (1.f - sg.z),
-                          d0.w * xv.w * sg.w * (1.f - sg.w));                        // dZ of s_gate
-      T2[r] = make_float4(d0.x * sv.x * xg.x * (1.f - xg.x), d0.y * sv.y * xg.y * (1.f - xg.y), d0.z * sv.z * xg.z * (1.f - xg.z),
-                          d0.w * sv.w * xg.w * (1.f - xg.w));                        // dZ of x_gate
-      U3[r] = cb_mul(d0, xg);                                                         // direct part of d s_value
-      U4[r] = cb_mul(d0, sg);                                                         // direct part of d x_value
-      save_nt(a.dz_sg, r, T1[r]);
-      save_nt(a.dz_xg, r, T2[r]);
-    }
-    zero_invalid(T1);
-    zero_invalid(T2);
-    put_max(smaxA, T1);
-    put_max(smaxB, T2);
+  for (int rt = 0; rt < NT; ++rt) {
+    const float4 d0 = T1[rt], sg = U1[rt], xg = U2[rt], sv = U3[rt], xv = U4[rt];
+    T1[rt] = make_float4(d0.x * xv.x * sg.x * (1.f - sg.x), d0.y * xv.y * sg.y * (1.f - sg.y), d0.z * xv.z * sg.z * (1.f - sg.z),
+                         d0.w * xv.w * sg.w * (1.f - sg.w));                        // dZ of s_gate
+    T2[rt] = make_float4(d0.x * sv.x * xg.x * (1.f - xg.x), d0.y * sv.y * xg.y * (1.f - xg.y), d0.z * sv.z * xg.z * (1.f - xg.z),
+                         d0.w * sv.w * xg.w * (1.f - xg.w));                        // dZ of x_gate
+    U3[rt] = cb_mul(d0, xg);                                                         // direct part of d s_value
+    U4[rt] = cb_mul(d0, sg);                                                         // direct part of d x_value
+    save_nt(a.dz_sg, rt, T1[rt]);
+    save_nt(a.dz_xg, rt, T2[rt]);
   }
+  zero_invalid(T1);
+  zero_invalid(T2);
+  put_max(smaxA, T1);
+  put_max(smaxB, T2);
+  tf_load_w(wb, a.w[7], wave, lane);
   cb_barrier();
-  if (act) { put_planes(P0, ainv0, smaxA, T1); put_planes(P2, ainv2, smaxB, T2); }
+  put_planes(P0, ainv0, smaxA, T1);
+  put_planes(P2, ainv2, smaxB, T2);
+  cb_barrier();
   // ---- d s_value = dZ_sg . Wsg^T + d o * xg ; d x_value = dZ_xg . Wxg^T + d o * sg
-  step(P0, a.w[7]);
-  if (act) {
-    fold(T1, ainv0, true);
+  tf_mma_lean<NT, DP_PLANE>(P0, wa, lane, accp);
+  fold(T1, ainv0, true);
+  tf_load_w(wa, a.w[8], wave, lane);
+  tf_mma_lean<NT, DP_PLANE>(P2, wb, lane, accp);
+  fold(T2, ainv2, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { T1[r] = cb_add(T1[r], U3[r]); save_nt(a.d_sv, r, T1[r]); }
-    zero_invalid(T1);
-    put_max(smaxA, T1);
+  for (int rt = 0; rt < NT; ++rt) {
+    T1[rt] = cb_add(T1[rt], U3[rt]);
+    T2[rt] = cb_add(T2[rt], U4[rt]);
+    save_nt(a.d_sv, rt, T1[rt]);
+    save_nt(a.d_xv, rt, T2[rt]);
   }
+  zero_invalid(T1);
+  zero_invalid(T2);
+  put_max(smaxA, T1);
+  put_max(smaxB, T2);
+  tf_load_w(wb, a.w[9], wave, lane);
   cb_barrier();
-  if (act) put_planes(P1, ainv1, smaxA, T1);
-  step(P2, a.w[8]);
-  if (act) {
-    fold(T2, ainv2, true);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { T2[r] = cb_add(T2[r], U4[r]); save_nt(a.d_xv, r, T2[r]); }
-    zero_invalid(T2);
-    put_max(smaxB, T2);
-  }
+  put_planes(P1, ainv1, smaxA, T1);
+  put_planes(P0, ainv0, smaxB, T2);
   cb_barrier();
-  if (act) put_planes(P0, ainv0, smaxB, T2);
   // ---- gradients of the two attention outputs
-  step(P1, a.w[9]);
-  if (act) {
-    fold(T1, ainv1, true);
+  tf_mma_lean<NT, DP_PLANE>(P1, wa, lane, accp);
+  fold(T1, ainv1, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) save(a.d_satt, r, T1[r]);
-  }
-  step(P0, nullptr);
-  if (act) {
-    fold(T2, ainv0, true);
+  for (int rt = 0; rt < NT; ++rt) save(a.d_satt, rt, T1[rt]);
+  tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
+  fold(T2, ainv0, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) save(a.d_xatt, r, T2[r]);
-  }
+  for (int rt = 0; rt < NT; ++rt) save(a.d_xatt, rt, T2[rt]);
 }
 
 #if defined(HUAL_STAMPS) && (HUAL_STAMPS == 1 || (HUAL_STAMPS >= 4 && HUAL_STAMPS <= 6))
 extern "C" int hual_debug_stamps(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hual_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+extern "C" int hual_debug_stamps_reset() {
+  static unsigned long long zeros[512 * HUAL_STAMP_SLOTS];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_hual_stamps), zeros, sizeof(zeros));
 }
 #endif
 
@@ -1018,11 +1012,15 @@ int launch_da_mid_bwd(const DaMidBwdArgs& a, hipStream_t s) {
   HUAL_REQUIRE(a.MT >= 1 && a.MT <= DP_ROWS, "da_mid_bwd: MT must be 1..48");
   for (int k = 0; k < 10; ++k) HUAL_REQUIRE(a.w[k] != nullptr, "da_mid_bwd: null weight image");
   HUAL_REQUIRE(a.d_sc && a.d_val && a.d_ln1a && a.d_g && a.dz_sg && a.dz_xg && a.d_sv && a.d_xv && a.d_satt && a.d_xatt, "da_mid_bwd: null output");
-  HUAL_DYN_LDS(da_mid_bwd_kernel, 160 * 1024);
-  const size_t lds = (size_t)3 * DP_SLOT + CB_WBYTES + (3 * DP_ROWS + 4 * DP_ROWS) * sizeof(float);
+  const size_t lds = (size_t)3 * DP_SLOT + (3 * DP_ROWS + 16 * DP_ROWS) * sizeof(float);
   const double rows = (double)a.R;
-  HUAL_LAUNCH(10.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 17.0 + 10.0 * HUAL_D * HUAL_D), da_mid_bwd_kernel,
-              dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), lds, s, a);
+  const double flops = 10.0 * 2.0 * rows * HUAL_D * HUAL_D, bytes = 4.0 * (rows * HUAL_D * 17.0 + 10.0 * HUAL_D * HUAL_D);
+  const dim3 grid(xcd_round8(cdiv(a.R, a.MT)));
+  switch (cdiv(a.MT, 16)) {      // row tiles per workgroup
+    case 1: { HUAL_DYN_LDS(da_mid_bwd_kernel<1>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_mid_bwd_kernel<1>, grid, dim3(CB_THREADS), lds, s, a); break; }
+    case 2: { HUAL_DYN_LDS(da_mid_bwd_kernel<2>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_mid_bwd_kernel<2>, grid, dim3(CB_THREADS), lds, s, a); break; }
+    default: { HUAL_DYN_LDS(da_mid_bwd_kernel<3>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_mid_bwd_kernel<3>, grid, dim3(CB_THREADS), lds, s, a); break; }
+  }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

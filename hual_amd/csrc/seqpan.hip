@@ -251,7 +251,8 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
       const DualAttnP& d = pm.da[li];
       const size_t w[] = {d.dense1.k, d.dense2.k, d.bl1_d1, d.bl1_d2, d.bl2_d1, d.bl2_d2, d.guided.k, d.s_gate.k, d.x_gate.k,
                           d.s_dense.k, d.x_dense.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
-      for (size_t o : w) add(o, D, FB);
+      // (the ten weights of the gated middle's backward chain as N images: da_mid_bwd_kernel keeps its weights in registers)
+      for (int k = 0; k < 16; ++k) add(w[k], D, (k == 0 || (k >= 2 && k <= 10)) ? (uint8_t)(HUAL_PACK_F | HUAL_PACK_N) : FB);
     }
     std::sort(c.dense.begin(), c.dense.end(), [](const Ctx::DenseW& a, const Ctx::DenseW& b) { return a.off < b.off; });
     // the image of a transposed weight takes ceil(K/128) blocks of 64 KB: it fits the weight's own byte range when K is a
@@ -1052,7 +1053,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       DaMidBwdArgs mb{};
       mb.dz1 = dz1; mb.gate = gate; mb.val = val; mb.sg = sg; mb.xg = xg; mb.sv = sv; mb.xv = xv;
       const size_t wo[10] = {d.dense1.k, d.bl1_d1, d.bl2_d1, d.bl1_d2, d.bl2_d2, d.guided.k, d.s_gate.k, d.x_gate.k, d.s_dense.k, d.x_dense.k};
-      for (int k = 0; k < 10; ++k) mb.w[k] = imgt(wo[k]);
+      for (int k = 0; k < 10; ++k) mb.w[k] = c.nimg(wo[k]);      // register-resident weights (N images)
       mb.d_sc = d_sc; mb.d_val = d_val; mb.d_ln1a = d_ln1a; mb.d_g = d_g; mb.dz_sg = dz_sg; mb.dz_xg = dz_xg; mb.d_sv = d_sv; mb.d_xv = d_xv;
       mb.d_satt = d_satt; mb.d_xatt = d_xatt; mb.R = R; mb.MT = da_post_rows(R);
       if (c.live()) c.chk(launch_da_mid_bwd(mb, c.stream));

@@ -21,7 +21,14 @@
 static __device__ unsigned long long g_hual_stamps[512 * HUAL_STAMP_SLOTS];      // one table per translation unit
 // HUAL_STAMPS selects the kernel that writes: 1 da_post_kernel, 2 conv_block_fwd_kernel, 3 conv_block_bwd_kernel,
 // 4 ln_proj_bwd_kernel, 5 da_mid_bwd_kernel, 6 ln_proj_kernel, 9 mproj kernels (build: HUAL_STAMPS=<n> python -m hual_amd.build)
-#define HUAL_STAMP_K(k, i) do { if (HUAL_STAMPS == (k) && threadIdx.x == 0 && blockIdx.x < 512 && (i) < HUAL_STAMP_SLOTS) g_hual_stamps[blockIdx.x * HUAL_STAMP_SLOTS + (i)] = __builtin_readcyclecounter(); } while (0)
+// -DHUAL_STAMPS_FIRST: a slot keeps its FIRST stamp since hual_debug_stamps_reset() - the first launch of the kernel in the step that
+// follows the reset instead of the last one
+#ifdef HUAL_STAMPS_FIRST
+#define HUAL_STAMP_KEEP(slot) ((slot) == 0ull)
+#else
+#define HUAL_STAMP_KEEP(slot) true
+#endif
+#define HUAL_STAMP_K(k, i) do { if (HUAL_STAMPS == (k) && threadIdx.x == 0 && blockIdx.x < 512 && (i) < HUAL_STAMP_SLOTS && HUAL_STAMP_KEEP(g_hual_stamps[blockIdx.x * HUAL_STAMP_SLOTS + (i)])) g_hual_stamps[blockIdx.x * HUAL_STAMP_SLOTS + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define HUAL_STAMP_K(k, i) do { } while (0)
 #endif
@@ -232,6 +239,53 @@ __device__ __forceinline__ void tf_mma(const char* Ahi, const TfW& w, int lane, 
       acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[ks], xh[rt], acc[rt], 0, 0, 0);
     }
   }
+}
+
+// the same with the activation fragments of at most two k-steps live (the fully unrolled form above lets the scheduler hoist the
+// reads of all four: 32 registers per row tile) - for kernels that hold many tiles in registers across the product
+template <int NT, int ALO>
+__device__ __forceinline__ void tf_mma_lean(const char* Ahi, const TfW& w, int lane, f32x4 (&acc)[NT]) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int rt = 0; rt < NT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f16x8 xh[2][NT], xl[2][NT];
+  auto rd = [&](int b, int ks) {
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      const int off = tile256_off(16 * rt + j, 4 * ks + g);
+      xh[b][rt] = *reinterpret_cast<const f16x8*>(Ahi + off);
+      xl[b][rt] = *reinterpret_cast<const f16x8*>(Ahi + ALO + off);
+    }
+  };
+  rd(0, 0);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if (ks < 3) rd((ks + 1) & 1, ks + 1);
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[ks], xh[ks & 1][rt], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[ks], xl[ks & 1][rt], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[ks], xh[ks & 1][rt], acc[rt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// lane partners across the 16-lane rows of a wave (v_permlane16_swap / v_permlane32_swap, one instruction each) and the maximum
+// over the four lanes (j, 0..3) that hold one row's 16-column slice in the T-form accumulator layout
+__device__ __forceinline__ float lane_xor16(float v, int lane) {
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  return __builtin_bit_cast(float, (lane & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v, int lane) {
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return __builtin_bit_cast(float, (lane & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float slice16_max(float v, int lane) {
+  v = fmaxf(v, lane_xor16(v, lane));
+  return fmaxf(v, lane_xor32(v, lane));
 }
 
 // row of the operand planes: scale to fp16 range, split, store (8 bytes per lane and plane); returns the inverse scale

@@ -18,6 +18,10 @@ for _ in range(30):
     tr.step(lr=1e-4, drop_rate=float(os.environ.get("DROP", "0.2")))
 torch.cuda.synchronize()
 l = lib.load()
+if os.environ.get('HUAL_STAMPS_FIRST'):      # (build with HUAL_STAMPS_FIRST=1 as well): the first launch of the kernel in one more step
+    print('reset', l.hual_debug_stamps_reset())
+    tr.step(lr=1e-4, drop_rate=float(os.environ.get("DROP", "0.2")))
+    torch.cuda.synchronize()
 n = 512 * 64
 buf = (ctypes.c_ulonglong * n)()
 l.hual_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
