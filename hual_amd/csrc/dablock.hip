@@ -174,36 +174,39 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_pair_kernel(LnProjArgs a0,
 #define DP_SLOT (2 * DP_PLANE)
 #define DP_NB 11                          // small vectors in LDS: 9 biases + ln2 gamma, beta
 
+// T-form (tilecore.h), like da_mid_bwd_kernel below: wave `wave` owns output columns 16 wave .. 16 wave + 15 of all NT row tiles and
+// keeps its weight fragments (T images, straight from L2, requested a step ahead) in registers.  Accumulator rt of lane (j, g) = row
+// 16 rt + j, columns 16 wave + 4 g .. + 3.  The row phases RP0 - RP2 keep the 32-lane row layout (thread group grp: rows grp + 16 u).
+template <int NT>
 __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char dp_lds[];
   char* P0 = dp_lds;
   char* P1 = P0 + DP_SLOT;
   char* P2 = P1 + DP_SLOT;
-  char* Wl = P2 + DP_SLOT;
-  float4* bl = reinterpret_cast<float4*>(Wl + CB_WBYTES);        // [DP_NB][32] float4
+  float4* bl = reinterpret_cast<float4*>(P2 + DP_SLOT);             // [DP_NB][32] float4
   float* ainv0 = reinterpret_cast<float*>(bl + DP_NB * 32);       // [48] per slot
   float* ainv1 = ainv0 + DP_ROWS;
   float* ainv2 = ainv1 + DP_ROWS;
-  float* smax = ainv2 + DP_ROWS;                                   // [48][2] half-row maxima of the tile being written
+  float* smaxA = ainv2 + DP_ROWS;                                  // [48][8] maxima of the 16-column slices of the tile being written
+  float* smaxB = smaxA + 8 * DP_ROWS;
   float4* scratch = reinterpret_cast<float4*>(P0);                 // fp32 rows [48][32] float4 for the LN2 pass (= slot 0)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
-  const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
+  const int MT = a.MT, R = a.R;
   const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
   if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
-  const int mt = wave >> 1, ch = wave & 1;
-  const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
-  const bool act = mt < ntile;                                     // wave owns an output tile
+  const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;
   const DropRegs dr = drop_load(drop);
 
   HUAL_STAMP(0);
-  cb_dma_weight(a.w[0], Wl, wave, lane, CB_THREADS / 64);
+  TfW wa, wb;
+  tf_load_w(wa, a.w[0], wave, lane);
   // ---- everything read from HBM is requested up front: the attention outputs and ln1 rows of the row phases, the residual
   // rows / row mask of the epilogues, the small vectors
-  float4 sa[3], xa[3], l1[3], xin[4];
-  float rm[4];
+  float4 sa[3], xa[3], l1[3], xin[NT];
+  float rm[NT];
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const size_t off = (size_t)min(r0 + grp + 16 * u, R - 1) * HUAL_D + col;
@@ -211,11 +214,15 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     xa[u] = ld4(a.x_att + off);
     l1[u] = ld4(a.ln1 + off);
   }
+  // element offsets of the lane's NT tile rows (clamped to the tensor: loads are unconditional, stores guarded by row < RE) as 32-bit
+  // values: uniform base + 32-bit lane offset addressing, one register per row for every tensor of the kernel
+  uint32_t eoff[NT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = min(r0 + 16 * mt + 4 * g + r, R - 1);
-    xin[r] = ld4(a.x + (size_t)row * HUAL_D + ecol);
-    rm[r] = a.rowmask[row];
+  for (int rt = 0; rt < NT; ++rt) {
+    const int row = min(r0 + 16 * rt + j, R - 1);
+    eoff[rt] = (uint32_t)row * (uint32_t)HUAL_D + (uint32_t)ecol;
+    xin[rt] = ld4(a.x + eoff[rt]);
+    rm[rt] = a.rowmask[row];
   }
   {
     // the group's vector.  Indexing the pointer array of the argument struct with the lane-dependent group is a vector load of the
@@ -229,6 +236,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     const float4 pv = ld4_global(((lane & 32) ? po : pe) + col);
     if (grp < DP_NB) bl[grp * 32 + l32] = pv;
   }
+  tf_load_w(wb, a.w[1], wave, lane);
   // ---- RP0: attention outputs -> slots 0, 1
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -240,117 +248,116 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     if (l32 == 0) { ainv0[lr] = ok ? i0 : 0.f; ainv1[lr] = ok ? i1 : 0.f; }
   }
 
-  // one weight step: wait for the image, multiply slot P by it, free the image and request the next one
-  f32x4 accp[4];
-  int si = 1;
-  auto step = [&](const char* P, const float* next) {
-    HUAL_STAMP(si); ++si;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    cb_barrier();
-    HUAL_STAMP(si); ++si;
-    if (act) cb_tile_mma_t<DP_PLANE>(P, Wl, mt, ch, lane, accp);
-    cb_barrier();
-    HUAL_STAMP(si); ++si;
-    if (next) cb_dma_weight(next, Wl, wave, lane, CB_THREADS / 64);
-  };
+  f32x4 accp[NT];
   // acc (+)= accp * inverse operand scale of the rows
-  auto fold = [&](float4 (&acc)[4], const float* ai, bool first) {
+  auto fold = [&](float4 (&acc)[NT], const float* ai, bool first) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float ir = ai[16 * mt + 4 * g + r];
-      if (first) acc[r] = make_float4(fmaf(accp[0][r], ir, 0.f), fmaf(accp[1][r], ir, 0.f), fmaf(accp[2][r], ir, 0.f), fmaf(accp[3][r], ir, 0.f));
-      else acc[r] = make_float4(fmaf(accp[0][r], ir, acc[r].x), fmaf(accp[1][r], ir, acc[r].y), fmaf(accp[2][r], ir, acc[r].z), fmaf(accp[3][r], ir, acc[r].w));
+    for (int rt = 0; rt < NT; ++rt) {
+      const float ir = ai[16 * rt + j];
+      if (first) acc[rt] = make_float4(fmaf(accp[rt][0], ir, 0.f), fmaf(accp[rt][1], ir, 0.f), fmaf(accp[rt][2], ir, 0.f), fmaf(accp[rt][3], ir, 0.f));
+      else acc[rt] = make_float4(fmaf(accp[rt][0], ir, acc[rt].x), fmaf(accp[rt][1], ir, acc[rt].y), fmaf(accp[rt][2], ir, acc[rt].z), fmaf(accp[rt][3], ir, acc[rt].w));
     }
   };
   auto addb = [&](float4 v, int k) { const float4 b = bl[k * 32 + (ecol >> 2)]; return make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w); };
-  auto save = [&](float* dst, int r, float4 v) {
-    const int row = r0 + 16 * mt + 4 * g + r;
-    if (row < RE) st4(dst + (size_t)row * HUAL_D + ecol, v);
+  auto save = [&](float* dst, int rt, float4 v) {
+    if (r0 + 16 * rt + j < RE) st4(dst + eoff[rt], v);
   };
-  auto save_nt = [&](float* dst, int r, float4 v) {      // tensors only the backward pass reads
-    const int row = r0 + 16 * mt + 4 * g + r;
-    if (row < RE) st4_nt(dst + (size_t)row * HUAL_D + ecol, v);
+  auto save_nt = [&](float* dst, int rt, float4 v) {      // tensors only the backward pass reads
+    if (r0 + 16 * rt + j < RE) st4_nt(dst + eoff[rt], v);
   };
-  // tile -> operand slot, part 1: half-row maxima to LDS (the other column half of a row lives in the partner wave)
-  auto put_max = [&](const float4 (&v)[4]) {
+  // tile -> operand slot, part 1: maxima of the wave's 16-column slices to LDS (the other columns of a row live in the other waves)
+  auto put_max = [&](float* sm, const float4 (&v)[NT]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float m = row16_max(f4absmax(v[r]));
-      if (j == 0) smax[(16 * mt + 4 * g + r) * 2 + ch] = m;
+    for (int rt = 0; rt < NT; ++rt) {
+      const float m = slice16_max(f4absmax(v[rt]), lane);
+      if (g == 0) sm[(16 * rt + j) * 8 + wave] = m;
     }
   };
   // part 2 (behind a barrier): common row scale, split, store
-  auto put_planes = [&](char* P, float* ai, const float4 (&v)[4]) {
+  auto put_planes = [&](char* P, float* ai, const float* sm, const float4 (&v)[NT]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lr = 16 * mt + 4 * g + r;
+    for (int rt = 0; rt < NT; ++rt) {
+      const int lr = 16 * rt + j;
+      const float4 ma = *reinterpret_cast<const float4*>(sm + lr * 8), mb = *reinterpret_cast<const float4*>(sm + lr * 8 + 4);
       float inv;
-      const float sc = f16_row_scale(fmaxf(smax[lr * 2], smax[lr * 2 + 1]), inv);
+      const float sc = f16_row_scale(fmaxf(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w)), fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w))), inv);
       uint2 h, l;
-      f16_split4(f4scale1(v[r], sc), h, l);
-      const int off = tile256_off(lr, ecol >> 3) + 8 * (j & 1);
+      f16_split4(f4scale1(v[rt], sc), h, l);
+      const int off = tile256_off(lr, ecol >> 3) + 8 * (g & 1);
       *reinterpret_cast<uint2*>(P + off) = h;
       *reinterpret_cast<uint2*>(P + DP_PLANE + off) = l;
-      if (ch == 0 && j == 0) ai[lr] = (r0 + lr < RE) ? inv : 0.f;
+      if (wave == 0 && g == 0) ai[lr] = (r0 + lr < RE) ? inv : 0.f;
     }
   };
-  auto zero_invalid = [&](float4 (&v)[4]) {      // rows beyond the tensor carry zeros through the chain
+  auto zero_invalid = [&](float4 (&v)[NT]) {      // rows beyond the tensor carry zeros through the chain
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (r0 + 16 * mt + 4 * g + r >= RE) v[r] = f4zero();
+    for (int rt = 0; rt < NT; ++rt) if (r0 + 16 * rt + j >= RE) v[rt] = f4zero();
+  };
+  // keep nibbles of the lane's NT rows at a dropout site of the accumulator layout (+ the keep bytes into the plane)
+  auto drop_rows = [&](uint32_t site, uint8_t* plane, uint32_t (&nib)[NT]) {
+#pragma unroll
+    for (int c = 0; c < (NT + 1) / 2; ++c) {
+      const int ra = r0 + 16 * (2 * c) + j, rb = (2 * c + 1 < NT) ? ra + 16 : ra;
+      uint32_t na, nb;
+      drop_nib2_store_t(dr, site, a.drop_row0, ra, rb, ra < RE, (2 * c + 1 < NT) && rb < RE, (uint32_t)(ecol >> 2), plane, na, nb, lane);
+      nib[2 * c] = na;
+      if (2 * c + 1 < NT) nib[2 * c + 1] = nb;
+    }
   };
 
-  float4 SV[4], XV[4], T1[4], T2[4];
-  // ---- s_value = s_att . Ws + b  (layers.py:93)
-  step(P0, a.w[1]);
-  if (act) {
-    fold(SV, ainv0, true);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { SV[r] = addb(SV[r], 0); save_nt(a.sv, r, SV[r]); }
-    zero_invalid(SV);
-    put_max(SV);
-  }
+  float4 SV[NT], XV[NT], T1[NT], T2[NT];
+  // ---- s_value = s_att . Ws + b ; x_value = x_att . Wx + b  (layers.py:93-94)
   cb_barrier();
-  if (act) put_planes(P2, ainv2, SV);
-  // ---- x_value = x_att . Wx + b  (layers.py:94)
-  step(P1, a.w[2]);
-  if (act) {
-    fold(XV, ainv1, true);
+  tf_mma_lean<NT, DP_PLANE>(P0, wa, lane, accp);
+  fold(SV, ainv0, true);
+  tf_load_w(wa, a.w[2], wave, lane);
+  tf_mma_lean<NT, DP_PLANE>(P1, wb, lane, accp);
+  fold(XV, ainv1, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { XV[r] = addb(XV[r], 1); save_nt(a.xv, r, XV[r]); }
-    zero_invalid(XV);
-    put_max(XV);
+  for (int rt = 0; rt < NT; ++rt) {
+    SV[rt] = addb(SV[rt], 0);
+    XV[rt] = addb(XV[rt], 1);
+    save_nt(a.sv, rt, SV[rt]);
+    save_nt(a.xv, rt, XV[rt]);
   }
+  zero_invalid(SV);
+  zero_invalid(XV);
+  put_max(smaxA, SV);
+  put_max(smaxB, XV);
+  tf_load_w(wb, a.w[3], wave, lane);
   cb_barrier();
-  if (act) put_planes(P0, ainv0, XV);
+  put_planes(P2, ainv2, smaxA, SV);
+  put_planes(P0, ainv0, smaxB, XV);
+  cb_barrier();
   // ---- cross gating (layers.py:96-103): o = sigmoid(s_value . Wsg + b) * x_value + sigmoid(x_value . Wxg + b) * s_value
-  step(P2, a.w[3]);
-  if (act) fold(T1, ainv2, true);
-  step(P0, a.w[4]);
-  if (act) {
-    fold(T2, ainv0, true);
+  tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
+  fold(T1, ainv2, true);
+  tf_load_w(wa, a.w[4], wave, lane);
+  tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
+  fold(T2, ainv0, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float4 sg = sig4(addb(T1[r], 2)), xg = sig4(addb(T2[r], 3));
-      save_nt(a.sg, r, sg);
-      save_nt(a.xg, r, xg);
-      T1[r] = cb_add(cb_mul(sg, XV[r]), cb_mul(xg, SV[r]));
-      save_nt(a.o, r, T1[r]);
-    }
-    zero_invalid(T1);
-    put_max(T1);
+  for (int rt = 0; rt < NT; ++rt) {
+    const float4 sg = sig4(addb(T1[rt], 2)), xg = sig4(addb(T2[rt], 3));
+    save_nt(a.sg, rt, sg);
+    save_nt(a.xg, rt, xg);
+    T1[rt] = cb_add(cb_mul(sg, XV[rt]), cb_mul(xg, SV[rt]));
+    save_nt(a.o, rt, T1[rt]);
   }
+  zero_invalid(T1);
+  put_max(smaxA, T1);
+  tf_load_w(wb, a.w[5], wave, lane);
   cb_barrier();
-  if (act) put_planes(P1, ainv1, T1);
+  put_planes(P1, ainv1, smaxA, T1);
+  cb_barrier();
   // ---- guided dense (layers.py:104)
-  step(P1, a.w[5]);
-  if (act) {
-    fold(T1, ainv1, true);
+  tf_mma_lean<NT, DP_PLANE>(P1, wa, lane, accp);
+  fold(T1, ainv1, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { T1[r] = addb(T1[r], 4); save_nt(a.gd, r, T1[r]); }
-    zero_invalid(T1);
-    put_max(T1);
-  }
-  // RP1: the layer-normed input (ln1) -> slot 0 (free since the x_gate product)
+  for (int rt = 0; rt < NT; ++rt) { T1[rt] = addb(T1[rt], 4); save_nt(a.gd, rt, T1[rt]); }
+  zero_invalid(T1);
+  put_max(smaxA, T1);
+  tf_load_w(wa, a.w[6], wave, lane);
+  // RP1: the layer-normed input (ln1) -> slot 0 (free since the x_gate product: two barriers ago)
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int lr = grp + 16 * u;
@@ -360,51 +367,53 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     if (l32 == 0) ainv0[lr] = ok ? i0 : 0.f;
   }
   cb_barrier();
-  if (act) put_planes(P2, ainv2, T1);
-  // ---- bilinear gate and value (layers.py:48-56, 106-110): scores = ln1 . W11 + g . W12 + b1 ; values = ln1 . W21 + g . W22 + b2
-  step(P0, a.w[6]);
-  if (act) fold(T1, ainv0, true);
-  step(P2, a.w[7]);
-  if (act) fold(T1, ainv2, false);
-  step(P0, a.w[8]);
-  if (act) fold(T2, ainv0, true);
-  step(P2, a.w[9]);
-  if (act) {
-    fold(T2, ainv2, false);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float4 gate = addb(T1[r], 5);
-      gate = rm[r] != 0.f ? sig4(gate) : f4zero();             // sigmoid(mask_logits(scores, mask)) (layers.py:110)
-      const float4 val = addb(T2[r], 6);
-      save_nt(a.gate, r, gate);
-      save_nt(a.val, r, val);
-      T1[r] = cb_mul(gate, val);
-      save_nt(a.mha, r, T1[r]);
-    }
-    zero_invalid(T1);
-    put_max(T1);
-  }
+  put_planes(P2, ainv2, smaxA, T1);
   cb_barrier();
-  if (act) put_planes(P1, ainv1, T1);
-  // ---- dense_1 + dropout + residual (modules.py:82-83); the rows also go to LDS as fp32 for the layer norm
-  step(P1, a.w[10]);
-  if (act) {
-    fold(SV, ainv1, true);                                      // SV now holds `res`
-    uint32_t nbd[4] = {15u, 15u, 15u, 15u};
-    if (dr.enabled) {
-      const int ra = r0 + 16 * mt + 4 * g;
-      drop_nib2_store_r(dr, (uint32_t)(a.site + 2), a.drop_row0, ra, ra + 1, ra < RE, ra + 1 < RE, (uint32_t)(ecol >> 2), a.bits2, nbd[0], nbd[1]);
-      drop_nib2_store_r(dr, (uint32_t)(a.site + 2), a.drop_row0, ra + 2, ra + 3, ra + 2 < RE, ra + 3 < RE, (uint32_t)(ecol >> 2), a.bits2, nbd[2], nbd[3]);
-    }
+  // ---- bilinear gate and value (layers.py:48-56, 106-110): scores = ln1 . W11 + g . W12 + b1 ; values = ln1 . W21 + g . W22 + b2
+  tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
+  fold(T1, ainv0, true);
+  tf_load_w(wb, a.w[7], wave, lane);
+  tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
+  fold(T1, ainv2, false);
+  tf_load_w(wa, a.w[8], wave, lane);
+  tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
+  fold(T2, ainv0, true);
+  tf_load_w(wb, a.w[9], wave, lane);
+  tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
+  fold(T2, ainv2, false);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lr = 16 * mt + 4 * g + r;
-      float4 v = addb(SV[r], 7);
-      if (dr.enabled) v = f4_select(nbd[r], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
-      v = cb_add(v, xin[r]);
-      SV[r] = v;
-      save(a.res, r, v);
-      scratch[lr * 32 + (ecol >> 2)] = v;
+  for (int rt = 0; rt < NT; ++rt) {
+    float4 gate = addb(T1[rt], 5);
+    gate = rm[rt] != 0.f ? sig4(gate) : f4zero();             // sigmoid(mask_logits(scores, mask)) (layers.py:110)
+    const float4 val = addb(T2[rt], 6);
+    save_nt(a.gate, rt, gate);
+    save_nt(a.val, rt, val);
+    T1[rt] = cb_mul(gate, val);
+    save_nt(a.mha, rt, T1[rt]);
+  }
+  zero_invalid(T1);
+  put_max(smaxA, T1);
+  tf_load_w(wa, a.w[10], wave, lane);
+  cb_barrier();
+  put_planes(P1, ainv1, smaxA, T1);
+  cb_barrier();
+  // ---- dense_1 + dropout + residual (modules.py:82-83); the rows also go to LDS as fp32 for the layer norm
+  tf_mma_lean<NT, DP_PLANE>(P1, wb, lane, accp);
+  fold(SV, ainv1, true);                                      // SV now holds `res`
+  {
+    uint32_t nbd[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) nbd[rt] = 15u;
+    if (dr.enabled) drop_rows((uint32_t)(a.site + 2), a.bits2, nbd);
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      const int lr = 16 * rt + j;
+      float4 v = addb(SV[rt], 7);
+      if (dr.enabled) v = f4_select(nbd[rt], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
+      v = cb_add(v, xin[rt]);
+      SV[rt] = v;
+      save(a.res, rt, v);
+      scratch[lr * 32 + (ecol >> 2)] = v;                     // (slot 0 was last read two products ago)
     }
   }
   cb_barrier();
@@ -437,25 +446,23 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
       if (l32 == 0) ainv2[lr] = ok ? i2 : 0.f;
     }
   }
+  cb_barrier();
   // ---- dense_2 + dropout + residual (modules.py:87-88)
-  step(P2, nullptr);
-  if (act) {
-    fold(T1, ainv2, true);
-    uint32_t nbe[4] = {15u, 15u, 15u, 15u};
-    if (dr.enabled) {
-      const int ra = r0 + 16 * mt + 4 * g;
-      drop_nib2_store_r(dr, (uint32_t)(a.site + 4), a.drop_row0, ra, ra + 1, ra < RE, ra + 1 < RE, (uint32_t)(ecol >> 2), a.bits4, nbe[0], nbe[1]);
-      drop_nib2_store_r(dr, (uint32_t)(a.site + 4), a.drop_row0, ra + 2, ra + 3, ra + 2 < RE, ra + 3 < RE, (uint32_t)(ecol >> 2), a.bits4, nbe[2], nbe[3]);
-    }
+  tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
+  fold(T1, ainv2, true);
+  {
+    uint32_t nbe[NT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float4 v = addb(T1[r], 8);
-      if (dr.enabled) v = f4_select(nbe[r], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
-      v = cb_add(v, SV[r]);
-      save(a.out, r, v);
+    for (int rt = 0; rt < NT; ++rt) nbe[rt] = 15u;
+    if (dr.enabled) drop_rows((uint32_t)(a.site + 4), a.bits4, nbe);
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      float4 v = addb(T1[rt], 8);
+      if (dr.enabled) v = f4_select(nbe[rt], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
+      v = cb_add(v, SV[rt]);
+      save(a.out, rt, v);
     }
   }
-  HUAL_STAMP(si);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -969,11 +976,15 @@ int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s) {
   for (int k = 0; k < 9; ++k) HUAL_REQUIRE(a.b[k] != nullptr, "da_post: null bias");
   HUAL_REQUIRE(a.sv && a.xv && a.sg && a.xg && a.o && a.gd && a.gate && a.val && a.mha && a.res && a.l2 && a.out && a.mean2 && a.rstd2,
                "da_post: null output");
-  HUAL_DYN_LDS(da_post_kernel, 160 * 1024);
-  const size_t lds = (size_t)3 * DP_SLOT + CB_WBYTES + DP_NB * 512 + (3 * DP_ROWS + 2 * DP_ROWS) * sizeof(float);
+  const size_t lds = (size_t)3 * DP_SLOT + DP_NB * 512 + (3 * DP_ROWS + 16 * DP_ROWS) * sizeof(float);
   const double rows = (double)a.R;
-  HUAL_LAUNCH(11.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 16.0 + 11.0 * HUAL_D * HUAL_D), da_post_kernel,
-              dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), lds, s, a, drop);
+  const double flops = 11.0 * 2.0 * rows * HUAL_D * HUAL_D, bytes = 4.0 * (rows * HUAL_D * 16.0 + 11.0 * HUAL_D * HUAL_D);
+  const dim3 grid(xcd_round8(cdiv(a.R, a.MT)));
+  switch (cdiv(a.MT, 16)) {      // row tiles per workgroup
+    case 1: { HUAL_DYN_LDS(da_post_kernel<1>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_post_kernel<1>, grid, dim3(CB_THREADS), lds, s, a, drop); break; }
+    case 2: { HUAL_DYN_LDS(da_post_kernel<2>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_post_kernel<2>, grid, dim3(CB_THREADS), lds, s, a, drop); break; }
+    default: { HUAL_DYN_LDS(da_post_kernel<3>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_post_kernel<3>, grid, dim3(CB_THREADS), lds, s, a, drop); break; }
+  }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

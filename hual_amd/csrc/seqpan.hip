@@ -251,8 +251,9 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
       const DualAttnP& d = pm.da[li];
       const size_t w[] = {d.dense1.k, d.dense2.k, d.bl1_d1, d.bl1_d2, d.bl2_d1, d.bl2_d2, d.guided.k, d.s_gate.k, d.x_gate.k,
                           d.s_dense.k, d.x_dense.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
-      // (the ten weights of the gated middle's backward chain as N images: da_mid_bwd_kernel keeps its weights in registers)
-      for (int k = 0; k < 16; ++k) add(w[k], D, (k == 0 || (k >= 2 && k <= 10)) ? (uint8_t)(HUAL_PACK_F | HUAL_PACK_N) : FB);
+      // the eleven weights of the gated chain behind the attentions: da_post_kernel / da_mid_bwd_kernel keep their weights in
+      // registers (T / N images); dense_2's dX product runs in ln_proj_bwd_kernel (LDS image)
+      for (int k = 0; k < 16; ++k) add(w[k], D, k > 10 ? FB : (uint8_t)(HUAL_PACK_T | (k == 1 ? HUAL_PACK_B : HUAL_PACK_N)));
     }
     std::sort(c.dense.begin(), c.dense.end(), [](const Ctx::DenseW& a, const Ctx::DenseW& b) { return a.off < b.off; });
     // the image of a transposed weight takes ceil(K/128) blocks of 64 KB: it fits the weight's own byte range when K is a
@@ -531,7 +532,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       const size_t wo[11] = {d.s_dense.k, d.x_dense.k, d.s_gate.k, d.x_gate.k, d.guided.k, d.bl1_d1, d.bl1_d2, d.bl2_d1, d.bl2_d2,
                              d.dense1.k, d.dense2.k};
       const size_t bo[9] = {d.s_dense.b, d.x_dense.b, d.s_gate.b, d.x_gate.b, d.guided.b, d.bl1_b, d.bl2_b, d.dense1.b, d.dense2.b};
-      for (int k = 0; k < 11; ++k) pa.w[k] = img(wo[k]);
+      for (int k = 0; k < 11; ++k) pa.w[k] = c.timg(wo[k]);      // register-resident weights (T images)
       for (int k = 0; k < 9; ++k) pa.b[k] = c.p(bo[k]);
       pa.ln2_g = c.p(d.ln2.g); pa.ln2_b = c.p(d.ln2.b);
       pa.sv = sv; pa.xv = xv; pa.sg = sg; pa.xg = xg; pa.o = o; pa.gd = gd; pa.gate = gate; pa.val = val; pa.mha = mha; pa.res = res;

@@ -287,6 +287,18 @@ __device__ __forceinline__ float slice16_max(float v, int lane) {
   v = fmaxf(v, lane_xor16(v, lane));
   return fmaxf(v, lane_xor32(v, lane));
 }
+// drop_nib2_store_r for the T-form accumulator layout: col4 = 4 wave + (lane >> 4), the lane with the other half of the 8-column group
+// is lane ^ 16.  The even lane of the pair draws rowA's call, the odd one rowB's (rowB = rowA with okB = false: a single row - both
+// draw the same call); all lanes of the wave must be active
+__device__ __forceinline__ void drop_nib2_store_t(const DropRegs& d, uint32_t site, uint32_t rowoff, int rowA, int rowB, bool okA, bool okB,
+                                                  uint32_t col4, uint8_t* plane, uint32_t& nibA, uint32_t& nibB, int lane) {
+  const bool odd = (col4 & 1u) != 0u;
+  const uint32_t b = drop_bits8_r(d, site, rowoff + (uint32_t)(odd ? rowB : rowA), col4 >> 1);
+  const uint32_t o = __builtin_bit_cast(uint32_t, lane_xor16(__builtin_bit_cast(float, b), lane));
+  nibA = odd ? (o >> 4) : (b & 15u);
+  nibB = odd ? (b >> 4) : (o & 15u);
+  if (plane && (odd ? okB : okA)) plane[(size_t)(odd ? rowB : rowA) * 16 + (col4 >> 1)] = (uint8_t)b;
+}
 
 // row of the operand planes: scale to fp16 range, split, store (8 bytes per lane and plane); returns the inverse scale
 __device__ __forceinline__ float cb_store_operand(char* Ahi, char* Alo, int arow, int l32, float4 v) {
