@@ -169,6 +169,10 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_pair_kernel(LnProjArgs a0,
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Stores of the T-form kernels: a wave writes 64 B of a row (its 16 columns), the neighbouring wave the other half of the 128-byte
+// line.  As streaming (nontemporal) stores the halves reached HBM separately - +22 % write traffic measured (WRITE_SIZE) and no
+// faster - so the tensors only the backward reads are stored plainly too: the halves merge in L2
+#define DA_ST_NT st4
 #define DP_ROWS 48
 #define DP_PLANE (DP_ROWS * 256)          // one plane of an operand slot
 #define DP_SLOT (2 * DP_PLANE)
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     if (r0 + 16 * rt + j < RE) st4(dst + eoff[rt], v);
   };
   auto save_nt = [&](float* dst, int rt, float4 v) {      // tensors only the backward pass reads
-    if (r0 + 16 * rt + j < RE) st4_nt(dst + eoff[rt], v);
+    if (r0 + 16 * rt + j < RE) DA_ST_NT(dst + eoff[rt], v);
   };
   // tile -> operand slot, part 1: maxima of the wave's 16-column slices to LDS (the other columns of a row live in the other waves)
   auto put_max = [&](float* sm, const float4 (&v)[NT]) {
@@ -759,7 +763,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
     if (r0 + 16 * rt + j < RE) st4(dst + eoff[rt], v);
   };
   auto save_nt = [&](float* dst, int rt, float4 v) {      // operands of the weight-gradient launch only
-    if (r0 + 16 * rt + j < RE) st4_nt(dst + eoff[rt], v);
+    if (r0 + 16 * rt + j < RE) DA_ST_NT(dst + eoff[rt], v);
   };
   auto put_max = [&](float* sm, const float4 (&v)[NT]) {
 #pragma unroll
