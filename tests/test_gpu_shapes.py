@@ -69,6 +69,14 @@ def test_c4_per_gpu_shape():
     _check_all(case, 0.2)
 
 
+def test_two_row_tile_shape():
+    """R = B (T + L) = 5920 rows: 24 rows per workgroup = TWO 16-row tiles in the T-form kernels of the dual-attention block
+    (da_post_kernel<2>, da_mid_bwd_kernel<2>: one, two and three tiles are separate instantiations - c1 runs <1>, c2 / c4 run <3>),
+    the last tile half used"""
+    case = pu.make_case(B=40, T=128, L=20, C=8, seed=2468, max_vlen=128, vdim=512)
+    _check_all(case, 0.2)
+
+
 def test_c1_shape():
     """BASELINE.json configs[0]: B=16, T=64, 'D=512' read as vdim=512, dropout 0.2"""
     case = pu.make_case(B=16, T=64, L=20, C=8, seed=777, max_vlen=64, vdim=512)
