@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
       }
     }
   }
-  // register-resident weights (tilecore.h "T-form"): one 64 KB block per 128 K rows at boff, [column][index] fp16 hi | lo
+  // register-resident weights (tilecore.h "T-form"): one 64 KB block per 128 K rows at boff, element [column][index] at tf_img_off
   if (timg && (job.need & HUAL_PACK_T)) {        // T image: W^T - column n, index k
     char* img = timg + job.boff + (size_t)(k0 >> 7) * TF_BLOCK;
     const int kb = k0 & 127;
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
       const int n = idx >> 3, pr = idx & 7;             // k pair (k0 + 2 pr, + 1) of column n
       uint32_t hi, lo;
       f16_split_pair(tile[2 * pr][n] * HUAL_F16_WSCALE, tile[2 * pr + 1][n] * HUAL_F16_WSCALE, hi, lo);
-      *reinterpret_cast<uint32_t*>(img + (size_t)n * 256 + 2 * (kb + 2 * pr)) = hi;
-      *reinterpret_cast<uint32_t*>(img + 32768 + (size_t)n * 256 + 2 * (kb + 2 * pr)) = lo;
+      *reinterpret_cast<uint32_t*>(img + tf_img_off(n, kb + 2 * pr)) = hi;
+      *reinterpret_cast<uint32_t*>(img + tf_img_off(n, kb + 2 * pr) + TF_LO_OFF) = lo;
     }
   }
   if (nimg && (job.need & HUAL_PACK_N)) {        // N image: W itself - "column" k, index n
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
       const int r = idx >> 6, np = idx & 63;            // n pair (2 np, 2 np + 1) of row k0 + r
       uint32_t hi, lo;
       f16_split_pair(tile[r][2 * np] * HUAL_F16_WSCALE, tile[r][2 * np + 1] * HUAL_F16_WSCALE, hi, lo);
-      *reinterpret_cast<uint32_t*>(img + (size_t)(kb + r) * 256 + 4 * np) = hi;
-      *reinterpret_cast<uint32_t*>(img + 32768 + (size_t)(kb + r) * 256 + 4 * np) = lo;
+      *reinterpret_cast<uint32_t*>(img + tf_img_off(kb + r, 2 * np)) = hi;
+      *reinterpret_cast<uint32_t*>(img + tf_img_off(kb + r, 2 * np) + TF_LO_OFF) = lo;
     }
   }
   // backward image: the 16 original rows k0..k0+15 are columns c = k0 % 128 + (0..15) of block k0 / 128; for every kk

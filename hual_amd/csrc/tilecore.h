@@ -203,18 +203,27 @@ __device__ __forceinline__ void cb_tile_mma_t(const char* Ahi, const char* Wl, i
 //   * the activation fragments are plain ds_read_b128 of the row-major operand planes (lane (j, g): row j, k 8 g .. 8 g + 7
 //     of a 32-deep step) - no transposed reads; every wave reads all rows (24 KB per 48 rows and step);
 //   * accumulator rt, element r of lane (j, g) = row 16 rt + j, column 16 ws + 4 g + r: four ADJACENT columns of one row.
-// Images (pack_weights_kernel, one 64 KB block per 128 contraction indices): [output column c][contraction index i] fp16 high
-// parts, 256 B per column (32 KB), then the residuals (32 KB).  For a forward product the block is W^T (c = n, i = k: "T image"),
+// Images (pack_weights_kernel, one 64 KB block per 128 contraction indices): fp16 high parts and residuals of element [output
+// column c][contraction index i] in the fragment-major byte order of tf_img_off below.  For a forward product the block is W^T (c = n, i = k: "T image"),
 // for dX = dY . W^T it is W itself (c = k, i = n: "N image").  Values are scaled by 2^HUAL_F16_WSCALE_LOG2 as in the LDS images.
+// Byte order inside a block ("fragment major"): the 16 bytes lane (j, g) = lane j + 16 g of wave ws loads for k-step ks - column
+// 16 ws + j, indices 32 ks + 8 g .. + 7 - sit at ((ws * 4 + ks) * 2 + plane) * 1024 + 16 * lane, plane 0 = high parts, 1 = residuals:
+// every load instruction of tf_load_w reads ONE contiguous KB (8 full cache lines).  In the [column][index] order of the first
+// version an instruction touched 16 half lines 256 B apart, and the halves were fetched again by the next k-step (8 waves x 8 KB
+// of fragments thrash the 32 KB L1): 8.1 M L1 requests per da_post launch against 1.8 M of an ln_proj launch (TCP_UTCL1_REQUEST).
 #define TF_BLOCK 65536
+__host__ __device__ __forceinline__ int tf_img_off(int c, int i) {      // byte offset of the high part of element (column c, index i)
+  return (((c >> 4) * 4 + (i >> 5)) * 2) * 1024 + ((((i >> 3) & 3) * 16 + (c & 15)) * 16) + 2 * (i & 7);
+}
+#define TF_LO_OFF 1024                                                   // ... its residual
 struct TfW { f16x8 h[4], l[4]; };
 __device__ __forceinline__ f16x8 tf_ld16(const char* p) { return __builtin_bit_cast(f16x8, ld4_global(p)); }
 __device__ __forceinline__ void tf_load_w(TfW& w, const void* img, int ws, int lane) {
-  const char* p = reinterpret_cast<const char*>(img) + (16 * ws + (lane & 15)) * 256 + 16 * (lane >> 4);
+  const char* p = reinterpret_cast<const char*>(img) + 8192 * ws + 16 * lane;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    w.h[ks] = tf_ld16(p + 64 * ks);
-    w.l[ks] = tf_ld16(p + 32768 + 64 * ks);
+    w.h[ks] = tf_ld16(p + 2048 * ks);
+    w.l[ks] = tf_ld16(p + 2048 * ks + TF_LO_OFF);
   }
 }
 // acc[rt] = (this wave's columns of) rows 16 rt .. 16 rt + 15 of the operand planes (hi at Ahi, lo at Ahi + ALO) . block
