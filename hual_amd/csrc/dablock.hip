@@ -28,27 +28,27 @@ __device__ __forceinline__ float4 ln_row(float4 v, float& mean, float& rstd) {
 
 // ------------------------------------------------------------------------------------------------------
 #define LP_ROWS 64
+template <int NT>
 __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg& drop) {
   extern __shared__ __attribute__((aligned(16))) char lp_lds[];
   char* P1 = lp_lds;                                  // hi plane [64][256 B] | lo plane
   char* P2 = P1 + 2 * LP_ROWS * 256;
-  char* Wl = P2 + 2 * LP_ROWS * 256;
-  float* ainv1 = reinterpret_cast<float*>(Wl + CB_WBYTES);
+  float* ainv1 = reinterpret_cast<float*>(P2 + 2 * LP_ROWS * 256);
   float* ainv2 = ainv1 + LP_ROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
-  const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
+  const int MT = a.MT, R = a.R;
   const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
   if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
-  const int mt = wave >> 1, ch = wave & 1;
-  const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
+  const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;
   const DropRegs dr = drop_load(drop);
 
-  HUAL_STAMP_K(6, 0);
-  cb_dma_weight(a.wimg[0], Wl, wave, lane, CB_THREADS / 64);
-  // every operand of the kernel is requested up front: rows (unconditional loads on clamped rows), layer-norm parameters, biases
+  // every operand of the kernel is requested up front: the first projection's weight fragments, rows (unconditional loads on
+  // clamped rows), layer-norm parameters, biases
+  TfW w[2];
+  tf_load_w(w[0], a.wimg[0], wave, lane);
   float4 xv[4], av[4], rv[4], bias[HUAL_LNPROJ_MAX];
   const float* xap = a.xa ? a.xa : a.x;
   const float* x2p = a.x2 ? a.x2 : a.x;
@@ -78,7 +78,6 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
         drop_nib2_store_r(dr, (uint32_t)a.drop_site1, a.drop_row0, r0 + lrA, r0 + lrB, okA, okB, (uint32_t)l32, a.y1_bits, nb1[2 * pr], nb1[2 * pr + 1]);
     }
   }
-  HUAL_STAMP_K(6, 1);
   // ---- (residual) + layer norm(s) -> operand planes
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -112,60 +111,53 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
       scratch[lr * 32 + l32] = xr;
     }
   }
-  // ---- the projections, one weight image at a time
-  float4 acc[4];
+  // ---- the projections.  T-form (tilecore.h): wave `wave` owns output columns 16 wave .. 16 wave + 15 of all NT row tiles and holds
+  // its weight fragments (T images, straight from L2, requested a projection ahead) in registers; the operand planes are never
+  // rewritten, so ONE barrier serves all projections.  Accumulator rt of lane (j, g) = row 16 rt + j, columns 16 wave + 4 g .. + 3
+  float4 acc[NT];
+  f32x4 accp[NT];
   bool fresh = true;
 #pragma unroll
   for (int p = 0; p < HUAL_LNPROJ_MAX; ++p) {
     if (p >= a.nproj) break;                                 // uniform
-    HUAL_STAMP_K(6, 2 + 4 * p);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's share of the image (and its stores) done
-    HUAL_STAMP_K(6, 3 + 4 * p);
-    cb_barrier();
-    HUAL_STAMP_K(6, 4 + 4 * p);
+    if (p + 1 < a.nproj) tf_load_w(w[(p + 1) & 1], a.wimg[p + 1], wave, lane);
+    if (p == 0) cb_barrier();
     const char* P = a.src[p] ? P2 : P1;
     const float* ai = a.src[p] ? ainv2 : ainv1;
-    f32x4 accp[4];
-    if (mt < ntile) cb_tile_mma_t<LP_ROWS * 256>(P, Wl, mt, ch, lane, accp);
-    cb_barrier();                                         // image consumed
-    HUAL_STAMP_K(6, 5 + 4 * p);
-    if (p + 1 < a.nproj) cb_dma_weight(a.wimg[p + 1], Wl, wave, lane, CB_THREADS / 64);
-    if (mt < ntile) {
+    tf_mma_lean<NT, LP_ROWS * 256>(P, w[p & 1], lane, accp);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ir = ai[16 * mt + 4 * g + r];
-        if (fresh) acc[r] = make_float4(fmaf(accp[0][r], ir, 0.f), fmaf(accp[1][r], ir, 0.f), fmaf(accp[2][r], ir, 0.f), fmaf(accp[3][r], ir, 0.f));
-        else acc[r] = make_float4(fmaf(accp[0][r], ir, acc[r].x), fmaf(accp[1][r], ir, acc[r].y), fmaf(accp[2][r], ir, acc[r].z), fmaf(accp[3][r], ir, acc[r].w));
-      }
+    for (int rt = 0; rt < NT; ++rt) {
+      const float ir = ai[16 * rt + j];
+      if (fresh) acc[rt] = make_float4(fmaf(accp[rt][0], ir, 0.f), fmaf(accp[rt][1], ir, 0.f), fmaf(accp[rt][2], ir, 0.f), fmaf(accp[rt][3], ir, 0.f));
+      else acc[rt] = make_float4(fmaf(accp[rt][0], ir, acc[rt].x), fmaf(accp[rt][1], ir, acc[rt].y), fmaf(accp[rt][2], ir, acc[rt].z), fmaf(accp[rt][3], ir, acc[rt].w));
     }
     fresh = a.accum[p] == 0;
-    if (a.accum[p] || mt >= ntile) continue;
-    uint32_t nbo[4] = {15u, 15u, 15u, 15u};
-    const bool dropo = a.out_site[p] >= 0 && dr.enabled;
-    if (dropo) {
-      const int ra = r0 + 16 * mt + 4 * g;
-      drop_nib2_store_r(dr, (uint32_t)a.out_site[p], a.drop_row0, ra, ra + 1, ra < RE, ra + 1 < RE, (uint32_t)(ecol >> 2), a.out_bits[p], nbo[0], nbo[1]);
-      drop_nib2_store_r(dr, (uint32_t)a.out_site[p], a.drop_row0, ra + 2, ra + 3, ra + 2 < RE, ra + 3 < RE, (uint32_t)(ecol >> 2), a.out_bits[p], nbo[2], nbo[3]);
-    }
+    if (a.accum[p]) continue;
+    uint32_t nbo[NT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lr = 16 * mt + 4 * g + r, row = r0 + lr;
+    for (int rt = 0; rt < NT; ++rt) nbo[rt] = 15u;
+    const bool dropo = a.out_site[p] >= 0 && dr.enabled;
+    if (dropo) drop_rows_t<NT>(dr, (uint32_t)a.out_site[p], a.drop_row0, r0 + j, RE, (uint32_t)(ecol >> 2), a.out_bits[p], nbo, lane);
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      const int lr = 16 * rt + j, row = r0 + lr;
       if (row >= RE) continue;
-      float4 v = make_float4(acc[r].x + bias[p].x, acc[r].y + bias[p].y, acc[r].z + bias[p].z, acc[r].w + bias[p].w);
+      float4 v = make_float4(acc[rt].x + bias[p].x, acc[rt].y + bias[p].y, acc[rt].z + bias[p].z, acc[rt].w + bias[p].w);
       if (a.act[p]) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-      if (dropo) v = f4_select(nbo[r], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
+      if (dropo) v = f4_select(nbo[rt], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
       if (a.add_x[p]) v = cb_add(v, scratch[lr * 32 + (ecol >> 2)]);
-      st4(a.out[p] + (size_t)row * a.ldo[p] + ecol, v);
+      st4(a.out[p] + (uint32_t)row * (uint32_t)a.ldo[p] + (uint32_t)ecol, v);
     }
   }
-  HUAL_STAMP_K(6, 2 + 4 * a.nproj);
 }
 
-__global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropCfg drop) { ln_proj_body(a, drop); }
+template <int NT>
+__global__ __launch_bounds__(CB_THREADS) void ln_proj_kernel(LnProjArgs a, DropCfg drop) { ln_proj_body<NT>(a, drop); }
 // two independent problems of the same row count in one launch (the start / end hidden layers of the predictor heads)
+template <int NT>
 __global__ __launch_bounds__(CB_THREADS) void ln_proj_pair_kernel(LnProjArgs a0, LnProjArgs a1, DropCfg drop) {
-  if (blockIdx.y == 0) ln_proj_body(a0, drop);
-  else ln_proj_body(a1, drop);
+  if (blockIdx.y == 0) ln_proj_body<NT>(a0, drop);
+  else ln_proj_body<NT>(a1, drop);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -297,16 +289,8 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) if (r0 + 16 * rt + j >= RE) v[rt] = f4zero();
   };
-  // keep nibbles of the lane's NT rows at a dropout site of the accumulator layout (+ the keep bytes into the plane)
   auto drop_rows = [&](uint32_t site, uint8_t* plane, uint32_t (&nib)[NT]) {
-#pragma unroll
-    for (int c = 0; c < (NT + 1) / 2; ++c) {
-      const int ra = r0 + 16 * (2 * c) + j, rb = (2 * c + 1 < NT) ? ra + 16 : ra;
-      uint32_t na, nb;
-      drop_nib2_store_t(dr, site, a.drop_row0, ra, rb, ra < RE, (2 * c + 1 < NT) && rb < RE, (uint32_t)(ecol >> 2), plane, na, nb, lane);
-      nib[2 * c] = na;
-      if (2 * c + 1 < NT) nib[2 * c + 1] = nb;
-    }
+    drop_rows_t<NT>(dr, site, a.drop_row0, r0 + j, RE, (uint32_t)(ecol >> 2), plane, nib, lane);
   };
 
   float4 SV[NT], XV[NT], T1[NT], T2[NT];
@@ -941,7 +925,7 @@ static int check_ln_proj(const LnProjArgs& a) {
   }
   return 0;
 }
-static const size_t kLnProjLds = (size_t)4 * LP_ROWS * 256 + CB_WBYTES + 2 * LP_ROWS * sizeof(float);
+static const size_t kLnProjLds = (size_t)4 * LP_ROWS * 256 + 2 * LP_ROWS * sizeof(float);
 static void ln_proj_work(const LnProjArgs& a, double& flops, double& bytes) {
   const double rows = (double)a.R;
   flops += 2.0 * rows * HUAL_D * HUAL_D * a.nproj;
@@ -951,10 +935,17 @@ static void ln_proj_work(const LnProjArgs& a, double& flops, double& bytes) {
 int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s) {
   int rc = check_ln_proj(a);
   if (rc) return rc;
-  HUAL_DYN_LDS(ln_proj_kernel, 160 * 1024);
   double flops = 0.0, bytes = 0.0;
   ln_proj_work(a, flops, bytes);
-  HUAL_LAUNCH(flops, bytes, ln_proj_kernel, dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), kLnProjLds, s, a, drop);
+  const dim3 grid(xcd_round8(cdiv(a.R, a.MT)));
+#define LN_PROJ_NT(NT) { HUAL_DYN_LDS(ln_proj_kernel<NT>, 160 * 1024); HUAL_LAUNCH(flops, bytes, ln_proj_kernel<NT>, grid, dim3(CB_THREADS), kLnProjLds, s, a, drop); break; }
+  switch (cdiv(a.MT, 16)) {      // row tiles per workgroup
+    case 1: LN_PROJ_NT(1)
+    case 2: LN_PROJ_NT(2)
+    case 3: LN_PROJ_NT(3)
+    default: LN_PROJ_NT(4)
+  }
+#undef LN_PROJ_NT
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -964,11 +955,18 @@ int launch_ln_proj_pair(const LnProjArgs& a0, const LnProjArgs& a1, const DropCf
   if (rc) return rc;
   if ((rc = check_ln_proj(a1))) return rc;
   HUAL_REQUIRE(a0.R == a1.R && a0.MT == a1.MT, "ln_proj_pair: the two problems must have the same rows / tile");
-  HUAL_DYN_LDS(ln_proj_pair_kernel, 160 * 1024);
   double flops = 0.0, bytes = 0.0;
   ln_proj_work(a0, flops, bytes);
   ln_proj_work(a1, flops, bytes);
-  HUAL_LAUNCH(flops, bytes, ln_proj_pair_kernel, dim3(xcd_round8(cdiv(a0.R, a0.MT)), 2), dim3(CB_THREADS), kLnProjLds, s, a0, a1, drop);
+  const dim3 grid(xcd_round8(cdiv(a0.R, a0.MT)), 2);
+#define LN_PROJ_NT(NT) { HUAL_DYN_LDS(ln_proj_pair_kernel<NT>, 160 * 1024); HUAL_LAUNCH(flops, bytes, ln_proj_pair_kernel<NT>, grid, dim3(CB_THREADS), kLnProjLds, s, a0, a1, drop); break; }
+  switch (cdiv(a0.MT, 16)) {
+    case 1: LN_PROJ_NT(1)
+    case 2: LN_PROJ_NT(2)
+    case 3: LN_PROJ_NT(3)
+    default: LN_PROJ_NT(4)
+  }
+#undef LN_PROJ_NT
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -243,8 +243,9 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
     c.ksplit = (cfg->vdim % 256) == 0 && cfg->vdim <= 1024 && (catw % 8) == 0 && qks <= 256;
     add(pm.vconv.k, cfg->vdim, c.ksplit ? HUAL_PACK_F : HUAL_PACK_T);
     add(pm.qconv.k, catw, (c.ksplit ? HUAL_PACK_F : HUAL_PACK_T) | HUAL_PACK_N);
-    add(pm.shid.k, 2 * D, HUAL_PACK_F | HUAL_PACK_N); add(pm.ehid.k, 2 * D, HUAL_PACK_F | HUAL_PACK_N);
-    add(pm.fe_dense.k, D, FB); add(pm.fe_q.k, D, FB); add(pm.fe_k.k, D, FB); add(pm.fe_v.k, D, FB);
+    const uint8_t TB = HUAL_PACK_T | HUAL_PACK_B;      // forward in a T-form kernel (ln_proj), dX in ln_proj_bwd_kernel (LDS image)
+    add(pm.shid.k, 2 * D, TN); add(pm.ehid.k, 2 * D, TN);
+    add(pm.fe_dense.k, D, TB); add(pm.fe_q.k, D, TB); add(pm.fe_k.k, D, TB); add(pm.fe_v.k, D, TB);
     for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D, FB); add(pm.cb.pw[i], D, FB); }
     add(pm.cqcat.k, 2 * D, TN); add(pm.cq[0].dense, 4 * D, TN); add(pm.cq[1].dense, 4 * D, TN);
     for (int li = 0; li < cfg->attn_layer; ++li) {
@@ -253,7 +254,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
                           d.s_dense.k, d.x_dense.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
       // the eleven weights of the gated chain behind the attentions: da_post_kernel / da_mid_bwd_kernel keep their weights in
       // registers (T / N images); dense_2's dX product runs in ln_proj_bwd_kernel (LDS image)
-      for (int k = 0; k < 16; ++k) add(w[k], D, k > 10 ? FB : (uint8_t)(HUAL_PACK_T | (k == 1 ? HUAL_PACK_B : HUAL_PACK_N)));
+      for (int k = 0; k < 16; ++k) add(w[k], D, (k == 1 || k > 10) ? TB : TN);
     }
     std::sort(c.dense.begin(), c.dense.end(), [](const Ctx::DenseW& a, const Ctx::DenseW& b) { return a.off < b.off; });
     // the image of a transposed weight takes ceil(K/128) blocks of 64 KB: it fits the weight's own byte range when K is a
@@ -475,7 +476,6 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* rstd = c.vec(t + ".rstd");
     float* qkv = c.buf(t + ".qkv", R, 3 * D);
     float* ktvt = c.buf(t + ".ktvt", R, 2 * D);
-    auto img = [&](size_t off) { return reinterpret_cast<const float*>(c.PKF + off * 4); };
     {                      // layer norms + the five projections in one launch (dablock.h)
       LnProjArgs lp{};
       lp.x = x; lp.g1 = c.p(d.ln1.g); lp.b1 = c.p(d.ln1.b); lp.y1 = ln1; lp.drop_site1 = -1; lp.pre_site = -1;
@@ -484,7 +484,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       const DenseP* pr[5] = {&d.query, &d.f_key, &d.f_value, &d.t_key, &d.t_value};
       float* outs[5] = {qkv, qkv + D, qkv + 2 * D, ktvt, ktvt + D};
       for (int k = 0; k < 5; ++k) {
-        lp.wimg[k] = img(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = outs[k]; lp.ldo[k] = k < 3 ? 3 * D : 2 * D; lp.src[k] = k < 3 ? 0 : 1;
+        lp.wimg[k] = c.timg(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = outs[k]; lp.ldo[k] = k < 3 ? 3 * D : 2 * D; lp.src[k] = k < 3 ? 0 : 1;
         lp.out_site[k] = -1;
       }
       if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
@@ -626,7 +626,6 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* mean = c.buf(t + ".ln1.mean", Nv, 1);
     float* rstd = c.buf(t + ".ln1.rstd", Nv, 1);
     float* qkv = c.buf(t + ".qkv", Nv, 3 * D);
-    auto img = [&](size_t off) { return reinterpret_cast<const float*>(c.PKF + off * 4); };
     {                      // layer_norm_1 + dropout + query / key / value in one launch (dablock.h)
       LnProjArgs lp{};
       lp.x = f; lp.g1 = c.p(pm.fe_ln1.g); lp.b1 = c.p(pm.fe_ln1.b); lp.y1 = a1; lp.drop_site1 = site + 4; lp.pre_site = -1;
@@ -634,7 +633,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       lp.mean = mean; lp.rstd = rstd; lp.nproj = 3; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
       const DenseP* pr[3] = {&pm.fe_q, &pm.fe_k, &pm.fe_v};
       for (int k = 0; k < 3; ++k) {
-        lp.wimg[k] = img(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = qkv + k * D; lp.ldo[k] = 3 * D; lp.out_site[k] = -1;
+        lp.wimg[k] = c.timg(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = qkv + k * D; lp.ldo[k] = 3 * D; lp.out_site[k] = -1;
       }
       if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
     }
@@ -659,7 +658,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       lp.pre_bits = c.bits(t + ".kb6", Nv); lp.y1_bits = c.bits(t + ".kb7", Nv); lp.out_bits[0] = c.bits(t + ".kb8", Nv);
       lp.g1 = c.p(pm.fe_ln2.g); lp.b1 = c.p(pm.fe_ln2.b); lp.y1 = l2; lp.drop_site1 = site + 7; lp.mean = mean2; lp.rstd = rstd2;
       lp.nproj = 1; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
-      lp.wimg[0] = img(pm.fe_dense.k); lp.bias[0] = c.p(pm.fe_dense.b); lp.out[0] = fo; lp.ldo[0] = D; lp.out_site[0] = site + 8; lp.add_x[0] = 1;
+      lp.wimg[0] = c.timg(pm.fe_dense.k); lp.bias[0] = c.p(pm.fe_dense.b); lp.out[0] = fo; lp.ldo[0] = D; lp.out_site[0] = site + 8; lp.add_x[0] = 1;
       if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
     }
     feo[ps] = fo;
@@ -680,8 +679,8 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       lp.x = feo[h]; lp.g1 = c.p(lnp.g); lp.b1 = c.p(lnp.b); lp.y1 = h == 0 ? sfn : efn; lp.drop_site1 = -1; lp.pre_site = -1;
       lp.mean = hmean + (size_t)h * Nv; lp.rstd = hrstd + (size_t)h * Nv; lp.x2 = outputs;
       lp.nproj = 2; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
-      lp.wimg[0] = reinterpret_cast<const float*>(c.PKF + hp.k * 4); lp.src[0] = 0; lp.accum[0] = 1; lp.out_site[0] = -1;
-      lp.wimg[1] = reinterpret_cast<const float*>(c.PKF + (hp.k + (size_t)D * D) * 4); lp.src[1] = 1; lp.bias[1] = c.p(hp.b);
+      lp.wimg[0] = c.timg(hp.k, 0); lp.src[0] = 0; lp.accum[0] = 1; lp.out_site[0] = -1;
+      lp.wimg[1] = c.timg(hp.k, 1); lp.src[1] = 1; lp.bias[1] = c.p(hp.b);
       lp.act[1] = 1; lp.out[1] = h == 0 ? hs : he; lp.ldo[1] = D; lp.out_site[1] = -1;
       lp2[h] = lp;
     }

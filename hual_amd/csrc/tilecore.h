@@ -308,6 +308,21 @@ __device__ __forceinline__ void drop_nib2_store_t(const DropRegs& d, uint32_t si
   nibB = odd ? (b >> 4) : (o & 15u);
   if (plane && (odd ? okB : okA)) plane[(size_t)(odd ? rowB : rowA) * 16 + (col4 >> 1)] = (uint8_t)b;
 }
+// keep nibbles of the lane's NT rows row0 + 16 rt (row0 = first row of the workgroup + lane & 15) at a dropout site of the T-form
+// accumulator layout, + the keep bytes of the rows < RE into the plane: ceil(NT / 2) calls per lane
+template <int NT>
+__device__ __forceinline__ void drop_rows_t(const DropRegs& d, uint32_t site, uint32_t rowoff, int row0, int RE, uint32_t col4, uint8_t* plane,
+                                            uint32_t (&nib)[NT], int lane) {
+#pragma unroll
+  for (int c = 0; c < (NT + 1) / 2; ++c) {
+    const bool two = 2 * c + 1 < NT;
+    const int ra = row0 + 32 * c, rb = two ? ra + 16 : ra;
+    uint32_t na, nb;
+    drop_nib2_store_t(d, site, rowoff, ra, rb, ra < RE, two && rb < RE, col4, plane, na, nb, lane);
+    nib[2 * c] = na;
+    if (two) nib[2 * c + 1] = nb;
+  }
+}
 
 // row of the operand planes: scale to fp16 range, split, store (8 bytes per lane and plane); returns the inverse scale
 __device__ __forceinline__ float cb_store_operand(char* Ahi, char* Alo, int arow, int l32, float4 v) {
