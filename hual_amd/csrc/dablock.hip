@@ -457,42 +457,44 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
 // dX products -> layer norm(s) backward (LnProjBwdArgs).  Two operand slots are filled alternately from HBM rows (the
 // rows of product k+1 are requested before product k's wait and written behind its matrix phase); the two output tiles
 // stay in registers until the last product, then go to LDS as fp32 rows for the row phase.
-#define LB_ROWS 64
+#define LB_ROWS 48
+#define LB_U (LB_ROWS / 16)     // rows of a 32-lane group in the row layout
 // PRE: with the layer-norm prologue (LnProjBwdArgs::pre_*) - a compile-time switch, the plain launches do not pay for its branches
-template <bool PRE>
+template <bool PRE, int NT>
 __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char lb_lds[];
-  char* S0 = lb_lds;                                   // operand slot 0: hi | lo planes [64][256 B]; later dy_0 as fp32 rows
+  char* S0 = lb_lds;                                   // operand slot 0: hi | lo planes [48][256 B]; later dy_0 as fp32 rows
   char* S1 = S0 + 2 * LB_ROWS * 256;                   // operand slot 1; later dy_1
-  char* Wl = S1 + 2 * LB_ROWS * 256;                   // weight image; later the per-wave parameter sums
-  float* ainv0 = reinterpret_cast<float*>(Wl + CB_WBYTES);
+  char* Ps = S1 + 2 * LB_ROWS * 256;                   // the per-wave parameter sums [8][4][32] float4
+  float* ainv0 = reinterpret_cast<float*>(Ps + 8 * 4 * 32 * 16);
   float* ainv1 = ainv0 + LB_ROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
-  const int MT = a.MT, ntile = (MT + 15) >> 4, R = a.R;
+  const int MT = a.MT, R = a.R;
   const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
   if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
-  const int mt = wave >> 1, ch = wave & 1;
-  const int j = lane & 15, g = lane >> 4, ecol = 64 * ch + 4 * j;
-  const bool act = mt < ntile;
+  const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;
   const DropRegs dr = drop_load(drop);
 
-  cb_dma_weight(a.wimg_t[0], Wl, wave, lane, CB_THREADS / 64);
+  // T-form (tilecore.h): wave `wave` owns gradient columns 16 wave .. 16 wave + 15 of all NT row tiles; its weight fragments (N images)
+  // come straight from L2 into registers, a product ahead.  Accumulator rt of lane (j, g) = row 16 rt + j, columns 16 wave + 4 g .. + 3
+  TfW w[2];
+  tf_load_w(w[0], a.wimg_t[0], wave, lane);
   // operand rows of product 0 and everything the row phase needs (unconditional loads on clamped rows)
-  float4 nv[4], xv[4], a1v[4];
-  float mu[4], rsd[4];
+  float4 nv[LB_U], xv[LB_U], a1v[LB_U];
+  float mu[LB_U], rsd[LB_U];
   constexpr bool pre = PRE;
   const float* add1p = pre ? (a.pre_add ? a.pre_add : a.x) : (a.add1 ? a.add1 : a.x);
   const float* a0p = pre ? a.pre_dy : a.A[0];
   const int lda0 = pre ? HUAL_D : a.lda[0];
-  uint32_t nkb[4];                                     // keep-bit bytes of the operand rows in flight
+  uint32_t nkb[LB_U];                                  // keep-bit bytes of the operand rows in flight
   const uint8_t* kb0p = a.a_bits[0] ? a.a_bits[0] : reinterpret_cast<const uint8_t*>(a.x);
-  float4 pxv[4];                                       // prologue: rows / statistics of the layer norm in front
-  float pmu[4], prs[4];
+  float4 pxv[LB_U];                                    // prologue: rows / statistics of the layer norm in front
+  float pmu[LB_U], prs[LB_U];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < LB_U; ++u) {
     const int row = min(r0 + grp + 16 * u, R - 1);
     nv[u] = ld4(a0p + (size_t)row * lda0 + col);
     nkb[u] = kb0p[(size_t)row * 16 + (l32 >> 1)];
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   if (pre) {      // dxp = LNbwd(pre_x; pre_dy, pre_g) + pre_add -> operand of product 0 and the residual addend of the row phase
     const float4 pg = ld4(a.pre_g + col);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < LB_U; ++u) {
       const int lr = grp + 16 * u;
       const bool ok = lr < MT && r0 + lr < RE;
       const float4 v = pxv[u], dy = nv[u];
@@ -525,16 +527,16 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     }
   }
   const float4 g2 = a.g2 ? ld4(a.g2 + col) : f4zero();
-  float4 addt[4];                                      // add_dy1 in the epilogue layout
+  float4 addt[NT];                                     // add_dy1 in the accumulator layout
   const float* addp = a.add_dy1 ? a.add_dy1 : a.x;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) addt[r] = ld4(addp + (size_t)min(r0 + 16 * mt + 4 * g + r, R - 1) * HUAL_D + ecol);
+  for (int rt = 0; rt < NT; ++rt) addt[rt] = ld4(addp + (uint32_t)min(r0 + 16 * rt + j, R - 1) * (uint32_t)HUAL_D + (uint32_t)ecol);
   // rows -> operand planes of slot `k & 1` (with the operand's dropout', saved for the weight-gradient job)
   auto fill = [&](int k) {
     char* S = (k & 1) ? S1 : S0;
     float* ai = (k & 1) ? ainv1 : ainv0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < LB_U; ++u) {
       const int lr = grp + 16 * u, row = r0 + lr;
       if (lr >= MT) continue;
       const bool ok = row < RE;
@@ -548,79 +550,68 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     }
   };
   fill(0);
-  float4 acc0[4], acc1[4];
+  float4 acc0[NT], acc1[NT];
   bool first0 = true, first1 = true;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { acc0[r] = f4zero(); acc1[r] = f4zero(); }
-#pragma unroll 1
-  for (int k = 0; k < a.nsteps; ++k) {
-    const bool more = k + 1 < a.nsteps;                // uniform
+  for (int rt = 0; rt < NT; ++rt) { acc0[rt] = f4zero(); acc1[rt] = f4zero(); }
+  // one barrier per product: slot k & 1 complete (filled behind product k - 1, whose reads of the other slot every wave has finished
+  // before it arrives here); the next product's rows and weight fragments are requested in front of it
+#pragma unroll
+  for (int k = 0; k < HUAL_LNBWD_MAX; ++k) {
+    if (k >= a.nsteps) break;                          // uniform
+    const bool more = k + 1 < a.nsteps;
     if (more) {
-      // the next product's operand rows: EXACTLY eight vector loads, the youngest vector-memory operations at the wait below, which
-      // therefore leaves them in flight under the matrix phase (vmcnt counts in order: everything older - the weight image, the
-      // stores of the previous fill - has landed); they are taken (pinned) in FRONT of the next image's DMA, which the compiler
-      // does not see and would otherwise wait for together with them
       const uint8_t* nbp = a.a_bits[k + 1] ? a.a_bits[k + 1] : reinterpret_cast<const uint8_t*>(a.x);      // (no bits: a byte that is ignored)
       const float* nap = a.A[k + 1];
       const int nld = a.lda[k + 1];
-      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < LB_U; ++u) {
         const size_t row = (size_t)min(r0 + grp + 16 * u, R - 1);
         nv[u] = ld4(nap + row * nld + col);
         nkb[u] = nbp[row * 16 + (l32 >> 1)];
       }
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tf_load_w(w[(k + 1) & 1], a.wimg_t[k + 1], wave, lane);
     }
     cb_barrier();
     const char* S = (k & 1) ? S1 : S0;
     const float* ai = (k & 1) ? ainv1 : ainv0;
-    f32x4 accp[4];
-    if (act) cb_tile_mma_t<LB_ROWS * 256>(S, Wl, mt, ch, lane, accp);
-    cb_barrier();
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(nv[u].x), "+v"(nv[u].y), "+v"(nv[u].z), "+v"(nv[u].w), "+v"(nkb[u]));
-      cb_dma_weight(a.wimg_t[k + 1], Wl, wave, lane, CB_THREADS / 64);
-    }
-    if (act) {
+    f32x4 accp[NT];
+    tf_mma_lean<NT, LB_ROWS * 256>(S, w[k & 1], lane, accp);
+    {
       const bool to1 = a.dst[k] != 0;
       const bool first = to1 ? first1 : first0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ir = ai[16 * mt + 4 * g + r];
-        const float4 o = to1 ? acc1[r] : acc0[r];
-        const float4 n = first ? make_float4(fmaf(accp[0][r], ir, 0.f), fmaf(accp[1][r], ir, 0.f), fmaf(accp[2][r], ir, 0.f), fmaf(accp[3][r], ir, 0.f))
-                               : make_float4(fmaf(accp[0][r], ir, o.x), fmaf(accp[1][r], ir, o.y), fmaf(accp[2][r], ir, o.z), fmaf(accp[3][r], ir, o.w));
-        if (to1) acc1[r] = n; else acc0[r] = n;
+      for (int rt = 0; rt < NT; ++rt) {
+        const float ir = ai[16 * rt + j];
+        const float4 o = to1 ? acc1[rt] : acc0[rt];
+        const float4 n = first ? make_float4(fmaf(accp[rt][0], ir, 0.f), fmaf(accp[rt][1], ir, 0.f), fmaf(accp[rt][2], ir, 0.f), fmaf(accp[rt][3], ir, 0.f))
+                               : make_float4(fmaf(accp[rt][0], ir, o.x), fmaf(accp[rt][1], ir, o.y), fmaf(accp[rt][2], ir, o.z), fmaf(accp[rt][3], ir, o.w));
+        if (to1) acc1[rt] = n; else acc0[rt] = n;
       }
     }
     if (a.dst[k] != 0) first1 = false; else first0 = false;
-    if (k + 1 < a.nsteps) fill(k + 1);                 // slot (k+1)&1 was last read by product k-1
+    if (more) fill(k + 1);                             // slot (k+1)&1 was last read by product k-1
   }
-  // ---- the two output-gradient tiles -> LDS as fp32 rows (both slots are free behind the last matrix phase)
+  cb_barrier();                                        // every wave is through the last product: both slots are free
+  // ---- the two output-gradient tiles -> LDS as fp32 rows
   float4* D0 = reinterpret_cast<float4*>(S0);
   float4* D1 = reinterpret_cast<float4*>(S1);
-  if (act) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lr = 16 * mt + 4 * g + r;
-      float4 v = acc0[r];
-      if (a.add_dy1) v = cb_add(v, addt[r]);
-      D0[lr * 32 + (ecol >> 2)] = v;
-      if (a.g2) D1[lr * 32 + (ecol >> 2)] = acc1[r];
-    }
+  for (int rt = 0; rt < NT; ++rt) {
+    const int lr = 16 * rt + j;
+    float4 v = acc0[rt];
+    if (a.add_dy1) v = cb_add(v, addt[rt]);
+    D0[lr * 32 + (ecol >> 2)] = v;
+    if (a.g2) D1[lr * 32 + (ecol >> 2)] = acc1[rt];
   }
   // keep bits of the row phase (dropout' of dy_0 / of dx): requested together in front of the barrier - a load behind a branch
   // inside the row loop is a round trip of its own per row (absent planes: a byte of x that is not used)
-  uint32_t kb1[4], kbz[4];
+  uint32_t kb1[LB_U], kbz[LB_U];
   {
     const uint8_t* b1p = a.dy1_bits ? a.dy1_bits : reinterpret_cast<const uint8_t*>(a.x);
     const uint8_t* bzp = a.dz_bits ? a.dz_bits : reinterpret_cast<const uint8_t*>(a.x);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < LB_U; ++u) {
       const size_t row = (size_t)min(r0 + grp + 16 * u, R - 1);
       kb1[u] = b1p[row * 16 + (l32 >> 1)];
       kbz[u] = bzp[row * 16 + (l32 >> 1)];
@@ -630,7 +621,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   // ---- row phase: layer norm(s) backward.  dy = dy*g ; dx = rstd * (gv - mean(gv) - xhat * mean(gv * xhat))   (ln_bwd_kernel)
   float4 sg1 = f4zero(), sb1 = f4zero();
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < LB_U; ++u) {
     const int lr = grp + 16 * u, row = r0 + lr;
     if (lr >= MT || row >= R) continue;
     const size_t off = (size_t)row * HUAL_D + col;
@@ -668,7 +659,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     };
     auto xor32_sum4 = [&](float4 v) { return make_float4(xor32_sum(v.x), xor32_sum(v.y), xor32_sum(v.z), xor32_sum(v.w)); };
     sg1 = xor32_sum4(sg1); sb1 = xor32_sum4(sb1); sg2 = xor32_sum4(sg2); sb2 = xor32_sum4(sb2);
-    float4* pb = reinterpret_cast<float4*>(Wl);        // [8 waves][4 vectors][32] float4
+    float4* pb = reinterpret_cast<float4*>(Ps);        // [8 waves][4 vectors][32] float4
     if (lane < 32) {
       float4* dst = pb + wave * 4 * 32 + l32;
       dst[0] = sg1; dst[32] = sb1; dst[64] = sg2; dst[96] = sb2;
@@ -996,7 +987,7 @@ int ln_proj_bwd_blocks(int R) { return cdiv(R, ln_proj_bwd_rows(R)); }
 
 int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.nsteps >= 1 && a.nsteps <= HUAL_LNBWD_MAX && a.R > 0, "ln_proj_bwd: step count / rows");
-  HUAL_REQUIRE(a.MT >= 1 && a.MT <= LB_ROWS, "ln_proj_bwd: MT must be 1..64");
+  HUAL_REQUIRE(a.MT >= 1 && a.MT <= LB_ROWS, "ln_proj_bwd: MT must be 1..48");
   HUAL_REQUIRE(a.x && a.mean && a.rstd && a.g1 && a.dx && a.part, "ln_proj_bwd: null tensor");
   bool any1 = false;
   for (int k = 0; k < a.nsteps; ++k) {
@@ -1006,16 +997,23 @@ int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t 
   }
   HUAL_REQUIRE(!a.g2 || any1, "ln_proj_bwd: second layer norm without a product");
   HUAL_REQUIRE(!a.pre_x || (!a.g2 && !a.add1 && a.pre_mean && a.pre_rstd && a.pre_g && a.pre_dy), "ln_proj_bwd: layer-norm prologue");
-  HUAL_DYN_LDS(ln_proj_bwd_kernel<false>, 160 * 1024);
-  HUAL_DYN_LDS(ln_proj_bwd_kernel<true>, 160 * 1024);
-  const size_t lds = (size_t)4 * LB_ROWS * 256 + CB_WBYTES + 2 * LB_ROWS * sizeof(float);
+  const size_t lds = (size_t)4 * LB_ROWS * 256 + 8 * 4 * 32 * 16 + 2 * LB_ROWS * sizeof(float);
   const double rows = (double)a.R;
-  if (a.pre_x)
-    HUAL_LAUNCH(2.0 * rows * HUAL_D * HUAL_D * a.nsteps, 4.0 * (rows * HUAL_D * (7.0 + a.nsteps) + (double)a.nsteps * HUAL_D * HUAL_D),
-                ln_proj_bwd_kernel<true>, dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), lds, s, a, drop);
-  else
-    HUAL_LAUNCH(2.0 * rows * HUAL_D * HUAL_D * a.nsteps, 4.0 * (rows * HUAL_D * (4.0 + a.nsteps) + (double)a.nsteps * HUAL_D * HUAL_D),
-                ln_proj_bwd_kernel<false>, dim3(xcd_round8(cdiv(a.R, a.MT))), dim3(CB_THREADS), lds, s, a, drop);
+  const double flops = 2.0 * rows * HUAL_D * HUAL_D * a.nsteps;
+  const double bytes = 4.0 * (rows * HUAL_D * ((a.pre_x ? 7.0 : 4.0) + a.nsteps) + (double)a.nsteps * HUAL_D * HUAL_D);
+  const dim3 grid(xcd_round8(cdiv(a.R, a.MT)));
+#define LN_BWD_NT(NT)                                                                                                   \
+  {                                                                                                                     \
+    if (a.pre_x) { HUAL_DYN_LDS((ln_proj_bwd_kernel<true, NT>), 160 * 1024); HUAL_LAUNCH(flops, bytes, (ln_proj_bwd_kernel<true, NT>), grid, dim3(CB_THREADS), lds, s, a, drop); } \
+    else { HUAL_DYN_LDS((ln_proj_bwd_kernel<false, NT>), 160 * 1024); HUAL_LAUNCH(flops, bytes, (ln_proj_bwd_kernel<false, NT>), grid, dim3(CB_THREADS), lds, s, a, drop); }      \
+    break;                                                                                                              \
+  }
+  switch (cdiv(a.MT, 16)) {      // row tiles per workgroup
+    case 1: LN_BWD_NT(1)
+    case 2: LN_BWD_NT(2)
+    default: LN_BWD_NT(3)
+  }
+#undef LN_BWD_NT
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

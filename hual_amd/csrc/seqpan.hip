@@ -243,18 +243,16 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
     c.ksplit = (cfg->vdim % 256) == 0 && cfg->vdim <= 1024 && (catw % 8) == 0 && qks <= 256;
     add(pm.vconv.k, cfg->vdim, c.ksplit ? HUAL_PACK_F : HUAL_PACK_T);
     add(pm.qconv.k, catw, (c.ksplit ? HUAL_PACK_F : HUAL_PACK_T) | HUAL_PACK_N);
-    const uint8_t TB = HUAL_PACK_T | HUAL_PACK_B;      // forward in a T-form kernel (ln_proj), dX in ln_proj_bwd_kernel (LDS image)
     add(pm.shid.k, 2 * D, TN); add(pm.ehid.k, 2 * D, TN);
-    add(pm.fe_dense.k, D, TB); add(pm.fe_q.k, D, TB); add(pm.fe_k.k, D, TB); add(pm.fe_v.k, D, TB);
+    add(pm.fe_dense.k, D, TN); add(pm.fe_q.k, D, TN); add(pm.fe_k.k, D, TN); add(pm.fe_v.k, D, TN);
     for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D, FB); add(pm.cb.pw[i], D, FB); }
     add(pm.cqcat.k, 2 * D, TN); add(pm.cq[0].dense, 4 * D, TN); add(pm.cq[1].dense, 4 * D, TN);
     for (int li = 0; li < cfg->attn_layer; ++li) {
       const DualAttnP& d = pm.da[li];
       const size_t w[] = {d.dense1.k, d.dense2.k, d.bl1_d1, d.bl1_d2, d.bl2_d1, d.bl2_d2, d.guided.k, d.s_gate.k, d.x_gate.k,
                           d.s_dense.k, d.x_dense.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
-      // the eleven weights of the gated chain behind the attentions: da_post_kernel / da_mid_bwd_kernel keep their weights in
-      // registers (T / N images); dense_2's dX product runs in ln_proj_bwd_kernel (LDS image)
-      for (int k = 0; k < 16; ++k) add(w[k], D, (k == 1 || k > 10) ? TB : TN);
+      // all sixteen in the T-form kernels (ln_proj, da_post; ln_proj_bwd, da_mid_bwd): T / N images
+      for (size_t o : w) add(o, D, TN);
     }
     std::sort(c.dense.begin(), c.dense.end(), [](const Ctx::DenseW& a, const Ctx::DenseW& b) { return a.off < b.off; });
     // the image of a transposed weight takes ceil(K/128) blocks of 64 KB: it fits the weight's own byte range when K is a
@@ -813,7 +811,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* dzd = c.actv("d." + t + ".zd");
     c.push_dw(mkdw(l2, D, D, dzd, D, Nv, c.g(pm.fe_dense.k), c.g(pm.fe_dense.b)));
     float* d_res = c.actv("d." + t + ".res");
-    auto imgt = [&](size_t off) { return reinterpret_cast<const float*>(c.PKB + off * 4); };
+    auto imgt = [&](size_t off) { return c.nimg(off); };      // N images: ln_proj_bwd_kernel / da_mid_bwd_kernel keep their weights in registers
     {                      // dense^T + layer_norm_2 backward in one launch (dablock.h); dZ of the dense layer came from upstream
       LnProjBwdArgs lb{};
       // prologue: gradient wrt fe<ps>.out = end / start layer norm backward (+ what pass 1 sent back to its input, for pass 0);
@@ -1027,7 +1025,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     float* d_xv = c.act(dt + ".x");
     float* d_satt = c.act(dt + ".s_att");
     float* d_xatt = c.act(dt + ".x_att");
-    auto imgt = [&](size_t off) { return reinterpret_cast<const float*>(c.PKB + off * 4); };
+    auto imgt = [&](size_t off) { return c.nimg(off); };      // N images: ln_proj_bwd_kernel / da_mid_bwd_kernel keep their weights in registers
     const bool dz2_ready = li < c.cfg->attn_layer - 1 && c.sel_stage < 0;     // the layer above left dropout'(dx) in dz2
     // weight-gradient jobs of this half of the block (operands are written by whichever path runs below)
     c.push_dw(mkdw(mha, D, D, dz1, D, R, c.g(d.dense1.k), c.g(d.dense1.b)));
