@@ -27,8 +27,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
   float4* X = reinterpret_cast<float4*>(cb_lds);            // [XR][CB_XS] float4
   char* Ahi = cb_lds + (size_t)XR * CB_XS * 16;             // [64][256 B]
   char* Alo = Ahi + 64 * 256;
-  char* Wl = Alo + 64 * 256;                                // CB_WBYTES
-  float* ainv = reinterpret_cast<float*>(Wl + CB_WBYTES);   // [64] inverse operand scale per A row
+  float* ainv = reinterpret_cast<float*>(Alo + 64 * 256);   // [64] inverse operand scale per A row
   float* smean = ainv + 64;                                 // [72] layer-norm statistics of the X rows
   float* srstd = smean + 72;                                // [72]
   float4* par = reinterpret_cast<float4*>(srstd + 72);      // [4][CB_NPAR][32] float4
@@ -42,7 +41,10 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
 
   const DropRegs dr = drop_load(drop);
   HUAL_STAMP_K(2, 0);
-  cb_dma_weight(a.l[0].wimg, Wl, wave, lane, CB_THREADS / 64);
+  // T-form (tilecore.h): wave `wave` owns output columns 16 wave .. 16 wave + 15 of all row tiles of a layer; its weight fragments
+  // (T images) come straight from L2 into registers, a layer ahead
+  TfW wc, wn;
+  tf_load_w(wc, a.l[0].wimg, wave, lane);
   // ---- block input (+ position embeddings for the predictor's feature encoder) and the small parameters of all four
   // layers: everything is requested before anything is used - one memory round trip.  The loads are unconditional on
   // clamped rows (a load behind a lane-dependent branch is waited for inside that branch: one round trip per load)
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
     const int nout = MT + 2 * H;                             // output rows r0-H .. r0+MT+H-1
     const int ntile = (nout + 15) >> 4;
     const int obase = r0 - H;                                // global row of output / operand row 0
-    const int mt = wave >> 1, ch = wave & 1;                 // P2 / P3: row tile and column half of this wave
+    const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;      // P2 / P3: accumulator rt of lane (j, g) = row 16 rt + j, columns ecol ..
     const float4* lp = par + l * CB_NPAR * 32;
     // ---------------- P1a: layer-norm statistics of the nout + 6 input rows, once per row.  Thread (row, quarter) owns 32
     // columns; the partial sums are associated exactly like the 32-lane butterfly of row_stats() in rowops.hip (lane =
@@ -128,10 +130,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
     cb_barrier();
     HUAL_STAMP_K(2, 2 + 6 * l);
     // ---------------- P1b: depthwise conv over a sliding window of normalised rows -> operand planes
-    // The wait for this wave's share of the weight image sits HERE, in front of the stores of this phase: vmcnt counts stores
-    // as well, and behind them the same wait would drain them (a store round trip per layer) before the matrix phase starts.
-    // The image was requested a whole phase ago; the barrier behind this phase publishes every wave's share.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (l + 1 < 4) tf_load_w(wn, a.l[l + 1].wimg, wave, lane);      // the next layer's fragments (requested in front of this phase's stores)
     {
       const float4 gam = lp[7 * 32 + l32], bet = lp[8 * 32 + l32];
       float4 w[7];
@@ -189,64 +188,61 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
       }
     }
     HUAL_STAMP_K(2, 3 + 6 * l);
-    cb_barrier();                                         // operand planes complete; every wave passed its weight-image wait above
+    cb_barrier();                                         // operand planes complete
     HUAL_STAMP_K(2, 4 + 6 * l);
-    // ---------------- P2: pointwise convolution on the matrix cores
+    // ---------------- P2: pointwise convolution on the matrix cores (three or four row tiles: H = 9, 6 / 3, 0 at 37 .. 46 owned rows)
     f32x4 acc[4];
-    if (mt < ntile) cb_tile_mma_t<64 * 256>(Ahi, Wl, mt, ch, lane, acc);
-    cb_barrier();                                         // operand planes and weight image are free again
+    if (ntile > 3) tf_mma_lean<4, 64 * 256>(Ahi, wc, lane, acc);
+    else tf_mma_lean<3, 64 * 256>(Ahi, wc, lane, reinterpret_cast<f32x4(&)[3]>(acc));
     HUAL_STAMP_K(2, 5 + 6 * l);
-    if (l + 1 < 4) cb_dma_weight(a.l[l + 1].wimg, Wl, wave, lane, CB_THREADS / 64);
-    HUAL_STAMP_K(2, 6 + 6 * l);
-    HUAL_STAMP_K(7, 0 + 4 * l);
     // ---------------- P3: bias, relu, dropout, residual.  The relu active set and the dropout keep set of the owned rows leave
     // as bit planes (tilecore.h): all the backward pass needs of y_l
-    if (mt < ntile) {
-      const int j = lane & 15, g = lane >> 4;
-      const int ecol = 64 * ch + 4 * j;
+    {
       const float4 bias = lp[9 * 32 + (ecol >> 2)];
-      const int lr0 = 16 * mt + 4 * g, o0 = obase + lr0;
-      const bool dropping = L.drop_site >= 0 && dr.enabled;
-      bool own[4];
+      const bool dropping = L.drop_site >= 0 && dr.enabled;      // (wave-uniform)
+      int orow[4];
+      bool own[4], live[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) own[r] = lr0 + r < nout && o0 + r >= r0 && o0 + r < r0 + MT && o0 + r < R;
-      uint32_t nib[4] = {15u, 15u, 15u, 15u};
-      if (dropping) {      // (wave-uniform) two calls per lane for its 4 rows; the keep bytes of the owned rows go to the plane
-        drop_nib2_store_r(dr, (uint32_t)L.drop_site, a.drop_row0, o0, o0 + 1, own[0], own[1], (uint32_t)(ecol >> 2), L.keep_bits, nib[0], nib[1]);
-        drop_nib2_store_r(dr, (uint32_t)L.drop_site, a.drop_row0, o0 + 2, o0 + 3, own[2], own[3], (uint32_t)(ecol >> 2), L.keep_bits, nib[2], nib[3]);
+      for (int rt = 0; rt < 4; ++rt) {
+        const int lr = 16 * rt + j;
+        orow[rt] = obase + lr;
+        live[rt] = rt < ntile && lr < nout && orow[rt] >= 0 && orow[rt] < R;
+        own[rt] = live[rt] && orow[rt] >= r0 && orow[rt] < r0 + MT;
       }
-      HUAL_STAMP_K(7, 1 + 4 * l);
+      uint32_t nib[4] = {15u, 15u, 15u, 15u};
+      if (dropping) {      // two calls per lane for its 4 rows; the keep bytes of the owned rows go to the plane
+        drop_nib2_store_t(dr, (uint32_t)L.drop_site, a.drop_row0, orow[0], orow[1], own[0], own[1], (uint32_t)(ecol >> 2), L.keep_bits, nib[0], nib[1], lane);
+        drop_nib2_store_t(dr, (uint32_t)L.drop_site, a.drop_row0, orow[2], orow[3], own[2], own[3], (uint32_t)(ecol >> 2), L.keep_bits, nib[2], nib[3], lane);
+      }
       uint32_t rb[4] = {0u, 0u, 0u, 0u};
-      // the four LDS reads per row (operand scale, residual row) are issued up front: the stores into X below would otherwise
+      // the LDS reads per row (operand scale, residual row) are issued up front: the stores into X below would otherwise
       // order every later read behind them
       float irv[4];
       float4 xres[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        irv[r] = ainv[min(lr0 + r, 63)];
-        xres[r] = X[min(max(o0 + r - xbase, 0), XR - 1) * CB_XS + (ecol >> 2)];
+      for (int rt = 0; rt < 4; ++rt) {
+        irv[rt] = ainv[16 * rt + j];
+        xres[rt] = X[min(max(orow[rt] - xbase, 0), XR - 1) * CB_XS + (ecol >> 2)];
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int lr = lr0 + r;
-        const int o = o0 + r;
-        if (lr >= nout || o < 0 || o >= R) continue;
-        const float ir = irv[r];
-        float4 v = make_float4(fmaf(acc[0][r], ir, 0.f) + bias.x, fmaf(acc[1][r], ir, 0.f) + bias.y,
-                               fmaf(acc[2][r], ir, 0.f) + bias.z, fmaf(acc[3][r], ir, 0.f) + bias.w);
+      for (int rt = 0; rt < 4; ++rt) {
+        if (!live[rt]) continue;
+        const int o = orow[rt];
+        const float ir = irv[rt];
+        float4 v = make_float4(fmaf(acc[rt][0], ir, 0.f) + bias.x, fmaf(acc[rt][1], ir, 0.f) + bias.y,
+                               fmaf(acc[rt][2], ir, 0.f) + bias.z, fmaf(acc[rt][3], ir, 0.f) + bias.w);
         v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        if (own[r] && L.y) st4_nt(L.y + (size_t)o * HUAL_D + ecol, v);
-        rb[r] = f4_posbits(v);
-        if (dropping) v = f4_select(nib[r], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
-        v = cb_add(v, xres[r]);
+        if (own[rt] && L.y) st4(L.y + (size_t)o * HUAL_D + ecol, v);
+        rb[rt] = f4_posbits(v);
+        if (dropping) v = f4_select(nib[rt], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
+        v = cb_add(v, xres[rt]);
         X[(o - xbase) * CB_XS + (ecol >> 2)] = v;
-        if (own[r]) st4(L.xout + (size_t)o * HUAL_D + ecol, v);
+        if (own[rt]) st4(L.xout + (size_t)o * HUAL_D + ecol, v);
       }
-      HUAL_STAMP_K(7, 2 + 4 * l);
-      bits_store2(L.relu_bits, o0, o0 + 1, own[0], own[1], ecol >> 2, rb[0], rb[1]);
-      bits_store2(L.relu_bits, o0 + 2, o0 + 3, own[2], own[3], ecol >> 2, rb[2], rb[3]);
-      HUAL_STAMP_K(7, 3 + 4 * l);
+      bits_store2_t(L.relu_bits, orow[0], orow[1], own[0], own[1], ecol >> 2, rb[0], rb[1], lane);
+      bits_store2_t(L.relu_bits, orow[2], orow[3], own[2], own[3], ecol >> 2, rb[2], rb[3], lane);
     }
+    if (l + 1 < 4) wc = wn;
     cb_barrier();
     HUAL_STAMP_K(2, 7 + 6 * l);
   }
@@ -515,7 +511,7 @@ int conv_block_fused_rows(int R) {
   return mt;
 }
 
-static size_t cb_fwd_lds(int MT) { return (size_t)(MT + 24) * CB_XS * 16 + 2 * 64 * 256 + CB_WBYTES + (64 + 72 + 72) * sizeof(float) + 4 * CB_NPAR * 512; }
+static size_t cb_fwd_lds(int MT) { return (size_t)(MT + 24) * CB_XS * 16 + 2 * 64 * 256 + (64 + 72 + 72) * sizeof(float) + 4 * CB_NPAR * 512; }
 
 int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.x0 && rs.R > 0 && a.MT >= 1 && a.MT <= HUAL_CB_MAXMT, "conv_block_fwd: bad arguments");

@@ -237,7 +237,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
     c.dense.clear();
     // which images of a weight the kernels read: F / B - forward and dX products of the LDS-DMA kernels (fused row-local chains,
     // K-split feature load); T / N - the same two for the register-resident weights of mproj (gemm.h HUAL_PACK_*)
-    const uint8_t FB = HUAL_PACK_F | HUAL_PACK_B, TN = HUAL_PACK_T | HUAL_PACK_N;
+    const uint8_t TN = HUAL_PACK_T | HUAL_PACK_N;
     auto add = [&](size_t off, int K, uint8_t need) { if (K % 8 == 0) c.dense.push_back({off, K, off * 4, need}); };
     const int qks = ((catw + 3) / 4 + 63) & ~63;        // quarter size of query_conv1d's K (multiple of 64)
     c.ksplit = (cfg->vdim % 256) == 0 && cfg->vdim <= 1024 && (catw % 8) == 0 && qks <= 256;
@@ -245,7 +245,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
     add(pm.qconv.k, catw, (c.ksplit ? HUAL_PACK_F : HUAL_PACK_T) | HUAL_PACK_N);
     add(pm.shid.k, 2 * D, TN); add(pm.ehid.k, 2 * D, TN);
     add(pm.fe_dense.k, D, TN); add(pm.fe_q.k, D, TN); add(pm.fe_k.k, D, TN); add(pm.fe_v.k, D, TN);
-    for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D, FB); add(pm.cb.pw[i], D, FB); }
+    for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D, HUAL_PACK_T | HUAL_PACK_B); add(pm.cb.pw[i], D, HUAL_PACK_T | HUAL_PACK_B); }
     add(pm.cqcat.k, 2 * D, TN); add(pm.cq[0].dense, 4 * D, TN); add(pm.cq[1].dense, 4 * D, TN);
     for (int li = 0; li < cfg->attn_layer; ++li) {
       const DualAttnP& d = pm.da[li];
@@ -301,7 +301,7 @@ float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP
       L.mean = c.buf(tag + ".mean" + is, R, 1);
       L.rstd = c.buf(tag + ".rstd" + is, R, 1);
       L.ln_g = c.p(cp.ln[i].g); L.ln_b = c.p(cp.ln[i].b); L.dw = c.p(cp.dw[i]);
-      L.wimg = reinterpret_cast<const float*>(c.PKF + cp.pw[i] * 4); L.bias = c.p(cp.b[i]);
+      L.wimg = c.timg(cp.pw[i]); L.bias = c.p(cp.b[i]);      // T image: conv_block_fwd_kernel keeps its weights in registers
       L.drop_site = site0 + i;
       xin = L.xout;
     }

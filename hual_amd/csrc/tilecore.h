@@ -308,6 +308,14 @@ __device__ __forceinline__ void drop_nib2_store_t(const DropRegs& d, uint32_t si
   nibB = odd ? (b >> 4) : (o & 15u);
   if (plane && (odd ? okB : okA)) plane[(size_t)(odd ? rowB : rowA) * 16 + (col4 >> 1)] = (uint8_t)b;
 }
+// bits_store2 for the T-form accumulator layout (col4 = 4 wave + (lane >> 4): the other half of the byte lives in lane ^ 16)
+__device__ __forceinline__ void bits_store2_t(uint8_t* plane, int rowA, int rowB, bool okA, bool okB, int col4, uint32_t nibA, uint32_t nibB, int lane) {
+  const bool odd = (col4 & 1) != 0;
+  const uint32_t mine = nibA | (nibB << 4);                  // even lane: [A lo | B lo], odd lane: [A hi | B hi]
+  const uint32_t other = __builtin_bit_cast(uint32_t, lane_xor16(__builtin_bit_cast(float, mine), lane));
+  const uint32_t byte = odd ? ((other >> 4) | (mine & 0xf0u)) : ((mine & 15u) | ((other & 15u) << 4));
+  if (odd ? okB : okA) plane[(size_t)(odd ? rowB : rowA) * 16 + (col4 >> 1)] = (uint8_t)byte;
+}
 // keep nibbles of the lane's NT rows row0 + 16 rt (row0 = first row of the workgroup + lane & 15) at a dropout site of the T-form
 // accumulator layout, + the keep bytes of the rows < RE into the plane: ceil(NT / 2) calls per lane
 template <int NT>
