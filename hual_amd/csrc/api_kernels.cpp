@@ -44,7 +44,7 @@ int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, con
   if (!trans_w) {        // Y = act(A[M,K] . W[K,128] + bias): ceil(K / 128) weight steps over one deep operand
     HUAL_REQUIRE(N == 128 && K % 8 == 0, "hual_linear_bf16x3: W must be [K,128] with K % 8 == 0");
     HUAL_REQUIRE(scratch_bytes >= (uint64_t)((K + 127) / 128) * 65536, "hual_linear_bf16x3: scratch too small (ceil(K/128) * 65536 bytes)");
-    int rc = launch_pack_weights(&off, &K, &boff, 1, W, nullptr, nullptr, (hipStream_t)stream, nullptr, (char*)scratch, nullptr);
+    int rc = launch_pack_weights(&off, &K, &boff, 1, W, nullptr, (hipStream_t)stream, nullptr, (char*)scratch, nullptr);
     if (rc) return rc;
     g.nsteps = 1;
     MProjStep& st = g.s[0];
@@ -53,7 +53,7 @@ int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, con
   } else {               // Y[M,N] = A[M,128] . W^T, W stored [N,128]  (dX of a dense layer with weight W): ceil(N / 128) column blocks
     HUAL_REQUIRE(K == 128 && N % 8 == 0 && (N + 127) / 128 <= MP_MAX, "hual_linear_bf16x3: transposed use needs K == 128, N % 8 == 0, N <= 1024");
     HUAL_REQUIRE(scratch_bytes >= (uint64_t)((N + 127) / 128) * HUAL_PACK_BLOCK_BYTES, "hual_linear_bf16x3: scratch too small");
-    int rc = launch_pack_weights(&off, &N, &boff, 1, W, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, (char*)scratch);
+    int rc = launch_pack_weights(&off, &N, &boff, 1, W, nullptr, (hipStream_t)stream, nullptr, nullptr, (char*)scratch);
     if (rc) return rc;
     g.nsteps = (N + 127) / 128;
     for (int p = 0; p < g.nsteps; ++p) {

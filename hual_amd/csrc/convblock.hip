@@ -270,8 +270,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
   char* Ahi = cb_lds + (size_t)XR * 512;                     // operand planes [64][256 B] x 2 ...
   char* Alo = Ahi + 64 * 256;
   float4* DC = reinterpret_cast<float4*>(Ahi);               // ... or dC as [64][32] float4 (same 32 KB)
-  char* Wl = Ahi + 64 * 512;
-  float* ainv = reinterpret_cast<float*>(Wl + CB_WBYTES);    // [64]
+  float* ainv = reinterpret_cast<float*>(Ahi + 64 * 512);    // [64]
   float4* par = reinterpret_cast<float4*>(ainv + 64);        // [9][32] float4: w[0..6], gamma, beta of the current layer
   float4* pbuf = par + 9 * 32;                               // [4][9][32] float4: per-wave parameter-gradient sums (one batch)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -281,12 +280,15 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
   const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;      // XCD-aware tile order (common.h)
   if (r0 >= rs.R) return;
   const int xbase = r0 - 12;
-  const int mt = wave >> 1, ch = wave & 1;
 
   const DropRegs dr = drop_load(drop);
   const float dscale3 = dr.enabled ? dr.scale : 1.0f;         // every dropout site of the block has the same rate
   HUAL_STAMP_K(3, 0);
-  cb_dma_weight(a.l[3].wimg_t, Wl, wave, lane, CB_THREADS / 64);
+  // T-form (tilecore.h): wave `wave` owns columns 16 wave .. 16 wave + 15 of all row tiles of dC; its fragments of W_i (N image) come
+  // straight from L2 into registers - ONE set: the next layer's are requested right behind the product that frees it and arrive
+  // under the row phase
+  TfW wc;
+  tf_load_w(wc, a.l[3].wimg_t, wave, lane);
   // ---- prologue: gradient wrt the block output -> DX; dZ_3 -> operand planes (+ HBM for the owned rows)
   {
     float4 dv[4];
@@ -326,17 +328,15 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
     // One unconditional load through a selected pointer (groups 9 .. 15 read a vector they do not store): a load behind the
     // lane-dependent branch would be waited for inside it.
     const float4 pv = ld4((grp < 7 ? L.dw + grp * HUAL_D : (grp == 7 ? L.ln_g : L.ln_b)) + col);
-    asm volatile("" ::: "memory");                           // (the 20 loads below stay behind this one: the wait counts on it)
-    // ---- operands of the row phase, requested before the matrix phase: their latency hides under it.  EXACTLY 20 vector loads
-    // (4 rows x: x, two bit bytes, mean, rstd); the wait below lets exactly these stay in flight - vmcnt counts in order, so the
-    // weight image (LDS-DMA, requested a phase ago) and the parameter vector have landed when at most 20 operations are outstanding
+    // ---- operands of the row phase, requested before the matrix phase: their latency hides under it (unconditional loads on clamped
+    // rows; plain loads now that no hand-placed wait for an LDS-DMA stands between them and their use)
     float4 xv[4];
     float mu[4], rsd[4];
     uint32_t zb[4], zk[4];                                    // relu' / keep nibbles of layer i-1 for this group's rows
     const uint8_t* rprev = L.relu_prev ? L.relu_prev : a.relu_bits3;      // layer 0 has no layer below it: the loaded bytes are ignored
     const uint8_t* kprev = L.keep_prev ? L.keep_prev : a.keep_bits3;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {                             // unconditional loads on clamped rows
+    for (int u = 0; u < 4; ++u) {
       const int tc = min(max(rbase + ra + u, 0), R - 1);
       xv[u] = ld4(L.x + (size_t)tc * HUAL_D + col);
       zk[u] = kprev[(size_t)tc * 16 + (l32 >> 1)];
@@ -344,39 +344,41 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
       mu[u] = L.mean[tc];
       rsd[u] = L.rstd[tc];
     }
-    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");        // weight image + parameter vector have landed
     if (grp < 9) par[grp * 32 + l32] = pv;
     HUAL_STAMP_K(3, 2 + 7 * (3 - i));
     cb_barrier();                                          // (1) operand planes + parameters complete
     HUAL_STAMP_K(3, 3 + 7 * (3 - i));
-    // ---- G: dC_i = dZ_i . W_i^T
+    // ---- G: dC_i = dZ_i . W_i^T (three or four row tiles)
     f32x4 acc[4];
-    if (mt < ntile) cb_tile_mma_t<64 * 256>(Ahi, Wl, mt, ch, lane, acc);
-    cb_barrier();                                          // (2) planes and weight image free
+    if (ntile > 3) tf_mma_lean<4, 64 * 256>(Ahi, wc, lane, acc);
+    else tf_mma_lean<3, 64 * 256>(Ahi, wc, lane, reinterpret_cast<f32x4(&)[3]>(acc));
+    if (i > 0) tf_load_w(wc, a.l[i - 1].wimg_t, wave, lane);      // the next layer's fragments: under the row phase
+    float irv[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) irv[rt] = ainv[16 * rt + (lane & 15)];
+    cb_barrier();                                          // (2) every wave is through the planes: they become dC
     HUAL_STAMP_K(3, 4 + 7 * (3 - i));
-    if (mt < ntile) {
+    {
+      // accumulator rt of lane (j, g) = row 16 rt + j, columns 16 wave + 4 g .. + 3.  The 16 lanes j of a store are 16 rows of one
+      // column group: the float4 column index is XOR-swizzled with 2 (row & 15) - 16 different 16-byte slots - and the row phase
+      // reads a row through the same permutation (still one contiguous 512 B per group)
       const int j = lane & 15, g = lane >> 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int lr = 16 * mt + 4 * g + r;
-        const float ir = ainv[lr];
-        DC[lr * 32 + 16 * ch + j] = make_float4(acc[0][r] * ir, acc[1][r] * ir, acc[2][r] * ir, acc[3][r] * ir);
+      for (int rt = 0; rt < 4; ++rt) {
+        if (rt >= ntile) continue;
+        const int lr = 16 * rt + j;
+        const float ir = irv[rt];
+        DC[lr * 32 + ((4 * wave + g) ^ (2 * j))] = make_float4(acc[rt][0] * ir, acc[rt][1] * ir, acc[rt][2] * ir, acc[rt][3] * ir);
       }
     }
     cb_barrier();                                          // (3) dC visible
-    // the row-phase operands requested at the top are taken here (the pins keep the loads up there and the wait down here, in
-    // FRONT of the next image's DMA - the compiler does not see those eight operations and a wait behind them would wait for them)
     // keep & relu' of dZ_{i-1}, 4 bits per row (bit c = column col + c), rows packed into one register
     uint32_t zbits = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      asm volatile("" : "+v"(xv[u].x), "+v"(xv[u].y), "+v"(xv[u].z), "+v"(xv[u].w), "+v"(zb[u]), "+v"(zk[u]), "+v"(mu[u]), "+v"(rsd[u]));
       const uint32_t sh = 4 * (l32 & 1);
       zbits |= (((zb[u] >> sh) & 15u) & (dr.enabled ? ((zk[u] >> sh) & 15u) : 15u)) << (4 * u);
     }
-    // next layer's weight image: requested only now, behind the barrier (a __syncthreads() with an LDS-DMA in flight
-    // waits for it), so that it lands under the row phase
-    if (i > 0) cb_dma_weight(a.l[i - 1].wimg_t, Wl, wave, lane, CB_THREADS / 64);
     HUAL_STAMP_K(3, 5 + 7 * (3 - i));
     // ---- R: transposed depthwise conv + layer-norm backward
     float4 sw[7], sg = f4zero(), sb = f4zero();
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
         const int tt = rbase + ra - 3 + s;
         const int di = tt - gbase;
         float4 dn = f4zero();
-        if (s < (rb - ra) + 6 && di >= 0 && di < nG && tt >= 0 && tt < R) dn = DC[di * 32 + l32];
+        if (s < (rb - ra) + 6 && di >= 0 && di < nG && tt >= 0 && tt < R) dn = DC[di * 32 + (l32 ^ (2 * (di & 15)))];
         d0 = d1; d1 = d2; d2 = d3; d3 = d4; d4 = d5; d5 = d6; d6 = dn;
         if (s < 6) continue;
         const int u = s - 6;                                  // compile-time index of this group's row
@@ -537,7 +539,7 @@ int conv_block_fused_rows_bwd(int R) {
 }
 int conv_block_bwd_blocks(int R) { return cdiv(R, conv_block_fused_rows_bwd(R)); }
 
-static size_t cb_bwd_lds(int MT) { return (size_t)(MT + 24) * 512 + 64 * 512 + CB_WBYTES + 64 * sizeof(float) + (1 + 4) * 9 * HUAL_D * sizeof(float); }
+static size_t cb_bwd_lds(int MT) { return (size_t)(MT + 24) * 512 + 64 * 512 + 64 * sizeof(float) + (1 + 4) * 9 * HUAL_D * sizeof(float); }
 
 int launch_conv_block_bwd(const CbBwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.dx_in && a.relu_bits3 && a.keep_bits3 && a.dx_out && rs.R > 0 && a.MT >= 1 && a.MT <= HUAL_CB_BWD_MAXMT, "conv_block_bwd: bad arguments");

@@ -36,9 +36,8 @@ struct DwBatch {
 };
 
 // Pre-split weight images (bf16x3.h "f16x3").  launch_pack_weights writes, for n dense weights [K,128] at float offsets offs[] of
-// P, the forward image at fwd + 4*off and the image of the transposed weight (for dX) at bwd + boffs[] (ceil(K/128) blocks
-// of 64 KB); either destination may be null.  The fused kernels, the multi-step kernel (mproj.h) and the feature-load kernel
-// stream these images into LDS.
+// P, the forward LDS image at fwd + 4*off (feature-load kernel) and the T / N images of the register-resident weights (tilecore.h)
+// at timg / nimg + boffs[] (ceil(K/128) blocks of 64 KB); any destination may be null, `needs` selects per weight.
 #define HUAL_PACK_BLOCK_BYTES (128 * 512)
 // `extra` (optional): work of the step's prologue that rides in the same launch as one more row of workgroups - the row
 // masks of model.py:31-32 (+ the loss accumulators cleared) and, when zero_ptr is set, the flat gradient buffer zeroed
@@ -67,8 +66,8 @@ inline int pack_ovf_words(const int* Ks, int n) {
 // timg / nimg (optional): images for the register-resident weights of the T-form kernels (tilecore.h), blocks of 64 KB at boffs[]
 // needs (optional, one byte per job): which of the images a weight is wanted in - the forward / transposed images of the LDS-DMA
 // kernels (F, B), the T / N images; default all that have a destination
-enum { HUAL_PACK_F = 1, HUAL_PACK_B = 2, HUAL_PACK_T = 4, HUAL_PACK_N = 8 };
-int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
+enum { HUAL_PACK_F = 1, HUAL_PACK_T = 4, HUAL_PACK_N = 8 };
+int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd,
                         hipStream_t stream, const PackExtra* extra = nullptr, char* timg = nullptr, char* nimg = nullptr,
                         const uint8_t* needs = nullptr);
 // Feature-load kernel: part[q][M][128] = dropout(A)[M, q*KS .. q*KS+KS) . W[q*KS .., :] for the four K-quarters q (Wimg =

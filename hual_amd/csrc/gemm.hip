@@ -31,7 +31,6 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 #define GL_KS 64                         // K rows per stage of a weight image
 #define GB_TILE (GL_KS * 256)            // bytes of one [64][128 x 16 bit] tile
 #define GB_STAGE (2 * GB_TILE)           // hi + lo
-#define GB_COLBLOCK (128 * 512)          // bytes between the images of consecutive 128-column blocks of a transposed weight
 
 // ------------------------------------------------------------------------------------------------------
 // Feature-load kernel: partial products of video_conv1d (model.py:47-48), Y_q[rows, 128] = dropout(video)[rows, Kq] . W[Kq, :]
@@ -163,16 +162,17 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
 
 // Pre-split weight images for gemm_bf16_kernel, made once per step (the weights are constant within a step).
 // For every dense weight W [K,128] at float offset `off` of the flat parameter buffer:
-//   forward image  at fwd + 4*off:  row k (512 B) = bf16 hi of W[k][perm(s)], s = 0..127 | the same for the residuals
-//   backward image at bwd + boff:   block b (64 KB) = the forward-style image of the 128 x 128 matrix W[128b + c][kk]^T
-//                                   (rows kk, columns c; zero where 128b + c >= K)
+//   forward image  at fwd + 4*off:  row k (512 B) = fp16 hi of W[k][perm(s)], s = 0..127 | the same for the residuals (LDS-DMA
+//                                   operand of the feature-load kernel)
+//   T / N images   at timg / nimg + boff: one 64 KB block per 128 contraction indices, fragment-major (tilecore.h tf_img_off): the
+//                                   register-resident weights of every other dense kernel, forward (W^T) and dX (W)
 // perm(s) = 64 (s>>6) + 4 (s&15) + ((s>>4)&3): stored column 16 t + i of a 64-column half is original column 4 i + t.
 struct PackJob { uint32_t off; int K; uint32_t boff; uint32_t need; };      // need: HUAL_PACK_* images wanted of this weight
 // start[j] = first 16-row block of job j in the packed block order (start[njobs] = total): the job rows of the launch hold the
 // blocks of all jobs back to back (a [K,128] weight has ceil(K / 128) * 8 of them) instead of one padded row per job
 struct PackBatch { PackJob j[HUAL_MAX_PACK]; uint16_t start[HUAL_MAX_PACK + 1]; };
 __device__ __forceinline__ int pack_perm(int s) { return 64 * (s >> 6) + 4 * (s & 15) + ((s >> 4) & 3); }
-__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* bwd, char* timg, char* nimg, int njobs, int jrows, PackExtra ex) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const float* P, char* fwd, char* timg, char* nimg, int njobs, int jrows, PackExtra ex) {
   __shared__ float tile[16][129];
   if ((int)blockIdx.y > jrows) {       // further rows: the embedding gather of the text encoder, one task per thread
     const int gid = (((int)blockIdx.y - jrows - 1) * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
@@ -252,24 +252,6 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackBatch b, const fl
       f16_split_pair(tile[r][2 * np] * HUAL_F16_WSCALE, tile[r][2 * np + 1] * HUAL_F16_WSCALE, hi, lo);
       *reinterpret_cast<uint32_t*>(img + tf_img_off(kb + r, 2 * np)) = hi;
       *reinterpret_cast<uint32_t*>(img + tf_img_off(kb + r, 2 * np) + TF_LO_OFF) = lo;
-    }
-  }
-  // backward image: the 16 original rows k0..k0+15 are columns c = k0 % 128 + (0..15) of block k0 / 128; for every kk
-  // they sit at stored columns s with perm(s) = c, i.e. s = 64 (c>>6) + 16 t + i with 4 i + t = c & 63
-  if (bwd && (job.need & HUAL_PACK_B)) {
-    char* img = bwd + job.boff + (size_t)(k0 >> 7) * GB_COLBLOCK;
-    const int cbase = k0 & 127;
-    for (int idx = threadIdx.x; idx < 128 * 8; idx += 256) {
-      const int kk = idx >> 3, pr = idx & 7;          // pair pr: local rows r = 2*? -> stored columns come in pairs (s, s+1)
-      // stored pair (s, s+1) with s even: perm(s) = c, perm(s+1) = c + 4  ->  local rows r and r + 4
-      const int t = pr & 3, ii = pr >> 2;             // r = 4*(2*ii') ...: enumerate r in {0..15} with (r>>2)&1 == 0
-      const int r = t + 8 * ii;                       // r in {0,1,2,3, 8,9,10,11}; partner r + 4
-      const int c = cbase + r;
-      const int s = 64 * (c >> 6) + 16 * (c & 3) + ((c & 63) >> 2);
-      uint32_t hi, lo;
-      f16_split_pair(tile[r][kk] * HUAL_F16_WSCALE, tile[r + 4][kk] * HUAL_F16_WSCALE, hi, lo);
-      *reinterpret_cast<uint32_t*>(img + (size_t)kk * 512 + 2 * s) = hi;
-      *reinterpret_cast<uint32_t*>(img + (size_t)kk * 512 + 256 + 2 * s) = lo;
     }
   }
 }
@@ -592,7 +574,7 @@ void dw_bf16_balanced_kernel(const DwJob* __restrict__ table, int n, DropCfg dro
 
 namespace hual {
 
-int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd, char* bwd,
+int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* boffs, int n, const float* P, char* fwd,
                         hipStream_t stream, const PackExtra* extra, char* timg, char* nimg, const uint8_t* needs) {
   HUAL_REQUIRE(!extra || (extra->lens && extra->word_ids && extra->rowmask && extra->loss_acc && (extra->zero_n % 4) == 0 &&
                           (reinterpret_cast<uintptr_t>(extra->zero_ptr) & 15) == 0), "pack: extra prologue work");
@@ -607,7 +589,7 @@ int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* bof
       nblk += ((Ks[base + i] + 127) & ~127) / 16;
       HUAL_REQUIRE(Ks[base + i] > 0 && (Ks[base + i] % 8) == 0, "pack: K must be a positive multiple of 8");
       b.j[i].off = offs[base + i]; b.j[i].K = Ks[base + i]; b.j[i].boff = boffs ? boffs[base + i] : 0;
-      b.j[i].need = needs ? needs[base + i] : (HUAL_PACK_F | HUAL_PACK_B | HUAL_PACK_T | HUAL_PACK_N);
+      b.j[i].need = needs ? needs[base + i] : (HUAL_PACK_F | HUAL_PACK_T | HUAL_PACK_N);
       const int kp = (Ks[base + i] + 127) & ~127;
       maxK = kp > maxK ? kp : maxK;
       elems += (double)Ks[base + i] * 128;
@@ -621,8 +603,8 @@ int launch_pack_weights(const uint32_t* offs, const int* Ks, const uint32_t* bof
     HUAL_REQUIRE(!(ex.ovf && n > HUAL_MAX_PACK), "pack: the overflow words cover one batch of jobs");
     HUAL_REQUIRE(!ex.ovf || ex.novf >= jrows * gx, "pack: overflow words");
     const int grows = (with_extra && ex.gather_tasks > 0) ? cdiv(ex.gather_tasks, gx * 256) : 0;      // rows of workgroups of the gather
-    HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (bwd ? 4.0 : 0.0)), pack_weights_kernel, dim3(gx, jrows + (with_extra ? 1 + grows : 0)),
-                dim3(256), 0, stream, b, P, fwd, bwd, timg, nimg, cnt, jrows, ex);
+    HUAL_LAUNCH(0.0, elems * (4.0 + (fwd ? 4.0 : 0.0) + (timg ? 4.0 : 0.0) + (nimg ? 4.0 : 0.0)), pack_weights_kernel, dim3(gx, jrows + (with_extra ? 1 + grows : 0)),
+                dim3(256), 0, stream, b, P, fwd, timg, nimg, cnt, jrows, ex);
   }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

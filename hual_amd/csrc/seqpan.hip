@@ -53,13 +53,12 @@ struct Ctx {
   std::vector<ColsumJob> colsum;
   int rc = 0;
   bool static_tables = false;   // hual_run_opts.static_tables
-  int wall_K = 0; uint32_t wall_off = 0, wall_boff = 0;      // packed char-CNN filter bank inside PKF / PKB (setup_ctx)
+  int wall_K = 0; uint32_t wall_off = 0, wall_boff = 0;      // packed char-CNN filter bank inside PKT / PKN (setup_ctx)
   struct DenseW { size_t off; int K; size_t boff; uint8_t need; };      // need: HUAL_PACK_* images the kernels read of this weight
   bool ksplit = false;                // feature-load phase on the K-split kernel (plan)
   typedef DenseW DenseW_t;
   std::vector<DenseW> dense;          // every [K,128] weight of the graph, sorted by offset
-  char* PKF = nullptr;                // pre-split images (gemm.h launch_pack_weights): forward ...
-  char* PKB = nullptr;                // ... and of the transposed weights, for dX
+  char* PKF = nullptr;                // pre-split LDS images (gemm.h launch_pack_weights) of the feature-load kernel's weights
   char* PKT = nullptr;                // images for the register-resident weights of the T-form kernels (tilecore.h): W^T blocks (forward) ...
   char* PKN = nullptr;                // ... and W blocks (dX), 64 KB per 128 contraction indices, at DenseW::boff
   const float* timg(size_t off, int blk = 0) const { return reinterpret_cast<const float*>(PKT + boff_of(off) + (size_t)blk * 65536); }
@@ -235,8 +234,8 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
     const ParamMap& pm = c.pm;
     const int D = HUAL_D, catw = cfg->word_dim + 100;
     c.dense.clear();
-    // which images of a weight the kernels read: F / B - forward and dX products of the LDS-DMA kernels (fused row-local chains,
-    // K-split feature load); T / N - the same two for the register-resident weights of mproj (gemm.h HUAL_PACK_*)
+    // which images of a weight the kernels read: F - the LDS-DMA image of the K-split feature load; T / N - forward and dX products
+    // with register-resident weights: every other dense kernel (gemm.h HUAL_PACK_*, tilecore.h)
     const uint8_t TN = HUAL_PACK_T | HUAL_PACK_N;
     auto add = [&](size_t off, int K, uint8_t need) { if (K % 8 == 0) c.dense.push_back({off, K, off * 4, need}); };
     const int qks = ((catw + 3) / 4 + 63) & ~63;        // quarter size of query_conv1d's K (multiple of 64)
@@ -245,7 +244,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
     add(pm.qconv.k, catw, (c.ksplit ? HUAL_PACK_F : HUAL_PACK_T) | HUAL_PACK_N);
     add(pm.shid.k, 2 * D, TN); add(pm.ehid.k, 2 * D, TN);
     add(pm.fe_dense.k, D, TN); add(pm.fe_q.k, D, TN); add(pm.fe_k.k, D, TN); add(pm.fe_v.k, D, TN);
-    for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D, HUAL_PACK_T | HUAL_PACK_B); add(pm.cb.pw[i], D, HUAL_PACK_T | HUAL_PACK_B); }
+    for (int i = 0; i < 4; ++i) { add(pm.fe_cb.pw[i], D, TN); add(pm.cb.pw[i], D, TN); }
     add(pm.cqcat.k, 2 * D, TN); add(pm.cq[0].dense, 4 * D, TN); add(pm.cq[1].dense, 4 * D, TN);
     for (int li = 0; li < cfg->attn_layer; ++li) {
       const DualAttnP& d = pm.da[li];
@@ -261,8 +260,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
     extra = (extra + 255) & ~(size_t)255;
     for (auto& d : c.dense)
       if (d.K % 128) { d.boff = extra; extra += (size_t)((d.K + 127) / 128) * HUAL_PACK_BLOCK_BYTES; }
-    // the packed char-CNN filter bank Wall [4 CP, 128] (embed.hip): forward image at PKF + wall_off * 4, image of its
-    // transpose at PKB + wall_boff - the same byte offset in both buffers
+    // the packed char-CNN filter bank Wall [4 CP, 128] (embed.hip): T image at PKT + wall_boff, N image at PKN + wall_boff
     c.wall_K = 4 * embed_cpad(cfg->char_dim);
     c.wall_off = (uint32_t)(extra / 4);
     c.wall_boff = (uint32_t)extra;
@@ -323,7 +321,7 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
       const std::string is = std::to_string(i);
       CbLayerBwd& L = a.l[i];
       L.ln_g = c.p(cp.ln[i].g); L.ln_b = c.p(cp.ln[i].b); L.dw = c.p(cp.dw[i]);
-      L.wimg_t = reinterpret_cast<const float*>(c.PKB + cp.pw[i] * 4);
+      L.wimg_t = c.nimg(cp.pw[i]);      // N image: conv_block_bwd_kernel keeps its weights in registers
       L.x = i == 0 ? x0 : c.buf(tag + ".x" + is, R, HUAL_D);
       L.mean = c.buf(tag + ".mean" + is, R, 1); L.rstd = c.buf(tag + ".rstd" + is, R, 1);
       L.relu_prev = i > 0 ? c.bits(tag + ".rb" + std::to_string(i - 1), R) : nullptr;
@@ -360,7 +358,6 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   // ---------------- prologue: row masks (model.py:31-32), cleared loss accumulators, pre-split images of every dense weight for
   // the split kernels (weights are constant within a step) and - hual_run_opts.grads_prezero - the gradient buffer zeroed: ONE launch
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
-  c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
   c.PKT = reinterpret_cast<char*>(c.buf("params.pkt", (c.pk_bytes + 3) / 4, 1));
   c.PKN = reinterpret_cast<char*>(c.buf("params.pkn", (c.pk_bytes + 3) / 4, 1));
   float* ortho_dE = c.buf("ortho.dE", 4, HUAL_D);
@@ -396,7 +393,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     ex.gather_rows = Nq; ex.emb = ea; ex.drop = c.drop;
     ex.wall_K = c.wall_K; ex.wall_off = c.wall_off; ex.wall_boff = c.wall_boff;
     if (c.novf) { ex.ovf = ovf; ex.novf = c.novf; }
-    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.want_bwd ? c.PKB : nullptr, c.stream, &ex,
+    c.chk(launch_pack_weights(offs.data(), Ks.data(), boffs.data(), (int)offs.size(), c.P, c.PKF, c.stream, &ex,
                               c.PKT, c.want_bwd ? c.PKN : nullptr, needs.data()));
     if (opt->prezero_token) *opt->prezero_token = (ex.zero_ptr && c.ok()) ? (uint64_t)(uintptr_t)ex.zero_ptr : 0;      // the receipt
   }
@@ -735,9 +732,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     if (!c.dry && opt->prezero_token) *opt->prezero_token = 0;
     if (c.live() && !prezeroed) c.chk(launch_zero(c.G, pm.total, c.stream));
   }
-  // every dX product reads the image of the transposed weight that forward's pack launch left in the workspace (PKB)
+  // every dX product reads the N image that forward's pack launch left in the workspace (PKN)
   c.PKF = reinterpret_cast<char*>(c.buf("params.pkf", (c.pk_bytes + 3) / 4, 1));
-  c.PKB = reinterpret_cast<char*>(c.buf("params.pkb", (c.pk_bytes + 3) / 4, 1));
   c.PKT = reinterpret_cast<char*>(c.buf("params.pkt", (c.pk_bytes + 3) / 4, 1));
   c.PKN = reinterpret_cast<char*>(c.buf("params.pkn", (c.pk_bytes + 3) / 4, 1));
   float* outputs = c.actv("outputs");

@@ -36,9 +36,6 @@ static __device__ unsigned long long g_hual_stamps[512 * HUAL_STAMP_SLOTS];     
 
 #define LN_EPS 1e-6f   // models/layers.py:15
 #define CB_THREADS 512
-#define CB_TILE 16384            // one [64][128 x 16 bit] tile
-#define CB_STAGE (2 * CB_TILE)   // hi + lo tile of 64 K rows
-#define CB_WBYTES (2 * CB_STAGE) // a whole [128,128] weight image
 
 __device__ __forceinline__ float4 cb_fma(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
@@ -135,64 +132,6 @@ __device__ __forceinline__ void cb_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-}
-
-// One LDS-DMA piece (global_load_lds_dwordx4: 64 lanes x 16 bytes -> 1 KB of LDS at the wave-uniform byte address `lds`),
-// issued from inline asm so that hipcc does not know about the pending LDS write.  With the builtin the compiler keeps a
-// DMA in flight "visible" to its wait insertion: every LDS read that may alias the destination and every __syncthreads()
-// is preceded by s_waitcnt vmcnt(0), which drains the DMA (and every store issued before it) at the first LDS access of
-// the phase the DMA was meant to run under.  The callers wait explicitly (s_waitcnt vmcnt(0) + barrier) before the
-// first read of the image (cdna_hip_programming.md 5.7: M0 is written in the same statement that uses it).
-__device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds)
-               : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
-  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(const char*)p;
-}
-
-// LDS-DMA of one [128,128] weight image (pack_weights_kernel layout: per K row 256 B of fp16 high parts, 256 B of
-// residuals) into two stages of {hi tile, lo tile}; the XOR swizzle of tile256_off is applied on the global side.
-// All 8 waves of the workgroup take part, 8 pieces of 1 KB (4 tile rows) each: wave w, piece k is tile row group
-// w + 8 (k & 1) of plane (k >> 1) & 1 of stage k >> 2, so the swizzle term of a lane ((row >> 2) & 3 = w & 3) and with it
-// the lane's byte offset are the same for all 8 pieces - one pointer per lane, compile-time strides per piece.
-__device__ __forceinline__ void cb_dma_weight(const float* wimg, char* Wl, int wave, int lane, int nwaves) {
-  (void)nwaves;                                       // CB_THREADS / 64 = 8 at every call site
-  const int chp = lane & 15, rr = lane >> 4;
-  const char* lp = reinterpret_cast<const char*>(wimg) + 2048 * wave + 512 * rr + 16 * (chp ^ ((rr << 2) | (wave & 3)));
-  const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds_addr_of(Wl) + 1024u * (uint32_t)wave);
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    glds16_asm(lp + (32768 * (k >> 2) + 16384 * (k & 1) + 256 * ((k >> 1) & 1)), ldsw + (uint32_t)(CB_STAGE * (k >> 2) + 8192 * (k & 3)));
-}
-
-// 16 x 64 output tile of A[16 rows of the LDS planes] . W: wave-level, accumulators in the column order of the epilogue
-// (accumulator t, register r, lane (j, g) = row 4g + r, column 64 ch + 4j + t).  The instruction stream is written out by
-// scripts/gen_tile_mma.py (software-pipelined LDS reads under the MFMAs; same summation order as the plain loop:
-// k-step major, hi.hi + hi.lo + lo.hi per 32-deep step).  ALO = byte distance from the hi to the lo operand plane.
-#include "tile_mma_asm.inc"
-template <int ALO>
-__device__ __forceinline__ void cb_tile_mma_t(const char* Ahi, const char* Wl, int mt, int ch, int lane, f32x4 (&acc)[4]) {
-  const int j = lane & 15, g = lane >> 4;
-  const int tq = (lane >> 2) & 3, tp = lane & 3;
-  const uint32_t ab = lds_addr_of(Ahi), wb = lds_addr_of(Wl);
-  uint32_t aa[4], wa[8];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) aa[ks] = ab + (uint32_t)tile256_off(16 * mt + j, 4 * ks + g);
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-      wa[2 * t + d] = wb + (uint32_t)(tile256_off(8 * g + tq + 4 * d, 8 * ch + 2 * t + (tp >> 1)) + 8 * (tp & 1));
-  asm volatile(CB_TILE_MMA_TEXT
-               : [c0] "=&v"(acc[0]), [c1] "=&v"(acc[1]), [c2] "=&v"(acc[2]), [c3] "=&v"(acc[3])
-               : [a0] "v"(aa[0]), [a1] "v"(aa[1]), [a2] "v"(aa[2]), [a3] "v"(aa[3]),
-                 [w00] "v"(wa[0]), [w01] "v"(wa[1]), [w10] "v"(wa[2]), [w11] "v"(wa[3]),
-                 [w20] "v"(wa[4]), [w21] "v"(wa[5]), [w30] "v"(wa[6]), [w31] "v"(wa[7]), [alo] "i"(ALO)
-               : "memory", CB_TILE_MMA_CLOBBERS);
 }
 
 // ---- "T-form" tile product: register-resident weights -----------------------------------------------------------------
