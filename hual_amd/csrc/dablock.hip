@@ -300,6 +300,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   fold(SV, ainv0, true);
   tf_load_w(wa, a.w[2], wave, lane);
   tf_mma_lean<NT, DP_PLANE>(P1, wb, lane, accp);
+  tf_load_w(wb, a.w[3], wave, lane);                   // (requests go in front of the epilogue's stores, here and below)
   fold(XV, ainv1, true);
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) {
@@ -312,7 +313,6 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   zero_invalid(XV);
   put_max(smaxA, SV);
   put_max(smaxB, XV);
-  tf_load_w(wb, a.w[3], wave, lane);
   cb_barrier();
   put_planes(P2, ainv2, smaxA, SV);
   put_planes(P0, ainv0, smaxB, XV);
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   fold(T1, ainv2, true);
   tf_load_w(wa, a.w[4], wave, lane);
   tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
+  tf_load_w(wb, a.w[5], wave, lane);
   fold(T2, ainv0, true);
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) {
@@ -333,18 +334,17 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   }
   zero_invalid(T1);
   put_max(smaxA, T1);
-  tf_load_w(wb, a.w[5], wave, lane);
   cb_barrier();
   put_planes(P1, ainv1, smaxA, T1);
   cb_barrier();
   // ---- guided dense (layers.py:104)
   tf_mma_lean<NT, DP_PLANE>(P1, wa, lane, accp);
+  tf_load_w(wa, a.w[6], wave, lane);
   fold(T1, ainv1, true);
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) { T1[rt] = addb(T1[rt], 4); save_nt(a.gd, rt, T1[rt]); }
   zero_invalid(T1);
   put_max(smaxA, T1);
-  tf_load_w(wa, a.w[6], wave, lane);
   // RP1: the layer-normed input (ln1) -> slot 0 (free since the x_gate product: two barriers ago)
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -368,6 +368,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   fold(T2, ainv0, true);
   tf_load_w(wb, a.w[9], wave, lane);
   tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
+  tf_load_w(wa, a.w[10], wave, lane);
   fold(T2, ainv2, false);
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) {
@@ -381,7 +382,6 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   }
   zero_invalid(T1);
   put_max(smaxA, T1);
-  tf_load_w(wa, a.w[10], wave, lane);
   cb_barrier();
   put_planes(P1, ainv1, smaxA, T1);
   cb_barrier();
@@ -774,6 +774,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   tile_ld(a.val, U2);
   cb_barrier();
   tf_mma_lean<NT, DP_PLANE>(P1, wa, lane, accp);
+  tf_load_w(wa, a.w[2], wave, lane);                   // (requests go in front of the epilogue's stores, here and below)
   fold(T1, ainv1, true);
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) {
@@ -788,7 +789,6 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   zero_invalid(T2);
   put_max(smaxA, T1);
   put_max(smaxB, T2);
-  tf_load_w(wa, a.w[2], wave, lane);
   cb_barrier();
   put_planes(P0, ainv0, smaxA, T1);
   put_planes(P2, ainv2, smaxB, T2);
@@ -798,30 +798,32 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   fold(T1, ainv0, true);
   tf_load_w(wb, a.w[3], wave, lane);
   tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
-  fold(T1, ainv2, false);
-#pragma unroll
-  for (int rt = 0; rt < NT; ++rt) save(a.d_ln1a, rt, T1[rt]);
+  fold(T1, ainv2, false);                              // d ln1a: stored below, BEHIND the loads of the next phase (the vector-memory
+                                                       // pipe is in order: requests issued behind stores wait for the stores' turn)
   // ---- gradient of the guided features: d scores . W12^T + d values . W22^T
   tf_load_w(wa, a.w[4], wave, lane);
   tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
-  fold(T1, ainv0, true);
+  fold(T2, ainv0, true);
   tf_load_w(wb, a.w[5], wave, lane);
   tile_ld(a.sg, U1);
   tile_ld(a.xg, U2);
   tile_ld(a.sv, U3);
   tile_ld(a.xv, U4);
-  tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
-  fold(T1, ainv2, false);
 #pragma unroll
-  for (int rt = 0; rt < NT; ++rt) save_nt(a.d_g, rt, T1[rt]);
-  zero_invalid(T1);
-  put_max(smaxA, T1);
+  for (int rt = 0; rt < NT; ++rt) save(a.d_ln1a, rt, T1[rt]);
+  tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
+  fold(T2, ainv2, false);
   tf_load_w(wa, a.w[6], wave, lane);
+#pragma unroll
+  for (int rt = 0; rt < NT; ++rt) save_nt(a.d_g, rt, T2[rt]);
+  zero_invalid(T2);
+  put_max(smaxA, T2);
   cb_barrier();
-  put_planes(P1, ainv1, smaxA, T1);
+  put_planes(P1, ainv1, smaxA, T2);
   cb_barrier();
   // ---- d o = d g . Wg^T ; cross gating backward (layers.py:96-103): o = sg * x + xg * s
   tf_mma_lean<NT, DP_PLANE>(P1, wb, lane, accp);
+  tf_load_w(wb, a.w[7], wave, lane);
   fold(T1, ainv1, true);
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) {
@@ -839,7 +841,6 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   zero_invalid(T2);
   put_max(smaxA, T1);
   put_max(smaxB, T2);
-  tf_load_w(wb, a.w[7], wave, lane);
   cb_barrier();
   put_planes(P0, ainv0, smaxA, T1);
   put_planes(P2, ainv2, smaxB, T2);
@@ -849,6 +850,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   fold(T1, ainv0, true);
   tf_load_w(wa, a.w[8], wave, lane);
   tf_mma_lean<NT, DP_PLANE>(P2, wb, lane, accp);
+  tf_load_w(wb, a.w[9], wave, lane);
   fold(T2, ainv2, true);
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) {
@@ -861,7 +863,6 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   zero_invalid(T2);
   put_max(smaxA, T1);
   put_max(smaxB, T2);
-  tf_load_w(wb, a.w[9], wave, lane);
   cb_barrier();
   put_planes(P1, ainv1, smaxA, T1);
   put_planes(P0, ainv0, smaxB, T2);
