@@ -77,6 +77,13 @@ def test_two_row_tile_shape():
     _check_all(case, 0.2)
 
 
+def test_four_row_tile_shape():
+    """R = 64 (256 + 20) = 17664 rows: more than 256 workgroups of the largest tile everywhere - ln_proj_kernel<4> (64 rows per
+    workgroup, four row tiles), the 48-row kernels (da_post / da_mid_bwd / ln_proj_bwd <3>) in two rounds of workgroups"""
+    case = pu.make_case(B=64, T=256, L=20, C=8, seed=1357, max_vlen=256, vdim=512)
+    _check_all(case, 0.2)
+
+
 def test_c1_shape():
     """BASELINE.json configs[0]: B=16, T=64, 'D=512' read as vdim=512, dropout 0.2"""
     case = pu.make_case(B=16, T=64, L=20, C=8, seed=777, max_vlen=64, vdim=512)
