@@ -43,6 +43,7 @@ FEATURE_LOAD_KERNEL = 'feature_ksplit_kernel'
 PIPE_NAMES = {0: 'none', 1: 'fp32 matrix (v_mfma_f32_*_f32)', 2: '16-bit matrix (v_mfma_f32_*_f16 / _bf16), split operands'}
 CLOCK_MHZ = 2400.0                # MI355X_MICROARCH.md: engine clock, for cycles <-> microseconds of the SQ counter figures
 N_SIMD = 1024                     # 256 CUs x 4 SIMDs
+DEFAULT_SHAPE_KEY = 'B64 T128 L20 C8 vdim1024 drop0.2 f32'
 
 
 def mfma_peak(kernel):
@@ -61,24 +62,30 @@ def _sq_file():
     return fs[-1] if fs else None
 
 
-def sq_figures(kernel, avg_launch_us):
+def sq_figures(kernel, avg_launch_us, shape_key=None):
     """committed SQ counter figures of `kernel` (newest profiles/r*_pmc_sq_counters.txt, scripts/profile_round.sh step 4):
-    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES per SIMD / cycles of a launch, wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES"""
+    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES per SIMD / cycles of a launch, wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES.
+    The table is keyed by the FULL kernel name (template arguments included: ln_proj_kernel<2> and <3> are different kernels) and
+    is only used when the profile was taken at this run's shape (the file's '# shape:' line; files without one are the default
+    bench shape)."""
     f = _sq_file()
     if not f:
         return None
-    cur, tab = None, {}
+    cur, tab, shape = None, {}, DEFAULT_SHAPE_KEY
     for line in open(f):
-        if line and not line[0].isspace():
-            cur = line.split()[0].split('<')[0]
+        if line.startswith('# shape:'):
+            shape = line.split(':', 1)[1].strip()
+        elif line and not line[0].isspace() and 'dispatches' in line:
+            cur = line[:line.rindex('dispatches')].strip()
             tab[cur] = {}
         elif cur and 'mean' in line:
             w = line.split()
             tab[cur][w[0]] = float(w[2])
-    key = kernel.split('<')[0]
-    if key not in tab or 'SQ_WAVE_CYCLES' not in tab[key]:
+    if shape_key is not None and shape_key != shape:
         return None
-    t = tab[key]
+    if kernel not in tab or 'SQ_WAVE_CYCLES' not in tab[kernel]:
+        return None
+    t = tab[kernel]
     return dict(mfma_busy_frac=round(t['SQ_VALU_MFMA_BUSY_CYCLES'] / N_SIMD / (avg_launch_us * CLOCK_MHZ), 4),
                 wait_frac=round(t['SQ_WAIT_ANY'] / t['SQ_WAVE_CYCLES'], 3), sq_source='profiles/' + os.path.basename(f))
 
@@ -124,6 +131,8 @@ def cpu_baseline(seconds_budget=20.0):
     # time one step at each candidate count up to ALL affinity cores and keep the fastest (the scan is reported)
     # (ascending; the scan stops at the first count that is clearly slower than the best so far - oversubscribed counts take many
     #  seconds per step - and every candidate prints a progress line: a silent bench is taken for a hung one)
+    # (R.train_step returns NEW parameter / slot dicts and never writes into the ones passed in - tests/test_oracle.py - so the
+    #  discarded warm-up and scan steps leave p, m, v at their initial values: round 3's trajectory started from leaked slots)
     scan = {}
     torch.set_num_threads(max(1, min(ncores, 16)))
     R.train_step(p, m, v, cfg, wv, batch, labels, 1e-4, 0.2, seed=1, offset=0)          # warm-up (result discarded)
@@ -153,8 +162,19 @@ def cpu_baseline(seconds_budget=20.0):
     out = dict(value=round(16 * n / dt, 2), unit='clips/s', cores=best, kind='port',
                sample='%d train steps (fwd+bwd+AdamWD, dropout 0.2) of the PyTorch-CPU oracle at B16 T64 vdim1024 L20 fp32, %.1f s'
                       % (n, dt), affinity_cores=ncores, seconds_per_step_by_threads=scan)
-    # the same n steps from the same initial parameters, batch and dropout stream on the GPU: losses side by side (two float32
-    # implementations under AdamWeightDecay-without-bias-correction separate by ~1.3-1.6x per step, tests/test_gpu_train.py)
+    # the float64 oracle's first ten losses from the same clean start (untimed): the yardstick both float32 paths are read against
+    k64 = min(n, 10)
+    p64 = {k: t.double() for k, t in p0.items()}
+    m64 = {k: torch.zeros_like(t) for k, t in p64.items()}
+    v64 = {k: torch.zeros_like(t) for k, t in p64.items()}
+    b64 = (batch[0].double(), batch[1], batch[2], batch[3])
+    l64 = tuple(x.double() if x.dtype.is_floating_point else x for x in labels)
+    losses64 = []
+    for s64 in range(k64):
+        p64, m64, v64, info = R.train_step(p64, m64, v64, cfg, wv.double(), b64, l64, 1e-4, 0.2, seed=1, offset=s64 + 1)
+        losses64.append(float(info['loss']))
+    print('[bench] cpu baseline: float64 oracle trajectory done', file=sys.stderr, flush=True)
+    # the same n steps from the same initial parameters, ZERO Adam slots, batch and dropout stream on the GPU: losses side by side
     try:
         from hual_amd import lib
         from hual_amd.model import SeqPAN
@@ -172,10 +192,15 @@ def cpu_baseline(seconds_budget=20.0):
             tt.step(lr=1e-4, drop_rate=0.2)
             hl.append(float(tt.last_loss()))
         k = min(n, 10)
+        rel = lambda xs, ys: round(max(abs(a - c) / max(abs(a), 1.0) for a, c in zip(xs, ys)), 7)
         out['loss_trajectory'] = dict(steps=n, oracle_first=[round(x, 4) for x in losses[:k]], hip_first=[round(x, 4) for x in hl[:k]],
+                                      oracle_f64_first=[round(x, 4) for x in losses64[:k]],
                                       oracle_final=round(losses[-1], 4), hip_final=round(hl[-1], 4),
-                                      max_rel_diff_first=round(max(abs(a - c) / max(abs(a), 1.0) for a, c in zip(losses[:k], hl[:k])), 6),
-                                      note='free-running: own parameters and Adam slots on each side, shared dropout stream')
+                                      max_rel_diff_first=rel(losses[:k], hl[:k]),
+                                      max_rel_diff_first_hip_vs_f64=rel(losses64[:k], hl[:k]),
+                                      max_rel_diff_first_f32_oracle_vs_f64=rel(losses64[:k], losses[:k]),
+                                      note='free-running from the same parameters and zero Adam slots: own state on each side, '
+                                           'shared dropout stream')
     except Exception as e:      # never cost the bench line
         out['loss_trajectory'] = dict(error=str(e)[:200])
     # the metric's second half, "R@1 IoU=0.5": no real features exist here, so it is reported as agreement - the
@@ -350,6 +375,8 @@ def main():
         except (OSError, ValueError):
             tr_tab = {}
 
+        shape_key = 'B%d T%d L%d C%d vdim%d drop%.1f %s' % (args.batch, args.T, args.L, args.C, args.vdim, args.drop, args.video_dtype)
+
         def roof_of(top):
             # which roof bounds a kernel: arithmetic intensity of its launches (algorithmic FLOPs / algorithmic bytes, both
             # summed by the launch wrappers) against the ridge of the pipe it runs on.  A [M,128]x[128,128] fp32-in/out
@@ -373,7 +400,7 @@ def main():
                 roof.update(algorithmic_tflops=round(tflops, 2), mfma_pipe=PIPE_NAMES[pipe], mfma_pipe_peak_tflops=peak,
                             mfma_passes=passes, mfma_issue_frac=round(passes * tflops / peak, 4),
                             frac_of_fp32_matrix_peak=round(tflops / PEAK_F32_MATRIX_TFLOPS, 4))
-            sq = sq_figures(top['kernel'], top['us'] / top['launches'])
+            sq = sq_figures(top['kernel'], top['us'] / top['launches'], shape_key)
             if sq:
                 roof.update(sq)
             # HBM traffic of that kernel: rocprofv3 PMC passes cannot run inside this process, so the per-launch figure is
@@ -413,7 +440,7 @@ def main():
                        frac=round(tf / peak, 4), mfma_pipe=PIPE_NAMES[pipe], mfma_passes=passes,
                        mfma_issue_frac=round(passes * tf / peak, 4), frac_of_fp32_matrix_peak=round(tf / PEAK_F32_MATRIX_TFLOPS, 4),
                        us_per_step=round(d['us'] / psteps, 1))
-            sq = sq_figures(d['kernel'], d['us'] / d['launches'])
+            sq = sq_figures(d['kernel'], d['us'] / d['launches'], shape_key)
             if sq:
                 row.update(sq)
             return row
@@ -461,7 +488,7 @@ def main():
                                             peak_is='fp32-matrix peak (a pipe this kernel does not use; kept for continuity)',
                                             mfma_pipe=PIPE_NAMES[2], mfma_passes=3,
                                             mfma_issue_frac=round(3 * tf_h / PEAK_BF16_MATRIX_TFLOPS, 4))
-            sq = sq_figures('attn_fwd_wide_kernel', us_h)
+            sq = sq_figures('attn_fwd_wide_kernel<8>', us_h, shape_key)
             if sq:
                 roof['attention_head64'].update(sq)
         except Exception as ex:                                  # (a demonstration leg: never fails the bench line)

@@ -620,7 +620,9 @@ int launch_attn_bwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
   HUAL_REQUIRE(lds <= 160 * 1024, "attn bwd: LDS footprint");
   HUAL_DYN_LDS(attn_bwd_kernel, 160 * 1024);
   dim3 grid(maxB * 8 * n), block(256);
-  HUAL_LAUNCH(5.0 * flops, 0.0, attn_bwd_kernel, grid, block, lds, s, b, n, drop);      // S, dP, dV, dK, dQ: computed once each
+  // algorithmic work of the backward: FOUR products (dP = dO.V^T, dV = P^T.dO, dK = dS^T.Q, dQ = dS.K) = 8.B.H.Tq.Tk.16; the
+  // recomputation of S = Q.K^T is the kernel's choice (it saves storing P) and is not counted
+  HUAL_LAUNCH(4.0 * flops, 0.0, attn_bwd_kernel, grid, block, lds, s, b, n, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -59,13 +59,30 @@ def global_count(local_count, device):
     return float(t.item())
 
 
-def global_max(local_value):
-    """max of a python integer over ranks (host collective: set_batch's shape check)"""
-    t = torch.tensor([int(local_value)], dtype=torch.int64)
+def check_padded_length(local_longest, T):
+    """Data-parallel shape contract of Trainer.set_batch: every shard is padded to the longest clip of the GLOBAL batch
+    (model.py:31 pads to the batch maximum and the reference's conv_block does not mask, modules.py:59-70, so the results depend on the
+    padded length).  ONE host collective returns the longest clip and the largest / smallest padded length over ranks: every rank
+    sees the same verdict and they raise TOGETHER (a rank raising alone would leave the others waiting in the next collective)."""
+    t = torch.tensor([int(local_longest), int(T), -int(T)], dtype=torch.int64)
     if world_size() > 1:
         if dist.get_backend() == 'nccl':
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    gmax, tmax, tmin = (int(x) for x in t.tolist())
+    if tmax != -tmin or gmax != tmax:
+        raise ValueError('data parallel: every shard must be padded to the longest clip of the GLOBAL batch (%d); padded lengths '
+                         'over ranks span %d..%d, this rank has T = %d - model.py:31' % (gmax, -tmin, tmax, T))
+    return gmax
+
+
+def global_min(local_value):
+    """min of a python integer over ranks (the collective graph-or-eager decision of Trainer._step_dp)"""
+    t = torch.tensor([int(local_value)], dtype=torch.int64)
+    if world_size() > 1:
+        if dist.get_backend() == 'nccl':
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return int(t.item())
 
 

@@ -42,9 +42,7 @@ class Trainer:
         if int(np.max(lens)) != T and not (self.dp and int(np.max(lens)) < T):
             raise ValueError('video T must equal max(video_seq_len) - model.py:31')
         if self.dp and os.environ.get('HUAL_DP_SKIP_T_CHECK') != '1':
-            gmax = hdist.global_max(int(np.max(lens)))      # a shard padded beyond the global longest clip no longer reproduces model.py:31
-            if gmax != T:
-                raise ValueError('data parallel: T (%d) must equal the longest clip of the GLOBAL batch (%d) - model.py:31' % (T, gmax))
+            hdist.check_padded_length(int(np.max(lens)), T)      # raises on EVERY rank together
         shape = (B, T, L, C, video_dtype)
         if shape != self.shape:
             self.shape = shape
@@ -222,11 +220,16 @@ class Trainer:
         m.global_step += 1
 
     def _step_dp(self, drop_rate):
-        """With the nccl backend (RCCL: its collectives are stream operations) the data-parallel step, collectives included, is
-        captured once into a hipGraph and replayed; HUAL_DP_GRAPH=0 or a failed capture falls back to the eager launch of the
-        same sequence (the failed capture has executed nothing: the step then runs eagerly from the restored state).  Other
-        backends (gloo: host collectives) always launch eagerly."""
-        want_graph = (os.environ.get('HUAL_DP_GRAPH', '1') != '0' and self.dp_graph and not self._dp_graph_failed
+        """With the nccl backend (RCCL: its collectives are stream operations) the data-parallel step, collectives included, CAN be
+        captured once into a hipGraph and replayed.  That is the default only on ONE rank (the forced-collectives rehearsal the GPU
+        suite runs); with more than one rank it is opt-in (HUAL_DP_GRAPH=1) until a multi-GPU run has validated capture and replay
+        of the all-gather / all-reduce pair - no such run exists yet - and the eager launch of the same sequence is
+        used: 60 launches per 1.2 ms step leave the host far ahead of the device.  The graph-or-eager decision is COLLECTIVE: after
+        the capture attempt the ranks all-reduce(MIN) an ok flag, so either every rank replays or every rank launches eagerly.  Only a
+        refused capture (a RuntimeError from torch / HIP) is treated as "no graph"; an error raised by one of our own launches
+        (lib.HualError) propagates.  Other backends (gloo: host collectives) always launch eagerly."""
+        default = '1' if self.world == 1 else '0'
+        want_graph = (os.environ.get('HUAL_DP_GRAPH', default) != '0' and self.dp_graph and not self._dp_graph_failed
                       and hdist.backend() == 'nccl')
         if not want_graph:
             self._enqueue_dp(drop_rate)
@@ -239,16 +242,23 @@ class Trainer:
             for t, sn in zip((m.params, m.adam_m, m.adam_v, m.rng_state), snap):
                 t.copy_(sn)
             torch.cuda.synchronize()
+            g, err = None, None
             try:
                 g = torch.cuda.CUDAGraph()
                 # thread_local: the process group's watchdog thread may touch the device while this thread captures
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._enqueue_dp(drop_rate)
-            except Exception as e:                   # capture of the collectives refused: eager from here on
+            except lib.HualError:                    # one of our launches failed: not a capture refusal
+                raise
+            except RuntimeError as e:                # capture of the collectives refused
+                g, err = None, e
+                torch.cuda.synchronize()
+            ok = hdist.global_min(1 if g is not None else 0)     # same path on every rank
+            if not ok:
                 self._dp_graph_failed = True
                 self.graph = None
-                torch.cuda.synchronize()
-                print('[hual] data-parallel step: graph capture failed (%s) - eager launches' % (str(e).splitlines()[0],), file=sys.stderr)
+                print('[hual] data-parallel step: graph capture %s - eager launches on every rank'
+                      % ('failed here (%s)' % str(err).splitlines()[0] if err is not None else 'failed on another rank'), file=sys.stderr)
                 self._enqueue_dp(drop_rate)
                 return
             self.graph, self.graph_drop = g, drop_rate

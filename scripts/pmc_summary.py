@@ -18,7 +18,7 @@ for name in sorted(rows):
         continue
     c = rows[name]
     n = max(len(v) for v in c.values())
-    print('%-46s dispatches %d' % (name[:46], n))
+    print('%-46s dispatches %d' % (name, n))
     for k in sorted(c):
         v = c[k]
         print('    %-32s mean %14.1f   sum %16.0f' % (k, sum(v) / len(v), sum(v)))

@@ -79,3 +79,39 @@ def test_two_rank_gradient_equals_single_process():
         off += sz
         r = ref_grads[k].numpy()
         assert np.abs(g - r).max() <= 2e-4 * max(1.0, np.abs(r).max()), k
+
+
+def _shape_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hual_amd import dist as hdist
+    res = []
+    # (longest local clip, padded T) per rank: consistent; rank 1 padded further than rank 0; nobody reaches the padded length
+    for longest, T in (((9, 14), (14, 14)), ((14, 14), (12, 16)), ((10, 14), (11, 14))):
+        try:
+            res.append(('ok', hdist.check_padded_length(longest[rank], T[rank])))
+        except ValueError:
+            res.append(('raised', None))
+    res.append(('min', hdist.global_min(1 if rank == 0 else 0)))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shape_check_and_graph_decision_are_collective():
+    """hual_amd/dist.py check_padded_length / global_min with 2 gloo ranks: a shape mismatch raises on BOTH ranks (neither is left
+    waiting in the next collective), and the graph-or-eager decision of Trainer._step_dp is the minimum over ranks"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_shape_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr_ in procs:
+        pr_.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for pr_ in procs:
+        pr_.join(timeout=60)
+        assert pr_.exitcode == 0
+    for r in range(2):
+        assert got[r] == [('ok', 14), ('raised', None), ('raised', None), ('min', 0)], got

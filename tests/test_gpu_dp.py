@@ -65,34 +65,45 @@ def test_dp_step_captured_as_graph_matches_eager(rccl_group, monkeypatch):
 
 
 def test_dp_path_on_one_rank_matches_single_path(rccl_group):
+    """single path vs data-parallel path (1-rank RCCL group), two steps.  Step 2 restarts BOTH paths from the single path's
+    parameters, Adam slots and dropout counter: the forwards are then identical (no atomics in the forward: same ReLU sets, same
+    masks) and the gradients are compared PER TENSOR, element by element - a wrong small tensor (a bias, a layer-norm or
+    label-embedding gradient, a missing column part of d v_hat) cannot hide in a global norm."""
     from hual_amd.train import Trainer
-    if True:
-        cfg, p, wv, b, labels = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
-        feeds = (b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(),
-                 *[x.numpy() for x in labels])
-        out = []
-        for force_dp in (False, True):
-            m = pu.hip_model(cfg, p, wv)
-            m.set_rng(7, 3)
-            tr = Trainer(m, world=1, use_graph=False, force_dp=force_dp)
-            tr.set_batch(*feeds)
-            losses, grads = [], []
-            for _ in range(2):
-                tr.step(lr=1e-4, drop_rate=0.2)
-                losses.append(float(tr.last_loss()))
-                grads.append(m.grads.detach().cpu().numpy().copy())
-            out.append((losses, m.params.detach().cpu().numpy().copy(), grads))
-        (l0, p0, g0), (l1, p1, g1) = out
-        np.testing.assert_allclose(l0[:1], l1[:1], rtol=1e-5, atol=1e-5)
-        # step 1: same weights, same masks - the two paths differ by the summation order of the alignment loss and of the float atomics
-        assert np.abs(g0[0] - g1[0]).max() <= 1e-4 * max(1.0, np.abs(g0[0]).max())
-        # step 2 starts from weights that Adam (no bias correction: the first update is ~lr * 3.16 * sign-like) moved by
-        # amounts that depend on rounding where a gradient is ~0, so its loss agrees to ~1e-5 relative, not to the last bits - and
-        # now and then (about one run in twenty) a ReLU unit within rounding of its kink flips between the two paths, which moves
-        # single gradient entries by O(0.1): the step-2 gradients are compared in norm
-        np.testing.assert_allclose(l0[1:], l1[1:], rtol=2e-4, atol=2e-4)
-        assert np.linalg.norm(g0[1] - g1[1]) <= 1e-2 * np.linalg.norm(g0[1])
-        assert np.abs(p0 - p1).max() < 5e-4      # Adam's first steps move every weight by ~3e-4 at lr 1e-4
+    cfg, p, wv, b, labels = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
+    feeds = (b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(),
+             *[x.numpy() for x in labels])
+    ms, trs = [], []
+    for force_dp in (False, True):
+        m = pu.hip_model(cfg, p, wv)
+        m.set_rng(7, 3)
+        tr = Trainer(m, world=1, use_graph=False, force_dp=force_dp)
+        tr.set_batch(*feeds)
+        ms.append(m)
+        trs.append(tr)
+
+    def per_tensor(step):
+        g0, g1 = ms[0].grads_dict(), ms[1].grads_dict()
+        for k in g0:
+            scale = max(float(np.abs(g0[k]).max()), 1e-6)
+            d = float(np.abs(g0[k] - g1[k]).max())
+            # the two paths differ by the summation order of the alignment loss and of the float atomics of the weight gradients
+            assert d <= 2e-4 * scale + 1e-7, (step, k, d, scale)
+
+    for step in range(2):
+        if step == 1:                                # same state on both sides before step 2
+            for a, c in zip((ms[0].params, ms[0].adam_m, ms[0].adam_v, ms[0].rng_state),
+                            (ms[1].params, ms[1].adam_m, ms[1].adam_v, ms[1].rng_state)):
+                c.copy_(a)
+        losses = []
+        for tr in trs:
+            tr.step(lr=1e-4, drop_rate=0.2)
+            losses.append(float(tr.last_loss()))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(losses[0], losses[1], rtol=1e-5, atol=1e-5)
+        per_tensor(step)
+    p0, p1 = ms[0].params.detach().cpu().numpy(), ms[1].params.detach().cpu().numpy()
+    assert np.abs(p0 - p1).max() < 5e-4      # one Adam step without bias correction moves every weight by ~3e-4 at lr 1e-4
 
 
 def test_bench_multi_rank_path_on_one_rank(tmp_path):

@@ -90,6 +90,21 @@ def test_c1_shape():
     _check_all(case, 0.2)
 
 
+def test_c1_shape_yaml_vdim():
+    """BASELINE.json configs[0] with the YAML's vdim 1024: B=16, T=64, L=20, C=8 - the shape both legs of
+    bench.py's cpu_baseline are timed on"""
+    case = pu.make_case(B=16, T=64, L=20, C=8, seed=778, max_vlen=64, vdim=1024)
+    _check_all(case, 0.2)
+
+
+def test_bench_shape_c2_bf16_feed():
+    """BASELINE.json configs[1] AS WRITTEN: bfloat16 clip features at B=64, T=128, vdim=1024 (hual_batch.video_dtype = BF16) -
+    every tap, output, loss term and all 170 gradients within 1e-3 of the oracle run on the same (bf16-representable) values"""
+    case = pu.make_case(B=64, T=128, L=20, C=8, seed=12345, max_vlen=128, vdim=1024)
+    rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2, video_bf16=True)
+    _check(rows, idx_equal)
+
+
 def test_activitynet_dims():
     # configs/anet/SeqPAN.yaml: char_dim 100, max_vlen 100; longest sentences ~30 words
     case = pu.make_case(B=3, T=100, L=30, C=9, seed=41, max_vlen=100, char_dim=100)

@@ -139,6 +139,26 @@ def test_adam_weight_decay_semantics():
     assert abs(float(p2['a/kernel'][0]) - (1 - 0.1 * (upd + 0.01))) < 1e-6
 
 
+def test_train_step_leaves_the_callers_state_alone():
+    """a discarded train_step (warm-up, timing scan) must not advance the caller's parameters or Adam slots: bench.py's
+    oracle trajectory in round 3 started from slots three discarded steps had written into"""
+    cfg = R.default_cfg(max_vlen=16, num_words=40)
+    p = R.init_params(cfg, seed=4)
+    wv = R.init_word_vectors(cfg)
+    b = R.synthetic_batch(cfg, 2, 10, 5, 5, seed=9)
+    lab = _labels(b, 10)
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    p0 = {k: t.clone() for k, t in p.items()}
+    batch = (b['video'], b['lens'], b['word_ids'], b['char_ids'])
+    a = R.train_step(p, m, v, cfg, wv, batch, lab, lr=1e-3, drop_rate=0.2, seed=1, offset=0)
+    assert all(float(m[k].abs().max()) == 0.0 and float(v[k].abs().max()) == 0.0 for k in m)
+    assert all(torch.equal(p[k], p0[k]) for k in p)
+    c = R.train_step(p, m, v, cfg, wv, batch, lab, lr=1e-3, drop_rate=0.2, seed=1, offset=0)
+    assert all(torch.equal(a[0][k], c[0][k]) for k in p) and float(a[3]['loss']) == float(c[3]['loss'])
+    assert any(float(a[1][k].abs().max()) > 0 for k in m)
+
+
 def test_softmax_cr_is_a_float32_softmax():
     """the reproducible softmax used for the span selection agrees with torch's float32 softmax to a few ulps and with
     the float64 softmax to float32 rounding; rows sum to 1"""
