@@ -9,7 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhual_seqpan.so')
 OBJ = os.path.join(HERE, 'csrc', 'build')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (the kernels' epilogues are VALU work on the accumulators: in the AGPR form
+# every accumulator register paid a v_accvgpr_read - one vector instruction per attention score; no kernel needs more than 256 registers)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function', '-mllvm', '-amdgpu-mfma-vgpr-form']
 if os.environ.get('HUAL_STAMPS'):        # debug build: in-kernel phase timestamps of one fused tile kernel (csrc/tilecore.h)
     FLAGS.append('-DHUAL_STAMPS=' + os.environ['HUAL_STAMPS'])
     if os.environ.get('HUAL_STAMPS_FIRST'):

@@ -99,7 +99,8 @@ int hual_attention_fwd_save(const float* Q, int ldq, const float* K, const float
   attn_job_init(j);
   j.Q = Q; j.ldq = ldq; j.K = K; j.V = V; j.ldkv = ldkv; j.O = O; j.ldo = ldo;
   j.B = B; j.Tq = Tq; j.Tk = Tk; j.qrow0 = 0; j.krow0 = 0; j.qmask = qmask; j.kmask = kmask;
-  j.stats = stats; j.dmask = keep_bytes; j.ldm = ldm; j.drop_site = drop_rate > 0.f ? drop_site : -1; j.drop_row0 = 0;
+  HUAL_REQUIRE(!keep_bytes || ldm >= attn_ldm(Tk), "hual_attention_fwd_save: ldm < hual_attention_keep_row_bytes(Tk)");
+  j.stats = stats; j.dmask = keep_bytes; j.drop_site = drop_rate > 0.f ? drop_site : -1; j.drop_row0 = 0;
   DropCfg d = make_dropcfg(rng_state, drop_rate);
   return launch_attn_fwd(&j, 1, d, (hipStream_t)stream);
 }
@@ -114,7 +115,8 @@ int hual_attention_bwd(const float* Q, int ldq, const float* K, const float* V, 
   attn_job_init(j);
   j.Q = Q; j.ldq = ldq; j.K = K; j.V = V; j.ldkv = ldkv; j.O = const_cast<float*>(O); j.ldo = ldo;
   j.B = B; j.Tq = Tq; j.Tk = Tk; j.qrow0 = 0; j.krow0 = 0; j.qmask = qmask; j.kmask = kmask;
-  j.stats = const_cast<float*>(stats); j.dmask = const_cast<uint8_t*>(keep_bytes); j.ldm = ldm;
+  HUAL_REQUIRE(!keep_bytes || ldm >= attn_ldm(Tk), "hual_attention_bwd: ldm < hual_attention_keep_row_bytes(Tk)");
+  j.stats = const_cast<float*>(stats); j.dmask = const_cast<uint8_t*>(keep_bytes);
   j.drop_site = drop_rate > 0.f ? drop_site : -1; j.drop_row0 = 0;
   j.dO = dO; j.lddo = lddo; j.dQ = dQ; j.lddq = lddq; j.dK = dK; j.dV = dV; j.lddkv = lddkv;
   DropCfg d = make_dropcfg(rng_state, drop_rate);

@@ -16,10 +16,11 @@ struct AttnJob {
                                            // (query, head); written by the forward when non-null, required by the backward
   int B, Tq, Tk, qrow0, krow0;
   const float* qmask; const float* kmask;  // [rows] floats
-  int drop_site; uint32_t drop_row0;       // Philox row = (drop_row0 + qrow) * 8 + head ; 8-bit decisions, see attn.hip
-  // keep bits of the dropout on the probabilities: row ((b*Tq + q)*8 + h) of ldm bytes; key k = 16 kt + 4 g + r is bit r of
-  // byte g * (ldm / 4) + kt.  Written by the forward when non-null; the backward needs it whenever dropout is on.
-  uint8_t* dmask; int ldm;                 // ldm >= attn_ldm(Tk), multiple of 16
+  int drop_site; uint32_t drop_row0;       // Philox row = (drop_row0 + qrow) * 8 + head ; 16-bit decisions, see attn.hip
+  // keep words of the dropout on the probabilities: per (clip b, head h) a block of nqt * nkt * 4 words of 8 bytes (nqt, nkt = query /
+  // key tiles of 16) at dmask + (b * 8 + h) * nqt * nkt * 32; word (qt * nkt + kt) * 4 + r, bit 16 g + jq = (query 16 qt + jq,
+  // key 16 kt + 4 g + r) is kept.  Written by the forward when non-null; the backward needs it whenever dropout is on.
+  uint8_t* dmask;                          // attn_keep_bytes(B, Tq, Tk) bytes, 8-byte aligned
   // backward
   const float* dO; int lddo;
   float* dQ; int lddq;                     // written (not accumulated)
@@ -30,9 +31,16 @@ struct AttnJob {
 struct AttnBatch {
   AttnJob j[HUAL_MAX_ATTN_JOBS];
 };
+// forward: the (job, 16-query tile) units of a launch, sorted by cost on the host: code = job << 4 | tile
+#define HUAL_MAX_ATTN_UNITS 64
+struct AttnUnits {
+  int n;
+  uint8_t u[HUAL_MAX_ATTN_UNITS];
+};
 
 void attn_job_init(AttnJob& j);
-int attn_ldm(int Tk);                     // bytes per keep-byte row for Tk keys
+int attn_ldm(int Tk);                     // public sizing rule (hual_attention_keep_row_bytes): B * Tq * 8 rows of this many bytes hold the keep words
+size_t attn_keep_bytes(int B, int Tq, int Tk);      // exact size of a job's keep words
 int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t s);
 // dQ, dK, dV in one launch (needs O and stats of the forward)
 int launch_attn_bwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t s);

@@ -16,16 +16,21 @@
 //              from one fp32 LDS slot per wave.  The forward leaves (row max in the log2 domain, 1 / row sum) and the keep bits of
 //              the dropout; delta = dO . O.
 //
-// Dropout on the probabilities (layers.py:86,91; modules.py:114): ONE Philox4x32-10 call yields 16 decisions from its 16
-// bytes (keep iff byte < t8, t8 = round(keep_prob * 256), kept values scaled by 256 / t8 - unbiased at the 8-bit keep
-// probability); the call with counter c0 = g + 4 (kt >> 2) covers keys 16 kt + 4 g + r for the four tiles kt of a group:
-// word kt & 3, byte r.  oracle/philox.py `mask8` is the same draw.  (The other dropout sites keep one decision per word.)
+// Dropout on the probabilities (layers.py:86,91; modules.py:114): 16-bit decisions, EIGHT per Philox4x32-7 call (keep iff half < t16,
+// t16 = round(keep_prob * 65536); kept values scaled by exactly 1 / (1 - rate), as tf.nn.dropout does); key k = 16 kt + 4 g + r of RNG
+// row (query row, head) takes the call with counter c0 = g + 4 (kt >> 1), word 2 (kt & 1) + (r >> 1), half r & 1.  oracle/philox.py
+// `mask_attn` is the same draw.  The forward stores the decisions as keep WORDS: for (query tile qt, key tile kt, r) the 64-bit lane
+// mask of the comparison - bit 16 g + jq = (query 16 qt + jq, key 16 kt + 4 g + r) - at word (qt * nkt + kt) * 4 + r of the
+// (clip, head)'s block; the backward reads 16 bits of a word per (key, query tile).
 #include "attn.h"
 #include "bf16x3.h"
 #include "philox.h"
 #include "prof.h"
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <type_traits>
+#include <vector>
 
 using namespace hual;
 
@@ -35,7 +40,8 @@ void attn_job_init(AttnJob& j) {
   j.drop_site = -1;
   j.dmask = nullptr;
 }
-int attn_ldm(int Tk) { return 4 * ((cdiv(Tk, 16) + 3) & ~3); }
+int attn_ldm(int Tk) { return 32 * cdiv(Tk, 16); }
+size_t attn_keep_bytes(int B, int Tq, int Tk) { return (size_t)B * 8 * cdiv(Tq, 16) * cdiv(Tk, 16) * 32; }
 }  // namespace hual
 
 #define ATT_LOG2E 1.4426950408889634f
@@ -62,12 +68,6 @@ __device__ __forceinline__ int xcd_logical_id() {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
-// 8-bit dropout decisions: threshold / scale from the 32-bit threshold of DropCfg (same arithmetic as oracle/philox.py)
-__device__ __forceinline__ uint32_t drop_t8(const DropCfg& d) {
-  uint32_t t = (uint32_t)(((uint64_t)d.thresh + (1ull << 23)) >> 24);
-  return t < 1u ? 1u : (t > 256u ? 256u : t);
 }
 
 // ---- LDS panels -----------------------------------------------------------------------------------------
@@ -102,191 +102,286 @@ __device__ __forceinline__ bf16x8 panel_tr(const char* panel, int plane, int row
 }
 
 // ======================================================================================================
-// forward
+// forward: ONE workgroup per (clip, head) for ALL jobs of the launch
 // ======================================================================================================
-// NKT = key tiles of 16 staged and processed (compile time: the tile loops carry no conditions; tiles beyond Tk hold zero
-// keys with an additive term of -inf, i.e. probability 0).  One Philox call per lane covers a group of 4 tiles.
-// DROP: dropout on the probabilities (compile time: the mask code carries no run-time branches)
-template <int NKT, bool DROP, int NT>      // NT threads per workgroup (NT / 64 query tiles in flight)
-__device__ __forceinline__ void attn_fwd_body(const AttnJob& job, int b, int h, char* lds, const DropCfg& drop) {
-  constexpr int Tkp = 16 * NKT, NKQ = (NKT + 3) / 4, NST = (Tkp * 4 + NT - 1) / NT;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The four attention problems of a dual_attn_block call (layers.py:80-96: video self 128 x 128, video -> query 128 x 20, query self
+// 20 x 20, query -> video 20 x 128 at the bench shape) used to be four workgroups per (clip, head); the small ones cost almost as
+// much as the large one (a cold start, a staging round trip and a barrier each: the 4-job launch took the SUM of its jobs).  Now a
+// workgroup stages the K / V panels of every job once and its waves walk a list of units = (job, 16-query tile), sorted by cost on
+// the host and dealt to the waves boustrophedon (near-LPT): at the bench shape 20 units of 8 or 2 key tiles, 25 +- 1 key tiles per wave.
+//
+// A unit (lane j = query of the tile, g = lane >> 4):
+//   S^T = K.Q^T per 16-key tile with [hi | lo] of the 16 head dims in the 32 contraction slots (two MFMAs per tile); row max / row sum
+//   in-lane + two cross-lane steps; e = exp2(s - max) stays UNNORMALISED (e in [0, 1]) and the dropped, unnormalised probabilities are
+//   the A operand of e.V; 1 / sum (x the dropout scale) multiplies the 16 x 16 output tile instead of the 16 x Tk probabilities.
+//   Dropout: 16-bit decisions, 8 per Philox call (pair of key tiles), kept iff half < t16, scale exactly 1 / (1 - rate) as
+//   tf.nn.dropout.  The comparison's lane mask IS the keep word of (query tile, key tile, r): it selects e or 0 (one v_cndmask per
+//   score) and is stored as 8 bytes for the backward pass - no per-score bit arithmetic.
+//   P operand: the bf16 hi + lo split of e (three MFMAs per 32 keys).  e as ONE fp16 operand (two MFMAs, no split) was built and
+//   measured in round 4: 2.2e-4 .. 5.3e-4 absolute on O(1) outputs (peaked rows: 2^-12 |V|), and the backward's delta = dO . O no
+//   longer matches the exact probabilities it recomputes (key-bias gradients, exact zeros by cancellation, came out at 1e-3): the
+//   backward would have to round its probabilities the same way (+2 vector instructions per score there for -3 here) - not taken.
+// NKT = key tiles of 16 of the unit's job (compile time per unit body; tiles beyond Tk hold zero keys with an additive term of -inf).
+__device__ __forceinline__ int nkt_pad(int Tk) {
+  const int n = (Tk + 15) >> 4;
+  return n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 16;
+}
+__device__ __forceinline__ uint32_t attn_t16(const DropCfg& d) {            // = oracle/philox.py keep_threshold16
+  const uint32_t t = (uint32_t)(((uint64_t)d.thresh + (1ull << 15)) >> 16);
+  return t < 1u ? 1u : (t > 65536u ? 65536u : t);
+}
+
+// compile-time loops (the loop index is a constant expression inside the body: template arguments, asm immediates)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(static_cast<F&&>(f));
+  }
+}
+// lanes L0 .. L0 + 7 of (lo, hi) = the eight 64-bit lane masks m[0..7] (wave-uniform values in SGPRs).  v_writelane_b32 reads its
+// scalar data operand EARLY: issued right behind the v_cmp that produced the mask it read the register's previous contents (measured:
+// every second keep word carried its predecessor's low half; the compiler's hazard tables know this for its own instructions, not for
+// asm) - so all eight masks are computed first and the block opens with the wait states (ISA: VALU writes SGPR -> lane instruction: 4).
+template <int L0>
+__device__ __forceinline__ void put_lanes8(uint32_t& lo, uint32_t& hi, const unsigned long long (&m)[8]) {
+  asm volatile("s_nop 4\n\t"
+               "v_writelane_b32 %0, %2, %18\n\tv_writelane_b32 %1, %3, %18\n\t"
+               "v_writelane_b32 %0, %4, %19\n\tv_writelane_b32 %1, %5, %19\n\t"
+               "v_writelane_b32 %0, %6, %20\n\tv_writelane_b32 %1, %7, %20\n\t"
+               "v_writelane_b32 %0, %8, %21\n\tv_writelane_b32 %1, %9, %21\n\t"
+               "v_writelane_b32 %0, %10, %22\n\tv_writelane_b32 %1, %11, %22\n\t"
+               "v_writelane_b32 %0, %12, %23\n\tv_writelane_b32 %1, %13, %23\n\t"
+               "v_writelane_b32 %0, %14, %24\n\tv_writelane_b32 %1, %15, %24\n\t"
+               "v_writelane_b32 %0, %16, %25\n\tv_writelane_b32 %1, %17, %25"
+               : "+v"(lo), "+v"(hi)
+               : "s"((uint32_t)m[0]), "s"((uint32_t)(m[0] >> 32)), "s"((uint32_t)m[1]), "s"((uint32_t)(m[1] >> 32)),
+                 "s"((uint32_t)m[2]), "s"((uint32_t)(m[2] >> 32)), "s"((uint32_t)m[3]), "s"((uint32_t)(m[3] >> 32)),
+                 "s"((uint32_t)m[4]), "s"((uint32_t)(m[4] >> 32)), "s"((uint32_t)m[5]), "s"((uint32_t)(m[5] >> 32)),
+                 "s"((uint32_t)m[6]), "s"((uint32_t)(m[6] >> 32)), "s"((uint32_t)m[7]), "s"((uint32_t)(m[7] >> 32)),
+                 "n"(L0), "n"(L0 + 1), "n"(L0 + 2), "n"(L0 + 3), "n"(L0 + 4), "n"(L0 + 5), "n"(L0 + 6), "n"(L0 + 7));
+}
+
+struct FwdUnitCtx {
+  const char* Kp; const char* Vp; const float* Bias; int RT;      // the job's panels (already offset) and the stride between the two bias rows
+  uint32_t k0, k1, off, t16; float scale;
+};
+
+template <int NKT, bool DROP>
+__device__ __forceinline__ void attn_fwd_unit(const AttnJob& job, int b, int h, int qt, const FwdUnitCtx& c, const float4& qv0, const float4& qv1,
+                                              float mq, int lane) {
+  constexpr int NKP = NKT / 2;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
-  const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
-  char* Kp = lds;                                   // [Tkp][64]
-  char* Vp = Kp + Tkp * 64;                         // [Tkp][64]
-  float* Bias = reinterpret_cast<float*>(Vp + Tkp * 64);      // [2][Tkp]: additive term of a key for padded / valid queries
-  const int nqt = (Tq + 15) >> 4;
-  // the dropout stream's key / offset live in device memory: read at the top (behind the barrier the load was a round trip of its own)
-  constexpr bool dodrop = DROP;
-  uint32_t k0 = 0, k1 = 0, off = 0;
-  if (dodrop) {      // (through the constant address space: scalar loads, no vector-memory wait in front of the staging loads)
-    const __attribute__((address_space(4))) uint32_t* sp = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)drop.state;
-    k0 = sp[0]; k1 = sp[1]; off = sp[2];
+  const int qbase = job.qrow0 + b * Tq;
+  const int q0 = qt * 16;
+  const bool qok = q0 + j < Tq;
+  const int qrow = qbase + min(q0 + j, Tq - 1);
+  // B operands: [Q_hi | Q_hi] and [Q_lo | 0] over the 32 slots (lane g covers head dims 8 (g & 1) .. + 7)
+  uint4 qh, ql;
+  split8(qv0, qv1, qh, ql);
+  if (g >= 2) ql = make_uint4(0u, 0u, 0u, 0u);
+  const bf16x8 B1 = as_bf8(qh), B2 = as_bf8(ql);
+  const float* bias = c.Bias + (mq != 0.f ? c.RT : 0);
+  f32x4 s[NKT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const bf16x8 a = panel_a(c.Kp, 16 * kt + j, g);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = mfma_bf(a, B1, acc);
+    acc = mfma_bf(a, B2, acc);
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + 16 * kt + 4 * g);
+    acc[0] = fmaf(acc[0], ATT_C1, b4.x); acc[1] = fmaf(acc[1], ATT_C1, b4.y);
+    acc[2] = fmaf(acc[2], ATT_C1, b4.z); acc[3] = fmaf(acc[3], ATT_C1, b4.w);
+    mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+    s[kt] = acc;
   }
-  // the wave's first query tile is requested before the staging so that it arrives under it, every further one while the tile
-  // in front of it is computed (two register sets); the query mask is read in the staging phase, from LDS afterwards
-  float4 qv0 = f4zero(), qv1 = f4zero(), nq0 = f4zero(), nq1 = f4zero();
-  auto load_q = [&](int qt, float4& d0, float4& d1) {
-    const int qrow = qbase + min(16 * qt + j, Tq - 1);
-    const float* qp = job.Q + (size_t)qrow * job.ldq + 16 * h + 8 * (g & 1);
-    d0 = ld4(qp); d1 = ld4(qp + 4);
-  };
-  if (wave < nqt) load_q(wave, qv0, qv1);
-  float qmk = 0.f;                                   // mask of query wave * 16 + j (the wave's first tile): requested behind the panels
-  {
-    // all loads of the block's panels first, then the splits and LDS stores
-    const float* Kg = job.K + (size_t)kbase * job.ldkv + 16 * h;
-    const float* Vg = job.V + (size_t)kbase * job.ldkv + 16 * h;
-    float4 kv[NST], vv[NST];
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
 #pragma unroll
-    for (int it = 0; it < NST; ++it) {
-      const int idx = threadIdx.x + NT * it, row = min(idx >> 2, Tk - 1), c4 = idx & 3;
-      kv[it] = ld4(Kg + (size_t)row * job.ldkv + 4 * c4);
-      vv[it] = ld4(Vg + (size_t)row * job.ldkv + 4 * c4);
-    }
-    // (unconditional on a clamped index: a load behind a lane-dependent branch is waited for inside that branch)
-    const float km = job.kmask[kbase + min((int)threadIdx.x, Tk - 1)];
-    qmk = job.qmask[qbase + min(16 * min(wave, nqt - 1) + j, Tq - 1)];
-#pragma unroll
-    for (int it = 0; it < NST; ++it) {
-      const int idx = threadIdx.x + NT * it, row = idx >> 2, c4 = idx & 3;
-      if (row < Tkp) {
-        panel_store(Kp, row, c4, row < Tk ? kv[it] : f4zero());
-        panel_store(Vp, row, c4, row < Tk ? vv[it] : f4zero());
-      }
-    }
-    if (threadIdx.x < Tkp) {
-      const bool in = (int)threadIdx.x < Tk;
-      Bias[threadIdx.x] = in ? ATT_NEGL : -INFINITY;                                  // layers.py:84: (1 - mq mk) * -1e30, mq = 0
-      Bias[Tkp + threadIdx.x] = in ? (km != 0.f ? 0.f : ATT_NEGL) : -INFINITY;
-    }
-  }
-  __syncthreads();
-  const uint32_t t8 = drop_t8(drop);
-  const float scale8 = 256.0f / (float)t8;
-  for (int qt = wave; qt < nqt; qt += NT / 64) {
-    const int q0 = qt * 16;
-    const bool qok = q0 + j < Tq;
-    const int qrow = qbase + min(q0 + j, Tq - 1);
-    if (qt != wave) { qv0 = nq0; qv1 = nq1; }
-    const bool more_q = qt + NT / 64 < nqt;
-    const int qnext = more_q ? qt + NT / 64 : qt;     // (the last tile asks for itself again: no branch around the loads)
-    load_q(qnext, nq0, nq1);
-    const float mqn = job.qmask[qbase + min(16 * qnext + j, Tq - 1)];
-    const float mq = qmk;
-    qmk = mqn;
-    // B operands: [Q_hi | Q_hi] and [Q_lo | 0] over the 32 slots (lane g covers head dims 8 (g & 1) .. + 7)
-    uint4 qh, ql;
-    split8(qv0, qv1, qh, ql);
-    if (g >= 2) ql = make_uint4(0u, 0u, 0u, 0u);
-    const bf16x8 B1 = as_bf8(qh), B2 = as_bf8(ql);
-    const float* bias = Bias + (mq != 0.f ? Tkp : 0);
-    f32x4 s[NKT];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const bf16x8 a = panel_a(Kp, 16 * kt + j, g);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = mfma_bf(a, B1, acc);
-      acc = mfma_bf(a, B2, acc);
-      const float4 b4 = *reinterpret_cast<const float4*>(bias + 16 * kt + 4 * g);
-      acc[0] = fmaf(acc[0], ATT_C1, b4.x); acc[1] = fmaf(acc[1], ATT_C1, b4.y);
-      acc[2] = fmaf(acc[2], ATT_C1, b4.z); acc[3] = fmaf(acc[3], ATT_C1, b4.w);
-      mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
-      s[kt] = acc;
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
-        s[kt][r] = e;
-        sum += e;
-      }
-    }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
-    const int ql_ = b * Tq + q0 + j;                  // job-local query index
-    if (job.stats && g == 0 && qok) {
-      job.stats[ql_ * 8 + h] = mx;
-      job.stats[job.B * Tq * 8 + ql_ * 8 + h] = inv;
-    }
-    const uint32_t drow = (job.drop_row0 + (uint32_t)qrow) * 8u + (uint32_t)h;
-    uint8_t* mrow = (job.dmask && dodrop && qok) ? job.dmask + ((size_t)ql_ * 8 + h) * job.ldm + g * (job.ldm >> 2) : nullptr;
-    const float keepv = dodrop ? inv * scale8 : inv;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kq = 0; kq < NKQ; ++kq) {
-      uint32_t w[4] = {0u, 0u, 0u, 0u};
-      uint32_t bits = 0u;
-      if (dodrop) {
-        const uint4_ rnd = philox4x32_10((uint32_t)(g + 4 * kq), drow, (uint32_t)job.drop_site, off, k0, k1);
-        w[0] = rnd.x; w[1] = rnd.y; w[2] = rnd.z; w[3] = rnd.w;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kt = 4 * kq + i;
-        if (kt < NKT) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool keep = !dodrop || ((w[i] >> (8 * r)) & 0xffu) < t8;
-            s[kt][r] *= keep ? keepv : 0.f;
-            bits |= keep ? (1u << (8 * i + r)) : 0u;
-          }
-        }
-      }
-      if (mrow) *reinterpret_cast<uint32_t*>(mrow + 4 * kq) = bits;
-#pragma unroll
-      for (int ip = 0; ip < 2; ++ip) {
-        const int kp = 2 * kq + ip;                 // key tiles 2 kp, 2 kp + 1
-        if (2 * kp < NKT) {
-          uint4 ph, pl;
-          split8(make_float4(s[2 * kp][0], s[2 * kp][1], s[2 * kp][2], s[2 * kp][3]),
-                 make_float4(s[2 * kp + 1][0], s[2 * kp + 1][1], s[2 * kp + 1][2], s[2 * kp + 1][3]), ph, pl);
-          const bf16x8 vh = panel_tr(Vp, 0, 32 * kp, lane), vl = panel_tr(Vp, 32, 32 * kp, lane);
-          o = mfma_bf(as_bf8(ph), vh, o);
-          o = mfma_bf(as_bf8(ph), vl, o);
-          o = mfma_bf(as_bf8(pl), vh, o);
-        }
-      }
-    }
+  for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int q = q0 + 4 * g + r;
-      if (q < Tq) job.O[(size_t)(qbase + q) * job.ldo + 16 * h + j] = o[r];
+      const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+      s[kt][r] = e;
+      sum += e;
     }
+  }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  const int ql_ = b * Tq + q0 + j;                  // job-local query index
+  if (job.stats && g == 0 && qok) {
+    job.stats[ql_ * 8 + h] = mx;
+    job.stats[job.B * Tq * 8 + ql_ * 8 + h] = inv;
+  }
+  // factor of output row 4 g + r: 1 / sum (x dropout scale) of query 4 g + r, which lane 4 g + r holds
+  const float fac = DROP ? inv * c.scale : inv;
+  float fr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) fr[r] = __shfl(fac, 4 * g + r);
+  const uint32_t drow = (job.drop_row0 + (uint32_t)qrow) * 8u + (uint32_t)h;
+  uint32_t wlo = 0u, whi = 0u;                      // lane 4 kt + r: keep word of (this query tile, key tile kt, r)
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  static_for<0, NKP>([&](auto kpc) {                // key tiles 2 kp, 2 kp + 1
+    constexpr int kp = decltype(kpc)::value;
+    if (DROP) {
+      const uint4_ rnd = philox4x32((uint32_t)(g + 4 * kp), drow, (uint32_t)job.drop_site, c.off, c.k0, c.k1);
+      const uint32_t w[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+      unsigned long long mk[8];
+      static_for<0, 8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value >> 2, r = decltype(ic)::value & 3;
+        const uint32_t word = w[2 * i + (r >> 1)];
+        const bool keep = ((r & 1) ? (word >> 16) : (word & 0xffffu)) < c.t16;
+        mk[decltype(ic)::value] = __ballot(keep);               // = the comparison's own lane mask
+        s[2 * kp + i][r] = keep ? s[2 * kp + i][r] : 0.f;
+      });
+      put_lanes8<8 * kp>(wlo, whi, mk);                         // lane 4 kt + r collects the keep word of (kt, r)
+    }
+    uint4 ph, pl;
+    split8(make_float4(s[2 * kp][0], s[2 * kp][1], s[2 * kp][2], s[2 * kp][3]),
+           make_float4(s[2 * kp + 1][0], s[2 * kp + 1][1], s[2 * kp + 1][2], s[2 * kp + 1][3]), ph, pl);
+    const bf16x8 vh = panel_tr(c.Vp, 0, 32 * kp, lane), vl = panel_tr(c.Vp, 32, 32 * kp, lane);
+    o = mfma_bf(as_bf8(ph), vh, o);
+    o = mfma_bf(as_bf8(ph), vl, o);
+    o = mfma_bf(as_bf8(pl), vh, o);
+  });
+  if (DROP && job.dmask) {      // keep words of the tile's real key tiles: one 8-byte store per lane, contiguous over the lanes
+    const int nkt = (Tk + 15) >> 4, nqt = (Tq + 15) >> 4;
+    if (lane < 4 * nkt)
+      *reinterpret_cast<uint2*>(job.dmask + (((size_t)(b * 8 + h) * nqt + qt) * nkt * 4 + lane) * 8) = make_uint2(wlo, whi);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + 4 * g + r;
+    if (q < Tq) job.O[(size_t)(qbase + q) * job.ldo + 16 * h + j] = o[r] * fr[r];
   }
 }
 
 // MAXNKT: the largest tile count among the jobs of the launch (the kernel's register budget is that of its largest body)
-// (limiting the kernel to 128 registers - 4 waves per SIMD - spills 17 of them in the 8-tile body and is SLOWER, with 4- or
-//  8-wave workgroups alike: 13.4 vs 10.7 us for the 128 x 128 job.  The kernel is VALU-issue bound: ~25 vector instructions per
-//  score - 10 for mask / max / exp / sum, 7.5 Philox, 3 keep decision + keep bits, 3.5 operand split - not latency bound.)
+// NT threads per workgroup: the units are latency chains (LDS read -> MFMA -> cross-lane reductions -> exp -> Philox -> MFMA chain), so a
+// SIMD wants as many waves as the registers allow: 512 threads x 2 workgroups per CU = 4 waves per SIMD where the body fits 128 registers
 template <int MAXNKT, int NT>
-__global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnBatch batch, int njobs, DropCfg drop) {
+__global__ __launch_bounds__(NT, (NT == 512 && MAXNKT <= 8) ? 4 : 2) void attn_fwd_kernel(AttnBatch batch, int njobs, AttnUnits units, DropCfg drop) {
+  constexpr int NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  int lid = xcd_logical_id();
-  const int h = lid & 7; lid >>= 3;
-  const AttnJob& job = batch.j[lid % njobs];       // clip-major: an XCD gets whole clips with ALL their jobs (balanced)
-  const int b = lid / njobs;
-  if (b >= job.B) return;   // block-uniform
-  const int nkt = (job.Tk + 15) >> 4;
-  if (job.drop_site >= 0 && drop.enabled) {
-    if (nkt <= 2) attn_fwd_body<2, true, NT>(job, b, h, lds, drop);
-    else if (MAXNKT >= 4 && nkt <= 4) attn_fwd_body<4, true, NT>(job, b, h, lds, drop);
-    else if (MAXNKT >= 8 && nkt <= 8) attn_fwd_body<8, true, NT>(job, b, h, lds, drop);
-    else if (MAXNKT >= 16) attn_fwd_body<16, true, NT>(job, b, h, lds, drop);
-  } else {
-    if (nkt <= 2) attn_fwd_body<2, false, NT>(job, b, h, lds, drop);
-    else if (MAXNKT >= 4 && nkt <= 4) attn_fwd_body<4, false, NT>(job, b, h, lds, drop);
-    else if (MAXNKT >= 8 && nkt <= 8) attn_fwd_body<8, false, NT>(job, b, h, lds, drop);
-    else if (MAXNKT >= 16) attn_fwd_body<16, false, NT>(job, b, h, lds, drop);
+  const int lid = xcd_logical_id();
+  const int h = lid & 7, b = lid >> 3;
+  if (b >= batch.j[0].B) return;   // block-uniform (grid rounded up to 8 clips)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int j = lane & 15, g = lane >> 4;
+  // panel rows of the jobs: job i owns rows ko[i] .. ko[i] + 16 nkt_pad(Tk_i) - 1 of the K and the V panel
+  int ko1, ko2, ko3, RT;
+  {
+    const int t0 = 16 * nkt_pad(batch.j[0].Tk), t1 = njobs > 1 ? 16 * nkt_pad(batch.j[1].Tk) : 0;
+    const int t2 = njobs > 2 ? 16 * nkt_pad(batch.j[2].Tk) : 0, t3 = njobs > 3 ? 16 * nkt_pad(batch.j[3].Tk) : 0;
+    ko1 = t0; ko2 = ko1 + t1; ko3 = ko2 + t2; RT = ko3 + t3;
+  }
+  char* Kp = lds;                                   // [RT][64]
+  char* Vp = Kp + RT * 64;                          // [RT][64]
+  float* Bias = reinterpret_cast<float*>(Vp + RT * 64);      // [2][RT]: additive term of a key for padded / valid queries
+  uint32_t k0 = 0, k1 = 0, off = 0;
+  if (drop.enabled) {      // (through the constant address space: scalar loads, no vector-memory wait in front of the staging loads)
+    const __attribute__((address_space(4))) uint32_t* sp = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)drop.state;
+    k0 = sp[0]; k1 = sp[1]; off = sp[2];
+  }
+  // the wave's units: entries NW k + w (k even) / NW k + NW - 1 - w (k odd) of the cost-sorted list
+  const int nun = units.n;
+  auto unit_of = [&](int k) { const int i = NW * k + ((k & 1) ? NW - 1 - wave : wave); return i < nun ? (int)units.u[i] : -1; };
+  float4 qv0 = f4zero(), qv1 = f4zero(), nq0 = f4zero(), nq1 = f4zero();
+  float mq = 0.f, nmq = 0.f;
+  auto load_q = [&](int u, float4& d0, float4& d1, float& m) {
+    const AttnJob& J = batch.j[u >> 4];
+    const int qrow = J.qrow0 + b * J.Tq + min(16 * (u & 15) + j, J.Tq - 1);
+    const float* qp = J.Q + (size_t)qrow * J.ldq + 16 * h + 8 * (g & 1);
+    d0 = ld4(qp); d1 = ld4(qp + 4);
+    m = J.qmask[qrow];
+  };
+  int ucur = unit_of(0);
+  if (ucur >= 0) load_q(ucur, qv0, qv1, mq);        // requested before the staging so that it arrives under it
+  {
+    // staging: every K / V row of every job once; ALL loads first, then the splits and LDS stores.  The loop over the jobs is
+    // static (job fields by constant index: their scalar loads sit at the top of the kernel - indexing the job table by a computed
+    // job id put a scalar-memory round trip in front of every batch of loads: 7.5 us for a launch that computed nothing)
+    constexpr int ITER = (1024 + NT - 1) / NT;        // a job has <= 256 panel rows x 4 pieces
+    float kmv[HUAL_MAX_ATTN_JOBS];
+    float4 kv[HUAL_MAX_ATTN_JOBS][ITER], vv[HUAL_MAX_ATTN_JOBS][ITER];
+#pragma unroll
+    for (int jb = 0; jb < HUAL_MAX_ATTN_JOBS; ++jb) {      // (unconditional on clamped indices: a load behind a branch is waited for inside it)
+      const AttnJob& J = batch.j[jb < njobs ? jb : 0];
+      kmv[jb] = J.kmask[J.krow0 + b * J.Tk + min((int)threadIdx.x, J.Tk - 1)];
+    }
+#pragma unroll
+    for (int jb = 0; jb < HUAL_MAX_ATTN_JOBS; ++jb) {
+      const AttnJob& J = batch.j[jb];
+      const int items = jb < njobs ? 64 * nkt_pad(J.Tk) : 0;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        kv[jb][it] = f4zero(); vv[jb][it] = f4zero();
+        if (it * NT < items) {                        // (workgroup-uniform)
+          const int idx = it * NT + (int)threadIdx.x;
+          const int r = min(idx >> 2, J.Tk - 1), c4 = idx & 3;
+          const size_t goff = (size_t)(J.krow0 + b * J.Tk + r) * J.ldkv + 16 * h + 4 * c4;
+          kv[jb][it] = ld4(J.K + goff);
+          vv[jb][it] = ld4(J.V + goff);
+        }
+      }
+    }
+#pragma unroll
+    for (int jb = 0; jb < HUAL_MAX_ATTN_JOBS; ++jb) {
+      const int Tk = batch.j[jb].Tk;
+      const int items = jb < njobs ? 64 * nkt_pad(Tk) : 0;
+      const int ko = jb == 0 ? 0 : jb == 1 ? ko1 : jb == 2 ? ko2 : ko3;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = it * NT + (int)threadIdx.x;
+        if (idx < items) {
+          const int row = idx >> 2, c4 = idx & 3;
+          const bool in = row < Tk;
+          panel_store(Kp, ko + row, c4, in ? kv[jb][it] : f4zero());
+          panel_store(Vp, ko + row, c4, in ? vv[jb][it] : f4zero());
+        }
+      }
+    }
+#pragma unroll
+    for (int jb = 0; jb < HUAL_MAX_ATTN_JOBS; ++jb) {
+      if (jb < njobs) {
+        const int ko = jb == 0 ? 0 : jb == 1 ? ko1 : jb == 2 ? ko2 : ko3;
+        const int Tk = batch.j[jb].Tk, Tkp = 16 * nkt_pad(Tk);
+        if ((int)threadIdx.x < Tkp) {
+          const bool in = (int)threadIdx.x < Tk;
+          Bias[ko + threadIdx.x] = in ? ATT_NEGL : -INFINITY;                                  // layers.py:84: (1 - mq mk) * -1e30, mq = 0
+          Bias[RT + ko + threadIdx.x] = in ? (kmv[jb] != 0.f ? 0.f : ATT_NEGL) : -INFINITY;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  FwdUnitCtx c;
+  c.RT = RT; c.k0 = k0; c.k1 = k1; c.off = off; c.t16 = attn_t16(drop); c.scale = drop.scale;
+  for (int k = 0; ucur >= 0; ++k) {
+    const int unext = unit_of(k + 1);
+    load_q(unext >= 0 ? unext : ucur, nq0, nq1, nmq);      // (the last unit asks for itself again: no branch around the loads)
+    const int jb = ucur >> 4, qt = ucur & 15;
+    const AttnJob& J = batch.j[jb];
+    const int ko = jb == 0 ? 0 : jb == 1 ? ko1 : jb == 2 ? ko2 : ko3;
+    c.Kp = Kp + ko * 64; c.Vp = Vp + ko * 64; c.Bias = Bias + ko;
+    const int nktp = nkt_pad(J.Tk);
+    if (J.drop_site >= 0 && drop.enabled) {
+      if (nktp == 2) attn_fwd_unit<2, true>(J, b, h, qt, c, qv0, qv1, mq, lane);
+      else if (MAXNKT >= 4 && nktp == 4) attn_fwd_unit<4, true>(J, b, h, qt, c, qv0, qv1, mq, lane);
+      else if (MAXNKT >= 8 && nktp == 8) attn_fwd_unit<8, true>(J, b, h, qt, c, qv0, qv1, mq, lane);
+      else if (MAXNKT >= 16) attn_fwd_unit<16, true>(J, b, h, qt, c, qv0, qv1, mq, lane);
+    } else {
+      if (nktp == 2) attn_fwd_unit<2, false>(J, b, h, qt, c, qv0, qv1, mq, lane);
+      else if (MAXNKT >= 4 && nktp == 4) attn_fwd_unit<4, false>(J, b, h, qt, c, qv0, qv1, mq, lane);
+      else if (MAXNKT >= 8 && nktp == 8) attn_fwd_unit<8, false>(J, b, h, qt, c, qv0, qv1, mq, lane);
+      else if (MAXNKT >= 16) attn_fwd_unit<16, false>(J, b, h, qt, c, qv0, qv1, mq, lane);
+    }
+    qv0 = nq0; qv1 = nq1; mq = nmq;
+    ucur = unext;
   }
 }
 
@@ -297,12 +392,12 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnBatch batch, int njobs
 //   Qp, Dp   [Tqp][64]       split Q / dO panels
 //   Kp       [Tkp][64]       split K panel (the V rows of a wave's keys go from HBM straight into its B operands)
 //   St       [6][Tqp]        row max (log2 domain), 1 / row sum, delta, additive term for masked / valid / padding keys
-//   Mk       [Tqp][ldm]      keep bytes of the head (forward layout: byte g * (ldm / 4) + kt, bit r)
+//   Mk       [nqt][nkt][4]   keep words of the head (8 bytes each, forward layout)
 //   dQw      [4 waves][Tqp][16]  fp32 dQ partial products, one slot per wave (plain stores: float atomics on LDS retire at
 //                            about one lane per clock and cost more than the rest of the kernel)
 //   Xs       [4 waves][32][20]   transposition scratch
 struct BwdLds { int qp, dp, kp, st, mk, dqw, xs, total; };
-__host__ __device__ inline BwdLds bwd_lds(int Tq, int Tk, int ldm) {
+__host__ __device__ inline BwdLds bwd_lds(int Tq, int Tk, bool dropout) {
   const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
   BwdLds l;
   int o = 0;
@@ -310,7 +405,7 @@ __host__ __device__ inline BwdLds bwd_lds(int Tq, int Tk, int ldm) {
   l.dp = o; o += Tqp * 64;
   l.kp = o; o += Tkp * 64;
   l.st = o; o += 6 * Tqp * 4;
-  l.mk = o; o += Tqp * ldm;
+  l.mk = o; o += dropout ? ((Tq + 15) >> 4) * ((Tk + 15) >> 4) * 32 : 0;
   l.dqw = o; o += 4 * Tqp * 64;
   l.xs = o; o += 4 * 32 * 20 * 4;
   l.total = o;
@@ -325,8 +420,8 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
   const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
   const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
   constexpr bool dodrop = DROP;
-  const int ldm = dodrop ? job.ldm : 0;
-  const BwdLds L = bwd_lds(Tq, Tk, ldm);
+  const BwdLds L = bwd_lds(Tq, Tk, dodrop);
+  const int nqt = (Tq + 15) >> 4, nkt = (Tk + 15) >> 4;
   char* Qp = lds + L.qp; char* Dp = lds + L.dp; char* Kp = lds + L.kp;
   float* St = reinterpret_cast<float*>(lds + L.st);
   uint8_t* Mk = reinterpret_cast<uint8_t*>(lds + L.mk);
@@ -391,15 +486,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
     }
   }
   if (dodrop) {
-    const int wpr = ldm >> 2;                          // words per row
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(job.dmask + ((size_t)(b * Tq) * 8 + h) * ldm);
-    for (int idx = threadIdx.x; idx < Tq * wpr; idx += 256) {
-      const int q = idx / wpr, w = idx - q * wpr;
-      reinterpret_cast<uint32_t*>(Mk)[idx] = src[(size_t)q * 8 * wpr + w];
-    }
+    const uint2* src = reinterpret_cast<const uint2*>(job.dmask + (size_t)(b * 8 + h) * nqt * nkt * 32);
+    for (int idx = threadIdx.x; idx < nqt * nkt * 4; idx += 256) reinterpret_cast<uint2*>(Mk)[idx] = src[idx];
   }
   __syncthreads();
-  const float scale8 = 256.0f / (float)drop_t8(drop);
+  const float scale8 = drop.scale;                  // exactly 1 / (1 - rate)
   float* slot = dQw + (qsplit ? 0 : wave) * Tqp * 16;
   bool first = true;
   const int qp0 = qsplit ? wave : 0, qpstep = qsplit ? 4 : 1;
@@ -441,10 +532,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
           const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
           uint32_t mbits = 0xfu;
           if (dodrop) {
-            // keep bits of queries q0 + 4 g + r for this lane's key: byte (j >> 2) * (ldm / 4) + kt of each query row, bit j & 3
-            const uint8_t* mp = Mk + (q0 + 4 * g) * ldm + (j >> 2) * (ldm >> 2) + 2 * kp + t;
-            mbits = ((mp[0] >> (j & 3)) & 1u) | (((mp[ldm] >> (j & 3)) & 1u) << 1) | (((mp[2 * ldm] >> (j & 3)) & 1u) << 2) |
-                    (((mp[3 * ldm] >> (j & 3)) & 1u) << 3);
+            // keep bits of queries q0 + 4 g + r for this lane's key 16 kt + j: bits 4 g .. 4 g + 3 of the 16-bit field j >> 2 of
+            // keep word (qt, kt, r = j & 3); tiles beyond the last real one are clamped (their probabilities are 0)
+            const int qtu = min(2 * qp + u, nqt - 1), ktt = min(2 * kp + t, nkt - 1);
+            const uint32_t f = *reinterpret_cast<const uint16_t*>(Mk + ((qtu * nkt + ktt) * 4 + (j & 3)) * 8 + 2 * (j >> 2));
+            mbits = (f >> (4 * g)) & 0xfu;
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -563,8 +655,7 @@ static int check_jobs(const AttnJob* jobs, int n, bool bwd, const DropCfg& drop,
     HUAL_REQUIRE(j.Q && j.K && j.V && j.qmask && j.kmask, "attn: null operand");
     HUAL_REQUIRE(j.B > 0 && j.Tq > 0 && j.Tk > 0 && j.Tk <= 256, "attn: need 0 < Tk <= 256, Tq > 0");
     HUAL_REQUIRE((j.ldq % 4) == 0 && (j.ldkv % 4) == 0, "attn: leading dims must be multiples of 4");
-    HUAL_REQUIRE(!j.dmask || (j.ldm >= attn_ldm(j.Tk) && (j.ldm % 16) == 0 && (reinterpret_cast<uintptr_t>(j.dmask) & 3) == 0),
-                 "attn: dropout keep-byte rows need ldm >= attn_ldm(Tk), multiple of 16");
+    HUAL_REQUIRE(!j.dmask || (reinterpret_cast<uintptr_t>(j.dmask) & 7) == 0, "attn: keep words must be 8-byte aligned");
     if (bwd) {
       HUAL_REQUIRE(j.dO && j.dQ && j.dK && j.dV && j.O && j.stats && (j.lddo % 4) == 0 && (j.ldo % 4) == 0 && (j.lddq % 4) == 0,
                    "attn bwd: needs dO, dQ, dK, dV, the forward output O and the forward softmax statistics");
@@ -580,24 +671,60 @@ static int check_jobs(const AttnJob* jobs, int n, bool bwd, const DropCfg& drop,
   return 0;
 }
 
+static int nkt_pad_host(int Tk) {
+  const int n = cdiv(Tk, 16);
+  return n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 16;
+}
+// algorithmic HBM bytes of an attention job (forward): Q, K, V rows of a head read once, O written, softmax statistics and keep words
+static double attn_job_bytes(const AttnJob& j, bool drop) {
+  return (double)j.B * 8.0 * ((double)j.Tq * 64.0 * 2.0 + (double)j.Tk * 128.0 + (double)j.Tq * 8.0) +
+         (drop && j.dmask ? (double)attn_keep_bytes(j.B, j.Tq, j.Tk) : 0.0);
+}
+
 int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t s) {
   int maxTq, maxTk, maxB;
   int rc = check_jobs(jobs, n, false, drop, maxTq, maxTk, maxB);
   if (rc) return rc;
   AttnBatch b;
   ::memset((void*)&b, 0, sizeof(b));
-  for (int i = 0; i < n; ++i) b.j[i] = jobs[i];
-  dim3 grid(maxB * 8 * n), block(256);
-  double flops = 0.0;
-  for (int i = 0; i < n; ++i) flops += 4.0 * jobs[i].B * 8.0 * jobs[i].Tq * jobs[i].Tk * 16.0;   // QK^T + PV
+  for (int i = 0; i < n; ++i) {
+    b.j[i] = jobs[i];
+    HUAL_REQUIRE(jobs[i].B == jobs[0].B, "attn fwd: the jobs of a launch share the clip count");
+  }
+  // units = (job, 16-query tile), sorted by cost = padded key tiles (+ the fixed part of a unit: query split, statistics, stores)
+  struct U { int cost, code; };
+  std::vector<U> us;
+  int RT = 0;
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const int nktp = nkt_pad_host(jobs[i].Tk);
+    RT += 16 * nktp;
+    for (int qt = 0; qt < cdiv(jobs[i].Tq, 16); ++qt) us.push_back(U{2 * nktp + 3, (i << 4) | qt});
+    flops += 4.0 * jobs[i].B * 8.0 * jobs[i].Tq * jobs[i].Tk * 16.0;   // QK^T + PV
+    bytes += attn_job_bytes(jobs[i], jobs[i].drop_site >= 0 && drop.enabled);
+  }
+  HUAL_REQUIRE((int)us.size() <= HUAL_MAX_ATTN_UNITS, "attn fwd: too many query tiles");
+  std::stable_sort(us.begin(), us.end(), [](const U& a, const U& c) { return a.cost > c.cost; });
+  AttnUnits un;
+  ::memset((void*)&un, 0, sizeof(un));
+  un.n = (int)us.size();
+  for (size_t k = 0; k < us.size(); ++k) un.u[k] = (uint8_t)us[k].code;
+  const size_t lds = (size_t)RT * 128 + (size_t)2 * RT * sizeof(float);
+  HUAL_REQUIRE(lds <= 160 * 1024, "attn fwd: LDS footprint");
   const int nkt = cdiv(maxTk, 16);
-  const int Tkp = 16 * (nkt <= 2 ? 2 : nkt <= 4 ? 4 : nkt <= 8 ? 8 : 16);
-  const size_t lds = (size_t)2 * Tkp * 64 + 2 * Tkp * sizeof(float);
-  // (8 waves per workgroup - one 8-wave workgroup per CU instead of two 4-wave ones - measured equal)
-  if (nkt <= 2) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<2, 256>), grid, block, lds, s, b, n, drop);
-  else if (nkt <= 4) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<4, 256>), grid, block, lds, s, b, n, drop);
-  else if (nkt <= 8) HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<8, 256>), grid, block, lds, s, b, n, drop);
-  else HUAL_LAUNCH(flops, 0.0, (attn_fwd_kernel<16, 256>), grid, block, lds, s, b, n, drop);
+  // eight waves per workgroup when there are units for them (four waves per SIMD at two workgroups per CU)
+  const bool wide = us.size() >= 8;
+  dim3 grid(xcd_round8(maxB) * 8), block(wide ? 512 : 256);
+#define HUAL_ATTN_FWD_LAUNCH(NK)                                                                                         \
+  do {                                                                                                                   \
+    if (wide) { HUAL_DYN_LDS((attn_fwd_kernel<NK, 512>), 160 * 1024); HUAL_LAUNCH(flops, bytes, (attn_fwd_kernel<NK, 512>), grid, block, lds, s, b, n, un, drop); } \
+    else { HUAL_DYN_LDS((attn_fwd_kernel<NK, 256>), 160 * 1024); HUAL_LAUNCH(flops, bytes, (attn_fwd_kernel<NK, 256>), grid, block, lds, s, b, n, un, drop); }      \
+  } while (0)
+  if (nkt <= 2) HUAL_ATTN_FWD_LAUNCH(2);
+  else if (nkt <= 4) HUAL_ATTN_FWD_LAUNCH(4);
+  else if (nkt <= 8) HUAL_ATTN_FWD_LAUNCH(8);
+  else HUAL_ATTN_FWD_LAUNCH(16);
+#undef HUAL_ATTN_FWD_LAUNCH
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -609,20 +736,22 @@ int launch_attn_bwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
   AttnBatch b;
   ::memset((void*)&b, 0, sizeof(b));
   size_t lds = 0;
-  double flops = 0.0;
+  double flops = 0.0, bytes = 0.0;
   for (int i = 0; i < n; ++i) {
     b.j[i] = jobs[i];
     const bool dd = jobs[i].drop_site >= 0 && drop.enabled;
-    const size_t need = (size_t)bwd_lds(jobs[i].Tq, jobs[i].Tk, dd ? jobs[i].ldm : 0).total;
+    const size_t need = (size_t)bwd_lds(jobs[i].Tq, jobs[i].Tk, dd).total;
     lds = need > lds ? need : lds;
     flops += 2.0 * jobs[i].B * 8.0 * jobs[i].Tq * jobs[i].Tk * 16.0;
+    // backward: the forward's reads + dO, dQ rows of the queries and dK, dV rows of the keys
+    bytes += attn_job_bytes(jobs[i], dd) + (double)jobs[i].B * 8.0 * ((double)jobs[i].Tq * 128.0 + (double)jobs[i].Tk * 128.0);
   }
   HUAL_REQUIRE(lds <= 160 * 1024, "attn bwd: LDS footprint");
   HUAL_DYN_LDS(attn_bwd_kernel, 160 * 1024);
   dim3 grid(maxB * 8 * n), block(256);
   // algorithmic work of the backward: FOUR products (dP = dO.V^T, dV = P^T.dO, dK = dS^T.Q, dQ = dS.K) = 8.B.H.Tq.Tk.16; the
   // recomputation of S = Q.K^T is the kernel's choice (it saves storing P) and is not counted
-  HUAL_LAUNCH(4.0 * flops, 0.0, attn_bwd_kernel, grid, block, lds, s, b, n, drop);
+  HUAL_LAUNCH(4.0 * flops, bytes, attn_bwd_kernel, grid, block, lds, s, b, n, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

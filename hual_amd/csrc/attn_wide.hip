@@ -163,7 +163,7 @@ __device__ __forceinline__ void aw_body(const AwArgs& a, int b, int h, char* lds
     for (int kq = 0; kq < NKQ; ++kq) {
       uint32_t w[4] = {0u, 0u, 0u, 0u};
       if (DROP) {
-        const uint4_ rnd = philox4x32_10((uint32_t)(g + 4 * kq), drow, (uint32_t)a.drop_site, off, k0, k1);
+        const uint4_ rnd = philox4x32((uint32_t)(g + 4 * kq), drow, (uint32_t)a.drop_site, off, k0, k1);
         w[0] = rnd.x; w[1] = rnd.y; w[2] = rnd.z; w[3] = rnd.w;
       }
 #pragma unroll

@@ -47,6 +47,41 @@ int ensure_dyn_lds(const void* fn, int bytes);
 // multiple of 8, tiles beyond the end return at once), the same eighth of the row space the attention kernels give it.
 __host__ __device__ inline int xcd_round8(int n) { return (n + 7) & ~7; }
 __device__ __forceinline__ int xcd_tile(int b, int nblk) { return (b & 7) * (nblk >> 3) + (b >> 3); }      // nblk: multiple of 8
+// The same for tiles of MT rows over the UNIFIED row space [Nv video rows | R - Nv query rows]: XCD x takes the tiles that start in
+// video-row eighth x and those that start in query-row eighth x - the rows of clips [B x / 8, B (x + 1) / 8), which is what the
+// attention kernels and the per-clip kernels give XCD x too.  (Plain eighths of the unified rows put clip b's video rows on XCD
+// 128 b / 1184 but its attention on XCD b / 8 at the bench shape, and every query row on XCDs 6 - 7: the attention launches read their
+// 24 MB of projections from another XCD's write-back instead of their own L2.)  Returns the tile id - every real tile exactly once
+// over a grid of xcd_clip_grid() workgroups - or -1.
+__host__ __device__ inline int xcd_clip_t(long rows, int MT) { return (int)((rows + MT - 1) / MT); }
+__device__ __forceinline__ int xcd_tile_clip(int bid, int R, int Nv, int MT) {
+  const int x = bid & 7, slot = bid >> 3;
+  const long nv = Nv > 0 ? Nv : R, nq = R - nv;
+  const int tv0 = xcd_clip_t(nv * x / 8, MT), tv1 = xcd_clip_t(nv * (x + 1) / 8, MT);
+  if (slot < tv1 - tv0) return tv0 + slot;
+  const int tq0 = xcd_clip_t(nv + nq * x / 8, MT), tq1 = xcd_clip_t(nv + nq * (x + 1) / 8, MT);
+  const int s2 = slot - (tv1 - tv0);
+  return s2 < tq1 - tq0 ? tq0 + s2 : -1;
+}
+static inline int xcd_clip_grid(int R, int Nv, int MT);
+// rows per workgroup for R rows (video rows Nv, 0: one row space): the smallest MT >= min_rows that needs no more than one workgroup
+// per CU under the clip order (no XCD gets more than 32 tiles), capped at max_rows
+static inline int xcd_clip_rows(int R, int Nv, int min_rows, int max_rows);
+static inline int xcd_clip_grid(int R, int Nv, int MT) {
+  const long nv = Nv > 0 ? Nv : R, nq = R - nv;
+  int m = 0;
+  for (int x = 0; x < 8; ++x) {
+    const int n = (xcd_clip_t(nv * (x + 1) / 8, MT) - xcd_clip_t(nv * x / 8, MT)) + (xcd_clip_t(nv + nq * (x + 1) / 8, MT) - xcd_clip_t(nv + nq * x / 8, MT));
+    m = n > m ? n : m;
+  }
+  return 8 * m;
+}
+static inline int xcd_clip_rows(int R, int Nv, int min_rows, int max_rows) {
+  int mt = (R + 255) / 256;
+  if (mt < min_rows) mt = min_rows;
+  while (mt < max_rows && xcd_clip_grid(R, Nv, mt) > 256) ++mt;
+  return mt > max_rows ? max_rows : mt;
+}
 
 // ---- dropout parameters shared by every kernel (derived from drop_rate on the host) -----------
 // The Philox key/offset live in DEVICE memory (state[0]=seed lo, [1]=seed hi, [2]=offset) so that a captured

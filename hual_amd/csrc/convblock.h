@@ -31,7 +31,7 @@ struct CbFwdArgs {
   uint32_t drop_row0;
 };
 #define HUAL_CB_MAXMT 46
-int conv_block_fused_rows(int R);            // the MT launch_conv_block_fwd picks for R rows
+int conv_block_fused_rows(int R, int Nv = 0);            // the MT launch_conv_block_fwd picks for R rows
 int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
 
 struct CbLayerBwd {
@@ -53,8 +53,8 @@ struct CbBwdArgs {
   uint32_t drop_row0;
 };
 #define HUAL_CB_BWD_MAXMT 40
-int conv_block_fused_rows_bwd(int R);
-int conv_block_bwd_blocks(int R);
+int conv_block_fused_rows_bwd(int R, int Nv = 0);
+int conv_block_bwd_blocks(int R, int Nv = 0);
 int launch_conv_block_bwd(const CbBwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
 
 }  // namespace hual

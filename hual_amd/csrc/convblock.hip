@@ -35,7 +35,9 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;          // 16 groups of 32 lanes: one row = 32 x float4
   const int col = 4 * l32;
   const int R = rs.R;
-  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;      // XCD-aware tile order (common.h)
+  const int tile_ = xcd_tile_clip(blockIdx.x, rs.R, rs.Nq > 0 ? rs.Nv : 0, MT);      // XCD-aware tile order by clips (common.h)
+  if (tile_ < 0) return;
+  const int r0 = tile_ * MT;
   if (r0 >= rs.R) return;
   const int xbase = r0 - 12;                                 // global row of X[0]
 
@@ -277,7 +279,9 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int R = rs.R;
-  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;      // XCD-aware tile order (common.h)
+  const int tile_ = xcd_tile_clip(blockIdx.x, rs.R, rs.Nq > 0 ? rs.Nv : 0, MT);      // XCD-aware tile order by clips (common.h)
+  if (tile_ < 0) return;
+  const int r0 = tile_ * MT;
   if (r0 >= rs.R) return;
   const int xbase = r0 - 12;
 
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int e = threadIdx.x + CB_THREADS * q;
-        if (e < 9 * HUAL_D) L.part[(size_t)xcd_tile(blockIdx.x, gridDim.x) * 9 * HUAL_D + e] = pacc[q];
+        if (e < 9 * HUAL_D) L.part[(size_t)tile_ * 9 * HUAL_D + e] = pacc[q];
       }
     }
     HUAL_STAMP_K(3, 7 + 7 * (3 - i));
@@ -504,13 +508,10 @@ extern "C" int hual_debug_stamps(unsigned long long* out, int n) {
 
 namespace hual {
 
-int conv_block_fused_rows(int R) {
+int conv_block_fused_rows(int R, int Nv) {
   // as many workgroups as there are CUs when the rows allow it (each workgroup streams all four weight images, so fewer,
   // taller workgroups cost nothing extra), never more than HUAL_CB_MAXMT rows: the halo'd operand must fit 64 rows
-  int mt = cdiv(R, 256);
-  if (mt < 16) mt = 16;
-  if (mt > HUAL_CB_MAXMT) mt = HUAL_CB_MAXMT;
-  return mt;
+  return xcd_clip_rows(R, Nv, 16, HUAL_CB_MAXMT);
 }
 
 static size_t cb_fwd_lds(int MT) { return (size_t)(MT + 24) * CB_XS * 16 + 2 * 64 * 256 + (64 + 72 + 72) * sizeof(float) + 4 * CB_NPAR * 512; }
@@ -526,18 +527,13 @@ int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg&
   const double rows = (double)rs.R;
   // algorithmic work: 4 pointwise products; bytes: x0 in, (c, y, x) out per layer, weights
   HUAL_LAUNCH(4.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 13.0 + 4.0 * HUAL_D * HUAL_D), conv_block_fwd_kernel,
-              dim3(xcd_round8(cdiv(rs.R, a.MT))), dim3(CB_THREADS), cb_fwd_lds(a.MT), s, a, rs, drop);
+              dim3(xcd_clip_grid(rs.R, rs.Nq > 0 ? rs.Nv : 0, a.MT)), dim3(CB_THREADS), cb_fwd_lds(a.MT), s, a, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-int conv_block_fused_rows_bwd(int R) {
-  int mt = cdiv(R, 256);
-  if (mt < 16) mt = 16;
-  if (mt > HUAL_CB_BWD_MAXMT) mt = HUAL_CB_BWD_MAXMT;
-  return mt;
-}
-int conv_block_bwd_blocks(int R) { return cdiv(R, conv_block_fused_rows_bwd(R)); }
+int conv_block_fused_rows_bwd(int R, int Nv) { return xcd_clip_rows(R, Nv, 16, HUAL_CB_BWD_MAXMT); }
+int conv_block_bwd_blocks(int R, int Nv) { return cdiv(R, conv_block_fused_rows_bwd(R, Nv)); }
 
 static size_t cb_bwd_lds(int MT) { return (size_t)(MT + 24) * 512 + 64 * 512 + 64 * sizeof(float) + (1 + 4) * 9 * HUAL_D * sizeof(float); }
 
@@ -551,7 +547,7 @@ int launch_conv_block_bwd(const CbBwdArgs& a, const RowSpace& rs, const DropCfg&
   HUAL_DYN_LDS(conv_block_bwd_kernel, 160 * 1024);
   const double rows = (double)rs.R;
   HUAL_LAUNCH(4.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 14.0 + 4.0 * HUAL_D * HUAL_D), conv_block_bwd_kernel,
-              dim3(xcd_round8(cdiv(rs.R, a.MT))), dim3(CB_THREADS), cb_bwd_lds(a.MT), s, a, rs, drop);
+              dim3(xcd_clip_grid(rs.R, rs.Nq > 0 ? rs.Nv : 0, a.MT)), dim3(CB_THREADS), cb_bwd_lds(a.MT), s, a, rs, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

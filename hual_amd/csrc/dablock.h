@@ -33,9 +33,10 @@ struct LnProjArgs {
   uint8_t* out_bits[HUAL_LNPROJ_MAX];              // ... and where its keep bits go
   int add_x[HUAL_LNPROJ_MAX];                      // 1: + the layer-norm input rows (residual; needs g2 == x2 == null)
   int R; int MT;                                   // rows, rows per workgroup (1..64)
+  int Nv;                                          // unified row space: its first Nv rows are video rows (0: one row space) - XCD order, common.h
   uint32_t drop_row0;
 };
-int ln_proj_rows(int R);
+int ln_proj_rows(int R, int Nv = 0);       // (Nv: video rows of a unified row space - XCD order by clips, common.h)
 int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s);
 int launch_ln_proj_pair(const LnProjArgs& a0, const LnProjArgs& a1, const DropCfg& drop, hipStream_t s);   // two problems, one launch
 
@@ -50,9 +51,10 @@ struct DaPostArgs {
   int site;                // dropout sites site+2 (dense_1 output), site+3 (LN2 output), site+4 (dense_2 output)
   uint8_t *bits2, *bits3, *bits4;   // their keep-bit planes [R][16] bytes (tilecore.h), read by the backward kernels
   int R; int MT;           // MT = 1..48
+  int Nv;                  // unified row space: video rows (0: one row space) - XCD order, common.h
   uint32_t drop_row0;
 };
-int da_post_rows(int R);
+int da_post_rows(int R, int Nv = 0);
 int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s);
 
 }  // namespace hual
@@ -80,13 +82,14 @@ struct LnProjBwdArgs {
   float* dz; const uint8_t* dz_bits;                           // optional: dz = dropout'(dx) with the keep bits dz_bits (null: dz = dx)
   float* part;                                                 // [grid][4][128] partial sums: dgamma1, dbeta1, dgamma2, dbeta2
   int R; int MT; uint32_t drop_row0;
+  int Nv;                  // unified row space: video rows (0: one row space) - XCD order, common.h
   // optional prologue (needs g2 == null, add1 == null): the gradient operand of product 0 is itself a layer norm's input gradient,
   //   dxp = LNbwd(pre_x; pre_dy, pre_g) (+ pre_add);   A[0] := dxp (a_bits[0] / a_save[0] apply as usual);   add1 := dxp
   // and that layer norm's dgamma / dbeta sums take the slots of the second layer norm in `part` (ln_bwd_kernel's arithmetic)
   const float* pre_x; const float* pre_mean; const float* pre_rstd; const float* pre_g; const float* pre_dy; const float* pre_add;
 };
-int ln_proj_bwd_rows(int R);
-int ln_proj_bwd_blocks(int R);
+int ln_proj_bwd_rows(int R, int Nv = 0);
+int ln_proj_bwd_blocks(int R, int Nv = 0);
 int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t s);
 
 // backward of the gated middle of dual_multihead_attention (layers.py:93-110): from dZ1 = dropout'(d res) down to the
@@ -96,7 +99,7 @@ struct DaMidBwdArgs {
   const float *gate, *val, *sg, *xg, *sv, *xv;                 // saved by the forward chain
   const float* w[10];     // transposed images: dense_1, bl1.dense_1, bl2.dense_1, bl1.dense_2, bl2.dense_2, guided, s_gate, x_gate, s_dense, x_dense
   float *d_sc, *d_val, *d_ln1a, *d_g, *dz_sg, *dz_xg, *d_sv, *d_xv, *d_satt, *d_xatt;
-  int R; int MT;
+  int R; int MT; int Nv;   // (Nv: video rows of a unified row space, 0: one row space - XCD order, common.h)
 };
 int launch_da_mid_bwd(const DaMidBwdArgs& a, hipStream_t s);
 

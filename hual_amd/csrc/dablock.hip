@@ -39,8 +39,9 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int MT = a.MT, R = a.R;
-  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
-  if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
+  const int tile_ = xcd_tile_clip(blockIdx.x, R, a.Nv, MT);
+  if (tile_ < 0) return;
+  const int r0 = tile_ * MT;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;
   const DropRegs dr = drop_load(drop);
@@ -190,8 +191,9 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int MT = a.MT, R = a.R;
-  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
-  if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
+  const int tile_ = xcd_tile_clip(blockIdx.x, R, a.Nv, MT);
+  if (tile_ < 0) return;
+  const int r0 = tile_ * MT;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;
   const DropRegs dr = drop_load(drop);
@@ -472,8 +474,9 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int MT = a.MT, R = a.R;
-  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
-  if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
+  const int tile_ = xcd_tile_clip(blockIdx.x, R, a.Nv, MT);
+  if (tile_ < 0) return;
+  const int r0 = tile_ * MT;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;
   const DropRegs dr = drop_load(drop);
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) s += pf[w * 4 * HUAL_D + e];
-    a.part[(size_t)xcd_tile(blockIdx.x, gridDim.x) * 4 * HUAL_D + e] = s;
+    a.part[(size_t)tile_ * 4 * HUAL_D + e] = s;
   }
 }
 
@@ -696,8 +699,9 @@ __global__ __launch_bounds__(CB_THREADS) void da_mid_bwd_kernel(DaMidBwdArgs a) 
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int MT = a.MT, R = a.R;
-  const int r0 = xcd_tile(blockIdx.x, gridDim.x) * MT;
-  if (r0 >= R) return;                        // (grid rounded up to whole XCD rounds)
+  const int tile_ = xcd_tile_clip(blockIdx.x, R, a.Nv, MT);
+  if (tile_ < 0) return;
+  const int r0 = tile_ * MT;                        // (grid rounded up to whole XCD rounds)
   const int RE = min(R, r0 + MT);             // rows [r0, RE) belong to this workgroup (MT need not be a multiple of 16)
   const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;
 
@@ -893,14 +897,9 @@ namespace hual {
 // rows per workgroup: one workgroup per CU when the rows allow it (every workgroup streams all the weight images of its
 // launch, so fewer, taller workgroups cost nothing extra).  Any count from 16 to max_rows: the matrix phase works on
 // whole 16-row tiles, rows of the last tile beyond the workgroup's own are computed on stale operands and discarded.
-static int tile_rows(int R, int max_rows) {
-  int t = cdiv(R, 256);
-  if (t < 16) t = 16;
-  if (t > max_rows) t = max_rows;
-  return t;
-}
-int ln_proj_rows(int R) { return tile_rows(R, LP_ROWS); }
-int da_post_rows(int R) { return tile_rows(R, DP_ROWS); }
+static int tile_rows(int R, int Nv, int max_rows) { return xcd_clip_rows(R, Nv, 16, max_rows); }
+int ln_proj_rows(int R, int Nv) { return tile_rows(R, Nv, LP_ROWS); }
+int da_post_rows(int R, int Nv) { return tile_rows(R, Nv, DP_ROWS); }
 
 static int check_ln_proj(const LnProjArgs& a) {
   HUAL_REQUIRE(a.x && a.g1 && a.b1 && a.y1 && a.mean && a.rstd && a.R > 0, "ln_proj: null / empty");
@@ -929,7 +928,7 @@ int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s) {
   if (rc) return rc;
   double flops = 0.0, bytes = 0.0;
   ln_proj_work(a, flops, bytes);
-  const dim3 grid(xcd_round8(cdiv(a.R, a.MT)));
+  const dim3 grid(xcd_clip_grid(a.R, a.Nv, a.MT));
 #define LN_PROJ_NT(NT) { HUAL_DYN_LDS(ln_proj_kernel<NT>, 160 * 1024); HUAL_LAUNCH(flops, bytes, ln_proj_kernel<NT>, grid, dim3(CB_THREADS), kLnProjLds, s, a, drop); break; }
   switch (cdiv(a.MT, 16)) {      // row tiles per workgroup
     case 1: LN_PROJ_NT(1)
@@ -950,7 +949,7 @@ int launch_ln_proj_pair(const LnProjArgs& a0, const LnProjArgs& a1, const DropCf
   double flops = 0.0, bytes = 0.0;
   ln_proj_work(a0, flops, bytes);
   ln_proj_work(a1, flops, bytes);
-  const dim3 grid(xcd_round8(cdiv(a0.R, a0.MT)), 2);
+  const dim3 grid(xcd_clip_grid(a0.R, a0.Nv, a0.MT), 2);
 #define LN_PROJ_NT(NT) { HUAL_DYN_LDS(ln_proj_pair_kernel<NT>, 160 * 1024); HUAL_LAUNCH(flops, bytes, ln_proj_pair_kernel<NT>, grid, dim3(CB_THREADS), kLnProjLds, s, a0, a1, drop); break; }
   switch (cdiv(a0.MT, 16)) {
     case 1: LN_PROJ_NT(1)
@@ -973,7 +972,7 @@ int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s) {
   const size_t lds = (size_t)3 * DP_SLOT + DP_NB * 512 + (3 * DP_ROWS + 16 * DP_ROWS) * sizeof(float);
   const double rows = (double)a.R;
   const double flops = 11.0 * 2.0 * rows * HUAL_D * HUAL_D, bytes = 4.0 * (rows * HUAL_D * 16.0 + 11.0 * HUAL_D * HUAL_D);
-  const dim3 grid(xcd_round8(cdiv(a.R, a.MT)));
+  const dim3 grid(xcd_clip_grid(a.R, a.Nv, a.MT));
   switch (cdiv(a.MT, 16)) {      // row tiles per workgroup
     case 1: { HUAL_DYN_LDS(da_post_kernel<1>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_post_kernel<1>, grid, dim3(CB_THREADS), lds, s, a, drop); break; }
     case 2: { HUAL_DYN_LDS(da_post_kernel<2>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_post_kernel<2>, grid, dim3(CB_THREADS), lds, s, a, drop); break; }
@@ -983,8 +982,8 @@ int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s) {
   return 0;
 }
 
-int ln_proj_bwd_rows(int R) { return tile_rows(R, LB_ROWS); }
-int ln_proj_bwd_blocks(int R) { return cdiv(R, ln_proj_bwd_rows(R)); }
+int ln_proj_bwd_rows(int R, int Nv) { return tile_rows(R, Nv, LB_ROWS); }
+int ln_proj_bwd_blocks(int R, int Nv) { return cdiv(R, ln_proj_bwd_rows(R, Nv)); }
 
 int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.nsteps >= 1 && a.nsteps <= HUAL_LNBWD_MAX && a.R > 0, "ln_proj_bwd: step count / rows");
@@ -1002,7 +1001,7 @@ int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t 
   const double rows = (double)a.R;
   const double flops = 2.0 * rows * HUAL_D * HUAL_D * a.nsteps;
   const double bytes = 4.0 * (rows * HUAL_D * ((a.pre_x ? 7.0 : 4.0) + a.nsteps) + (double)a.nsteps * HUAL_D * HUAL_D);
-  const dim3 grid(xcd_round8(cdiv(a.R, a.MT)));
+  const dim3 grid(xcd_clip_grid(a.R, a.Nv, a.MT));
 #define LN_BWD_NT(NT)                                                                                                   \
   {                                                                                                                     \
     if (a.pre_x) { HUAL_DYN_LDS((ln_proj_bwd_kernel<true, NT>), 160 * 1024); HUAL_LAUNCH(flops, bytes, (ln_proj_bwd_kernel<true, NT>), grid, dim3(CB_THREADS), lds, s, a, drop); } \
@@ -1027,7 +1026,7 @@ int launch_da_mid_bwd(const DaMidBwdArgs& a, hipStream_t s) {
   const size_t lds = (size_t)3 * DP_SLOT + (3 * DP_ROWS + 16 * DP_ROWS) * sizeof(float);
   const double rows = (double)a.R;
   const double flops = 10.0 * 2.0 * rows * HUAL_D * HUAL_D, bytes = 4.0 * (rows * HUAL_D * 17.0 + 10.0 * HUAL_D * HUAL_D);
-  const dim3 grid(xcd_round8(cdiv(a.R, a.MT)));
+  const dim3 grid(xcd_clip_grid(a.R, a.Nv, a.MT));
   switch (cdiv(a.MT, 16)) {      // row tiles per workgroup
     case 1: { HUAL_DYN_LDS(da_mid_bwd_kernel<1>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_mid_bwd_kernel<1>, grid, dim3(CB_THREADS), lds, s, a); break; }
     case 2: { HUAL_DYN_LDS(da_mid_bwd_kernel<2>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_mid_bwd_kernel<2>, grid, dim3(CB_THREADS), lds, s, a); break; }

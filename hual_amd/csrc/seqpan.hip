@@ -131,8 +131,8 @@ struct Ctx {
   // fused dX products + layer norm(s) backward (dablock.h); the per-workgroup parameter sums are folded in by flush_colsum()
   void ln_proj_bwd(const LnProjBwdArgs& a0, float* dg1, float* db1, float* dg2, float* db2) {
     LnProjBwdArgs a = a0;
-    a.MT = ln_proj_bwd_rows(a.R);
-    const int nblk = ln_proj_bwd_blocks(a.R);
+    a.MT = ln_proj_bwd_rows(a.R, a.Nv);
+    const int nblk = ln_proj_bwd_blocks(a.R, a.Nv);
     a.part = buf("part." + std::to_string(part_seq++), (size_t)nblk * 4, HUAL_D);
     ColsumJob cj{};
     cj.src = a.part; cj.nblk = nblk; cj.nvec = 4;
@@ -175,8 +175,7 @@ void fill_embed_args(Ctx& c, EmbedArgs& ea, const hual_batch* bt, float* cat, in
 // keep-byte buffer of an attention job's probability dropout (attn.h): B*Tq*8 rows of ldm bytes
 // + the softmax statistics the forward leaves for the backward
 void set_dmask(Ctx& c, AttnJob& a, const std::string& name) {
-  a.ldm = attn_ldm(a.Tk);
-  a.dmask = reinterpret_cast<uint8_t*>(c.buf(name, (size_t)a.B * a.Tq * 8, a.ldm / 4));
+  a.dmask = reinterpret_cast<uint8_t*>(c.buf(name, (attn_keep_bytes(a.B, a.Tq, a.Tk) + 3) / 4, 1));
   a.stats = c.buf(name + ".st", (size_t)2 * a.B * a.Tq * 8, 1);
 }
 DwJob mkdw(const float* A, int lda, int K, const float* dY, int ldy, int M, float* dW, float* db, int N = HUAL_D) {
@@ -285,7 +284,7 @@ float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP
   {                      // all four layers in one launch (convblock.h)
     CbFwdArgs a{};
     a.x0 = pos_src ? pos_src : x; a.pos = pos; a.x0_out = pos_src ? x : nullptr;
-    a.MT = conv_block_fused_rows(R); a.drop_row0 = 0;
+    a.MT = conv_block_fused_rows(R, rs.Nq > 0 ? rs.Nv : 0); a.drop_row0 = 0;
     float* xin = x;
     for (int i = 0; i < 4; ++i) {
       const std::string is = std::to_string(i);
@@ -315,8 +314,8 @@ float* conv_block_bwd(Ctx& c, const std::string& tag, float* x0, float* dx, cons
     CbBwdArgs a{};
     a.dx_in = dx; a.relu_bits3 = c.bits(tag + ".rb3", R); a.keep_bits3 = c.bits(tag + ".kb3", R);
     a.dx_out = c.buf("d." + tag + ".x0", R, HUAL_D);
-    a.MT = conv_block_fused_rows_bwd(R); a.drop_row0 = 0;
-    const int nblk = conv_block_bwd_blocks(R);
+    a.MT = conv_block_fused_rows_bwd(R, rs.Nq > 0 ? rs.Nv : 0); a.drop_row0 = 0;
+    const int nblk = conv_block_bwd_blocks(R, rs.Nq > 0 ? rs.Nv : 0);
     for (int i = 3; i >= 0; --i) {
       const std::string is = std::to_string(i);
       CbLayerBwd& L = a.l[i];
@@ -475,7 +474,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       LnProjArgs lp{};
       lp.x = x; lp.g1 = c.p(d.ln1.g); lp.b1 = c.p(d.ln1.b); lp.y1 = ln1; lp.drop_site1 = -1; lp.pre_site = -1;
       lp.g2 = c.p(d.lnt.g); lp.b2 = c.p(d.lnt.b); lp.y2 = lnt; lp.mean = mean; lp.rstd = rstd;
-      lp.nproj = 5; lp.R = R; lp.MT = ln_proj_rows(R); lp.drop_row0 = 0;
+      lp.nproj = 5; lp.R = R; lp.Nv = Nv; lp.MT = ln_proj_rows(R, Nv); lp.drop_row0 = 0;
       const DenseP* pr[5] = {&d.query, &d.f_key, &d.f_value, &d.t_key, &d.t_value};
       float* outs[5] = {qkv, qkv + D, qkv + 2 * D, ktvt, ktvt + D};
       for (int k = 0; k < 5; ++k) {
@@ -532,7 +531,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       pa.ln2_g = c.p(d.ln2.g); pa.ln2_b = c.p(d.ln2.b);
       pa.sv = sv; pa.xv = xv; pa.sg = sg; pa.xg = xg; pa.o = o; pa.gd = gd; pa.gate = gate; pa.val = val; pa.mha = mha; pa.res = res;
       pa.l2 = l2; pa.out = xo; pa.mean2 = mean2; pa.rstd2 = rstd2;
-      pa.site = site; pa.R = R; pa.MT = da_post_rows(R); pa.drop_row0 = 0;
+      pa.site = site; pa.R = R; pa.Nv = Nv; pa.MT = da_post_rows(R, Nv); pa.drop_row0 = 0;
       pa.bits2 = c.bits(t + ".kb2", R); pa.bits3 = c.bits(t + ".kb3", R); pa.bits4 = c.bits(t + ".kb4", R);
       if (c.live()) c.chk(launch_da_post(pa, c.drop, c.stream));
     }
@@ -1042,14 +1041,14 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       if (dz2_ready) { lb.A[0] = dz2; }
       else { lb.A[0] = dx; lb.a_bits[0] = c.bits(t + ".kb4", R); lb.a_save[0] = dz2; }
       lb.dy1_bits = c.bits(t + ".kb3", R); lb.x = res; lb.mean = mean2; lb.rstd = rstd2; lb.g1 = c.p(d.ln2.g); lb.add1 = dx;
-      lb.dx = d_res; lb.dz = dz1; lb.dz_bits = c.bits(t + ".kb2", R); lb.R = R; lb.drop_row0 = 0;
+      lb.dx = d_res; lb.dz = dz1; lb.dz_bits = c.bits(t + ".kb2", R); lb.R = R; lb.Nv = Nv; lb.drop_row0 = 0;
       c.ln_proj_bwd(lb, c.g(d.ln2.g), c.g(d.ln2.b), nullptr, nullptr);
       DaMidBwdArgs mb{};
       mb.dz1 = dz1; mb.gate = gate; mb.val = val; mb.sg = sg; mb.xg = xg; mb.sv = sv; mb.xv = xv;
       const size_t wo[10] = {d.dense1.k, d.bl1_d1, d.bl2_d1, d.bl1_d2, d.bl2_d2, d.guided.k, d.s_gate.k, d.x_gate.k, d.s_dense.k, d.x_dense.k};
       for (int k = 0; k < 10; ++k) mb.w[k] = c.nimg(wo[k]);      // register-resident weights (N images)
       mb.d_sc = d_sc; mb.d_val = d_val; mb.d_ln1a = d_ln1a; mb.d_g = d_g; mb.dz_sg = dz_sg; mb.dz_xg = dz_xg; mb.d_sv = d_sv; mb.d_xv = d_xv;
-      mb.d_satt = d_satt; mb.d_xatt = d_xatt; mb.R = R; mb.MT = da_post_rows(R);
+      mb.d_satt = d_satt; mb.d_xatt = d_xatt; mb.R = R; mb.Nv = Nv; mb.MT = da_post_rows(R, Nv);
       if (c.live()) c.chk(launch_da_mid_bwd(mb, c.stream));
     }
     // the four attentions
@@ -1093,7 +1092,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
       const size_t wo[6] = {d.query.k, d.query.k, d.f_key.k, d.f_value.k, d.t_key.k, d.t_value.k};
       for (int k = 0; k < 6; ++k) { lb.A[k] = As[k]; lb.lda[k] = lds_[k]; lb.wimg_t[k] = imgt(wo[k]); lb.dst[k] = k < 4 ? 0 : 1; }
       lb.add_dy1 = d_ln1a; lb.x = xin; lb.mean = mean; lb.rstd = rstd; lb.g1 = c.p(d.ln1.g); lb.g2 = c.p(d.lnt.g);
-      lb.add1 = d_res; lb.dx = d_xin; lb.dz = nz; lb.dz_bits = nz_bits; lb.R = R; lb.drop_row0 = 0;
+      lb.add1 = d_res; lb.dx = d_xin; lb.dz = nz; lb.dz_bits = nz_bits; lb.R = R; lb.Nv = Nv; lb.drop_row0 = 0;
       c.ln_proj_bwd(lb, c.g(d.ln1.g), c.g(d.ln1.b), c.g(d.lnt.g), c.g(d.lnt.b));
     }
     dx = d_xin;

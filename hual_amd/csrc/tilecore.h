@@ -71,7 +71,7 @@ __device__ __forceinline__ DropRegs drop_load(const hual::DropCfg& d) {
 // t16) - bit e of the result.  Half the generator work per element of the 32-bit scheme of philox.h, keep probability
 // t16 / 65536 (0.800003 for rate 0.2; tf.nn.dropout's own float32 uniform is no finer than 2^-23).
 __device__ __forceinline__ uint32_t drop_bits8_r(const DropRegs& d, uint32_t site, uint32_t row, uint32_t col8) {
-  const uint4_ r = philox4x32_10(col8, row, site, d.off, d.k0, d.k1);
+  const uint4_ r = philox4x32(col8, row, site, d.off, d.k0, d.k1);
   const uint32_t t = d.t16;
   return ((r.x & 0xffffu) < t ? 1u : 0u) | ((r.x >> 16) < t ? 2u : 0u) | ((r.y & 0xffffu) < t ? 4u : 0u) | ((r.y >> 16) < t ? 8u : 0u) |
          ((r.z & 0xffffu) < t ? 16u : 0u) | ((r.z >> 16) < t ? 32u : 0u) | ((r.w & 0xffffu) < t ? 64u : 0u) | ((r.w >> 16) < t ? 128u : 0u);

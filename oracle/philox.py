@@ -4,7 +4,9 @@ The reference draws dropout masks from TensorFlow's stateful RNG
 (`tf.nn.dropout`, e.g. /root/reference/models/modules.py:15,27,69 and the
 sites listed in SURVEY.md §8 a21).  TF's generator cannot be reproduced (TF is
 not installed, version unpinned), so the build defines its own counter-based
-generator - Philox4x32-10 (Salmon et al., SC'11) - and uses it on both sides:
+generator - Philox4x32-7 (Salmon et al., SC'11: the fewest-round variant that passes
+BigCrush; Random123 publishes known-answer vectors for 7 and for 10 rounds, both
+checked in tests/test_oracle.py) - and uses it on both sides:
 the HIP kernels (hual_amd/csrc/philox.h) and this numpy restatement.  With the
 same (seed, offset) the oracle and the kernels drop exactly the same elements,
 which makes parity tests with drop_rate > 0 exact instead of statistical.
@@ -17,11 +19,11 @@ An element is KEPT iff  out < thresh,  thresh = floor((1 - rate) * 2**32)
 (clamped to 2**32-1) and kept elements are scaled by float32(1)/(float32(1)-float32(rate)).
 
 The dropout on the attention probabilities (layers.py:86,91; modules.py:114 - half of all decisions of a step) draws
-16 decisions from the 16 bytes of ONE call (hual_amd/csrc/attn.hip): key k = 16 kt + 4 g + r of RNG row `rid` uses
-the call with c0 = g + 4 (kt >> 2), output word kt & 3, byte r of that word (little endian); the element is KEPT iff
-byte < t8, t8 = round(keep_prob * 256) in [1, 256] (computed from the 32-bit threshold as (thresh + 2**23) >> 24), and kept
-elements are scaled by float32(256) / float32(t8): inverted dropout at the keep probability t8 / 256 closest to
-1 - rate (0.80078 for rate 0.2), unbiased.
+8 decisions from the eight 16-bit halves of ONE call (hual_amd/csrc/attn.hip): key k = 16 kt + 4 g + r of RNG row `rid` uses
+the call with c0 = g + 4 (kt >> 1), output word 2 (kt & 1) + (r >> 1), half r & 1 (little endian) - the order in which a
+lane of the forward kernel holds its scores; the element is KEPT iff half < t16 and kept elements are scaled by
+1 / (1 - rate) exactly as tf.nn.dropout does (`mask_attn`; rounds 1-3 used 8-bit decisions with the scale 256 / t8, which
+`mask8` still restates for the head-size-64 demonstration kernel csrc/attn_wide.hip).
 
 The row-local sites INSIDE the network (every dropout of conv_block, dual_attn_block and the predictor's feature encoders
 that is not an attention-probability site: SITE_CONV+l, SITE_DA+8li+{2,3,4}, SITE_FE+16p+{0..4,6,7,8}) draw 8 decisions
@@ -52,8 +54,11 @@ SITE_TRI = 24        # +{0 q2v.x1(v rows), 1 q2v.x2(q rows), 2 v2q.x1(q rows), 3
 SITE_FE = 32         # +16*pass + {0..3 conv layer, 4 LN1 out, 5 attn probs, 6 attn out, 7 LN2 out, 8 dense out}
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Vectorised Philox4x32-10.  All inputs broadcastable uint32-valued arrays."""
+PHILOX_ROUNDS = 7    # hual_amd/csrc/philox.h HUAL_PHILOX_ROUNDS
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=PHILOX_ROUNDS):
+    """Vectorised Philox4x32-<rounds>.  All inputs broadcastable uint32-valued arrays."""
     c0 = np.asarray(c0, dtype=np.uint64) & MASK32
     c1 = np.asarray(c1, dtype=np.uint64) & MASK32
     c2 = np.asarray(c2, dtype=np.uint64) & MASK32
@@ -61,7 +66,7 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
     k0 = int(k0) & 0xFFFFFFFF
     k1 = int(k1) & 0xFFFFFFFF
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = PHILOX_M0 * c0
         p1 = PHILOX_M1 * c2
         hi0, lo0 = p0 >> np.uint64(32), p0 & MASK32
@@ -72,6 +77,11 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
         k0 = (k0 + PHILOX_W0) & 0xFFFFFFFF
         k1 = (k1 + PHILOX_W1) & 0xFFFFFFFF
     return (c0.astype(np.uint32), c1.astype(np.uint32), c2.astype(np.uint32), c3.astype(np.uint32))
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """the 10-round generator (Random123's default; the build's generator in rounds 1-3), kept for its known-answer test"""
+    return philox4x32(c0, c1, c2, c3, k0, k1, rounds=10)
 
 
 def keep_threshold(rate):
@@ -128,7 +138,7 @@ class DropoutRNG:
         rows = np.asarray(rows, dtype=np.uint64).reshape(-1, 1)
         nblk = (ncols + 3) // 4
         c0 = np.arange(nblk, dtype=np.uint64).reshape(1, -1)
-        o = philox4x32_10(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
+        o = philox4x32(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
         out = np.stack(o, axis=-1).reshape(rows.shape[0], nblk * 4)
         return out[:, :ncols]
 
@@ -137,7 +147,7 @@ class DropoutRNG:
         rows = np.atleast_1d(np.asarray(rows, dtype=np.uint64)).reshape(-1, 1)
         nblk = (ncols + 7) // 8
         c0 = np.arange(nblk, dtype=np.uint64).reshape(1, -1)
-        o = philox4x32_10(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
+        o = philox4x32(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
         words = np.stack(o, axis=-1)                                   # [rows, call, word]
         halves = np.stack([words & np.uint32(0xFFFF), words >> np.uint32(16)], axis=-1)     # [rows, call, word, half]
         h = halves.reshape(rows.shape[0], nblk * 8)[:, :ncols]
@@ -151,6 +161,22 @@ class DropoutRNG:
         b = self.bits(site, rows, ncols)
         return np.where(b < np.uint32(self.thresh), self.scale, np.float32(0.0)).astype(np.float32)
 
+    def mask_attn(self, site, rows, ncols):
+        """16-bit decisions of the attention-probability sites in the forward kernel's lane order (module docstring):
+        [len(rows), ncols] float32 of {0, 1 / (1 - rate)}."""
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.uint64)).reshape(-1, 1)
+        if self.rate == 0.0:
+            return np.ones((rows.shape[0], ncols), dtype=np.float32)
+        k = np.arange(ncols, dtype=np.int64)
+        kt, g, r = k >> 4, (k >> 2) & 3, k & 3
+        ncall = 4 * ((int(kt.max()) >> 1) + 1)
+        c0 = np.arange(ncall, dtype=np.uint64).reshape(1, -1)
+        o = philox4x32(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
+        words = np.stack(o, axis=-1)                                   # [rows, call, word]
+        w = words[:, g + 4 * (kt >> 1), 2 * (kt & 1) + (r >> 1)]       # [rows, ncols]
+        half = (w >> (16 * (r & 1)).astype(np.uint32)) & np.uint32(0xFFFF)
+        return np.where(half < np.uint32(self.t16), self.scale, np.float32(0.0)).astype(np.float32)
+
     def mask8(self, site, rows, ncols):
         """8-bit decisions of the attention-probability sites: [len(rows), ncols] float32 of {0, 256 / t8}."""
         rows = np.atleast_1d(np.asarray(rows, dtype=np.uint64)).reshape(-1, 1)
@@ -160,7 +186,7 @@ class DropoutRNG:
         kt, g, r = k >> 4, (k >> 2) & 3, k & 3
         ncall = 4 * ((int(kt.max()) >> 2) + 1)
         c0 = np.arange(ncall, dtype=np.uint64).reshape(1, -1)
-        o = philox4x32_10(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
+        o = philox4x32(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
         words = np.stack(o, axis=-1)                                   # [rows, call, word]
         w = words[:, g + 4 * (kt >> 2), kt & 3]                        # [rows, ncols]
         byte = (w >> (8 * r).astype(np.uint32)) & np.uint32(0xFF)

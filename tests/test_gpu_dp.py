@@ -84,11 +84,14 @@ def test_dp_path_on_one_rank_matches_single_path(rccl_group):
 
     def per_tensor(step):
         g0, g1 = ms[0].grads_dict(), ms[1].grads_dict()
+        gmax = max(float(np.abs(v).max()) for v in g0.values())
         for k in g0:
-            scale = max(float(np.abs(g0[k]).max()), 1e-6)
+            # (floor: a tensor whose gradient is mathematically zero - the key biases, softmax is invariant to them - holds rounding
+            #  noise of the products it is the difference of; 1e-3 of the largest gradient of the step is far below any real entry)
+            scale = max(float(np.abs(g0[k]).max()), 1e-3 * gmax)
             d = float(np.abs(g0[k] - g1[k]).max())
             # the two paths differ by the summation order of the alignment loss and of the float atomics of the weight gradients
-            assert d <= 2e-4 * scale + 1e-7, (step, k, d, scale)
+            assert d <= 2e-4 * scale, (step, k, d, scale)
 
     for step in range(2):
         if step == 1:                                # same state on both sides before step 2

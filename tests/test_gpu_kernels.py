@@ -45,8 +45,8 @@ def _attn_case(dev, B, Tq, Tk, seed):
 
 
 def _attn_ref(Q, K, V, qm, km, B, Tq, Tk, drop=None):
-    """float64 restatement of layers.py:80-96 for merged heads; drop = (seed, offset, rate, site) uses the oracle's 8-bit
-    Philox decisions (oracle/philox.py mask8) with RNG row = query row * 8 + head"""
+    """float64 restatement of layers.py:80-96 for merged heads; drop = (seed, offset, rate, site) uses the oracle's 16-bit
+    Philox decisions (oracle/philox.py mask_attn) with RNG row = query row * 8 + head"""
     q = Q.view(B, Tq, 8, 16).transpose(1, 2)
     k = K.view(B, Tk, 8, 16).transpose(1, 2)
     v = V.view(B, Tk, 8, 16).transpose(1, 2)
@@ -59,7 +59,7 @@ def _attn_ref(Q, K, V, qm, km, B, Tq, Tk, drop=None):
         seed, offset, rate, site = drop
         rng = px.DropoutRNG(seed, offset, rate)
         rid = (np.arange(B * Tq).reshape(B, 1, Tq) * 8 + np.arange(8).reshape(1, 8, 1)).reshape(-1)
-        m = torch.from_numpy(rng.mask8(site, rid, Tk)).to(pr.dtype).reshape(B, 8, Tq, Tk).to(pr.device)
+        m = torch.from_numpy(rng.mask_attn(site, rid, Tk)).to(pr.dtype).reshape(B, 8, Tq, Tk).to(pr.device)
         pr = pr * m
     return (pr @ v).transpose(1, 2).reshape(B * Tq, 128)
 

@@ -33,6 +33,15 @@ def test_philox_known_answers():
         == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
+def test_philox7_known_answers():
+    """the generator the build uses since round 4: Philox4x32-7, Random123 kat_vectors ("philox4x32 7 ...")"""
+    assert px.PHILOX_ROUNDS == 7
+    assert [int(x) for x in px.philox4x32(0, 0, 0, 0, 0, 0)] == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    assert [int(x) for x in px.philox4x32(*([0xffffffff] * 6))] == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    assert [int(x) for x in px.philox4x32(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)] \
+        == [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
+
+
 def test_dropout_mask_statistics():
     r = px.DropoutRNG(seed=7, offset=3, rate=0.2)
     m = r.mask(px.SITE_VIDEO, np.arange(512), 1024)
