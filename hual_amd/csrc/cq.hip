@@ -3,6 +3,7 @@
 // K-contiguous (float4 fragment loads) or K-strided (4 scalar loads) - same fragment maps as gemm.hip/attn.hip.
 #include <stdlib.h>
 #include "cq.h"
+#include "bf16x3.h"
 #include "philox.h"
 #include "prof.h"
 
@@ -75,10 +76,13 @@ __device__ __forceinline__ ClipGeom clip_geom(const RowSpace& rs, int clip, int 
   c.ld = c.N2p + 4;
   return c;
 }
-__host__ __device__ inline size_t cq_mat_elems(int T, int L) {   // max over both directions of N1p*(N2p+4)
+__host__ __device__ inline size_t cq_mat_elems(int T, int L) {   // max over both directions of N1p*(N2p+4); room for the staged kernels' image too
   int Tp = (T + 15) & ~15, Lp = (L + 15) & ~15;
   size_t a = (size_t)Tp * (Lp + 4), b = (size_t)Lp * (Tp + 4);
-  return a > b ? a : b;
+  const int Tq = (T + 31) & ~31, Lq = (L + 31) & ~31;
+  const size_t im = (size_t)(Tq < Lq ? Tq : Lq) * 128;      // [short side][128] bf16 hi + lo planes = 512 bytes per row
+  a = a > b ? a : b;
+  return a > im ? a : im;
 }
 __host__ __device__ inline size_t cq_m2_rows(int T, int L) {
   int Tp = (T + 15) & ~15, Lp = (L + 15) & ~15;
@@ -248,56 +252,131 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
 }
 
 // ------------------------------------------------------------------------------------------------------
-// cq_fwd_staged_kernel: the same computation for clips whose operands fit LDS next to the three score matrices
-// (T + L <= 160 rows after padding).  In cq_fwd_kernel every matrix phase starts with round trips to the memory side
-// for its [rows,128] operands (~2 us each on a loaded chip: the rows were written by other XCDs) and the phases of a clip
-// are strictly ordered, so the kernel ran at 70 k cycles per clip for 20 k cycles of work.  Here the operands of a
-// phase are staged in LDS ([rows][CQ_LDX] floats: 16 rows x one float4 cover the 64 banks) and the next phase's operands
-// are requested while the current one computes:
-//   bufA (x1 rows): D1W, then X1          bufB (x2 rows): D2, then X2, then M2
-#define CQ_LDX 132
-#define CQ_STAGE_MAX 5          // float4 per thread of a 1024-thread workgroup: (N1p + N2p) * 32 / 1024
+// Staged kernels (clips whose operands fit LDS: every shape of the YAML configs; longer clips run cq_fwd_kernel / cq_bwd_kernel
+// above on operands in global memory).  Round 4: every product on the 16-bit matrix pipe with split fp32 operands (bf16 hi + lo,
+// hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16: 3/16 of the fp32-MFMA time the round 1-3 kernels were bound by, and operand
+// fragments by ONE wide LDS read instead of four scalar ones for the row-strided operands).
+//
+// Operand IMAGES in LDS: [rows][128] bf16 high parts + [rows][128] bf16 residuals (a plane = rows x 256 B), 256-byte rows with the XOR
+// swizzle of tile256_off (bf16x3.h) that keeps both kinds of fragment read conflict free:
+//   * direct     - element (x, k) at image[row x][col k]: the operand's non-contraction index is the image row (one ds_read_b128);
+//   * transposed - element (x, k) at image[row k][col x]: the contraction runs over the image rows (ds_read_b64_tr_b16).
+// An element is split ONCE, when it is written into an image; every product reads fragments of both planes.
+//   bufA (x1 rows), bufB (x2 rows): row images of the [rows,128] operands of the current phase (rows padded to 32 with zeros);
+//   SrI, ScI (dscore in the backward): the softmax matrices, stored with the LONGER of (N1, N2) along the 128 columns and the
+//   shorter one along the rows (template LONG1: N1 is the column index) - also the layout in which they are saved for the backward.
+struct CqImg { char* p; int plane; };
+__device__ __forceinline__ CqImg cq_img(char* p, int rows) { CqImg im; im.p = p; im.plane = rows * 256; return im; }
+__device__ __forceinline__ void cq_img_store4(const CqImg& im, int row, int col, const float4& v) {      // cols col .. col + 3, col % 4 == 0
+  uint2 h, l;
+  bf16_split4(v, h, l);
+  const int off = tile256_off(row, col >> 3) + 2 * (col & 7);
+  *reinterpret_cast<uint2*>(im.p + off) = h;
+  *reinterpret_cast<uint2*>(im.p + im.plane + off) = l;
+}
+__device__ __forceinline__ void cq_img_store1(const CqImg& im, int row, int col, float v) {
+  uint32_t h, l;
+  bf16_split_pair(v, 0.f, h, l);
+  const int off = tile256_off(row, col >> 3) + 2 * (col & 7);
+  *reinterpret_cast<uint16_t*>(im.p + off) = (uint16_t)h;
+  *reinterpret_cast<uint16_t*>(im.p + im.plane + off) = (uint16_t)l;
+}
+__device__ __forceinline__ float cq_img_load1(const CqImg& im, int row, int col) {      // hi + lo: the value to 2^-17
+  const int off = tile256_off(row, col >> 3) + 2 * (col & 7);
+  const uint32_t h = *reinterpret_cast<const uint16_t*>(im.p + off), l = *reinterpret_cast<const uint16_t*>(im.p + im.plane + off);
+  return __uint_as_float(h << 16) + __uint_as_float(l << 16);
+}
+// fragment of the 16 x 32 operand block (non-contraction indices x0 .. x0 + 15, contraction indices k0 .. k0 + 31): lane (j, g) holds
+// element (x0 + j, k0 + 8 g + e), e = 0..7 - the A and the B map of v_mfma_f32_16x16x32_bf16 alike
+template <bool TR>
+__device__ __forceinline__ void cq_frag(const CqImg& im, int x0, int k0, int lane, bf16x8& hi, bf16x8& lo) {
+  if (!TR) {
+    const int off = tile256_off(x0 + (lane & 15), (k0 >> 3) + (lane >> 4));
+    hi = *reinterpret_cast<const bf16x8*>(im.p + off);
+    lo = *reinterpret_cast<const bf16x8*>(im.p + im.plane + off);
+  } else {      // lane 4 q + p of a 16-lane group supplies row q, columns 4 p .. 4 p + 3 of the group's 4 x 16 block (EXEC all ones)
+    const int q = (lane & 15) >> 2, pp = lane & 3, r = k0 + 8 * (lane >> 4) + q, ch = (x0 >> 3) + (pp >> 1);
+    const int o1 = tile256_off(r, ch) + 8 * (pp & 1), o2 = tile256_off(r + 4, ch) + 8 * (pp & 1);
+    hi = join_tr(lds_read_tr16(im.p, o1), lds_read_tr16(im.p, o2));
+    lo = join_tr(lds_read_tr16(im.p + im.plane, o1), lds_read_tr16(im.p + im.plane, o2));
+  }
+}
+// C tile [m0, m0 + 16) x [n0, n0 + 16) += sum over k < K (K % 32 == 0) of A(m, k) B(k, n); lane (j, g) register r = C[m0 + 4 g + r][n0 + j]
+template <bool AT, bool BT>
+__device__ __forceinline__ f32x4 cq_mma(const CqImg& A, int m0, const CqImg& B, int n0, int K, int lane, f32x4 acc) {
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    bf16x8 ah, al, bh, bl;
+    cq_frag<AT>(A, m0, k0, lane, ah, al);
+    cq_frag<BT>(B, n0, k0, lane, bh, bl);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// score-matrix images: element (i, j) at [row j][col i] when LONG1 (N1 is the longer side), else [row i][col j]
+template <bool LONG1> __device__ __forceinline__ void cq_sc_store(const CqImg& im, int i, int j, float v) { cq_img_store1(im, LONG1 ? j : i, LONG1 ? i : j, v); }
+template <bool LONG1> __device__ __forceinline__ float cq_sc_load(const CqImg& im, int i, int j) { return cq_img_load1(im, LONG1 ? j : i, LONG1 ? i : j); }
+
+#define CQ_STAGE_MAX 5          // float4 per thread of a 1024-thread workgroup: (N1q + N2q) * 32 / 1024
 struct CqRows { float4 v[CQ_STAGE_MAX]; };
-// request rows [0,n1) of A (N1p staged rows) and [0,n2) of B (N2p staged rows), zero beyond
-__device__ __forceinline__ void cq_rows_load(CqRows& r, const float* A, int n1, int N1p, const float* B, int n2, int N2p) {
+__device__ __forceinline__ int cq_r32(int n) { return (n + 31) & ~31; }
+// request rows [0, n1) of A (N1q staged rows) and [0, n2) of B (N2q staged rows), zero beyond
+__device__ __forceinline__ void cq_rows_load(CqRows& r, const float* A, int n1, int N1q, const float* B, int n2, int N2q) {
 #pragma unroll
   for (int u = 0; u < CQ_STAGE_MAX; ++u) {
     const int idx = threadIdx.x + CQ_MAX_THREADS * u, row = idx >> 5, c4 = idx & 31;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < N1p) { if (row < n1) v = ld4(A + (size_t)row * HUAL_D + 4 * c4); }
-    else if (row - N1p < n2) v = ld4(B + (size_t)(row - N1p) * HUAL_D + 4 * c4);
+    if (row < N1q) { if (row < n1) v = ld4(A + (size_t)row * HUAL_D + 4 * c4); }
+    else if (row - N1q < n2) v = ld4(B + (size_t)(row - N1q) * HUAL_D + 4 * c4);
     r.v[u] = v;
   }
 }
-__device__ __forceinline__ void cq_rows_store(const CqRows& r, float* bufA, int N1p, float* bufB, int N2p) {
+// split the rows into the images of bufA (N1q rows) and bufB (N2q rows; 0: bufB is left alone)
+__device__ __forceinline__ void cq_rows_store(const CqRows& r, const CqImg& A, int N1q, const CqImg& B, int N2q) {
 #pragma unroll
   for (int u = 0; u < CQ_STAGE_MAX; ++u) {
     const int idx = threadIdx.x + CQ_MAX_THREADS * u, row = idx >> 5, c4 = idx & 31;
-    if (row < N1p) *reinterpret_cast<float4*>(bufA + row * CQ_LDX + 4 * c4) = r.v[u];
-    else if (row - N1p < N2p) *reinterpret_cast<float4*>(bufB + (row - N1p) * CQ_LDX + 4 * c4) = r.v[u];
+    if (row < N1q) cq_img_store4(A, row, 4 * c4, r.v[u]);
+    else if (row - N1q < N2q) cq_img_store4(B, row - N1q, 4 * c4, r.v[u]);
   }
 }
-
+struct CqLds { int s, sri, sci, m, bufa, bufb, total, N1q, N2q, Sq; };
+// byte offsets of the staged kernels' LDS regions: nf32 fp32 score matrices [N1p][ld], two score images, masks / rank-1 terms, bufA, bufB
+__host__ __device__ inline CqLds cq_lds_map(int N1, int N2, int nf32) {
+  CqLds l;
+  const int N1p = (N1 + 15) & ~15, N2p = (N2 + 15) & ~15;
+  l.N1q = (N1 + 31) & ~31; l.N2q = (N2 + 31) & ~31;
+  l.Sq = l.N1q >= l.N2q ? l.N2q : l.N1q;
+  int o = 0;
+  l.s = o; o += nf32 * N1p * (N2p + 4) * 4;
+  l.sri = o; o += l.Sq * 512;
+  l.sci = o; o += l.Sq * 512;
+  l.m = o; o += 2 * (N1p + N2p) * 4 + 64;
+  o = (o + 15) & ~15;
+  l.bufa = o; o += l.N1q * 512;
+  l.bufb = o; o += l.N2q * 512;
+  l.total = o;
+  return l;
+}
 // (the tri_prep step - dropout on both roles of a row, the rank-1 terms, ops.py:104-114 - happens here on the rows as they are
 //  staged: in direction `dir` the x1 rows of the clip get their D1W / S0, the x2 rows their D2 / S1, so over the two directions
 //  every row is prepared exactly once in each role; the prepared rows are also written out for the backward pass)
-__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b, CqParams p, RowSpace rs, DropCfg drop) {
-  extern __shared__ float lds[];
-  const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
-  if (clip >= rs.B) return;
+template <bool LONG1>
+__device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, int clip, int dir,
+                                                   char* lds) {
   const ClipGeom c = clip_geom(rs, clip, dir);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int msz = c.N1p * c.ld;
-  float* S = lds;
-  float* Sr = lds + msz;
-  float* Sc = lds + 2 * msz;
-  float* m1 = lds + 3 * msz;            // row masks and rank-1 terms of the clip: m1, s0 [N1p]; m2, s1 [N2p]
+  const CqLds L = cq_lds_map(c.N1, c.N2, 1);
+  const int N1q = L.N1q, N2q = L.N2q;
+  float* S = reinterpret_cast<float*>(lds + L.s);
+  const CqImg SrI = cq_img(lds + L.sri, L.Sq), ScI = cq_img(lds + L.sci, L.Sq);
+  float* m1 = reinterpret_cast<float*>(lds + L.m);            // row masks and rank-1 terms of the clip: m1, s0 [N1p]; m2, s1 [N2p]
   float* m2 = m1 + c.N1p;
   float* s0 = m2 + c.N2p;
   float* s1 = s0 + c.N1p;
-  float* bufA = s1 + c.N2p;             // [N1p][CQ_LDX]
-  float* bufB = bufA + c.N1p * CQ_LDX;  // [N2p][CQ_LDX]
+  const CqImg bufA = cq_img(lds + L.bufa, N1q), bufB = cq_img(lds + L.bufb, N2q);
   const float* X1 = b.X + (size_t)c.x1base * HUAL_D;
   const float* X2 = b.X + (size_t)c.x2base * HUAL_D;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -305,7 +384,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
   CQ_STAMP(0);
   // ---- stage the rows (X1, X2) and the masks: one round trip; D1W / D2 and the rank-1 terms are formed from the rows in registers
   CqRows rows, xrows;
-  cq_rows_load(xrows, X1, c.N1, c.N1p, X2, c.N2, c.N2p);
+  cq_rows_load(xrows, X1, c.N1, N1q, X2, c.N2, N2q);
   {
     const int idx = threadIdx.x;
     if (idx < c.N1p + c.N2p) {
@@ -321,8 +400,8 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
 #pragma unroll
     for (int u = 0; u < CQ_STAGE_MAX; ++u) {
       const int idx = threadIdx.x + CQ_MAX_THREADS * u, row = idx >> 5;
-      const bool first = row < c.N1p;
-      const int k = first ? row : row - c.N1p;
+      const bool first = row < N1q;
+      const int k = first ? row : row - N1q;
       const bool live = first ? k < c.N1 : k < c.N2;
       const int grow = (first ? c.x1base : c.x2base) + (live ? k : 0);      // unified row (dropout counter, destination)
       float4 x = xrows.v[u];
@@ -331,8 +410,8 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
       const float sv = half_sum32(x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w);
       const float4 o = first ? make_float4(x.x * wm.x, x.y * wm.y, x.z * wm.z, x.w * wm.w) : x;
       rows.v[u] = o;
-      if (row < c.N1p + c.N2p) {
-        if (c4 == 0) s0[row] = live ? sv : 0.f;          // (s1 follows s0)
+      if (row < N1q + N2q && k < (first ? c.N1p : c.N2p)) {
+        if (c4 == 0) (first ? s0 : s1)[k] = live ? sv : 0.f;
         if (live) {
           st4((first ? b.D1W : b.D2) + (size_t)grow * HUAL_D + 4 * c4, o);
           if (c4 == 0) (first ? b.S0 : b.S1)[grow] = sv;
@@ -340,25 +419,24 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
       }
     }
   }
-  cq_rows_store(rows, bufA, c.N1p, bufB, c.N2p);
+  cq_rows_store(rows, bufA, N1q, bufB, N2q);
   __syncthreads();
   CQ_STAMP(1);
   // ---- score = d1w . d2^T + s0 + s1
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
-    f32x4 acc = tile_mma<true, true>(bufA, CQ_LDX, c.N1p, bufB, CQ_LDX, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
+    const f32x4 acc = cq_mma<false, false>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[(i0 + 4 * g + r) * c.ld + n0 + j] = acc[r] + s0[i0 + 4 * g + r] + s1[n0 + j];
   }
   __syncthreads();
   CQ_STAMP(2);
-  cq_rows_store(xrows, bufA, c.N1p, bufB, c.N2p);      // X1, X2
-  // ---- row softmax over j with mask2 (layers.py:122-123) ; zero outside the valid block.  Rows of at most 32 columns go
-  // two per wave (a 32-lane half each; the half-wave reductions add the same pairs in the same order as wave_*64 with
-  // the upper half idle, so the values are those of cq_fwd_kernel)
-  if (c.N2p <= 32) {
+  cq_rows_store(xrows, bufA, N1q, bufB, N2q);      // X1, X2
+  // ---- row softmax over j with mask2 (layers.py:122-123); zero outside the valid block (the images are read up to N1q x N2q).
+  // Rows of at most 32 columns go two per wave (a 32-lane half each)
+  if (N2q <= 32) {
     const int hh = lane >> 5, l32 = lane & 31;
-    for (int i = 2 * wave + hh; i < c.N1p; i += 2 * CQ_WAVES) {
+    for (int i = 2 * wave + hh; i < N1q; i += 2 * CQ_WAVES) {
       const bool ok = i < c.N1 && l32 < c.N2;
       float lg = -INFINITY;
       if (ok) {
@@ -368,10 +446,10 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
       const float mx = half_max32(lg);
       const float e = ok ? __expf(lg - mx) : 0.f;
       const float inv = 1.0f / half_sum32(e);
-      if (l32 < c.N2p) Sr[i * c.ld + l32] = ok ? e * inv : 0.f;
+      cq_sc_store<LONG1>(SrI, i, l32, ok ? e * inv : 0.f);
     }
   } else {
-    for (int i = wave; i < c.N1p; i += CQ_WAVES) {
+    for (int i = wave; i < N1q; i += CQ_WAVES) {
       float mx = -INFINITY;
       if (i < c.N1)
         for (int jj = lane; jj < c.N2; jj += 64) {
@@ -387,20 +465,20 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
         }
       sum = wave_sum64(sum);
       const float inv = 1.0f / sum;
-      for (int jj = lane; jj < c.N2p; jj += 64) {
+      for (int jj = lane; jj < N2q; jj += 64) {
         float v = 0.f;
         if (i < c.N1 && jj < c.N2) {
           const float mk = m2[jj];
           v = __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx) * inv;
         }
-        Sr[i * c.ld + jj] = v;
+        cq_sc_store<LONG1>(SrI, i, jj, v);
       }
     }
   }
   // ---- column softmax over i with mask1 (layers.py:124-125); columns of at most 32 rows go two per wave
-  if (c.N1p <= 32) {
+  if (N1q <= 32) {
     const int hh = lane >> 5, l32 = lane & 31;
-    for (int jj = 2 * wave + hh; jj < c.N2p; jj += 2 * CQ_WAVES) {
+    for (int jj = 2 * wave + hh; jj < N2q; jj += 2 * CQ_WAVES) {
       const bool ok = jj < c.N2 && l32 < c.N1;
       float lg = -INFINITY;
       if (ok) {
@@ -410,10 +488,10 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
       const float mx = half_max32(lg);
       const float e = ok ? __expf(lg - mx) : 0.f;
       const float inv = 1.0f / half_sum32(e);
-      if (l32 < c.N1p) Sc[l32 * c.ld + jj] = ok ? e * inv : 0.f;
+      cq_sc_store<LONG1>(ScI, l32, jj, ok ? e * inv : 0.f);
     }
   } else {
-    for (int jj = wave; jj < c.N2p; jj += CQ_WAVES) {
+    for (int jj = wave; jj < N2q; jj += CQ_WAVES) {
       float mx = -INFINITY;
       if (jj < c.N2)
         for (int i = lane; i < c.N1; i += 64) {
@@ -429,29 +507,33 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
         }
       sum = wave_sum64(sum);
       const float inv = 1.0f / sum;
-      for (int i = lane; i < c.N1p; i += 64) {
+      for (int i = lane; i < N1q; i += 64) {
         float v = 0.f;
         if (i < c.N1 && jj < c.N2) {
           const float mk = m1[i];
           v = __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx) * inv;
         }
-        Sc[i * c.ld + jj] = v;
+        cq_sc_store<LONG1>(ScI, i, jj, v);
       }
     }
   }
   __syncthreads();
   CQ_STAMP(3);
-  // ---- save both softmaxes for the backward pass
-  const size_t mat = cq_mat_elems(rs.T, rs.L);
-  float* gSr = b.SR + ((size_t)dir * rs.B + clip) * mat;
-  float* gSc = b.SC + ((size_t)dir * rs.B + clip) * mat;
-  for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { gSr[idx] = Sr[idx]; gSc[idx] = Sc[idx]; }
+  // ---- save both softmaxes for the backward pass: the images as they stand (both planes)
+  {
+    const size_t mat = cq_mat_elems(rs.T, rs.L);
+    float4* gSr = reinterpret_cast<float4*>(b.SR + ((size_t)dir * rs.B + clip) * mat);
+    float4* gSc = reinterpret_cast<float4*>(b.SC + ((size_t)dir * rs.B + clip) * mat);
+    const float4* lr = reinterpret_cast<const float4*>(SrI.p);
+    const float4* lc = reinterpret_cast<const float4*>(ScI.p);
+    for (int idx = threadIdx.x; idx < L.Sq * 32; idx += CQ_THREADS) { gSr[idx] = lr[idx]; gSc[idx] = lc[idx]; }
+  }
   CQ_STAMP(4);
   // ---- c2q = Sr . x2   and   M2 = Sc^T . x1 (kept in registers until every wave is done with X2)
   float* M2 = b.M2 + ((size_t)dir * rs.B + clip) * cq_m2_rows(rs.T, rs.L) * HUAL_D;
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    f32x4 acc = tile_mma<true, false>(Sr, c.ld, c.N1p, bufB, CQ_LDX, HUAL_D, c.N2p, c.N2p, c.N2p, i0, n0, j, g, zero);
+    const f32x4 acc = cq_mma<LONG1, true>(SrI, i0, bufB, n0, N2q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * g + r;
@@ -459,26 +541,27 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
     }
   }
   CQ_STAMP(5);
-  f32x4 m2acc[4];                        // nj * 8 <= 64 tiles over 16 waves
+  const int njq = N2q >> 4;              // M2 rows up to N2q (zero beyond N2: Sc is zero there), the contraction length of q2c
+  f32x4 m2acc[4];                        // njq * 8 <= 64 tiles over 16 waves
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tile = wave + CQ_WAVES * q;
     m2acc[q] = zero;
-    if (tile < nj * 8) {
+    if (tile < njq * 8) {
       const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;   // rows of M2 = index j of the score
-      m2acc[q] = tile_mma<false, false>(Sc, c.ld, c.N2p, bufA, CQ_LDX, HUAL_D, c.N1p, c.N1p, c.N1p, i0, n0, j, g, zero);
+      m2acc[q] = cq_mma<!LONG1, true>(ScI, i0, bufA, n0, N1q, lane, zero);
     }
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tile = wave + CQ_WAVES * q;
-    if (tile < nj * 8) {
+    if (tile < njq * 8) {
       const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        M2[(size_t)(i0 + 4 * g + r) * HUAL_D + n0 + j] = m2acc[q][r];
-        bufB[(i0 + 4 * g + r) * CQ_LDX + n0 + j] = m2acc[q][r];
+        if (i0 + 4 * g + r < c.N2p) M2[(size_t)(i0 + 4 * g + r) * HUAL_D + n0 + j] = m2acc[q][r];
+        cq_img_store1(bufB, i0 + 4 * g + r, n0 + j, m2acc[q][r]);
       }
     }
   }
@@ -487,7 +570,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
   // ---- q2c = Sr . M2          (= (Sr.Sc^T).x1 of layers.py:127, re-associated)
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    f32x4 acc = tile_mma<true, false>(Sr, c.ld, c.N1p, bufB, CQ_LDX, HUAL_D, c.N2p, c.N2p, c.N2p, i0, n0, j, g, zero);
+    const f32x4 acc = cq_mma<LONG1, true>(SrI, i0, bufB, n0, N2q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * g + r;
@@ -495,6 +578,15 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b,
     }
   }
   CQ_STAMP(7);
+}
+
+__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_staged_kernel(CqBufs b, CqParams p, RowSpace rs, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char cq_lds[];
+  const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
+  if (clip >= rs.B) return;
+  const int N1 = dir == 0 ? rs.T : rs.L, N2 = dir == 0 ? rs.L : rs.T;
+  if (cq_r32(N1) >= cq_r32(N2)) cq_fwd_staged_body<true>(b, p, rs, drop, clip, dir, cq_lds);
+  else cq_fwd_staged_body<false>(b, p, rs, drop, clip, dir, cq_lds);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -649,61 +741,65 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
   CQ_STAMP(23);
 }
 
-// cq_bwd_staged_kernel: cq_bwd_kernel with the [rows,128] operands of every product staged in LDS and requested one
-// phase ahead (see cq_fwd_staged_kernel).   bufA (x1 rows): dC2Q, dQ2C, X1, D1W      bufB (x2 rows): X2, M2, dM2, D2
-__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb) {
-  extern __shared__ float lds[];
-  const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
-  if (clip >= rs.B) return;
+// cq_bwd_staged_kernel: cq_bwd_kernel with the [rows,128] operands of every product staged in LDS as split images and requested
+// one phase ahead (see cq_fwd_staged_body).   bufA (x1 rows): dC2Q, dQ2C, X1, D1W      bufB (x2 rows): X2, M2, dM2, D2
+// The saved softmaxes arrive as the forward's images; dscore takes the place of the Sr image once both softmax backward passes are done.
+template <bool LONG1>
+__device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdBufs& gb, const RowSpace& rs, float* dXa, float* dXb, int clip, int dir,
+                                                   char* lds) {
   const ClipGeom c = clip_geom(rs, clip, dir);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
+  const CqLds L = cq_lds_map(c.N1, c.N2, 2);
+  const int N1q = L.N1q, N2q = L.N2q;
   const int msz = c.N1p * c.ld;
-  float* Sr = lds;
-  float* Sc = lds + msz;
-  float* dSr = lds + 2 * msz;    // becomes dscore
-  float* dSc = lds + 3 * msz;
-  float* m1 = lds + 4 * msz;
+  float* dSr = reinterpret_cast<float*>(lds + L.s);      // becomes dscore
+  float* dSc = dSr + msz;
+  const CqImg SrI = cq_img(lds + L.sri, L.Sq), ScI = cq_img(lds + L.sci, L.Sq);
+  float* m1 = reinterpret_cast<float*>(lds + L.m);
   float* m2 = m1 + c.N1p;
-  float* bufA = m2 + c.N2p;             // [N1p][CQ_LDX]
-  float* bufB = bufA + c.N1p * CQ_LDX;  // [N2p][CQ_LDX]
+  const CqImg bufA = cq_img(lds + L.bufa, N1q), bufB = cq_img(lds + L.bufb, N2q);
   const size_t x1off = (size_t)c.x1base * HUAL_D, x2off = (size_t)c.x2base * HUAL_D;
   const size_t mat = cq_mat_elems(rs.T, rs.L);
-  const float* gSr = b.SR + ((size_t)dir * rs.B + clip) * mat;
-  const float* gSc = b.SC + ((size_t)dir * rs.B + clip) * mat;
+  const float4* gSr = reinterpret_cast<const float4*>(b.SR + ((size_t)dir * rs.B + clip) * mat);
+  const float4* gSc = reinterpret_cast<const float4*>(b.SC + ((size_t)dir * rs.B + clip) * mat);
   const size_t m2off = ((size_t)dir * rs.B + clip) * cq_m2_rows(rs.T, rs.L) * HUAL_D;
   float* dM2 = gb.dM2 + m2off;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const int nj = c.N2p >> 4, ni = c.N1p >> 4;
+  const int nj = c.N2p >> 4, ni = c.N1p >> 4, njq = N2q >> 4;
   CQ_STAMP(16);
   // ---- requests of the first two operand pairs, the saved softmaxes and the masks: one round trip
   CqRows r1, r2;
-  cq_rows_load(r1, gb.dC2Q + x1off, c.N1, c.N1p, b.X + x2off, c.N2, c.N2p);
-  cq_rows_load(r2, gb.dQ2C + x1off, c.N1, c.N1p, b.M2 + m2off, c.N2p, c.N2p);
+  cq_rows_load(r1, gb.dC2Q + x1off, c.N1, N1q, b.X + x2off, c.N2, N2q);
+  cq_rows_load(r2, gb.dQ2C + x1off, c.N1, N1q, b.M2 + m2off, c.N2p, N2q);
   if ((int)threadIdx.x < c.N1p + c.N2p) {
     const int idx = threadIdx.x;
     const bool first = idx < c.N1p;
     const int k = first ? idx : idx - c.N1p;
     m1[idx] = (k < (first ? c.N1 : c.N2)) ? rs.rowmask[(first ? c.x1base : c.x2base) + k] : 0.f;     // (m2 follows m1)
   }
-  for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { Sr[idx] = gSr[idx]; Sc[idx] = gSc[idx]; dSr[idx] = 0.f; dSc[idx] = 0.f; }
-  cq_rows_store(r1, bufA, c.N1p, bufB, c.N2p);          // dC2Q, X2
+  {
+    float4* lr = reinterpret_cast<float4*>(SrI.p);
+    float4* lc = reinterpret_cast<float4*>(ScI.p);
+    for (int idx = threadIdx.x; idx < L.Sq * 32; idx += CQ_THREADS) { lr[idx] = gSr[idx]; lc[idx] = gSc[idx]; }
+  }
+  cq_rows_store(r1, bufA, N1q, bufB, N2q);          // dC2Q, X2
   __syncthreads();
   CQ_STAMP(17);
   // ---- first half of dSr = dc2q . x2^T (+ dq2c . M2^T below) ;  dXb (x2 rows) = Sr^T . dc2q
-  cq_rows_load(r1, b.X + x1off, c.N1, c.N1p, nullptr, 0, c.N2p);      // X1, for the dSc product
+  cq_rows_load(r1, b.X + x1off, c.N1, N1q, nullptr, 0, N2q);      // X1, for the dSc product
   f32x4 sacc[2] = {zero, zero};                          // ni * nj <= 25 tiles over 16 waves
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int tile = wave + CQ_WAVES * q;
     if (tile < ni * nj) {
       const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
-      sacc[q] = tile_mma<true, true>(bufA, CQ_LDX, c.N1p, bufB, CQ_LDX, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
+      sacc[q] = cq_mma<false, false>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
     }
   }
   for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    f32x4 acc2 = tile_mma<false, false>(Sr, c.ld, c.N2p, bufA, CQ_LDX, HUAL_D, c.N1p, c.N1p, c.N1p, i0, n0, j, g, zero);
+    const f32x4 acc2 = cq_mma<!LONG1, true>(SrI, i0, bufA, n0, N1q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int jj = i0 + 4 * g + r;
@@ -712,42 +808,42 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b,
   }
   __syncthreads();
   CQ_STAMP(18);
-  cq_rows_store(r2, bufA, c.N1p, bufB, c.N2p);          // dQ2C, M2
+  cq_rows_store(r2, bufA, N1q, bufB, N2q);          // dQ2C, M2
   __syncthreads();
-  cq_rows_load(r2, b.D1W + x1off, c.N1, c.N1p, b.D2 + x2off, c.N2, c.N2p);     // for the last two products
+  cq_rows_load(r2, b.D1W + x1off, c.N1, N1q, b.D2 + x2off, c.N2, N2q);     // for the last two products
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int tile = wave + CQ_WAVES * q;
     if (tile < ni * nj) {
       const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
-      const f32x4 acc = tile_mma<true, true>(bufA, CQ_LDX, c.N1p, bufB, CQ_LDX, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, sacc[q]);
+      const f32x4 acc = cq_mma<false, false>(bufA, i0, bufB, n0, HUAL_D, lane, sacc[q]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) dSr[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
     }
   }
-  // dM2 = Sr^T . dq2c (kept in registers until every wave is done with M2)
-  f32x4 macc[4];                                          // nj * 8 <= 64 tiles over 16 waves
+  // dM2 = Sr^T . dq2c (kept in registers until every wave is done with M2); rows up to N2q: zero beyond N2 (Sr is zero there)
+  f32x4 macc[4];                                          // njq * 8 <= 64 tiles over 16 waves
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tile = wave + CQ_WAVES * q;
     macc[q] = zero;
-    if (tile < nj * 8) {
+    if (tile < njq * 8) {
       const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-      macc[q] = tile_mma<false, false>(Sr, c.ld, c.N2p, bufA, CQ_LDX, HUAL_D, c.N1p, c.N1p, c.N1p, i0, n0, j, g, zero);
+      macc[q] = cq_mma<!LONG1, true>(SrI, i0, bufA, n0, N1q, lane, zero);
     }
   }
   __syncthreads();
   CQ_STAMP(19);
-  cq_rows_store(r1, bufA, c.N1p, bufB, 0);               // X1 (bufB receives dM2 below)
+  cq_rows_store(r1, bufA, N1q, bufB, 0);                 // X1 (bufB receives dM2 below)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tile = wave + CQ_WAVES * q;
-    if (tile < nj * 8) {
+    if (tile < njq * 8) {
       const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        dM2[(size_t)(i0 + 4 * g + r) * HUAL_D + n0 + j] = macc[q][r];
-        bufB[(i0 + 4 * g + r) * CQ_LDX + n0 + j] = macc[q][r];
+        if (i0 + 4 * g + r < c.N2p) dM2[(size_t)(i0 + 4 * g + r) * HUAL_D + n0 + j] = macc[q][r];
+        cq_img_store1(bufB, i0 + 4 * g + r, n0 + j, macc[q][r]);
       }
     }
   }
@@ -755,13 +851,13 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b,
   // ---- dSc = x1 . dM2^T ;  dXa (x1 rows) = Sc . dM2
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
-    f32x4 acc = tile_mma<true, true>(bufA, CQ_LDX, c.N1p, bufB, CQ_LDX, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
+    const f32x4 acc = cq_mma<false, false>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) dSc[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
   }
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    f32x4 acc = tile_mma<true, false>(Sc, c.ld, c.N1p, bufB, CQ_LDX, HUAL_D, c.N2p, c.N2p, c.N2p, i0, n0, j, g, zero);
+    const f32x4 acc = cq_mma<LONG1, true>(ScI, i0, bufB, n0, N2q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * g + r;
@@ -770,31 +866,31 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b,
   }
   __syncthreads();
   CQ_STAMP(20);
-  cq_rows_store(r2, bufA, c.N1p, bufB, c.N2p);          // D1W, D2
+  cq_rows_store(r2, bufA, N1q, bufB, N2q);          // D1W, D2
   // ---- softmax backward -> dscore (in dSr).  mask_logits is multiplicative, so its derivative is the mask.
-  // (rows / columns of at most 32 elements go two per wave, as in the forward kernel: same sums, same order)
+  // (rows / columns of at most 32 elements go two per wave, as in the forward kernel)
   const int hh = lane >> 5, l32 = lane & 31;
   if (c.N2p <= 32) {
     for (int i = 2 * wave + hh; i < c.N1p; i += 2 * CQ_WAVES) {
       const bool ok = i < c.N1 && l32 < c.N2;
-      const float sr = ok ? Sr[i * c.ld + l32] : 0.f, ds = ok ? dSr[i * c.ld + l32] : 0.f;
+      const float sr = ok ? cq_sc_load<LONG1>(SrI, i, l32) : 0.f, ds = ok ? dSr[i * c.ld + l32] : 0.f;
       const float dot = half_sum32(sr * ds);
       if (ok) dSr[i * c.ld + l32] = sr * (ds - dot) * m2[l32];
     }
   } else {
     for (int i = wave; i < c.N1; i += CQ_WAVES) {
       float dot = 0.f;
-      for (int jj = lane; jj < c.N2; jj += 64) dot += Sr[i * c.ld + jj] * dSr[i * c.ld + jj];
+      for (int jj = lane; jj < c.N2; jj += 64) dot += cq_sc_load<LONG1>(SrI, i, jj) * dSr[i * c.ld + jj];
       dot = wave_sum64(dot);
       for (int jj = lane; jj < c.N2; jj += 64)
-        dSr[i * c.ld + jj] = Sr[i * c.ld + jj] * (dSr[i * c.ld + jj] - dot) * m2[jj];
+        dSr[i * c.ld + jj] = cq_sc_load<LONG1>(SrI, i, jj) * (dSr[i * c.ld + jj] - dot) * m2[jj];
     }
   }
   __syncthreads();
   if (c.N1p <= 32) {
     for (int jj = 2 * wave + hh; jj < c.N2p; jj += 2 * CQ_WAVES) {
       const bool ok = jj < c.N2 && l32 < c.N1;
-      const float sc = ok ? Sc[l32 * c.ld + jj] : 0.f, ds = ok ? dSc[l32 * c.ld + jj] : 0.f;
+      const float sc = ok ? cq_sc_load<LONG1>(ScI, l32, jj) : 0.f, ds = ok ? dSc[l32 * c.ld + jj] : 0.f;
       const float dot = half_sum32(sc * ds);
       float v = 0.f;
       if (ok) {
@@ -807,11 +903,11 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b,
   } else {
     for (int jj = wave; jj < c.N2; jj += CQ_WAVES) {
       float dot = 0.f;
-      for (int i = lane; i < c.N1; i += 64) dot += Sc[i * c.ld + jj] * dSc[i * c.ld + jj];
+      for (int i = lane; i < c.N1; i += 64) dot += cq_sc_load<LONG1>(ScI, i, jj) * dSc[i * c.ld + jj];
       dot = wave_sum64(dot);
       float colsum = 0.f;
       for (int i = lane; i < c.N1; i += 64) {
-        const float v = dSr[i * c.ld + jj] + Sc[i * c.ld + jj] * (dSc[i * c.ld + jj] - dot) * m1[i];
+        const float v = dSr[i * c.ld + jj] + cq_sc_load<LONG1>(ScI, i, jj) * (dSc[i * c.ld + jj] - dot) * m1[i];
         dSr[i * c.ld + jj] = v;
         colsum += v;
       }
@@ -821,24 +917,33 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b,
   }
   __syncthreads();
   CQ_STAMP(21);
+  // row sums (d s0) and the dscore image (in place of the Sr image: both softmaxes are done with it)
+  const CqImg dscI = SrI;
   if (c.N2p <= 32) {
-    for (int i = 2 * wave + hh; i < c.N1p; i += 2 * CQ_WAVES) {
-      const float rowsum = half_sum32((i < c.N1 && l32 < c.N2) ? dSr[i * c.ld + l32] : 0.f);
+    for (int i = 2 * wave + hh; i < N1q; i += 2 * CQ_WAVES) {
+      const float v = (i < c.N1 && l32 < c.N2) ? dSr[i * c.ld + l32] : 0.f;
+      const float rowsum = half_sum32(v);
       if (l32 == 0 && i < c.N1) gb.dS0[c.x1base + i] = rowsum;
+      cq_sc_store<LONG1>(dscI, i, l32, v);
     }
   } else {
-    for (int i = wave; i < c.N1; i += CQ_WAVES) {
+    for (int i = wave; i < N1q; i += CQ_WAVES) {
       float rowsum = 0.f;
-      for (int jj = lane; jj < c.N2; jj += 64) rowsum += dSr[i * c.ld + jj];
+      for (int jj = lane; jj < N2q; jj += 64) {
+        const float v = (i < c.N1 && jj < c.N2) ? dSr[i * c.ld + jj] : 0.f;
+        rowsum += v;
+        cq_sc_store<LONG1>(dscI, i, jj, v);
+      }
       rowsum = wave_sum64(rowsum);
-      if (lane == 0) gb.dS0[c.x1base + i] = rowsum;
+      if (lane == 0 && i < c.N1) gb.dS0[c.x1base + i] = rowsum;
     }
   }
+  __syncthreads();
   CQ_STAMP(22);
   // ---- dD1W = dscore . d2 ;  dD2 = dscore^T . d1w
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    f32x4 acc = tile_mma<true, false>(dSr, c.ld, c.N1p, bufB, CQ_LDX, HUAL_D, c.N2p, c.N2p, c.N2p, i0, n0, j, g, zero);
+    const f32x4 acc = cq_mma<LONG1, true>(dscI, i0, bufB, n0, N2q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * g + r;
@@ -847,7 +952,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b,
   }
   for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    f32x4 acc = tile_mma<false, false>(dSr, c.ld, c.N2p, bufA, CQ_LDX, HUAL_D, c.N1p, c.N1p, c.N1p, i0, n0, j, g, zero);
+    const f32x4 acc = cq_mma<!LONG1, true>(dscI, i0, bufA, n0, N1q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int jj = i0 + 4 * g + r;
@@ -855,6 +960,15 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b,
     }
   }
   CQ_STAMP(23);
+}
+
+__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_staged_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb) {
+  extern __shared__ __attribute__((aligned(16))) char cq_lds[];
+  const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
+  if (clip >= rs.B) return;
+  const int N1 = dir == 0 ? rs.T : rs.L, N2 = dir == 0 ? rs.L : rs.T;
+  if (cq_r32(N1) >= cq_r32(N2)) cq_bwd_staged_body<true>(b, gb, rs, dXa, dXb, clip, dir, cq_lds);
+  else cq_bwd_staged_body<false>(b, gb, rs, dXa, dXb, clip, dir, cq_lds);
 }
 
 // backward, step 3 (row kernel): through the two dropouts and the rank-1 terms; parameter gradients.
@@ -923,21 +1037,28 @@ int launch_tri_prep(const CqBufs& b, const CqParams& p, const RowSpace& rs, cons
   return 0;
 }
 
-// LDS of the staged kernels: `nmats` score matrices, 2 x (masks or rank-1 terms) and the two operand buffers
-static int cq_staged_bytes(const RowSpace& rs, int nmats) {
-  const int Tp = cq_padded(rs.T), Lp = cq_padded(rs.L);
-  return (int)((cq_mat_elems(rs.T, rs.L) * nmats + 2 * (Tp + Lp) + (size_t)(Tp + Lp) * CQ_LDX) * sizeof(float));
+// LDS of the staged kernels (cq_lds_map): the larger of the two directions; both kernels must fit (the forward saves its softmaxes in
+// the image layout only the staged backward reads)
+static int cq_staged_bytes(const RowSpace& rs, int nf32) {
+  const int a = cq_lds_map(rs.T, rs.L, nf32).total, c = cq_lds_map(rs.L, rs.T, nf32).total;
+  return a > c ? a : c;
 }
-static bool cq_staged_ok(const RowSpace& rs, int nmats) {
-  return (cq_padded(rs.T) + cq_padded(rs.L)) * 32 <= CQ_STAGE_MAX * CQ_MAX_THREADS && cq_staged_bytes(rs, nmats) <= 160 * 1024;
+static bool cq_staged_ok(const RowSpace& rs) {
+  const int Tq = (rs.T + 31) & ~31, Lq = (rs.L + 31) & ~31;
+  return Tq <= 128 && Lq <= 128 && (Tq + Lq) * 32 <= CQ_STAGE_MAX * CQ_MAX_THREADS && cq_staged_bytes(rs, 1) <= 160 * 1024 &&
+         cq_staged_bytes(rs, 2) <= 160 * 1024;
 }
+// algorithmic HBM bytes per launch: forward - the [R,128] rows in, D1W / D2 / C2Q / Q2C out, M2 and the two saved softmaxes; backward -
+// 8 row tensors in, 5 out, softmaxes + M2 in, dM2 out
+static double cq_fwd_bytes(const RowSpace& rs) { return 4.0 * (5.0 * rs.R * HUAL_D + 2.0 * rs.B * (3.0 * cq_mat_elems(rs.T, rs.L))); }
+static double cq_bwd_bytes(const RowSpace& rs) { return 4.0 * (13.0 * rs.R * HUAL_D + 2.0 * rs.B * (4.0 * cq_mat_elems(rs.T, rs.L))); }
 
 // tri_prep (dropout on both roles of every row, rank-1 terms) + the attention itself: one launch when the clip fits the staged
 // kernel (it prepares the rows as it stages them), else two
 int launch_cq_fwd(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
-  if (cq_staged_ok(rs, 3)) {
+  if (cq_staged_ok(rs)) {
     HUAL_DYN_LDS(cq_fwd_staged_kernel, 160 * 1024);
-    HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_staged_kernel, dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 3), s, b, p, rs, drop);
+    HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, cq_fwd_bytes(rs), cq_fwd_staged_kernel, dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 1), s, b, p, rs, drop);
     HUAL_CHECK_HIP(hipGetLastError());
     return 0;
   }
@@ -946,7 +1067,7 @@ int launch_cq_fwd(const CqBufs& b, const CqParams& p, const RowSpace& rs, const 
   const int bytes = cq_lds_bytes(rs, 3);
   HUAL_REQUIRE(bytes <= 160 * 1024, "cq_fwd: T x L score matrix does not fit LDS");
   HUAL_DYN_LDS(cq_fwd_kernel, 160 * 1024);
-  HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_fwd_kernel, dim3(xcd_round8(rs.B), 2), dim3(cq_threads()), bytes, s, b, rs);
+  HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, cq_fwd_bytes(rs), cq_fwd_kernel, dim3(xcd_round8(rs.B), 2), dim3(cq_threads()), bytes, s, b, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -961,16 +1082,16 @@ int launch_cq_bwd_pre(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, h
 
 // dXa/dXb scratch = g.dC2Q / g.dQ2C can NOT be reused (read by the kernel); callers pass dedicated buffers
 int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, float* dXa, float* dXb, hipStream_t s) {
-  if (cq_staged_ok(rs, 4)) {
+  if (cq_staged_ok(rs)) {
     HUAL_DYN_LDS(cq_bwd_staged_kernel, 160 * 1024);
-    HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_staged_kernel, dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 4), s, b, g, rs, dXa, dXb);
+    HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, cq_bwd_bytes(rs), cq_bwd_staged_kernel, dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 2), s, b, g, rs, dXa, dXb);
     HUAL_CHECK_HIP(hipGetLastError());
     return 0;
   }
   const int bytes = cq_lds_bytes(rs, 4);
   HUAL_REQUIRE(bytes <= 160 * 1024, "cq_bwd: T x L score matrix does not fit LDS");
   HUAL_DYN_LDS(cq_bwd_kernel, 160 * 1024);
-  HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 0.0, cq_bwd_kernel, dim3(xcd_round8(rs.B), 2), dim3(cq_threads()), bytes, s, b, g, rs, dXa, dXb);
+  HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, cq_bwd_bytes(rs), cq_bwd_kernel, dim3(xcd_round8(rs.B), 2), dim3(cq_threads()), bytes, s, b, g, rs, dXa, dXb);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
