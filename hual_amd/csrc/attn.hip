@@ -412,6 +412,17 @@ __host__ __device__ inline BwdLds bwd_lds(int Tq, int Tk, bool dropout) {
   return l;
 }
 
+#ifdef HUAL_STAMPS
+// debug: clock stamps of the backward kernel's phases per workgroup (scripts/exp/attn_stamps.py)
+__device__ unsigned long long g_attn_stamps[4096 * 8];
+extern "C" int hual_debug_attn_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#define ATT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_attn_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
+
 template <bool DROP>
 __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, char* lds, const DropCfg& drop) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -449,47 +460,77 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
   // keys - all four work on key block 0, wave w takes the query pairs w, w + 4, ..; dQ rows are then disjoint (one slot), and the
   // partial dK / dV of the waves are summed through the three free slots
   const bool qsplit = nkp == 1 && nqp >= 4;
+  ATT_STAMP(0);
   if (wave < nkp || qsplit) load_v(qsplit ? 0 : wave);
-  // ---- staging: per pass every thread requests its piece of all three panels (+ O for delta = dO . O) before any split
+  // ---- staging: EVERY load of the workgroup's panels (+ O for delta = dO . O, the softmax statistics, the keep words) is requested
+  // before the first split / LDS store: one memory round trip (a pass per 64 rows used to wait for its own loads, and the loads
+  // of the statistics sat behind a lane-dependent branch: three to five serial round trips in front of the products)
   const int stat_n = job.B * Tq * 8;
   const int npass = (max(Tqp, Tkp) * 4 + 255) >> 8;
-  for (int it = 0; it < npass; ++it) {
-    const int idx = threadIdx.x + 256 * it, row = idx >> 2, c4 = idx & 3;
-    const int qr = min(row, Tq - 1), kr = min(row, Tk - 1);
-    const float4 qv = ld4(Qg + (size_t)qr * job.ldq + 4 * c4);
-    const float4 dv = ld4(Dg + (size_t)qr * job.lddo + 4 * c4);
-    const float4 ov = ld4(Og + (size_t)qr * job.ldo + 4 * c4);
-    const float4 kv = ld4(Kg + (size_t)kr * job.ldkv + 4 * c4);
-    float smx = 0.f, sinv = 0.f, qm = 0.f;
-    const bool qok = row < Tq;
-    if (c4 == 0 && qok) {
-      const int si = (b * Tq + row) * 8 + h;
-      smx = job.stats[si];
-      sinv = job.stats[stat_n + si];
-      qm = job.qmask[qbase + row];
-    }
-    if (row < Tqp) {
-      panel_store(Qp, row, c4, qok ? qv : f4zero());
-      panel_store(Dp, row, c4, qok ? dv : f4zero());
-    }
-    if (row < Tkp) panel_store(Kp, row, c4, row < Tk ? kv : f4zero());
-    float part = qok ? (dv.x * ov.x + dv.y * ov.y) + (dv.z * ov.z + dv.w * ov.w) : 0.f;
-    part += __shfl_xor(part, 1);
-    part += __shfl_xor(part, 2);
-    if (c4 == 0 && row < Tqp) {
-      St[row] = smx;
-      St[Tqp + row] = sinv;                                                      // 1 / row sum = 0 for padding queries -> p = 0
-      St[2 * Tqp + row] = part;
-      St[3 * Tqp + row] = ATT_NEGL;                                              // key masked
-      St[4 * Tqp + row] = (qok && qm != 0.f) ? 0.f : ATT_NEGL;                   // key valid: (1 - mq) * -1e30
-      St[5 * Tqp + row] = -INFINITY;                                             // key beyond Tk (tile padding)
+  constexpr int MAXP = 4;                               // Tq, Tk <= 256
+  float4 sq[MAXP], sd[MAXP], so[MAXP], sk[MAXP];
+  float ssm[MAXP], ssi[MAXP], sqm[MAXP];
+  uint2 mkw[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+  const int nmk = dodrop ? nqt * nkt * 4 : 0;           // keep words of the head (<= 16 x 16 x 4 = 1024: four per thread)
+  uint2 mkx[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+#pragma unroll
+  for (int it = 0; it < MAXP; ++it) {
+    sq[it] = sd[it] = so[it] = sk[it] = f4zero();
+    ssm[it] = ssi[it] = sqm[it] = 0.f;
+    if (it < npass) {                                   // (workgroup-uniform)
+      const int idx = threadIdx.x + 256 * it, row = idx >> 2, c4 = idx & 3;
+      const int qr = min(row, Tq - 1), kr = min(row, Tk - 1);
+      sq[it] = ld4(Qg + (size_t)qr * job.ldq + 4 * c4);
+      sd[it] = ld4(Dg + (size_t)qr * job.lddo + 4 * c4);
+      so[it] = ld4(Og + (size_t)qr * job.ldo + 4 * c4);
+      sk[it] = ld4(Kg + (size_t)kr * job.ldkv + 4 * c4);
+      const int si = (b * Tq + qr) * 8 + h;             // (unconditional on the clamped row: every lane of a row reads the same words)
+      ssm[it] = job.stats[si];
+      ssi[it] = job.stats[stat_n + si];
+      sqm[it] = job.qmask[qbase + qr];
     }
   }
   if (dodrop) {
     const uint2* src = reinterpret_cast<const uint2*>(job.dmask + (size_t)(b * 8 + h) * nqt * nkt * 32);
-    for (int idx = threadIdx.x; idx < nqt * nkt * 4; idx += 256) reinterpret_cast<uint2*>(Mk)[idx] = src[idx];
+    mkw[0] = src[min((int)threadIdx.x, nmk - 1)];
+    mkw[1] = src[min((int)threadIdx.x + 256, nmk - 1)];
+    mkx[0] = src[min((int)threadIdx.x + 512, nmk - 1)];
+    mkx[1] = src[min((int)threadIdx.x + 768, nmk - 1)];
   }
+#pragma unroll
+  for (int it = 0; it < MAXP; ++it) {
+    if (it < npass) {
+      const int idx = threadIdx.x + 256 * it, row = idx >> 2, c4 = idx & 3;
+      const bool qok = row < Tq;
+      const float4 qv = sq[it], dv = sd[it], ov = so[it], kv = sk[it];
+      if (row < Tqp) {
+        panel_store(Qp, row, c4, qok ? qv : f4zero());
+        panel_store(Dp, row, c4, qok ? dv : f4zero());
+      }
+      if (row < Tkp) panel_store(Kp, row, c4, row < Tk ? kv : f4zero());
+      float part = qok ? (dv.x * ov.x + dv.y * ov.y) + (dv.z * ov.z + dv.w * ov.w) : 0.f;
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      if (c4 == 0 && row < Tqp) {
+        St[row] = qok ? ssm[it] : 0.f;
+        St[Tqp + row] = qok ? ssi[it] : 0.f;                                       // 1 / row sum = 0 for padding queries -> p = 0
+        St[2 * Tqp + row] = part;
+        St[3 * Tqp + row] = ATT_NEGL;                                              // key masked
+        St[4 * Tqp + row] = (qok && sqm[it] != 0.f) ? 0.f : ATT_NEGL;              // key valid: (1 - mq) * -1e30
+        St[5 * Tqp + row] = -INFINITY;                                             // key beyond Tk (tile padding)
+      }
+    }
+  }
+  if (dodrop) {
+    uint2* mk2 = reinterpret_cast<uint2*>(Mk);
+    if ((int)threadIdx.x < nmk) mk2[threadIdx.x] = mkw[0];
+    if ((int)threadIdx.x + 256 < nmk) mk2[threadIdx.x + 256] = mkw[1];
+    if ((int)threadIdx.x + 512 < nmk) mk2[threadIdx.x + 512] = mkx[0];
+    if ((int)threadIdx.x + 768 < nmk) mk2[threadIdx.x + 768] = mkx[1];
+  }
+  ATT_STAMP(1);
   __syncthreads();
+  ATT_STAMP(2);
   const float scale8 = drop.scale;                  // exactly 1 / (1 - rate)
   float* slot = dQw + (qsplit ? 0 : wave) * Tqp * 16;
   bool first = true;
@@ -608,7 +649,9 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
         }
       }
   }
+  ATT_STAMP(3);
   __syncthreads();
+  ATT_STAMP(4);
   if (qsplit) {      // dK / dV of key block 0: the four waves' partials, in wave order
     const float* red = dQw + Tqp * 16;
     for (int idx = threadIdx.x; idx < 1024; idx += 256) {
@@ -632,6 +675,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
     }
     st4(job.dQ + (size_t)(qbase + q) * job.lddq + 16 * h + 4 * c4, make_float4(v.x * 0.25f, v.y * 0.25f, v.z * 0.25f, v.w * 0.25f));
   }
+  ATT_STAMP(5);
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBatch batch, int njobs, DropCfg drop) {

@@ -50,6 +50,9 @@ __device__ __forceinline__ void f16_split_pair(float x0, float x1, uint32_t& hi,
   const f16x2_t l = __builtin_convertvector((f32x2_t){x0 - hf[0], x1 - hf[1]}, f16x2_t);   // x - hi is exact in fp32
   lo = __builtin_bit_cast(uint32_t, l);
 }
+__device__ __forceinline__ uint32_t f16_pack2(float x0, float x1) {      // v_cvt_pk_f16_f32, round to nearest even
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){x0, x1}, f16x2_t));
+}
 __device__ __forceinline__ void f16_split4(const float4& x, uint2& hi, uint2& lo) {
   f16_split_pair(x.x, x.y, hi.x, lo.x);
   f16_split_pair(x.z, x.w, hi.y, lo.y);

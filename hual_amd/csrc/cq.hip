@@ -265,6 +265,13 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
 //   bufA (x1 rows), bufB (x2 rows): row images of the [rows,128] operands of the current phase (rows padded to 32 with zeros);
 //   SrI, ScI (dscore in the backward): the softmax matrices, stored with the LONGER of (N1, N2) along the 128 columns and the
 //   shorter one along the rows (template LONG1: N1 is the column index) - also the layout in which they are saved for the backward.
+// workgroup barrier that waits for the wave's LDS operations only: __syncthreads() also drains every outstanding global STORE of the
+// wave (s_waitcnt vmcnt(0)) - a store round trip in front of every phase; the staged kernels never read back their own global stores
+__device__ __forceinline__ void cq_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 struct CqImg { char* p; int plane; };
 __device__ __forceinline__ CqImg cq_img(char* p, int rows) { CqImg im; im.p = p; im.plane = rows * 256; return im; }
 __device__ __forceinline__ void cq_img_store4(const CqImg& im, int row, int col, const float4& v) {      // cols col .. col + 3, col % 4 == 0
@@ -420,7 +427,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
     }
   }
   cq_rows_store(rows, bufA, N1q, bufB, N2q);
-  __syncthreads();
+  cq_barrier();
   CQ_STAMP(1);
   // ---- score = d1w . d2^T + s0 + s1
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
@@ -429,7 +436,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[(i0 + 4 * g + r) * c.ld + n0 + j] = acc[r] + s0[i0 + 4 * g + r] + s1[n0 + j];
   }
-  __syncthreads();
+  cq_barrier();
   CQ_STAMP(2);
   cq_rows_store(xrows, bufA, N1q, bufB, N2q);      // X1, X2
   // ---- row softmax over j with mask2 (layers.py:122-123); zero outside the valid block (the images are read up to N1q x N2q).
@@ -517,7 +524,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       }
     }
   }
-  __syncthreads();
+  cq_barrier();
   CQ_STAMP(3);
   // ---- save both softmaxes for the backward pass: the images as they stand (both planes)
   {
@@ -552,7 +559,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       m2acc[q] = cq_mma<!LONG1, true>(ScI, i0, bufA, n0, N1q, lane, zero);
     }
   }
-  __syncthreads();
+  cq_barrier();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tile = wave + CQ_WAVES * q;
@@ -565,7 +572,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       }
     }
   }
-  __syncthreads();
+  cq_barrier();
   CQ_STAMP(6);
   // ---- q2c = Sr . M2          (= (Sr.Sc^T).x1 of layers.py:127, re-associated)
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
@@ -784,7 +791,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
     for (int idx = threadIdx.x; idx < L.Sq * 32; idx += CQ_THREADS) { lr[idx] = gSr[idx]; lc[idx] = gSc[idx]; }
   }
   cq_rows_store(r1, bufA, N1q, bufB, N2q);          // dC2Q, X2
-  __syncthreads();
+  cq_barrier();
   CQ_STAMP(17);
   // ---- first half of dSr = dc2q . x2^T (+ dq2c . M2^T below) ;  dXb (x2 rows) = Sr^T . dc2q
   cq_rows_load(r1, b.X + x1off, c.N1, N1q, nullptr, 0, N2q);      // X1, for the dSc product
@@ -806,10 +813,10 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
       if (jj < c.N2) dXb[(size_t)(c.x2base + jj) * HUAL_D + n0 + j] = acc2[r];
     }
   }
-  __syncthreads();
+  cq_barrier();
   CQ_STAMP(18);
   cq_rows_store(r2, bufA, N1q, bufB, N2q);          // dQ2C, M2
-  __syncthreads();
+  cq_barrier();
   cq_rows_load(r2, b.D1W + x1off, c.N1, N1q, b.D2 + x2off, c.N2, N2q);     // for the last two products
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -832,7 +839,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
       macc[q] = cq_mma<!LONG1, true>(SrI, i0, bufA, n0, N1q, lane, zero);
     }
   }
-  __syncthreads();
+  cq_barrier();
   CQ_STAMP(19);
   cq_rows_store(r1, bufA, N1q, bufB, 0);                 // X1 (bufB receives dM2 below)
 #pragma unroll
@@ -847,7 +854,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
       }
     }
   }
-  __syncthreads();
+  cq_barrier();
   // ---- dSc = x1 . dM2^T ;  dXa (x1 rows) = Sc . dM2
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
@@ -864,7 +871,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
       if (i < c.N1) dXa[(size_t)(c.x1base + i) * HUAL_D + n0 + j] = acc[r];
     }
   }
-  __syncthreads();
+  cq_barrier();
   CQ_STAMP(20);
   cq_rows_store(r2, bufA, N1q, bufB, N2q);          // D1W, D2
   // ---- softmax backward -> dscore (in dSr).  mask_logits is multiplicative, so its derivative is the mask.
@@ -886,7 +893,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
         dSr[i * c.ld + jj] = cq_sc_load<LONG1>(SrI, i, jj) * (dSr[i * c.ld + jj] - dot) * m2[jj];
     }
   }
-  __syncthreads();
+  cq_barrier();
   if (c.N1p <= 32) {
     for (int jj = 2 * wave + hh; jj < c.N2p; jj += 2 * CQ_WAVES) {
       const bool ok = jj < c.N2 && l32 < c.N1;
@@ -915,7 +922,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
       if (lane == 0) gb.dS1[c.x2base + jj] = colsum;
     }
   }
-  __syncthreads();
+  cq_barrier();
   CQ_STAMP(21);
   // row sums (d s0) and the dscore image (in place of the Sr image: both softmaxes are done with it)
   const CqImg dscI = SrI;
@@ -938,7 +945,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
       if (lane == 0 && i < c.N1) gb.dS0[c.x1base + i] = rowsum;
     }
   }
-  __syncthreads();
+  cq_barrier();
   CQ_STAMP(22);
   // ---- dD1W = dscore . d2 ;  dD2 = dscore^T . d1w
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {

@@ -4,12 +4,14 @@
 //                           orthogonality term, embedding gather)
 //   dw_bf16_balanced_kernel every weight / bias gradient of a step in one persistent launch
 #include "gemm.h"
+#include <type_traits>
 #include "philox.h"
 #include "bf16x3.h"
 #include "tilecore.h"
 #include "prof.h"
 #include "ortho.h"
 #include "embed_gather.h"
+#include <math.h>
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -99,6 +101,10 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int tq = (lane >> 2) & 3, tp = lane & 3;
+  // A16 (bfloat16 features): 8 significant bits x the dropout scale 1.25 x a power-of-two row scale fit fp16's 11 - the residual
+  // plane is identically zero, so its split and the third MFMA pass are not issued (compile time: the loop body carries no test)
+  auto kloop = [&](auto a16c) {
+  constexpr bool A16 = decltype(a16c)::value;      // bfloat16 features AND a dropout scale of at most 4 significant bits (a_bf16 == 2)
   for (int ks = 0; ks < nks; ++ks) {
     float4 f0 = f4zero(), f1 = f4zero();
     if (ks + 2 < nks) a_fetch(ks + 2, f0, f1);       // two k-steps ahead
@@ -123,9 +129,15 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
     rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
     float inv;
     const float sc = f16_row_scale(rmax, inv);
-    uint2 h0, l0, h1, l1;
-    f16_split4(f4scale1(c0, sc), h0, l0);
-    f16_split4(f4scale1(c1, sc), h1, l1);
+    uint2 h0, l0 = make_uint2(0u, 0u), h1, l1 = make_uint2(0u, 0u);
+    if (A16) {
+      const float4 s0 = f4scale1(c0, sc), s1 = f4scale1(c1, sc);
+      h0 = make_uint2(f16_pack2(s0.x, s0.y), f16_pack2(s0.z, s0.w));
+      h1 = make_uint2(f16_pack2(s1.x, s1.y), f16_pack2(s1.z, s1.w));
+    } else {
+      f16_split4(f4scale1(c0, sc), h0, l0);
+      f16_split4(f4scale1(c1, sc), h1, l1);
+    }
     const f16x8 ah = __builtin_bit_cast(f16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
     const f16x8 al = __builtin_bit_cast(f16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
     const char* hi = ldsb + (ks >> 1) * GB_STAGE;
@@ -142,12 +154,14 @@ __global__ __launch_bounds__(512) void feature_ksplit_kernel(FkBatch batch, Drop
       f32x4 p = (f32x4){0.f, 0.f, 0.f, 0.f};
       p = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, p, 0, 0, 0);
       p = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, p, 0, 0, 0);
-      p = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, p, 0, 0, 0);
+      if (!A16) p = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, p, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(p[r], ir[r], acc[t][r]);
     }
     c0 = n0; c1 = n1; n0 = f0; n1 = f1;
   }
+  };
+  if (job.a_bf16 == 2) kloop(std::true_type{}); else kloop(std::false_type{});
   // accumulator tile t, lane (j, g), register r = row 4g + r, column 64 (t>>2) + 4j + (t&3)
   float* out = job.part + (size_t)q * job.part_stride;
 #pragma unroll
@@ -621,6 +635,14 @@ int launch_feature_ksplit(const FkJob* jobs, int n, const DropCfg& drop, hipStre
     HUAL_REQUIRE(j.K > 0 && (j.K % 8) == 0 && (j.KS % 64) == 0 && j.KS >= 64 && j.KS <= 256 && 4 * j.KS >= j.K && (j.lda % 4) == 0,
                  "feature_ksplit: need K % 8 == 0 and a quarter size KS (multiple of 64, <= 256) with 4*KS >= K");
     b.j[i] = j;
+    if (j.a_bf16) {
+      // bfloat16 features (8 significant bits) x the dropout scale x a power-of-two row scale are EXACT in fp16 (11 bits) when the scale
+      // has at most 4 significant bits (1.25 for rate 0.2, 2 for 0.5, 1 without dropout): the residual plane is zero and the kernel
+      // skips it (a_bf16 = 2); any other rate keeps the full split
+      int e = 0;
+      const double m16 = frexp((double)((j.drop_site >= 0 && drop.enabled) ? drop.scale : 1.0f), &e) * 16.0;
+      b.j[i].a_bf16 = (m16 == floor(m16)) ? 2 : 1;
+    }
     maxM = j.M > maxM ? j.M : maxM;
     maxKS = j.KS > maxKS ? j.KS : maxKS;
     flops += 2.0 * j.M * (double)j.K * 128.0;
