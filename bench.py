@@ -448,51 +448,6 @@ def main():
         # north_star asks for >= 60 % of the attention-GEMM MFMA peak: at the reference's head size 16 the kernels issue MFMAs at
         # the `mfma_issue_frac` above of the pipe they run on (VALU bound: exp, dropout, operand splits) - not met, stated
         roof['north_star_attention_60pct_met'] = False
-        # the same attention forward at head size 64 (8 heads, dim 512; csrc/attn_wide.hip): NOT part of the SeqPAN step (its
-        # configs fix 8 heads of 16) - the matrix-core utilisation the attention products reach when the head is wide enough
-        # for them to carry the kernel (north_star: "MFMA utilisation on the attention GEMMs"), timed by graph replay
-        try:
-            Bh, Th, Hh = args.batch, args.T, 8
-            gq = torch.Generator().manual_seed(7)
-            Qh = torch.randn(Bh * Th, 64 * Hh, generator=gq).to(dev)
-            Kh = torch.randn(Bh * Th, 64 * Hh, generator=gq).to(dev)
-            Vh = torch.randn(Bh * Th, 64 * Hh, generator=gq).to(dev)
-            mh = (torch.arange(Th)[None, :] < torch.randint(Th // 2 + 1, Th + 1, (Bh, 1), generator=gq)).float().reshape(-1).to(dev)
-            Oh = torch.empty(Bh * Th, 64 * Hh, device=dev)
-            rs_h = torch.tensor(np.array([1, 2, 3], dtype=np.uint32).view(np.int32)).to(dev)
-
-            def wide():
-                lib.check(l.hual_attention_fwd_wide(lib.ptr(Qh), 64 * Hh, lib.ptr(Kh), lib.ptr(Vh), 64 * Hh, lib.ptr(Oh), 64 * Hh, Bh, Th, Th,
-                                                    Hh, lib.ptr(mh), lib.ptr(mh), lib.ptr(rs_h), args.drop, 9, lib.stream_ptr()))
-            for _ in range(3):
-                wide()
-            torch.cuda.synchronize()
-            gr_h = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr_h):
-                for _ in range(50):
-                    wide()
-            gr_h.replay()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(4):
-                gr_h.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            us_h = e0.elapsed_time(e1) * 1e3 / 200
-            tf_h = 4.0 * Bh * Hh * Th * Th * 64 / us_h / 1e6
-            roof['attention_head64'] = dict(kernel='attn_fwd_wide_kernel<8>', note='head size 64, 8 heads, dim 512, self attention over '
-                                            'T keys with the step\'s dropout rate; not a launch of the SeqPAN step (8 heads of 16)',
-                                            us_per_launch=round(us_h, 2), achieved=round(tf_h, 2), peak=PEAK_F32_MATRIX_TFLOPS,
-                                            unit='TFLOP/s', frac=round(tf_h / PEAK_F32_MATRIX_TFLOPS, 4),
-                                            peak_is='fp32-matrix peak (a pipe this kernel does not use; kept for continuity)',
-                                            mfma_pipe=PIPE_NAMES[2], mfma_passes=3,
-                                            mfma_issue_frac=round(3 * tf_h / PEAK_BF16_MATRIX_TFLOPS, 4))
-            sq = sq_figures('attn_fwd_wide_kernel<8>', us_h, shape_key)
-            if sq:
-                roof['attention_head64'].update(sq)
-        except Exception as ex:                                  # (a demonstration leg: never fails the bench line)
-            roof['attention_head64'] = dict(error=str(ex))
         # whole step: algorithmic FLOPs (BASELINE.md section 2 for the c2 shape, else the launch wrappers' own sums) over the timed
         # ms/step; HBM bytes per step measured by the PMC passes (sum over kernels of bytes/launch x launches/step) against
         # the compulsory bytes (clip features + query ids + labels read once, outputs written, parameters read once,
@@ -503,7 +458,9 @@ def main():
         is_c2 = (args.T, args.vdim, args.L, args.C) == (128, 1024, 20, 8)
         gflop = MFLOP_PER_CLIP_C2 * args.batch / 1e3 if is_c2 else sum(d['flops'] for d in fam) / psteps / 1e9
         ms = dt / args.steps * 1e3
+        alg_bytes = sum(d['bytes'] for d in fam) / psteps      # what the launch wrappers count: operands in, results out, per launch
         step = dict(algorithmic_gflop_per_step=round(gflop, 2), tflops=round(gflop / ms, 2),
+                    algorithmic_bytes_per_step=int(alg_bytes), algorithmic_tb_s=round(alg_bytes / (ms * 1e-3) / 1e12, 3),
                     frac_of_fp32_matrix_peak=round(gflop / ms / PEAK_F32_MATRIX_TFLOPS, 4),
                     frac_of_bf16_matrix_peak=round(gflop / ms / PEAK_BF16_MATRIX_TFLOPS, 4),
                     compulsory_hbm_bytes_per_step=int(compulsory), launches_per_step=sum(d['launches'] for d in fam) // psteps,
@@ -514,7 +471,9 @@ def main():
                 if d['kernel'] in tr_tab:
                     meas += tr_tab[d['kernel']]['hbm_bytes_per_launch'] * (d['launches'] // psteps)
                     covered += 1
-            step.update(measured_hbm_bytes_per_step=int(meas), measured_over_compulsory=round(meas / compulsory, 1),
+            step.update(measured_hbm_bytes_per_step=int(meas), measured_tb_s=round(meas / (ms * 1e-3) / 1e12, 3),
+                        measured_frac_of_hbm_peak=round(meas / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        measured_over_compulsory=round(meas / compulsory, 1),
                         traffic_source='profiles/' + TRAFFIC_FILE, kernels_covered='%d of %d' % (covered, len(fam)))
         roof['step'] = step
         roof['families'] = [dict(kernel=d['kernel'], launches_per_step=d['launches'] // psteps,
@@ -557,7 +516,8 @@ def main():
                    warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32 (fp16x3 / bf16x3 split-operand MFMA, fp32 accumulate)', data='synthetic',
                    config=dict(workload='Charades-STA SeqPAN train step (fwd+bwd+clip+AdamWD, dropout %.1f), batch %d/GPU, '
-                                        'T=%d, vdim=%d, L=%d, C=%d, dim=128, 8 heads, 2 attention layers, random init'
+                                        'T=%d, vdim=%d, L=%d, C=%d, dim=128, 8 heads, 2 attention layers, random init; ONE batch resident in '
+                                        'HBM, batch assembly (hual_assemble_batch) outside the timed region'
                                         % (args.drop, args.batch, args.T, args.vdim, args.L, args.C),
                                global_batch=args.batch * world, T=args.T, vdim=args.vdim, L=args.L,
                                parallelism='dp%d' % world, launch='eager' if args.no_graph else 'hipGraph',

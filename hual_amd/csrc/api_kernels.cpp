@@ -125,15 +125,6 @@ int hual_attention_bwd(const float* Q, int ldq, const float* K, const float* V, 
 
 int hual_attention_keep_row_bytes(int Tk) { return attn_ldm(Tk); }
 
-int hual_attention_fwd_wide(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
-                            int Tk, int heads, const float* qmask, const float* kmask, const uint32_t* rng_state,
-                            float drop_rate, int drop_site, void* stream) {
-  HUAL_REQUIRE(drop_rate >= 0.f && drop_rate < 1.f && (drop_rate == 0.f || rng_state), "hual_attention_fwd_wide: dropout needs rng_state");
-  DropCfg d = make_dropcfg(rng_state, drop_rate);
-  return launch_attn_fwd_wide(Q, ldq, K, V, ldkv, O, ldo, B, Tq, Tk, heads, qmask, kmask, drop_rate > 0.f ? drop_site : -1, d,
-                              (hipStream_t)stream);
-}
-
 int hual_span_argmax(const float* start_logits, const float* end_logits, const float* vmask, int64_t* start_index,
                      int64_t* end_index, int B, int T, void* stream) {
   HUAL_REQUIRE(start_logits && end_logits && vmask && start_index && end_index && B > 0 && T > 0, "hual_span_argmax: null / empty");

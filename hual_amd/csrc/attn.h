@@ -45,11 +45,4 @@ int launch_attn_fwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
 // dQ, dK, dV in one launch (needs O and stats of the forward)
 int launch_attn_bwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t s);
 
-// Forward of the same attention at head size 64 (`heads` heads merged in [rows, 64 * heads]; Tk <= 128; no saved statistics /
-// keep bits): csrc/attn_wide.hip.  Not used by the SeqPAN graph (8 heads of 16) - it measures the attention products at a
-// head size where the matrix cores are not idle behind the softmax.  Philox row = query row * heads + head.
-int launch_attn_fwd_wide(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
-                         int Tk, int heads, const float* qmask, const float* kmask, int drop_site, const DropCfg& drop,
-                         hipStream_t s);
-
 }  // namespace hual

@@ -3,13 +3,14 @@
 // Forward, one workgroup (512 threads = 8 waves) per MT owned rows:
 //   LDS  X   [MT+24][128] fp32     x_l of the rows r0-12 .. r0+MT+11 (updated in place layer by layer)
 //        A   hi / lo planes        the GEMM operand c_l = depthwise7(LN(x_l)) pre-split into scaled fp16 pairs (bf16x3.h)
-//        W   64 KB                 the pointwise weight image of the current layer (LDS-DMA, requested one phase ahead)
+//        (the pointwise weights stay in REGISTERS: wave w keeps the fragments of its 16 output columns, loaded one layer ahead
+//         from the fragment-major T image - tilecore.h "T-form"; no weight buffer in LDS)
 //   per layer l (halo H_l = 9, 6, 3, 0 rows on either side of the owned rows):
 //     P1  every 32-lane group slides a 7-row window over its chunk of rows: layer norm (shuffle reductions), depthwise
 //         taps masked at clip boundaries (modules.py:66 zero padding), row scale, split, write A; c / mean / rstd of owned rows
 //         go to HBM for backward
-//     P2  wave (mt, ch) multiplies row tile mt by column half ch: A fragments by ds_read_b128, weight fragments by
-//         ds_read_b64_tr_b16, 48 x v_mfma_f32_16x16x32_f16
+//     P2  wave w multiplies its 16 output columns (register-resident weight fragments) by every row tile of the workgroup:
+//         activation fragments by ds_read_b128, 3 x v_mfma_f32_16x16x32_f16 per row tile and 32-deep k-step
 //     P3  bias, relu (saved), Philox dropout, + x_l from LDS -> x_{l+1} back into X (+ HBM for the owned rows)
 #include "convblock.h"
 #include "tilecore.h"

@@ -272,57 +272,83 @@ __device__ __forceinline__ void cq_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
-struct CqImg { char* p; int plane; };
-__device__ __forceinline__ CqImg cq_img(char* p, int rows) { CqImg im; im.p = p; im.plane = rows * 256; return im; }
+// Element format of an image: FMT 0 - bf16 hi + lo (16 significant bits whatever the magnitude: the backward's gradient operands);
+// FMT 1 - fp16 hi + lo of x * scale with a FIXED power-of-two scale (22 significant bits down to |x| scale >= 2^-3, an absolute floor of
+// 2^-25 / scale below: the forward's activations (scale 2^4: |x| < 4096 or the product turns Inf / NaN, loudly) and softmax
+// probabilities (scale 2^10)).  Round 4 first ran the forward on bf16 pairs too: the step-0 loss of the c1 trajectory test moved from
+// 1e-7 to 1.2e-6 of the float64 oracle's and the free-running trajectories separated ten times sooner.
+struct CqImg { char* p; int plane; float scale; };
+__device__ __forceinline__ CqImg cq_img(char* p, int rows, float scale = 1.0f) { CqImg im; im.p = p; im.plane = rows * 256; im.scale = scale; return im; }
+#define CQ_SCALE_ACT 16.0f
+#define CQ_SCALE_PROB 1024.0f
+template <int FMT>
+__device__ __forceinline__ void cq_split4(const CqImg& im, const float4& v, uint2& h, uint2& l) {
+  if (FMT == 1) f16_split4(f4scale1(v, im.scale), h, l);
+  else bf16_split4(v, h, l);
+}
+template <int FMT>
 __device__ __forceinline__ void cq_img_store4(const CqImg& im, int row, int col, const float4& v) {      // cols col .. col + 3, col % 4 == 0
   uint2 h, l;
-  bf16_split4(v, h, l);
+  cq_split4<FMT>(im, v, h, l);
   const int off = tile256_off(row, col >> 3) + 2 * (col & 7);
   *reinterpret_cast<uint2*>(im.p + off) = h;
   *reinterpret_cast<uint2*>(im.p + im.plane + off) = l;
 }
+template <int FMT>
 __device__ __forceinline__ void cq_img_store1(const CqImg& im, int row, int col, float v) {
   uint32_t h, l;
-  bf16_split_pair(v, 0.f, h, l);
+  if (FMT == 1) f16_split_pair(v * im.scale, 0.f, h, l);
+  else bf16_split_pair(v, 0.f, h, l);
   const int off = tile256_off(row, col >> 3) + 2 * (col & 7);
   *reinterpret_cast<uint16_t*>(im.p + off) = (uint16_t)h;
   *reinterpret_cast<uint16_t*>(im.p + im.plane + off) = (uint16_t)l;
 }
-__device__ __forceinline__ float cq_img_load1(const CqImg& im, int row, int col) {      // hi + lo: the value to 2^-17
+__device__ __forceinline__ float cq_img_load1(const CqImg& im, int row, int col) {      // bf16 image: hi + lo, the value to 2^-17
   const int off = tile256_off(row, col >> 3) + 2 * (col & 7);
   const uint32_t h = *reinterpret_cast<const uint16_t*>(im.p + off), l = *reinterpret_cast<const uint16_t*>(im.p + im.plane + off);
   return __uint_as_float(h << 16) + __uint_as_float(l << 16);
 }
 // fragment of the 16 x 32 operand block (non-contraction indices x0 .. x0 + 15, contraction indices k0 .. k0 + 31): lane (j, g) holds
-// element (x0 + j, k0 + 8 g + e), e = 0..7 - the A and the B map of v_mfma_f32_16x16x32_bf16 alike
+// element (x0 + j, k0 + 8 g + e), e = 0..7 - the A and the B map of v_mfma_f32_16x16x32_{bf16,f16} alike (the bytes are format blind)
 template <bool TR>
-__device__ __forceinline__ void cq_frag(const CqImg& im, int x0, int k0, int lane, bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void cq_frag(const CqImg& im, int x0, int k0, int lane, uint4& hi, uint4& lo) {
   if (!TR) {
     const int off = tile256_off(x0 + (lane & 15), (k0 >> 3) + (lane >> 4));
-    hi = *reinterpret_cast<const bf16x8*>(im.p + off);
-    lo = *reinterpret_cast<const bf16x8*>(im.p + im.plane + off);
+    hi = *reinterpret_cast<const uint4*>(im.p + off);
+    lo = *reinterpret_cast<const uint4*>(im.p + im.plane + off);
   } else {      // lane 4 q + p of a 16-lane group supplies row q, columns 4 p .. 4 p + 3 of the group's 4 x 16 block (EXEC all ones)
     const int q = (lane & 15) >> 2, pp = lane & 3, r = k0 + 8 * (lane >> 4) + q, ch = (x0 >> 3) + (pp >> 1);
     const int o1 = tile256_off(r, ch) + 8 * (pp & 1), o2 = tile256_off(r + 4, ch) + 8 * (pp & 1);
-    hi = join_tr(lds_read_tr16(im.p, o1), lds_read_tr16(im.p, o2));
-    lo = join_tr(lds_read_tr16(im.p + im.plane, o1), lds_read_tr16(im.p + im.plane, o2));
+    hi = __builtin_bit_cast(uint4, join_tr(lds_read_tr16(im.p, o1), lds_read_tr16(im.p, o2)));
+    lo = __builtin_bit_cast(uint4, join_tr(lds_read_tr16(im.p + im.plane, o1), lds_read_tr16(im.p + im.plane, o2)));
   }
 }
 // C tile [m0, m0 + 16) x [n0, n0 + 16) += sum over k < K (K % 32 == 0) of A(m, k) B(k, n); lane (j, g) register r = C[m0 + 4 g + r][n0 + j]
-template <bool AT, bool BT>
+// (FMT 1: the scales of the two images are divided out of the sum before it joins `acc`)
+template <bool AT, bool BT, int FMT>
 __device__ __forceinline__ f32x4 cq_mma(const CqImg& A, int m0, const CqImg& B, int n0, int K, int lane, f32x4 acc) {
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < K; k0 += 32) {
-    bf16x8 ah, al, bh, bl;
+    uint4 ah, al, bh, bl;
     cq_frag<AT>(A, m0, k0, lane, ah, al);
     cq_frag<BT>(B, n0, k0, lane, bh, bl);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+    if (FMT == 1) {
+      t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), t, 0, 0, 0);
+    } else {
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), t, 0, 0, 0);
+    }
   }
+  const float inv = FMT == 1 ? 1.0f / (A.scale * B.scale) : 1.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = FMT == 1 ? fmaf(t[r], inv, acc[r]) : acc[r] + t[r];
   return acc;
 }
 // score-matrix images: element (i, j) at [row j][col i] when LONG1 (N1 is the longer side), else [row i][col j]
-template <bool LONG1> __device__ __forceinline__ void cq_sc_store(const CqImg& im, int i, int j, float v) { cq_img_store1(im, LONG1 ? j : i, LONG1 ? i : j, v); }
+template <bool LONG1, int FMT> __device__ __forceinline__ void cq_sc_store(const CqImg& im, int i, int j, float v) { cq_img_store1<FMT>(im, LONG1 ? j : i, LONG1 ? i : j, v); }
 template <bool LONG1> __device__ __forceinline__ float cq_sc_load(const CqImg& im, int i, int j) { return cq_img_load1(im, LONG1 ? j : i, LONG1 ? i : j); }
 
 #define CQ_STAGE_MAX 5          // float4 per thread of a 1024-thread workgroup: (N1q + N2q) * 32 / 1024
@@ -340,12 +366,13 @@ __device__ __forceinline__ void cq_rows_load(CqRows& r, const float* A, int n1, 
   }
 }
 // split the rows into the images of bufA (N1q rows) and bufB (N2q rows; 0: bufB is left alone)
+template <int FMT>
 __device__ __forceinline__ void cq_rows_store(const CqRows& r, const CqImg& A, int N1q, const CqImg& B, int N2q) {
 #pragma unroll
   for (int u = 0; u < CQ_STAGE_MAX; ++u) {
     const int idx = threadIdx.x + CQ_MAX_THREADS * u, row = idx >> 5, c4 = idx & 31;
-    if (row < N1q) cq_img_store4(A, row, 4 * c4, r.v[u]);
-    else if (row - N1q < N2q) cq_img_store4(B, row - N1q, 4 * c4, r.v[u]);
+    if (row < N1q) cq_img_store4<FMT>(A, row, 4 * c4, r.v[u]);
+    else if (row - N1q < N2q) cq_img_store4<FMT>(B, row - N1q, 4 * c4, r.v[u]);
   }
 }
 struct CqLds { int s, sri, sci, m, bufa, bufb, total, N1q, N2q, Sq; };
@@ -378,12 +405,12 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
   const CqLds L = cq_lds_map(c.N1, c.N2, 1);
   const int N1q = L.N1q, N2q = L.N2q;
   float* S = reinterpret_cast<float*>(lds + L.s);
-  const CqImg SrI = cq_img(lds + L.sri, L.Sq), ScI = cq_img(lds + L.sci, L.Sq);
+  const CqImg SrI = cq_img(lds + L.sri, L.Sq, CQ_SCALE_PROB), ScI = cq_img(lds + L.sci, L.Sq, CQ_SCALE_PROB);
   float* m1 = reinterpret_cast<float*>(lds + L.m);            // row masks and rank-1 terms of the clip: m1, s0 [N1p]; m2, s1 [N2p]
   float* m2 = m1 + c.N1p;
   float* s0 = m2 + c.N2p;
   float* s1 = s0 + c.N1p;
-  const CqImg bufA = cq_img(lds + L.bufa, N1q), bufB = cq_img(lds + L.bufb, N2q);
+  const CqImg bufA = cq_img(lds + L.bufa, N1q, CQ_SCALE_ACT), bufB = cq_img(lds + L.bufb, N2q, CQ_SCALE_ACT);
   const float* X1 = b.X + (size_t)c.x1base * HUAL_D;
   const float* X2 = b.X + (size_t)c.x2base * HUAL_D;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -426,19 +453,19 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       }
     }
   }
-  cq_rows_store(rows, bufA, N1q, bufB, N2q);
+  cq_rows_store<1>(rows, bufA, N1q, bufB, N2q);
   cq_barrier();
   CQ_STAMP(1);
   // ---- score = d1w . d2^T + s0 + s1
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
-    const f32x4 acc = cq_mma<false, false>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
+    const f32x4 acc = cq_mma<false, false, 1>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[(i0 + 4 * g + r) * c.ld + n0 + j] = acc[r] + s0[i0 + 4 * g + r] + s1[n0 + j];
   }
   cq_barrier();
   CQ_STAMP(2);
-  cq_rows_store(xrows, bufA, N1q, bufB, N2q);      // X1, X2
+  cq_rows_store<1>(xrows, bufA, N1q, bufB, N2q);      // X1, X2
   // ---- row softmax over j with mask2 (layers.py:122-123); zero outside the valid block (the images are read up to N1q x N2q).
   // Rows of at most 32 columns go two per wave (a 32-lane half each)
   if (N2q <= 32) {
@@ -453,7 +480,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       const float mx = half_max32(lg);
       const float e = ok ? __expf(lg - mx) : 0.f;
       const float inv = 1.0f / half_sum32(e);
-      cq_sc_store<LONG1>(SrI, i, l32, ok ? e * inv : 0.f);
+      cq_sc_store<LONG1, 1>(SrI, i, l32, ok ? e * inv : 0.f);
     }
   } else {
     for (int i = wave; i < N1q; i += CQ_WAVES) {
@@ -478,7 +505,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
           const float mk = m2[jj];
           v = __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx) * inv;
         }
-        cq_sc_store<LONG1>(SrI, i, jj, v);
+        cq_sc_store<LONG1, 1>(SrI, i, jj, v);
       }
     }
   }
@@ -495,7 +522,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       const float mx = half_max32(lg);
       const float e = ok ? __expf(lg - mx) : 0.f;
       const float inv = 1.0f / half_sum32(e);
-      cq_sc_store<LONG1>(ScI, l32, jj, ok ? e * inv : 0.f);
+      cq_sc_store<LONG1, 1>(ScI, l32, jj, ok ? e * inv : 0.f);
     }
   } else {
     for (int jj = wave; jj < N2q; jj += CQ_WAVES) {
@@ -520,7 +547,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
           const float mk = m1[i];
           v = __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx) * inv;
         }
-        cq_sc_store<LONG1>(ScI, i, jj, v);
+        cq_sc_store<LONG1, 1>(ScI, i, jj, v);
       }
     }
   }
@@ -540,7 +567,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
   float* M2 = b.M2 + ((size_t)dir * rs.B + clip) * cq_m2_rows(rs.T, rs.L) * HUAL_D;
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    const f32x4 acc = cq_mma<LONG1, true>(SrI, i0, bufB, n0, N2q, lane, zero);
+    const f32x4 acc = cq_mma<LONG1, true, 1>(SrI, i0, bufB, n0, N2q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * g + r;
@@ -556,7 +583,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
     m2acc[q] = zero;
     if (tile < njq * 8) {
       const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;   // rows of M2 = index j of the score
-      m2acc[q] = cq_mma<!LONG1, true>(ScI, i0, bufA, n0, N1q, lane, zero);
+      m2acc[q] = cq_mma<!LONG1, true, 1>(ScI, i0, bufA, n0, N1q, lane, zero);
     }
   }
   cq_barrier();
@@ -568,7 +595,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (i0 + 4 * g + r < c.N2p) M2[(size_t)(i0 + 4 * g + r) * HUAL_D + n0 + j] = m2acc[q][r];
-        cq_img_store1(bufB, i0 + 4 * g + r, n0 + j, m2acc[q][r]);
+        cq_img_store1<1>(bufB, i0 + 4 * g + r, n0 + j, m2acc[q][r]);
       }
     }
   }
@@ -577,7 +604,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
   // ---- q2c = Sr . M2          (= (Sr.Sc^T).x1 of layers.py:127, re-associated)
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    const f32x4 acc = cq_mma<LONG1, true>(SrI, i0, bufB, n0, N2q, lane, zero);
+    const f32x4 acc = cq_mma<LONG1, true, 1>(SrI, i0, bufB, n0, N2q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * g + r;
@@ -786,11 +813,28 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
     m1[idx] = (k < (first ? c.N1 : c.N2)) ? rs.rowmask[(first ? c.x1base : c.x2base) + k] : 0.f;     // (m2 follows m1)
   }
   {
-    float4* lr = reinterpret_cast<float4*>(SrI.p);
-    float4* lc = reinterpret_cast<float4*>(ScI.p);
-    for (int idx = threadIdx.x; idx < L.Sq * 32; idx += CQ_THREADS) { lr[idx] = gSr[idx]; lc[idx] = gSc[idx]; }
+    // the forward saved fp16 pairs of p * 2^10 (both planes, Sq x 256 bytes each): every 16-byte chunk becomes the bf16 pair of the
+    // same eight probabilities at the same place (the swizzle is a permutation of chunks)
+    const int nch = L.Sq * 16;                         // chunks per plane
+    for (int idx = threadIdx.x; idx < 2 * nch; idx += CQ_THREADS) {
+      const bool sc = idx >= nch;
+      const int ch = sc ? idx - nch : idx;
+      const float4* g = sc ? gSc : gSr;
+      const uint4 h = __builtin_bit_cast(uint4, g[ch]), l = __builtin_bit_cast(uint4, g[nch + ch]);
+      const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+      uint32_t oh[4], ol[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x2_t hf = __builtin_convertvector(__builtin_bit_cast(f16x2_t, hw[k]), f32x2_t);
+        const f32x2_t lf = __builtin_convertvector(__builtin_bit_cast(f16x2_t, lw[k]), f32x2_t);
+        bf16_split_pair((hf[0] + lf[0]) * (1.0f / CQ_SCALE_PROB), (hf[1] + lf[1]) * (1.0f / CQ_SCALE_PROB), oh[k], ol[k]);
+      }
+      char* dst = (sc ? ScI.p : SrI.p) + (size_t)ch * 16;
+      *reinterpret_cast<uint4*>(dst) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+      *reinterpret_cast<uint4*>(dst + SrI.plane) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+    }
   }
-  cq_rows_store(r1, bufA, N1q, bufB, N2q);          // dC2Q, X2
+  cq_rows_store<0>(r1, bufA, N1q, bufB, N2q);          // dC2Q, X2
   cq_barrier();
   CQ_STAMP(17);
   // ---- first half of dSr = dc2q . x2^T (+ dq2c . M2^T below) ;  dXb (x2 rows) = Sr^T . dc2q
@@ -801,12 +845,12 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
     const int tile = wave + CQ_WAVES * q;
     if (tile < ni * nj) {
       const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
-      sacc[q] = cq_mma<false, false>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
+      sacc[q] = cq_mma<false, false, 0>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
     }
   }
   for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    const f32x4 acc2 = cq_mma<!LONG1, true>(SrI, i0, bufA, n0, N1q, lane, zero);
+    const f32x4 acc2 = cq_mma<!LONG1, true, 0>(SrI, i0, bufA, n0, N1q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int jj = i0 + 4 * g + r;
@@ -815,7 +859,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   }
   cq_barrier();
   CQ_STAMP(18);
-  cq_rows_store(r2, bufA, N1q, bufB, N2q);          // dQ2C, M2
+  cq_rows_store<0>(r2, bufA, N1q, bufB, N2q);          // dQ2C, M2
   cq_barrier();
   cq_rows_load(r2, b.D1W + x1off, c.N1, N1q, b.D2 + x2off, c.N2, N2q);     // for the last two products
 #pragma unroll
@@ -823,7 +867,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
     const int tile = wave + CQ_WAVES * q;
     if (tile < ni * nj) {
       const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
-      const f32x4 acc = cq_mma<false, false>(bufA, i0, bufB, n0, HUAL_D, lane, sacc[q]);
+      const f32x4 acc = cq_mma<false, false, 0>(bufA, i0, bufB, n0, HUAL_D, lane, sacc[q]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) dSr[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
     }
@@ -836,12 +880,12 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
     macc[q] = zero;
     if (tile < njq * 8) {
       const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-      macc[q] = cq_mma<!LONG1, true>(SrI, i0, bufA, n0, N1q, lane, zero);
+      macc[q] = cq_mma<!LONG1, true, 0>(SrI, i0, bufA, n0, N1q, lane, zero);
     }
   }
   cq_barrier();
   CQ_STAMP(19);
-  cq_rows_store(r1, bufA, N1q, bufB, 0);                 // X1 (bufB receives dM2 below)
+  cq_rows_store<0>(r1, bufA, N1q, bufB, 0);                 // X1 (bufB receives dM2 below)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tile = wave + CQ_WAVES * q;
@@ -850,7 +894,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (i0 + 4 * g + r < c.N2p) dM2[(size_t)(i0 + 4 * g + r) * HUAL_D + n0 + j] = macc[q][r];
-        cq_img_store1(bufB, i0 + 4 * g + r, n0 + j, macc[q][r]);
+        cq_img_store1<0>(bufB, i0 + 4 * g + r, n0 + j, macc[q][r]);
       }
     }
   }
@@ -858,13 +902,13 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   // ---- dSc = x1 . dM2^T ;  dXa (x1 rows) = Sc . dM2
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
-    const f32x4 acc = cq_mma<false, false>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
+    const f32x4 acc = cq_mma<false, false, 0>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) dSc[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
   }
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    const f32x4 acc = cq_mma<LONG1, true>(ScI, i0, bufB, n0, N2q, lane, zero);
+    const f32x4 acc = cq_mma<LONG1, true, 0>(ScI, i0, bufB, n0, N2q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * g + r;
@@ -873,7 +917,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   }
   cq_barrier();
   CQ_STAMP(20);
-  cq_rows_store(r2, bufA, N1q, bufB, N2q);          // D1W, D2
+  cq_rows_store<0>(r2, bufA, N1q, bufB, N2q);          // D1W, D2
   // ---- softmax backward -> dscore (in dSr).  mask_logits is multiplicative, so its derivative is the mask.
   // (rows / columns of at most 32 elements go two per wave, as in the forward kernel)
   const int hh = lane >> 5, l32 = lane & 31;
@@ -931,7 +975,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
       const float v = (i < c.N1 && l32 < c.N2) ? dSr[i * c.ld + l32] : 0.f;
       const float rowsum = half_sum32(v);
       if (l32 == 0 && i < c.N1) gb.dS0[c.x1base + i] = rowsum;
-      cq_sc_store<LONG1>(dscI, i, l32, v);
+      cq_sc_store<LONG1, 0>(dscI, i, l32, v);
     }
   } else {
     for (int i = wave; i < N1q; i += CQ_WAVES) {
@@ -939,7 +983,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
       for (int jj = lane; jj < N2q; jj += 64) {
         const float v = (i < c.N1 && jj < c.N2) ? dSr[i * c.ld + jj] : 0.f;
         rowsum += v;
-        cq_sc_store<LONG1>(dscI, i, jj, v);
+        cq_sc_store<LONG1, 0>(dscI, i, jj, v);
       }
       rowsum = wave_sum64(rowsum);
       if (lane == 0 && i < c.N1) gb.dS0[c.x1base + i] = rowsum;
@@ -950,7 +994,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   // ---- dD1W = dscore . d2 ;  dD2 = dscore^T . d1w
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    const f32x4 acc = cq_mma<LONG1, true>(dscI, i0, bufB, n0, N2q, lane, zero);
+    const f32x4 acc = cq_mma<LONG1, true, 0>(dscI, i0, bufB, n0, N2q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * g + r;
@@ -959,7 +1003,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   }
   for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    const f32x4 acc = cq_mma<!LONG1, true>(dscI, i0, bufA, n0, N1q, lane, zero);
+    const f32x4 acc = cq_mma<!LONG1, true, 0>(dscI, i0, bufA, n0, N1q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int jj = i0 + 4 * g + r;
@@ -1109,7 +1153,8 @@ int launch_tri_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const CqParams& p, 
                         const DropCfg& drop, const float* dXa, const float* dXb, hipStream_t s) {
   HUAL_REQUIRE(part != nullptr, "tri_bwd: null partial-sum buffer");
   const int nv = tri_bwd_blocks_v(rs), nq = tri_bwd_blocks_q(rs);
-  HUAL_LAUNCH(0.0, 0.0, tri_bwd_kernel, dim3(nv + nq), dim3(256), 0, s, b, g, p, part, rs, drop, dXa, dXb, nv);
+  // bytes: X, D2, dD1W, dD2, dXa, dXb, dX in; dX out
+  HUAL_LAUNCH(0.0, 8.0 * 512.0 * rs.R, tri_bwd_kernel, dim3(nv + nq), dim3(256), 0, s, b, g, p, part, rs, drop, dXa, dXb, nv);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

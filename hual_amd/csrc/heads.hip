@@ -743,15 +743,18 @@ namespace hual {
 int launch_pool_align_fwd(const PoolArgs& a, const AlignPool* ap, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(rs.L <= 256, "pool: L <= 256");
   AlignPool z{};
-  HUAL_LAUNCH(0.0, 0.0, pool_align_fwd_kernel, dim3(xcd_round8(rs.B), ap ? 2 : 1), dim3(512), 0, s, a, ap ? *ap : z, rs);
+  // bytes: cq.feats rows in (query rows for the pooling; all rows for the alignment pooling), the [B,128] results out
+  HUAL_LAUNCH(0.0, 512.0 * (rs.Nq + (ap ? rs.R : 0) + 4.0 * rs.B), pool_align_fwd_kernel, dim3(xcd_round8(rs.B), ap ? 2 : 1), dim3(512), 0, s, a, ap ? *ap : z, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_pool_align_bwd(const PoolArgs& a, const PoolBwd& g, const AlignPool& ap, const AlignPoolBwd& ab, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(rs.T <= 256 && rs.L <= 256, "pool_align_bwd: T, L <= 256");
   HUAL_REQUIRE(ab.dF2 == g.dF2, "pool_align_bwd: the two parts write the same query rows");
-  if (rs.T <= 128 && rs.L <= 32) HUAL_LAUNCH(0.0, 0.0, (pool_align_bwd_kernel<32, 8>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
-  else HUAL_LAUNCH(0.0, 0.0, (pool_align_bwd_kernel<64, 64>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
+  // bytes: d fuse and d cq.feats of the video rows in, d cq.feats of the video rows back out, cq.feats query rows in, their gradient out
+  const double pab = 512.0 * (3.0 * rs.Nv + 2.0 * rs.Nq);
+  if (rs.T <= 128 && rs.L <= 32) HUAL_LAUNCH(0.0, pab, (pool_align_bwd_kernel<32, 8>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
+  else HUAL_LAUNCH(0.0, pab, (pool_align_bwd_kernel<64, 64>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -774,13 +777,15 @@ int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, const AlignSim* as,
     HUAL_REQUIRE(as->Bg >= 1 && as->Bg <= 1024 && as->ld >= HUAL_D && as->row0 == 0 && as->nrows == as->Bg, "align: global batch <= 1024");
     z = *as;
   }
-  HUAL_LAUNCH(0.0, 0.0, match_align_fwd_kernel, dim3(nm + (as ? as->Bg : 0)), dim3(256), 0, s, a, rs, z, nm);
+  // bytes: fuse in, outputs out (+ the [Nv,4] scores twice)
+  HUAL_LAUNCH(0.0, (1024.0 + 32.0) * rs.Nv, match_align_fwd_kernel, dim3(nm + (as ? as->Bg : 0)), dim3(256), 0, s, a, rs, z, nm);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, hipStream_t s) {
   HUAL_REQUIRE(g.part != nullptr, "match_bwd: partial-sum scratch");
-  HUAL_LAUNCH(0.0, 0.0, match_bwd_kernel, dim3(match_bwd_blocks(rs.Nv)), dim3(256), 0, s, a, g, rs);
+  // bytes: two gradient tensors and fuse in, d fuse out
+  HUAL_LAUNCH(0.0, 4.0 * 512.0 * rs.Nv, match_bwd_kernel, dim3(match_bwd_blocks(rs.Nv)), dim3(256), 0, s, a, g, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -789,8 +794,10 @@ int launch_heads(const HeadsArgs& a, int B, int T, hipStream_t s) {
   HUAL_REQUIRE(a.grad_only ? (a.ds && a.de && a.dZ[0]) : (a.logit[0] && a.logit[1] && a.vmask && a.start_index && a.end_index), "heads: null tensor");
   HUAL_REQUIRE(!a.h[0] || (a.h[1] && a.w[0] && a.w[1] && a.b[0] && a.b[1]), "heads: hidden layers incomplete");
   HUAL_REQUIRE(!a.dZ[0] || (a.dZ[1] && a.part[0] && a.part[1] && a.h[0]), "heads: gradient outputs incomplete");
-  if (T <= 128) HUAL_LAUNCH(0.0, 0.0, heads_kernel<8>, dim3(xcd_round8(B)), dim3(512), 0, s, a, T, B);
-  else HUAL_LAUNCH(0.0, 0.0, heads_kernel<16>, dim3(xcd_round8(B)), dim3(512), 0, s, a, T, B);
+  // bytes: the two hidden layers in, their gradients out (labels present), logits
+  const double hb = (a.dZ[0] ? 4.0 : 2.0) * 512.0 * B * T + 16.0 * B * T;
+  if (T <= 128) HUAL_LAUNCH(0.0, hb, heads_kernel<8>, dim3(xcd_round8(B)), dim3(512), 0, s, a, T, B);
+  else HUAL_LAUNCH(0.0, hb, heads_kernel<16>, dim3(xcd_round8(B)), dim3(512), 0, s, a, T, B);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -1,6 +1,7 @@
-// Building blocks of the fused multi-layer kernels (convblock.hip, dablock.hip): a workgroup of 512 threads keeps a tile of
-// activation rows in LDS as pre-split fp16 operand planes (bf16x3.h "f16x3"), streams one [128,128] weight image at a time
-// into LDS by LDS-DMA, and each wave multiplies a 16-row tile by a 64-column half on the matrix cores.
+// Building blocks of the fused multi-layer kernels (convblock.hip, dablock.hip, mproj.hip): a workgroup of 512 threads keeps a tile of
+// activation rows in LDS as pre-split fp16 operand planes (bf16x3.h "f16x3"); the weights never touch LDS - wave w holds the
+// fragments of ITS 16 output columns of the current [128,128] weight in registers, loaded one step ahead straight from the
+// fragment-major T / N images in L2 ("T-form", tf_* below), and multiplies them against all row tiles of the workgroup.
 #pragma once
 #include "common.h"
 #include "rowops.h"

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libhual_seqpan.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -119,7 +119,6 @@ def load():
                                        vp, f32, i32, vp]
     lib.hual_attention_keep_row_bytes.argtypes = [i32]
     lib.hual_span_argmax.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
-    lib.hual_attention_fwd_wide.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, f32, i32, vp]
     lib.hual_linear_dw.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, u64, vp]
     lib.hual_al_score.argtypes = [P(hual_al_set), vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]
     lib.hual_al_renew.argtypes = [P(hual_al_set), vp, i32, vp, vp, vp, P(ctypes.c_double), vp, vp]

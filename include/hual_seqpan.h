@@ -16,7 +16,9 @@
  *    (a hipStream_t passed as void*), so a whole step can be captured into a hipGraph.
  *  - return 0 on success, negative on error; message via hual_last_error() (thread local).
  *    No C++ exception crosses the ABI.
- *  - re-entrant: no global mutable state; one stream per device/rank is safe.
+ *  - re-entrant: the compute entry points keep no global mutable state; one stream per device/rank is safe.  The one exception
+ *    is the OPTIONAL per-kernel timing of bench.py's roofline leg (hual_prof_begin / hual_prof_end / hual_prof_get below): a
+ *    thread-local recorder that is off unless armed, and whose hual_prof_end() is the only call that synchronises.
  *  - kernels are specialised for gfx950 and model.dim = 128, num_heads = 8 (the value in both
  *    configs/<task>/SeqPAN.yaml); other values are rejected by hual_seqpan_validate().
  */
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HUAL_ABI_VERSION 5
+#define HUAL_ABI_VERSION 6
 
 #define HUAL_OK 0
 #define HUAL_ERR_INVALID (-1)
@@ -265,20 +267,12 @@ int hual_attention_fwd(const float* Q, int ldq, const float* K, const float* V, 
 /* The same with what a backward pass needs: stats [2][B*Tq*8] (row max of the scaled scores in the log2 domain, 1 / row sum,
  * per query and head) and - when drop_rate > 0 - the dropout of layers.py:86,91 / modules.py:114 on the probabilities with
  * the build's Philox stream (rng_state = device u32[3] {seed lo, seed hi, offset}, call site `drop_site`, RNG row =
- * query row * 8 + head; 8-bit decisions, see DESIGN.md "Dropout") and its keep bits: row (b*Tq + q)*8 + h of `ldm` bytes,
- * ldm >= hual_attention_keep_row_bytes(Tk) and a multiple of 16. */
+ * query row * 8 + head; 16-bit decisions with the exact 1 / (1 - rate) scale, see DESIGN.md "Dropout") and its keep words: an opaque
+ * buffer of B*Tq*8 rows of `ldm` bytes, ldm >= hual_attention_keep_row_bytes(Tk), 8-byte aligned (layout: csrc/attn.h). */
 int hual_attention_fwd_save(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
                             int Tk, const float* qmask, const float* kmask, float* stats, uint8_t* keep_bytes, int ldm,
                             const uint32_t* rng_state, float drop_rate, int drop_site, void* stream);
 int hual_attention_keep_row_bytes(int Tk);
-
-/* The forward of the same attention core at head size 64: `heads` heads merged in [rows, 64 * heads], Tk <= 128, dropout on
- * the probabilities with RNG row = query row * heads + head.  SeqPAN's configs use 8 heads of 16 (dim 128) and never reach
- * this entry point; it exists to measure the attention products at a head size where the matrix cores carry the kernel
- * (BASELINE.json north_star "MFMA utilisation on the attention GEMMs"; scripts/bench_attn.py --wide). */
-int hual_attention_fwd_wide(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
-                            int Tk, int heads, const float* qmask, const float* kmask, const uint32_t* rng_state,
-                            float drop_rate, int drop_site, void* stream);
 
 /* gradient of the attention core (tf.gradients through layers.py:80-96): dQ, dK, dV [rows,128] (written, not accumulated)
  * from dO, the forward output O, `stats` and `keep_bytes` of hual_attention_fwd_save with the same arguments.  Tq, Tk <= 256. */

@@ -22,8 +22,7 @@ The dropout on the attention probabilities (layers.py:86,91; modules.py:114 - ha
 8 decisions from the eight 16-bit halves of ONE call (hual_amd/csrc/attn.hip): key k = 16 kt + 4 g + r of RNG row `rid` uses
 the call with c0 = g + 4 (kt >> 1), output word 2 (kt & 1) + (r >> 1), half r & 1 (little endian) - the order in which a
 lane of the forward kernel holds its scores; the element is KEPT iff half < t16 and kept elements are scaled by
-1 / (1 - rate) exactly as tf.nn.dropout does (`mask_attn`; rounds 1-3 used 8-bit decisions with the scale 256 / t8, which
-`mask8` still restates for the head-size-64 demonstration kernel csrc/attn_wide.hip).
+1 / (1 - rate) exactly as tf.nn.dropout does (`mask_attn`; rounds 1-3 used 8-bit decisions with the scale 256 / t8).
 
 The row-local sites INSIDE the network (every dropout of conv_block, dual_attn_block and the predictor's feature encoders
 that is not an attention-probability site: SITE_CONV+l, SITE_DA+8li+{2,3,4}, SITE_FE+16p+{0..4,6,7,8}) draw 8 decisions
@@ -113,12 +112,6 @@ def uses_16bit_decisions(site):
     return False
 
 
-def keep_threshold8(rate):
-    """8-bit threshold of the attention-probability dropout: keep iff byte < t8"""
-    t = (keep_threshold(rate) + (1 << 23)) >> 24
-    return max(1, min(t, 256))
-
-
 class DropoutRNG:
     """mask(site, rows, ncols) -> float32 array [len(rows), ncols] of {0, scale}."""
 
@@ -131,8 +124,6 @@ class DropoutRNG:
         self.thresh = keep_threshold(rate)
         self.scale = keep_scale(rate)
         self.t16 = keep_threshold16(rate)
-        self.t8 = keep_threshold8(rate)
-        self.scale8 = np.float32(256.0) / np.float32(self.t8)
 
     def bits(self, site, rows, ncols):
         rows = np.asarray(rows, dtype=np.uint64).reshape(-1, 1)
@@ -176,18 +167,3 @@ class DropoutRNG:
         w = words[:, g + 4 * (kt >> 1), 2 * (kt & 1) + (r >> 1)]       # [rows, ncols]
         half = (w >> (16 * (r & 1)).astype(np.uint32)) & np.uint32(0xFFFF)
         return np.where(half < np.uint32(self.t16), self.scale, np.float32(0.0)).astype(np.float32)
-
-    def mask8(self, site, rows, ncols):
-        """8-bit decisions of the attention-probability sites: [len(rows), ncols] float32 of {0, 256 / t8}."""
-        rows = np.atleast_1d(np.asarray(rows, dtype=np.uint64)).reshape(-1, 1)
-        if self.rate == 0.0:
-            return np.ones((rows.shape[0], ncols), dtype=np.float32)
-        k = np.arange(ncols, dtype=np.int64)
-        kt, g, r = k >> 4, (k >> 2) & 3, k & 3
-        ncall = 4 * ((int(kt.max()) >> 2) + 1)
-        c0 = np.arange(ncall, dtype=np.uint64).reshape(1, -1)
-        o = philox4x32(c0, rows, np.uint64(site), np.uint64(self.offset & 0xFFFFFFFF), self.k0, self.k1)
-        words = np.stack(o, axis=-1)                                   # [rows, call, word]
-        w = words[:, g + 4 * (kt >> 2), kt & 3]                        # [rows, ncols]
-        byte = (w >> (8 * r).astype(np.uint32)) & np.uint32(0xFF)
-        return np.where(byte < np.uint32(self.t8), self.scale8, np.float32(0.0)).astype(np.float32)

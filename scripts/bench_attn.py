@@ -22,7 +22,6 @@ def main():
     ap.add_argument('--T', type=int, default=128)
     ap.add_argument('--L', type=int, default=20)
     ap.add_argument('--rate', type=float, default=0.2)
-    ap.add_argument('--wide', action='store_true', help='also time hual_attention_fwd_wide (head size 64, 8 heads, dim 512)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     l = lib.load()
@@ -78,41 +77,6 @@ def main():
         tot_f += res[0]
         tot_b += res[1]
     print('sum of the four jobs: fwd %.1f us, bwd %.1f us' % (tot_f, tot_b))
-    if a.wide:
-        # the same forward at head size 64 (8 heads, dim 512): algorithmic FLOPs 4 B H Tq Tk 64 against the fp32-matrix peak
-        # (157.3 TFLOP/s) and, counting the three split passes, against the bf16 pipe (2516.8 TFLOP/s)
-        H = 8
-        for name, Tq, Tk in (('v-self', a.T, a.T), ('v->q', a.T, a.L), ('q->v', a.L, a.T)):
-            g = torch.Generator().manual_seed(2)
-            Q = torch.randn(B * Tq, 64 * H, generator=g).to(dev)
-            K = torch.randn(B * Tk, 64 * H, generator=g).to(dev)
-            V = torch.randn(B * Tk, 64 * H, generator=g).to(dev)
-            qm = (torch.arange(Tq)[None, :] < torch.randint(Tq // 2 + 1, Tq + 1, (B, 1), generator=g)).float().reshape(-1).to(dev)
-            km = (torch.arange(Tk)[None, :] < torch.randint(Tk // 2 + 1, Tk + 1, (B, 1), generator=g)).float().reshape(-1).to(dev)
-            O = torch.empty(B * Tq, 64 * H, device=dev)
-
-            def wide():
-                lib.check(l.hual_attention_fwd_wide(lib.ptr(Q), 64 * H, lib.ptr(K), lib.ptr(V), 64 * H, lib.ptr(O), 64 * H, B, Tq, Tk, H,
-                                                    lib.ptr(qm), lib.ptr(km), lib.ptr(rng_state), a.rate, 9, lib.stream_ptr()))
-            for _ in range(3):
-                wide()
-            torch.cuda.synchronize()
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                for _ in range(a.iters):
-                    wide()
-            gr.replay()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(4):
-                gr.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / (4 * a.iters)
-            tf = 4.0 * B * H * Tq * Tk * 64 / us / 1e6
-            print('wide %-7s Tq=%3d Tk=%3d dh=64  fwd %7.2f us  %6.1f TF = %.2f of the fp32-matrix peak, %.3f of the bf16 pipe (3 passes)' %
-                  (name, Tq, Tk, us, tf, tf / 157.3, 3 * tf / 2516.8))
 
 
 if __name__ == '__main__':

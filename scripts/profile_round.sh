@@ -4,7 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of the same command  -> <tag>_bench_kernel_stats.csv, <tag>_bench_under_rocprof.json,
 #                                                               <tag>_step_timeline.txt
 #   3. PMC passes FETCH_SIZE / WRITE_SIZE (separate runs)    -> <tag>_pmc_traffic.json
-#   4. SQ counters of the dense / dW / attention kernels (+ the head-size-64 attention forward) -> <tag>_pmc_sq_counters.txt
+#   4. SQ counters of the dense / dW / attention kernels -> <tag>_pmc_sq_counters.txt
 # usage: scripts/profile_round.sh <tag>
 set -o pipefail
 tag=${1:-rX}
@@ -38,9 +38,4 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_W
 q=$(ls $out/pmc_sq/*/*counter_collection.csv $out/pmc_sq/*counter_collection.csv 2>/dev/null | head -1)
 { echo "# shape: B64 T128 L20 C8 vdim1024 drop0.2 f32"; for k in dw_bf16 conv_block_fwd conv_block_bwd ln_proj_kernel ln_proj_bwd da_post da_mid_bwd attn_fwd attn_bwd feature_ksplit mproj_kernel mproj_pair cq_fwd_staged cq_bwd_staged; do python $R/scripts/pmc_summary.py "$q" $k; done; } > $out/${tag}_pmc_sq_counters.txt
 rm -rf $out/pmc_sq
-# the head-size-64 attention forward (not a launch of the step): its own SQ pass, appended to the same file
-timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d $out/pmc_sqw -o s --output-format csv -- python3 $R/scripts/bench_attn.py --wide > /dev/null 2> $out/${tag}_pmc_sqw.err || { tail -5 $out/${tag}_pmc_sqw.err; exit 5; }
-q=$(ls $out/pmc_sqw/*/*counter_collection.csv $out/pmc_sqw/*counter_collection.csv 2>/dev/null | head -1)
-python $R/scripts/pmc_summary.py "$q" attn_fwd_wide >> $out/${tag}_pmc_sq_counters.txt
-rm -rf $out/pmc_sqw
 echo "[4] sq counters done"

@@ -108,42 +108,6 @@ def test_attention_fwd_bwd_with_dropout(dev, B, Tq, Tk, rate):
         assert err <= 1e-3 * want.abs().max().item() + 5e-5, (name, err, want.abs().max().item())
 
 
-@pytest.mark.parametrize('B,Tq,Tk,H', [(2, 16, 16, 2), (3, 37, 9, 1), (2, 128, 128, 8), (2, 128, 20, 4), (2, 20, 128, 4), (2, 100, 100, 3), (3, 1, 1, 2)])
-@pytest.mark.parametrize('rate', [0.0, 0.2])
-def test_attention_fwd_wide_heads(dev, B, Tq, Tk, H, rate):
-    """hual_attention_fwd_wide (head size 64, H heads merged in [rows, 64 H]) against the float64 restatement of
-    layers.py:80-96 at that head size, with the oracle's 8-bit dropout mask (RNG row = query row * H + head)"""
-    from hual_amd import lib
-    from oracle import philox as px
-    g = torch.Generator().manual_seed(1000 * B + 10 * Tq + Tk + H)
-    D = 64 * H
-    Q = torch.randn(B * Tq, D, generator=g).to(dev)
-    K = torch.randn(B * Tk, D, generator=g).to(dev)
-    V = torch.randn(B * Tk, D, generator=g).to(dev)
-    qlen = torch.randint(1, Tq + 1, (B,), generator=g)
-    klen = torch.randint(1, Tk + 1, (B,), generator=g)
-    qlen[0], klen[0] = Tq, Tk
-    qm = (torch.arange(Tq)[None, :] < qlen[:, None]).float().reshape(-1).to(dev)
-    km = (torch.arange(Tk)[None, :] < klen[:, None]).float().reshape(-1).to(dev)
-    seed, offset, site = 0x1234567800000042, 3, 9
-    rng_state = torch.tensor(np.array([seed & 0xffffffff, seed >> 32, offset], dtype=np.uint32).view(np.int32)).to(dev)
-    O = torch.empty(B * Tq, D, device=dev)
-    lib.check(lib.load().hual_attention_fwd_wide(lib.ptr(Q), D, lib.ptr(K), lib.ptr(V), D, lib.ptr(O), D, B, Tq, Tk, H, lib.ptr(qm),
-                                                 lib.ptr(km), lib.ptr(rng_state), rate, site, lib.stream_ptr()))
-    q = Q.double().cpu().view(B, Tq, H, 64).transpose(1, 2)
-    k = K.double().cpu().view(B, Tk, H, 64).transpose(1, 2)
-    v = V.double().cpu().view(B, Tk, H, 64).transpose(1, 2)
-    sc = q @ k.transpose(-1, -2) / 8.0
-    mask = qm.double().cpu().view(B, 1, Tq, 1) * km.double().cpu().view(B, 1, 1, Tk)
-    pr = torch.softmax(sc + (1.0 - mask) * (-1e30), -1)
-    if rate > 0:
-        rng = px.DropoutRNG(seed, offset, rate)
-        rid = (np.arange(B * Tq).reshape(B, 1, Tq) * H + np.arange(H).reshape(1, H, 1)).reshape(-1)
-        pr = pr * torch.from_numpy(rng.mask8(site, rid, Tk)).to(pr.dtype).reshape(B, H, Tq, Tk)
-    ref = (pr @ v).transpose(1, 2).reshape(B * Tq, D)
-    assert (O.double().cpu() - ref).abs().max().item() < 3e-4
-
-
 def _span_ref(s, e, m):
     """ans_predictor of the oracle (oracle/seqpan_ref.py, layers.py:194-203) on CPU float32"""
     from oracle import seqpan_ref as R
