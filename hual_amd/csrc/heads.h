@@ -73,6 +73,8 @@ struct HeadsArgs {
   float* part[2];                                 // with dZ: [B][2][128] per-clip sums (vector 0 = d w, vector 1[0] = d b), folded by colsum_kernel
   float* loc_part;                                // [B] per-clip loss terms (summed in a fixed order by the last workgroup)
   float inv_batch;                                // 1/B (reduce_mean over the batch)
+  const uint32_t* ovf; int novf;                  // label-free calls (no loss launch to carry the flag): the pack launch's overflow words
+                                                  // (gemm.h PackExtra); any set -> NaN logits, span indices -1
 };
 int launch_heads(const HeadsArgs& a, int B, int T, hipStream_t s);
 // matching-loss denominator (layers.py:173) + the four reported loss terms (model.py:120) from the partial sums

@@ -283,6 +283,12 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a, int T, int B) {
   HEADS_STAMP(0);
   float4 hs[NR], he[NR];
   float4 ws = f4zero(), we = f4zero();
+  float poison = 0.f;      // NaN when a weight did not fit its fp16 image (label-free calls; with labels the loss tail carries the flag)
+  if (a.ovf) {
+    bool bad = false;
+    for (int i = tid & 63; i < a.novf; i += 64) bad |= a.ovf[i] != 0u;
+    if (__any(bad)) poison = __builtin_nanf("");
+  }
   if (a.h[0]) {
     ws = ld4(a.w[0] + col); we = ld4(a.w[1] + col);
 #pragma unroll
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a, int T, int B) {
     if (tid < T) { dls[tid] = a.ds[b * T + tid]; dle[tid] = a.de[b * T + tid]; }
   } else if (a.h[0]) {
     // ---- 1. logits
-    const float bs = a.b[0][0], be = a.b[1][0];
+    const float bs = a.b[0][0] + poison, be = a.b[1][0] + poison;
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
       const int t = grp + 16 * u;
@@ -390,6 +396,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a, int T, int B) {
       v = bestv[1][0]; i = besti[1][0];
       for (int w = 1; w < 4; ++w) if (bestv[1][w] > v || (bestv[1][w] == v && besti[1][w] < i)) { v = bestv[1][w]; i = besti[1][w]; }
       a.end_index[b] = i;
+      if (poison != poison) { a.start_index[b] = -1; a.end_index[b] = -1; }
     }
   } else {
     __syncthreads();

@@ -699,6 +699,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     ha.ds = lab ? d_s : nullptr; ha.de = lab ? d_e : nullptr;
     if (lab) { ha.dZ[0] = dz_hs; ha.dZ[1] = dz_he; ha.part[0] = hpart_s; ha.part[1] = hpart_e; }
     ha.loc_part = loc_part; ha.inv_batch = 1.0f / (float)B;
+    if (!lab && c.novf) { ha.ovf = ovf; ha.novf = c.novf; }
     c.chk(launch_heads(ha, B, T, c.stream));
     if (lab && c.ok()) {
       LossTailArgs lt{loss_acc, match_part, match_fwd_blocks(Nv), loc_part, B, c.cfg->match_lambda, opt->match_denom_override,

@@ -159,7 +159,10 @@ typedef struct hual_ws_entry {
 int hual_seqpan_ws_table(const hual_cfg* cfg, int B, int T, int L, int C, hual_ws_entry* out, int max_entries);
 
 /* the graph of model.py:29-118: all five fetch tensors in ONE pass (the reference runs five).  With `labels`
- * it also evaluates model.py:76-120 (losses) and keeps what backward needs in the workspace. */
+ * it also evaluates model.py:76-120 (losses) and keeps what backward needs in the workspace.
+ * Dense weights travel as fp16 hi + lo images scaled by 2^10: a weight with |w| >= 63 does not fit.  The pass does not fail
+ * silently on one: with labels the four loss terms are NaN, without labels the start / end logits are NaN and the span
+ * indices -1. */
 int hual_seqpan_forward(const hual_cfg* cfg, const float* params, const float* word_table, const hual_batch* batch,
                         const hual_labels* labels, const hual_outputs* out, const hual_run_opts* opts, void* workspace,
                         uint64_t ws_bytes, void* stream);

@@ -71,3 +71,9 @@ def test_weight_outside_the_fp16_image_range_poisons_the_loss():
     m2 = pu.hip_model(cfg, p2, wv)
     bad = m2.forward(*feeds, drop_rate=0.0, labels=labels)
     assert np.isnan(float(bad['loss'])) and np.isnan(float(bad['loc_loss']))
+    # label-free calls have no loss launch to carry the flag: the logits are NaN and the span indices -1
+    free_ok = m.forward(*feeds, drop_rate=0.0)
+    assert np.isfinite(free_ok['start_logits'].cpu().numpy()).all() and int(free_ok['start_index'].min()) >= 0
+    free_bad = m2.forward(*feeds, drop_rate=0.0)
+    assert np.isnan(free_bad['start_logits'].cpu().numpy()).all() and np.isnan(free_bad['end_logits'].cpu().numpy()).all()
+    assert (free_bad['start_index'].cpu().numpy() == -1).all() and (free_bad['end_index'].cpu().numpy() == -1).all()
