@@ -99,6 +99,12 @@ DropCfg make_dropcfg(const uint32_t* state, float rate);
 
 // ---- device helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+// x / n for 0 <= x < 2^20, 1 <= n <= 2^12 (row -> clip lookups: n = T or L) in 4 instructions instead of the ~30 of the integer
+// division sequence (two quarter-rate multiplies among them; 17 % of the VALU issue cycles of conv_block_fwd_kernel's listing,
+// scripts/exp/isa_by_line.py).  (x + 0.5) / n is >= 0.5 / n away from the nearest integer; the float product is within
+// (x / n) * 2^-22 <= 0.25 / n of it (v_rcp_f32: 1 ulp), so the truncation is exact.  The callers' R = B (T + L) < 2^20 is checked
+// on the host (seqpan.hip setup_ctx).
+__device__ __forceinline__ int small_div(int x, int n) { return (int)(((float)x + 0.5f) * __builtin_amdgcn_rcpf((float)n)); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 // loads through a pointer that was itself read from device memory (job tables): without the address-space cast they are
 // FLAT loads, which count in lgkmcnt as well - every wait for an LDS read then waits for the global loads in flight

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
         v = ok ? cb_add(v, pv[u]) : v;
         if (row >= r0 && row < r0 + MT && row < R) st4(a.x0_out + (size_t)row * HUAL_D + col, v);
       }
-      X[i * CB_XS + l32] = v;
+      X[__mul24(i, CB_XS) + l32] = v;
     }
 #pragma unroll
     for (int l = 0; l < 4; ++l)
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
       const bool ok = ri < nout + 6 && t >= 0 && t < R;      // (quad-uniform)
       float4 v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = ok ? X[xi * CB_XS + 8 * q + k] : f4zero();
+      for (int k = 0; k < 8; ++k) v[k] = ok ? X[__mul24(xi, CB_XS) + 8 * q + k] : f4zero();
       float p[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) p[k] = cb_hsum(v[k]);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
         for (int s = 0; s < 10; ++s) {
           const int t = obase + la - 3 + s;
           const int xi = min(max(t - xbase, 0), XR - 1);
-          xr[s] = X[xi * CB_XS + l32];
+          xr[s] = X[__mul24(xi, CB_XS) + l32];      // (24-bit multiply: the 32-bit one is quarter rate)
           mr[s] = smean[xi];
           sr[s] = srstd[xi];
         }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         irv[rt] = ainv[16 * rt + j];
-        xres[rt] = X[min(max(orow[rt] - xbase, 0), XR - 1) * CB_XS + (ecol >> 2)];
+        xres[rt] = X[__mul24(min(max(orow[rt] - xbase, 0), XR - 1), CB_XS) + (ecol >> 2)];
       }
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
         rb[rt] = f4_posbits(v);
         if (dropping) v = f4_select(nib[rt], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
         v = cb_add(v, xres[rt]);
-        X[(o - xbase) * CB_XS + (ecol >> 2)] = v;
+        X[__mul24(o - xbase, CB_XS) + (ecol >> 2)] = v;
         if (own[rt]) st4(L.xout + (size_t)o * HUAL_D + ecol, v);
       }
       bits_store2_t(L.relu_bits, orow[0], orow[1], own[0], own[1], ecol >> 2, rb[0], rb[1], lane);

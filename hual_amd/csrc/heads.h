@@ -44,6 +44,8 @@ struct MatchArgs {
   float* loss_acc;        // accumulators (LA_*), may be null when labels is null
   float* part;            // [match_fwd_blocks(Nv)][2] per-block (cross-entropy sum, mask sum): summed by launch_loss_tail - float
                           // atomics queued on one address retire at ~30 ns each, 2 x 128 of them were half of this kernel
+  const uint32_t* rng;    // gumbel branch (layers.py:163-166; loss.no_gumbel false): the Philox state {k0, k1, offset}, else null
+  float inv_tau;          // 1 / loss.tau: logits = (logits + noise) * inv_tau; the backward scales d logits by it
 };
 int match_fwd_blocks(int Nv);
 struct AlignSim;

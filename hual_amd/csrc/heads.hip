@@ -1,5 +1,6 @@
 // Heads, losses and span argmax (see heads.h).  These are tiny, HBM/latency-bound row kernels.
 #include "heads.h"
+#include "philox.h"
 #include "prof.h"
 
 using namespace hual;
@@ -97,6 +98,11 @@ __device__ __forceinline__ void pool_fwd_body(const PoolArgs& a, const RowSpace&
   if (on && !half) a.PW[b * HUAL_D + c] = o + part[c];
 }
 
+// -log(-log(u + 1e-20) + 1e-20) with u = top 24 bits of a Philox word * 2^-24 (ops.py:6-9)
+__device__ __forceinline__ float gumbel_noise(uint32_t w) {
+  const float u = (float)(w >> 8) * 5.9604644775390625e-08f;
+  return -logf(-logf(u + 1e-20f) + 1e-20f);
+}
 __device__ __forceinline__ void match_fwd_body(const MatchArgs& a, const RowSpace& rs, int bid, int nblk) {
   __shared__ float red[2][8];
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -106,6 +112,8 @@ __device__ __forceinline__ void match_fwd_body(const MatchArgs& a, const RowSpac
   float4 w0 = ld4(a.Wm + (col + 0) * 4), w1 = ld4(a.Wm + (col + 1) * 4), w2 = ld4(a.Wm + (col + 2) * 4), w3 = ld4(a.Wm + (col + 3) * 4);
   const float4 bm = ld4(a.bm);
   float4 e0 = ld4(a.E + col), e1 = ld4(a.E + HUAL_D + col), e2 = ld4(a.E + 2 * HUAL_D + col), e3 = ld4(a.E + 3 * HUAL_D + col);
+  uint3 gk = make_uint3(0u, 0u, 0u);
+  if (a.rng) gk = make_uint3(a.rng[0], a.rng[1], a.rng[2]);
   for (int row = bid * 8 + grp; row < rs.Nv; row += nblk * 8) {
     const size_t off = (size_t)row * HUAL_D + col;
     const float4 f = ld4(a.fuse + off);
@@ -114,6 +122,11 @@ __device__ __forceinline__ void match_fwd_body(const MatchArgs& a, const RowSpac
     float l2 = f.x * w0.z + f.y * w1.z + f.z * w2.z + f.w * w3.z;
     float l3 = f.x * w0.w + f.y * w1.w + f.z * w2.w + f.w * w3.w;
     l0 = half_sum32(l0) + bm.x; l1 = half_sum32(l1) + bm.y; l2 = half_sum32(l2) + bm.z; l3 = half_sum32(l3) + bm.w;
+    if (a.rng) {      // gumbel noise (ops.py:6-9): u on the 2^-24 grid from the four words of one call, oracle/philox.py gumbel_uniform
+      const uint4_ r = philox4x32(0u, (uint32_t)row, (uint32_t)HUAL_SITE_GUMBEL, gk.z, gk.x, gk.y);
+      l0 = (l0 + gumbel_noise(r.x)) * a.inv_tau; l1 = (l1 + gumbel_noise(r.y)) * a.inv_tau;
+      l2 = (l2 + gumbel_noise(r.z)) * a.inv_tau; l3 = (l3 + gumbel_noise(r.w)) * a.inv_tau;
+    }
     const float mx = fmaxf(fmaxf(l0, l1), fmaxf(l2, l3));
     const float x0 = expf(l0 - mx), x1 = expf(l1 - mx), x2 = expf(l2 - mx), x3 = expf(l3 - mx);
     const float sum = x0 + x1 + x2 + x3;
@@ -182,6 +195,7 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
       dl2 += cs * (p.z - (lab == 2 ? 1.f : 0.f));
       dl3 += cs * (p.w - (lab == 3 ? 1.f : 0.f));
     }
+    if (a.rng) { dl0 *= a.inv_tau; dl1 *= a.inv_tau; dl2 *= a.inv_tau; dl3 *= a.inv_tau; }      // z = (logits + noise) / tau
     // dfuse = d + sum_c dl[c] * Wm[:,c]
     st4(g.dFuse + off, make_float4(d.x + dl0 * w0.x + dl1 * w0.y + dl2 * w0.z + dl3 * w0.w,
                                    d.y + dl0 * w1.x + dl1 * w1.y + dl2 * w1.z + dl3 * w1.w,

@@ -13,7 +13,7 @@ int validate_cfg(const hual_cfg& c) {
   HUAL_REQUIRE(c.max_vlen >= 1 && c.max_vlen <= 256, "max_vlen in [1,256]");
   HUAL_REQUIRE(c.attn_layer >= 1 && c.attn_layer <= HUAL_MAX_ATTN_LAYERS, "attn_layer in [1,8]");
   HUAL_REQUIRE(c.num_chars >= 2 && c.num_words >= 2, "num_chars / num_words too small");
-  if (!c.no_gumbel) return fail(HUAL_ERR_UNSUPPORTED, "loss.no_gumbel=false is not supported (both reference YAMLs set true)");
+  HUAL_REQUIRE(c.no_gumbel || c.tau > 0.f, "loss.tau must be positive when loss.no_gumbel is false");
   return 0;
 }
 

@@ -38,8 +38,11 @@ __device__ __forceinline__ void store_dz(float* dz, const uint8_t* bits, float s
 }
 
 __device__ __forceinline__ void row_to_clip(int row, int Nv, int T, int L, int& t, int& n, int& base) {
-  if (row < Nv) { int b = row / T; t = row - b * T; n = T; base = b * T; }
-  else { int r = row - Nv; int b = r / L; t = r - b * L; n = L; base = Nv + b * L; }
+  const bool v = row < Nv;
+  n = v ? T : L;
+  const int first = v ? 0 : Nv;
+  base = first + __mul24(small_div(row - first, n), n);
+  t = row - base;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -228,6 +228,7 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
   HUAL_REQUIRE(T <= 256 && L <= 256, "T, L <= 256");
   HUAL_REQUIRE(C >= 4, "char_ids need C >= 4 (conv width 4, VALID)");
   HUAL_REQUIRE((long long)B * (T + L) * 8 < (1ll << 28), "batch too large for 32-bit RNG row ids");
+  HUAL_REQUIRE((long long)B * (T + L) < (1ll << 20), "batch too large: B (T + L) < 2^20 rows (row -> clip lookups, common.h small_div)");
   c.cfg = cfg; c.B = B; c.T = T; c.L = L; c.C = C;
   {
     const ParamMap& pm = c.pm;
@@ -598,6 +599,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   ma.probs2 = (lab && !c.dry) ? probs_keep : nullptr;
   float* match_part = c.buf("match.part", (size_t)match_fwd_blocks(Nv), 2);
   ma.part = match_part;
+  if (!c.cfg->no_gumbel) { ma.rng = opt->rng_state; ma.inv_tau = 1.0f / c.cfg->tau; }      // layers.py:163-166
   // ---------------- alignment loss, cross-sample part (layers.py:232-247), rows of the [B,B] similarity in the same launch (its
   // column part is formed by the backward's pool_align launch); exact data parallel evaluates it outside
   float* d_that = c.buf("d.align.that", B, D);
@@ -872,6 +874,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     ma.labels = lab->match_labels; ma.probs = nullptr; ma.outputs = outputs; ma.loss_acc = loss_acc;
     // probs were written to the caller's match_scores buffer; keep a private copy for backward
     ma.probs = c.buf("match.probs", Nv, 4);
+    if (!c.cfg->no_gumbel) { ma.rng = opt->rng_state; ma.inv_tau = 1.0f / c.cfg->tau; }
     MatchBwd mb{};
     mb.dOut = d_in; mb.dOut2 = d_out_heads; mb.dFuse = d_fuse; mb.dWm = c.g(pm.match.k); mb.dbm = c.g(pm.match.b); mb.dE = c.g(pm.label_emb);
     mb.lambda = c.cfg->match_lambda;
@@ -1254,6 +1257,7 @@ static int check_common(const hual_cfg* cfg, const float* params, const hual_bat
   HUAL_REQUIRE(((uintptr_t)batch->video & 15) == 0, "video features must be 16-byte aligned");
   HUAL_REQUIRE(opts->drop_rate >= 0.f && opts->drop_rate < 1.f, "drop_rate in [0,1)");
   HUAL_REQUIRE(opts->drop_rate == 0.f || opts->rng_state != nullptr, "rng_state required when drop_rate > 0");
+  HUAL_REQUIRE(cfg->no_gumbel || opts->rng_state != nullptr, "rng_state required when loss.no_gumbel is false");
   HUAL_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)params & 15) == 0, "workspace/params alignment");
   return 0;
 }

@@ -122,8 +122,10 @@ __device__ __forceinline__ uint32_t f4_posbits(float4 v) {
 
 // clip segment [lo, hi) of unified row `row` (rowops.h RowSpace)
 __device__ __forceinline__ void cb_segment(int row, const hual::RowSpace& rs, int& lo, int& hi) {
-  if (row < rs.Nv) { const int b = row / rs.T; lo = b * rs.T; hi = lo + rs.T; }
-  else { const int q = row - rs.Nv; const int b = q / rs.L; lo = rs.Nv + b * rs.L; hi = lo + rs.L; }
+  const bool v = row < rs.Nv;
+  const int n = v ? rs.T : rs.L, base = v ? 0 : rs.Nv;
+  lo = base + __mul24(small_div(row - base, n), n);
+  hi = lo + n;
 }
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the fence makes

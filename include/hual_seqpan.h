@@ -47,6 +47,7 @@ extern "C" {
 #define HUAL_SITE_CONV 3
 #define HUAL_SITE_DA 8
 #define HUAL_SITE_TRI 24
+#define HUAL_SITE_GUMBEL 28   /* gumbel noise of the matching head (layers.py:163-166): RNG row = b*T+t, one call = the 4 classes */
 #define HUAL_SITE_FE 32
 
 /* keys of configs/<task>/SeqPAN.yaml read by models/model.py (model.py:17,36-43,61,83,101,122) */
@@ -60,9 +61,9 @@ typedef struct hual_cfg {
   int32_t attn_layer;  /* model.attn_layer */
   int32_t num_chars;   /* configs.num_chars */
   int32_t num_words;   /* rows of [zero; unk; word_table] */
-  int32_t no_gumbel;   /* loss.no_gumbel (must be 1; both YAMLs set true) */
+  int32_t no_gumbel;   /* loss.no_gumbel (both YAMLs set true); 0: gumbel noise on the matching logits, (logits + noise) / tau - needs rng_state */
   float match_lambda;  /* loss.match_lambda */
-  float tau;           /* loss.tau (unused when no_gumbel) */
+  float tau;           /* loss.tau (> 0; unused when no_gumbel) */
   float clip_norm;     /* train.clip_norm */
 } hual_cfg;
 
@@ -124,7 +125,7 @@ typedef struct hual_outputs {
 
 typedef struct hual_run_opts {
   float drop_rate;                /* the `dropout_rate` placeholder (0 = inference) */
-  const uint32_t* rng_state;      /* device u32[3] = {seed lo, seed hi, offset}; may be NULL when drop_rate == 0 */
+  const uint32_t* rng_state;      /* device u32[3] = {seed lo, seed hi, offset}; may be NULL when drop_rate == 0 and cfg.no_gumbel */
   float match_denom_override;     /* > 0: denominator of the masked matching loss (exact data parallel) */
   int32_t align_external;         /* 1: the [B,B] alignment loss is evaluated by the caller through
                                         hual_align_loss() on gathered features (exact data parallel) */

@@ -50,6 +50,7 @@ SITE_VIDEO = 2       # model.py:47     video_inputs    rows = b*T+t,        cols
 SITE_CONV = 3        # +layer (0..3)   modules.py:69   shared conv_block, unified rows
 SITE_DA = 8          # +8*li + {0 self probs, 1 cross probs, 2 dense_1 out, 3 LN2 out, 4 dense_2 out}
 SITE_TRI = 24        # +{0 q2v.x1(v rows), 1 q2v.x2(q rows), 2 v2q.x1(q rows), 3 v2q.x2(v rows)}  ops.py:104
+SITE_GUMBEL = 28     # layers.py:163-166 gumbel noise of the matching head: rows = b*T+t, the 4 words of ONE call = the 4 classes
 SITE_FE = 32         # +16*pass + {0..3 conv layer, 4 LN1 out, 5 attn probs, 6 attn out, 7 LN2 out, 8 dense out}
 
 
@@ -167,3 +168,15 @@ class DropoutRNG:
         w = words[:, g + 4 * (kt >> 1), 2 * (kt & 1) + (r >> 1)]       # [rows, ncols]
         half = (w >> (16 * (r & 1)).astype(np.uint32)) & np.uint32(0xFFFF)
         return np.where(half < np.uint32(self.t16), self.scale, np.float32(0.0)).astype(np.float32)
+
+
+def gumbel_uniform(seed, offset, rows):
+    """the uniform draws behind the gumbel noise of matching_loss (layers.py:163-166, ops.py:6-9): float32 [len(rows), 4] in
+    [0, 1) on the 2**-24 grid - the top 24 bits of the four output words of the call (c0 = 0, c1 = row, c2 = SITE_GUMBEL,
+    c3 = offset); hual_amd/csrc/heads.hip match_fwd_body draws the same numbers."""
+    seed = int(seed)
+    rows = np.atleast_1d(np.asarray(rows, dtype=np.uint64))
+    o = philox4x32(np.uint64(0), rows, np.uint64(SITE_GUMBEL), np.uint64(int(offset) & 0xFFFFFFFF), seed & 0xFFFFFFFF,
+                   (seed >> 32) & 0xFFFFFFFF)
+    w = np.stack(o, axis=-1)
+    return ((w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)

@@ -70,7 +70,8 @@ def hip_model(cfg, p, wv, device='cuda:0'):
     from hual_amd.model import SeqPAN
     hc = lib.make_cfg(vdim=cfg.vdim, dim=cfg.dim, num_heads=cfg.num_heads, word_dim=cfg.word_dim, char_dim=cfg.char_dim,
                       max_vlen=cfg.max_vlen, attn_layer=cfg.attn_layer, num_chars=cfg.num_chars, num_words=cfg.num_words,
-                      match_lambda=cfg.match_lambda, clip_norm=cfg.clip_norm)
+                      match_lambda=cfg.match_lambda, clip_norm=cfg.clip_norm, no_gumbel=1 if cfg.get('no_gumbel', True) else 0,
+                      tau=float(cfg.get('tau', 0.3)))
     m = SeqPAN(hc, wv.numpy(), device=device)
     m.load_state_dict({k: v.detach().numpy() for k, v in p.items()})
     return m

@@ -57,6 +57,25 @@ def test_bfloat16_video_feed_any_width():
     assert idx_equal
 
 
+def test_gumbel_branch_of_the_matching_loss():
+    """loss.no_gumbel false (layers.py:163-166, ops.py:6-9): logits = (logits + gumbel noise) / tau in the matching head, noise from
+    the shared Philox stream (site HUAL_SITE_GUMBEL) - every tensor, the losses and all gradients, with and without dropout; the
+    noise is also there in label-free calls (the reference's graph samples it whenever match_scores is evaluated)"""
+    for rate in (0.0, 0.2):
+        cfg, p, wv, b, labels = pu.make_case(B=3, T=20, L=6, C=5, seed=11)
+        cfg['no_gumbel'] = False
+        cfg['tau'] = 0.3
+        rows, idx_equal, o, h, m = pu.compare(cfg, p, wv, b, labels, drop_rate=rate)
+        _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
+        assert idx_equal
+    # the noise changes the scores (the test would pass vacuously if the flag were ignored on both sides)
+    cfg2, p2, wv2, b2, labels2 = pu.make_case(B=3, T=20, L=6, C=5, seed=11)
+    feeds = (b2['video'], b2['lens'], b2['word_ids'], b2['char_ids'])
+    plain = pu.hip_model(cfg2, p2, wv2).forward(*feeds, drop_rate=0.0)['match_scores'].cpu().numpy()
+    noisy = m.forward(*feeds, drop_rate=0.0)['match_scores'].cpu().numpy()
+    assert np.abs(plain - noisy).max() > 0.05
+
+
 def test_weight_outside_the_fp16_image_range_poisons_the_loss():
     """the dense weights travel as fp16 hi + lo images scaled by 2^10 (csrc/bf16x3.h): |w| >= 63 does not fit.  The pack launch
     flags such a weight and the loss launch turns the flag into NaN losses instead of silently wrong products"""

@@ -51,6 +51,22 @@ def test_dropout_mask_statistics():
     assert (m != m2).mean() > 0.2
 
 
+def test_gumbel_noise_of_the_matching_head():
+    """ops.py:6-9 / layers.py:163-166: uniform draws on the 2^-24 grid from one Philox call per row (site SITE_GUMBEL); the noise
+    -log(-log(u + 1e-20) + 1e-20) is finite at both ends of the grid and has the Gumbel(0, 1) mean (Euler's constant)"""
+    u = px.gumbel_uniform(seed=5, offset=7, rows=np.arange(20000))
+    assert u.shape == (20000, 4) and u.dtype == np.float32
+    assert u.min() >= 0.0 and u.max() < 1.0 and np.all(u * 2.0 ** 24 == np.floor(u * 2.0 ** 24))
+    w = px.philox4x32(0, 3, px.SITE_GUMBEL, 7, 5, 0)
+    assert [float(x) for x in u[3]] == [float(np.float32(int(x) >> 8) * np.float32(2.0 ** -24)) for x in w]
+    ends = np.array([0.0, 1.0 - 2.0 ** -24], dtype=np.float32)
+    n_ends = -np.log(-np.log(ends + np.float32(1e-20)) + np.float32(1e-20))
+    assert np.isfinite(n_ends).all() and n_ends[0] < -3.8 and n_ends[1] > 16.0
+    noise = -np.log(-np.log(u.astype(np.float64) + 1e-20) + 1e-20)
+    assert abs(noise.mean() - 0.5772) < 0.02
+    assert (px.gumbel_uniform(5, 8, np.arange(64)) != u[:64]).mean() > 0.9
+
+
 def test_param_count_formula():
     assert R.param_count(R.default_cfg(num_chars=40)) == 1186508       # SURVEY.md App. A, Charades YAML
     sh = R.param_shapes(R.default_cfg())
