@@ -5,6 +5,7 @@
 #include "cq.h"
 #include "bf16x3.h"
 #include "philox.h"
+#include "tilecore.h"
 #include "prof.h"
 
 using namespace hual;
@@ -94,6 +95,7 @@ __host__ __device__ inline size_t cq_m2_rows(int T, int L) {
 __global__ __launch_bounds__(256) void tri_prep_kernel(CqBufs b, CqParams p, RowSpace rs, DropCfg drop) {
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
+  const DropRegs dr = drop_load(drop);
   for (int row = blockIdx.x * 8 + grp; row < rs.R; row += gridDim.x * 8) {
     const bool isv = row < rs.Nv;
     const int d1 = isv ? 0 : 1;          // direction in which this row plays x1
@@ -103,9 +105,12 @@ __global__ __launch_bounds__(256) void tri_prep_kernel(CqBufs b, CqParams p, Row
     const size_t off = (size_t)row * HUAL_D + col;
     float4 x = ld4(b.X + off);
     float4 a = x, c = x;
-    if (drop.enabled) {
-      a = apply_drop4(drop, site1, (uint32_t)row, (uint32_t)l32, x);
-      c = apply_drop4(drop, site2, (uint32_t)row, (uint32_t)l32, x);
+    if (dr.enabled) {      // 16-bit decisions, one call per lane for both roles of the row (tilecore.h)
+      uint32_t n1, n2;
+      drop_nib2_sites_r(dr, site1, (uint32_t)row, site2, (uint32_t)row, (uint32_t)l32, n1, n2);
+      const float4 xs = make_float4(x.x * dr.scale, x.y * dr.scale, x.z * dr.scale, x.w * dr.scale);
+      a = f4_select(n1, xs);
+      c = f4_select(n2, xs);
     }
     float4 w0 = ld4(p.w0[d1] + col), wm = ld4(p.wm[d1] + col), w1 = ld4(p.w1[d2] + col);
     float s0 = half_sum32(a.x * w0.x + a.y * w0.y + a.z * w0.z + a.w * w0.w);
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
   // ---- score = d1w . d2^T + s0 + s1
   const int nj = c.N2p >> 4, ni = c.N1p >> 4;
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
-    const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+    const int ti = small_div(tile, nj), i0 = ti * 16, n0 = (tile - ti * nj) * 16;      // (no integer division: common.h)
     // (the rank-1 terms are requested before the product: one memory round trip for the whole tile)
     const float s1 = b.S1[c.x2base + min(n0 + j, c.N2 - 1)];
     float s0[4];
@@ -431,6 +436,26 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
     const uint32_t site1 = (uint32_t)HUAL_SITE_TRI + (dir == 0 ? 0u : 2u), site2 = (uint32_t)HUAL_SITE_TRI + (dir == 0 ? 1u : 3u);
     const int c4 = threadIdx.x & 31;
     const float4 w0 = ld4(p.w0[dir] + 4 * c4), wm = ld4(p.wm[dir] + 4 * c4), w1 = ld4(p.w1[dir] + 4 * c4);
+    // dropout: 16-bit decisions, the rows of a thread in pairs - one Philox call per lane and pair (tilecore.h drop_nib2_sites_r)
+    const DropRegs dr = drop_load(drop);
+    uint32_t nib[CQ_STAGE_MAX + 1];
+    auto stage_row = [&](int u, uint32_t& site, uint32_t& grow) {
+      const int row = (threadIdx.x + CQ_MAX_THREADS * u) >> 5;
+      const bool first = row < N1q;
+      const int k = first ? row : row - N1q;
+      const bool live = first ? k < c.N1 : k < c.N2;
+      site = first ? site1 : site2;
+      grow = (uint32_t)((first ? c.x1base : c.x2base) + (live ? k : 0));
+    };
+    if (dr.enabled) {
+#pragma unroll
+      for (int u = 0; u < CQ_STAGE_MAX; u += 2) {
+        uint32_t sA, rA, sB, rB;
+        stage_row(u, sA, rA);
+        stage_row(u + 1 < CQ_STAGE_MAX ? u + 1 : u, sB, rB);
+        drop_nib2_sites_r(dr, sA, rA, sB, rB, (uint32_t)c4, nib[u], nib[u + 1]);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < CQ_STAGE_MAX; ++u) {
       const int idx = threadIdx.x + CQ_MAX_THREADS * u, row = idx >> 5;
@@ -439,7 +464,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       const bool live = first ? k < c.N1 : k < c.N2;
       const int grow = (first ? c.x1base : c.x2base) + (live ? k : 0);      // unified row (dropout counter, destination)
       float4 x = xrows.v[u];
-      if (drop.enabled) x = apply_drop4(drop, first ? site1 : site2, (uint32_t)grow, (uint32_t)c4, x);
+      if (dr.enabled) x = f4_select(nib[u], make_float4(x.x * dr.scale, x.y * dr.scale, x.z * dr.scale, x.w * dr.scale));
       const float4 w = first ? w0 : w1;
       const float sv = half_sum32(x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w);
       const float4 o = first ? make_float4(x.x * wm.x, x.y * wm.y, x.z * wm.z, x.w * wm.w) : x;
@@ -458,10 +483,10 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
   CQ_STAMP(1);
   // ---- score = d1w . d2^T + s0 + s1
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
-    const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+    const int ti = small_div(tile, nj), i0 = ti * 16, n0 = (tile - ti * nj) * 16;      // (no integer division: common.h)
     const f32x4 acc = cq_mma<false, false, 1>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[(i0 + 4 * g + r) * c.ld + n0 + j] = acc[r] + s0[i0 + 4 * g + r] + s1[n0 + j];
+    for (int r = 0; r < 4; ++r) S[__mul24(i0 + 4 * g + r, c.ld) + n0 + j] = acc[r] + s0[i0 + 4 * g + r] + s1[n0 + j];
   }
   cq_barrier();
   CQ_STAMP(2);
@@ -475,7 +500,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       float lg = -INFINITY;
       if (ok) {
         const float mk = m2[l32];
-        lg = S[i * c.ld + l32] * mk + HUAL_MASK_VALUE * (1.0f - mk);
+        lg = S[__mul24(i, c.ld) + l32] * mk + HUAL_MASK_VALUE * (1.0f - mk);
       }
       const float mx = half_max32(lg);
       const float e = ok ? __expf(lg - mx) : 0.f;
@@ -488,14 +513,14 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       if (i < c.N1)
         for (int jj = lane; jj < c.N2; jj += 64) {
           const float mk = m2[jj];
-          mx = fmaxf(mx, S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk));
+          mx = fmaxf(mx, S[__mul24(i, c.ld) + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk));
         }
       mx = wave_max64(mx);
       float sum = 0.f;
       if (i < c.N1)
         for (int jj = lane; jj < c.N2; jj += 64) {
           const float mk = m2[jj];
-          sum += __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx);
+          sum += __expf(S[__mul24(i, c.ld) + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx);
         }
       sum = wave_sum64(sum);
       const float inv = 1.0f / sum;
@@ -503,7 +528,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
         float v = 0.f;
         if (i < c.N1 && jj < c.N2) {
           const float mk = m2[jj];
-          v = __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx) * inv;
+          v = __expf(S[__mul24(i, c.ld) + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx) * inv;
         }
         cq_sc_store<LONG1, 1>(SrI, i, jj, v);
       }
@@ -517,7 +542,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       float lg = -INFINITY;
       if (ok) {
         const float mk = m1[l32];
-        lg = S[l32 * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk);
+        lg = S[__mul24(l32, c.ld) + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk);
       }
       const float mx = half_max32(lg);
       const float e = ok ? __expf(lg - mx) : 0.f;
@@ -530,14 +555,14 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       if (jj < c.N2)
         for (int i = lane; i < c.N1; i += 64) {
           const float mk = m1[i];
-          mx = fmaxf(mx, S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk));
+          mx = fmaxf(mx, S[__mul24(i, c.ld) + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk));
         }
       mx = wave_max64(mx);
       float sum = 0.f;
       if (jj < c.N2)
         for (int i = lane; i < c.N1; i += 64) {
           const float mk = m1[i];
-          sum += __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx);
+          sum += __expf(S[__mul24(i, c.ld) + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx);
         }
       sum = wave_sum64(sum);
       const float inv = 1.0f / sum;
@@ -545,7 +570,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
         float v = 0.f;
         if (i < c.N1 && jj < c.N2) {
           const float mk = m1[i];
-          v = __expf(S[i * c.ld + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx) * inv;
+          v = __expf(S[__mul24(i, c.ld) + jj] * mk + HUAL_MASK_VALUE * (1.0f - mk) - mx) * inv;
         }
         cq_sc_store<LONG1, 1>(ScI, i, jj, v);
       }
@@ -681,11 +706,11 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
   CQ_STAMP(17);
   // dSr = dc2q . x2^T + dq2c . M2^T
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
-    const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+    const int ti = small_div(tile, nj), i0 = ti * 16, n0 = (tile - ti * nj) * 16;      // (no integer division: common.h)
     f32x4 acc = tile_mma<true, true>(dC2Q, HUAL_D, c.N1, X2, HUAL_D, c.N2, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
     acc = tile_mma<true, true>(dQ2C, HUAL_D, c.N1, M2, HUAL_D, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, acc);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dSr[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
+    for (int r = 0; r < 4; ++r) dSr[__mul24(i0 + 4 * g + r, c.ld) + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
   }
   CQ_STAMP(18);
   // dM2 = Sr^T . dq2c ;  dXb (x2 rows) = Sr^T . dc2q
@@ -704,10 +729,10 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
   CQ_STAMP(19);
   // dSc = x1 . dM2^T ;  dXa (x1 rows) = Sc . dM2
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
-    const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+    const int ti = small_div(tile, nj), i0 = ti * 16, n0 = (tile - ti * nj) * 16;      // (no integer division: common.h)
     f32x4 acc = tile_mma<true, true>(X1, HUAL_D, c.N1, dM2, HUAL_D, c.N2p, HUAL_D, HUAL_D, HUAL_D, i0, n0, j, g, zero);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dSc[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
+    for (int r = 0; r < 4; ++r) dSc[__mul24(i0 + 4 * g + r, c.ld) + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
   }
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
@@ -723,20 +748,20 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
   // softmax backward -> dscore (in dSr).  mask_logits is multiplicative, so its derivative is the mask.
   for (int i = wave; i < c.N1; i += CQ_WAVES) {
     float dot = 0.f;
-    for (int jj = lane; jj < c.N2; jj += 64) dot += Sr[i * c.ld + jj] * dSr[i * c.ld + jj];
+    for (int jj = lane; jj < c.N2; jj += 64) dot += Sr[__mul24(i, c.ld) + jj] * dSr[__mul24(i, c.ld) + jj];
     dot = wave_sum64(dot);
     for (int jj = lane; jj < c.N2; jj += 64)
-      dSr[i * c.ld + jj] = Sr[i * c.ld + jj] * (dSr[i * c.ld + jj] - dot) * m2[jj];
+      dSr[__mul24(i, c.ld) + jj] = Sr[__mul24(i, c.ld) + jj] * (dSr[__mul24(i, c.ld) + jj] - dot) * m2[jj];
   }
   __syncthreads();
   for (int jj = wave; jj < c.N2; jj += CQ_WAVES) {
     float dot = 0.f;
-    for (int i = lane; i < c.N1; i += 64) dot += Sc[i * c.ld + jj] * dSc[i * c.ld + jj];
+    for (int i = lane; i < c.N1; i += 64) dot += Sc[__mul24(i, c.ld) + jj] * dSc[__mul24(i, c.ld) + jj];
     dot = wave_sum64(dot);
     float colsum = 0.f;
     for (int i = lane; i < c.N1; i += 64) {
-      const float v = dSr[i * c.ld + jj] + Sc[i * c.ld + jj] * (dSc[i * c.ld + jj] - dot) * m1[i];
-      dSr[i * c.ld + jj] = v;
+      const float v = dSr[__mul24(i, c.ld) + jj] + Sc[__mul24(i, c.ld) + jj] * (dSc[__mul24(i, c.ld) + jj] - dot) * m1[i];
+      dSr[__mul24(i, c.ld) + jj] = v;
       colsum += v;
     }
     colsum = wave_sum64(colsum);
@@ -746,7 +771,7 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
   CQ_STAMP(21);
   for (int i = wave; i < c.N1; i += CQ_WAVES) {
     float rowsum = 0.f;
-    for (int jj = lane; jj < c.N2; jj += 64) rowsum += dSr[i * c.ld + jj];
+    for (int jj = lane; jj < c.N2; jj += 64) rowsum += dSr[__mul24(i, c.ld) + jj];
     rowsum = wave_sum64(rowsum);
     if (lane == 0) gb.dS0[c.x1base + i] = rowsum;
   }
@@ -844,7 +869,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   for (int q = 0; q < 2; ++q) {
     const int tile = wave + CQ_WAVES * q;
     if (tile < ni * nj) {
-      const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+      const int ti = small_div(tile, nj), i0 = ti * 16, n0 = (tile - ti * nj) * 16;      // (no integer division: common.h)
       sacc[q] = cq_mma<false, false, 0>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
     }
   }
@@ -866,10 +891,10 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   for (int q = 0; q < 2; ++q) {
     const int tile = wave + CQ_WAVES * q;
     if (tile < ni * nj) {
-      const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+      const int ti = small_div(tile, nj), i0 = ti * 16, n0 = (tile - ti * nj) * 16;      // (no integer division: common.h)
       const f32x4 acc = cq_mma<false, false, 0>(bufA, i0, bufB, n0, HUAL_D, lane, sacc[q]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dSr[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
+      for (int r = 0; r < 4; ++r) dSr[__mul24(i0 + 4 * g + r, c.ld) + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
     }
   }
   // dM2 = Sr^T . dq2c (kept in registers until every wave is done with M2); rows up to N2q: zero beyond N2 (Sr is zero there)
@@ -901,10 +926,10 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   cq_barrier();
   // ---- dSc = x1 . dM2^T ;  dXa (x1 rows) = Sc . dM2
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
-    const int i0 = (tile / nj) * 16, n0 = (tile % nj) * 16;
+    const int ti = small_div(tile, nj), i0 = ti * 16, n0 = (tile - ti * nj) * 16;      // (no integer division: common.h)
     const f32x4 acc = cq_mma<false, false, 0>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dSc[(i0 + 4 * g + r) * c.ld + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
+    for (int r = 0; r < 4; ++r) dSc[__mul24(i0 + 4 * g + r, c.ld) + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
   }
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
@@ -924,29 +949,29 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   if (c.N2p <= 32) {
     for (int i = 2 * wave + hh; i < c.N1p; i += 2 * CQ_WAVES) {
       const bool ok = i < c.N1 && l32 < c.N2;
-      const float sr = ok ? cq_sc_load<LONG1>(SrI, i, l32) : 0.f, ds = ok ? dSr[i * c.ld + l32] : 0.f;
+      const float sr = ok ? cq_sc_load<LONG1>(SrI, i, l32) : 0.f, ds = ok ? dSr[__mul24(i, c.ld) + l32] : 0.f;
       const float dot = half_sum32(sr * ds);
-      if (ok) dSr[i * c.ld + l32] = sr * (ds - dot) * m2[l32];
+      if (ok) dSr[__mul24(i, c.ld) + l32] = sr * (ds - dot) * m2[l32];
     }
   } else {
     for (int i = wave; i < c.N1; i += CQ_WAVES) {
       float dot = 0.f;
-      for (int jj = lane; jj < c.N2; jj += 64) dot += cq_sc_load<LONG1>(SrI, i, jj) * dSr[i * c.ld + jj];
+      for (int jj = lane; jj < c.N2; jj += 64) dot += cq_sc_load<LONG1>(SrI, i, jj) * dSr[__mul24(i, c.ld) + jj];
       dot = wave_sum64(dot);
       for (int jj = lane; jj < c.N2; jj += 64)
-        dSr[i * c.ld + jj] = cq_sc_load<LONG1>(SrI, i, jj) * (dSr[i * c.ld + jj] - dot) * m2[jj];
+        dSr[__mul24(i, c.ld) + jj] = cq_sc_load<LONG1>(SrI, i, jj) * (dSr[__mul24(i, c.ld) + jj] - dot) * m2[jj];
     }
   }
   cq_barrier();
   if (c.N1p <= 32) {
     for (int jj = 2 * wave + hh; jj < c.N2p; jj += 2 * CQ_WAVES) {
       const bool ok = jj < c.N2 && l32 < c.N1;
-      const float sc = ok ? cq_sc_load<LONG1>(ScI, l32, jj) : 0.f, ds = ok ? dSc[l32 * c.ld + jj] : 0.f;
+      const float sc = ok ? cq_sc_load<LONG1>(ScI, l32, jj) : 0.f, ds = ok ? dSc[__mul24(l32, c.ld) + jj] : 0.f;
       const float dot = half_sum32(sc * ds);
       float v = 0.f;
       if (ok) {
-        v = dSr[l32 * c.ld + jj] + sc * (ds - dot) * m1[l32];
-        dSr[l32 * c.ld + jj] = v;
+        v = dSr[__mul24(l32, c.ld) + jj] + sc * (ds - dot) * m1[l32];
+        dSr[__mul24(l32, c.ld) + jj] = v;
       }
       const float colsum = half_sum32(v);
       if (l32 == 0 && jj < c.N2) gb.dS1[c.x2base + jj] = colsum;
@@ -954,12 +979,12 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   } else {
     for (int jj = wave; jj < c.N2; jj += CQ_WAVES) {
       float dot = 0.f;
-      for (int i = lane; i < c.N1; i += 64) dot += cq_sc_load<LONG1>(ScI, i, jj) * dSc[i * c.ld + jj];
+      for (int i = lane; i < c.N1; i += 64) dot += cq_sc_load<LONG1>(ScI, i, jj) * dSc[__mul24(i, c.ld) + jj];
       dot = wave_sum64(dot);
       float colsum = 0.f;
       for (int i = lane; i < c.N1; i += 64) {
-        const float v = dSr[i * c.ld + jj] + cq_sc_load<LONG1>(ScI, i, jj) * (dSc[i * c.ld + jj] - dot) * m1[i];
-        dSr[i * c.ld + jj] = v;
+        const float v = dSr[__mul24(i, c.ld) + jj] + cq_sc_load<LONG1>(ScI, i, jj) * (dSc[__mul24(i, c.ld) + jj] - dot) * m1[i];
+        dSr[__mul24(i, c.ld) + jj] = v;
         colsum += v;
       }
       colsum = wave_sum64(colsum);
@@ -972,7 +997,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   const CqImg dscI = SrI;
   if (c.N2p <= 32) {
     for (int i = 2 * wave + hh; i < N1q; i += 2 * CQ_WAVES) {
-      const float v = (i < c.N1 && l32 < c.N2) ? dSr[i * c.ld + l32] : 0.f;
+      const float v = (i < c.N1 && l32 < c.N2) ? dSr[__mul24(i, c.ld) + l32] : 0.f;
       const float rowsum = half_sum32(v);
       if (l32 == 0 && i < c.N1) gb.dS0[c.x1base + i] = rowsum;
       cq_sc_store<LONG1, 0>(dscI, i, l32, v);
@@ -981,7 +1006,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
     for (int i = wave; i < N1q; i += CQ_WAVES) {
       float rowsum = 0.f;
       for (int jj = lane; jj < N2q; jj += 64) {
-        const float v = (i < c.N1 && jj < c.N2) ? dSr[i * c.ld + jj] : 0.f;
+        const float v = (i < c.N1 && jj < c.N2) ? dSr[__mul24(i, c.ld) + jj] : 0.f;
         rowsum += v;
         cq_sc_store<LONG1, 0>(dscI, i, jj, v);
       }
@@ -1038,14 +1063,17 @@ __global__ __launch_bounds__(256) void tri_bwd_kernel(CqBufs b, CqBwdBufs gb, Cq
   const uint32_t site1 = (uint32_t)HUAL_SITE_TRI + (isv ? 0u : 2u);
   const uint32_t site2 = (uint32_t)HUAL_SITE_TRI + (isv ? 3u : 1u);
   const float4 w0 = ld4(p.w0[d1] + col), wm = ld4(p.wm[d1] + col), w1 = ld4(p.w1[d2] + col);
+  const DropRegs dr = drop_load(drop);
   float4 gwm = f4zero(), gw0 = f4zero(), gw1 = f4zero();
   for (int row = row_lo + bid * 8 + grp; row < row_hi; row += nblk * 8) {
     const size_t off = (size_t)row * HUAL_D + col;
     float4 x = ld4(b.X + off);
     float4 mk1 = make_float4(1.f, 1.f, 1.f, 1.f), mk2 = mk1;
-    if (drop.enabled) {
-      mk1 = drop_mask4(drop, site1, (uint32_t)row, (uint32_t)l32);
-      mk2 = drop_mask4(drop, site2, (uint32_t)row, (uint32_t)l32);
+    if (dr.enabled) {
+      uint32_t n1, n2;
+      drop_nib2_sites_r(dr, site1, (uint32_t)row, site2, (uint32_t)row, (uint32_t)l32, n1, n2);
+      mk1 = mask_from_bits4(n1, dr.scale);
+      mk2 = mask_from_bits4(n2, dr.scale);
     }
     const float4 dd1w = ld4(gb.dD1W + off), dd2 = ld4(gb.dD2 + off);
     const float ds0 = gb.dS0[row], ds1 = gb.dS1[row];

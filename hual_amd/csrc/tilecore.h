@@ -91,6 +91,15 @@ __device__ __forceinline__ uint32_t drop_nib2_r(const DropRegs& d, uint32_t site
   nibB = odd ? (b >> 4) : (o & 15u);
   return b;        // the whole byte of the bit plane for (odd ? rowB : rowA, col4 >> 1)
 }
+// the same pairing for two (site, row) pairs - the two roles of a row at the trilinear sites (ops.py:104), or two rows of different sites
+__device__ __forceinline__ void drop_nib2_sites_r(const DropRegs& d, uint32_t siteA, uint32_t rowA, uint32_t siteB, uint32_t rowB, uint32_t col4,
+                                                  uint32_t& nibA, uint32_t& nibB) {
+  const bool odd = (col4 & 1u) != 0u;
+  const uint32_t b = drop_bits8_r(d, odd ? siteB : siteA, odd ? rowB : rowA, col4 >> 1);
+  const uint32_t o = dpp_xor1_u32(b);
+  nibA = odd ? (o >> 4) : (b & 15u);
+  nibB = odd ? (b >> 4) : (o & 15u);
+}
 // the same + the keep bytes stored into `plane` (rows are indices into the plane; rowoff = RNG row - plane row)
 __device__ __forceinline__ void drop_nib2_store_r(const DropRegs& d, uint32_t site, uint32_t rowoff, int rowA, int rowB, bool okA, bool okB,
                                                   uint32_t col4, uint8_t* plane, uint32_t& nibA, uint32_t& nibB) {

@@ -30,8 +30,9 @@ from the eight 16-bit halves of one call (hual_amd/csrc/tilecore.h drop_bits8_r)
 e = col & 7 uses word e >> 1, half e & 1 (little endian) and is KEPT iff half < t16, t16 = round(keep_prob * 65536) in
 [1, 65536] (= (thresh + 2**15) >> 16); kept elements are scaled by 1 / (1 - rate) exactly as tf.nn.dropout does.  The keep
 probability is t16 / 65536 (0.8000031 for rate 0.2 - closer to 1 - rate than the 2**-23 grid of TensorFlow's own float32
-uniform draw allows it to be).  The clip-feature site SITE_VIDEO (model.py:47) uses the same 16-bit decisions; the word /
-char embedding sites and the trilinear sites keep one decision per 32-bit word.
+uniform draw allows it to be).  The clip-feature site SITE_VIDEO (model.py:47) and the four trilinear sites SITE_TRI+{0..3}
+(ops.py:104; since round 4 - the Philox rounds were 30 % of the VALU time of the context-query forward) use the same 16-bit
+decisions; the word / char embedding sites keep one decision per 32-bit word.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
@@ -102,12 +103,14 @@ def keep_threshold16(rate):
 
 
 def uses_16bit_decisions(site):
-    """the clip features + the row-local dropout sites of conv_block / dual_attn_block / feature_encoder (not the attention
-    probabilities)"""
+    """the clip features, the trilinear sites + the row-local dropout sites of conv_block / dual_attn_block / feature_encoder
+    (not the attention probabilities, which have their own lane order: mask_attn)"""
     if site == SITE_VIDEO or SITE_CONV <= site < SITE_CONV + 4:
         return True
     if SITE_DA <= site < SITE_TRI:
         return (site - SITE_DA) % 8 in (2, 3, 4)
+    if SITE_TRI <= site < SITE_TRI + 4:
+        return True
     if site >= SITE_FE:
         return (site - SITE_FE) % 16 in (0, 1, 2, 3, 4, 6, 7, 8)
     return False
