@@ -170,6 +170,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_pair_kernel(LnProjArgs a0,
 #define DP_PLANE (DP_ROWS * 256)          // one plane of an operand slot
 #define DP_SLOT (2 * DP_PLANE)
 #define DP_NB 11                          // small vectors in LDS: 9 biases + ln2 gamma, beta
+#define DA_ACT_SCALE 16.0f                // fixed operand scale of the chained tiles of da_post_kernel
 
 // T-form (tilecore.h), like da_mid_bwd_kernel below: wave `wave` owns output columns 16 wave .. 16 wave + 15 of all NT row tiles and
 // keeps its weight fragments (T images, straight from L2, requested a step ahead) in registers.  Accumulator rt of lane (j, g) = row
@@ -180,12 +181,12 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   char* P0 = dp_lds;
   char* P1 = P0 + DP_SLOT;
   char* P2 = P1 + DP_SLOT;
-  float4* bl = reinterpret_cast<float4*>(P2 + DP_SLOT);             // [DP_NB][32] float4
+  char* P3 = P2 + DP_SLOT;
+  float4* bl = reinterpret_cast<float4*>(P3 + DP_SLOT);             // [DP_NB][32] float4
   float* ainv0 = reinterpret_cast<float*>(bl + DP_NB * 32);       // [48] per slot
   float* ainv1 = ainv0 + DP_ROWS;
   float* ainv2 = ainv1 + DP_ROWS;
-  float* smaxA = ainv2 + DP_ROWS;                                  // [48][8] maxima of the 16-column slices of the tile being written
-  float* smaxB = smaxA + 8 * DP_ROWS;
+  float* ainv3 = ainv2 + DP_ROWS;
   float4* scratch = reinterpret_cast<float4*>(P0);                 // fp32 rows [48][32] float4 for the LN2 pass (= slot 0)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -263,28 +264,21 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   auto save_nt = [&](float* dst, int rt, float4 v) {      // tensors only the backward pass reads
     if (r0 + 16 * rt + j < RE) DA_ST_NT(dst + eoff[rt], v);
   };
-  // tile -> operand slot, part 1: maxima of the wave's 16-column slices to LDS (the other columns of a row live in the other waves)
-  auto put_max = [&](float* sm, const float4 (&v)[NT]) {
-#pragma unroll
-    for (int rt = 0; rt < NT; ++rt) {
-      const float m = slice16_max(f4absmax(v[rt]), lane);
-      if (g == 0) sm[(16 * rt + j) * 8 + wave] = m;
-    }
-  };
-  // part 2 (behind a barrier): common row scale, split, store
-  auto put_planes = [&](char* P, float* ai, const float* sm, const float4 (&v)[NT]) {
+  // tile -> operand slot.  The tiles of the chain are layer-norm outputs, gated products of them and O(1) projections: a FIXED
+  // power-of-two scale (2^4; fp16 pairs then carry 22 bits for |x| >= 2^-7 and an absolute 2^-28 below - |x| must stay under
+  // 2^12) replaces the per-row scale, whose maximum needed an exchange of the waves' 16-column slice maxima
+  // through LDS and a barrier of its own.  With a fourth operand slot no product overwrites a slot another wave may still
+  // read: ONE barrier per chained product (behind the stores), where the per-row form had two.
+  auto put = [&](char* P, float* ai, const float4 (&v)[NT]) {
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
       const int lr = 16 * rt + j;
-      const float4 ma = *reinterpret_cast<const float4*>(sm + lr * 8), mb = *reinterpret_cast<const float4*>(sm + lr * 8 + 4);
-      float inv;
-      const float sc = f16_row_scale(fmaxf(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w)), fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w))), inv);
       uint2 h, l;
-      f16_split4(f4scale1(v[rt], sc), h, l);
+      f16_split4(f4scale1(v[rt], DA_ACT_SCALE), h, l);
       const int off = tile256_off(lr, ecol >> 3) + 8 * (g & 1);
       *reinterpret_cast<uint2*>(P + off) = h;
       *reinterpret_cast<uint2*>(P + DP_PLANE + off) = l;
-      if (wave == 0 && g == 0) ai[lr] = (r0 + lr < RE) ? inv : 0.f;
+      if (wave == 0 && g == 0) ai[lr] = (r0 + lr < RE) ? 1.0f / (DA_ACT_SCALE * HUAL_F16_WSCALE) : 0.f;
     }
   };
   auto zero_invalid = [&](float4 (&v)[NT]) {      // rows beyond the tensor carry zeros through the chain
@@ -313,19 +307,16 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   }
   zero_invalid(SV);
   zero_invalid(XV);
-  put_max(smaxA, SV);
-  put_max(smaxB, XV);
-  cb_barrier();
-  put_planes(P2, ainv2, smaxA, SV);
-  put_planes(P0, ainv0, smaxB, XV);
+  put(P2, ainv2, SV);
+  put(P3, ainv3, XV);
   cb_barrier();
   // ---- cross gating (layers.py:96-103): o = sigmoid(s_value . Wsg + b) * x_value + sigmoid(x_value . Wxg + b) * s_value
   tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
   fold(T1, ainv2, true);
   tf_load_w(wa, a.w[4], wave, lane);
-  tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
+  tf_mma_lean<NT, DP_PLANE>(P3, wb, lane, accp);
   tf_load_w(wb, a.w[5], wave, lane);
-  fold(T2, ainv0, true);
+  fold(T2, ainv3, true);
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) {
     const float4 sg = sig4(addb(T1[rt], 2)), xg = sig4(addb(T2[rt], 3));
@@ -335,39 +326,35 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     save_nt(a.o, rt, T1[rt]);
   }
   zero_invalid(T1);
-  put_max(smaxA, T1);
-  cb_barrier();
-  put_planes(P1, ainv1, smaxA, T1);
+  put(P0, ainv0, T1);                                        // (slot 0: last read by the s_value product, a barrier ago)
   cb_barrier();
   // ---- guided dense (layers.py:104)
-  tf_mma_lean<NT, DP_PLANE>(P1, wa, lane, accp);
+  tf_mma_lean<NT, DP_PLANE>(P0, wa, lane, accp);
   tf_load_w(wa, a.w[6], wave, lane);
-  fold(T1, ainv1, true);
+  fold(T1, ainv0, true);
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) { T1[rt] = addb(T1[rt], 4); save_nt(a.gd, rt, T1[rt]); }
   zero_invalid(T1);
-  put_max(smaxA, T1);
-  // RP1: the layer-normed input (ln1) -> slot 0 (free since the x_gate product: two barriers ago)
+  put(P2, ainv2, T1);                                        // (slot 2: last read by the s_gate product, a barrier ago)
+  // RP1: the layer-normed input (ln1) -> slot 1 (last read by the x_value product)
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int lr = grp + 16 * u;
     if (lr >= MT) continue;
     const bool ok = r0 + lr < RE;
-    const float i0 = cb_store_operand(P0, P0 + DP_PLANE, lr, l32, ok ? l1[u] : f4zero());
-    if (l32 == 0) ainv0[lr] = ok ? i0 : 0.f;
+    const float i0 = cb_store_operand(P1, P1 + DP_PLANE, lr, l32, ok ? l1[u] : f4zero());
+    if (l32 == 0) ainv1[lr] = ok ? i0 : 0.f;
   }
   cb_barrier();
-  put_planes(P2, ainv2, smaxA, T1);
-  cb_barrier();
   // ---- bilinear gate and value (layers.py:48-56, 106-110): scores = ln1 . W11 + g . W12 + b1 ; values = ln1 . W21 + g . W22 + b2
-  tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
-  fold(T1, ainv0, true);
+  tf_mma_lean<NT, DP_PLANE>(P1, wb, lane, accp);
+  fold(T1, ainv1, true);
   tf_load_w(wb, a.w[7], wave, lane);
   tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
   fold(T1, ainv2, false);
   tf_load_w(wa, a.w[8], wave, lane);
-  tf_mma_lean<NT, DP_PLANE>(P0, wb, lane, accp);
-  fold(T2, ainv0, true);
+  tf_mma_lean<NT, DP_PLANE>(P1, wb, lane, accp);
+  fold(T2, ainv1, true);
   tf_load_w(wb, a.w[9], wave, lane);
   tf_mma_lean<NT, DP_PLANE>(P2, wa, lane, accp);
   tf_load_w(wa, a.w[10], wave, lane);
@@ -383,13 +370,11 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     save_nt(a.mha, rt, T1[rt]);
   }
   zero_invalid(T1);
-  put_max(smaxA, T1);
-  cb_barrier();
-  put_planes(P1, ainv1, smaxA, T1);
+  put(P3, ainv3, T1);                                        // (slot 3: last read by the x_gate product, two barriers ago)
   cb_barrier();
   // ---- dense_1 + dropout + residual (modules.py:82-83); the rows also go to LDS as fp32 for the layer norm
-  tf_mma_lean<NT, DP_PLANE>(P1, wb, lane, accp);
-  fold(SV, ainv1, true);                                      // SV now holds `res`
+  tf_mma_lean<NT, DP_PLANE>(P3, wb, lane, accp);
+  fold(SV, ainv3, true);                                      // SV now holds `res`
   {
     uint32_t nbd[NT];
 #pragma unroll
@@ -969,7 +954,7 @@ int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s) {
   for (int k = 0; k < 9; ++k) HUAL_REQUIRE(a.b[k] != nullptr, "da_post: null bias");
   HUAL_REQUIRE(a.sv && a.xv && a.sg && a.xg && a.o && a.gd && a.gate && a.val && a.mha && a.res && a.l2 && a.out && a.mean2 && a.rstd2,
                "da_post: null output");
-  const size_t lds = (size_t)3 * DP_SLOT + DP_NB * 512 + (3 * DP_ROWS + 16 * DP_ROWS) * sizeof(float);
+  const size_t lds = (size_t)4 * DP_SLOT + DP_NB * 512 + 4 * DP_ROWS * sizeof(float);
   const double rows = (double)a.R;
   const double flops = 11.0 * 2.0 * rows * HUAL_D * HUAL_D, bytes = 4.0 * (rows * HUAL_D * 16.0 + 11.0 * HUAL_D * HUAL_D);
   const dim3 grid(xcd_clip_grid(a.R, a.Nv, a.MT));
