@@ -101,12 +101,12 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
       st4(a.y1 + (size_t)row * HUAL_D + col, y1);
       if (l32 == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
     }
-    const float i1 = cb_store_operand(P1, P1 + LP_ROWS * 256, lr, l32, y1);
+    const float i1 = cb_store_operand_fx(P1, P1 + LP_ROWS * 256, lr, l32, y1);      // layer-norm output: fixed operand scale (tilecore.h)
     if (l32 == 0) ainv1[lr] = ok ? i1 : 0.f;
     if (a.g2 || a.x2) {
       const float4 y2 = !ok ? f4zero() : (a.g2 ? cb_fma(xh, g2, b2) : rv[u]);
       if (ok && a.g2) st4(a.y2 + (size_t)row * HUAL_D + col, y2);
-      const float i2 = cb_store_operand(P2, P2 + LP_ROWS * 256, lr, l32, y2);
+      const float i2 = a.g2 ? cb_store_operand_fx(P2, P2 + LP_ROWS * 256, lr, l32, y2) : cb_store_operand(P2, P2 + LP_ROWS * 256, lr, l32, y2);
       if (l32 == 0) ainv2[lr] = ok ? i2 : 0.f;
     } else {
       scratch[lr * 32 + l32] = xr;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     const int lr = grp + 16 * u;
     if (lr >= MT) continue;
     const bool ok = r0 + lr < RE;
-    const float i0 = cb_store_operand(P1, P1 + DP_PLANE, lr, l32, ok ? l1[u] : f4zero());
+    const float i0 = cb_store_operand_fx(P1, P1 + DP_PLANE, lr, l32, ok ? l1[u] : f4zero());
     if (l32 == 0) ainv1[lr] = ok ? i0 : 0.f;
   }
   cb_barrier();
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
         st4_nt(a.l2 + (size_t)row * HUAL_D + col, y);
         if (l32 == 0) { a.mean2[row] = mean; a.rstd2[row] = rstd; }
       }
-      const float i2 = cb_store_operand(P2, P2 + DP_PLANE, lr, l32, y);
+      const float i2 = cb_store_operand_fx(P2, P2 + DP_PLANE, lr, l32, y);
       if (l32 == 0) ainv2[lr] = ok ? i2 : 0.f;
     }
   }

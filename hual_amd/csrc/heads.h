@@ -84,6 +84,8 @@ struct LossTailArgs {
   float* loss_acc; const float* match_part; int match_nblk; const float* loc_part; int loc_nblk;
   float lambda, override_denom; const float* denom_dev; float* loss_out;
   const uint32_t* ovf; int novf;      // optional: the pack launch's overflow words (gemm.h PackExtra): any set -> the losses are NaN
+  const float* align_rows; int nalign;      // optional: the alignment loss' row terms (AlignSim::row_loss), summed here in row order into
+                                            // loss_acc[LA_ALIGN]; null: loss_acc[LA_ALIGN] was written by the caller (data parallel)
 };
 int launch_loss_tail(const LossTailArgs& a, hipStream_t s);
 

@@ -474,6 +474,11 @@ __global__ __launch_bounds__(256) void loss_tail_kernel(LossTailArgs a) {
     la[LA_MATCH_SUM] = cs; la[LA_MASK_SUM] = ms; la[LA_LOC] = ls;
     const float denom = a.denom_dev ? *a.denom_dev : (a.override_denom > 0.f ? a.override_denom : ms + 1e-12f);
     la[LA_DENOM] = denom;
+    if (a.align_rows) {
+      float l = 0.f;
+      for (int i = 0; i < a.nalign; ++i) l += a.align_rows[i];
+      la[LA_ALIGN] = l;
+    }
     if (a.loss_out) {
       const float match = cs / denom + la[LA_ORTHO];
       const float align = la[LA_ALIGN];

@@ -605,8 +605,11 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   float* d_that = c.buf("d.align.that", B, D);
   float* d_vhat = c.buf("d.align.vhat", B, D);
   float* align_scratch = c.buf("align.scratch", (size_t)2 * B, B);
+  // the rows' loss terms: summed in row order by the loss tail (the same arithmetic as hual_align_loss_rows' column launch; float
+  // atomics from B workgroups made the reported loss differ by an ulp from run to run)
+  float* align_rows = c.buf("align.rowloss", B, 1);
   if (c.live()) {
-    AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, nullptr, d_that, d_vhat, loss_acc, 1.0f, ap.ld, 0, B};
+    AlignSim as{ap.that, ap.vhat, B, align_scratch, align_scratch + (size_t)B * B, align_rows, d_that, d_vhat, loss_acc, 1.0f, ap.ld, 0, B};
     c.chk(launch_match_fwd(ma, c.rs, (lab && !opt->align_external) ? &as : nullptr, c.stream));
   }
   // ---------------- conditioned predictor (modules.py:143-160)
@@ -705,7 +708,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     c.chk(launch_heads(ha, B, T, c.stream));
     if (lab && c.ok()) {
       LossTailArgs lt{loss_acc, match_part, match_fwd_blocks(Nv), loc_part, B, c.cfg->match_lambda, opt->match_denom_override,
-                      opt->match_denom_dev, out->loss_terms, ovf, c.novf};
+                      opt->match_denom_dev, out->loss_terms, ovf, c.novf, opt->align_external ? nullptr : align_rows, B};
       c.chk(launch_loss_tail(lt, c.stream));
     }
   }

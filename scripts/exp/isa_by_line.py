@@ -12,7 +12,7 @@ for l in lines:
     if m:
         files[int(m.group(1))] = (m.group(3) or m.group(2)).split('/')[-1]
 start = [i for i, l in enumerate(lines) if l.startswith('_Z') and sys.argv[2] in l.split(':')[0] and ':' in l][0]
-end = [i for i in range(start, len(lines)) if 's_endpgm' in lines[i]][0]
+end = [i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end')][0]
 labels = {}
 for i in range(start, end):
     m = re.match(r'^(\.LBB\d+_\d+):', lines[i])

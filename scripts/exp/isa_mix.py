@@ -2,7 +2,7 @@
 import sys, collections
 lines = open(sys.argv[1]).read().split('\n')
 start = [i for i, l in enumerate(lines) if l.startswith('_Z') and sys.argv[2] in l.split(':')[0] and ':' in l][0]
-end = [i for i in range(start, len(lines)) if 's_endpgm' in lines[i]][0]
+end = [i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end')][0]
 c = collections.Counter()
 for l in lines[start:end]:
     l = l.strip()
