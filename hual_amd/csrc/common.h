@@ -124,6 +124,24 @@ __device__ __forceinline__ uint2 ld2_global(const void* p) {
   return make_uint2(v.x, v.y);
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// componentwise select (a ternary on the struct goes through a stack slot: the compiler selects the ADDRESS)
+__device__ __forceinline__ float4 f4_pick(bool c, float4 a, float4 b) { return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
+// ---- range-checked row stores: buffer instructions drop a store whose offset lies outside the resource, so "store this row only if
+// it belongs to the tile" needs no branch - and a branch around a vector-memory operation makes the compiler's wait-count pass give
+// up (it drains EVERY outstanding load and store at the next wait: a memory round trip per guarded store, scripts/exp/isa_vmcnt0.py).
+// A resource covers `bytes` from `base` (< 4 GB); a lane whose row is not to be written passes an offset of ROW_SKIP.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#define ROW_SKIP 0xfffffff0u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);      // raw buffer, 32-bit data format (gfx9 family)
+}
+__device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, float4 v) {
+  const u32x4_t d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void bst1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 0);
+}
 // stores through a pointer whose address space the compiler cannot see (read from LDS / a device table): as FLAT stores they
 // would count in lgkmcnt too
 __device__ __forceinline__ void st4_global(float* p, float4 v) {

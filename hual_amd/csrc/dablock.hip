@@ -79,38 +79,56 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
         drop_nib2_store_r(dr, (uint32_t)a.drop_site1, a.drop_row0, r0 + lrA, r0 + lrB, okA, okB, (uint32_t)l32, a.y1_bits, nb1[2 * pr], nb1[2 * pr + 1]);
     }
   }
-  // ---- (residual) + layer norm(s) -> operand planes
+  // ---- (residual) + layer norm(s) -> operand planes.  Straight-line code over the NT row tiles: every global store is a range-checked
+  // buffer store (common.h: rows that are not this tile's get the offset ROW_SKIP and are dropped by the hardware, absent tensors a
+  // resource of zero bytes) - a branch around a store made the compiler drain every outstanding load and store at the next wait
+  // (scripts/exp/isa_vmcnt0.py: one full drain per row here, three per projection in the epilogues below)
+  const uint32_t rbytes = (uint32_t)R * (uint32_t)(HUAL_D * 4);
+  const __amdgpu_buffer_rsrc_t rs_xo = row_rsrc(a.x_out, a.xa ? rbytes : 0u), rs_y1 = row_rsrc(a.y1, rbytes), rs_y2 = row_rsrc(a.y2, a.g2 ? rbytes : 0u);
+  const __amdgpu_buffer_rsrc_t rs_mean = row_rsrc(a.mean, (uint32_t)R * 4u), rs_rstd = row_rsrc(a.rstd, (uint32_t)R * 4u);
+  const bool has_xa = a.xa != nullptr, pre_drop = a.pre_site >= 0 && dr.enabled, drop1 = a.drop_site1 >= 0 && dr.enabled;
+  const bool second = a.g2 || a.x2, ln2 = a.g2 != nullptr;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < NT; ++u) {
     const int lr = grp + 16 * u, row = r0 + lr;
-    if (lr >= MT) continue;
-    const bool ok = row < RE;
+    if (__builtin_amdgcn_readfirstlane(2 * wave + 16 * u) >= MT) {      // (wave-uniform, no vector-memory operation inside) both row groups of the wave lie beyond the tile
+      const float i0 = cb_store_operand_fx(P1, P1 + LP_ROWS * 256, lr, l32, f4zero());
+      if (l32 == 0) ainv1[lr] = 0.f * i0;
+      if (second) { cb_store_operand_fx(P2, P2 + LP_ROWS * 256, lr, l32, f4zero()); if (l32 == 0) ainv2[lr] = 0.f; }
+      continue;
+    }
+    const bool ok = lr < MT && row < RE;
+    const uint32_t roff = ok ? (uint32_t)row * (uint32_t)(HUAL_D * 4) + (uint32_t)col * 4u : ROW_SKIP;
+    const uint32_t soff = (ok && l32 == 0) ? (uint32_t)row * 4u : ROW_SKIP;
     float4 xr = xv[u];
-    if (a.xa) {
+    {
       float4 t = av[u];
-      if (a.pre_site >= 0 && dr.enabled) t = f4_select(nbp[u], make_float4(t.x * dr.scale, t.y * dr.scale, t.z * dr.scale, t.w * dr.scale));
-      xr = cb_add(t, xr);
-      if (ok) st4(a.x_out + (size_t)row * HUAL_D + col, xr);
+      const float4 td = f4_select(nbp[u], make_float4(t.x * dr.scale, t.y * dr.scale, t.z * dr.scale, t.w * dr.scale));
+      t = f4_pick(pre_drop, td, t);
+      xr = f4_pick(has_xa, cb_add(t, xr), xr);
+      bst4(rs_xo, roff, xr);
     }
     float mean, rstd;
     const float4 xh = ln_row(xr, mean, rstd);
     float4 y1 = cb_fma(xh, g1, b1);
-    if (a.drop_site1 >= 0 && dr.enabled) y1 = f4_select(nb1[u], make_float4(y1.x * dr.scale, y1.y * dr.scale, y1.z * dr.scale, y1.w * dr.scale));
-    if (!ok) y1 = f4zero();
-    if (ok) {
-      st4(a.y1 + (size_t)row * HUAL_D + col, y1);
-      if (l32 == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    {
+      const float4 yd = f4_select(nb1[u], make_float4(y1.x * dr.scale, y1.y * dr.scale, y1.z * dr.scale, y1.w * dr.scale));
+      y1 = f4_pick(drop1, yd, y1);
     }
+    y1 = f4_pick(ok, y1, f4zero());
+    bst4(rs_y1, roff, y1);
+    bst1(rs_mean, soff, mean);
+    bst1(rs_rstd, soff, rstd);
     const float i1 = cb_store_operand_fx(P1, P1 + LP_ROWS * 256, lr, l32, y1);      // layer-norm output: fixed operand scale (tilecore.h)
     if (l32 == 0) ainv1[lr] = ok ? i1 : 0.f;
-    if (a.g2 || a.x2) {
-      const float4 y2 = !ok ? f4zero() : (a.g2 ? cb_fma(xh, g2, b2) : rv[u]);
-      if (ok && a.g2) st4(a.y2 + (size_t)row * HUAL_D + col, y2);
-      const float i2 = a.g2 ? cb_store_operand_fx(P2, P2 + LP_ROWS * 256, lr, l32, y2) : cb_store_operand(P2, P2 + LP_ROWS * 256, lr, l32, y2);
+    if (second) {      // (uniform; LDS stores only)
+      const float4 y2 = f4_pick(ok, f4_pick(ln2, cb_fma(xh, g2, b2), rv[u]), f4zero());
+      const float i2 = ln2 ? cb_store_operand_fx(P2, P2 + LP_ROWS * 256, lr, l32, y2) : cb_store_operand(P2, P2 + LP_ROWS * 256, lr, l32, y2);
       if (l32 == 0) ainv2[lr] = ok ? i2 : 0.f;
     } else {
       scratch[lr * 32 + l32] = xr;
     }
+    bst4(rs_y2, roff, f4_pick(ok, cb_fma(xh, g2, b2), f4zero()));      // (zero-byte resource without a second layer norm)
   }
   // ---- the projections.  T-form (tilecore.h): wave `wave` owns output columns 16 wave .. 16 wave + 15 of all NT row tiles and holds
   // its weight fragments (T images, straight from L2, requested a projection ahead) in registers; the operand planes are never
@@ -121,7 +139,7 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
 #pragma unroll
   for (int p = 0; p < HUAL_LNPROJ_MAX; ++p) {
     if (p >= a.nproj) break;                                 // uniform
-    if (p + 1 < a.nproj) tf_load_w(w[(p + 1) & 1], a.wimg[p + 1], wave, lane);
+    tf_load_w_if(w[(p + 1) & 1], a.wimg[p + 1 < a.nproj ? p + 1 : p], p + 1 < a.nproj, wave, lane);      // (straight-line: no traffic behind the last one)
     if (p == 0) cb_barrier();
     const char* P = a.src[p] ? P2 : P1;
     const float* ai = a.src[p] ? ainv2 : ainv1;
@@ -139,15 +157,19 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
     for (int rt = 0; rt < NT; ++rt) nbo[rt] = 15u;
     const bool dropo = a.out_site[p] >= 0 && dr.enabled;
     if (dropo) drop_rows_t<NT>(dr, (uint32_t)a.out_site[p], a.drop_row0, r0 + j, RE, (uint32_t)(ecol >> 2), a.out_bits[p], nbo, lane);
+    const __amdgpu_buffer_rsrc_t rs_out = row_rsrc(a.out[p], ((uint32_t)(R - 1) * (uint32_t)a.ldo[p] + (uint32_t)HUAL_D) * 4u);
+    const bool relu = a.act[p] != 0, addx = a.add_x[p] != 0;
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
       const int lr = 16 * rt + j, row = r0 + lr;
-      if (row >= RE) continue;
       float4 v = make_float4(acc[rt].x + bias[p].x, acc[rt].y + bias[p].y, acc[rt].z + bias[p].z, acc[rt].w + bias[p].w);
-      if (a.act[p]) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-      if (dropo) v = f4_select(nbo[rt], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
-      if (a.add_x[p]) v = cb_add(v, scratch[lr * 32 + (ecol >> 2)]);
-      st4(a.out[p] + (uint32_t)row * (uint32_t)a.ldo[p] + (uint32_t)ecol, v);
+      const float4 vr = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      v = f4_pick(relu, vr, v);
+      const float4 vd = f4_select(nbo[rt], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
+      v = f4_pick(dropo, vd, v);
+      const float4 vx = cb_add(v, scratch[lr * 32 + (ecol >> 2)]);
+      v = f4_pick(addx, vx, v);
+      bst4(rs_out, row < RE ? ((uint32_t)row * (uint32_t)a.ldo[p] + (uint32_t)ecol) * 4u : ROW_SKIP, v);
     }
   }
 }

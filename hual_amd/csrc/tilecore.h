@@ -178,6 +178,17 @@ __device__ __forceinline__ void tf_load_w(TfW& w, const void* img, int ws, int l
     w.l[ks] = tf_ld16(p + 2048 * ks + TF_LO_OFF);
   }
 }
+// the same through a buffer resource: `live` false gives a resource of zero bytes - the eight loads are issued (straight-line code, the
+// compiler counts them) but touch no memory and return zeros.  For "prefetch the NEXT weights, if there are any" without a branch
+__device__ __forceinline__ void tf_load_w_if(TfW& w, const void* img, bool live, int ws, int lane) {
+  const __amdgpu_buffer_rsrc_t r = row_rsrc(img, live ? (uint32_t)TF_BLOCK : 0u);
+  const uint32_t off = 8192u * (uint32_t)ws + 16u * (uint32_t)lane;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    w.h[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off + 2048u * ks, 0, 0));
+    w.l[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off + 2048u * ks + TF_LO_OFF, 0, 0));
+  }
+}
 // acc[rt] = (this wave's columns of) rows 16 rt .. 16 rt + 15 of the operand planes (hi at Ahi, lo at Ahi + ALO) . block
 template <int NT, int ALO>
 __device__ __forceinline__ void tf_mma(const char* Ahi, const TfW& w, int lane, f32x4 (&acc)[NT]) {
