@@ -423,8 +423,29 @@ extern "C" int hual_debug_attn_stamps(unsigned long long* out, int n) {
 #define ATT_STAMP(i) do { } while (0)
 #endif
 
+// The backward of one job is cut in three: the V rows of a wave's first key block (registers), the staging of the panels (every load
+// requested before the first LDS store), and the products + epilogue.  A workgroup of the plain kind runs them back to back
+// (attn_bwd_body); the workgroup that serves the SMALL jobs of a four-job launch runs the next job's loads under the current job's
+// products (attn_bwd_chain below).
+struct BwdV { float4 v[2][2]; float km[2]; };
 template <bool DROP>
-__device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, char* lds, const DropCfg& drop) {
+__device__ __forceinline__ void attn_bwd_load_v(const AttnJob& job, int b, int h, int kp, BwdV& bv) {
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int Tk = job.Tk, kbase = job.krow0 + b * Tk;
+  const float* Vg = job.V + (size_t)kbase * job.ldkv + 16 * h;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int krow = min(32 * kp + 16 * t + j, Tk - 1);
+    const float* vptr = Vg + (size_t)krow * job.ldkv + 8 * (g & 1);
+    bv.v[t][0] = ld4(vptr); bv.v[t][1] = ld4(vptr + 4);
+    bv.km[t] = job.kmask[kbase + krow];
+  }
+}
+__device__ __forceinline__ bool attn_bwd_qsplit(int Tq, int Tk) { return (((Tk + 31) & ~31) >> 5) == 1 && (((Tq + 31) & ~31) >> 5) >= 4; }
+
+// ---- staging of a job (any shape up to 256 x 256): loads and LDS stores in one piece
+template <bool DROP>
+__device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h, char* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
@@ -444,24 +465,8 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
   const float* Kg = job.K + (size_t)kbase * job.ldkv + 16 * h;
   const float* Vg = job.V + (size_t)kbase * job.ldkv + 16 * h;
   const int nkp = Tkp >> 5, nqp = Tqp >> 5;
-  // V rows of the wave's first 32 keys: requested before the staging so that they arrive under it
-  float4 vreg[2][2];
-  float kmv[2];
-  auto load_v = [&](int kp) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int krow = min(32 * kp + 16 * t + j, Tk - 1);
-      const float* vptr = Vg + (size_t)krow * job.ldkv + 8 * (g & 1);
-      vreg[t][0] = ld4(vptr); vreg[t][1] = ld4(vptr + 4);
-      kmv[t] = job.kmask[kbase + krow];
-    }
-  };
-  // ONE block of <= 32 keys and at least four 32-query pairs (the video -> query jobs): the waves split the QUERIES instead of the
-  // keys - all four work on key block 0, wave w takes the query pairs w, w + 4, ..; dQ rows are then disjoint (one slot), and the
-  // partial dK / dV of the waves are summed through the three free slots
-  const bool qsplit = nkp == 1 && nqp >= 4;
+  (void)j; (void)g; (void)Xs; (void)dQw; (void)Vg; (void)nkp; (void)nqp; (void)wave;
   ATT_STAMP(0);
-  if (wave < nkp || qsplit) load_v(qsplit ? 0 : wave);
   // ---- staging: EVERY load of the workgroup's panels (+ O for delta = dO . O, the softmax statistics, the keep words) is requested
   // before the first split / LDS store: one memory round trip (a pass per 64 rows used to wait for its own loads, and the loads
   // of the statistics sat behind a lane-dependent branch: three to five serial round trips in front of the products)
@@ -528,9 +533,39 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
     if ((int)threadIdx.x + 512 < nmk) mk2[threadIdx.x + 512] = mkx[0];
     if ((int)threadIdx.x + 768 < nmk) mk2[threadIdx.x + 768] = mkx[1];
   }
-  ATT_STAMP(1);
-  __syncthreads();
-  ATT_STAMP(2);
+}
+
+// ---- products + epilogue of a staged job (ends with the dQ stores; the caller separates it from the next staging by a barrier)
+template <bool DROP>
+__device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int h, char* lds, const DropCfg& drop, BwdV& bv, bool have_v) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int Tq = job.Tq, Tk = job.Tk;
+  const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
+  const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
+  constexpr bool dodrop = DROP;
+  const BwdLds L = bwd_lds(Tq, Tk, dodrop);
+  const int nqt = (Tq + 15) >> 4, nkt = (Tk + 15) >> 4;
+  char* Qp = lds + L.qp; char* Dp = lds + L.dp; char* Kp = lds + L.kp;
+  float* St = reinterpret_cast<float*>(lds + L.st);
+  uint8_t* Mk = reinterpret_cast<uint8_t*>(lds + L.mk);
+  float* dQw = reinterpret_cast<float*>(lds + L.dqw);
+  float* Xs = reinterpret_cast<float*>(lds + L.xs) + wave * 32 * 20;
+  const float* Qg = job.Q + (size_t)qbase * job.ldq + 16 * h;
+  const float* Dg = job.dO + (size_t)qbase * job.lddo + 16 * h;
+  const float* Og = job.O + (size_t)qbase * job.ldo + 16 * h;
+  const float* Kg = job.K + (size_t)kbase * job.ldkv + 16 * h;
+  const float* Vg = job.V + (size_t)kbase * job.ldkv + 16 * h;
+  const int nkp = Tkp >> 5, nqp = Tqp >> 5;
+  (void)Qg; (void)Dg; (void)Og; (void)Kg; (void)Vg; (void)nqt;
+  float4 (&vreg)[2][2] = bv.v;
+  float (&kmv)[2] = bv.km;
+  auto load_v = [&](int kp) { attn_bwd_load_v<DROP>(job, b, h, kp, bv); };
+  // ONE block of <= 32 keys and at least four 32-query pairs (the video -> query jobs): the waves split the QUERIES instead of the
+  // keys - all four work on key block 0, wave w takes the query pairs w, w + 4, ..; dQ rows are then disjoint (one slot), and the
+  // partial dK / dV of the waves are summed through the three free slots
+  const bool qsplit = nkp == 1 && nqp >= 4;
+  if (!have_v && (wave < nkp || qsplit)) load_v(qsplit ? 0 : wave);
   const float scale8 = drop.scale;                  // exactly 1 / (1 - rate)
   float* slot = dQw + (qsplit ? 0 : wave) * Tqp * 16;
   bool first = true;
@@ -678,6 +713,131 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
   ATT_STAMP(5);
 }
 
+template <bool DROP>
+__device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, char* lds, const DropCfg& drop) {
+  const int wave = threadIdx.x >> 6;
+  const int nkp = ((job.Tk + 31) & ~31) >> 5;
+  const bool qsplit = attn_bwd_qsplit(job.Tq, job.Tk);
+  BwdV bv;
+  ATT_STAMP(0);
+  // V rows of the wave's first 32 keys: requested before the staging so that they arrive under it
+  if (wave < nkp || qsplit) attn_bwd_load_v<DROP>(job, b, h, qsplit ? 0 : wave, bv);
+  attn_bwd_stage<DROP>(job, b, h, lds);
+  ATT_STAMP(1);
+  __syncthreads();
+  ATT_STAMP(2);
+  attn_bwd_compute<DROP>(job, b, h, lds, drop, bv, true);
+}
+
+// ---- the small jobs of a four-job launch in ONE workgroup.  Per (clip, head) the three small jobs cost 13-20 k cycles each as workgroups
+// of their own, more than half of it the staging round trip (scripts/exp/attn_stamps.py).  Here the rows of job n + 1 are requested
+// (BwdPre: 25 registers - a job with Tq <= 32, Tk <= 128 has one pass of query rows and two of key rows) before job n's products and
+// stored behind them: two of the three round trips disappear under products.  Measured (same-box A/B, B64 T128 L20): the four-job launches
+// 42.0 -> 38.2 us each - the load latency hides, the split + LDS stores + barrier of a staging do not.
+struct BwdPre { float4 q, d, o, k[2]; float sm, si, qm; uint2 mk; };
+__host__ __device__ __forceinline__ bool attn_bwd_pre_ok(int Tq, int Tk) { return Tq <= 32 && Tk <= 128; }
+template <bool DROP>
+__device__ __forceinline__ void attn_bwd_pre_load(const AttnJob& job, int b, int h, BwdPre& s) {
+  const int Tq = job.Tq, Tk = job.Tk;
+  const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
+  const int row = threadIdx.x >> 2, c4 = threadIdx.x & 3;
+  const int qr = min(row, Tq - 1);
+  s.q = ld4(job.Q + (size_t)(qbase + qr) * job.ldq + 16 * h + 4 * c4);
+  s.d = ld4(job.dO + (size_t)(qbase + qr) * job.lddo + 16 * h + 4 * c4);
+  s.o = ld4(job.O + (size_t)(qbase + qr) * job.ldo + 16 * h + 4 * c4);
+  s.k[0] = ld4(job.K + (size_t)(kbase + min(row, Tk - 1)) * job.ldkv + 16 * h + 4 * c4);
+  s.k[1] = ld4(job.K + (size_t)(kbase + min(row + 64, Tk - 1)) * job.ldkv + 16 * h + 4 * c4);
+  const int si = (b * Tq + qr) * 8 + h;
+  s.sm = job.stats[si];
+  s.si = job.stats[job.B * Tq * 8 + si];
+  s.qm = job.qmask[qbase + qr];
+  s.mk = make_uint2(0u, 0u);
+  if (DROP) {
+    const int nmk = ((Tq + 15) >> 4) * ((Tk + 15) >> 4) * 4;      // <= 2 x 8 x 4 keep words
+    s.mk = reinterpret_cast<const uint2*>(job.dmask + (size_t)(b * 8 + h) * nmk * 8)[min((int)threadIdx.x, nmk - 1)];
+  }
+}
+template <bool DROP>
+__device__ __forceinline__ void attn_bwd_pre_store(const AttnJob& job, char* lds, const BwdPre& s) {
+  const int Tq = job.Tq, Tk = job.Tk;
+  const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
+  const BwdLds L = bwd_lds(Tq, Tk, DROP);
+  char* Qp = lds + L.qp; char* Dp = lds + L.dp; char* Kp = lds + L.kp;
+  float* St = reinterpret_cast<float*>(lds + L.st);
+  const int row = threadIdx.x >> 2, c4 = threadIdx.x & 3;
+  const bool qok = row < Tq;
+  if (row < Tqp) {
+    panel_store(Qp, row, c4, qok ? s.q : f4zero());
+    panel_store(Dp, row, c4, qok ? s.d : f4zero());
+  }
+  if (row < Tkp) panel_store(Kp, row, c4, row < Tk ? s.k[0] : f4zero());
+  if (row + 64 < Tkp) panel_store(Kp, row + 64, c4, row + 64 < Tk ? s.k[1] : f4zero());
+  float part = qok ? (s.d.x * s.o.x + s.d.y * s.o.y) + (s.d.z * s.o.z + s.d.w * s.o.w) : 0.f;
+  part += __shfl_xor(part, 1);
+  part += __shfl_xor(part, 2);
+  if (c4 == 0 && row < Tqp) {      // (the six statistic rows of attn_bwd_stage)
+    St[row] = qok ? s.sm : 0.f;
+    St[Tqp + row] = qok ? s.si : 0.f;
+    St[2 * Tqp + row] = part;
+    St[3 * Tqp + row] = ATT_NEGL;
+    St[4 * Tqp + row] = (qok && s.qm != 0.f) ? 0.f : ATT_NEGL;
+    St[5 * Tqp + row] = -INFINITY;
+  }
+  if (DROP) {
+    const int nmk = ((Tq + 15) >> 4) * ((Tk + 15) >> 4) * 4;
+    if ((int)threadIdx.x < nmk) reinterpret_cast<uint2*>(lds + L.mk)[threadIdx.x] = s.mk;
+  }
+}
+template <bool DROP>
+__device__ __forceinline__ void attn_bwd_chain(const AttnJob& j1, const AttnJob& j2, const AttnJob& j3, int b, int h, char* lds, const DropCfg& drop) {
+  const int wave = threadIdx.x >> 6;
+  BwdV bv;
+  BwdPre pre;
+  {
+    const int nkp = ((j1.Tk + 31) & ~31) >> 5;
+    const bool qsplit = attn_bwd_qsplit(j1.Tq, j1.Tk);
+    if (wave < nkp || qsplit) attn_bwd_load_v<DROP>(j1, b, h, qsplit ? 0 : wave, bv);
+  }
+  attn_bwd_stage<DROP>(j1, b, h, lds);
+  __syncthreads();
+  attn_bwd_pre_load<DROP>(j2, b, h, pre);
+  attn_bwd_compute<DROP>(j1, b, h, lds, drop, bv, true);
+  __syncthreads();                                   // every wave is through job 1's panels and dQ slots
+  attn_bwd_pre_store<DROP>(j2, lds, pre);
+  __syncthreads();
+  attn_bwd_pre_load<DROP>(j3, b, h, pre);
+  attn_bwd_compute<DROP>(j2, b, h, lds, drop, bv, false);
+  __syncthreads();
+  attn_bwd_pre_store<DROP>(j3, lds, pre);
+  __syncthreads();
+  attn_bwd_compute<DROP>(j3, b, h, lds, drop, bv, false);
+}
+
+// four jobs = two kinds of workgroup per (clip, head): kind 0 the largest job, kind 1 the chain of the other three
+__global__ __launch_bounds__(256) void attn_bwd_chain_kernel(AttnBatch batch, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int lid = xcd_logical_id();
+  const int h = lid & 7; lid >>= 3;
+  int kind = lid & 1, b = lid >> 1;
+  {
+    const int per = (int)(gridDim.x >> 6);           // (kind, clip) pairs per XCD: the chains of an XCD's clips first
+    if ((gridDim.x & 63) == 0 && (per & 1) == 0) {
+      const int cpx = per >> 1, x = lid / per, w = lid - x * per;
+      kind = 1 - w / cpx;                            // the chain is the longer of the two (~44 k against 27 k cycles): it goes first
+      b = x * cpx + (w - (w / cpx) * cpx);
+    }
+  }
+  if (b >= batch.j[0].B) return;   // block-uniform
+  const bool dd = batch.j[0].drop_site >= 0 && drop.enabled;
+  if (kind == 0) {
+    if (dd) attn_bwd_body<true>(batch.j[0], b, h, lds, drop);
+    else attn_bwd_body<false>(batch.j[0], b, h, lds, drop);
+  } else {
+    if (dd) attn_bwd_chain<true>(batch.j[1], batch.j[2], batch.j[3], b, h, lds, drop);
+    else attn_bwd_chain<false>(batch.j[1], batch.j[2], batch.j[3], b, h, lds, drop);
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBatch batch, int njobs, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int lid = xcd_logical_id();
@@ -808,6 +968,17 @@ int launch_attn_bwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
     bytes += attn_job_bytes(jobs[i], dd) + (double)jobs[i].B * 8.0 * ((double)jobs[i].Tq * 128.0 + (double)jobs[i].Tk * 128.0);
   }
   HUAL_REQUIRE(lds <= 160 * 1024, "attn bwd: LDS footprint");
+  // four jobs whose two smallest have <= 32 queries and <= 128 keys (the dual attention at T <= 128): the three small jobs share a
+  // workgroup that prefetches across them (attn_bwd_chain); same dropout setting and clip count on all four
+  bool chain = n == 4 && attn_bwd_pre_ok(b.j[2].Tq, b.j[2].Tk) && attn_bwd_pre_ok(b.j[3].Tq, b.j[3].Tk);
+  for (int k = 1; k < n && chain; ++k)
+    chain = b.j[k].B == b.j[0].B && ((b.j[k].drop_site >= 0) == (b.j[0].drop_site >= 0));
+  if (chain) {
+    HUAL_DYN_LDS(attn_bwd_chain_kernel, 160 * 1024);
+    HUAL_LAUNCH(4.0 * flops, bytes, attn_bwd_chain_kernel, dim3(maxB * 8 * 2), dim3(256), lds, s, b, drop);
+    HUAL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   HUAL_DYN_LDS(attn_bwd_kernel, 160 * 1024);
   dim3 grid(maxB * 8 * n), block(256);
   // algorithmic work of the backward: FOUR products (dP = dO.V^T, dV = P^T.dO, dK = dS^T.Q, dQ = dS.K) = 8.B.H.Tq.Tk.16; the
