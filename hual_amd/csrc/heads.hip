@@ -779,7 +779,9 @@ int launch_pool_align_bwd(const PoolArgs& a, const PoolBwd& g, const AlignPool& 
   HUAL_REQUIRE(ab.dF2 == g.dF2, "pool_align_bwd: the two parts write the same query rows");
   // bytes: d fuse and d cq.feats of the video rows in, d cq.feats of the video rows back out, cq.feats query rows in, their gradient out
   const double pab = 512.0 * (3.0 * rs.Nv + 2.0 * rs.Nq);
+  // (KT / KL = rows per thread held in registers: the 64 / 64 form is a wall of spills - 87.6 us at B32 T256 L20, where 64 / 8 does)
   if (rs.T <= 128 && rs.L <= 32) HUAL_LAUNCH(0.0, pab, (pool_align_bwd_kernel<32, 8>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
+  else if (rs.L <= 32) HUAL_LAUNCH(0.0, pab, (pool_align_bwd_kernel<64, 8>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
   else HUAL_LAUNCH(0.0, pab, (pool_align_bwd_kernel<64, 64>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
