@@ -880,6 +880,7 @@ static int check_jobs(const AttnJob* jobs, int n, bool bwd, const DropCfg& drop,
       HUAL_REQUIRE(!(j.drop_site >= 0 && drop.enabled) || j.dmask, "attn bwd: dropout needs the keep bytes of the forward");
     } else {
       HUAL_REQUIRE(j.O != nullptr, "attn fwd: null output");
+      HUAL_REQUIRE(j.Tq <= 256, "attn fwd: Tq <= 256 (a unit code holds 16 query tiles per job)");
     }
     maxTq = j.Tq > maxTq ? j.Tq : maxTq;
     maxTk = j.Tk > maxTk ? j.Tk : maxTk;

@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libhual_seqpan.so')
+# HUAL_LIB_PATH: an experiment build of the library (scripts/exp/tl_variant.sh) - the in-tree file is never overwritten
+LIB_PATH = os.environ.get('HUAL_LIB_PATH') or os.path.join(_HERE, 'libhual_seqpan.so')
 ABI_VERSION = 6
 
 _lib = None

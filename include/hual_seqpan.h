@@ -264,7 +264,8 @@ int hual_layer_norm_fwd(const float* x, const float* gamma, const float* beta, f
 
 /* multi-head attention core of dual_multihead_attention / top_self_attention (models/layers.py:80-96, modules.py:104-119):
  * 8 heads of size 16 kept merged in [rows,128]; scores / sqrt(16) + (1 - qmask x kmask) * (-1e30), softmax, P.V.
- * Q rows b*Tq + t, K/V rows b*Tk + t; masks are [B*Tq] / [B*Tk] floats (0/1).  Tk <= 256. */
+ * Q rows b*Tq + t, K/V rows b*Tk + t; masks are [B*Tq] / [B*Tk] floats (0/1).  Tq <= 256 and Tk <= 256
+ * (longer queries: HUAL_ERR_INVALID - a launch's unit codes hold 16 query tiles per job). */
 int hual_attention_fwd(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
                        int Tk, const float* qmask, const float* kmask, void* stream);
 

@@ -2,7 +2,7 @@
 # timeline of the bench step with a variant library: scripts/exp/tl_variant.sh <tag> <lib.so> [bench args]
 tag=$1; libv=$2; shift; shift
 R=$GRAFT_REPO_ROOT
-cp $R/$libv $R/hual_amd/libhual_seqpan.so
+export HUAL_LIB_PATH=$R/$libv      # hual_amd/lib.py loads this file instead of the in-tree library (nothing is overwritten)
 out=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $out/prof_$tag

@@ -76,6 +76,20 @@ def test_attention_fwd(dev, B, Tq, Tk):
     assert (O.double() - ref).abs().max().item() < 2e-4
 
 
+def test_attention_fwd_rejects_more_than_256_queries(dev):
+    """a launch's unit codes hold 16 query tiles per job: Tq > 256 is refused with an error code (never launched), in the
+    forward as in the backward (include/hual_seqpan.h)"""
+    from hual_amd import lib
+    B, Tq, Tk = 1, 272, 32
+    Q, K, V, qm, km = _attn_case(dev, B, Tq, Tk, 5)
+    O = torch.empty(B * Tq, 128, device=dev)
+    rc = lib.load().hual_attention_fwd(lib.ptr(Q), 128, lib.ptr(K), lib.ptr(V), 128, lib.ptr(O), 128, B, Tq, Tk, lib.ptr(qm),
+                                       lib.ptr(km), lib.stream_ptr())
+    assert rc < 0 and b'Tq <= 256' in lib.load().hual_last_error()
+    with pytest.raises(lib.HualError):
+        lib.check(rc)
+
+
 @pytest.mark.parametrize('B,Tq,Tk', [(2, 16, 16), (3, 37, 9), (2, 128, 128), (1, 20, 256), (2, 128, 20), (1, 256, 20), (2, 200, 32), (2, 100, 100), (1, 256, 256), (3, 1, 1)])
 @pytest.mark.parametrize('rate', [0.0, 0.2])
 def test_attention_fwd_bwd_with_dropout(dev, B, Tq, Tk, rate):

@@ -1,8 +1,8 @@
 """GPU parity at the other shapes BASELINE.json names and at the edges of the supported range:
 the bench shape itself (configs[1]: B=64, T=128, vdim=1024), the per-GPU shape of configs[3] (B=32, T=256), configs[0]
 (B=16, T=64, vdim=512), ActivityNet dims (char_dim 100, max_vlen 100), single-clip batches, clips of length 1-2 frames
-next to full-length clips, one-word queries.  Tolerance 1e-3 for EVERY tensor incl. all gradients (north_star), span
-indices equal."""
+next to full-length clips, one-word queries.  Tolerance 1e-3 for EVERY tensor (north_star); gradients are held to 1e-3 of
+the tensor's OWN largest magnitude (parity_util.row_ok - no absolute arm), span indices equal."""
 import numpy as np
 import pytest
 import torch
@@ -14,8 +14,8 @@ TOL = 1e-3
 
 
 def _check(rows, idx_equal, kinds=('tap', 'out', 'loss', 'grad')):
-    bad = [(k, n, d, r) for (k, n, d, r) in rows if k in kinds and not (d <= TOL or d <= TOL * r)]
-    assert not bad, 'parity failures:\n' + pu.format_report(bad)
+    """parity_util.row_ok: forward tensors abs-or-rel 1e-3; every gradient tensor RELATIVE: d <= 1e-3 max(max|ref|, 1e-3 gmax)"""
+    pu.assert_rows(rows, kinds, TOL)
     assert idx_equal
 
 
