@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 PEAK_BF16_MATRIX_TFLOPS = 2516.8  # MI355X_MICROARCH.md: bf16 MFMA = 16 x the fp32 matrix rate (~2.5 PF dense)
 PEAK_HBM_GBS = 8000.0
+PEAK_HBM_ACHIEVABLE_GBS = 6290.0   # MI355X_MICROARCH.md: what a streaming copy kernel reaches on this part (0.79 of the spec figure)
 def _traffic_file():
     """newest committed per-kernel HBM-traffic summary (scripts/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes)"""
     import glob
@@ -258,6 +259,55 @@ def gpu_at_cpu_shape(dev, drop, steps=400):
                 shape='B16 T64 vdim1024 L20 C8 (the cpu_baseline shape)')
 
 
+def epoch_loop_leg(dev, args, resident_ms):
+    """The reference's ACTUAL loop (runner_utils.py:139-159, data_loader.py:23-28): a shuffled epoch over a training set, every batch
+    padded to its own longest clip / query / word, on the device-fed path (DeviceDataset + Trainer.run_epoch).  Untimed first epoch
+    (every padded shape is seen, launched eagerly once and captured once), then timed epochs - assembly launches, shape changes and
+    the span fetch included.  Synthetic set at the headline's dims: clips of T/2..T frames, queries of 3..L words."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import al_synth
+    from hual_amd import al, lib
+    from hual_amd.dataset import DeviceDataset
+    from hual_amd.model import SeqPAN
+    from hual_amd.train import Trainer
+    N, nvid, bs = args.epoch_samples, 512, args.batch
+    recs, vis, data_gt, _ = al_synth.make_trainset(N, nvid, args.vdim, args.T, seed=11, num_words=1000, num_chars=40, max_words=args.L)
+    cfg = lib.make_cfg(vdim=args.vdim, max_vlen=max(args.T, args.L), num_words=1000, num_chars=40)
+    wv = np.random.default_rng(777).normal(0, 0.4, size=(998, 300)).astype(np.float32)
+    model = SeqPAN(cfg, wv, device=dev, seed=12345, rng_seed=12345)
+    ds = DeviceDataset(recs, vis, device=dev)
+    s0, e0 = al.labels_from_times(data_gt, ds.vlen_h)
+    ds.set_labels(s0, e0)
+    tr = Trainer(model, world=1, use_graph=not args.no_graph)
+    g = np.random.default_rng(0)
+    order = g.permutation(N)
+    tr.run_epoch(ds, order, bs, lr=1e-4, drop_rate=args.drop, min_chars=4)           # untimed: shapes seen + captured
+    tr.run_epoch(ds, g.permutation(N), bs, lr=1e-4, drop_rate=args.drop, min_chars=4)
+    torch.cuda.synchronize()
+    warm = dict(tr.stats)
+    epochs, Ts, shapes = 3, [], set()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        order = g.permutation(N)
+        st, en = tr.run_epoch(ds, order, bs, lr=1e-4, drop_rate=args.drop, min_chars=4)
+        for lo in range(0, N, bs):
+            shp = ds.batch_shape(order[lo:lo + bs])
+            Ts.append(shp[0])
+            shapes.add((len(order[lo:lo + bs]),) + shp)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nsteps = epochs * ((N + bs - 1) // bs)
+    timed = {k: tr.stats[k] - warm[k] for k in warm}
+    ms = dt / nsteps * 1e3
+    return dict(value=round(N * epochs / dt, 1), unit='clips/s', ms_per_step=round(ms, 4), steps=nsteps, epochs=epochs,
+                samples=N, batch=bs, mean_T=round(float(np.mean(Ts)), 1), max_T=int(max(Ts)), distinct_padded_shapes=len(shapes),
+                step_launch_modes=timed, resident_batch_ms_per_step=round(resident_ms, 4),
+                frac_of_resident_batch_rate=round(resident_ms / ms, 3),
+                workload='shuffled epochs over an HBM-resident synthetic training set (%d samples, %d videos of %d..%d frames, vdim %d, '
+                         'queries of 3..%d words): hual_assemble_batch + train step per batch, every batch padded to its own longest '
+                         'clip / query / word, spans fetched once per epoch' % (N, nvid, max(4, args.T // 2), args.T, args.vdim, args.L))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -272,6 +322,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-epoch-loop', action='store_true', help='skip the epoch-loop leg (varying padded shapes, after the timed region)')
+    ap.add_argument('--epoch-samples', type=int, default=4096)
     ap.add_argument('--prewarm', type=int, default=200, help='untimed steps before the warm-up steps (clock ramp)')
     ap.add_argument('--video-dtype', choices=['f32', 'bf16'], default='f32',
                     help='element type of the clip features in HBM (hual_batch.video_dtype); arithmetic is the same')
@@ -395,6 +447,7 @@ def main():
                             traffic=None, **common)
             else:
                 roof = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
+                            peak_achievable_gbs=PEAK_HBM_ACHIEVABLE_GBS, frac_of_achievable=round(gbs / PEAK_HBM_ACHIEVABLE_GBS, 4),
                             traffic=None, **common)
             if top['flops'] > 0 and passes:
                 roof.update(algorithmic_tflops=round(tflops, 2), mfma_pipe=PIPE_NAMES[pipe], mfma_pipe_peak_tflops=peak,
@@ -511,6 +564,14 @@ def main():
         except Exception as e:      # never cost the bench line
             other_feed = dict(error=str(e)[:200])
 
+    epoch_loop = None
+    if rank == 0 and world == 1 and not args.no_epoch_loop:
+        try:
+            epoch_loop = epoch_loop_leg(dev, args, dt / args.steps * 1e3)
+            print('[bench] epoch-loop leg done: %.3f ms/step' % epoch_loop['ms_per_step'], file=sys.stderr, flush=True)
+        except Exception as e:      # never cost the bench line
+            epoch_loop = dict(error=str(e)[:300])
+
     if rank == 0:
         out = dict(metric='train clips/sec', value=round(clips / dt, 2), unit='clips/s', n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
@@ -526,6 +587,8 @@ def main():
                    roofline=roof, cpu_baseline=cpu)
         if other_feed is not None:
             out['other_feature_dtype'] = other_feed
+        if epoch_loop is not None:
+            out['epoch_loop'] = epoch_loop
         if rccl is not None:
             out['rccl'] = rccl
         print(json.dumps(out))

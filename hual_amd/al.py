@@ -219,7 +219,7 @@ def labels_from_times(data, vlens):
 
 
 def run_round(model, dataset, data_old, data_gt, last_prop, task, I, epochs, batch_size, lr, drop_rate, mc_dropout=0.5,
-              shuffle_seed=0, log=None):
+              shuffle_seed=0, log=None, trainer=None):
     """One active-learning round of run_charades.py:9-41 on device-resident data:
          update_label.py <task> I   ->  main.py --mode train (epochs)   ->  main.py --mode infer_trainset
     dataset: DeviceDataset over the training records in the SAME order as data_old / data_gt / last_prop.
@@ -235,18 +235,14 @@ def run_round(model, dataset, data_old, data_gt, last_prop, task, I, epochs, bat
     for r, a, b in zip(dataset.records, s_ind, e_ind):
         r['s_ind'], r['e_ind'] = int(a), int(b)
     N = len(dataset)
-    tr = Trainer(model, world=1, use_graph=False)
+    tr = trainer if trainer is not None else Trainer(model, world=1, use_graph=True)
     rng = np.random.default_rng(shuffle_seed)
-    feeds, steps = None, 0
+    steps = 0
     for ep in range(epochs):
         cur_lr = lr * (1.0 - ep / epochs)                       # main.py:61
         order = rng.permutation(N)                              # random.shuffle(self.dataset), data_loader.py:24
-        for lo in range(0, N, batch_size):
-            sel = order[lo:lo + batch_size]
-            feeds = dataset.assemble(sel, out=feeds, min_chars=4)
-            tr.set_batch_device(feeds)
-            tr.step(lr=cur_lr, drop_rate=drop_rate)
-            steps += 1
+        tr.run_epoch(dataset, order, batch_size, lr=cur_lr, drop_rate=drop_rate, min_chars=4)      # spans fetched: train_epoch's IoU log
+        steps += (N + batch_size - 1) // batch_size
     torch.cuda.synchronize()
     t2 = time.perf_counter()
 
@@ -261,6 +257,7 @@ def run_round(model, dataset, data_old, data_gt, last_prop, task, I, epochs, bat
     t3 = time.perf_counter()
     r3, r5, r7, mi = iou_metrics(ious)
     m = dict(update_s=t1 - t0, train_s=t2 - t1, infer_s=t3 - t2, train_steps=steps, clips_per_s=N * epochs / max(t2 - t1, 1e-9),
+             step_launch_modes=dict(tr.stats),
              r1i3=r3, r1i5=r5, r1i7=r7, miou=mi)
     if log:
         log('round %d: update_label %.3f s | train %d steps %.3f s (%.0f clips/s) | infer_trainset %.3f s | pseudo-label '

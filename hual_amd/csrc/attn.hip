@@ -101,6 +101,46 @@ __device__ __forceinline__ bf16x8 panel_tr(const char* panel, int plane, int row
   return join_tr(lds_read_tr16(panel, off), lds_read_tr16(panel, off + 16 * 64));
 }
 
+// ---- fp16-pair operands (round 5: forward and backward; scales in the header of the backward section)
+#define ATT_SX 16.0f                            // Q, K, V
+#define ATT_SP 1024.0f                          // probabilities
+#ifdef ATT_EXP_BF16       // timing experiment: the round-5 structure on bf16 instructions
+#define att_split_pair bf16_split_pair
+#define att_split4 bf16_split4
+__device__ __forceinline__ f32x4 mfma_h(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#else
+#define att_split_pair f16_split_pair
+#define att_split4 f16_split4
+__device__ __forceinline__ f32x4 mfma_h(bf16x8 a, bf16x8 b, f32x4 c) {      // (operand bytes are format blind: the panel helpers serve both)
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+#endif
+__device__ __forceinline__ void split8h(const float4& a, const float4& b, float sc, uint4& hi, uint4& lo) {
+  att_split_pair(a.x * sc, a.y * sc, hi.x, lo.x);
+  att_split_pair(a.z * sc, a.w * sc, hi.y, lo.y);
+  att_split_pair(b.x * sc, b.y * sc, hi.z, lo.z);
+  att_split_pair(b.z * sc, b.w * sc, hi.w, lo.w);
+}
+__device__ __forceinline__ void panel_store_h(char* dst, int row, int c4, const float4& v, float sc) {
+  uint2 h, l;
+  att_split4(f4scale1(v, sc), h, l);
+  *reinterpret_cast<uint2*>(dst + row * 64 + 8 * c4) = h;
+  *reinterpret_cast<uint2*>(dst + row * 64 + 32 + 8 * c4) = l;
+}
+// power-of-two scale that brings amax >= 0 into [2^13, 2^14) and its exact inverse (amax = 0: 2^113, finite)
+__device__ __forceinline__ float att_pow2_scale(float amax, float& inv) {
+  uint32_t eb = (__float_as_uint(amax) >> 23) & 0xffu;
+  eb = eb < 27u ? 27u : (eb > 240u ? 240u : eb);
+  inv = __uint_as_float((eb - 13u) << 23);
+  return __uint_as_float((267u - eb) << 23);
+}
+// workgroup barrier that waits for the wave's LDS operations only (__syncthreads() also drains the global stores of the job before)
+__device__ __forceinline__ void att_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ======================================================================================================
 // forward: ONE workgroup per (clip, head) for ALL jobs of the launch
 // ======================================================================================================
@@ -179,7 +219,7 @@ __device__ __forceinline__ void attn_fwd_unit(const AttnJob& job, int b, int h, 
   const int qrow = qbase + min(q0 + j, Tq - 1);
   // B operands: [Q_hi | Q_hi] and [Q_lo | 0] over the 32 slots (lane g covers head dims 8 (g & 1) .. + 7)
   uint4 qh, ql;
-  split8(qv0, qv1, qh, ql);
+  split8h(qv0, qv1, ATT_SX, qh, ql);
   if (g >= 2) ql = make_uint4(0u, 0u, 0u, 0u);
   const bf16x8 B1 = as_bf8(qh), B2 = as_bf8(ql);
   const float* bias = c.Bias + (mq != 0.f ? c.RT : 0);
@@ -189,36 +229,41 @@ __device__ __forceinline__ void attn_fwd_unit(const AttnJob& job, int b, int h, 
   for (int kt = 0; kt < NKT; ++kt) {
     const bf16x8 a = panel_a(c.Kp, 16 * kt + j, g);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = mfma_bf(a, B1, acc);
-    acc = mfma_bf(a, B2, acc);
+    acc = mfma_h(a, B1, acc);
+    acc = mfma_h(a, B2, acc);                              // (16 K) . (16 Q)
     const float4 b4 = *reinterpret_cast<const float4*>(bias + 16 * kt + 4 * g);
-    acc[0] = fmaf(acc[0], ATT_C1, b4.x); acc[1] = fmaf(acc[1], ATT_C1, b4.y);
-    acc[2] = fmaf(acc[2], ATT_C1, b4.z); acc[3] = fmaf(acc[3], ATT_C1, b4.w);
+    constexpr float c_s = ATT_C1 / (ATT_SX * ATT_SX);
+    acc[0] = fmaf(acc[0], c_s, b4.x); acc[1] = fmaf(acc[1], c_s, b4.y);
+    acc[2] = fmaf(acc[2], c_s, b4.z); acc[3] = fmaf(acc[3], c_s, b4.w);
     mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
     s[kt] = acc;
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  mx = fmaxf(mx, lane_xor16_partner(mx));      // (v_permlane16_swap / v_permlane32_swap: no LDS round trip)
+  mx = fmaxf(mx, lane_xor32_partner(mx));
+  // e = 2^10 exp2(s - max): the operand scale of the probabilities rides in the exponent (no multiplication), the row sum and with
+  // it 1 / sum carry it too, so the normalisation of the output tile needs no correction for it; the SAVED 1 / sum is the true one
+  const float mxs = mx - 10.0f;                     // log2(ATT_SP)
   float sum = 0.f;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+      const float e = __builtin_amdgcn_exp2f(s[kt][r] - mxs);
       s[kt][r] = e;
       sum += e;
     }
   }
-  sum += __shfl_xor(sum, 16);
-  sum += __shfl_xor(sum, 32);
-  const float inv = 1.0f / sum;
+  sum += lane_xor16_partner(sum);
+  sum += lane_xor32_partner(sum);
+  const float inv = 1.0f / sum;                     // = (true 1 / sum) / 2^(mx - mxs)
   const int ql_ = b * Tq + q0 + j;                  // job-local query index
   if (job.stats && g == 0 && qok) {
     job.stats[ql_ * 8 + h] = mx;
-    job.stats[job.B * Tq * 8 + ql_ * 8 + h] = inv;
+    // (mx - mxs is 10, except for rows whose every key is masked: there max = -1.44e30 absorbs the 10 and e = 1)
+    job.stats[job.B * Tq * 8 + ql_ * 8 + h] = inv * __builtin_amdgcn_exp2f(mx - mxs);
   }
-  // factor of output row 4 g + r: 1 / sum (x dropout scale) of query 4 g + r, which lane 4 g + r holds
-  const float fac = DROP ? inv * c.scale : inv;
+  // factor of output row 4 g + r: 1 / sum (x dropout scale) of query 4 g + r, which lane 4 g + r holds (x 2^-4: the V panel holds 16 V)
+  const float fac = (DROP ? inv * c.scale : inv) * (1.0f / ATT_SX);
   float fr[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) fr[r] = __shfl(fac, 4 * g + r);
@@ -241,12 +286,12 @@ __device__ __forceinline__ void attn_fwd_unit(const AttnJob& job, int b, int h, 
       put_lanes8<8 * kp>(wlo, whi, mk);                         // lane 4 kt + r collects the keep word of (kt, r)
     }
     uint4 ph, pl;
-    split8(make_float4(s[2 * kp][0], s[2 * kp][1], s[2 * kp][2], s[2 * kp][3]),
-           make_float4(s[2 * kp + 1][0], s[2 * kp + 1][1], s[2 * kp + 1][2], s[2 * kp + 1][3]), ph, pl);
+    split8h(make_float4(s[2 * kp][0], s[2 * kp][1], s[2 * kp][2], s[2 * kp][3]),
+            make_float4(s[2 * kp + 1][0], s[2 * kp + 1][1], s[2 * kp + 1][2], s[2 * kp + 1][3]), 1.0f, ph, pl);
     const bf16x8 vh = panel_tr(c.Vp, 0, 32 * kp, lane), vl = panel_tr(c.Vp, 32, 32 * kp, lane);
-    o = mfma_bf(as_bf8(ph), vh, o);
-    o = mfma_bf(as_bf8(ph), vl, o);
-    o = mfma_bf(as_bf8(pl), vh, o);
+    o = mfma_h(as_bf8(ph), vh, o);
+    o = mfma_h(as_bf8(ph), vl, o);
+    o = mfma_h(as_bf8(pl), vh, o);
   });
   if (DROP && job.dmask) {      // keep words of the tile's real key tiles: one 8-byte store per lane, contiguous over the lanes
     const int nkt = (Tk + 15) >> 4, nqt = (Tq + 15) >> 4;
@@ -340,8 +385,8 @@ __global__ __launch_bounds__(NT, (NT == 512 && MAXNKT <= 8) ? 4 : 2) void attn_f
         if (idx < items) {
           const int row = idx >> 2, c4 = idx & 3;
           const bool in = row < Tk;
-          panel_store(Kp, ko + row, c4, in ? kv[jb][it] : f4zero());
-          panel_store(Vp, ko + row, c4, in ? vv[jb][it] : f4zero());
+          panel_store_h(Kp, ko + row, c4, in ? kv[jb][it] : f4zero(), ATT_SX);
+          panel_store_h(Vp, ko + row, c4, in ? vv[jb][it] : f4zero(), ATT_SX);
         }
       }
     }
@@ -388,15 +433,47 @@ __global__ __launch_bounds__(NT, (NT == 512 && MAXNKT <= 8) ? 4 : 2) void attn_f
 // ======================================================================================================
 // backward
 // ======================================================================================================
+// Round 5: the backward's five products run on FP16 pairs (x s = hi + lo, 22 significant bits, v_mfma_f32_16x16x32_f16) instead of bf16
+// pairs (16 bits): the 2^-16 per product of rounds 2-4 was, with the context-query backward, what put every gradient tensor upstream
+// of an attention block 2-4e-5 of its maximum from the float64 oracle (a float32 PyTorch implementation: 5e-6).  fp16's narrow range
+// needs a power-of-two scale that is constant along each contraction:
+//   Q, K, V   fixed 2^4 (projections of layer-norm outputs, the forward's activation scale: |x| >= 4094 ends in Inf / NaN gradients).
+//             The scale is NOT cosmetic: measured with the operands as they are, every gradient tensor moved from 5.3e-6 back to 8.6e-6
+//             of its maximum - an element below 2^-3 has a residual below fp16's normal range, and the subnormal residuals do not
+//             survive (conversion / matrix pipe flush them): such an element keeps 11 bits instead of 22.  2^4 moves that edge to 2^-7;
+//             it costs one v_pk_mul per element pair in the staging (+5.7 us per step over the six attention launches' issue-bound
+//             split-and-store phase, same-box A/B);
+//   P         fixed 2^10 (p <= 1, x 1 / (1 - rate));
+//   dO        ONE scale per (clip, head) workgroup from the largest |dO| of the head's panel (a workgroup maximum in the staging:
+//             one extra LDS-only barrier per job);
+//   dS        one scale per (wave, 32-key block) from a BOUND: |dS| <= p (16 max|dO| max|V_block| / (1 - rate) + max|delta|), with max|V|
+//             of the block from the wave's own V registers and max|delta| from the staging - no reduction inside the query loop;
+//             the bound is loose by 2^10..2^14 against typical values, which fp16's 2^-24 .. 2^15 span absorbs (hi + lo still carry
+//             >= 19 bits of the largest element of a contraction).
+// Same instruction count in the products (13 MFMAs per 16 x 16 tile), the same split cost (v_cvt_pk_f16_f32 + v_cvt_f32_f16 + v_sub
+// against v_cvt_pk_bf16_f32 + shifts + v_sub); the scales ride on multiplications that were there (ATT_C1, 1 / sum, the 0.25 of the
+// epilogues) except for one v_cndmask and one v_mul per score.
+// largest |dO| and |delta| of the head: every wave leaves its maxima in Red[wave], Red[4 + wave] during the staging (plain stores, no
+// barrier of their own); attn_bwd_compute reads all eight behind the barrier that ends the staging
+__device__ __forceinline__ float att_wave_max(float v) {      // DPP / permlane butterflies only (no LDS round trip)
+  v = fast_max32(v);
+  return fmaxf(v, lane_xor32_partner(v));
+}
+__device__ __forceinline__ void att_wave_max2_put(float* Red, float a, float b) {
+  a = att_wave_max(a); b = att_wave_max(b);
+  if ((threadIdx.x & 63) == 0) { Red[threadIdx.x >> 6] = a; Red[4 + (threadIdx.x >> 6)] = b; }
+}
+
 // LDS map of one (job, clip, head), Tqp = Tq rounded up to 32 queries, Tkp likewise:
 //   Qp, Dp   [Tqp][64]       split Q / dO panels
 //   Kp       [Tkp][64]       split K panel (the V rows of a wave's keys go from HBM straight into its B operands)
-//   St       [6][Tqp]        row max (log2 domain), 1 / row sum, delta, additive term for masked / valid / padding keys
+//   St       [7][Tqp]        row max (log2 domain), 1 / row sum, delta, additive term for masked / valid / padding keys, 1 / scale of the dO row
 //   Mk       [nqt][nkt][4]   keep words of the head (8 bytes each, forward layout)
 //   dQw      [4 waves][Tqp][16]  fp32 dQ partial products, one slot per wave (plain stores: float atomics on LDS retire at
 //                            about one lane per clock and cost more than the rest of the kernel)
 //   Xs       [4 waves][32][20]   transposition scratch
-struct BwdLds { int qp, dp, kp, st, mk, dqw, xs, total; };
+//   Red      [16]            per-wave maxima of |dO| and |delta| (staging), then the two workgroup maxima at [8], [9]
+struct BwdLds { int qp, dp, kp, st, mk, dqw, xs, red, total; };
 __host__ __device__ inline BwdLds bwd_lds(int Tq, int Tk, bool dropout) {
   const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
   BwdLds l;
@@ -404,10 +481,11 @@ __host__ __device__ inline BwdLds bwd_lds(int Tq, int Tk, bool dropout) {
   l.qp = o; o += Tqp * 64;
   l.dp = o; o += Tqp * 64;
   l.kp = o; o += Tkp * 64;
-  l.st = o; o += 6 * Tqp * 4;
+  l.st = o; o += 7 * Tqp * 4;
   l.mk = o; o += dropout ? ((Tq + 15) >> 4) * ((Tk + 15) >> 4) * 32 : 0;
   l.dqw = o; o += 4 * Tqp * 64;
   l.xs = o; o += 4 * 32 * 20 * 4;
+  l.red = o; o += 64;
   l.total = o;
   return l;
 }
@@ -478,16 +556,27 @@ __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h,
   uint2 mkw[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
   const int nmk = dodrop ? nqt * nkt * 4 : 0;           // keep words of the head (<= 16 x 16 x 4 = 1024: four per thread)
   uint2 mkx[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+  // order of the requests = order of arrival = order of use: dO and O first (the workgroup maximum of |dO| - the scale of the dO panel -
+  // is the one thing everything else has to wait for), then Q / K, whose panels (fixed scale) are split and stored while that
+  // maximum crosses the workgroup, then the statistics and the keep words
 #pragma unroll
   for (int it = 0; it < MAXP; ++it) {
-    sq[it] = sd[it] = so[it] = sk[it] = f4zero();
-    ssm[it] = ssi[it] = sqm[it] = 0.f;
+    sd[it] = so[it] = f4zero();
     if (it < npass) {                                   // (workgroup-uniform)
+      const int idx = threadIdx.x + 256 * it, row = idx >> 2, c4 = idx & 3;
+      const int qr = min(row, Tq - 1);
+      sd[it] = ld4(Dg + (size_t)qr * job.lddo + 4 * c4);
+      so[it] = ld4(Og + (size_t)qr * job.ldo + 4 * c4);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < MAXP; ++it) {
+    sq[it] = sk[it] = f4zero();
+    ssm[it] = ssi[it] = sqm[it] = 0.f;
+    if (it < npass) {
       const int idx = threadIdx.x + 256 * it, row = idx >> 2, c4 = idx & 3;
       const int qr = min(row, Tq - 1), kr = min(row, Tk - 1);
       sq[it] = ld4(Qg + (size_t)qr * job.ldq + 4 * c4);
-      sd[it] = ld4(Dg + (size_t)qr * job.lddo + 4 * c4);
-      so[it] = ld4(Og + (size_t)qr * job.ldo + 4 * c4);
       sk[it] = ld4(Kg + (size_t)kr * job.ldkv + 4 * c4);
       const int si = (b * Tq + qr) * 8 + h;             // (unconditional on the clamped row: every lane of a row reads the same words)
       ssm[it] = job.stats[si];
@@ -502,27 +591,51 @@ __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h,
     mkx[0] = src[min((int)threadIdx.x + 512, nmk - 1)];
     mkx[1] = src[min((int)threadIdx.x + 768, nmk - 1)];
   }
+  // delta = dO . O per query row; the head's largest |dO| and |delta| (scales of the dO panel and of dS): per-wave maxima into LDS
+  float part[MAXP], gmax = 0.f, dmax = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXP; ++it) {
+    part[it] = 0.f;
+    if (it < npass) {
+      const int row = (threadIdx.x + 256 * it) >> 2;
+      const bool qok = row < Tq;
+      const float4 dv = sd[it], ov = so[it];
+      float pt = qok ? (dv.x * ov.x + dv.y * ov.y) + (dv.z * ov.z + dv.w * ov.w) : 0.f;
+      pt += dpp_xor_partner(pt, 1);            // (quad butterflies on the VALU: __shfl_xor is an LDS round trip each)
+      pt += dpp_xor_partner(pt, 2);
+      part[it] = pt;
+      gmax = fmaxf(gmax, qok ? f4absmax(dv) : 0.f);
+      dmax = fmaxf(dmax, fabsf(pt));
+    }
+  }
+  // the per-wave maxima go to LDS as they are: attn_bwd_compute combines them behind the barrier that ends the staging anyway
+  att_wave_max2_put(reinterpret_cast<float*>(lds + L.red), gmax, dmax);
 #pragma unroll
   for (int it = 0; it < MAXP; ++it) {
     if (it < npass) {
       const int idx = threadIdx.x + 256 * it, row = idx >> 2, c4 = idx & 3;
       const bool qok = row < Tq;
-      const float4 qv = sq[it], dv = sd[it], ov = so[it], kv = sk[it];
+      // dO row: its OWN power-of-two scale (the four lanes of a row agree on the row maximum with two quad steps) - no workgroup-wide
+      // quantity in front of the panel stores.  dP = dO . V^T contracts along the row (any row scale divides out per row, St[6]);
+      // dV = Pd^T . dO contracts over the rows: there Pd carries the ratio to the head's common scale (attn_bwd_compute)
+      float rmax = qok ? f4absmax(sd[it]) : 0.f;
+      rmax = fmaxf(rmax, dpp_xor_partner(rmax, 1));
+      rmax = fmaxf(rmax, dpp_xor_partner(rmax, 2));
+      float rinv;
+      const float rsc = att_pow2_scale(rmax, rinv);
       if (row < Tqp) {
-        panel_store(Qp, row, c4, qok ? qv : f4zero());
-        panel_store(Dp, row, c4, qok ? dv : f4zero());
+        panel_store_h(Qp, row, c4, qok ? sq[it] : f4zero(), ATT_SX);
+        panel_store_h(Dp, row, c4, qok ? sd[it] : f4zero(), rsc);
       }
-      if (row < Tkp) panel_store(Kp, row, c4, row < Tk ? kv : f4zero());
-      float part = qok ? (dv.x * ov.x + dv.y * ov.y) + (dv.z * ov.z + dv.w * ov.w) : 0.f;
-      part += __shfl_xor(part, 1);
-      part += __shfl_xor(part, 2);
+      if (row < Tkp) panel_store_h(Kp, row, c4, row < Tk ? sk[it] : f4zero(), ATT_SX);
       if (c4 == 0 && row < Tqp) {
         St[row] = qok ? ssm[it] : 0.f;
         St[Tqp + row] = qok ? ssi[it] : 0.f;                                       // 1 / row sum = 0 for padding queries -> p = 0
-        St[2 * Tqp + row] = part;
+        St[2 * Tqp + row] = part[it];
         St[3 * Tqp + row] = ATT_NEGL;                                              // key masked
         St[4 * Tqp + row] = (qok && sqm[it] != 0.f) ? 0.f : ATT_NEGL;              // key valid: (1 - mq) * -1e30
         St[5 * Tqp + row] = -INFINITY;                                             // key beyond Tk (tile padding)
+        St[6 * Tqp + row] = rinv;                                                  // 1 / scale of the dO row
       }
     }
   }
@@ -567,6 +680,22 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
   const bool qsplit = nkp == 1 && nqp >= 4;
   if (!have_v && (wave < nkp || qsplit)) load_v(qsplit ? 0 : wave);
   const float scale8 = drop.scale;                  // exactly 1 / (1 - rate)
+  // scales (see the header of this section): the head's largest |dO| and |delta| come from the staging
+  const float* Red = reinterpret_cast<const float*>(lds + L.red);
+  // (wave-uniform values: through readfirstlane into scalar registers, with everything derived from them)
+  float gmax, dmax;
+  {
+    const float4 va = *reinterpret_cast<const float4*>(Red), vb = *reinterpret_cast<const float4*>(Red + 4);
+    gmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w)))));
+    dmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)))));
+  }
+  // the dO panel holds dO_q * s_q with the row's own scale s_q >= sg = the scale of the head's largest |dO|; St[6] = 1 / s_q
+  float sg_inv;
+  const float sg = att_pow2_scale(gmax, sg_inv);
+  const float c_s = ATT_C1 / (ATT_SX * ATT_SX);     // scores: (16 Q) . (16 K)
+  const float m_dp0 = (dodrop ? scale8 : 1.0f) / ATT_SX;      // dP = dO . V^T: (s_q dO) . (16 V) -> x 1 / (16 s_q) per row
+  const float c_dv = sg_inv / ATT_SP;               // dV = Pd^T . dO with Pd_q x (sg / s_q) <= 1: sum_q (2^10 Pd sg / s_q) . (s_q dO)
+  float c_dk = 0.f;                                 // 1 / (16 s_ds) of the current key block (dK, dQ)
   float* slot = dQw + (qsplit ? 0 : wave) * Tqp * 16;
   bool first = true;
   const int qp0 = qsplit ? wave : 0, qpstep = qsplit ? 4 : 1;
@@ -575,16 +704,29 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
     bf16x8 Kb1[2], Kb2[2], Vb1[2], Vb2[2];
     int bsel[2];
     if (kp != wave && !qsplit) load_v(kp);
+    float vmax = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int key = 32 * kp + 16 * t + j;
       Kb1[t] = panel_b1(Kp, key, g); Kb2[t] = panel_b2(Kp, key, g);
+      const float4 v0 = key < Tk ? vreg[t][0] : f4zero(), v1 = key < Tk ? vreg[t][1] : f4zero();
+      vmax = fmaxf(vmax, fmaxf(f4absmax(v0), f4absmax(v1)));
       uint4 h4, l4;
-      split8(key < Tk ? vreg[t][0] : f4zero(), key < Tk ? vreg[t][1] : f4zero(), h4, l4);
+      split8h(v0, v1, ATT_SX, h4, l4);
       if (g >= 2) l4 = make_uint4(0u, 0u, 0u, 0u);
       Vb1[t] = as_bf8(h4); Vb2[t] = as_bf8(l4);
       bsel[t] = key < Tk ? (kmv[t] != 0.f ? 4 : 3) : 5;
     }
+    // |dS| <= p (|dP| / (1 - rate) + |delta|) <= 16 max|dO| max|V of these keys| / (1 - rate) + max|delta|   (p <= 1 up to rounding: x 2)
+#ifdef ATT_EXP_NOVMAX     // timing experiment
+    vmax = 1.0f;
+#else
+    vmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_max64(vmax))));
+#endif
+    float s_ds_inv;
+    const float s_ds = att_pow2_scale(2.0f * (16.0f * gmax * vmax * (dodrop ? scale8 : 1.0f) + dmax), s_ds_inv);
+    c_dk = s_ds_inv / ATT_SX;
+    const float m_pd0 = (dodrop ? scale8 : 1.0f) * ATT_SP * s_ds_inv * sg;      // pd = (p s_ds) m_pd0 / s_q = 2^10 (sg / s_q) x dropped probability
     const bf16x8 kh = panel_tr(Kp, 0, 32 * kp, lane), kl = panel_tr(Kp, 32, 32 * kp, lane);      // B operand of dQ
     f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int qp = qp0; qp < nqp; qp += qpstep) {
@@ -596,14 +738,17 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
         const float4 m4 = *reinterpret_cast<const float4*>(St + q0 + 4 * g);
         const float4 i4 = *reinterpret_cast<const float4*>(St + Tqp + q0 + 4 * g);
         const float4 d4 = *reinterpret_cast<const float4*>(St + 2 * Tqp + q0 + 4 * g);
-        const float mxv[4] = {m4.x, m4.y, m4.z, m4.w}, inv[4] = {i4.x, i4.y, i4.z, i4.w}, dlv[4] = {d4.x, d4.y, d4.z, d4.w};
+        // (1 / sum x s_ds: the scale of the dS operand rides on the normalisation)
+        const float4 g4 = *reinterpret_cast<const float4*>(St + 6 * Tqp + q0 + 4 * g);
+        const float mxv[4] = {m4.x, m4.y, m4.z, m4.w}, inv[4] = {i4.x * s_ds, i4.y * s_ds, i4.z * s_ds, i4.w * s_ds}, dlv[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float m_pd[4] = {g4.x * m_pd0, g4.y * m_pd0, g4.z * m_pd0, g4.w * m_pd0}, m_dp[4] = {g4.x * m_dp0, g4.y * m_dp0, g4.z * m_dp0, g4.w * m_dp0};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma_bf(aq, Kb1[t], s);
-          s = mfma_bf(aq, Kb2[t], s);          // lane: S[query q0 + 4 g + r][key 32 kp + 16 t + j]
-          dp = mfma_bf(ad, Vb1[t], dp);
-          dp = mfma_bf(ad, Vb2[t], dp);
+          s = mfma_h(aq, Kb1[t], s);
+          s = mfma_h(aq, Kb2[t], s);           // lane: 256 S[query q0 + 4 g + r][key 32 kp + 16 t + j]
+          dp = mfma_h(ad, Vb1[t], dp);
+          dp = mfma_h(ad, Vb2[t], dp);         // 16 sg dP
           const float4 b4 = *reinterpret_cast<const float4*>(St + bsel[t] * Tqp + q0 + 4 * g);
           const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
           uint32_t mbits = 0xfu;
@@ -616,49 +761,56 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = fmaf(s[r], ATT_C1, bv[r]);
-            const float p = __builtin_amdgcn_exp2f(v - mxv[r]) * inv[r];
-            const float m = dodrop ? (((mbits >> r) & 1u) ? scale8 : 0.f) : 1.0f;
-            pd[t][u][r] = p * m;                                  // dropped probability: A operand of dV
-            ds[t][u][r] = p * fmaf(dp[r], m, -dlv[r]);            // dS / 0.25: A operand of dK, dQ
+            const float v = fmaf(s[r], c_s, bv[r]);
+            const float p = __builtin_amdgcn_exp2f(v - mxv[r]) * inv[r];          // s_ds x probability
+            const bool keep = !dodrop || ((mbits >> r) & 1u);
+            pd[t][u][r] = p * (keep ? m_pd[r] : 0.f);                            // 2^10 (sg / s_q) x dropped probability: A operand of dV
+            ds[t][u][r] = p * fmaf(dp[r], keep ? m_dp[r] : 0.f, -dlv[r]);        // s_ds x dS / 0.25: A operand of dK, dQ
           }
         }
       }
       // dV += Pd^T . dO, dK += dS^T . Q over the 32 queries of the pair
       const bf16x8 doh = panel_tr(Dp, 0, 32 * qp, lane), dol = panel_tr(Dp, 32, 32 * qp, lane);
       const bf16x8 qh = panel_tr(Qp, 0, 32 * qp, lane), ql = panel_tr(Qp, 32, 32 * qp, lane);
+      uint4 dsh[2], dsl[2];                      // split dS of key tile t: halves .x .y = query tile u = 0 (r = 0..3), .z .w = u = 1
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         uint4 ah, al;
-        split8(make_float4(pd[t][0][0], pd[t][0][1], pd[t][0][2], pd[t][0][3]),
-               make_float4(pd[t][1][0], pd[t][1][1], pd[t][1][2], pd[t][1][3]), ah, al);
-        dv[t] = mfma_bf(as_bf8(ah), doh, dv[t]);
-        dv[t] = mfma_bf(as_bf8(ah), dol, dv[t]);
-        dv[t] = mfma_bf(as_bf8(al), doh, dv[t]);
-        split8(make_float4(ds[t][0][0], ds[t][0][1], ds[t][0][2], ds[t][0][3]),
-               make_float4(ds[t][1][0], ds[t][1][1], ds[t][1][2], ds[t][1][3]), ah, al);
-        dk[t] = mfma_bf(as_bf8(ah), qh, dk[t]);
-        dk[t] = mfma_bf(as_bf8(ah), ql, dk[t]);
-        dk[t] = mfma_bf(as_bf8(al), qh, dk[t]);
+        split8h(make_float4(pd[t][0][0], pd[t][0][1], pd[t][0][2], pd[t][0][3]),
+                make_float4(pd[t][1][0], pd[t][1][1], pd[t][1][2], pd[t][1][3]), 1.0f, ah, al);
+        dv[t] = mfma_h(as_bf8(ah), doh, dv[t]);
+        dv[t] = mfma_h(as_bf8(ah), dol, dv[t]);
+        dv[t] = mfma_h(as_bf8(al), doh, dv[t]);
+        split8h(make_float4(ds[t][0][0], ds[t][0][1], ds[t][0][2], ds[t][0][3]),
+                make_float4(ds[t][1][0], ds[t][1][1], ds[t][1][2], ds[t][1][3]), 1.0f, dsh[t], dsl[t]);
+        dk[t] = mfma_h(as_bf8(dsh[t]), qh, dk[t]);
+        dk[t] = mfma_h(as_bf8(dsh[t]), ql, dk[t]);
+        dk[t] = mfma_h(as_bf8(dsl[t]), qh, dk[t]);
       }
-      // dQ partial of the pair's two query tiles: transpose dS through the wave's scratch (key-major rows of 16 queries)
+      // dQ partial of the pair's two query tiles: dS . K contracts over the keys, i.e. over the LANES of the dS tiles.  The halves that
+      // were just split for dK go through the wave's scratch as a [32 keys][16 queries] 16-bit tile per plane and come back through
+      // the transposing read - the A operand of the product, keys in the order the K panel's transposed B operand has them (round 4
+      // moved the fp32 values and split them a second time: 16 more values to split per lane and iteration)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
+        char* Xw = reinterpret_cast<char*>(Xs);
+        asm volatile("" ::: "memory");
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          *reinterpret_cast<float4*>(Xs + (16 * t + j) * 20 + 4 * g) = make_float4(ds[t][u][0], ds[t][u][1], ds[t][u][2], ds[t][u][3]);
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = Xs[(16 * (e >> 2) + 4 * g + (e & 3)) * 20 + j];      // dS[query j][key 16 t + 4 g + r]
-        uint4 ah, al;
-        split8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), ah, al);
+        for (int t = 0; t < 2; ++t) {
+          *reinterpret_cast<uint2*>(Xw + (16 * t + j) * 32 + 8 * g) = u == 0 ? make_uint2(dsh[t].x, dsh[t].y) : make_uint2(dsh[t].z, dsh[t].w);
+          *reinterpret_cast<uint2*>(Xw + 1024 + (16 * t + j) * 32 + 8 * g) = u == 0 ? make_uint2(dsl[t].x, dsl[t].y) : make_uint2(dsl[t].z, dsl[t].w);
+        }
+        asm volatile("" ::: "memory");
+        const int xoff = (4 * g + (j >> 2)) * 32 + 8 * (j & 3);      // lane 4 q + p of a 16-lane group: row q of the group's four keys, queries 4 p ..
+        const bf16x8 xh = join_tr(lds_read_tr16(Xw, xoff), lds_read_tr16(Xw, xoff + 16 * 32));
+        const bf16x8 xl = join_tr(lds_read_tr16(Xw, 1024 + xoff), lds_read_tr16(Xw, 1024 + xoff + 16 * 32));
         f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-        dq = mfma_bf(as_bf8(ah), kh, dq);
-        dq = mfma_bf(as_bf8(ah), kl, dq);
-        dq = mfma_bf(as_bf8(al), kh, dq);      // lane: dQ[query 4 g + r][head dim j]
+        dq = mfma_h(xh, kh, dq);
+        dq = mfma_h(xh, kl, dq);
+        dq = mfma_h(xl, kh, dq);               // lane: 16 s_ds dQ[query 4 g + r][head dim j] of these keys
         float* dst = slot + (32 * qp + 16 * u + 4 * g) * 16 + j;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[16 * r] = first ? dq[r] : dst[16 * r] + dq[r];
+        for (int r = 0; r < 4; ++r) dst[16 * r] = first ? dq[r] * c_dk : fmaf(dq[r], c_dk, dst[16 * r]);
       }
     }
     first = false;
@@ -668,8 +820,8 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          red[(t * 4 + r) * 64 + lane] = dk[t][r];
-          red[512 + (t * 4 + r) * 64 + lane] = dv[t][r];
+          red[(t * 4 + r) * 64 + lane] = dk[t][r] * c_dk;      // (every wave works on key block 0: the same scales)
+          red[512 + (t * 4 + r) * 64 + lane] = dv[t][r] * c_dv;
         }
       continue;
     }
@@ -679,8 +831,8 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
       for (int r = 0; r < 4; ++r) {
         const int kk = 32 * kp + 16 * t + 4 * g + r;
         if (kk < Tk) {
-          job.dK[(size_t)(kbase + kk) * job.lddkv + 16 * h + j] = dk[t][r] * 0.25f;
-          job.dV[(size_t)(kbase + kk) * job.lddkv + 16 * h + j] = dv[t][r];
+          job.dK[(size_t)(kbase + kk) * job.lddkv + 16 * h + j] = dk[t][r] * (0.25f * c_dk);
+          job.dV[(size_t)(kbase + kk) * job.lddkv + 16 * h + j] = dv[t][r] * c_dv;
         }
       }
   }
@@ -734,7 +886,9 @@ __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, 
 // (BwdPre: 25 registers - a job with Tq <= 32, Tk <= 128 has one pass of query rows and two of key rows) before job n's products and
 // stored behind them: two of the three round trips disappear under products.  Measured (same-box A/B, B64 T128 L20): the four-job launches
 // 42.0 -> 38.2 us each - the load latency hides, the split + LDS stores + barrier of a staging do not.
-struct BwdPre { float4 q, d, o, k[2]; float sm, si, qm; uint2 mk; };
+// (st: lane c4 = 0 / 1 / 2 of a row's four lanes holds the row's softmax maximum / 1 / row sum / query mask - one register instead of three:
+//  at 256 registers a spilled prefetch register is stored behind an s_waitcnt vmcnt(0), i.e. the prefetch is waited for up front)
+struct BwdPre { float4 q, d, o, k[2]; float st; uint2 mk; };
 __host__ __device__ __forceinline__ bool attn_bwd_pre_ok(int Tq, int Tk) { return Tq <= 32 && Tk <= 128; }
 template <bool DROP>
 __device__ __forceinline__ void attn_bwd_pre_load(const AttnJob& job, int b, int h, BwdPre& s) {
@@ -748,9 +902,8 @@ __device__ __forceinline__ void attn_bwd_pre_load(const AttnJob& job, int b, int
   s.k[0] = ld4(job.K + (size_t)(kbase + min(row, Tk - 1)) * job.ldkv + 16 * h + 4 * c4);
   s.k[1] = ld4(job.K + (size_t)(kbase + min(row + 64, Tk - 1)) * job.ldkv + 16 * h + 4 * c4);
   const int si = (b * Tq + qr) * 8 + h;
-  s.sm = job.stats[si];
-  s.si = job.stats[job.B * Tq * 8 + si];
-  s.qm = job.qmask[qbase + qr];
+  const float* sp = c4 == 2 ? job.qmask + (qbase + qr) : job.stats + (c4 == 1 ? job.B * Tq * 8 + si : si);
+  s.st = *sp;
   s.mk = make_uint2(0u, 0u);
   if (DROP) {
     const int nmk = ((Tq + 15) >> 4) * ((Tk + 15) >> 4) * 4;      // <= 2 x 8 x 4 keep words
@@ -766,21 +919,31 @@ __device__ __forceinline__ void attn_bwd_pre_store(const AttnJob& job, char* lds
   float* St = reinterpret_cast<float*>(lds + L.st);
   const int row = threadIdx.x >> 2, c4 = threadIdx.x & 3;
   const bool qok = row < Tq;
-  if (row < Tqp) {
-    panel_store(Qp, row, c4, qok ? s.q : f4zero());
-    panel_store(Dp, row, c4, qok ? s.d : f4zero());
-  }
-  if (row < Tkp) panel_store(Kp, row, c4, row < Tk ? s.k[0] : f4zero());
-  if (row + 64 < Tkp) panel_store(Kp, row + 64, c4, row + 64 < Tk ? s.k[1] : f4zero());
   float part = qok ? (s.d.x * s.o.x + s.d.y * s.o.y) + (s.d.z * s.o.z + s.d.w * s.o.w) : 0.f;
-  part += __shfl_xor(part, 1);
-  part += __shfl_xor(part, 2);
+  part += dpp_xor_partner(part, 1);
+  part += dpp_xor_partner(part, 2);
+  float rmax = qok ? f4absmax(s.d) : 0.f;
+  att_wave_max2_put(reinterpret_cast<float*>(lds + L.red), rmax, fabsf(part));
+  rmax = fmaxf(rmax, dpp_xor_partner(rmax, 1));
+  rmax = fmaxf(rmax, dpp_xor_partner(rmax, 2));
+  float rinv;
+  const float rsc = att_pow2_scale(rmax, rinv);          // the row's own scale (attn_bwd_stage)
+  if (row < Tqp) {
+    panel_store_h(Qp, row, c4, qok ? s.q : f4zero(), ATT_SX);
+    panel_store_h(Dp, row, c4, qok ? s.d : f4zero(), rsc);
+  }
+  if (row < Tkp) panel_store_h(Kp, row, c4, row < Tk ? s.k[0] : f4zero(), ATT_SX);
+  if (row + 64 < Tkp) panel_store_h(Kp, row + 64, c4, row + 64 < Tk ? s.k[1] : f4zero(), ATT_SX);
+  const int sti = __builtin_bit_cast(int, s.st);
+  const float s_si = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(sti, sti, 0x55, 0xF, 0xF, false));      // quad lane 1
+  const float s_qm = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(sti, sti, 0xAA, 0xF, 0xF, false));      // quad lane 2
   if (c4 == 0 && row < Tqp) {      // (the six statistic rows of attn_bwd_stage)
-    St[row] = qok ? s.sm : 0.f;
-    St[Tqp + row] = qok ? s.si : 0.f;
+    St[row] = qok ? s.st : 0.f;
+    St[Tqp + row] = qok ? s_si : 0.f;
     St[2 * Tqp + row] = part;
     St[3 * Tqp + row] = ATT_NEGL;
-    St[4 * Tqp + row] = (qok && s.qm != 0.f) ? 0.f : ATT_NEGL;
+    St[4 * Tqp + row] = (qok && s_qm != 0.f) ? 0.f : ATT_NEGL;
+    St[6 * Tqp + row] = rinv;
     St[5 * Tqp + row] = -INFINITY;
   }
   if (DROP) {
@@ -814,7 +977,7 @@ __device__ __forceinline__ void attn_bwd_chain(const AttnJob& j1, const AttnJob&
 }
 
 // four jobs = two kinds of workgroup per (clip, head): kind 0 the largest job, kind 1 the chain of the other three
-__global__ __launch_bounds__(256) void attn_bwd_chain_kernel(AttnBatch batch, DropCfg drop) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_chain_kernel(AttnBatch batch, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int lid = xcd_logical_id();
   const int h = lid & 7; lid >>= 3;
@@ -838,7 +1001,7 @@ __global__ __launch_bounds__(256) void attn_bwd_chain_kernel(AttnBatch batch, Dr
   }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBatch batch, int njobs, DropCfg drop) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBatch batch, int njobs, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int lid = xcd_logical_id();
   const int h = lid & 7; lid >>= 3;

@@ -282,10 +282,37 @@ __device__ __forceinline__ void cq_barrier() {
 // 2^-25 / scale below: the forward's activations (scale 2^4: |x| < 4096 or the product turns Inf / NaN, loudly) and softmax
 // probabilities (scale 2^10)).  Round 4 first ran the forward on bf16 pairs too: the step-0 loss of the c1 trajectory test moved from
 // 1e-7 to 1.2e-6 of the float64 oracle's and the free-running trajectories separated ten times sooner.
-struct CqImg { char* p; int plane; float scale; };
-__device__ __forceinline__ CqImg cq_img(char* p, int rows, float scale = 1.0f) { CqImg im; im.p = p; im.plane = rows * 256; im.scale = scale; return im; }
+struct CqImg { char* p; int plane; float scale, inv; };
+__device__ __forceinline__ CqImg cq_img(char* p, int rows, float scale = 1.0f) {
+  CqImg im; im.p = p; im.plane = rows * 256; im.scale = scale; im.inv = 1.0f / scale;      // (compile-time powers of two)
+  return im;
+}
 #define CQ_SCALE_ACT 16.0f
 #define CQ_SCALE_PROB 1024.0f
+// FMT 1 image of a GRADIENT tensor (round 5: the backward's operands carry 22 bits too): its magnitude is not known in advance, so the
+// power-of-two scale is taken from the largest |element| of the whole image - a workgroup reduction - and brings it into [2^13, 2^14);
+// one scale per image, because every image of the backward is read along its rows in one product and along its columns in another
+// (a per-row scale would not be constant along the second contraction).  amax = 0 / denormal: 2^113, still finite.
+__device__ __forceinline__ void cq_img_autoscale(CqImg& im, float amax) {
+  uint32_t eb = (__float_as_uint(amax) >> 23) & 0xffu;
+  eb = eb < 27u ? 27u : (eb > 240u ? 240u : eb);
+  im.scale = __uint_as_float((267u - eb) << 23);
+  im.inv = __uint_as_float((eb - 13u) << 23);
+}
+// largest value over the workgroup: every wave leaves its maximum in its slot; the caller's next barrier publishes the slots
+// (cq_wgmax_get).  Slots are plain stores - no zeroing pass, no atomics; a slot row is reused only after a later barrier.
+__device__ __forceinline__ void cq_wgmax_put(float* slots, float v) {
+  v = wave_max64(v);
+  if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = v;
+}
+__device__ __forceinline__ float cq_wgmax_get(const float* slots) {
+  float m = 0.f;
+  for (int w = 0; w < CQ_WAVES; w += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(slots + w);
+    m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  return m;
+}
 template <int FMT>
 __device__ __forceinline__ void cq_split4(const CqImg& im, const float4& v, uint2& h, uint2& l) {
   if (FMT == 1) f16_split4(f4scale1(v, im.scale), h, l);
@@ -308,8 +335,13 @@ __device__ __forceinline__ void cq_img_store1(const CqImg& im, int row, int col,
   *reinterpret_cast<uint16_t*>(im.p + off) = (uint16_t)h;
   *reinterpret_cast<uint16_t*>(im.p + im.plane + off) = (uint16_t)l;
 }
-__device__ __forceinline__ float cq_img_load1(const CqImg& im, int row, int col) {      // bf16 image: hi + lo, the value to 2^-17
+template <int FMT>
+__device__ __forceinline__ float cq_img_load1(const CqImg& im, int row, int col) {      // hi + lo: the value to 2^-17 (bf16) / 2^-23 (fp16 pair)
   const int off = tile256_off(row, col >> 3) + 2 * (col & 7);
+  if (FMT == 1) {
+    const _Float16 h = *reinterpret_cast<const _Float16*>(im.p + off), l = *reinterpret_cast<const _Float16*>(im.p + im.plane + off);
+    return ((float)h + (float)l) * im.inv;
+  }
   const uint32_t h = *reinterpret_cast<const uint16_t*>(im.p + off), l = *reinterpret_cast<const uint16_t*>(im.p + im.plane + off);
   return __uint_as_float(h << 16) + __uint_as_float(l << 16);
 }
@@ -347,14 +379,14 @@ __device__ __forceinline__ f32x4 cq_mma(const CqImg& A, int m0, const CqImg& B, 
       t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), t, 0, 0, 0);
     }
   }
-  const float inv = FMT == 1 ? 1.0f / (A.scale * B.scale) : 1.0f;
+  const float inv = FMT == 1 ? A.inv * B.inv : 1.0f;      // (exact: powers of two)
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = FMT == 1 ? fmaf(t[r], inv, acc[r]) : acc[r] + t[r];
   return acc;
 }
 // score-matrix images: element (i, j) at [row j][col i] when LONG1 (N1 is the longer side), else [row i][col j]
 template <bool LONG1, int FMT> __device__ __forceinline__ void cq_sc_store(const CqImg& im, int i, int j, float v) { cq_img_store1<FMT>(im, LONG1 ? j : i, LONG1 ? i : j, v); }
-template <bool LONG1> __device__ __forceinline__ float cq_sc_load(const CqImg& im, int i, int j) { return cq_img_load1(im, LONG1 ? j : i, LONG1 ? i : j); }
+template <bool LONG1, int FMT> __device__ __forceinline__ float cq_sc_load(const CqImg& im, int i, int j) { return cq_img_load1<FMT>(im, LONG1 ? j : i, LONG1 ? i : j); }
 
 #define CQ_STAGE_MAX 5          // float4 per thread of a 1024-thread workgroup: (N1q + N2q) * 32 / 1024
 struct CqRows { float4 v[CQ_STAGE_MAX]; };
@@ -802,7 +834,22 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
 
 // cq_bwd_staged_kernel: cq_bwd_kernel with the [rows,128] operands of every product staged in LDS as split images and requested
 // one phase ahead (see cq_fwd_staged_body).   bufA (x1 rows): dC2Q, dQ2C, X1, D1W      bufB (x2 rows): X2, M2, dM2, D2
-// The saved softmaxes arrive as the forward's images; dscore takes the place of the Sr image once both softmax backward passes are done.
+// The saved softmaxes arrive as the forward's images and are used as they are; dscore takes the place of the Sr image once both softmax
+// backward passes are done.
+// Round 5: EVERY image is an fp16 pair (FMT 1, 22 significant bits; round 4 ran the backward on bf16 pairs - 16 bits - and its 2^-16 per
+// product was the largest single source of the 2-4e-5 gradient noise that every tensor upstream of this block carried).  Activations
+// (X1, X2, M2, D1W, D2) use the forward's fixed scale 2^4, probabilities 2^10; the four GRADIENT images (dC2Q, dQ2C, dM2, dscore) take a
+// power-of-two scale from their own largest element (cq_img_autoscale: one workgroup maximum each - two of them ride on barriers that
+// were there already, the first two share one extra barrier).
+__device__ __forceinline__ float cq_rows_absmax_a(const CqRows& r, int N1q) {      // largest |element| of the bufA part of staged rows
+  float m = 0.f;
+#pragma unroll
+  for (int u = 0; u < CQ_STAGE_MAX; ++u) {
+    const int idx = threadIdx.x + CQ_MAX_THREADS * u, row = idx >> 5;
+    if (row < N1q) m = fmaxf(m, f4absmax(r.v[u]));
+  }
+  return m;
+}
 template <bool LONG1>
 __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdBufs& gb, const RowSpace& rs, float* dXa, float* dXb, int clip, int dir,
                                                    char* lds) {
@@ -814,10 +861,12 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   const int msz = c.N1p * c.ld;
   float* dSr = reinterpret_cast<float*>(lds + L.s);      // becomes dscore
   float* dSc = dSr + msz;
-  const CqImg SrI = cq_img(lds + L.sri, L.Sq), ScI = cq_img(lds + L.sci, L.Sq);
+  const CqImg SrI = cq_img(lds + L.sri, L.Sq, CQ_SCALE_PROB), ScI = cq_img(lds + L.sci, L.Sq, CQ_SCALE_PROB);
   float* m1 = reinterpret_cast<float*>(lds + L.m);
   float* m2 = m1 + c.N1p;
-  const CqImg bufA = cq_img(lds + L.bufa, N1q), bufB = cq_img(lds + L.bufb, N2q);
+  float* mx0 = m1 + c.N1p + c.N2p;                       // two rows of 16 per-wave maxima (cq_wgmax_put / _get): >= 48 floats are free here
+  float* mx1 = mx0 + 16;
+  CqImg bufA = cq_img(lds + L.bufa, N1q, CQ_SCALE_ACT), bufB = cq_img(lds + L.bufb, N2q, CQ_SCALE_ACT);
   const size_t x1off = (size_t)c.x1base * HUAL_D, x2off = (size_t)c.x2base * HUAL_D;
   const size_t mat = cq_mat_elems(rs.T, rs.L);
   const float4* gSr = reinterpret_cast<const float4*>(b.SR + ((size_t)dir * rs.B + clip) * mat);
@@ -838,28 +887,22 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
     m1[idx] = (k < (first ? c.N1 : c.N2)) ? rs.rowmask[(first ? c.x1base : c.x2base) + k] : 0.f;     // (m2 follows m1)
   }
   {
-    // the forward saved fp16 pairs of p * 2^10 (both planes, Sq x 256 bytes each): every 16-byte chunk becomes the bf16 pair of the
-    // same eight probabilities at the same place (the swizzle is a permutation of chunks)
-    const int nch = L.Sq * 16;                         // chunks per plane
-    for (int idx = threadIdx.x; idx < 2 * nch; idx += CQ_THREADS) {
-      const bool sc = idx >= nch;
-      const int ch = sc ? idx - nch : idx;
-      const float4* g = sc ? gSc : gSr;
-      const uint4 h = __builtin_bit_cast(uint4, g[ch]), l = __builtin_bit_cast(uint4, g[nch + ch]);
-      const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
-      uint32_t oh[4], ol[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const f32x2_t hf = __builtin_convertvector(__builtin_bit_cast(f16x2_t, hw[k]), f32x2_t);
-        const f32x2_t lf = __builtin_convertvector(__builtin_bit_cast(f16x2_t, lw[k]), f32x2_t);
-        bf16_split_pair((hf[0] + lf[0]) * (1.0f / CQ_SCALE_PROB), (hf[1] + lf[1]) * (1.0f / CQ_SCALE_PROB), oh[k], ol[k]);
-      }
-      char* dst = (sc ? ScI.p : SrI.p) + (size_t)ch * 16;
-      *reinterpret_cast<uint4*>(dst) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
-      *reinterpret_cast<uint4*>(dst + SrI.plane) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+    // the forward saved fp16 pairs of p * 2^10 (both planes, Sq x 256 bytes each) in the very layout of the images: plain copies
+    const int nch = L.Sq * 32;                         // 16-byte chunks of both planes
+    uint4* lr = reinterpret_cast<uint4*>(SrI.p);
+    uint4* lc = reinterpret_cast<uint4*>(ScI.p);
+    for (int idx = threadIdx.x; idx < nch; idx += CQ_THREADS) {
+      lr[idx] = __builtin_bit_cast(uint4, gSr[idx]);
+      lc[idx] = __builtin_bit_cast(uint4, gSc[idx]);
     }
   }
-  cq_rows_store<0>(r1, bufA, N1q, bufB, N2q);          // dC2Q, X2
+  cq_wgmax_put(mx0, cq_rows_absmax_a(r1, N1q));          // max |dC2Q|, max |dQ2C| of the clip
+  cq_wgmax_put(mx1, cq_rows_absmax_a(r2, N1q));
+  cq_barrier();
+  CqImg bufA2 = bufA;                                    // the dQ2C image (same bytes as bufA, its own scale)
+  cq_img_autoscale(bufA, cq_wgmax_get(mx0));
+  cq_img_autoscale(bufA2, cq_wgmax_get(mx1));
+  cq_rows_store<1>(r1, bufA, N1q, bufB, N2q);            // dC2Q, X2
   cq_barrier();
   CQ_STAMP(17);
   // ---- first half of dSr = dc2q . x2^T (+ dq2c . M2^T below) ;  dXb (x2 rows) = Sr^T . dc2q
@@ -870,12 +913,12 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
     const int tile = wave + CQ_WAVES * q;
     if (tile < ni * nj) {
       const int ti = small_div(tile, nj), i0 = ti * 16, n0 = (tile - ti * nj) * 16;      // (no integer division: common.h)
-      sacc[q] = cq_mma<false, false, 0>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
+      sacc[q] = cq_mma<false, false, 1>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
     }
   }
   for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    const f32x4 acc2 = cq_mma<!LONG1, true, 0>(SrI, i0, bufA, n0, N1q, lane, zero);
+    const f32x4 acc2 = cq_mma<!LONG1, true, 1>(SrI, i0, bufA, n0, N1q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int jj = i0 + 4 * g + r;
@@ -884,7 +927,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   }
   cq_barrier();
   CQ_STAMP(18);
-  cq_rows_store<0>(r2, bufA, N1q, bufB, N2q);          // dQ2C, M2
+  cq_rows_store<1>(r2, bufA2, N1q, bufB, N2q);         // dQ2C, M2
   cq_barrier();
   cq_rows_load(r2, b.D1W + x1off, c.N1, N1q, b.D2 + x2off, c.N2, N2q);     // for the last two products
 #pragma unroll
@@ -892,25 +935,31 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
     const int tile = wave + CQ_WAVES * q;
     if (tile < ni * nj) {
       const int ti = small_div(tile, nj), i0 = ti * 16, n0 = (tile - ti * nj) * 16;      // (no integer division: common.h)
-      const f32x4 acc = cq_mma<false, false, 0>(bufA, i0, bufB, n0, HUAL_D, lane, sacc[q]);
+      const f32x4 acc = cq_mma<false, false, 1>(bufA2, i0, bufB, n0, HUAL_D, lane, sacc[q]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) dSr[__mul24(i0 + 4 * g + r, c.ld) + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
     }
   }
   // dM2 = Sr^T . dq2c (kept in registers until every wave is done with M2); rows up to N2q: zero beyond N2 (Sr is zero there)
   f32x4 macc[4];                                          // njq * 8 <= 64 tiles over 16 waves
+  float mmax = 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tile = wave + CQ_WAVES * q;
     macc[q] = zero;
     if (tile < njq * 8) {
       const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-      macc[q] = cq_mma<!LONG1, true, 0>(SrI, i0, bufA, n0, N1q, lane, zero);
+      macc[q] = cq_mma<!LONG1, true, 1>(SrI, i0, bufA2, n0, N1q, lane, zero);
+      mmax = fmaxf(mmax, fmaxf(fmaxf(fabsf(macc[q][0]), fabsf(macc[q][1])), fmaxf(fabsf(macc[q][2]), fabsf(macc[q][3]))));
     }
   }
+  cq_wgmax_put(mx0, mmax);                               // (mx0 was read behind the first barrier: four barriers ago)
   cq_barrier();
   CQ_STAMP(19);
-  cq_rows_store<0>(r1, bufA, N1q, bufB, 0);                 // X1 (bufB receives dM2 below)
+  bufA.scale = CQ_SCALE_ACT; bufA.inv = 1.0f / CQ_SCALE_ACT;
+  CqImg bufB2 = bufB;                                    // the dM2 image
+  cq_img_autoscale(bufB2, cq_wgmax_get(mx0));
+  cq_rows_store<1>(r1, bufA, N1q, bufB, 0);                 // X1 (bufB receives dM2 below)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tile = wave + CQ_WAVES * q;
@@ -919,7 +968,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (i0 + 4 * g + r < c.N2p) dM2[(size_t)(i0 + 4 * g + r) * HUAL_D + n0 + j] = macc[q][r];
-        cq_img_store1<0>(bufB, i0 + 4 * g + r, n0 + j, macc[q][r]);
+        cq_img_store1<1>(bufB2, i0 + 4 * g + r, n0 + j, macc[q][r]);
       }
     }
   }
@@ -927,13 +976,13 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   // ---- dSc = x1 . dM2^T ;  dXa (x1 rows) = Sc . dM2
   for (int tile = wave; tile < ni * nj; tile += CQ_WAVES) {
     const int ti = small_div(tile, nj), i0 = ti * 16, n0 = (tile - ti * nj) * 16;      // (no integer division: common.h)
-    const f32x4 acc = cq_mma<false, false, 0>(bufA, i0, bufB, n0, HUAL_D, lane, zero);
+    const f32x4 acc = cq_mma<false, false, 1>(bufA, i0, bufB2, n0, HUAL_D, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) dSc[__mul24(i0 + 4 * g + r, c.ld) + n0 + j] = ((i0 + 4 * g + r) < c.N1 && (n0 + j) < c.N2) ? acc[r] : 0.f;
   }
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    const f32x4 acc = cq_mma<LONG1, true, 0>(ScI, i0, bufB, n0, N2q, lane, zero);
+    const f32x4 acc = cq_mma<LONG1, true, 1>(ScI, i0, bufB2, n0, N2q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * g + r;
@@ -942,65 +991,70 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   }
   cq_barrier();
   CQ_STAMP(20);
-  cq_rows_store<0>(r2, bufA, N1q, bufB, N2q);          // D1W, D2
+  cq_rows_store<1>(r2, bufA, N1q, bufB, N2q);          // D1W, D2 (activation scale on both)
   // ---- softmax backward -> dscore (in dSr).  mask_logits is multiplicative, so its derivative is the mask.
   // (rows / columns of at most 32 elements go two per wave, as in the forward kernel)
   const int hh = lane >> 5, l32 = lane & 31;
   if (c.N2p <= 32) {
     for (int i = 2 * wave + hh; i < c.N1p; i += 2 * CQ_WAVES) {
       const bool ok = i < c.N1 && l32 < c.N2;
-      const float sr = ok ? cq_sc_load<LONG1>(SrI, i, l32) : 0.f, ds = ok ? dSr[__mul24(i, c.ld) + l32] : 0.f;
+      const float sr = ok ? cq_sc_load<LONG1, 1>(SrI, i, l32) : 0.f, ds = ok ? dSr[__mul24(i, c.ld) + l32] : 0.f;
       const float dot = half_sum32(sr * ds);
       if (ok) dSr[__mul24(i, c.ld) + l32] = sr * (ds - dot) * m2[l32];
     }
   } else {
     for (int i = wave; i < c.N1; i += CQ_WAVES) {
       float dot = 0.f;
-      for (int jj = lane; jj < c.N2; jj += 64) dot += cq_sc_load<LONG1>(SrI, i, jj) * dSr[__mul24(i, c.ld) + jj];
+      for (int jj = lane; jj < c.N2; jj += 64) dot += cq_sc_load<LONG1, 1>(SrI, i, jj) * dSr[__mul24(i, c.ld) + jj];
       dot = wave_sum64(dot);
       for (int jj = lane; jj < c.N2; jj += 64)
-        dSr[__mul24(i, c.ld) + jj] = cq_sc_load<LONG1>(SrI, i, jj) * (dSr[__mul24(i, c.ld) + jj] - dot) * m2[jj];
+        dSr[__mul24(i, c.ld) + jj] = cq_sc_load<LONG1, 1>(SrI, i, jj) * (dSr[__mul24(i, c.ld) + jj] - dot) * m2[jj];
     }
   }
   cq_barrier();
+  float dmax = 0.f;                                       // largest |dscore| this thread produced
   if (c.N1p <= 32) {
     for (int jj = 2 * wave + hh; jj < c.N2p; jj += 2 * CQ_WAVES) {
       const bool ok = jj < c.N2 && l32 < c.N1;
-      const float sc = ok ? cq_sc_load<LONG1>(ScI, l32, jj) : 0.f, ds = ok ? dSc[__mul24(l32, c.ld) + jj] : 0.f;
+      const float sc = ok ? cq_sc_load<LONG1, 1>(ScI, l32, jj) : 0.f, ds = ok ? dSc[__mul24(l32, c.ld) + jj] : 0.f;
       const float dot = half_sum32(sc * ds);
       float v = 0.f;
       if (ok) {
         v = dSr[__mul24(l32, c.ld) + jj] + sc * (ds - dot) * m1[l32];
         dSr[__mul24(l32, c.ld) + jj] = v;
       }
+      dmax = fmaxf(dmax, fabsf(v));
       const float colsum = half_sum32(v);
       if (l32 == 0 && jj < c.N2) gb.dS1[c.x2base + jj] = colsum;
     }
   } else {
     for (int jj = wave; jj < c.N2; jj += CQ_WAVES) {
       float dot = 0.f;
-      for (int i = lane; i < c.N1; i += 64) dot += cq_sc_load<LONG1>(ScI, i, jj) * dSc[__mul24(i, c.ld) + jj];
+      for (int i = lane; i < c.N1; i += 64) dot += cq_sc_load<LONG1, 1>(ScI, i, jj) * dSc[__mul24(i, c.ld) + jj];
       dot = wave_sum64(dot);
       float colsum = 0.f;
       for (int i = lane; i < c.N1; i += 64) {
-        const float v = dSr[__mul24(i, c.ld) + jj] + cq_sc_load<LONG1>(ScI, i, jj) * (dSc[__mul24(i, c.ld) + jj] - dot) * m1[i];
+        const float v = dSr[__mul24(i, c.ld) + jj] + cq_sc_load<LONG1, 1>(ScI, i, jj) * (dSc[__mul24(i, c.ld) + jj] - dot) * m1[i];
         dSr[__mul24(i, c.ld) + jj] = v;
+        dmax = fmaxf(dmax, fabsf(v));
         colsum += v;
       }
       colsum = wave_sum64(colsum);
       if (lane == 0) gb.dS1[c.x2base + jj] = colsum;
     }
   }
+  cq_wgmax_put(mx1, dmax);
   cq_barrier();
   CQ_STAMP(21);
   // row sums (d s0) and the dscore image (in place of the Sr image: both softmaxes are done with it)
-  const CqImg dscI = SrI;
+  CqImg dscI = SrI;
+  cq_img_autoscale(dscI, cq_wgmax_get(mx1));
   if (c.N2p <= 32) {
     for (int i = 2 * wave + hh; i < N1q; i += 2 * CQ_WAVES) {
       const float v = (i < c.N1 && l32 < c.N2) ? dSr[__mul24(i, c.ld) + l32] : 0.f;
       const float rowsum = half_sum32(v);
       if (l32 == 0 && i < c.N1) gb.dS0[c.x1base + i] = rowsum;
-      cq_sc_store<LONG1, 0>(dscI, i, l32, v);
+      cq_sc_store<LONG1, 1>(dscI, i, l32, v);
     }
   } else {
     for (int i = wave; i < N1q; i += CQ_WAVES) {
@@ -1008,7 +1062,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
       for (int jj = lane; jj < N2q; jj += 64) {
         const float v = (i < c.N1 && jj < c.N2) ? dSr[__mul24(i, c.ld) + jj] : 0.f;
         rowsum += v;
-        cq_sc_store<LONG1, 0>(dscI, i, jj, v);
+        cq_sc_store<LONG1, 1>(dscI, i, jj, v);
       }
       rowsum = wave_sum64(rowsum);
       if (lane == 0 && i < c.N1) gb.dS0[c.x1base + i] = rowsum;
@@ -1019,7 +1073,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   // ---- dD1W = dscore . d2 ;  dD2 = dscore^T . d1w
   for (int tile = wave; tile < ni * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    const f32x4 acc = cq_mma<LONG1, true, 0>(dscI, i0, bufB, n0, N2q, lane, zero);
+    const f32x4 acc = cq_mma<LONG1, true, 1>(dscI, i0, bufB, n0, N2q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + 4 * g + r;
@@ -1028,7 +1082,7 @@ __device__ __forceinline__ void cq_bwd_staged_body(const CqBufs& b, const CqBwdB
   }
   for (int tile = wave; tile < nj * 8; tile += CQ_WAVES) {
     const int i0 = (tile >> 3) * 16, n0 = (tile & 7) * 16;
-    const f32x4 acc = cq_mma<!LONG1, true, 0>(dscI, i0, bufA, n0, N1q, lane, zero);
+    const f32x4 acc = cq_mma<!LONG1, true, 1>(dscI, i0, bufA, n0, N1q, lane, zero);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int jj = i0 + 4 * g + r;

@@ -526,70 +526,88 @@ __device__ __forceinline__ void align_pool_body(const AlignPool& a, const RowSpa
   }
 }
 
-// row i of the [Bg,Bg] similarity matrices; one block (256 threads) per row, Bg <= 1024
+// row i of the [Bg,Bg] similarity matrices; one block (256 threads) per row, Bg <= 1024.
+// Round 5: evaluated in DOUBLE.  The gradient of a row, p (log p + 1 - 2 p' - dot), is a small difference of O(1) terms (log-sum-exp
+// ~ ln Bg against similarities in [-1, 1]): in float32 its rounding put 1.4e-5 of noise on d that (a float32 PyTorch evaluation: 5e-6)
+// that every query-side gradient downstream carried - at [Bg, Bg] <= 1024 x 1024 elements per step the double pipe costs nothing.
+__device__ __forceinline__ double block_max_d(double v, double* sm) {
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  double s = sm[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) s = fmax(s, sm[i]);
+  return s;
+}
 __device__ __forceinline__ void align_sim_rows_body(const AlignSim& a, int i) {
   __shared__ float ti[HUAL_D], vi[HUAL_D];
-  __shared__ float sm[4];
-  __shared__ float sa[1024], sq[1024];
+  __shared__ double sm[4];
+  __shared__ double sa[1024], sq[1024];
   const int tid = threadIdx.x, Bg = a.Bg;
   const int ld = a.ld;
   if (tid < HUAL_D) { ti[tid] = a.that[(size_t)i * ld + tid]; vi[tid] = a.vhat[(size_t)i * ld + tid]; }
   __syncthreads();
-  float mxa = -INFINITY, mxq = -INFINITY;
-  for (int j = tid; j < Bg; j += 256) {
-    const float* vj = a.vhat + (size_t)j * ld;
-    float da = 0.f, dq = 0.f;
-#pragma unroll 16
-    for (int k = 0; k < HUAL_D; ++k) { da = fmaf(vi[k], vj[k], da); dq = fmaf(ti[k], vj[k], dq); }
-    sa[j] = da; sq[j] = dq;
-    mxa = fmaxf(mxa, da); mxq = fmaxf(mxq, dq);
+  double mxa = -INFINITY, mxq = -INFINITY;
+  // four threads per column j, a quarter of the 128 dimensions each (at Bg = 64 every thread of the block works)
+  for (int j0 = 0; j0 < Bg; j0 += 64) {
+    const int j = j0 + (tid >> 2), kq = (tid & 3) * 32;
+    const float* vj = a.vhat + (size_t)min(j, Bg - 1) * ld + kq;
+    double da = 0.0, dq = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) { const double v = (double)vj[k]; da = fma((double)vi[kq + k], v, da); dq = fma((double)ti[kq + k], v, dq); }
+    da += __shfl_xor(da, 1); dq += __shfl_xor(dq, 1);
+    da += __shfl_xor(da, 2); dq += __shfl_xor(dq, 2);
+    if ((tid & 3) == 0 && j < Bg) { sa[j] = da; sq[j] = dq; }
   }
-  mxa = block_max(mxa, sm);
-  mxq = block_max(mxq, sm);
-  float suma = 0.f, sumq = 0.f;
-  for (int j = tid; j < Bg; j += 256) { suma += expf(sa[j] - mxa); sumq += expf(sq[j] - mxq); }
-  suma = block_sum(suma, sm);
-  sumq = block_sum(sumq, sm);
-  const float lsa = mxa + logf(suma), lsq = mxq + logf(sumq);
+  __syncthreads();
+  for (int j = tid; j < Bg; j += 256) { mxa = fmax(mxa, sa[j]); mxq = fmax(mxq, sq[j]); }
+  mxa = block_max_d(mxa, sm);
+  mxq = block_max_d(mxq, sm);
+  double suma = 0.0, sumq = 0.0;
+  for (int j = tid; j < Bg; j += 256) { suma += exp(sa[j] - mxa); sumq += exp(sq[j] - mxq); }
+  suma = block_sum_d(suma, sm);
+  sumq = block_sum_d(sumq, sm);
+  const double lsa = mxa + log(suma), lsq = mxq + log(sumq);
   // loss_i = sum Pq logPq + sum Pv logPv - 2 sum Pq Pv ; dPq = logPq + 1 - 2Pv ; dPv = logPv + 1 - 2Pq
-  float li = 0.f, dotq = 0.f, dota = 0.f;
+  double li = 0.0, dotq = 0.0, dota = 0.0;
   for (int j = tid; j < Bg; j += 256) {
-    const float lpv = sa[j] - lsa, lpq = sq[j] - lsq;
-    const float pv = expf(lpv), pq = expf(lpq);
-    li += pq * lpq + pv * lpv - 2.0f * pq * pv;
-    dotq += pq * (lpq + 1.0f - 2.0f * pv);
-    dota += pv * (lpv + 1.0f - 2.0f * pq);
+    const double lpv = sa[j] - lsa, lpq = sq[j] - lsq;
+    const double pv = exp(lpv), pq = exp(lpq);
+    li += pq * lpq + pv * lpv - 2.0 * pq * pv;
+    dotq += pq * (lpq + 1.0 - 2.0 * pv);
+    dota += pv * (lpv + 1.0 - 2.0 * pq);
   }
-  li = block_sum(li, sm);
-  dotq = block_sum(dotq, sm);
-  dota = block_sum(dota, sm);
+  li = block_sum_d(li, sm);
+  dotq = block_sum_d(dotq, sm);
+  dota = block_sum_d(dota, sm);
   if (tid == 0) {
-    if (a.row_loss) a.row_loss[i] = li;
-    else if (a.loss_acc) atomicAdd(a.loss_acc + LA_ALIGN, li);
+    if (a.row_loss) a.row_loss[i] = (float)li;
+    else if (a.loss_acc) atomicAdd(a.loss_acc + LA_ALIGN, (float)li);
   }
   __syncthreads();
   for (int j = tid; j < Bg; j += 256) {
-    const float lpv = sa[j] - lsa, lpq = sq[j] - lsq;
-    const float pv = expf(lpv), pq = expf(lpq);
-    const float gq = pq * ((lpq + 1.0f - 2.0f * pv) - dotq) * a.scale;
-    const float ga = pv * ((lpv + 1.0f - 2.0f * pq) - dota) * a.scale;
-    a.dq[(size_t)i * Bg + j] = gq;
-    a.da[(size_t)i * Bg + j] = ga;
+    const double lpv = sa[j] - lsa, lpq = sq[j] - lsq;
+    const double pv = exp(lpv), pq = exp(lpq);
+    const double gq = pq * ((lpq + 1.0 - 2.0 * pv) - dotq) * (double)a.scale;
+    const double ga = pv * ((lpv + 1.0 - 2.0 * pq) - dota) * (double)a.scale;
+    a.dq[(size_t)i * Bg + j] = (float)gq;
+    a.da[(size_t)i * Bg + j] = (float)ga;
     sq[j] = gq; sa[j] = ga;
   }
   __syncthreads();
   // dthat_i = sum_j dq[i][j] vhat_j ; dvhat_i (row part) = sum_j da[i][j] vhat_j
   // only the rows [row0, row0 + nrows) are wanted (exact data parallel: a rank keeps the gradient rows of its own samples)
   if (tid < HUAL_D && i >= a.row0 && i < a.row0 + a.nrows) {
-    float st = 0.f, sv = 0.f;
+    double st = 0.0, sv = 0.0;
 #pragma unroll 8
     for (int j = 0; j < Bg; ++j) {
-      const float v = a.vhat[(size_t)j * ld + tid];
-      st = fmaf(sq[j], v, st);
-      sv = fmaf(sa[j], v, sv);
+      const double v = (double)a.vhat[(size_t)j * ld + tid];
+      st = fma(sq[j], v, st);
+      sv = fma(sa[j], v, sv);
     }
-    a.dthat[(i - a.row0) * HUAL_D + tid] = st;
-    a.dvhat[(i - a.row0) * HUAL_D + tid] = sv;
+    a.dthat[(i - a.row0) * HUAL_D + tid] = (float)st;
+    a.dvhat[(i - a.row0) * HUAL_D + tid] = (float)sv;
   }
 }
 __global__ __launch_bounds__(256) void align_sim_rows_kernel(AlignSim a) { align_sim_rows_body(a, blockIdx.x); }
@@ -710,9 +728,10 @@ __global__ __launch_bounds__(512) void pool_align_bwd_kernel(PoolArgs pa, PoolBw
   }
   const float tn = red6[0], vn = red6[1], tdot = red6[2], vdot = red6[3];
   tc = red6[4]; vc = red6[5];
+  // (the difference dxh - x_hat (x_hat . dxh) in double: it cancels to a few per cent of its terms)
   const float rt = rsqrtf(fmaxf(tn, L2_EPS)), rv = rsqrtf(fmaxf(vn, L2_EPS));
-  const float dtp = tn > L2_EPS ? rt * (dth - th * tdot) : rt * dth;
-  const float dvp = vn > L2_EPS ? rv * (dvh - vh * vdot) : rv * dvh;
+  const float dtp = tn > L2_EPS ? (float)((double)rt * ((double)dth - (double)th * (double)tdot)) : rt * dth;
+  const float dvp = vn > L2_EPS ? (float)((double)rv * ((double)dvh - (double)vh * (double)vdot)) : rv * dvh;
   const float dts = dtp / tc;
   // ---- video rows: d cq.feats += d vpre * inner / n_v
 #pragma unroll

@@ -72,16 +72,47 @@ class DeviceDataset:
         sel = np.asarray(sel)
         return int(self.vlen_h[sel].max()), int(self.nwords_h[sel].max()), int(self.maxchars_h[sel].max())
 
-    def assemble(self, sel, out=None, labels=True, min_chars=None):
+    def max_shape(self, min_chars=None):
+        """(T, L, C) no batch of this set exceeds"""
+        C = int(self.maxchars_h.max())
+        return int(self.vlen_h.max()), int(self.nwords_h.max()), max(C, min_chars) if min_chars else C
+
+    def feed_buffers(self, batch_size, min_chars=None, labels=True):
+        """ONE set of feed buffers sized for the largest batch of the set.  assemble(..., buffers=) hands out views of them in
+        the batch's own padded shape, so the device addresses of the feeds never change from step to step (what a per-shape
+        hipGraph of the train step needs) and nothing is allocated inside the epoch loop (runner_utils.py:139-159)."""
+        T, L, C = self.max_shape(min_chars)
+        f32, i32, d, B = torch.float32, torch.int32, self.dev, int(batch_size)
+        buf = dict(video=torch.empty(B * T * self.vdim, dtype=f32, device=d), video_seq_len=torch.empty(B, dtype=i32, device=d),
+                   word_ids=torch.empty(B * L, dtype=i32, device=d), char_ids=torch.empty(B * L * C, dtype=i32, device=d),
+                   sel=torch.empty(B, dtype=i32, device=d), shape=(B, T, L, C))
+        if labels and self.s_ind is not None:
+            buf.update(y1=torch.empty(B * T, dtype=f32, device=d), y2=torch.empty(B * T, dtype=f32, device=d),
+                       match_labels=torch.empty(B * T, dtype=i32, device=d), inner_labels=torch.empty(B * T, dtype=f32, device=d))
+        return buf
+
+    def assemble(self, sel, out=None, labels=True, min_chars=None, buffers=None, sel_dev=None):
         """Gather the batch `sel` (sample ids) on the device.  Returns a dict of device tensors named like the feeds of
-        model.py:16-27.  out: a dict from a previous call with the same shape to write into (static buffers)."""
+        model.py:16-27.  out: a dict from a previous call with the same shape to write into (static buffers).
+        buffers: feed_buffers() - the returned tensors are views of them (no allocation).  sel_dev: the same ids already on the
+        device (a slice of the epoch's permutation): nothing is uploaded for this batch."""
         sel = np.ascontiguousarray(sel, dtype=np.int32)
         B = len(sel)
         T, L, C = self.batch_shape(sel)
         if min_chars:
             C = max(C, min_chars)
         labels = labels and self.s_ind is not None
-        if out is None or out['video'].shape != (B, T, self.vdim) or out['char_ids'].shape != (B, L, C):
+        if buffers is not None:
+            Bm, Tm, Lm, Cm = buffers['shape']
+            if B > Bm or T > Tm or L > Lm or C > Cm:
+                raise ValueError('batch (%d,%d,%d,%d) exceeds the feed buffers %s' % (B, T, L, C, (buffers['shape'],)))
+            out = dict(video=buffers['video'][:B * T * self.vdim].view(B, T, self.vdim), video_seq_len=buffers['video_seq_len'][:B],
+                       word_ids=buffers['word_ids'][:B * L].view(B, L), char_ids=buffers['char_ids'][:B * L * C].view(B, L, C),
+                       sel=buffers['sel'][:B] if sel_dev is None else sel_dev)
+            if labels:
+                out.update(y1=buffers['y1'][:B * T].view(B, T), y2=buffers['y2'][:B * T].view(B, T),
+                           match_labels=buffers['match_labels'][:B * T].view(B, T), inner_labels=buffers['inner_labels'][:B * T].view(B, T))
+        elif out is None or out['video'].shape != (B, T, self.vdim) or out['char_ids'].shape != (B, L, C):
             f32, i32, d = torch.float32, torch.int32, self.dev
             out = dict(video=torch.empty(B, T, self.vdim, dtype=f32, device=d), video_seq_len=torch.empty(B, dtype=i32, device=d),
                        word_ids=torch.empty(B, L, dtype=i32, device=d), char_ids=torch.empty(B, L, C, dtype=i32, device=d),
@@ -89,7 +120,11 @@ class DeviceDataset:
             if labels:
                 out.update(y1=torch.empty(B, T, dtype=f32, device=d), y2=torch.empty(B, T, dtype=f32, device=d),
                            match_labels=torch.empty(B, T, dtype=i32, device=d), inner_labels=torch.empty(B, T, dtype=f32, device=d))
-        out['sel'].copy_(torch.from_numpy(sel))
+        if sel_dev is None:
+            out['sel'].copy_(torch.from_numpy(sel))
+        else:
+            assert sel_dev.dtype == torch.int32 and sel_dev.numel() == B and sel_dev.is_cuda
+            out['sel'] = sel_dev
         p = lib.ptr
         lib.check(self._lib.hual_assemble_batch(
             ctypes.byref(self.ds), p(out['sel']), B, T, L, C, p(out['video']), p(out['video_seq_len']), p(out['word_ids']),

@@ -42,7 +42,7 @@ class Runner:
         self.ckpt_dir = ckpt_dir or os.path.join('ckpt', '%s_' % configs.get('task', 'task'))      # main.py:42 (sic)
         self.log = logger or logging.getLogger('hual_amd')
         self.rand = random.Random(seed)
-        self.trainer = Trainer(self.model, world=1, use_graph=False)
+        self.trainer = Trainer(self.model, world=1, use_graph=True)     # per-shape step graphs (Trainer.set_batch_device)
         self.clips_per_s = 0.0
 
     # ------------------------------------------------------------------ runner_utils.train_epoch (:139-159)
@@ -59,21 +59,11 @@ class Runner:
         ds, N = self.train_set, len(self.train_set)
         order = list(range(N))
         self.rand.shuffle(order)                                   # data_loader.py:24
-        ious, feeds, pending = [], None, None
         t0 = time.perf_counter()
-        for lo in range(0, N, self.batch_size):
-            sel = order[lo:lo + self.batch_size]
-            feeds = ds.assemble(sel, out=None, min_chars=4)
-            self.trainer.set_batch_device(feeds)
-            self.trainer.step(lr=cur_lr, drop_rate=self.droprate)
-            # the spans of the previous batch are fetched while this one runs (one step of latency hiding)
-            if pending is not None:
-                ious += self._ious(pending[0], pending[1].cpu().numpy(), pending[2].cpu().numpy())
-            pending = ([ds.records[i] for i in sel], self.trainer.start_index.clone(), self.trainer.end_index.clone())
-        if pending is not None:
-            ious += self._ious(pending[0], pending[1].cpu().numpy(), pending[2].cpu().numpy())
-        torch.cuda.synchronize()
+        # the whole epoch is enqueued without a host wait; the spans come back in one transfer (Trainer.run_epoch)
+        st, en = self.trainer.run_epoch(ds, order, self.batch_size, lr=cur_lr, drop_rate=self.droprate, min_chars=4)
         self.clips_per_s = N / max(time.perf_counter() - t0, 1e-9)
+        ious = self._ious([ds.records[i] for i in order], st, en)
         return al.iou_metrics(ious)
 
     # ------------------------------------------------------------------ runner_utils.test_epoch (:161-176)

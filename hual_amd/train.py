@@ -28,6 +28,15 @@ class Trainer:
         self.shape = None
         self._tables_ready = False
         self._lib = lib.load()
+        # device-fed mode (set_batch_device): per-shape cache of ABI structs and step graphs, outputs at the largest shape seen
+        self.dynamic = False
+        self.graph_shapes = use_graph and not self.dp
+        self.cache_limit = 64
+        self._cache = {}
+        self._entry = None
+        self._out_cap = None
+        self._dp_B = None
+        self.stats = dict(eager=0, captured=0, replayed=0)
 
     # ------------------------------------------------------------------ static batch buffers
     def set_batch(self, video, lens, word_ids, char_ids, y1, y2, match_labels, inner_labels, video_dtype=torch.float32):
@@ -44,7 +53,8 @@ class Trainer:
         if self.dp and os.environ.get('HUAL_DP_SKIP_T_CHECK') != '1':
             hdist.check_padded_length(int(np.max(lens)), T)      # raises on EVERY rank together
         shape = (B, T, L, C, video_dtype)
-        if shape != self.shape:
+        if shape != self.shape or self.dynamic:
+            self.dynamic = False
             self.shape = shape
             self.graph = None
             self._tables_ready = False
@@ -109,33 +119,68 @@ class Trainer:
 
     def set_batch_device(self, feeds):
         """Point the step at feeds that already live on the device (DeviceDataset.assemble): no host copy, no upload.
-        Shapes may change from batch to batch (T = longest video of the batch), so this path launches eagerly."""
+        The padded shape changes from batch to batch (runner_utils.py:139-159: T / L / C are maxima over the batch), so this
+        mode keeps a small cache keyed by (shape, feed addresses): the structs of the C ABI, and - single GPU, use_graph - a
+        hipGraph of the whole step per shape.  A shape is launched eagerly the first time it is seen (first-use attribute calls
+        happen outside any capture) and captured the second time; with static feed buffers (DeviceDataset.feed_buffers) and
+        the one workspace of SeqPAN.reserve() every later batch of that shape is ONE graph launch.  Nothing is allocated,
+        filled or synchronised when the shape changes."""
         m, dev = self.m, self.m.device
         B, T, V = feeds['video'].shape
         L, C = feeds['word_ids'].shape[1], feeds['char_ids'].shape[2]
-        self.use_graph, self.dp_graph, self.graph = False, False, None
-        self._tables_ready = False
+        self.dynamic = True
         self.video, self.lens, self.word_ids, self.char_ids = (feeds[k] for k in ('video', 'video_seq_len', 'word_ids', 'char_ids'))
         self.y1, self.y2, self.match, self.inner = (feeds[k] for k in ('y1', 'y2', 'match_labels', 'inner_labels'))
         vdt = self.video.dtype
-        if (B, T, L, C, vdt) != self.shape:
-            self.shape = (B, T, L, C, vdt)
-            self.start_logits = torch.empty(B, T, device=dev)
-            self.end_logits = torch.empty(B, T, device=dev)
-            self.match_scores = torch.empty(B, T, 4, device=dev)
-            self.start_index = torch.empty(B, device=dev, dtype=torch.int64)
-            self.end_index = torch.empty(B, device=dev, dtype=torch.int64)
-            self.loss_terms = torch.zeros(4, device=dev)
-            if self.dp:
-                self._alloc_dp(B)
+        self.shape = (B, T, L, C, vdt)
+        self._ensure_outputs(B, T)
         self.ws = m._workspace(B, T, L, C)
         p = lib.ptr
-        self.bt = lib.hual_batch(p(self.video).value, p(self.lens).value, p(self.word_ids).value, p(self.char_ids).value,
-                                 B, T, L, C, 1 if vdt == torch.bfloat16 else 0)
-        self.lab = lib.hual_labels(p(self.y1).value, p(self.y2).value, p(self.match).value, p(self.inner).value)
+        key = (B, T, L, C, vdt, self.ws.data_ptr(), self._out_flat.data_ptr()) + tuple(
+            t.data_ptr() for t in (self.video, self.lens, self.word_ids, self.char_ids, self.y1, self.y2, self.match, self.inner))
+        e = self._cache.get(key)
+        if e is None:
+            if len(self._cache) >= self.cache_limit:            # bounded: drop the least recently used shape
+                self._cache.pop(next(iter(self._cache)))
+            e = dict(seen=0, graph=None, drop=None,
+                     bt=lib.hual_batch(p(self.video).value, p(self.lens).value, p(self.word_ids).value, p(self.char_ids).value,
+                                       B, T, L, C, 1 if vdt == torch.bfloat16 else 0),
+                     lab=lib.hual_labels(p(self.y1).value, p(self.y2).value, p(self.match).value, p(self.inner).value))
+        else:
+            self._cache.pop(key)                                 # re-insert: most recently used last
+        self._cache[key] = e
+        self._entry = e
+        self.bt, self.lab = e['bt'], e['lab']
+        self.start_logits = self._out_flat[:B * T].view(B, T)
+        self.end_logits = self._out_flat[self._out_cap[0] * self._out_cap[1]:][:B * T].view(B, T)
+        self.match_scores = self._out_flat[2 * self._out_cap[0] * self._out_cap[1]:][:B * T * 4].view(B, T, 4)
+        self.start_index, self.end_index = self.spans[0, :B], self.spans[1, :B]
         self.out = lib.hual_outputs(p(self.start_logits).value, p(self.end_logits).value, p(self.match_scores).value,
                                     p(self.start_index).value, p(self.end_index).value, p(self.loss_terms).value)
+        self._tables_ready = False                               # the workspace is shared between shapes: job tables are rewritten
+        if self.dp and (self._dp_B != B):
+            self._alloc_dp(B)
+            self._dp_B = B
         self._update_match_denominator()
+
+    def _ensure_outputs(self, B, T):
+        """fetch tensors of the device-fed mode: one allocation for the largest (B, T) seen (grown geometrically, which drops
+        the cached graphs - they hold the old addresses); spans as ONE [2, B] tensor so a loop can bank both with one copy"""
+        cap = self._out_cap
+        if cap is not None and B <= cap[0] and T <= cap[1]:
+            return
+        Bc, Tc = max(B, cap[0] if cap else 0), max(T, cap[1] if cap else 0)
+        dev = self.m.device
+        self._out_cap = (Bc, Tc)
+        self._out_flat = torch.empty(6 * Bc * Tc, device=dev)
+        self.spans = torch.zeros(2, Bc, device=dev, dtype=torch.int64)
+        self.loss_terms = torch.zeros(4, device=dev)
+        self._cache.clear()
+
+    def reserve(self, B, T, L, C):
+        """size workspace and fetch tensors for the largest batch of a loop up front (no growth inside it)"""
+        self.m.reserve(B, T, L, C)
+        self._ensure_outputs(B, T)
 
     # ------------------------------------------------------------------ one step
     def _opts(self, drop_rate, align_external):
@@ -198,7 +243,9 @@ class Trainer:
         if m.lr_value != float(lr):               # the fed scalar changes once per epoch (main.py:61): no fill launch otherwise
             m.lr.fill_(float(lr))
             m.lr_value = float(lr)
-        if self.dp:
+        if self.dynamic:
+            self._step_dynamic(drop_rate)
+        elif self.dp:
             self._step_dp(drop_rate)
         elif not self.use_graph:
             self._enqueue_single(drop_rate)
@@ -218,6 +265,29 @@ class Trainer:
                 self.graph, self.graph_drop = g, drop_rate
             self.graph.replay()
         m.global_step += 1
+
+    def _step_dynamic(self, drop_rate):
+        """device-fed mode: eager on the first sighting of a (shape, addresses) key, captured on the second, replayed after"""
+        e = self._entry
+        if self.dp:
+            self._enqueue_dp(drop_rate)
+            self.stats['eager'] += 1
+            return
+        if e['graph'] is not None and e['drop'] == drop_rate:
+            e['graph'].replay()
+            self.stats['replayed'] += 1
+            return
+        if not self.graph_shapes or e['seen'] == 0:
+            self._enqueue_single(drop_rate)
+            e['seen'] += 1
+            self.stats['eager'] += 1
+            return
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):                                # records, executes nothing: the replay below IS the step
+            self._enqueue_single(drop_rate)
+        e['graph'], e['drop'] = g, drop_rate
+        g.replay()
+        self.stats['captured'] += 1
 
     def _step_dp(self, drop_rate):
         """With the nccl backend (RCCL: its collectives are stream operations) the data-parallel step, collectives included, CAN be
@@ -263,6 +333,43 @@ class Trainer:
                 return
             self.graph, self.graph_drop = g, drop_rate
         self.graph.replay()
+
+    # ------------------------------------------------------------------ one epoch on a device-resident training set
+    def run_epoch(self, dataset, order, batch_size, lr, drop_rate, min_chars=4, want_spans=True):
+        """The loop of runner_utils.py:139-159 (train_epoch) on a DeviceDataset: for every batch of `order` (sample ids, already
+        shuffled - data_loader.py:23-28) assemble the feeds on the device, run the train step, bank the predicted spans.
+
+        Nothing in the loop waits for the device and nothing is uploaded per step: the permutation goes up ONCE, a batch's ids
+        are a slice of it; the feeds are views of one set of max-shape buffers; the workspace and the fetch tensors are sized
+        once; a step is one hipGraph launch for every padded shape seen before (set_batch_device); the spans of each step are
+        copied (device to device) into an epoch-long bank that is fetched with ONE transfer after the last step - the
+        reference's IoU bookkeeping (runner_utils.py:150-156) only needs them at the end of the epoch.
+        Returns (start, end) int64 numpy arrays in the order of `order` (None, None with want_spans False)."""
+        m = self.m
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        N, bs = len(order), int(batch_size)
+        nsteps = (N + bs - 1) // bs
+        if getattr(self, '_feed_owner', None) is not dataset or self._feeds['shape'][0] < min(bs, N):
+            self._feeds = dataset.feed_buffers(min(bs, N), min_chars=min_chars)
+            self._feed_owner = dataset
+        Bm, Tm, Lm, Cm = self._feeds['shape']
+        self.reserve(Bm, Tm, Lm, Cm)
+        order_dev = torch.from_numpy(order).to(m.device)
+        bank = torch.empty(nsteps, 2, self.spans.shape[1], dtype=torch.int64, device=m.device) if want_spans else None
+        for i in range(nsteps):
+            lo = i * bs
+            sel = order[lo:lo + bs]
+            feeds = dataset.assemble(sel, min_chars=min_chars, buffers=self._feeds, sel_dev=order_dev[lo:lo + len(sel)])
+            self.set_batch_device(feeds)
+            self.step(lr=lr, drop_rate=drop_rate)
+            if want_spans:
+                bank[i].copy_(self.spans)
+        if not want_spans:
+            return None, None
+        host = bank.cpu().numpy()                                # the epoch's only device -> host transfer (and only sync)
+        st = np.concatenate([host[i, 0, :len(order[i * bs:(i + 1) * bs])] for i in range(nsteps)])
+        en = np.concatenate([host[i, 1, :len(order[i * bs:(i + 1) * bs])] for i in range(nsteps)])
+        return st, en
 
     def last_loss(self):
         """total loss of the last step (device sync).  DP: local loc/match terms + the global alignment loss."""

@@ -73,6 +73,7 @@ def hip_model(cfg, p, wv, device='cuda:0'):
                       match_lambda=cfg.match_lambda, clip_norm=cfg.clip_norm, no_gumbel=1 if cfg.get('no_gumbel', True) else 0,
                       tau=float(cfg.get('tau', 0.3)))
     m = SeqPAN(hc, wv.numpy(), device=device)
+    m.ws_poison = 0xFF       # the workspace is never cleared by the product path: every parity run starts from NaN-pattern bytes
     m.load_state_dict({k: v.detach().numpy() for k, v in p.items()})
     return m
 
