@@ -56,20 +56,36 @@ def infer_trainset(model, batches, mc_dropout=None):
     """
     from . import data
     records, ious = [], []
-    for raw, video, lens, word_ids, char_ids in batches:
+
+    def enqueue(batch):
+        """all forwards of a batch (one deterministic + two stochastic), nothing fetched: the device runs them while the host
+        writes the records of the batch before"""
+        raw, video, lens, word_ids, char_ids = batch
         o = model.forward(video, lens, word_ids, char_ids, drop_rate=0.0)
-        s0, e0 = o['start_logits'].cpu().numpy(), o['end_logits'].cpu().numpy()
-        ms = o['match_scores'].cpu().numpy()
-        si, ei = o['start_index'].cpu().numpy(), o['end_index'].cpu().numpy()
+        dev = [o['start_logits'], o['end_logits'], o['match_scores'], o['start_index'], o['end_index']]
+        if mc_dropout is not None:
+            o1 = model.forward(video, lens, word_ids, char_ids, drop_rate=mc_dropout)
+            model.rng_state[2] += 1                              # a fresh Philox offset for the second stochastic pass
+            o2 = model.forward(video, lens, word_ids, char_ids, drop_rate=mc_dropout)
+            model.rng_state[2] += 1
+            dev += [o1['start_logits'], o1['end_logits'], o2['start_logits'], o2['end_logits']]
+        # device -> pinned host, asynchronously on the compute stream; the event marks their arrival
+        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in dev]
+        for h, t in zip(host, dev):
+            h.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return raw, host, ev
+
+    def emit(job):
+        raw, host, ev = job
+        ev.synchronize()
+        # (copies: the records outlive the loop, the pinned staging buffers should not)
+        s0, e0, ms, si, ei = (h.numpy().copy() for h in host[:5])
         if mc_dropout is None:
             s1, e1, s2, e2 = s0, e0, s0, e0                     # as written: drop_rate never reaches the graph (F8)
         else:
-            o1 = model.forward(video, lens, word_ids, char_ids, drop_rate=mc_dropout)
-            s1, e1 = o1['start_logits'].cpu().numpy(), o1['end_logits'].cpu().numpy()
-            model.rng_state[2] += 1                              # a fresh Philox offset for the second stochastic pass
-            o2 = model.forward(video, lens, word_ids, char_ids, drop_rate=mc_dropout)
-            s2, e2 = o2['start_logits'].cpu().numpy(), o2['end_logits'].cpu().numpy()
-            model.rng_state[2] += 1
+            s1, e1, s2, e2 = (h.numpy().copy() for h in host[5:9])
         for i, r in enumerate(raw):
             st, et = data.index_to_time([int(si[i]), int(ei[i])], r['v_len'], r['duration'])
             gs, ge = data.index_to_time([r['s_ind'], r['e_ind']], r['v_len'], r['duration'])
@@ -78,6 +94,15 @@ def infer_trainset(model, batches, mc_dropout=None):
                             'sentence': ' '.join(r['words']), 'v_len': int(r['v_len']),
                             'prop_idx': [int(si[i]), int(ei[i])], 'prop_logits': [s0[i], e0[i]],
                             'prop_logits1': [s1[i], e1[i]], 'prop_logits2': [s2[i], e2[i]], 'm_score': ms[i]})
+
+    pending = None
+    for batch in batches:
+        job = enqueue(batch)                                     # batch n is on the device ...
+        if pending is not None:
+            emit(pending)                                        # ... while the records of batch n - 1 are written
+        pending = job
+    if pending is not None:
+        emit(pending)
     return records, ious
 
 

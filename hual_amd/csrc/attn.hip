@@ -1,8 +1,9 @@
-// Attention kernels (see attn.h), head size 16, on v_mfma_f32_16x16x32_bf16 with split fp32 operands (bf16x3.h:
-// x = hi + lo, a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate).
+// Attention kernels (see attn.h), head size 16, on v_mfma_f32_16x16x32_f16 with split fp32 operands (bf16x3.h, "f16x3":
+// x s = hi + lo with fp16 hi / lo and a power-of-two scale s, a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate - 22-bit
+// operands; rounds 2-4 used bf16 pairs, 16 bits: see the header of the backward section for the scales and what they cost).
 //
 // One workgroup (4 waves) = one (job, clip, head).  The head's K / V (forward) or Q / dO / K (backward) panels are split
-// once into bf16 planes in LDS; everything between the products stays in registers:
+// once into fp16 hi / lo planes in LDS; everything between the products stays in registers:
 //
 //   forward  - a wave owns 16 queries and ALL keys.  It computes S^T = K.Q^T per 16-key tile (K = 32 slots of the MFMA =
 //              [hi | lo] of the 16 head dims, so hi.hi + lo.hi is ONE instruction and hi.lo the second), so lane
@@ -48,19 +49,9 @@ size_t attn_keep_bytes(int B, int Tq, int Tk) { return (size_t)B * 8 * cdiv(Tq, 
 #define ATT_C1 (0.25f * ATT_LOG2E)              // 1/sqrt(head_size = 16) (layers.py:82), scores kept in the log2 domain
 #define ATT_NEGL (HUAL_MASK_VALUE * ATT_LOG2E)  // the additive mask value (ops.py:89 via layers.py:84) in the log2 domain
 
-__device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
+// (bf16x8 is the register type of an operand fragment: the bytes are format blind, mfma_h below reads them as fp16)
 __device__ __forceinline__ bf16x8 as_bf8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ bf16x8 as_bf8(uint2 a, uint2 b) { return as_bf8(make_uint4(a.x, a.y, b.x, b.y)); }
-// eight floats -> packed high parts and residuals
-__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
-  bf16_split_pair(a.x, a.y, hi.x, lo.x);
-  bf16_split_pair(a.z, a.w, hi.y, lo.y);
-  bf16_split_pair(b.x, b.y, hi.z, lo.z);
-  bf16_split_pair(b.z, b.w, hi.w, lo.w);
-}
-
 // XCD-aware block order (cdna_hip_programming.md T1, bijective form).  The dispatcher deals consecutive linear block ids
 // round-robin over the 8 XCDs, each with a private L2; all blocks of one clip (jobs x heads) read that clip's rows, so the
 // remap hands each XCD a contiguous run of logical ids, i.e. whole clips.
@@ -71,18 +62,12 @@ __device__ __forceinline__ int xcd_logical_id() {
 }
 
 // ---- LDS panels -----------------------------------------------------------------------------------------
-// A panel holds the 16 head dims of up to 256 rows, split: row r = [16 x bf16 high parts | 16 x bf16 residuals] (64 bytes).
+// A panel holds the 16 head dims of up to 256 rows, split: row r = [16 x fp16 high parts | 16 x fp16 residuals] (64 bytes).
 // It serves every operand shape of the kernels:
 //   * rows as the M / N index of a product whose contraction runs over the head dims (S = Q.K^T, dP = dO.V^T): one
 //     16-byte read per lane, slots [hi | lo] (panel_a) or [hi | hi], [lo | 0] (panel_b1 / panel_b2);
 //   * rows as the CONTRACTION index (P.V, dS^T.Q, P^T.dO, dS.K): ds_read_b64_tr_b16 delivers a 4-row x 16-column block
 //     column-major, i.e. lane (col = lane & 15, g) receives rows 4 g .. 4 g + 3 of its column (panel_tr).
-__device__ __forceinline__ void panel_store(char* dst, int row, int c4, const float4& v) {
-  uint2 h, l;
-  bf16_split4(v, h, l);
-  *reinterpret_cast<uint2*>(dst + row * 64 + 8 * c4) = h;
-  *reinterpret_cast<uint2*>(dst + row * 64 + 32 + 8 * c4) = l;
-}
 __device__ __forceinline__ bf16x8 panel_a(const char* panel, int row, int g) {
   return *reinterpret_cast<const bf16x8*>(panel + row * 64 + 16 * g);
 }
@@ -123,6 +108,14 @@ __device__ __forceinline__ void split8h(const float4& a, const float4& b, float 
 }
 __device__ __forceinline__ void panel_store_h(char* dst, int row, int c4, const float4& v, float sc) {
   uint2 h, l;
+#ifdef ATT_EXP_RAWPANEL     // timing experiment: what the splits of the fixed-scale panels (Q, K, V) cost - raw bits instead (numerically wrong)
+  if (sc == ATT_SX) {
+    h = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); l = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+    *reinterpret_cast<uint2*>(dst + row * 64 + 8 * c4) = h;
+    *reinterpret_cast<uint2*>(dst + row * 64 + 32 + 8 * c4) = l;
+    return;
+  }
+#endif
   att_split4(f4scale1(v, sc), h, l);
   *reinterpret_cast<uint2*>(dst + row * 64 + 8 * c4) = h;
   *reinterpret_cast<uint2*>(dst + row * 64 + 32 + 8 * c4) = l;
@@ -724,7 +717,10 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
     vmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_max64(vmax))));
 #endif
     float s_ds_inv;
-    const float s_ds = att_pow2_scale(2.0f * (16.0f * gmax * vmax * (dodrop ? scale8 : 1.0f) + dmax), s_ds_inv);
+    // (the bound itself goes to [2^14, 2^15): p <= 1 + 1e-4 keeps p |t| below fp16's 65504, and every binade the scale gives away is a binade
+    //  of small dS elements whose residual falls below fp16's normal range and is lost)
+    float s_ds = att_pow2_scale(16.0f * gmax * vmax * (dodrop ? scale8 : 1.0f) + dmax, s_ds_inv);
+    s_ds *= 2.0f; s_ds_inv *= 0.5f;
     c_dk = s_ds_inv / ATT_SX;
     const float m_pd0 = (dodrop ? scale8 : 1.0f) * ATT_SP * s_ds_inv * sg;      // pd = (p s_ds) m_pd0 / s_q = 2^10 (sg / s_q) x dropped probability
     const bf16x8 kh = panel_tr(Kp, 0, 32 * kp, lane), kl = panel_tr(Kp, 32, 32 * kp, lane);      // B operand of dQ

@@ -66,14 +66,15 @@ def _attn_ref(Q, K, V, qm, km, B, Tq, Tk, drop=None):
 
 @pytest.mark.parametrize('B,Tq,Tk', [(2, 16, 16), (3, 37, 9), (2, 128, 128), (1, 20, 256), (2, 100, 30), (1, 256, 256), (3, 1, 1)])
 def test_attention_fwd(dev, B, Tq, Tk):
-    """split-bf16 products (three passes, ~2^-16 per product) + fp32 softmax: 2e-4 absolute on O(1) outputs (bar: 1e-3)"""
+    """fp16-pair products (three passes, 22-bit operands) + fp32 softmax: at the level of a float32 PyTorch evaluation of the same
+    function (3e-7 .. 1.4e-6 measured on these cases against 3e-7 .. 7e-7, scripts/exp/attn_err.py); gate 6e-6 on O(1) outputs (bar: 1e-3)"""
     from hual_amd import lib
     Q, K, V, qm, km = _attn_case(dev, B, Tq, Tk, B * 1000 + Tq + Tk)
     O = torch.empty(B * Tq, 128, device=dev)
     lib.check(lib.load().hual_attention_fwd(lib.ptr(Q), 128, lib.ptr(K), lib.ptr(V), 128, lib.ptr(O), 128, B, Tq, Tk, lib.ptr(qm),
                                             lib.ptr(km), lib.stream_ptr()))
     ref = _attn_ref(Q.double(), K.double(), V.double(), qm.double(), km.double(), B, Tq, Tk)
-    assert (O.double() - ref).abs().max().item() < 2e-4
+    assert (O.double() - ref).abs().max().item() < 6e-6
 
 
 def test_attention_fwd_rejects_more_than_256_queries(dev):
@@ -94,7 +95,8 @@ def test_attention_fwd_rejects_more_than_256_queries(dev):
 @pytest.mark.parametrize('rate', [0.0, 0.2])
 def test_attention_fwd_bwd_with_dropout(dev, B, Tq, Tk, rate):
     """hual_attention_fwd_save + hual_attention_bwd against float64 autograd of the same function with the oracle's dropout
-    mask: the kernels drop exactly the same probabilities, gradients within 1e-3 of each tensor's scale"""
+    mask: the kernels drop exactly the same probabilities; gradients within 3e-6 of each tensor's scale (measured 1-7e-7, the level of
+    float32 PyTorch autograd on the same function: round 5 moved the kernels from bf16 pairs - 2e-5 .. 1e-4 here - to fp16 pairs)"""
     from hual_amd import lib
     l = lib.load()
     Q, K, V, qm, km = _attn_case(dev, B, Tq, Tk, 77 + B * 1000 + Tq + Tk)
@@ -114,12 +116,15 @@ def test_attention_fwd_bwd_with_dropout(dev, B, Tq, Tk, rate):
                                    lib.ptr(rng_state), rate, site, lib.stream_ptr()))
     Qd, Kd, Vd = (t.double().cpu().requires_grad_(True) for t in (Q, K, V))
     ref = _attn_ref(Qd, Kd, Vd, qm.double().cpu(), km.double().cpu(), B, Tq, Tk, (seed, offset, rate, site) if rate > 0 else None)
-    assert (O.double().cpu() - ref.detach()).abs().max().item() < 3e-4
+    # (6e-6, not 3e-6: an operand element whose residual lies below fp16's normal range - 1.5 % of them - loses it in the matrix pipe:
+    #  up to 2^-14 / 16 = 3.8e-6 absolute on that element, visible one to one where a single key carries the whole probability)
+    assert (O.double().cpu() - ref.detach()).abs().max().item() < 6e-6
     ref.backward(dO.double().cpu())
     for name, got, want in (('dQ', dQ, Qd.grad), ('dK', dK, Kd.grad), ('dV', dV, Vd.grad)):
         err = (got.double().cpu() - want).abs().max().item()
-        # (+ 5e-5 absolute: with a single key the softmax is constant and dQ, dK are rounding noise around an exact zero)
-        assert err <= 1e-3 * want.abs().max().item() + 5e-5, (name, err, want.abs().max().item())
+        # (+ 3e-6 absolute: with a single key the softmax is constant and dQ, dK are rounding noise around an exact zero - dP - delta
+        #  with delta = dO . O from the forward's own rounding of O)
+        assert err <= 3e-6 * want.abs().max().item() + 3e-6, (name, err, want.abs().max().item())
 
 
 def _span_ref(s, e, m):

@@ -126,14 +126,13 @@ def test_c1_trajectory_matches_the_clean_fp64_oracle():
 
     What sets the drift: AdamWeightDecay has no bias correction (ops.py:149-174), so the first updates are lr * 3.16 * sign(g) for
     EVERY element - an element whose gradient is small against the rounding noise of its tensor moves a full step in a direction
-    the noise decides.  The HIP gradients sit 2-4e-5 of each tensor's maximum from the float64 oracle's (attention and context-query
-    backward on split-bf16 products: 2^-16 per product; scripts/exp/grad_noise.py), PyTorch's float32 ones ~1e-6: on the sample
-    path of this seed (round 4, 16-bit decisions at the trilinear sites) the float32 oracle stays within 6e-7 of float64 for all
-    ten steps while the HIP loss is within 1e-6 for two steps, 3e-6 at step 2, 1.2e-4 at step 3 and 1.8e-3 at step 9; on the
-    previous path (32-bit trilinear decisions) it held 1e-6 through step 5, and on bench.py's batch it is the float32 oracle that
-    leaves first.  The test therefore demands what every path has delivered: the forward's precision on the first steps (<= 5e-6
-    for steps 0-2), the reference's loss to 5e-3 over all ten steps, a falling loss, and the spans EQUAL to the float64 oracle's
-    while the loss agrees to 1e-5.  The per-step numbers of all three runs are printed (-s) and recorded in DESIGN.md section 5."""
+    the noise decides.  Round 4's kernels (attention and context-query backward on bf16 pairs, 16-bit operands) put every gradient
+    tensor 2-4e-5 of its maximum from the float64 oracle's and this trajectory left it by 1.8e-3 at step 9.  Round 5 (fp16 pairs, 22
+    bits, in the attention forward + backward and the context-query backward; the [B,B] alignment similarity in double): median
+    5.3e-6 of each tensor's maximum against 4.6e-6 for float32 PyTorch (profiles/r5_grad_error_c1.txt), and on this sample path the
+    HIP loss stays within 1.2e-6 of float64 through step 7 and within 4e-5 through step 9 (float32 PyTorch: 8e-7).  The test demands:
+    steps 0-2 within 1e-6 (the forward's precision), steps 0-6 within 1e-5, ALL TEN steps within 1e-3 (the 5e-3 of round 4 is gone),
+    a falling loss, and the spans EQUAL to the float64 oracle's while the loss agrees to 1e-5."""
     from hual_amd.train import Trainer
     lr, drop, seed, off, steps = 1e-4, 0.2, 1, 1, 10
     cfg, p, wv, b, labels = pu.make_case(B=16, T=64, L=20, C=8, seed=12345, max_vlen=64, vdim=1024, num_words=1000)
@@ -156,9 +155,11 @@ def test_c1_trajectory_matches_the_clean_fp64_oracle():
         rel_h, rel_o = abs(hl - o64[s][0]) / den, abs(o32[s][0] - o64[s][0]) / den
         worst_h, worst_o = max(worst_h, rel_h), max(worst_o, rel_o)
         print('step %2d  loss hip %.5f  f32 %.5f  f64 %.5f   rel to f64: hip %.2e  f32 oracle %.2e' % (s, hl, o32[s][0], o64[s][0], rel_h, rel_o))
-        assert rel_h <= 5e-3, (s, hl, o64[s][0])
+        assert rel_h <= 1e-3, (s, hl, o64[s][0])
+        if s < 7:
+            assert rel_h <= 1e-5, (s, hl, o64[s][0])
         if s < 3:
-            assert rel_h <= 5e-6, (s, hl, o64[s][0])
+            assert rel_h <= 1e-6, (s, hl, o64[s][0])
         if worst_h <= 1e-5:
             assert torch.equal(tr.start_index.cpu(), o64[s][3]) and torch.equal(tr.end_index.cpu(), o64[s][4]), s
     assert last < first - 5.0 and o64[-1][0] < o64[0][0] - 5.0
