@@ -615,7 +615,11 @@ __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h,
       rmax = fmaxf(rmax, dpp_xor_partner(rmax, 1));
       rmax = fmaxf(rmax, dpp_xor_partner(rmax, 2));
       float rinv;
+#ifdef ATT_EXP_DOFIX      // timing experiment: what the per-row scale of the dO panel costs (numerically wrong for small gradients)
+      const float rsc = 1024.0f; rinv = 1.0f / 1024.0f; (void)rmax;
+#else
       const float rsc = att_pow2_scale(rmax, rinv);
+#endif
       if (row < Tqp) {
         panel_store_h(Qp, row, c4, qok ? sq[it] : f4zero(), ATT_SX);
         panel_store_h(Dp, row, c4, qok ? sd[it] : f4zero(), rsc);
@@ -737,7 +741,11 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
         // (1 / sum x s_ds: the scale of the dS operand rides on the normalisation)
         const float4 g4 = *reinterpret_cast<const float4*>(St + 6 * Tqp + q0 + 4 * g);
         const float mxv[4] = {m4.x, m4.y, m4.z, m4.w}, inv[4] = {i4.x * s_ds, i4.y * s_ds, i4.z * s_ds, i4.w * s_ds}, dlv[4] = {d4.x, d4.y, d4.z, d4.w};
+#ifdef ATT_EXP_MCONST     // timing experiment: per-row factors of the dO scale replaced by constants (numerically wrong)
+        const float m_pd[4] = {m_pd0, m_pd0, m_pd0, m_pd0}, m_dp[4] = {m_dp0, m_dp0, m_dp0, m_dp0}; (void)g4;
+#else
         const float m_pd[4] = {g4.x * m_pd0, g4.y * m_pd0, g4.z * m_pd0, g4.w * m_pd0}, m_dp[4] = {g4.x * m_dp0, g4.y * m_dp0, g4.z * m_dp0, g4.w * m_dp0};
+#endif
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -923,7 +931,11 @@ __device__ __forceinline__ void attn_bwd_pre_store(const AttnJob& job, char* lds
   rmax = fmaxf(rmax, dpp_xor_partner(rmax, 1));
   rmax = fmaxf(rmax, dpp_xor_partner(rmax, 2));
   float rinv;
+#ifdef ATT_EXP_DOFIX
+  const float rsc = 1024.0f; rinv = 1.0f / 1024.0f;
+#else
   const float rsc = att_pow2_scale(rmax, rinv);          // the row's own scale (attn_bwd_stage)
+#endif
   if (row < Tqp) {
     panel_store_h(Qp, row, c4, qok ? s.q : f4zero(), ATT_SX);
     panel_store_h(Dp, row, c4, qok ? s.d : f4zero(), rsc);
@@ -982,8 +994,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_chain_kernel(AttnBatch batch,
     const int per = (int)(gridDim.x >> 6);           // (kind, clip) pairs per XCD: the chains of an XCD's clips first
     if ((gridDim.x & 63) == 0 && (per & 1) == 0) {
       const int cpx = per >> 1, x = lid / per, w = lid - x * per;
-      kind = 1 - w / cpx;                            // the chain is the longer of the two (~44 k against 27 k cycles): it goes first
-      b = x * cpx + (w - (w / cpx) * cpx);
+      // Order inside an XCD's run.  Round 4 put the chains of an XCD's clips first (the longer kind: ~45 k against ~30 k cycles) - but then
+      // the two workgroups of a CU are always of one kind, start together and run their memory and compute phases in lockstep.  Round 5:
+      // runs of FOUR (kind, clip) pairs alternate, so that the two slots of a CU (workgroups i and i + 32 of the XCD's dispatch order)
+      // hold one chain and one large job: their phases interleave instead of coinciding (83.8 -> 79.0 us for the two launches, same-box A/B)
+      if ((cpx & 3) == 0) { kind = 1 - ((w >> 2) & 1); b = x * cpx + (w & 3) + 4 * (w >> 3); }
+      else { kind = 1 - w / cpx; b = x * cpx + (w - (w / cpx) * cpx); }
     }
   }
   if (b >= batch.j[0].B) return;   // block-uniform

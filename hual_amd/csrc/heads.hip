@@ -668,14 +668,17 @@ __global__ __launch_bounds__(512) void pool_align_bwd_kernel(PoolArgs pa, PoolBw
   const int L = rs.L, T = rs.T;
   const size_t vrow0 = (size_t)b * T, qrow0 = (size_t)rs.Nv + (size_t)b * L;
   // ---- phase 0: every load
-  float rdf[KT], rf1[KT], rin[KT], rF[KL];
+  // (the inner labels of the clip go through LDS, one float per frame: as a third register array of KT they cost the 64-row
+  //  instantiation - T = 256 - 53 spilled registers, 47.6 us per launch at B32 T256)
+  __shared__ float inl[256];
+  float rdf[KT], rf1[KT], rF[KL];
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     const int t = min(grp + 4 * k, T - 1);
     rdf[k] = pb.dFuse[(vrow0 + t) * HUAL_D + c];
     rf1[k] = ab.dF1[(vrow0 + t) * HUAL_D + c];
-    rin[k] = ap.inner[vrow0 + t];
   }
+  for (int t = tid; t < T; t += 512) inl[t] = ap.inner[vrow0 + t];      // (published by the barriers of phase 1)
 #pragma unroll
   for (int k = 0; k < KL; ++k) rF[k] = pa.F2[(qrow0 + min(grp + 4 * k, L - 1)) * HUAL_D + c];
   const float tp = ap.tpre[b * HUAL_D + c], vp = ap.vpre[b * HUAL_D + c];
@@ -737,7 +740,7 @@ __global__ __launch_bounds__(512) void pool_align_bwd_kernel(PoolArgs pa, PoolBw
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     const int t = grp + 4 * k;
-    if (t < T) ab.dF1[(vrow0 + t) * HUAL_D + c] = rf1[k] + dvp * (rin[k] / vc);
+    if (t < T) ab.dF1[(vrow0 + t) * HUAL_D + c] = rf1[k] + dvp * (inl[t] / vc);
   }
   // ---- d pooled[c] = sum_n dPW[n] * Wbot[c][n]  (four slices of n)
   {
