@@ -312,23 +312,30 @@ class Trainer:
             for t, sn in zip((m.params, m.adam_m, m.adam_v, m.rng_state), snap):
                 t.copy_(sn)
             torch.cuda.synchronize()
-            g, err = None, None
+            g, err, fatal = None, None, None
             try:
                 g = torch.cuda.CUDAGraph()
                 # thread_local: the process group's watchdog thread may touch the device while this thread captures
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._enqueue_dp(drop_rate)
-            except lib.HualError:                    # one of our launches failed: not a capture refusal
-                raise
+            except lib.HualError as e:               # one of our launches failed: not a capture refusal - but the peers are about to
+                g, fatal = None, e                   # enter the collective below, so it is raised only after this rank has joined it
             except RuntimeError as e:                # capture of the collectives refused
                 g, err = None, e
                 torch.cuda.synchronize()
-            ok = hdist.global_min(1 if g is not None else 0)     # same path on every rank
-            if not ok:
+            except BaseException as e:               # anything else: same rule - join the collective first
+                g, fatal = None, e
+            # the same decision on every rank: 2 = captured, 1 = capture refused (eager launches), 0 = a launch failed (everybody raises)
+            state = hdist.global_min(2 if g is not None else (0 if fatal is not None else 1))
+            if fatal is not None:
+                raise fatal
+            if state == 0:
+                raise lib.HualError('data-parallel step: a launch failed on another rank during graph capture')
+            if state == 1:
                 self._dp_graph_failed = True
                 self.graph = None
                 print('[hual] data-parallel step: graph capture %s - eager launches on every rank'
-                      % ('failed here (%s)' % str(err).splitlines()[0] if err is not None else 'failed on another rank'), file=sys.stderr)
+                      % ('refused here (%s)' % str(err).splitlines()[0] if err is not None else 'refused on another rank'), file=sys.stderr)
                 self._enqueue_dp(drop_rate)
                 return
             self.graph, self.graph_drop = g, drop_rate
