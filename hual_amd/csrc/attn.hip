@@ -89,22 +89,18 @@ __device__ __forceinline__ bf16x8 panel_tr(const char* panel, int plane, int row
 // ---- fp16-pair operands (round 5: forward and backward; scales in the header of the backward section)
 #define ATT_SX 16.0f                            // Q, K, V
 #define ATT_SP 1024.0f                          // probabilities
-#ifdef ATT_EXP_BF16       // timing experiment: the round-5 structure on bf16 instructions
-#define att_split_pair bf16_split_pair
-#define att_split4 bf16_split4
-__device__ __forceinline__ f32x4 mfma_h(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-#else
-#define att_split_pair f16_split_pair
-#define att_split4 f16_split4
 __device__ __forceinline__ f32x4 mfma_h(bf16x8 a, bf16x8 b, f32x4 c) {      // (operand bytes are format blind: the panel helpers serve both)
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-#endif
+// (the same structure on bf16 instructions was measured to take the same time - the instruction kind is not what the 22-bit form costs.
+//  Panels - LDS stores - split with the scale folded into the mixed-precision FMA, bf16x3.h f16_split_pair_s)
 __device__ __forceinline__ void split8h(const float4& a, const float4& b, float sc, uint4& hi, uint4& lo) {
-  att_split_pair(a.x * sc, a.y * sc, hi.x, lo.x);
-  att_split_pair(a.z * sc, a.w * sc, hi.y, lo.y);
-  att_split_pair(b.x * sc, b.y * sc, hi.z, lo.z);
-  att_split_pair(b.z * sc, b.w * sc, hi.w, lo.w);
+  // (the conversion sequence the compiler sees, NOT the asm form of bf16x3.h f16_split_pair_s: these halves go straight into MFMA operands,
+  //  and the hazard recogniser does not look inside inline asm - a VALU write of an MFMA source needs wait states: wrong products at Tk = 256)
+  f16_split_pair(a.x * sc, a.y * sc, hi.x, lo.x);
+  f16_split_pair(a.z * sc, a.w * sc, hi.y, lo.y);
+  f16_split_pair(b.x * sc, b.y * sc, hi.z, lo.z);
+  f16_split_pair(b.z * sc, b.w * sc, hi.w, lo.w);
 }
 __device__ __forceinline__ void panel_store_h(char* dst, int row, int c4, const float4& v, float sc) {
   uint2 h, l;
@@ -116,7 +112,7 @@ __device__ __forceinline__ void panel_store_h(char* dst, int row, int c4, const 
     return;
   }
 #endif
-  att_split4(f4scale1(v, sc), h, l);
+  f16_split4_s(v, sc, h, l);
   *reinterpret_cast<uint2*>(dst + row * 64 + 8 * c4) = h;
   *reinterpret_cast<uint2*>(dst + row * 64 + 32 + 8 * c4) = l;
 }

@@ -50,6 +50,28 @@ __device__ __forceinline__ void f16_split_pair(float x0, float x1, uint32_t& hi,
   const f16x2_t l = __builtin_convertvector((f32x2_t){x0 - hf[0], x1 - hf[1]}, f16x2_t);   // x - hi is exact in fp32
   lo = __builtin_bit_cast(uint32_t, l);
 }
+// The same split of (x0 s, x1 s) with the scale folded in, on the mixed-precision FMA: v_fma_mixlo_f16 / v_fma_mixhi_f16 evaluate
+// f16(a * b + c) with every source either float32 or one half of a register - hi = f16(x s + 0), lo = f16(x s - hi), the fma exact in
+// float32 (s is a power of two), ONE rounding each: bit-identical to f16_split_pair(x0 * s, x1 * s, ..) (scripts/exp/mix_split_test.hip)
+// in FOUR vector instructions per pair instead of seven (v_pk_mul, v_cvt_pk_f16_f32, 2 v_cvt_f32_f16, v_pk_fma, v_cvt_pk_f16_f32), none
+// of them packed-f32 (an anti-lever beside MFMAs, MI355X_MICROARCH.md: the scale multiplications alone cost the weight-gradient launch 18 us).
+// ONLY where the halves go to memory (LDS / global stores): as MFMA operands they need the wait states of a VALU write in front of a matrix
+// instruction, which the compiler's hazard recogniser cannot place behind inline asm (the attention forward computed wrong products at
+// Tk = 256 that way).  Measured per kernel (same-box A/B): weight gradients 159 -> 144 us, attention forward panels -1.8 us; the fused
+// chains, conv_block and the context-query kernels were 1-2 % SLOWER with it (their splits sit in phases that are not issue bound) and
+// keep the conversion sequence.
+__device__ __forceinline__ void f16_split_pair_s(float x0, float x1, float s, uint32_t& hi, uint32_t& lo) {
+  uint32_t h, l;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(s));      // (the upper half is written next)
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+  hi = h; lo = l;
+}
+__device__ __forceinline__ void f16_split4_s(const float4& x, float s, uint2& hi, uint2& lo) {
+  f16_split_pair_s(x.x, x.y, s, hi.x, lo.x);
+  f16_split_pair_s(x.z, x.w, s, hi.y, lo.y);
+}
 __device__ __forceinline__ uint32_t f16_pack2(float x0, float x1) {      // v_cvt_pk_f16_f32, round to nearest even
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){x0, x1}, f16x2_t));
 }

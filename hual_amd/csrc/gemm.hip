@@ -2,7 +2,7 @@
 //   feature_ksplit_kernel   the feature-load phase (video_conv1d + query_conv1d) when the weight quarters fit LDS
 //   pack_weights_kernel     once per step: pre-split images of every dense weight (+ the step prologue: masks, gradient zeroing,
 //                           orthogonality term, embedding gather)
-//   dw_bf16_balanced_kernel every weight / bias gradient of a step in one persistent launch
+//   dw_f16_balanced_kernel every weight / bias gradient of a step in one persistent launch
 #include "gemm.h"
 #include <type_traits>
 #include "philox.h"
@@ -293,14 +293,15 @@ __global__ void dw_table_write_kernel(DwBatch part, DwPlanPart pre, DwJob* table
 }
 
 // ------------------------------------------------------------------------------------------------------
-// dw_bf16_kernel: the same job semantics, tiling (128 x 128 gradient tile per block over a chunk of rows, one 64 x 64
-// quadrant per wave) and atomics epilogue as dw_kernel, with the products on the bf16 matrix cores as three passes of
-// split operands (bf16x3.h).  The reduction index of dW = A^T.dY is the ROW index m, which is the strided direction of
-// both operands in memory: the 32-row tiles are staged row-major as bf16 (hi and lo planes, 256-byte rows, XOR swizzled)
-// and read back with ds_read_b64_tr_b16, the LDS transpose read, so each lane receives 8 consecutive rows of its column.
-// Per 32-row tile and wave: 24 MFMAs (768 cycles) instead of 64 (4096 cycles); the kernel is then bound by streaming
-// the operands from HBM (every job reads its A and dY once).
-#define DWB_PLANE (64 * 256)             // bytes of one [DWB_TM][128] bf16 plane
+// dw_f16_balanced_kernel (rounds 1-4: dw_bf16_*): tiling (128 x 128 gradient tile per unit over a run of rows, one 64 x 32 block per
+// wave) and atomics epilogue of the first fp32 kernel, with the products on the 16-bit matrix cores as three passes of split operands
+// (bf16x3.h) - since round 5 fp16 pairs (22-bit operands; the scales are described in dw_f16_segment), before that bf16 pairs.  The
+// reduction index of dW = A^T.dY is the ROW index m, which is the strided direction of both operands in memory: the 64-row tiles are
+// staged row-major as 16-bit hi and lo planes (256-byte rows, XOR swizzled) and read back with ds_read_b64_tr_b16, the LDS transpose
+// read, so each lane receives 8 consecutive rows of its column.  The kernel is bound by streaming the operands from HBM (every job
+// reads its A and dY once).
+#define DWB_PLANE (64 * 256)             // bytes of one [DWB_TM][128] 16-bit plane
+#define DWB_A_SCALE 16.0f                // fixed operand scale of the A side (activations: |a| >= 4094 ends in Inf / NaN gradients)
 // one segment: rows [m_lo, m_hi) of k-block kb of piece p of a job -> atomics into its 128 x 128 gradient tile.
 // 512 threads: wave (kq, nq) owns the 64 x 32 block of gradient rows 64kq.., columns 32nq.. (two 32x32 accumulators,
 // <= 128 registers per lane, so two workgroups share a CU).  The launch is bound by how many bytes a CU keeps in flight
@@ -316,7 +317,7 @@ __global__ void dw_table_write_kernel(DwBatch part, DwPlanPart pre, DwJob* table
 #define DWB_PROD 1
 #define DWB_DROP 2
 template <int MODE, int DEPTH>
-__device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, const int kb, const int m_lo, const int m_hi,
+__device__ __forceinline__ void dw_f16_segment(const DwJob& job, const int p, const int kb, const int m_lo, const int m_hi,
                                                 const DropCfg& drop, char* ldsb, float4 (*bred)[32]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -341,6 +342,13 @@ __device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, c
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
   float4 bsum = f4zero();
+  // Round 5: fp16 pairs (22-bit operands) instead of bf16 pairs.  A (activations) takes the fixed 2^4 of every other kernel; dY is a
+  // GRADIENT and the contraction runs over all rows of the segment, so its scale has to hold for the whole segment: a RUNNING power-of-two
+  // scale s_y - set from the first tile's largest |dY| with three binades of headroom, and whenever a later tile would exceed 2^14 the
+  // accumulators are multiplied down with it (32 multiplications per wave, rare: gradient magnitudes vary slowly along the rows).  A
+  // tile's maximum crosses the workgroup through eight LDS slots one barrier ahead of its split (the barriers were there).
+  float* mxs = reinterpret_cast<float*>(&bred[0][0]);      // [2][8] slots (bred is free until the bias reduction at the end)
+  float s_y = 0.f, s_y_inv = 0.f;                           // (wave-uniform)
 
   // staging: thread -> rows (tid>>5) + 16u, columns 4*(tid&31)..+3 of both tiles; prologues (bf16 widening, product,
   // dropout) are applied at the store, so that a load is only waited for one iteration after its issue.  Addresses are
@@ -402,10 +410,10 @@ __device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, c
         }
       }
       uint2 hi, lo;
-      bf16_split4(a, hi, lo);
+      f16_split4_s(a, DWB_A_SCALE, hi, lo);                   // (scale folded into the mixed-precision FMA: bf16x3.h)
       *reinterpret_cast<uint2*>(base + off) = hi;
       *reinterpret_cast<uint2*>(base + DWB_PLANE + off) = lo;
-      bf16_split4(st.y[u], hi, lo);
+      f16_split4_s(st.y[u], s_y, hi, lo);
       *reinterpret_cast<uint2*>(base + 2 * DWB_PLANE + off) = hi;
       *reinterpret_cast<uint2*>(base + 3 * DWB_PLANE + off) = lo;
       bsum = f4add(bsum, st.y[u]);
@@ -424,47 +432,100 @@ __device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, c
 #pragma unroll
     for (int ks = 0; ks < DWB_TM / 16; ++ks) {
       const int y0 = tr_off(nq * 32, ks, 0), y1 = tr_off(nq * 32, ks, 1);
-      const bf16x8 yh = join_tr(lds_read_tr16(base + 2 * DWB_PLANE, y0), lds_read_tr16(base + 2 * DWB_PLANE, y1));
-      const bf16x8 yl = join_tr(lds_read_tr16(base + 3 * DWB_PLANE, y0), lds_read_tr16(base + 3 * DWB_PLANE, y1));
+      const f16x8 yh = join_tr_f16(lds_read_tr16(base + 2 * DWB_PLANE, y0), lds_read_tr16(base + 2 * DWB_PLANE, y1));
+      const f16x8 yl = join_tr_f16(lds_read_tr16(base + 3 * DWB_PLANE, y0), lds_read_tr16(base + 3 * DWB_PLANE, y1));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int o0 = tr_off(kq * 64 + 32 * c, ks, 0), o1 = tr_off(kq * 64 + 32 * c, ks, 1);
-        const bf16x8 ah = join_tr(lds_read_tr16(base, o0), lds_read_tr16(base, o1));
-        const bf16x8 al = join_tr(lds_read_tr16(base + DWB_PLANE, o0), lds_read_tr16(base + DWB_PLANE, o1));
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, yh, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, yl, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, yh, acc[c], 0, 0, 0);
+        const f16x8 ah = join_tr_f16(lds_read_tr16(base, o0), lds_read_tr16(base, o1));
+        const f16x8 al = join_tr_f16(lds_read_tr16(base + DWB_PLANE, o0), lds_read_tr16(base + DWB_PLANE, o1));
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, yh, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, yl, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, yh, acc[c], 0, 0, 0);
       }
     }
   };
 
+  // largest |dY| of a staged tile: this wave's part into its slot of row `par` (published by the next workgroup barrier) ...
+  auto put_max = [&](const Stage& st, int par) {
+#ifdef DWB_EXP_FIXSCALE     // timing experiment: no maxima, a fixed dY scale (numerically wrong for small gradients)
+    return;
+#endif
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < DWB_RU; ++u) m = fmaxf(m, f4absmax(st.y[u]));
+    m = fast_max32(m);
+    m = fmaxf(m, lane_xor32_partner(m));
+    if (lane == 0) mxs[par * 8 + wave] = m;
+  };
+  // ... and the scale for the tile whose maxima sit in row `par`: the first tile sets it, a later one only lowers it
+  auto take_scale = [&](int par) {
+#ifdef DWB_EXP_FIXSCALE
+    s_y = 1024.0f; s_y_inv = 1.0f / 1024.0f;
+    return;
+#endif
+    const float4 m0 = *reinterpret_cast<const float4*>(mxs + par * 8), m1 = *reinterpret_cast<const float4*>(mxs + par * 8 + 4);
+    float g = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+    g = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g)));
+    if (s_y == 0.f || g * s_y > 16384.0f) {      // (uniform)
+      uint32_t eb = (__float_as_uint(g) >> 23) & 0xffu;
+      eb = eb < 27u ? 27u : (eb > 240u ? 240u : eb);
+      const float s_new = __uint_as_float((265u - eb) << 23);      // g s_new in [2^11, 2^12)
+      if (s_y != 0.f) {
+        const float f = s_new * s_y_inv;                             // < 1, exact
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[c][r] *= f;
+      }
+      s_y = s_new;
+      s_y_inv = __uint_as_float((eb - 11u) << 23);
+    }
+  };
   // tile i sits in LDS buffer i&1 while the registers hold tiles i+1 .. i+DEPTH-1 (the last of them just issued)
 #pragma unroll
   for (int q = 0; q < DEPTH - 1; ++q) stage_load(m_lo + q * DWB_TM, st[q]);     // rows at or beyond m_hi load nothing
-  stage_store(0, m_lo, st[0]);
+  put_max(st[0], 0);
   __syncthreads();
-  int buf = 0, mt = m_lo;
+  take_scale(0);
+  stage_store(0, m_lo, st[0]);
+#ifndef DWB_EXP_LATEMAX
+  if (DEPTH == 4) put_max(st[1], 1);
+#endif
+  __syncthreads();
+  int buf = 0, mt = m_lo, par = 1;
   // one tile: issue the loads of tile i+DEPTH-1 into `in` (the stage tile i left), multiply tile i, move tile i+1 from
-  // `out` to the other buffer
-  auto step = [&](Stage& in, const Stage& out) -> bool {
+  // `out` to the other buffer (its maxima were published one barrier ago: row `par`), leave the maxima of tile i+2 (`nxt`)
+  auto step = [&](Stage& in, const Stage& out, const Stage& nxt) -> bool {
     stage_load(mt + (DEPTH - 1) * DWB_TM, in);
     products(buf);
     if (mt + DWB_TM >= m_hi) return true;      // block-uniform
+#ifdef DWB_EXP_LATEMAX      // (measured: the maximum taken when the tile is due, on a barrier of its own: 149 us against 144 for the form below)
+    put_max(out, par);
+    __syncthreads();
+    take_scale(par);
     stage_store(buf ^ 1, mt + DWB_TM, out);
+#else
+    if (DEPTH == 2) { put_max(out, par); __syncthreads(); }      // (one register stage: the tile has only just been requested - its own barrier)
+    take_scale(par);
+    stage_store(buf ^ 1, mt + DWB_TM, out);
+    if (DEPTH == 4) put_max(nxt, par ^ 1);     // the maxima of tile i+2 ride on the barrier below: known when its split comes up
+#endif
     __syncthreads();
     mt += DWB_TM;
     buf ^= 1;
+    par ^= 1;
     return false;
   };
   static_assert(DEPTH == 2 || DEPTH == 4, "the rotations below are written out for one and three stages");
   if (DEPTH == 2) {
     for (;;)
-      if (step(st[0], st[0])) break;
+      if (step(st[0], st[0], st[0])) break;
   } else {
-    for (;;) {       // st[0] held tile i (now in LDS) and receives tile i+3; st[1] holds tile i+1
-      if (step(st[0], st[1])) break;
-      if (step(st[1], st[2])) break;
-      if (step(st[2], st[0])) break;
+    for (;;) {       // st[0] held tile i (now in LDS) and receives tile i+3; st[1] holds tile i+1, st[2] tile i+2
+      if (step(st[0], st[1], st[2])) break;
+      if (step(st[1], st[2], st[0])) break;
+      if (step(st[2], st[0], st[1])) break;
     }
   }
 
@@ -472,12 +533,13 @@ __device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, c
   // (i, h) is gradient row 32c + (r&3) + 8*(r>>2) + 4h, column i of the block.
   float* dWp = job.dW[p];
   const int kbase = k0 + kq * 64, n = nq * 32 + i;
+  const float flush_scale = s_y_inv * (1.0f / DWB_A_SCALE);
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = kbase + 32 * c + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (k < kw) atomic_add_global(dWp + (size_t)k * job.ldw + n, acc[c][r]);
+      if (k < kw) atomic_add_global(dWp + (size_t)k * job.ldw + n, acc[c][r] * flush_scale);
     }
   if (dob) {                                   // block-uniform
     bred[srow][c4] = bsum;
@@ -493,11 +555,11 @@ __device__ __forceinline__ void dw_bf16_segment(const DwJob& job, const int p, c
 }
 
 // block-uniform choice of the variant (launch_dw rejects a product prologue together with dropout / bfloat16)
-__device__ __forceinline__ void dw_bf16_any_segment(const DwJob& job, const int p, const int kb, const int m_lo, const int m_hi,
+__device__ __forceinline__ void dw_f16_any_segment(const DwJob& job, const int p, const int kb, const int m_lo, const int m_hi,
                                                     const DropCfg& drop, char* ldsb, float4 (*bred)[32]) {
-  if (job.A2[p]) dw_bf16_segment<DWB_PROD, 2>(job, p, kb, m_lo, m_hi, drop, ldsb, bred);
-  else if (job.a_bf16 || job.a_drop_site >= 0) dw_bf16_segment<DWB_DROP, 4>(job, p, kb, m_lo, m_hi, drop, ldsb, bred);
-  else dw_bf16_segment<DWB_PLAIN, 4>(job, p, kb, m_lo, m_hi, drop, ldsb, bred);
+  if (job.A2[p]) dw_f16_segment<DWB_PROD, 2>(job, p, kb, m_lo, m_hi, drop, ldsb, bred);
+  else if (job.a_bf16 || job.a_drop_site >= 0) dw_f16_segment<DWB_DROP, 4>(job, p, kb, m_lo, m_hi, drop, ldsb, bred);
+  else dw_f16_segment<DWB_PLAIN, 4>(job, p, kb, m_lo, m_hi, drop, ldsb, bred);
 }
 
 // Balanced launch: the 64-row tiles of all (job, piece, k-block) units form one list (job-major; plan.tiles[j] = tiles in
@@ -520,7 +582,7 @@ extern "C" int hual_debug_dw_stamps(unsigned long long* out, int n) {
 #endif
 #define DW_UNIT_COST 72
 __global__ __launch_bounds__(DWB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void dw_bf16_balanced_kernel(const DwJob* __restrict__ table, int n, DropCfg drop) {
+void dw_f16_balanced_kernel(const DwJob* __restrict__ table, int n, DropCfg drop) {
   extern __shared__ float lds[];
   __shared__ float4 bred[16][32];
   int* s_job = reinterpret_cast<int*>(&bred[0][0]);     // (no further static array: the planes must stay 16-byte aligned)
@@ -573,7 +635,7 @@ void dw_bf16_balanced_kernel(const DwJob* __restrict__ table, int n, DropCfg dro
       unit -= nkb;
     }
     const bool plain = !job.a_bf16 && !job.A2[p] && job.a_drop_site < 0;      // (stamps)
-    dw_bf16_any_segment(job, p, unit, tile * DWB_TM, min((tile + cnt) * DWB_TM, job.M), drop, reinterpret_cast<char*>(lds), bred);
+    dw_f16_any_segment(job, p, unit, tile * DWB_TM, min((tile + cnt) * DWB_TM, job.M), drop, reinterpret_cast<char*>(lds), bred);
     t += cnt;
     if (t >= prefix[j + 1]) ++j;
     __syncthreads();                            // LDS planes and bred are reused by the next segment
@@ -715,8 +777,8 @@ int launch_dw(const DwJob* jobs, int n, const DropCfg& drop, hipStream_t stream,
   HUAL_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   int nblocks = blocks > 0 ? blocks : cus;
   if (nblocks > tiles) nblocks = tiles;
-  HUAL_DYN_LDS(dw_bf16_balanced_kernel, 144 * 1024);
-  HUAL_LAUNCH(flops, bytes, dw_bf16_balanced_kernel, dim3(nblocks), dim3(DWB_THREADS), (size_t)8 * DWB_PLANE, stream, (const DwJob*)table, n, drop);
+  HUAL_DYN_LDS(dw_f16_balanced_kernel, 144 * 1024);
+  HUAL_LAUNCH(flops, bytes, dw_f16_balanced_kernel, dim3(nblocks), dim3(DWB_THREADS), (size_t)8 * DWB_PLANE, stream, (const DwJob*)table, n, drop);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

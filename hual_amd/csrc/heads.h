@@ -50,6 +50,13 @@ struct MatchArgs {
 int match_fwd_blocks(int Nv);
 struct AlignSim;
 int launch_match_fwd(const MatchArgs& a, const RowSpace& rs, const AlignSim* as, hipStream_t s);
+struct LossTailArgs {
+  float* loss_acc; const float* match_part; int match_nblk; const float* loc_part; int loc_nblk;
+  float lambda, override_denom; const float* denom_dev; float* loss_out;
+  const uint32_t* ovf; int novf;      // optional: the pack launch's overflow words (gemm.h PackExtra): any set -> the losses are NaN
+  const float* align_rows; int nalign;      // optional: the alignment loss' row terms (AlignSim::row_loss), summed here in row order into
+                                            // loss_acc[LA_ALIGN]; null: loss_acc[LA_ALIGN] was written by the caller (data parallel)
+};
 struct MatchBwd {
   const float* dOut;      // [Nv,128] gradient wrt outputs
   const float* dOut2;     // optional second part of it (added on the fly: the predictor's heads and encoders both read `outputs`)
@@ -58,6 +65,9 @@ struct MatchBwd {
   const float* dE_ortho;  // optional [4,128]: gradient of the orthogonality term left by the step's prologue (ortho.h), added to dE
   float* part;            // [match_bwd_blocks(Nv)][9][128] per-workgroup sums (dE rows, dWm flat, dbm): folded by launch_colsum
   float lambda;           // loss.match_lambda
+  // deferred loss tail (hual_run_opts.deferred_loss_terms): every workgroup forms the matching-loss denominator itself from the forward's
+  // partial sums (loss_acc[LA_DENOM] has not been written), workgroup 0 also closes the loss as loss_tail_kernel would have
+  int do_tail; LossTailArgs tail;
 };
 int match_bwd_blocks(int Nv);
 int launch_match_bwd(const MatchArgs& a, const MatchBwd& g, const RowSpace& rs, hipStream_t s);
@@ -80,13 +90,6 @@ struct HeadsArgs {
 };
 int launch_heads(const HeadsArgs& a, int B, int T, hipStream_t s);
 // matching-loss denominator (layers.py:173) + the four reported loss terms (model.py:120) from the partial sums
-struct LossTailArgs {
-  float* loss_acc; const float* match_part; int match_nblk; const float* loc_part; int loc_nblk;
-  float lambda, override_denom; const float* denom_dev; float* loss_out;
-  const uint32_t* ovf; int novf;      // optional: the pack launch's overflow words (gemm.h PackExtra): any set -> the losses are NaN
-  const float* align_rows; int nalign;      // optional: the alignment loss' row terms (AlignSim::row_loss), summed here in row order into
-                                            // loss_acc[LA_ALIGN]; null: loss_acc[LA_ALIGN] was written by the caller (data parallel)
-};
 int launch_loss_tail(const LossTailArgs& a, hipStream_t s);
 
 // ---- alignment loss (layers.py:205-248)

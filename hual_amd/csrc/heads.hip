@@ -161,6 +161,7 @@ __device__ __forceinline__ void match_fwd_body(const MatchArgs& a, const RowSpac
   }
 }
 
+__device__ __forceinline__ float loss_tail_body(const LossTailArgs& a, float* sm, bool write);      // (defined with loss_tail_kernel below)
 __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g, RowSpace rs) {
   __shared__ float4 red[8][8][32];    // [vec][grp][lane]: 4 dE rows + 4 dWm columns(as float4 over cols)
   __shared__ float redb[8][4];
@@ -168,7 +169,14 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
   const int col = 4 * l32;
   float4 w0 = ld4(a.Wm + (col + 0) * 4), w1 = ld4(a.Wm + (col + 1) * 4), w2 = ld4(a.Wm + (col + 2) * 4), w3 = ld4(a.Wm + (col + 3) * 4);
   float4 e0 = ld4(a.E + col), e1 = ld4(a.E + HUAL_D + col), e2 = ld4(a.E + 2 * HUAL_D + col), e3 = ld4(a.E + 3 * HUAL_D + col);
-  const float ce_scale = a.labels ? g.lambda / a.loss_acc[LA_DENOM] : 0.f;
+  float denom = 1.0f;
+  if (g.do_tail) {      // (uniform) the forward left the loss open: the denominator from its partial sums; workgroup 0 closes the loss
+    __shared__ float smt[12];
+    denom = loss_tail_body(g.tail, smt, blockIdx.x == 0);
+  } else if (a.labels) {
+    denom = a.loss_acc[LA_DENOM];
+  }
+  const float ce_scale = a.labels ? g.lambda / denom : 0.f;
   float4 dE0 = f4zero(), dE1 = f4zero(), dE2 = f4zero(), dE3 = f4zero();
   float4 dW0 = f4zero(), dW1 = f4zero(), dW2 = f4zero(), dW3 = f4zero();   // dWk = column k of dWm over this lane's 4 rows
   float db0 = 0.f, db1 = 0.f, db2 = 0.f, db3 = 0.f;
@@ -459,20 +467,24 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a, int T, int B) {
 // fixed order, sets the matching-loss denominator and writes the four reported terms.  A launch of its own: taking a
 // "last workgroup" ticket inside heads_kernel needs a device-scope release fence in every workgroup, which on this part
 // writes back the L2 (measured: 19 k cycles per workgroup).
-__global__ __launch_bounds__(256) void loss_tail_kernel(LossTailArgs a) {
-  __shared__ float sm[12];
+// (a device function: the launch of its own when the forward closes the loss, the head of match_bwd_kernel's workgroup 0 when the
+//  close is deferred to the backward pass - hual_run_opts.deferred_loss_terms.  Returns the denominator.)
+__device__ __forceinline__ float loss_tail_body(const LossTailArgs& a, float* sm, bool write) {
   const int tid = threadIdx.x;
   float cs = 0.f, ms = 0.f, ls = 0.f;
   for (int i = tid; i < a.match_nblk; i += 256) { cs += a.match_part[2 * i]; ms += a.match_part[2 * i + 1]; }
-  for (int i = tid; i < a.loc_nblk; i += 256) ls += a.loc_part[i];
+  if (write)
+    for (int i = tid; i < a.loc_nblk; i += 256) ls += a.loc_part[i];
   int bad = 0;
-  for (int i = tid; i < a.novf; i += 256) bad |= a.ovf[i] != 0u;
-  bad = __syncthreads_or(bad);
+  if (write) {
+    for (int i = tid; i < a.novf; i += 256) bad |= a.ovf[i] != 0u;
+    bad = __syncthreads_or(bad);
+  }
   block_sum3(cs, ms, ls, sm);
-  if (tid == 0) {
+  const float denom = a.denom_dev ? *a.denom_dev : (a.override_denom > 0.f ? a.override_denom : ms + 1e-12f);
+  if (write && tid == 0) {
     float* la = a.loss_acc;
     la[LA_MATCH_SUM] = cs; la[LA_MASK_SUM] = ms; la[LA_LOC] = ls;
-    const float denom = a.denom_dev ? *a.denom_dev : (a.override_denom > 0.f ? a.override_denom : ms + 1e-12f);
     la[LA_DENOM] = denom;
     if (a.align_rows) {
       float l = 0.f;
@@ -490,6 +502,11 @@ __global__ __launch_bounds__(256) void loss_tail_kernel(LossTailArgs a) {
       a.loss_out[3] = align + poison;
     }
   }
+  return denom;
+}
+__global__ __launch_bounds__(256) void loss_tail_kernel(LossTailArgs a) {
+  __shared__ float sm[12];
+  loss_tail_body(a, sm, true);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -94,7 +94,7 @@ int hual_prof_kernel_pipe(const char* kernel, int* pipe, int* passes) {
       // fp16 / bf16 hi + lo splits: hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_{f16,bf16} / 32x32x16_bf16
       {"conv_block_", HUAL_PIPE_MATRIX16, 3}, {"ln_proj", HUAL_PIPE_MATRIX16, 3}, {"da_post", HUAL_PIPE_MATRIX16, 3},
       {"da_mid_bwd", HUAL_PIPE_MATRIX16, 3},  {"mproj_", HUAL_PIPE_MATRIX16, 3},
-      {"feature_", HUAL_PIPE_MATRIX16, 3},    {"dw_bf16_", HUAL_PIPE_MATRIX16, 3},
+      {"feature_", HUAL_PIPE_MATRIX16, 3},    {"dw_f16_", HUAL_PIPE_MATRIX16, 3},
       {"attn_", HUAL_PIPE_MATRIX16, 3},      {"cq_fwd_staged", HUAL_PIPE_MATRIX16, 3}, {"cq_bwd_staged", HUAL_PIPE_MATRIX16, 3},
       // exact fp32: v_mfma_f32_16x16x4_f32 (context-query attention of clips beyond the staged kernels' LDS budget)
       {"cq_", HUAL_PIPE_MATRIX32, 1},

@@ -706,7 +706,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     ha.loc_part = loc_part; ha.inv_batch = 1.0f / (float)B;
     if (!lab && c.novf) { ha.ovf = ovf; ha.novf = c.novf; }
     c.chk(launch_heads(ha, B, T, c.stream));
-    if (lab && c.ok()) {
+    if (lab && c.ok() && !opt->deferred_loss_terms) {      // (deferred: match_bwd_kernel closes the loss, backward_graph)
       LossTailArgs lt{loss_acc, match_part, match_fwd_blocks(Nv), loc_part, B, c.cfg->match_lambda, opt->match_denom_override,
                       opt->match_denom_dev, out->loss_terms, ovf, c.novf, opt->align_external ? nullptr : align_rows, B};
       c.chk(launch_loss_tail(lt, c.stream));
@@ -883,6 +883,13 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     mb.lambda = c.cfg->match_lambda;
     mb.dE_ortho = c.buf("ortho.dE", 4, D);
     mb.part = match_part_b;
+    if (opt->deferred_loss_terms && c.sel_stage < 0) {      // the forward left the loss open (hual_run_opts.deferred_loss_terms)
+      uint32_t* ovf = reinterpret_cast<uint32_t*>(c.buf("params.ovf", 1, 1));
+      mb.do_tail = 1;
+      mb.tail = LossTailArgs{loss_acc, c.buf("match.part", 1, 1), match_fwd_blocks(Nv), c.buf("loc.part", 1, 1), B, c.cfg->match_lambda,
+                             opt->match_denom_override, opt->match_denom_dev, opt->deferred_loss_terms, ovf, c.novf,
+                             opt->align_external ? nullptr : c.buf("align.rowloss", 1, 1), B};
+    }
     c.chk(launch_match_bwd(ma, mb, c.rs, c.stream));
   } else {
     c.buf("ortho.dE", 4, D);

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HUAL_LIB_PATH: an experiment build of the library (scripts/exp/tl_variant.sh) - the in-tree file is never overwritten
 LIB_PATH = os.environ.get('HUAL_LIB_PATH') or os.path.join(_HERE, 'libhual_seqpan.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -48,7 +48,7 @@ class hual_run_opts(ctypes.Structure):
     _fields_ = [('drop_rate', ctypes.c_float), ('rng_state', ctypes.c_void_p), ('match_denom_override', ctypes.c_float),
                 ('align_external', ctypes.c_int32), ('static_tables', ctypes.c_int32),
                 ('match_denom_dev', ctypes.c_void_p), ('debug_taps', ctypes.c_int32), ('grads_prezero', ctypes.c_void_p),
-                ('prezero_token', ctypes.c_void_p)]
+                ('prezero_token', ctypes.c_void_p), ('deferred_loss_terms', ctypes.c_void_p)]
 
 
 class hual_al_set(ctypes.Structure):

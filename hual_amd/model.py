@@ -190,7 +190,7 @@ class SeqPAN:
 
     def _opts(self, drop_rate, match_denom=0.0, align_external=0):
         return lib.hual_run_opts(float(drop_rate), lib.ptr(self.rng_state).value, float(match_denom), int(align_external), 0, None,
-                                 1 if self.debug_taps else 0, None)
+                                 1 if self.debug_taps else 0, None, None, None)
 
     # ------------------------------------------------------------------ fetches
     def forward(self, video_inputs, video_seq_len, word_ids, char_ids, drop_rate=0.0, labels=None, _opts=None):

@@ -36,6 +36,7 @@ class Trainer:
         self._entry = None
         self._out_cap = None
         self._dp_B = None
+        self._cap_stream = None
         self.stats = dict(eager=0, captured=0, replayed=0)
 
     # ------------------------------------------------------------------ static batch buffers
@@ -183,7 +184,9 @@ class Trainer:
         self._ensure_outputs(B, T)
 
     # ------------------------------------------------------------------ one step
-    def _opts(self, drop_rate, align_external):
+    def _opts(self, drop_rate, align_external, defer_loss=True):
+        """defer_loss: the forward leaves the closing of the loss to the backward's matching-head launch (one launch fewer per step,
+        hual_run_opts.deferred_loss_terms) - for a forward that IS followed by its backward; False for a forward on its own"""
         # static_tables: all buffers of this trainer are static per shape, so after one backward on them the job tables
         # in the workspace stay valid (hual_run_opts.static_tables)
         return lib.hual_run_opts(float(drop_rate), lib.ptr(self.m.rng_state).value, float(self.match_denom),
@@ -192,7 +195,8 @@ class Trainer:
                                  lib.ptr(self.denom_dev).value if self.dp else None, 0,
                                  # the forward's first launch zeroes the gradient bucket (one launch fewer in backward); the
                                  # host word is the receipt the backward call checks and clears (hual_run_opts.prezero_token)
-                                 lib.ptr(self.m.grads).value, ctypes.addressof(self._prezero_token))
+                                 lib.ptr(self.m.grads).value, ctypes.addressof(self._prezero_token),
+                                 lib.ptr(self.loss_terms).value if defer_loss else None)
 
     def _forward(self, opts):
         m = self.m
@@ -282,9 +286,21 @@ class Trainer:
             e['seen'] += 1
             self.stats['eager'] += 1
             return
+        # capture on a side stream by hand (records, executes nothing: the replay below IS the step).  Not `with torch.cuda.graph(g)`:
+        # that context synchronises the device and runs the garbage collector on entry - tens of milliseconds per shape, which is
+        # what the first epoch of a training set with a handful of padded shapes then spends most of its time on
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):                                # records, executes nothing: the replay below IS the step
-            self._enqueue_single(drop_rate)
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream(device=self.m.device)
+        cs, cur = self._cap_stream, torch.cuda.current_stream()
+        cs.wait_stream(cur)
+        with torch.cuda.stream(cs):
+            g.capture_begin()
+            try:
+                self._enqueue_single(drop_rate)
+            finally:
+                g.capture_end()
+        cur.wait_stream(cs)
         e['graph'], e['drop'] = g, drop_rate
         g.replay()
         self.stats['captured'] += 1

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HUAL_ABI_VERSION 6
+#define HUAL_ABI_VERSION 7
 
 #define HUAL_OK 0
 #define HUAL_ERR_INVALID (-1)
@@ -146,6 +146,11 @@ typedef struct hual_run_opts {
                                         zeroing launch only if the word holds the address of its `grads`, and clears it.  Any
                                         sequence that breaks the pairing (two backward calls, a forward that failed or had no
                                         labels) therefore zeroes the bucket in backward as before.  NULL: no pre-zeroing. */
+  float* deferred_loss_terms;     /* non-NULL (ABI 7), a TRAIN step whose backward call follows on the same stream: the forward leaves the
+                                        closing of the loss (matching-loss denominator, the four reported terms) to the backward pass,
+                                        which writes float[4] = {total, loc, match, align} HERE from inside its matching-head launch -
+                                        one launch fewer per step.  hual_outputs.loss_terms is then not written by the forward.
+                                        Pass the same options to both calls.  NULL: the forward closes the loss itself (a launch). */
 } hual_run_opts;
 
 /* bytes of workspace needed for one forward(+backward) of this shape */

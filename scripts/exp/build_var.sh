@@ -5,7 +5,7 @@ out=$1; shift
 R=$(cd "$(dirname "$0")/../.." && pwd)
 tmp=$(mktemp -d /tmp/hual_var.XXXXXX)
 mkdir -p $tmp/obj $(dirname $R/$out)
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form -I$R/include"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form -I$R/include $EXTRA_FLAGS"
 for d in "$@"; do FLAGS="$FLAGS -D$d"; done
 pids=()
 for f in $R/hual_amd/csrc/*.hip $R/hual_amd/csrc/*.cpp; do

@@ -90,7 +90,7 @@ def test_first_step_of_a_shape_is_bit_identical_whatever_ran_before():
     m0 = SeqPAN(cfg, wv)
     t0 = Trainer(m0, world=1, use_graph=False)
     t0.set_batch_device(ds.assemble(sel_a, out=None, min_chars=4))
-    opts = t0._opts(0.2, 0)
+    opts = t0._opts(0.2, 0, defer_loss=False)                     # a forward on its own: it closes the loss itself
     t0._forward(opts)
     want = (t0.loss_terms.cpu().numpy().copy(), t0.start_logits.cpu().numpy().copy())
     # loop model: lr 0 steps keep the parameters (AdamWD with lr 0 leaves p untouched), the Philox offset is reset for the comparison
