@@ -258,7 +258,9 @@ int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, con
 /* gradients of the dense above: dW[K,N] += A^T . dY ; db[N] += colsum(dY) (db may be NULL), through the persistent
  * weight-gradient launch of the training step: the 64-row tiles of the job dealt evenly to `workgroups` workgroups
  * (0 = one per CU), the job table living in `scratch` (device, >= 512 bytes).  N must be 128 (every dense layer of the
- * graph has 128 outputs).  Accumulates with float atomics: zero the destinations first. */
+ * graph has 128 outputs).  Accumulates with float atomics: zero the destinations first.
+ * Arithmetic (ABI 7): fp16-pair operands - A scaled by 2^4 (|a| >= 4094 does not fit: Inf / NaN gradients, loudly), dY by a running
+ * power-of-two scale taken from the data (any gradient magnitude); 2-5e-7 of the largest entry against a float64 product. */
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
                    int N, int workgroups, void* scratch, uint64_t scratch_bytes, void* stream);
 
@@ -270,7 +272,9 @@ int hual_layer_norm_fwd(const float* x, const float* gamma, const float* beta, f
 /* multi-head attention core of dual_multihead_attention / top_self_attention (models/layers.py:80-96, modules.py:104-119):
  * 8 heads of size 16 kept merged in [rows,128]; scores / sqrt(16) + (1 - qmask x kmask) * (-1e30), softmax, P.V.
  * Q rows b*Tq + t, K/V rows b*Tk + t; masks are [B*Tq] / [B*Tk] floats (0/1).  Tq <= 256 and Tk <= 256
- * (longer queries: HUAL_ERR_INVALID - a launch's unit codes hold 16 query tiles per job). */
+ * (longer queries: HUAL_ERR_INVALID - a launch's unit codes hold 16 query tiles per job).
+ * Arithmetic (ABI 7): fp16-pair operands, Q / K / V scaled by 2^4 (|x| >= 4094 does not fit: Inf / NaN outputs, loudly); outputs within
+ * 1e-6 of a float64 evaluation on O(1) inputs - the level of a float32 evaluation. */
 int hual_attention_fwd(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo, int B, int Tq,
                        int Tk, const float* qmask, const float* kmask, void* stream);
 
