@@ -523,6 +523,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
   cq_barrier();
   CQ_STAMP(2);
   cq_rows_store<1>(xrows, bufA, N1q, bufB, N2q);      // X1, X2
+  CQ_STAMP(8);
   // ---- row softmax over j with mask2 (layers.py:122-123); zero outside the valid block (the images are read up to N1q x N2q).
   // Rows of at most 32 columns go two per wave (a 32-lane half each)
   if (N2q <= 32) {
@@ -566,6 +567,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       }
     }
   }
+  CQ_STAMP(9);
   // ---- column softmax over i with mask1 (layers.py:124-125); columns of at most 32 rows go two per wave
   if (N1q <= 32) {
     const int hh = lane >> 5, l32 = lane & 31;
@@ -608,6 +610,7 @@ __device__ __forceinline__ void cq_fwd_staged_body(const CqBufs& b, const CqPara
       }
     }
   }
+  CQ_STAMP(10);
   cq_barrier();
   CQ_STAMP(3);
   // ---- save both softmaxes for the backward pass: the images as they stand (both planes)

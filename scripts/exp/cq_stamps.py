@@ -31,6 +31,7 @@ for d, nm in ((0, 'dir 0 (x1 = video)'), (1, 'dir 1 (x1 = query)')):
     for k, n_ in enumerate(names_f):
         print('   fwd %-20s mean %7.0f  max %7.0f' % (n_, df[:, k].mean(), df[:, k].max()))
     print('   fwd total %.0f' % (blk[:, 7] - blk[:, 0]).mean())
+    print('   fwd softmax phase of wave 0: X image stores %.0f, row softmax %.0f, column softmax %.0f, barrier %.0f' % ((blk[:, 8] - blk[:, 2]).mean(), (blk[:, 9] - blk[:, 8]).mean(), (blk[:, 10] - blk[:, 9]).mean(), (blk[:, 3] - blk[:, 10]).mean()))
     db = np.diff(blk[:, 16:24], axis=1)
     for k, n_ in enumerate(names_b[:7]):
         print('   bwd %-20s mean %7.0f  max %7.0f' % (n_, db[:, k].mean(), db[:, k].max()))
