@@ -390,7 +390,10 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a, int T, int B) {
       if (lane == 0) wtot[1][w] = suf;
       ps[tid] = pre; pe[tid] = suf;
     }
-    __syncthreads();
+    // (a barrier that was there, now carrying a flag) NaN logits - an activation beyond the fp16 operand range, |x| >= 4094, turns into
+    // Inf - Inf in a product and spreads: the spans of such a clip are not an argmax of anything and come back as -1, like the spans
+    // of a step whose weights did not fit (poison)
+    const int nanlogit = __syncthreads_or(in && (zs_[t] != zs_[t] || ze_[t] != ze_[t]));
     float vs = -1.f, ve = -1.f;
     if (in) {
       const int w = t >> 6;
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a, int T, int B) {
       v = bestv[1][0]; i = besti[1][0];
       for (int w = 1; w < 4; ++w) if (bestv[1][w] > v || (bestv[1][w] == v && besti[1][w] < i)) { v = bestv[1][w]; i = besti[1][w]; }
       a.end_index[b] = i;
-      if (poison != poison) { a.start_index[b] = -1; a.end_index[b] = -1; }
+      if (poison != poison || nanlogit) { a.start_index[b] = -1; a.end_index[b] = -1; }
     }
   } else {
     __syncthreads();

@@ -95,3 +95,21 @@ def test_weight_outside_the_fp16_image_range_poisons_the_loss():
     free_bad = m2.forward(*feeds, drop_rate=0.0)
     assert np.isnan(free_bad['start_logits'].cpu().numpy()).all() and np.isnan(free_bad['end_logits'].cpu().numpy()).all()
     assert (free_bad['start_index'].cpu().numpy() == -1).all() and (free_bad['end_index'].cpu().numpy() == -1).all()
+
+
+def test_activation_outside_the_fp16_operand_range_is_loud():
+    """activations travel to the matrix cores as fp16 pairs of 2^4 x value (attention Q / K / V, the fused chains' operands, the
+    weight-gradient launch's A side): |x| >= 4094 does not fit.  Unlike an oversized WEIGHT (flagged by the pack launch) nothing checks
+    activations up front - the products turn Inf - Inf = NaN and the NaN has to arrive where the caller looks: NaN losses with labels,
+    NaN logits and span indices -1 without (never a plausible-looking span)."""
+    import collections
+    cfg, p, wv, b, labels = pu.make_case(B=2, T=16, L=6, C=5, seed=3)
+    feeds = (b['video'], b['lens'], b['word_ids'], b['char_ids'])
+    p2 = collections.OrderedDict((k, v.clone()) for k, v in p.items())
+    p2['d_attn_0/dual_multihead_attention/query/bias'].view(-1)[3] = 5000.0      # a bias is not range checked: Q[:, 3] = 5000 + ...
+    m2 = pu.hip_model(cfg, p2, wv)
+    bad = m2.forward(*feeds, drop_rate=0.0, labels=labels)
+    assert np.isnan(float(bad['loss']))
+    free = m2.forward(*feeds, drop_rate=0.0)
+    assert np.isnan(free['start_logits'].cpu().numpy()).any()
+    assert (free['start_index'].cpu().numpy() == -1).all() and (free['end_index'].cpu().numpy() == -1).all()
