@@ -49,6 +49,10 @@ int tri_bwd_blocks_v(const RowSpace& rs);
 int tri_bwd_blocks_q(const RowSpace& rs);
 int launch_tri_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const CqParams& p, float* part, const RowSpace& rs,
                         const DropCfg& drop, const float* dXa, const float* dXb, hipStream_t s);
+// long clips (cqwide.hip): 128 < T <= 256, L <= 32
+bool cq_wide_ok(const RowSpace& rs);
+int launch_cq_fwd_wide(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
+int launch_cq_bwd_wide(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, float* dXa, float* dXb, hipStream_t s);
 size_t cq_mat_elems_host(int T, int L);   // floats per saved softmax matrix (per clip, per direction)
 size_t cq_m2_rows_host(int T, int L);     // rows of the per-clip M2 scratch
 

@@ -1,0 +1,169 @@
+// Device helpers shared by the context-query kernels (cq.hip: staged kernels for clips of up to 128 frames; cqwide.hip: long clips):
+// per-clip geometry, split-operand images in LDS and the three-pass 16-bit MFMA product on them.
+#pragma once
+#include "cq.h"
+#include "bf16x3.h"
+#include "tilecore.h"
+
+using namespace hual;
+
+// per-clip kernels: one block = one (clip, direction); 16 waves share the tiles / rows of every phase
+#define CQ_MAX_THREADS 1024
+#define CQ_THREADS ((int)blockDim.x)
+#define CQ_WAVES ((int)blockDim.x >> 6)
+struct ClipGeom {
+  int N1, N2, N1p, N2p, ld, x1base, x2base;
+};
+__device__ __forceinline__ ClipGeom clip_geom(const RowSpace& rs, int clip, int dir) {
+  ClipGeom c;
+  if (dir == 0) { c.N1 = rs.T; c.N2 = rs.L; c.x1base = clip * rs.T; c.x2base = rs.Nv + clip * rs.L; }
+  else { c.N1 = rs.L; c.N2 = rs.T; c.x1base = rs.Nv + clip * rs.L; c.x2base = clip * rs.T; }
+  c.N1p = (c.N1 + 15) & ~15;
+  c.N2p = (c.N2 + 15) & ~15;
+  c.ld = c.N2p + 4;
+  return c;
+}
+__host__ __device__ inline size_t cq_mat_elems(int T, int L) {   // max over both directions of N1p*(N2p+4); room for the staged kernels' image too
+  int Tp = (T + 15) & ~15, Lp = (L + 15) & ~15;
+  size_t a = (size_t)Tp * (Lp + 4), b = (size_t)Lp * (Tp + 4);
+  const int Tq = (T + 31) & ~31, Lq = (L + 31) & ~31;
+  // [short side][128] hi + lo planes = 512 bytes per row, one such block per 128 entries of the long side (cqwide.hip: two blocks)
+  const size_t im = (size_t)(Tq < Lq ? Tq : Lq) * 128 * (size_t)(((Tq > Lq ? Tq : Lq) + 127) >> 7);
+  a = a > b ? a : b;
+  return a > im ? a : im;
+}
+__host__ __device__ inline size_t cq_m2_rows(int T, int L) {
+  int Tp = (T + 15) & ~15, Lp = (L + 15) & ~15;
+  return Tp > Lp ? Tp : Lp;
+}
+
+// Staged kernels (clips whose operands fit LDS: every shape of the YAML configs; longer clips run cq_fwd_kernel / cq_bwd_kernel
+// above on operands in global memory).  Round 4: every product on the 16-bit matrix pipe with split fp32 operands (bf16 hi + lo,
+// hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16: 3/16 of the fp32-MFMA time the round 1-3 kernels were bound by, and operand
+// fragments by ONE wide LDS read instead of four scalar ones for the row-strided operands).
+//
+// Operand IMAGES in LDS: [rows][128] bf16 high parts + [rows][128] bf16 residuals (a plane = rows x 256 B), 256-byte rows with the XOR
+// swizzle of tile256_off (bf16x3.h) that keeps both kinds of fragment read conflict free:
+//   * direct     - element (x, k) at image[row x][col k]: the operand's non-contraction index is the image row (one ds_read_b128);
+//   * transposed - element (x, k) at image[row k][col x]: the contraction runs over the image rows (ds_read_b64_tr_b16).
+// An element is split ONCE, when it is written into an image; every product reads fragments of both planes.
+//   bufA (x1 rows), bufB (x2 rows): row images of the [rows,128] operands of the current phase (rows padded to 32 with zeros);
+//   SrI, ScI (dscore in the backward): the softmax matrices, stored with the LONGER of (N1, N2) along the 128 columns and the
+//   shorter one along the rows (template LONG1: N1 is the column index) - also the layout in which they are saved for the backward.
+// workgroup barrier that waits for the wave's LDS operations only: __syncthreads() also drains every outstanding global STORE of the
+// wave (s_waitcnt vmcnt(0)) - a store round trip in front of every phase; the staged kernels never read back their own global stores
+__device__ __forceinline__ void cq_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// Element format of an image: FMT 0 - bf16 hi + lo (16 significant bits whatever the magnitude: the backward's gradient operands);
+// FMT 1 - fp16 hi + lo of x * scale with a FIXED power-of-two scale (22 significant bits down to |x| scale >= 2^-3, an absolute floor of
+// 2^-25 / scale below: the forward's activations (scale 2^4: |x| < 4096 or the product turns Inf / NaN, loudly) and softmax
+// probabilities (scale 2^10)).  Round 4 first ran the forward on bf16 pairs too: the step-0 loss of the c1 trajectory test moved from
+// 1e-7 to 1.2e-6 of the float64 oracle's and the free-running trajectories separated ten times sooner.
+struct CqImg { char* p; int plane; float scale, inv; };
+__device__ __forceinline__ CqImg cq_img(char* p, int rows, float scale = 1.0f) {
+  CqImg im; im.p = p; im.plane = rows * 256; im.scale = scale; im.inv = 1.0f / scale;      // (compile-time powers of two)
+  return im;
+}
+#define CQ_SCALE_ACT 16.0f
+#define CQ_SCALE_PROB 1024.0f
+// FMT 1 image of a GRADIENT tensor (round 5: the backward's operands carry 22 bits too): its magnitude is not known in advance, so the
+// power-of-two scale is taken from the largest |element| of the whole image - a workgroup reduction - and brings it into [2^13, 2^14);
+// one scale per image, because every image of the backward is read along its rows in one product and along its columns in another
+// (a per-row scale would not be constant along the second contraction).  amax = 0 / denormal: 2^113, still finite.
+__device__ __forceinline__ void cq_img_autoscale(CqImg& im, float amax) {
+  uint32_t eb = (__float_as_uint(amax) >> 23) & 0xffu;
+  eb = eb < 27u ? 27u : (eb > 240u ? 240u : eb);
+  im.scale = __uint_as_float((267u - eb) << 23);
+  im.inv = __uint_as_float((eb - 13u) << 23);
+}
+// largest value over the workgroup: every wave leaves its maximum in its slot; the caller's next barrier publishes the slots
+// (cq_wgmax_get).  Slots are plain stores - no zeroing pass, no atomics; a slot row is reused only after a later barrier.
+__device__ __forceinline__ void cq_wgmax_put(float* slots, float v) {
+  v = wave_max64(v);
+  if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = v;
+}
+__device__ __forceinline__ float cq_wgmax_get(const float* slots) {
+  float m = 0.f;
+  for (int w = 0; w < CQ_WAVES; w += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(slots + w);
+    m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  return m;
+}
+template <int FMT>
+__device__ __forceinline__ void cq_split4(const CqImg& im, const float4& v, uint2& h, uint2& l) {
+  if (FMT == 1) f16_split4(f4scale1(v, im.scale), h, l);
+  else bf16_split4(v, h, l);
+}
+template <int FMT>
+__device__ __forceinline__ void cq_img_store4(const CqImg& im, int row, int col, const float4& v) {      // cols col .. col + 3, col % 4 == 0
+  uint2 h, l;
+  cq_split4<FMT>(im, v, h, l);
+  const int off = tile256_off(row, col >> 3) + 2 * (col & 7);
+  *reinterpret_cast<uint2*>(im.p + off) = h;
+  *reinterpret_cast<uint2*>(im.p + im.plane + off) = l;
+}
+template <int FMT>
+__device__ __forceinline__ void cq_img_store1(const CqImg& im, int row, int col, float v) {
+  uint32_t h, l;
+  if (FMT == 1) f16_split_pair(v * im.scale, 0.f, h, l);
+  else bf16_split_pair(v, 0.f, h, l);
+  const int off = tile256_off(row, col >> 3) + 2 * (col & 7);
+  *reinterpret_cast<uint16_t*>(im.p + off) = (uint16_t)h;
+  *reinterpret_cast<uint16_t*>(im.p + im.plane + off) = (uint16_t)l;
+}
+template <int FMT>
+__device__ __forceinline__ float cq_img_load1(const CqImg& im, int row, int col) {      // hi + lo: the value to 2^-17 (bf16) / 2^-23 (fp16 pair)
+  const int off = tile256_off(row, col >> 3) + 2 * (col & 7);
+  if (FMT == 1) {
+    const _Float16 h = *reinterpret_cast<const _Float16*>(im.p + off), l = *reinterpret_cast<const _Float16*>(im.p + im.plane + off);
+    return ((float)h + (float)l) * im.inv;
+  }
+  const uint32_t h = *reinterpret_cast<const uint16_t*>(im.p + off), l = *reinterpret_cast<const uint16_t*>(im.p + im.plane + off);
+  return __uint_as_float(h << 16) + __uint_as_float(l << 16);
+}
+// fragment of the 16 x 32 operand block (non-contraction indices x0 .. x0 + 15, contraction indices k0 .. k0 + 31): lane (j, g) holds
+// element (x0 + j, k0 + 8 g + e), e = 0..7 - the A and the B map of v_mfma_f32_16x16x32_{bf16,f16} alike (the bytes are format blind)
+template <bool TR>
+__device__ __forceinline__ void cq_frag(const CqImg& im, int x0, int k0, int lane, uint4& hi, uint4& lo) {
+  if (!TR) {
+    const int off = tile256_off(x0 + (lane & 15), (k0 >> 3) + (lane >> 4));
+    hi = *reinterpret_cast<const uint4*>(im.p + off);
+    lo = *reinterpret_cast<const uint4*>(im.p + im.plane + off);
+  } else {      // lane 4 q + p of a 16-lane group supplies row q, columns 4 p .. 4 p + 3 of the group's 4 x 16 block (EXEC all ones)
+    const int q = (lane & 15) >> 2, pp = lane & 3, r = k0 + 8 * (lane >> 4) + q, ch = (x0 >> 3) + (pp >> 1);
+    const int o1 = tile256_off(r, ch) + 8 * (pp & 1), o2 = tile256_off(r + 4, ch) + 8 * (pp & 1);
+    hi = __builtin_bit_cast(uint4, join_tr(lds_read_tr16(im.p, o1), lds_read_tr16(im.p, o2)));
+    lo = __builtin_bit_cast(uint4, join_tr(lds_read_tr16(im.p + im.plane, o1), lds_read_tr16(im.p + im.plane, o2)));
+  }
+}
+// C tile [m0, m0 + 16) x [n0, n0 + 16) += sum over k < K (K % 32 == 0) of A(m, k) B(k, n); lane (j, g) register r = C[m0 + 4 g + r][n0 + j]
+// (FMT 1: the scales of the two images are divided out of the sum before it joins `acc`)
+template <bool AT, bool BT, int FMT>
+__device__ __forceinline__ f32x4 cq_mma(const CqImg& A, int m0, const CqImg& B, int n0, int K, int lane, f32x4 acc) {
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    uint4 ah, al, bh, bl;
+    cq_frag<AT>(A, m0, k0, lane, ah, al);
+    cq_frag<BT>(B, n0, k0, lane, bh, bl);
+    if (FMT == 1) {
+      t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), t, 0, 0, 0);
+    } else {
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), t, 0, 0, 0);
+    }
+  }
+  const float inv = FMT == 1 ? A.inv * B.inv : 1.0f;      // (exact: powers of two)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = FMT == 1 ? fmaf(t[r], inv, acc[r]) : acc[r] + t[r];
+  return acc;
+}
+// score-matrix images: element (i, j) at [row j][col i] when LONG1 (N1 is the longer side), else [row i][col j]
+template <bool LONG1, int FMT> __device__ __forceinline__ void cq_sc_store(const CqImg& im, int i, int j, float v) { cq_img_store1<FMT>(im, LONG1 ? j : i, LONG1 ? i : j, v); }
+template <bool LONG1, int FMT> __device__ __forceinline__ float cq_sc_load(const CqImg& im, int i, int j) { return cq_img_load1<FMT>(im, LONG1 ? j : i, LONG1 ? i : j); }

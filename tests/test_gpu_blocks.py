@@ -154,7 +154,13 @@ def test_dual_attn_fwd_bwd(shape, layer):
     _check_param_grads(blk, pr, lambda k: k.startswith(n + '/'))
 
 
-@pytest.mark.parametrize('shape', SHAPES)
+# clips of more than 128 frames run the long-clip kernels (csrc/cqwide.hip): both 128-column blocks full, a ragged second block, three
+# words / 32 words (the largest query those kernels take)
+CQ_WIDE_SHAPES = [dict(B=3, T=256, L=20, C=4, seed=21, max_vlen=256), dict(B=2, T=170, L=32, C=4, seed=22, max_vlen=192),
+                  dict(B=9, T=129, L=3, C=4, seed=23, max_vlen=160)]
+
+
+@pytest.mark.parametrize('shape', SHAPES + CQ_WIDE_SHAPES)
 def test_cq_attn_fwd_bwd(shape):
     blk = Block(**shape)
     lib = blk.lib
