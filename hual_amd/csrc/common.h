@@ -162,6 +162,10 @@ __device__ __forceinline__ void st4_nt(float* p, float4 v) {
   __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(p));
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// relu that lets a NaN through, like tf.nn.relu (fmaxf(NaN, 0) is 0: an activation beyond the fp16 operand range - Inf - Inf = NaN in a
+// product - would come out of the next relu as a plausible zero instead of reaching the loss / the logits)
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+__device__ __forceinline__ float4 relu_nan4(const float4& v) { return make_float4(relu_nan(v.x), relu_nan(v.y), relu_nan(v.z), relu_nan(v.w)); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 __device__ __forceinline__ float wave_sum16(float v) {   // sum across the 16 lanes sharing lane>>4

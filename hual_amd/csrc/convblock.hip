@@ -237,7 +237,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
         const float ir = irv[rt];
         float4 v = make_float4(fmaf(acc[rt][0], ir, 0.f) + bias.x, fmaf(acc[rt][1], ir, 0.f) + bias.y,
                                fmaf(acc[rt][2], ir, 0.f) + bias.z, fmaf(acc[rt][3], ir, 0.f) + bias.w);
-        v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        v = relu_nan4(v);
         if (own[rt] && L.y) st4(L.y + (size_t)o * HUAL_D + ecol, v);
         rb[rt] = f4_posbits(v);
         if (dropping) v = f4_select(nib[rt], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));

@@ -1034,14 +1034,16 @@ static double cq_bwd_bytes(const RowSpace& rs) { return 4.0 * (13.0 * rs.R * HUA
 
 // tri_prep (dropout on both roles of every row, rank-1 terms) + the attention itself: one launch when the clip fits the staged
 // kernel (it prepares the rows as it stages them), else two
-// clips of 129 .. 256 frames against queries of at most 32 words run the long-clip kernels of cqwide.hip (HUAL_CQ_NO_WIDE=1: the
-// global-operand kernels above instead - timing experiments and the tests that compare the two paths)
+// Which kernels serve a shape: queries of at most 32 words against clips of L <= T <= 256 frames - every shape of the YAML configs and of
+// BASELINE.json - run the kernels of cqwide.hip (round 5: at the bench shape 20.8 + 26.1 us against 26.3 + 33.6 us for the staged kernels
+// below, at B32 T256 33 + 47 us against 65 + 6 + 109 us for the global-operand kernels); longer queries (or queries longer than the clip)
+// the staged kernels when everything fits LDS, else the global-operand kernels.  HUAL_CQ_NO_WIDE=1 takes cqwide.hip out (A/B timings, tests).
 static bool cq_use_wide(const RowSpace& rs) {
   static const bool off = getenv("HUAL_CQ_NO_WIDE") != nullptr && atoi(getenv("HUAL_CQ_NO_WIDE")) != 0;
   return !off && cq_wide_ok(rs);
 }
 int launch_cq_fwd(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
-  if (!cq_staged_ok(rs) && cq_use_wide(rs)) return launch_cq_fwd_wide(b, p, rs, drop, s);
+  if (cq_use_wide(rs)) return launch_cq_fwd_wide(b, p, rs, drop, s);
   if (cq_staged_ok(rs)) {
     HUAL_DYN_LDS(cq_fwd_staged_kernel, 160 * 1024);
     HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, cq_fwd_bytes(rs), cq_fwd_staged_kernel, dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 1), s, b, p, rs, drop);
@@ -1068,7 +1070,7 @@ int launch_cq_bwd_pre(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, h
 
 // dXa/dXb scratch = g.dC2Q / g.dQ2C can NOT be reused (read by the kernel); callers pass dedicated buffers
 int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, float* dXa, float* dXb, hipStream_t s) {
-  if (!cq_staged_ok(rs) && cq_use_wide(rs)) return launch_cq_bwd_wide(b, g, rs, dXa, dXb, s);
+  if (cq_use_wide(rs)) return launch_cq_bwd_wide(b, g, rs, dXa, dXb, s);
   if (cq_staged_ok(rs)) {
     HUAL_DYN_LDS(cq_bwd_staged_kernel, 160 * 1024);
     HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, cq_bwd_bytes(rs), cq_bwd_staged_kernel, dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cq_staged_bytes(rs, 2), s, b, g, rs, dXa, dXb);

@@ -34,7 +34,8 @@ __host__ __device__ inline size_t cq_mat_elems(int T, int L) {   // max over bot
 }
 __host__ __device__ inline size_t cq_m2_rows(int T, int L) {
   int Tp = (T + 15) & ~15, Lp = (L + 15) & ~15;
-  return Tp > Lp ? Tp : Lp;
+  const int r = Tp > Lp ? Tp : Lp;
+  return r < 32 ? 32 : r;      // (cqwide.hip writes the 32 rows of its short-side image whatever L is)
 }
 
 // Staged kernels (clips whose operands fit LDS: every shape of the YAML configs; longer clips run cq_fwd_kernel / cq_bwd_kernel

@@ -1,8 +1,11 @@
-// Context-query attention for LONG clips: 128 < T <= 256 frames against queries of at most 32 words (BASELINE configs[3] / [4]: ActivityNet,
-// T = 256) - the shapes for which the staged kernels of cq.hip (every [rows,128] operand of a clip as a split image in LDS) do not fit:
-// 256 rows of fp16 pairs are 128 KB.  /root/reference/models/layers.py:114-130 (cq_attention), ops.py:94-116 (trilinear_attention).
+// Context-query attention for queries of at most 32 words against clips of up to 256 frames (every shape of the YAML configs and of
+// BASELINE.json: Charades T <= 128, ActivityNet T = 256): /root/reference/models/layers.py:114-130 (cq_attention), ops.py:94-116
+// (trilinear_attention).  The staged kernels of cq.hip keep EVERY [rows,128] operand of a clip as a split image in LDS - 256 rows of fp16
+// pairs are 128 KB, so they stop at 128 frames - and re-stage the long side for every phase; here the long side never goes through LDS
+// except for the products that contract over it.
 //
-// One workgroup of 16 waves per (clip, direction), written in the LONG x SHORT view U[l][s] of the score matrix whatever the direction
+// One workgroup per (clip, direction) - 16 waves for clips of more than 128 frames, 8 waves (and 256 registers per lane: every global
+// load requested a phase ahead) for shorter ones - written in the LONG x SHORT view U[l][s] of the score matrix whatever the direction
 // (direction 0: x1 = the clip's frames = long side, direction 1: x1 = the query's words = short side, U = score^T):
 //   * wave w OWNS the 16 long-side rows 16 w .. 16 w + 15.  It reads them from global memory straight into the A-operand layout of
 //     v_mfma_f32_16x16x32_f16 (lane (j, g): row j, columns 32 s + 8 g .. + 7 of k-step s - which is also one 16-byte chunk of an LDS image
@@ -29,12 +32,12 @@ using namespace hual;
 #define CQW_SQ 32                      // short-side rows of every image
 #define CQW_BLK (CQW_SQ * 512)         // bytes of one [32][128] block of a probability image (both planes)
 struct CqwLds { int simg, ps, pl, chunk, vec, total; };
-__host__ __device__ inline CqwLds cqw_lds_map() {
+__host__ __device__ inline CqwLds cqw_lds_map(int nblk) {      // nblk: blocks of 128 long-side entries (1 or 2)
   CqwLds l;
   int o = 0;
   l.simg = o; o += CQW_SQ * 512;       // short-side row image
-  l.ps = o; o += 2 * CQW_BLK;          // softmax along the short axis (later: dscore)
-  l.pl = o; o += 2 * CQW_BLK;          // softmax along the long axis
+  l.ps = o; o += nblk * CQW_BLK;       // softmax along the short axis (later: dscore)
+  l.pl = o; o += nblk * CQW_BLK;       // softmax along the long axis
   l.chunk = o; o += 128 * 512;         // 128 long-side rows
   l.vec = o; o += 1632 * 4;            // masks, rank-1 terms, cross-wave statistics (offsets below)
   l.total = o;
@@ -48,6 +51,28 @@ __host__ __device__ inline CqwLds cqw_lds_map() {
 #define CQW_V_CB 1088
 #define CQW_V_MX0 1600
 #define CQW_V_MX1 1616
+
+#ifdef HUAL_STAMPS
+// debug: clock stamps of wave 0 before and after every barrier of the long-clip kernels (scripts/exp/cqw_stamps.py): 64 slots per
+// workgroup, forward kernel in [0, 32), backward in [32, 64)
+__device__ unsigned long long g_cqw_stamps[256 * 64];
+extern "C" int hual_debug_cqw_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cqw_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#define CQW_STAMP_INIT(base) int cqw_si = (base)
+// per-wave stamps of the backward kernel's first phase: slot s (0..3) of wave w at [wg][s][w]
+__device__ unsigned long long g_cqw_wstamps[256 * 64];
+extern "C" int hual_debug_cqw_wstamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cqw_wstamps), sizeof(unsigned long long) * (size_t)n);
+}
+#define CQW_WSTAMP(s, drain) do { if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) g_cqw_wstamps[(blockIdx.y * gridDim.x + blockIdx.x) % 256 * 64 + (s) * 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter(); } while (0)
+#define CQW_STAMP() do { if (threadIdx.x == 0) g_cqw_stamps[(blockIdx.y * gridDim.x + blockIdx.x) % 256 * 64 + cqw_si] = __builtin_readcyclecounter(); ++cqw_si; } while (0)
+#else
+#define CQW_STAMP_INIT(base) do { } while (0)
+#define CQW_STAMP() do { } while (0)
+#define CQW_WSTAMP(s, drain) do { } while (0)
+#endif
+#define CQW_BARRIER() do { CQW_STAMP(); cq_barrier(); CQW_STAMP(); } while (0)
 
 struct CqwFrag { uint4 h[4], l[4]; };      // 16 rows x 128 columns of a wave as A fragments: k-step s = columns 32 s .. 32 s + 31
 // this lane's 32 columns of a row (rowp = the row's first element): x[2 s], x[2 s + 1] = columns 32 s + 8 g .. + 7
@@ -110,23 +135,30 @@ __device__ __forceinline__ f32x4 cqw_mma_rows(const CqwFrag& a, const CqImg& B, 
   }
   return t;
 }
+// The products whose results leave the kernel (or enter an image) are computed TRANSPOSED - the operand that carries the output's
+// columns goes in as A - so that lane (j, g) register r holds OUT[row0 + j][col0 + 4 g + r]: four consecutive columns of one row = one
+// 16-byte global store / one 8-byte store per image plane (the direct orientation would hold four ROWS: four scalar stores each).
 // "alpha" products: OUT[l] = sum over s of P[l][s] S[s] for the wave's own rows (contraction over the 32 short rows = one k-step);
-// ah / al = the transposed fragment of the wave's 16 columns of the P image
-__device__ __forceinline__ f32x4 cqw_alpha_tile(const uint4& ah, const uint4& al, const CqImg& S, int n0, int lane) {
-  uint4 bh, bl;
-  cq_frag<true>(S, n0, 0, lane, bh, bl);
+// ph / pl = the transposed fragment of the wave's 16 columns of the P image; lane (j, g) register r = OUT[l0 + j][n0 + 4 g + r]
+__device__ __forceinline__ f32x4 cqw_alpha_tile(const uint4& ph, const uint4& pl, const CqImg& S, int n0, int lane) {
+  uint4 sh, sl;
+  cq_frag<true>(S, n0, 0, lane, sh, sl);
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  return cqw_mfma3(ah, al, bh, bl, z);
+  return cqw_mfma3(sh, sl, ph, pl, z);
 }
-// "beta" products: OUT[s] = sum over the K rows l of a chunk of P[l][s] LONG[l]: tile [s0 + 4 g + r][n0 + j]
+// "beta" products: OUT[s] = sum over the K rows l of a chunk of P[l][s] LONG[l]; lane (j, g) register r = OUT[s0 + j][n0 + 4 g + r]
 __device__ __forceinline__ f32x4 cqw_beta(f32x4 acc, const CqImg& Pb, int s0, const CqImg& chunk, int n0, int K, int lane) {
   for (int k0 = 0; k0 < K; k0 += 32) {
-    uint4 ah, al, bh, bl;
-    cq_frag<false>(Pb, s0, k0, lane, ah, al);
-    cq_frag<true>(chunk, n0, k0, lane, bh, bl);
-    acc = cqw_mfma3(ah, al, bh, bl, acc);
+    uint4 ph, pl, ch, cl;
+    cq_frag<false>(Pb, s0, k0, lane, ph, pl);
+    cq_frag<true>(chunk, n0, k0, lane, ch, cl);
+    acc = cqw_mfma3(ch, cl, ph, pl, acc);
   }
   return acc;
+}
+// range-checked 16-byte / 4-byte row stores (common.h: a store that is not to happen gets the offset ROW_SKIP - no branch around it)
+__device__ __forceinline__ void cqw_st4(__amdgpu_buffer_rsrc_t r, bool ok, int row, int col, const f32x4& v, float scale) {
+  bst4(r, ok ? (uint32_t)(row * HUAL_D + col) * 4u : ROW_SKIP, make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale));
 }
 __device__ __forceinline__ float cqw_max16(float v) {      // over the 16 lanes of a row group (same g)
   v = fmaxf(v, dpp_xor_partner(v, 1)); v = fmaxf(v, dpp_xor_partner(v, 2));
@@ -158,38 +190,80 @@ __device__ __forceinline__ f32x4 cqw_img_load4(const CqImg& im, int row, int col
 }
 __device__ __forceinline__ float4 cqw_f4(const float (&v)[4]) { return make_float4(v[0], v[1], v[2], v[3]); }
 
-// geometry shared by the two kernels
+// geometry shared by the two kernels (NW waves: 16 or 8)
 struct CqwGeom {
-  int lane, wave, j, g, Nl, Ns, Nlq, lbase, sbase, l0, lc0, lblk, nlive, K1, lrow, lrc, k, c4, kc, s0, n0;
-  bool live, lok, sok;
+  int lane, wave, j, g, c4, Nl, Ns, Nlq, lbase, sbase, l0, lc0, lblk, nlive, nblk, K0, K1, lrow, lrc;
+  bool live, lok;
 };
 __device__ __forceinline__ CqwGeom cqw_geom(const RowSpace& rs, int clip) {
   CqwGeom q;
-  q.lane = threadIdx.x & 63; q.wave = threadIdx.x >> 6; q.j = q.lane & 15; q.g = q.lane >> 4;
+  q.lane = threadIdx.x & 63; q.wave = threadIdx.x >> 6; q.j = q.lane & 15; q.g = q.lane >> 4; q.c4 = threadIdx.x & 31;
   q.Nl = rs.T; q.Ns = rs.L; q.Nlq = (rs.T + 31) & ~31;
   q.lbase = clip * rs.T; q.sbase = rs.Nv + clip * rs.L;
   q.l0 = 16 * q.wave; q.lc0 = q.l0 & 127; q.lblk = q.l0 >> 7;
-  q.live = q.l0 < q.Nlq; q.nlive = q.Nlq >> 4; q.K1 = q.Nlq - 128;
+  q.live = q.l0 < q.Nlq; q.nlive = q.Nlq >> 4; q.nblk = (q.Nlq + 127) >> 7;
+  q.K0 = q.Nlq < 128 ? q.Nlq : 128; q.K1 = q.Nlq - q.K0;      // rows of the two chunks (the second one may be empty)
   q.lrow = q.l0 + q.j; q.lok = q.live && q.lrow < q.Nl; q.lrc = min(q.lrow, q.Nl - 1);
-  q.k = threadIdx.x >> 5; q.c4 = threadIdx.x & 31; q.sok = q.k < q.Ns; q.kc = min(q.k, q.Ns - 1);      // short rows: one float4 per thread
-  q.s0 = 16 * (q.wave >> 3); q.n0 = 16 * (q.wave & 7);                                                     // tile of a beta product
   return q;
 }
 __device__ __forceinline__ CqImg cqw_blk(char* lds, int base, int c, float scale = CQ_SCALE_PROB) { return cq_img(lds + base + c * CQW_BLK, CQW_SQ, scale); }
+// this lane's 32 columns of a row: the loads alone (cqw_rows_zero finishes what cqw_row_load does in one piece)
+__device__ __forceinline__ void cqw_row_issue(const float* rowp, int g, float4 (&x)[8]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    x[2 * s] = ld4(rowp + 32 * s + 8 * g);
+    x[2 * s + 1] = ld4(rowp + 32 * s + 8 * g + 4);
+  }
+}
+__device__ __forceinline__ void cqw_row_zero(bool ok, float4 (&x)[8]) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) x[u] = f4_pick(ok, x[u], f4zero());
+}
+// the mask element a thread stages (threads 0 .. 255: long side, 256 .. 287: short side; zero beyond the clip): selects only - a branch
+// in front of the load made the compiler wait for it before the next loads were requested
+__device__ __forceinline__ float cqw_mask_load(const RowSpace& rs, const CqwGeom& q) {
+  const int t = threadIdx.x;
+  const bool isl = t < 256;
+  const int idx = isl ? t : t - 256, n = isl ? q.Nl : q.Ns, base = isl ? q.lbase : q.sbase;
+  const float mv = rs.rowmask[base + min(idx, n - 1)];
+  return idx < n ? mv : 0.f;
+}
+// the NW waves' beta tiles: tile t = wave + NW u -> short rows 16 (t >> 3), columns 16 (t & 7).  With 8 waves a wave's two tiles share
+// their columns (one chunk fragment feeds both)
+template <int NW>
+__device__ __forceinline__ void cqw_beta_all(f32x4 (&acc)[16 / NW], const CqImg& Pb, const CqImg& chunk, int K, int wave, int lane) {
+  if (NW == 16) {
+    acc[0] = cqw_beta(acc[0], Pb, 16 * (wave >> 3), chunk, 16 * (wave & 7), K, lane);
+  } else {
+    for (int k0 = 0; k0 < K; k0 += 32) {
+      uint4 bh, bl;
+      cq_frag<true>(chunk, 16 * wave, k0, lane, bh, bl);
+#pragma unroll
+      for (int u = 0; u < 16 / NW; ++u) {
+        uint4 ph, pl;
+        cq_frag<false>(Pb, 16 * u, k0, lane, ph, pl);
+        acc[u] = cqw_mfma3(bh, bl, ph, pl, acc[u]);
+      }
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------------
 // forward.  DIR 0: long = x1 (d1w = dropout(x) * wm, s0 = dropout(x) . w0), short = x2 (d2 = dropout(x), s1 = d2 . w1); Sr = softmax along
 // the short axis, Sc along the long one.  DIR 1: the roles swap.
-template <int DIR>
+template <int DIR, int NW>
 __device__ __forceinline__ void cqw_fwd_body(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, int clip, char* lds) {
+  constexpr int NT = NW * 64, SR = 1024 / NT, TPW = 16 / NW;      // threads; short-row float4 per thread; beta tiles per wave
   const CqwGeom q = cqw_geom(rs, clip);
   const int lane = q.lane, j = q.j, g = q.g;
-  const CqwLds L = cqw_lds_map();
+  const CqwLds L = cqw_lds_map(NW == 16 ? 2 : 1);
   const CqImg simg = cq_img(lds + L.simg, CQW_SQ, CQ_SCALE_ACT), chunk = cq_img(lds + L.chunk, 128, CQ_SCALE_ACT);
   float* vec = reinterpret_cast<float*>(lds + L.vec);
   float* mlong = vec + CQW_V_MLONG; float* tlong = vec + CQW_V_TLONG; float* mshort = vec + CQW_V_MSHORT; float* tshort = vec + CQW_V_TSHORT;
   float* ca = vec + CQW_V_CA; float* cb = vec + CQW_V_CB;
   const DropRegs dr = drop_load(drop);
+  CQW_STAMP_INIT(0);
+  CQW_STAMP();
   const float* w_lterm = DIR == 0 ? p.w0[0] : p.w1[1];
   const float* w_sterm = DIR == 0 ? p.w1[0] : p.w0[1];
   const float* w_mul = DIR == 0 ? p.wm[0] : p.wm[1];                  // applies to the x1 role: the long rows (DIR 0) / the short rows (DIR 1)
@@ -197,13 +271,37 @@ __device__ __forceinline__ void cqw_fwd_body(const CqBufs& b, const CqParams& p,
   float* Dlong = DIR == 0 ? b.D1W : b.D2; float* Tlong = DIR == 0 ? b.S0 : b.S1;
   float* Dshort = DIR == 0 ? b.D2 : b.D1W; float* Tshort = DIR == 0 ? b.S1 : b.S0;
   const float* xrow = b.X + (size_t)(q.lbase + q.lrc) * HUAL_D;
-  // ---- short rows: one float4 per thread (dropout, rank-1 term, the prepared row out, its image)
-  float4 xs = f4_pick(q.sok, ld4(b.X + (size_t)(q.sbase + q.kc) * HUAL_D + 4 * q.c4), f4zero());
-  // ---- the wave's long rows
+  const uint32_t rbytes = (uint32_t)rs.R * HUAL_D * 4u;
+  const __amdgpu_buffer_rsrc_t rDlong = row_rsrc(Dlong, rbytes), rTlong = row_rsrc(Tlong, (uint32_t)rs.R * 4u);
+  const __amdgpu_buffer_rsrc_t rDshort = row_rsrc(Dshort, rbytes), rTshort = row_rsrc(Tshort, (uint32_t)rs.R * 4u);
+  auto srow = [&](int u) { return (int)(threadIdx.x + NT * u) >> 5; };      // short row of this thread's u-th float4 (column 4 c4)
+  // ---- every load of the first phase before any store (stores would pin the order of the loads behind them)
+  float mval;
+  {
+    mval = cqw_mask_load(rs, q);
+  }
+  float4 xs[SR];
+#pragma unroll
+  for (int u = 0; u < SR; ++u) xs[u] = ld4(b.X + (size_t)(q.sbase + min(srow(u), q.Ns - 1)) * HUAL_D + 4 * q.c4);
+  const float4 wS = ld4(w_sterm + 4 * q.c4), mS = ld4(w_mul + 4 * q.c4);
+  float4 x[8];
+  cqw_row_issue(xrow, g, x);
+  float4 wl[8], wm[8];                 // (8 waves: the long side's weights with the first round of loads; 16 waves: no registers for that)
+  if (NW == 8 && q.live) {
+    cqw_row_issue(w_lterm, g, wl);
+    if (DIR == 0) cqw_row_issue(w_mul, g, wm);
+  }
+#pragma unroll
+  for (int u = 0; u < SR; ++u) xs[u] = f4_pick(srow(u) < q.Ns, xs[u], f4zero());
+  cqw_row_zero(q.lok, x);
+  // ---- the wave's long rows: the raw rows of the first 128 go into the chunk image at once (it is free until the first product
+  // that contracts over the long side), then dropout, the rank-1 term, the prepared rows out and as fragments
   CqwFrag fa;
   if (q.live) {
-    float4 x[8];
-    cqw_row_load(xrow, g, q.lok, x);
+    if (q.lblk == 0) {
+      cqw_split(x, CQ_SCALE_ACT, fa);
+      cqw_frag_store(chunk, q.lc0 + j, g, fa);
+    }
     float term = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -213,51 +311,46 @@ __device__ __forceinline__ void cqw_fwd_body(const CqBufs& b, const CqParams& p,
         a = f4_select(bits & 15u, f4scale1(a, dr.scale));
         c = f4_select(bits >> 4, f4scale1(c, dr.scale));
       }
-      const float4 w0 = ld4(w_lterm + 32 * s + 8 * g), w1 = ld4(w_lterm + 32 * s + 8 * g + 4);
+      const float4 w0 = NW == 8 ? wl[2 * s] : ld4(w_lterm + 32 * s + 8 * g), w1 = NW == 8 ? wl[2 * s + 1] : ld4(w_lterm + 32 * s + 8 * g + 4);
       term += (a.x * w0.x + a.y * w0.y + a.z * w0.z + a.w * w0.w) + (c.x * w1.x + c.y * w1.y + c.z * w1.z + c.w * w1.w);
       if (DIR == 0) {
-        const float4 m0 = ld4(w_mul + 32 * s + 8 * g), m1 = ld4(w_mul + 32 * s + 8 * g + 4);
+        const float4 m0 = NW == 8 ? wm[2 * s] : ld4(w_mul + 32 * s + 8 * g), m1 = NW == 8 ? wm[2 * s + 1] : ld4(w_mul + 32 * s + 8 * g + 4);
         a = make_float4(a.x * m0.x, a.y * m0.y, a.z * m0.z, a.w * m0.w);
         c = make_float4(c.x * m1.x, c.y * m1.y, c.z * m1.z, c.w * m1.w);
       }
       x[2 * s] = a; x[2 * s + 1] = c;
-      if (q.lok) {
-        float* o = Dlong + (size_t)(q.lbase + q.lrow) * HUAL_D + 32 * s + 8 * g;
-        st4(o, a); st4(o + 4, c);
-      }
     }
     term = cqw_gsum(term);
-    if (g == 0) {
-      tlong[q.lrow] = q.lok ? term : 0.f;
-      if (q.lok) Tlong[q.lbase + q.lrow] = term;
-    }
+    if (g == 0) tlong[q.lrow] = q.lok ? term : 0.f;
     cqw_split(x, CQ_SCALE_ACT, fa);
+    const uint32_t ro = (uint32_t)((q.lbase + q.lrow) * HUAL_D + 8 * g) * 4u;      // (ROW_SKIP per store: it must not be offset)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bst4(rDlong, q.lok ? ro + 128u * s : ROW_SKIP, x[2 * s]);
+      bst4(rDlong, q.lok ? ro + 128u * s + 16u : ROW_SKIP, x[2 * s + 1]);
+    }
+    bst1(rTlong, (q.lok && g == 0) ? (uint32_t)(q.lbase + q.lrow) * 4u : ROW_SKIP, term);
   }
-  {
-    float4 o = xs;
+  // ---- short rows: dropout, rank-1 term, the prepared row out, its image
+#pragma unroll
+  for (int u = 0; u < SR; ++u) {
+    const int k = srow(u);
+    const bool sok = k < q.Ns;
+    float4 o = xs[u];
     if (dr.enabled) {
-      const uint32_t bits = drop_bits8_r(dr, site_short, (uint32_t)(q.sbase + q.kc), (uint32_t)(q.c4 >> 1));
-      o = f4_select((bits >> (4 * (q.c4 & 1))) & 15u, f4scale1(xs, dr.scale));
+      const uint32_t bits = drop_bits8_r(dr, site_short, (uint32_t)(q.sbase + min(k, q.Ns - 1)), (uint32_t)(q.c4 >> 1));
+      o = f4_select((bits >> (4 * (q.c4 & 1))) & 15u, f4scale1(xs[u], dr.scale));
     }
-    const float4 w = ld4(w_sterm + 4 * q.c4);
-    const float sv = half_sum32(o.x * w.x + o.y * w.y + o.z * w.z + o.w * w.w);
-    if (DIR == 1) {
-      const float4 m = ld4(w_mul + 4 * q.c4);
-      o = make_float4(o.x * m.x, o.y * m.y, o.z * m.z, o.w * m.w);
-    }
-    if (q.c4 == 0) tshort[q.k] = q.sok ? sv : 0.f;
-    if (q.sok) {
-      st4(Dshort + (size_t)(q.sbase + q.k) * HUAL_D + 4 * q.c4, o);
-      if (q.c4 == 0) Tshort[q.sbase + q.k] = sv;
-    }
-    cq_img_store4<1>(simg, q.k, 4 * q.c4, o);
+    const float sv = half_sum32(o.x * wS.x + o.y * wS.y + o.z * wS.z + o.w * wS.w);
+    if (DIR == 1) o = make_float4(o.x * mS.x, o.y * mS.y, o.z * mS.z, o.w * mS.w);
+    if (q.c4 == 0) tshort[k] = sok ? sv : 0.f;
+    cq_img_store4<1>(simg, k, 4 * q.c4, o);
+    bst4(rDshort, sok ? (uint32_t)((q.sbase + k) * HUAL_D + 4 * q.c4) * 4u : ROW_SKIP, o);
+    bst1(rTshort, (sok && q.c4 == 0) ? (uint32_t)(q.sbase + k) * 4u : ROW_SKIP, sv);
   }
-  if ((int)threadIdx.x < 256) mlong[threadIdx.x] = (int)threadIdx.x < q.Nl ? rs.rowmask[q.lbase + threadIdx.x] : 0.f;
-  else if ((int)threadIdx.x < 256 + CQW_SQ) {
-    const int kk = threadIdx.x - 256;
-    mshort[kk] = kk < q.Ns ? rs.rowmask[q.sbase + kk] : 0.f;
-  }
-  cq_barrier();
+  if ((int)threadIdx.x < 256) mlong[threadIdx.x] = mval;
+  else if ((int)threadIdx.x < 256 + CQW_SQ) mshort[threadIdx.x - 256] = mval;
+  CQW_BARRIER();
   // ---- scores of the wave's rows, the softmax along the short axis, the wave's part of the softmax along the long axis
   float lgl[2][4];
   bool valid[2][4];
@@ -308,7 +401,8 @@ __device__ __forceinline__ void cqw_fwd_body(const CqBufs& b, const CqParams& p,
       cq_img_store4<1>(cqw_blk(lds, L.ps, q.lblk), 16 * nt + j, q.lc0 + 4 * g, cqw_f4(Ps[nt]));
     }
   }
-  cq_barrier();
+  CQW_BARRIER();
+  if (NW == 16 && q.live && q.lblk == 1) cqw_row_issue(xrow, g, x);      // the raw rows of the second chunk, requested two phases ahead
   if (q.live) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -324,29 +418,10 @@ __device__ __forceinline__ void cqw_fwd_body(const CqBufs& b, const CqParams& p,
       cq_img_store4<1>(cqw_blk(lds, L.pl, q.lblk), col, q.lc0 + 4 * g, cqw_f4(Pl));
     }
   }
-  // the raw rows for the products with the probabilities: short side into its image, the first 128 long rows into the chunk
-  cq_img_store4<1>(simg, q.k, 4 * q.c4, xs);
-  auto chunk_raw = [&](int blk) {
-    if (q.live && q.lblk == blk) {
-      float4 x[8];
-      cqw_row_load(xrow, g, q.lok, x);
-      CqwFrag f;
-      cqw_split(x, CQ_SCALE_ACT, f);
-      cqw_frag_store(chunk, q.lc0 + j, g, f);
-    }
-  };
-  chunk_raw(0);
-  cq_barrier();
-  // ---- both softmaxes out for the backward pass: the images as they stand
-  {
-    const size_t mat = cq_mat_elems(rs.T, rs.L);
-    uint4* gps = reinterpret_cast<uint4*>((DIR == 0 ? b.SR : b.SC) + ((size_t)DIR * rs.B + clip) * mat);
-    uint4* gpl = reinterpret_cast<uint4*>((DIR == 0 ? b.SC : b.SR) + ((size_t)DIR * rs.B + clip) * mat);
-    const uint4* lps = reinterpret_cast<const uint4*>(lds + L.ps);
-    const uint4* lpl = reinterpret_cast<const uint4*>(lds + L.pl);
-    for (int idx = threadIdx.x; idx < 2 * CQW_BLK / 16; idx += CQ_MAX_THREADS) { gps[idx] = lps[idx]; gpl[idx] = lpl[idx]; }
-  }
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // the raw short rows for the products with the probabilities
+#pragma unroll
+  for (int u = 0; u < SR; ++u) cq_img_store4<1>(simg, srow(u), 4 * q.c4, xs[u]);
+  CQW_BARRIER();
   const float inv_pa = 1.0f / (CQ_SCALE_PROB * CQ_SCALE_ACT);
   float* M2 = b.M2 + ((size_t)DIR * rs.B + clip) * cq_m2_rows(rs.T, rs.L) * HUAL_D;
   uint4 ah = make_uint4(0u, 0u, 0u, 0u), al = ah;
@@ -354,88 +429,111 @@ __device__ __forceinline__ void cqw_fwd_body(const CqBufs& b, const CqParams& p,
   // OUT[own rows] = Ps . (short image) -> out (rows of the long side)
   auto alpha_out = [&](float* out) {
     if (q.live) {
+      const __amdgpu_buffer_rsrc_t ro = row_rsrc(out, rbytes);
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        const f32x4 t = cqw_alpha_tile(ah, al, simg, 16 * nt, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int l = q.l0 + 4 * g + r;
-          if (l < q.Nl) out[(size_t)(q.lbase + l) * HUAL_D + 16 * nt + j] = t[r] * inv_pa;
-        }
-      }
+      for (int nt = 0; nt < 8; ++nt) cqw_st4(ro, q.lok, q.lbase + q.lrow, 16 * nt + 4 * g, cqw_alpha_tile(ah, al, simg, 16 * nt, lane), inv_pa);
     }
   };
-  if (DIR == 0) {
-    alpha_out(b.C2Q);                                                           // c2q = Sr . x2
-    f32x4 acc = cqw_beta(zero, cqw_blk(lds, L.pl, 0), q.s0, chunk, q.n0, 128, lane);      // M2 = Sc^T . x1
-    cq_barrier();
-    chunk_raw(1);
-    cq_barrier();
-    acc = cqw_beta(acc, cqw_blk(lds, L.pl, 1), q.s0, chunk, q.n0, q.K1, lane);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = acc[r] * inv_pa;
-      M2[(size_t)(q.s0 + 4 * g + r) * HUAL_D + q.n0 + j] = v;
-      cq_img_store1<1>(simg, q.s0 + 4 * g + r, q.n0 + j, v);
+  auto chunk_raw1 = [&]() {      // (16 waves) the raw rows of the second chunk, requested above
+    if (NW == 16 && q.live && q.lblk == 1) {
+      cqw_row_zero(q.lok, x);
+      CqwFrag f;
+      cqw_split(x, CQ_SCALE_ACT, f);
+      cqw_frag_store(chunk, q.lc0 + j, g, f);
     }
-    cq_barrier();
+  };
+  // both softmaxes out for the backward pass: the images as they stand
+  auto save_images = [&]() {
+    const size_t mat = cq_mat_elems(rs.T, rs.L);
+    uint4* gps = reinterpret_cast<uint4*>((DIR == 0 ? b.SR : b.SC) + ((size_t)DIR * rs.B + clip) * mat);
+    uint4* gpl = reinterpret_cast<uint4*>((DIR == 0 ? b.SC : b.SR) + ((size_t)DIR * rs.B + clip) * mat);
+    const uint4* lps = reinterpret_cast<const uint4*>(lds + L.ps);
+    const uint4* lpl = reinterpret_cast<const uint4*>(lds + L.pl);
+    for (int idx = threadIdx.x; idx < q.nblk * (CQW_BLK / 16); idx += NT) { gps[idx] = lps[idx]; gpl[idx] = lpl[idx]; }
+  };
+  auto tile_s0 = [&](int u) { return 16 * ((q.wave + NW * u) >> 3); };
+  auto tile_n0 = [&](int u) { return 16 * ((q.wave + NW * u) & 7); };
+  f32x4 acc[TPW];
+  auto acc_zero = [&]() {
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto beta_short_out = [&](float* out) {      // beta tiles -> rows of the short side
+    const __amdgpu_buffer_rsrc_t ro = row_rsrc(out, rbytes);
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) cqw_st4(ro, tile_s0(u) + j < q.Ns, q.sbase + tile_s0(u) + j, tile_n0(u) + 4 * g, acc[u], inv_pa);
+  };
+  acc_zero();
+  if (DIR == 0) {
+    cqw_beta_all<NW>(acc, cqw_blk(lds, L.pl, 0), chunk, q.K0, q.wave, lane);       // M2 = Sc^T . x1
+    alpha_out(b.C2Q);                                                           // c2q = Sr . x2
+    save_images();
+    CQW_BARRIER();
+    if (NW == 16 && q.nblk == 2) {
+      chunk_raw1();
+      CQW_BARRIER();
+      cqw_beta_all<NW>(acc, cqw_blk(lds, L.pl, 1), chunk, q.K1, q.wave, lane);
+    }
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      const float4 v = make_float4(acc[u][0] * inv_pa, acc[u][1] * inv_pa, acc[u][2] * inv_pa, acc[u][3] * inv_pa);
+      st4(M2 + (size_t)(tile_s0(u) + j) * HUAL_D + tile_n0(u) + 4 * g, v);
+      cq_img_store4<1>(simg, tile_s0(u) + j, tile_n0(u) + 4 * g, v);
+    }
+    CQW_BARRIER();
     alpha_out(b.Q2C);                                                           // q2c = Sr . M2
   } else {
-    f32x4 acc = cqw_beta(zero, cqw_blk(lds, L.pl, 0), q.s0, chunk, q.n0, 128, lane);      // c2q = Sr . x2 (Sr: along the long axis)
+    cqw_beta_all<NW>(acc, cqw_blk(lds, L.pl, 0), chunk, q.K0, q.wave, lane);       // c2q = Sr . x2 (Sr: along the long axis)
     f32x4 m2o[8];                                                               // M2 = Sc^T . x1: the wave's rows
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) m2o[nt] = zero;
+    for (int nt = 0; nt < 8; ++nt) m2o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (q.live) {
+      const __amdgpu_buffer_rsrc_t rm = row_rsrc(M2, (uint32_t)cq_m2_rows(rs.T, rs.L) * HUAL_D * 4u);
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
         const f32x4 t = cqw_alpha_tile(ah, al, simg, 16 * nt, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          m2o[nt][r] = t[r] * inv_pa;
-          const int l = q.l0 + 4 * g + r;
-          if (l < q.Nl) M2[(size_t)l * HUAL_D + 16 * nt + j] = m2o[nt][r];
-        }
+        for (int r = 0; r < 4; ++r) m2o[nt][r] = t[r] * inv_pa;
+        cqw_st4(rm, q.lok, q.lrow, 16 * nt + 4 * g, m2o[nt], 1.0f);
       }
     }
-    cq_barrier();
-    chunk_raw(1);
-    cq_barrier();
-    acc = cqw_beta(acc, cqw_blk(lds, L.pl, 1), q.s0, chunk, q.n0, q.K1, lane);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int s = q.s0 + 4 * g + r;
-      if (s < q.Ns) b.C2Q[(size_t)(q.sbase + s) * HUAL_D + q.n0 + j] = acc[r] * inv_pa;
+    save_images();
+    if (NW == 16 && q.nblk == 2) {
+      CQW_BARRIER();
+      chunk_raw1();
+      CQW_BARRIER();
+      cqw_beta_all<NW>(acc, cqw_blk(lds, L.pl, 1), chunk, q.K1, q.wave, lane);
     }
+    beta_short_out(b.C2Q);
     auto chunk_m2 = [&](int blk) {
       if (q.live && q.lblk == blk) {
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cq_img_store1<1>(chunk, q.lc0 + 4 * g + r, 16 * nt + j, m2o[nt][r]);
+        for (int nt = 0; nt < 8; ++nt) cq_img_store4<1>(chunk, q.lc0 + j, 16 * nt + 4 * g, make_float4(m2o[nt][0], m2o[nt][1], m2o[nt][2], m2o[nt][3]));
       }
     };
-    cq_barrier();
+    CQW_BARRIER();
     chunk_m2(0);
-    cq_barrier();
-    acc = cqw_beta(zero, cqw_blk(lds, L.pl, 0), q.s0, chunk, q.n0, 128, lane);            // q2c = Sr . M2
-    cq_barrier();
-    chunk_m2(1);
-    cq_barrier();
-    acc = cqw_beta(acc, cqw_blk(lds, L.pl, 1), q.s0, chunk, q.n0, q.K1, lane);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int s = q.s0 + 4 * g + r;
-      if (s < q.Ns) b.Q2C[(size_t)(q.sbase + s) * HUAL_D + q.n0 + j] = acc[r] * inv_pa;
+    CQW_BARRIER();
+    acc_zero();
+    cqw_beta_all<NW>(acc, cqw_blk(lds, L.pl, 0), chunk, q.K0, q.wave, lane);       // q2c = Sr . M2
+    if (NW == 16 && q.nblk == 2) {
+      CQW_BARRIER();
+      chunk_m2(1);
+      CQW_BARRIER();
+      cqw_beta_all<NW>(acc, cqw_blk(lds, L.pl, 1), chunk, q.K1, q.wave, lane);
     }
+    beta_short_out(b.Q2C);
   }
+  CQW_STAMP();
 }
 
-__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_wide_kernel(CqBufs b, CqParams p, RowSpace rs, DropCfg drop) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void cq_fwd_wide_kernel(CqBufs b, CqParams p, RowSpace rs, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char cqw_lds[];
   const int clip = xcd_tile(blockIdx.x, gridDim.x);      // XCD-aware clip order (common.h)
   if (clip >= rs.B) return;
-  if (blockIdx.y == 0) cqw_fwd_body<0>(b, p, rs, drop, clip, cqw_lds);
-  else cqw_fwd_body<1>(b, p, rs, drop, clip, cqw_lds);
+  if (blockIdx.y == 0) cqw_fwd_body<0, NW>(b, p, rs, drop, clip, cqw_lds);
+  else cqw_fwd_body<1, NW>(b, p, rs, drop, clip, cqw_lds);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -445,48 +543,82 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_wide_kernel(CqBufs b, C
 //   DIR 1:  dPl = x2 . dc2q^T + M2 . dq2c^T (own rows)      dXb = Pl . dc2q, dM2 = Pl . dq2c (alpha)        dPs = dM2 . x1^T (own rows)
 //           dXa = Ps^T . dM2 (beta)    dD2 = dscore . d1w (alpha)     dD1W = dscore^T . d2 (beta)
 //   dscore = Ps (dPs - <Ps, dPs> along s) mask_short[s] + Pl (dPl - <Pl, dPl> along l) mask_long[l]; its row / column sums are d s0 / d s1.
-// Softmax backward pass common to both directions; dps / dpl = the gradients of the two softmaxes on the wave's rows (tile nt, register r)
-struct CqwSm { float ds[2][4]; };
-template <int DIR>
+// With 8 waves (256 registers per lane) the rows of every later phase are requested one or two phases ahead (PF); with 16 waves they
+// are loaded where they are used.
+template <int DIR, int NW>
 __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& gb, const RowSpace& rs, float* dXa, float* dXb, int clip, char* lds) {
+  constexpr int NT = NW * 64, SR = 1024 / NT, TPW = 16 / NW;
+  constexpr bool PF = NW == 8;
   const CqwGeom q = cqw_geom(rs, clip);
   const int lane = q.lane, j = q.j, g = q.g;
-  const CqwLds L = cqw_lds_map();
+  const CqwLds L = cqw_lds_map(NW == 16 ? 2 : 1);
   const CqImg simg = cq_img(lds + L.simg, CQW_SQ, CQ_SCALE_ACT), chunk = cq_img(lds + L.chunk, 128, CQ_SCALE_ACT);
   float* vec = reinterpret_cast<float*>(lds + L.vec);
   float* mlong = vec + CQW_V_MLONG; float* mshort = vec + CQW_V_MSHORT;
   float* ca = vec + CQW_V_CA; float* cb = vec + CQW_V_CB; float* mx0 = vec + CQW_V_MX0; float* mx1 = vec + CQW_V_MX1;
-  const size_t lrowoff = (size_t)(q.lbase + q.lrc) * HUAL_D, srowoff = (size_t)(q.sbase + q.kc) * HUAL_D + 4 * q.c4;
+  const size_t lrowoff = (size_t)(q.lbase + q.lrc) * HUAL_D;
   const float* M2 = b.M2 + ((size_t)DIR * rs.B + clip) * cq_m2_rows(rs.T, rs.L) * HUAL_D;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  // ---- the saved softmaxes (plain copies of the forward's images) and the masks
+  CQW_STAMP_INIT(32);
+  CQW_STAMP();
+  CQW_WSTAMP(0, false);
+  auto srow = [&](int u) { return (int)(threadIdx.x + NT * u) >> 5; };
+  auto short_rows = [&](const float* base, float4 (&v)[SR]) {      // this thread's float4 of the short-side rows of a [R,128] tensor (zero beyond Ns)
+#pragma unroll
+    for (int u = 0; u < SR; ++u) v[u] = f4_pick(srow(u) < q.Ns, ld4(base + (size_t)(q.sbase + min(srow(u), q.Ns - 1)) * HUAL_D + 4 * q.c4), f4zero());
+  };
+  auto short_store = [&](const CqImg& im, const float4 (&v)[SR]) {
+#pragma unroll
+    for (int u = 0; u < SR; ++u) cq_img_store4<1>(im, srow(u), 4 * q.c4, v[u]);
+  };
+  auto short_absmax = [&](const float4 (&v)[SR]) {
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < SR; ++u) m = fmaxf(m, f4absmax(v[u]));
+    return m;
+  };
+  // ---- the saved softmaxes (plain copies of the forward's images: exactly two 16-byte pieces per thread and image with either wave
+  // count) and the masks: requested here, written to LDS by prologue_finish() once the direction's own loads are on their way too (as
+  // a loop of load / wait / store per piece these were three memory round trips in front of everything else)
+  uint4 cps[2], cpl[2];
+  float mval;
   {
     const size_t mat = cq_mat_elems(rs.T, rs.L);
     const uint4* gps = reinterpret_cast<const uint4*>((DIR == 0 ? b.SR : b.SC) + ((size_t)DIR * rs.B + clip) * mat);
     const uint4* gpl = reinterpret_cast<const uint4*>((DIR == 0 ? b.SC : b.SR) + ((size_t)DIR * rs.B + clip) * mat);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { cps[it] = gps[threadIdx.x + NT * it]; cpl[it] = gpl[threadIdx.x + NT * it]; }
+    mval = cqw_mask_load(rs, q);
+  }
+  auto prologue_finish = [&]() {
     uint4* lps = reinterpret_cast<uint4*>(lds + L.ps);
     uint4* lpl = reinterpret_cast<uint4*>(lds + L.pl);
-    for (int idx = threadIdx.x; idx < 2 * CQW_BLK / 16; idx += CQ_MAX_THREADS) { lps[idx] = gps[idx]; lpl[idx] = gpl[idx]; }
-  }
-  if ((int)threadIdx.x < 256) mlong[threadIdx.x] = (int)threadIdx.x < q.Nl ? rs.rowmask[q.lbase + threadIdx.x] : 0.f;
-  else if ((int)threadIdx.x < 256 + CQW_SQ) {
-    const int kk = threadIdx.x - 256;
-    mshort[kk] = kk < q.Ns ? rs.rowmask[q.sbase + kk] : 0.f;
-  }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { lps[threadIdx.x + NT * it] = cps[it]; lpl[threadIdx.x + NT * it] = cpl[it]; }
+    if ((int)threadIdx.x < 256) mlong[threadIdx.x] = mval;
+    else if ((int)threadIdx.x < 256 + CQW_SQ) mshort[threadIdx.x - 256] = mval;
+  };
   float dps[2][4], dpl[2][4];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) dps[nt][r] = dpl[nt][r] = 0.f;
-  auto own_rows = [&](const float* base, float scale, CqwFrag& f) {      // the wave's rows of a [R,128] tensor as fragments
-    float4 x[8];
-    cqw_row_load(base + lrowoff, g, q.lok, x);
+  float4 xa[8], xb[8];                                                          // staging of the wave's rows of two [R,128] tensors
+  auto rows_issue = [&](const float* base, float4 (&x)[8]) { cqw_row_issue(base + lrowoff, g, x); };
+  auto rows_split = [&](float4 (&x)[8], float scale, CqwFrag& f) {
+    cqw_row_zero(q.lok, x);
     cqw_split(x, scale, f);
   };
-  auto short_row = [&](const float* base) { return f4_pick(q.sok, ld4(base + srowoff), f4zero()); };
   float* dS_long = DIR == 0 ? gb.dS0 : gb.dS1;
+  const __amdgpu_buffer_rsrc_t rdsl = row_rsrc(dS_long, (uint32_t)rs.R * 4u);
   float* dS_short = DIR == 0 ? gb.dS1 : gb.dS0;
-  CqImg dsc0 = cqw_blk(lds, L.ps, 0), dsc1 = cqw_blk(lds, L.ps, 1);      // the dscore image (takes the place of Ps)
+  CqImg dsc0 = cqw_blk(lds, L.ps, 0), dsc1 = cqw_blk(lds, L.ps, NW == 16 ? 1 : 0);      // the dscore image (takes the place of Ps)
+  auto tile_s0 = [&](int u) { return 16 * ((q.wave + NW * u) >> 3); };
+  auto tile_n0 = [&](int u) { return 16 * ((q.wave + NW * u) & 7); };
+  f32x4 acc[TPW];
+  auto acc_zero = [&]() {
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
 
   // softmax backward on the wave's rows: part 1 (before the barrier that publishes the long-axis dot products) ...
   float Ps[2][4], Pl[2][4], dots[4];
@@ -540,7 +672,7 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
       for (int r = 0; r < 4; ++r) {
         const float v = cqw_sum16(rs4[r]);
         const int l = q.l0 + 4 * g + r;
-        if (j == 0 && l < q.Nl) dS_long[q.lbase + l] = v;
+        bst1(rdsl, (j == 0 && l < q.Nl) ? (uint32_t)(q.lbase + l) * 4u : ROW_SKIP, v);
       }
     }
     cq_wgmax_put(mx1, dmax);
@@ -561,46 +693,56 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
     }
   };
   // OUT[own rows] = P . (short image S), P = the wave's columns of an image block
+  const uint32_t rbytes = (uint32_t)rs.R * HUAL_D * 4u;
   auto alpha_out = [&](const CqImg& Pb, const CqImg& S, float scale, float* out) {
     if (q.live) {
+      const __amdgpu_buffer_rsrc_t ro = row_rsrc(out, rbytes);
       uint4 ah, al;
       cq_frag<true>(Pb, q.lc0, 0, lane, ah, al);
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        const f32x4 t = cqw_alpha_tile(ah, al, S, 16 * nt, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int l = q.l0 + 4 * g + r;
-          if (l < q.Nl) out[(size_t)(q.lbase + l) * HUAL_D + 16 * nt + j] = t[r] * scale;
-        }
-      }
+      for (int nt = 0; nt < 8; ++nt) cqw_st4(ro, q.lok, q.lbase + q.lrow, 16 * nt + 4 * g, cqw_alpha_tile(ah, al, S, 16 * nt, lane), scale);
     }
   };
-  auto beta_out = [&](const f32x4& acc, float scale, float* out) {      // a beta tile -> rows of the short side
+  auto beta_out = [&](float scale, float* out) {      // the beta tiles -> rows of the short side
+    const __amdgpu_buffer_rsrc_t ro = row_rsrc(out, rbytes);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int s = q.s0 + 4 * g + r;
-      if (s < q.Ns) out[(size_t)(q.sbase + s) * HUAL_D + q.n0 + j] = acc[r] * scale;
+    for (int u = 0; u < TPW; ++u) cqw_st4(ro, tile_s0(u) + j < q.Ns, q.sbase + tile_s0(u) + j, tile_n0(u) + 4 * g, acc[u], scale);
+  };
+  // one beta product over both chunks; the wave's fragments f go into the chunk image (block 0 by the caller BEFORE the barrier in front
+  // of this call when `stored0`, block 1 in here)
+  auto beta_rounds = [&](const CqImg& P0, const CqImg& P1, const CqImg& ch, const CqwFrag& f) {
+    cqw_beta_all<NW>(acc, P0, ch, q.K0, q.wave, lane);
+    if (NW == 16 && q.nblk == 2) {
+      CQW_BARRIER();
+      if (q.live && q.lblk == 1) cqw_frag_store(ch, q.lc0 + j, g, f);
+      CQW_BARRIER();
+      cqw_beta_all<NW>(acc, P1, ch, q.K1, q.wave, lane);
     }
   };
 
   if (DIR == 0) {
-    const float4 xs = short_row(b.X), m2s = ld4(M2 + (size_t)q.k * HUAL_D + 4 * q.c4), d2s = short_row(b.D2);
-    cq_img_store4<1>(simg, q.k, 4 * q.c4, xs);
-    float4 x1[8];
-    cqw_row_load(gb.dC2Q + lrowoff, g, q.lok, x1);
-    cq_wgmax_put(mx0, q.live ? cqw_absmax(x1) : 0.f);
-    {
-      float4 x2[8];
-      cqw_row_load(gb.dQ2C + lrowoff, g, q.lok, x2);
-      cq_wgmax_put(mx1, q.live ? cqw_absmax(x2) : 0.f);
-    }
-    cq_barrier();                                                               // 1
+    float4 xs[SR], m2s[SR], d2s[SR];
+    short_rows(b.X, xs);
+#pragma unroll
+    for (int u = 0; u < SR; ++u) m2s[u] = ld4(M2 + (size_t)srow(u) * HUAL_D + 4 * q.c4);
+    if (PF) short_rows(b.D2, d2s);
+    rows_issue(gb.dC2Q, xa);
+    rows_issue(gb.dQ2C, xb);
+    CQW_WSTAMP(1, false);
+    CQW_WSTAMP(2, true);
+    prologue_finish();
+    short_store(simg, xs);
+    cqw_row_zero(q.lok, xa);
+    cqw_row_zero(q.lok, xb);
+    cq_wgmax_put(mx0, cqw_absmax(xa));
+    cq_wgmax_put(mx1, cqw_absmax(xb));
+    CQW_WSTAMP(3, false);
+    CQW_BARRIER();                                                              // 1
     CqImg cg1 = chunk, cg2 = chunk;
     cq_img_autoscale(cg1, cq_wgmax_get(mx0));
     cq_img_autoscale(cg2, cq_wgmax_get(mx1));
     CqwFrag f;
-    cqw_split(x1, cg1.scale, f);
+    cqw_split(xa, cg1.scale, f);
     if (q.live) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -610,15 +752,15 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
       }
       if (q.lblk == 0) cqw_frag_store(cg1, q.lc0 + j, g, f);
     }
-    cq_barrier();                                                               // 2
-    f32x4 acc = cqw_beta(zero, cqw_blk(lds, L.ps, 0), q.s0, cg1, q.n0, 128, lane);        // dXb = Sr^T . dc2q
-    cq_img_store4<1>(simg, q.k, 4 * q.c4, m2s);
-    cq_barrier();                                                               // 3
-    if (q.live && q.lblk == 1) cqw_frag_store(cg1, q.lc0 + j, g, f);
-    cq_barrier();                                                               // 4
-    acc = cqw_beta(acc, cqw_blk(lds, L.ps, 1), q.s0, cg1, q.n0, q.K1, lane);
-    beta_out(acc, cg1.inv * (1.0f / CQ_SCALE_PROB), dXb);
-    own_rows(gb.dQ2C, cg2.scale, f);
+    CQW_BARRIER();                                                              // 2
+    short_store(simg, m2s);
+    acc_zero();
+    beta_rounds(cqw_blk(lds, L.ps, 0), cqw_blk(lds, L.ps, NW == 16 ? 1 : 0), cg1, f);      // dXb = Sr^T . dc2q
+    beta_out(cg1.inv * (1.0f / CQ_SCALE_PROB), dXb);
+    if (!PF) rows_issue(gb.dQ2C, xb);
+    rows_split(xb, cg2.scale, f);
+    if (PF) rows_issue(b.X, xa);
+    CQW_BARRIER();                                                              // 5 (the M2 image is complete; every read of the dc2q chunk is done)
     if (q.live) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -626,29 +768,29 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
 #pragma unroll
         for (int r = 0; r < 4; ++r) dps[nt][r] = fmaf(t[r], cg2.inv * (1.0f / CQ_SCALE_ACT), dps[nt][r]);
       }
+      if (q.lblk == 0) cqw_frag_store(cg2, q.lc0 + j, g, f);
     }
-    cq_barrier();                                                               // 5
-    if (q.live && q.lblk == 0) cqw_frag_store(cg2, q.lc0 + j, g, f);
-    cq_barrier();                                                               // 6
-    acc = cqw_beta(zero, cqw_blk(lds, L.ps, 0), q.s0, cg2, q.n0, 128, lane);              // dM2 = Sr^T . dq2c
-    cq_barrier();                                                               // 7
-    if (q.live && q.lblk == 1) cqw_frag_store(cg2, q.lc0 + j, g, f);
-    cq_barrier();                                                               // 8
-    acc = cqw_beta(acc, cqw_blk(lds, L.ps, 1), q.s0, cg2, q.n0, q.K1, lane);
-    float dm[4], dmmax = 0.f;
+    CQW_BARRIER();                                                              // 6
+    acc_zero();
+    beta_rounds(cqw_blk(lds, L.ps, 0), cqw_blk(lds, L.ps, NW == 16 ? 1 : 0), cg2, f);      // dM2 = Sr^T . dq2c
+    if (PF) rows_issue(b.D1W, xb);
+    float dmmax = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dm[r] = acc[r] * (cg2.inv * (1.0f / CQ_SCALE_PROB));
-      dmmax = fmaxf(dmmax, fabsf(dm[r]));
-    }
+    for (int u = 0; u < TPW; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[u][r] *= cg2.inv * (1.0f / CQ_SCALE_PROB);
+        dmmax = fmaxf(dmmax, fabsf(acc[u][r]));
+      }
     cq_wgmax_put(mx0, dmmax);
-    cq_barrier();                                                               // 9
+    CQW_BARRIER();                                                              // 9
     CqImg sdm = simg;
     cq_img_autoscale(sdm, cq_wgmax_get(mx0));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cq_img_store1<1>(sdm, q.s0 + 4 * g + r, q.n0 + j, dm[r]);
-    cq_barrier();                                                               // 10
-    own_rows(b.X, CQ_SCALE_ACT, f);
+    for (int u = 0; u < TPW; ++u) cq_img_store4<1>(sdm, tile_s0(u) + j, tile_n0(u) + 4 * g, make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]));
+    if (!PF) rows_issue(b.X, xa);
+    rows_split(xa, CQ_SCALE_ACT, f);
+    CQW_BARRIER();                                                              // 10
     if (q.live) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -657,44 +799,45 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
         for (int r = 0; r < 4; ++r) dpl[nt][r] = t[r] * (sdm.inv * (1.0f / CQ_SCALE_ACT));
       }
     }
-    alpha_out(cqw_blk(lds, L.pl, q.lblk), sdm, sdm.inv * (1.0f / CQ_SCALE_PROB), dXa);      // dXa = Sc . dM2
+    if (!PF) { short_rows(b.D2, d2s); rows_issue(b.D1W, xb); }
     sm_part1();
-    cq_barrier();                                                               // 11
-    cq_img_store4<1>(simg, q.k, 4 * q.c4, d2s);
-    own_rows(b.D1W, CQ_SCALE_ACT, f);
+    alpha_out(cqw_blk(lds, L.pl, q.lblk), sdm, sdm.inv * (1.0f / CQ_SCALE_PROB), dXa);      // dXa = Sc . dM2
+    CQW_BARRIER();                                                              // 11
+    short_store(simg, d2s);
+    rows_split(xb, CQ_SCALE_ACT, f);
     if (q.live && q.lblk == 0) cqw_frag_store(chunk, q.lc0 + j, g, f);
     sm_part2();
-    cq_barrier();                                                               // 12
+    CQW_BARRIER();                                                              // 12
     sm_part3();
-    cq_barrier();                                                               // 13
+    CQW_BARRIER();                                                              // 13
+    acc_zero();
+    beta_rounds(dsc0, dsc1, chunk, f);                                          // dD2 = dscore^T . d1w
     alpha_out(q.lblk == 0 ? dsc0 : dsc1, simg, dsc0.inv * (1.0f / CQ_SCALE_ACT), gb.dD1W);  // dD1W = dscore . d2
-    acc = cqw_beta(zero, dsc0, q.s0, chunk, q.n0, 128, lane);                   // dD2 = dscore^T . d1w
-    cq_barrier();                                                               // 14
-    if (q.live && q.lblk == 1) cqw_frag_store(chunk, q.lc0 + j, g, f);
-    cq_barrier();                                                               // 15
-    acc = cqw_beta(acc, dsc1, q.s0, chunk, q.n0, q.K1, lane);
-    beta_out(acc, dsc0.inv * (1.0f / CQ_SCALE_ACT), gb.dD2);
+    beta_out(dsc0.inv * (1.0f / CQ_SCALE_ACT), gb.dD2);
   } else {
-    const float4 g1s = short_row(gb.dC2Q), g2s = short_row(gb.dQ2C);
-    cq_wgmax_put(mx0, f4absmax(g1s));
-    cq_wgmax_put(mx1, f4absmax(g2s));
-    CqwFrag fx, fm;
-    own_rows(b.X, CQ_SCALE_ACT, fx);
-    {
-      float4 x[8];
-      cqw_row_load(M2 + (size_t)q.lrc * HUAL_D, g, q.lok, x);
-      cqw_split(x, CQ_SCALE_ACT, fm);
-    }
-    cq_barrier();                                                               // 1
+    float4 g1s[SR], g2s[SR], xs[SR], d1s[SR];
+    short_rows(gb.dC2Q, g1s);
+    short_rows(gb.dQ2C, g2s);
+    if (PF) { short_rows(b.X, xs); short_rows(b.D1W, d1s); }
+    rows_issue(b.X, xa);
+    cqw_row_issue(M2 + (size_t)q.lrc * HUAL_D, g, xb);
+    prologue_finish();
+    cq_wgmax_put(mx0, short_absmax(g1s));
+    cq_wgmax_put(mx1, short_absmax(g2s));
+    CQW_BARRIER();                                                              // 1
     CqImg sa = simg, sb = cq_img(lds + L.chunk, CQW_SQ, CQ_SCALE_ACT);          // dc2q, dq2c images (the second one in the idle chunk buffer)
     cq_img_autoscale(sa, cq_wgmax_get(mx0));
     cq_img_autoscale(sb, cq_wgmax_get(mx1));
-    cq_img_store4<1>(sa, q.k, 4 * q.c4, g1s);
-    cq_img_store4<1>(sb, q.k, 4 * q.c4, g2s);
-    cq_barrier();                                                               // 2
+    short_store(sa, g1s);
+    short_store(sb, g2s);
+    CqwFrag fx, fm;
+    rows_split(xa, CQ_SCALE_ACT, fx);
+    rows_split(xb, CQ_SCALE_ACT, fm);
+    if (PF) rows_issue(b.D2, xa);
+    CQW_BARRIER();                                                              // 2
     f32x4 dm[8];
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) dm[nt] = zero;
+    for (int nt = 0; nt < 8; ++nt) dm[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dmmax = 0.f;
     if (q.live) {
 #pragma unroll
@@ -703,9 +846,6 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
 #pragma unroll
         for (int r = 0; r < 4; ++r) dpl[nt][r] = t[r] * (sa.inv * (1.0f / CQ_SCALE_ACT)) + u[r] * (sb.inv * (1.0f / CQ_SCALE_ACT));
       }
-    }
-    alpha_out(cqw_blk(lds, L.pl, q.lblk), sa, sa.inv * (1.0f / CQ_SCALE_PROB), dXb);        // dXb = Sr^T . dc2q (rows of the long side)
-    if (q.live) {
       uint4 ah, al;
       cq_frag<true>(cqw_blk(lds, L.pl, q.lblk), q.lc0, 0, lane, ah, al);
 #pragma unroll
@@ -719,18 +859,17 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
       }
     }
     cq_wgmax_put(mx0, dmmax);
-    const float4 xs = short_row(b.X), d1s = short_row(b.D1W);
-    cq_barrier();                                                               // 3
+    alpha_out(cqw_blk(lds, L.pl, q.lblk), sa, sa.inv * (1.0f / CQ_SCALE_PROB), dXb);        // dXb = Sr^T . dc2q (rows of the long side)
+    if (!PF) { short_rows(b.X, xs); short_rows(b.D1W, d1s); }
+    CQW_BARRIER();                                                              // 3
     CqImg cdm = chunk;
     cq_img_autoscale(cdm, cq_wgmax_get(mx0));
-    cq_img_store4<1>(simg, q.k, 4 * q.c4, xs);
+    short_store(simg, xs);
     // dM2 rows into the chunk (also the transposition from the accumulator layout to fragments of the wave's rows)
     auto chunk_dm = [&](int blk) {
       if (q.live && q.lblk == blk) {
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cq_img_store1<1>(cdm, q.lc0 + 4 * g + r, 16 * nt + j, dm[nt][r]);
+        for (int nt = 0; nt < 8; ++nt) cq_img_store4<1>(cdm, q.lc0 + j, 16 * nt + 4 * g, make_float4(dm[nt][0], dm[nt][1], dm[nt][2], dm[nt][3]));
       }
     };
     auto dps_rows = [&](int blk) {                                              // dSc^T = dM2 . x1^T on the wave's rows
@@ -746,61 +885,76 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
       }
     };
     chunk_dm(0);
-    cq_barrier();                                                               // 4
+    CQW_BARRIER();                                                              // 4
+    acc_zero();
+    cqw_beta_all<NW>(acc, cqw_blk(lds, L.ps, 0), cdm, q.K0, q.wave, lane);         // dXa = Sc . dM2 (rows of the short side)
     dps_rows(0);
-    f32x4 acc = cqw_beta(zero, cqw_blk(lds, L.ps, 0), q.s0, cdm, q.n0, 128, lane);        // dXa = Sc . dM2 (rows of the short side)
-    cq_barrier();                                                               // 5
-    chunk_dm(1);
-    cq_barrier();                                                               // 6
-    dps_rows(1);
-    acc = cqw_beta(acc, cqw_blk(lds, L.ps, 1), q.s0, cdm, q.n0, q.K1, lane);
-    beta_out(acc, cdm.inv * (1.0f / CQ_SCALE_PROB), dXa);
+    if (NW == 16 && q.nblk == 2) {
+      CQW_BARRIER();                                                            // 5
+      chunk_dm(1);
+      CQW_BARRIER();                                                            // 6
+      cqw_beta_all<NW>(acc, cqw_blk(lds, L.ps, 1), cdm, q.K1, q.wave, lane);
+      dps_rows(1);
+    }
+    beta_out(cdm.inv * (1.0f / CQ_SCALE_PROB), dXa);
+    if (!PF) rows_issue(b.D2, xa);
     sm_part1();
-    cq_barrier();                                                               // 7
-    cq_img_store4<1>(simg, q.k, 4 * q.c4, d1s);
+    CQW_BARRIER();                                                              // 7
+    short_store(simg, d1s);
     CqwFrag f;
-    own_rows(b.D2, CQ_SCALE_ACT, f);
+    rows_split(xa, CQ_SCALE_ACT, f);
     if (q.live && q.lblk == 0) cqw_frag_store(chunk, q.lc0 + j, g, f);
     sm_part2();
-    cq_barrier();                                                               // 8
+    CQW_BARRIER();                                                              // 8
     sm_part3();
-    cq_barrier();                                                               // 9
+    CQW_BARRIER();                                                              // 9
+    acc_zero();
+    beta_rounds(dsc0, dsc1, chunk, f);                                          // dD1W = dscore . d2
     alpha_out(q.lblk == 0 ? dsc0 : dsc1, simg, dsc0.inv * (1.0f / CQ_SCALE_ACT), gb.dD2);   // dD2 = dscore^T . d1w (rows of the long side)
-    acc = cqw_beta(zero, dsc0, q.s0, chunk, q.n0, 128, lane);                   // dD1W = dscore . d2
-    cq_barrier();                                                               // 10
-    if (q.live && q.lblk == 1) cqw_frag_store(chunk, q.lc0 + j, g, f);
-    cq_barrier();                                                               // 11
-    acc = cqw_beta(acc, dsc1, q.s0, chunk, q.n0, q.K1, lane);
-    beta_out(acc, dsc0.inv * (1.0f / CQ_SCALE_ACT), gb.dD1W);
+    beta_out(dsc0.inv * (1.0f / CQ_SCALE_ACT), gb.dD1W);
   }
+  CQW_STAMP();
 }
 
-__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_wide_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void cq_bwd_wide_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb) {
   extern __shared__ __attribute__((aligned(16))) char cqw_lds[];
   const int clip = xcd_tile(blockIdx.x, gridDim.x);      // XCD-aware clip order (common.h)
   if (clip >= rs.B) return;
-  if (blockIdx.y == 0) cqw_bwd_body<0>(b, gb, rs, dXa, dXb, clip, cqw_lds);
-  else cqw_bwd_body<1>(b, gb, rs, dXa, dXb, clip, cqw_lds);
+  if (blockIdx.y == 0) cqw_bwd_body<0, NW>(b, gb, rs, dXa, dXb, clip, cqw_lds);
+  else cqw_bwd_body<1, NW>(b, gb, rs, dXa, dXb, clip, cqw_lds);
 }
 
 namespace hual {
 
-bool cq_wide_ok(const RowSpace& rs) { return rs.T > 128 && rs.T <= 256 && rs.L >= 1 && rs.L <= CQW_SQ; }
+bool cq_wide_ok(const RowSpace& rs) { return rs.T >= 1 && rs.T <= 256 && rs.L >= 1 && rs.L <= CQW_SQ && rs.T >= rs.L; }
 
-// algorithmic bytes as for the staged kernels (cq.hip): rows in / out, M2, the two saved softmaxes (as images: 32 KB each)
+// algorithmic bytes as for the staged kernels (cq.hip): rows in / out, M2, the two saved softmaxes (as images: 16 KB per 128 frames each)
 int launch_cq_fwd_wide(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
-  HUAL_REQUIRE(cq_wide_ok(rs), "cq_fwd_wide: needs 128 < T <= 256 and L <= 32");
-  HUAL_DYN_LDS(cq_fwd_wide_kernel, 160 * 1024);
-  HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, 4.0 * 5.0 * rs.R * HUAL_D + 2.0 * rs.B * (4.0 * CQW_BLK + 4.0 * CQW_SQ * HUAL_D), cq_fwd_wide_kernel,
-              dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cqw_lds_map().total, s, b, p, rs, drop);
+  HUAL_REQUIRE(cq_wide_ok(rs), "cq_fwd_wide: needs L <= T <= 256 and L <= 32");
+  const int nblk = rs.T > 128 ? 2 : 1;
+  const double flops = 2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, bytes = 4.0 * 5.0 * rs.R * HUAL_D + 2.0 * rs.B * (2.0 * nblk * CQW_BLK + 4.0 * CQW_SQ * HUAL_D);
+  if (nblk == 2) {
+    HUAL_DYN_LDS(cq_fwd_wide_kernel<16>, 160 * 1024);
+    HUAL_LAUNCH(flops, bytes, cq_fwd_wide_kernel<16>, dim3(xcd_round8(rs.B), 2), dim3(1024), cqw_lds_map(2).total, s, b, p, rs, drop);
+  } else {
+    HUAL_DYN_LDS(cq_fwd_wide_kernel<8>, 160 * 1024);
+    HUAL_LAUNCH(flops, bytes, cq_fwd_wide_kernel<8>, dim3(xcd_round8(rs.B), 2), dim3(512), cqw_lds_map(1).total, s, b, p, rs, drop);
+  }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 int launch_cq_bwd_wide(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, float* dXa, float* dXb, hipStream_t s) {
-  HUAL_REQUIRE(cq_wide_ok(rs), "cq_bwd_wide: needs 128 < T <= 256 and L <= 32");
-  HUAL_DYN_LDS(cq_bwd_wide_kernel, 160 * 1024);
-  HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, 4.0 * 13.0 * rs.R * HUAL_D + 2.0 * rs.B * (4.0 * CQW_BLK + 4.0 * CQW_SQ * HUAL_D), cq_bwd_wide_kernel,
-              dim3(xcd_round8(rs.B), 2), dim3(CQ_MAX_THREADS), cqw_lds_map().total, s, b, g, rs, dXa, dXb);
+  HUAL_REQUIRE(cq_wide_ok(rs), "cq_bwd_wide: needs L <= T <= 256 and L <= 32");
+  const int nblk = rs.T > 128 ? 2 : 1;
+  const double flops = 2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, bytes = 4.0 * 13.0 * rs.R * HUAL_D + 2.0 * rs.B * (2.0 * nblk * CQW_BLK + 4.0 * CQW_SQ * HUAL_D);
+  if (nblk == 2) {
+    HUAL_DYN_LDS(cq_bwd_wide_kernel<16>, 160 * 1024);
+    HUAL_LAUNCH(flops, bytes, cq_bwd_wide_kernel<16>, dim3(xcd_round8(rs.B), 2), dim3(1024), cqw_lds_map(2).total, s, b, g, rs, dXa, dXb);
+  } else {
+    HUAL_DYN_LDS(cq_bwd_wide_kernel<8>, 160 * 1024);
+    HUAL_LAUNCH(flops, bytes, cq_bwd_wide_kernel<8>, dim3(xcd_round8(rs.B), 2), dim3(512), cqw_lds_map(1).total, s, b, g, rs, dXa, dXb);
+  }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -163,7 +163,7 @@ __device__ __forceinline__ void ln_proj_body(const LnProjArgs& a, const DropCfg&
     for (int rt = 0; rt < NT; ++rt) {
       const int lr = 16 * rt + j, row = r0 + lr;
       float4 v = make_float4(acc[rt].x + bias[p].x, acc[rt].y + bias[p].y, acc[rt].z + bias[p].z, acc[rt].w + bias[p].w);
-      const float4 vr = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      const float4 vr = relu_nan4(v);
       v = f4_pick(relu, vr, v);
       const float4 vd = f4_select(nbo[rt], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
       v = f4_pick(dropo, vd, v);

@@ -213,7 +213,7 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
       for (int rt = 0; rt < NT; ++rt) {
         const int row = r0 + 16 * rt + j;
         float4 v = st.bias ? cb_add(acc[rt], bias) : acc[rt];
-        if (st.act) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (st.act) v = relu_nan4(v);
         if ((F & MPF_ADD) && st.add) v = cb_add(v, addv[rt]);
         if (closes && 16 * rt + j < MT && row < RE) st4(outp + (size_t)row * st.ldo + ecol, v);
         if (F & MPF_QUAD) {

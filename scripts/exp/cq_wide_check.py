@@ -1,5 +1,5 @@
 """Context-query block (hual_cq_attn_fwd / _bwd) against the CPU oracle at long-clip shapes: errors relative to each tensor's
-largest element.  HUAL_CQ_NO_WIDE=1 runs the global-operand kernels instead of csrc/cqwide.hip (same script, for comparison)."""
+largest element.  HUAL_CQ_NO_WIDE=1 runs the staged / global-operand kernels of csrc/cq.hip instead of csrc/cqwide.hip (for comparison)."""
 import os
 import sys
 
@@ -14,6 +14,7 @@ from oracle import philox as px   # noqa: E402
 from oracle import seqpan_ref as R  # noqa: E402
 
 shapes = tb.CQ_WIDE_SHAPES + [dict(B=32, T=256, L=20, C=4, seed=31, max_vlen=256)]
+shapes += tb.SHAPES + [dict(B=64, T=128, L=20, C=4, seed=32, max_vlen=128), dict(B=5, T=100, L=30, C=4, seed=33, max_vlen=100)]
 for shape in shapes:
     blk = tb.Block(**shape)
     lib = blk.lib

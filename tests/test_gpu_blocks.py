@@ -154,10 +154,11 @@ def test_dual_attn_fwd_bwd(shape, layer):
     _check_param_grads(blk, pr, lambda k: k.startswith(n + '/'))
 
 
-# clips of more than 128 frames run the long-clip kernels (csrc/cqwide.hip): both 128-column blocks full, a ragged second block, three
-# words / 32 words (the largest query those kernels take)
+# csrc/cqwide.hip (queries of at most 32 words): clips of more than 128 frames (16 waves, two 128-column blocks: both full, a ragged
+# second block, three words / 32 words); the shapes beyond it - queries of more than 32 words - run the staged kernels of csrc/cq.hip
 CQ_WIDE_SHAPES = [dict(B=3, T=256, L=20, C=4, seed=21, max_vlen=256), dict(B=2, T=170, L=32, C=4, seed=22, max_vlen=192),
-                  dict(B=9, T=129, L=3, C=4, seed=23, max_vlen=160)]
+                  dict(B=9, T=129, L=3, C=4, seed=23, max_vlen=160), dict(B=5, T=100, L=30, C=4, seed=33, max_vlen=100),
+                  dict(B=3, T=64, L=40, C=4, seed=24, max_vlen=64)]
 
 
 @pytest.mark.parametrize('shape', SHAPES + CQ_WIDE_SHAPES)
