@@ -37,6 +37,6 @@ echo "[3] pmc traffic done"
 rm -rf $out/pmc_sq
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d $out/pmc_sq -o s --output-format csv -- python3 $R/bench.py $short > /dev/null 2> $out/${tag}_pmc_sq.err || { tail -5 $out/${tag}_pmc_sq.err; exit 4; }
 q=$(ls $out/pmc_sq/*/*counter_collection.csv $out/pmc_sq/*counter_collection.csv 2>/dev/null | head -1)
-{ echo "# shape: B64 T128 L20 C8 vdim1024 drop0.2 f32"; for k in dw_f16 conv_block_fwd conv_block_bwd ln_proj_kernel ln_proj_bwd da_post da_mid_bwd attn_fwd attn_bwd feature_ksplit mproj_kernel mproj_pair cq_fwd_staged cq_bwd_staged; do python $R/scripts/pmc_summary.py "$q" $k; done; } > $out/${tag}_pmc_sq_counters.txt
+{ echo "# shape: B64 T128 L20 C8 vdim1024 drop0.2 f32"; for k in dw_f16 conv_block_fwd conv_block_bwd ln_proj_kernel ln_proj_bwd da_post da_mid_bwd attn_fwd attn_bwd feature_ksplit mproj_kernel mproj_pair cq_fwd_wide cq_bwd_wide; do python $R/scripts/pmc_summary.py "$q" $k; done; } > $out/${tag}_pmc_sq_counters.txt
 rm -rf $out/pmc_sq
 echo "[4] sq counters done"
