@@ -727,20 +727,19 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
     for (int u = 0; u < SR; ++u) m2s[u] = ld4(M2 + (size_t)srow(u) * HUAL_D + 4 * q.c4);
     if (PF) short_rows(b.D2, d2s);
     rows_issue(gb.dC2Q, xa);
-    rows_issue(gb.dQ2C, xb);
     CQW_WSTAMP(1, false);
     CQW_WSTAMP(2, true);
     prologue_finish();
     short_store(simg, xs);
     cqw_row_zero(q.lok, xa);
-    cqw_row_zero(q.lok, xb);
     cq_wgmax_put(mx0, cqw_absmax(xa));
-    cq_wgmax_put(mx1, cqw_absmax(xb));
     CQW_WSTAMP(3, false);
     CQW_BARRIER();                                                              // 1
+    // d q2c is not needed before the second half of dSr: its rows are requested HERE, not with the first burst (the first phase of
+    // 128 workgroups asks for 200 KB each at once and is bound by that burst), and its scale rides on the barrier in front of its use
+    rows_issue(gb.dQ2C, xb);
     CqImg cg1 = chunk, cg2 = chunk;
     cq_img_autoscale(cg1, cq_wgmax_get(mx0));
-    cq_img_autoscale(cg2, cq_wgmax_get(mx1));
     CqwFrag f;
     cqw_split(xa, cg1.scale, f);
     if (q.live) {
@@ -757,10 +756,12 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
     acc_zero();
     beta_rounds(cqw_blk(lds, L.ps, 0), cqw_blk(lds, L.ps, NW == 16 ? 1 : 0), cg1, f);      // dXb = Sr^T . dc2q
     beta_out(cg1.inv * (1.0f / CQ_SCALE_PROB), dXb);
-    if (!PF) rows_issue(gb.dQ2C, xb);
-    rows_split(xb, cg2.scale, f);
+    cqw_row_zero(q.lok, xb);
+    cq_wgmax_put(mx1, cqw_absmax(xb));
     if (PF) rows_issue(b.X, xa);
     CQW_BARRIER();                                                              // 5 (the M2 image is complete; every read of the dc2q chunk is done)
+    cq_img_autoscale(cg2, cq_wgmax_get(mx1));
+    cqw_split(xb, cg2.scale, f);
     if (q.live) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -820,19 +821,18 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
     short_rows(gb.dQ2C, g2s);
     if (PF) { short_rows(b.X, xs); short_rows(b.D1W, d1s); }
     rows_issue(b.X, xa);
-    cqw_row_issue(M2 + (size_t)q.lrc * HUAL_D, g, xb);
     prologue_finish();
     cq_wgmax_put(mx0, short_absmax(g1s));
     cq_wgmax_put(mx1, short_absmax(g2s));
     CQW_BARRIER();                                                              // 1
+    cqw_row_issue(M2 + (size_t)q.lrc * HUAL_D, g, xb);      // (behind the first burst, used last in the next phase: see direction 0)
     CqImg sa = simg, sb = cq_img(lds + L.chunk, CQW_SQ, CQ_SCALE_ACT);          // dc2q, dq2c images (the second one in the idle chunk buffer)
     cq_img_autoscale(sa, cq_wgmax_get(mx0));
     cq_img_autoscale(sb, cq_wgmax_get(mx1));
     short_store(sa, g1s);
     short_store(sb, g2s);
-    CqwFrag fx, fm;
+    CqwFrag fx;
     rows_split(xa, CQ_SCALE_ACT, fx);
-    rows_split(xb, CQ_SCALE_ACT, fm);
     if (PF) rows_issue(b.D2, xa);
     CQW_BARRIER();                                                              // 2
     f32x4 dm[8];
@@ -842,9 +842,9 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
     if (q.live) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const f32x4 t = cqw_mma_rows(fx, sa, 16 * nt, lane), u = cqw_mma_rows(fm, sb, 16 * nt, lane);      // dSr^T = x2 . dc2q^T + M2 . dq2c^T
+        const f32x4 t = cqw_mma_rows(fx, sa, 16 * nt, lane);                    // dSr^T = x2 . dc2q^T (+ M2 . dq2c^T below)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dpl[nt][r] = t[r] * (sa.inv * (1.0f / CQ_SCALE_ACT)) + u[r] * (sb.inv * (1.0f / CQ_SCALE_ACT));
+        for (int r = 0; r < 4; ++r) dpl[nt][r] = t[r] * (sa.inv * (1.0f / CQ_SCALE_ACT));
       }
       uint4 ah, al;
       cq_frag<true>(cqw_blk(lds, L.pl, q.lblk), q.lc0, 0, lane, ah, al);
@@ -860,6 +860,18 @@ __device__ __forceinline__ void cqw_bwd_body(const CqBufs& b, const CqBwdBufs& g
     }
     cq_wgmax_put(mx0, dmmax);
     alpha_out(cqw_blk(lds, L.pl, q.lblk), sa, sa.inv * (1.0f / CQ_SCALE_PROB), dXb);        // dXb = Sr^T . dc2q (rows of the long side)
+    {
+      CqwFrag fm;
+      rows_split(xb, CQ_SCALE_ACT, fm);
+      if (q.live) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x4 u = cqw_mma_rows(fm, sb, 16 * nt, lane);                  // + M2 . dq2c^T
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dpl[nt][r] = fmaf(u[r], sb.inv * (1.0f / CQ_SCALE_ACT), dpl[nt][r]);
+        }
+      }
+    }
     if (!PF) { short_rows(b.X, xs); short_rows(b.D1W, d1s); }
     CQW_BARRIER();                                                              // 3
     CqImg cdm = chunk;
