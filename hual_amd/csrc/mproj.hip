@@ -24,8 +24,9 @@ using namespace hual;
 enum { MPF_A2 = 1, MPF_BF16 = 2, MPF_DROP = 4, MPF_ADD = 8, MPF_LN = 16, MPF_REUSE = 32, MPF_QUAD = 64, MPF_POOL = 128 };
 
 // NT = row tiles of a workgroup (MT <= 16 NT)
+// (tile < 0: the workgroup derives its tile from blockIdx.x - the XCD-aware order over this problem's own tiles, common.h)
 template <int NT, int F>
-__device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& drop) {
+__device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& drop, int tile = -1) {
   extern __shared__ __attribute__((aligned(16))) char mp_lds[];
   char* S0 = mp_lds;                                   // operand slot 0: hi | lo planes [64][256 B]; LN mode: x as fp32 rows
   char* S1 = S0 + 2 * MP_ROWS * 256;
@@ -35,9 +36,12 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int col = 4 * l32;
   const int MT = a.MT, R = a.R;
-  const int nblk = xcd_round8((R + MT - 1) / MT);      // XCD-aware tile order (common.h) over this problem's own tiles: in a pair
-  if ((int)blockIdx.x >= nblk) return;                 // launch every XCD gets an eighth of EACH problem
-  const int r0 = xcd_tile(blockIdx.x, nblk) * MT;
+  if (tile < 0) {
+    const int nblk = xcd_round8((R + MT - 1) / MT);
+    if ((int)blockIdx.x >= nblk) return;
+    tile = xcd_tile(blockIdx.x, nblk);
+  }
+  const int r0 = tile * MT;
   if (r0 >= R) return;
   const int RE = min(R, r0 + MT);
   const int j = lane & 15, g = lane >> 4, ecol = 16 * wave + 4 * g;      // T-form: lane = row j of a tile, columns ecol .. ecol + 3
@@ -326,10 +330,22 @@ __device__ __forceinline__ void mproj_body(const MProjArgs& a, const DropCfg& dr
 
 template <int NT, int F>
 __global__ __launch_bounds__(CB_THREADS) void mproj_kernel(MProjArgs a, DropCfg drop) { mproj_body<NT, F>(a, drop); }
+// Two problems in one launch, ONE grid row: XCD x (= blockIdx.x & 7, the dispatcher's round robin) takes its eighth of the tiles of
+// problem 0, then its eighth of problem 1 (mproj_pair_tiles: the same split on the host sizes the grid).  Round 5: the launch used to
+// be (tiles of the LARGER problem) x 2 with the second row mostly empty - at 8192 + 640 rows 221 of 480 workgroups returned at once,
+// but each of them takes a CU slot (96 KB of LDS: one per CU) through dispatch, argument load and exit, and the 19 real workgroups of
+// the second row queued behind them: 29.9 / 28.2 us against 19.1 / 17.9 us for the same work at 8192 + 1280 rows.
+__host__ __device__ inline int mproj_pair_lo(int nb, int x) { return nb * x / 8; }
 template <int NT, int F>
 __global__ __launch_bounds__(CB_THREADS) void mproj_pair_kernel(MProjArgs a0, MProjArgs a1, DropCfg drop) {
-  if (blockIdx.y == 0) mproj_body<NT, F>(a0, drop);
-  else mproj_body<NT, F>(a1, drop);
+  const int x = blockIdx.x & 7;
+  int sl = blockIdx.x >> 3;
+  const int nb0 = (a0.R + a0.MT - 1) / a0.MT, nb1 = (a1.R + a1.MT - 1) / a1.MT;
+  const int lo0 = mproj_pair_lo(nb0, x), n0 = mproj_pair_lo(nb0, x + 1) - lo0;
+  if (sl < n0) { mproj_body<NT, F>(a0, drop, lo0 + sl); return; }
+  sl -= n0;
+  const int lo1 = mproj_pair_lo(nb1, x), n1 = mproj_pair_lo(nb1, x + 1) - lo1;
+  if (sl < n1) mproj_body<NT, F>(a1, drop, lo1 + sl);
 }
 
 #undef ld4
@@ -345,9 +361,20 @@ namespace hual {
 
 // rows per workgroup for problems of R0 (+ R1) rows in one launch: the smallest tile (>= 16) with which ALL workgroups of the
 // launch are resident at once - one per CU; a launch with one workgroup more than there are CUs takes two rounds
+// workgroups of a pair launch: 8 x the largest per-XCD count of the two problems' tiles (mproj_pair_kernel)
+static int mproj_pair_grid(int R0, int R1, int t) {
+  const int nb0 = cdiv(R0, t), nb1 = cdiv(R1, t);
+  int m = 0;
+  for (int x = 0; x < 8; ++x) {
+    const int n = (mproj_pair_lo(nb0, x + 1) - mproj_pair_lo(nb0, x)) + (mproj_pair_lo(nb1, x + 1) - mproj_pair_lo(nb1, x));
+    m = n > m ? n : m;
+  }
+  return 8 * m;
+}
 int mproj_rows(int R0, int R1) {
   int t = 16;
-  while (t < MP_ROWS && cdiv(R0, t) + (R1 > 0 ? cdiv(R1, t) : 0) > 256) ++t;
+  if (R1 > 0) { while (t < MP_ROWS && mproj_pair_grid(R0, R1, t) > 256) ++t; }      // (no XCD gets more than its 32 CUs' worth)
+  else { while (t < MP_ROWS && cdiv(R0, t) > 256) ++t; }
   return t;
 }
 
@@ -424,7 +451,7 @@ int launch_mproj(const MProjArgs* a, int nprob, const DropCfg& drop, hipStream_t
     HUAL_DYN_LDS((mproj_kernel<NT, FS>), 96 * 1024);                                                                       \
     HUAL_DYN_LDS((mproj_pair_kernel<NT, FS>), 96 * 1024);                                                                  \
     if (nprob == 1) HUAL_LAUNCH(flops, bytes, (mproj_kernel<NT, FS>), dim3(blocks), dim3(CB_THREADS), lds, s, a[0], drop); \
-    else HUAL_LAUNCH(flops, bytes, (mproj_pair_kernel<NT, FS>), dim3(blocks, 2), dim3(CB_THREADS), lds, s, a[0], a[1], drop); \
+    else HUAL_LAUNCH(flops, bytes, (mproj_pair_kernel<NT, FS>), dim3(mproj_pair_grid(a[0].R, a[1].R, a[0].MT)), dim3(CB_THREADS), lds, s, a[0], a[1], drop); \
   } while (0)
 #define MPROJ_NT(FS)                                                                                                       \
   do {                                                                                                                     \
