@@ -16,6 +16,7 @@ struct AssembleArgs {
   int B, T, L, C;
   float* video; int32_t* lens; int32_t* word_ids; int32_t* char_ids;
   float* y1; float* y2; int32_t* match; float* inner;
+  const int64_t* carry_src; int64_t* carry_dst; int carry_n;      // optional: 8-byte words copied by one block of the launch (0: none)
 };
 
 int launch_assemble(const AssembleArgs& a, hipStream_t s);

@@ -2,19 +2,23 @@
 // pad_seq / pad_char_seq / pad_video_seq (/root/reference/utils/data_utils.py:130-172) do with numpy per step, from a
 // training set that stays RESIDENT in HBM (Charades: 12.4 k clips x 64 x 1024 fp32 = 3.2 GB of the 288 GB).  The host
 // only picks the sample ids of the batch and its padded sizes (T, L, C = maxima of lengths it already knows).
-//   assemble_video_kernel : [B,T,V] zero-padded gather of the feature rows (HBM bound: reads the valid rows once,
-//                           writes B*T*V floats once, 16-byte accesses)
-//   assemble_side_kernel  : one block per sample - word ids, char ids, lengths, soft start/end labels, 4-class
-//                           match labels, inner labels (bit exact with the reference's float32 results)
+// ONE launch (round 5: two launches + the caller's copy of the previous step's spans were three eager operations between two
+// replayed step graphs, ~13 us of idle device each - the epoch loop ran at 0.938 of the resident-batch rate for 26 us of kernels):
+//   blocks [0, B)      : one block per sample - word ids, char ids, lengths, soft start/end labels, 4-class match
+//                        labels, inner labels (bit exact with the reference's float32 results)
+//   block  B           : optional carry - copies `carry_n` 8-byte words (the spans the PREVIOUS step left in its fetch buffer) to
+//                        their place in the caller's epoch-long bank
+//   blocks (B, ..)     : [B,T,V] zero-padded gather of the feature rows (HBM bound: reads the valid rows once, writes B*T*V floats
+//                        once, 16-byte accesses)
 #include "assemble.h"
 #include "prof.h"
 
 using namespace hual;
 
-__global__ __launch_bounds__(256) void assemble_video_kernel(AssembleArgs a) {
+__device__ __forceinline__ void assemble_video_body(const AssembleArgs& a, int blk, int nblk) {
   const int v4 = a.vdim >> 2;
   const size_t total = (size_t)a.B * a.T * v4;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = blk * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)nblk * blockDim.x) {
     const int c = (int)(i % v4);
     const size_t r = i / v4;
     const int t = (int)(r % a.T), b = (int)(r / a.T);
@@ -27,8 +31,7 @@ __global__ __launch_bounds__(256) void assemble_video_kernel(AssembleArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void assemble_side_kernel(AssembleArgs a) {
-  const int b = blockIdx.x;
+__device__ __forceinline__ void assemble_side_body(const AssembleArgs& a, int b) {
   const int s = a.sel[b];
   const int vid = a.sample_vid[s];
   const int n = (int)(a.feat_off[vid + 1] - a.feat_off[vid]);
@@ -85,6 +88,16 @@ __global__ __launch_bounds__(256) void assemble_side_kernel(AssembleArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
+  const int blk = blockIdx.x;
+  if (blk < a.B) { assemble_side_body(a, blk); return; }
+  if (blk == a.B) {
+    for (int i = threadIdx.x; i < a.carry_n; i += blockDim.x) a.carry_dst[i] = a.carry_src[i];
+    return;
+  }
+  assemble_video_body(a, blk - a.B - 1, (int)gridDim.x - a.B - 1);
+}
+
 namespace hual {
 
 int launch_assemble(const AssembleArgs& a, hipStream_t s) {
@@ -96,8 +109,8 @@ int launch_assemble(const AssembleArgs& a, hipStream_t s) {
   const size_t total = (size_t)a.B * a.T * (a.vdim >> 2);
   const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   const double valid_guess = 0.75;     // bytes read depend on the lengths; reported figure assumes 3/4 valid rows
-  HUAL_LAUNCH(0.0, 4.0 * (double)a.B * a.T * a.vdim * (1.0 + valid_guess), assemble_video_kernel, dim3(grid), dim3(256), 0, s, a);
-  HUAL_LAUNCH(0.0, 0.0, assemble_side_kernel, dim3(a.B), dim3(256), 0, s, a);
+  HUAL_REQUIRE(a.carry_n == 0 || (a.carry_n > 0 && a.carry_src && a.carry_dst), "assemble: carry needs source, destination and a count");
+  HUAL_LAUNCH(0.0, 4.0 * (double)a.B * a.T * a.vdim * (1.0 + valid_guess), assemble_kernel, dim3(grid + a.B + 1), dim3(256), 0, s, a);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -109,6 +122,14 @@ extern "C" {
 int hual_assemble_batch(const hual_dataset* ds, const int32_t* sel, int B, int T, int L, int C, float* video,
                         int32_t* video_seq_len, int32_t* word_ids, int32_t* char_ids, float* y1, float* y2,
                         int32_t* match_labels, float* inner_labels, void* stream) {
+  return hual_assemble_batch_carry(ds, sel, B, T, L, C, video, video_seq_len, word_ids, char_ids, y1, y2, match_labels, inner_labels,
+                                   nullptr, nullptr, 0, stream);
+}
+
+int hual_assemble_batch_carry(const hual_dataset* ds, const int32_t* sel, int B, int T, int L, int C, float* video,
+                              int32_t* video_seq_len, int32_t* word_ids, int32_t* char_ids, float* y1, float* y2,
+                              int32_t* match_labels, float* inner_labels, const int64_t* carry_src, int64_t* carry_dst, int carry_n,
+                              void* stream) {
   HUAL_REQUIRE(ds, "hual_assemble_batch: null dataset");
   AssembleArgs a{};
   a.feat_bank = ds->feat_bank; a.feat_off = ds->feat_off; a.vdim = ds->vdim; a.sample_vid = ds->sample_vid;
@@ -117,6 +138,7 @@ int hual_assemble_batch(const hual_dataset* ds, const int32_t* sel, int B, int T
   a.sel = sel; a.B = B; a.T = T; a.L = L; a.C = C;
   a.video = video; a.lens = video_seq_len; a.word_ids = word_ids; a.char_ids = char_ids;
   a.y1 = y1; a.y2 = y2; a.match = match_labels; a.inner = inner_labels;
+  a.carry_src = carry_src; a.carry_dst = carry_dst; a.carry_n = carry_n;
   return launch_assemble(a, (hipStream_t)stream);
 }
 

@@ -91,11 +91,12 @@ class DeviceDataset:
                        match_labels=torch.empty(B * T, dtype=i32, device=d), inner_labels=torch.empty(B * T, dtype=f32, device=d))
         return buf
 
-    def assemble(self, sel, out=None, labels=True, min_chars=None, buffers=None, sel_dev=None):
+    def assemble(self, sel, out=None, labels=True, min_chars=None, buffers=None, sel_dev=None, carry=None):
         """Gather the batch `sel` (sample ids) on the device.  Returns a dict of device tensors named like the feeds of
         model.py:16-27.  out: a dict from a previous call with the same shape to write into (static buffers).
         buffers: feed_buffers() - the returned tensors are views of them (no allocation).  sel_dev: the same ids already on the
-        device (a slice of the epoch's permutation): nothing is uploaded for this batch."""
+        device (a slice of the epoch's permutation): nothing is uploaded for this batch.  carry: (src, dst) int64 device tensors of
+        equal size - the launch also copies src to dst (hual_assemble_batch_carry: the previous step's spans into the epoch's bank)."""
         sel = np.ascontiguousarray(sel, dtype=np.int32)
         B = len(sel)
         T, L, C = self.batch_shape(sel)
@@ -126,8 +127,13 @@ class DeviceDataset:
             assert sel_dev.dtype == torch.int32 and sel_dev.numel() == B and sel_dev.is_cuda
             out['sel'] = sel_dev
         p = lib.ptr
-        lib.check(self._lib.hual_assemble_batch(
+        csrc, cdst, cn = None, None, 0
+        if carry is not None:
+            src, dst = carry
+            assert src.dtype == torch.int64 and dst.dtype == torch.int64 and src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+            csrc, cdst, cn = p(src), p(dst), src.numel()
+        lib.check(self._lib.hual_assemble_batch_carry(
             ctypes.byref(self.ds), p(out['sel']), B, T, L, C, p(out['video']), p(out['video_seq_len']), p(out['word_ids']),
             p(out['char_ids']), p(out['y1']) if labels else None, p(out['y2']) if labels else None,
-            p(out['match_labels']) if labels else None, p(out['inner_labels']) if labels else None, lib.stream_ptr()))
+            p(out['match_labels']) if labels else None, p(out['inner_labels']) if labels else None, csrc, cdst, cn, lib.stream_ptr()))
         return out

@@ -124,6 +124,7 @@ def load():
     lib.hual_al_score.argtypes = [P(hual_al_set), vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]
     lib.hual_al_renew.argtypes = [P(hual_al_set), vp, i32, vp, vp, vp, P(ctypes.c_double), vp, vp]
     lib.hual_assemble_batch.argtypes = [P(hual_dataset), vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.hual_assemble_batch_carry.argtypes = [P(hual_dataset), vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     _lib = lib
     return lib
 

@@ -365,7 +365,7 @@ class Trainer:
         Nothing in the loop waits for the device and nothing is uploaded per step: the permutation goes up ONCE, a batch's ids
         are a slice of it; the feeds are views of one set of max-shape buffers; the workspace and the fetch tensors are sized
         once; a step is one hipGraph launch for every padded shape seen before (set_batch_device); the spans of each step are
-        copied (device to device) into an epoch-long bank that is fetched with ONE transfer after the last step - the
+        copied (device to device, by the NEXT step's assembly launch) into an epoch-long bank that is fetched with ONE transfer after the last step - the
         reference's IoU bookkeeping (runner_utils.py:150-156) only needs them at the end of the epoch.
         Returns (start, end) int64 numpy arrays in the order of `order` (None, None with want_spans False)."""
         m = self.m
@@ -382,13 +382,14 @@ class Trainer:
         for i in range(nsteps):
             lo = i * bs
             sel = order[lo:lo + bs]
-            feeds = dataset.assemble(sel, min_chars=min_chars, buffers=self._feeds, sel_dev=order_dev[lo:lo + len(sel)])
+            # (the spans of step i - 1 ride into the bank inside step i's assembly launch: one eager operation between two step graphs)
+            feeds = dataset.assemble(sel, min_chars=min_chars, buffers=self._feeds, sel_dev=order_dev[lo:lo + len(sel)],
+                                     carry=(self.spans, bank[i - 1]) if want_spans and i > 0 else None)
             self.set_batch_device(feeds)
             self.step(lr=lr, drop_rate=drop_rate)
-            if want_spans:
-                bank[i].copy_(self.spans)
         if not want_spans:
             return None, None
+        bank[nsteps - 1].copy_(self.spans)
         host = bank.cpu().numpy()                                # the epoch's only device -> host transfer (and only sync)
         st = np.concatenate([host[i, 0, :len(order[i * bs:(i + 1) * bs])] for i in range(nsteps)])
         en = np.concatenate([host[i, 1, :len(order[i * bs:(i + 1) * bs])] for i in range(nsteps)])

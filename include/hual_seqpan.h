@@ -328,6 +328,13 @@ typedef struct hual_dataset {
 int hual_assemble_batch(const hual_dataset* ds, const int32_t* sel, int B, int T, int L, int C, float* video,
                         int32_t* video_seq_len, int32_t* word_ids, int32_t* char_ids, float* y1, float* y2,
                         int32_t* match_labels, float* inner_labels, void* stream);
+/* The same launch with a CARRY: one of its workgroups also copies carry_n 8-byte words from carry_src to carry_dst (carry_n = 0: none).
+ * For epoch loops that bank what the PREVIOUS step left in its fetch buffers (the predicted spans, runner_utils.py:150-156) without an
+ * operation of their own between two replayed step graphs: every eager operation there costs ~13 us of idle device. */
+int hual_assemble_batch_carry(const hual_dataset* ds, const int32_t* sel, int B, int T, int L, int C, float* video,
+                              int32_t* video_seq_len, int32_t* word_ids, int32_t* char_ids, float* y1, float* y2,
+                              int32_t* match_labels, float* inner_labels, const int64_t* carry_src, int64_t* carry_dst, int carry_n,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Active-learning label update (BASELINE.json configs[4]): what /root/reference/update_label.py does
