@@ -448,9 +448,10 @@ __device__ __forceinline__ float att_wave_max(float v) {      // DPP / permlane 
   v = fast_max32(v);
   return fmaxf(v, lane_xor32_partner(v));
 }
+template <int NW = 4>
 __device__ __forceinline__ void att_wave_max2_put(float* Red, float a, float b) {
   a = att_wave_max(a); b = att_wave_max(b);
-  if ((threadIdx.x & 63) == 0) { Red[threadIdx.x >> 6] = a; Red[4 + (threadIdx.x >> 6)] = b; }
+  if ((threadIdx.x & 63) == 0) { Red[threadIdx.x >> 6] = a; Red[NW + (threadIdx.x >> 6)] = b; }
 }
 
 // LDS map of one (job, clip, head), Tqp = Tq rounded up to 32 queries, Tkp likewise:
@@ -460,10 +461,11 @@ __device__ __forceinline__ void att_wave_max2_put(float* Red, float a, float b) 
 //   Mk       [nqt][nkt][4]   keep words of the head (8 bytes each, forward layout)
 //   dQw      [4 waves][Tqp][16]  fp32 dQ partial products, one slot per wave (plain stores: float atomics on LDS retire at
 //                            about one lane per clock and cost more than the rest of the kernel)
-//   Xs       [4 waves][32][20]   transposition scratch
-//   Red      [16]            per-wave maxima of |dO| and |delta| (staging), then the two workgroup maxima at [8], [9]
+//   Xs       [waves][32][20]     transposition scratch
+//   Red      [16]            per-wave maxima of |dO| and |delta| (staging)
+// (nw = waves of the workgroup: 4, or 8 for the large job of a launch whose jobs do not fit two workgroups per CU - attn_bwd_big_kernel)
 struct BwdLds { int qp, dp, kp, st, mk, dqw, xs, red, total; };
-__host__ __device__ inline BwdLds bwd_lds(int Tq, int Tk, bool dropout) {
+__host__ __device__ inline BwdLds bwd_lds(int Tq, int Tk, bool dropout, int nw = 4) {
   const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
   BwdLds l;
   int o = 0;
@@ -473,7 +475,7 @@ __host__ __device__ inline BwdLds bwd_lds(int Tq, int Tk, bool dropout) {
   l.st = o; o += 7 * Tqp * 4;
   l.mk = o; o += dropout ? ((Tq + 15) >> 4) * ((Tk + 15) >> 4) * 32 : 0;
   l.dqw = o; o += 4 * Tqp * 64;
-  l.xs = o; o += 4 * 32 * 20 * 4;
+  l.xs = o; o += nw * 32 * 20 * 4;
   l.red = o; o += 64;
   l.total = o;
   return l;
@@ -511,15 +513,16 @@ __device__ __forceinline__ void attn_bwd_load_v(const AttnJob& job, int b, int h
 __device__ __forceinline__ bool attn_bwd_qsplit(int Tq, int Tk) { return (((Tk + 31) & ~31) >> 5) == 1 && (((Tq + 31) & ~31) >> 5) >= 4; }
 
 // ---- staging of a job (any shape up to 256 x 256): loads and LDS stores in one piece
-template <bool DROP>
+template <bool DROP, int NW = 4>
 __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h, char* lds) {
+  constexpr int NT = 64 * NW;                           // threads of the workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
   const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
   const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
   constexpr bool dodrop = DROP;
-  const BwdLds L = bwd_lds(Tq, Tk, dodrop);
+  const BwdLds L = bwd_lds(Tq, Tk, dodrop, NW);
   const int nqt = (Tq + 15) >> 4, nkt = (Tk + 15) >> 4;
   char* Qp = lds + L.qp; char* Dp = lds + L.dp; char* Kp = lds + L.kp;
   float* St = reinterpret_cast<float*>(lds + L.st);
@@ -538,13 +541,14 @@ __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h,
   // before the first split / LDS store: one memory round trip (a pass per 64 rows used to wait for its own loads, and the loads
   // of the statistics sat behind a lane-dependent branch: three to five serial round trips in front of the products)
   const int stat_n = job.B * Tq * 8;
-  const int npass = (max(Tqp, Tkp) * 4 + 255) >> 8;
-  constexpr int MAXP = 4;                               // Tq, Tk <= 256
+  const int npass = (max(Tqp, Tkp) * 4 + NT - 1) / NT;
+  constexpr int MAXP = 1024 / NT;                       // Tq, Tk <= 256: four passes of 256 threads, two of 512
   float4 sq[MAXP], sd[MAXP], so[MAXP], sk[MAXP];
   float ssm[MAXP], ssi[MAXP], sqm[MAXP];
-  uint2 mkw[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
-  const int nmk = dodrop ? nqt * nkt * 4 : 0;           // keep words of the head (<= 16 x 16 x 4 = 1024: four per thread)
-  uint2 mkx[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+  uint2 mkw[MAXP];                                      // keep words of the head (<= 16 x 16 x 4 = 1024: MAXP per thread)
+#pragma unroll
+  for (int it = 0; it < MAXP; ++it) mkw[it] = make_uint2(0u, 0u);
+  const int nmk = dodrop ? nqt * nkt * 4 : 0;
   // order of the requests = order of arrival = order of use: dO and O first (the workgroup maximum of |dO| - the scale of the dO panel -
   // is the one thing everything else has to wait for), then Q / K, whose panels (fixed scale) are split and stored while that
   // maximum crosses the workgroup, then the statistics and the keep words
@@ -552,7 +556,7 @@ __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h,
   for (int it = 0; it < MAXP; ++it) {
     sd[it] = so[it] = f4zero();
     if (it < npass) {                                   // (workgroup-uniform)
-      const int idx = threadIdx.x + 256 * it, row = idx >> 2, c4 = idx & 3;
+      const int idx = threadIdx.x + NT * it, row = idx >> 2, c4 = idx & 3;
       const int qr = min(row, Tq - 1);
       sd[it] = ld4(Dg + (size_t)qr * job.lddo + 4 * c4);
       so[it] = ld4(Og + (size_t)qr * job.ldo + 4 * c4);
@@ -563,7 +567,7 @@ __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h,
     sq[it] = sk[it] = f4zero();
     ssm[it] = ssi[it] = sqm[it] = 0.f;
     if (it < npass) {
-      const int idx = threadIdx.x + 256 * it, row = idx >> 2, c4 = idx & 3;
+      const int idx = threadIdx.x + NT * it, row = idx >> 2, c4 = idx & 3;
       const int qr = min(row, Tq - 1), kr = min(row, Tk - 1);
       sq[it] = ld4(Qg + (size_t)qr * job.ldq + 4 * c4);
       sk[it] = ld4(Kg + (size_t)kr * job.ldkv + 4 * c4);
@@ -575,10 +579,8 @@ __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h,
   }
   if (dodrop) {
     const uint2* src = reinterpret_cast<const uint2*>(job.dmask + (size_t)(b * 8 + h) * nqt * nkt * 32);
-    mkw[0] = src[min((int)threadIdx.x, nmk - 1)];
-    mkw[1] = src[min((int)threadIdx.x + 256, nmk - 1)];
-    mkx[0] = src[min((int)threadIdx.x + 512, nmk - 1)];
-    mkx[1] = src[min((int)threadIdx.x + 768, nmk - 1)];
+#pragma unroll
+    for (int it = 0; it < MAXP; ++it) mkw[it] = src[min((int)threadIdx.x + NT * it, nmk - 1)];
   }
   // delta = dO . O per query row; the head's largest |dO| and |delta| (scales of the dO panel and of dS): per-wave maxima into LDS
   float part[MAXP], gmax = 0.f, dmax = 0.f;
@@ -586,7 +588,7 @@ __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h,
   for (int it = 0; it < MAXP; ++it) {
     part[it] = 0.f;
     if (it < npass) {
-      const int row = (threadIdx.x + 256 * it) >> 2;
+      const int row = (threadIdx.x + NT * it) >> 2;
       const bool qok = row < Tq;
       const float4 dv = sd[it], ov = so[it];
       float pt = qok ? (dv.x * ov.x + dv.y * ov.y) + (dv.z * ov.z + dv.w * ov.w) : 0.f;
@@ -598,11 +600,11 @@ __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h,
     }
   }
   // the per-wave maxima go to LDS as they are: attn_bwd_compute combines them behind the barrier that ends the staging anyway
-  att_wave_max2_put(reinterpret_cast<float*>(lds + L.red), gmax, dmax);
+  att_wave_max2_put<NW>(reinterpret_cast<float*>(lds + L.red), gmax, dmax);
 #pragma unroll
   for (int it = 0; it < MAXP; ++it) {
     if (it < npass) {
-      const int idx = threadIdx.x + 256 * it, row = idx >> 2, c4 = idx & 3;
+      const int idx = threadIdx.x + NT * it, row = idx >> 2, c4 = idx & 3;
       const bool qok = row < Tq;
       // dO row: its OWN power-of-two scale (the four lanes of a row agree on the row maximum with two quad steps) - no workgroup-wide
       // quantity in front of the panel stores.  dP = dO . V^T contracts along the row (any row scale divides out per row, St[6]);
@@ -634,23 +636,29 @@ __device__ __forceinline__ void attn_bwd_stage(const AttnJob& job, int b, int h,
   }
   if (dodrop) {
     uint2* mk2 = reinterpret_cast<uint2*>(Mk);
-    if ((int)threadIdx.x < nmk) mk2[threadIdx.x] = mkw[0];
-    if ((int)threadIdx.x + 256 < nmk) mk2[threadIdx.x + 256] = mkw[1];
-    if ((int)threadIdx.x + 512 < nmk) mk2[threadIdx.x + 512] = mkx[0];
-    if ((int)threadIdx.x + 768 < nmk) mk2[threadIdx.x + 768] = mkx[1];
+#pragma unroll
+    for (int it = 0; it < MAXP; ++it)
+      if ((int)threadIdx.x + NT * it < nmk) mk2[threadIdx.x + NT * it] = mkw[it];
   }
 }
 
 // ---- products + epilogue of a staged job (ends with the dQ stores; the caller separates it from the next staging by a barrier)
-template <bool DROP>
+// NW = 8 (attn_bwd_big_kernel: a job of more than 128 queries AND keys, whose 137 KB of LDS leave room for one workgroup per CU - with
+// four waves that is ONE wave per SIMD, and neither pipe of a SIMD works under the other's latency): every wave takes ONE block of 32
+// keys, so dK / dV stay private to a wave; the dQ slot of key blocks w and w + 4 is shared by waves w and w + 4, which walk the query
+// pairs in lockstep - a workgroup barrier per pair - half a revolution apart (wave w + 4 starts at pair h = ceil(nqp / 2)): at every
+// step the two waves touch different rows of the slot, and the barrier orders a row's first write (by the wave that gets there first:
+// w for pairs < h, w + 4 for pairs >= h) before the other wave's read-modify-write.
+template <bool DROP, int NW = 4>
 __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int h, char* lds, const DropCfg& drop, BwdV& bv, bool have_v) {
+  constexpr int NT = 64 * NW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int Tq = job.Tq, Tk = job.Tk;
   const int Tqp = (Tq + 31) & ~31, Tkp = (Tk + 31) & ~31;
   const int qbase = job.qrow0 + b * Tq, kbase = job.krow0 + b * Tk;
   constexpr bool dodrop = DROP;
-  const BwdLds L = bwd_lds(Tq, Tk, dodrop);
+  const BwdLds L = bwd_lds(Tq, Tk, dodrop, NW);
   const int nqt = (Tq + 15) >> 4, nkt = (Tk + 15) >> 4;
   char* Qp = lds + L.qp; char* Dp = lds + L.dp; char* Kp = lds + L.kp;
   float* St = reinterpret_cast<float*>(lds + L.st);
@@ -670,7 +678,7 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
   // ONE block of <= 32 keys and at least four 32-query pairs (the video -> query jobs): the waves split the QUERIES instead of the
   // keys - all four work on key block 0, wave w takes the query pairs w, w + 4, ..; dQ rows are then disjoint (one slot), and the
   // partial dK / dV of the waves are summed through the three free slots
-  const bool qsplit = nkp == 1 && nqp >= 4;
+  const bool qsplit = NW == 4 && nkp == 1 && nqp >= 4;
   if (!have_v && (wave < nkp || qsplit)) load_v(qsplit ? 0 : wave);
   const float scale8 = drop.scale;                  // exactly 1 / (1 - rate)
   // scales (see the header of this section): the head's largest |dO| and |delta| come from the staging
@@ -678,7 +686,12 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
   // (wave-uniform values: through readfirstlane into scalar registers, with everything derived from them)
   float gmax, dmax;
   {
-    const float4 va = *reinterpret_cast<const float4*>(Red), vb = *reinterpret_cast<const float4*>(Red + 4);
+    float4 va = *reinterpret_cast<const float4*>(Red), vb = *reinterpret_cast<const float4*>(Red + NW);
+    if (NW == 8) {
+      const float4 va2 = *reinterpret_cast<const float4*>(Red + 4), vb2 = *reinterpret_cast<const float4*>(Red + 12);
+      va = make_float4(fmaxf(va.x, va2.x), fmaxf(va.y, va2.y), fmaxf(va.z, va2.z), fmaxf(va.w, va2.w));
+      vb = make_float4(fmaxf(vb.x, vb2.x), fmaxf(vb.y, vb2.y), fmaxf(vb.z, vb2.z), fmaxf(vb.w, vb2.w));
+    }
     gmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w)))));
     dmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)))));
   }
@@ -689,10 +702,12 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
   const float m_dp0 = (dodrop ? scale8 : 1.0f) / ATT_SX;      // dP = dO . V^T: (s_q dO) . (16 V) -> x 1 / (16 s_q) per row
   const float c_dv = sg_inv / ATT_SP;               // dV = Pd^T . dO with Pd_q x (sg / s_q) <= 1: sum_q (2^10 Pd sg / s_q) . (s_q dO)
   float c_dk = 0.f;                                 // 1 / (16 s_ds) of the current key block (dK, dQ)
-  float* slot = dQw + (qsplit ? 0 : wave) * Tqp * 16;
+  float* slot = dQw + (qsplit ? 0 : (wave & 3)) * Tqp * 16;
   bool first = true;
   const int qp0 = qsplit ? wave : 0, qpstep = qsplit ? 4 : 1;
-  for (int kp = qsplit ? 0 : wave; kp < nkp; kp += 4) {
+  const int hrev = (nqp + 1) >> 1;                  // (NW = 8) half a revolution of the query pairs
+  const bool partner = NW == 8 && wave < 4 && wave + 4 < nkp;      // (NW = 8, waves 0 .. 3) a wave shares this wave's dQ slot
+  for (int kp = qsplit ? 0 : wave; kp < nkp; kp += NW) {
     // B operands of this wave's 32 keys: [K_hi | K_hi], [K_lo | 0] and the same of V, per 16-key tile t
     bf16x8 Kb1[2], Kb2[2], Vb1[2], Vb2[2];
     int bsel[2];
@@ -725,7 +740,13 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
     const float m_pd0 = (dodrop ? scale8 : 1.0f) * ATT_SP * s_ds_inv * sg;      // pd = (p s_ds) m_pd0 / s_q = 2^10 (sg / s_q) x dropped probability
     const bf16x8 kh = panel_tr(Kp, 0, 32 * kp, lane), kl = panel_tr(Kp, 32, 32 * kp, lane);      // B operand of dQ
     f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int qp = qp0; qp < nqp; qp += qpstep) {
+    for (int qi = qp0; qi < nqp; qi += qpstep) {
+      int qp = qi;
+      bool fst = first;
+      if (NW == 8) {
+        if (wave >= 4) { qp = qi + hrev; qp = qp >= nqp ? qp - nqp : qp; fst = qp >= hrev; }
+        else fst = !partner || qp < hrev;
+      }
       float pd[2][2][4], ds[2][2][4];          // [t][u][r]
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -810,8 +831,9 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
         dq = mfma_h(xl, kh, dq);               // lane: 16 s_ds dQ[query 4 g + r][head dim j] of these keys
         float* dst = slot + (32 * qp + 16 * u + 4 * g) * 16 + j;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[16 * r] = first ? dq[r] * c_dk : fmaf(dq[r], c_dk, dst[16 * r]);
+        for (int r = 0; r < 4; ++r) dst[16 * r] = fst ? dq[r] * c_dk : fmaf(dq[r], c_dk, dst[16 * r]);
       }
+      if (NW == 8) att_lds_barrier();          // the slot's rows of this step are written before the other wave comes to them
     }
     first = false;
     if (qsplit) {      // partial dK / dV of this wave's queries -> slots 1 .. 3 as [wave][dk | dv][t][r][lane]; summed below
@@ -836,6 +858,9 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
         }
       }
   }
+  if (NW == 8 && !(wave < nkp)) {               // a wave without a key block (Tk <= 224) keeps the others' step barriers company
+    for (int qi = 0; qi < nqp; ++qi) att_lds_barrier();
+  }
   ATT_STAMP(3);
   __syncthreads();
   ATT_STAMP(4);
@@ -853,7 +878,7 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
   }
   // dQ = 0.25 * sum of the slots of the waves that had keys
   const int nw = qsplit ? 1 : min(4, nkp);
-  for (int idx = threadIdx.x; idx < Tq * 4; idx += 256) {
+  for (int idx = threadIdx.x; idx < Tq * 4; idx += NT) {
     const int q = idx >> 2, c4 = idx & 3;
     float4 v = reinterpret_cast<const float4*>(dQw)[idx];
     for (int w = 1; w < nw; ++w) {
@@ -865,20 +890,20 @@ __device__ __forceinline__ void attn_bwd_compute(const AttnJob& job, int b, int 
   ATT_STAMP(5);
 }
 
-template <bool DROP>
+template <bool DROP, int NW = 4>
 __device__ __forceinline__ void attn_bwd_body(const AttnJob& job, int b, int h, char* lds, const DropCfg& drop) {
   const int wave = threadIdx.x >> 6;
   const int nkp = ((job.Tk + 31) & ~31) >> 5;
-  const bool qsplit = attn_bwd_qsplit(job.Tq, job.Tk);
+  const bool qsplit = NW == 4 && attn_bwd_qsplit(job.Tq, job.Tk);
   BwdV bv;
   ATT_STAMP(0);
   // V rows of the wave's first 32 keys: requested before the staging so that they arrive under it
   if (wave < nkp || qsplit) attn_bwd_load_v<DROP>(job, b, h, qsplit ? 0 : wave, bv);
-  attn_bwd_stage<DROP>(job, b, h, lds);
+  attn_bwd_stage<DROP, NW>(job, b, h, lds);
   ATT_STAMP(1);
   __syncthreads();
   ATT_STAMP(2);
-  attn_bwd_compute<DROP>(job, b, h, lds, drop, bv, true);
+  attn_bwd_compute<DROP, NW>(job, b, h, lds, drop, bv, true);
 }
 
 // ---- the small jobs of a four-job launch in ONE workgroup.  Per (clip, head) the three small jobs cost 13-20 k cycles each as workgroups
@@ -1033,6 +1058,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnBatch batch, int n
   else attn_bwd_body<false>(job, b, h, lds, drop);
 }
 
+// A launch whose LARGEST job has more than 128 queries and keys (dual attention at T = 256): that job on eight waves
+// (attn_bwd_compute NW = 8); the other jobs of the launch as before on the first four waves of their workgroups - the other four
+// end at once (s_barrier waits for the surviving waves of a workgroup only).  Workgroup -> (job, clip) as in attn_bwd_kernel.
+__global__ __launch_bounds__(512) void attn_bwd_big_kernel(AttnBatch batch, int njobs, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int lid = xcd_logical_id();
+  const int h = lid & 7; lid >>= 3;
+  int jb = lid % njobs, b = lid / njobs;
+  {
+    const int per = (int)(gridDim.x >> 6);      // (job, clip) pairs per XCD
+    if ((gridDim.x & 63) == 0 && per % njobs == 0) {
+      const int cpx = per / njobs, x = lid / per, w = lid - x * per;
+      jb = w / cpx;
+      b = x * cpx + (w - jb * cpx);
+    }
+  }
+  const AttnJob& job = batch.j[jb];
+  if (b >= job.B) return;   // block-uniform
+  const bool dd = job.drop_site >= 0 && drop.enabled;
+  if (jb == 0) {
+    if (dd) attn_bwd_body<true, 8>(job, b, h, lds, drop);
+    else attn_bwd_body<false, 8>(job, b, h, lds, drop);
+    return;
+  }
+  if (threadIdx.x >= 256) return;               // (wave-uniform)
+  if (dd) attn_bwd_body<true>(job, b, h, lds, drop);
+  else attn_bwd_body<false>(job, b, h, lds, drop);
+}
+
 namespace hual {
 
 static int check_jobs(const AttnJob* jobs, int n, bool bwd, const DropCfg& drop, int& maxTq, int& maxTk, int& maxB) {
@@ -1060,6 +1114,10 @@ static int check_jobs(const AttnJob* jobs, int n, bool bwd, const DropCfg& drop,
   return 0;
 }
 
+static bool getenv_flag(const char* name) {
+  const char* v = getenv(name);
+  return v != nullptr && atoi(v) != 0;
+}
 static int nkt_pad_host(int Tk) {
   const int n = cdiv(Tk, 16);
   return n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : 16;
@@ -1150,6 +1208,22 @@ int launch_attn_bwd(const AttnJob* jobs, int n, const DropCfg& drop, hipStream_t
     HUAL_LAUNCH(4.0 * flops, bytes, attn_bwd_chain_kernel, dim3(maxB * 8 * 2), dim3(256), lds, s, b, drop);
     HUAL_CHECK_HIP(hipGetLastError());
     return 0;
+  }
+  // the largest job beyond 128 queries AND keys (its workgroup fills a CU's LDS): eight waves for it (attn_bwd_big_kernel)
+  if (b.j[0].Tq > 128 && b.j[0].Tk > 128 && !getenv_flag("HUAL_ATTN_NO_BIG")) {
+    size_t lds8 = (size_t)bwd_lds(b.j[0].Tq, b.j[0].Tk, b.j[0].drop_site >= 0 && drop.enabled, 8).total;
+    for (int k = 1; k < n; ++k) {
+      const size_t need = (size_t)bwd_lds(b.j[k].Tq, b.j[k].Tk, b.j[k].drop_site >= 0 && drop.enabled).total;
+      lds8 = need > lds8 ? need : lds8;
+    }
+    bool ok = lds8 <= 160 * 1024;
+    for (int k = 1; k < n; ++k) ok = ok && !(b.j[k].Tq > 128 && b.j[k].Tk > 128) && b.j[k].B == b.j[0].B;      // one large job per launch
+    if (ok) {
+      HUAL_DYN_LDS(attn_bwd_big_kernel, 160 * 1024);
+      HUAL_LAUNCH(4.0 * flops, bytes, attn_bwd_big_kernel, dim3(maxB * 8 * n), dim3(512), lds8, s, b, n, drop);
+      HUAL_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
   }
   HUAL_DYN_LDS(attn_bwd_kernel, 160 * 1024);
   dim3 grid(maxB * 8 * n), block(256);

@@ -130,7 +130,13 @@ def test_conv_block_fwd_bwd(shape):
     _check_param_grads(blk, pr, lambda k: k.startswith('conv_block/'))
 
 
-@pytest.mark.parametrize('shape', SHAPES)
+# clips of more than 128 frames: the backward's large job runs on eight waves (csrc/attn.hip attn_bwd_big_kernel): all eight key blocks,
+# six of them (two idle waves, three waves without a partner on their dQ slot), an odd number of query pairs
+DA_LONG_SHAPES = [dict(B=2, T=256, L=20, C=4, seed=41, max_vlen=256), dict(B=3, T=170, L=9, C=4, seed=42, max_vlen=192),
+                  dict(B=2, T=131, L=12, C=4, seed=43, max_vlen=160)]
+
+
+@pytest.mark.parametrize('shape', SHAPES + DA_LONG_SHAPES)
 @pytest.mark.parametrize('layer', [0, 1])
 def test_dual_attn_fwd_bwd(shape, layer):
     blk = Block(**shape)
