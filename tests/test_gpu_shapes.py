@@ -116,6 +116,13 @@ def test_t256_configs3_shape():
     _check_all(case, 0.1)
 
 
+def test_long_clips_without_dropout():
+    """T > 128 with dropout OFF (evaluation-style step): the no-dropout instantiations of the long-clip kernels - the eight-wave attention
+    backward job (csrc/attn.hip attn_bwd_big_kernel) and the 16-wave context-query kernels (csrc/cqwide.hip) - on a ragged length"""
+    case = pu.make_case(B=2, T=200, L=17, C=5, seed=53, max_vlen=224)
+    _check_all(case, 0.0)
+
+
 def test_long_queries():
     """L = 40 words (> 32): the staged context-query kernels take their general softmax branches (rows / columns longer than
     a 32-lane half) - T + L still within their 160 padded rows"""
