@@ -16,7 +16,9 @@ int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStre
 // weight-gradient launch (embed_dw_job fills the same job without launching anything: workspace planning);
 // launch_embed_unpack must run after that launch.
 void embed_dw_job(const EmbedArgs& a, int nrows, DwJob* dwjob);
-int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const DropCfg& drop, hipStream_t s, DwJob* dwjob);
+int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const DropCfg& drop, hipStream_t s, DwJob* dwjob, bool finish = true);
+int embed_finish_blocks(const EmbedArgs& a, int nrows);      // workgroups / dynamic LDS bytes of the last step when it rides elsewhere
+int embed_finish_lds(const EmbedArgs& a);
 int launch_embed_unpack(const EmbedArgs& a, const EmbedGrads& g, hipStream_t s);
 int embed_unpack_tasks(const EmbedArgs& a);      // tasks / char_dim padding of the unpack (for the launch it rides in: rowops.h)
 int embed_unpack_cpad(const EmbedArgs& a);

@@ -99,40 +99,10 @@ __global__ __launch_bounds__(256) void char_pool_bwd_kernel(EmbedArgs a, EmbedGr
   if (x < 4 * CP * NALL + NALL) a.dfall[x] = 0.f;
 }
 
-// backward 2: fold the window gradients back to char slots:  d cemb[r][d] = sum_dk dXall[r - dk][dk*CP + d]  (same
-// word only), through the dropout mask, accumulated per char id.  Block = 64 slot rows, LDS accumulator per table row.
-#define EF_ROWS 64
+// backward 2 (embed_gather.h embed_finish_block) as a launch of its own
 __global__ __launch_bounds__(256) void embed_finish_kernel(EmbedArgs a, EmbedGrads gr, DropCfg drop, int nrows, int CP) {
   extern __shared__ float dT[];      // [(num_chars-1) * cd]
-  const int cd = a.char_dim, C = a.C;
-  const int ntab = (a.num_chars - 1) * cd;
-  for (int i = threadIdx.x; i < ntab; i += 256) dT[i] = 0.f;
-  __syncthreads();
-  const int ngc = (cd + 3) >> 2;
-  const int M = nrows * C;
-  const int r0 = blockIdx.x * EF_ROWS;
-  for (int t = threadIdx.x; t < EF_ROWS * ngc; t += 256) {
-    const int r = r0 + t / ngc, g4 = t % ngc;
-    if (r >= M) break;
-    const int cid = a.char_ids[r];
-    if (cid <= 0) continue;
-    const int c = r % C;
-    float4 s = f4zero();
-    for (int dk = 0; dk < 4 && dk <= c; ++dk) {
-      const float4 v = ld4(a.dxall + (size_t)(r - dk) * 4 * CP + dk * CP + 4 * g4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    if (drop.enabled) s = apply_drop4(drop, HUAL_SITE_CHAR, (uint32_t)r, (uint32_t)g4, s);
-    const float sv[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (4 * g4 + q < cd) atomicAdd(&dT[(size_t)(cid - 1) * cd + 4 * g4 + q], sv[q]);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < ntab; i += 256) {
-    const float v = dT[i];
-    if (v != 0.f) atomicAdd(gr.dchar_table + i, v);
-  }
+  embed_finish_block(a, gr, drop, nrows, CP, blockIdx.x, dT);
 }
 
 // backward 3 (after the weight-gradient launch): packed dFall / dball -> filter and bias gradients (embed_gather.h embed_unpack_task;
@@ -186,7 +156,10 @@ int launch_embed_fwd(const EmbedArgs& a, int nrows, const DropCfg& drop, hipStre
   return 0;
 }
 
-int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const DropCfg& drop, hipStream_t s, DwJob* dwjob) {
+int embed_finish_blocks(const EmbedArgs& a, int nrows) { return cdiv(nrows * a.C, EF_ROWS); }
+int embed_finish_lds(const EmbedArgs& a) { return (a.num_chars - 1) * a.char_dim * (int)sizeof(float); }
+// finish = false: the caller lets the last step (embed_finish_block) ride in a later launch (rowops.h launch_colsum: EmbedUnpack)
+int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const DropCfg& drop, hipStream_t s, DwJob* dwjob, bool finish) {
   int rc = check_args(a);
   if (rc) return rc;
   HUAL_REQUIRE(dwjob != nullptr, "embed_bwd: null weight-gradient job");
@@ -213,6 +186,7 @@ int launch_embed_bwd(const EmbedArgs& a, const EmbedGrads& g, int nrows, const D
   if (rc) return rc;
   const size_t lds = (size_t)(a.num_chars - 1) * cd * sizeof(float);
   HUAL_REQUIRE(lds <= 64 * 1024, "embed_bwd: char table too large for the LDS accumulator");
+  if (!finish) return 0;
   HUAL_LAUNCH(0.0, 0.0, embed_finish_kernel, dim3(cdiv(M, EF_ROWS)), dim3(256), lds, s, a, g, drop, nrows, CP);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;

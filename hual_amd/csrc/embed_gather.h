@@ -87,3 +87,41 @@ __device__ __forceinline__ void embed_unpack_task(const hual::EmbedArgs& a, cons
     gr.dfbias[k - 1][chk] += a.dfall[(size_t)4 * CP * NALL + ch];
   }
 }
+
+// backward 2 of the text encoder front end (embed.hip): fold the window gradients back to char slots:
+//   d cemb[r][d] = sum_dk dXall[r - dk][dk*CP + d]  (same word only), through the dropout mask, accumulated per char id.
+// Workgroup `blk` (256 threads) = 64 slot rows, dT = its LDS accumulator [(num_chars - 1) * char_dim].  A launch of its own
+// (embed_finish_kernel) or further workgroups of the launch that folds the per-workgroup partial sums (rowops.h launch_colsum).
+#define EF_ROWS 64
+__device__ __forceinline__ void embed_finish_block(const hual::EmbedArgs& a, const hual::EmbedGrads& gr, const hual::DropCfg& drop, int nrows, int CP,
+                                                   int blk, float* dT) {
+  const int cd = a.char_dim, C = a.C;
+  const int ntab = (a.num_chars - 1) * cd;
+  for (int i = threadIdx.x; i < ntab; i += 256) dT[i] = 0.f;
+  __syncthreads();
+  const int ngc = (cd + 3) >> 2;
+  const int M = nrows * C;
+  const int r0 = blk * EF_ROWS;
+  for (int t = threadIdx.x; t < EF_ROWS * ngc; t += 256) {
+    const int r = r0 + t / ngc, g4 = t % ngc;
+    if (r >= M) break;
+    const int cid = a.char_ids[r];
+    if (cid <= 0) continue;
+    const int c = r % C;
+    float4 s = f4zero();
+    for (int dk = 0; dk < 4 && dk <= c; ++dk) {
+      const float4 v = ld4(a.dxall + (size_t)(r - dk) * 4 * CP + dk * CP + 4 * g4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (drop.enabled) s = apply_drop4(drop, HUAL_SITE_CHAR, (uint32_t)r, (uint32_t)g4, s);
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (4 * g4 + q < cd) atomicAdd(&dT[(size_t)(cid - 1) * cd + 4 * g4 + q], sv[q]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ntab; i += 256) {
+    const float v = dT[i];
+    if (v != 0.f) atomicAdd(gr.dchar_table + i, v);
+  }
+}

@@ -64,7 +64,9 @@ struct ColsumJob {
   int last_ncols;                      // > 0: the LAST vector only has this many columns (a destination shorter than 128)
 };
 // unpack (optional): the char-CNN filter-gradient unpack (embed_gather.h embed_unpack_task) as further workgroups of the launch
-struct EmbedUnpack { EmbedArgs a; EmbedGrads g; int CP; int ntasks; };
+// (+ optionally the last step of the text encoder's backward - embed_gather.h embed_finish_block: finish_blocks workgroups with
+//  finish_lds bytes of dynamic LDS - which depends on nothing the weight-gradient launch produces and so needs no launch of its own)
+struct EmbedUnpack { EmbedArgs a; EmbedGrads g; int CP; int ntasks; int finish_blocks; int finish_lds; int nrows; DropCfg drop; };
 int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s, const EmbedUnpack* unpack = nullptr);
 
 // dpos[t] += sum_b dx[b,t] (over the video rows, the query rows or both: the shared table serves both sides, model.py:53,56)

@@ -134,21 +134,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a, DropCfg drop) { ln
 // ------------------------------------------------------------------------------------------------------
 struct ColsumBatch { ColsumJob j[HUAL_COLSUM_MAX_JOBS]; };
 #define COLSUM_SPLIT 16   // independent row slices per (job, vector): the kernel is a chain of dependent-latency loads (18.5 us at 4, see profiles)
-__global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch batch, int njobs, EmbedUnpack eu) {
+// One grid row of workgroups: the riding embed_finish blocks FIRST (they are the long ones of the launch: dispatched behind the
+// thousands of short fold workgroups they were its tail - 16.2 us against 9.0 without them), then the fold / unpack workgroups in
+// the order (job or unpack column x, vector y, slice z), x fastest, of the former three-dimensional grid (rx, ry, rz = its dimensions).
+__global__ __launch_bounds__(256) void colsum_kernel(ColsumBatch batch, int njobs, EmbedUnpack eu, int rx, int ry) {
   __shared__ float part[HUAL_D];
-  if ((int)blockIdx.x >= njobs) {      // the workgroups behind the jobs: unpack tasks, one per thread
-    const int lid = (((int)blockIdx.x - njobs) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.z + (int)blockIdx.z;
+  extern __shared__ float colsum_dyn[];      // (embed_finish_block's accumulator, when that step rides here)
+  if ((int)blockIdx.x < eu.finish_blocks) {      // (block-uniform)
+    embed_finish_block(eu.a, eu.g, eu.drop, eu.nrows, eu.CP, (int)blockIdx.x, colsum_dyn);
+    return;
+  }
+  const int role = (int)blockIdx.x - eu.finish_blocks;
+  const int bx = role % rx, byz = role / rx, by = byz % ry, bz = byz / ry;
+  if (bx >= njobs) {      // the workgroups behind the jobs: unpack tasks, one per thread
+    const int lid = ((bx - njobs) * ry + by) * COLSUM_SPLIT + bz;
     const int gid = lid * 256 + (int)threadIdx.x;
     if (gid < eu.ntasks) embed_unpack_task(eu.a, eu.g, eu.CP, gid);
     return;
   }
-  const ColsumJob& job = batch.j[blockIdx.x];
-  const int vec = blockIdx.y;
+  const ColsumJob& job = batch.j[bx];
+  const int vec = by;
   if (vec >= job.nvec || job.dst[vec] == nullptr) return;     // block-uniform
   const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
   float s = 0.f;
 #pragma unroll 8
-  for (int r = blockIdx.z * 2 + half; r < job.nblk; r += 2 * COLSUM_SPLIT) s += job.src[((size_t)r * job.nvec + vec) * HUAL_D + c];
+  for (int r = bz * 2 + half; r < job.nblk; r += 2 * COLSUM_SPLIT) s += job.src[((size_t)r * job.nvec + vec) * HUAL_D + c];
   if (half) part[c] = s;
   __syncthreads();
   if (!half && !(job.last_ncols > 0 && vec == job.nvec - 1 && c >= job.last_ncols)) atomicAdd(job.dst[vec] + c, s + part[c]);
@@ -258,8 +268,16 @@ int launch_colsum(const ColsumJob* jobs, int n, hipStream_t s, const EmbedUnpack
   if (maxvec == 0) maxvec = 1;
   EmbedUnpack eu{};
   int xu = 0;
-  if (unpack) { eu = *unpack; xu = cdiv(cdiv(eu.ntasks, 256), maxvec * COLSUM_SPLIT); }
-  HUAL_LAUNCH(0.0, 0.0, colsum_kernel, dim3(n + xu, maxvec, COLSUM_SPLIT), dim3(256), 0, s, b, n, eu);
+  int lds = 0;
+  if (unpack) {
+    eu = *unpack;
+    xu = cdiv(cdiv(eu.ntasks, 256), maxvec * COLSUM_SPLIT);
+    lds = eu.finish_blocks > 0 ? eu.finish_lds : 0;
+    HUAL_REQUIRE(lds <= 64 * 1024, "colsum: LDS accumulator of the riding embed_finish blocks");
+  }
+  if (lds > 32 * 1024) HUAL_DYN_LDS(colsum_kernel, 64 * 1024);
+  const int rx = n + xu;
+  HUAL_LAUNCH(0.0, 0.0, colsum_kernel, dim3(eu.finish_blocks + rx * maxvec * COLSUM_SPLIT), dim3(256), lds, s, b, n, eu, rx, maxvec);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

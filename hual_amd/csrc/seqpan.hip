@@ -1172,7 +1172,8 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
     fill_embed_args(c, ea, bt, cat, catw, char_arg, embed_scratch);
     eg.dcat = d_cat; eg.lddcat = catw; eg.dunk = c.g(pm.unk); eg.dchar_table = c.g(pm.char_table);
     for (int i = 0; i < 4; ++i) { eg.dfilt[i] = c.g(pm.filt[i]); eg.dfbias[i] = c.g(pm.fbias[i]); }
-    c.chk(launch_embed_bwd(ea, eg, Nq, c.drop, c.stream, &embed_dw));
+    // (its last step - folding the window gradients into the char table's - rides in the launch that folds the partial sums, below)
+    c.chk(launch_embed_bwd(ea, eg, Nq, c.drop, c.stream, &embed_dw, false));
   }
   c.push_dw(embed_dw);
   const bool input_ran = c.active;
@@ -1182,7 +1183,10 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   // filter gradients (behind the weight-gradient launch) as further workgroups of the same launch
   EmbedUnpack eu{};
   const bool unpack = !c.dry && input_ran && c.active;
-  if (unpack) { eu.a = ea; eu.g = eg; eu.CP = embed_unpack_cpad(ea); eu.ntasks = embed_unpack_tasks(ea); }
+  if (unpack) {
+    eu.a = ea; eu.g = eg; eu.CP = embed_unpack_cpad(ea); eu.ntasks = embed_unpack_tasks(ea);
+    eu.finish_blocks = embed_finish_blocks(ea, Nq); eu.finish_lds = embed_finish_lds(ea); eu.nrows = Nq; eu.drop = c.drop;
+  }
   c.flush_colsum(unpack ? &eu : nullptr);
   (void)opt;
   return c.rc;
