@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace -d gpurun_out/tl -o tl --output-format csv -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline
     python scripts/step_timeline.py gpurun_out/tl/*kernel_trace.csv [--steps 20] [--group]
 
-A step starts at every `pack_weights_kernel` (the first launch of the forward; `prep_masks_kernel` in older traces); the last --steps complete steps are averaged position by position
+A step starts at every `pack_weights_kernel` (the first launch of the forward; `prep_masks_kernel` in older traces); --steps complete steps from the middle of the run are averaged position by position
 (duration and the idle gap in front of the kernel).
 """
 import argparse
@@ -48,7 +48,7 @@ def main():
     sig = sigs.most_common(1)[0][0]
     n = len(sig)
     same = [s for s in steps if tuple(k[2] for k in s) == sig]
-    print('%d kernels per step, %d steps with this launch sequence in the trace (of %d), averaging the last %d'
+    print('%d kernels per step, %d steps with this launch sequence in the trace (of %d), averaging %d from the middle of the run'
           % (n, len(same), len(steps), min(a.steps, len(same))))
     if a.stats:
         # per-kernel launch statistics over ALL steps of that sequence (the profiler's own --stats file mixes shapes)
@@ -60,7 +60,10 @@ def main():
             f.write('"Name","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs"\n')
             for nm, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
                 f.write('"%s",%d,%d,%.3f,%d,%d\n' % (nm, len(v), sum(v), sum(v) / len(v), min(v), max(v)))
-    steps = same[-a.steps:]
+    # from the MIDDLE of the run: the trace of a whole bench.py run ends with the legs behind the timed region (the roofline leg
+    # launches the same sequence eagerly, with events: ~2 us of host gap per launch) - the middle is the timed, replayed workload
+    mid = len(same) // 2
+    steps = same[max(0, mid - a.steps // 2):max(0, mid - a.steps // 2) + a.steps] if len(same) > 2 * a.steps else same[-a.steps:]
     tot = defaultdict(lambda: [0, 0.0, 0.0])
     t_sum = g_sum = 0.0
     for k in range(n):
