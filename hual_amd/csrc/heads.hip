@@ -169,6 +169,13 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
   const int col = 4 * l32;
   float4 w0 = ld4(a.Wm + (col + 0) * 4), w1 = ld4(a.Wm + (col + 1) * 4), w2 = ld4(a.Wm + (col + 2) * 4), w3 = ld4(a.Wm + (col + 3) * 4);
   float4 e0 = ld4(a.E + col), e1 = ld4(a.E + HUAL_D + col), e2 = ld4(a.E + 2 * HUAL_D + col), e3 = ld4(a.E + 3 * HUAL_D + col);
+  // the first row of every group is requested BEFORE the loss is closed (its denominator is a workgroup reduction over the forward's
+  // partial sums: a memory round trip and two barriers that the row loads do not depend on)
+  const int row0 = min((int)blockIdx.x * 8 + grp, rs.Nv - 1);
+  const size_t off0 = (size_t)row0 * HUAL_D + col;
+  float pmk = rs.rowmask[row0];
+  float4 pd = ld4(g.dOut + off0), pd2 = g.dOut2 ? ld4(g.dOut2 + off0) : f4zero();
+  float4 pf = ld4(a.fuse + off0), pp = *reinterpret_cast<const float4*>(a.probs + (size_t)row0 * 4);
   float denom = 1.0f;
   if (g.do_tail) {      // (uniform) the forward left the loss open: the denominator from its partial sums; workgroup 0 closes the loss
     __shared__ float smt[12];
@@ -180,15 +187,23 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(MatchArgs a, MatchBwd g,
   float4 dE0 = f4zero(), dE1 = f4zero(), dE2 = f4zero(), dE3 = f4zero();
   float4 dW0 = f4zero(), dW1 = f4zero(), dW2 = f4zero(), dW3 = f4zero();   // dWk = column k of dWm over this lane's 4 rows
   float db0 = 0.f, db1 = 0.f, db2 = 0.f, db3 = 0.f;
-#pragma unroll 2
   for (int row = blockIdx.x * 8 + grp; row < rs.Nv; row += gridDim.x * 8) {
     const size_t off = (size_t)row * HUAL_D + col;
-    const float mk = rs.rowmask[row];
-    float4 d = ld4(g.dOut + off);
-    if (g.dOut2) { const float4 d2 = ld4(g.dOut2 + off); d = make_float4(d.x + d2.x, d.y + d2.y, d.z + d2.z, d.w + d2.w); }
+    // this row's operands (requested one trip ahead); the next row's requests go out before this row's arithmetic
+    const float mk = pmk;
+    float4 d = pd;
+    if (g.dOut2) d = make_float4(d.x + pd2.x, d.y + pd2.y, d.z + pd2.z, d.w + pd2.w);
+    const float4 f = pf, p = pp;
+    {
+      const int rn = min(row + (int)gridDim.x * 8, rs.Nv - 1);
+      const size_t offn = (size_t)rn * HUAL_D + col;
+      pmk = rs.rowmask[rn];
+      pd = ld4(g.dOut + offn);
+      if (g.dOut2) pd2 = ld4(g.dOut2 + offn);
+      pf = ld4(a.fuse + offn);
+      pp = *reinterpret_cast<const float4*>(a.probs + (size_t)rn * 4);
+    }
     d = make_float4(d.x * mk, d.y * mk, d.z * mk, d.w * mk);   // through the *v_mask of model.py:97
-    const float4 f = ld4(a.fuse + off);
-    const float4 p = *reinterpret_cast<const float4*>(a.probs + (size_t)row * 4);
     float q0 = half_sum32(d.x * e0.x + d.y * e0.y + d.z * e0.z + d.w * e0.w);
     float q1 = half_sum32(d.x * e1.x + d.y * e1.y + d.z * e1.z + d.w * e1.w);
     float q2 = half_sum32(d.x * e2.x + d.y * e2.y + d.z * e2.z + d.w * e2.w);
