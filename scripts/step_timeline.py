@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace -d gpurun_out/tl -o tl --output-format csv -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline
     python scripts/step_timeline.py gpurun_out/tl/*kernel_trace.csv [--steps 20] [--group]
 
-A step starts at every `pack_weights_kernel` (the first launch of the forward; `prep_masks_kernel` in older traces); --steps complete steps from the middle of the run are averaged position by position
+A step starts at every `pack_weights_kernel` (the first launch of the forward; `prep_masks_kernel` in older traces); --steps complete steps from the middle of the run are reduced (median) position by position
 (duration and the idle gap in front of the kernel).
 """
 import argparse
@@ -48,7 +48,7 @@ def main():
     sig = sigs.most_common(1)[0][0]
     n = len(sig)
     same = [s for s in steps if tuple(k[2] for k in s) == sig]
-    print('%d kernels per step, %d steps with this launch sequence in the trace (of %d), averaging %d from the middle of the run'
+    print('%d kernels per step, %d steps with this launch sequence in the trace (of %d), median of %d from the middle of the run'
           % (n, len(same), len(steps), min(a.steps, len(same))))
     if a.stats:
         # per-kernel launch statistics over ALL steps of that sequence (the profiler's own --stats file mixes shapes)
@@ -66,9 +66,12 @@ def main():
     steps = same[max(0, mid - a.steps // 2):max(0, mid - a.steps // 2) + a.steps] if len(same) > 2 * a.steps else same[-a.steps:]
     tot = defaultdict(lambda: [0, 0.0, 0.0])
     t_sum = g_sum = 0.0
+    def med(v):      # (median over the selected steps: one profiler-buffer flush inside a step is a 4 ms gap in a 1.2 ms step)
+        v = sorted(v)
+        return (v[(len(v) - 1) // 2] + v[len(v) // 2]) / 2.0
     for k in range(n):
-        dur = sum(s[k][1] - s[k][0] for s in steps) / len(steps) / 1e3
-        gap = sum((s[k][0] - s[k - 1][1]) for s in steps) / len(steps) / 1e3 if k else 0.0
+        dur = med([s[k][1] - s[k][0] for s in steps]) / 1e3
+        gap = med([(s[k][0] - s[k - 1][1]) for s in steps]) / 1e3 if k else 0.0
         nm = short(steps[0][k][2])
         tot[nm][0] += 1
         tot[nm][1] += dur
@@ -77,7 +80,7 @@ def main():
         g_sum += gap
         if not a.group:
             print('%4d %-50s %8.2f us  gap %6.2f' % (k, nm, dur, gap))
-    span = sum(s[-1][1] - s[0][0] for s in steps) / len(steps) / 1e3
+    span = med([s[-1][1] - s[0][0] for s in steps]) / 1e3
     print('--- totals: kernel time %.1f us, gaps %.1f us, first-to-last span %.1f us' % (t_sum, g_sum, span))
     for nm, (cnt, d, g) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
         print('%-50s x%-3d %9.1f us  (avg %6.2f)  gaps %7.1f' % (nm, cnt, d, d / cnt, g))
