@@ -26,6 +26,7 @@ struct CqBufs {
   float* C2Q; float* Q2C;  // outputs
   float* SR; float* SC;    // [2][B][Tp*Lp] saved softmaxes (row / column)
   float* M2;               // [2][B][max(Tp,Lp)][128] scratch
+  float* GS;               // [2][B][Tp*Lp] score scratch of the global-memory form of the forward (cq_fwd_global(): else unused / null)
 };
 
 int cq_padded(int n);      // rows padded to a multiple of 16
@@ -39,6 +40,7 @@ struct CqBwdBufs {
   float* dD1W; float* dD2;        // [R,128] gradient wrt D1W / D2
   float* dS0; float* dS1;         // [R]
   float* dM2;                     // scratch like M2
+  float* GD;                      // [2][B][2][Tp*Lp] gradient scratch of the global-memory form of the backward (cq_bwd_global(): else null)
 };
 int launch_cq_bwd_pre(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, hipStream_t s);
 // dXa / dXb: dedicated [R,128] scratch (partial dX of the x1-role rows / x2-role rows of each direction)
@@ -53,6 +55,10 @@ int launch_tri_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const CqParams& p, 
 bool cq_wide_ok(const RowSpace& rs);
 int launch_cq_fwd_wide(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
 int launch_cq_bwd_wide(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, float* dXa, float* dXb, hipStream_t s);
+// shapes whose score matrices fit none of the LDS forms (long clips with queries of more than 32 words): the global-operand kernels keep
+// the matrices in global memory too - slow, but every T, L <= 256 runs.  The orchestrator sizes GS / GD by these.
+bool cq_fwd_global(int B, int T, int L);
+bool cq_bwd_global(int B, int T, int L);
 size_t cq_mat_elems_host(int T, int L);   // floats per saved softmax matrix (per clip, per direction)
 size_t cq_m2_rows_host(int T, int L);     // rows of the per-clip M2 scratch
 

@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256) void tri_prep_kernel(CqBufs b, CqParams p, Row
 }
 
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpace rs) {
+// glob != 0: the three matrices do not fit LDS (T > 128 with a query of more than 32 words, ..): the scores live in the global scratch
+// b.GS and the two softmaxes are written straight into their save buffers - the same code on global pointers (a workgroup's waves share
+// the CU's vector L1, which is write-through: __syncthreads() orders one wave's stores before another's loads); only the masks use LDS
+__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpace rs, int glob) {
   extern __shared__ float lds[];
   const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
   if (clip >= rs.B) return;
@@ -103,12 +106,13 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int msz = c.N1p * c.ld;
-  float* S = lds;
-  float* Sr = lds + msz;
-  float* Sc = lds + 2 * msz;
+  const size_t gslot = ((size_t)dir * rs.B + clip) * cq_mat_elems(rs.T, rs.L);
+  float* S = glob ? b.GS + gslot : lds;
+  float* Sr = glob ? b.SR + gslot : lds + msz;
+  float* Sc = glob ? b.SC + gslot : lds + 2 * msz;
   // the two row masks of the clip, staged once: the softmax passes below read them per element (from global memory every
   // pass paid an L2 round trip)
-  float* m1 = lds + 3 * msz;
+  float* m1 = glob ? lds : lds + 3 * msz;
   float* m2 = m1 + c.N1p;
   for (int idx = threadIdx.x; idx < c.N1p + c.N2p; idx += CQ_THREADS) {
     const bool first = idx < c.N1p;
@@ -194,7 +198,8 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_fwd_kernel(CqBufs b, RowSpa
   const size_t mat = cq_mat_elems(rs.T, rs.L);
   float* gSr = b.SR + ((size_t)dir * rs.B + clip) * mat;
   float* gSc = b.SC + ((size_t)dir * rs.B + clip) * mat;
-  for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { gSr[idx] = Sr[idx]; gSc[idx] = Sc[idx]; }
+  if (!glob)
+    for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { gSr[idx] = Sr[idx]; gSc[idx] = Sc[idx]; }
   CQ_STAMP(4);
   // ---- c2q = Sr . x2   and   M2 = Sc^T . x1
   float* M2 = b.M2 + ((size_t)dir * rs.B + clip) * cq_m2_rows(rs.T, rs.L) * HUAL_D;
@@ -547,7 +552,8 @@ __global__ __launch_bounds__(256) void cq_bwd_pre_kernel(CqBufs b, CqBwdBufs gb,
 //   dXa (x1-role rows, via M2)  is ADDED into gb.dX rows of x1;  dXb (x2-role rows, via c2q) goes to dD2's
 //   companion buffer - to stay race free between the two directions of a clip it is folded into dD2 itself is
 //   not possible (different dropout), so it is written to gb.dC2Q rows?  -> see below: uses dedicated slices.
-__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb) {
+// (glob != 0: the saved softmaxes are read where they are, the two gradient matrices live in the global scratch gb.GD - see cq_fwd_kernel)
+__global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdBufs gb, RowSpace rs, float* dXa, float* dXb, int glob) {
   extern __shared__ float lds[];
   const int clip = xcd_tile(blockIdx.x, gridDim.x), dir = blockIdx.y;      // XCD-aware clip order (common.h)
   if (clip >= rs.B) return;
@@ -555,11 +561,12 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int msz = c.N1p * c.ld;
-  float* Sr = lds;
-  float* Sc = lds + msz;
-  float* dSr = lds + 2 * msz;    // becomes dscore
-  float* dSc = lds + 3 * msz;
-  float* m1 = lds + 4 * msz;     // the two row masks of the clip (see cq_fwd_kernel)
+  const size_t gslot = ((size_t)dir * rs.B + clip) * cq_mat_elems(rs.T, rs.L);
+  float* Sr = glob ? b.SR + gslot : lds;
+  float* Sc = glob ? b.SC + gslot : lds + msz;
+  float* dSr = glob ? gb.GD + 2 * gslot : lds + 2 * msz;    // becomes dscore
+  float* dSc = glob ? gb.GD + 2 * gslot + cq_mat_elems(rs.T, rs.L) : lds + 3 * msz;
+  float* m1 = glob ? lds : lds + 4 * msz;     // the two row masks of the clip (see cq_fwd_kernel)
   float* m2 = m1 + c.N1p;
   for (int idx = threadIdx.x; idx < c.N1p + c.N2p; idx += CQ_THREADS) {
     const bool first = idx < c.N1p;
@@ -579,7 +586,8 @@ __global__ __launch_bounds__(CQ_MAX_THREADS) void cq_bwd_kernel(CqBufs b, CqBwdB
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const int nj = c.N2p >> 4, ni = c.N1p >> 4;
   CQ_STAMP(16);
-  for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { Sr[idx] = gSr[idx]; Sc[idx] = gSc[idx]; dSr[idx] = 0.f; dSc[idx] = 0.f; }
+  if (glob) { for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { dSr[idx] = 0.f; dSc[idx] = 0.f; } }
+  else for (int idx = threadIdx.x; idx < msz; idx += CQ_THREADS) { Sr[idx] = gSr[idx]; Sc[idx] = gSc[idx]; dSr[idx] = 0.f; dSc[idx] = 0.f; }
   __syncthreads();
   CQ_STAMP(17);
   // dSr = dc2q . x2^T + dq2c . M2^T
@@ -1042,6 +1050,19 @@ static bool cq_use_wide(const RowSpace& rs) {
   static const bool off = getenv("HUAL_CQ_NO_WIDE") != nullptr && atoi(getenv("HUAL_CQ_NO_WIDE")) != 0;
   return !off && cq_wide_ok(rs);
 }
+static RowSpace cq_shape(int B, int T, int L) {
+  RowSpace rs{};
+  rs.B = B; rs.T = T; rs.L = L; rs.Nv = B * T; rs.Nq = B * L; rs.R = rs.Nv + rs.Nq;
+  return rs;
+}
+bool cq_fwd_global(int B, int T, int L) {
+  const RowSpace rs = cq_shape(B, T, L);
+  return !cq_use_wide(rs) && !cq_staged_ok(rs) && cq_lds_bytes(rs, 3) > 160 * 1024;
+}
+bool cq_bwd_global(int B, int T, int L) {
+  const RowSpace rs = cq_shape(B, T, L);
+  return !cq_use_wide(rs) && !cq_staged_ok(rs) && cq_lds_bytes(rs, 4) > 160 * 1024;
+}
 int launch_cq_fwd(const CqBufs& b, const CqParams& p, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
   if (cq_use_wide(rs)) return launch_cq_fwd_wide(b, p, rs, drop, s);
   if (cq_staged_ok(rs)) {
@@ -1052,10 +1073,11 @@ int launch_cq_fwd(const CqBufs& b, const CqParams& p, const RowSpace& rs, const 
   }
   int rc = launch_tri_prep(b, p, rs, drop, s);
   if (rc) return rc;
-  const int bytes = cq_lds_bytes(rs, 3);
-  HUAL_REQUIRE(bytes <= 160 * 1024, "cq_fwd: T x L score matrix does not fit LDS");
+  const bool glob = cq_fwd_global(rs.B, rs.T, rs.L);
+  const int bytes = glob ? cq_lds_bytes(rs, 0) : cq_lds_bytes(rs, 3);
+  HUAL_REQUIRE(!glob || b.GS != nullptr, "cq_fwd: the global-memory form needs the score scratch (CqBufs::GS)");
   HUAL_DYN_LDS(cq_fwd_kernel, 160 * 1024);
-  HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, cq_fwd_bytes(rs), cq_fwd_kernel, dim3(xcd_round8(rs.B), 2), dim3(cq_threads()), bytes, s, b, rs);
+  HUAL_LAUNCH(2.0 * 8.0 * rs.B * rs.T * rs.L * HUAL_D, cq_fwd_bytes(rs), cq_fwd_kernel, dim3(xcd_round8(rs.B), 2), dim3(cq_threads()), bytes, s, b, rs, glob ? 1 : 0);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1077,10 +1099,11 @@ int launch_cq_bwd_impl(const CqBufs& b, const CqBwdBufs& g, const RowSpace& rs, 
     HUAL_CHECK_HIP(hipGetLastError());
     return 0;
   }
-  const int bytes = cq_lds_bytes(rs, 4);
-  HUAL_REQUIRE(bytes <= 160 * 1024, "cq_bwd: T x L score matrix does not fit LDS");
+  const bool glob = cq_bwd_global(rs.B, rs.T, rs.L);
+  const int bytes = glob ? cq_lds_bytes(rs, 0) : cq_lds_bytes(rs, 4);
+  HUAL_REQUIRE(!glob || g.GD != nullptr, "cq_bwd: the global-memory form needs the gradient scratch (CqBwdBufs::GD)");
   HUAL_DYN_LDS(cq_bwd_kernel, 160 * 1024);
-  HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, cq_bwd_bytes(rs), cq_bwd_kernel, dim3(xcd_round8(rs.B), 2), dim3(cq_threads()), bytes, s, b, g, rs, dXa, dXb);
+  HUAL_LAUNCH(2.0 * 18.0 * rs.B * rs.T * rs.L * HUAL_D, cq_bwd_bytes(rs), cq_bwd_kernel, dim3(xcd_round8(rs.B), 2), dim3(cq_threads()), bytes, s, b, g, rs, dXa, dXb, glob ? 1 : 0);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -301,7 +301,9 @@ __global__ void dw_table_write_kernel(DwBatch part, DwPlanPart pre, DwJob* table
 // read, so each lane receives 8 consecutive rows of its column.  The kernel is bound by streaming the operands from HBM (every job
 // reads its A and dY once).
 #define DWB_PLANE (64 * 256)             // bytes of one [DWB_TM][128] 16-bit plane
-#define DWB_A_SCALE 16.0f                // fixed operand scale of the A side (activations: |a| >= 4094 ends in Inf / NaN gradients)
+// (the A side had the fixed 2^4 of the other kernels until the end of round 5: the PRODUCT pieces of the context-query dense layer -
+//  x * c2q, x * q2c - and the unnormalised inputs of the predictor's hidden layers passed 4094 in a fast-learning toy run every ~20th
+//  training run of tests/test_gpu_runner.py: NaN gradients for tensors whose forward was finite.  Now a running scale like dY's.)
 // one segment: rows [m_lo, m_hi) of k-block kb of piece p of a job -> atomics into its 128 x 128 gradient tile.
 // 512 threads: wave (kq, nq) owns the 64 x 32 block of gradient rows 64kq.., columns 32nq.. (two 32x32 accumulators,
 // <= 128 registers per lane, so two workgroups share a CU).  The launch is bound by how many bytes a CU keeps in flight
@@ -347,8 +349,11 @@ __device__ __forceinline__ void dw_f16_segment(const DwJob& job, const int p, co
   // scale s_y - set from the first tile's largest |dY| with three binades of headroom, and whenever a later tile would exceed 2^14 the
   // accumulators are multiplied down with it (32 multiplications per wave, rare: gradient magnitudes vary slowly along the rows).  A
   // tile's maximum crosses the workgroup through eight LDS slots one barrier ahead of its split (the barriers were there).
-  float* mxs = reinterpret_cast<float*>(&bred[0][0]);      // [2][8] slots (bred is free until the bias reduction at the end)
+  // A gets the same treatment (s_a): its magnitude is NOT bounded by construction - products of two activations, unnormalised block
+  // outputs - and an operand beyond fp16's range turns a finite forward pass into NaN gradients.
+  float* mxs = reinterpret_cast<float*>(&bred[0][0]);      // [2][16] slots: |dY| maxima, then |A| maxima (bred is free until the bias reduction at the end)
   float s_y = 0.f, s_y_inv = 0.f;                           // (wave-uniform)
+  float s_a = 0.f, s_a_inv = 0.f;
 
   // staging: thread -> rows (tid>>5) + 16u, columns 4*(tid&31)..+3 of both tiles; prologues (bf16 widening, product,
   // dropout) are applied at the store, so that a load is only waited for one iteration after its issue.  Addresses are
@@ -410,7 +415,7 @@ __device__ __forceinline__ void dw_f16_segment(const DwJob& job, const int p, co
         }
       }
       uint2 hi, lo;
-      f16_split4_s(a, DWB_A_SCALE, hi, lo);                   // (scale folded into the mixed-precision FMA: bf16x3.h)
+      f16_split4_s(a, s_a, hi, lo);                           // (scale folded into the mixed-precision FMA: bf16x3.h)
       *reinterpret_cast<uint2*>(base + off) = hi;
       *reinterpret_cast<uint2*>(base + DWB_PLANE + off) = lo;
       f16_split4_s(st.y[u], s_y, hi, lo);
@@ -451,36 +456,56 @@ __device__ __forceinline__ void dw_f16_segment(const DwJob& job, const int p, co
 #ifdef DWB_EXP_FIXSCALE     // timing experiment: no maxima, a fixed dY scale (numerically wrong for small gradients)
     return;
 #endif
-    float m = 0.f;
+    float m = 0.f, ma = 0.f;
 #pragma unroll
-    for (int u = 0; u < DWB_RU; ++u) m = fmaxf(m, f4absmax(st.y[u]));
+    for (int u = 0; u < DWB_RU; ++u) {
+      m = fmaxf(m, f4absmax(st.y[u]));
+      float4 a = st.a[u];                      // the operand as stage_store will split it (an upper bound under dropout: x 1 / (1 - rate))
+      if (abf) {
+        const uint32_t r0 = __float_as_uint(a.x), r1 = __float_as_uint(a.y);
+        a = make_float4(__uint_as_float(r0 << 16), __uint_as_float(r0 & 0xffff0000u), __uint_as_float(r1 << 16), __uint_as_float(r1 & 0xffff0000u));
+      }
+      if (MODE == DWB_PROD && A2p) a = f4mul(a, st.a2[u]);
+      ma = fmaxf(ma, f4absmax(a));
+    }
+    if (adrop) ma *= drop.scale;
     m = fast_max32(m);
     m = fmaxf(m, lane_xor32_partner(m));
-    if (lane == 0) mxs[par * 8 + wave] = m;
+    ma = fast_max32(ma);
+    ma = fmaxf(ma, lane_xor32_partner(ma));
+    if (lane == 0) { mxs[par * 16 + wave] = m; mxs[par * 16 + 8 + wave] = ma; }
   };
   // ... and the scale for the tile whose maxima sit in row `par`: the first tile sets it, a later one only lowers it
   auto take_scale = [&](int par) {
 #ifdef DWB_EXP_FIXSCALE
-    s_y = 1024.0f; s_y_inv = 1.0f / 1024.0f;
+    s_y = 1024.0f; s_y_inv = 1.0f / 1024.0f; s_a = 16.0f; s_a_inv = 1.0f / 16.0f;
     return;
 #endif
-    const float4 m0 = *reinterpret_cast<const float4*>(mxs + par * 8), m1 = *reinterpret_cast<const float4*>(mxs + par * 8 + 4);
-    float g = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
-    g = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g)));
-    if (s_y == 0.f || g * s_y > 16384.0f) {      // (uniform)
-      uint32_t eb = (__float_as_uint(g) >> 23) & 0xffu;
-      eb = eb < 27u ? 27u : (eb > 240u ? 240u : eb);
-      const float s_new = __uint_as_float((265u - eb) << 23);      // g s_new in [2^11, 2^12)
-      if (s_y != 0.f) {
-        const float f = s_new * s_y_inv;                             // < 1, exact
+    auto wgmax = [&](const float* q) {
+      const float4 m0 = *reinterpret_cast<const float4*>(q), m1 = *reinterpret_cast<const float4*>(q + 4);
+      const float g = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+      return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g)));
+    };
+    // one running scale: set by the first tile (its maximum x scale in [2^11, 2^12)), lowered - and the accumulators with it - when a later
+    // tile would pass 2^14
+    auto running = [&](float g, float& sc, float& sc_inv) {
+      if (sc == 0.f || g * sc > 16384.0f) {      // (uniform)
+        uint32_t eb = (__float_as_uint(g) >> 23) & 0xffu;
+        eb = eb < 27u ? 27u : (eb > 240u ? 240u : eb);
+        const float s_new = __uint_as_float((265u - eb) << 23);
+        if (sc != 0.f) {
+          const float f = s_new * sc_inv;                              // < 1, exact
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+          for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[c][r] *= f;
+            for (int r = 0; r < 16; ++r) acc[c][r] *= f;
+        }
+        sc = s_new;
+        sc_inv = __uint_as_float((eb - 11u) << 23);
       }
-      s_y = s_new;
-      s_y_inv = __uint_as_float((eb - 11u) << 23);
-    }
+    };
+    running(wgmax(mxs + par * 16), s_y, s_y_inv);
+    running(wgmax(mxs + par * 16 + 8), s_a, s_a_inv);
   };
   // tile i sits in LDS buffer i&1 while the registers hold tiles i+1 .. i+DEPTH-1 (the last of them just issued)
 #pragma unroll
@@ -533,7 +558,7 @@ __device__ __forceinline__ void dw_f16_segment(const DwJob& job, const int p, co
   // (i, h) is gradient row 32c + (r&3) + 8*(r>>2) + 4h, column i of the block.
   float* dWp = job.dW[p];
   const int kbase = k0 + kq * 64, n = nq * 32 + i;
-  const float flush_scale = s_y_inv * (1.0f / DWB_A_SCALE);
+  const float flush_scale = s_y_inv * s_a_inv;
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll

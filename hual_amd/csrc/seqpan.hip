@@ -548,6 +548,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   cq.SR = c.buf("cq.sr", (size_t)2 * B, mat);
   cq.SC = c.buf("cq.sc", (size_t)2 * B, mat);
   cq.M2 = c.buf("cq.m2", (size_t)2 * B * cq_m2_rows_host(T, L), D);
+  cq.GS = cq_fwd_global(B, T, L) ? c.buf("cq.gs", (size_t)2 * B, mat) : nullptr;
   CqParams cqp{};
   for (int i = 0; i < 2; ++i) { cqp.w0[i] = c.p(pm.cq[i].w0); cqp.w1[i] = c.p(pm.cq[i].w1); cqp.wm[i] = c.p(pm.cq[i].wm); }
   if (c.live()) c.chk(launch_cq_fwd(cq, cqp, c.rs, c.drop, c.stream));      // (tri_prep inside)
@@ -937,6 +938,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   cq.SR = c.buf("cq.sr", (size_t)2 * B, mat);
   cq.SC = c.buf("cq.sc", (size_t)2 * B, mat);
   cq.M2 = c.buf("cq.m2", (size_t)2 * B * cq_m2_rows_host(T, L), D);
+  cq.GS = cq_fwd_global(B, T, L) ? c.buf("cq.gs", (size_t)2 * B, mat) : nullptr;
   for (int s = 0; s < 2; ++s) {
     const size_t ro = s == 0 ? 0 : (size_t)Nv * D;
     DwJob j = mkdw(xf + ro, D, D, d_cqf + ro, D, s == 0 ? Nv : Nq, c.g(pm.cq[s].dense), nullptr);
@@ -969,6 +971,7 @@ int backward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const h
   }
   cg.dD1W = c.act("d.cq.d1w"); cg.dD2 = c.act("d.cq.d2"); cg.dS0 = c.vec("d.cq.s0"); cg.dS1 = c.vec("d.cq.s1");
   cg.dM2 = c.buf("d.cq.m2", (size_t)2 * B * cq_m2_rows_host(T, L), D);
+  cg.GD = cq_bwd_global(B, T, L) ? c.buf("d.cq.gd", (size_t)4 * B, mat) : nullptr;
   float* dXa = c.act("d.cq.xa");
   float* dXb = c.act("d.cq.xb");
   CqParams cqp{};

@@ -259,8 +259,9 @@ int hual_linear_bf16x3(const float* A, int lda, const float* W, int trans_w, con
  * weight-gradient launch of the training step: the 64-row tiles of the job dealt evenly to `workgroups` workgroups
  * (0 = one per CU), the job table living in `scratch` (device, >= 512 bytes).  N must be 128 (every dense layer of the
  * graph has 128 outputs).  Accumulates with float atomics: zero the destinations first.
- * Arithmetic (ABI 7): fp16-pair operands - A scaled by 2^4 (|a| >= 4094 does not fit: Inf / NaN gradients, loudly), dY by a running
- * power-of-two scale taken from the data (any gradient magnitude); 2-5e-7 of the largest entry against a float64 product. */
+ * Arithmetic (ABI 7): fp16-pair operands - A and dY each by a running power-of-two scale taken from the data (any magnitude: the
+ * operands of a weight gradient are not bounded by construction - products of activations, unnormalised block outputs);
+ * 2-5e-7 of the largest entry against a float64 product. */
 int hual_linear_dw(const float* A, int lda, const float* dY, int ldy, float* dW, int ldw, float* db, int M, int K,
                    int N, int workgroups, void* scratch, uint64_t scratch_bytes, void* stream);
 

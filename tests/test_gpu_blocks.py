@@ -164,7 +164,9 @@ def test_dual_attn_fwd_bwd(shape, layer):
 # second block, three words / 32 words); the shapes beyond it - queries of more than 32 words - run the staged kernels of csrc/cq.hip
 CQ_WIDE_SHAPES = [dict(B=3, T=256, L=20, C=4, seed=21, max_vlen=256), dict(B=2, T=170, L=32, C=4, seed=22, max_vlen=192),
                   dict(B=9, T=129, L=3, C=4, seed=23, max_vlen=160), dict(B=5, T=100, L=30, C=4, seed=33, max_vlen=100),
-                  dict(B=3, T=64, L=40, C=4, seed=24, max_vlen=64)]
+                  dict(B=3, T=64, L=40, C=4, seed=24, max_vlen=64),
+                  # score matrices beyond every LDS form: the global-operand kernels with the matrices in global memory too
+                  dict(B=2, T=256, L=40, C=4, seed=61, max_vlen=256), dict(B=2, T=128, L=100, C=4, seed=64, max_vlen=128)]
 
 
 @pytest.mark.parametrize('shape', SHAPES + CQ_WIDE_SHAPES)

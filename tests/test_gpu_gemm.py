@@ -76,6 +76,31 @@ def test_linear_dw_gradient_magnitudes(dev, M, K, mode):
     assert (db.double() - dY.double().sum(0)).abs().max().item() <= 1e-5 * dY.double().abs().sum(0).max().item()
 
 
+@pytest.mark.parametrize('mode', ['large', 'rising', 'tiny'])
+def test_linear_dw_activation_magnitudes(dev, mode):
+    """the A side of a weight gradient is not bounded by construction (products of two activations, unnormalised block outputs): operands
+    far beyond the 4094 that a fixed 2^4 fp16 scale could hold, a magnitude that rises by 2^20 along the rows of a segment (the running
+    scale is lowered on the way and the accumulators with it), and operands of 1e-10"""
+    from hual_amd import lib
+    M, K = 1500, 256
+    g = torch.Generator(device='cpu').manual_seed(77)
+    A = torch.randn(M, K, generator=g)
+    dY = torch.randn(M, 128, generator=g) * 1e-3
+    if mode == 'large':
+        A = A * 3e5
+    elif mode == 'rising':
+        A = A * torch.logspace(-2, 4, M).unsqueeze(1)
+    else:
+        A = A * 1e-10
+    A, dY = A.to(dev), dY.to(dev)
+    dW = torch.zeros(K, 128, device=dev)
+    db = torch.zeros(128, device=dev)
+    lib.linear_dw(A, dY, dW, db, workgroups=0)
+    ref = A.double().t() @ dY.double()
+    assert torch.isfinite(dW).all()
+    assert (dW.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize('M,K', [(16, 64), (37, 128), (1000, 400), (2048, 1024), (9472, 128), (100, 256), (48, 8)])
 @pytest.mark.parametrize('act', [0, 1])
 def test_linear_bf16x3_forward(dev, M, K, act):

@@ -58,7 +58,9 @@ def test_train_test_infer_and_checkpoint(tmp_path):
     after = r.test_epoch()
     assert any(l.startswith('TRAIN:\t') for l in lines) and any(l.startswith('TEST:\t') for l in lines)
     assert os.path.exists(tmp_path / 'ckpt' / 'best_SeqPAN.npz')
-    # mIoU improves on the learnable task (the run is not bit-reproducible - float atomics - and short: +4 .. +12 points over the runs seen)
+    # mIoU improves on the learnable task (the run is not bit-reproducible - float atomics - and short: +9 .. +25 points over 400 runs
+    # of scripts/exp/runner_repeat.py; until the weight-gradient launch took a running scale for its A operand, one run in ~20 ended
+    # in NaN parameters - activation products beyond the fixed fp16 operand range - and one in ~40 landed below the bar by noise)
     assert after[3] > before[3] + 3.0, (before, after)
     assert r.clips_per_s > 0
     # checkpoint round trip: perturb, reload, same predictions as the best epoch's weights give

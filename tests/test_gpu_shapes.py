@@ -123,6 +123,13 @@ def test_long_clips_without_dropout():
     _check_all(case, 0.0)
 
 
+def test_long_clips_with_long_queries():
+    """T = 256 with a 40-word query: no LDS form of the context-query kernels holds the 256 x 48 score matrices - the global-operand
+    kernels keep them in global memory (csrc/cq.hip cq_fwd_global / cq_bwd_global: slow, but every T, L <= 256 runs)"""
+    case = pu.make_case(B=2, T=256, L=40, C=5, seed=71, max_vlen=256)
+    _check_all(case, 0.2)
+
+
 def test_long_queries():
     """L = 40 words (> 32): the staged context-query kernels take their general softmax branches (rows / columns longer than
     a 32-lane half) - T + L still within their 160 padded rows"""
