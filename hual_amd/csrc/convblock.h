@@ -32,7 +32,10 @@ struct CbFwdArgs {
 };
 #define HUAL_CB_MAXMT 46
 int conv_block_fused_rows(int R, int Nv = 0);            // the MT launch_conv_block_fwd picks for R rows
-int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s);
+// tail (optional): the layer norm(s) + projections launch that would follow on the block output (dablock.h: x = l[3].xout, same rows,
+// no xa / x2) rides at the end of this one, tile by tile, its input rows taken from LDS (conv_block_fwd_lnproj_kernel)
+struct LnProjArgs;
+int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s, const LnProjArgs* tail = nullptr);
 
 struct CbLayerBwd {
   const float* ln_g; const float* ln_b; const float* dw;

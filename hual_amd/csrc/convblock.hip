@@ -18,15 +18,23 @@
 
 using namespace hual;
 
+#include "lnproj_body.h"      // the tail of conv_block_fwd_lnproj_kernel
+
 #define CB_XS 33          // float4 per X row: 528-byte rows spread the 128-byte column quarters of the statistics pass over the banks
 #define CB_NPAR 10        // small parameter vectors of a layer staged in LDS: w[0..6], gamma, beta, bias
+#define CB_TP_F4 (10 * 32) // float4 reserved for the tail's vectors (>= LNP_TP_VECS * 32)
 
-__global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a, RowSpace rs, DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) char cb_lds[];
+// TAIL (round 5): the launch that follows a conv block in the step is the layer norm(s) + projections of the SAME rows (dual attention
+// layer 0: LN1 / LN_t + five projections; the predictor's encoders: LN1 + dropout + query / key / value) - the block output is still in
+// X, so the tile goes straight on (lnproj_body.h) instead of ending the launch and reading x_4 back: one launch and one memory round trip
+// less per site
+template <bool TAIL>
+__device__ __forceinline__ void conv_block_fwd_body(const CbFwdArgs& a, const RowSpace& rs, const DropCfg& drop, const LnProjArgs* lp, char* cb_lds) {
   const int MT = a.MT;
   const int XR = MT + 24;                                   // rows of X
   float4* X = reinterpret_cast<float4*>(cb_lds);            // [XR][CB_XS] float4
-  char* Ahi = cb_lds + (size_t)XR * CB_XS * 16;             // [64][256 B]
+  float4* TP = X + XR * CB_XS;                              // TAIL: [LNP_TP_VECS][32] float4, the tail's small vectors (lnproj_body.h)
+  char* Ahi = reinterpret_cast<char*>(TP + (TAIL ? CB_TP_F4 : 0));      // [64][256 B]
   char* Alo = Ahi + 64 * 256;
   float* ainv = reinterpret_cast<float*>(Alo + 64 * 256);   // [64] inverse operand scale per A row
   float* smean = ainv + 64;                                 // [72] layer-norm statistics of the X rows
@@ -68,6 +76,17 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
       const float* src = grp < 7 ? L.dw + grp * HUAL_D : (grp == 7 ? L.ln_g : (grp == 8 ? L.ln_b : L.bias));
       qv[l] = ld4(src + col);
     }
+    float4 tq = f4zero();
+    if (TAIL) {                                              // group k < LNP_TP_VECS: vector k of the tail (absent ones: any valid address)
+      const float* src = lp->g1;
+      if (grp == 1) src = lp->b1;
+      if (grp == 2 && lp->g2) src = lp->g2;
+      if (grp == 3 && lp->g2) src = lp->b2;
+#pragma unroll
+      for (int k = 0; k < HUAL_LNPROJ_MAX; ++k)
+        if (grp == 4 + k && k < lp->nproj && lp->bias[k]) src = lp->bias[k];
+      tq = ld4(src + col);
+    }
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       const int i = grp + 16 * u, row = xbase + i;
@@ -83,6 +102,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
 #pragma unroll
     for (int l = 0; l < 4; ++l)
       if (grp < CB_NPAR) par[(l * CB_NPAR + grp) * 32 + l32] = qv[l];
+    if (TAIL && grp < LNP_TP_VECS) TP[grp * 32 + l32] = tq;
   }
   cb_barrier();
   HUAL_STAMP_K(2, 1);
@@ -252,6 +272,19 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a,
     cb_barrier();
     HUAL_STAMP_K(2, 7 + 6 * l);
   }
+  if (TAIL) {      // x_4 of the owned rows is in X (rows r0 - xbase ..); the tail's operand slots take over everything from the operand planes on
+    if (MT <= 32) ln_proj_body<2, true, true>(*lp, drop, Ahi, r0, X, xbase, CB_XS, XR, TP);
+    else ln_proj_body<3, true, true>(*lp, drop, Ahi, r0, X, xbase, CB_XS, XR, TP);
+  }
+}
+
+__global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_kernel(CbFwdArgs a, RowSpace rs, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char cb_lds[];
+  conv_block_fwd_body<false>(a, rs, drop, nullptr, cb_lds);
+}
+__global__ __launch_bounds__(CB_THREADS) void conv_block_fwd_lnproj_kernel(CbFwdArgs a, RowSpace rs, DropCfg drop, LnProjArgs lp) {
+  extern __shared__ __attribute__((aligned(16))) char cb_lds[];
+  conv_block_fwd_body<true>(a, rs, drop, &lp, cb_lds);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -507,6 +540,10 @@ __global__ __launch_bounds__(CB_THREADS) void conv_block_bwd_kernel(CbBwdArgs a,
 extern "C" int hual_debug_stamps(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hual_stamps), sizeof(unsigned long long) * (size_t)n);
 }
+extern "C" int hual_debug_stamps_reset() {
+  static unsigned long long zeros[512 * HUAL_STAMP_SLOTS];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_hual_stamps), zeros, sizeof(zeros));
+}
 #endif
 
 namespace hual {
@@ -519,18 +556,35 @@ int conv_block_fused_rows(int R, int Nv) {
 
 static size_t cb_fwd_lds(int MT) { return (size_t)(MT + 24) * CB_XS * 16 + 2 * 64 * 256 + (64 + 72 + 72) * sizeof(float) + 4 * CB_NPAR * 512; }
 
-int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s) {
+int launch_conv_block_fwd(const CbFwdArgs& a, const RowSpace& rs, const DropCfg& drop, hipStream_t s, const LnProjArgs* tail) {
   HUAL_REQUIRE(a.x0 && rs.R > 0 && a.MT >= 1 && a.MT <= HUAL_CB_MAXMT, "conv_block_fwd: bad arguments");
   HUAL_REQUIRE(!a.pos || a.x0_out, "conv_block_fwd: pos needs x0_out");
   for (int l = 0; l < 4; ++l) {
     const CbLayerFwd& L = a.l[l];
     HUAL_REQUIRE(L.ln_g && L.ln_b && L.dw && L.wimg && L.bias && L.c && L.xout && L.mean && L.rstd && L.relu_bits && L.keep_bits, "conv_block_fwd: null layer tensor");
   }
-  HUAL_DYN_LDS(conv_block_fwd_kernel, 160 * 1024);
   const double rows = (double)rs.R;
+  const dim3 grid(xcd_clip_grid(rs.R, rs.Nq > 0 ? rs.Nv : 0, a.MT));
   // algorithmic work: 4 pointwise products; bytes: x0 in, (c, y, x) out per layer, weights
-  HUAL_LAUNCH(4.0 * 2.0 * rows * HUAL_D * HUAL_D, 4.0 * (rows * HUAL_D * 13.0 + 4.0 * HUAL_D * HUAL_D), conv_block_fwd_kernel,
-              dim3(xcd_clip_grid(rs.R, rs.Nq > 0 ? rs.Nv : 0, a.MT)), dim3(CB_THREADS), cb_fwd_lds(a.MT), s, a, rs, drop);
+  double flops = 4.0 * 2.0 * rows * HUAL_D * HUAL_D, bytes = 4.0 * (rows * HUAL_D * 13.0 + 4.0 * HUAL_D * HUAL_D);
+  if (!tail) {
+    HUAL_DYN_LDS(conv_block_fwd_kernel, 160 * 1024);
+    HUAL_LAUNCH(flops, bytes, conv_block_fwd_kernel, grid, dim3(CB_THREADS), cb_fwd_lds(a.MT), s, a, rs, drop);
+  } else {
+    // the tail works on this launch's tiles: the block output as its layer-norm input, rows straight from LDS
+    LnProjArgs lp = *tail;
+    lp.MT = a.MT;
+    int rc = check_ln_proj_args(lp);
+    if (rc) return rc;
+    HUAL_REQUIRE(lp.x == a.l[3].xout && lp.R == rs.R && ln_proj_plain(lp), "conv_block_fwd: the tail must read the block output and be of the plain shape");
+    const size_t tail_from_planes = std::max((size_t)LN_PROJ_LDS, cb_fwd_lds(a.MT) - (size_t)(a.MT + 24) * CB_XS * 16);
+    const size_t lds = (size_t)(a.MT + 24) * CB_XS * 16 + CB_TP_F4 * 16 + tail_from_planes;
+    HUAL_REQUIRE(lds <= 160 * 1024, "conv_block_fwd: LDS of the tail");
+    flops += 2.0 * rows * HUAL_D * HUAL_D * lp.nproj;
+    bytes += 4.0 * rows * HUAL_D * (lp.nproj + 1.0 + (lp.g2 ? 1.0 : 0.0)) - 4.0 * rows * HUAL_D;      // (x_4 is not read back)
+    HUAL_DYN_LDS(conv_block_fwd_lnproj_kernel, 160 * 1024);
+    HUAL_LAUNCH(flops, bytes, conv_block_fwd_lnproj_kernel, grid, dim3(CB_THREADS), lds, s, a, rs, drop, lp);
+  }
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -38,6 +38,8 @@ struct LnProjArgs {
 };
 int ln_proj_rows(int R, int Nv = 0);       // (Nv: video rows of a unified row space - XCD order by clips, common.h)
 int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s);
+int check_ln_proj_args(const LnProjArgs& a);
+bool ln_proj_plain(const LnProjArgs& a);         // the query / key / value shape (lnproj_body.h PLAIN): a leaner instantiation      // (the argument checks of launch_ln_proj, for the launch that carries it as a tail: convblock.h)
 int launch_ln_proj_pair(const LnProjArgs& a0, const LnProjArgs& a1, const DropCfg& drop, hipStream_t s);   // two problems, one launch
 
 struct DaPostArgs {

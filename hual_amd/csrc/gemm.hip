@@ -344,8 +344,8 @@ __device__ __forceinline__ void dw_f16_segment(const DwJob& job, const int p, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
   float4 bsum = f4zero();
-  // Round 5: fp16 pairs (22-bit operands) instead of bf16 pairs.  A (activations) takes the fixed 2^4 of every other kernel; dY is a
-  // GRADIENT and the contraction runs over all rows of the segment, so its scale has to hold for the whole segment: a RUNNING power-of-two
+  // Round 5: fp16 pairs (22-bit operands) instead of bf16 pairs.  dY is a GRADIENT and the contraction runs over all rows of the
+  // segment, so its scale has to hold for the whole segment: a RUNNING power-of-two
   // scale s_y - set from the first tile's largest |dY| with three binades of headroom, and whenever a later tile would exceed 2^14 the
   // accumulators are multiplied down with it (32 multiplications per wave, rare: gradient magnitudes vary slowly along the rows).  A
   // tile's maximum crosses the workgroup through eight LDS slots one barrier ahead of its split (the barriers were there).

@@ -279,8 +279,29 @@ int setup_ctx(Ctx& c, const hual_cfg* cfg, int B, int T, int L, int C) {
 
 // conv_block (modules.py:59-70) on rows described by `rs`; x0 -> returns x4.  tag prefixes the buffer names.
 // pos_src / pos (predictor feature encoder, modules.py:124): x0 = pos_src + pos[t] is formed on the way in.
+// layer norms (LN1, LN_t) + the five projections of dual attention layer li (dablock.h ln_proj; x is set by the caller)
+void fill_da_ln_proj(Ctx& c, LnProjArgs& lp, int li, int R, int Nv) {
+  const int D = HUAL_D;
+  const DualAttnP& d = c.pm.da[li];
+  const std::string t = "da" + std::to_string(li);
+  lp = LnProjArgs{};
+  lp.g1 = c.p(d.ln1.g); lp.b1 = c.p(d.ln1.b); lp.y1 = c.act(t + ".ln1"); lp.drop_site1 = -1; lp.pre_site = -1;
+  lp.g2 = c.p(d.lnt.g); lp.b2 = c.p(d.lnt.b); lp.y2 = c.act(t + ".lnt"); lp.mean = c.vec(t + ".mean"); lp.rstd = c.vec(t + ".rstd");
+  lp.nproj = 5; lp.R = R; lp.Nv = Nv; lp.MT = ln_proj_rows(R, Nv); lp.drop_row0 = 0;
+  float* qkv = c.buf(t + ".qkv", R, 3 * D);
+  float* ktvt = c.buf(t + ".ktvt", R, 2 * D);
+  const DenseP* pr[5] = {&d.query, &d.f_key, &d.f_value, &d.t_key, &d.t_value};
+  float* outs[5] = {qkv, qkv + D, qkv + 2 * D, ktvt, ktvt + D};
+  for (int k = 0; k < 5; ++k) {
+    lp.wimg[k] = c.timg(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = outs[k]; lp.ldo[k] = k < 3 ? 3 * D : 2 * D; lp.src[k] = k < 3 ? 0 : 1;
+    lp.out_site[k] = -1;
+  }
+}
+
+// tail: the ln_proj launch that follows on the block output (its x is filled in here); it rides in the block's launch when the
+// whole graph runs (the per-block entry points keep the two launches: the caller launches *tail itself when this returns false)
 float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP& cp, const RowSpace& rs, int site0,
-                      const float* pos_src = nullptr, const float* pos = nullptr) {
+                      const float* pos_src = nullptr, const float* pos = nullptr, LnProjArgs* tail = nullptr, bool* tail_done = nullptr) {
   const int R = rs.R;
   {                      // all four layers in one launch (convblock.h)
     CbFwdArgs a{};
@@ -303,7 +324,11 @@ float* conv_block_fwd(Ctx& c, const std::string& tag, float* x, const ConvBlockP
       L.drop_site = site0 + i;
       xin = L.xout;
     }
-    if (c.live()) c.chk(launch_conv_block_fwd(a, rs, c.drop, c.stream));
+    static const bool no_tail = getenv("HUAL_CB_NO_TAIL") != nullptr && atoi(getenv("HUAL_CB_NO_TAIL")) != 0;      // (A/B timings)
+    const bool fuse = tail && c.sel_stage < 0 && !no_tail;
+    if (tail) tail->x = xin;
+    if (tail_done) *tail_done = fuse;
+    if (c.live()) c.chk(launch_conv_block_fwd(a, rs, c.drop, c.stream, fuse ? tail : nullptr));
     return xin;
   }
 }
@@ -458,7 +483,11 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   }
   // ---------------- shared conv block (model.py:54-58)
   c.stage(ST_CONV);
-  x = conv_block_fwd(c, "cb", x, pm.cb, rs, HUAL_SITE_CONV);
+  LnProjArgs da0_lp{};      // layer 0's layer norms + projections: filled below, launched at the end of the conv block's launch
+  bool da0_lp_done = false;
+  const bool da0_tail = c.cfg->attn_layer > 0;
+  if (da0_tail) fill_da_ln_proj(c, da0_lp, 0, R, Nv);
+  x = conv_block_fwd(c, "cb", x, pm.cb, rs, HUAL_SITE_CONV, nullptr, nullptr, da0_tail ? &da0_lp : nullptr, &da0_lp_done);
   // ---------------- dual attention layers (model.py:60-68)
   for (int li = 0; li < c.cfg->attn_layer; ++li) {
     const DualAttnP& d = pm.da[li];
@@ -471,17 +500,10 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* rstd = c.vec(t + ".rstd");
     float* qkv = c.buf(t + ".qkv", R, 3 * D);
     float* ktvt = c.buf(t + ".ktvt", R, 2 * D);
-    {                      // layer norms + the five projections in one launch (dablock.h)
+    if (!(li == 0 && da0_lp_done)) {      // layer norms + the five projections in one launch (dablock.h); layer 0's rode in the conv block's
       LnProjArgs lp{};
-      lp.x = x; lp.g1 = c.p(d.ln1.g); lp.b1 = c.p(d.ln1.b); lp.y1 = ln1; lp.drop_site1 = -1; lp.pre_site = -1;
-      lp.g2 = c.p(d.lnt.g); lp.b2 = c.p(d.lnt.b); lp.y2 = lnt; lp.mean = mean; lp.rstd = rstd;
-      lp.nproj = 5; lp.R = R; lp.Nv = Nv; lp.MT = ln_proj_rows(R, Nv); lp.drop_row0 = 0;
-      const DenseP* pr[5] = {&d.query, &d.f_key, &d.f_value, &d.t_key, &d.t_value};
-      float* outs[5] = {qkv, qkv + D, qkv + 2 * D, ktvt, ktvt + D};
-      for (int k = 0; k < 5; ++k) {
-        lp.wimg[k] = c.timg(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = outs[k]; lp.ldo[k] = k < 3 ? 3 * D : 2 * D; lp.src[k] = k < 3 ? 0 : 1;
-        lp.out_site[k] = -1;
-      }
+      fill_da_ln_proj(c, lp, li, R, Nv);
+      lp.x = x;
       if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
     }
     float* s_att = c.act(t + ".s_att");
@@ -621,22 +643,24 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     const std::string t = "fe" + std::to_string(ps);
     const int site = HUAL_SITE_FE + 16 * ps;
     float* x0 = c.actv(t + ".x0");
-    float* f = conv_block_fwd(c, t, x0, pm.fe_cb, c.rsv, site, fin, c.p(pm.fe_pos));
     float* a1 = c.actv(t + ".a");
     float* mean = c.buf(t + ".ln1.mean", Nv, 1);
     float* rstd = c.buf(t + ".ln1.rstd", Nv, 1);
     float* qkv = c.buf(t + ".qkv", Nv, 3 * D);
-    {                      // layer_norm_1 + dropout + query / key / value in one launch (dablock.h)
-      LnProjArgs lp{};
-      lp.x = f; lp.g1 = c.p(pm.fe_ln1.g); lp.b1 = c.p(pm.fe_ln1.b); lp.y1 = a1; lp.drop_site1 = site + 4; lp.pre_site = -1;
-      lp.y1_bits = c.bits(t + ".kb4", Nv);
-      lp.mean = mean; lp.rstd = rstd; lp.nproj = 3; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
+    // layer_norm_1 + dropout + query / key / value (dablock.h ln_proj): at the end of the conv block's launch when the whole graph runs
+    LnProjArgs lp{};
+    lp.g1 = c.p(pm.fe_ln1.g); lp.b1 = c.p(pm.fe_ln1.b); lp.y1 = a1; lp.drop_site1 = site + 4; lp.pre_site = -1;
+    lp.y1_bits = c.bits(t + ".kb4", Nv);
+    lp.mean = mean; lp.rstd = rstd; lp.nproj = 3; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
+    {
       const DenseP* pr[3] = {&pm.fe_q, &pm.fe_k, &pm.fe_v};
       for (int k = 0; k < 3; ++k) {
         lp.wimg[k] = c.timg(pr[k]->k); lp.bias[k] = c.p(pr[k]->b); lp.out[k] = qkv + k * D; lp.ldo[k] = 3 * D; lp.out_site[k] = -1;
       }
-      if (c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
     }
+    bool lp_done = false;
+    float* f = conv_block_fwd(c, t, x0, pm.fe_cb, c.rsv, site, fin, c.p(pm.fe_pos), &lp, &lp_done);
+    if (!lp_done && c.live()) c.chk(launch_ln_proj(lp, c.drop, c.stream));
     float* att = c.actv(t + ".att");
     {
       AttnJob a;

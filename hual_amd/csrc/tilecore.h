@@ -243,6 +243,36 @@ __device__ __forceinline__ void tf_mma_lean(const char* Ahi, const TfW& w, int l
   }
 }
 
+// the activation fragments of ALL four k-steps in registers (32 per row tile), for a run of products that read the same operand slot:
+// every wave reads the whole slot per product (8 waves x 24 KB at three row tiles = 1536 cycles of the CU's LDS bandwidth, more than the
+// 1152 cycles its MFMAs take), so projections that share a source read it once
+template <int NT> struct TfA { f16x8 h[4][NT], l[4][NT]; };
+template <int NT, int ALO>
+__device__ __forceinline__ void tf_load_a(TfA<NT>& x, const char* Ahi, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      const int off = tile256_off(16 * rt + j, 4 * ks + g);
+      x.h[ks][rt] = *reinterpret_cast<const f16x8*>(Ahi + off);
+      x.l[ks][rt] = *reinterpret_cast<const f16x8*>(Ahi + ALO + off);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void tf_mma_regs(const TfA<NT>& x, const TfW& w, f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int rt = 0; rt < NT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[ks], x.h[ks][rt], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[ks], x.l[ks][rt], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[ks], x.h[ks][rt], acc[rt], 0, 0, 0);
+    }
+}
+
 // lane partners across the 16-lane rows of a wave (v_permlane16_swap / v_permlane32_swap, one instruction each) and the maximum
 // over the four lanes (j, 0..3) that hold one row's 16-column slice in the T-form accumulator layout
 __device__ __forceinline__ float lane_xor16(float v, int lane) {

@@ -29,11 +29,13 @@ rc = l.hual_debug_stamps(buf, n)
 st = np.frombuffer(buf, dtype=np.uint64).reshape(512, 64).astype(np.int64)
 nb = int((st[:, 0] > 0).sum())
 st = st[:nb]
-ns = int((st[0] > 0).sum())
+used = [k for k in range(st.shape[1]) if (st[:, k] > 0).all()]      # (slot numbers need not be contiguous)
+ns = len(used)
 print('rc', rc, 'blocks', nb, 'stamps', ns)
-d = np.diff(st[:, :ns], axis=1)
-tot = st[:, ns - 1] - st[:, 0]
+sv = st[:, used]
+d = np.diff(sv, axis=1)
+tot = sv[:, -1] - sv[:, 0]
 print('total cycles per workgroup: mean %.0f min %d max %d' % (tot.mean(), tot.min(), tot.max()))
-print('kernel span (first start .. last end) cycles:', st[:, ns - 1].max() - st[:, 0].min())
+print('kernel span (first start .. last end) cycles:', sv[:, -1].max() - sv[:, 0].min())
 for k in range(ns - 1):
-    print('%2d -> %2d  mean %7.0f  p10 %7.0f  p90 %7.0f' % (k, k + 1, d[:, k].mean(), np.percentile(d[:, k], 10), np.percentile(d[:, k], 90)))
+    print('%2d -> %2d  mean %7.0f  p10 %7.0f  p90 %7.0f' % (used[k], used[k + 1], d[:, k].mean(), np.percentile(d[:, k], 10), np.percentile(d[:, k], 90)))
