@@ -57,7 +57,8 @@ struct DaPostArgs {
   uint32_t drop_row0;
 };
 int da_post_rows(int R, int Nv = 0);
-int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s);
+// tail (optional): the next layer's ln_proj launch on the block output (x = a.out, same rows, plain shape) rides at the end of this one
+int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s, const LnProjArgs* tail = nullptr);
 
 }  // namespace hual
 

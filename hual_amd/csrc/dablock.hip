@@ -46,9 +46,11 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_pair_kernel(LnProjArgs a0,
 // T-form (tilecore.h), like da_mid_bwd_kernel below: wave `wave` owns output columns 16 wave .. 16 wave + 15 of all NT row tiles and
 // keeps its weight fragments (T images, straight from L2, requested a step ahead) in registers.  Accumulator rt of lane (j, g) = row
 // 16 rt + j, columns 16 wave + 4 g .. + 3.  The row phases RP0 - RP2 keep the 32-lane row layout (thread group grp: rows grp + 16 u).
-template <int NT>
-__global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) char dp_lds[];
+// TAIL (round 5, as in conv_block_fwd_lnproj_kernel): the next dual attention layer's layer norms + projections (lnproj_body.h) go on with
+// the block output of the same rows instead of a launch of their own - the output tiles pass through slot 0 as fp32 rows, the tail's
+// operand slots take slots 1 .. 3, its small vectors are staged with this kernel's
+template <int NT, bool TAIL>
+__device__ __forceinline__ void da_post_body(const DaPostArgs& a, const DropCfg& drop, const LnProjArgs* lp, char* dp_lds) {
   char* P0 = dp_lds;
   char* P1 = P0 + DP_SLOT;
   char* P2 = P1 + DP_SLOT;
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
   float* ainv1 = ainv0 + DP_ROWS;
   float* ainv2 = ainv1 + DP_ROWS;
   float* ainv3 = ainv2 + DP_ROWS;
+  float4* TP = reinterpret_cast<float4*>(ainv3 + DP_ROWS);         // TAIL: [LNP_TP_VECS][32] float4
   float4* scratch = reinterpret_cast<float4*>(P0);                 // fp32 rows [48][32] float4 for the LN2 pass (= slot 0)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -105,6 +108,22 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
     const float* po = vec_ptr(min(2 * wv + 1, 10));
     const float4 pv = ld4_global(((lane & 32) ? po : pe) + col);
     if (grp < DP_NB) bl[grp * 32 + l32] = pv;
+    if (TAIL) {                                              // group k < LNP_TP_VECS: vector k of the tail (absent ones: any valid address)
+      auto tail_ptr = [&](int k) -> const float* {
+        const float* q = lp->g1;
+        if (k == 1) q = lp->b1;
+        if (k == 2 && lp->g2) q = lp->g2;
+        if (k == 3 && lp->g2) q = lp->b2;
+#pragma unroll
+        for (int i = 0; i < HUAL_LNPROJ_MAX; ++i)
+          if (k == 4 + i && i < lp->nproj && lp->bias[i]) q = lp->bias[i];
+        return q;
+      };
+      const float* te = tail_ptr(min(2 * wv, LNP_TP_VECS - 1));
+      const float* to = tail_ptr(min(2 * wv + 1, LNP_TP_VECS - 1));
+      const float4 tv = ld4_global(((lane & 32) ? to : te) + col);
+      if (grp < LNP_TP_VECS) TP[grp * 32 + l32] = tv;
+    }
   }
   tf_load_w(wb, a.w[1], wave, lane);
   // ---- RP0: attention outputs -> slots 0, 1
@@ -307,8 +326,23 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropC
       if (dr.enabled) v = f4_select(nbe[rt], make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
       v = cb_add(v, SV[rt]);
       save(a.out, rt, v);
+      if (TAIL) scratch[(16 * rt + j) * 32 + (ecol >> 2)] = v;      // (slot 0 has been free since the LN2 pass)
     }
   }
+  if (TAIL) {
+    cb_barrier();      // the rows are complete, and every wave is through its last product (slot 2)
+    ln_proj_body<NT, true, true>(*lp, drop, P1, r0, scratch, r0, 32, DP_ROWS, TP);
+  }
+}
+template <int NT>
+__global__ __launch_bounds__(CB_THREADS) void da_post_kernel(DaPostArgs a, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char dp_lds[];
+  da_post_body<NT, false>(a, drop, nullptr, dp_lds);
+}
+template <int NT>
+__global__ __launch_bounds__(CB_THREADS) void da_post_lnproj_kernel(DaPostArgs a, DropCfg drop, LnProjArgs lp) {
+  extern __shared__ __attribute__((aligned(16))) char dp_lds[];
+  da_post_body<NT, true>(a, drop, &lp, dp_lds);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -827,17 +861,35 @@ int launch_ln_proj_pair(const LnProjArgs& a0, const LnProjArgs& a1, const DropCf
   return 0;
 }
 
-int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s) {
+int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s, const LnProjArgs* tail) {
   HUAL_REQUIRE(a.s_att && a.x_att && a.ln1 && a.x && a.rowmask && a.ln2_g && a.ln2_b && a.R > 0, "da_post: null / empty");
   HUAL_REQUIRE(a.MT >= 1 && a.MT <= DP_ROWS, "da_post: MT must be 1..48");
   for (int k = 0; k < 11; ++k) HUAL_REQUIRE(a.w[k] != nullptr, "da_post: null weight image");
   for (int k = 0; k < 9; ++k) HUAL_REQUIRE(a.b[k] != nullptr, "da_post: null bias");
   HUAL_REQUIRE(a.sv && a.xv && a.sg && a.xg && a.o && a.gd && a.gate && a.val && a.mha && a.res && a.l2 && a.out && a.mean2 && a.rstd2,
                "da_post: null output");
-  const size_t lds = (size_t)4 * DP_SLOT + DP_NB * 512 + 4 * DP_ROWS * sizeof(float);
+  const size_t lds = (size_t)4 * DP_SLOT + DP_NB * 512 + 4 * DP_ROWS * sizeof(float) + (tail ? 10 * 512 : 0);
   const double rows = (double)a.R;
-  const double flops = 11.0 * 2.0 * rows * HUAL_D * HUAL_D, bytes = 4.0 * (rows * HUAL_D * 16.0 + 11.0 * HUAL_D * HUAL_D);
+  double flops = 11.0 * 2.0 * rows * HUAL_D * HUAL_D, bytes = 4.0 * (rows * HUAL_D * 16.0 + 11.0 * HUAL_D * HUAL_D);
   const dim3 grid(xcd_clip_grid(a.R, a.Nv, a.MT));
+  if (tail) {
+    // the tail works on this launch's tiles (lnproj_body.h): rows of the block output from LDS, operand slots over slots 1 .. 3
+    LnProjArgs lp = *tail;
+    lp.MT = a.MT;
+    int rc = check_ln_proj(lp);
+    if (rc) return rc;
+    HUAL_REQUIRE(lp.x == a.out && lp.R == a.R && ln_proj_plain(lp), "da_post: the tail must read the block output and be of the plain shape");
+    static_assert(DP_SLOT + LN_PROJ_LDS <= 4 * DP_SLOT, "the tail's operand slots must fit slots 1 .. 3");
+    flops += 2.0 * rows * HUAL_D * HUAL_D * lp.nproj;
+    bytes += 4.0 * rows * HUAL_D * (lp.nproj + (lp.g2 ? 1.0 : 0.0));
+    switch (cdiv(a.MT, 16)) {
+      case 1: { HUAL_DYN_LDS(da_post_lnproj_kernel<1>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_post_lnproj_kernel<1>, grid, dim3(CB_THREADS), lds, s, a, drop, lp); break; }
+      case 2: { HUAL_DYN_LDS(da_post_lnproj_kernel<2>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_post_lnproj_kernel<2>, grid, dim3(CB_THREADS), lds, s, a, drop, lp); break; }
+      default: { HUAL_DYN_LDS(da_post_lnproj_kernel<3>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_post_lnproj_kernel<3>, grid, dim3(CB_THREADS), lds, s, a, drop, lp); break; }
+    }
+    HUAL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   switch (cdiv(a.MT, 16)) {      // row tiles per workgroup
     case 1: { HUAL_DYN_LDS(da_post_kernel<1>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_post_kernel<1>, grid, dim3(CB_THREADS), lds, s, a, drop); break; }
     case 2: { HUAL_DYN_LDS(da_post_kernel<2>, 160 * 1024); HUAL_LAUNCH(flops, bytes, da_post_kernel<2>, grid, dim3(CB_THREADS), lds, s, a, drop); break; }

@@ -489,6 +489,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
   if (da0_tail) fill_da_ln_proj(c, da0_lp, 0, R, Nv);
   x = conv_block_fwd(c, "cb", x, pm.cb, rs, HUAL_SITE_CONV, nullptr, nullptr, da0_tail ? &da0_lp : nullptr, &da0_lp_done);
   // ---------------- dual attention layers (model.py:60-68)
+  bool da_lp_done = da0_lp_done;      // this layer's ln_proj went with the previous launch (the conv block's / the previous layer's da_post)
   for (int li = 0; li < c.cfg->attn_layer; ++li) {
     const DualAttnP& d = pm.da[li];
     const std::string t = "da" + std::to_string(li);
@@ -500,7 +501,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
     float* rstd = c.vec(t + ".rstd");
     float* qkv = c.buf(t + ".qkv", R, 3 * D);
     float* ktvt = c.buf(t + ".ktvt", R, 2 * D);
-    if (!(li == 0 && da0_lp_done)) {      // layer norms + the five projections in one launch (dablock.h); layer 0's rode in the conv block's
+    if (!da_lp_done) {      // layer norms + the five projections in one launch (dablock.h) - unless they rode in the launch in front
       LnProjArgs lp{};
       fill_da_ln_proj(c, lp, li, R, Nv);
       lp.x = x;
@@ -556,7 +557,13 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       pa.l2 = l2; pa.out = xo; pa.mean2 = mean2; pa.rstd2 = rstd2;
       pa.site = site; pa.R = R; pa.Nv = Nv; pa.MT = da_post_rows(R, Nv); pa.drop_row0 = 0;
       pa.bits2 = c.bits(t + ".kb2", R); pa.bits3 = c.bits(t + ".kb3", R); pa.bits4 = c.bits(t + ".kb4", R);
-      if (c.live()) c.chk(launch_da_post(pa, c.drop, c.stream));
+      // the next layer's layer norms + projections ride at the end of this launch when the whole graph runs
+      static const bool no_tail = getenv("HUAL_CB_NO_TAIL") != nullptr && atoi(getenv("HUAL_CB_NO_TAIL")) != 0;      // (A/B timings)
+      LnProjArgs nlp{};
+      const bool fuse = li + 1 < c.cfg->attn_layer && c.sel_stage < 0 && !no_tail;
+      if (fuse) { fill_da_ln_proj(c, nlp, li + 1, R, Nv); nlp.x = xo; }
+      if (c.live()) c.chk(launch_da_post(pa, c.drop, c.stream, fuse ? &nlp : nullptr));
+      da_lp_done = fuse;
     }
     x = xo;
   }
