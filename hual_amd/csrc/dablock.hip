@@ -442,7 +442,9 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       if (l32 == 0) ai[lr] = ok ? inv : 0.f;
     }
   };
+  HUAL_STAMP_K(4, 0);
   fill(0);
+  HUAL_STAMP_K(4, 1);
   float4 acc0[NT], acc1[NT];
   bool first0 = true, first1 = true;
 #pragma unroll
@@ -466,10 +468,12 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       tf_load_w(w[(k + 1) & 1], a.wimg_t[k + 1], wave, lane);
     }
     cb_barrier();
+    HUAL_STAMP_K(4, 2 + 3 * k);
     const char* S = (k & 1) ? S1 : S0;
     const float* ai = (k & 1) ? ainv1 : ainv0;
     f32x4 accp[NT];
     tf_mma_lean<NT, LB_ROWS * 256>(S, w[k & 1], lane, accp);
+    HUAL_STAMP_K(4, 3 + 3 * k);
     {
       const bool to1 = a.dst[k] != 0;
       const bool first = to1 ? first1 : first0;
@@ -484,8 +488,10 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     }
     if (a.dst[k] != 0) first1 = false; else first0 = false;
     if (more) fill(k + 1);                             // slot (k+1)&1 was last read by product k-1
+    HUAL_STAMP_K(4, 4 + 3 * k);
   }
   cb_barrier();                                        // every wave is through the last product: both slots are free
+  HUAL_STAMP_K(4, 20);
   // ---- the two output-gradient tiles -> LDS as fp32 rows
   float4* D0 = reinterpret_cast<float4*>(S0);
   float4* D1 = reinterpret_cast<float4*>(S1);
@@ -511,6 +517,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     }
   }
   cb_barrier();
+  HUAL_STAMP_K(4, 21);
   // ---- row phase: layer norm(s) backward.  dy = dy*g ; dx = rstd * (gv - mean(gv) - xhat * mean(gv * xhat))   (ln_bwd_kernel)
   float4 sg1 = f4zero(), sb1 = f4zero();
 #pragma unroll
@@ -543,6 +550,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       st4(a.dz + off, dx);
     }
   }
+  HUAL_STAMP_K(4, 22);
   // ---- parameter sums of the workgroup: halves of a wave in registers, the 8 waves through LDS (the weight buffer is free)
   {
     auto xor32_sum = [&](float v) {
@@ -565,6 +573,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     for (int w = 0; w < 8; ++w) s += pf[w * 4 * HUAL_D + e];
     a.part[(size_t)tile_ * 4 * HUAL_D + e] = s;
   }
+  HUAL_STAMP_K(4, 23);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@
 #define HUAL_STAMP_SLOTS 64
 static __device__ unsigned long long g_hual_stamps[512 * HUAL_STAMP_SLOTS];      // one table per translation unit
 // HUAL_STAMPS selects the kernel that writes: 2 conv_block_fwd_kernel, 3 conv_block_bwd_kernel, 9 mproj kernels carry stamps (build:
-// HUAL_STAMPS=<n> python -m hual_amd.build); ids 1 / 4 / 5 / 6 are reserved for da_post / ln_proj_bwd / da_mid_bwd / ln_proj, whose stamps
+// HUAL_STAMPS=<n> python -m hual_amd.build), 4 ln_proj_bwd_kernel (round 5) and the ln_proj tail of conv_block_fwd (id 2, slots 26 ..) too; ids 1 / 5 / 6 are reserved for da_post / da_mid_bwd / ln_proj, whose stamps
 // are put in for a measurement with HUAL_STAMP_K(id, slot) at the phase boundaries and taken out again
 // -DHUAL_STAMPS_FIRST: a slot keeps its FIRST stamp since hual_debug_stamps_reset() - the first launch of the kernel in the step that
 // follows the reset instead of the last one
