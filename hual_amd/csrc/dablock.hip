@@ -352,7 +352,10 @@ __global__ __launch_bounds__(CB_THREADS) void da_post_lnproj_kernel(DaPostArgs a
 #define LB_ROWS 48
 #define LB_U (LB_ROWS / 16)     // rows of a 32-lane group in the row layout
 // PRE: with the layer-norm prologue (LnProjBwdArgs::pre_*) - a compile-time switch, the plain launches do not pay for its branches
-template <bool PRE, int NT>
+// SIX: the dual attention's shape - six products, the last two into the second layer norm, no dropout' on an operand, add_dy1, both
+// layer norms, a residual addend - as compile-time facts (ln_proj_bwd_six() on the host): per product ~100 of ~575 instructions of a
+// wave were selects and compares on those uniform options, and a pair of waves saturates its SIMD's issue in these phases
+template <bool PRE, int NT, bool SIX = false>
 __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char lb_lds[];
   char* S0 = lb_lds;                                   // operand slot 0: hi | lo planes [48][256 B]; later dy_0 as fp32 rows
@@ -383,14 +386,18 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   const float* a0p = pre ? a.pre_dy : a.A[0];
   const int lda0 = pre ? HUAL_D : a.lda[0];
   uint32_t nkb[LB_U];                                  // keep-bit bytes of the operand rows in flight
-  const uint8_t* kb0p = a.a_bits[0] ? a.a_bits[0] : reinterpret_cast<const uint8_t*>(a.x);
+  const int nsteps = SIX ? 6 : a.nsteps;
+  auto has_bits = [&](int k) { return !SIX && a.a_bits[k] != nullptr; };
+  auto to_second = [&](int k) { return SIX ? k >= 4 : a.dst[k] != 0; };
+  const bool has_g2 = SIX || a.g2 != nullptr, has_add_dy1 = SIX || a.add_dy1 != nullptr, has_dy1_bits = !SIX && a.dy1_bits != nullptr;
+  const uint8_t* kb0p = has_bits(0) ? a.a_bits[0] : reinterpret_cast<const uint8_t*>(a.x);
   float4 pxv[LB_U];                                    // prologue: rows / statistics of the layer norm in front
   float pmu[LB_U], prs[LB_U];
 #pragma unroll
   for (int u = 0; u < LB_U; ++u) {
     const int row = min(r0 + grp + 16 * u, R - 1);
     nv[u] = ld4(a0p + (size_t)row * lda0 + col);
-    nkb[u] = kb0p[(size_t)row * 16 + (l32 >> 1)];
+    nkb[u] = SIX ? 0u : kb0p[(size_t)row * 16 + (l32 >> 1)];
     xv[u] = ld4(a.x + (size_t)row * HUAL_D + col);
     a1v[u] = ld4(add1p + (size_t)row * HUAL_D + col);
     mu[u] = a.mean[row];
@@ -419,11 +426,11 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       a1v[u] = dx;
     }
   }
-  const float4 g2 = a.g2 ? ld4(a.g2 + col) : f4zero();
+  const float4 g2 = has_g2 ? ld4(a.g2 + col) : f4zero();
   float4 addt[NT];                                     // add_dy1 in the accumulator layout
-  const float* addp = a.add_dy1 ? a.add_dy1 : a.x;
+  const float* addp = has_add_dy1 ? a.add_dy1 : a.x;
 #pragma unroll
-  for (int rt = 0; rt < NT; ++rt) addt[rt] = ld4(addp + (uint32_t)min(r0 + 16 * rt + j, R - 1) * (uint32_t)HUAL_D + (uint32_t)ecol);
+  for (int rt = 0; rt < NT; ++rt) addt[rt] = SIX ? f4zero() : ld4(addp + (uint32_t)min(r0 + 16 * rt + j, R - 1) * (uint32_t)HUAL_D + (uint32_t)ecol);      // (SIX: requested in front of the last product - 12 registers less across the loop)
   // rows -> operand planes of slot `k & 1` (with the operand's dropout', saved for the weight-gradient job)
   auto fill = [&](int k) {
     char* S = (k & 1) ? S1 : S0;
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
       if (lr >= MT) continue;
       const bool ok = row < RE;
       float4 v = ok ? nv[u] : f4zero();
-      if (a.a_bits[k]) {      // dropout' with the keep bits the forward left (requested with the rows)
+      if (has_bits(k)) {      // dropout' with the keep bits the forward left (requested with the rows)
         if (dr.enabled) v = f4_select((nkb[u] >> (4 * (l32 & 1))) & 15u, make_float4(v.x * dr.scale, v.y * dr.scale, v.z * dr.scale, v.w * dr.scale));
         if (ok && a.a_save[k]) st4_nt(a.a_save[k] + (size_t)row * HUAL_D + col, v);
       }
@@ -453,17 +460,21 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   // before it arrives here); the next product's rows and weight fragments are requested in front of it
 #pragma unroll
   for (int k = 0; k < HUAL_LNBWD_MAX; ++k) {
-    if (k >= a.nsteps) break;                          // uniform
-    const bool more = k + 1 < a.nsteps;
+    if (k >= nsteps) break;                            // uniform
+    const bool more = k + 1 < nsteps;
+    if (SIX && k == 5) {
+#pragma unroll
+      for (int rt = 0; rt < NT; ++rt) addt[rt] = ld4(addp + (uint32_t)min(r0 + 16 * rt + j, R - 1) * (uint32_t)HUAL_D + (uint32_t)ecol);
+    }
     if (more) {
-      const uint8_t* nbp = a.a_bits[k + 1] ? a.a_bits[k + 1] : reinterpret_cast<const uint8_t*>(a.x);      // (no bits: a byte that is ignored)
+      const uint8_t* nbp = has_bits(k + 1) ? a.a_bits[k + 1] : reinterpret_cast<const uint8_t*>(a.x);      // (no bits: a byte that is ignored)
       const float* nap = a.A[k + 1];
       const int nld = a.lda[k + 1];
 #pragma unroll
       for (int u = 0; u < LB_U; ++u) {
         const size_t row = (size_t)min(r0 + grp + 16 * u, R - 1);
         nv[u] = ld4(nap + row * nld + col);
-        nkb[u] = nbp[row * 16 + (l32 >> 1)];
+        nkb[u] = SIX ? 0u : nbp[row * 16 + (l32 >> 1)];
       }
       tf_load_w(w[(k + 1) & 1], a.wimg_t[k + 1], wave, lane);
     }
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     tf_mma_lean<NT, LB_ROWS * 256>(S, w[k & 1], lane, accp);
     HUAL_STAMP_K(4, 3 + 3 * k);
     {
-      const bool to1 = a.dst[k] != 0;
+      const bool to1 = to_second(k);
       const bool first = to1 ? first1 : first0;
 #pragma unroll
       for (int rt = 0; rt < NT; ++rt) {
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
         if (to1) acc1[rt] = n; else acc0[rt] = n;
       }
     }
-    if (a.dst[k] != 0) first1 = false; else first0 = false;
+    if (to_second(k)) first1 = false; else first0 = false;
     if (more) fill(k + 1);                             // slot (k+1)&1 was last read by product k-1
     HUAL_STAMP_K(4, 4 + 3 * k);
   }
@@ -499,20 +510,20 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
   for (int rt = 0; rt < NT; ++rt) {
     const int lr = 16 * rt + j;
     float4 v = acc0[rt];
-    if (a.add_dy1) v = cb_add(v, addt[rt]);
+    if (has_add_dy1) v = cb_add(v, addt[rt]);
     D0[lr * 32 + (ecol >> 2)] = v;
-    if (a.g2) D1[lr * 32 + (ecol >> 2)] = acc1[rt];
+    if (has_g2) D1[lr * 32 + (ecol >> 2)] = acc1[rt];
   }
   // keep bits of the row phase (dropout' of dy_0 / of dx): requested together in front of the barrier - a load behind a branch
   // inside the row loop is a round trip of its own per row (absent planes: a byte of x that is not used)
   uint32_t kb1[LB_U], kbz[LB_U];
   {
-    const uint8_t* b1p = a.dy1_bits ? a.dy1_bits : reinterpret_cast<const uint8_t*>(a.x);
+    const uint8_t* b1p = has_dy1_bits ? a.dy1_bits : reinterpret_cast<const uint8_t*>(a.x);
     const uint8_t* bzp = a.dz_bits ? a.dz_bits : reinterpret_cast<const uint8_t*>(a.x);
 #pragma unroll
     for (int u = 0; u < LB_U; ++u) {
       const size_t row = (size_t)min(r0 + grp + 16 * u, R - 1);
-      kb1[u] = b1p[row * 16 + (l32 >> 1)];
+      kb1[u] = SIX ? 0u : b1p[row * 16 + (l32 >> 1)];
       kbz[u] = bzp[row * 16 + (l32 >> 1)];
     }
   }
@@ -529,11 +540,11 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     const float mean = mu[u], rstd = rsd[u];
     const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
     float4 dy = D0[lr * 32 + l32];
-    if (a.dy1_bits && dr.enabled) dy = f4_select((kb1[u] >> (4 * (l32 & 1))) & 15u, make_float4(dy.x * dr.scale, dy.y * dr.scale, dy.z * dr.scale, dy.w * dr.scale));
+    if (has_dy1_bits && dr.enabled) dy = f4_select((kb1[u] >> (4 * (l32 & 1))) & 15u, make_float4(dy.x * dr.scale, dy.y * dr.scale, dy.z * dr.scale, dy.w * dr.scale));
     sb1 = cb_add(sb1, dy);
     sg1 = cb_fma(dy, xh, sg1);
     float4 gv = cb_mul(dy, g1);
-    if (a.g2) {
+    if (has_g2) {
       const float4 dy2 = D1[lr * 32 + l32];
       sb2 = cb_add(sb2, dy2);
       sg2 = cb_fma(dy2, xh, sg2);
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(CB_THREADS) void ln_proj_bwd_kernel(LnProjBwdArgs a
     const float m2 = fast_sum32(cb_hsum(cb_mul(gv, xh))) * (1.0f / HUAL_D);
     float4 dx = make_float4(rstd * (gv.x - m1 - xh.x * m2), rstd * (gv.y - m1 - xh.y * m2),
                             rstd * (gv.z - m1 - xh.z * m2), rstd * (gv.w - m1 - xh.w * m2));
-    if (a.add1 || pre) dx = make_float4(__fadd_rn(dx.x, a1v[u].x), __fadd_rn(dx.y, a1v[u].y), __fadd_rn(dx.z, a1v[u].z), __fadd_rn(dx.w, a1v[u].w));
+    if (SIX || a.add1 || pre) dx = make_float4(__fadd_rn(dx.x, a1v[u].x), __fadd_rn(dx.y, a1v[u].y), __fadd_rn(dx.z, a1v[u].z), __fadd_rn(dx.w, a1v[u].w));
     st4(a.dx + off, dx);
     if (a.dz) {
       if (a.dz_bits && dr.enabled) dx = f4_select((kbz[u] >> (4 * (l32 & 1))) & 15u, make_float4(dx.x * dr.scale, dx.y * dr.scale, dx.z * dr.scale, dx.w * dr.scale));
@@ -911,6 +922,14 @@ int launch_da_post(const DaPostArgs& a, const DropCfg& drop, hipStream_t s, cons
 int ln_proj_bwd_rows(int R, int Nv) { return tile_rows(R, Nv, LB_ROWS); }
 int ln_proj_bwd_blocks(int R, int Nv) { return cdiv(R, ln_proj_bwd_rows(R, Nv)); }
 
+// the dual attention's shape (ln_proj_bwd_kernel SIX)
+static bool ln_proj_bwd_six(const LnProjBwdArgs& a) {
+  if (a.pre_x || a.nsteps != 6 || !a.g2 || !a.add_dy1 || a.dy1_bits || !a.add1) return false;
+  for (int k = 0; k < 6; ++k)
+    if (a.a_bits[k] || a.a_save[k] || (a.dst[k] != 0) != (k >= 4)) return false;
+  return true;
+}
+
 int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t s) {
   HUAL_REQUIRE(a.nsteps >= 1 && a.nsteps <= HUAL_LNBWD_MAX && a.R > 0, "ln_proj_bwd: step count / rows");
   HUAL_REQUIRE(a.MT >= 1 && a.MT <= LB_ROWS, "ln_proj_bwd: MT must be 1..48");
@@ -928,9 +947,11 @@ int launch_ln_proj_bwd(const LnProjBwdArgs& a, const DropCfg& drop, hipStream_t 
   const double flops = 2.0 * rows * HUAL_D * HUAL_D * a.nsteps;
   const double bytes = 4.0 * (rows * HUAL_D * ((a.pre_x ? 7.0 : 4.0) + a.nsteps) + (double)a.nsteps * HUAL_D * HUAL_D);
   const dim3 grid(xcd_clip_grid(a.R, a.Nv, a.MT));
+  const bool six = ln_proj_bwd_six(a);
 #define LN_BWD_NT(NT)                                                                                                   \
   {                                                                                                                     \
     if (a.pre_x) { HUAL_DYN_LDS((ln_proj_bwd_kernel<true, NT>), 160 * 1024); HUAL_LAUNCH(flops, bytes, (ln_proj_bwd_kernel<true, NT>), grid, dim3(CB_THREADS), lds, s, a, drop); } \
+    else if (six) { HUAL_DYN_LDS((ln_proj_bwd_kernel<false, NT, true>), 160 * 1024); HUAL_LAUNCH(flops, bytes, (ln_proj_bwd_kernel<false, NT, true>), grid, dim3(CB_THREADS), lds, s, a, drop); } \
     else { HUAL_DYN_LDS((ln_proj_bwd_kernel<false, NT>), 160 * 1024); HUAL_LAUNCH(flops, bytes, (ln_proj_bwd_kernel<false, NT>), grid, dim3(CB_THREADS), lds, s, a, drop); }      \
     break;                                                                                                              \
   }
