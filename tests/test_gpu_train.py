@@ -69,8 +69,9 @@ def _free_run(cfg, p, wv, b, labels, dtype, lr, drop, seed, off, steps):
     return out
 
 
-def test_thirty_step_trajectory_against_free_running_oracle():
-    """30 consecutive steps on one batch at the reference's settings (lr 1e-4, dropout 0.2: configs/charades/SeqPAN.yaml).
+def test_twenty_step_trajectory_against_free_running_oracle():
+    """20 consecutive steps on one batch (30 until round 5: the envelope below is vacuous from step ~12 on - 1e-3 . 2.5^12 = 60 - and the
+    sixty CPU-oracle steps of the two reference trajectories were 180 s of a GPU suite that has to finish in 900 s on any box) at the reference's settings (lr 1e-4, dropout 0.2: configs/charades/SeqPAN.yaml).
     The oracle runs ON ITS OWN - its own parameters, Adam slots and ReLU signs, never re-seeded from the HIP state; only the
     dropout stream (seed, step) is shared.
 
@@ -82,13 +83,13 @@ def test_thirty_step_trajectory_against_free_running_oracle():
     The test runs all three trajectories, prints them side by side, and demands of the HIP path:
       * steps 0-3: loss within 1e-3 relative of the float64 oracle's and the spans EQUAL;
       * steps 4-7: loss within 1e-2 relative (1e-2 absolute below 1);
-      * all 30 steps: logit deviation from the float64 trajectory inside the envelope 1e-3 . 2.5^step (the HIP path injects
+      * all 20 steps: logit deviation from the float64 trajectory inside the envelope 1e-3 . 2.5^step (the HIP path injects
         more rounding per step than float32 PyTorch - split-bf16 weight-gradient and attention-backward products, 2^-16 per
         product - and the printed table shows both deviations side by side);
       * the float64 loss actually falls (an optimizer that does nothing would pass the rest).
-    Step-by-step agreement over the whole 30 steps (same state on both sides at every step) is test_train_steps_match_oracle."""
+    Step-by-step agreement over 30 steps (same state on both sides at every step) is test_train_steps_match_oracle."""
     from hual_amd.train import Trainer
-    lr, drop, seed, off, steps = 1e-4, 0.2, 31, 11, 30
+    lr, drop, seed, off, steps = 1e-4, 0.2, 31, 11, 20
     cfg, p, wv, b, labels = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
     m = pu.hip_model(cfg, p, wv)
     m.set_rng(seed, off)
