@@ -41,6 +41,7 @@ int launch_ln_proj(const LnProjArgs& a, const DropCfg& drop, hipStream_t s);
 int check_ln_proj_args(const LnProjArgs& a);
 bool ln_proj_plain(const LnProjArgs& a);         // the query / key / value shape (lnproj_body.h PLAIN): a leaner instantiation      // (the argument checks of launch_ln_proj, for the launch that carries it as a tail: convblock.h)
 int launch_ln_proj_pair(const LnProjArgs& a0, const LnProjArgs& a1, const DropCfg& drop, hipStream_t s);   // two problems, one launch
+int ln_proj_pair_rows(int R);              // rows per workgroup for the pair launch: both problems within one workgroup per CU
 
 struct DaPostArgs {
   const float* s_att; const float* x_att; const float* ln1; const float* x;    // [R,128] inputs (x: the layer input, residual)

@@ -809,6 +809,13 @@ namespace hual {
 // whole 16-row tiles, rows of the last tile beyond the workgroup's own are computed on stale operands and discarded.
 static int tile_rows(int R, int Nv, int max_rows) { return xcd_clip_rows(R, Nv, 16, max_rows); }
 int ln_proj_rows(int R, int Nv) { return tile_rows(R, Nv, LP_ROWS); }
+// the pair launch: BOTH problems in one round of workgroups (a workgroup fills a CU: 2 x 256 workgroups of 32 rows ran as two rounds,
+// each paying the cold start - weights, parameters, layer-norm phase)
+int ln_proj_pair_rows(int R) {
+  int mt = 16;
+  while (mt < LP_ROWS && 2 * xcd_clip_grid(R, 0, mt) > 256) ++mt;
+  return mt;
+}
 int da_post_rows(int R, int Nv) { return tile_rows(R, Nv, DP_ROWS); }
 
 static int check_ln_proj(const LnProjArgs& a) {

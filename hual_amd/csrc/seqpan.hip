@@ -709,7 +709,7 @@ int forward_graph(Ctx& c, const hual_batch* bt, const hual_labels* lab, const hu
       LnProjArgs lp{};
       lp.x = feo[h]; lp.g1 = c.p(lnp.g); lp.b1 = c.p(lnp.b); lp.y1 = h == 0 ? sfn : efn; lp.drop_site1 = -1; lp.pre_site = -1;
       lp.mean = hmean + (size_t)h * Nv; lp.rstd = hrstd + (size_t)h * Nv; lp.x2 = outputs;
-      lp.nproj = 2; lp.R = Nv; lp.MT = ln_proj_rows(Nv); lp.drop_row0 = 0;
+      lp.nproj = 2; lp.R = Nv; lp.MT = ln_proj_pair_rows(Nv); lp.drop_row0 = 0;
       lp.wimg[0] = c.timg(hp.k, 0); lp.src[0] = 0; lp.accum[0] = 1; lp.out_site[0] = -1;
       lp.wimg[1] = c.timg(hp.k, 1); lp.src[1] = 1; lp.bias[1] = c.p(hp.b);
       lp.act[1] = 1; lp.out[1] = h == 0 ? hs : he; lp.ldo[1] = D; lp.out_site[1] = -1;
