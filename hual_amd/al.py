@@ -47,15 +47,23 @@ def get_coff(task, I):
 
 
 # ---------------------------------------------------------------- infer_trainset ----------------
-def infer_trainset(model, batches, mc_dropout=None):
+def infer_trainset(model, batches, mc_dropout=None, batch_ids=None):
     """eval_test_save (runner_utils.py:69-110) without the file write: returns (records, ious).
 
     batches: iterable of (raw_records, video, video_seq_len, word_ids, char_ids) as TestLoader.test_iter yields them
     (data_loader.py:131-143).  Each record of the result has the keys of runner_utils.py:90-100; logits are the raw
     [T_b] rows of the batch (unmasked beyond v_len), m_score is [T_b, 4].
+    batch_ids (with mc_dropout): the position of each yielded batch in the whole pass - the two stochastic forwards of batch i use the
+    Philox offsets base + 2 i and base + 2 i + 1, whichever rank runs the batch and whatever ran before it (infer_trainset_sharded).
     """
     from . import data
     records, ious = [], []
+    batch_ids = iter(batch_ids) if batch_ids is not None else None
+    rng_base = int(model.rng_state[2].item()) & 0xFFFFFFFF if (batch_ids is not None and mc_dropout is not None) else None
+    rng_seed = None
+    if rng_base is not None:
+        st = model.rng_state.cpu().numpy().view(np.uint32)
+        rng_seed = int(st[0]) | (int(st[1]) << 32)
 
     def enqueue(batch):
         """all forwards of a batch (one deterministic + two stochastic), nothing fetched: the device runs them while the host
@@ -64,6 +72,8 @@ def infer_trainset(model, batches, mc_dropout=None):
         o = model.forward(video, lens, word_ids, char_ids, drop_rate=0.0)
         dev = [o['start_logits'], o['end_logits'], o['match_scores'], o['start_index'], o['end_index']]
         if mc_dropout is not None:
+            if rng_base is not None:
+                model.set_rng(rng_seed, rng_base + 2 * int(next(batch_ids)))
             o1 = model.forward(video, lens, word_ids, char_ids, drop_rate=mc_dropout)
             model.rng_state[2] += 1                              # a fresh Philox offset for the second stochastic pass
             o2 = model.forward(video, lens, word_ids, char_ids, drop_rate=mc_dropout)
@@ -104,6 +114,41 @@ def infer_trainset(model, batches, mc_dropout=None):
     if pending is not None:
         emit(pending)
     return records, ious
+
+
+def infer_trainset_sharded(model, dataset, batch_size, mc_dropout=None, min_chars=4):
+    """infer_trainset over a DeviceDataset in the reference's order (TrainNoSuffleLoader.test_iter, data_loader.py:167-206), the
+    batches dealt round-robin to the ranks of the process group (batch i -> rank i % world; every rank holds the whole set):
+    rank 0 returns (records, ious) of the WHOLE set in sample order, the other ranks (None, None).  One rank: the plain pass.
+    The batches are the single-process ones (own padded shape each), so the records equal a single-process pass; the Philox offsets
+    of the stochastic forwards depend on the batch index only."""
+    from . import dist as hdist
+    world, rank = hdist.world_size(), hdist.rank()
+    N = len(dataset)
+    los = list(range(0, N, batch_size))
+    own = [i for i in range(len(los)) if i % world == rank]
+
+    def batches():
+        for i in own:
+            sel = np.arange(los[i], min(N, los[i] + batch_size))
+            f = dataset.assemble(sel, out=None, labels=False, min_chars=min_chars)
+            yield [dataset.records[k] for k in sel], f['video'], f['video_seq_len'], f['word_ids'], f['char_ids']
+    st0 = model.rng_state.cpu().numpy().view(np.uint32).copy()
+    records, ious = infer_trainset(model, batches(), mc_dropout=mc_dropout, batch_ids=own)
+    if mc_dropout is not None:                                  # every rank leaves the stream behind the WHOLE pass
+        model.set_rng(int(st0[0]) | (int(st0[1]) << 32), int(st0[2]) + 2 * len(los))
+    parts = hdist.gather_objects((own, records, ious))
+    if parts is None:
+        return None, None
+    out_r, out_i = [None] * N, [None] * N
+    for own_r, recs_r, ious_r in parts:
+        k = 0
+        for i in own_r:
+            n = min(N, los[i] + batch_size) - los[i]
+            out_r[los[i]:los[i] + n] = recs_r[k:k + n]
+            out_i[los[i]:los[i] + n] = ious_r[k:k + n]
+            k += n
+    return out_r, out_i
 
 
 def calculate_iou(i0, i1):
@@ -248,11 +293,18 @@ def run_round(model, dataset, data_old, data_gt, last_prop, task, I, epochs, bat
     """One active-learning round of run_charades.py:9-41 on device-resident data:
          update_label.py <task> I   ->  main.py --mode train (epochs)   ->  main.py --mode infer_trainset
     dataset: DeviceDataset over the training records in the SAME order as data_old / data_gt / last_prop.
-    Returns (new train list, new results records, metrics dict)."""
+    Data parallel (torch.distributed initialised, one process per GPU): every rank calls this with the same dataset and train lists;
+    `last_prop` is needed on rank 0 only (the other ranks may pass None).  Rank 0 renews the labels and broadcasts the new train
+    list, the epochs run data parallel (`batch_size` clips per rank, Trainer.run_epoch), infer_trainset is sharded by batch and its
+    records are gathered on rank 0.
+    Returns (new train list, new results records - rank 0 only, else None -, metrics dict)."""
     import time
+    from . import dist as hdist
     from .train import Trainer
+    world, rank = hdist.world_size(), hdist.rank()
     t0 = time.perf_counter()
-    new_data = update_labels(data_old, data_gt, last_prop, get_coff(task, I), device=model.device)
+    new_data = update_labels(data_old, data_gt, last_prop, get_coff(task, I), device=model.device) if rank == 0 else None
+    new_data = hdist.broadcast_object(new_data)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     s_ind, e_ind = labels_from_times(new_data, dataset.vlen_h)
@@ -260,31 +312,25 @@ def run_round(model, dataset, data_old, data_gt, last_prop, task, I, epochs, bat
     for r, a, b in zip(dataset.records, s_ind, e_ind):
         r['s_ind'], r['e_ind'] = int(a), int(b)
     N = len(dataset)
-    tr = trainer if trainer is not None else Trainer(model, world=1, use_graph=True)
-    rng = np.random.default_rng(shuffle_seed)
+    tr = trainer if trainer is not None else Trainer(model, world=world, use_graph=True)
+    rng = np.random.default_rng(shuffle_seed)                   # the same permutations on every rank
     steps = 0
     for ep in range(epochs):
         cur_lr = lr * (1.0 - ep / epochs)                       # main.py:61
         order = rng.permutation(N)                              # random.shuffle(self.dataset), data_loader.py:24
         tr.run_epoch(dataset, order, batch_size, lr=cur_lr, drop_rate=drop_rate, min_chars=4)      # spans fetched: train_epoch's IoU log
-        steps += (N + batch_size - 1) // batch_size
+        steps += (N + batch_size * world - 1) // (batch_size * world)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-
-    def batches():
-        f = None
-        for lo in range(0, N, batch_size):
-            sel = np.arange(lo, min(N, lo + batch_size))
-            f = dataset.assemble(sel, out=None, labels=False, min_chars=4)
-            yield [dataset.records[i] for i in sel], f['video'], f['video_seq_len'], f['word_ids'], f['char_ids']
-    records, ious = infer_trainset(model, batches(), mc_dropout=mc_dropout)
+    records, ious = infer_trainset_sharded(model, dataset, batch_size, mc_dropout=mc_dropout, min_chars=4)
     torch.cuda.synchronize()
     t3 = time.perf_counter()
-    r3, r5, r7, mi = iou_metrics(ious)
+    met = hdist.broadcast_object(iou_metrics(ious) if rank == 0 else None)
+    r3, r5, r7, mi = met
     m = dict(update_s=t1 - t0, train_s=t2 - t1, infer_s=t3 - t2, train_steps=steps, clips_per_s=N * epochs / max(t2 - t1, 1e-9),
-             step_launch_modes=dict(tr.stats),
+             step_launch_modes=dict(tr.stats), world=world,
              r1i3=r3, r1i5=r5, r1i7=r7, miou=mi)
-    if log:
+    if log and rank == 0:
         log('round %d: update_label %.3f s | train %d steps %.3f s (%.0f clips/s) | infer_trainset %.3f s | pseudo-label '
             'R1@0.5 %.2f mIoU %.2f' % (I, m['update_s'], steps, m['train_s'], m['clips_per_s'], m['infer_s'], r5, mi))
     return new_data, records, m

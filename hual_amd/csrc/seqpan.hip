@@ -53,6 +53,7 @@ struct Ctx {
   std::vector<ColsumJob> colsum;
   int rc = 0;
   bool static_tables = false;   // hual_run_opts.static_tables
+  void* ext_table = nullptr; size_t ext_table_bytes = 0;      // hual_run_opts.dw_table
   int wall_K = 0; uint32_t wall_off = 0, wall_boff = 0;      // packed char-CNN filter bank inside PKT / PKN (setup_ctx)
   struct DenseW { size_t off; int K; size_t boff; uint8_t need; };      // need: HUAL_PACK_* images the kernels read of this weight
   bool ksplit = false;                // feature-load phase on the K-split kernel (plan)
@@ -215,6 +216,10 @@ void flush_dw(Ctx& c) {
   if (n == 0) return;
   std::stable_sort(c.dwjobs.begin(), c.dwjobs.end(), [](const DwJob& a, const DwJob& b) { return a.M > b.M; });
   DwJob* table = reinterpret_cast<DwJob*>(c.buf("dw.table.0", 1, dw_table_words(n)));
+  if (!c.dry && c.ext_table) {       // the caller's own table (one per padded shape of an epoch loop) instead of the workspace copy
+    if (4 * dw_table_words(n) > c.ext_table_bytes) { c.chk(fail(HUAL_ERR_INVALID, "hual_run_opts.dw_table too small: hual_seqpan_dw_table_bytes()")); return; }
+    table = reinterpret_cast<DwJob*>(c.ext_table);
+  }
   if (!c.dry && c.ok()) c.chk(launch_dw(c.dwjobs.data(), (int)n, c.drop, c.stream, table, !c.static_tables));
   c.dwjobs.clear();
 }
@@ -1249,6 +1254,10 @@ int hual_seqpan_validate(const hual_cfg* cfg) {
   return validate_cfg(*cfg);
 }
 
+// room for the weight-gradient jobs of any configuration (attn_layer 2: 62 jobs; every further dual-attention layer adds 16)
+#define HUAL_DW_TABLE_JOBS 256
+uint64_t hual_seqpan_dw_table_bytes(void) { return 4 * dw_table_words(HUAL_DW_TABLE_JOBS); }
+
 int hual_seqpan_param_count(const hual_cfg* cfg, uint64_t* padded_floats, uint64_t* count) {
   HUAL_REQUIRE(cfg != nullptr, "null cfg");
   ParamMap pm;
@@ -1353,6 +1362,9 @@ int hual_seqpan_backward(const hual_cfg* cfg, const float* params, const float* 
   c.P = params;
   c.G = grads;
   c.static_tables = opts->static_tables != 0;
+  HUAL_REQUIRE(!opts->dw_table || ((uintptr_t)opts->dw_table & 15) == 0, "unaligned hual_run_opts.dw_table");
+  c.ext_table = opts->dw_table;
+  c.ext_table_bytes = (size_t)opts->dw_table_bytes;
   c.word_table = word_table;
   c.drop = make_dropcfg(opts->rng_state, opts->drop_rate);
   c.rs.rowmask = c.vec("rowmask");

@@ -105,6 +105,28 @@ def process_train_batch(records, visual_feats):
                  inner_labels=inner)
 
 
+def pad_batch_to(batch, T, L, C):
+    """A processed batch zero-padded to (T, L, C) >= its own maxima, labels re-derived for the padded length: what a data-parallel
+    shard looks like when it is padded to the GLOBAL batch's shape (hual_amd/dist.py shard_plan) - the rows a longer clip / query /
+    word of ANOTHER shard forces onto it are exactly the rows the single-process batch holds for these samples."""
+    B, T0, V = batch['video'].shape
+    L0, C0 = batch['word_ids'].shape[1], batch['char_ids'].shape[2]
+    assert T >= T0 and L >= L0 and C >= C0
+    out = Batch(batch)
+    out['video'] = np.zeros((B, T, V), dtype=np.float32)
+    out['video'][:, :T0] = batch['video']
+    out['word_ids'] = np.zeros((B, L), dtype=np.int32)
+    out['word_ids'][:, :L0] = batch['word_ids']
+    out['char_ids'] = np.zeros((B, L, C), dtype=np.int32)
+    out['char_ids'][:, :L0, :C0] = batch['char_ids']
+    for k in ('y1', 'y2', 'match_labels', 'inner_labels'):
+        if k in batch:
+            a = np.zeros((B, T), dtype=batch[k].dtype)
+            a[:, :T0] = batch[k]
+            out[k] = a
+    return out
+
+
 def process_test_batch(records, visual_feats):
     """data_loader.py:145-164."""
     video, lens = pad_video([visual_feats[r['vid']] for r in records])

@@ -14,9 +14,11 @@ from . import lib
 
 
 class DeviceDataset:
-    def __init__(self, records, visual_feats, device='cuda:0'):
+    def __init__(self, records, visual_feats, device='cuda:0', feat_bank=None):
         """records: dicts with vid, w_ids, c_ids (and s_ind, e_ind for training sets), as produced by the reference's
-        dataset_gen (utils/data_gen.py:98-125); visual_feats: {vid: float32 [n_clips, vdim]} (data_utils.py:56-67)."""
+        dataset_gen (utils/data_gen.py:98-125); visual_feats: {vid: float32 [n_clips, vdim]} (data_utils.py:56-67).
+        feat_bank: the features already on the device as ONE float32 [total_clips, vdim] tensor, videos in sorted-vid order
+        (synthetic sets generated on the GPU); visual_feats then maps vid -> n_clips."""
         if not torch.cuda.is_available():
             raise lib.HualError('DeviceDataset needs a GPU: the HIP path has no CPU fallback')
         self._lib = lib.load()
@@ -24,13 +26,22 @@ class DeviceDataset:
         self.records = records
         vids = sorted({r['vid'] for r in records})
         vid_id = {v: i for i, v in enumerate(vids)}
-        nclips = np.array([visual_feats[v].shape[0] for v in vids], dtype=np.int64)
-        self.vdim = int(visual_feats[vids[0]].shape[1])
+        if feat_bank is not None:
+            nclips = np.array([int(visual_feats[v]) for v in vids], dtype=np.int64)
+            self.vdim = int(feat_bank.shape[1])
+        else:
+            nclips = np.array([visual_feats[v].shape[0] for v in vids], dtype=np.int64)
+            self.vdim = int(visual_feats[vids[0]].shape[1])
         feat_off = np.zeros(len(vids) + 1, dtype=np.int64)
         feat_off[1:] = np.cumsum(nclips)
-        bank = torch.empty(int(feat_off[-1]), self.vdim, dtype=torch.float32, device=self.dev)
-        for i, v in enumerate(vids):
-            bank[int(feat_off[i]):int(feat_off[i + 1])] = torch.from_numpy(np.ascontiguousarray(visual_feats[v], dtype=np.float32))
+        if feat_bank is not None:
+            if feat_bank.dtype != torch.float32 or tuple(feat_bank.shape) != (int(feat_off[-1]), self.vdim) or not feat_bank.is_contiguous():
+                raise ValueError('feat_bank must be a contiguous float32 [%d, vdim] tensor' % int(feat_off[-1]))
+            bank = feat_bank.to(self.dev)
+        else:
+            bank = torch.empty(int(feat_off[-1]), self.vdim, dtype=torch.float32, device=self.dev)
+            for i, v in enumerate(vids):
+                bank[int(feat_off[i]):int(feat_off[i + 1])] = torch.from_numpy(np.ascontiguousarray(visual_feats[v], dtype=np.float32))
         self.feat_bank = bank
         self.sample_vid_h = np.array([vid_id[r['vid']] for r in records], dtype=np.int32)
         self.vlen_h = nclips[self.sample_vid_h].astype(np.int32)
@@ -91,17 +102,23 @@ class DeviceDataset:
                        match_labels=torch.empty(B * T, dtype=i32, device=d), inner_labels=torch.empty(B * T, dtype=f32, device=d))
         return buf
 
-    def assemble(self, sel, out=None, labels=True, min_chars=None, buffers=None, sel_dev=None, carry=None):
+    def assemble(self, sel, out=None, labels=True, min_chars=None, buffers=None, sel_dev=None, carry=None, shape=None):
         """Gather the batch `sel` (sample ids) on the device.  Returns a dict of device tensors named like the feeds of
         model.py:16-27.  out: a dict from a previous call with the same shape to write into (static buffers).
         buffers: feed_buffers() - the returned tensors are views of them (no allocation).  sel_dev: the same ids already on the
         device (a slice of the epoch's permutation): nothing is uploaded for this batch.  carry: (src, dst) int64 device tensors of
-        equal size - the launch also copies src to dst (hual_assemble_batch_carry: the previous step's spans into the epoch's bank)."""
+        equal size - the launch also copies src to dst (hual_assemble_batch_carry: the previous step's spans into the epoch's bank).
+        shape: (T, L, C) to pad to instead of the batch's own maxima - a data-parallel shard is padded to the maxima of the GLOBAL
+        batch (hual_amd/dist.py shard_plan)."""
         sel = np.ascontiguousarray(sel, dtype=np.int32)
         B = len(sel)
         T, L, C = self.batch_shape(sel)
         if min_chars:
             C = max(C, min_chars)
+        if shape is not None:
+            if shape[0] < T or shape[1] < L or shape[2] < C:
+                raise ValueError('padded shape %s is smaller than the batch needs (%d, %d, %d)' % (tuple(shape), T, L, C))
+            T, L, C = (int(x) for x in shape)
         labels = labels and self.s_ind is not None
         if buffers is not None:
             Bm, Tm, Lm, Cm = buffers['shape']

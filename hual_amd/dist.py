@@ -126,3 +126,87 @@ def allgather_rows_(out, local):
 def local_rows(t, batch):
     r = rank()
     return t[r * batch:(r + 1) * batch]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the epoch loop, data parallel (runner_utils.py:139-159 + data_loader.py:23-28 over `world` ranks)
+def shard_plan(order, batch_size, world, vlen, nwords, maxchars, min_chars=None):
+    """Host-side plan of ONE data-parallel epoch; pure numpy, the same on every rank (every rank holds the set's length arrays).
+
+    order: the epoch's shuffled sample ids; batch_size: clips per RANK (a global batch is batch_size * world consecutive ids of
+    `order`, rank r takes the r-th slice of batch_size).  Returns a list of steps, each a dict
+        ids     int32 [world * B]   the global batch, rank r's shard = ids[r * B : (r + 1) * B]
+        B       clips per rank (batch_size; the epoch's last global batch: what is left // world - shards must be equal for the
+                all-gather of the alignment features and for `mean over clips` to decompose; the < world clips that do
+                not fill a round are dropped from this epoch and reported in `dropped`)
+        shape   (T, L, C) of the GLOBAL batch: every shard is padded to it, NOT to its own maxima - model.py:31 pads to the batch
+                maximum and the reference's conv_block does not mask (modules.py:59-70), so a shard padded to its own longest clip /
+                query / word would not reproduce the single-process numbers
+        frames  valid frames of the global batch: the matching loss divides by it (layers.py:172-173), each rank by frames / world
+    With world = 1 this is exactly the reference's batching (ragged last batch kept)."""
+    import numpy as np
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    world, bs = int(world), int(batch_size)
+    steps, dropped = [], 0
+    for lo in range(0, len(order), bs * world):
+        ids = order[lo:lo + bs * world]
+        B = bs if len(ids) == bs * world else len(ids) // world
+        if B == 0:
+            dropped += len(ids)
+            break
+        dropped += len(ids) - B * world
+        ids = ids[:B * world]
+        C = int(maxchars[ids].max())
+        steps.append(dict(ids=ids, B=B, shape=(int(vlen[ids].max()), int(nwords[ids].max()), max(C, min_chars) if min_chars else C),
+                          frames=int(vlen[ids].sum())))
+    return steps, dropped
+
+
+def check_same(value, what='value'):
+    """every rank must hold the same integer (e.g. a checksum of the epoch's permutation): MIN == MAX over ranks, and the ranks
+    raise TOGETHER if not"""
+    t = torch.tensor([int(value), -int(value)], dtype=torch.int64)
+    if world_size() > 1:
+        if dist.get_backend() == 'nccl':
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    hi, lo = int(t[0]), -int(t[1])
+    if hi != lo:
+        raise ValueError('data parallel: the ranks disagree on %s (%d .. %d)' % (what, lo, hi))
+
+
+def allgather_cat(t):
+    """[world, *t.shape] of every rank's `t` (equal shapes), on t's device"""
+    w = world_size()
+    if w == 1:
+        return t.unsqueeze(0)
+    if _host_staged(t) or not t.is_cuda:
+        h = t.cpu().contiguous()
+        parts = [torch.empty_like(h) for _ in range(w)]
+        dist.all_gather(parts, h)
+        return torch.stack(parts, dim=0).to(t.device)
+    out = torch.empty((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
+def gather_objects(obj, dst=0):
+    """python objects of every rank as a list on rank `dst` (None elsewhere); world 1: [obj]"""
+    if world_size() == 1:
+        return [obj]
+    out = [None] * world_size() if rank() == dst else None
+    dist.gather_object(obj, out, dst=dst)
+    return out
+
+
+def broadcast_object(obj, src=0):
+    if world_size() == 1:
+        return obj
+    box = [obj if rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()

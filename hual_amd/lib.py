@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HUAL_LIB_PATH: an experiment build of the library (scripts/exp/tl_variant.sh) - the in-tree file is never overwritten
 LIB_PATH = os.environ.get('HUAL_LIB_PATH') or os.path.join(_HERE, 'libhual_seqpan.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -48,7 +48,8 @@ class hual_run_opts(ctypes.Structure):
     _fields_ = [('drop_rate', ctypes.c_float), ('rng_state', ctypes.c_void_p), ('match_denom_override', ctypes.c_float),
                 ('align_external', ctypes.c_int32), ('static_tables', ctypes.c_int32),
                 ('match_denom_dev', ctypes.c_void_p), ('debug_taps', ctypes.c_int32), ('grads_prezero', ctypes.c_void_p),
-                ('prezero_token', ctypes.c_void_p), ('deferred_loss_terms', ctypes.c_void_p)]
+                ('prezero_token', ctypes.c_void_p), ('deferred_loss_terms', ctypes.c_void_p),
+                ('dw_table', ctypes.c_void_p), ('dw_table_bytes', ctypes.c_uint64)]
 
 
 class hual_al_set(ctypes.Structure):
@@ -84,6 +85,7 @@ def load():
     v = lib.hual_abi_version()
     if v != ABI_VERSION:
         raise HualError('libhual_seqpan.so ABI %d != python binding %d: rebuild' % (v, ABI_VERSION))
+    lib.hual_seqpan_dw_table_bytes.restype = ctypes.c_uint64
     vp, i32, u64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_float
     P = ctypes.POINTER
     lib.hual_seqpan_validate.argtypes = [P(hual_cfg)]

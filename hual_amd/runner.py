@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import al, data, lib
+from . import dist as hdist
 from .dataset import DeviceDataset
 from .model import SeqPAN
 from .train import Trainer
@@ -42,7 +43,10 @@ class Runner:
         self.ckpt_dir = ckpt_dir or os.path.join('ckpt', '%s_' % configs.get('task', 'task'))      # main.py:42 (sic)
         self.log = logger or logging.getLogger('hual_amd')
         self.rand = random.Random(seed)
-        self.trainer = Trainer(self.model, world=1, use_graph=True)     # per-shape step graphs (Trainer.set_batch_device)
+        # data parallel when torch.distributed is initialised (one process per GPU, every rank constructs the same Runner with the
+        # same seed): configs.train.batch_size is then the batch PER RANK, the global batch is world times that
+        self.world, self.rank = hdist.world_size(), hdist.rank()
+        self.trainer = Trainer(self.model, world=self.world, use_graph=True)     # per-shape step graphs (Trainer.set_batch_device)
         self.clips_per_s = 0.0
 
     # ------------------------------------------------------------------ runner_utils.train_epoch (:139-159)
@@ -63,18 +67,23 @@ class Runner:
         # the whole epoch is enqueued without a host wait; the spans come back in one transfer (Trainer.run_epoch)
         st, en = self.trainer.run_epoch(ds, order, self.batch_size, lr=cur_lr, drop_rate=self.droprate, min_chars=4)
         self.clips_per_s = N / max(time.perf_counter() - t0, 1e-9)
-        ious = self._ious([ds.records[i] for i in order], st, en)
+        ious = self._ious([ds.records[i] for i in self.trainer.last_epoch_ids], st, en)       # (= order unless world > 1 dropped a tail)
         return al.iou_metrics(ious)
 
     # ------------------------------------------------------------------ runner_utils.test_epoch (:161-176)
     def test_epoch(self, dataset=None):
         ds = dataset or self.test_set
         ious = []
-        for lo in range(0, len(ds), self.batch_size):
+        for k, lo in enumerate(range(0, len(ds), self.batch_size)):
+            if k % self.world != self.rank:                        # batches dealt round-robin to the ranks, IoUs gathered below
+                continue
             sel = np.arange(lo, min(len(ds), lo + self.batch_size))
             f = ds.assemble(sel, labels=False, min_chars=4)
             o = self.model.forward(f['video'], f['video_seq_len'], f['word_ids'], f['char_ids'], drop_rate=0.0)
             ious += self._ious([ds.records[i] for i in sel], o['start_index'].cpu().numpy(), o['end_index'].cpu().numpy())
+        if self.world > 1:
+            parts = hdist.gather_objects(ious)
+            ious = hdist.broadcast_object([x for p in parts for x in p] if self.rank == 0 else None)
         return al.iou_metrics(ious)
 
     # ------------------------------------------------------------------ main.py --mode train (:50-78)
@@ -96,13 +105,15 @@ class Runner:
                 r1i7 = t[2]
             if r1i7 > best:                                       # main.py:71-75
                 best = r1i7
-                self.save(os.path.join(self.ckpt_dir, 'best_SeqPAN.npz'))
+                if self.rank == 0:
+                    self.save(os.path.join(self.ckpt_dir, 'best_SeqPAN.npz'))
                 best_lines = '\n' + train_line + '\n' + test_line
         self.log.info('\n\nHighest R1i7 epoch\n')
         self.log.info(best_lines)
         return best
 
     def test(self):
+        hdist.barrier()                                            # rank 0 wrote the checkpoint
         self.load(os.path.join(self.ckpt_dir, 'best_SeqPAN.npz'))
         t = self.test_epoch()
         self.log.info('TEST:\t{:.2f}\t{:.2f}\t{:.2f}\t{:.2f}\t'.format(*t))
@@ -112,20 +123,16 @@ class Runner:
     def infer_trainset(self, path=None, mc_dropout=None, load_best=True):
         """results/<task>/<suffix>.pkl of runner_utils.py:103-104.  mc_dropout=None: as the reference runs."""
         if load_best:
+            hdist.barrier()
             self.load(os.path.join(self.ckpt_dir, 'best_SeqPAN.npz'))
-        ds = self.train_set
-
-        def batches():                                            # TrainNoSuffleLoader.test_iter (data_loader.py:167-206)
-            for lo in range(0, len(ds), self.batch_size):
-                sel = np.arange(lo, min(len(ds), lo + self.batch_size))
-                f = ds.assemble(sel, labels=False, min_chars=4)
-                yield [ds.records[i] for i in sel], f['video'], f['video_seq_len'], f['word_ids'], f['char_ids']
-        records, ious = al.infer_trainset(self.model, batches(), mc_dropout=mc_dropout)
+        records, ious = al.infer_trainset_sharded(self.model, self.train_set, self.batch_size, mc_dropout=mc_dropout, min_chars=4)
+        if self.rank != 0:
+            return None, hdist.broadcast_object(None)
         if path:
             os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
             with open(path, 'wb') as f:
                 pickle.dump(records, f)
-        m = al.iou_metrics(ious)
+        m = hdist.broadcast_object(al.iou_metrics(ious))
         self.log.info('predict train set:\t{:.2f}\t{:.2f}\t{:.2f}\t{:.2f}\t'.format(*m))
         return records, m
 

@@ -6,6 +6,7 @@ Equivalent of the loop body of /root/reference/utils/runner_utils.py:144-147 (fe
 import ctypes
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -31,13 +32,20 @@ class Trainer:
         # device-fed mode (set_batch_device): per-shape cache of ABI structs and step graphs, outputs at the largest shape seen
         self.dynamic = False
         self.graph_shapes = use_graph and not self.dp
-        self.cache_limit = 64
+        # per-shape cache of the device-fed mode.  The reference's own annotations give ~340 distinct (L, C) padded shapes per
+        # ActivityNet epoch at batch 16 and more with varying T (tests/golden/lengths_anet.npz): the bound is far above that (an entry
+        # is a few ctypes structs, a 60 KB job table and - once captured - a hipGraphExec of ~55 kernel nodes), evictions are counted
+        self.cache_limit = 8192
+        self.capture_after = 1       # sightings of a shape that are launched eagerly before its step graph is captured
         self._cache = {}
         self._entry = None
         self._out_cap = None
         self._dp_B = None
         self._cap_stream = None
-        self.stats = dict(eager=0, captured=0, replayed=0)
+        self._host_denom = None      # data-parallel epoch loop: the matching-loss denominator computed on the host (shard_plan)
+        self._table_bytes = int(self._lib.hual_seqpan_dw_table_bytes())
+        self._dw_table = None        # static mode: this trainer's own job table (hual_run_opts.dw_table), never in the shared workspace
+        self.stats = dict(eager=0, captured=0, replayed=0, evicted=0, capture_failed=0)
 
     # ------------------------------------------------------------------ static batch buffers
     def set_batch(self, video, lens, word_ids, char_ids, y1, y2, match_labels, inner_labels, video_dtype=torch.float32):
@@ -75,6 +83,11 @@ class Trainer:
             self.end_index = torch.empty(B, device=dev, dtype=torch.int64)
             self.loss_terms = torch.zeros(4, device=dev)
             self.ws = m._workspace(B, T, L, C)
+            # the job table of the weight-gradient launch is this trainer's own: the workspace is shared with every other user of the
+            # model (model.forward at another shape, a second Trainer), static_tables must not depend on what they leave there
+            self._dw_table = torch.empty(self._table_bytes, dtype=torch.uint8, device=dev)
+            self._cache.clear()       # (entries of an earlier device-fed phase hold the addresses of the old fetch tensors)
+            self._out_cap = None
             p = lib.ptr
             self.bt = lib.hual_batch(p(self.video).value, p(self.lens).value, p(self.word_ids).value,
                                      p(self.char_ids).value, B, T, L, C, 1 if video_dtype == torch.bfloat16 else 0)
@@ -114,6 +127,9 @@ class Trainer:
         self.match_denom = 0.0
         if not self.dp:
             return
+        if self._host_denom is not None:      # the epoch loop knows the global batch's lengths on the host: no device work, no collective
+            self.match_denom = float(self._host_denom)
+            return
         torch.sum(self.lens.to(torch.float32), dim=0, keepdim=True, out=self.denom_dev)
         hdist.allreduce_sum_(self.denom_dev)
         self.denom_dev.add_(1e-12).div_(float(self.world))
@@ -137,13 +153,17 @@ class Trainer:
         self._ensure_outputs(B, T)
         self.ws = m._workspace(B, T, L, C)
         p = lib.ptr
-        key = (B, T, L, C, vdt, self.ws.data_ptr(), self._out_flat.data_ptr()) + tuple(
+        key = (B, T, L, C, vdt, self.ws.data_ptr(), self._out_flat.data_ptr(), self.loss_terms.data_ptr(), self.spans.data_ptr()) + tuple(
             t.data_ptr() for t in (self.video, self.lens, self.word_ids, self.char_ids, self.y1, self.y2, self.match, self.inner))
         e = self._cache.get(key)
         if e is None:
             if len(self._cache) >= self.cache_limit:            # bounded: drop the least recently used shape
                 self._cache.pop(next(iter(self._cache)))
-            e = dict(seen=0, graph=None, drop=None,
+                self.stats['evicted'] += 1
+            # table: the shape's OWN job table of the weight-gradient launch - the workspace is shared between shapes, the table is
+            # not, so from the shape's second step on nothing rewrites it (five launches fewer per step, eager or replayed)
+            e = dict(seen=0, graph=None, drop=None, nograph=False, tables_ready=False,
+                     table=torch.empty(self._table_bytes, dtype=torch.uint8, device=dev),
                      bt=lib.hual_batch(p(self.video).value, p(self.lens).value, p(self.word_ids).value, p(self.char_ids).value,
                                        B, T, L, C, 1 if vdt == torch.bfloat16 else 0),
                      lab=lib.hual_labels(p(self.y1).value, p(self.y2).value, p(self.match).value, p(self.inner).value))
@@ -158,15 +178,17 @@ class Trainer:
         self.start_index, self.end_index = self.spans[0, :B], self.spans[1, :B]
         self.out = lib.hual_outputs(p(self.start_logits).value, p(self.end_logits).value, p(self.match_scores).value,
                                     p(self.start_index).value, p(self.end_index).value, p(self.loss_terms).value)
-        self._tables_ready = False                               # the workspace is shared between shapes: job tables are rewritten
+        self._dw_table = e['table']
+        self._tables_ready = e['tables_ready']
         if self.dp and (self._dp_B != B):
             self._alloc_dp(B)
             self._dp_B = B
         self._update_match_denominator()
 
     def _ensure_outputs(self, B, T):
-        """fetch tensors of the device-fed mode: one allocation for the largest (B, T) seen (grown geometrically, which drops
-        the cached graphs - they hold the old addresses); spans as ONE [2, B] tensor so a loop can bank both with one copy"""
+        """fetch tensors of the device-fed mode: one allocation for the largest (B, T) seen (growing it drops the cached graphs -
+        they hold the old addresses; run_epoch reserves the set's maximum up front, so a loop never grows it); spans as ONE [2, B]
+        tensor so a loop can bank both with one copy"""
         cap = self._out_cap
         if cap is not None and B <= cap[0] and T <= cap[1]:
             return
@@ -192,11 +214,13 @@ class Trainer:
         return lib.hual_run_opts(float(drop_rate), lib.ptr(self.m.rng_state).value, float(self.match_denom),
                                  int(align_external),
                                  1 if (self._tables_ready and not os.environ.get('HUAL_NO_STATIC_TABLES')) else 0,
-                                 lib.ptr(self.denom_dev).value if self.dp else None, 0,
+                                 lib.ptr(self.denom_dev).value if (self.dp and self._host_denom is None) else None, 0,
                                  # the forward's first launch zeroes the gradient bucket (one launch fewer in backward); the
                                  # host word is the receipt the backward call checks and clears (hual_run_opts.prezero_token)
                                  lib.ptr(self.m.grads).value, ctypes.addressof(self._prezero_token),
-                                 lib.ptr(self.loss_terms).value if defer_loss else None)
+                                 lib.ptr(self.loss_terms).value if defer_loss else None,
+                                 lib.ptr(self._dw_table).value if self._dw_table is not None else None,
+                                 self._table_bytes if self._dw_table is not None else 0)
 
     def _forward(self, opts):
         m = self.m
@@ -207,6 +231,8 @@ class Trainer:
     def _backward(self, opts):
         m = self.m
         self._tables_ready = True
+        if self.dynamic and self._entry is not None:
+            self._entry['tables_ready'] = True
         lib.check(self._lib.hual_seqpan_backward(
             ctypes.byref(m.cfg), lib.ptr(m.params), lib.ptr(m.word_table), ctypes.byref(self.bt), ctypes.byref(self.lab),
             ctypes.byref(opts), lib.ptr(m.grads), lib.ptr(self.ws), self.ws.numel(), lib.stream_ptr()))
@@ -271,36 +297,56 @@ class Trainer:
         m.global_step += 1
 
     def _step_dynamic(self, drop_rate):
-        """device-fed mode: eager on the first sighting of a (shape, addresses) key, captured on the second, replayed after"""
+        """device-fed mode: eager on the first `capture_after` sightings of a (shape, addresses) key, then captured, replayed after.
+        Data parallel: eager launches (the collectives inside a step graph are opt-in, _step_dp)."""
         e = self._entry
         if self.dp:
             self._enqueue_dp(drop_rate)
+            e['seen'] += 1
             self.stats['eager'] += 1
             return
         if e['graph'] is not None and e['drop'] == drop_rate:
             e['graph'].replay()
             self.stats['replayed'] += 1
             return
-        if not self.graph_shapes or e['seen'] == 0:
+        if not self.graph_shapes or e['nograph'] or e['seen'] < self.capture_after:
             self._enqueue_single(drop_rate)
             e['seen'] += 1
             self.stats['eager'] += 1
             return
         # capture on a side stream by hand (records, executes nothing: the replay below IS the step).  Not `with torch.cuda.graph(g)`:
-        # that context synchronises the device and runs the garbage collector on entry - tens of milliseconds per shape, which is
-        # what the first epoch of a training set with a handful of padded shapes then spends most of its time on
+        # that context synchronises the device and runs the garbage collector on entry - tens of milliseconds per shape.  A capture
+        # costs ~1 ms of host time (measured over 250 shapes of the ActivityNet length distribution, scripts/exp/epoch_real.py).
         g = torch.cuda.CUDAGraph()
         if self._cap_stream is None:
             self._cap_stream = torch.cuda.Stream(device=self.m.device)
         cs, cur = self._cap_stream, torch.cuda.current_stream()
         cs.wait_stream(cur)
+        err = None
         with torch.cuda.stream(cs):
             g.capture_begin()
             try:
                 self._enqueue_single(drop_rate)
-            finally:
+            except BaseException as ex:          # our own launch failed under capture: end the capture, keep THIS error
+                err = ex
+            try:
                 g.capture_end()
+            except RuntimeError as ex:           # the runtime refused the capture
+                err = err or ex
         cur.wait_stream(cs)
+        if err is not None:
+            # nothing was executed.  A refused capture leaves the shape on eager launches for good; an error of one of our own
+            # launches (lib.HualError: bad arguments) would fail eagerly too and is raised
+            self.stats['capture_failed'] += 1
+            e['nograph'] = True
+            if isinstance(err, lib.HualError) or not isinstance(err, RuntimeError):
+                raise err
+            print('[hual] step graph capture refused for shape %s (%s): eager launches' % (self.shape[:4], str(err).splitlines()[0]),
+                  file=sys.stderr)
+            self._enqueue_single(drop_rate)
+            e['seen'] += 1
+            self.stats['eager'] += 1
+            return
         e['graph'], e['drop'] = g, drop_rate
         g.replay()
         self.stats['captured'] += 1
@@ -365,35 +411,64 @@ class Trainer:
         Nothing in the loop waits for the device and nothing is uploaded per step: the permutation goes up ONCE, a batch's ids
         are a slice of it; the feeds are views of one set of max-shape buffers; the workspace and the fetch tensors are sized
         once; a step is one hipGraph launch for every padded shape seen before (set_batch_device); the spans of each step are
-        copied (device to device, by the NEXT step's assembly launch) into an epoch-long bank that is fetched with ONE transfer after the last step - the
-        reference's IoU bookkeeping (runner_utils.py:150-156) only needs them at the end of the epoch.
-        Returns (start, end) int64 numpy arrays in the order of `order` (None, None with want_spans False)."""
+        copied (device to device, by the NEXT step's assembly launch) into an epoch-long bank that is fetched with ONE transfer after
+        the last step - the reference's IoU bookkeeping (runner_utils.py:150-156) only needs them at the end of the epoch.
+
+        Data parallel (world > 1; `batch_size` = clips per rank): every rank calls this with the SAME dataset and order.  A global
+        batch is batch_size * world consecutive ids, rank r trains on its r-th slice, padded to the GLOBAL batch's (T, L, C); the
+        matching-loss denominator comes from the global batch's lengths on the host; plan: hual_amd/dist.py shard_plan (the < world
+        clips that do not fill the last round are dropped from the epoch).  The spans of all ranks are gathered once, after the
+        last step.
+
+        Returns (start, end) int64 numpy arrays for the ids of `self.last_epoch_ids` (= `order` unless clips were dropped), in that
+        order - (None, None) with want_spans False."""
         m = self.m
         order = np.ascontiguousarray(order, dtype=np.int32)
-        N, bs = len(order), int(batch_size)
-        nsteps = (N + bs - 1) // bs
-        if getattr(self, '_feed_owner', None) is not dataset or self._feeds['shape'][0] < min(bs, N):
-            self._feeds = dataset.feed_buffers(min(bs, N), min_chars=min_chars)
+        world, rank = (self.world, hdist.rank()) if self.world > 1 else (1, 0)
+        if world > 1:
+            hdist.check_same(int(np.dot(order.astype(np.int64) % 1000003, np.arange(1, len(order) + 1) % 1009) % (1 << 40)) + len(order),
+                             "the epoch's sample order")
+        steps, dropped = hdist.shard_plan(order, batch_size, world, dataset.vlen_h, dataset.nwords_h, dataset.maxchars_h, min_chars)
+        nsteps, bs = len(steps), int(batch_size)
+        self.last_epoch_ids = np.concatenate([st['ids'] for st in steps]) if steps else order[:0]
+        self.stats['dropped'] = self.stats.get('dropped', 0) + dropped
+        if nsteps == 0:
+            return (order[:0].astype(np.int64),) * 2 if want_spans else (None, None)
+        Bmax = max(st['B'] for st in steps)
+        if getattr(self, '_feed_owner', None) is not dataset or self._feeds['shape'][0] < Bmax:
+            self._feeds = dataset.feed_buffers(Bmax, min_chars=min_chars)
             self._feed_owner = dataset
         Bm, Tm, Lm, Cm = self._feeds['shape']
         self.reserve(Bm, Tm, Lm, Cm)
-        order_dev = torch.from_numpy(order).to(m.device)
+        # the ids this rank trains on, step after step, uploaded once
+        mine = np.concatenate([st['ids'][rank * st['B']:(rank + 1) * st['B']] for st in steps])
+        mine_dev = torch.from_numpy(np.ascontiguousarray(mine)).to(m.device)
         bank = torch.empty(nsteps, 2, self.spans.shape[1], dtype=torch.int64, device=m.device) if want_spans else None
-        for i in range(nsteps):
-            lo = i * bs
-            sel = order[lo:lo + bs]
+        t_host = time.perf_counter()
+        lo = 0
+        for i, st in enumerate(steps):
+            B = st['B']
+            sel = mine[lo:lo + B]
             # (the spans of step i - 1 ride into the bank inside step i's assembly launch: one eager operation between two step graphs)
-            feeds = dataset.assemble(sel, min_chars=min_chars, buffers=self._feeds, sel_dev=order_dev[lo:lo + len(sel)],
+            feeds = dataset.assemble(sel, min_chars=min_chars, buffers=self._feeds, sel_dev=mine_dev[lo:lo + B],
+                                     shape=st['shape'] if world > 1 else None,
                                      carry=(self.spans, bank[i - 1]) if want_spans and i > 0 else None)
+            lo += B
+            self._host_denom = (st['frames'] + 1e-12) / world if self.dp else None
             self.set_batch_device(feeds)
             self.step(lr=lr, drop_rate=drop_rate)
+        self._host_denom = None
+        self.stats['host_enqueue_s'] = self.stats.get('host_enqueue_s', 0.0) + (time.perf_counter() - t_host)
         if not want_spans:
             return None, None
         bank[nsteps - 1].copy_(self.spans)
-        host = bank.cpu().numpy()                                # the epoch's only device -> host transfer (and only sync)
-        st = np.concatenate([host[i, 0, :len(order[i * bs:(i + 1) * bs])] for i in range(nsteps)])
-        en = np.concatenate([host[i, 1, :len(order[i * bs:(i + 1) * bs])] for i in range(nsteps)])
-        return st, en
+        host = hdist.allgather_cat(bank).cpu().numpy() if world > 1 else bank.cpu().numpy()[None]      # the epoch's only device -> host transfer
+        st_, en_ = [], []
+        for i, stp in enumerate(steps):
+            for r in range(world):
+                st_.append(host[r, i, 0, :stp['B']])
+                en_.append(host[r, i, 1, :stp['B']])
+        return np.concatenate(st_), np.concatenate(en_)
 
     def last_loss(self):
         """total loss of the last step (device sync).  DP: local loc/match terms + the global alignment loss."""

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HUAL_ABI_VERSION 7
+#define HUAL_ABI_VERSION 8
 
 #define HUAL_OK 0
 #define HUAL_ERR_INVALID (-1)
@@ -151,7 +151,17 @@ typedef struct hual_run_opts {
                                         which writes float[4] = {total, loc, match, align} HERE from inside its matching-head launch -
                                         one launch fewer per step.  hual_outputs.loss_terms is then not written by the forward.
                                         Pass the same options to both calls.  NULL: the forward closes the loss itself (a launch). */
+  void* dw_table;                 /* non-NULL (ABI 8): caller-owned DEVICE storage of >= hual_seqpan_dw_table_bytes() bytes, 16-byte aligned,
+                                        for the job table of the backward's weight-gradient launch INSTEAD of the copy inside the
+                                        workspace.  A caller that runs several padded shapes in ONE workspace (the epoch loop of
+                                        runner_utils.py:139-159) keeps one such table per shape: `static_tables` then holds per
+                                        TABLE - whatever other shapes did to the workspace in between - and every replayed step graph
+                                        drops the table-writing launches.  NULL: the table lives in the workspace. */
+  uint64_t dw_table_bytes;        /* size of dw_table (checked) */
 } hual_run_opts;
+
+/* bytes a hual_run_opts.dw_table must hold (any cfg, any shape) */
+uint64_t hual_seqpan_dw_table_bytes(void);
 
 /* bytes of workspace needed for one forward(+backward) of this shape */
 int hual_seqpan_query_workspace(const hual_cfg* cfg, int B, int T, int L, int C, uint64_t* bytes);

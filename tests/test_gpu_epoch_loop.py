@@ -102,7 +102,7 @@ def test_first_step_of_a_shape_is_bit_identical_whatever_ran_before():
     for sel in (sel_a, sel_b, sel_a, sel_b):                      # eager a, eager b, capture a, capture b
         t1.set_batch_device(ds.assemble(sel, min_chars=4, buffers=bufs))
         t1.step(lr=0.0, drop_rate=0.2)
-    assert t1.stats == dict(eager=2, captured=2, replayed=0)
+    assert (t1.stats['eager'], t1.stats['captured'], t1.stats['replayed']) == (2, 2, 0)
     m1.set_rng(12345, 0)
     t1.set_batch_device(ds.assemble(sel_a, min_chars=4, buffers=bufs))
     t1.step(lr=0.0, drop_rate=0.2)                                # replay of a's graph
@@ -110,3 +110,50 @@ def test_first_step_of_a_shape_is_bit_identical_whatever_ran_before():
     assert t1.stats['replayed'] == 1
     np.testing.assert_array_equal(t1.loss_terms.cpu().numpy(), want[0])
     np.testing.assert_array_equal(t1.start_logits.cpu().numpy(), want[1])
+
+
+def test_an_epoch_of_more_than_64_padded_shapes_replays_bit_identical_to_eager():
+    """The reference's own ActivityNet annotations (tests/golden/lengths_anet.npz) give several hundred distinct (L, C) padded shapes
+    per epoch (data_loader.py:23-28 + pad_seq / pad_char_seq): far more than the 64-entry cache of round 5.  Every shape keeps its
+    own step graph and its own job table; a replayed step gives bit for bit the loss terms, logits and spans of the eager launch."""
+    import al_synth
+    from hual_amd import al, lib
+    from hual_amd.dataset import DeviceDataset
+    from hual_amd.model import SeqPAN
+    from hual_amd.train import Trainer
+    recs, vis, data_gt, _ = al_synth.make_trainset_from_lengths('anet', 480, 64, 24, seed=4, num_words=200, num_chars=30)
+    Lm = max(len(r['w_ids']) for r in recs)
+    cfg = lib.make_cfg(vdim=64, max_vlen=max(24, Lm), num_words=200, num_chars=30)
+    wv = np.random.default_rng(1).normal(0, 0.4, size=(198, 300)).astype(np.float32)
+    ds = DeviceDataset(recs, vis)
+    s0, e0 = al.labels_from_times(data_gt, ds.vlen_h)
+    ds.set_labels(s0, e0)
+    bs, N = 4, len(ds)
+    batches = [np.arange(lo, min(N, lo + bs), dtype=np.int32) for lo in range(0, N, bs)]
+    shapes = {(len(s),) + ds.batch_shape(s) for s in batches}
+    assert len(shapes) > 64, len(shapes)
+    m = SeqPAN(cfg, wv)
+    m.ws_poison = 0xFF
+    tr = Trainer(m, world=1, use_graph=True)
+    bufs = ds.feed_buffers(bs, min_chars=4)
+    tr.reserve(*bufs['shape'])
+    p0 = m.params.clone()
+    runs = []
+    for pas in range(3):                                          # eager / captured / replayed (repeated shapes are ahead by one)
+        before = dict(tr.stats)
+        out = []
+        for k, sel in enumerate(batches):
+            m.set_rng(777, k)                                     # the same dropout stream for batch k in every pass
+            tr.set_batch_device(ds.assemble(sel, min_chars=4, buffers=bufs))
+            tr.step(lr=0.0, drop_rate=0.2)                        # lr 0: AdamWD leaves the parameters where they are
+            B, T = tr.shape[0], tr.shape[1]
+            out.append((tr.loss_terms.clone(), tr.start_logits.clone(), tr.end_logits.clone(), tr.spans[:, :B].clone()))
+        runs.append((out, {k: tr.stats[k] - before[k] for k in before}))
+    torch.cuda.synchronize()
+    assert runs[0][1]['eager'] == len(shapes) and runs[2][1]['replayed'] == len(batches), [r[1] for r in runs]
+    assert tr.stats['evicted'] == 0 and tr.stats['capture_failed'] == 0 and len(tr._cache) == len(shapes)
+    assert torch.equal(m.params, p0)
+    for a, b in zip(runs[0][0], runs[2][0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert all(torch.isfinite(o[0]).all() for o in runs[2][0])

@@ -208,3 +208,41 @@ def test_backward_zeroes_the_bucket_unless_the_forward_left_a_receipt():
     assert torch.isfinite(g1).all() and float(g1.abs().max()) < 1e3
     scale = float(g1.abs().max())
     assert float((g1 - g2).abs().max()) <= 1e-5 * scale      # (atomics: the summation order differs between the two launches)
+
+
+def test_static_step_graph_survives_other_users_of_the_workspace():
+    """A Trainer fed by set_batch replays ONE graph with static job tables (hual_run_opts.static_tables).  The model's workspace is
+    shared: an evaluation forward at another shape (or a second Trainer) runs in the same allocation in between.  The table of the
+    weight-gradient launch is the trainer's own (hual_run_opts.dw_table), so the replay still computes the same gradients."""
+    from hual_amd.train import Trainer
+    cfg, p, wv, b, labels = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
+    feeds = (b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(), *[x.numpy() for x in labels])
+    # undisturbed run: two steps at lr 0 (parameters stay), the gradient of the second replay
+    m0 = pu.hip_model(cfg, p, wv)
+    t0 = Trainer(m0, world=1, use_graph=True)
+    t0.set_batch(*feeds)
+    for _ in range(3):
+        t0.step(lr=0.0, drop_rate=0.0)
+    torch.cuda.synchronize()
+    want = m0.grads.clone()
+    # disturbed run: a forward of a SMALLER batch (its buffers lie over the table's old place in the workspace) and a second
+    # trainer at yet another shape between the replays
+    m1 = pu.hip_model(cfg, p, wv)
+    m1.ws_poison = None
+    t1 = Trainer(m1, world=1, use_graph=True)
+    t1.set_batch(*feeds)
+    t1.step(lr=0.0, drop_rate=0.0)
+    t1.step(lr=0.0, drop_rate=0.0)
+    cfg2, _, _, b2, labels2 = pu.make_case(B=2, T=12, L=4, C=4, seed=5)
+    m1.forward(b2['video'].numpy(), b2['lens'].numpy(), b2['word_ids'].numpy(), b2['char_ids'].numpy())
+    t2 = Trainer(m1, world=1, use_graph=False)
+    t2.set_batch(b2['video'].numpy(), b2['lens'].numpy(), b2['word_ids'].numpy(), b2['char_ids'].numpy(), *[x.numpy() for x in labels2])
+    t2.step(lr=0.0, drop_rate=0.0)
+    torch.cuda.synchronize()
+    m1._ws.fill_(0xFF)                                            # and whatever else was left there
+    m1._workspace(4, 24, 7, 5)
+    t1.step(lr=0.0, drop_rate=0.0)                                # replay of the graph captured before
+    torch.cuda.synchronize()
+    assert torch.isfinite(m1.grads).all()
+    scale = max(1.0, float(want.abs().max()))
+    assert float((m1.grads - want).abs().max()) <= 1e-5 * scale   # (float atomics: not bit-reproducible)
