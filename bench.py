@@ -259,53 +259,109 @@ def gpu_at_cpu_shape(dev, drop, steps=400):
                 shape='B16 T64 vdim1024 L20 C8 (the cpu_baseline shape)')
 
 
-def epoch_loop_leg(dev, args, resident_ms):
-    """The reference's ACTUAL loop (runner_utils.py:139-159, data_loader.py:23-28): a shuffled epoch over a training set, every batch
-    padded to its own longest clip / query / word, on the device-fed path (DeviceDataset + Trainer.run_epoch).  Untimed first epoch
-    (every padded shape is seen, launched eagerly once and captured once), then timed epochs - assembly launches, shape changes and
-    the span fetch included.  Synthetic set at the headline's dims: clips of T/2..T frames, queries of 3..L words."""
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    import al_synth
-    from hual_amd import al, lib
-    from hual_amd.dataset import DeviceDataset
+def _resident_ms(dev, cfg, wv, B, T, L, C, vdim, drop, steps=300):
+    """ms/step of ONE resident batch of this padded shape replayed as a graph (the headline's kind of number) - the yardstick of an epoch loop"""
     from hual_amd.model import SeqPAN
     from hual_amd.train import Trainer
-    N, nvid, bs = args.epoch_samples, 512, args.batch
-    recs, vis, data_gt, _ = al_synth.make_trainset(N, nvid, args.vdim, args.T, seed=11, num_words=1000, num_chars=40, max_words=args.L)
-    cfg = lib.make_cfg(vdim=args.vdim, max_vlen=max(args.T, args.L), num_words=1000, num_chars=40)
-    wv = np.random.default_rng(777).normal(0, 0.4, size=(998, 300)).astype(np.float32)
     model = SeqPAN(cfg, wv, device=dev, seed=12345, rng_seed=12345)
-    ds = DeviceDataset(recs, vis, device=dev)
+    b = synth_batch(B, T, L, C, vdim, 1000, 40, 12345)
+    tr = Trainer(model, world=1, use_graph=True)
+    tr.set_batch(b['video'], b['lens'], b['word_ids'], b['char_ids'], b['y1'], b['y2'], b['match'], b['inner'])
+    for _ in range(60):
+        tr.step(lr=1e-4, drop_rate=drop)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(lr=1e-4, drop_rate=drop)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def _epoch_set(dev, kind, N, vdim, max_vlen, L):
+    """device-resident training set for an epoch-loop leg.  kind 'synthetic': clips of T/2..T frames, queries of 3..L words
+    (tests/al_synth.py make_trainset); 'anet' / 'charades': (v_len, words, longest word) drawn from the reference's OWN training
+    annotations (tests/golden/lengths_<task>.npz <- /root/reference/data/<task>/train.json, scripts/gen_lengths.py), features random"""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import al_synth
+    from hual_amd import al
+    from hual_amd.dataset import DeviceDataset
+    if kind == 'synthetic':
+        recs, vis, data_gt, _ = al_synth.make_trainset(N, 512, vdim, max_vlen, seed=11, num_words=1000, num_chars=40, max_words=L)
+        ds = DeviceDataset(recs, vis, device=dev)
+    else:
+        recs, vlens, data_gt, _ = al_synth.make_trainset_from_lengths(kind, N, vdim, max_vlen, 11, feats=False)
+        total = sum(vlens[v] for v in vlens)
+        bank = torch.randn(total, vdim, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
+        ds = DeviceDataset(recs, vlens, device=dev, feat_bank=bank)
     s0, e0 = al.labels_from_times(data_gt, ds.vlen_h)
     ds.set_labels(s0, e0)
-    tr = Trainer(model, world=1, use_graph=not args.no_graph)
+    return ds
+
+
+def epoch_loop_leg(dev, args, resident_ms, kind='synthetic', bs=None, max_vlen=None, N=None, world=1, epochs=3):
+    """The reference's ACTUAL loop (runner_utils.py:139-159, data_loader.py:23-28): a shuffled epoch over a training set, every batch
+    padded to its own longest clip / query / word, on the device-fed path (DeviceDataset + Trainer.run_epoch).  The FIRST epoch is
+    timed on its own (every padded shape is seen for the first time: launched eagerly, then captured), a second untimed epoch
+    follows, then `epochs` timed epochs - assembly launches, shape changes and the span fetch included.  world > 1: the same loop data
+    parallel (every rank holds the set, trains on its shard of each global batch of bs x world clips; Trainer.run_epoch).
+    resident_ms None: a resident batch of the loop's MEAN padded shape is timed as the yardstick."""
+    from hual_amd import lib
+    from hual_amd.model import SeqPAN
+    from hual_amd.train import Trainer
+    from hual_amd import dist as hdist
+    bs = bs or args.batch
+    max_vlen = max_vlen or args.T
+    N = N or args.epoch_samples
+    ds = _epoch_set(dev, kind, N, args.vdim, max_vlen, args.L)
+    N = len(ds)
+    Tm, Lm, Cm = ds.max_shape(4)
+    cfg = lib.make_cfg(vdim=args.vdim, max_vlen=max(Tm, Lm, max_vlen), num_words=1000, num_chars=40)
+    wv = np.random.default_rng(777).normal(0, 0.4, size=(998, 300)).astype(np.float32)
+    model = SeqPAN(cfg, wv, device=dev, seed=12345, rng_seed=12345 + hdist.rank())
+    tr = Trainer(model, world=world, use_graph=not args.no_graph, force_dp=(world == 1 and os.environ.get('HUAL_DP_FORCE_COLLECTIVES') == '1'))
     g = np.random.default_rng(0)
-    order = g.permutation(N)
-    tr.run_epoch(ds, order, bs, lr=1e-4, drop_rate=args.drop, min_chars=4)           # untimed: shapes seen + captured
-    tr.run_epoch(ds, g.permutation(N), bs, lr=1e-4, drop_rate=args.drop, min_chars=4)
-    torch.cuda.synchronize()
-    warm = dict(tr.stats)
-    epochs, Ts, shapes = 3, [], set()
-    t0 = time.perf_counter()
-    for _ in range(epochs):
+
+    def epoch():
         order = g.permutation(N)
-        st, en = tr.run_epoch(ds, order, bs, lr=1e-4, drop_rate=args.drop, min_chars=4)
-        for lo in range(0, N, bs):
-            shp = ds.batch_shape(order[lo:lo + bs])
-            Ts.append(shp[0])
-            shapes.add((len(order[lo:lo + bs]),) + shp)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    nsteps = epochs * ((N + bs - 1) // bs)
-    timed = {k: tr.stats[k] - warm[k] for k in warm}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.run_epoch(ds, order, bs, lr=1e-4, drop_rate=args.drop, min_chars=4)
+        torch.cuda.synchronize()
+        return order, time.perf_counter() - t0
+    gb = bs * world
+    nsteps_ep = (N + gb - 1) // gb
+    _, first_s = epoch()                                                             # every shape new: eager launches + captures
+    first_modes = dict(tr.stats)
+    epoch()
+    warm = dict(tr.stats)
+    shapes, Ts, Ls, Cs, dt = set(), [], [], [], 0.0
+    for _ in range(epochs):
+        order, d = epoch()
+        dt += d
+        for lo in range(0, N, gb):
+            ids = order[lo:lo + gb]
+            shp = ds.batch_shape(ids)
+            shapes.add((min(bs, len(ids) // world if world > 1 else len(ids)),) + (shp[0], shp[1], max(4, shp[2])))
+            Ts.append(shp[0]); Ls.append(shp[1]); Cs.append(max(4, shp[2]))
+    nsteps = epochs * nsteps_ep
+    timed = {k: (round(tr.stats[k] - warm[k], 4) if isinstance(tr.stats[k], float) else tr.stats[k] - warm[k]) for k in warm}
     ms = dt / nsteps * 1e3
+    mT, mL, mC = int(round(np.mean(Ts))), int(round(np.mean(Ls))), int(round(np.mean(Cs)))
+    yard = 'the headline batch'
+    if resident_ms is None:
+        resident_ms = _resident_ms(dev, cfg, wv, bs, mT, mL, mC, args.vdim, args.drop)
+        yard = 'ONE resident batch of the mean padded shape B%d T%d L%d C%d, graph replay' % (bs, mT, mL, mC)
     return dict(value=round(N * epochs / dt, 1), unit='clips/s', ms_per_step=round(ms, 4), steps=nsteps, epochs=epochs,
-                samples=N, batch=bs, mean_T=round(float(np.mean(Ts)), 1), max_T=int(max(Ts)), distinct_padded_shapes=len(shapes),
-                step_launch_modes=timed, resident_batch_ms_per_step=round(resident_ms, 4),
+                samples=N, batch_per_gpu=bs, n_gpus=world, lengths_from=kind, mean_T=round(float(np.mean(Ts)), 1), max_T=int(max(Ts)),
+                mean_L=round(float(np.mean(Ls)), 1), max_L=int(max(Ls)), mean_C=round(float(np.mean(Cs)), 1),
+                distinct_padded_shapes=len(shapes), graph_cache_entries=len(tr._cache),
+                step_launch_modes=timed, first_epoch=dict(ms_per_step=round(first_s / nsteps_ep * 1e3, 4), steps=nsteps_ep,
+                                                          step_launch_modes={k: first_modes[k] for k in ('eager', 'captured', 'replayed')}),
+                resident_batch_ms_per_step=round(resident_ms, 4), resident_batch=yard,
                 frac_of_resident_batch_rate=round(resident_ms / ms, 3),
-                workload='shuffled epochs over an HBM-resident synthetic training set (%d samples, %d videos of %d..%d frames, vdim %d, '
-                         'queries of 3..%d words): hual_assemble_batch + train step per batch, every batch padded to its own longest '
-                         'clip / query / word, spans fetched once per epoch' % (N, nvid, max(4, args.T // 2), args.T, args.vdim, args.L))
+                workload='shuffled epochs over an HBM-resident training set (%d samples, max_vlen %d, vdim %d): hual_assemble_batch + train '
+                         'step per batch, every batch padded to its own longest clip / query / word (data parallel: to the global '
+                         "batch's), spans fetched once per epoch" % (N, max_vlen, args.vdim))
 
 
 def main():
@@ -324,6 +380,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-epoch-loop', action='store_true', help='skip the epoch-loop leg (varying padded shapes, after the timed region)')
     ap.add_argument('--epoch-samples', type=int, default=4096)
+    ap.add_argument('--anet-samples', type=int, default=8192, help='queries drawn from the ActivityNet length fixture for the epoch_loop_anet legs')
     ap.add_argument('--prewarm', type=int, default=200, help='untimed steps before the warm-up steps (clock ramp)')
     ap.add_argument('--video-dtype', choices=['f32', 'bf16'], default='f32',
                     help='element type of the clip features in HBM (hual_batch.video_dtype); arithmetic is the same')
@@ -564,13 +621,22 @@ def main():
         except Exception as e:      # never cost the bench line
             other_feed = dict(error=str(e)[:200])
 
-    epoch_loop = None
-    if rank == 0 and world == 1 and not args.no_epoch_loop:
-        try:
-            epoch_loop = epoch_loop_leg(dev, args, dt / args.steps * 1e3)
-            print('[bench] epoch-loop leg done: %.3f ms/step' % epoch_loop['ms_per_step'], file=sys.stderr, flush=True)
-        except Exception as e:      # never cost the bench line
-            epoch_loop = dict(error=str(e)[:300])
+    epoch_loop, epoch_anet = None, None
+    if not args.no_epoch_loop and (world == 1 or dp):
+        # every rank runs these legs when the job is data parallel (collectives inside); rank 0 reports
+        def leg(name, **kw):
+            try:
+                r = epoch_loop_leg(dev, args, world=world, **kw)
+                if rank == 0:
+                    print('[bench] %s leg done: %.3f ms/step' % (name, r['ms_per_step']), file=sys.stderr, flush=True)
+                return r
+            except Exception as e:      # never cost the bench line (every rank fails or passes together: the legs are collective)
+                return dict(error=str(e)[:300])
+        epoch_loop = leg('epoch-loop', resident_ms=dt / args.steps * 1e3)
+        # the reference's own shape distributions (BASELINE configs[3], [4]: ActivityNet annotations): the YAML's batch 16 at
+        # max_vlen 100, and configs[3]'s 32 clips per GPU at T <= 256
+        epoch_anet = [leg('epoch-loop anet b16', resident_ms=None, kind='anet', bs=16, max_vlen=100, N=args.anet_samples, epochs=3),
+                      leg('epoch-loop anet b32 T256', resident_ms=None, kind='anet', bs=32, max_vlen=256, N=args.anet_samples // 2, epochs=3)]
 
     if rank == 0:
         out = dict(metric='train clips/sec', value=round(clips / dt, 2), unit='clips/s', n_gpus=world, steps=args.steps,
@@ -589,6 +655,8 @@ def main():
             out['other_feature_dtype'] = other_feed
         if epoch_loop is not None:
             out['epoch_loop'] = epoch_loop
+        if epoch_anet is not None:
+            out['epoch_loop_anet'] = epoch_anet
         if rccl is not None:
             out['rccl'] = rccl
         print(json.dumps(out))

@@ -18,11 +18,12 @@ using namespace hual;
 __device__ __forceinline__ void assemble_video_body(const AssembleArgs& a, int blk, int nblk) {
   const int v4 = a.vdim >> 2;
   const size_t total = (size_t)a.B * a.T * v4;
+  const int32_t* sel = a.cursor ? a.sel + a.cursor[0] : a.sel;
   for (size_t i = blk * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)nblk * blockDim.x) {
     const int c = (int)(i % v4);
     const size_t r = i / v4;
     const int t = (int)(r % a.T), b = (int)(r / a.T);
-    const int vid = a.sample_vid[a.sel[b]];
+    const int vid = a.sample_vid[sel[b]];
     const int64_t r0 = a.feat_off[vid];
     const int n = (int)(a.feat_off[vid + 1] - r0);
     float4 v = f4zero();
@@ -32,7 +33,7 @@ __device__ __forceinline__ void assemble_video_body(const AssembleArgs& a, int b
 }
 
 __device__ __forceinline__ void assemble_side_body(const AssembleArgs& a, int b) {
-  const int s = a.sel[b];
+  const int s = (a.cursor ? a.sel + a.cursor[0] : a.sel)[b];
   const int vid = a.sample_vid[s];
   const int n = (int)(a.feat_off[vid + 1] - a.feat_off[vid]);
   if (threadIdx.x == 0) a.lens[b] = n;
@@ -139,6 +140,20 @@ int hual_assemble_batch_carry(const hual_dataset* ds, const int32_t* sel, int B,
   a.video = video; a.lens = video_seq_len; a.word_ids = word_ids; a.char_ids = char_ids;
   a.y1 = y1; a.y2 = y2; a.match = match_labels; a.inner = inner_labels;
   a.carry_src = carry_src; a.carry_dst = carry_dst; a.carry_n = carry_n;
+  return launch_assemble(a, (hipStream_t)stream);
+}
+
+int hual_assemble_batch_cursor(const hual_dataset* ds, const int32_t* ids, const int64_t* cursor, int B, int T, int L, int C, float* video,
+                               int32_t* video_seq_len, int32_t* word_ids, int32_t* char_ids, float* y1, float* y2,
+                               int32_t* match_labels, float* inner_labels, void* stream) {
+  HUAL_REQUIRE(ds && cursor, "hual_assemble_batch_cursor: null dataset / cursor");
+  AssembleArgs a{};
+  a.feat_bank = ds->feat_bank; a.feat_off = ds->feat_off; a.vdim = ds->vdim; a.sample_vid = ds->sample_vid;
+  a.word_off = ds->word_off; a.word_bank = ds->word_bank; a.char_off = ds->char_off; a.char_bank = ds->char_bank;
+  a.s_ind = ds->s_ind; a.e_ind = ds->e_ind;
+  a.sel = ids; a.cursor = cursor; a.B = B; a.T = T; a.L = L; a.C = C;
+  a.video = video; a.lens = video_seq_len; a.word_ids = word_ids; a.char_ids = char_ids;
+  a.y1 = y1; a.y2 = y2; a.match = match_labels; a.inner = inner_labels;
   return launch_assemble(a, (hipStream_t)stream);
 }
 

@@ -15,6 +15,9 @@ struct AdamArgs {
   float prescale;         // multiplies the gradient first (1/world after a sum all-reduce)
   float* sqnorm;          // device scratch, HUAL_SQNORM_SLOTS floats: per-block partial sums of |prescale*g|^2
   uint32_t* rng_state;    // optional: Philox state {k0, k1, offset}; offset += 1 after the update (next step's dropout)
+  // optional: the epoch loop's device-side position (hual_loop_step): block 0 copies span_words 8-byte words (the step's predicted
+  // spans) to bank + cursor[1], then cursor[0] += sel_inc (ids consumed), cursor[1] += bank_inc
+  int64_t* cursor; const int64_t* spans; int64_t* bank; int span_words, sel_inc, bank_inc;
 };
 int launch_adamw(const AdamArgs& a, hipStream_t s);
 // p[0..n) = 0 with a kernel (no memset node inside captured graphs)

@@ -30,9 +30,17 @@ __global__ __launch_bounds__(256) void zero_kernel(float* p, size_t n) {
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, const float* decay,
                                                     size_t n, const float* lr_dev, float clip_norm, float prescale,
-                                                    const float* sqnorm, float b1, float b2, float eps, uint32_t* rng_state) {
+                                                    const float* sqnorm, float b1, float b2, float eps, uint32_t* rng_state,
+                                                    int64_t* cursor, const int64_t* spans, int64_t* bank, int span_words, int sel_inc,
+                                                    int bank_inc) {
   const float lr = lr_dev[0];
   if (rng_state && blockIdx.x == 0 && threadIdx.x == 0) rng_state[2] += 1u;     // nothing in this launch reads it
+  if (cursor && blockIdx.x == gridDim.x - 1) {      // the epoch loop's position: bank this step's spans, move on (one block: ordered by its barrier)
+    const int64_t bp = cursor[1];
+    for (int i = threadIdx.x; i < span_words; i += blockDim.x) bank[bp + i] = spans[i];
+    __syncthreads();
+    if (threadIdx.x == 0) { cursor[0] += sel_inc; cursor[1] = bp + bank_inc; }
+  }
   float part = 0.f;
   for (int i = threadIdx.x & 63; i < HUAL_SQNORM_SLOTS; i += 64) part += sqnorm[i];     // same order in every wave
   const float gn = sqrtf(wave_sum64(part));
@@ -63,9 +71,11 @@ namespace hual {
 int launch_adamw(const AdamArgs& a, hipStream_t s) {
   HUAL_REQUIRE(a.p && a.g && a.m && a.v && a.decay && a.lr_dev && a.sqnorm, "adamw: null pointer");
   HUAL_REQUIRE((a.n % 4) == 0, "adamw: flat size must be a multiple of 4");
+  HUAL_REQUIRE(!a.cursor || (a.span_words == 0 || (a.spans && a.bank)), "adamw: loop cursor needs the span source and the bank");
   HUAL_LAUNCH(0.0, 4.0 * a.n, sqnorm_kernel, dim3(HUAL_SQNORM_SLOTS), dim3(256), 0, s, (const float*)a.g, a.n, a.prescale, a.sqnorm);
   HUAL_LAUNCH(0.0, 32.0 * a.n, adamw_kernel, dim3(512), dim3(256), 0, s, a.p, (const float*)a.g, a.m, a.v, a.decay, a.n, a.lr_dev,
-                     a.clip_norm, a.prescale, (const float*)a.sqnorm, 0.9f, 0.999f, 1e-6f, a.rng_state);
+                     a.clip_norm, a.prescale, (const float*)a.sqnorm, 0.9f, 0.999f, 1e-6f, a.rng_state,
+                     a.cursor, a.spans, a.bank, a.span_words, a.sel_inc, a.bank_inc);
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }

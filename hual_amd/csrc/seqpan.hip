@@ -1376,7 +1376,7 @@ int hual_adamw_clip_step(float* params, const float* grads, float* adam_m, float
                          uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
                          void* stream) {
   AdamArgs a{params, const_cast<float*>(grads), adam_m, adam_v, decay, (size_t)n_padded, lr, clip_norm, grad_prescale, sqnorm,
-             nullptr};
+             nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
   return launch_adamw(a, (hipStream_t)stream);
 }
 
@@ -1384,7 +1384,17 @@ int hual_adamw_clip_step_rng(float* params, const float* grads, float* adam_m, f
                              uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
                              uint32_t* rng_state, void* stream) {
   AdamArgs a{params, const_cast<float*>(grads), adam_m, adam_v, decay, (size_t)n_padded, lr, clip_norm, grad_prescale, sqnorm,
-             rng_state};
+             rng_state, nullptr, nullptr, nullptr, 0, 0, 0};
+  return launch_adamw(a, (hipStream_t)stream);
+}
+
+int hual_adamw_clip_step_loop(float* params, const float* grads, float* adam_m, float* adam_v, const float* decay,
+                              uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
+                              uint32_t* rng_state, int64_t* cursor, const int64_t* spans, int64_t* bank, int span_words, int sel_inc,
+                              int bank_inc, void* stream) {
+  HUAL_REQUIRE(cursor != nullptr && span_words >= 0 && sel_inc >= 0 && bank_inc >= 0, "hual_adamw_clip_step_loop: cursor / increments");
+  AdamArgs a{params, const_cast<float*>(grads), adam_m, adam_v, decay, (size_t)n_padded, lr, clip_norm, grad_prescale, sqnorm,
+             rng_state, cursor, spans, bank, span_words, sel_inc, bank_inc};
   return launch_adamw(a, (hipStream_t)stream);
 }
 

@@ -102,6 +102,31 @@ class DeviceDataset:
                        match_labels=torch.empty(B * T, dtype=i32, device=d), inner_labels=torch.empty(B * T, dtype=f32, device=d))
         return buf
 
+    def feed_views(self, B, T, L, C, buffers, labels=True):
+        """views of feed_buffers() in the padded shape (B, T, L, C): the tensors assemble(..., buffers=) fills, without the launch"""
+        Bm, Tm, Lm, Cm = buffers['shape']
+        if B > Bm or T > Tm or L > Lm or C > Cm:
+            raise ValueError('batch (%d,%d,%d,%d) exceeds the feed buffers %s' % (B, T, L, C, (buffers['shape'],)))
+        out = dict(video=buffers['video'][:B * T * self.vdim].view(B, T, self.vdim), video_seq_len=buffers['video_seq_len'][:B],
+                   word_ids=buffers['word_ids'][:B * L].view(B, L), char_ids=buffers['char_ids'][:B * L * C].view(B, L, C))
+        if labels and 'y1' in buffers:
+            out.update(y1=buffers['y1'][:B * T].view(B, T), y2=buffers['y2'][:B * T].view(B, T),
+                       match_labels=buffers['match_labels'][:B * T].view(B, T), inner_labels=buffers['inner_labels'][:B * T].view(B, T))
+        return out
+
+    def enqueue_assemble_cursor(self, views, ids_dev, cursor):
+        """the assembly launch of an epoch loop whose position lives on the device (hual_assemble_batch_cursor): fills `views`
+        (feed_views) with the batch ids_dev[cursor[0] .. + B).  The same arguments every step of a padded shape: it is captured
+        into the shape's step graph (Trainer.run_epoch)."""
+        B, T, _ = views['video'].shape
+        L, C = views['word_ids'].shape[1], views['char_ids'].shape[2]
+        labels = 'y1' in views
+        p = lib.ptr
+        lib.check(self._lib.hual_assemble_batch_cursor(
+            ctypes.byref(self.ds), p(ids_dev), p(cursor), B, T, L, C, p(views['video']), p(views['video_seq_len']), p(views['word_ids']),
+            p(views['char_ids']), p(views['y1']) if labels else None, p(views['y2']) if labels else None,
+            p(views['match_labels']) if labels else None, p(views['inner_labels']) if labels else None, lib.stream_ptr()))
+
     def assemble(self, sel, out=None, labels=True, min_chars=None, buffers=None, sel_dev=None, carry=None, shape=None):
         """Gather the batch `sel` (sample ids) on the device.  Returns a dict of device tensors named like the feeds of
         model.py:16-27.  out: a dict from a previous call with the same shape to write into (static buffers).

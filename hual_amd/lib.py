@@ -99,6 +99,8 @@ def load():
                                          u64, vp]
     lib.hual_adamw_clip_step.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp]
     lib.hual_adamw_clip_step_rng.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp, vp]
+    lib.hual_adamw_clip_step_loop.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.hual_assemble_batch_cursor.argtypes = [P(hual_dataset), vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.hual_align_loss.argtypes = [vp, vp, i32, vp, vp, vp, vp, f32, vp]
     lib.hual_align_loss_rows.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp]
     blk = [P(hual_cfg), vp, P(hual_batch), P(hual_run_opts)]

@@ -43,6 +43,7 @@ class Trainer:
         self._dp_B = None
         self._cap_stream = None
         self._host_denom = None      # data-parallel epoch loop: the matching-loss denominator computed on the host (shard_plan)
+        self._loop = None            # run_epoch: ids / cursor / span bank of the device-side epoch position, the dataset, the current views
         self._table_bytes = int(self._lib.hual_seqpan_dw_table_bytes())
         self._dw_table = None        # static mode: this trainer's own job table (hual_run_opts.dw_table), never in the shared workspace
         self.stats = dict(eager=0, captured=0, replayed=0, evicted=0, capture_failed=0)
@@ -153,7 +154,9 @@ class Trainer:
         self._ensure_outputs(B, T)
         self.ws = m._workspace(B, T, L, C)
         p = lib.ptr
-        key = (B, T, L, C, vdt, self.ws.data_ptr(), self._out_flat.data_ptr(), self.loss_terms.data_ptr(), self.spans.data_ptr()) + tuple(
+        lp = self._loop
+        key = (B, T, L, C, vdt, self.ws.data_ptr(), self._out_flat.data_ptr(), self.loss_terms.data_ptr(), self.spans.data_ptr(),
+               0 if lp is None else (lp['ids'].data_ptr(), lp['cursor'].data_ptr(), lp['bank'].data_ptr())) + tuple(
             t.data_ptr() for t in (self.video, self.lens, self.word_ids, self.char_ids, self.y1, self.y2, self.match, self.inner))
         e = self._cache.get(key)
         if e is None:
@@ -240,12 +243,29 @@ class Trainer:
     def _adam(self, prescale):
         m = self.m
         # the Philox offset of the dropout stream advances in the same launch (rng_state[2] += 1)
+        lp = self._loop
+        if lp is not None:
+            # ... and so does the epoch loop's device-side position: the step's spans go to their place in the bank, the cursor moves on
+            nsp = self.spans.numel()
+            lib.check(self._lib.hual_adamw_clip_step_loop(
+                lib.ptr(m.params), lib.ptr(m.grads), lib.ptr(m.adam_m), lib.ptr(m.adam_v), lib.ptr(m.decay),
+                m.params.numel(), lib.ptr(m.lr), float(m.cfg.clip_norm), float(prescale), lib.ptr(m.sqnorm),
+                lib.ptr(m.rng_state), lib.ptr(lp['cursor']), lib.ptr(self.spans), lib.ptr(lp['bank']), nsp, int(self.shape[0]), nsp,
+                lib.stream_ptr()))
+            return
         lib.check(self._lib.hual_adamw_clip_step_rng(
             lib.ptr(m.params), lib.ptr(m.grads), lib.ptr(m.adam_m), lib.ptr(m.adam_v), lib.ptr(m.decay),
             m.params.numel(), lib.ptr(m.lr), float(m.cfg.clip_norm), float(prescale), lib.ptr(m.sqnorm),
             lib.ptr(m.rng_state), lib.stream_ptr()))
 
+    def _enqueue_assembly(self):
+        """epoch loop: the batch-assembly launch is the first launch of the step (and of the step's graph)"""
+        lp = self._loop
+        if lp is not None:
+            lp['ds'].enqueue_assemble_cursor(lp['views'], lp['ids'], lp['cursor'])
+
     def _enqueue_single(self, drop_rate):
+        self._enqueue_assembly()
         opts = self._opts(drop_rate, 0)
         self._forward(opts)
         self._backward(opts)
@@ -256,6 +276,7 @@ class Trainer:
         features -> global [Bg,Bg] alignment loss, gradient rows of the own samples written straight into the backward's
         workspace buffers -> backward -> ONE all-reduce of the flat gradient bucket -> clip + AdamWD on the averaged gradient"""
         m, B = self.m, self.shape[0]
+        self._enqueue_assembly()
         opts = self._opts(drop_rate, 1)
         self._forward(opts)
         hdist.allgather_rows_(self.feat_all, m.tap('align.tv'))      # [that | vhat] rows as the forward left them: no copy
@@ -440,28 +461,31 @@ class Trainer:
             self._feed_owner = dataset
         Bm, Tm, Lm, Cm = self._feeds['shape']
         self.reserve(Bm, Tm, Lm, Cm)
-        # the ids this rank trains on, step after step, uploaded once
+        # the ids this rank trains on, step after step, uploaded ONCE; the epoch's position is a device cursor that the step's own
+        # last launch advances (hual_adamw_clip_step_loop), and the step's first launch is its batch assembly at that position
+        # (hual_assemble_batch_cursor): a step of a known padded shape is ONE graph launch and nothing else - no eager launch between
+        # two step graphs (each cost ~10 us of idle device on either side), nothing uploaded, nothing fetched
         mine = np.concatenate([st['ids'][rank * st['B']:(rank + 1) * st['B']] for st in steps])
-        mine_dev = torch.from_numpy(np.ascontiguousarray(mine)).to(m.device)
-        bank = torch.empty(nsteps, 2, self.spans.shape[1], dtype=torch.int64, device=m.device) if want_spans else None
+        lp = self._ensure_loop(dataset, len(mine), nsteps)
+        lp['ids'][:len(mine)].copy_(torch.from_numpy(np.ascontiguousarray(mine)))
+        lp['cursor'].zero_()
+        self._loop = lp
         t_host = time.perf_counter()
-        lo = 0
-        for i, st in enumerate(steps):
-            B = st['B']
-            sel = mine[lo:lo + B]
-            # (the spans of step i - 1 ride into the bank inside step i's assembly launch: one eager operation between two step graphs)
-            feeds = dataset.assemble(sel, min_chars=min_chars, buffers=self._feeds, sel_dev=mine_dev[lo:lo + B],
-                                     shape=st['shape'] if world > 1 else None,
-                                     carry=(self.spans, bank[i - 1]) if want_spans and i > 0 else None)
-            lo += B
-            self._host_denom = (st['frames'] + 1e-12) / world if self.dp else None
-            self.set_batch_device(feeds)
-            self.step(lr=lr, drop_rate=drop_rate)
-        self._host_denom = None
+        try:
+            for st in steps:
+                T, L, C = st['shape']
+                lp['views'] = dataset.feed_views(st['B'], T, L, C, self._feeds)
+                self._host_denom = (st['frames'] + 1e-12) / world if self.dp else None
+                self.set_batch_device(lp['views'])
+                self.step(lr=lr, drop_rate=drop_rate)
+        finally:
+            self._host_denom = None
+            self._loop = None
         self.stats['host_enqueue_s'] = self.stats.get('host_enqueue_s', 0.0) + (time.perf_counter() - t_host)
         if not want_spans:
             return None, None
-        bank[nsteps - 1].copy_(self.spans)
+        Bcap = self.spans.shape[1]
+        bank = lp['bank'][:nsteps * 2 * Bcap].view(nsteps, 2, Bcap)
         host = hdist.allgather_cat(bank).cpu().numpy() if world > 1 else bank.cpu().numpy()[None]      # the epoch's only device -> host transfer
         st_, en_ = [], []
         for i, stp in enumerate(steps):
@@ -469,6 +493,22 @@ class Trainer:
                 st_.append(host[r, i, 0, :stp['B']])
                 en_.append(host[r, i, 1, :stp['B']])
         return np.concatenate(st_), np.concatenate(en_)
+
+    def _ensure_loop(self, dataset, n_ids, nsteps):
+        """device state of the epoch loop: the rank's id list, the cursor {ids consumed, bank words written} and the span bank
+        [steps, 2, B capacity].  Allocated once per (dataset size, fetch capacity) - the step graphs hold these addresses."""
+        lp = getattr(self, '_loop_state', None)
+        Bcap = self.spans.shape[1]
+        if lp is None or lp['ds'] is not dataset or lp['ids'].numel() < n_ids or lp['bank'].numel() < nsteps * 2 * Bcap or lp['Bcap'] != Bcap:
+            dev = self.m.device
+            # capacity for ANY epoch over this set (a batch size of one: as many steps as samples; 34 MB for ActivityNet at B 64), so
+            # that a later epoch with another batch size or order never moves the buffers
+            cap = max(n_ids, nsteps, len(dataset), 1)
+            lp = dict(ds=dataset, Bcap=Bcap, ids=torch.zeros(cap, dtype=torch.int32, device=dev),
+                      cursor=torch.zeros(2, dtype=torch.int64, device=dev),
+                      bank=torch.zeros(cap * 2 * Bcap, dtype=torch.int64, device=dev), views=None)
+            self._loop_state = lp
+        return lp
 
     def last_loss(self):
         """total loss of the last step (device sync).  DP: local loc/match terms + the global alignment loss."""

@@ -202,6 +202,17 @@ int hual_adamw_clip_step_rng(float* params, const float* grads, float* adam_m, f
                              uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
                              uint32_t* rng_state, void* stream);
 
+/* the same for an EPOCH LOOP whose position lives on the device (ABI 8; runner_utils.py:139-159): `cursor` = device i64[2] =
+ * {ids consumed so far, words written to the span bank so far}.  The launch also copies `span_words` 8-byte words from `spans` (the step's
+ * predicted start / end indices in the caller's fetch buffer) to bank + cursor[1], then cursor[0] += sel_inc, cursor[1] += bank_inc.
+ * Together with hual_assemble_batch_cursor (which reads its batch's ids at ids + cursor[0]) a whole step - batch assembly, forward,
+ * backward, optimizer, span banking - has the SAME arguments every time it runs with a given padded shape: one hipGraph per shape,
+ * nothing launched between two graphs, nothing uploaded or fetched until the epoch ends. */
+int hual_adamw_clip_step_loop(float* params, const float* grads, float* adam_m, float* adam_v, const float* decay,
+                              uint64_t n_padded, const float* lr, float clip_norm, float grad_prescale, float* sqnorm,
+                              uint32_t* rng_state, int64_t* cursor, const int64_t* spans, int64_t* bank, int span_words, int sel_inc,
+                              int bank_inc, void* stream);
+
 /* cross-sample part of lossfun_aligment (layers.py:232-247) on [Bg,128] l2-normalised features
  * (all-gathered over ranks in exact data-parallel mode).  scratch: 2*Bg*Bg + Bg floats.
  * Writes d_that / d_vhat [Bg,128] (scaled by grad_scale) and WRITES the loss to *loss (device scalar: the row terms are summed
@@ -346,6 +357,12 @@ int hual_assemble_batch_carry(const hual_dataset* ds, const int32_t* sel, int B,
                               int32_t* video_seq_len, int32_t* word_ids, int32_t* char_ids, float* y1, float* y2,
                               int32_t* match_labels, float* inner_labels, const int64_t* carry_src, int64_t* carry_dst, int carry_n,
                               void* stream);
+
+/* The same launch for an epoch loop with a device-side position: the batch's ids are ids[cursor[0] .. cursor[0] + B) (cursor: device
+ * i64[2], advanced by hual_adamw_clip_step_loop at the end of the step). */
+int hual_assemble_batch_cursor(const hual_dataset* ds, const int32_t* ids, const int64_t* cursor, int B, int T, int L, int C, float* video,
+                               int32_t* video_seq_len, int32_t* word_ids, int32_t* char_ids, float* y1, float* y2,
+                               int32_t* match_labels, float* inner_labels, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Active-learning label update (BASELINE.json configs[4]): what /root/reference/update_label.py does

@@ -119,7 +119,8 @@ def test_bench_multi_rank_path_on_one_rank(tmp_path):
     env = dict(os.environ, HUAL_DP_FORCE_COLLECTIVES='1', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
                MASTER_PORT=str(29900 + os.getpid() % 90))
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--batch', '8', '--T', '32', '--L', '8', '--C', '5',
-                        '--vdim', '256', '--steps', '4', '--warmup', '1', '--prewarm', '2', '--no-cpu-baseline', '--no-roofline'],
+                        '--vdim', '256', '--steps', '4', '--warmup', '1', '--prewarm', '2', '--no-cpu-baseline', '--no-roofline',
+                        '--epoch-samples', '256', '--anet-samples', '512'],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
@@ -130,3 +131,9 @@ def test_bench_multi_rank_path_on_one_rank(tmp_path):
     assert rc['rccl_ranks'] == 1 and rc['backend'] == 'nccl' and rc['allreduce_us'] > 0
     assert rc['step_launch'].startswith('hipGraph')          # the captured data-parallel step is the default with nccl
     assert np.isfinite(out['config']['final_loss'])
+    # the epoch-loop legs ran on the data-parallel code path too (Trainer.run_epoch: shard plan, host-side denominators, eager steps
+    # with the collectives on the stream), incl. the reference's ActivityNet length distribution
+    el = out['epoch_loop']
+    assert 'error' not in el and el['step_launch_modes']['eager'] == el['steps'] and el['value'] > 0
+    for leg in out['epoch_loop_anet']:
+        assert 'error' not in leg and leg['lengths_from'] == 'anet' and leg['step_launch_modes']['eager'] == leg['steps']
