@@ -453,6 +453,38 @@ def main():
         rccl = dict(rccl_ranks=world, allreduce_us=round(ev0.elapsed_time(ev1) * 1e3 / 50, 1),
                     allreduce_bytes=int(model.grads.numel() * 4), backend=torch.distributed.get_backend(),
                     step_launch='hipGraph with the collectives captured' if trainer.graph is not None else 'eager')
+        # the same sum through the one-shot peer-mapped all-reduce (hual_amd/xgmi.py; off by default in the step:
+        # HUAL_ALLREDUCE=custom): ONE guarded call first - compared with RCCL's result, status word checked - and only then the timing
+        if world > 1:
+            try:
+                from hual_amd.xgmi import OneShotAllReduce
+                buf = torch.randn(model.grads.numel(), device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank))
+                ref = buf.clone()
+                torch.distributed.all_reduce(ref)
+                ar = OneShotAllReduce(buf)
+                ar()
+                torch.cuda.synchronize()
+                ar.check()
+                err = float((buf - ref).abs().max() / ref.abs().max())
+                okf = torch.tensor([1.0 if err < 1e-5 else 0.0], device=dev)
+                torch.distributed.all_reduce(okf, op=torch.distributed.ReduceOp.MIN)
+                if float(okf.item()) < 1.0:
+                    raise RuntimeError('result differs from RCCL (max rel %.3g on this rank)' % err)
+                for _ in range(5):
+                    ar()
+                barrier()
+                ev0.record()
+                for _ in range(50):
+                    ar()
+                ev1.record()
+                torch.cuda.synchronize()
+                ar.check()
+                rccl['custom_allreduce'] = dict(us=round(ev0.elapsed_time(ev1) * 1e3 / 50, 1), max_rel_diff_vs_rccl=err,
+                                                kind='one-shot reduce-scatter + all-gather over hipIpc peer mappings, 2 flag barriers',
+                                                used_by_the_timed_steps=os.environ.get('HUAL_ALLREDUCE') == 'custom')
+                ar.close()
+            except Exception as e:      # never cost the bench line
+                rccl['custom_allreduce'] = dict(error=str(e)[:300])
         model.grads.zero_()
     roof = None
     print('[bench] timed region done: %.3f ms/step' % (dt / args.steps * 1e3), file=sys.stderr, flush=True)

@@ -37,10 +37,39 @@ def _host_staged(t):
     return t.is_cuda and dist.get_backend() == 'gloo'
 
 
+_custom = {}      # data_ptr of a bucket -> hual_amd.xgmi.OneShotAllReduce (HUAL_ALLREDUCE=custom)
+
+
+def custom_allreduce_wanted():
+    import os
+    return os.environ.get('HUAL_ALLREDUCE', 'rccl') == 'custom'
+
+
+def enable_custom_allreduce(flat):
+    """COLLECTIVE.  With HUAL_ALLREDUCE=custom the sum of this bucket runs as the one-shot peer-mapped all-reduce (SURVEY.md 8f #4,
+    hual_amd/xgmi.py) instead of RCCL's; default off.  Returns the OneShotAllReduce or None."""
+    if not custom_allreduce_wanted() or not flat.is_cuda or world_size() < 2:
+        return None
+    if flat.data_ptr() not in _custom:
+        from .xgmi import OneShotAllReduce
+        _custom[flat.data_ptr()] = OneShotAllReduce(flat)
+    return _custom[flat.data_ptr()]
+
+
+def disable_custom_allreduce():
+    """COLLECTIVE: unmap and free everything enable_custom_allreduce set up"""
+    for ar in list(_custom.values()):
+        ar.close()
+    _custom.clear()
+
+
 def allreduce_sum_(flat):
     """in-place sum of the flat gradient bucket over ranks"""
     if world_size() > 1 or _forced():
-        if _host_staged(flat):
+        ar = _custom.get(flat.data_ptr()) if flat.is_cuda else None
+        if ar is not None and ar.flat is flat:
+            ar()
+        elif _host_staged(flat):
             h = flat.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
             flat.copy_(h)

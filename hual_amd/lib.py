@@ -101,6 +101,13 @@ def load():
     lib.hual_adamw_clip_step_rng.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp, vp]
     lib.hual_adamw_clip_step_loop.argtypes = [vp, vp, vp, vp, vp, u64, vp, f32, f32, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.hual_assemble_batch_cursor.argtypes = [P(hual_dataset), vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.hual_xgmi_flags_bytes.restype = ctypes.c_uint64
+    lib.hual_xgmi_flags_alloc.argtypes = [P(vp)]
+    lib.hual_xgmi_flags_free.argtypes = [vp]
+    lib.hual_xgmi_ipc_export.argtypes = [vp, vp, P(u64)]
+    lib.hual_xgmi_ipc_open.argtypes = [vp, P(vp)]
+    lib.hual_xgmi_ipc_close.argtypes = [vp]
+    lib.hual_xgmi_allreduce.argtypes = [i32, i32, P(vp), P(vp), P(vp), vp, vp, u64, u64, vp]
     lib.hual_align_loss.argtypes = [vp, vp, i32, vp, vp, vp, vp, f32, vp]
     lib.hual_align_loss_rows.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp]
     blk = [P(hual_cfg), vp, P(hual_batch), P(hual_run_opts)]

@@ -46,6 +46,8 @@ class Trainer:
         self._loop = None            # run_epoch: ids / cursor / span bank of the device-side epoch position, the dataset, the current views
         self._table_bytes = int(self._lib.hual_seqpan_dw_table_bytes())
         self._dw_table = None        # static mode: this trainer's own job table (hual_run_opts.dw_table), never in the shared workspace
+        if self.dp and world > 1:
+            hdist.enable_custom_allreduce(model.grads)      # collective; a no-op unless HUAL_ALLREDUCE=custom (default: RCCL)
         self.stats = dict(eager=0, captured=0, replayed=0, evicted=0, capture_failed=0)
 
     # ------------------------------------------------------------------ static batch buffers

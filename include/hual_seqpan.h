@@ -213,6 +213,24 @@ int hual_adamw_clip_step_loop(float* params, const float* grads, float* adam_m, 
                               uint32_t* rng_state, int64_t* cursor, const int64_t* spans, int64_t* bank, int span_words, int sel_inc,
                               int bank_inc, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * One-shot all-reduce of the flat gradient bucket over peer mappings (csrc/xgmi.hip; absent in the reference, which
+ * pins one GPU: utils/runner_utils.py:11).  ONE launch per rank: flag barrier, reduce-scatter read straight from the peers' buckets
+ * (rank order: identical bits on every rank), flag barrier, all-gather.  flat / scratch / flags: `world` device pointers each - entry
+ * `rank` the rank's own memory, the others the peers' memory mapped into this process (hipIpcOpenMemHandle); scratch holds
+ * ceil(n / world) floats rounded up to 4; flags are hual_xgmi_flags_bytes() of UNCACHED device memory (the setup helpers below own that
+ * allocation - the one exception to "the library never allocates": the caller's allocator cannot provide it), zeroed once; seq: local
+ * device u32, zero at start, advanced by the call itself (graph replays included); status: local device u32, 0 = ok, 1 = a peer did not
+ * arrive within the spin limit (all waves left the kernel, the bucket is garbage).  Off by default (hual_amd/dist.py: HUAL_ALLREDUCE=custom). */
+uint64_t hual_xgmi_flags_bytes(void);
+int hual_xgmi_flags_alloc(void** p);
+int hual_xgmi_flags_free(void* p);
+int hual_xgmi_ipc_export(void* p, void* handle64, uint64_t* offset);      /* hipIpcGetMemHandle of p's allocation: 64 bytes + p's offset in it */
+int hual_xgmi_ipc_open(const void* handle64, void** p);      /* hipIpcOpenMemHandle in ANOTHER process than the exporter's: the allocation's base */
+int hual_xgmi_ipc_close(void* p);
+int hual_xgmi_allreduce(int rank, int world, void* const* flat, void* const* scratch, void* const* flags, uint32_t* seq, uint32_t* status,
+                        uint64_t n, uint64_t scratch_floats, void* stream);
+
 /* cross-sample part of lossfun_aligment (layers.py:232-247) on [Bg,128] l2-normalised features
  * (all-gathered over ranks in exact data-parallel mode).  scratch: 2*Bg*Bg + Bg floats.
  * Writes d_that / d_vhat [Bg,128] (scaled by grad_scale) and WRITES the loss to *loss (device scalar: the row terms are summed
