@@ -51,28 +51,50 @@ class OneShotAllReduce:
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         p = ctypes.c_void_p()
         with torch.cuda.device(dev):
-            lib.check(self._lib.hual_xgmi_flags_alloc(ctypes.byref(p)))
-            self._flags = p.value
-            torch.cuda.synchronize()
-            mine = (_export(flat.data_ptr()), _export(self.scratch.data_ptr()), _export(self._flags), flat.numel())
+            try:
+                lib.check(self._lib.hual_xgmi_flags_alloc(ctypes.byref(p)))
+                self._flags = p.value
+                torch.cuda.synchronize()
+                mine = (_export(flat.data_ptr()), _export(self.scratch.data_ptr()), _export(self._flags), flat.numel())
+            except Exception as e:                               # (e.g. HSA_ENABLE_IPC_MODE_LEGACY=0 missing) - raised on every rank below
+                mine = 'export failed: %s' % e
             everyone = [None] * self.world
             dist.all_gather_object(everyone, mine, group=group)
+            bad = [(r, v) for r, v in enumerate(everyone) if isinstance(v, str)]
+            if bad:
+                if p.value:
+                    self._lib.hual_xgmi_flags_free(p)
+                raise lib.HualError('one-shot all-reduce: rank %d: %s' % bad[0])
             self._opened = []
             bases = {}                                           # handle -> mapped base: two tensors of one segment are opened once
             ptrs = ([], [], [])
-            for r, (hf, hs, hg, nr) in enumerate(everyone):
-                if nr != n:
-                    raise lib.HualError('one-shot all-reduce: rank %d holds a bucket of %d floats, this rank %d' % (r, nr, n))
-                if r == self.rank:
-                    own = (flat.data_ptr(), self.scratch.data_ptr(), self._flags)
-                    for k in range(3):
-                        ptrs[k].append(own[k])
-                else:
-                    for k, (h, off) in enumerate((hf, hs, hg)):
-                        if h not in bases:
-                            bases[h] = _open(h)
-                            self._opened.append(bases[h])
-                        ptrs[k].append(bases[h] + off)
+            err = None
+            try:
+                for r, (hf, hs, hg, nr) in enumerate(everyone):
+                    if nr != n:
+                        raise lib.HualError('one-shot all-reduce: rank %d holds a bucket of %d floats, this rank %d' % (r, nr, n))
+                    if r == self.rank:
+                        own = (flat.data_ptr(), self.scratch.data_ptr(), self._flags)
+                        for k in range(3):
+                            ptrs[k].append(own[k])
+                    else:
+                        for k, (h, off) in enumerate((hf, hs, hg)):
+                            if h not in bases:
+                                bases[h] = _open(h)
+                                self._opened.append(bases[h])
+                            ptrs[k].append(bases[h] + off)
+            except Exception as e:                               # the verdict is collective: every rank raises or none does
+                err = e
+            verdicts = [None] * self.world
+            dist.all_gather_object(verdicts, None if err is None else str(err), group=group)
+            bad = [(r, v) for r, v in enumerate(verdicts) if v is not None]
+            if bad:
+                for q in self._opened:
+                    self._lib.hual_xgmi_ipc_close(ctypes.c_void_p(q))
+                self._opened = None
+                dist.barrier(group=group)
+                self._lib.hual_xgmi_flags_free(ctypes.c_void_p(self._flags))
+                raise lib.HualError('one-shot all-reduce: peer mapping failed on rank %d: %s' % bad[0])
         arr = ctypes.c_void_p * self.world
         self._flat_p, self._scratch_p, self._flags_p = (arr(*[ctypes.c_void_p(x) for x in ptrs[k]]) for k in range(3))
         dist.barrier(group=group)             # every rank has opened every handle before anybody may free or signal
