@@ -38,19 +38,26 @@ def _stamp(src):
     return h.hexdigest()
 
 
-def build(verbose=False, force=False):
+def build(verbose=False, force=False, out=None, defines=()):
+    """out / defines: a VARIANT of the current tree (scripts/exp A/B builds) - the same global and per-file flags plus -D switches,
+    objects in a directory of its own next to `out`, the in-tree library untouched"""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    os.makedirs(OBJ, exist_ok=True)
+    lib_path, obj_dir, extra = LIB, OBJ, []
+    if out is not None:
+        lib_path = os.path.abspath(out)
+        obj_dir = lib_path + '.obj'
+        extra = ['-D' + d for d in defines]
+    os.makedirs(obj_dir, exist_ok=True)
     objs, rebuilt, procs = [], False, []
     for src in _sources():
         base = os.path.basename(src)
-        obj = os.path.join(OBJ, base + '.o')
+        obj = os.path.join(obj_dir, base + '.o')
         stamp_file = obj + '.stamp'
-        stamp = _stamp(src)
+        stamp = _stamp(src) + ' '.join(extra)
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
             continue
-        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(base, []) + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', src, '-o', obj]
+        cmd = [hipcc] + FLAGS + extra + FILE_FLAGS.get(base, []) + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), stamp_file, stamp, base))
@@ -64,13 +71,17 @@ def build(verbose=False, force=False):
             print(out.decode())
         with open(stamp_file, 'w') as fh:
             fh.write(stamp)
-    if rebuilt or not os.path.exists(LIB):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if rebuilt or not os.path.exists(lib_path):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path] + objs
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib_path
 
 
 if __name__ == '__main__':
-    print(build(verbose=True, force='--force' in sys.argv))
+    # python -m hual_amd.build [--force] [--out build_exp/x.so --define A --define B=1 ...]
+    args = sys.argv[1:]
+    out = args[args.index('--out') + 1] if '--out' in args else None
+    defs = [args[i + 1] for i, a in enumerate(args) if a == '--define']
+    print(build(verbose=out is None, force='--force' in args, out=out, defines=defs))

@@ -11,6 +11,8 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -mllvm -a
 pids=()
 for f in $tmp/hual_amd/csrc/*.hip $tmp/hual_amd/csrc/*.cpp; do
   x=""; [[ $f == *.hip ]] && x="-x hip"
+  # per-file flags of hual_amd/build.py FILE_FLAGS (an A/B must not differ by them)
+  [[ $(basename $f) == convblock.hip ]] && x="$x -mllvm -amdgpu-sched-strategy=max-ilp"
   /opt/rocm/bin/hipcc $FLAGS $x -c $f -o $tmp/obj/$(basename $f).o 2>/dev/null &
   pids+=($!)
 done
