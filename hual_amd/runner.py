@@ -67,6 +67,14 @@ class Runner:
         # the whole epoch is enqueued without a host wait; the spans come back in one transfer (Trainer.run_epoch)
         st, en = self.trainer.run_epoch(ds, order, self.batch_size, lr=cur_lr, drop_rate=self.droprate, min_chars=4)
         self.clips_per_s = N / max(time.perf_counter() - t0, 1e-9)
+        # spans of -1 are the kernels' overflow marker (include/hual_seqpan.h: a weight beyond the scaled fp16 image's range, |w| >= 63, or
+        # an activation beyond the fp16 operand range, |x| >= 4094, turned a clip's logits into NaN): the float32 reference would still
+        # be finite there, so the run stops and says so instead of training on
+        if (np.asarray(st) < 0).any() or not np.isfinite(float(self.trainer.last_loss())):
+            bad = int((np.asarray(st) < 0).sum())
+            raise lib.HualError('training diverged out of the split-fp16 operand range: %d clip(s) of this epoch came back with span -1 '
+                                '(loss %s).  Lower the learning rate or clip_norm; the last good checkpoint is %s'
+                                % (bad, float(self.trainer.last_loss()), os.path.join(self.ckpt_dir, 'best_SeqPAN.npz')))
         ious = self._ious([ds.records[i] for i in self.trainer.last_epoch_ids], st, en)       # (= order unless world > 1 dropped a tail)
         return al.iou_metrics(ious)
 
