@@ -456,35 +456,51 @@ def main():
         # the same sum through the one-shot peer-mapped all-reduce (hual_amd/xgmi.py; off by default in the step:
         # HUAL_ALLREDUCE=custom): ONE guarded call first - compared with RCCL's result, status word checked - and only then the timing
         if world > 1:
+            # every decision below is COLLECTIVE (an all-reduced flag): a rank that raised alone would leave its peers in a collective
+            def agree(ok):
+                f = torch.tensor([1.0 if ok else 0.0], device=dev)
+                torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MIN)
+                return float(f.item()) >= 1.0
+            ar, msg, err = None, None, None
             try:
                 from hual_amd.xgmi import OneShotAllReduce
                 buf = torch.randn(model.grads.numel(), device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank))
                 ref = buf.clone()
                 torch.distributed.all_reduce(ref)
-                ar = OneShotAllReduce(buf)
-                ar()
-                torch.cuda.synchronize()
-                ar.check()
-                err = float((buf - ref).abs().max() / ref.abs().max())
-                okf = torch.tensor([1.0 if err < 1e-5 else 0.0], device=dev)
-                torch.distributed.all_reduce(okf, op=torch.distributed.ReduceOp.MIN)
-                if float(okf.item()) < 1.0:
-                    raise RuntimeError('result differs from RCCL (max rel %.3g on this rank)' % err)
-                for _ in range(5):
+                ar = OneShotAllReduce(buf)                     # (its own failures are collective: hual_amd/xgmi.py)
+            except Exception as e:
+                msg = 'setup: ' + str(e)[:250]
+            if agree(ar is not None):
+                try:
                     ar()
-                barrier()
-                ev0.record()
-                for _ in range(50):
-                    ar()
-                ev1.record()
-                torch.cuda.synchronize()
-                ar.check()
-                rccl['custom_allreduce'] = dict(us=round(ev0.elapsed_time(ev1) * 1e3 / 50, 1), max_rel_diff_vs_rccl=err,
-                                                kind='one-shot reduce-scatter + all-gather over hipIpc peer mappings, 2 flag barriers',
-                                                used_by_the_timed_steps=os.environ.get('HUAL_ALLREDUCE') == 'custom')
-                ar.close()
-            except Exception as e:      # never cost the bench line
-                rccl['custom_allreduce'] = dict(error=str(e)[:300])
+                    torch.cuda.synchronize()
+                    ar.check()
+                    err = float((buf - ref).abs().max() / ref.abs().max())
+                    if not err < 1e-5:
+                        msg = 'result differs from RCCL (max rel %.3g on this rank)' % err
+                except Exception as e:
+                    msg = 'first call: ' + str(e)[:250]
+                if agree(msg is None):
+                    for _ in range(5):
+                        ar()
+                    barrier()
+                    ev0.record()
+                    for _ in range(50):
+                        ar()
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    st = int(ar.status.item())
+                    rccl['custom_allreduce'] = dict(us=round(ev0.elapsed_time(ev1) * 1e3 / 50, 1), max_rel_diff_vs_rccl=err, status_word=st,
+                                                    kind='one-shot reduce-scatter + all-gather over hipIpc peer mappings, 2 flag barriers',
+                                                    used_by_the_timed_steps=os.environ.get('HUAL_ALLREDUCE') == 'custom')
+                else:
+                    rccl['custom_allreduce'] = dict(error=msg or 'failed on another rank')
+                try:
+                    ar.close()
+                except Exception:
+                    pass
+            else:
+                rccl['custom_allreduce'] = dict(error=msg or 'setup failed on another rank')
         model.grads.zero_()
     roof = None
     print('[bench] timed region done: %.3f ms/step' % (dt / args.steps * 1e3), file=sys.stderr, flush=True)
