@@ -47,23 +47,26 @@ def get_coff(task, I):
 
 
 # ---------------------------------------------------------------- infer_trainset ----------------
-def infer_trainset(model, batches, mc_dropout=None, batch_ids=None):
+def infer_trainset(model, batches, mc_dropout=None, batch_ids=None, rng=None):
     """eval_test_save (runner_utils.py:69-110) without the file write: returns (records, ious).
 
     batches: iterable of (raw_records, video, video_seq_len, word_ids, char_ids) as TestLoader.test_iter yields them
     (data_loader.py:131-143).  Each record of the result has the keys of runner_utils.py:90-100; logits are the raw
     [T_b] rows of the batch (unmasked beyond v_len), m_score is [T_b, 4].
     batch_ids (with mc_dropout): the position of each yielded batch in the whole pass - the two stochastic forwards of batch i use the
-    Philox offsets base + 2 i and base + 2 i + 1, whichever rank runs the batch and whatever ran before it (infer_trainset_sharded).
+    Philox offsets base + 2 i and base + 2 i + 1, whichever rank runs the batch and whatever ran before it (infer_trainset_sharded);
+    rng = (seed, base) of that stream (default: the model's own state).
     """
     from . import data
     records, ious = [], []
     batch_ids = iter(batch_ids) if batch_ids is not None else None
-    rng_base = int(model.rng_state[2].item()) & 0xFFFFFFFF if (batch_ids is not None and mc_dropout is not None) else None
-    rng_seed = None
-    if rng_base is not None:
-        st = model.rng_state.cpu().numpy().view(np.uint32)
-        rng_seed = int(st[0]) | (int(st[1]) << 32)
+    rng_base = rng_seed = None
+    if batch_ids is not None and mc_dropout is not None:
+        if rng is not None:
+            rng_seed, rng_base = int(rng[0]), int(rng[1])
+        else:
+            st = model.rng_state.cpu().numpy().view(np.uint32)
+            rng_seed, rng_base = int(st[0]) | (int(st[1]) << 32), int(st[2])
 
     def enqueue(batch):
         """all forwards of a batch (one deterministic + two stochastic), nothing fetched: the device runs them while the host
@@ -134,9 +137,11 @@ def infer_trainset_sharded(model, dataset, batch_size, mc_dropout=None, min_char
             f = dataset.assemble(sel, out=None, labels=False, min_chars=min_chars)
             yield [dataset.records[k] for k in sel], f['video'], f['video_seq_len'], f['word_ids'], f['char_ids']
     st0 = model.rng_state.cpu().numpy().view(np.uint32).copy()
-    records, ious = infer_trainset(model, batches(), mc_dropout=mc_dropout, batch_ids=own)
-    if mc_dropout is not None:                                  # every rank leaves the stream behind the WHOLE pass
-        model.set_rng(int(st0[0]) | (int(st0[1]) << 32), int(st0[2]) + 2 * len(los))
+    own_rng = (int(st0[0]) | (int(st0[1]) << 32), int(st0[2]))
+    rng = hdist.broadcast_object(own_rng)                       # rank 0's stream for the stochastic passes: the records do not depend on `world`
+    records, ious = infer_trainset(model, batches(), mc_dropout=mc_dropout, batch_ids=own, rng=rng)
+    # every rank returns to its OWN dropout stream, behind the whole pass
+    model.set_rng(own_rng[0], own_rng[1] + (2 * len(los) if mc_dropout is not None else 0))
     parts = hdist.gather_objects((own, records, ious))
     if parts is None:
         return None, None

@@ -34,7 +34,8 @@ class Runner:
                  ckpt_dir=None, logger=None):
         """configs: dict with the keys of configs/<task>/SeqPAN.yaml (+ num_chars, num_words like main.py:35-36)."""
         self.configs = configs
-        self.model = SeqPAN(configs, word_vectors, device=device, seed=seed, rng_seed=seed)
+        # (same parameter seed on every rank of a data-parallel job, its own dropout stream per rank)
+        self.model = SeqPAN(configs, word_vectors, device=device, seed=seed, rng_seed=seed + 1000003 * hdist.rank())
         self.train_set = DeviceDataset(train_records, visual_feats, device=device)
         self.test_set = DeviceDataset(test_records, visual_feats, device=device) if test_records else None
         self.batch_size = int(configs['train']['batch_size'])
