@@ -837,9 +837,16 @@ int launch_pool_align_bwd(const PoolArgs& a, const PoolBwd& g, const AlignPool& 
   // bytes: d fuse and d cq.feats of the video rows in, d cq.feats of the video rows back out, cq.feats query rows in, their gradient out
   const double pab = 512.0 * (3.0 * rs.Nv + 2.0 * rs.Nq);
   // (KT / KL = rows per thread held in registers: the 64 / 64 form is a wall of spills - 87.6 us at B32 T256 L20, where 64 / 8 does)
-  if (rs.T <= 128 && rs.L <= 32) HUAL_LAUNCH(0.0, pab, (pool_align_bwd_kernel<32, 8>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
-  else if (rs.L <= 32) HUAL_LAUNCH(0.0, pab, (pool_align_bwd_kernel<64, 8>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
-  else HUAL_LAUNCH(0.0, pab, (pool_align_bwd_kernel<64, 64>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs);
+  // KT / KL = rows per thread of the video / query side (T <= 4 KT, L <= 4 KL): the register arrays are sized by them, so a shape takes
+  // the smallest instantiation that holds it (queries of 33-79 words are a quarter of the reference's ActivityNet batches,
+  // tests/golden/lengths_anet.npz: they ran the <64, 64> form - 41 us against 13 - whatever the clip length)
+#define PAB(KT, KL) HUAL_LAUNCH(0.0, pab, (pool_align_bwd_kernel<KT, KL>), dim3(xcd_round8(rs.B)), dim3(512), 0, s, a, g, ap, ab, rs)
+  if (rs.T <= 128) {
+    if (rs.L <= 32) PAB(32, 8); else if (rs.L <= 64) PAB(32, 16); else if (rs.L <= 128) PAB(32, 32); else PAB(64, 64);
+  } else {
+    if (rs.L <= 32) PAB(64, 8); else if (rs.L <= 64) PAB(64, 16); else if (rs.L <= 128) PAB(64, 32); else PAB(64, 64);
+  }
+#undef PAB
   HUAL_CHECK_HIP(hipGetLastError());
   return 0;
 }
