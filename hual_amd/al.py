@@ -311,11 +311,14 @@ def run_round(model, dataset, data_old, data_gt, last_prop, task, I, epochs, bat
     new_data = update_labels(data_old, data_gt, last_prop, get_coff(task, I), device=model.device) if rank == 0 else None
     new_data = hdist.broadcast_object(new_data)
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
+    t1a = time.perf_counter()
+    # the pseudo-label frame indices of the new train list: the reference regenerates its dataset cache for this (dataset_gen,
+    # utils/data_gen.py:98-125 - one time_to_index per record, a T x T overlap table each), outside its training loop
     s_ind, e_ind = labels_from_times(new_data, dataset.vlen_h)
     dataset.set_labels(s_ind, e_ind)
     for r, a, b in zip(dataset.records, s_ind, e_ind):
         r['s_ind'], r['e_ind'] = int(a), int(b)
+    t1 = time.perf_counter()
     N = len(dataset)
     tr = trainer if trainer is not None else Trainer(model, world=world, use_graph=True)
     rng = np.random.default_rng(shuffle_seed)                   # the same permutations on every rank
@@ -332,7 +335,7 @@ def run_round(model, dataset, data_old, data_gt, last_prop, task, I, epochs, bat
     t3 = time.perf_counter()
     met = hdist.broadcast_object(iou_metrics(ious) if rank == 0 else None)
     r3, r5, r7, mi = met
-    m = dict(update_s=t1 - t0, train_s=t2 - t1, infer_s=t3 - t2, train_steps=steps, clips_per_s=N * epochs / max(t2 - t1, 1e-9),
+    m = dict(update_s=t1a - t0, relabel_s=t1 - t1a, train_s=t2 - t1, infer_s=t3 - t2, train_steps=steps, clips_per_s=N * epochs / max(t2 - t1, 1e-9),
              step_launch_modes=dict(tr.stats), world=world,
              r1i3=r3, r1i5=r5, r1i7=r7, miou=mi)
     if log and rank == 0:
