@@ -137,6 +137,17 @@ def test_long_queries():
     _check_all(case, 0.2)
 
 
+@pytest.mark.parametrize('shape', [dict(B=4, T=100, L=79, C=22, seed=91, max_vlen=100),       # the longest query / word of the fixture
+                                   dict(B=6, T=100, L=45, C=13, seed=92, max_vlen=100),       # a typical long-query batch at max_vlen 100
+                                   dict(B=3, T=256, L=64, C=16, seed=93, max_vlen=256)])      # the same at configs[3]'s T
+def test_activitynet_annotation_lengths(shape):
+    """the padded shapes the reference's OWN ActivityNet annotations produce (tests/golden/lengths_anet.npz <- data/anet_gt/train.json
+    through data_loader.py:23-28: queries of up to 79 words, words of up to 22 characters; a quarter of the batches at batch 16 holds a
+    query of more than 32 words): the global-operand context-query kernels, the pool_align_bwd instantiations for 33-128 words, the
+    char CNN at 22 characters per word"""
+    _check_all(pu.make_case(char_dim=100, **shape), 0.2)
+
+
 def test_single_clip_batch():
     case = pu.make_case(B=1, T=33, L=5, C=4, seed=61, max_vlen=40)
     _check_all(case, 0.0)
