@@ -1,6 +1,7 @@
 """GPU: whole training steps (forward + backward + clip_by_global_norm + AdamWeightDecay) against the CPU oracle's
 train_step (ops.py:119-174), eager and as a replayed hipGraph."""
 import collections
+import os
 
 import numpy as np
 import pytest
@@ -70,7 +71,7 @@ def _free_run(cfg, p, wv, b, labels, dtype, lr, drop, seed, off, steps):
 
 
 def test_twenty_step_trajectory_against_free_running_oracle():
-    """20 consecutive steps on one batch (30 until round 5: the envelope below is vacuous from step ~12 on - 1e-3 . 2.5^12 = 60 - and the
+    """14 consecutive steps on one batch (20 in round 5, 30 before: the envelope below is vacuous from step ~12 on - 1e-3 . 2.5^12 = 60 - and the
     sixty CPU-oracle steps of the two reference trajectories were 180 s of a GPU suite that has to finish in 900 s on any box) at the reference's settings (lr 1e-4, dropout 0.2: configs/charades/SeqPAN.yaml).
     The oracle runs ON ITS OWN - its own parameters, Adam slots and ReLU signs, never re-seeded from the HIP state; only the
     dropout stream (seed, step) is shared.
@@ -83,13 +84,13 @@ def test_twenty_step_trajectory_against_free_running_oracle():
     The test runs all three trajectories, prints them side by side, and demands of the HIP path:
       * steps 0-3: loss within 1e-3 relative of the float64 oracle's and the spans EQUAL;
       * steps 4-7: loss within 1e-2 relative (1e-2 absolute below 1);
-      * all 20 steps: logit deviation from the float64 trajectory inside the envelope 1e-3 . 2.5^step (the HIP path injects
+      * all 14 steps: logit deviation from the float64 trajectory inside the envelope 1e-3 . 1.5^step (the HIP path injects
         more rounding per step than float32 PyTorch - split-bf16 weight-gradient and attention-backward products, 2^-16 per
         product - and the printed table shows both deviations side by side);
       * the float64 loss actually falls (an optimizer that does nothing would pass the rest).
     Step-by-step agreement over 30 steps (same state on both sides at every step) is test_train_steps_match_oracle."""
     from hual_amd.train import Trainer
-    lr, drop, seed, off, steps = 1e-4, 0.2, 31, 11, 20
+    lr, drop, seed, off, steps = 1e-4, 0.2, 31, 11, 14      # (20 in round 5: sixty CPU-oracle steps were a quarter of the GPU suite)
     cfg, p, wv, b, labels = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
     m = pu.hip_model(cfg, p, wv)
     m.set_rng(seed, off)
@@ -97,7 +98,9 @@ def test_twenty_step_trajectory_against_free_running_oracle():
     tr.set_batch(b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(),
                  *[x.numpy() for x in labels])
     o64 = _free_run(cfg, p, wv, b, labels, torch.float64, lr, drop, seed, off, steps)
-    o32 = _free_run(cfg, p, wv, b, labels, torch.float32, lr, drop, seed, off, steps)
+    # the float32 oracle's own trajectory is printed beside the two (nothing is asserted on it) - only on request: its steps were a
+    # quarter of the GPU suite's run time; bench.py prints the same three-way comparison on its batch (cpu_baseline.loss_trajectory)
+    o32 = _free_run(cfg, p, wv, b, labels, torch.float32, lr, drop, seed, off, steps) if os.environ.get('HUAL_TEST_F32_TRAJ') == '1' else o64
 
     def dev(a, ref):
         return max(float((a[1] - ref[1]).abs().max()), float((a[2] - ref[2]).abs().max()))
@@ -109,14 +112,14 @@ def test_twenty_step_trajectory_against_free_running_oracle():
         hip = (float(tr.last_loss()), tr.start_logits.cpu().double(), tr.end_logits.cpu().double())
         dev_h.append(dev(hip, o64[s]))
         dev_o.append(dev(o32[s], o64[s]))
-        print('step %2d  loss hip %.5f  f64 %.5f  f32 %.5f   logit deviation from f64: hip %.2e  f32 oracle %.2e' %
-              (s, hip[0], o64[s][0], o32[s][0], dev_h[-1], dev_o[-1]))
+        print('step %2d  loss hip %.5f  f64 %.5f  f32 %.5f   logit deviation from f64: hip %.2e  f32 oracle %s' %
+              (s, hip[0], o64[s][0], o32[s][0], dev_h[-1], '%.2e' % dev_o[-1] if o32 is not o64 else 'not run'))
         if s < 4:
             assert abs(hip[0] - o64[s][0]) <= 1e-3 * max(abs(o64[s][0]), 1.0), (s, hip[0], o64[s][0])
             assert torch.equal(tr.start_index.cpu(), o64[s][3]) and torch.equal(tr.end_index.cpu(), o64[s][4]), s
         elif s < 8:
             assert abs(hip[0] - o64[s][0]) <= 1e-2 * max(abs(o64[s][0]), 1.0), (s, hip[0], o64[s][0])
-        assert dev_h[s] <= 1e-3 * 2.5 ** s, (s, dev_h[s])
+        assert dev_h[s] <= 1e-3 * 1.5 ** s, (s, dev_h[s])      # (round 6: 2.5^s until then; measured 3.3e-3 at step 13 against 0.19)
     assert o64[-1][0] < o64[0][0] - 1.0
 
 
@@ -143,7 +146,7 @@ def test_c1_trajectory_matches_the_clean_fp64_oracle():
     tr.set_batch(b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy(),
                  *[x.numpy() for x in labels])
     o64 = _free_run(cfg, p, wv, b, labels, torch.float64, lr, drop, seed, off, steps)
-    o32 = _free_run(cfg, p, wv, b, labels, torch.float32, lr, drop, seed, off, steps)
+    o32 = _free_run(cfg, p, wv, b, labels, torch.float32, lr, drop, seed, off, steps) if os.environ.get('HUAL_TEST_F32_TRAJ') == '1' else o64
     worst_h = worst_o = 0.0
     first = last = None
     for s in range(steps):
