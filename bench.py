@@ -408,6 +408,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    # rehearsal switches (tests/test_gpu_dp.py): HUAL_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and HUAL_BENCH_BACKEND=gloo moves the
+    # collectives through the host, so that the N > 1 code path - the custom all-reduce leg included - runs on a one-GPU box (RCCL refuses
+    # two ranks on one device).  The numbers of such a run mean nothing.
+    if os.environ.get('HUAL_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     # HUAL_DP_FORCE_COLLECTIVES=1: the multi-rank code path (RCCL group, data-parallel step, rccl block, MAX-reduce of the time)
@@ -415,7 +420,11 @@ def main():
     dp = world > 1 or os.environ.get('HUAL_DP_FORCE_COLLECTIVES') == '1'
     if dp:
         import torch.distributed as dist
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get('HUAL_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     from hual_amd import lib
     from hual_amd.model import SeqPAN
     from hual_amd.train import Trainer

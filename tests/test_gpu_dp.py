@@ -137,3 +137,37 @@ def test_bench_multi_rank_path_on_one_rank(tmp_path):
     assert 'error' not in el and el['step_launch_modes']['eager'] == el['steps'] and el['value'] > 0
     for leg in out['epoch_loop_anet']:
         assert 'error' not in leg and leg['lengths_from'] == 'anet' and leg['step_launch_modes']['eager'] == leg['steps']
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py --gpus 2 as TWO processes on the one GPU of the test box (HUAL_BENCH_ONE_DEVICE=1, collectives over gloo): the N > 1
+    code path that a one-rank group cannot reach - the data-parallel step between two real ranks, the guarded one-shot all-reduce leg
+    (hual_amd/xgmi.py: peer mappings, first call compared with the backend's sum, then timed), the data-parallel epoch-loop legs with
+    their shard plans, rank 0 alone in the roofline leg while rank 1 waits in the next collective"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = str(29700 + os.getpid() % 90)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, HUAL_BENCH_ONE_DEVICE='1', HUAL_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', WORLD_SIZE='2',
+                   RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--batch', '8', '--T', '32', '--L', '8',
+                                       '--C', '5', '--vdim', '256', '--steps', '4', '--warmup', '1', '--prewarm', '2', '--no-cpu-baseline',
+                                       '--epoch-samples', '256', '--anet-samples', '512'],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith('{')][-1]
+    assert not [l for l in outs[1][0].splitlines() if l.startswith('{')]          # rank 0 prints the one line
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2' and out['config']['global_batch'] == 16
+    ca = out['rccl']['custom_allreduce']
+    assert 'error' not in ca and ca['us'] > 0 and ca['status_word'] == 0 and ca['max_rel_diff_vs_rccl'] < 1e-5, ca
+    assert out['roofline'] is not None and out['roofline']['kernel']
+    el = out['epoch_loop']
+    assert 'error' not in el and el['n_gpus'] == 2 and el['step_launch_modes']['eager'] == el['steps']
+    for leg in out['epoch_loop_anet']:
+        assert 'error' not in leg and leg['n_gpus'] == 2 and leg['lengths_from'] == 'anet'
