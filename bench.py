@@ -478,7 +478,7 @@ def main():
         torch.cuda.synchronize()
         rccl = dict(rccl_ranks=world, allreduce_us=round(ev0.elapsed_time(ev1) * 1e3 / 50, 1),
                     allreduce_bytes=int(model.grads.numel() * 4), backend=torch.distributed.get_backend(),
-                    step_launch='hipGraph with the collectives captured' if trainer.graph is not None else 'eager')
+                    step_launch=trainer.dp_launch)
         # the same sum through the one-shot peer-mapped all-reduce (hual_amd/xgmi.py; off by default in the step:
         # HUAL_ALLREDUCE=custom): ONE guarded call first - compared with RCCL's result, status word checked - and only then the timing
         if world > 1:

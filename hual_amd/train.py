@@ -23,6 +23,7 @@ class Trainer:
         self.use_graph = use_graph and not self.dp
         self.dp_graph = use_graph and self.dp     # data-parallel step as a graph (nccl backend only, see _step_dp)
         self._dp_graph_failed = False
+        self.dp_launch = 'eager'                  # how the last data-parallel step was launched: eager / segment graphs / one graph
         self._prezero_token = ctypes.c_uint64(0)
         self.graph = None
         self.graph_drop = None
@@ -273,23 +274,80 @@ class Trainer:
         self._backward(opts)
         self._adam(1.0)
 
-    def _enqueue_dp(self, drop_rate):
-        """one data-parallel step, enqueued without any host synchronisation: forward -> all-gather of the [B,256] alignment
-        features -> global [Bg,Bg] alignment loss, gradient rows of the own samples written straight into the backward's
-        workspace buffers -> backward -> ONE all-reduce of the flat gradient bucket -> clip + AdamWD on the averaged gradient"""
-        m, B = self.m, self.shape[0]
+    # one data-parallel step = three runs of our own launches with a collective between them
+    def _dp_part_a(self, opts):
         self._enqueue_assembly()
-        opts = self._opts(drop_rate, 1)
         self._forward(opts)
-        hdist.allgather_rows_(self.feat_all, m.tap('align.tv'))      # [that | vhat] rows as the forward left them: no copy
-        fa = self.feat_all
+
+    def _dp_gather(self):
+        hdist.allgather_rows_(self.feat_all, self.m.tap('align.tv'))      # [that | vhat] rows as the forward left them: no copy
+
+    def _dp_part_b(self, opts):
+        m, B, fa = self.m, self.shape[0], self.feat_all
         lib.check(self._lib.hual_align_loss_rows(
             lib.ptr(fa), ctypes.c_void_p(fa.data_ptr() + 128 * 4), 256, fa.shape[0], hdist.rank() * B if self.world > 1 else 0, B,
             lib.ptr(self.align_scratch), lib.ptr(m.tap('d.align.that')), lib.ptr(m.tap('d.align.vhat')), lib.ptr(self.align_loss),
             float(self.world), lib.stream_ptr()))
         self._backward(opts)
-        hdist.allreduce_sum_(m.grads)
+
+    def _dp_reduce(self):
+        hdist.allreduce_sum_(self.m.grads)
+
+    def _dp_part_c(self):
         self._adam(1.0 / self.world)
+
+    def _enqueue_dp(self, drop_rate):
+        """one data-parallel step, enqueued without any host synchronisation: forward -> all-gather of the [B,256] alignment
+        features -> global [Bg,Bg] alignment loss, gradient rows of the own samples written straight into the backward's
+        workspace buffers -> backward -> ONE all-reduce of the flat gradient bucket -> clip + AdamWD on the averaged gradient"""
+        opts = self._opts(drop_rate, 1)
+        self._dp_part_a(opts)
+        self._dp_gather()
+        self._dp_part_b(opts)
+        self._dp_reduce()
+        self._dp_part_c()
+
+    def _capture_dp_segments(self, drop_rate):
+        """The three runs of OUR launches as three hipGraphs (records only, nothing executes); the collectives stay OUTSIDE and are
+        issued eagerly between the replays - no RCCL call inside a graph (that form, _step_dp's full capture, has never run on two
+        devices and stays opt-in), but 57 of the step's 59 host launches collapse into three.  Ranks need not agree on it: a rank on
+        segment graphs and a rank on eager launches issue the same two collectives in the same order.  Returns None if a capture is
+        refused."""
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream(device=self.m.device)
+        cs, cur = self._cap_stream, torch.cuda.current_stream()
+        opts = self._opts(drop_rate, 1)
+        segs = []
+        for part in (lambda: self._dp_part_a(opts), lambda: self._dp_part_b(opts), self._dp_part_c):
+            g = torch.cuda.CUDAGraph()
+            cs.wait_stream(cur)
+            err = None
+            with torch.cuda.stream(cs):
+                # thread_local: the process group's watchdog thread may touch the device while this thread captures
+                g.capture_begin(capture_error_mode='thread_local')
+                try:
+                    part()
+                except BaseException as ex:
+                    err = ex
+                try:
+                    g.capture_end()
+                except RuntimeError as ex:
+                    err = err or ex
+            cur.wait_stream(cs)
+            if err is not None:
+                if isinstance(err, lib.HualError) or not isinstance(err, RuntimeError):
+                    raise err
+                print('[hual] data-parallel step: segment capture refused (%s) - eager launches' % str(err).splitlines()[0], file=sys.stderr)
+                return None
+            segs.append(g)
+        return segs
+
+    def _replay_dp_segments(self, segs):
+        segs[0].replay()
+        self._dp_gather()
+        segs[1].replay()
+        self._dp_reduce()
+        segs[2].replay()
 
     def step(self, lr, drop_rate):
         m = self.m
@@ -324,6 +382,21 @@ class Trainer:
         Data parallel: eager launches (the collectives inside a step graph are opt-in, _step_dp)."""
         e = self._entry
         if self.dp:
+            # segment graphs per shape (the collectives between them eager): default with world > 1 (HUAL_DP_GRAPH=seg), see _step_dp
+            segmented = self.dp_graph and self._dp_mode() == 'seg' and not e['nograph']
+            if segmented and e.get('segs') is not None and e['drop'] == drop_rate:
+                self._replay_dp_segments(e['segs'])
+                self.stats['replayed'] += 1
+                return
+            if segmented and e['seen'] >= self.capture_after:
+                segs = self._capture_dp_segments(drop_rate)
+                if segs is not None:
+                    e['segs'], e['drop'] = segs, drop_rate
+                    self._replay_dp_segments(segs)
+                    self.stats['captured'] += 1
+                    return
+                e['nograph'] = True
+                self.stats['capture_failed'] += 1
             self._enqueue_dp(drop_rate)
             e['seen'] += 1
             self.stats['eager'] += 1
@@ -374,21 +447,49 @@ class Trainer:
         g.replay()
         self.stats['captured'] += 1
 
+    def _dp_mode(self):
+        """HUAL_DP_GRAPH: '1' = the whole step incl. its RCCL collectives as ONE hipGraph (default on a one-rank group: the rehearsal the
+        GPU suite runs; opt-in with more ranks - never validated on two devices), 'seg' = three graphs of our own launches with the two
+        collectives eager between them (default with more than one rank), '0' = eager launches"""
+        return os.environ.get('HUAL_DP_GRAPH', '1' if self.world == 1 else 'seg')
+
     def _step_dp(self, drop_rate):
-        """With the nccl backend (RCCL: its collectives are stream operations) the data-parallel step, collectives included, CAN be
-        captured once into a hipGraph and replayed.  That is the default only on ONE rank (the forced-collectives rehearsal the GPU
+        """Three launch modes (_dp_mode).  With more than one rank the default is SEGMENT graphs: forward | backward | optimizer as three
+        hipGraphs of our own launches, the all-gather and the all-reduce issued eagerly between the replays - no collective inside a
+        graph, and a rank whose capture is refused simply launches eagerly (same collective sequence).  Measured on a one-rank RCCL
+        group: eager 1.253 ms/step, one graph with the collectives inside 1.210, the single-GPU graph 1.195.
+        With the nccl backend (RCCL: its collectives are stream operations) the data-parallel step, collectives included, CAN also be
+        captured into ONE hipGraph and replayed.  That is the default only on ONE rank (the forced-collectives rehearsal the GPU
         suite runs); with more than one rank it is opt-in (HUAL_DP_GRAPH=1) until a multi-GPU run has validated capture and replay
-        of the all-gather / all-reduce pair - no such run exists yet - and the eager launch of the same sequence is
-        used: 60 launches per 1.2 ms step leave the host far ahead of the device.  The graph-or-eager decision is COLLECTIVE: after
+        of the all-gather / all-reduce pair - no such run exists yet.  There the graph-or-eager decision is COLLECTIVE: after
         the capture attempt the ranks all-reduce(MIN) an ok flag, so either every rank replays or every rank launches eagerly.  Only a
         refused capture (a RuntimeError from torch / HIP) is treated as "no graph"; an error raised by one of our own launches
         (lib.HualError) propagates.  Other backends (gloo: host collectives) always launch eagerly."""
-        default = '1' if self.world == 1 else '0'
-        want_graph = (os.environ.get('HUAL_DP_GRAPH', default) != '0' and self.dp_graph and not self._dp_graph_failed
-                      and hdist.backend() == 'nccl')
+        mode = self._dp_mode()
+        if mode == 'seg' and self.dp_graph and not self._dp_graph_failed:
+            m = self.m
+            if self.graph is None or self.graph_drop != drop_rate:
+                snap = [t.clone() for t in (m.params, m.adam_m, m.adam_v, m.rng_state)]
+                self._enqueue_dp(drop_rate)          # warm-up outside capture (first-use attributes, RCCL channel setup)
+                torch.cuda.synchronize()
+                for t, sn in zip((m.params, m.adam_m, m.adam_v, m.rng_state), snap):
+                    t.copy_(sn)
+                torch.cuda.synchronize()
+                segs = self._capture_dp_segments(drop_rate)
+                if segs is None:
+                    self._dp_graph_failed = True
+                    self._enqueue_dp(drop_rate)
+                    return
+                self.graph, self.graph_drop = segs, drop_rate
+            self._replay_dp_segments(self.graph)
+            self.dp_launch = 'three hipGraphs of the launches, the two collectives eager between them'
+            return
+        want_graph = (mode == '1' and self.dp_graph and not self._dp_graph_failed and hdist.backend() == 'nccl')
         if not want_graph:
             self._enqueue_dp(drop_rate)
+            self.dp_launch = 'eager'
             return
+        self.dp_launch = 'hipGraph with the collectives captured'
         m = self.m
         if self.graph is None or self.graph_drop != drop_rate:
             snap = [t.clone() for t in (m.params, m.adam_m, m.adam_v, m.rng_state)]
@@ -422,6 +523,7 @@ class Trainer:
                 print('[hual] data-parallel step: graph capture %s - eager launches on every rank'
                       % ('refused here (%s)' % str(err).splitlines()[0] if err is not None else 'refused on another rank'), file=sys.stderr)
                 self._enqueue_dp(drop_rate)
+                self.dp_launch = 'eager'
                 return
             self.graph, self.graph_drop = g, drop_rate
         self.graph.replay()

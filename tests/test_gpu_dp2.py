@@ -28,7 +28,7 @@ def _case(lens=(18, 11, 18, 7)):
     return cfg, p, wv, b, labels
 
 
-def _worker(rank, world, port, q, lens):
+def _worker(rank, world, port, q, lens, seg=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -41,28 +41,34 @@ def _worker(rank, world, port, q, lens):
     B = 4 // world
     sl = slice(rank * B, (rank + 1) * B)
     m = pu.hip_model(cfg, p, wv)
-    tr = Trainer(m, world=world, use_graph=False)
+    if seg:
+        os.environ['HUAL_DP_GRAPH'] = 'seg'
+    tr = Trainer(m, world=world, use_graph=seg)
     tr.set_batch(b['video'][sl].numpy(), b['lens'][sl].numpy(), b['word_ids'][sl].numpy(), b['char_ids'][sl].numpy(),
                  *[x[sl].numpy() for x in labels])
     tr.step(lr=1e-3, drop_rate=0.0)
     torch.cuda.synchronize()
+    if seg:
+        assert tr.dp_launch.startswith('three hipGraphs'), tr.dp_launch
     q.put((rank, m.grads.detach().cpu().numpy() / world, m.params.detach().cpu().numpy(), float(tr.last_loss())))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('lens', [(18, 11, 18, 7), (18, 11, 9, 7)])
-def test_two_ranks_on_one_gpu_match_single_process(lens):
+@pytest.mark.parametrize('lens,seg', [((18, 11, 18, 7), False), ((18, 11, 9, 7), False), ((18, 11, 9, 7), True)])
+def test_two_ranks_on_one_gpu_match_single_process(lens, seg):
     """lens (18, 11, 9, 7): the second shard holds no full-length clip; it is padded to the GLOBAL T = 18 (Trainer.set_batch,
     data-parallel mode), which is what keeps the decomposition exact - with a shard-local T the reference's unmasked
-    conv_block (modules.py:59-70) would see different rows behind each clip's end"""
+    conv_block (modules.py:59-70) would see different rows behind each clip's end.
+    seg: the step as three hipGraphs of the launches with the two collectives eager between them (Trainer._step_dp, the default launch
+    mode with more than one rank)"""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import parity_util as pu
     from hual_amd.train import Trainer
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29800 + (os.getpid() % 150) + (7 if lens[2] == 9 else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, lens)) for r in range(2)]
+    port = 29800 + (os.getpid() % 150) + (7 if lens[2] == 9 else 0) + (13 if seg else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, lens, seg)) for r in range(2)]
     for pr in procs:
         pr.start()
     got = dict()
