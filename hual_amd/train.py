@@ -115,12 +115,16 @@ class Trainer:
 
     def _alloc_dp(self, B):
         """static buffers of the data-parallel exchange: [that | vhat] of the local / all samples, the [Bg,Bg] scratch of the
-        alignment loss, its value, and the device scalar holding the matching-loss denominator"""
-        dev, Bg = self.m.device, B * self.world
-        self.align_scratch = torch.empty(2 * Bg * Bg + Bg, device=dev)
-        self.feat_all = torch.empty(Bg, 256, device=dev)
-        self.align_loss = torch.zeros(1, device=dev)
-        self.denom_dev = torch.zeros(1, device=dev)
+        alignment loss, its value, and the device scalar holding the matching-loss denominator.  One set per local batch size, kept for
+        the trainer's lifetime: the segment graphs of a padded shape hold their addresses (an epoch's ragged last batch comes back
+        every epoch)."""
+        if not hasattr(self, '_dp_bufs'):
+            self._dp_bufs = {}
+        if B not in self._dp_bufs:
+            dev, Bg = self.m.device, B * self.world
+            self._dp_bufs[B] = (torch.empty(2 * Bg * Bg + Bg, device=dev), torch.empty(Bg, 256, device=dev), torch.zeros(1, device=dev),
+                                torch.zeros(1, device=dev))
+        self.align_scratch, self.feat_all, self.align_loss, self.denom_dev = self._dp_bufs[B]
         self.graph = None
 
     def _update_match_denominator(self):
@@ -131,8 +135,11 @@ class Trainer:
         self.match_denom = 0.0
         if not self.dp:
             return
-        if self._host_denom is not None:      # the epoch loop knows the global batch's lengths on the host: no device work, no collective
-            self.match_denom = float(self._host_denom)
+        if self._host_denom is not None:
+            # the epoch loop knows the global batch's lengths on the host: no collective - but the value still travels through the DEVICE
+            # scalar (one fill launch): a step's options must not change from batch to batch of a padded shape, they are baked into
+            # that shape's segment graphs (by value the first batch's denominator would be replayed for every later one)
+            self.denom_dev.fill_(float(self._host_denom))
             return
         torch.sum(self.lens.to(torch.float32), dim=0, keepdim=True, out=self.denom_dev)
         hdist.allreduce_sum_(self.denom_dev)
@@ -220,7 +227,7 @@ class Trainer:
         return lib.hual_run_opts(float(drop_rate), lib.ptr(self.m.rng_state).value, float(self.match_denom),
                                  int(align_external),
                                  1 if (self._tables_ready and not os.environ.get('HUAL_NO_STATIC_TABLES')) else 0,
-                                 lib.ptr(self.denom_dev).value if (self.dp and self._host_denom is None) else None, 0,
+                                 lib.ptr(self.denom_dev).value if self.dp else None, 0,
                                  # the forward's first launch zeroes the gradient bucket (one launch fewer in backward); the
                                  # host word is the receipt the backward call checks and clears (hual_run_opts.prezero_token)
                                  lib.ptr(self.m.grads).value, ctypes.addressof(self._prezero_token),

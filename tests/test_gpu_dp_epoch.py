@@ -32,14 +32,14 @@ def _setup():
     return cfg, wv, ds, orders
 
 
-def _run(world):
+def _run(world, seg=False):
     """per-step averaged gradients + spans at lr 0, then two real epochs; returns what the comparison needs"""
     from hual_amd.model import SeqPAN
     from hual_amd.train import Trainer
     cfg, wv, ds, orders = _setup()
     m = SeqPAN(cfg, wv)
     m.ws_poison = 0xFF
-    tr = Trainer(m, world=world, use_graph=(world == 1))
+    tr = Trainer(m, world=world, use_graph=(world == 1) or seg)      # seg: three segment graphs per padded shape, collectives eager
     gb = BS * WORLD
     grads, spans = [], []
     for lo in range(0, N, gb):
@@ -54,23 +54,24 @@ def _run(world):
     return grads, spans, m.params.detach().cpu().numpy(), ep_spans, dict(tr.stats), tr.last_epoch_ids.copy()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, seg=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    res = _run(world)
+    res = _run(world, seg)
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_epoch_loop_matches_single_process_global_batches():
+@pytest.mark.parametrize('seg', [False, True])
+def test_two_rank_epoch_loop_matches_single_process_global_batches(seg):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29650 + (os.getpid() % 120)
-    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    port = 29650 + (os.getpid() % 120) + (5 if seg else 0)
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q, seg)) for r in range(WORLD)]
     for pr in procs:
         pr.start()
     got = dict(q.get(timeout=600) for _ in range(WORLD))
@@ -87,7 +88,9 @@ def test_two_rank_epoch_loop_matches_single_process_global_batches():
                for lo in range(0, N, BS * WORLD))
     for r in range(WORLD):
         g, s, p, e, st, ids = got[r]
-        assert st['eager'] == len(g1) + 2 * (N // (BS * WORLD)) and st.get('dropped', 0) == 0
+        nst = len(g1) + 2 * (N // (BS * WORLD))
+        assert st['eager'] + st['captured'] + st['replayed'] == nst and st.get('dropped', 0) == 0
+        assert (st['eager'] == nst) if not seg else (st['replayed'] > 0 and st['capture_failed'] == 0), st
         assert np.array_equal(ids, ids1)
         for k in range(len(g1)):
             scale = max(1.0, float(np.abs(g1[k]).max()))
