@@ -47,12 +47,13 @@ def _worker(rank, world, port, q):
     B = 4 // world
     sl = slice(rank * B, (rank + 1) * B)
     m = pu.hip_model(cfg, p, wv)
-    tr = Trainer(m, world=world, use_graph=False)
+    tr = Trainer(m, world=world, use_graph=True)             # the default launch with more than one rank: segment graphs, collectives eager
     used = hdist._custom.get(m.grads.data_ptr()) is not None
     tr.set_batch(b['video'][sl].numpy(), b['lens'][sl].numpy(), b['word_ids'][sl].numpy(), b['char_ids'][sl].numpy(),
                  *[x[sl].numpy() for x in labels])
     tr.step(lr=1e-3, drop_rate=0.0)
     torch.cuda.synchronize()
+    assert tr.dp_launch.startswith('three hipGraphs'), tr.dp_launch
     hdist._custom[m.grads.data_ptr()].check()
     q.put((rank, ok, used, m.grads.detach().cpu().numpy() / world, m.params.detach().cpu().numpy()))
     ar.close()
