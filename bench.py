@@ -163,6 +163,20 @@ def cpu_baseline(seconds_budget=20.0):
     out = dict(value=round(16 * n / dt, 2), unit='clips/s', cores=best, kind='port',
                sample='%d train steps (fwd+bwd+AdamWD, dropout 0.2) of the PyTorch-CPU oracle at B16 T64 vdim1024 L20 fp32, %.1f s'
                       % (n, dt), affinity_cores=ncores, seconds_per_step_by_threads=scan)
+    # the forward alone (the reference's evaluation fetches, runner_utils.py:166) and the CPU's name beside the numbers
+    try:
+        with torch.no_grad():
+            R.forward(p0, cfg, wv, batch[0], batch[1], batch[2], batch[3], drop_rate=0.0)
+            nf, tf0 = 0, time.perf_counter()
+            while nf < 40 and time.perf_counter() - tf0 < 4.0:
+                R.forward(p0, cfg, wv, batch[0], batch[1], batch[2], batch[3], drop_rate=0.0)
+                nf += 1
+            out['forward_only'] = dict(value=round(16 * nf / (time.perf_counter() - tf0), 2), unit='clips/s', passes=nf)
+        model_name = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')]
+        out['cpu_model'] = model_name[0] if model_name else None
+        out['cpu_count'] = os.cpu_count()
+    except Exception as e:      # never cost the bench line
+        out['forward_only'] = dict(error=str(e)[:200])
     # the float64 oracle's first ten losses from the same clean start (untimed): the yardstick both float32 paths are read against
     k64 = min(n, 10)
     p64 = {k: t.double() for k, t in p0.items()}
