@@ -709,6 +709,26 @@ def main():
         except Exception as e:      # never cost the bench line
             other_feed = dict(error=str(e)[:200])
 
+    fwd_only = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the evaluation fetch set on its own (runner_utils.py:166: start / end index; all five fetches come out of the one pass), eager launches
+        try:
+            dv = [torch.as_tensor(b[k]).to(dev) for k in ('video', 'lens', 'word_ids', 'char_ids')]
+            for _ in range(20):
+                model.forward(*dv, drop_rate=0.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(300):
+                model.forward(*dv, drop_rate=0.0)
+            torch.cuda.synchronize()
+            d3 = time.perf_counter() - t0
+            fwd_only = dict(value=round(args.batch * 300 / d3, 1), unit='clips/s', ms_per_pass=round(d3 / 300 * 1e3, 4), passes=300,
+                            launch='eager', note='hual_seqpan_forward without labels: logits, match scores and spans of one batch per pass')
+            if cpu is not None and isinstance(cpu.get('forward_only'), dict) and 'value' in cpu['forward_only']:
+                fwd_only['cpu_forward_only_c1_clips_s'] = cpu['forward_only']['value']
+        except Exception as e:      # never cost the bench line
+            fwd_only = dict(error=str(e)[:200])
+
     epoch_loop, epoch_anet = None, None
     if not args.no_epoch_loop and (world == 1 or dp):
         # every rank runs these legs when the job is data parallel (collectives inside); rank 0 reports
@@ -741,6 +761,8 @@ def main():
                    roofline=roof, cpu_baseline=cpu)
         if other_feed is not None:
             out['other_feature_dtype'] = other_feed
+        if fwd_only is not None:
+            out['forward_only'] = fwd_only
         if epoch_loop is not None:
             out['epoch_loop'] = epoch_loop
         if epoch_anet is not None:
