@@ -39,6 +39,27 @@ def _worker(rank, world, port, q):
         ar.check()
         ok = ok and torch.equal(flat.cpu(), want)
         flat.mul_(0.5).add_(float(rank + it))                    # another bucket for the next call
+    # captured into a hipGraph and replayed: the sequence number lives on the device and advances with every replay.  After the first
+    # call both ranks hold the same sum, so every further call doubles it exactly
+    flat.copy_(torch.randn(n, generator=g).to(dev))
+    want = flat.cpu()
+    dist.all_reduce(want)
+    ar()                                                         # (eager warm call: both ranks at the same sum)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        gr.capture_begin()
+        ar(stream=st)
+        gr.capture_end()
+    torch.cuda.current_stream().wait_stream(st)
+    dist.barrier()
+    for _ in range(8):
+        gr.replay()
+    torch.cuda.synchronize()
+    ar.check()
+    ok = ok and torch.equal(flat.cpu(), want * float(world ** 8))
     # the same through the data-parallel train step: HUAL_ALLREDUCE=custom routes hual_amd.dist.allreduce_sum_(model.grads) here
     import test_gpu_dp2 as t2
     import parity_util as pu
