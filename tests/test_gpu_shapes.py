@@ -148,6 +148,15 @@ def test_activitynet_annotation_lengths(shape):
     _check_all(pu.make_case(char_dim=100, **shape), 0.2)
 
 
+@pytest.mark.parametrize('shape', [dict(B=1, T=256, L=256, C=4, seed=5, max_vlen=256),       # both sides at the kernels' maximum
+                                   dict(B=2, T=256, L=128, C=32, seed=6, max_vlen=256),      # 32-character words
+                                   dict(B=2, T=3, L=200, C=5, seed=7, max_vlen=200)])        # a query far longer than its clip
+def test_maximum_sizes(shape):
+    """the edges of the supported range (T, L <= 256; hual_seqpan_forward rejects more): every context-query form, the attention
+    kernels at 256 keys on both sides, the char CNN at 32 characters per word"""
+    _check_all(pu.make_case(**shape), 0.2)
+
+
 def test_single_clip_batch():
     case = pu.make_case(B=1, T=33, L=5, C=4, seed=61, max_vlen=40)
     _check_all(case, 0.0)
