@@ -113,3 +113,26 @@ def test_activation_outside_the_fp16_operand_range_is_loud():
     free = m2.forward(*feeds, drop_rate=0.0)
     assert np.isnan(free['start_logits'].cpu().numpy()).any()
     assert (free['start_index'].cpu().numpy() == -1).all() and (free['end_index'].cpu().numpy() == -1).all()
+
+
+def test_feed_errors_are_python_exceptions_like_the_references():
+    """the façade raises where sess.run would (runner_utils.py:53-65 feeds): the placeholder's T is the batch's longest clip
+    (model.py:31), the feature width is the configured one (model.py:17), a word has at least the char CNN's four characters
+    (modules.py:19-38), a clip fits the position table (modules.py:44)"""
+    from hual_amd import lib
+    cfg, p, wv, b, labels = pu.make_case(B=2, T=12, L=5, C=5, seed=4, max_vlen=16)
+    m = pu.hip_model(cfg, p, wv)
+    v, ln, w, c = b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy()
+    m.forward(v, ln, w, c)                                            # fine as it is
+    with pytest.raises(ValueError, match='max\\(video_seq_len\\)'):
+        m.forward(np.concatenate([v, np.zeros_like(v[:, :1])], axis=1), ln, w, c)
+    with pytest.raises(ValueError, match='vdim'):
+        m.forward(v[:, :, :512], ln, w, c)
+    with pytest.raises(ValueError, match='4 chars'):
+        m.forward(v, ln, w, c[:, :, :3])
+    long_v = np.zeros((2, 20, v.shape[2]), dtype=np.float32)
+    with pytest.raises(lib.HualError, match='max_vlen'):
+        m.forward(long_v, np.array([20, 20], dtype=np.int32), w, c)   # 20 frames against a position table of 16
+    torch.cuda.synchronize()
+    o = m.forward(v, ln, w, c)                                        # and the model is still usable
+    assert torch.isfinite(o['start_logits']).all()
