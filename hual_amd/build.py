@@ -26,7 +26,44 @@ def _sources():
 
 # per-file additions.  convblock.hip: the machine scheduler's max-ILP strategy (conv_block_bwd 3 x 39.5 -> 3 x 38.8 us, conv_block_fwd -0.3 us
 # per launch in a same-box A/B of the whole library built with it; the other files gain nothing or lose: mproj +1..2 us, dw +0.7)
-FILE_FLAGS = {'convblock.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp']}
+FILE_FLAGS = {'convblock.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'],
+              # heads.hip without packed fp32 math.  The matching head's float4 arithmetic (f.y * w.xy, p1 * e.xy) was compiled to
+              # v_pk_mul/fma_f32 with op_sel:[0,1,..] - the LOW lane of the pair reading the HIGH register of a source pair - the
+              # only such instructions in the library, and exactly those instructions lost their low result in lanes 48-63 of a
+              # wave whenever a second queue ran our kernels next to them (12 % of forwards with a second stream in the process,
+              # 0.3-3 % with a second process; never alone, never with this flag: profiles/r6_packed_fp32_opsel.txt).  The
+              # kernels of this file are latency bound: no launch got slower (same-box A/B +-0.3 us).  _check_isa() refuses the
+              # instruction form in every file.
+              'heads.hip': ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']}
+OBJDUMP = os.environ.get('HUAL_OBJDUMP', '/opt/rocm/lib/llvm/bin/llvm-objdump')
+
+
+def _check_isa(obj):
+    """refuse a device object holding a packed-fp32 instruction whose op_sel makes the low lane read the high source register (see
+    FILE_FLAGS['heads.hip']): the form is not reliable on gfx950 when two queues share the GPU"""
+    import re
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='hual_isa_')
+    try:
+        o = os.path.join(tmp, os.path.basename(obj))
+        shutil.copy(obj, o)
+        subprocess.run([OBJDUMP, '--offloading', o], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        cos = [f for f in glob.glob(o + '.*') if 'amdgcn' in f]
+        if not cos:      # a .hip file without kernels (host code only) holds no device bundle
+            src = os.path.join(CSRC, os.path.basename(obj)[:-2])
+            if '__global__' in open(src).read():
+                raise RuntimeError('no gfx950 code object found in %s' % obj)
+            return
+        bad = []
+        for co in cos:
+            dis = subprocess.run([OBJDUMP, '-d', co], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+            bad += [l.strip() for l in dis.splitlines() if re.search(r'v_pk_(fma|mul|add)_f32 .*op_sel:\[', l)]
+        if bad:
+            raise RuntimeError('%s: %d packed-fp32 instructions with op_sel (low lane reads the high register), e.g. "%s": compile the file '
+                               'with -packed-fp32-ops (FILE_FLAGS) or restate the arithmetic' % (os.path.basename(obj), len(bad), bad[0]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _stamp(src):
@@ -38,7 +75,7 @@ def _stamp(src):
     return h.hexdigest()
 
 
-def build(verbose=False, force=False, out=None, defines=()):
+def build(verbose=False, force=False, out=None, defines=(), flags=(), file_flags=None):
     """out / defines: a VARIANT of the current tree (scripts/exp A/B builds) - the same global and per-file flags plus -D switches,
     objects in a directory of its own next to `out`, the in-tree library untouched"""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -46,18 +83,19 @@ def build(verbose=False, force=False, out=None, defines=()):
     if out is not None:
         lib_path = os.path.abspath(out)
         obj_dir = lib_path + '.obj'
-        extra = ['-D' + d for d in defines]
+        extra = ['-D' + d for d in defines] + list(flags)
     os.makedirs(obj_dir, exist_ok=True)
     objs, rebuilt, procs = [], False, []
     for src in _sources():
         base = os.path.basename(src)
         obj = os.path.join(obj_dir, base + '.o')
         stamp_file = obj + '.stamp'
-        stamp = _stamp(src) + ' '.join(extra)
+        ff = list((file_flags or {}).get(base, []))
+        stamp = _stamp(src) + ' '.join(extra + ff)
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
             continue
-        cmd = [hipcc] + FLAGS + extra + FILE_FLAGS.get(base, []) + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', src, '-o', obj]
+        cmd = [hipcc] + FLAGS + extra + FILE_FLAGS.get(base, []) + ff + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), stamp_file, stamp, base))
@@ -69,6 +107,8 @@ def build(verbose=False, force=False, out=None, defines=()):
             raise RuntimeError('hipcc failed on %s' % base)
         if verbose and out:
             print(out.decode())
+        if base.endswith('.hip'):
+            _check_isa(os.path.join(obj_dir, base + '.o'))
         with open(stamp_file, 'w') as fh:
             fh.write(stamp)
     if rebuilt or not os.path.exists(lib_path):
@@ -80,8 +120,10 @@ def build(verbose=False, force=False, out=None, defines=()):
 
 
 if __name__ == '__main__':
-    # python -m hual_amd.build [--force] [--out build_exp/x.so --define A --define B=1 ...]
+    # python -m hual_amd.build [--force] [--out build_exp/x.so --define A --define B=1 --flags "-mllvm -x" --file-flags "heads.hip=-mllvm -y" ...]
     args = sys.argv[1:]
     out = args[args.index('--out') + 1] if '--out' in args else None
     defs = [args[i + 1] for i, a in enumerate(args) if a == '--define']
-    print(build(verbose=out is None, force='--force' in args, out=out, defines=defs))
+    flags = [f for i, a in enumerate(args) if a == '--flags' for f in args[i + 1].split()]
+    ffl = {args[i + 1].split('=', 1)[0]: args[i + 1].split('=', 1)[1].split() for i, a in enumerate(args) if a == '--file-flags'}
+    print(build(verbose=out is None, force='--force' in args, out=out, defines=defs, flags=flags, file_flags=ffl))
