@@ -17,6 +17,7 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -478,6 +479,48 @@ def main():
     loss = float(trainer.last_loss())
     clips = args.batch * world * args.steps
 
+    # Everything below rides in the same line but is not the measurement: the legs report into `legs` as they finish, and a deadline
+    # (HUAL_BENCH_LEG_DEADLINE_S, default 900 s after the timed region) prints the line with what has finished and ends every rank - a
+    # leg that hangs (a collective one rank never reaches, a peer mapping that never answers) must not cost the timed number.
+    legs = dict()
+    emitted = [False]
+    emit_lock = threading.Lock()
+
+    def emit(extra=None):
+        with emit_lock:
+            if emitted[0]:
+                return
+            emitted[0] = True
+            if rank == 0:
+                out = dict(metric='train clips/sec', value=round(clips / dt, 2), unit='clips/s', n_gpus=world, steps=args.steps,
+                           warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
+                           scaling='weak', vs_baseline=None, dtype='f32 (fp16x3 / bf16x3 split-operand MFMA, fp32 accumulate)', data='synthetic',
+                           config=dict(workload='Charades-STA SeqPAN train step (fwd+bwd+clip+AdamWD, dropout %.1f), batch %d/GPU, '
+                                                'T=%d, vdim=%d, L=%d, C=%d, dim=128, 8 heads, 2 attention layers, random init; ONE batch resident in '
+                                                'HBM, batch assembly (hual_assemble_batch) outside the timed region'
+                                                % (args.drop, args.batch, args.T, args.vdim, args.L, args.C),
+                                       global_batch=args.batch * world, T=args.T, vdim=args.vdim, L=args.L,
+                                       parallelism='dp%d' % world, launch='eager' if args.no_graph else 'hipGraph',
+                                       video_dtype=args.video_dtype,
+                                       final_loss=round(loss, 4)),
+                           roofline=legs.get('roofline'), cpu_baseline=legs.get('cpu_baseline'))
+                for k in ('other_feature_dtype', 'forward_only', 'epoch_loop', 'epoch_loop_anet', 'rccl'):
+                    if legs.get(k) is not None:
+                        out[k] = legs[k]
+                out.update(extra or {})
+                print(json.dumps(out), flush=True)
+
+    deadline_s = float(os.environ.get('HUAL_BENCH_LEG_DEADLINE_S', '900'))
+
+    def cut_short():
+        emit(dict(legs_cut_short='the legs after the timed region did not finish within %.0f s; the line holds those that did' % deadline_s))
+        sys.stderr.write('[bench] rank %d: leg deadline reached, leaving\n' % rank)
+        sys.stderr.flush()
+        os._exit(0)
+    watchdog = threading.Timer(deadline_s, cut_short)
+    watchdog.daemon = True
+    watchdog.start()
+
     rccl = None
     if dp:
         # the step's one collective of size: all-reduce(sum) of the flat fp32 gradient bucket, timed on its own
@@ -542,6 +585,7 @@ def main():
             else:
                 rccl['custom_allreduce'] = dict(error=msg or 'setup failed on another rank')
         model.grads.zero_()
+    legs['rccl'] = rccl
     roof = None
     print('[bench] timed region done: %.3f ms/step' % (dt / args.steps * 1e3), file=sys.stderr, flush=True)
     if rank == 0 and not args.no_roofline:
@@ -678,6 +722,7 @@ def main():
                                  us_per_step=round(d['us'] / psteps, 1),
                                  tflops=round(d['flops'] / d['us'] / 1e6, 2) if d['flops'] > 0 else None,
                                  gbs=round(d['bytes'] / d['us'] / 1e3, 1) if d['bytes'] > 0 else None) for d in fam]
+    legs['roofline'] = roof
     print('[bench] roofline leg done', file=sys.stderr, flush=True)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -688,6 +733,7 @@ def main():
         except Exception as e:      # never cost the bench line
             cpu['gpu_at_cpu_shape'] = dict(error=str(e)[:200])
 
+    legs['cpu_baseline'] = cpu
     other_feed = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same step with the clip features held in HBM in the other element type (BASELINE configs[1] says bf16 features;
@@ -709,6 +755,7 @@ def main():
         except Exception as e:      # never cost the bench line
             other_feed = dict(error=str(e)[:200])
 
+    legs['other_feature_dtype'] = other_feed
     fwd_only = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the evaluation fetch set on its own (runner_utils.py:166: start / end index; all five fetches come out of the one pass), eager launches
@@ -729,6 +776,7 @@ def main():
         except Exception as e:      # never cost the bench line
             fwd_only = dict(error=str(e)[:200])
 
+    legs['forward_only'] = fwd_only
     epoch_loop, epoch_anet = None, None
     if not args.no_epoch_loop and (world == 1 or dp):
         # every rank runs these legs when the job is data parallel (collectives inside); rank 0 reports
@@ -741,35 +789,15 @@ def main():
             except Exception as e:      # never cost the bench line (every rank fails or passes together: the legs are collective)
                 return dict(error=str(e)[:300])
         epoch_loop = leg('epoch-loop', resident_ms=dt / args.steps * 1e3)
+        legs['epoch_loop'] = epoch_loop
         # the reference's own shape distributions (BASELINE configs[3], [4]: ActivityNet annotations): the YAML's batch 16 at
         # max_vlen 100, and configs[3]'s 32 clips per GPU at T <= 256
         epoch_anet = [leg('epoch-loop anet b16', resident_ms=None, kind='anet', bs=16, max_vlen=100, N=args.anet_samples, epochs=3),
                       leg('epoch-loop anet b32 T256', resident_ms=None, kind='anet', bs=32, max_vlen=256, N=args.anet_samples // 2, epochs=3)]
 
-    if rank == 0:
-        out = dict(metric='train clips/sec', value=round(clips / dt, 2), unit='clips/s', n_gpus=world, steps=args.steps,
-                   warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
-                   scaling='weak', vs_baseline=None, dtype='f32 (fp16x3 / bf16x3 split-operand MFMA, fp32 accumulate)', data='synthetic',
-                   config=dict(workload='Charades-STA SeqPAN train step (fwd+bwd+clip+AdamWD, dropout %.1f), batch %d/GPU, '
-                                        'T=%d, vdim=%d, L=%d, C=%d, dim=128, 8 heads, 2 attention layers, random init; ONE batch resident in '
-                                        'HBM, batch assembly (hual_assemble_batch) outside the timed region'
-                                        % (args.drop, args.batch, args.T, args.vdim, args.L, args.C),
-                               global_batch=args.batch * world, T=args.T, vdim=args.vdim, L=args.L,
-                               parallelism='dp%d' % world, launch='eager' if args.no_graph else 'hipGraph',
-                               video_dtype=args.video_dtype,
-                               final_loss=round(loss, 4)),
-                   roofline=roof, cpu_baseline=cpu)
-        if other_feed is not None:
-            out['other_feature_dtype'] = other_feed
-        if fwd_only is not None:
-            out['forward_only'] = fwd_only
-        if epoch_loop is not None:
-            out['epoch_loop'] = epoch_loop
-        if epoch_anet is not None:
-            out['epoch_loop_anet'] = epoch_anet
-        if rccl is not None:
-            out['rccl'] = rccl
-        print(json.dumps(out))
+    legs['epoch_loop_anet'] = epoch_anet
+    emit()
+    watchdog.cancel()
     if dp:
         torch.distributed.barrier()      # rank 0 ran the roofline leg alone: leave together
         torch.distributed.destroy_process_group()

@@ -139,6 +139,24 @@ def test_bench_multi_rank_path_on_one_rank(tmp_path):
         assert 'error' not in leg and leg['lengths_from'] == 'anet' and leg['step_launch_modes']['eager'] == leg['steps']
 
 
+def test_bench_line_survives_a_leg_that_does_not_finish():
+    """the legs after the timed region (roofline, CPU baseline, epoch loops, the all-reduce figures) run under a deadline: when it
+    passes, rank 0 prints the line with the legs that did finish and every rank leaves with exit code 0"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HUAL_BENCH_LEG_DEADLINE_S='2')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--batch', '8', '--T', '32', '--L', '8', '--C', '5', '--vdim', '256',
+                        '--steps', '4', '--warmup', '1', '--prewarm', '2'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['value'] > 0 and out['steps'] == 4 and 'legs_cut_short' in out      # (the CPU baseline alone takes ~20 s)
+    assert 'leg deadline reached' in r.stderr
+
+
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """bench.py --gpus 2 as TWO processes on the one GPU of the test box (HUAL_BENCH_ONE_DEVICE=1, collectives over gloo): the N > 1
     code path that a one-rank group cannot reach - the data-parallel step between two real ranks, the guarded one-shot all-reduce leg
