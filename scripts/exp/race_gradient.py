@@ -1,11 +1,12 @@
 """same process, second stream running our forward + backward: does the gradient bucket (before clipping) of the same batch change its
-bits under that load, and by how much?   dbg_step_race.py N"""
+bits under that load, and by how much?   race_gradient.py N [B T L C vdim max_vlen]"""
 import sys, os, threading, time
 import numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import parity_util as pu
-case = pu.make_case(B=16, T=64, L=20, C=8, seed=12345, max_vlen=64, vdim=256)
+sh = [int(x) for x in sys.argv[2:8]] if len(sys.argv) >= 8 else [16, 64, 20, 8, 256, 64]
+case = pu.make_case(B=sh[0], T=sh[1], L=sh[2], C=sh[3], seed=12345, max_vlen=sh[5], vdim=sh[4])
 cfg, p, wv, b, labels = case
 m = pu.hip_model(cfg, p, wv); m.ws_poison = None
 m2 = pu.hip_model(cfg, p, wv); m2.ws_poison = None
@@ -37,5 +38,5 @@ for it in range(n):
         nel.append(d); rel.append(float(np.abs(g - ref).max() / scale))
 stop = True; th.join()
 big = [(a, '%.1e' % r) for a, r in zip(nel, rel) if r > 1e-5]
-print('quiet: differing elements per run max %d (runs that differ: %d of 50); under a second stream running forward+backward: %d of %d differ; '
+print('shape B T L C vdim max_vlen = %s; ' % sh + 'quiet: differing elements per run max %d (runs that differ: %d of 50); under a second stream running forward+backward: %d of %d differ; '
       'of those with max |dg| > 1e-5 of the largest gradient: %d %s (bucket of %d)' % (max(q), sum(x > 0 for x in q), len(nel), n, len(big), big[:12], ref.size))
