@@ -504,7 +504,7 @@ def main():
                                        video_dtype=args.video_dtype,
                                        final_loss=round(loss, 4)),
                            roofline=legs.get('roofline'), cpu_baseline=legs.get('cpu_baseline'))
-                for k in ('other_feature_dtype', 'forward_only', 'epoch_loop', 'epoch_loop_anet', 'rccl'):
+                for k in ('other_feature_dtype', 'forward_only', 'host_fed', 'epoch_loop', 'epoch_loop_anet', 'rccl'):
                     if legs.get(k) is not None:
                         out[k] = legs[k]
                 out.update(extra or {})
@@ -777,6 +777,60 @@ def main():
             fwd_only = dict(error=str(e)[:200])
 
     legs['forward_only'] = fwd_only
+    host_fed = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # The PCIe-inclusive rate (never `value`): the same step fed from HOST batches the way the reference feeds it
+        # (runner_utils.py:141-147: a numpy batch per step through feed_dict), as hual_amd/feeder.py pipelines it - batch k + 1 uploads
+        # from pinned memory on a copy stream while step k runs.  `pinned`: the producer wrote the batch into the pinned slot itself
+        # (no host copy in the loop: what the device side can sustain); `pageable`: numpy arrays in pageable memory, staged by one
+        # memcpy per step on the calling thread (what a drop-in feed_dict caller gets).
+        try:
+            from hual_amd.feeder import HostFeeder
+            host_fed = dict(note='train step fed from host batches through pinned staging + one async upload per step (hual_amd/feeder.py); '
+                                 'PCIe-inclusive, not the bench value')
+            hb = dict(video=np.ascontiguousarray(b['video'], dtype=np.float32), video_seq_len=b['lens'], word_ids=b['word_ids'],
+                      char_ids=b['char_ids'], y1=b['y1'], y2=b['y2'], match_labels=b['match'], inner_labels=b['inner'])
+            for fdt, name in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
+                ht = Trainer(model, world=1, use_graph=not args.no_graph)
+                fd = HostFeeder(ht, capacity=(args.batch, args.T, args.L, args.C), vdim=args.vdim, video_dtype=fdt)
+                for _ in range(6):
+                    fd.feed(hb, 1e-4, args.drop)                     # fills both pinned slots, captures both slots' graphs
+                fd.collect()
+                nst = 300
+                t0 = time.perf_counter()
+                for _ in range(nst):
+                    fd.stage_views(args.batch, args.T, args.L, args.C)      # (the slot already holds the batch)
+                    fd.submit(1e-4, args.drop)
+                fd.collect()
+                d4 = time.perf_counter() - t0
+                nbytes = fd.stats['bytes_uploaded'] // fd.stats['batches']
+                # the upload on its own
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for _ in range(20):
+                    fd.dev[0][:nbytes].copy_(fd.host[0][:nbytes], non_blocking=True)
+                ev1.record()
+                torch.cuda.synchronize()
+                up_ms = ev0.elapsed_time(ev1) / 20
+                row = dict(ms_per_step=round(d4 / nst * 1e3, 4), value=round(args.batch * nst / d4, 1), unit='clips/s', steps=nst,
+                           upload_bytes_per_step=int(nbytes), upload_alone_ms=round(up_ms, 4),
+                           upload_gb_s=round(nbytes / up_ms / 1e6, 1), over_resident=round(d4 / nst / (dt / args.steps), 3))
+                if fdt == torch.float32:
+                    npg = 60
+                    t0 = time.perf_counter()
+                    for _ in range(npg):
+                        fd.feed(hb, 1e-4, args.drop)
+                    fd.collect()
+                    d5 = time.perf_counter() - t0
+                    row['pageable'] = dict(ms_per_step=round(d5 / npg * 1e3, 4), value=round(args.batch * npg / d5, 1), steps=npg,
+                                           note='numpy batch in pageable memory, staged into the pinned slot by 4 copy threads per step')
+                host_fed['pinned_' + name] = row
+                del fd, ht
+        except Exception as e:      # never cost the bench line
+            host_fed = dict(error=str(e)[:300])
+        model.grads.zero_()
+
+    legs['host_fed'] = host_fed
     epoch_loop, epoch_anet = None, None
     if not args.no_epoch_loop and (world == 1 or dp):
         # every rank runs these legs when the job is data parallel (collectives inside); rank 0 reports

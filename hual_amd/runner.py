@@ -31,12 +31,19 @@ from .train import Trainer
 
 class Runner:
     def __init__(self, configs, word_vectors, train_records, test_records, visual_feats, device='cuda:0', seed=12345,
-                 ckpt_dir=None, logger=None):
-        """configs: dict with the keys of configs/<task>/SeqPAN.yaml (+ num_chars, num_words like main.py:35-36)."""
+                 ckpt_dir=None, logger=None, feed='device'):
+        """configs: dict with the keys of configs/<task>/SeqPAN.yaml (+ num_chars, num_words like main.py:35-36).
+        feed='host': the training features stay in host memory and every batch is padded on the host and uploaded through the pinned
+        pipeline of hual_amd/feeder.py (the reference's own data path, for feature sets beyond the HBM); default: the training set
+        lives in HBM and batches are assembled there."""
+        assert feed in ('device', 'host')
         self.configs = configs
+        self.feed = feed
+        self._host_train = (train_records, visual_feats) if feed == 'host' else None
+        self._feeder = None
         # (same parameter seed on every rank of a data-parallel job, its own dropout stream per rank)
         self.model = SeqPAN(configs, word_vectors, device=device, seed=seed, rng_seed=seed + 1000003 * hdist.rank())
-        self.train_set = DeviceDataset(train_records, visual_feats, device=device)
+        self.train_set = DeviceDataset(train_records, visual_feats, device=device) if feed == 'device' else None
         self.test_set = DeviceDataset(test_records, visual_feats, device=device) if test_records else None
         self.batch_size = int(configs['train']['batch_size'])
         self.droprate = float(configs['train']['droprate'])
@@ -60,7 +67,42 @@ class Runner:
             out.append(al.calculate_iou([st, et], [gs, ge]))
         return out
 
+    def _train_epoch_host(self, cur_lr):
+        """runner_utils.train_epoch with the reference's own data path: process_batch on the host (hual_amd/data.py), one upload per
+        step behind the previous step (hual_amd/feeder.py)"""
+        from .feeder import HostFeeder
+        recs, feats = self._host_train
+        if self.world > 1:
+            raise lib.HualError('feed=\'host\' is single-process: the data-parallel loop shards the device-resident set (Trainer.run_epoch)')
+        N, bs = len(recs), self.batch_size
+        if self._feeder is None:
+            T = max(int(r['v_len']) for r in recs)
+            L = max(len(r['w_ids']) for r in recs)
+            C = max(4, max(len(w) for r in recs for w in r['c_ids']))
+            self._feeder = HostFeeder(self.trainer, capacity=(min(bs, N), T, L, C), vdim=int(next(iter(feats.values())).shape[1]))
+        order = list(range(N))
+        self.rand.shuffle(order)                                   # data_loader.py:24
+
+        def batches():
+            for lo in range(0, N, bs):
+                b = data.process_train_batch([recs[i] for i in order[lo:lo + bs]], feats)
+                if b['char_ids'].shape[2] < 4:                     # the char CNN's widest filter (modules.py:19-38) needs 4 characters
+                    b = data.pad_batch_to(b, b['video'].shape[1], b['word_ids'].shape[1], 4)
+                yield b
+        t0 = time.perf_counter()
+        spans = self._feeder.run_epoch(batches(), cur_lr, self.droprate)
+        self.clips_per_s = N / max(time.perf_counter() - t0, 1e-9)
+        st = np.concatenate([s for s, _ in spans])
+        en = np.concatenate([e for _, e in spans])
+        if (st < 0).any() or not np.isfinite(float(self.trainer.last_loss())):
+            raise lib.HualError('training diverged out of the split-fp16 operand range: %d clip(s) of this epoch came back with span -1 '
+                                '(loss %s).  Lower the learning rate or clip_norm; the last good checkpoint is %s'
+                                % (int((st < 0).sum()), float(self.trainer.last_loss()), os.path.join(self.ckpt_dir, 'best_SeqPAN.npz')))
+        return al.iou_metrics(self._ious([recs[i] for i in order], st, en))
+
     def train_epoch(self, cur_lr):
+        if self.feed == 'host':
+            return self._train_epoch_host(cur_lr)
         ds, N = self.train_set, len(self.train_set)
         order = list(range(N))
         self.rand.shuffle(order)                                   # data_loader.py:24
@@ -134,6 +176,8 @@ class Runner:
         if load_best:
             hdist.barrier()
             self.load(os.path.join(self.ckpt_dir, 'best_SeqPAN.npz'))
+        if self.train_set is None:          # feed='host': the inference pass works on a device-resident set, built on first use
+            self.train_set = DeviceDataset(*self._host_train, device=self.model.device)
         records, ious = al.infer_trainset_sharded(self.model, self.train_set, self.batch_size, mc_dropout=mc_dropout, min_chars=4)
         if self.rank != 0:
             return None, hdist.broadcast_object(None)

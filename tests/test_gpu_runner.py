@@ -72,3 +72,38 @@ def test_train_test_infer_and_checkpoint(tmp_path):
     recs, m = r.infer_trainset(path=str(tmp_path / 'results' / 're0.pkl'), mc_dropout=0.5)
     assert len(recs) == len(train) and os.path.exists(tmp_path / 'results' / 're0.pkl')
     assert recs[0]['prop_logits'][0].shape == recs[0]['prop_logits1'][0].shape
+
+
+def test_host_fed_runner_follows_the_device_fed_one(tmp_path):
+    """Runner(feed='host'): the reference's own data path (process_batch on the host, one upload per step: hual_amd/feeder.py) instead of
+    the HBM-resident set.  Same seeds, same epoch orders, no dropout: the first epoch's metrics are those of the device-fed runner (the
+    batches are the same arrays - test_gpu_al.py pins the device assembly to the loader bit for bit), and the task is learnt."""
+    from hual_amd.runner import Runner
+    vdim = 64
+    vis = _videos(24, vdim, 0)
+    train = _task(192, vis, 1)
+    test = _task(64, vis, 2)
+    cfg = dict(task='synth', train=dict(batch_size=32, droprate=0.0, lr=2e-3, epochs=8, clip_norm=1.0),
+               model=dict(vdim=vdim, dim=128, num_heads=8, word_dim=300, char_dim=50, max_vlen=32, attn_layer=2),
+               loss=dict(match_lambda=1.0, tau=0.3, no_gumbel=True), num_chars=10)
+    wv = np.random.default_rng(0).normal(0, 0.4, size=(40, 300)).astype(np.float32)
+
+    class L:
+        def info(self, s):
+            pass
+    rd = Runner(cfg, wv, train, test, vis, ckpt_dir=str(tmp_path / 'd'), logger=L())
+    rh = Runner(cfg, wv, train, test, vis, ckpt_dir=str(tmp_path / 'h'), logger=L(), feed='host')
+    assert rh.train_set is None
+    md, mh = rd.train_epoch(1e-4), rh.train_epoch(1e-4)            # six steps each, at a step size where 1e-7 of gradient noise stays noise
+    assert np.allclose(md, mh, atol=2.0), (md, mh)                 # (percent)
+    d = (rd.model.params - rh.model.params).abs()
+    # (two device-fed runs of this task agree on 93 % of the parameters by the same yardstick after these six steps, and on 4 % after twelve:
+    # scripts/exp/runner_feed_cmp.py - the bit-level equivalence of the two feeds is test_gpu_feeder.py's, at lr 0)
+    assert float((d <= 0.1 * 1e-4).float().mean()) >= 0.85, float((d <= 0.1 * 1e-4).float().mean())
+    before = rh.test_epoch()
+    rh.train(epochs=7)
+    after = rh.test_epoch()
+    assert after[3] > before[3] + 3.0, (before, after)
+    assert rh.clips_per_s > 0 and rh._feeder.stats['batches'] == 8 * 6
+    recs, m = rh.infer_trainset(mc_dropout=0.5)                    # builds the device-resident set on first use
+    assert len(recs) == len(train)
