@@ -32,7 +32,7 @@ n = len(spans)
 print('steps analysed %d: mean span %.1f us, kernel time %.1f us, idle %.1f us, kernels/step %.1f' % (n, sum(s[0] for s in spans) / n / 1e3, sum(s[1] for s in spans) / n / 1e3, sum(s[0] - s[1] for s in spans) / n / 1e3, sum(s[2] for s in spans) / n))
 for k, v in gaps.items():
     print('  idle %-45s %7.1f us/step' % (k, v / n / 1e3))
-for nm, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:12]:
+for nm, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:48]:
     print('%-62s x%6.2f/step %8.1f us/step (avg %6.2f)' % (nm, c / n, t / n / 1e3, t / c / 1e3))
 PY
 rm -rf $out/prof_erg
