@@ -41,6 +41,10 @@ class HostFeeder:
         staging_threads: feed() copies the clip features of a pageable batch into the pinned slot with that many threads (numpy's copy
         releases the GIL; one thread moves ~17 GB/s on the test box = 2 ms for the bench batch, longer than its train step)"""
         assert video_dtype in (torch.float32, torch.bfloat16) and depth >= 2
+        if trainer.dp:
+            # a data-parallel shard must be padded to the GLOBAL batch's shape with the global matching denominator (hual_amd/dist.py
+            # shard_plan); that loop exists for the device-resident set only (Trainer.run_epoch)
+            raise ValueError('HostFeeder is single-process: the data-parallel epoch loop shards the device-resident set (Trainer.run_epoch)')
         self._pool = None
         if staging_threads > 1:
             from concurrent.futures import ThreadPoolExecutor
@@ -125,7 +129,7 @@ class HostFeeder:
         L, C = np.shape(batch['word_ids'])[1], np.shape(batch['char_ids'])[2]
         if V != self.V:
             raise ValueError('feature width %d, feeder built for %d' % (V, self.V))
-        if int(np.max(batch['video_seq_len'])) != T and not self.tr.dp:
+        if int(np.max(batch['video_seq_len'])) != T:
             raise ValueError('video T must equal max(video_seq_len) - model.py:31')
         views = self.stage_views(B, T, L, C)
         for k in FEEDS:
