@@ -225,10 +225,15 @@ def compare(cfg, p, wv, b, labels, drop_rate=0.0, seed=5, offset=7, with_grads=T
         hg = m.grads_dict()
         for k, gref in o_grads.items():
             add('grad', k, torch.from_numpy(hg[k]), gref)
+            # the same tensor in the Euclidean norm: a max-norm gate alone would admit an error of the gate's size in EVERY element
+            dh = torch.from_numpy(hg[k]).double().reshape(-1) - gref.detach().double().cpu().reshape(-1)
+            GL2_SIZE[k] = dh.numel()
+            rows.append(('gl2', k, float(dh.norm()), float(gref.detach().double().norm())))
     return rows, idx_equal, o_out, h_out, m
 
 
 TOL = 1e-3              # north_star: outputs within 1e-3 fp32
+GL2_SIZE = {}           # elements per gradient tensor (the floor of the Euclidean gate scales with sqrt(n))
 
 
 def grad_scale(rows):
@@ -247,15 +252,17 @@ def row_ok(row, gmax, tol=TOL):
         return True
     if kind == 'grad':
         return d <= tol * max(r, 1e-3 * gmax)
+    if kind == 'gl2':       # ||d||_2 <= tol ||ref||_2, with the same floor per element as the max-norm gate
+        return d <= tol * max(r, 1e-3 * gmax * GL2_SIZE.get(name, 1) ** 0.5)
     return d <= tol or d <= tol * r
 
 
-def failures(rows, kinds=('tap', 'out', 'loss', 'grad'), tol=TOL):
+def failures(rows, kinds=('tap', 'out', 'loss', 'grad', 'gl2'), tol=TOL):
     gmax = grad_scale(rows)
     return [row for row in rows if row[0] in kinds and not row_ok(row, gmax, tol)]
 
 
-def assert_rows(rows, kinds=('tap', 'out', 'loss', 'grad'), tol=TOL):
+def assert_rows(rows, kinds=('tap', 'out', 'loss', 'grad', 'gl2'), tol=TOL):
     bad = failures(rows, kinds, tol)
     assert not bad, 'parity failures:\n' + format_report(bad, grad_scale(rows))
 

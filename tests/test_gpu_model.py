@@ -20,13 +20,13 @@ def test_forward_backward_parity_small(drop):
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=drop)
     _assert_rows(rows, ('tap', 'out', 'loss'))
     assert idx_equal
-    _assert_rows(rows, ('grad',))
+    _assert_rows(rows, ('grad', 'gl2'))
 
 
 def test_second_shape_with_dropout():
     case = pu.make_case(B=4, T=24, L=7, C=5, seed=21)
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2)
-    _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
+    _assert_rows(rows, ('tap', 'out', 'loss', 'grad', 'gl2'))
     assert idx_equal
 
 
@@ -34,7 +34,7 @@ def test_ragged_shapes_parity():
     # T, L not multiples of 16; C = 4 (minimum); one clip of length 1-ish neighbours
     case = pu.make_case(B=3, T=37, L=9, C=4, seed=11, max_vlen=40)
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.1)
-    _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
+    _assert_rows(rows, ('tap', 'out', 'loss', 'grad', 'gl2'))
     assert idx_equal
 
 
@@ -44,7 +44,7 @@ def test_bfloat16_video_feed_parity(shape):
     video_conv1d weight-gradient kernels read bfloat16 features; same graph on the same values in the oracle"""
     case = pu.make_case(**shape)
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2, video_bf16=True)
-    _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
+    _assert_rows(rows, ('tap', 'out', 'loss', 'grad', 'gl2'))
     assert idx_equal
 
 
@@ -52,7 +52,7 @@ def test_bfloat16_video_feed_any_width():
     """vdim 320 (not a multiple of 128: the feature-load launch ends on a partial weight block) with bfloat16 features"""
     case = pu.make_case(vdim=320)
     rows, idx_equal, o, h, m = pu.compare(*case, drop_rate=0.2, video_bf16=True)
-    _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
+    _assert_rows(rows, ('tap', 'out', 'loss', 'grad', 'gl2'))
     assert idx_equal
 
 
@@ -65,7 +65,7 @@ def test_gumbel_branch_of_the_matching_loss():
         cfg['no_gumbel'] = False
         cfg['tau'] = 0.3
         rows, idx_equal, o, h, m = pu.compare(cfg, p, wv, b, labels, drop_rate=rate)
-        _assert_rows(rows, ('tap', 'out', 'loss', 'grad'))
+        _assert_rows(rows, ('tap', 'out', 'loss', 'grad', 'gl2'))
         assert idx_equal
     # the noise changes the scores (the test would pass vacuously if the flag were ignored on both sides)
     cfg2, p2, wv2, b2, labels2 = pu.make_case(B=3, T=20, L=6, C=5, seed=11)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def _check(rows, idx_equal, kinds=('tap', 'out', 'loss', 'grad')):
+def _check(rows, idx_equal, kinds=('tap', 'out', 'loss', 'grad', 'gl2')):
     """parity_util.row_ok: forward tensors abs-or-rel 1e-3; every gradient tensor RELATIVE: d <= 1e-3 max(max|ref|, 1e-3 gmax)"""
     pu.assert_rows(rows, kinds, TOL)
     assert idx_equal
