@@ -61,7 +61,7 @@ def _check_isa(obj):
         bad = []
         for co in cos:
             dis = subprocess.run([OBJDUMP, '-d', co], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
-            bad += [l.strip() for l in dis.splitlines() if re.search(r'v_pk_(fma|mul|add)_f32 .*op_sel:\[', l)]
+            bad += [l.strip() for l in dis.splitlines() if re.search(r'v_pk_((fma|mul|add)_f32|mov_b32) .*op_sel:\[', l)]      # (v_pk_mov_b32: the same operand select; none in the library)
         if bad:
             raise RuntimeError('%s: %d packed-fp32 instructions with op_sel (low lane reads the high register), e.g. "%s": compile the file '
                                'with -packed-fp32-ops (FILE_FLAGS) or restate the arithmetic' % (os.path.basename(obj), len(bad), bad[0]))
