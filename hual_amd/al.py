@@ -99,10 +99,8 @@ def infer_trainset(model, batches, mc_dropout=None, batch_ids=None, rng=None):
             s1, e1, s2, e2 = s0, e0, s0, e0                     # as written: drop_rate never reaches the graph (F8)
         else:
             s1, e1, s2, e2 = (h.numpy().copy() for h in host[5:9])
+        ious.extend(ious_of_spans(raw, si, ei))
         for i, r in enumerate(raw):
-            st, et = data.index_to_time([int(si[i]), int(ei[i])], r['v_len'], r['duration'])
-            gs, ge = data.index_to_time([r['s_ind'], r['e_ind']], r['v_len'], r['duration'])
-            ious.append(calculate_iou([st, et], [gs, ge]))
             records.append({'vid': r['vid'], 'duration': r['duration'], 'psuedo_idx': [r['s_ind'], r['e_ind']],
                             'sentence': ' '.join(r['words']), 'v_len': int(r['v_len']),
                             'prop_idx': [int(si[i]), int(ei[i])], 'prop_logits': [s0[i], e0[i]],
@@ -161,6 +159,35 @@ def calculate_iou(i0, i1):
     union = (min(i0[0], i1[0]), max(i0[1], i1[1]))
     inter = (max(i0[0], i1[0]), min(i0[1], i1[1]))
     return max(0.0, 1.0 * (inter[1] - inter[0]) / (union[1] - union[0]))
+
+
+def ious_of_spans(records, sidx, eidx):
+    """IoU of the predicted spans against the records' own (s_ind, e_ind), both through index_to_time (data_utils.py:121-128) and
+    calculate_iou (runner_utils.py:34-38): the per-sample loop of runner_utils.py:149-156 for a whole list at once, in the reference's
+    own arithmetic (float32 unit grid times, float32 ratio).  Equal to the scalar functions element for element
+    (tests/test_data_golden.py)."""
+    n = len(records)
+    if n == 0:
+        return []
+    f32 = np.float32
+    vl = np.array([r['v_len'] for r in records], dtype=f32)
+    du = np.array([float(r['duration']) for r in records], dtype=f32)
+    gs = np.array([r['s_ind'] for r in records], dtype=np.int64)
+    ge = np.array([r['e_ind'] for r in records], dtype=np.int64)
+    ps = np.asarray(sidx, dtype=np.int64)[:n]
+    pe = np.asarray(eidx, dtype=np.int64)[:n]
+
+    def t0(i):      # s_times[i] = float32(i) * duration / num_units
+        return i.astype(f32) * du / vl
+
+    def t1(i):      # e_times[i] = float32(i + 1) * duration / num_units
+        return (i + 1).astype(f32) * du / vl
+    st, et, g0, g1 = t0(ps), t1(pe), t0(gs), t1(ge)
+    union = np.maximum(et, g1) - np.minimum(st, g0)
+    inter = np.minimum(et, g1) - np.maximum(st, g0)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iou = inter / union
+    return np.where(iou > 0, iou, f32(0.0)).tolist()
 
 
 def iou_metrics(ious):

@@ -147,6 +147,49 @@ class HostFeeder:
                 np.copyto(views[k], np.asarray(src), casting='same_kind' if views[k].dtype.kind == 'f' else 'unsafe')
         self.submit(lr, drop_rate)
 
+    def feed_records(self, records, visual_feats, lr, drop_rate, min_chars=4):
+        """one batch straight from the loader's INPUTS (data_loader.py:30-98: records with vid / w_ids / c_ids / s_ind / e_ind and the
+        {vid: float32 [n, V]} features): padded directly into the pinned slot - no intermediate batch, no staging copy; the clips are
+        copied by the staging threads.  float32 feed only."""
+        from . import data
+        if self.vdt != torch.float32:
+            return self.feed(data.process_train_batch(records, visual_feats), lr, drop_rate)
+        feats = [visual_feats[r['vid']] for r in records]
+        B = len(records)
+        lens = np.array([f.shape[0] for f in feats], dtype=np.int32)
+        T = int(lens.max())
+        L = max(len(r['w_ids']) for r in records)
+        C = max(int(min_chars), max(len(w) for r in records for w in r['c_ids']))
+        if feats[0].shape[1] != self.V:
+            raise ValueError('feature width %d, feeder built for %d' % (feats[0].shape[1], self.V))
+        v = self.stage_views(B, T, L, C)
+        video = v['video']
+
+        def fill(ab):
+            for b in range(ab[0], ab[1]):
+                n = int(lens[b])
+                video[b, :n] = feats[b]
+                video[b, n:] = 0.0
+        if self._pool is not None and B >= self._nthr:
+            cuts = [B * i // self._nthr for i in range(self._nthr + 1)]
+            list(self._pool.map(fill, zip(cuts[:-1], cuts[1:])))
+        else:
+            fill((0, B))
+        v['video_seq_len'][:] = lens
+        w, c = v['word_ids'], v['char_ids']
+        w[...] = 0
+        c[...] = 0
+        for b, r in enumerate(records):
+            w[b, :len(r['w_ids'])] = r['w_ids']
+            for l, cw in enumerate(r['c_ids']):
+                c[b, l, :len(cw)] = cw
+        y1, y2, match, inner = data.make_labels([r['s_ind'] for r in records], [r['e_ind'] for r in records], lens)
+        v['y1'][...] = y1
+        v['y2'][...] = y2
+        v['match_labels'][...] = match
+        v['inner_labels'][...] = inner
+        self.submit(lr, drop_rate)
+
     def collect(self):
         """wait for the submitted steps and return the predicted (start, end) indices of every step since the last collect() as numpy
         arrays - the ONE synchronisation of a host-fed epoch"""

@@ -60,12 +60,7 @@ class Runner:
     # ------------------------------------------------------------------ runner_utils.train_epoch (:139-159)
     @staticmethod
     def _ious(records, sidx, eidx):
-        out = []
-        for r, s, e in zip(records, sidx, eidx):
-            st, et = data.index_to_time([int(s), int(e)], r['v_len'], r['duration'])
-            gs, ge = data.index_to_time([r['s_ind'], r['e_ind']], r['v_len'], r['duration'])
-            out.append(al.calculate_iou([st, et], [gs, ge]))
-        return out
+        return al.ious_of_spans(records, sidx, eidx)
 
     def _train_epoch_host(self, cur_lr):
         """runner_utils.train_epoch with the reference's own data path: process_batch on the host (hual_amd/data.py), one upload per
@@ -83,14 +78,12 @@ class Runner:
         order = list(range(N))
         self.rand.shuffle(order)                                   # data_loader.py:24
 
-        def batches():
-            for lo in range(0, N, bs):
-                b = data.process_train_batch([recs[i] for i in order[lo:lo + bs]], feats)
-                if b['char_ids'].shape[2] < 4:                     # the char CNN's widest filter (modules.py:19-38) needs 4 characters
-                    b = data.pad_batch_to(b, b['video'].shape[1], b['word_ids'].shape[1], 4)
-                yield b
         t0 = time.perf_counter()
-        spans = self._feeder.run_epoch(batches(), cur_lr, self.droprate)
+        # every batch is padded straight into a pinned slot (HostFeeder.feed_records: process_batch without the intermediate arrays; words
+        # padded to >= 4 characters - the char CNN's widest filter, modules.py:19-38) while the device runs the previous step
+        for lo in range(0, N, bs):
+            self._feeder.feed_records([recs[i] for i in order[lo:lo + bs]], feats, cur_lr, self.droprate, min_chars=4)
+        spans = self._feeder.collect()
         self.clips_per_s = N / max(time.perf_counter() - t0, 1e-9)
         st = np.concatenate([s for s, _ in spans])
         en = np.concatenate([e for _, e in spans])

@@ -62,3 +62,27 @@ def test_time_index_and_sampling(golden_dir):
         np.testing.assert_array_equal(out, g['samp%d_out' % k])
         k += 1
     assert k == 5
+
+
+def test_batched_iou_bookkeeping_equals_the_scalar_functions():
+    """al.ious_of_spans (one numpy pass per batch / epoch) against the per-sample path it replaced: data.index_to_time (pinned above to
+    data_utils.py:121-128 by the fixture) + calculate_iou (runner_utils.py:34-38), value for value"""
+    from hual_amd import al
+    g = np.random.default_rng(11)
+    recs, ps, pe = [], [], []
+    for _ in range(3000):
+        n = int(g.integers(2, 257))
+        dur = float(np.round(g.uniform(1.0, 400.0), int(g.integers(0, 7))))
+        s = int(g.integers(0, n)); e = int(g.integers(s, n))
+        recs.append(dict(v_len=n, duration=dur, s_ind=s, e_ind=e))
+        a = int(g.integers(0, n)); b = int(g.integers(0, n))            # predictions may have end < start (argmax of an outer product does not, but the formula must agree anyway)
+        ps.append(a); pe.append(b)
+    want = []
+    for r, a, b in zip(recs, ps, pe):
+        st, et = data.index_to_time([a, b], r['v_len'], r['duration'])
+        gs, ge = data.index_to_time([r['s_ind'], r['e_ind']], r['v_len'], r['duration'])
+        want.append(float(al.calculate_iou([st, et], [gs, ge])))
+    got = al.ious_of_spans(recs, np.array(ps), np.array(pe))
+    assert got == want
+    assert al.iou_metrics(got) == al.iou_metrics(want)
+    assert al.ious_of_spans([], [], []) == []

@@ -124,3 +124,40 @@ def test_producer_writes_into_the_pinned_slot_and_errors_are_loud():
     short = dict(batches[0]); short['video_seq_len'] = short['video_seq_len'] - 1
     with pytest.raises(ValueError, match='max\\(video_seq_len\\)'):
         fd.feed(short, 0.0, 0.0)
+
+
+def test_records_padded_straight_into_the_pinned_slot_equal_the_loader_batch():
+    """HostFeeder.feed_records (the loader's padding written into pinned memory by the staging threads) against
+    feed(process_train_batch(...)) - the restated loader, pinned to the reference's by tests/golden/labels.npz: same spans, same logits"""
+    import al_synth
+    from hual_amd import data, lib
+    from hual_amd.feeder import HostFeeder
+    from hual_amd.model import SeqPAN
+    from hual_amd.train import Trainer
+    recs, vis, data_gt, _ = al_synth.make_trainset(40, 10, 64, 24, seed=8)
+    for r, g in zip(recs, data_gt):
+        r['s_ind'], r['e_ind'] = (int(x) for x in data.time_to_index(g[2][0], g[2][1], r['v_len'], r['duration']))
+    cfg = lib.make_cfg(vdim=64, max_vlen=24, num_words=200, num_chars=30)
+    wv = np.random.default_rng(1).normal(0, 0.4, size=(198, 300)).astype(np.float32)
+    cap = (8, 24, max(len(r['w_ids']) for r in recs), 8)
+    out = []
+    for mode in ('batch', 'records'):
+        m = SeqPAN(cfg, wv)
+        tr = Trainer(m, world=1, use_graph=True)
+        fd = HostFeeder(tr, capacity=cap, vdim=64)
+        logits = []
+        for lo in range(0, 40, 8):
+            if mode == 'batch':
+                b = data.process_train_batch(recs[lo:lo + 8], vis)
+                if b['char_ids'].shape[2] < 4:
+                    b = data.pad_batch_to(b, b['video'].shape[1], b['word_ids'].shape[1], 4)
+                fd.feed(b, 0.0, 0.0)
+            else:
+                fd.feed_records(recs[lo:lo + 8], vis, 0.0, 0.0)
+            logits.append(tr.start_logits.clone())
+        out.append((fd.collect(), [x.cpu().numpy() for x in logits]))
+    for (sa, ea), (sb, eb) in zip(out[0][0], out[1][0]):
+        np.testing.assert_array_equal(sa, sb)
+        np.testing.assert_array_equal(ea, eb)
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_array_equal(a, b)

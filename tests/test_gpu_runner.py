@@ -94,16 +94,16 @@ def test_host_fed_runner_follows_the_device_fed_one(tmp_path):
     rd = Runner(cfg, wv, train, test, vis, ckpt_dir=str(tmp_path / 'd'), logger=L())
     rh = Runner(cfg, wv, train, test, vis, ckpt_dir=str(tmp_path / 'h'), logger=L(), feed='host')
     assert rh.train_set is None
+    before = rh.test_epoch()                                       # untrained
     md, mh = rd.train_epoch(1e-4), rh.train_epoch(1e-4)            # six steps each, at a step size where 1e-7 of gradient noise stays noise
     assert np.allclose(md, mh, atol=2.0), (md, mh)                 # (percent)
     d = (rd.model.params - rh.model.params).abs()
     # (two device-fed runs of this task agree on 93 % of the parameters by the same yardstick after these six steps, and on 4 % after twelve:
     # scripts/exp/runner_feed_cmp.py - the bit-level equivalence of the two feeds is test_gpu_feeder.py's, at lr 0)
     assert float((d <= 0.1 * 1e-4).float().mean()) >= 0.85, float((d <= 0.1 * 1e-4).float().mean())
-    before = rh.test_epoch()
-    rh.train(epochs=7)
+    rh.train(epochs=8)
     after = rh.test_epoch()
-    assert after[3] > before[3] + 3.0, (before, after)
-    assert rh.clips_per_s > 0 and rh._feeder.stats['batches'] == 8 * 6
+    assert after[3] > before[3] + 3.0, (before, after)             # (the margin of the device-fed test above: +9 .. +25 points over 400 runs)
+    assert rh.clips_per_s > 0 and rh._feeder.stats['batches'] == 9 * 6
     recs, m = rh.infer_trainset(mc_dropout=0.5)                    # builds the device-resident set on first use
     assert len(recs) == len(train)
