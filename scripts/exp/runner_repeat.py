@@ -7,6 +7,7 @@ import numpy as np
 import test_gpu_runner as tr
 from hual_amd.runner import Runner
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+feed = sys.argv[2] if len(sys.argv) > 2 else 'device'
 bad = 0
 for i in range(n):
     vdim = 64
@@ -15,12 +16,17 @@ for i in range(n):
                model=dict(vdim=vdim, dim=128, num_heads=8, word_dim=300, char_dim=50, max_vlen=32, attn_layer=2),
                loss=dict(match_lambda=1.0, tau=0.3, no_gumbel=True), num_chars=10)
     wv = np.random.default_rng(0).normal(0, 0.4, size=(40, 300)).astype(np.float32)
+    tests_ = []
     class L:
-        def info(self, s): pass
+        def info(self, s):
+            for l in str(s).splitlines():
+                if l.startswith('TEST:'): tests_.append(float(l.split('\t')[4]))
     with tempfile.TemporaryDirectory() as d:
-        r = Runner(cfg, wv, train, test, vis, ckpt_dir=str(pathlib.Path(d) / 'ckpt'), logger=L())
+        r = Runner(cfg, wv, train, test, vis, ckpt_dir=str(pathlib.Path(d) / 'ckpt'), logger=L(), feed=feed)
         before = r.test_epoch(); r.train(); after = r.test_epoch()
     ok = after[3] > before[3] + 3.0
+    best_gain = max(tests_) - before[3]
+    gains = globals().setdefault('gains', []); gains.append(best_gain)
     bad += 0 if ok else 1
     print(i, 'before mIoU %.2f after %.2f %s' % (before[3], after[3], '' if ok else '  <<<< MISS'), flush=True)
-print('misses', bad, 'of', n)
+print('feed', feed, 'misses', bad, 'of', n, '| best-epoch test mIoU gain: min %.1f p1 %.1f median %.1f' % (min(gains), np.percentile(gains, 1), np.median(gains)))
