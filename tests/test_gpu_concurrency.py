@@ -1,6 +1,6 @@
 """GPU: the hot path's results do not depend on what else runs on the GPU.  Round 6 found the matching head's packed-fp32 arithmetic
 (v_pk_mul/fma_f32 whose op_sel makes the low lane read the high source register) losing terms in lanes 48-63 whenever a second queue ran
-our kernels beside it - 12 % of forwards with a second stream in the process, never alone - which is what made the two-ranks-on-one-GPU
+matrix-core kernels beside it (scripts/exp/opsel_repro.hip) - 12 % of forwards with a second stream in the process, never alone - which is what made the two-ranks-on-one-GPU
 tests flaky; hual_amd/build.py compiles heads.hip without packed fp32 and refuses the instruction form everywhere
 (profiles/r6_packed_fp32_opsel.txt).  These tests run the forward / the gradient under exactly that load."""
 import threading
