@@ -88,3 +88,54 @@ def test_gradient_does_not_change_under_a_second_stream():
         worst = max(float(np.abs(one() - ref).max()) for _ in range(150)) / scale
     assert quiet <= 2e-6, quiet
     assert worst <= 2e-6, worst
+
+
+def _mfma_corunner(tmp_path):
+    """the strongest trigger of the finding as a co-runner: back-to-back matrix instructions on a second stream (tests/aux/co_mfma.hip, compiled here -
+    a few seconds; None when no hipcc is at hand)"""
+    import ctypes
+    import os
+    import subprocess
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'aux', 'co_mfma.hip')
+    so = str(tmp_path / 'co_mfma.so')
+    if not os.path.exists(hipcc):
+        return None
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', '-o', so, src], capture_output=True, text=True)
+    if r.returncode != 0:
+        return None
+    co = ctypes.CDLL(so)
+    co.co_mfma_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    sink = torch.zeros(16, device='cuda')
+
+    def launch():
+        s = torch.cuda.current_stream()
+        assert co.co_mfma_launch(ctypes.c_void_p(s.cuda_stream), ctypes.c_void_p(sink.data_ptr()), 1024, 3000) == 0
+    return launch
+
+
+def test_forward_and_gradient_beside_a_matrix_instruction_loop(tmp_path):
+    """a library built WITH the refused instructions gets 88 % of its forwards wrong beside this co-runner (profiles/r6_packed_fp32_opsel.txt,
+    scripts/exp/race_mfma_soak.py); the shipped one none"""
+    load = _mfma_corunner(tmp_path)
+    if load is None:
+        pytest.skip('no hipcc to build the co-runner')
+    m, _, dv, lab = _models()
+
+    def fwd():
+        o = m.forward(*dv, drop_rate=0.0)
+        torch.cuda.synchronize()
+        return [o[k].cpu().numpy().copy() for k in ('start_logits', 'end_logits', 'match_scores', 'start_index', 'end_index')]
+
+    def grad():
+        m.forward(*dv, drop_rate=0.0, labels=lab)
+        m.backward()
+        torch.cuda.synchronize()
+        return m.grads.detach().cpu().numpy().copy()
+    ref, g0 = fwd(), grad()
+    scale = float(np.abs(g0).max())
+    with _Load(load):
+        bad = sum(any(not np.array_equal(a, b) for a, b in zip(ref, fwd())) for _ in range(300))
+        worst = max(float(np.abs(grad() - g0).max()) for _ in range(100)) / scale
+    assert bad == 0, '%d of 300 forwards changed their bits beside the matrix-instruction loop' % bad
+    assert worst <= 2e-6, worst
