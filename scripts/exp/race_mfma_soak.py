@@ -1,5 +1,5 @@
 """shared-GPU soak with the strongest trigger of the round-6 finding: a second stream runs back-to-back matrix instructions (build_exp/co_mfma.so,
-tests/aux/co_mfma.hip) while the forward / the gradient / the whole train step / the active-learning scoring run.   race_mfma_soak.py N"""
+tests/aux/co_mfma.hip) while the forward / the gradient / the whole train step / the active-learning scoring run.   race_mfma_soak.py N [B T L C vdim max_vlen]"""
 import sys, os, threading, time, ctypes
 import numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,9 @@ co = ctypes.CDLL(os.path.join(R, 'build_exp', 'co_mfma.so'))
 co.co_mfma_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 sink = torch.zeros(16, device='cuda')
 n = int(sys.argv[1])
-cfg, p, wv, b, labels = pu.make_case(B=16, T=64, L=20, C=8, seed=12345, max_vlen=64, vdim=256)
+sh = [int(x) for x in sys.argv[2:8]] if len(sys.argv) >= 8 else [16, 64, 20, 8, 256, 64]      # B T L C vdim max_vlen
+print('shape B T L C vdim max_vlen =', sh, flush=True)
+cfg, p, wv, b, labels = pu.make_case(B=sh[0], T=sh[1], L=sh[2], C=sh[3], seed=12345, max_vlen=sh[5], vdim=sh[4])
 m = pu.hip_model(cfg, p, wv); m.ws_poison = None
 dv = [torch.as_tensor(x).cuda() for x in (b['video'].numpy(), b['lens'].numpy(), b['word_ids'].numpy(), b['char_ids'].numpy())]
 lab = [torch.as_tensor(x.numpy()).cuda() for x in labels]
