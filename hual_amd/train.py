@@ -378,7 +378,9 @@ class Trainer:
                     t.copy_(s)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: a capture must not make other threads' HIP calls illegal (a loader thread that synchronises its own stream
+                # would fail AND invalidate the capture in the default global mode); the capturing thread itself only launches kernels
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._enqueue_single(drop_rate)
                 self.graph, self.graph_drop = g, drop_rate
             self.graph.replay()
@@ -427,7 +429,7 @@ class Trainer:
         cs.wait_stream(cur)
         err = None
         with torch.cuda.stream(cs):
-            g.capture_begin()
+            g.capture_begin(capture_error_mode='thread_local')      # (other threads stay free to use the GPU: see step())
             try:
                 self._enqueue_single(drop_rate)
             except BaseException as ex:          # our own launch failed under capture: end the capture, keep THIS error

@@ -139,3 +139,34 @@ def test_forward_and_gradient_beside_a_matrix_instruction_loop(tmp_path):
         worst = max(float(np.abs(grad() - g0).max()) for _ in range(100)) / scale
     assert bad == 0, '%d of 300 forwards changed their bits beside the matrix-instruction loop' % bad
     assert worst <= 2e-6, worst
+
+
+def test_step_graphs_are_captured_while_another_thread_uses_the_gpu():
+    """Trainer captures its step graphs in thread_local mode: a second thread that launches and SYNCHRONISES on its own stream (a loader, another
+    model) neither fails nor invalidates the capture (in the default global mode its synchronise raises 'operation not permitted when stream
+    is capturing' and the capture dies) - resident-batch graph and per-shape graphs of the device-fed mode"""
+    from hual_amd.train import Trainer
+    cfg, p, wv, b, labels = pu.make_case(B=4, T=18, L=6, C=5, seed=33, max_vlen=24, vdim=64)
+    m = pu.hip_model(cfg, p, wv)
+    x = torch.randn(256, 256, device='cuda')
+
+    def other():
+        (x @ x).sum()
+        torch.cuda.current_stream().synchronize()
+    feeds = [np.asarray(t.numpy()) for t in (b['video'], b['lens'], b['word_ids'], b['char_ids'])] + [t.numpy() for t in labels]
+    with _Load(other):
+        for rep in range(6):                       # every repetition captures anew
+            tr = Trainer(m, world=1, use_graph=True)
+            tr.set_batch(*feeds)
+            for _ in range(3):
+                tr.step(lr=1e-4, drop_rate=0.1)
+            assert tr.graph is not None
+            dev = dict(video=tr.video, video_seq_len=tr.lens, word_ids=tr.word_ids, char_ids=tr.char_ids, y1=tr.y1, y2=tr.y2,
+                       match_labels=tr.match, inner_labels=tr.inner)
+            td = Trainer(m, world=1, use_graph=True)
+            for _ in range(4):
+                td.set_batch_device(dev)
+                td.step(lr=1e-4, drop_rate=0.1)
+            assert td.stats['captured'] == 1 and td.stats['capture_failed'] == 0 and td.stats['replayed'] >= 1, td.stats
+    torch.cuda.synchronize()
+    assert torch.isfinite(m.params).all()
