@@ -128,6 +128,9 @@ def relu_pins(m, B, T, L):
             pin['fe%d' % ps].append(m.tap_bits('fe%d.rb%d' % (ps, i)).reshape(B, T, -1))
     pin['head.hs'] = (m.tap('head.hs').cpu() > 0).reshape(B, T, -1)
     pin['head.he'] = (m.tap('head.he').cpu() > 0).reshape(B, T, -1)
+    # the window every (word, channel) unit of the char CNN took its maximum from (-1: the relu floor), int32 [Nq, 100] in the workspace
+    off, rows, cols = m._ws_table['char_arg']
+    pin['char.arg'] = m._ws[off:off + rows * cols * 4].view(torch.int32).cpu().reshape(B, L, cols).clone()
     return pin
 
 
@@ -171,7 +174,33 @@ def audit_pins(o_tap, pins):
             sites.append(('fe%d.z%d' % (ps, i), o_tap['fe%d.z%d' % (ps, i)], pins['fe%d' % ps][i]))
     sites.append(('head.zs', o_tap['head.zs'], pins['head.hs']))
     sites.append(('head.ze', o_tap['head.ze'], pins['head.he']))
-    return assert_pins_ok(sites)
+    n, total = assert_pins_ok(sites)
+    nc, tc = audit_char_pins(o_tap, pins)
+    return n + nc, total + tc
+
+
+def audit_char_pins(o_tap, pins):
+    """The char CNN's max over the characters (modules.py:33-36): the pinned window of a unit must carry the oracle's OWN maximum to within
+    rounding - |max_p relu(z_p) - relu-gated z_pin| <= PIN_Z_TOL max|z| - and only a rounding-level share of the units may take their value
+    from another window than the oracle's at all (windows of equal value, e.g. all-padding ones, do not count: the value and every gradient
+    are the same).  A unit the kernels pool wrongly shows up with a difference of ordinary size."""
+    if 'char.arg' not in pins or 'char.z0' not in o_tap:
+        return 0, 0
+    n = total = c0 = 0
+    for i in range(4):
+        z = o_tap['char.z%d' % i].detach().double()                      # [B, ch, L, P]
+        ch = z.shape[1]
+        a = pins['char.arg'][:, :, c0:c0 + ch].permute(0, 2, 1).long()
+        c0 += ch
+        own = torch.relu(z).max(dim=3).values
+        got = torch.gather(z, 3, a.clamp_min(0).unsqueeze(-1)).squeeze(-1) * (a >= 0).to(z.dtype)
+        d = (own - got).abs()
+        worst = float(d.max() / z.abs().max())
+        assert worst <= PIN_Z_TOL, 'char max-pool pin: a unit of filter %d takes a window %.2e max|z| below the oracle\'s maximum' % (i, worst)
+        n += int((d > 0).sum())
+        total += d.numel()
+    assert n <= max(1, PIN_FRAC_TOL * total), 'char max-pool pins differ from the oracle at %d of %d units' % (n, total)
+    return n, total
 
 
 def compare(cfg, p, wv, b, labels, drop_rate=0.0, seed=5, offset=7, with_grads=True, device='cuda:0', pin_relu=True,
