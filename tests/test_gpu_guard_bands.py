@@ -87,3 +87,44 @@ def test_no_write_outside_the_callers_buffers(shape):
         torch.cuda.synchronize(); ar.check('clip + AdamWD')
         assert torch.isfinite(o['loss']).all()
     assert torch.isfinite(m.params).all() and int(outs['start_index'].min()) >= 0
+
+
+def test_batch_assembly_stays_inside_its_feed_tensors():
+    """hual_assemble_batch / hual_assemble_batch_cursor (the loaders' process_batch on the device) into feed tensors of EXACTLY the batch's padded
+    shape, guard bands around each: nothing outside is touched, and the contents equal an assembly into ordinary tensors"""
+    import al_synth
+    from hual_amd import al
+    from hual_amd.dataset import DeviceDataset
+    recs, vis, data_gt, _ = al_synth.make_trainset(60, 12, 96, 40, seed=4, max_words=17)
+    ds = DeviceDataset(recs, vis)
+    s0, e0 = al.labels_from_times(data_gt, ds.vlen_h)
+    ds.set_labels(s0, e0)
+    g = np.random.default_rng(2)
+    f32, i32 = torch.float32, torch.int32
+    for rep in range(6):
+        sel = g.choice(60, size=int(g.integers(1, 9)), replace=False).astype(np.int32)
+        B = len(sel)
+        T, L, C = ds.batch_shape(sel)
+        C = max(C, 4)
+        ar = Arena(12 * (GUARD + 512) + B * T * 96 * 4 + B * L * (C + 1) * 4 + 5 * B * T * 4 + 65536, ds.dev)
+        out = dict(video=ar.take(B * T * 96 * 4, f32, (B, T, 96)), video_seq_len=ar.take(B * 4, i32, (B,)), word_ids=ar.take(B * L * 4, i32, (B, L)),
+                   char_ids=ar.take(B * L * C * 4, i32, (B, L, C)), sel=ar.take(B * 4, i32, (B,)), y1=ar.take(B * T * 4, f32, (B, T)),
+                   y2=ar.take(B * T * 4, f32, (B, T)), match_labels=ar.take(B * T * 4, i32, (B, T)), inner_labels=ar.take(B * T * 4, f32, (B, T)))
+        got = ds.assemble(sel, out=out, min_chars=4)
+        torch.cuda.synchronize()
+        ar.check('hual_assemble_batch, batch %s' % (sel.tolist(),))
+        ref = ds.assemble(sel, min_chars=4)
+        for k in ('video', 'video_seq_len', 'word_ids', 'char_ids', 'y1', 'y2', 'match_labels', 'inner_labels'):
+            assert got[k].data_ptr() == out[k].data_ptr() and torch.equal(got[k], ref[k]), k
+        # the cursor form: the same batch as ids[2 .. 2 + B) of a device-side list
+        ids = torch.zeros(2 + B + 3, dtype=i32, device=ds.dev)
+        ids[2:2 + B] = torch.from_numpy(sel).to(ds.dev)
+        cursor = torch.tensor([2, 0], dtype=torch.int64, device=ds.dev)
+        for k in out:
+            if k != 'sel':
+                out[k].fill_(7)
+        ds.enqueue_assemble_cursor({k: v for k, v in out.items() if k != 'sel'}, ids, cursor)
+        torch.cuda.synchronize()
+        ar.check('hual_assemble_batch_cursor, batch %s' % (sel.tolist(),))
+        for k in ('video', 'video_seq_len', 'word_ids', 'char_ids', 'y1', 'y2', 'match_labels', 'inner_labels'):
+            assert torch.equal(out[k], ref[k]), k
