@@ -39,11 +39,18 @@ SHAPES = [dict(B=3, T=20, L=6, C=5, vdim=64, max_vlen=32), dict(B=5, T=131, L=33
           dict(B=7, T=17, L=3, C=4, vdim=64, max_vlen=32), dict(B=4, T=65, L=40, C=22, vdim=64, max_vlen=128), dict(B=1, T=5, L=3, C=4, vdim=64, max_vlen=16)]
 
 
+@pytest.mark.parametrize('variant', ['f32', 'bf16 feed', 'gumbel'])
 @pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'B%d_T%d_L%d_C%d' % (s['B'], s['T'], s['L'], s['C']))
-def test_no_write_outside_the_callers_buffers(shape):
+def test_no_write_outside_the_callers_buffers(shape, variant):
+    if variant != 'f32' and shape is not SHAPES[1] and shape is not SHAPES[3]:
+        pytest.skip('the feed / loss variants run at two shapes')
     cfg, p, wv, b, labels = pu.make_case(seed=9, **shape)
+    if variant == 'gumbel':
+        cfg['no_gumbel'] = False          # loss.no_gumbel false: gumbel noise in the matching head (layers.py:163-166)
+        cfg['tau'] = 0.3
     m = pu.hip_model(cfg, p, wv)
     B, T, L, C, V = shape['B'], shape['T'], shape['L'], shape['C'], shape['vdim']
+    vdt, vb = (torch.bfloat16, 2) if variant == 'bf16 feed' else (torch.float32, 4)
     need = lib.query_workspace(m.cfg, B, T, L, C)                 # exactly what the ABI asks for: no slack
     n = m.params.numel()
     total = 25 * (GUARD + 512) + need + 4 * n * 4 + B * T * V * 4 + B * L * (C + 1) * 4 + 8 * B * T * 4 + 4096
@@ -57,7 +64,7 @@ def test_no_write_outside_the_callers_buffers(shape):
     assert m._ws.data_ptr() % 256 == 0
     m._ws_need[(B, T, L, C)] = need
     m._ws_tables[(B, T, L, C)] = lib.ws_table(m.cfg, B, T, L, C)
-    video = ar.take(B * T * V * 4, f32, (B, T, V)); video.copy_(b['video'])
+    video = ar.take(B * T * V * vb, vdt, (B, T, V)); video.copy_(b['video'])      # (bfloat16: hual_batch.video_dtype, exactly half the bytes)
     lens = ar.take(B * 4, i32, (B,)); lens.copy_(b['lens'])
     words = ar.take(B * L * 4, i32, (B, L)); words.copy_(b['word_ids'])
     chars = ar.take(B * L * C * 4, i32, (B, L, C)); chars.copy_(b['char_ids'])
