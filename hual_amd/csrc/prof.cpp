@@ -1,3 +1,4 @@
+#include <stdlib.h>
 #include "prof.h"
 #include <map>
 #include <string>
@@ -27,6 +28,10 @@ std::string clean(const char* s) {
 }  // namespace
 
 bool prof_on() { return g_prof.on; }
+bool lds_poison_on() {
+  static const bool on = getenv("HUAL_DEBUG_LDS_POISON") != nullptr && atoi(getenv("HUAL_DEBUG_LDS_POISON")) != 0;
+  return on;
+}
 
 void prof_events(const char* name, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop) {
   *start = *stop = nullptr;

@@ -14,12 +14,19 @@ bool prof_on();
 // a fresh event pair for one launch of kernel `name` (the stringified kernel expression)
 void prof_events(const char* name, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop);
 
+// debug aid (HUAL_DEBUG_LDS_POISON=1 in the environment, read once): before EVERY launch a filler launch writes NaN patterns over the whole
+// LDS of every CU, so a kernel that reads shared memory it has not written itself computes NaNs instead of living off what the previous
+// launch happened to leave there - the shared-memory counterpart of the 0xFF workspace poison of the parity tests.  Off: one predictable branch.
+bool lds_poison_on();
+void lds_poison(hipStream_t stream);
+
 }  // namespace hual
 
 // Launch KERN (parenthesise template instantiations that contain commas).  FLOPS / BYTES = algorithmic work of this
 // launch for the roofline report (0.0 when not meaningful).
 #define HUAL_LAUNCH(FLOPS, BYTES, KERN, GRID, BLOCK, LDS, STREAM, ...)                              \
   do {                                                                                              \
+    if (hual::lds_poison_on()) hual::lds_poison(STREAM);                                            \
     if (hual::prof_on()) {                                                                          \
       hipEvent_t hual_e0_ = nullptr, hual_e1_ = nullptr;                                            \
       hual::prof_events(#KERN, (FLOPS), (BYTES), &hual_e0_, &hual_e1_);                             \

@@ -307,3 +307,24 @@ int launch_add_rows(const float* a, const float* b, float* out, int R, hipStream
 }
 
 }  // namespace hual
+
+
+// ---- debug: NaN patterns over the whole LDS of every CU (prof.h lds_poison; HUAL_DEBUG_LDS_POISON=1).  One 160 KB workgroup fits a CU at a time,
+// so a grid of twice the CU count reaches every CU whatever else is resident; plain launch (it must not poison in front of itself).
+__global__ __launch_bounds__(256) void lds_poison_kernel() {
+  extern __shared__ uint32_t lds_all[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) lds_all[i] = 0xFFFFFFFFu;
+  __syncthreads();
+  if (lds_all[threadIdx.x] == 0u) __builtin_trap();      // (keeps the stores alive)
+}
+namespace hual {
+void lds_poison(hipStream_t stream) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  hipLaunchKernelGGL(lds_poison_kernel, dim3(2 * cus), dim3(256), 160 * 1024, stream);
+}
+}  // namespace hual
