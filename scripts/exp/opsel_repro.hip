@@ -79,6 +79,29 @@ __global__ __launch_bounds__(256) void co_mfma(float* sink, int iters) {
   if (c[0] == 12345.678f) sink[0] = c[0];
 }
 
+// ONE kernel, one stream: waves 0-3 of every workgroup do the victim's arithmetic, waves 4-7 run matrix instructions beside them
+__global__ __launch_bounds__(512) void mixed(const float4* f, const float4* w, float4* out, float* sink, int rows, int iters, int mfma_iters) {
+  if (threadIdx.x >= 256) {
+    h16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (threadIdx.x + i)); b[i] = (_Float16)(0.002f * (threadIdx.x - i)); }
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < mfma_iters; ++it) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    if (c[0] == 12345.678f) sink[0] = c[0];
+    return;
+  }
+  const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const float4 w0 = w[4 * l32], w1 = w[4 * l32 + 1], w2 = w[4 * l32 + 2], w3 = w[4 * l32 + 3];
+  for (int row = blockIdx.x * 8 + grp; row < rows; row += gridDim.x * 8) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int it = 0; it < iters; ++it) {
+      const float4 a = f[(size_t)((row + 97 * it) % rows) * 32 + l32];
+      const float4 l = logits(a, w0, w1, w2, w3);
+      acc.x += l.x; acc.y += l.y; acc.z += l.z; acc.w += l.w;
+    }
+    out[(size_t)row * 32 + l32] = acc;
+  }
+}
+
 int main(int argc, char** argv) {
   const int launches = argc > 1 ? atoi(argv[1]) : 2000;
   const int rows = 8192, iters = argc > 2 ? atoi(argv[2]) : 16;
@@ -100,8 +123,9 @@ int main(int argc, char** argv) {
   CHECK(hipStreamSynchronize(s0));
   std::vector<float> href((size_t)rows * 128), hout((size_t)rows * 128);
   CHECK(hipMemcpy(href.data(), ref, nb, hipMemcpyDeviceToHost));
-  const char* names[7] = {"nothing", "the victim itself", "exp + shuffle loop", "streaming copy", "ds_read_b64_tr_b16 loop", "ds_read_b64 loop", "v_mfma 16x16x32 f16 loop"};
-  for (int mode = 0; mode < 7; ++mode) {
+  const char* names[8] = {"nothing", "the victim itself", "exp + shuffle loop", "streaming copy", "ds_read_b64_tr_b16 loop", "ds_read_b64 loop", "v_mfma 16x16x32 f16 loop",
+                          "NOTHING - the victim's own workgroups hold 4 more waves running v_mfma (one kernel, one stream)"};
+  for (int mode = 0; mode < 8; ++mode) {
     long bad_launches = 0, bad_elems = 0, upper_only = 0;
     for (int k = 0; k < launches; ++k) {
       if (mode == 1) victim<<<512, 256, 0, s1>>>(f, w, ref, rows, iters);
@@ -110,7 +134,8 @@ int main(int argc, char** argv) {
       if (mode == 4) co_ldstr<<<1024, 256, 0, s1>>>(reinterpret_cast<int*>(tr), 4000);
       if (mode == 5) co_lds<<<1024, 256, 0, s1>>>(reinterpret_cast<int*>(tr), 4000);
       if (mode == 6) co_mfma<<<1024, 256, 0, s1>>>(tr, 4000);
-      victim<<<512, 256, 0, s0>>>(f, w, out, rows, iters);
+      if (mode == 7) mixed<<<512, 512, 0, s0>>>(f, w, out, tr, rows, iters, 20000);
+      else victim<<<512, 256, 0, s0>>>(f, w, out, rows, iters);
       CHECK(hipStreamSynchronize(s0));
       CHECK(hipMemcpy(hout.data(), out, nb, hipMemcpyDeviceToHost));
       if (memcmp(hout.data(), href.data(), nb) != 0) {
